@@ -1,0 +1,192 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into, imported by, or called from
+// the product path (sentencepiece_amd/).  Only tests/, __graft_entry__.smoke()
+// and bench.py's cpu_baseline leg may load the library built from this file.
+//
+// A thin extern "C" shim over the *compiled upstream reference*
+// (sentencepiece::SentencePieceProcessor, /root/reference/src/
+// sentencepiece_processor.h:245-300, :458-460, :622-631).  It is linked
+// against objects built from the reference sources where they lie (see
+// oracle/Makefile); no reference source is copied here.  It exists so that
+// Python tests can (1) pin the C restatement in spm_oracle.c against the
+// real thing and (2) time the reference CPU path as bench.py's cpu_baseline.
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "sentencepiece_processor.h"
+
+namespace {
+struct RefHandle {
+  sentencepiece::SentencePieceProcessor sp;
+  std::string last_error;
+};
+}  // namespace
+
+extern "C" {
+
+void *spmref_load(const void *model_bytes, uint64_t n) {
+  auto *h = new RefHandle;
+  const auto st = h->sp.LoadFromSerializedProto(
+      absl::string_view(static_cast<const char *>(model_bytes), n));
+  if (!st.ok()) {
+    delete h;
+    return nullptr;
+  }
+  return h;
+}
+
+void spmref_free(void *handle) { delete static_cast<RefHandle *>(handle); }
+
+const char *spmref_last_error(void *handle) {
+  return static_cast<RefHandle *>(handle)->last_error.c_str();
+}
+
+// SetEncodeExtraOptions (sentencepiece_processor.h:267). 0 on success.
+int spmref_set_encode_extra_options(void *handle, const char *opts) {
+  auto *h = static_cast<RefHandle *>(handle);
+  const auto st = h->sp.SetEncodeExtraOptions(opts);
+  if (!st.ok()) h->last_error = st.ToString();
+  return st.ok() ? 0 : static_cast<int>(st.code());
+}
+
+// SetVocabulary / ResetVocabulary (sentencepiece_processor.h:279-283).
+// `pieces` is a '\n'-joined list.
+int spmref_set_vocabulary(void *handle, const char *pieces, uint64_t len) {
+  auto *h = static_cast<RefHandle *>(handle);
+  std::vector<std::string> store;
+  const char *p = pieces, *end = pieces + len;
+  while (p < end) {
+    const char *q = static_cast<const char *>(memchr(p, '\n', end - p));
+    if (!q) q = end;
+    store.emplace_back(p, q - p);
+    p = q + 1;
+  }
+  std::vector<absl::string_view> v(store.begin(), store.end());
+  const auto st = h->sp.SetVocabulary(v);
+  if (!st.ok()) h->last_error = st.ToString();
+  return st.ok() ? 0 : static_cast<int>(st.code());
+}
+
+int spmref_reset_vocabulary(void *handle) {
+  auto *h = static_cast<RefHandle *>(handle);
+  return h->sp.ResetVocabulary().ok() ? 0 : 1;
+}
+
+// Encode(input, vector<int>*) (sentencepiece_processor.h:299-300).
+// Returns the id count (>= 0), -1 on a Status error, or -(needed) - 2 if
+// `cap` is too small.
+int64_t spmref_encode(void *handle, const char *text, uint64_t len,
+                      int32_t *out, uint64_t cap) {
+  auto *h = static_cast<RefHandle *>(handle);
+  std::vector<int> ids;
+  const auto st = h->sp.Encode(absl::string_view(text, len), &ids);
+  if (!st.ok()) {
+    h->last_error = st.ToString();
+    return -1;
+  }
+  if (ids.size() > cap) return -static_cast<int64_t>(ids.size()) - 2;
+  for (size_t i = 0; i < ids.size(); ++i) out[i] = ids[i];
+  return static_cast<int64_t>(ids.size());
+}
+
+// Normalize(input, &normalized) (sentencepiece_processor.h:622-623).
+int64_t spmref_normalize(void *handle, const char *text, uint64_t len,
+                         char *out, uint64_t cap) {
+  auto *h = static_cast<RefHandle *>(handle);
+  std::string normalized;
+  const auto st = h->sp.Normalize(absl::string_view(text, len), &normalized);
+  if (!st.ok()) {
+    h->last_error = st.ToString();
+    return -1;
+  }
+  if (normalized.size() > cap) return -static_cast<int64_t>(normalized.size()) - 2;
+  memcpy(out, normalized.data(), normalized.size());
+  return static_cast<int64_t>(normalized.size());
+}
+
+// The batch form of python/src/sentencepiece/sentencepiece.i:245-267: a pool
+// of `num_threads` workers pulling sentence indices from one atomic counter,
+// each calling Encode(ins[i], &ids).  Ids are written to a flat CSR:
+// id_offsets[n + 1], ids[cap].  Two passes are avoided by letting every
+// worker keep its results and copying at the end.  Returns total ids, -1 on
+// a Status error, or -(needed) - 2 if cap is too small.
+int64_t spmref_encode_batch(void *handle, const char *text,
+                            const uint64_t *offsets, uint64_t n,
+                            int32_t *ids, uint64_t cap, uint64_t *id_offsets,
+                            int num_threads) {
+  auto *h = static_cast<RefHandle *>(handle);
+  if (num_threads < 1) num_threads = 1;
+  std::vector<std::vector<int>> outs(n);
+  std::atomic<uint64_t> index{0};
+  std::atomic<bool> failed{false};
+  auto worker = [&]() {
+    for (;;) {
+      const uint64_t i = index.fetch_add(1);
+      if (i >= n) return;
+      const auto st = h->sp.Encode(
+          absl::string_view(text + offsets[i], offsets[i + 1] - offsets[i]),
+          &outs[i]);
+      if (!st.ok()) failed = true;
+    }
+  };
+  if (num_threads == 1) {
+    worker();
+  } else {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < num_threads; ++t) pool.emplace_back(worker);
+    for (auto &t : pool) t.join();
+  }
+  if (failed) return -1;
+  uint64_t total = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    id_offsets[i] = total;
+    total += outs[i].size();
+  }
+  id_offsets[n] = total;
+  if (total > cap) return -static_cast<int64_t>(total) - 2;
+  for (uint64_t i = 0; i < n; ++i)
+    for (size_t k = 0; k < outs[i].size(); ++k) ids[id_offsets[i] + k] = outs[i][k];
+  return static_cast<int64_t>(total);
+}
+
+// Timed loop for cpu_baseline: encodes every sentence, keeps only the count.
+// Same worker scheme as above, but without materialising the CSR.
+int64_t spmref_encode_count(void *handle, const char *text,
+                            const uint64_t *offsets, uint64_t n,
+                            int num_threads) {
+  auto *h = static_cast<RefHandle *>(handle);
+  if (num_threads < 1) num_threads = 1;
+  std::atomic<uint64_t> index{0};
+  std::atomic<int64_t> total{0};
+  auto worker = [&]() {
+    std::vector<int> ids;
+    int64_t local = 0;
+    for (;;) {
+      const uint64_t i = index.fetch_add(1);
+      if (i >= n) break;
+      if (h->sp.Encode(absl::string_view(text + offsets[i],
+                                         offsets[i + 1] - offsets[i]),
+                       &ids)
+              .ok())
+        local += static_cast<int64_t>(ids.size());
+    }
+    total += local;
+  };
+  if (num_threads == 1) {
+    worker();
+  } else {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < num_threads; ++t) pool.emplace_back(worker);
+    for (auto &t : pool) t.join();
+  }
+  return total;
+}
+
+int spmref_piece_size(void *handle) {
+  return static_cast<RefHandle *>(handle)->sp.GetPieceSize();
+}
+
+}  // extern "C"

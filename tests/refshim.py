@@ -1,0 +1,117 @@
+"""ctypes binding of oracle/_ref/libspm_ref.so (the compiled upstream reference).
+
+TEST INFRASTRUCTURE ONLY.  Used by tests/, scripts/make_fixtures.py and
+bench.py's cpu_baseline leg; never by the product package.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libspm_ref.so")
+
+
+def available():
+    return os.path.exists(REF_SO)
+
+
+class RefLib:
+    def __init__(self, path=REF_SO):
+        self.lib = lib = C.CDLL(path)
+        lib.spmref_load.restype = C.c_void_p
+        lib.spmref_load.argtypes = [C.c_char_p, C.c_uint64]
+        lib.spmref_free.argtypes = [C.c_void_p]
+        lib.spmref_last_error.restype = C.c_char_p
+        lib.spmref_last_error.argtypes = [C.c_void_p]
+        lib.spmref_set_encode_extra_options.argtypes = [C.c_void_p, C.c_char_p]
+        lib.spmref_set_vocabulary.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
+        lib.spmref_reset_vocabulary.argtypes = [C.c_void_p]
+        lib.spmref_encode.restype = C.c_int64
+        lib.spmref_encode.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        lib.spmref_normalize.restype = C.c_int64
+        lib.spmref_normalize.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        lib.spmref_encode_batch.restype = C.c_int64
+        lib.spmref_encode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                            C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+        lib.spmref_encode_count.restype = C.c_int64
+        lib.spmref_encode_count.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
+        lib.spmref_piece_size.argtypes = [C.c_void_p]
+
+    def load(self, model_bytes):
+        h = self.lib.spmref_load(model_bytes, len(model_bytes))
+        if not h:
+            raise RuntimeError("reference failed to load the model")
+        return RefHandle(self.lib, h)
+
+
+class RefHandle:
+    def __init__(self, lib, h):
+        self.lib, self.h = lib, h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.spmref_free(self.h)
+            self.h = None
+
+    def set_encode_extra_options(self, opts):
+        rc = self.lib.spmref_set_encode_extra_options(self.h, opts.encode())
+        if rc:
+            raise RuntimeError(self.lib.spmref_last_error(self.h).decode())
+
+    def set_vocabulary(self, pieces):
+        blob = "\n".join(pieces).encode()
+        rc = self.lib.spmref_set_vocabulary(self.h, blob, len(blob))
+        if rc:
+            raise RuntimeError(self.lib.spmref_last_error(self.h).decode())
+
+    def reset_vocabulary(self):
+        self.lib.spmref_reset_vocabulary(self.h)
+
+    def piece_size(self):
+        return self.lib.spmref_piece_size(self.h)
+
+    def encode(self, text):
+        if isinstance(text, str):
+            text = text.encode()
+        cap = 4 * len(text) + 16
+        out = np.empty(cap, dtype=np.int32)
+        n = self.lib.spmref_encode(self.h, text, len(text), out.ctypes.data, cap)
+        if n < 0:
+            raise RuntimeError("reference Encode failed: %d" % n)
+        return out[:n].copy()
+
+    def normalize(self, text):
+        if isinstance(text, str):
+            text = text.encode()
+        cap = 32 * len(text) + 64
+        out = np.empty(cap, dtype=np.uint8)
+        n = self.lib.spmref_normalize(self.h, text, len(text), out.ctypes.data, cap)
+        if n < 0:
+            raise RuntimeError("reference Normalize failed: %d" % n)
+        return out[:n].tobytes()
+
+    def encode_batch(self, text, offs, threads=1):
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        n = len(offs) - 1
+        cap = int(len(text)) * 2 + 8 * n + 64
+        ids = np.empty(cap, dtype=np.int32)
+        id_offs = np.empty(n + 1, dtype=np.uint64)
+        tp = text.ctypes.data if len(text) else None
+        tot = self.lib.spmref_encode_batch(self.h, tp, offs.ctypes.data, n, ids.ctypes.data, cap,
+                                           id_offs.ctypes.data, threads)
+        if tot < -1:
+            cap = -tot - 2
+            ids = np.empty(cap, dtype=np.int32)
+            tot = self.lib.spmref_encode_batch(self.h, tp, offs.ctypes.data, n, ids.ctypes.data, cap,
+                                               id_offs.ctypes.data, threads)
+        if tot < 0:
+            raise RuntimeError("reference EncodeBatch failed")
+        return ids[:tot].copy(), id_offs
+
+    def encode_count(self, text, offs, threads=1):
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        return self.lib.spmref_encode_count(self.h, text.ctypes.data, offs.ctypes.data,
+                                            len(offs) - 1, threads)
