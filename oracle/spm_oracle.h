@@ -1,0 +1,41 @@
+/* TEST INFRASTRUCTURE ONLY -- a plain-C CPU restatement of the reference's
+ * encode hot path, used as the parity checker.
+ * Nothing under sentencepiece_amd/ may include, link or call this.
+ * See spm_oracle.c for the reference file:line each function follows. */
+#ifndef SPM_ORACLE_H_
+#define SPM_ORACLE_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct Oracle Oracle;
+
+/* Parses a serialized ModelProto (copied). NULL + message in err on failure. */
+Oracle *oracle_load(const void *model_bytes, uint64_t n, char *err, uint64_t errcap);
+void oracle_free(Oracle *o);
+
+/* SetEncodeExtraOptions: "bos:eos:reverse" in any order. 0 on success. */
+int oracle_set_encode_extra_options(Oracle *o, const char *opts);
+/* SetVocabulary / ResetVocabulary; pieces joined by '\n'. */
+int oracle_set_vocabulary(Oracle *o, const char *pieces, uint64_t len);
+int oracle_reset_vocabulary(Oracle *o);
+
+/* Normalizer::Normalize. Returns length, or -(needed)-2 if cap too small. */
+int64_t oracle_normalize(const Oracle *o, const char *in, uint64_t n, char *out, uint64_t cap);
+/* SentencePieceProcessor::Encode(input, vector<int>*). Returns id count,
+ * -1 on an error status, -(needed)-2 if cap too small. */
+int64_t oracle_encode(const Oracle *o, const char *in, uint64_t n, int32_t *out, uint64_t cap);
+/* Per-sentence Encode over a packed buffer -> CSR. Returns total ids. */
+int64_t oracle_encode_batch(const Oracle *o, const char *text, const uint64_t *offsets, uint64_t n,
+                            int32_t *ids, uint64_t cap, uint64_t *id_offsets);
+
+int oracle_piece_size(const Oracle *o);
+int oracle_model_type(const Oracle *o); /* 1 unigram, 2 bpe */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
