@@ -1,0 +1,108 @@
+/* spmx -- C ABI of the MI355X batch tokenization engine (libspmx.so).
+ *
+ * Drop-in boundary for ONE path of google/sentencepiece: text -> token ids
+ * (normalize -> unigram Viterbi / BPE merge -> id post-processing).  Plain
+ * pointers and sizes only; no C++ or torch types cross this boundary.
+ *
+ * Every entry point names the reference interface it replaces (paths relative
+ * to the reference tree).  Return values are util::StatusCode numbers
+ * (src/sentencepiece_processor.h:34-52): 0 = OK, 13 = INTERNAL, ...; the text
+ * of the last error is available from spmx_last_error().  No C++ exception
+ * crosses the boundary, as in the reference (only Status values).
+ *
+ * Thread safety: like SentencePieceProcessor, a loaded handle may be used
+ * for encoding from several host threads (calls are serialized inside the
+ * handle); the mutators (set_encode_extra_options, set_vocabulary, ...) must
+ * not race with encodes.
+ */
+#ifndef SPMX_H_
+#define SPMX_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct spmx_handle spmx_handle;
+
+/* ---- load ---------------------------------------------------------------
+ * SentencePieceProcessor::LoadFromSerializedProto(serialized)
+ *   (src/sentencepiece_processor.h:261, .cc:234-240) followed by the Load()
+ *   body (.cc:242-281): model factory (unigram | bpe), normalizer, prefix
+ *   matcher.  The model's tables are compiled into the device layout and
+ *   uploaded to GPU `device` (hip device ordinal).  Fails loudly (UNAVAILABLE)
+ *   when no HIP device is usable: there is no CPU fallback. */
+int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_handle **out);
+/* SentencePieceProcessor::Load(filename) (src/sentencepiece_processor.h:245). */
+int spmx_create_from_file(const char *filename, int device, spmx_handle **out);
+void spmx_destroy(spmx_handle *h);
+
+/* util::Status::ToString() of the last failing call on this handle (or of the
+ * last failed spmx_create when h is NULL). */
+const char *spmx_last_error(const spmx_handle *h);
+
+/* ---- configuration ------------------------------------------------------
+ * SetEncodeExtraOptions("bos:eos:reverse") (src/sentencepiece_processor.h:267). */
+int spmx_set_encode_extra_options(spmx_handle *h, const char *options);
+/* SetVocabulary / ResetVocabulary (src/sentencepiece_processor.h:279-283). */
+int spmx_set_vocabulary(spmx_handle *h, const char *const *pieces, const uint64_t *piece_lens, uint64_t n);
+int spmx_reset_vocabulary(spmx_handle *h);
+
+/* ---- vocabulary accessors (src/sentencepiece_processor.h:638-677) -------- */
+int spmx_piece_size(const spmx_handle *h);                                  /* GetPieceSize */
+int spmx_piece_to_id(const spmx_handle *h, const char *piece, uint64_t len);/* PieceToId */
+/* IdToPiece: copies up to cap bytes, returns the piece length (or -1). */
+int64_t spmx_id_to_piece(const spmx_handle *h, int id, char *out, uint64_t cap);
+int spmx_unk_id(const spmx_handle *h);
+int spmx_bos_id(const spmx_handle *h);
+int spmx_eos_id(const spmx_handle *h);
+int spmx_pad_id(const spmx_handle *h);
+int spmx_model_type(const spmx_handle *h);   /* 1 unigram, 2 bpe */
+
+/* ---- encode -------------------------------------------------------------
+ * All three are element-wise identical to calling
+ *   SentencePieceProcessor::Encode(input, std::vector<int>* ids)
+ *     (src/sentencepiece_processor.h:299-300, .cc:392-403)
+ * per sentence, which is what the reference's only batch form --
+ *   _EncodeAsIdsBatch (python/src/sentencepiece/sentencepiece.i:439-446) --
+ * computes with a thread pool.
+ *
+ * Sentences are passed packed: `text` holds the bytes of all sentences back to
+ * back, offsets[i] .. offsets[i+1] delimit sentence i (n + 1 entries).
+ * Ids come back as CSR: ids[id_offsets[i] .. id_offsets[i+1]). */
+
+/* Device-resident form: every pointer is HIP device memory on the handle's
+ * GPU; `stream` is a hipStream_t (NULL = default stream).  The call enqueues
+ * its kernels on `stream`, waits for them, and returns the number of ids in
+ * *total_ids.  If ids_capacity is too small, returns RESOURCE_EXHAUSTED (8)
+ * with the required capacity in *total_ids (id_offsets is still valid). */
+int spmx_encode_batch_device(spmx_handle *h, const void *d_text, uint64_t text_bytes, const uint64_t *d_offsets,
+                             uint64_t n, int32_t *d_ids, uint64_t ids_capacity, uint64_t *d_id_offsets, void *stream,
+                             uint64_t *total_ids);
+
+/* Host-buffer form: copies text to the GPU, encodes, copies ids back.
+ * *ids (total ids) and *id_offsets (n + 1) are allocated by the library and
+ * released with spmx_free(). */
+int spmx_encode_batch(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
+                      uint64_t **id_offsets);
+void spmx_free(void *p);
+
+/* Single sentence, caller-provided buffer (Encode(input, &ids)).  Returns
+ * RESOURCE_EXHAUSTED with the needed size in *n_ids if cap is too small. */
+int spmx_encode(spmx_handle *h, const char *text, uint64_t len, int32_t *ids, uint64_t cap, uint64_t *n_ids);
+
+/* ---- measurement --------------------------------------------------------
+ * Per length-class timing of the encode kernels of the LAST
+ * spmx_encode_batch_device call, measured with hipEvents on the caller's
+ * stream (enable first).  Arrays hold up to 8 entries; returns the number of
+ * classes.  bytes[] is the algorithmic byte count SURVEY.md section 8d defines
+ * (raw bytes + 8 + 4 * ids + 8 per sentence). */
+int spmx_set_profiling(spmx_handle *h, int enabled);
+int spmx_last_profile(const spmx_handle *h, float *kernel_ms, uint64_t *sentences, uint64_t *raw_bytes,
+                      uint64_t *ids, uint64_t *bytes, uint32_t *rcap, float *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,92 @@
+// Device-visible model description shared by the host table compiler and the
+// HIP kernels.  Plain pointers + scalars; passed to kernels by value (kernarg).
+#ifndef SPMX_DEV_H_
+#define SPMX_DEV_H_
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SPMX_HD __host__ __device__
+#else
+#define SPMX_HD
+#endif
+
+namespace spmx {
+
+struct U2 { uint32_t x, y; };
+struct U4 { uint32_t x, y, z, w; };
+
+// normalizer flags
+enum : uint32_t {
+  kNfAddDummyPrefix = 1u << 0,
+  kNfRemoveExtraWs = 1u << 1,
+  kNfEscapeWs = 1u << 2,
+  kNfWsSuffix = 1u << 3,
+  kNfHasTrie = 1u << 4,      // charsmap rules and / or user-defined symbols present
+  kNfByteFallback = 1u << 5,
+  kNfReverse = 1u << 6,      // net effect of the extra options (see tables.cc)
+  kNfHasUserDefined = 1u << 7,
+  kNfHasUnused = 1u << 8,    // some piece is currently UNUSED (BPE resegmentation armed)
+};
+
+// ntrie value word: key index | flags
+constexpr uint32_t kNkUds = 1u << 31;
+constexpr uint32_t kNkRule = 1u << 30;
+constexpr uint32_t kNkIndexMask = (1u << 30) - 1;
+// ninfo.x: blob offset << 8 | flags ; ninfo.y: len | lead << 12 | nspaces << 20
+constexpr uint32_t kNiEndsSpace = 1u << 0;
+
+// ptrie payload (U4: w0, idflags, score bits, 0)
+constexpr uint32_t kPtUnused = 1u << 31;
+constexpr uint32_t kPtUserDefined = 1u << 30;
+constexpr uint32_t kPtIdMask = (1u << 30) - 1;
+
+constexpr uint32_t kSymNone = 0xFFFFFFFFu;
+// sym_final word: final id | flags
+constexpr uint32_t kSfUnused = 1u << 31;
+constexpr uint32_t kSfControl = 1u << 30;
+constexpr uint32_t kSfIdMask = (1u << 30) - 1;
+
+// unit word of the device tries (dat.h): base << 10 | terminal << 9 | occupied << 8 | label
+constexpr int kDatBaseShiftDev = 10;
+constexpr uint32_t kDatTerminalDev = 1u << 9;
+constexpr int kMaxResegDepth = 64;
+
+constexpr int kMaxExtra = 4;       // bos/eos ids on either side
+constexpr int kMaxPieceBytes = 64; // systolic unigram walk: one lane per start, 64 lanes
+
+struct SpmxDev {
+  // ---- normalizer (reference: src/normalizer.cc:71-253) ----
+  const U2 *ntrie;        // merged trie over charsmap keys and user-defined symbols
+  const U2 *ninfo;        // per key: replacement string descriptor
+  const uint8_t *nblob;   // replacement strings
+  uint32_t flags;
+  // ---- unigram (reference: src/unigram_model.cc:889-1020) ----
+  const U4 *ptrie;        // piece trie with inline id / flags / score
+  float unk_score;        // min_score - 10.0f
+  float max_score;
+  int32_t unk_id;
+  // ---- id post-processing (reference: src/sentencepiece_processor.cc:547-636) ----
+  const int32_t *byte_ids;   // [256]
+  int32_t n_prefix, n_suffix;
+  int32_t prefix_ids[kMaxExtra], suffix_ids[kMaxExtra];
+  // ---- BPE (reference: src/bpe_model.cc:38-203) ----
+  const U2 *utrie;        // user-defined symbols only (PrefixMatcher over normalized text)
+  const U4 *chartab;      // {bytes, len, sym, 0}   open addressing, empty: len == 0
+  const U4 *pairtab;      // {symL, symR, merged sym, score bits}   empty: symL == kSymNone
+  const uint32_t *sym_final;  // per symbol: final id | flags
+  const uint16_t *sym_len;    // per symbol: byte length
+  uint32_t chartab_mask, pairtab_mask;
+  int32_t model_type;     // 1 unigram, 2 bpe
+};
+
+SPMX_HD inline uint32_t HashPair(uint32_t a, uint32_t b) {
+  uint64_t h = (static_cast<uint64_t>(a) << 32 | b) * 0x9E3779B97F4A7C15ull;
+  return static_cast<uint32_t>(h >> 32);
+}
+SPMX_HD inline uint32_t HashChar(uint32_t bytes, uint32_t len) {
+  uint64_t h = (static_cast<uint64_t>(len) << 32 | bytes) * 0xD6E8FEB86659FD93ull;
+  return static_cast<uint32_t>(h >> 32);
+}
+
+}  // namespace spmx
+#endif

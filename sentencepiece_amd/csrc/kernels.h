@@ -1,0 +1,698 @@
+// Device bodies of the encode path: one sentence per 64-lane wavefront, the
+// whole sentence resident in LDS between the raw-byte load and the id store.
+//
+//   normalize_wave   Normalizer::Normalize          (src/normalizer.cc:71-253)
+//   unigram_wave     unigram::Model::EncodeOptimized (src/unigram_model.cc:889-1020)
+//   bpe_wave         bpe::Model::SampleEncode(a=0)   (src/bpe_model.cc:38-203)
+//   emit_wave        PopulateSentencePieceText + ApplyExtraOptions, ids only
+//                    (src/sentencepiece_processor.cc:547-636, :1019-1064)
+//
+// All cross-lane traffic goes through wv:: (wave.h) and sits in wave-uniform
+// control flow.  No MFMA: this is byte / index work bound by dependent table
+// lookups, not by FLOPs.
+#ifndef SPMX_KERNELS_H_
+#define SPMX_KERNELS_H_
+
+#ifndef SPMX_WAVE_API   // tests/emu/ supplies a lock-step CPU model of wv:: (test seam)
+#include "wave.h"
+#endif
+#include "dev.h"
+
+namespace spmx {
+
+// status bits written to EncodeArgs::status
+enum : uint32_t {
+  kStArenaOverflow = 1u << 0,   // the scratch id arena was too small: caller retries with a bigger one
+  kStTooLong = 1u << 1,         // a sentence does not fit the largest LDS class
+  kStInternal = 1u << 2,        // "all normalized characters are not consumed" and friends
+  kStRevMergeOverflow = 1u << 3 // BPE: too many distinct UNUSED merges in one sentence
+};
+
+struct EncodeArgs {
+  SpmxDev dev;
+  const uint8_t *text;          // packed sentences
+  const uint64_t *offs;         // n + 1 byte offsets
+  const uint32_t *list;         // sentence indices of this length class
+  const uint32_t *list_count;   // number of entries in list (device resident)
+  uint32_t *next_list;          // escalation: sentences whose normalized form overflowed ncap
+  uint32_t *next_count;
+  int32_t *arena;               // scratch id arena, filled in completion order
+  unsigned long long *arena_head;
+  uint64_t arena_cap;
+  uint64_t *tmp_off;            // per sentence: where its ids sit in the arena
+  uint32_t *counts;             // per sentence: number of ids
+  uint32_t *status;
+  unsigned long long *stats;    // {sentences, raw bytes, ids} finished by this class (profiling)
+  uint32_t rcap, ncap;          // LDS capacities of this class: raw bytes, normalized bytes
+};
+
+constexpr uint32_t kTokEnd = 0x8000u;  // blen[] flag: a token of the best path ends here
+
+SPMX_DEVICE int OneCharLenDev(uint32_t c) {  // src/util.h:151-153
+  const uint32_t h = c >> 4;
+  return h < 12 ? 1 : (h < 14 ? 2 : (h == 14 ? 3 : 4));
+}
+
+// ---------------------------------------------------------------- helpers --
+// Inclusive -> exclusive prefix sum over the 64 lanes; *total gets the wave sum.
+SPMX_DEVICE int wave_excl_scan(int v, int lane, int *total) {
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = wv::shfl_up(incl, d);
+    if (lane >= d) incl += up;
+  }
+  *total = wv::shfl(incl, 63);
+  return incl - v;
+}
+
+// Resolves which positions of a 64-position window are reached by the chain
+//   start -> start + step[start] -> ...
+// given the (uniform) first start inside or beyond the window.  step is each
+// lane's own hop length (>= 1).  Returns the bitmask of reached positions and
+// advances *next_start (absolute) past the window.  Hops of 1 are flooded with
+// one 64-bit add (carry propagation); 2/3/4 with shifts; longer hops one by one.
+SPMX_DEVICE uint64_t resolve_chain(int base, int step, bool valid, int *next_start) {
+  const uint64_t m1 = wv::ballot(valid && step == 1);
+  const uint64_t m2 = wv::ballot(valid && step == 2);
+  const uint64_t m3 = wv::ballot(valid && step == 3);
+  const uint64_t m4 = wv::ballot(valid && step == 4);
+  const uint64_t mo = wv::ballot(valid && step > 4);
+  const uint64_t mv = wv::ballot(valid);
+  uint64_t S = 0;
+  const int rel = *next_start - base;
+  if (rel < 64) S = 1ull << rel;
+  S &= mv;
+  uint64_t done_long = 0;
+  for (;;) {
+    const uint64_t S0 = S;
+    const uint64_t x = S & m1;
+    S |= ((x + m1) ^ m1);
+    S |= (S & m2) << 2;
+    S |= (S & m3) << 3;
+    S |= (S & m4) << 4;
+    uint64_t lg = S & mo & ~done_long;
+    done_long |= lg;
+    while (lg) {  // uniform: S and mo are wave-uniform
+      const int i = wv::ffs64(lg) - 1;
+      lg &= lg - 1;
+      const int st = wv::shfl(step, i);
+      if (i + st < 64) S |= 1ull << (i + st);
+    }
+    S &= mv;
+    if (S == S0) break;
+  }
+  if (S) {
+    const int hi = 63 - wv::clz64(S);
+    *next_start = base + hi + wv::shfl(step, hi);
+  }
+  return S;
+}
+
+// ------------------------------------------------------------- normalizer --
+// Returns the normalized length, or -1 if it does not fit in ncap bytes.
+// raw[0, L) and norm[] live in LDS.  Restates Normalize()'s per-prefix loop as
+// 64-position sweeps: (1) every position speculatively computes its own
+// NormalizePrefix result (longest user-defined symbol, else longest charsmap
+// rule, else one UTF-8 char or U+FFFD for a malformed byte); (2) the chain of
+// real prefix starts is resolved on wave-uniform bitmasks; (3) the whitespace
+// state machine (is_prev_space) becomes a "last writer" lookup on ballot masks;
+// (4) a prefix sum places every prefix's output.
+SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint8_t *norm, int ncap, int lane) {
+  const uint32_t F = d.flags;
+  const bool esc = (F & kNfEscapeWs) != 0, rm = (F & kNfRemoveExtraWs) != 0;
+  const bool has_trie = (F & kNfHasTrie) != 0;
+  const int spw = esc ? 3 : 1;
+  int out = 0;
+  if ((F & kNfAddDummyPrefix) && !(F & kNfWsSuffix)) {   // :128
+    if (spw > ncap) return -1;
+    if (lane < spw) norm[lane] = esc ? (lane == 0 ? 0xE2 : (lane == 1 ? 0x96 : 0x81)) : 0x20;
+    out = spw;
+  }
+  bool P = rm;                       // is_prev_space (:130), wave-uniform between sweeps
+  bool any_other = false;            // some prefix normalizes to something other than exactly " "
+  int next_start = 0;
+  const uint32_t nroot = has_trie ? (d.ntrie[0].x >> kDatBaseShiftDev) : 0u;
+  for (int b = 0; b < L; b += 64) {
+    const int p = b + lane;
+    const bool valid = p < L;
+    // (1) NormalizePrefix at every position (:195-253)
+    int uds_len = 0, rule_len = 0;
+    uint32_t rule_idx = 0;
+    if (has_trie) {
+      bool alive = valid;
+      uint32_t nb = nroot;
+      int depth = 0;
+      while (wv::any(alive)) {
+        if (alive) {
+          const int q = p + depth;
+          if (q < L) {
+            const uint32_t c = raw[q];
+            const U2 u = d.ntrie[nb ^ c];
+            if ((u.x & 0x1FFu) == (0x100u | c)) {
+              ++depth;
+              nb = u.x >> kDatBaseShiftDev;
+              if (u.x & kDatTerminalDev) {
+                if (u.y & kNkUds) uds_len = depth;
+                if (u.y & kNkRule) { rule_len = depth; rule_idx = u.y & kNkIndexMask; }
+              }
+            } else {
+              alive = false;
+            }
+          } else {
+            alive = false;
+          }
+        }
+      }
+    }
+    // kind: 0 copy raw span, 1 rule string, 2 U+FFFD
+    int kind = 0, consumed = 1;
+    int len = 1, lead = 0, nsp = 0;
+    bool ends_sp = false;
+    uint32_t src = 0;
+    if (valid) {
+      if (uds_len > 0) {                       // :201-205 user-defined symbols pass through
+        consumed = len = uds_len;
+        for (int k = 0; k < len; ++k) nsp += raw[p + k] == 0x20;
+        while (lead < len && raw[p + lead] == 0x20) ++lead;
+        ends_sp = raw[p + len - 1] == 0x20;
+      } else if (rule_len > 0) {               // :222-228 longest rule, :245-250
+        kind = 1;
+        consumed = rule_len;
+        const U2 info = d.ninfo[rule_idx];
+        src = info.x >> 8;
+        ends_sp = (info.x & kNiEndsSpace) != 0;
+        len = static_cast<int>(info.y & 0xFFFu);
+        lead = static_cast<int>((info.y >> 12) & 0xFFu);
+        nsp = static_cast<int>(info.y >> 20);
+      } else {                                 // :231-244 one UTF-8 char (DecodeUTF8, util.cc:51-84)
+        const uint32_t b0 = raw[p];
+        const int rem = L - p;
+        int mb = 1;
+        bool ok = b0 < 0x80;
+        if (!ok) {
+          const uint32_t b1 = rem >= 2 ? raw[p + 1] : 0u, b2 = rem >= 3 ? raw[p + 2] : 0u, b3 = rem >= 4 ? raw[p + 3] : 0u;
+          const bool t1 = (b1 & 0xC0u) == 0x80u, t2 = (b2 & 0xC0u) == 0x80u, t3 = (b3 & 0xC0u) == 0x80u;
+          if (rem >= 2 && (b0 & 0xE0u) == 0xC0u) {
+            const uint32_t cp = (b0 & 0x1Fu) << 6 | (b1 & 0x3Fu);
+            if (t1 && cp >= 0x80u) { ok = true; mb = 2; }
+          } else if (rem >= 3 && (b0 & 0xF0u) == 0xE0u) {
+            const uint32_t cp = (b0 & 0x0Fu) << 12 | (b1 & 0x3Fu) << 6 | (b2 & 0x3Fu);
+            if (t1 && t2 && cp >= 0x800u && (cp < 0xD800u || cp >= 0xE000u)) { ok = true; mb = 3; }
+          } else if (rem >= 4 && (b0 & 0xF8u) == 0xF0u) {
+            const uint32_t cp = (b0 & 0x07u) << 18 | (b1 & 0x3Fu) << 12 | (b2 & 0x3Fu) << 6 | (b3 & 0x3Fu);
+            if (t1 && t2 && t3 && cp >= 0x10000u && cp <= 0x10FFFFu) { ok = true; mb = 4; }
+          }
+        }
+        if (ok) {
+          consumed = len = mb;
+          if (b0 == 0x20) { lead = nsp = 1; ends_sp = true; }
+        } else {
+          kind = 2; consumed = 1; len = 3;     // U+FFFD, one byte consumed
+        }
+      }
+    }
+    // (2) which positions are real prefix starts
+    const uint64_t S = resolve_chain(b, consumed, valid, &next_start);
+    const bool is_start = ((S >> lane) & 1ull) != 0;
+    // (3) whitespace state machine (:131-163)
+    const bool single_sp = len == 1 && lead == 1;                 // p.first == " "
+    any_other = any_other || wv::any(is_start && !single_sp);
+    const bool clsA = is_start && len > 0 && lead == len;          // all spaces: leaves is_prev_space true
+    const bool clsN = is_start && lead < len;                      // has a non-space byte
+    bool Pl = false;
+    if (rm) {
+      const uint64_t mA = wv::ballot(clsA), mN = wv::ballot(clsN), mNe = wv::ballot(clsN && ends_sp);
+      const uint64_t setters = mA | mN, val = mA | mNe;
+      const uint64_t below = setters & ((1ull << lane) - 1ull);
+      Pl = below ? (((val >> (63 - wv::clz64(below))) & 1ull) != 0) : P;
+      if (setters) P = ((val >> (63 - wv::clz64(setters))) & 1ull) != 0;
+    }
+    const int strip = Pl ? lead : 0;                               // :137-138
+    const int eff_len = is_start ? len - strip : 0;
+    const int eff_sp = is_start ? nsp - strip : 0;
+    const int out_len = eff_len + (esc ? 2 * eff_sp : 0);
+    // (4) placement
+    int total = 0;
+    int w = out + wave_excl_scan(out_len, lane, &total);
+    if (out + total > ncap) return -1;
+    int k = strip;
+    const int kend = is_start ? len : 0;
+    while (wv::any(k < kend)) {
+      if (k < kend) {
+        uint32_t ch;
+        if (kind == 0) ch = raw[p + k];
+        else if (kind == 1) ch = d.nblob[src + k];
+        else ch = k == 0 ? 0xEFu : (k == 1 ? 0xBFu : 0xBDu);
+        if (esc && ch == 0x20u) {                                  // :143-148
+          norm[w] = 0xE2; norm[w + 1] = 0x96; norm[w + 2] = 0x81;
+          w += 3;
+        } else {
+          norm[w++] = static_cast<uint8_t>(ch);
+        }
+        ++k;
+      }
+    }
+    out += total;
+  }
+  wv::sync();
+  if (rm && !any_other) return 0;      // :86-100 every prefix was " ": empty result, no dummy prefix
+  if (rm) {                            // :166-176 trailing space symbols
+    for (;;) {
+      if (out < spw) break;
+      const bool is_sp = esc ? (norm[out - 3] == 0xE2 && norm[out - 2] == 0x96 && norm[out - 1] == 0x81)
+                             : (norm[out - 1] == 0x20);
+      if (!is_sp) break;
+      out -= spw;
+    }
+  }
+  if ((F & kNfAddDummyPrefix) && (F & kNfWsSuffix)) {   // :179
+    if (out + spw > ncap) return -1;
+    if (lane < spw) norm[out + lane] = esc ? (lane == 0 ? 0xE2 : (lane == 1 ? 0x96 : 0x81)) : 0x20;
+    out += spw;
+    wv::sync();
+  }
+  return out;
+}
+
+// ---------------------------------------------------------------- unigram --
+// EncodeOptimized transposed for a wavefront: time t walks the END positions
+// serially; lane (s mod 64) owns the trie walk that started at character start
+// s and advances it by the one byte norm[t] that every live walk consumes at
+// time t.  All pieces (s, t+1) ending at t+1 therefore surface in the same
+// step, and best[t+1] is folded from them in increasing s -- the order the
+// reference visits them in -- with the reference's arithmetic: a piece
+// candidate is a double sum compared against the float-rounded best (:979-989),
+// the UNK candidate is a float sum (:997-1001).  Pieces are <= 64 bytes
+// (checked at load), so a lane is free again before its slot is reused.
+// Outputs the back-pointers: bid[e] = id, blen[e] = byte length of the piece
+// ending at e on the best path into e.
+SPMX_DEVICE void unigram_wave(const SpmxDev &d, const uint8_t *norm, int nlen, int32_t *bid, uint16_t *blen, int lane) {
+  const uint32_t root = d.ptrie[0].x >> kDatBaseShiftDev;
+  bool alive = false, pending = false;
+  uint32_t nb = 0;
+  float s_best = 0.f;
+  int s_start = 0, unk_t = -1;
+  float cur_best = 0.f;   // best_path_ends_at[t].best_path_score for a start at t (uniform)
+  int next_cstart = 0;
+  uint32_t vb = 0;
+  for (int t = 0; t < nlen; ++t) {
+    if ((t & 63) == 0) vb = (t + lane < nlen) ? norm[t + lane] : 0u;
+    const uint32_t c = wv::shfl(vb, t & 63);
+    if (t == next_cstart) {                                // :960-968 a new character start
+      int mb = OneCharLenDev(c);
+      if (mb > nlen - t) mb = nlen - t;
+      next_cstart = t + mb;
+      if (lane == (t & 63)) {
+        alive = true; pending = true; nb = root; s_best = cur_best; s_start = t; unk_t = t + mb - 1;
+      }
+    }
+    bool has = false;
+    double cd = 0.0;
+    int32_t cid = 0;
+    if (alive) {                                           // :970-971 traverse one byte
+      const U4 u = d.ptrie[nb ^ c];
+      if ((u.x & 0x1FFu) == (0x100u | c)) {
+        nb = u.x >> kDatBaseShiftDev;
+        if ((u.x & kDatTerminalDev) && !(u.y & kPtUnused)) {   // :973-974
+          has = true;
+          cid = static_cast<int32_t>(u.y & kPtIdMask);
+          const int length = t + 1 - s_start;
+          double score;
+          if (u.y & kPtUserDefined) {                      // :979-981 (length * max_score_ - 0.1)
+            const float prod = static_cast<float>(length) * d.max_score;
+            score = static_cast<double>(prod) - 0.1;
+          } else {
+            score = static_cast<double>(wv::bits_to_float(u.z));
+          }
+          cd = score + static_cast<double>(s_best);        // :982-983
+        }
+      } else {
+        alive = false;                                     // ret == -2
+      }
+    }
+    if (pending && t == unk_t) {                           // :990-1005 no single-character piece -> UNK
+      pending = false;
+      if (!has) {
+        has = true;
+        cid = d.unk_id;
+        const float cf = d.unk_score + s_best;             // float arithmetic
+        cd = static_cast<double>(cf);
+      }
+    }
+    const uint64_t m = wv::ballot(has);
+    if (m) {
+      const int r = (t + 1) & 63;                          // lane of the oldest possible start
+      uint64_t rot = r ? ((m >> r) | (m << (64 - r))) : m;
+      bool set = false;
+      float acc = 0.f;
+      int win = 0;
+      while (rot) {
+        const int k = wv::ffs64(rot) - 1;
+        rot &= rot - 1;
+        const int l = (k + r) & 63;
+        const double v = wv::shfl(cd, l);
+        if (!set || v > static_cast<double>(acc)) {        // :984-989
+          acc = static_cast<float>(v);
+          win = l;
+          set = true;
+        }
+      }
+      cur_best = acc;
+      if (lane == win) {
+        bid[t + 1] = cid;
+        blen[t + 1] = static_cast<uint16_t>(t + 1 - s_start);
+      }
+    }
+  }
+  wv::sync();
+}
+
+// Marks the token ends of the best path (:1010-1018). Returns false on a broken chain.
+SPMX_DEVICE bool backtrack_wave(int nlen, uint16_t *blen, int lane) {
+  int e = nlen;
+  bool ok = true;
+  while (e > 0) {
+    const uint32_t l = blen[e] & (kTokEnd - 1);
+    if (l == 0 || static_cast<int>(l) > e) { ok = false; break; }
+    if (lane == 0) blen[e] = static_cast<uint16_t>(l | kTokEnd);
+    e -= static_cast<int>(l);
+  }
+  wv::sync();
+  return ok;
+}
+
+// ------------------------------------------------------------------- emit --
+// ids of the marked tokens in forward order, with the unknown-run merge or the
+// byte-fallback expansion (sentencepiece_processor.cc:581-613) and the net
+// effect of the extra options (:1019-1064).
+SPMX_DEVICE int emit_wave(const EncodeArgs &a, uint32_t sid, const uint8_t *norm, int nlen, const int32_t *bid,
+                           const uint16_t *blen, int lane) {
+  const SpmxDev &d = a.dev;
+  const bool bf = (d.flags & kNfByteFallback) != 0;
+  const bool reverse = (d.flags & kNfReverse) != 0;
+  int total = 0;
+  for (int b = 0; b < nlen; b += 64) {
+    const int e = b + lane + 1;
+    int cnt = 0;
+    if (e <= nlen) {
+      const uint32_t l = blen[e];
+      if (l & kTokEnd) {
+        const int len = static_cast<int>(l & (kTokEnd - 1));
+        if (bid[e] == d.unk_id) {
+          if (bf) cnt = len;
+          else cnt = (e - len > 0 && bid[e - len] == d.unk_id) ? 0 : 1;
+        } else {
+          cnt = 1;
+        }
+      }
+    }
+    int t = 0;
+    wave_excl_scan(cnt, lane, &t);
+    total += t;
+  }
+  const int n_out = d.n_prefix + total + d.n_suffix;
+  unsigned long long off = 0;
+  if (lane == 0) off = wv::atomic_add(a.arena_head, static_cast<unsigned long long>(n_out));
+  off = (static_cast<unsigned long long>(wv::shfl(static_cast<uint32_t>(off >> 32), 0)) << 32) |
+        wv::shfl(static_cast<uint32_t>(off), 0);
+  if (lane == 0) {
+    a.counts[sid] = static_cast<uint32_t>(n_out);
+    a.tmp_off[sid] = off;
+  }
+  if (off + static_cast<unsigned long long>(n_out) > a.arena_cap) {
+    if (lane == 0) wv::atomic_or(a.status, kStArenaOverflow);
+    return n_out;
+  }
+  int32_t *dst = a.arena + off;
+  if (lane < d.n_prefix) dst[lane] = d.prefix_ids[lane];
+  if (lane < d.n_suffix) dst[d.n_prefix + total + lane] = d.suffix_ids[lane];
+  int done = 0;
+  for (int b = 0; b < nlen; b += 64) {
+    const int e = b + lane + 1;
+    int cnt = 0, len = 0;
+    int32_t id = 0;
+    if (e <= nlen) {
+      const uint32_t l = blen[e];
+      if (l & kTokEnd) {
+        len = static_cast<int>(l & (kTokEnd - 1));
+        id = bid[e];
+        if (id == d.unk_id) {
+          if (bf) cnt = len;
+          else cnt = (e - len > 0 && bid[e - len] == d.unk_id) ? 0 : 1;
+        } else {
+          cnt = 1;
+        }
+      }
+    }
+    int t = 0;
+    const int pos = done + wave_excl_scan(cnt, lane, &t);
+    done += t;
+    if (cnt == 1 && !(bf && id == d.unk_id)) {
+      dst[d.n_prefix + (reverse ? total - 1 - pos : pos)] = id;
+    } else if (cnt > 0) {          // byte fallback: one BYTE id per byte of the unknown piece
+      for (int k = 0; k < cnt; ++k) {
+        const int j = pos + k;
+        dst[d.n_prefix + (reverse ? total - 1 - j : j)] = d.byte_ids[norm[e - len + k]];
+      }
+    }
+  }
+  return n_out;
+}
+
+// ------------------------------------------------------- one work item -----
+struct WaveLds {
+  uint8_t *raw, *norm;
+  int32_t *bid;
+  uint16_t *blen;
+  unsigned char *extra;   // model-specific scratch (BPE symbol tables)
+};
+
+SPMX_DEVICE WaveLds carve_lds(unsigned char *base, uint32_t rcap, uint32_t ncap) {
+  WaveLds w;
+  const uint32_t r = (rcap + 16 + 15) & ~15u, n = (ncap + 16 + 15) & ~15u;
+  const uint32_t n4 = ((ncap + 4) * 4 + 15) & ~15u, n2 = ((ncap + 8) * 2 + 15) & ~15u;
+  w.raw = base;
+  w.norm = base + r;
+  w.bid = reinterpret_cast<int32_t *>(base + r + n);
+  w.blen = reinterpret_cast<uint16_t *>(base + r + n + n4);
+  w.extra = base + r + n + n4 + n2;
+  return w;
+}
+
+SPMX_DEVICE void fail_sentence(const EncodeArgs &a, uint32_t sid, uint32_t bit, int lane) {
+  if (lane == 0) {
+    a.counts[sid] = 0;
+    a.tmp_off[sid] = 0;
+    wv::atomic_or(a.status, bit);
+  }
+}
+
+}  // namespace spmx
+
+#include "kernels_bpe.h"
+
+namespace spmx {
+
+// Encodes sentence `sid` with this wave. MODEL: 1 unigram, 2 BPE.
+// Returns the number of ids written, or -1 if the sentence was handed on / failed.
+template <int MODEL>
+SPMX_DEVICE int encode_sentence(const EncodeArgs &a, uint32_t sid, const WaveLds &w, int lane, int *raw_len) {
+  const uint64_t beg = a.offs[sid];
+  const uint64_t L64 = a.offs[sid + 1] - beg;
+  if (L64 > a.rcap) {   // only reachable for the last class
+    fail_sentence(a, sid, kStTooLong, lane);
+    return -1;
+  }
+  const int L = static_cast<int>(L64);
+  *raw_len = L;
+  const uint8_t *src = a.text + beg;
+  for (int p = lane; p < L; p += 64) w.raw[p] = src[p];
+  wv::sync();
+  int nlen = 0;
+  if (L > 0) nlen = normalize_wave(a.dev, w.raw, L, w.norm, static_cast<int>(a.ncap), lane);
+  if (nlen < 0) {
+    if (a.next_list) {
+      if (lane == 0) a.next_list[wv::atomic_add(a.next_count, 1u)] = sid;
+    } else {
+      fail_sentence(a, sid, kStTooLong, lane);
+    }
+    return -1;
+  }
+  bool ok = true;
+  if (nlen > 0) {
+    for (int e = lane; e <= nlen; e += 64) w.blen[e] = 0;
+    wv::sync();
+    if (MODEL == 1) {
+      unigram_wave(a.dev, w.norm, nlen, w.bid, w.blen, lane);
+      ok = backtrack_wave(nlen, w.blen, lane);
+    } else {
+      ok = bpe_wave(a, w.norm, nlen, w.bid, w.blen, carve_bpe(w.extra, a.ncap), lane);
+    }
+  }
+  if (!ok) {
+    fail_sentence(a, sid, kStInternal, lane);
+    return -1;
+  }
+  return emit_wave(a, sid, w.norm, nlen, w.bid, w.blen, lane);
+}
+
+// Persistent block body: 64-thread workgroups, grid-stride over the class list.
+template <int MODEL>
+SPMX_DEVICE void encode_block(const EncodeArgs &a, unsigned char *smem) {
+  const int lane = wv::lane();
+  const WaveLds w = carve_lds(smem, a.rcap, a.ncap);
+  const uint32_t count = *a.list_count;
+  unsigned long long n_sent = 0, n_raw = 0, n_ids = 0;
+  for (uint32_t item = static_cast<uint32_t>(wv::block_id()); item < count; item += static_cast<uint32_t>(wv::grid_size())) {
+    int raw_len = 0;
+    const int n_out = encode_sentence<MODEL>(a, a.list[item], w, lane, &raw_len);
+    if (n_out >= 0) { ++n_sent; n_raw += static_cast<unsigned long long>(raw_len); n_ids += static_cast<unsigned long long>(n_out); }
+  }
+  if (a.stats && lane == 0 && n_sent) {
+    wv::atomic_add(&a.stats[0], n_sent);
+    wv::atomic_add(&a.stats[1], n_raw);
+    wv::atomic_add(&a.stats[2], n_ids);
+  }
+}
+
+// LDS bytes one wave needs for a (rcap, ncap) class.  Host and device agree on it.
+inline uint32_t EncodeLdsBytes(int model_type, uint32_t rcap, uint32_t ncap) {
+  const uint32_t r = (rcap + 16 + 15) & ~15u, n = (ncap + 16 + 15) & ~15u;
+  const uint32_t n4 = ((ncap + 4) * 4 + 15) & ~15u, n2 = ((ncap + 8) * 2 + 15) & ~15u;
+  uint32_t total = r + n + n4 + n2;
+  if (model_type == 2) total += 3 * n4 + 2 * n2 + kRevCap * 12;
+  return total;
+}
+
+// ---------------------------------------------------- bookkeeping kernels --
+constexpr int kMaxClasses = 8;
+
+struct ClassifyArgs {
+  const uint64_t *offs;
+  uint32_t n;
+  uint32_t n_classes;
+  uint32_t rcap[kMaxClasses];   // ascending; sentences longer than the last go to the last class
+  uint32_t *lists;              // n_classes x n
+  uint32_t *list_counts;        // n_classes (zeroed before launch)
+};
+
+// Buckets sentence indices by raw byte length, one wave-aggregated atomic per
+// class per wave.  Waves are grid-strided over tiles of 64 sentences.
+SPMX_DEVICE void classify_block(const ClassifyArgs &a) {
+  const int lane = wv::lane();
+  const uint32_t tiles = (a.n + 63) / 64;
+  for (uint32_t tile = static_cast<uint32_t>(wv::block_id()); tile < tiles; tile += static_cast<uint32_t>(wv::grid_size())) {
+    const uint32_t i = tile * 64 + static_cast<uint32_t>(lane);
+    int cls = -1;
+    if (i < a.n) {
+      const uint64_t len = a.offs[i + 1] - a.offs[i];
+      cls = static_cast<int>(a.n_classes) - 1;
+      for (int c = static_cast<int>(a.n_classes) - 2; c >= 0; --c) if (len <= a.rcap[c]) cls = c;
+    }
+    for (uint32_t c = 0; c < a.n_classes; ++c) {
+      const uint64_t m = wv::ballot(cls == static_cast<int>(c));
+      if (m == 0) continue;
+      const int leader = wv::ffs64(m) - 1;
+      uint32_t base = 0;
+      if (lane == leader) base = wv::atomic_add(&a.list_counts[c], static_cast<uint32_t>(wv::popc64(m)));
+      base = wv::shfl(base, leader);
+      if (cls == static_cast<int>(c))
+        a.lists[static_cast<uint64_t>(c) * a.n + base + static_cast<uint32_t>(wv::popc64(m & ((1ull << lane) - 1ull)))] = i;
+    }
+  }
+}
+
+// counts[n] -> exclusive prefix sums id_offs[n + 1] (uint64), in three passes
+// over tiles of kScanTile sentences: tile sums, scan of tile sums (one wave),
+// final offsets.
+constexpr uint32_t kScanTile = 2048;   // 64 lanes x 32 consecutive counts
+
+struct ScanArgs {
+  const uint32_t *counts;
+  uint32_t n;
+  uint64_t *tile_sums;    // ceil(n / kScanTile) + 1
+  uint64_t *id_offs;      // n + 1
+};
+
+SPMX_DEVICE uint64_t wave_excl_scan64(uint64_t v, int lane, uint64_t *total) {
+  uint64_t incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t lo = static_cast<uint32_t>(wv::shfl_up(static_cast<int>(static_cast<uint32_t>(incl)), d));
+    const uint32_t hi = static_cast<uint32_t>(wv::shfl_up(static_cast<int>(static_cast<uint32_t>(incl >> 32)), d));
+    if (lane >= d) incl += (static_cast<uint64_t>(hi) << 32 | lo);
+  }
+  const uint32_t tl = wv::shfl(static_cast<uint32_t>(incl), 63), th = wv::shfl(static_cast<uint32_t>(incl >> 32), 63);
+  *total = static_cast<uint64_t>(th) << 32 | tl;
+  return incl - v;
+}
+
+SPMX_DEVICE void scan_tiles_block(const ScanArgs &a) {     // pass 1
+  const int lane = wv::lane();
+  const uint32_t tiles = (a.n + kScanTile - 1) / kScanTile;
+  for (uint32_t tile = static_cast<uint32_t>(wv::block_id()); tile < tiles; tile += static_cast<uint32_t>(wv::grid_size())) {
+    const uint32_t first = tile * kScanTile + static_cast<uint32_t>(lane) * 32;
+    uint64_t s = 0;
+    for (uint32_t k = 0; k < 32; ++k) if (first + k < a.n) s += a.counts[first + k];
+    uint64_t total = 0;
+    wave_excl_scan64(s, lane, &total);
+    if (lane == 0) a.tile_sums[tile] = total;
+  }
+}
+
+SPMX_DEVICE void scan_sums_block(const ScanArgs &a) {      // pass 2, ONE wave
+  const int lane = wv::lane();
+  const uint32_t tiles = (a.n + kScanTile - 1) / kScanTile;
+  uint64_t carry = 0;
+  for (uint32_t b = 0; b < tiles; b += 64) {
+    const uint32_t t = b + static_cast<uint32_t>(lane);
+    const uint64_t v = t < tiles ? a.tile_sums[t] : 0;
+    uint64_t total = 0;
+    const uint64_t ex = wave_excl_scan64(v, lane, &total);
+    if (t < tiles) a.tile_sums[t] = carry + ex;
+    carry += total;
+  }
+  if (lane == 0) { a.tile_sums[tiles] = carry; a.id_offs[a.n] = carry; }
+}
+
+SPMX_DEVICE void scan_final_block(const ScanArgs &a) {     // pass 3
+  const int lane = wv::lane();
+  const uint32_t tiles = (a.n + kScanTile - 1) / kScanTile;
+  for (uint32_t tile = static_cast<uint32_t>(wv::block_id()); tile < tiles; tile += static_cast<uint32_t>(wv::grid_size())) {
+    const uint32_t first = tile * kScanTile + static_cast<uint32_t>(lane) * 32;
+    uint64_t s = 0;
+    for (uint32_t k = 0; k < 32; ++k) if (first + k < a.n) s += a.counts[first + k];
+    uint64_t total = 0;
+    uint64_t run = a.tile_sums[tile] + wave_excl_scan64(s, lane, &total);
+    for (uint32_t k = 0; k < 32; ++k) {
+      if (first + k < a.n) { a.id_offs[first + k] = run; run += a.counts[first + k]; }
+    }
+  }
+}
+
+struct CompactArgs {
+  const int32_t *arena;
+  const uint64_t *tmp_off;
+  const uint32_t *counts;
+  const uint64_t *id_offs;
+  int32_t *ids;
+  uint64_t ids_cap;
+  uint32_t n;
+};
+
+// Moves every sentence's ids from where its wave happened to put them in the
+// arena to their place in the caller's CSR.  One wave per sentence, grid-strided.
+SPMX_DEVICE void compact_block(const CompactArgs &a) {
+  const int lane = wv::lane();
+  if (a.id_offs[a.n] > a.ids_cap) return;   // caller sees the needed size in id_offs[n]
+  for (uint32_t i = static_cast<uint32_t>(wv::block_id()); i < a.n; i += static_cast<uint32_t>(wv::grid_size())) {
+    const uint32_t cnt = a.counts[i];
+    const int32_t *src = a.arena + a.tmp_off[i];
+    int32_t *dst = a.ids + a.id_offs[i];
+    for (uint32_t j = static_cast<uint32_t>(lane); j < cnt; j += 64) dst[j] = src[j];
+  }
+}
+
+}  // namespace spmx
+#endif

@@ -1,0 +1,66 @@
+// __global__ entry points for gfx950.  One 64-thread workgroup = one wavefront
+// = one sentence at a time; grids are persistent (grid-stride over work lists
+// whose lengths live in device memory, so no host round trip sits between the
+// classify, encode, scan and compact launches).
+#include "launch.h"
+
+namespace spmx {
+
+// CLS only gives every length class its own kernel symbol (rocprofv3 lists and
+// times them separately); the capacities travel in EncodeArgs.
+template <int MODEL, int CLS>
+__global__ __launch_bounds__(64) void EncodeKernel(EncodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  encode_block<MODEL>(a, smem);
+}
+
+__global__ __launch_bounds__(64) void ClassifyKernel(ClassifyArgs a) { classify_block(a); }
+__global__ __launch_bounds__(64) void ScanTilesKernel(ScanArgs a) { scan_tiles_block(a); }
+__global__ __launch_bounds__(64) void ScanSumsKernel(ScanArgs a) { scan_sums_block(a); }
+__global__ __launch_bounds__(64) void ScanFinalKernel(ScanArgs a) { scan_final_block(a); }
+__global__ __launch_bounds__(64) void CompactKernel(CompactArgs a) { compact_block(a); }
+
+namespace {
+using EncodeFn = void (*)(EncodeArgs);
+
+template <int MODEL>
+EncodeFn PickEncode(int cls) {
+  switch (cls) {
+    case 0: return EncodeKernel<MODEL, 0>;
+    case 1: return EncodeKernel<MODEL, 1>;
+    case 2: return EncodeKernel<MODEL, 2>;
+    case 3: return EncodeKernel<MODEL, 3>;
+    default: return EncodeKernel<MODEL, 4>;
+  }
+}
+}  // namespace
+
+hipError_t LaunchEncode(int model_type, int cls, const EncodeArgs &a, int grid, uint32_t lds_bytes, hipStream_t stream) {
+  EncodeFn fn = model_type == 2 ? PickEncode<2>(cls) : PickEncode<1>(cls);
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds_bytes));
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds_bytes, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t LaunchClassify(const ClassifyArgs &a, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL(ClassifyKernel, dim3(grid), dim3(64), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t LaunchScan(const ScanArgs &a, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL(ScanTilesKernel, dim3(grid), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL(ScanSumsKernel, dim3(1), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL(ScanFinalKernel, dim3(grid), dim3(64), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t LaunchCompact(const CompactArgs &a, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL(CompactKernel, dim3(grid), dim3(64), 0, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace spmx

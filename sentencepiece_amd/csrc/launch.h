@@ -1,0 +1,26 @@
+// Host-callable launchers of the kernels in kernels.hip.
+#ifndef SPMX_LAUNCH_H_
+#define SPMX_LAUNCH_H_
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace spmx {
+
+struct LengthClass { uint32_t rcap, ncap; };
+// Length classes per model type: raw-byte capacity and normalized-byte capacity
+// of the per-wave LDS workspace.  A sentence whose normalized form overflows
+// ncap is handed to the next class; past the last class it is an error.
+constexpr int kNumClassesUnigram = 5;
+constexpr int kNumClassesBpe = 4;
+constexpr LengthClass kClassesUnigram[kNumClassesUnigram] = {
+    {192, 448}, {576, 1280}, {1536, 3328}, {4096, 8704}, {8192, 20480}};
+constexpr LengthClass kClassesBpe[kNumClassesBpe] = {{192, 448}, {576, 1280}, {1536, 3328}, {4096, 6400}};
+
+hipError_t LaunchEncode(int model_type, int cls, const EncodeArgs &a, int grid, uint32_t lds_bytes, hipStream_t stream);
+hipError_t LaunchClassify(const ClassifyArgs &a, int grid, hipStream_t stream);
+hipError_t LaunchScan(const ScanArgs &a, int grid, hipStream_t stream);
+hipError_t LaunchCompact(const CompactArgs &a, int grid, hipStream_t stream);
+
+}  // namespace spmx
+#endif

@@ -1,0 +1,46 @@
+// Table compiler: ModelData -> flat arrays in the device layout of dev.h.
+#ifndef SPMX_TABLES_H_
+#define SPMX_TABLES_H_
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "dev.h"
+#include "model.h"
+
+namespace spmx {
+
+struct HostTables {
+  // normalizer
+  std::vector<U2> ntrie;
+  std::vector<U2> ninfo;
+  std::vector<uint8_t> nblob;
+  // unigram
+  std::vector<U4> ptrie;
+  // bpe
+  std::vector<U2> utrie;
+  std::vector<U4> chartab, pairtab;
+  std::vector<uint32_t> sym_final;
+  std::vector<uint16_t> sym_len;
+  std::vector<int32_t> byte_ids;
+  // scalars (pointers are filled in by whoever owns the memory)
+  SpmxDev scalars{};
+  int max_norm_key_len = 0;   // longest charsmap key / user-defined symbol, bytes
+  int max_expansion_num = 3, max_expansion_den = 1;  // worst normalized/raw byte ratio (>= 3 for ' ' -> U+2581)
+  int max_piece_len = 0;
+  int max_prefixes = 0;
+};
+
+// Builds everything that depends only on load-time structure.
+Status CompileTables(const ModelData &m, HostTables *t);
+// Refreshes the type-dependent bits (UNUSED / USER_DEFINED flags) after
+// SetVocabulary / ResetVocabulary without rebuilding tries.
+void RefreshTypeFlags(const ModelData &m, HostTables *t);
+// Net effect of ApplyExtraOptions (src/sentencepiece_processor.cc:1019-1064)
+// for an option string such as "bos:eos:reverse".
+Status CompileExtraOptions(const ModelData &m, const std::string &opts, HostTables *t);
+// Points t->scalars at t's own vectors (host execution / emulation).
+void BindHostPointers(HostTables *t);
+
+}  // namespace spmx
+#endif

@@ -1,0 +1,54 @@
+// Wave-level primitives for gfx950 (64-lane wavefronts).  Everything the
+// kernels need across lanes goes through this small API so that every
+// cross-lane operation sits in wave-uniform control flow (all 64 lanes call
+// it together).  tests/emu/ provides a lock-step CPU model of the same API to
+// run the kernel bodies under a debugger without a GPU (test seam only).
+#ifndef SPMX_WAVE_H_
+#define SPMX_WAVE_H_
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SPMX_DEVICE __device__ __forceinline__
+
+namespace spmx {
+namespace wv {
+
+SPMX_DEVICE int lane() { return static_cast<int>(threadIdx.x) & 63; }
+SPMX_DEVICE int block_id() { return static_cast<int>(blockIdx.x); }
+SPMX_DEVICE int grid_size() { return static_cast<int>(gridDim.x); }
+
+SPMX_DEVICE uint64_t ballot(bool p) { return __ballot(p ? 1 : 0); }
+SPMX_DEVICE bool any(bool p) { return __ballot(p ? 1 : 0) != 0ull; }
+
+SPMX_DEVICE uint32_t shfl(uint32_t v, int src) { return static_cast<uint32_t>(__shfl(static_cast<int>(v), src, 64)); }
+SPMX_DEVICE int shfl(int v, int src) { return __shfl(v, src, 64); }
+SPMX_DEVICE float shfl(float v, int src) { return __shfl(v, src, 64); }
+SPMX_DEVICE double shfl(double v, int src) {
+  const uint64_t u = static_cast<uint64_t>(__double_as_longlong(v));
+  const uint32_t lo = shfl(static_cast<uint32_t>(u), src), hi = shfl(static_cast<uint32_t>(u >> 32), src);
+  return __longlong_as_double(static_cast<long long>(static_cast<uint64_t>(hi) << 32 | lo));
+}
+// value of lane (lane - delta); lanes < delta keep their own value
+SPMX_DEVICE int shfl_up(int v, int delta) { return __shfl_up(v, static_cast<unsigned>(delta), 64); }
+
+// Orders this wave's LDS traffic: writes before the call are visible to every
+// lane's reads after it.  A wave executes in lock step, so only the compiler
+// and the LDS queue need to be fenced -- no s_barrier.
+SPMX_DEVICE void sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+SPMX_DEVICE uint32_t atomic_add(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
+SPMX_DEVICE unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
+SPMX_DEVICE void atomic_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }
+
+SPMX_DEVICE int popc64(uint64_t x) { return __popcll(x); }
+SPMX_DEVICE int ffs64(uint64_t x) { return __ffsll(static_cast<unsigned long long>(x)); }   // 1-based, 0 if none
+SPMX_DEVICE int clz64(uint64_t x) { return __clzll(static_cast<long long>(x)); }
+SPMX_DEVICE float bits_to_float(uint32_t u) { return __uint_as_float(u); }
+
+}  // namespace wv
+}  // namespace spmx
+#endif

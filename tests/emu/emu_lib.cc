@@ -1,0 +1,240 @@
+// TEST INFRASTRUCTURE ONLY (see wave_emu.h).  Builds tests/emu/libspmx_emu.so:
+// the product's host code (model.cc, dat.cc, tables.cc) + the product's device
+// bodies (kernels.h) compiled for the CPU against the lock-step wave model, and
+// a C entry point that runs the same launch sequence as csrc/api.cc.
+#include "wave_emu.h"
+
+#include <sys/mman.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../sentencepiece_amd/csrc/kernels.h"
+#include "../../sentencepiece_amd/csrc/model.h"
+#include "../../sentencepiece_amd/csrc/tables.h"
+
+namespace spmx {
+namespace emu {
+
+Wave g_wave;
+
+asm(R"(
+.text
+.globl spmx_emu_switch
+.type spmx_emu_switch,@function
+spmx_emu_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+)");
+
+namespace {
+constexpr size_t kStack = 256 * 1024;
+
+void LaneEntry() {
+  Lane &l = g_wave.lanes[g_wave.cur];
+  g_wave.body();
+  l.done = true;
+  l.op = kNone;
+  spmx_emu_switch(&l.sp, g_wave.sched_sp);
+  abort();  // never resumed
+}
+
+void Fail(const char *msg) {
+  fprintf(stderr, "wave_emu: %s (block %d)\n", msg, g_wave.block);
+  abort();
+}
+}  // namespace
+
+void RunWave(int block, int grid, unsigned char *smem, const std::function<void()> &body) {
+  Wave &w = g_wave;
+  w.block = block; w.grid = grid; w.smem = smem; w.body = body;
+  for (int i = 0; i < 64; ++i) {
+    Lane &l = w.lanes[i];
+    if (!l.stack) {
+      l.stack = static_cast<unsigned char *>(mmap(nullptr, kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
+      if (l.stack == MAP_FAILED) Fail("mmap failed");
+    }
+    l.done = false; l.op = kNone;
+    uintptr_t top = reinterpret_cast<uintptr_t>(l.stack + kStack) & ~uintptr_t(15);
+    void **sp = reinterpret_cast<void **>(top - 16);
+    *sp = reinterpret_cast<void *>(&LaneEntry);   // return address popped by `ret`
+    sp -= 6;                                      // rbp rbx r12 r13 r14 r15
+    for (int k = 0; k < 6; ++k) sp[k] = nullptr;
+    l.sp = sp;
+  }
+  for (;;) {
+    int n_done = 0;
+    for (int i = 0; i < 64; ++i) {
+      Lane &l = w.lanes[i];
+      if (l.done) { ++n_done; continue; }
+      w.cur = i;
+      spmx_emu_switch(&w.sched_sp, l.sp);
+      if (l.done) ++n_done;
+    }
+    if (n_done == 64) break;
+    if (n_done != 0) Fail("divergent collective: some lanes exited while others wait");
+    const Op op = w.lanes[0].op;
+    for (int i = 1; i < 64; ++i) if (w.lanes[i].op != op) {
+      fprintf(stderr, "wave_emu: ops per lane:");
+      for (int k = 0; k < 64; ++k) fprintf(stderr, " %d", static_cast<int>(w.lanes[k].op));
+      fprintf(stderr, "\n");
+      Fail("divergent collective: lanes wait at different operations");
+    }
+    ++w.n_collectives;
+    switch (op) {
+      case kBallot: {
+        uint64_t m = 0;
+        for (int i = 0; i < 64; ++i) if (w.lanes[i].a) m |= 1ull << i;
+        for (int i = 0; i < 64; ++i) w.lanes[i].out = m;
+        break;
+      }
+      case kShfl:
+        for (int i = 0; i < 64; ++i) w.lanes[i].out = w.lanes[w.lanes[i].b & 63].a;
+        break;
+      case kShflUp:
+        for (int i = 0; i < 64; ++i) {
+          const int d = static_cast<int>(w.lanes[i].b);
+          w.lanes[i].out = i >= d ? w.lanes[i - d].a : w.lanes[i].a;
+        }
+        break;
+      case kSync: break;
+      default: Fail("unknown collective");
+    }
+  }
+}
+
+}  // namespace emu
+}  // namespace spmx
+
+using namespace spmx;
+
+struct EmuHandle {
+  ModelData model;
+  HostTables tables;
+  std::string error;
+};
+
+namespace {
+struct LengthClass { uint32_t rcap, ncap; };
+// keep in sync with csrc/launch.h (the test compares the emulated pipeline with
+// the oracle, not with these numbers; small classes are added to exercise the
+// escalation path on short inputs)
+const LengthClass kUniCls[] = {{24, 40}, {192, 448}, {576, 1280}, {1536, 3328}, {4096, 8704}, {8192, 20480}};
+const LengthClass kBpeCls[] = {{24, 40}, {192, 448}, {576, 1280}, {1536, 3328}, {4096, 6400}};
+}  // namespace
+
+extern "C" {
+
+void *emu_load(const void *bytes, uint64_t n, char *err, uint64_t errcap) {
+  auto *h = new EmuHandle;
+  Status st = ParseModelProto(bytes, n, &h->model);
+  if (st.ok()) st = InitializeModel(&h->model);
+  if (st.ok()) st = CompileTables(h->model, &h->tables);
+  if (st.ok()) st = CompileExtraOptions(h->model, "", &h->tables);
+  if (!st.ok()) {
+    if (err && errcap) snprintf(err, errcap, "%s", st.message.c_str());
+    delete h;
+    return nullptr;
+  }
+  BindHostPointers(&h->tables);
+  return h;
+}
+
+void emu_free(void *h) { delete static_cast<EmuHandle *>(h); }
+
+int emu_set_encode_extra_options(void *hv, const char *opts) {
+  auto *h = static_cast<EmuHandle *>(hv);
+  Status st = CompileExtraOptions(h->model, opts, &h->tables);
+  return st.code;
+}
+
+int emu_set_vocabulary(void *hv, const char *pieces, uint64_t len) {
+  auto *h = static_cast<EmuHandle *>(hv);
+  std::vector<std::string> v;
+  const char *p = pieces, *end = pieces + len;
+  while (p < end) {
+    const char *q = static_cast<const char *>(memchr(p, '\n', end - p));
+    if (!q) q = end;
+    v.emplace_back(p, q - p);
+    p = q + 1;
+  }
+  Status st = SetVocabulary(&h->model, v);
+  RefreshTypeFlags(h->model, &h->tables);
+  return st.code;
+}
+
+int emu_reset_vocabulary(void *hv) {
+  auto *h = static_cast<EmuHandle *>(hv);
+  ResetVocabulary(&h->model);
+  RefreshTypeFlags(h->model, &h->tables);
+  return 0;
+}
+
+// Runs classify -> encode (every class) -> scan -> compact with `grid` waves
+// per launch.  Returns total ids, or -(needed) - 2 if cap is too small; the
+// device status word is returned in *status.
+int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, uint64_t n, int32_t *ids, uint64_t cap,
+                         uint64_t *id_offs, int grid, uint32_t *status_out) {
+  auto *h = static_cast<EmuHandle *>(hv);
+  const SpmxDev &dev = h->tables.scalars;
+  const bool bpe = dev.model_type == 2;
+  const LengthClass *cls = bpe ? kBpeCls : kUniCls;
+  const int ncls = bpe ? static_cast<int>(sizeof(kBpeCls) / sizeof(kBpeCls[0])) : static_cast<int>(sizeof(kUniCls) / sizeof(kUniCls[0]));
+  if (grid < 1) grid = 1;
+  std::vector<uint32_t> lists(static_cast<size_t>(ncls) * (n ? n : 1)), list_counts(kMaxClasses, 0), counts(n + 1, 0);
+  std::vector<uint64_t> tmp_off(n + 1, 0);
+  ClassifyArgs ca{};
+  ca.offs = offs; ca.n = static_cast<uint32_t>(n); ca.n_classes = static_cast<uint32_t>(ncls);
+  for (int c = 0; c < ncls; ++c) ca.rcap[c] = cls[c].rcap;
+  ca.lists = lists.data(); ca.list_counts = list_counts.data();
+  for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { classify_block(ca); });
+  const uint64_t text_bytes = offs[n];
+  std::vector<int32_t> arena(text_bytes + (2 + dev.n_prefix + dev.n_suffix) * n + 64);
+  unsigned long long arena_head = 0;
+  uint32_t status = 0;
+  unsigned long long stats[3 * kMaxClasses] = {0};
+  for (int c = 0; c < ncls; ++c) {
+    EncodeArgs a{};
+    a.dev = dev; a.text = text; a.offs = offs;
+    a.list = lists.data() + static_cast<size_t>(c) * n; a.list_count = &list_counts[c];
+    a.next_list = c + 1 < ncls ? lists.data() + static_cast<size_t>(c + 1) * n : nullptr;
+    a.next_count = c + 1 < ncls ? &list_counts[c + 1] : nullptr;
+    a.arena = arena.data(); a.arena_head = &arena_head; a.arena_cap = arena.size();
+    a.tmp_off = tmp_off.data(); a.counts = counts.data(); a.status = &status; a.stats = &stats[3 * c];
+    a.rcap = cls[c].rcap; a.ncap = cls[c].ncap;
+    std::vector<unsigned char> smem(EncodeLdsBytes(dev.model_type, a.rcap, a.ncap) + 64, 0xCD);
+    for (int b = 0; b < grid; ++b) {
+      if (bpe) emu::RunWave(b, grid, smem.data(), [&] { encode_block<2>(a, smem.data()); });
+      else emu::RunWave(b, grid, smem.data(), [&] { encode_block<1>(a, smem.data()); });
+    }
+  }
+  std::vector<uint64_t> tile_sums((n + kScanTile - 1) / kScanTile + 2, 0);
+  ScanArgs sa{counts.data(), static_cast<uint32_t>(n), tile_sums.data(), id_offs};
+  for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { scan_tiles_block(sa); });
+  emu::RunWave(0, 1, nullptr, [&] { scan_sums_block(sa); });
+  for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { scan_final_block(sa); });
+  CompactArgs pa{arena.data(), tmp_off.data(), counts.data(), id_offs, ids, cap, static_cast<uint32_t>(n)};
+  for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { compact_block(pa); });
+  if (status_out) *status_out = status;
+  const uint64_t total = id_offs[n];
+  if (total > cap) return -static_cast<int64_t>(total) - 2;
+  return static_cast<int64_t>(total);
+}
+
+uint64_t emu_collectives() { return emu::g_wave.n_collectives; }
+
+}  // extern "C"

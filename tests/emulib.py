@@ -1,0 +1,73 @@
+"""ctypes binding of tests/emu/libspmx_emu.so: the product's device code run on
+the CPU under a lock-step wavefront model.  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+EMU_SO = os.path.join(EMU_DIR, "libspmx_emu.so")
+
+
+class EmuLib:
+    def __init__(self):
+        subprocess.check_call(["make", "-s", "-C", EMU_DIR])
+        self.lib = lib = C.CDLL(EMU_SO)
+        lib.emu_load.restype = C.c_void_p
+        lib.emu_load.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]
+        lib.emu_free.argtypes = [C.c_void_p]
+        lib.emu_set_encode_extra_options.argtypes = [C.c_void_p, C.c_char_p]
+        lib.emu_set_vocabulary.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
+        lib.emu_reset_vocabulary.argtypes = [C.c_void_p]
+        lib.emu_encode_batch.restype = C.c_int64
+        lib.emu_encode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                         C.c_void_p, C.c_int, C.c_void_p]
+        lib.emu_collectives.restype = C.c_uint64
+
+    def load(self, model_bytes):
+        err = C.create_string_buffer(512)
+        h = self.lib.emu_load(model_bytes, len(model_bytes), err, 512)
+        if not h:
+            raise RuntimeError("emu_load: " + err.value.decode())
+        return EmuHandle(self.lib, h)
+
+
+class EmuHandle:
+    def __init__(self, lib, h):
+        self.lib, self.h = lib, h
+        self.status = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.emu_free(self.h)
+            self.h = None
+
+    def set_encode_extra_options(self, opts):
+        rc = self.lib.emu_set_encode_extra_options(self.h, opts.encode())
+        if rc:
+            raise RuntimeError("bad extra options (%d)" % rc)
+
+    def set_vocabulary(self, pieces):
+        blob = "\n".join(pieces).encode()
+        self.lib.emu_set_vocabulary(self.h, blob, len(blob))
+
+    def reset_vocabulary(self):
+        self.lib.emu_reset_vocabulary(self.h)
+
+    def encode_batch(self, text, offs, grid=3):
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        n = len(offs) - 1
+        cap = int(len(text)) * 2 + 8 * n + 64
+        ids = np.empty(cap, dtype=np.int32)
+        id_offs = np.zeros(n + 1, dtype=np.uint64)
+        st = C.c_uint32(0)
+        tp = text.ctypes.data if len(text) else None
+        tot = self.lib.emu_encode_batch(self.h, tp, offs.ctypes.data, n, ids.ctypes.data, cap, id_offs.ctypes.data,
+                                        grid, C.byref(st))
+        self.status = st.value
+        if tot < 0:
+            raise RuntimeError("emu_encode_batch failed: %d status %d" % (tot, st.value))
+        return ids[:tot].copy(), id_offs
