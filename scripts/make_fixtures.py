@@ -47,8 +47,18 @@ def make_models():
     shutil.copy(f"{REF}/data/botchan.txt", f"{G}/botchan.txt")
     with open(f"{REF}/data/wagahaiwa_nekodearu.txt", "rb") as f:
         lines = f.read().split(b"\n")[:700]
+    # paragraphs of up to 17 KB: cut them at character boundaries so that every
+    # fixture line fits the device path's largest common length class (<= 4096 B)
+    cut = []
+    for ln in lines:
+        s = ln.decode("utf-8")
+        while len(s.encode("utf-8")) > 3900:
+            k = 1300
+            cut.append(s[:k].encode("utf-8"))
+            s = s[k:]
+        cut.append(s.encode("utf-8"))
     with open(f"{G}/ja_sample.txt", "wb") as f:
-        f.write(b"\n".join(lines) + b"\n")
+        f.write(b"\n".join(cut) + b"\n")
     bot = f"{G}/botchan.txt"
     train("uni1k", bot, vocab_size=1000, model_type="unigram")
     train("bpe1k", bot, vocab_size=1000, model_type="bpe")

@@ -49,27 +49,40 @@ bool BuildDat(const std::vector<std::pair<std::string, uint32_t>> &keys_in, DatT
     }
     nodes[cur].value = keys[k].second;
   }
-  // 2. place nodes breadth-first.
+  // 2. place nodes breadth-first.  Free slots are kept on a doubly linked list
+  //    (index 0 is the list head sentinel = the root slot, never free).
   std::vector<uint32_t> &w0 = out->w0;
   std::vector<uint32_t> &val = out->value;
   w0.assign(256, 0);
   val.assign(256, 0xFFFFFFFFu);
   std::vector<uint8_t> occupied(256, 0), base_used(256, 0);
-  auto grow = [&](size_t need) {
-    while (w0.size() < need) {
-      w0.resize(w0.size() + 256, 0);
-      val.resize(val.size() + 256, 0xFFFFFFFFu);
-      occupied.resize(occupied.size() + 256, 0);
-      base_used.resize(base_used.size() + 256, 0);
-    }
+  std::vector<uint32_t> nxt(256), prv(256);
+  for (uint32_t i = 0; i < 256; ++i) { nxt[i] = (i + 1) & 255; prv[i] = (i + 255) & 255; }
+  auto grow = [&]() {
+    const uint32_t old = static_cast<uint32_t>(w0.size());
+    w0.resize(old + 256, 0);
+    val.resize(old + 256, 0xFFFFFFFFu);
+    occupied.resize(old + 256, 0);
+    base_used.resize(old + 256, 0);
+    nxt.resize(old + 256);
+    prv.resize(old + 256);
+    const uint32_t tail = prv[0];
+    for (uint32_t i = old; i < old + 256; ++i) { nxt[i] = i + 1; prv[i] = i - 1; }
+    nxt[tail] = old; prv[old] = tail;
+    nxt[old + 255] = 0; prv[0] = old + 255;
   };
-  occupied[0] = 1;  // root
+  auto take = [&](uint32_t slot) {
+    occupied[slot] = 1;
+    nxt[prv[slot]] = nxt[slot];
+    prv[nxt[slot]] = prv[slot];
+  };
+  occupied[0] = 1;   // root; stays linked as the sentinel
   base_used[0] = 1;  // base 0 is what childless units carry: never a real base, so their probes always mismatch
   w0[0] = 0;  // the root carries no label: a NUL byte probe from a childless unit (base 0) must not match it
   std::vector<std::pair<int32_t, uint32_t>> queue;  // (tmp node, unit index)
   queue.emplace_back(0, 0u);
-  size_t first_free = 1;
   std::vector<uint8_t> labels;
+  uint32_t cursor = 0;
   for (size_t qi = 0; qi < queue.size(); ++qi) {
     const int32_t tn = queue[qi].first;
     const uint32_t unit = queue[qi].second;
@@ -80,29 +93,44 @@ bool BuildDat(const std::vector<std::pair<std::string, uint32_t>> &keys_in, DatT
       val[unit] = nodes[tn].value;
     }
     if (labels.empty()) continue;
-    while (first_free < w0.size() && occupied[first_free]) ++first_free;
     uint32_t base = 0;
     bool found = false;
-    for (size_t f = first_free; !found; ++f) {
-      if (f >= w0.size()) grow(f + 1);
-      if (occupied[f]) continue;
-      const uint32_t b = static_cast<uint32_t>(f) ^ labels[0];
-      if (b >= w0.size() || base_used[b]) continue;
-      bool ok = true;
-      for (size_t i = 1; i < labels.size() && ok; ++i) ok = !occupied[b ^ labels[i]];
-      if (ok) { base = b; found = true; }
-      if (f > kDatMaxUnits) break;
+    auto fits = [&](uint32_t f) {
+      const uint32_t b = f ^ labels[0];
+      if (base_used[b]) return false;
+      for (size_t i = 1; i < labels.size(); ++i) if (occupied[b ^ labels[i]]) return false;
+      base = b;
+      return true;
+    };
+    // Single-child nodes (the bulk of a trie) can sit in any hole: first fit
+    // from the head of the free list.  Branching nodes need several holes in
+    // one 256-slot block: next fit from a cursor that only moves forward.
+    int tries = 0;
+    if (labels.size() == 1) {
+      for (uint32_t f = nxt[0]; f != 0 && tries < 8192 && !found; f = nxt[f], ++tries) found = fits(f);
+    } else {
+      if (cursor == 0 || occupied[cursor]) cursor = nxt[0];
+      for (uint32_t f = cursor; f != 0 && tries < 2048 && !found; f = nxt[f], ++tries) {
+        found = fits(f);
+        if (found) cursor = f;
+      }
     }
-    if (!found || w0.size() > kDatMaxUnits) {
-      if (error) *error = "trie needs more than 4M units";
-      return false;
+    while (!found) {       // a fresh block always fits
+      const uint32_t old = static_cast<uint32_t>(w0.size());
+      if (old + 256 > kDatMaxUnits) {
+        if (error) *error = "trie needs more than 4M units";
+        return false;
+      }
+      grow();
+      for (uint32_t f = old; f < old + 256 && !found; ++f) found = fits(f);
+      if (labels.size() > 1) cursor = old;
     }
     base_used[base] = 1;
     w0[unit] |= base << kDatBaseShift;
     size_t li = 0;
     for (int32_t ch = nodes[tn].first_child; ch >= 0; ch = nodes[ch].next_sibling, ++li) {
       const uint32_t slot = base ^ labels[li];
-      occupied[slot] = 1;
+      take(slot);
       w0[slot] = kDatOccupied | labels[li];
       queue.emplace_back(ch, slot);
     }

@@ -21,19 +21,13 @@ enum : uint32_t {
   kNfRemoveExtraWs = 1u << 1,
   kNfEscapeWs = 1u << 2,
   kNfWsSuffix = 1u << 3,
-  kNfHasTrie = 1u << 4,      // charsmap rules and / or user-defined symbols present
+  kNfHasCharsmap = 1u << 4,  // precompiled_charsmap present (Darts units used verbatim)
   kNfByteFallback = 1u << 5,
   kNfReverse = 1u << 6,      // net effect of the extra options (see tables.cc)
   kNfHasUserDefined = 1u << 7,
   kNfHasUnused = 1u << 8,    // some piece is currently UNUSED (BPE resegmentation armed)
 };
 
-// ntrie value word: key index | flags
-constexpr uint32_t kNkUds = 1u << 31;
-constexpr uint32_t kNkRule = 1u << 30;
-constexpr uint32_t kNkIndexMask = (1u << 30) - 1;
-// ninfo.x: blob offset << 8 | flags ; ninfo.y: len | lead << 12 | nspaces << 20
-constexpr uint32_t kNiEndsSpace = 1u << 0;
 
 // ptrie payload (U4: w0, idflags, score bits, 0)
 constexpr uint32_t kPtUnused = 1u << 31;
@@ -56,9 +50,9 @@ constexpr int kMaxPieceBytes = 64; // systolic unigram walk: one lane per start,
 
 struct SpmxDev {
   // ---- normalizer (reference: src/normalizer.cc:71-253) ----
-  const U2 *ntrie;        // merged trie over charsmap keys and user-defined symbols
-  const U2 *ninfo;        // per key: replacement string descriptor
-  const uint8_t *nblob;   // replacement strings
+  const uint32_t *ndarts; // the model's own Darts double-array units (part of the .model format)
+  const uint8_t *nblob;   // NUL-terminated replacement strings
+  uint32_t ndarts_n, nblob_n;
   uint32_t flags;
   // ---- unigram (reference: src/unigram_model.cc:889-1020) ----
   const U4 *ptrie;        // piece trie with inline id / flags / score
@@ -70,7 +64,7 @@ struct SpmxDev {
   int32_t n_prefix, n_suffix;
   int32_t prefix_ids[kMaxExtra], suffix_ids[kMaxExtra];
   // ---- BPE (reference: src/bpe_model.cc:38-203) ----
-  const U2 *utrie;        // user-defined symbols only (PrefixMatcher over normalized text)
+  const U2 *utrie;        // user-defined symbols only (PrefixMatcher; normalizer and BPE both use it)
   const U4 *chartab;      // {bytes, len, sym, 0}   open addressing, empty: len == 0
   const U4 *pairtab;      // {symL, symR, merged sym, score bits}   empty: symL == kSymNone
   const uint32_t *sym_final;  // per symbol: final id | flags

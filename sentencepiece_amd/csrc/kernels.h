@@ -48,6 +48,9 @@ struct EncodeArgs {
 
 constexpr uint32_t kTokEnd = 0x8000u;  // blen[] flag: a token of the best path ends here
 
+// Darts::DoubleArrayUnit::offset() (third_party/darts_clone/darts.h:72-74)
+SPMX_DEVICE uint32_t DartsOffset(uint32_t u) { return (u >> 10) << ((u & (1u << 9)) >> 6); }
+
 SPMX_DEVICE int OneCharLenDev(uint32_t c) {  // src/util.h:151-153
   const uint32_t h = c >> 4;
   return h < 12 ? 1 : (h < 14 ? 2 : (h == 14 ? 3 : 4));
@@ -121,7 +124,6 @@ SPMX_DEVICE uint64_t resolve_chain(int base, int step, bool valid, int *next_sta
 SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint8_t *norm, int ncap, int lane) {
   const uint32_t F = d.flags;
   const bool esc = (F & kNfEscapeWs) != 0, rm = (F & kNfRemoveExtraWs) != 0;
-  const bool has_trie = (F & kNfHasTrie) != 0;
   const int spw = esc ? 3 : 1;
   int out = 0;
   if ((F & kNfAddDummyPrefix) && !(F & kNfWsSuffix)) {   // :128
@@ -132,35 +134,61 @@ SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint
   bool P = rm;                       // is_prev_space (:130), wave-uniform between sweeps
   bool any_other = false;            // some prefix normalizes to something other than exactly " "
   int next_start = 0;
-  const uint32_t nroot = has_trie ? (d.ntrie[0].x >> kDatBaseShiftDev) : 0u;
+  const bool has_map = (F & kNfHasCharsmap) != 0, has_uds = (F & kNfHasUserDefined) != 0;
+  const uint32_t droot = has_map ? DartsOffset(d.ndarts[0]) : 0u;
+  const uint32_t uroot = has_uds ? (d.utrie[0].x >> kDatBaseShiftDev) : 0u;
   for (int b = 0; b < L; b += 64) {
     const int p = b + lane;
     const bool valid = p < L;
     // (1) NormalizePrefix at every position (:195-253)
     int uds_len = 0, rule_len = 0;
-    uint32_t rule_idx = 0;
-    if (has_trie) {
+    uint32_t rule_off = 0;
+    if (has_uds) {                         // matcher_->PrefixMatch (:201-205, :324-346): longest user-defined symbol
       bool alive = valid;
-      uint32_t nb = nroot;
+      uint32_t nb = uroot;
       int depth = 0;
       while (wv::any(alive)) {
         if (alive) {
           const int q = p + depth;
           if (q < L) {
             const uint32_t c = raw[q];
-            const U2 u = d.ntrie[nb ^ c];
+            const U2 u = d.utrie[nb ^ c];
             if ((u.x & 0x1FFu) == (0x100u | c)) {
               ++depth;
               nb = u.x >> kDatBaseShiftDev;
-              if (u.x & kDatTerminalDev) {
-                if (u.y & kNkUds) uds_len = depth;
-                if (u.y & kNkRule) { rule_len = depth; rule_idx = u.y & kNkIndexMask; }
-              }
+              if (u.x & kDatTerminalDev) uds_len = depth;
             } else {
               alive = false;
             }
           } else {
             alive = false;
+          }
+        }
+      }
+    }
+    if (has_map) {                         // trie_->commonPrefixSearch (:218-228; darts.h:467-513), longest key
+      bool alive = valid;
+      uint32_t pos = droot;
+      int depth = 0;
+      while (wv::any(alive)) {
+        if (alive) {
+          const int q = p + depth;
+          alive = false;
+          if (q < L) {
+            const uint32_t c = raw[q];
+            pos ^= c;
+            if (pos < d.ndarts_n) {
+              const uint32_t u = d.ndarts[pos];
+              if ((u & 0x800000FFu) == c) {          // unit.label() == c
+                pos ^= DartsOffset(u);
+                ++depth;
+                alive = true;
+                if ((u >> 8) & 1u) {                 // has_leaf: value sits in the unit at pos
+                  if (pos < d.ndarts_n) { rule_len = depth; rule_off = d.ndarts[pos] & 0x7FFFFFFFu; }
+                  else alive = false;
+                }
+              }
+            }
           }
         }
       }
@@ -173,18 +201,10 @@ SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint
     if (valid) {
       if (uds_len > 0) {                       // :201-205 user-defined symbols pass through
         consumed = len = uds_len;
-        for (int k = 0; k < len; ++k) nsp += raw[p + k] == 0x20;
-        while (lead < len && raw[p + lead] == 0x20) ++lead;
-        ends_sp = raw[p + len - 1] == 0x20;
       } else if (rule_len > 0) {               // :222-228 longest rule, :245-250
         kind = 1;
         consumed = rule_len;
-        const U2 info = d.ninfo[rule_idx];
-        src = info.x >> 8;
-        ends_sp = (info.x & kNiEndsSpace) != 0;
-        len = static_cast<int>(info.y & 0xFFFu);
-        lead = static_cast<int>((info.y >> 12) & 0xFFu);
-        nsp = static_cast<int>(info.y >> 20);
+        src = rule_off;
       } else {                                 // :231-244 one UTF-8 char (DecodeUTF8, util.cc:51-84)
         const uint32_t b0 = raw[p];
         const int rem = L - p;
@@ -215,6 +235,21 @@ SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint
     // (2) which positions are real prefix starts
     const uint64_t S = resolve_chain(b, consumed, valid, &next_start);
     const bool is_start = ((S >> lane) & 1ull) != 0;
+    if (is_start && uds_len > 0) {             // the matched span itself, spaces and all
+      for (int k = 0; k < len; ++k) nsp += raw[p + k] == 0x20;
+      while (lead < len && raw[p + lead] == 0x20) ++lead;
+      ends_sp = raw[p + len - 1] == 0x20;
+    } else if (is_start && kind == 1) {        // replacement = C string at normalized_[value] (:249)
+      len = 0;
+      bool leading = true;
+      while (src + static_cast<uint32_t>(len) < d.nblob_n) {
+        const uint32_t ch = d.nblob[src + len];
+        if (ch == 0) break;
+        ++len;
+        if (ch == 0x20u) { ++nsp; if (leading) ++lead; } else { leading = false; }
+        ends_sp = ch == 0x20u;
+      }
+    }
     // (3) whitespace state machine (:131-163)
     const bool single_sp = len == 1 && lead == 1;                 // p.first == " "
     any_other = any_other || wv::any(is_start && !single_sp);

@@ -9,68 +9,6 @@
 namespace spmx {
 namespace {
 
-// Darts unit accessors (reference: third_party/darts_clone/darts.h:50-80).
-inline uint32_t DuOffset(uint32_t u) { return (u >> 10) << ((u & (1u << 9)) >> 6); }
-inline uint32_t DuLabel(uint32_t u) { return u & ((1u << 31) | 0xFF); }
-inline bool DuHasLeaf(uint32_t u) { return (u >> 8) & 1; }
-inline uint32_t DuValue(uint32_t u) { return u & ((1u << 31) - 1); }
-
-struct NormKey {
-  bool uds = false, rule = false;
-  uint32_t off = 0, len = 0;
-};
-
-// Enumerates every (key, value) of the serialized Darts trie inside a
-// precompiled_charsmap (layout: src/normalizer.cc:274-309) by walking it the
-// way commonPrefixSearch does (darts.h:467-513).  Also validates it: every
-// reachable unit index is in range.  Darts-clone builds its array from a DAWG,
-// so units are legitimately shared between keys (merged suffixes); termination
-// on a malformed (cyclic) blob is guaranteed by the key-length and step caps.
-Status EnumerateCharsmap(const std::string &blob, std::map<std::string, NormKey> *keys, std::string *strings) {
-  if (blob.size() <= 4) return Status::Error(kInternal, "Blob for normalization rule is broken.");
-  uint32_t trie_bytes = 0;
-  memcpy(&trie_bytes, blob.data(), 4);
-  if (trie_bytes >= blob.size()) return Status::Error(kInternal, "Trie data size exceeds the input blob size.");
-  const size_t n = trie_bytes / 4;
-  std::vector<uint32_t> units(n);
-  memcpy(units.data(), blob.data() + 4, n * 4);
-  strings->assign(blob.data() + 4 + trie_bytes, blob.size() - 4 - trie_bytes);
-  if (n == 0) return Status::OK();
-  uint64_t steps = 0;
-  struct Frame { uint32_t pos; int next_c; };
-  std::vector<Frame> stack;
-  std::string key;
-  stack.push_back({DuOffset(units[0]), 1});
-  while (!stack.empty()) {
-    Frame &f = stack.back();
-    if (f.next_c > 255) {
-      stack.pop_back();
-      if (!key.empty()) key.pop_back();
-      continue;
-    }
-    const int c = f.next_c++;
-    const uint32_t p2 = f.pos ^ static_cast<uint32_t>(c);
-    if (p2 >= n) continue;
-    const uint32_t u = units[p2];
-    if (DuLabel(u) != static_cast<uint32_t>(c)) continue;
-    if (++steps > (1ull << 26)) return Status::Error(kInternal, "precompiled_charsmap trie is malformed (too many paths).");
-    const uint32_t child = p2 ^ DuOffset(u);
-    key.push_back(static_cast<char>(c));
-    if (key.size() > 1024) return Status::Error(kInternal, "precompiled_charsmap trie is malformed (key too long).");
-    if (DuHasLeaf(u)) {
-      if (child >= n) return Status::Error(kInternal, "precompiled_charsmap trie is malformed (leaf out of range).");
-      const uint32_t off = DuValue(units[child]);
-      if (off >= strings->size()) return Status::Error(kInternal, "precompiled_charsmap value out of range.");
-      NormKey &k = (*keys)[key];
-      k.rule = true;
-      k.off = off;
-      k.len = static_cast<uint32_t>(strnlen(strings->data() + off, strings->size() - off));
-    }
-    stack.push_back({child, 1});
-  }
-  return Status::OK();
-}
-
 void PackTrie2(const DatTrie &d, const std::vector<uint32_t> &payload, std::vector<U2> *out) {
   out->resize(d.w0.size());
   for (size_t i = 0; i < d.w0.size(); ++i) {
@@ -109,60 +47,33 @@ Status CompileTables(const ModelData &m, HostTables *t) {
   if (m.byte_fallback) flags |= kNfByteFallback;
 
   // ---------------------------------------------------------- normalizer ---
-  std::map<std::string, NormKey> nkeys;
-  std::string strings;
+  // DecodePrecompiledCharsMap (src/normalizer.cc:274-309): <u32 trie bytes><Darts units><strings>.
+  // The units are used on the device exactly as serialized; every probe is
+  // bounds-checked there, so a malformed blob cannot read out of range.
+  t->ndarts.clear();
+  t->nblob.clear();
   if (!m.charsmap.empty()) {
-    Status st = EnumerateCharsmap(m.charsmap, &nkeys, &strings);
-    if (!st.ok()) return st;
+    const std::string &blob = m.charsmap;
+    if (blob.size() <= 4) return Status::Error(kInternal, "Blob for normalization rule is broken.");
+    uint32_t trie_bytes = 0;
+    memcpy(&trie_bytes, blob.data(), 4);
+    if (trie_bytes >= blob.size()) return Status::Error(kInternal, "Trie data size exceeds the input blob size.");
+    t->ndarts.resize(trie_bytes / 4);
+    memcpy(t->ndarts.data(), blob.data() + 4, t->ndarts.size() * 4);
+    t->nblob.assign(blob.begin() + 4 + trie_bytes, blob.end());
+    if (!t->ndarts.empty()) flags |= kNfHasCharsmap;
   }
+  if (t->ndarts.empty()) t->ndarts.push_back(0);
+  if (t->nblob.empty()) t->nblob.push_back(0);
+  sc.ndarts_n = static_cast<uint32_t>(t->ndarts.size());
+  sc.nblob_n = static_cast<uint32_t>(t->nblob.size());
   std::vector<std::pair<std::string, uint32_t>> uds_keys;
   for (size_t i = 0; i < m.pieces.size(); ++i) {
     if (m.pieces[i].load_type != kUserDefined) continue;
-    nkeys[m.pieces[i].piece].uds = true;
     uds_keys.emplace_back(m.pieces[i].piece, static_cast<uint32_t>(i));
     flags |= kNfHasUserDefined;
   }
-  if (strings.size() >= (1u << 24)) return Status::Error(kResourceExhausted, "precompiled_charsmap strings exceed 16 MiB");
-  t->nblob.assign(strings.begin(), strings.end());
-  if (t->nblob.empty()) t->nblob.push_back(0);
-  t->ninfo.clear();
-  t->max_norm_key_len = 4;
-  t->max_expansion_num = 3;
-  t->max_expansion_den = 1;
-  if (!nkeys.empty()) {
-    std::vector<std::pair<std::string, uint32_t>> keys;
-    std::vector<uint32_t> payload;
-    for (const auto &kv : nkeys) {
-      const NormKey &k = kv.second;
-      uint32_t lead = 0, nsp = 0, f = 0;
-      if (k.rule) {
-        const char *s = strings.data() + k.off;
-        while (lead < k.len && s[lead] == ' ') ++lead;
-        for (uint32_t i = 0; i < k.len; ++i) nsp += s[i] == ' ';
-        if (k.len > 0 && s[k.len - 1] == ' ') f |= kNiEndsSpace;
-        if (k.len >= 4096 || lead >= 256 || nsp >= 4096)
-          return Status::Error(kUnimplemented, "normalization rule replacement too long for the device path");
-        const uint64_t out_bytes = k.len + (m.escape_ws ? 2ull * nsp : 0);
-        if (out_bytes * t->max_expansion_den > static_cast<uint64_t>(t->max_expansion_num) * kv.first.size()) {
-          t->max_expansion_num = static_cast<int>(out_bytes);
-          t->max_expansion_den = static_cast<int>(kv.first.size());
-        }
-      }
-      const uint32_t idx = static_cast<uint32_t>(t->ninfo.size());
-      t->ninfo.push_back(U2{k.off << 8 | f, k.len | lead << 12 | nsp << 20});
-      payload.push_back(idx | (k.uds ? kNkUds : 0) | (k.rule ? kNkRule : 0));
-      keys.emplace_back(kv.first, idx);
-      t->max_norm_key_len = std::max<int>(t->max_norm_key_len, static_cast<int>(kv.first.size()));
-    }
-    DatTrie d;
-    if (!BuildDat(keys, &d, &err)) return Status::Error(kInternal, "normalizer trie: " + err);
-    PackTrie2(d, payload, &t->ntrie);
-    flags |= kNfHasTrie;
-  } else {
-    t->ntrie.assign(256, U2{0, 0});
-    t->ninfo.assign(1, U2{0, 0});
-  }
-  {  // user-defined symbols alone, for PrefixMatch over normalized text (BPE)
+  {  // PrefixMatcher over USER_DEFINED pieces (src/normalizer.cc:311-346): raw text in the normalizer, normalized text in BPE
     if (!uds_keys.empty()) {
       DatTrie d;
       std::vector<std::pair<std::string, uint32_t>> keys;
@@ -357,8 +268,7 @@ Status CompileExtraOptions(const ModelData &m, const std::string &opts, HostTabl
 
 void BindHostPointers(HostTables *t) {
   SpmxDev &sc = t->scalars;
-  sc.ntrie = t->ntrie.data();
-  sc.ninfo = t->ninfo.data();
+  sc.ndarts = t->ndarts.data();
   sc.nblob = t->nblob.data();
   sc.ptrie = t->ptrie.data();
   sc.byte_ids = t->byte_ids.data();

@@ -12,8 +12,7 @@ namespace spmx {
 
 struct HostTables {
   // normalizer
-  std::vector<U2> ntrie;
-  std::vector<U2> ninfo;
+  std::vector<uint32_t> ndarts;
   std::vector<uint8_t> nblob;
   // unigram
   std::vector<U4> ptrie;
@@ -25,8 +24,6 @@ struct HostTables {
   std::vector<int32_t> byte_ids;
   // scalars (pointers are filled in by whoever owns the memory)
   SpmxDev scalars{};
-  int max_norm_key_len = 0;   // longest charsmap key / user-defined symbol, bytes
-  int max_expansion_num = 3, max_expansion_den = 1;  // worst normalized/raw byte ratio (>= 3 for ' ' -> U+2581)
   int max_piece_len = 0;
   int max_prefixes = 0;
 };
