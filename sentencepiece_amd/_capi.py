@@ -1,0 +1,59 @@
+"""ctypes binding of libspmx.so (include/spmx.h).  No compute lives here.
+
+The library is built in-tree by ``sentencepiece_amd/csrc/Makefile`` (hipcc,
+gfx950).  If it is missing this module raises: the product has no CPU path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspmx.so")
+
+# every symbol include/spmx.h declares: (name, restype, argtypes)
+_H = C.c_void_p
+_U64 = C.c_uint64
+SYMBOLS = [
+    ("spmx_create", C.c_int, [C.c_void_p, _U64, C.c_int, C.POINTER(_H)]),
+    ("spmx_create_from_file", C.c_int, [C.c_char_p, C.c_int, C.POINTER(_H)]),
+    ("spmx_destroy", None, [_H]),
+    ("spmx_last_error", C.c_char_p, [_H]),
+    ("spmx_set_encode_extra_options", C.c_int, [_H, C.c_char_p]),
+    ("spmx_set_vocabulary", C.c_int, [_H, C.POINTER(C.c_char_p), C.POINTER(_U64), _U64]),
+    ("spmx_reset_vocabulary", C.c_int, [_H]),
+    ("spmx_piece_size", C.c_int, [_H]),
+    ("spmx_piece_to_id", C.c_int, [_H, C.c_char_p, _U64]),
+    ("spmx_id_to_piece", C.c_int64, [_H, C.c_int, C.c_char_p, _U64]),
+    ("spmx_unk_id", C.c_int, [_H]),
+    ("spmx_bos_id", C.c_int, [_H]),
+    ("spmx_eos_id", C.c_int, [_H]),
+    ("spmx_pad_id", C.c_int, [_H]),
+    ("spmx_model_type", C.c_int, [_H]),
+    ("spmx_encode_batch_device", C.c_int,
+     [_H, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, C.c_void_p, C.POINTER(_U64)]),
+    ("spmx_encode_batch", C.c_int,
+     [_H, C.c_void_p, C.c_void_p, _U64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    ("spmx_free", None, [C.c_void_p]),
+    ("spmx_encode", C.c_int, [_H, C.c_char_p, _U64, C.c_void_p, _U64, C.POINTER(_U64)]),
+    ("spmx_set_profiling", C.c_int, [_H, C.c_int]),
+    ("spmx_last_profile", C.c_int,
+     [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+]
+
+_lib = None
+
+
+def lib():
+    """Loads libspmx.so once.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "%s is missing: build it with `make -C sentencepiece_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(l, name)   # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib

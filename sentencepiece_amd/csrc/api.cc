@@ -1,0 +1,506 @@
+// libspmx.so: the C ABI of include/spmx.h over the HIP kernels of kernels.hip.
+//
+// One handle = one loaded model on one GPU: the compiled tables live in HBM for
+// the life of the handle, a grow-only workspace (class lists, id arena, scan
+// scratch) is reused from call to call, and one encode call is a fixed
+// sequence of launches on the caller's stream with a single small read-back at
+// the end:
+//
+//   memset ctrl -> classify -> encode[class 0..k) -> scan x3 -> compact -> D2H {ctrl, total}
+//
+// There is no CPU path: without a usable HIP device spmx_create fails with
+// UNAVAILABLE.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/spmx.h"
+#include "launch.h"
+#include "model.h"
+#include "tables.h"
+
+using namespace spmx;
+
+namespace {
+
+std::mutex g_err_mu;
+std::string g_create_error;
+
+// ctrl block layout (device + pinned host mirror), zeroed before every call
+struct Ctrl {
+  uint32_t list_counts[kMaxClasses];
+  uint32_t status;
+  uint32_t pad;
+  unsigned long long arena_head;
+  unsigned long long stats[3 * kMaxClasses];
+  uint64_t total_ids;   // copied from id_offs[n] by the final D2H
+};
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t cap = 0;   // elements
+  hipError_t Reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+    const size_t want = n + n / 4 + 64;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), want * sizeof(T));
+    if (e != hipSuccess) return e;
+    cap = want;
+    return hipSuccess;
+  }
+  void Free() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct Profile {
+  int n = 0;
+  float kernel_ms[kMaxClasses] = {0};
+  uint64_t sentences[kMaxClasses] = {0}, raw_bytes[kMaxClasses] = {0}, ids[kMaxClasses] = {0};
+  uint32_t rcap[kMaxClasses] = {0};
+  float total_ms = 0.f;
+};
+
+}  // namespace
+
+struct spmx_handle {
+  std::mutex mu;
+  std::string error;
+  ModelData model;
+  HostTables tables;
+  std::string extra_options;
+  int device = 0;
+  int n_cu = 256;
+  // device copies of the tables
+  DevBuf<uint32_t> d_ndarts, d_sym_final;
+  DevBuf<uint8_t> d_nblob;
+  DevBuf<U4> d_ptrie, d_chartab, d_pairtab;
+  DevBuf<U2> d_utrie;
+  DevBuf<uint16_t> d_sym_len;
+  DevBuf<int32_t> d_byte_ids;
+  SpmxDev dev{};   // scalars + device pointers
+  // workspace
+  DevBuf<uint32_t> d_lists, d_counts;
+  DevBuf<uint64_t> d_tmp_off, d_tile_sums;
+  DevBuf<int32_t> d_arena;
+  Ctrl *d_ctrl = nullptr;
+  Ctrl *h_ctrl = nullptr;   // pinned
+  // host-form staging
+  DevBuf<uint8_t> d_text;
+  DevBuf<uint64_t> d_offs, d_id_offs;
+  DevBuf<int32_t> d_ids;
+  // profiling
+  bool profiling = false;
+  hipEvent_t ev[kMaxClasses + 1][2] = {};
+  bool ev_ready = false;
+  Profile prof;
+};
+
+namespace {
+
+int Fail(spmx_handle *h, int code, const std::string &msg) {
+  if (h) h->error = msg;
+  else { std::lock_guard<std::mutex> l(g_err_mu); g_create_error = msg; }
+  return code;
+}
+int FailHip(spmx_handle *h, hipError_t e, const char *what) {
+  return Fail(h, kInternal, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_OR_RETURN(h, expr)                                   \
+  do {                                                           \
+    hipError_t e_ = (expr);                                      \
+    if (e_ != hipSuccess) return FailHip((h), e_, #expr);        \
+  } while (0)
+
+template <typename T>
+hipError_t Upload(DevBuf<T> *b, const std::vector<T> &v) {
+  hipError_t e = b->Reserve(v.size() ? v.size() : 1);
+  if (e != hipSuccess) return e;
+  if (v.empty()) return hipSuccess;
+  return hipMemcpy(b->p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+// Uploads every table and binds h->dev to the device copies.
+int UploadTables(spmx_handle *h) {
+  HostTables &t = h->tables;
+  HIP_OR_RETURN(h, Upload(&h->d_ndarts, t.ndarts));
+  HIP_OR_RETURN(h, Upload(&h->d_nblob, t.nblob));
+  HIP_OR_RETURN(h, Upload(&h->d_ptrie, t.ptrie));
+  HIP_OR_RETURN(h, Upload(&h->d_utrie, t.utrie));
+  HIP_OR_RETURN(h, Upload(&h->d_chartab, t.chartab));
+  HIP_OR_RETURN(h, Upload(&h->d_pairtab, t.pairtab));
+  HIP_OR_RETURN(h, Upload(&h->d_sym_final, t.sym_final));
+  HIP_OR_RETURN(h, Upload(&h->d_sym_len, t.sym_len));
+  HIP_OR_RETURN(h, Upload(&h->d_byte_ids, t.byte_ids));
+  h->dev = t.scalars;
+  h->dev.ndarts = h->d_ndarts.p;
+  h->dev.nblob = h->d_nblob.p;
+  h->dev.ptrie = h->d_ptrie.p;
+  h->dev.utrie = h->d_utrie.p;
+  h->dev.chartab = h->d_chartab.p;
+  h->dev.pairtab = h->d_pairtab.p;
+  h->dev.sym_final = h->d_sym_final.p;
+  h->dev.sym_len = h->d_sym_len.p;
+  h->dev.byte_ids = h->d_byte_ids.p;
+  return kOk;
+}
+
+// After SetVocabulary / ResetVocabulary / SetEncodeExtraOptions: only the
+// type-dependent words and the scalars change.
+int RefreshDevice(spmx_handle *h, bool types_changed) {
+  HostTables &t = h->tables;
+  if (types_changed) {
+    if (h->model.model_type == kUnigram) HIP_OR_RETURN(h, Upload(&h->d_ptrie, t.ptrie));
+    else HIP_OR_RETURN(h, Upload(&h->d_sym_final, t.sym_final));
+  }
+  SpmxDev d = t.scalars;
+  d.ndarts = h->dev.ndarts; d.nblob = h->dev.nblob; d.ptrie = h->d_ptrie.p; d.utrie = h->dev.utrie;
+  d.chartab = h->dev.chartab; d.pairtab = h->dev.pairtab; d.sym_final = h->d_sym_final.p;
+  d.sym_len = h->dev.sym_len; d.byte_ids = h->dev.byte_ids;
+  h->dev = d;
+  return kOk;
+}
+
+void DestroyHandle(spmx_handle *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  h->d_ndarts.Free(); h->d_sym_final.Free(); h->d_nblob.Free(); h->d_ptrie.Free(); h->d_chartab.Free();
+  h->d_pairtab.Free(); h->d_utrie.Free(); h->d_sym_len.Free(); h->d_byte_ids.Free();
+  h->d_lists.Free(); h->d_counts.Free(); h->d_tmp_off.Free(); h->d_tile_sums.Free(); h->d_arena.Free();
+  h->d_text.Free(); h->d_offs.Free(); h->d_id_offs.Free(); h->d_ids.Free();
+  if (h->d_ctrl) (void)hipFree(h->d_ctrl);
+  if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);
+  if (h->ev_ready)
+    for (auto &pair : h->ev) { (void)hipEventDestroy(pair[0]); (void)hipEventDestroy(pair[1]); }
+  delete h;
+}
+
+int NumClasses(const spmx_handle *h) { return h->model.model_type == kBpe ? kNumClassesBpe : kNumClassesUnigram; }
+const LengthClass *Classes(const spmx_handle *h) { return h->model.model_type == kBpe ? kClassesBpe : kClassesUnigram; }
+
+// The launch sequence.  Caller holds h->mu and has set the device.
+int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, const uint64_t *d_offsets, uint64_t n,
+                 int32_t *d_ids, uint64_t ids_capacity, uint64_t *d_id_offsets, hipStream_t stream,
+                 uint64_t *total_ids) {
+  if (total_ids) *total_ids = 0;
+  if (n >= (1ull << 32) - 64) return Fail(h, kInvalidArgument, "more than 2^32 - 64 sentences in one batch");
+  if (!d_offsets || !d_id_offsets) return Fail(h, kInvalidArgument, "null offsets");
+  if (n == 0) {
+    HIP_OR_RETURN(h, hipMemsetAsync(d_id_offsets, 0, sizeof(uint64_t), stream));
+    HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+    return kOk;
+  }
+  const int ncls = NumClasses(h);
+  const LengthClass *cls = Classes(h);
+  HIP_OR_RETURN(h, h->d_lists.Reserve(static_cast<size_t>(ncls) * n));
+  HIP_OR_RETURN(h, h->d_counts.Reserve(n + 1));
+  HIP_OR_RETURN(h, h->d_tmp_off.Reserve(n + 1));
+  HIP_OR_RETURN(h, h->d_tile_sums.Reserve((n + kScanTile - 1) / kScanTile + 2));
+  uint64_t arena_need = text_bytes + (2 + static_cast<uint64_t>(h->dev.n_prefix + h->dev.n_suffix)) * n + 64;
+  if (h->profiling && !h->ev_ready) {
+    for (auto &pair : h->ev) {
+      HIP_OR_RETURN(h, hipEventCreate(&pair[0]));
+      HIP_OR_RETURN(h, hipEventCreate(&pair[1]));
+    }
+    h->ev_ready = true;
+  }
+  const bool prof = h->profiling;
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    HIP_OR_RETURN(h, h->d_arena.Reserve(arena_need));
+    if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[kMaxClasses][0], stream));
+    HIP_OR_RETURN(h, hipMemsetAsync(h->d_ctrl, 0, sizeof(Ctrl), stream));
+    const uint32_t n32 = static_cast<uint32_t>(n);
+    const int wide = h->n_cu * 8;
+    {
+      ClassifyArgs ca{};
+      ca.offs = d_offsets; ca.n = n32; ca.n_classes = static_cast<uint32_t>(ncls);
+      for (int c = 0; c < ncls; ++c) ca.rcap[c] = cls[c].rcap;
+      ca.lists = h->d_lists.p; ca.list_counts = h->d_ctrl->list_counts;
+      const uint32_t tiles = (n32 + 63) / 64;
+      HIP_OR_RETURN(h, LaunchClassify(ca, static_cast<int>(tiles < static_cast<uint32_t>(wide) ? tiles : wide), stream));
+    }
+    for (int c = 0; c < ncls; ++c) {
+      EncodeArgs a{};
+      a.dev = h->dev; a.text = d_text; a.offs = d_offsets;
+      a.list = h->d_lists.p + static_cast<size_t>(c) * n; a.list_count = &h->d_ctrl->list_counts[c];
+      a.next_list = c + 1 < ncls ? h->d_lists.p + static_cast<size_t>(c + 1) * n : nullptr;
+      a.next_count = c + 1 < ncls ? &h->d_ctrl->list_counts[c + 1] : nullptr;
+      a.arena = h->d_arena.p; a.arena_head = &h->d_ctrl->arena_head; a.arena_cap = h->d_arena.cap;
+      a.tmp_off = h->d_tmp_off.p; a.counts = h->d_counts.p; a.status = &h->d_ctrl->status;
+      a.stats = &h->d_ctrl->stats[3 * c];
+      a.rcap = cls[c].rcap; a.ncap = cls[c].ncap;
+      const uint32_t lds = EncodeLdsBytes(h->model.model_type, a.rcap, a.ncap);
+      int per_cu = static_cast<int>((160u * 1024u) / lds);
+      if (per_cu > 32) per_cu = 32;
+      if (per_cu < 1) per_cu = 1;
+      uint64_t grid = static_cast<uint64_t>(h->n_cu) * per_cu;
+      if (grid > n) grid = n;
+      if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[c][0], stream));
+      HIP_OR_RETURN(h, LaunchEncode(h->model.model_type, c, a, static_cast<int>(grid), lds, stream));
+      if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[c][1], stream));
+    }
+    {
+      ScanArgs sa{h->d_counts.p, n32, h->d_tile_sums.p, d_id_offsets};
+      const uint32_t tiles = (n32 + kScanTile - 1) / kScanTile;
+      HIP_OR_RETURN(h, LaunchScan(sa, static_cast<int>(tiles < static_cast<uint32_t>(wide) ? tiles : wide), stream));
+      CompactArgs pa{h->d_arena.p, h->d_tmp_off.p, h->d_counts.p, d_id_offsets, d_ids, d_ids ? ids_capacity : 0, n32};
+      const uint64_t cgrid = n < static_cast<uint64_t>(h->n_cu) * 32 ? n : static_cast<uint64_t>(h->n_cu) * 32;
+      HIP_OR_RETURN(h, LaunchCompact(pa, static_cast<int>(cgrid), stream));
+    }
+    if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[kMaxClasses][1], stream));
+    HIP_OR_RETURN(h, hipMemcpyAsync(h->h_ctrl, h->d_ctrl, offsetof(Ctrl, total_ids), hipMemcpyDeviceToHost, stream));
+    HIP_OR_RETURN(h, hipMemcpyAsync(&h->h_ctrl->total_ids, d_id_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+    const uint32_t st = h->h_ctrl->status;
+    if (st & kStArenaOverflow) {   // rare: byte fallback of multi-byte unknowns; arena_head holds what was asked for
+      arena_need = h->h_ctrl->arena_head + 64;
+      continue;
+    }
+    if (st & kStTooLong) return Fail(h, kOutOfRange, "a sentence is too long for the device path (normalized form exceeds the largest length class)");
+    if (st & kStRevMergeOverflow) return Fail(h, kResourceExhausted, "BPE: more than 64 distinct unused merged pieces in one sentence");
+    if (st & kStInternal) return Fail(h, kInternal, "all normalized characters are not consumed.");   // sentencepiece_processor.cc:628
+    if (prof) {
+      Profile &p = h->prof;
+      p = Profile();
+      p.n = ncls;
+      for (int c = 0; c < ncls; ++c) {
+        HIP_OR_RETURN(h, hipEventElapsedTime(&p.kernel_ms[c], h->ev[c][0], h->ev[c][1]));
+        p.sentences[c] = h->h_ctrl->stats[3 * c];
+        p.raw_bytes[c] = h->h_ctrl->stats[3 * c + 1];
+        p.ids[c] = h->h_ctrl->stats[3 * c + 2];
+        p.rcap[c] = cls[c].rcap;
+      }
+      HIP_OR_RETURN(h, hipEventElapsedTime(&p.total_ms, h->ev[kMaxClasses][0], h->ev[kMaxClasses][1]));
+    }
+    if (total_ids) *total_ids = h->h_ctrl->total_ids;
+    if (h->h_ctrl->total_ids > ids_capacity || !d_ids) {
+      if (h->h_ctrl->total_ids == 0) return kOk;
+      return Fail(h, kResourceExhausted, "ids_capacity is too small");
+    }
+    return kOk;
+  }
+  return Fail(h, kInternal, "id arena kept overflowing");
+}
+
+bool ReadFile(const char *path, std::string *out) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  std::ostringstream ss;
+  ss << f.rdbuf();
+  *out = ss.str();
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_handle **out) {
+  if (!out) return Fail(nullptr, kInvalidArgument, "null output handle");
+  *out = nullptr;
+  if (!model_bytes || n_bytes == 0) return Fail(nullptr, kInvalidArgument, "empty model");   // "model file is empty" analogue
+  int n_dev = 0;
+  hipError_t e = hipGetDeviceCount(&n_dev);
+  if (e != hipSuccess || n_dev <= 0)
+    return Fail(nullptr, kUnavailable, std::string("no HIP device is available (libspmx has no CPU path): ") +
+                                           (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+  if (device < 0 || device >= n_dev) return Fail(nullptr, kInvalidArgument, "device ordinal out of range");
+  spmx_handle *h = new spmx_handle;
+  h->device = device;
+  Status st = ParseModelProto(model_bytes, n_bytes, &h->model);
+  if (st.ok()) st = InitializeModel(&h->model);
+  if (st.ok()) st = CompileTables(h->model, &h->tables);
+  if (st.ok()) st = CompileExtraOptions(h->model, "", &h->tables);
+  if (!st.ok()) { const int c = Fail(nullptr, st.code, st.message); delete h; return c; }
+  auto bail = [&](hipError_t err, const char *what) {
+    const int c = FailHip(nullptr, err, what);
+    DestroyHandle(h);
+    return c;
+  };
+  if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
+  h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if ((e = hipMalloc(reinterpret_cast<void **>(&h->d_ctrl), sizeof(Ctrl))) != hipSuccess) return bail(e, "hipMalloc(ctrl)");
+  if ((e = hipHostMalloc(reinterpret_cast<void **>(&h->h_ctrl), sizeof(Ctrl), hipHostMallocDefault)) != hipSuccess)
+    return bail(e, "hipHostMalloc(ctrl)");
+  if (UploadTables(h) != kOk) {
+    const std::string msg = h->error;
+    DestroyHandle(h);
+    return Fail(nullptr, kInternal, msg);
+  }
+  *out = h;
+  return kOk;
+}
+
+int spmx_create_from_file(const char *filename, int device, spmx_handle **out) {
+  if (out) *out = nullptr;
+  std::string blob;
+  if (!filename || !ReadFile(filename, &blob))   // io::LoadModelProto (sentencepiece_processor.cc:1131-1149)
+    return Fail(nullptr, kNotFound, std::string("\"") + (filename ? filename : "") + "\": No such file or directory");
+  return spmx_create(blob.data(), blob.size(), device, out);
+}
+
+void spmx_destroy(spmx_handle *h) { DestroyHandle(h); }
+
+const char *spmx_last_error(const spmx_handle *h) {
+  if (h) return h->error.c_str();
+  static thread_local std::string copy;
+  std::lock_guard<std::mutex> l(g_err_mu);
+  copy = g_create_error;
+  return copy.c_str();
+}
+
+int spmx_set_encode_extra_options(spmx_handle *h, const char *options) {
+  if (!h) return kInvalidArgument;
+  std::lock_guard<std::mutex> l(h->mu);
+  Status st = CompileExtraOptions(h->model, options ? options : "", &h->tables);
+  if (!st.ok()) return Fail(h, st.code, st.message);
+  HIP_OR_RETURN(h, hipSetDevice(h->device));
+  return RefreshDevice(h, false);
+}
+
+int spmx_set_vocabulary(spmx_handle *h, const char *const *pieces, const uint64_t *piece_lens, uint64_t n) {
+  if (!h) return kInvalidArgument;
+  std::lock_guard<std::mutex> l(h->mu);
+  std::vector<std::string> v;
+  v.reserve(n);
+  for (uint64_t i = 0; i < n; ++i) v.emplace_back(pieces[i], piece_lens[i]);
+  Status st = SetVocabulary(&h->model, v);
+  if (!st.ok()) return Fail(h, st.code, st.message);
+  RefreshTypeFlags(h->model, &h->tables);
+  HIP_OR_RETURN(h, hipSetDevice(h->device));
+  return RefreshDevice(h, true);
+}
+
+int spmx_reset_vocabulary(spmx_handle *h) {
+  if (!h) return kInvalidArgument;
+  std::lock_guard<std::mutex> l(h->mu);
+  ResetVocabulary(&h->model);
+  RefreshTypeFlags(h->model, &h->tables);
+  HIP_OR_RETURN(h, hipSetDevice(h->device));
+  return RefreshDevice(h, true);
+}
+
+int spmx_piece_size(const spmx_handle *h) { return h ? static_cast<int>(h->model.pieces.size()) : 0; }
+int spmx_piece_to_id(const spmx_handle *h, const char *piece, uint64_t len) {
+  if (!h) return 0;
+  return h->model.PieceToId(std::string(piece ? piece : "", piece ? len : 0));
+}
+int64_t spmx_id_to_piece(const spmx_handle *h, int id, char *out, uint64_t cap) {
+  if (!h || id < 0 || id >= static_cast<int>(h->model.pieces.size())) return -1;
+  const std::string &p = h->model.pieces[id].piece;
+  if (out && cap) memcpy(out, p.data(), p.size() < cap ? p.size() : cap);
+  return static_cast<int64_t>(p.size());
+}
+int spmx_unk_id(const spmx_handle *h) { return h ? h->model.unk_id : -1; }
+// bos_id / eos_id / pad_id (src/sentencepiece_processor.cc:1002-1017): PieceToId, -1 if it resolves to unk
+static int ReservedId(const spmx_handle *h, const std::string &piece) {
+  if (!h) return -1;
+  const int id = h->model.PieceToId(std::string(piece.c_str()));
+  return h->model.pieces[id].type == kUnknown_ ? -1 : id;
+}
+int spmx_bos_id(const spmx_handle *h) { return h ? ReservedId(h, h->model.bos_piece) : -1; }
+int spmx_eos_id(const spmx_handle *h) { return h ? ReservedId(h, h->model.eos_piece) : -1; }
+int spmx_pad_id(const spmx_handle *h) { return h ? ReservedId(h, h->model.pad_piece) : -1; }
+int spmx_model_type(const spmx_handle *h) { return h ? h->model.model_type : 0; }
+
+int spmx_encode_batch_device(spmx_handle *h, const void *d_text, uint64_t text_bytes, const uint64_t *d_offsets,
+                             uint64_t n, int32_t *d_ids, uint64_t ids_capacity, uint64_t *d_id_offsets, void *stream,
+                             uint64_t *total_ids) {
+  if (!h) return kInvalidArgument;
+  std::lock_guard<std::mutex> l(h->mu);
+  HIP_OR_RETURN(h, hipSetDevice(h->device));
+  return EncodeDevice(h, static_cast<const uint8_t *>(d_text), text_bytes, d_offsets, n, d_ids, ids_capacity,
+                      d_id_offsets, static_cast<hipStream_t>(stream), total_ids);
+}
+
+int spmx_encode_batch(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
+                      uint64_t **id_offsets) {
+  if (!h) return kInvalidArgument;
+  std::lock_guard<std::mutex> l(h->mu);
+  if (!ids || !id_offsets) return Fail(h, kInternal, "output container is null");   // sentencepiece_processor.cc:367-370
+  *ids = nullptr; *id_offsets = nullptr;
+  if (n && !offsets) return Fail(h, kInvalidArgument, "null offsets");
+  HIP_OR_RETURN(h, hipSetDevice(h->device));
+  uint64_t *ho = static_cast<uint64_t *>(malloc((n + 1) * sizeof(uint64_t)));
+  if (!ho) return Fail(h, kResourceExhausted, "out of host memory");
+  if (n == 0) { ho[0] = 0; *id_offsets = ho; *ids = static_cast<int32_t *>(malloc(sizeof(int32_t))); return kOk; }
+  const uint64_t base = offsets[0], text_bytes = offsets[n] - base;
+  HIP_OR_RETURN(h, h->d_text.Reserve(text_bytes + 16));
+  HIP_OR_RETURN(h, h->d_offs.Reserve(n + 1));
+  HIP_OR_RETURN(h, h->d_id_offs.Reserve(n + 1));
+  if (text_bytes) HIP_OR_RETURN(h, hipMemcpyAsync(h->d_text.p, text + base, text_bytes, hipMemcpyHostToDevice, nullptr));
+  HIP_OR_RETURN(h, hipMemcpyAsync(h->d_offs.p, offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, nullptr));
+  // offsets are used as given: the kernels address text + offs[i], so rebase the text pointer instead
+  const uint8_t *d_text = h->d_text.p - base;
+  uint64_t cap = text_bytes / 2 + 4 * n + 64, total = 0;
+  int rc = kOk;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (hipError_t e = h->d_ids.Reserve(cap); e != hipSuccess) { free(ho); return FailHip(h, e, "hipMalloc(ids)"); }
+    rc = EncodeDevice(h, d_text, text_bytes, h->d_offs.p, n, h->d_ids.p, h->d_ids.cap, h->d_id_offs.p, nullptr, &total);
+    if (rc != kResourceExhausted || total <= h->d_ids.cap) break;
+    cap = total;
+  }
+  if (rc != kOk) { free(ho); return rc; }
+  int32_t *hi = static_cast<int32_t *>(malloc((total ? total : 1) * sizeof(int32_t)));
+  if (!hi) { free(ho); return Fail(h, kResourceExhausted, "out of host memory"); }
+  hipError_t e = hipMemcpy(ho, h->d_id_offs.p, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && total) e = hipMemcpy(hi, h->d_ids.p, total * sizeof(int32_t), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { free(ho); free(hi); return FailHip(h, e, "hipMemcpy(ids)"); }
+  *ids = hi;
+  *id_offsets = ho;
+  return kOk;
+}
+
+void spmx_free(void *p) { free(p); }
+
+int spmx_encode(spmx_handle *h, const char *text, uint64_t len, int32_t *ids, uint64_t cap, uint64_t *n_ids) {
+  if (!h) return kInvalidArgument;
+  if (!n_ids || (!ids && cap)) return Fail(h, kInternal, "output container is null");
+  const uint64_t offs[2] = {0, len};
+  int32_t *out = nullptr;
+  uint64_t *oo = nullptr;
+  const int rc = spmx_encode_batch(h, text ? text : "", offs, 1, &out, &oo);
+  if (rc != kOk) return rc;
+  const uint64_t total = oo[1];
+  *n_ids = total;
+  int ret = kOk;
+  if (total > cap) ret = Fail(h, kResourceExhausted, "ids buffer is too small");
+  else if (total) memcpy(ids, out, total * sizeof(int32_t));
+  free(out);
+  free(oo);
+  return ret;
+}
+
+int spmx_set_profiling(spmx_handle *h, int enabled) {
+  if (!h) return kInvalidArgument;
+  std::lock_guard<std::mutex> l(h->mu);
+  h->profiling = enabled != 0;
+  return kOk;
+}
+
+int spmx_last_profile(const spmx_handle *h, float *kernel_ms, uint64_t *sentences, uint64_t *raw_bytes, uint64_t *ids,
+                      uint64_t *bytes, uint32_t *rcap, float *total_ms) {
+  if (!h) return 0;
+  const Profile &p = h->prof;
+  for (int c = 0; c < p.n; ++c) {
+    if (kernel_ms) kernel_ms[c] = p.kernel_ms[c];
+    if (sentences) sentences[c] = p.sentences[c];
+    if (raw_bytes) raw_bytes[c] = p.raw_bytes[c];
+    if (ids) ids[c] = p.ids[c];
+    // L + 8 + 4 T' + 8 per sentence
+    if (bytes) bytes[c] = p.raw_bytes[c] + 16 * p.sentences[c] + 4 * p.ids[c];
+    if (rcap) rcap[c] = p.rcap[c];
+  }
+  if (total_ms) *total_ms = p.total_ms;
+  return p.n;
+}
+
+}  // extern "C"

@@ -1,0 +1,267 @@
+"""Host-side mirror of the reference's Python ``SentencePieceProcessor`` for the
+encode -> ids path, over the C ABI (``include/spmx.h``).
+
+Same names, argument meaning and error behaviour as the reference wrapper
+(python/src/sentencepiece/__init__.py:471-562 ``Encode``; sentencepiece.i:
+439-446 ``_EncodeAsIdsBatch``; :138-145 ``RewriteIds``), restricted to
+``out_type=int`` and deterministic encoding.  Everything that computes runs in
+libspmx.so on the GPU; this file only marshals buffers.
+
+Besides the list-of-str form the processor takes the packed form the engine
+works on -- one ``uint8`` text blob + ``uint64`` offsets (host numpy arrays or
+device torch tensors) -- and returns CSR ``(ids, id_offsets)``.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+_OK = 0
+_RESOURCE_EXHAUSTED = 8
+
+
+class SentencePieceProcessor:
+    def __init__(self, model_file=None, model_proto=None, out_type=int, add_bos=False, add_eos=False,
+                 reverse=False, emit_unk_piece=False, enable_sampling=False, nbest_size=-1, alpha=0.1,
+                 num_threads=-1, device=0):
+        self._lib = _capi.lib()
+        self._h = None
+        self._device = device
+        self._out_type = out_type
+        self._add_bos, self._add_eos, self._reverse = add_bos, add_eos, reverse
+        self._enable_sampling = enable_sampling
+        self._extra = ""          # SetEncodeExtraOptions string
+        self._applied = ""        # option string currently compiled into the handle
+        if model_file or model_proto:
+            self.Load(model_file=model_file, model_proto=model_proto)
+
+    # ------------------------------------------------------------- load ----
+    def Load(self, model_file=None, model_proto=None):
+        """Load / LoadFromSerializedProto (src/sentencepiece_processor.h:245, :261)."""
+        if model_proto is None:
+            if model_file is None:
+                raise RuntimeError("model_file or model_proto must be given")
+            try:
+                with open(model_file, "rb") as f:
+                    model_proto = f.read()
+            except OSError:
+                raise OSError('Not found: "%s": No such file or directory' % model_file)
+        self._close()
+        h = C.c_void_p()
+        rc = self._lib.spmx_create(model_proto, len(model_proto), self._device, C.byref(h))
+        if rc != _OK:
+            raise RuntimeError(self._lib.spmx_last_error(None).decode("utf-8", "replace"))
+        self._h = h
+        self._extra = self._applied = ""
+        return True
+
+    LoadFromSerializedProto = lambda self, proto: self.Load(model_proto=proto)  # noqa: E731
+    load = Load
+
+    def _close(self):
+        if self._h:
+            self._lib.spmx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self._close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != _OK:
+            raise RuntimeError(self._lib.spmx_last_error(self._h).decode("utf-8", "replace"))
+
+    def _need(self):
+        if not self._h:
+            raise RuntimeError("Model is not initialized.")   # sentencepiece_processor.cc:293-299
+
+    # ----------------------------------------------------- configuration ---
+    def SetEncodeExtraOptions(self, extra_option):
+        """bos:eos:reverse in any order (src/sentencepiece_processor.cc:283-291, :1067-1101)."""
+        self._need()
+        self._check(self._lib.spmx_set_encode_extra_options(self._h, extra_option.encode()))
+        self._extra = self._applied = extra_option
+        return True
+
+    def _apply(self, add_bos, add_eos, reverse):
+        # RewriteIds (sentencepiece.i:138-145) runs after the processor's own
+        # extra options: reverse, then bos in front, then eos at the back --
+        # the same net effect as appending "reverse:bos:eos" to the option list.
+        opts = [o for o in (self._extra,) if o]
+        if reverse:
+            opts.append("reverse")
+        if add_bos:
+            opts.append("bos")
+        if add_eos:
+            opts.append("eos")
+        want = ":".join(opts)
+        if want != self._applied:
+            self._check(self._lib.spmx_set_encode_extra_options(self._h, want.encode()))
+            self._applied = want
+
+    def SetVocabulary(self, valid_vocab):
+        self._need()
+        bs = [v.encode("utf-8") if isinstance(v, str) else bytes(v) for v in valid_vocab]
+        arr = (C.c_char_p * len(bs))(*bs)
+        lens = (C.c_uint64 * len(bs))(*[len(b) for b in bs])
+        self._check(self._lib.spmx_set_vocabulary(self._h, arr, lens, len(bs)))
+        return True
+
+    def ResetVocabulary(self):
+        self._need()
+        self._check(self._lib.spmx_reset_vocabulary(self._h))
+        return True
+
+    # ------------------------------------------------------- vocabulary ----
+    def GetPieceSize(self):
+        self._need()
+        return self._lib.spmx_piece_size(self._h)
+
+    piece_size = vocab_size = __len__ = GetPieceSize
+
+    def PieceToId(self, piece):
+        self._need()
+        b = piece.encode("utf-8") if isinstance(piece, str) else bytes(piece)
+        return self._lib.spmx_piece_to_id(self._h, b, len(b))
+
+    piece_to_id = PieceToId
+
+    def IdToPiece(self, id):
+        self._need()
+        n = self._lib.spmx_id_to_piece(self._h, id, None, 0)
+        if n < 0:
+            raise IndexError("piece id is out of range.")
+        buf = C.create_string_buffer(int(n) + 1)
+        self._lib.spmx_id_to_piece(self._h, id, buf, n)
+        return buf.raw[:n].decode("utf-8", "replace")
+
+    id_to_piece = IdToPiece
+
+    def unk_id(self):
+        self._need()
+        return self._lib.spmx_unk_id(self._h)
+
+    def bos_id(self):
+        self._need()
+        return self._lib.spmx_bos_id(self._h)
+
+    def eos_id(self):
+        self._need()
+        return self._lib.spmx_eos_id(self._h)
+
+    def pad_id(self):
+        self._need()
+        return self._lib.spmx_pad_id(self._h)
+
+    def model_type(self):
+        self._need()
+        return self._lib.spmx_model_type(self._h)
+
+    # ----------------------------------------------------------- encode ----
+    def Encode(self, input, out_type=None, add_bos=None, add_eos=None, reverse=None, emit_unk_piece=None,
+               enable_sampling=None, nbest_size=None, alpha=None, num_threads=None):
+        """str -> list[int]; list[str] -> list[list[int]] (``_EncodeAsIdsBatch``).
+
+        ``num_threads`` is accepted and ignored: the batch is one GPU launch
+        sequence, not a host thread pool."""
+        self._need()
+        out_type = self._out_type if out_type is None else out_type
+        if out_type is not int:
+            raise NotImplementedError("only out_type=int is on the device path")
+        if (self._enable_sampling if enable_sampling is None else enable_sampling):
+            raise NotImplementedError("sampling is not on the device path")
+        self._apply(self._add_bos if add_bos is None else add_bos,
+                    self._add_eos if add_eos is None else add_eos,
+                    self._reverse if reverse is None else reverse)
+        single = not isinstance(input, list)
+        items = [input] if single else input
+        bs = [s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in items]
+        offs = np.zeros(len(bs) + 1, dtype=np.uint64)
+        if bs:
+            np.cumsum([len(b) for b in bs], out=offs[1:])
+        text = np.frombuffer(b"".join(bs), dtype=np.uint8)
+        ids, io = self._encode_host(text, offs)
+        io = io.astype(np.int64)
+        out = [ids[io[i]:io[i + 1]].tolist() for i in range(len(bs))]
+        return out[0] if single else out
+
+    encode = Encode
+
+    def EncodeAsIds(self, input, **kw):
+        return self.Encode(input, out_type=int, **kw)
+
+    encode_as_ids = EncodeAsIds
+
+    def EncodePacked(self, text, offsets, add_bos=False, add_eos=False, reverse=False):
+        """Packed host arrays -> CSR host arrays ``(ids int32, id_offsets uint64)``."""
+        self._need()
+        self._apply(add_bos, add_eos, reverse)
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        return self._encode_host(text, offsets)
+
+    def _encode_host(self, text, offs):
+        n = len(offs) - 1
+        p_ids, p_off = C.c_void_p(), C.c_void_p()
+        tp = text.ctypes.data if len(text) else None
+        self._check(self._lib.spmx_encode_batch(self._h, tp, offs.ctypes.data, n, C.byref(p_ids), C.byref(p_off)))
+        try:
+            io = np.ctypeslib.as_array(C.cast(p_off, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+            total = int(io[n])
+            ids = (np.ctypeslib.as_array(C.cast(p_ids, C.POINTER(C.c_int32)), shape=(total,)).copy()
+                   if total else np.zeros(0, dtype=np.int32))
+        finally:
+            self._lib.spmx_free(p_ids)
+            self._lib.spmx_free(p_off)
+        return ids, io
+
+    def EncodeDevice(self, d_text, d_offsets, d_ids=None, d_id_offsets=None, stream=None,
+                     add_bos=False, add_eos=False, reverse=False):
+        """Device-resident form over torch tensors on this processor's GPU.
+
+        ``d_text`` uint8[bytes], ``d_offsets`` int64/uint64[n + 1].  ``d_ids``
+        (int32) and ``d_id_offsets`` (int64[n + 1]) are allocated when not
+        given; a too-small ``d_ids`` is re-allocated once.  Returns
+        ``(d_ids, d_id_offsets, total)``; ``d_ids[:total]`` is valid."""
+        import torch
+        self._need()
+        self._apply(add_bos, add_eos, reverse)
+        n = d_offsets.numel() - 1
+        if d_id_offsets is None:
+            d_id_offsets = torch.empty(n + 1, dtype=torch.int64, device=d_text.device)
+        if d_ids is None:
+            d_ids = torch.empty(d_text.numel() // 2 + 4 * n + 64, dtype=torch.int32, device=d_text.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(d_text.device).cuda_stream
+        total = C.c_uint64(0)
+        for _ in range(2):
+            rc = self._lib.spmx_encode_batch_device(
+                self._h, d_text.data_ptr(), d_text.numel(), d_offsets.data_ptr(), n, d_ids.data_ptr(),
+                d_ids.numel(), d_id_offsets.data_ptr(), stream, C.byref(total))
+            if rc == _RESOURCE_EXHAUSTED and total.value > d_ids.numel():
+                d_ids = torch.empty(total.value, dtype=torch.int32, device=d_text.device)
+                continue
+            break
+        self._check(rc)
+        return d_ids, d_id_offsets, total.value
+
+    # ------------------------------------------------------ measurement ----
+    def SetProfiling(self, enabled):
+        self._need()
+        self._lib.spmx_set_profiling(self._h, 1 if enabled else 0)
+
+    def LastProfile(self):
+        """Per length class: dict(kernel_ms, sentences, raw_bytes, ids, bytes, rcap) + total_ms."""
+        self._need()
+        ms = np.zeros(8, dtype=np.float32)
+        sent, raw, ids, byt = (np.zeros(8, dtype=np.uint64) for _ in range(4))
+        rcap = np.zeros(8, dtype=np.uint32)
+        tot = C.c_float(0)
+        k = self._lib.spmx_last_profile(self._h, ms.ctypes.data, sent.ctypes.data, raw.ctypes.data, ids.ctypes.data,
+                                        byt.ctypes.data, rcap.ctypes.data, C.byref(tot))
+        return dict(classes=[dict(kernel_ms=float(ms[c]), sentences=int(sent[c]), raw_bytes=int(raw[c]),
+                                  ids=int(ids[c]), bytes=int(byt[c]), rcap=int(rcap[c])) for c in range(k)],
+                    total_ms=float(tot.value))

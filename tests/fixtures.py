@@ -1,0 +1,39 @@
+"""Shared test inputs: the deterministic corpora the golden ids were made on
+(scripts/make_fixtures.py builds exactly these) and model blobs."""
+import os
+
+import numpy as np
+
+from scripts import make_fixtures as mf
+
+GOLDEN = mf.G
+
+
+def model_blob(name):
+    with open(os.path.join(GOLDEN, name + ".model"), "rb") as f:
+        return f.read()
+
+
+class Corpora:
+    """Lazy name -> (text uint8, offsets uint64)."""
+
+    def __init__(self):
+        self._c = {}
+
+    def __getitem__(self, name):
+        if name not in self._c:
+            if not self._c.get("_all"):
+                self._c.update(mf.corpora())
+                self._c["_all"] = True
+        return self._c[name]
+
+
+def sha(ids):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(ids).astype("<i4").tobytes()).hexdigest()
+
+
+def head(text, offs, n):
+    """First n sentences of a packed buffer."""
+    n = min(n, len(offs) - 1)
+    return text[:int(offs[n])], offs[:n + 1]

@@ -1,0 +1,80 @@
+"""The oracle (plain-C restatement, oracle/spm_oracle.c) pinned against
+ (a) the golden ids the compiled reference produced (tests/golden/), on every
+     model x corpus pair of the manifest, and
+ (b) the compiled reference itself where oracle/_ref/libspm_ref.so exists
+     (this container), including normalizer output."""
+import numpy as np
+import pytest
+
+from tests import fixtures, refshim
+
+
+def _keys():
+    import json
+    import os
+    with open(os.path.join(fixtures.GOLDEN, "manifest.json")) as f:
+        return sorted(json.load(f))
+
+
+@pytest.mark.parametrize("key", _keys())
+def test_oracle_matches_golden(key, manifest, golden_arrays, corpora, oracle):
+    m = manifest[key]
+    o = oracle.load(fixtures.model_blob(m["model"]))
+    if m["options"]:
+        o.set_encode_extra_options(m["options"])
+    text, offs = corpora[m["corpus"]]
+    ids, io = o.encode_batch(text, offs)
+    assert len(ids) == m["tokens"]
+    np.testing.assert_array_equal(np.diff(io.astype(np.int64)), golden_arrays[key + "__cnt"].astype(np.int64))
+    if key + "__ids" in golden_arrays:
+        np.testing.assert_array_equal(ids, golden_arrays[key + "__ids"])
+    assert fixtures.sha(ids) == m["sha256"]
+
+
+def test_botchan_survey_kat(corpora, oracle):
+    """95,515 tokens on botchan with the bundled 1k model, and
+    the four double/float tie lines come out in the reference's order."""
+    o = oracle.load(fixtures.model_blob("test_model"))
+    text, offs = corpora["botchan"]
+    ids, io = o.encode_batch(text, offs)
+    assert len(ids) == 95515
+    lines = fixtures.mf.synth.unpack(text, offs)
+    for ln in (1754, 1973, 2567, 2998):
+        assert b"......." in lines[ln] or b"......" in lines[ln]
+
+
+@pytest.mark.skipif(not refshim.available(), reason="compiled reference not built (needs /root/reference)")
+@pytest.mark.parametrize("model", ["test_model", "test_ja_model", "uni1k_uds", "uni1k_ident", "uni1k_suffix",
+                                   "bpe1k_noesc", "bpe1k_bf_uds"])
+def test_oracle_normalizer_matches_reference(model, corpora, oracle):
+    ref = refshim.RefLib().load(fixtures.model_blob(model))
+    o = oracle.load(fixtures.model_blob(model))
+    sents = fixtures.mf.edge_sentences() + fixtures.mf.synth.unpack(*fixtures.head(*corpora["mixed2k"], 100))
+    for s in sents:
+        if b"\x00" in s:
+            continue   # the shim passes C strings through ctypes.c_char_p
+        assert o.normalize(s) == ref.normalize(s), s
+
+
+@pytest.mark.skipif(not refshim.available(), reason="compiled reference not built (needs /root/reference)")
+def test_oracle_set_vocabulary_matches_reference(corpora, oracle):
+    """SetVocabulary / ResetVocabulary (sentencepiece_processor_test.cc:1357-1372 analogue)."""
+    for model in ("uni1k", "bpe1k"):
+        blob = fixtures.model_blob(model)
+        ref = refshim.RefLib().load(blob)
+        o = oracle.load(blob)
+        text, offs = fixtures.head(*corpora["botchan"], 400)
+        import sentencepiece as spm   # only to list the piece strings
+        sp = spm.SentencePieceProcessor(model_proto=blob)
+        vocab = [sp.id_to_piece(i) for i in range(0, sp.get_piece_size(), 3)]
+        ref.set_vocabulary(vocab)
+        o.set_vocabulary(vocab)
+        a, ao = ref.encode_batch(text, offs)
+        b, bo = o.encode_batch(text, offs)
+        np.testing.assert_array_equal(ao, bo)
+        np.testing.assert_array_equal(a, b)
+        ref.reset_vocabulary()
+        o.reset_vocabulary()
+        a, _ = ref.encode_batch(text, offs)
+        b, _ = o.encode_batch(text, offs)
+        np.testing.assert_array_equal(a, b)
