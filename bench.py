@@ -183,7 +183,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
                          "kernel_ms": k_ms[dom], "algorithmic_bytes_per_launch": cls["bytes"],
                          "sentences_per_launch": cls["sentences"],
-                         "all_classes_ms": k_ms, "pipeline_ms": sum(p["total_ms"] for p in prof) / len(prof)},
+                         "all_classes_ms": k_ms, "phase_cycles": cls.get("phase_cycles"), "pipeline_ms": sum(p["total_ms"] for p in prof) / len(prof)},
         }
         if world == 1 and not args.no_cpu_baseline:
             counts = np.diff(d_io.cpu().numpy())

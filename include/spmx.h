@@ -102,6 +102,11 @@ int spmx_set_profiling(spmx_handle *h, int enabled);
 int spmx_last_profile(const spmx_handle *h, float *kernel_ms, uint64_t *sentences, uint64_t *raw_bytes,
                       uint64_t *ids, uint64_t *bytes, uint32_t *rcap, float *total_ms);
 
+/* Shader-clock cycles the waves of the LAST profiled call spent per phase, summed
+ * over waves: cycles[5 * class + {0 load, 1 normalize, 2 segment, 3 emit}]; entry 4 is the
+ * number of search-loop iterations the waves of the tile form executed. */
+int spmx_last_phase_cycles(const spmx_handle *h, uint64_t *cycles);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <mutex>
@@ -38,7 +39,7 @@ struct Ctrl {
   uint32_t status;
   uint32_t pad;
   unsigned long long arena_head;
-  unsigned long long stats[3 * kMaxClasses];
+  unsigned long long stats[kStatsPerClass * kMaxClasses];
   uint64_t total_ids;   // copied from id_offs[n] by the final D2H
 };
 
@@ -63,6 +64,7 @@ struct Profile {
   float kernel_ms[kMaxClasses] = {0};
   uint64_t sentences[kMaxClasses] = {0}, raw_bytes[kMaxClasses] = {0}, ids[kMaxClasses] = {0};
   uint32_t rcap[kMaxClasses] = {0};
+  uint64_t cycles[kMaxClasses][5] = {{0}};
   float total_ms = 0.f;
 };
 
@@ -76,6 +78,7 @@ struct spmx_handle {
   std::string extra_options;
   int device = 0;
   int n_cu = 256;
+  bool no_tile = false;   // SPMX_NO_TILE=1: sentence-per-wave form for every class (A/B measurements)
   // device copies of the tables
   DevBuf<uint32_t> d_ndarts, d_sym_final;
   DevBuf<uint8_t> d_nblob;
@@ -233,16 +236,21 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
       a.next_count = c + 1 < ncls ? &h->d_ctrl->list_counts[c + 1] : nullptr;
       a.arena = h->d_arena.p; a.arena_head = &h->d_ctrl->arena_head; a.arena_cap = h->d_arena.cap;
       a.tmp_off = h->d_tmp_off.p; a.counts = h->d_counts.p; a.status = &h->d_ctrl->status;
-      a.stats = &h->d_ctrl->stats[3 * c];
+      a.stats = &h->d_ctrl->stats[kStatsPerClass * c];
       a.rcap = cls[c].rcap; a.ncap = cls[c].ncap;
-      const uint32_t lds = EncodeLdsBytes(h->model.model_type, a.rcap, a.ncap);
+      const bool tile = h->model.model_type == kUnigram && c < kNumTileClasses && !h->no_tile;
+      if (tile) { a.ring = TileRing(h->tables.max_piece_len); a.tile_area = kTileClasses[c].area; }
+      const uint32_t lds = tile ? TileLdsBytes(a.rcap, a.ring, a.tile_area)
+                                : EncodeLdsBytes(h->model.model_type, a.rcap, a.ncap);
       int per_cu = static_cast<int>((160u * 1024u) / lds);
       if (per_cu > 32) per_cu = 32;
       if (per_cu < 1) per_cu = 1;
       uint64_t grid = static_cast<uint64_t>(h->n_cu) * per_cu;
-      if (grid > n) grid = n;
+      const uint64_t items = tile ? (n + 63) / 64 : n;
+      if (grid > items) grid = items;
       if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[c][0], stream));
-      HIP_OR_RETURN(h, LaunchEncode(h->model.model_type, c, a, static_cast<int>(grid), lds, stream));
+      if (tile) HIP_OR_RETURN(h, LaunchEncodeTile(c, a, static_cast<int>(grid), lds, stream));
+      else HIP_OR_RETURN(h, LaunchEncode(h->model.model_type, c, a, static_cast<int>(grid), lds, stream));
       if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[c][1], stream));
     }
     {
@@ -271,9 +279,11 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
       p.n = ncls;
       for (int c = 0; c < ncls; ++c) {
         HIP_OR_RETURN(h, hipEventElapsedTime(&p.kernel_ms[c], h->ev[c][0], h->ev[c][1]));
-        p.sentences[c] = h->h_ctrl->stats[3 * c];
-        p.raw_bytes[c] = h->h_ctrl->stats[3 * c + 1];
-        p.ids[c] = h->h_ctrl->stats[3 * c + 2];
+        const unsigned long long *s = &h->h_ctrl->stats[kStatsPerClass * c];
+        p.sentences[c] = s[0];
+        p.raw_bytes[c] = s[1];
+        p.ids[c] = s[2];
+        for (int k = 0; k < 5; ++k) p.cycles[c][k] = s[3 + k];
         p.rcap[c] = cls[c].rcap;
       }
       HIP_OR_RETURN(h, hipEventElapsedTime(&p.total_ms, h->ev[kMaxClasses][0], h->ev[kMaxClasses][1]));
@@ -327,6 +337,7 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
   hipDeviceProp_t prop;
   if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
   h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (const char *e = getenv("SPMX_NO_TILE")) h->no_tile = e[0] == '1';
   if ((e = hipMalloc(reinterpret_cast<void **>(&h->d_ctrl), sizeof(Ctrl))) != hipSuccess) return bail(e, "hipMalloc(ctrl)");
   if ((e = hipHostMalloc(reinterpret_cast<void **>(&h->h_ctrl), sizeof(Ctrl), hipHostMallocDefault)) != hipSuccess)
     return bail(e, "hipHostMalloc(ctrl)");
@@ -484,6 +495,13 @@ int spmx_set_profiling(spmx_handle *h, int enabled) {
   std::lock_guard<std::mutex> l(h->mu);
   h->profiling = enabled != 0;
   return kOk;
+}
+
+int spmx_last_phase_cycles(const spmx_handle *h, uint64_t *cycles) {
+  if (!h) return 0;
+  for (int c = 0; c < h->prof.n; ++c)
+    for (int k = 0; k < 5; ++k) cycles[5 * c + k] = h->prof.cycles[c][k];
+  return h->prof.n;
 }
 
 int spmx_last_profile(const spmx_handle *h, float *kernel_ms, uint64_t *sentences, uint64_t *raw_bytes, uint64_t *ids,

@@ -42,10 +42,12 @@ struct EncodeArgs {
   uint64_t *tmp_off;            // per sentence: where its ids sit in the arena
   uint32_t *counts;             // per sentence: number of ids
   uint32_t *status;
-  unsigned long long *stats;    // {sentences, raw bytes, ids} finished by this class (profiling)
+  unsigned long long *stats;    // kStatsPerClass words: {sentences, raw bytes, ids, cycles load, normalize, segment, emit}
   uint32_t rcap, ncap;          // LDS capacities of this class: raw bytes, normalized bytes
+  uint32_t ring, tile_area;     // tile form (kernels_tile.h): score ring entries (power of two), bytes of the text area
 };
 
+constexpr int kStatsPerClass = 8;
 constexpr uint32_t kTokEnd = 0x8000u;  // blen[] flag: a token of the best path ends here
 
 // Darts::DoubleArrayUnit::offset() (third_party/darts_clone/darts.h:72-74)
@@ -532,7 +534,9 @@ namespace spmx {
 // Encodes sentence `sid` with this wave. MODEL: 1 unigram, 2 BPE.
 // Returns the number of ids written, or -1 if the sentence was handed on / failed.
 template <int MODEL>
-SPMX_DEVICE int encode_sentence(const EncodeArgs &a, uint32_t sid, const WaveLds &w, int lane, int *raw_len) {
+SPMX_DEVICE int encode_sentence(const EncodeArgs &a, uint32_t sid, const WaveLds &w, int lane, int *raw_len,
+                                unsigned long long *cyc) {
+  const unsigned long long c0 = wv::clock();
   const uint64_t beg = a.offs[sid];
   const uint64_t L64 = a.offs[sid + 1] - beg;
   if (L64 > a.rcap) {   // only reachable for the last class
@@ -544,8 +548,10 @@ SPMX_DEVICE int encode_sentence(const EncodeArgs &a, uint32_t sid, const WaveLds
   const uint8_t *src = a.text + beg;
   for (int p = lane; p < L; p += 64) w.raw[p] = src[p];
   wv::sync();
+  const unsigned long long c1 = wv::clock();
   int nlen = 0;
   if (L > 0) nlen = normalize_wave(a.dev, w.raw, L, w.norm, static_cast<int>(a.ncap), lane);
+  const unsigned long long c2 = wv::clock();
   if (nlen < 0) {
     if (a.next_list) {
       if (lane == 0) a.next_list[wv::atomic_add(a.next_count, 1u)] = sid;
@@ -569,7 +575,11 @@ SPMX_DEVICE int encode_sentence(const EncodeArgs &a, uint32_t sid, const WaveLds
     fail_sentence(a, sid, kStInternal, lane);
     return -1;
   }
-  return emit_wave(a, sid, w.norm, nlen, w.bid, w.blen, lane);
+  const unsigned long long c3 = wv::clock();
+  const int n_out = emit_wave(a, sid, w.norm, nlen, w.bid, w.blen, lane);
+  const unsigned long long c4 = wv::clock();
+  cyc[0] += c1 - c0; cyc[1] += c2 - c1; cyc[2] += c3 - c2; cyc[3] += c4 - c3;
+  return n_out;
 }
 
 // Persistent block body: 64-thread workgroups, grid-stride over the class list.
@@ -579,15 +589,17 @@ SPMX_DEVICE void encode_block(const EncodeArgs &a, unsigned char *smem) {
   const WaveLds w = carve_lds(smem, a.rcap, a.ncap);
   const uint32_t count = *a.list_count;
   unsigned long long n_sent = 0, n_raw = 0, n_ids = 0;
+  unsigned long long cyc[4] = {0, 0, 0, 0};
   for (uint32_t item = static_cast<uint32_t>(wv::block_id()); item < count; item += static_cast<uint32_t>(wv::grid_size())) {
     int raw_len = 0;
-    const int n_out = encode_sentence<MODEL>(a, a.list[item], w, lane, &raw_len);
+    const int n_out = encode_sentence<MODEL>(a, a.list[item], w, lane, &raw_len, cyc);
     if (n_out >= 0) { ++n_sent; n_raw += static_cast<unsigned long long>(raw_len); n_ids += static_cast<unsigned long long>(n_out); }
   }
   if (a.stats && lane == 0 && n_sent) {
     wv::atomic_add(&a.stats[0], n_sent);
     wv::atomic_add(&a.stats[1], n_raw);
     wv::atomic_add(&a.stats[2], n_ids);
+    for (int k = 0; k < 4; ++k) wv::atomic_add(&a.stats[3 + k], cyc[k]);
   }
 }
 
@@ -730,4 +742,7 @@ SPMX_DEVICE void compact_block(const CompactArgs &a) {
 }
 
 }  // namespace spmx
+
+#include "kernels_tile.h"
+
 #endif

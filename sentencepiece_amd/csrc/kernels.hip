@@ -14,6 +14,12 @@ __global__ __launch_bounds__(64) void EncodeKernel(EncodeArgs a) {
   encode_block<MODEL>(a, smem);
 }
 
+template <int CLS>
+__global__ __launch_bounds__(64) void EncodeTileKernel(EncodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  encode_tile_block(a, smem);
+}
+
 __global__ __launch_bounds__(64) void ClassifyKernel(ClassifyArgs a) { classify_block(a); }
 __global__ __launch_bounds__(64) void ScanTilesKernel(ScanArgs a) { scan_tiles_block(a); }
 __global__ __launch_bounds__(64) void ScanSumsKernel(ScanArgs a) { scan_sums_block(a); }
@@ -37,6 +43,17 @@ EncodeFn PickEncode(int cls) {
 
 hipError_t LaunchEncode(int model_type, int cls, const EncodeArgs &a, int grid, uint32_t lds_bytes, hipStream_t stream) {
   EncodeFn fn = model_type == 2 ? PickEncode<2>(cls) : PickEncode<1>(cls);
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds_bytes));
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds_bytes, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t LaunchEncodeTile(int cls, const EncodeArgs &a, int grid, uint32_t lds_bytes, hipStream_t stream) {
+  EncodeFn fn = cls == 0 ? EncodeTileKernel<0> : EncodeTileKernel<1>;
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds_bytes));

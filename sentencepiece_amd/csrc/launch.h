@@ -17,6 +17,21 @@ constexpr LengthClass kClassesUnigram[kNumClassesUnigram] = {
     {192, 448}, {576, 1280}, {1536, 3328}, {4096, 8704}, {8192, 20480}};
 constexpr LengthClass kClassesBpe[kNumClassesBpe] = {{192, 448}, {576, 1280}, {1536, 3328}, {4096, 6400}};
 
+// Unigram classes that run in the tile form (kernels_tile.h): a wave takes 64
+// sentences, one per lane.  area = LDS bytes for the round's text + back-pointer
+// bytes (>= 2 * ncap + 1); the per-wave classes above remain for longer sentences
+// and for BPE.
+struct TileClass { uint32_t area; };
+constexpr int kNumTileClasses = 2;
+constexpr TileClass kTileClasses[kNumTileClasses] = {{24 * 1024}, {40 * 1024}};
+// score ring entries for a model whose longest piece has max_piece_len bytes
+inline uint32_t TileRing(int max_piece_len) {
+  uint32_t r = 16;
+  while (r < static_cast<uint32_t>(max_piece_len) + 1) r <<= 1;
+  return r;
+}
+
+hipError_t LaunchEncodeTile(int cls, const EncodeArgs &a, int grid, uint32_t lds_bytes, hipStream_t stream);
 hipError_t LaunchEncode(int model_type, int cls, const EncodeArgs &a, int grid, uint32_t lds_bytes, hipStream_t stream);
 hipError_t LaunchClassify(const ClassifyArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchScan(const ScanArgs &a, int grid, hipStream_t stream);

@@ -44,6 +44,8 @@ SPMX_DEVICE uint32_t atomic_add(uint32_t *p, uint32_t v) { return atomicAdd(p, v
 SPMX_DEVICE unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
 SPMX_DEVICE void atomic_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }
 
+SPMX_DEVICE unsigned long long clock() { return __builtin_amdgcn_s_memtime(); }   // shader cycles
+
 SPMX_DEVICE int popc64(uint64_t x) { return __popcll(x); }
 SPMX_DEVICE int ffs64(uint64_t x) { return __ffsll(static_cast<unsigned long long>(x)); }   // 1-based, 0 if none
 SPMX_DEVICE int clz64(uint64_t x) { return __clzll(static_cast<long long>(x)); }

@@ -262,6 +262,11 @@ class SentencePieceProcessor:
         tot = C.c_float(0)
         k = self._lib.spmx_last_profile(self._h, ms.ctypes.data, sent.ctypes.data, raw.ctypes.data, ids.ctypes.data,
                                         byt.ctypes.data, rcap.ctypes.data, C.byref(tot))
+        cyc = np.zeros(40, dtype=np.uint64)
+        self._lib.spmx_last_phase_cycles(self._h, cyc.ctypes.data)
         return dict(classes=[dict(kernel_ms=float(ms[c]), sentences=int(sent[c]), raw_bytes=int(raw[c]),
-                                  ids=int(ids[c]), bytes=int(byt[c]), rcap=int(rcap[c])) for c in range(k)],
+                                  ids=int(ids[c]), bytes=int(byt[c]), rcap=int(rcap[c]),
+                                  phase_cycles=dict(zip(("load", "normalize", "segment", "emit", "search_trips"),
+                                                        (int(x) for x in cyc[5 * c:5 * c + 5]))))
+                             for c in range(k)],
                     total_ms=float(tot.value))

@@ -206,7 +206,7 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
   std::vector<int32_t> arena(text_bytes + (2 + dev.n_prefix + dev.n_suffix) * n + 64);
   unsigned long long arena_head = 0;
   uint32_t status = 0;
-  unsigned long long stats[3 * kMaxClasses] = {0};
+  unsigned long long stats[kStatsPerClass * kMaxClasses] = {0};
   for (int c = 0; c < ncls; ++c) {
     EncodeArgs a{};
     a.dev = dev; a.text = text; a.offs = offs;
@@ -214,8 +214,19 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
     a.next_list = c + 1 < ncls ? lists.data() + static_cast<size_t>(c + 1) * n : nullptr;
     a.next_count = c + 1 < ncls ? &list_counts[c + 1] : nullptr;
     a.arena = arena.data(); a.arena_head = &arena_head; a.arena_cap = arena.size();
-    a.tmp_off = tmp_off.data(); a.counts = counts.data(); a.status = &status; a.stats = &stats[3 * c];
+    a.tmp_off = tmp_off.data(); a.counts = counts.data(); a.status = &status; a.stats = &stats[kStatsPerClass * c];
     a.rcap = cls[c].rcap; a.ncap = cls[c].ncap;
+    // tile form for the first unigram classes, as in csrc/api.cc (small areas here to exercise the rounds)
+    const bool tile = !bpe && c < 3 && !getenv("SPMX_NO_TILE");
+    if (tile) {
+      a.ring = 16;
+      while (a.ring < static_cast<uint32_t>(h->tables.max_piece_len) + 1) a.ring <<= 1;
+      a.tile_area = c == 0 ? 512 : (c == 1 ? 4096 : 6144);
+      if (a.tile_area < 2 * a.ncap + 1) a.tile_area = 2 * a.ncap + 1;
+      std::vector<unsigned char> tsmem(TileLdsBytes(a.rcap, a.ring, a.tile_area) + 64, 0xCD);
+      for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, tsmem.data(), [&] { encode_tile_block(a, tsmem.data()); });
+      continue;
+    }
     std::vector<unsigned char> smem(EncodeLdsBytes(dev.model_type, a.rcap, a.ncap) + 64, 0xCD);
     for (int b = 0; b < grid; ++b) {
       if (bpe) emu::RunWave(b, grid, smem.data(), [&] { encode_block<2>(a, smem.data()); });

@@ -89,6 +89,8 @@ inline uint32_t atomic_add(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p 
 inline unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { const unsigned long long o = *p; *p = o + v; return o; }
 inline void atomic_or(uint32_t *p, uint32_t v) { *p |= v; }
 
+inline unsigned long long clock() { return 0; }
+
 inline int popc64(uint64_t x) { return __builtin_popcountll(x); }
 inline int ffs64(uint64_t x) { return __builtin_ffsll(static_cast<long long>(x)); }
 inline int clz64(uint64_t x) { return x ? __builtin_clzll(x) : 64; }
