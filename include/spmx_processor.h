@@ -1,0 +1,198 @@
+// C++ host facade over the C ABI (spmx.h): the reference's
+// sentencepiece::SentencePieceProcessor, restricted to the text -> ids path,
+// with the same method names, argument meaning and error convention
+// (util::Status values, no exceptions; reference: src/sentencepiece_processor.h
+// :34-76 Status, :245 Load, :261 LoadFromSerializedProto, :264 status,
+// :267 SetEncodeExtraOptions, :279-283 SetVocabulary / ResetVocabulary,
+// :299-300 Encode(input, vector<int>*), :458-460 EncodeAsIds, :638-677
+// vocabulary accessors), plus the batch form the reference only has in its
+// Python wrapper (python/src/sentencepiece/sentencepiece.i:439-446
+// _EncodeAsIdsBatch): EncodeBatch == element-wise Encode.
+//
+// Header-only; link with libspmx.so.  An application written against the
+// reference switches by including this header and
+//   namespace sentencepiece = sentencepiece_amd;
+#ifndef SPMX_PROCESSOR_H_
+#define SPMX_PROCESSOR_H_
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <string_view>
+#include <utility>
+#include <vector>
+
+#include "spmx.h"
+
+namespace sentencepiece_amd {
+namespace util {
+
+enum class StatusCode : int {   // src/sentencepiece_processor.h:34-52
+  kOk = 0, kCancelled = 1, kUnknown = 2, kInvalidArgument = 3, kDeadlineExceeded = 4, kNotFound = 5,
+  kAlreadyExists = 6, kPermissionDenied = 7, kResourceExhausted = 8, kFailedPrecondition = 9, kAborted = 10,
+  kOutOfRange = 11, kUnimplemented = 12, kInternal = 13, kUnavailable = 14, kDataLoss = 15, kUnauthenticated = 16,
+};
+
+class Status {
+ public:
+  Status() = default;
+  Status(StatusCode code, std::string_view msg) : code_(code), msg_(msg) {}
+  bool ok() const { return code_ == StatusCode::kOk; }
+  StatusCode code() const { return code_; }
+  const char *error_message() const { return msg_.c_str(); }
+  std::string ToString() const {   // src/error.cc:62-
+    if (ok()) return "OK";
+    static const char *const kNames[] = {"OK", "Cancelled", "Unknown", "Invalid argument", "Deadline exceeded",
+                                         "Not found", "Already exists", "Permission denied", "Resource exhausted",
+                                         "Failed precondition", "Aborted", "Out of range", "Unimplemented",
+                                         "Internal", "Unavailable", "Data loss", "Unauthenticated"};
+    const int c = static_cast<int>(code_);
+    return std::string(c >= 0 && c <= 16 ? kNames[c] : "Unknown") + ": " + msg_;
+  }
+
+ private:
+  StatusCode code_ = StatusCode::kOk;
+  std::string msg_;
+};
+
+}  // namespace util
+
+class SentencePieceProcessor {
+ public:
+  explicit SentencePieceProcessor(int device = 0) : device_(device) {}
+  ~SentencePieceProcessor() { spmx_destroy(h_); }
+  SentencePieceProcessor(const SentencePieceProcessor &) = delete;
+  SentencePieceProcessor &operator=(const SentencePieceProcessor &) = delete;
+
+  util::Status Load(std::string_view filename) {
+    Reset();
+    const std::string f(filename);
+    return Created(spmx_create_from_file(f.c_str(), device_, &h_));
+  }
+  util::Status LoadFromSerializedProto(std::string_view serialized) {
+    Reset();
+    return Created(spmx_create(serialized.data(), serialized.size(), device_, &h_));
+  }
+  void LoadOrDie(std::string_view filename) {
+    if (!Load(filename).ok()) std::abort();
+  }
+  util::Status status() const {
+    return h_ ? util::Status() : util::Status(util::StatusCode::kInternal, "Model is not initialized.");
+  }
+
+  util::Status SetEncodeExtraOptions(std::string_view extra_option) {
+    if (!h_) return status();
+    const std::string o(extra_option);
+    return FromHandle(spmx_set_encode_extra_options(h_, o.c_str()));
+  }
+  util::Status SetVocabulary(const std::vector<std::string_view> &valid_vocab) {
+    if (!h_) return status();
+    std::vector<const char *> p;
+    std::vector<uint64_t> l;
+    for (auto v : valid_vocab) { p.push_back(v.data()); l.push_back(v.size()); }
+    return FromHandle(spmx_set_vocabulary(h_, p.data(), l.data(), p.size()));
+  }
+  util::Status ResetVocabulary() { return h_ ? FromHandle(spmx_reset_vocabulary(h_)) : status(); }
+
+  // ---- encode ----
+  util::Status Encode(std::string_view input, std::vector<int> *ids) const {
+    if (!h_) return status();
+    if (!ids) return util::Status(util::StatusCode::kInternal, "output container is null");
+    ids->clear();
+    int32_t *out = nullptr;
+    uint64_t *offs = nullptr;
+    const uint64_t io[2] = {0, input.size()};
+    const int rc = spmx_encode_batch(h_, input.data(), io, 1, &out, &offs);
+    if (rc != 0) return FromHandle(rc);
+    ids->assign(out, out + offs[1]);
+    spmx_free(out);
+    spmx_free(offs);
+    return util::Status();
+  }
+  std::vector<int> EncodeAsIds(std::string_view input) const {   // errors are swallowed, as in the reference (:427-436)
+    std::vector<int> ids;
+    (void)Encode(input, &ids);
+    return ids;
+  }
+  // Flat form: packed text + offsets in, CSR out (ids and id_offsets are resized).
+  util::Status EncodeBatchFlat(const char *text, const uint64_t *offsets, uint64_t n, std::vector<int32_t> *ids,
+                               std::vector<uint64_t> *id_offsets) const {
+    if (!h_) return status();
+    if (!ids || !id_offsets) return util::Status(util::StatusCode::kInternal, "output container is null");
+    ids->clear();
+    id_offsets->clear();
+    int32_t *out = nullptr;
+    uint64_t *offs = nullptr;
+    const int rc = spmx_encode_batch(h_, text, offsets, n, &out, &offs);
+    if (rc != 0) return FromHandle(rc);
+    id_offsets->assign(offs, offs + n + 1);
+    ids->assign(out, out + offs[n]);
+    spmx_free(out);
+    spmx_free(offs);
+    return util::Status();
+  }
+  // Element-wise identical to Encode() per input (sentencepiece.i:245-267).
+  util::Status EncodeBatch(const std::vector<std::string_view> &ins, std::vector<std::vector<int>> *outs) const {
+    if (!outs) return util::Status(util::StatusCode::kInternal, "output container is null");
+    outs->clear();
+    std::string text;
+    std::vector<uint64_t> offs(ins.size() + 1, 0);
+    for (size_t i = 0; i < ins.size(); ++i) offs[i + 1] = offs[i] + ins[i].size();
+    text.reserve(offs.back());
+    for (auto s : ins) text.append(s.data(), s.size());
+    std::vector<int32_t> ids;
+    std::vector<uint64_t> io;
+    const util::Status st = EncodeBatchFlat(text.data(), offs.data(), ins.size(), &ids, &io);
+    if (!st.ok()) return st;
+    outs->resize(ins.size());
+    for (size_t i = 0; i < ins.size(); ++i) (*outs)[i].assign(ids.begin() + io[i], ids.begin() + io[i + 1]);
+    return util::Status();
+  }
+  // Device-resident form (HIP pointers, see spmx_encode_batch_device).
+  util::Status EncodeBatchDevice(const void *d_text, uint64_t text_bytes, const uint64_t *d_offsets, uint64_t n,
+                                 int32_t *d_ids, uint64_t ids_capacity, uint64_t *d_id_offsets, void *stream,
+                                 uint64_t *total_ids) const {
+    if (!h_) return status();
+    return FromHandle(spmx_encode_batch_device(h_, d_text, text_bytes, d_offsets, n, d_ids, ids_capacity,
+                                               d_id_offsets, stream, total_ids));
+  }
+
+  // ---- vocabulary ----
+  int GetPieceSize() const { return h_ ? spmx_piece_size(h_) : 0; }
+  int PieceToId(std::string_view piece) const { return h_ ? spmx_piece_to_id(h_, piece.data(), piece.size()) : 0; }
+  std::string IdToPiece(int id) const {
+    static const std::string kEmpty;
+    if (!h_) return kEmpty;
+    const int64_t n = spmx_id_to_piece(h_, id, nullptr, 0);
+    if (n < 0) return kEmpty;
+    std::string s(static_cast<size_t>(n), '\0');
+    spmx_id_to_piece(h_, id, s.data(), s.size());
+    return s;
+  }
+  int unk_id() const { return h_ ? spmx_unk_id(h_) : 0; }
+  int bos_id() const { return h_ ? spmx_bos_id(h_) : 0; }
+  int eos_id() const { return h_ ? spmx_eos_id(h_) : 0; }
+  int pad_id() const { return h_ ? spmx_pad_id(h_) : 0; }
+
+  spmx_handle *handle() const { return h_; }
+
+ private:
+  void Reset() {
+    spmx_destroy(h_);
+    h_ = nullptr;
+  }
+  util::Status Created(int rc) {
+    if (rc == 0) return util::Status();
+    h_ = nullptr;
+    return util::Status(static_cast<util::StatusCode>(rc), spmx_last_error(nullptr));
+  }
+  util::Status FromHandle(int rc) const {
+    if (rc == 0) return util::Status();
+    return util::Status(static_cast<util::StatusCode>(rc), spmx_last_error(h_));
+  }
+  int device_ = 0;
+  spmx_handle *h_ = nullptr;
+};
+
+}  // namespace sentencepiece_amd
+#endif

