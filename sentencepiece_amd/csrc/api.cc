@@ -78,6 +78,7 @@ struct spmx_handle {
   std::string extra_options;
   int device = 0;
   int n_cu = 256;
+  uint32_t tile_area_override[kNumTileClasses] = {0, 0};
   bool no_tile = false;   // SPMX_NO_TILE=1: sentence-per-wave form for every class (A/B measurements)
   // device copies of the tables
   DevBuf<uint32_t> d_ndarts, d_sym_final;
@@ -239,7 +240,12 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
       a.stats = &h->d_ctrl->stats[kStatsPerClass * c];
       a.rcap = cls[c].rcap; a.ncap = cls[c].ncap;
       const bool tile = h->model.model_type == kUnigram && c < kNumTileClasses && !h->no_tile;
-      if (tile) { a.ring = TileRing(h->tables.max_piece_len); a.tile_area = kTileClasses[c].area; }
+      if (tile) {
+        a.ring = TileRing(h->tables.max_piece_len);
+        a.tile_area = kTileClasses[c].area;
+        if (h->tile_area_override[c]) a.tile_area = h->tile_area_override[c];   // SPMX_TILE_AREA0/1: tuning experiments
+        if (a.tile_area < 2 * a.ncap + 1) a.tile_area = 2 * a.ncap + 1;
+      }
       const uint32_t lds = tile ? TileLdsBytes(a.rcap, a.ring, a.tile_area)
                                 : EncodeLdsBytes(h->model.model_type, a.rcap, a.ncap);
       int per_cu = static_cast<int>((160u * 1024u) / lds);
@@ -338,6 +344,8 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
   if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
   h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char *e = getenv("SPMX_NO_TILE")) h->no_tile = e[0] == '1';
+  if (const char *e = getenv("SPMX_TILE_AREA0")) h->tile_area_override[0] = static_cast<uint32_t>(atoi(e));
+  if (const char *e = getenv("SPMX_TILE_AREA1")) h->tile_area_override[1] = static_cast<uint32_t>(atoi(e));
   if ((e = hipMalloc(reinterpret_cast<void **>(&h->d_ctrl), sizeof(Ctrl))) != hipSuccess) return bail(e, "hipMalloc(ctrl)");
   if ((e = hipHostMalloc(reinterpret_cast<void **>(&h->h_ctrl), sizeof(Ctrl), hipHostMallocDefault)) != hipSuccess)
     return bail(e, "hipHostMalloc(ctrl)");

@@ -53,6 +53,9 @@ struct SpmxDev {
   const uint32_t *ndarts; // the model's own Darts double-array units (part of the .model format)
   const uint8_t *nblob;   // NUL-terminated replacement strings
   uint32_t ndarts_n, nblob_n;
+  // bit b (b < 128): no charsmap key is `b` alone or `b` followed by another ASCII byte, so an ASCII byte b
+  // whose successor is ASCII (or the end of the input) cannot begin a rule and needs no trie probe
+  uint32_t ascii_safe[4];
   uint32_t flags;
   // ---- unigram (reference: src/unigram_model.cc:889-1020) ----
   const U4 *ptrie;        // piece trie with inline id / flags / score
@@ -72,6 +75,11 @@ struct SpmxDev {
   uint32_t chartab_mask, pairtab_mask;
   int32_t model_type;     // 1 unigram, 2 bpe
 };
+
+// ptrie unit word w: 32-bit summary of the node's child labels, bit ChildBit(c) set for every child byte c.
+// A clear bit proves "no child c" without a probe (the walk's last, failing probe is usually predictable:
+// 97 % on the round-1 bench corpus); a set bit means "probe".
+SPMX_HD inline uint32_t ChildBit(uint32_t c) { return ((c * 37u) >> 3) & 31u; }
 
 SPMX_HD inline uint32_t HashPair(uint32_t a, uint32_t b) {
   uint64_t h = (static_cast<uint64_t>(a) << 32 | b) * 0x9E3779B97F4A7C15ull;

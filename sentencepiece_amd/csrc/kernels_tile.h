@@ -27,6 +27,7 @@ constexpr uint32_t kBpUnk = 0x80u;     // back-pointer byte: the UNK candidate w
 constexpr uint32_t kBpLen = 0x7Fu;
 
 struct TileLds {
+  U4 *roottab;       // [256] trie units of the one-byte prefixes (first level of every walk)
   uint8_t *raw;      // staging of one raw sentence (rcap + 16)
   float *ring;       // [R][64] best scores, lane-interleaved
   uint8_t *area;     // text + back-pointer regions of the round's sentences
@@ -34,93 +35,137 @@ struct TileLds {
 
 SPMX_HD inline uint32_t TileRawBytes(uint32_t rcap) { return (rcap + 16 + 15) & ~15u; }
 SPMX_HD inline uint32_t TileLdsBytes(uint32_t rcap, uint32_t ring, uint32_t area) {
-  return TileRawBytes(rcap) + 64u * ring * 4u + ((area + 15) & ~15u);
+  return 256u * 16u + TileRawBytes(rcap) + 64u * ring * 4u + ((area + 15) & ~15u);
 }
 
 SPMX_DEVICE TileLds carve_tile(unsigned char *base, uint32_t rcap, uint32_t ring) {
   TileLds t;
+  t.roottab = reinterpret_cast<U4 *>(base);
+  base += 256u * 16u;
   t.raw = base;
   t.ring = reinterpret_cast<float *>(base + TileRawBytes(rcap));
   t.area = base + TileRawBytes(rcap) + 64u * ring * 4u;
   return t;
 }
 
-// EncodeOptimized for this lane's sentence.  text/bp are this lane's regions,
-// ring is &ring[lane]; slot of position e is ring[(e & rm) * 64].
+// :979-983 score of the piece in unit u (byte length len) as the reference's double
+SPMX_DEVICE double piece_score(const U4 &u, int len, float max_score) {
+  double score = static_cast<double>(wv::bits_to_float(u.z));
+  if (u.y & kPtUserDefined) {                                      // (length * max_score_ - 0.1)
+    const float prod = static_cast<float>(len) * max_score;
+    score = static_cast<double>(prod) - 0.1;
+  }
+  return score;
+}
+
+// EncodeOptimized for this lane's sentence.  text/bp are this lane's regions, ring is &ring[lane]; slot of
+// position e is ring[(e & rm) * 64]; roottab[c] is the trie unit of the one-byte prefix c (LDS copy).
 //
-// One trie probe per iteration, software-pipelined: at the top of an iteration
-// the unit `u` of the CURRENT probe (byte c = text[s + dep] below `node`) is
-// already in flight; the iteration decides match / mismatch, immediately
-// issues the NEXT probe (the two bytes it can need were prefetched from LDS
-// before `u` was waited for), and only then does the relax of the current
-// candidate in LDS, under the shadow of that load.  Match and mismatch share
-// one predicated relax: a match relaxes (s, s + dep + 1) with the piece score
-// (double add, double compare against the float-rounded best, :979-989), a
-// mismatch relaxes (s, s + mb) with the UNK score (float add, :995-1005)
-// unless a single-character piece was seen, then moves to the next start.
+// The reference's two nested loops (for each start: for each prefix, :960-1008) are flattened so that one
+// iteration costs ONE global trie probe per lane, split into a control half and a data half:
+//   control  (registers only) -- consume the probe in flight (:969-971); the child-label summary in the unit
+//            tells whether the next byte can match at all, so a walk's last, failing probe is usually never
+//            issued; if the walk of this start is over, move to the next start (:1007) and take its first
+//            trie level from the root-table unit that was fetched from LDS when the previous start began;
+//            issue the next probe;
+//   data     (LDS, under the shadow of that probe) -- up to three relaxations of best_path_ends_at, in the
+//            reference's order: (A) the piece just matched (double add, double compare against the
+//            float-rounded best, :979-989), (B) UNK for the start that is over unless a one-character piece
+//            was seen (float add, :990-1005), (C) a one-byte piece of the next start.  Their six LDS reads
+//            are issued together; where two of them hit the same position the later one is forwarded the
+//            earlier one's result in registers.
+// Returns the number of iterations (wave-uniform) for the profiling counters.
 SPMX_DEVICE int unigram_lane(const SpmxDev &d, const uint8_t *text, uint8_t *bp, int nlen, float *ring, uint32_t rm,
-                             bool active_in) {
+                             const U4 *roottab, bool active_in) {
   const U4 *__restrict__ ptrie = d.ptrie;
-  const uint32_t root = ptrie[0].x >> kDatBaseShiftDev;
   const float unk_score = d.unk_score, max_score = d.max_score;
   int trips = 0;
-  int s = 0, dep = 0, mb = 1;
+  bool active = active_in && nlen > 0;
+  if (!active) nlen = 0;                          // all indices of an idle lane stay 0
+  // a finished pseudo-start in front of position 0: single = true (no UNK), mb = 0 (the next start is 0)
+  int s = 0, mb = 0, dep = 0;
+  bool walking = false, single = true;
   uint32_t c = 0;
   float sbest = 0.f;
-  // lane predicates kept as 0 / 1 integers: the loop body is straight-line code with selects
-  uint32_t active = (active_in && nlen > 0) ? 1u : 0u, valid = active, single = 0;
   U4 u{0, 0, 0, 0};
+  // fetched when a start begins, for the start that follows it: first byte, the byte after, root-table unit
+  uint32_t cs = 0, cs1 = 0;
+  U4 rn{0, 0, 0, 0};
+  uint32_t cq = 0;                                // text[s + dep + 1]: the byte after the one being probed
   if (active) {
-    c = text[0];
-    mb = OneCharLenDev(c);                                         // :962-963
-    if (mb > nlen) mb = nlen;
-    ring[0] = 0.f;                                                 // best_path_ends_at[0].best_path_score = 0
-    u = ptrie[root ^ c];
-  } else {
-    nlen = 0;                                                      // all indices of an idle lane stay 0
+    ring[0] = 0.f;                                // best_path_ends_at[0].best_path_score = 0
+    cs = text[0];
+    cs1 = text[1];
+    rn = roottab[cs];
   }
-  while (wv::any(active != 0)) {
+  while (wv::any(active)) {
     ++trips;
-    const int dep1 = dep + 1, s1 = s + mb;
-    // the two bytes the next probe can need; both indices are <= nlen + 1, inside this lane's text + bp region
-    const uint32_t cq = text[s + dep1], cs = text[s1];
-    const uint32_t match = valid & ((u.x & 0x1FFu) == (0x100u | c) ? 1u : 0u);        // :969-971 traverse one byte
-    const uint32_t term_ok = match & (u.x >> 9) & (~u.y >> 31);                          // :973-974 leaf, not UNUSED
-    // ---- next probe ----
-    const int ns = match ? s : s1;                                 // :1007 next character start on a mismatch
-    const int ndep = match ? dep1 : 0;
-    const uint32_t nc = match ? cq : cs;
-    const uint32_t nnode = match ? (u.x >> kDatBaseShiftDev) : root;
-    int cl = OneCharLenDev(cs);
-    if (cl > nlen - s1) cl = nlen - s1;
-    const int nmb = match ? mb : cl;
-    const uint32_t nactive = active & (match | (s1 < nlen ? 1u : 0u));
-    const uint32_t nvalid = nactive & (ns + ndep < nlen ? 1u : 0u);
-    const U4 nu = ptrie[nvalid ? (nnode ^ nc) : 0u];               // idle lanes re-read unit 0 (one cached line)
-    // ---- relax of the current candidate ----
-    const int e = ns + ndep * static_cast<int>(match);             // match: s + dep + 1; mismatch: s + mb
-    double score = static_cast<double>(wv::bits_to_float(u.z));
-    if (u.y & kPtUserDefined) {                                    // :979-981 (length * max_score_ - 0.1)
-      const float prod = static_cast<float>(dep1) * max_score;
-      score = static_cast<double>(prod) - 0.1;
+    // ---------------- control ----------------
+    const int dep1 = dep + 1;
+    const bool matchA = active && walking && (u.x & 0x1FFu) == (0x100u | c);           // :969-971
+    const bool termA = matchA && (u.x & kDatTerminalDev) && !(u.y & kPtUnused);          // :973-974
+    const bool cont = matchA && s + dep1 < nlen && ((u.w >> ChildBit(cq)) & 1u);
+    const bool ended = active && !cont;           // not walking, mismatch, or no child can match the next byte
+    const int s2 = s + mb;                        // :1007 the next start
+    const bool begin = ended && s2 < nlen;
+    int mb2 = OneCharLenDev(cs);                  // :962-963
+    if (mb2 > nlen - s2) mb2 = nlen - s2;
+    const U4 r = rn;
+    const bool rootC = begin && (r.x & 0x1FFu) == (0x100u | cs);                         // first trie level
+    const bool termC = rootC && (r.x & kDatTerminalDev) && !(r.y & kPtUnused);
+    const bool contC = rootC && s2 + 1 < nlen && ((r.w >> ChildBit(cs1)) & 1u);
+    const bool nwalking = cont || contC;
+    const uint32_t nnode = cont ? (u.x >> kDatBaseShiftDev) : (r.x >> kDatBaseShiftDev);
+    const uint32_t nc = cont ? cq : cs1;
+    const U4 uA = u;                              // the unit the data half scores
+    if (nwalking) u = ptrie[nnode ^ nc];          // next probe
+    // ---------------- data ----------------
+    const int eA = s + dep1;                      // <= nlen when matchA
+    const int eB = s2;                            // <= nlen
+    const int eC = s2 + 1 <= nlen ? s2 + 1 : nlen;
+    float *slotA = ring + ((static_cast<uint32_t>(eA) & rm) << 6);
+    float *slotB = ring + ((static_cast<uint32_t>(eB) & rm) << 6);
+    float *slotC = ring + ((static_cast<uint32_t>(eC) & rm) << 6);
+    const int iA = matchA ? eA : 0;
+    uint32_t bpA = bp[iA], bpB = bp[eB], bpC = bp[eC];
+    float rA = *(matchA ? slotA : ring), rB = *slotB, rC = *slotC;
+    // (A) the piece that just matched
+    const double candA = piece_score(uA, dep1, max_score) + static_cast<double>(sbest);  // :982-983
+    const bool updA = termA && (bpA == 0 || candA > static_cast<double>(rA));            // :984-989
+    const float nvA = static_cast<float>(candA);
+    if (updA && eB == eA) { rB = nvA; bpB = static_cast<uint32_t>(dep1); }
+    if (updA && eC == eA) { rC = nvA; bpC = static_cast<uint32_t>(dep1); }
+    const bool single2 = single || (termA && dep1 == mb);                                // :990
+    // (B) UNK for the start that is over
+    const float candB = unk_score + sbest;                                               // :997-1001, float
+    const bool updB = ended && !single2 && (bpB == 0 || candB > rB);
+    const float sbest2 = updB ? candB : rB;       // best score at the next start, after (A) and (B)
+    // (C) a one-byte piece of the next start
+    const double candC = piece_score(r, 1, max_score) + static_cast<double>(sbest2);
+    const bool updC = termC && (bpC == 0 || candC > static_cast<double>(rC));
+    if (updA) { *slotA = nvA; bp[eA] = static_cast<uint8_t>(dep1); }
+    if (updB) { *slotB = candB; bp[eB] = static_cast<uint8_t>(static_cast<uint32_t>(mb) | kBpUnk); }
+    if (updC) { *slotC = static_cast<float>(candC); bp[eC] = 1; }
+    // ---------------- commit ----------------
+    if (ended) {
+      active = begin;
+      s = s2;
+      mb = begin ? mb2 : 0;
+      sbest = sbest2;
+      single = termC && mb2 == 1;
+      dep = rootC ? 1 : 0;
+      if (begin) {                                // what the start after this one will need
+        cs = text[s2 + mb2];
+        cs1 = text[s2 + mb2 + 1];
+        rn = roottab[cs];
+      }
+    } else {
+      dep = dep1;
+      single = single2;
     }
-    const float unk_cand = unk_score + sbest;                      // float arithmetic (:997-1001)
-    const double cand = match ? score + static_cast<double>(sbest) : static_cast<double>(unk_cand);   // :982-983
-    const uint32_t nbp = match ? static_cast<uint32_t>(dep1) : (static_cast<uint32_t>(mb) | kBpUnk);
-    float *slot = ring + ((static_cast<uint32_t>(e) & rm) << 6);
-    const uint32_t bpv = bp[e];
-    const float rv = *slot;
-    const uint32_t do_relax = active & (match ? term_ok : (single ^ 1u));
-    const bool upd = do_relax && (bpv == 0 || cand > static_cast<double>(rv));           // :984-989
-    const float nv = upd ? static_cast<float>(cand) : rv;
-    if (upd) {
-      *slot = nv;
-      bp[e] = static_cast<uint8_t>(nbp);
-    }
-    // on a mismatch e is the next start, so its best score is what the slot holds now
-    sbest = match ? sbest : nv;
-    single = match & (single | (term_ok & (dep1 == mb ? 1u : 0u)));                      // :990
-    s = ns; dep = ndep; mb = nmb; c = nc; u = nu; active = nactive; valid = nvalid;
+    walking = nwalking;
+    c = nc;
+    if (nwalking) cq = text[s + dep + 1];
   }
   return trips;
 }
@@ -212,6 +257,15 @@ SPMX_DEVICE void encode_tile_block(const EncodeArgs &a, unsigned char *smem) {
   const TileLds T = carve_tile(smem, a.rcap, a.ring);
   const uint32_t rm = a.ring - 1;
   float *my_ring = T.ring + lane;
+  {   // LDS copy of the trie's first level: unit of byte c, or an empty unit if no piece starts with c
+    const uint32_t root = d.ptrie[0].x >> kDatBaseShiftDev;
+    for (uint32_t cb = static_cast<uint32_t>(lane); cb < 256u; cb += 64u) {
+      U4 r = d.ptrie[root ^ cb];
+      if ((r.x & 0x1FFu) != (0x100u | cb)) r = U4{0, 0, 0, 0};
+      T.roottab[cb] = r;
+    }
+    wv::sync();
+  }
   const uint32_t count = *a.list_count;
   const uint32_t tiles = (count + 63) / 64;
   const int n_extra = d.n_prefix + d.n_suffix;
@@ -277,7 +331,7 @@ SPMX_DEVICE void encode_tile_block(const EncodeArgs &a, unsigned char *smem) {
       const uint8_t *text = T.area + (mine ? my_off : 0);
       uint8_t *bp = T.area + (mine ? my_off + my_nlen : 0);
       // ---- segment: one sentence per lane ----
-      n_trips += static_cast<unsigned long long>(unigram_lane(d, text, bp, my_nlen, my_ring, rm, mine));
+      n_trips += static_cast<unsigned long long>(unigram_lane(d, text, bp, my_nlen, my_ring, rm, T.roottab, mine));
       const unsigned long long c2 = wv::clock();
       // ---- ids ----
       int n = count_lane(d, bp, my_nlen, mine);

@@ -63,6 +63,29 @@ Status CompileTables(const ModelData &m, HostTables *t) {
     t->nblob.assign(blob.begin() + 4 + trie_bytes, blob.end());
     if (!t->ndarts.empty()) flags |= kNfHasCharsmap;
   }
+  // ASCII fast path of the normalizer: which ASCII first bytes can only start a rule when a non-ASCII byte
+  // follows (in nmt_nfkc / nfkc: letters that take combining marks).  Walk the model's own Darts units
+  // (darts.h:50-80, :467-513) two levels deep.
+  for (uint32_t &w : sc.ascii_safe) w = 0;
+  {
+    const std::vector<uint32_t> &u = t->ndarts;
+    auto offset = [](uint32_t x) { return (x >> 10) << ((x & (1u << 9)) >> 6); };
+    for (uint32_t b = 0; b < 128; ++b) {
+      bool safe = true;
+      if (!u.empty()) {
+        uint32_t pos = offset(u[0]) ^ b;
+        if (pos < u.size() && (u[pos] & 0x800000FFu) == b) {       // a key starts with b
+          if ((u[pos] >> 8) & 1u) safe = false;                    // b alone is a key
+          const uint32_t base = pos ^ offset(u[pos]);
+          for (uint32_t c2 = 0; c2 < 128 && safe; ++c2) {
+            const uint32_t p2 = base ^ c2;
+            if (p2 < u.size() && (u[p2] & 0x800000FFu) == c2) safe = false;   // b followed by ASCII continues a key
+          }
+        }
+      }
+      if (safe) sc.ascii_safe[b >> 5] |= 1u << (b & 31);
+    }
+  }
   if (t->ndarts.empty()) t->ndarts.push_back(0);
   if (t->nblob.empty()) t->nblob.push_back(0);
   sc.ndarts_n = static_cast<uint32_t>(t->ndarts.size());
@@ -112,6 +135,22 @@ Status CompileTables(const ModelData &m, HostTables *t) {
         u.z = FloatBits(m.pieces[d.value[i]].score);
       }
       t->ptrie[i] = u;
+    }
+    // child-label summaries (dev.h ChildBit): a unit at index j with label c is the child of the node whose
+    // base is j ^ c; bases are unique, so map base -> node unit first
+    {
+      std::vector<uint32_t> owner(d.w0.size(), 0xFFFFFFFFu);   // base -> unit that owns it
+      for (size_t i = 0; i < d.w0.size(); ++i)
+        if (i == 0 || (d.w0[i] & kDatOccupied)) {
+          const uint32_t base = d.w0[i] >> kDatBaseShift;
+          if (base < owner.size() && (i == 0 || base != 0)) owner[base] = static_cast<uint32_t>(i);
+        }
+      for (size_t j = 1; j < d.w0.size(); ++j) {
+        if (!(d.w0[j] & kDatOccupied)) continue;
+        const uint32_t c = d.w0[j] & 0xFFu;
+        const uint32_t base = static_cast<uint32_t>(j) ^ c;
+        if (base < owner.size() && owner[base] != 0xFFFFFFFFu) t->ptrie[owner[base]].w |= 1u << ChildBit(c);
+      }
     }
   } else {
     t->ptrie.assign(256, U4{0, 0, 0, 0});
