@@ -161,10 +161,10 @@ def main():
         achieved = cls["bytes"] / (k_ms[dom] * 1e-3) / 1e9 if k_ms[dom] > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        kname = cls["kernel"]
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get("%s:%d" % (args.model, args.sentences))
-        kname = "EncodeKernel<%d, %d>" % (sp.model_type(), dom)
+                traffic = json.load(f).get("%s:%d:%s" % (args.model, args.sentences, kname))
         out = {
             "metric": "sentences/sec EncodeBatch, 32k %s, MI355X" % ("unigram" if sp.model_type() == 1 else "bpe"),
             "value": world * n * args.steps / dt,
@@ -183,7 +183,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
                          "kernel_ms": k_ms[dom], "algorithmic_bytes_per_launch": cls["bytes"],
                          "sentences_per_launch": cls["sentences"],
-                         "all_classes_ms": k_ms, "phase_cycles": cls.get("phase_cycles"), "pipeline_ms": sum(p["total_ms"] for p in prof) / len(prof)},
+                         "all_kernels_ms": {prof[-1]["classes"][c]["kernel"]: round(k_ms[c], 4)
+                                            for c in range(ncls) if prof[-1]["classes"][c]["kernel"]}, "phase_cycles": cls.get("phase_cycles"), "pipeline_ms": sum(p["total_ms"] for p in prof) / len(prof)},
         }
         if world == 1 and not args.no_cpu_baseline:
             counts = np.diff(d_io.cpu().numpy())

@@ -93,12 +93,16 @@ void spmx_free(void *p);
 int spmx_encode(spmx_handle *h, const char *text, uint64_t len, int32_t *ids, uint64_t cap, uint64_t *n_ids);
 
 /* ---- measurement --------------------------------------------------------
- * Per length-class timing of the encode kernels of the LAST
+ * Per-kernel timing of the encode kernels of the LAST
  * spmx_encode_batch_device call, measured with hipEvents on the caller's
- * stream (enable first).  Arrays hold up to 8 entries; returns the number of
- * classes.  bytes[] is the algorithmic byte count SURVEY.md section 8d defines
- * (raw bytes + 8 + 4 * ids + 8 per sentence). */
+ * stream (enable first).  Arrays hold 8 entries ("kernel slots": one per
+ * length class, plus the GENERAL tile kernels that follow a FAST tile kernel;
+ * unused slots are zero); returns the number of slots.
+ * spmx_last_profile_name() gives the kernel symbol of a slot as rocprofv3
+ * prints it.  bytes[] is the algorithmic byte count SURVEY.md section 8d
+ * defines (raw bytes + 8 + 4 * ids + 8 per sentence). */
 int spmx_set_profiling(spmx_handle *h, int enabled);
+int spmx_last_profile_name(const spmx_handle *h, int slot, char *out, uint64_t cap);
 int spmx_last_profile(const spmx_handle *h, float *kernel_ms, uint64_t *sentences, uint64_t *raw_bytes,
                       uint64_t *ids, uint64_t *bytes, uint32_t *rcap, float *total_ms);
 

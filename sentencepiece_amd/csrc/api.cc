@@ -30,12 +30,15 @@ using namespace spmx;
 
 namespace {
 
+constexpr uint32_t kLdsPerCu = 160u * 1024u;   // gfx950 (MI355X_MICROARCH.md)
+
 std::mutex g_err_mu;
 std::string g_create_error;
 
 // ctrl block layout (device + pinned host mirror), zeroed before every call
 struct Ctrl {
   uint32_t list_counts[kMaxClasses];
+  uint32_t hard_counts[kMaxClasses];   // tile classes: sentences the FAST kernel left to the GENERAL kernel
   uint32_t status;
   uint32_t pad;
   unsigned long long arena_head;
@@ -59,8 +62,12 @@ struct DevBuf {
   void Free() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// One entry per kernel slot: slot c < number of classes is the class's encode kernel (the FAST tile kernel where
+// one runs); slot kSlotGeneral + c is the GENERAL tile kernel that follows a FAST kernel of tile class c.
+constexpr int kSlotGeneral = kMaxClasses - kNumTileClasses;
 struct Profile {
   int n = 0;
+  char name[kMaxClasses][40] = {{0}};
   float kernel_ms[kMaxClasses] = {0};
   uint64_t sentences[kMaxClasses] = {0}, raw_bytes[kMaxClasses] = {0}, ids[kMaxClasses] = {0};
   uint32_t rcap[kMaxClasses] = {0};
@@ -80,10 +87,12 @@ struct spmx_handle {
   int n_cu = 256;
   uint32_t tile_area_override[kNumTileClasses] = {0, 0};
   bool no_tile = false;   // SPMX_NO_TILE=1: sentence-per-wave form for every class (A/B measurements)
+  bool no_fast = false;   // SPMX_NO_FAST=1: GENERAL tile kernel only
+  int tile_waves_override = 0;   // SPMX_TILE_WAVES: cap on wavefronts per tile workgroup
   // device copies of the tables
   DevBuf<uint32_t> d_ndarts, d_sym_final;
   DevBuf<uint8_t> d_nblob;
-  DevBuf<U4> d_ptrie, d_chartab, d_pairtab;
+  DevBuf<U4> d_ptrie, d_idtab, d_chartab, d_pairtab;
   DevBuf<U2> d_utrie;
   DevBuf<uint16_t> d_sym_len;
   DevBuf<int32_t> d_byte_ids;
@@ -100,7 +109,9 @@ struct spmx_handle {
   DevBuf<int32_t> d_ids;
   // profiling
   bool profiling = false;
-  hipEvent_t ev[kMaxClasses + 1][2] = {};
+  hipEvent_t ev[kMaxClasses + 1][2] = {};   // per kernel slot (see Profile) + the whole call
+  char slot_name[kMaxClasses][40] = {{0}};
+  bool slot_used[kMaxClasses] = {false};
   bool ev_ready = false;
   Profile prof;
 };
@@ -136,6 +147,7 @@ int UploadTables(spmx_handle *h) {
   HIP_OR_RETURN(h, Upload(&h->d_ndarts, t.ndarts));
   HIP_OR_RETURN(h, Upload(&h->d_nblob, t.nblob));
   HIP_OR_RETURN(h, Upload(&h->d_ptrie, t.ptrie));
+  HIP_OR_RETURN(h, Upload(&h->d_idtab, t.idtab));
   HIP_OR_RETURN(h, Upload(&h->d_utrie, t.utrie));
   HIP_OR_RETURN(h, Upload(&h->d_chartab, t.chartab));
   HIP_OR_RETURN(h, Upload(&h->d_pairtab, t.pairtab));
@@ -146,6 +158,7 @@ int UploadTables(spmx_handle *h) {
   h->dev.ndarts = h->d_ndarts.p;
   h->dev.nblob = h->d_nblob.p;
   h->dev.ptrie = h->d_ptrie.p;
+  h->dev.idtab = h->d_idtab.p;
   h->dev.utrie = h->d_utrie.p;
   h->dev.chartab = h->d_chartab.p;
   h->dev.pairtab = h->d_pairtab.p;
@@ -164,7 +177,7 @@ int RefreshDevice(spmx_handle *h, bool types_changed) {
     else HIP_OR_RETURN(h, Upload(&h->d_sym_final, t.sym_final));
   }
   SpmxDev d = t.scalars;
-  d.ndarts = h->dev.ndarts; d.nblob = h->dev.nblob; d.ptrie = h->d_ptrie.p; d.utrie = h->dev.utrie;
+  d.ndarts = h->dev.ndarts; d.nblob = h->dev.nblob; d.ptrie = h->d_ptrie.p; d.idtab = h->d_idtab.p; d.utrie = h->dev.utrie;
   d.chartab = h->dev.chartab; d.pairtab = h->dev.pairtab; d.sym_final = h->d_sym_final.p;
   d.sym_len = h->dev.sym_len; d.byte_ids = h->dev.byte_ids;
   h->dev = d;
@@ -174,7 +187,7 @@ int RefreshDevice(spmx_handle *h, bool types_changed) {
 void DestroyHandle(spmx_handle *h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
-  h->d_ndarts.Free(); h->d_sym_final.Free(); h->d_nblob.Free(); h->d_ptrie.Free(); h->d_chartab.Free();
+  h->d_ndarts.Free(); h->d_sym_final.Free(); h->d_nblob.Free(); h->d_ptrie.Free(); h->d_idtab.Free(); h->d_chartab.Free();
   h->d_pairtab.Free(); h->d_utrie.Free(); h->d_sym_len.Free(); h->d_byte_ids.Free();
   h->d_lists.Free(); h->d_counts.Free(); h->d_tmp_off.Free(); h->d_tile_sums.Free(); h->d_arena.Free();
   h->d_text.Free(); h->d_offs.Free(); h->d_id_offs.Free(); h->d_ids.Free();
@@ -202,7 +215,7 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
   }
   const int ncls = NumClasses(h);
   const LengthClass *cls = Classes(h);
-  HIP_OR_RETURN(h, h->d_lists.Reserve(static_cast<size_t>(ncls) * n));
+  HIP_OR_RETURN(h, h->d_lists.Reserve(static_cast<size_t>(ncls + kNumTileClasses) * n));
   HIP_OR_RETURN(h, h->d_counts.Reserve(n + 1));
   HIP_OR_RETURN(h, h->d_tmp_off.Reserve(n + 1));
   HIP_OR_RETURN(h, h->d_tile_sums.Reserve((n + kScanTile - 1) / kScanTile + 2));
@@ -219,6 +232,7 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
     HIP_OR_RETURN(h, h->d_arena.Reserve(arena_need));
     if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[kMaxClasses][0], stream));
     HIP_OR_RETURN(h, hipMemsetAsync(h->d_ctrl, 0, sizeof(Ctrl), stream));
+    for (bool &u : h->slot_used) u = false;
     const uint32_t n32 = static_cast<uint32_t>(n);
     const int wide = h->n_cu * 8;
     {
@@ -240,24 +254,53 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
       a.stats = &h->d_ctrl->stats[kStatsPerClass * c];
       a.rcap = cls[c].rcap; a.ncap = cls[c].ncap;
       const bool tile = h->model.model_type == kUnigram && c < kNumTileClasses && !h->no_tile;
+      if (!tile) snprintf(h->slot_name[c], sizeof(h->slot_name[c]), "EncodeKernel<%d, %d>", h->model.model_type, c);
+      if (prof && !tile) HIP_OR_RETURN(h, hipEventRecord(h->ev[c][0], stream));
       if (tile) {
+        // FAST kernel on the class list (when the model allows it), then the GENERAL kernel on what it left over
         a.ring = TileRing(h->tables.max_piece_len);
-        a.tile_area = kTileClasses[c].area;
-        if (h->tile_area_override[c]) a.tile_area = h->tile_area_override[c];   // SPMX_TILE_AREA0/1: tuning experiments
-        if (a.tile_area < 2 * a.ncap + 1) a.tile_area = 2 * a.ncap + 1;
+        const bool fast = TileFastEligible(h->dev.flags) && !h->no_fast;
+        for (int pass = fast ? 0 : 1; pass < 2; ++pass) {
+          const bool is_fast = pass == 0;
+          a.tile_area = is_fast ? kTileClasses[c].fast_area : kTileClasses[c].area;
+          if (h->tile_area_override[c] && is_fast == fast) a.tile_area = h->tile_area_override[c];   // SPMX_TILE_AREA0/1
+          const uint32_t floor_area = is_fast ? 2 * (a.rcap + 1) + 1 : 2 * a.ncap + 1;
+          if (a.tile_area < floor_area) a.tile_area = floor_area;
+          if (is_fast) {
+            a.hard_list = h->d_lists.p + static_cast<size_t>(ncls + c) * n;
+            a.hard_count = &h->d_ctrl->hard_counts[c];
+          } else if (fast) {
+            a.list = h->d_lists.p + static_cast<size_t>(ncls + c) * n;
+            a.list_count = &h->d_ctrl->hard_counts[c];
+            a.hard_list = nullptr; a.hard_count = nullptr;
+          }
+          const uint32_t priv = TilePrivateBytes(is_fast, a.rcap, a.ring, a.tile_area);
+          int waves = static_cast<int>((kLdsPerCu - kTileSharedBytes) / priv);
+          if (waves > (is_fast ? 16 : 8)) waves = is_fast ? 16 : 8;   // __launch_bounds__ of the two kernels
+          if (waves < 1) waves = 1;
+          if (h->tile_waves_override > 0 && h->tile_waves_override < waves) waves = h->tile_waves_override;
+          uint64_t grid = static_cast<uint64_t>(h->n_cu);          // one workgroup per CU; short batches: one
+          if (grid * waves > n) grid = (n + waves - 1) / waves;    // sentence per wave (the kernel sizes its tiles)
+          const uint32_t lds = TileLdsBytes(is_fast, a.rcap, a.ring, a.tile_area, static_cast<uint32_t>(waves));
+          const int slot = (fast && !is_fast) ? kSlotGeneral + c : c;
+          a.stats = &h->d_ctrl->stats[kStatsPerClass * slot];
+          snprintf(h->slot_name[slot], sizeof(h->slot_name[slot]), "EncodeTileKernel<%d, %s>", c, is_fast ? "true" : "false");
+          if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[slot][0], stream));
+          HIP_OR_RETURN(h, LaunchEncodeTile(c, is_fast, a, static_cast<int>(grid), waves, lds, stream));
+          if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[slot][1], stream));
+          h->slot_used[slot] = true;
+        }
+      } else {
+        const uint32_t lds = EncodeLdsBytes(h->model.model_type, a.rcap, a.ncap);
+        int per_cu = static_cast<int>(kLdsPerCu / lds);
+        if (per_cu > 32) per_cu = 32;
+        if (per_cu < 1) per_cu = 1;
+        uint64_t grid = static_cast<uint64_t>(h->n_cu) * per_cu;
+        if (grid > n) grid = n;
+        HIP_OR_RETURN(h, LaunchEncode(h->model.model_type, c, a, static_cast<int>(grid), lds, stream));
+        if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[c][1], stream));
+        h->slot_used[c] = true;
       }
-      const uint32_t lds = tile ? TileLdsBytes(a.rcap, a.ring, a.tile_area)
-                                : EncodeLdsBytes(h->model.model_type, a.rcap, a.ncap);
-      int per_cu = static_cast<int>((160u * 1024u) / lds);
-      if (per_cu > 32) per_cu = 32;
-      if (per_cu < 1) per_cu = 1;
-      uint64_t grid = static_cast<uint64_t>(h->n_cu) * per_cu;
-      const uint64_t items = tile ? (n + 63) / 64 : n;
-      if (grid > items) grid = items;
-      if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[c][0], stream));
-      if (tile) HIP_OR_RETURN(h, LaunchEncodeTile(c, a, static_cast<int>(grid), lds, stream));
-      else HIP_OR_RETURN(h, LaunchEncode(h->model.model_type, c, a, static_cast<int>(grid), lds, stream));
-      if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[c][1], stream));
     }
     {
       ScanArgs sa{h->d_counts.p, n32, h->d_tile_sums.p, d_id_offsets};
@@ -282,15 +325,17 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
     if (prof) {
       Profile &p = h->prof;
       p = Profile();
-      p.n = ncls;
-      for (int c = 0; c < ncls; ++c) {
+      p.n = kMaxClasses;
+      for (int c = 0; c < kMaxClasses; ++c) {
+        if (!h->slot_used[c]) continue;
+        memcpy(p.name[c], h->slot_name[c], sizeof(p.name[c]));
         HIP_OR_RETURN(h, hipEventElapsedTime(&p.kernel_ms[c], h->ev[c][0], h->ev[c][1]));
         const unsigned long long *s = &h->h_ctrl->stats[kStatsPerClass * c];
         p.sentences[c] = s[0];
         p.raw_bytes[c] = s[1];
         p.ids[c] = s[2];
         for (int k = 0; k < 5; ++k) p.cycles[c][k] = s[3 + k];
-        p.rcap[c] = cls[c].rcap;
+        p.rcap[c] = cls[c < ncls ? c : c - kSlotGeneral].rcap;
       }
       HIP_OR_RETURN(h, hipEventElapsedTime(&p.total_ms, h->ev[kMaxClasses][0], h->ev[kMaxClasses][1]));
     }
@@ -344,6 +389,8 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
   if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
   h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char *e = getenv("SPMX_NO_TILE")) h->no_tile = e[0] == '1';
+  if (const char *e = getenv("SPMX_NO_FAST")) h->no_fast = e[0] == '1';
+  if (const char *e = getenv("SPMX_TILE_WAVES")) h->tile_waves_override = atoi(e);
   if (const char *e = getenv("SPMX_TILE_AREA0")) h->tile_area_override[0] = static_cast<uint32_t>(atoi(e));
   if (const char *e = getenv("SPMX_TILE_AREA1")) h->tile_area_override[1] = static_cast<uint32_t>(atoi(e));
   if ((e = hipMalloc(reinterpret_cast<void **>(&h->d_ctrl), sizeof(Ctrl))) != hipSuccess) return bail(e, "hipMalloc(ctrl)");
@@ -510,6 +557,12 @@ int spmx_last_phase_cycles(const spmx_handle *h, uint64_t *cycles) {
   for (int c = 0; c < h->prof.n; ++c)
     for (int k = 0; k < 5; ++k) cycles[5 * c + k] = h->prof.cycles[c][k];
   return h->prof.n;
+}
+
+int spmx_last_profile_name(const spmx_handle *h, int slot, char *out, uint64_t cap) {
+  if (!h || slot < 0 || slot >= h->prof.n || !out || !cap) return 0;
+  snprintf(out, cap, "%s", h->prof.name[slot]);
+  return static_cast<int>(strlen(h->prof.name[slot]));
 }
 
 int spmx_last_profile(const spmx_handle *h, float *kernel_ms, uint64_t *sentences, uint64_t *raw_bytes, uint64_t *ids,

@@ -45,6 +45,8 @@ struct EncodeArgs {
   unsigned long long *stats;    // kStatsPerClass words: {sentences, raw bytes, ids, cycles load, normalize, segment, emit}
   uint32_t rcap, ncap;          // LDS capacities of this class: raw bytes, normalized bytes
   uint32_t ring, tile_area;     // tile form (kernels_tile.h): score ring entries (power of two), bytes of the text area
+  uint32_t *hard_list;          // tile form, FAST kernel: sentences it leaves to the GENERAL kernel of the class
+  uint32_t *hard_count;
 };
 
 constexpr int kStatsPerClass = 8;
@@ -57,6 +59,8 @@ SPMX_DEVICE int OneCharLenDev(uint32_t c) {  // src/util.h:151-153
   const uint32_t h = c >> 4;
   return h < 12 ? 1 : (h < 14 ? 2 : (h == 14 ? 3 : 4));
 }
+// The byte that stands for a whole character U+2581 in the normalized text, or a value no byte equals.
+SPMX_DEVICE uint32_t SpByteOf(const SpmxDev &d) { return (d.flags & kNfCompressSp) ? kSpByte : 0x100u; }
 
 // ---------------------------------------------------------------- helpers --
 // Inclusive -> exclusive prefix sum over the 64 lanes; *total gets the wave sum.
@@ -125,12 +129,15 @@ SPMX_DEVICE uint64_t resolve_chain(int base, int step, bool valid, int *next_sta
 // (4) a prefix sum places every prefix's output.
 SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint8_t *norm, int ncap, int lane) {
   const uint32_t F = d.flags;
-  const bool esc = (F & kNfEscapeWs) != 0, rm = (F & kNfRemoveExtraWs) != 0;
+  const bool rm = (F & kNfRemoveExtraWs) != 0;
+  const bool one = (F & kNfCompressSp) != 0;             // U+2581 is the single byte kSpByte (dev.h)
+  const bool esc = (F & kNfEscapeWs) != 0 && !one;       // escaped spaces take three bytes
   const int spw = esc ? 3 : 1;
+  const uint32_t sp1 = one ? kSpByte : 0x20u;            // the one-byte space symbol when !esc
   int out = 0;
   if ((F & kNfAddDummyPrefix) && !(F & kNfWsSuffix)) {   // :128
     if (spw > ncap) return -1;
-    if (lane < spw) norm[lane] = esc ? (lane == 0 ? 0xE2 : (lane == 1 ? 0x96 : 0x81)) : 0x20;
+    if (lane < spw) norm[lane] = static_cast<uint8_t>(esc ? (lane == 0 ? 0xE2u : (lane == 1 ? 0x96u : 0x81u)) : sp1);
     out = spw;
   }
   bool P = rm;                       // is_prev_space (:130), wave-uniform between sweeps
@@ -200,7 +207,7 @@ SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint
         }
       }
     }
-    // kind: 0 copy raw span, 1 rule string, 2 U+FFFD
+    // kind: 0 copy raw span, 1 rule string, 2 U+FFFD, 3 a literal U+2581 written as kSpByte
     int kind = 0, consumed = 1;
     int len = 1, lead = 0, nsp = 0;
     bool ends_sp = false;
@@ -234,6 +241,7 @@ SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint
         if (ok) {
           consumed = len = mb;
           if (b0 == 0x20) { lead = nsp = 1; ends_sp = true; }
+          if (one && mb == 3 && b0 == 0xE2u && raw[p + 1] == 0x96u && raw[p + 2] == 0x81u) { kind = 3; len = 1; }
         } else {
           kind = 2; consumed = 1; len = 3;     // U+FFFD, one byte consumed
         }
@@ -285,7 +293,9 @@ SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint
         uint32_t ch;
         if (kind == 0) ch = raw[p + k];
         else if (kind == 1) ch = d.nblob[src + k];
-        else ch = k == 0 ? 0xEFu : (k == 1 ? 0xBFu : 0xBDu);
+        else if (kind == 2) ch = k == 0 ? 0xEFu : (k == 1 ? 0xBFu : 0xBDu);
+        else ch = kSpByte;
+        if (one && ch == 0x20u) ch = kSpByte;
         if (esc && ch == 0x20u) {                                  // :143-148
           norm[w] = 0xE2; norm[w + 1] = 0x96; norm[w + 2] = 0x81;
           w += 3;
@@ -303,14 +313,14 @@ SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint
     for (;;) {
       if (out < spw) break;
       const bool is_sp = esc ? (norm[out - 3] == 0xE2 && norm[out - 2] == 0x96 && norm[out - 1] == 0x81)
-                             : (norm[out - 1] == 0x20);
+                             : (norm[out - 1] == sp1);
       if (!is_sp) break;
       out -= spw;
     }
   }
   if ((F & kNfAddDummyPrefix) && (F & kNfWsSuffix)) {   // :179
     if (out + spw > ncap) return -1;
-    if (lane < spw) norm[out + lane] = esc ? (lane == 0 ? 0xE2 : (lane == 1 ? 0x96 : 0x81)) : 0x20;
+    if (lane < spw) norm[out + lane] = static_cast<uint8_t>(esc ? (lane == 0 ? 0xE2u : (lane == 1 ? 0x96u : 0x81u)) : sp1);
     out += spw;
     wv::sync();
   }
@@ -338,11 +348,12 @@ SPMX_DEVICE void unigram_wave(const SpmxDev &d, const uint8_t *norm, int nlen, i
   float cur_best = 0.f;   // best_path_ends_at[t].best_path_score for a start at t (uniform)
   int next_cstart = 0;
   uint32_t vb = 0;
+  const uint32_t spb = SpByteOf(d);
   for (int t = 0; t < nlen; ++t) {
     if ((t & 63) == 0) vb = (t + lane < nlen) ? norm[t + lane] : 0u;
     const uint32_t c = wv::shfl(vb, t & 63);
     if (t == next_cstart) {                                // :960-968 a new character start
-      int mb = OneCharLenDev(c);
+      int mb = c == spb ? 1 : OneCharLenDev(c);
       if (mb > nlen - t) mb = nlen - t;
       next_cstart = t + mb;
       if (lane == (t & 63)) {
@@ -433,6 +444,7 @@ SPMX_DEVICE int emit_wave(const EncodeArgs &a, uint32_t sid, const uint8_t *norm
   const SpmxDev &d = a.dev;
   const bool bf = (d.flags & kNfByteFallback) != 0;
   const bool reverse = (d.flags & kNfReverse) != 0;
+  const uint32_t spb = SpByteOf(d);
   int total = 0;
   for (int b = 0; b < nlen; b += 64) {
     const int e = b + lane + 1;
@@ -442,7 +454,7 @@ SPMX_DEVICE int emit_wave(const EncodeArgs &a, uint32_t sid, const uint8_t *norm
       if (l & kTokEnd) {
         const int len = static_cast<int>(l & (kTokEnd - 1));
         if (bid[e] == d.unk_id) {
-          if (bf) cnt = len;
+          if (bf) cnt = norm[e - len] == spb ? 3 : len;   // an unknown piece is one character; U+2581 has 3 bytes
           else cnt = (e - len > 0 && bid[e - len] == d.unk_id) ? 0 : 1;
         } else {
           cnt = 1;
@@ -480,7 +492,7 @@ SPMX_DEVICE int emit_wave(const EncodeArgs &a, uint32_t sid, const uint8_t *norm
         len = static_cast<int>(l & (kTokEnd - 1));
         id = bid[e];
         if (id == d.unk_id) {
-          if (bf) cnt = len;
+          if (bf) cnt = norm[e - len] == spb ? 3 : len;
           else cnt = (e - len > 0 && bid[e - len] == d.unk_id) ? 0 : 1;
         } else {
           cnt = 1;
@@ -493,9 +505,11 @@ SPMX_DEVICE int emit_wave(const EncodeArgs &a, uint32_t sid, const uint8_t *norm
     if (cnt == 1 && !(bf && id == d.unk_id)) {
       dst[d.n_prefix + (reverse ? total - 1 - pos : pos)] = id;
     } else if (cnt > 0) {          // byte fallback: one BYTE id per byte of the unknown piece
+      const bool sp = norm[e - len] == spb;
       for (int k = 0; k < cnt; ++k) {
         const int j = pos + k;
-        dst[d.n_prefix + (reverse ? total - 1 - j : j)] = d.byte_ids[norm[e - len + k]];
+        const uint32_t byte = sp ? (k == 0 ? 0xE2u : (k == 1 ? 0x96u : 0x81u)) : norm[e - len + k];
+        dst[d.n_prefix + (reverse ? total - 1 - j : j)] = d.byte_ids[byte];
       }
     }
   }

@@ -14,10 +14,11 @@ __global__ __launch_bounds__(64) void EncodeKernel(EncodeArgs a) {
   encode_block<MODEL>(a, smem);
 }
 
-template <int CLS>
-__global__ __launch_bounds__(64) void EncodeTileKernel(EncodeArgs a) {
+// Tile form (kernels_tile.h): workgroups of up to 16 wavefronts, each wave on its own tiles.
+template <int CLS, bool FAST>
+__global__ __launch_bounds__(FAST ? 1024 : 512) void EncodeTileKernel(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  encode_tile_block(a, smem);
+  encode_tile_block<FAST>(a, smem);
 }
 
 __global__ __launch_bounds__(64) void ClassifyKernel(ClassifyArgs a) { classify_block(a); }
@@ -52,14 +53,16 @@ hipError_t LaunchEncode(int model_type, int cls, const EncodeArgs &a, int grid, 
   return hipGetLastError();
 }
 
-hipError_t LaunchEncodeTile(int cls, const EncodeArgs &a, int grid, uint32_t lds_bytes, hipStream_t stream) {
-  EncodeFn fn = cls == 0 ? EncodeTileKernel<0> : EncodeTileKernel<1>;
+hipError_t LaunchEncodeTile(int cls, bool fast, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes,
+                            hipStream_t stream) {
+  EncodeFn fn = cls == 0 ? (fast ? EncodeTileKernel<0, true> : EncodeTileKernel<0, false>)
+                         : (fast ? EncodeTileKernel<1, true> : EncodeTileKernel<1, false>);
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds_bytes));
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds_bytes, stream, a);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * waves), lds_bytes, stream, a);
   return hipGetLastError();
 }
 

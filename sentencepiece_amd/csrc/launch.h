@@ -21,9 +21,9 @@ constexpr LengthClass kClassesBpe[kNumClassesBpe] = {{192, 448}, {576, 1280}, {1
 // sentences, one per lane.  area = LDS bytes for the round's text + back-pointer
 // bytes (>= 2 * ncap + 1); the per-wave classes above remain for longer sentences
 // and for BPE.
-struct TileClass { uint32_t area; };
+struct TileClass { uint32_t area, fast_area; };   // GENERAL kernel, FAST kernel (slots of 2 (L + 1) + 1 bytes)
 constexpr int kNumTileClasses = 2;
-constexpr TileClass kTileClasses[kNumTileClasses] = {{24 * 1024}, {40 * 1024}};
+constexpr TileClass kTileClasses[kNumTileClasses] = {{24 * 1024, 15616}, {40 * 1024, 27 * 1024}};
 // score ring entries for a model whose longest piece has max_piece_len bytes
 inline uint32_t TileRing(int max_piece_len) {
   uint32_t r = 16;
@@ -31,7 +31,8 @@ inline uint32_t TileRing(int max_piece_len) {
   return r;
 }
 
-hipError_t LaunchEncodeTile(int cls, const EncodeArgs &a, int grid, uint32_t lds_bytes, hipStream_t stream);
+hipError_t LaunchEncodeTile(int cls, bool fast, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes,
+                            hipStream_t stream);
 hipError_t LaunchEncode(int model_type, int cls, const EncodeArgs &a, int grid, uint32_t lds_bytes, hipStream_t stream);
 hipError_t LaunchClassify(const ClassifyArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchScan(const ScanArgs &a, int grid, hipStream_t stream);

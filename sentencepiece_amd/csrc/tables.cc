@@ -1,8 +1,10 @@
 #include "tables.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 
 #include "dat.h"
 
@@ -28,6 +30,19 @@ uint32_t PackChar(const std::string &s) {
   return v;
 }
 uint32_t NextPow2(size_t n) { uint32_t p = 16; while (p < n) p <<= 1; return p; }
+
+const char kSpaceSymbol[] = "\xE2\x96\x81";   // U+2581 (src/normalizer.cc:109)
+
+// kNfCompressSp: every U+2581 of a piece becomes the single byte kSpByte.
+std::string CompressSp(const std::string &s) {
+  std::string o;
+  o.reserve(s.size());
+  for (size_t i = 0; i < s.size();) {
+    if (s.compare(i, 3, kSpaceSymbol) == 0) { o.push_back(static_cast<char>(kSpByte)); i += 3; }
+    else o.push_back(s[i++]);
+  }
+  return o;
+}
 
 }  // namespace
 
@@ -109,6 +124,20 @@ Status CompileTables(const ModelData &m, HostTables *t) {
     }
   }
 
+  // One-byte space symbol (dev.h kNfCompressSp).  Sound when 0xFF cannot reach the normalized text by any other
+  // route and every U+2581 in it is produced where the device normalizer can see it: escaped spaces and literal
+  // U+2581 characters of the raw text.  So: no user-defined symbols (their raw spans are copied verbatim), no
+  // 0xFF / U+2581 inside the charsmap's replacement strings, no 0xFF inside a piece.
+  bool compress = m.model_type == kUnigram && m.escape_ws && uds_keys.empty() && !getenv("SPMX_NO_COMPRESS");
+  if (compress) {
+    const std::string blob(t->nblob.begin(), t->nblob.end());
+    if (blob.find(static_cast<char>(kSpByte)) != std::string::npos || blob.find(kSpaceSymbol) != std::string::npos)
+      compress = false;
+    for (const auto &kv : m.pieces_map)
+      if (kv.first.find(static_cast<char>(kSpByte)) != std::string::npos) { compress = false; break; }
+  }
+  if (compress) flags |= kNfCompressSp;
+
   // ------------------------------------------------------- id post-process --
   t->byte_ids.assign(m.byte_ids, m.byte_ids + 256);
   sc.unk_id = m.unk_id;
@@ -120,7 +149,8 @@ Status CompileTables(const ModelData &m, HostTables *t) {
   t->max_piece_len = 0;
   if (m.model_type == kUnigram) {
     std::vector<std::pair<std::string, uint32_t>> keys;
-    for (const auto &kv : m.pieces_map) keys.emplace_back(kv.first, static_cast<uint32_t>(kv.second));
+    for (const auto &kv : m.pieces_map)
+      keys.emplace_back(compress ? CompressSp(kv.first) : kv.first, static_cast<uint32_t>(kv.second));
     DatTrie d;
     if (!BuildDat(keys, &d, &err)) return Status::Error(kInternal, "piece trie: " + err);
     t->max_piece_len = d.max_key_len;
@@ -152,8 +182,31 @@ Status CompileTables(const ModelData &m, HostTables *t) {
         if (base < owner.size() && owner[base] != 0xFFFFFFFFu) t->ptrie[owner[base]].w |= 1u << ChildBit(c);
       }
     }
+    // piece bytes -> id by fingerprint, for the backtrack (kernels_tile.h write_lane)
+    for (uint32_t seed = 0;; ++seed) {
+      if (seed == 64) return Status::Error(kInternal, "piece fingerprints keep colliding");
+      std::set<std::pair<uint32_t, uint32_t>> seen;
+      const uint32_t sz = NextPow2(keys.size() * 2 + 16);
+      t->idtab.assign(sz, U4{0, 0, kSymNone, 0});
+      bool clash = false;
+      for (const auto &kv : keys) {
+        uint32_t a, b;
+        PieceHashInit(seed, &a, &b);
+        for (unsigned char c : kv.first) PieceHashStep(&a, &b, c);
+        if (!seen.emplace(a, b).second) { clash = true; break; }
+        uint32_t s = PieceHashSlot(a, b) & (sz - 1);
+        while (t->idtab[s].z != kSymNone) s = (s + 1) & (sz - 1);
+        t->idtab[s] = U4{a, b, kv.second, 0};
+      }
+      if (clash) continue;
+      sc.id_seed = seed;
+      sc.idtab_mask = sz - 1;
+      break;
+    }
   } else {
     t->ptrie.assign(256, U4{0, 0, 0, 0});
+    t->idtab.assign(16, U4{0, 0, kSymNone, 0});
+    sc.idtab_mask = 15;
   }
 
   // ------------------------------------------------------------------- BPE --
@@ -310,6 +363,7 @@ void BindHostPointers(HostTables *t) {
   sc.ndarts = t->ndarts.data();
   sc.nblob = t->nblob.data();
   sc.ptrie = t->ptrie.data();
+  sc.idtab = t->idtab.data();
   sc.byte_ids = t->byte_ids.data();
   sc.utrie = t->utrie.data();
   sc.chartab = t->chartab.data();

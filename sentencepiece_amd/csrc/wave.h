@@ -16,6 +16,9 @@ namespace wv {
 SPMX_DEVICE int lane() { return static_cast<int>(threadIdx.x) & 63; }
 SPMX_DEVICE int block_id() { return static_cast<int>(blockIdx.x); }
 SPMX_DEVICE int grid_size() { return static_cast<int>(gridDim.x); }
+// workgroups of several wavefronts (tile kernels): this wave's index in its workgroup, waves per workgroup
+SPMX_DEVICE int wave_in_block() { return static_cast<int>(threadIdx.x) >> 6; }
+SPMX_DEVICE int waves_per_block() { return static_cast<int>(blockDim.x) >> 6; }
 
 SPMX_DEVICE uint64_t ballot(bool p) { return __ballot(p ? 1 : 0); }
 SPMX_DEVICE bool any(bool p) { return __ballot(p ? 1 : 0) != 0ull; }

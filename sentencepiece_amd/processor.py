@@ -254,7 +254,8 @@ class SentencePieceProcessor:
         self._lib.spmx_set_profiling(self._h, 1 if enabled else 0)
 
     def LastProfile(self):
-        """Per length class: dict(kernel_ms, sentences, raw_bytes, ids, bytes, rcap) + total_ms."""
+        """Per kernel slot (length class; GENERAL tile kernels after a FAST one sit in the last slots):
+        dict(kernel, kernel_ms, sentences, raw_bytes, ids, bytes, rcap, phase_cycles) + total_ms."""
         self._need()
         ms = np.zeros(8, dtype=np.float32)
         sent, raw, ids, byt = (np.zeros(8, dtype=np.uint64) for _ in range(4))
@@ -264,7 +265,12 @@ class SentencePieceProcessor:
                                         byt.ctypes.data, rcap.ctypes.data, C.byref(tot))
         cyc = np.zeros(40, dtype=np.uint64)
         self._lib.spmx_last_phase_cycles(self._h, cyc.ctypes.data)
-        return dict(classes=[dict(kernel_ms=float(ms[c]), sentences=int(sent[c]), raw_bytes=int(raw[c]),
+        names = []
+        for c in range(k):
+            buf = C.create_string_buffer(64)
+            self._lib.spmx_last_profile_name(self._h, c, buf, 64)
+            names.append(buf.value.decode())
+        return dict(classes=[dict(kernel=names[c], kernel_ms=float(ms[c]), sentences=int(sent[c]), raw_bytes=int(raw[c]),
                                   ids=int(ids[c]), bytes=int(byt[c]), rcap=int(rcap[c]),
                                   phase_cycles=dict(zip(("load", "normalize", "segment", "emit", "search_trips"),
                                                         (int(x) for x in cyc[5 * c:5 * c + 5]))))

@@ -138,6 +138,7 @@ const LengthClass kBpeCls[] = {{24, 40}, {192, 448}, {576, 1280}, {1536, 3328}, 
 }  // namespace
 
 extern "C" {
+extern uint64_t g_fast_kept, g_fast_handed;
 
 void *emu_load(const void *bytes, uint64_t n, char *err, uint64_t errcap) {
   auto *h = new EmuHandle;
@@ -195,6 +196,7 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
   const LengthClass *cls = bpe ? kBpeCls : kUniCls;
   const int ncls = bpe ? static_cast<int>(sizeof(kBpeCls) / sizeof(kBpeCls[0])) : static_cast<int>(sizeof(kUniCls) / sizeof(kUniCls[0]));
   if (grid < 1) grid = 1;
+  g_fast_kept = g_fast_handed = 0;
   std::vector<uint32_t> lists(static_cast<size_t>(ncls) * (n ? n : 1)), list_counts(kMaxClasses, 0), counts(n + 1, 0);
   std::vector<uint64_t> tmp_off(n + 1, 0);
   ClassifyArgs ca{};
@@ -216,15 +218,28 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
     a.arena = arena.data(); a.arena_head = &arena_head; a.arena_cap = arena.size();
     a.tmp_off = tmp_off.data(); a.counts = counts.data(); a.status = &status; a.stats = &stats[kStatsPerClass * c];
     a.rcap = cls[c].rcap; a.ncap = cls[c].ncap;
-    // tile form for the first unigram classes, as in csrc/api.cc (small areas here to exercise the rounds)
+    // tile form for the first unigram classes, as in csrc/api.cc (small areas here to exercise the rounds):
+    // the FAST kernel first (when the model allows it), then the GENERAL kernel on what it left over
     const bool tile = !bpe && c < 3 && !getenv("SPMX_NO_TILE");
     if (tile) {
       a.ring = 16;
       while (a.ring < static_cast<uint32_t>(h->tables.max_piece_len) + 1) a.ring <<= 1;
       a.tile_area = c == 0 ? 512 : (c == 1 ? 4096 : 6144);
       if (a.tile_area < 2 * a.ncap + 1) a.tile_area = 2 * a.ncap + 1;
-      std::vector<unsigned char> tsmem(TileLdsBytes(a.rcap, a.ring, a.tile_area) + 64, 0xCD);
-      for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, tsmem.data(), [&] { encode_tile_block(a, tsmem.data()); });
+      if (a.tile_area < 2 * (a.rcap + 1) + 1) a.tile_area = 2 * (a.rcap + 1) + 1;
+      std::vector<uint32_t> hard(n ? n : 1);
+      uint32_t hard_count = 0;
+      if (TileFastEligible(dev.flags) && !getenv("SPMX_NO_FAST")) {
+        a.hard_list = hard.data(); a.hard_count = &hard_count;
+        std::vector<unsigned char> fsmem(TileLdsBytes(true, a.rcap, a.ring, a.tile_area, 1) + 64, 0xCD);
+        for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, fsmem.data(), [&] { encode_tile_block<true>(a, fsmem.data()); });
+        g_fast_kept += list_counts[c] - hard_count;
+        g_fast_handed += hard_count;
+        a.list = hard.data(); a.list_count = &hard_count;
+        a.hard_list = nullptr; a.hard_count = nullptr;
+      }
+      std::vector<unsigned char> tsmem(TileLdsBytes(false, a.rcap, a.ring, a.tile_area, 1) + 64, 0xCD);
+      for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, tsmem.data(), [&] { encode_tile_block<false>(a, tsmem.data()); });
       continue;
     }
     std::vector<unsigned char> smem(EncodeLdsBytes(dev.model_type, a.rcap, a.ncap) + 64, 0xCD);
@@ -247,5 +262,10 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
 }
 
 uint64_t emu_collectives() { return emu::g_wave.n_collectives; }
+uint32_t emu_flags(void *hv) { return static_cast<EmuHandle *>(hv)->tables.scalars.flags; }
+// sentences the FAST tile kernel kept / handed to the GENERAL kernel in the last emu_encode_batch
+uint64_t g_fast_kept = 0, g_fast_handed = 0;
+uint64_t emu_fast_kept() { return g_fast_kept; }
+uint64_t emu_fast_handed() { return g_fast_handed; }
 
 }  // extern "C"

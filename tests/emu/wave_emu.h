@@ -67,6 +67,8 @@ namespace wv {
 inline int lane() { return emu::g_wave.cur; }
 inline int block_id() { return emu::g_wave.block; }
 inline int grid_size() { return emu::g_wave.grid; }
+inline int wave_in_block() { return 0; }
+inline int waves_per_block() { return 1; }
 
 inline uint64_t ballot(bool p) { return emu::Collective(emu::kBallot, p ? 1 : 0, 0); }
 inline bool any(bool p) { return ballot(p) != 0; }

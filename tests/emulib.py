@@ -25,6 +25,10 @@ class EmuLib:
         lib.emu_encode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                          C.c_void_p, C.c_int, C.c_void_p]
         lib.emu_collectives.restype = C.c_uint64
+        lib.emu_flags.restype = C.c_uint32
+        lib.emu_flags.argtypes = [C.c_void_p]
+        lib.emu_fast_kept.restype = C.c_uint64
+        lib.emu_fast_handed.restype = C.c_uint64
 
     def load(self, model_bytes):
         err = C.create_string_buffer(512)
@@ -43,6 +47,13 @@ class EmuHandle:
         if getattr(self, "h", None):
             self.lib.emu_free(self.h)
             self.h = None
+
+    def flags(self):
+        return int(self.lib.emu_flags(self.h))
+
+    def fast_split(self):
+        """(sentences the FAST tile kernel kept, sentences it handed to the GENERAL kernel) in the last call."""
+        return int(self.lib.emu_fast_kept()), int(self.lib.emu_fast_handed())
 
     def set_encode_extra_options(self, opts):
         rc = self.lib.emu_set_encode_extra_options(self.h, opts.encode())

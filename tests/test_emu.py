@@ -31,6 +31,35 @@ def test_emu_edge_and_samples(model, emu, oracle, corpora):
         np.testing.assert_array_equal(ids, oids)
 
 
+K_COMPRESS = 1 << 9   # dev.h kNfCompressSp
+
+
+@pytest.mark.parametrize("model", ["test_model", "uni1k_bf", "uni1k_suffix", "uni1k_ident", "uni32k"])
+@pytest.mark.parametrize("env", [{}, {"SPMX_NO_COMPRESS": "1"}, {"SPMX_NO_FAST": "1"},
+                                 {"SPMX_NO_COMPRESS": "1", "SPMX_NO_FAST": "1"}])
+def test_emu_tile_variants(model, env, emu, oracle, corpora, monkeypatch):
+    """One-byte space symbol on/off x FAST per-lane normalizer on/off: same ids; with both on, ASCII sentences
+    stay in the FAST kernel and the rest is handed over."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    blob = fixtures.model_blob(model)
+    h = emu.load(blob)
+    assert bool(h.flags() & K_COMPRESS) == ("SPMX_NO_COMPRESS" not in env)
+    o = oracle.load(blob)
+    for name, k in (("edge", 10 ** 6), ("synth20k", 300), ("mixed2k", 40), ("botchan", 150)):
+        text, offs = fixtures.head(*corpora[name], k)
+        ids, io = h.encode_batch(text, offs, grid=2)
+        assert h.status == 0
+        oids, oio = o.encode_batch(text, offs)
+        np.testing.assert_array_equal(io, oio)
+        np.testing.assert_array_equal(ids, oids)
+        kept, handed = h.fast_split()
+        if not env and name == "synth20k":
+            assert kept > 0.9 * (len(offs) - 1)
+        if "SPMX_NO_FAST" in env or "SPMX_NO_COMPRESS" in env:
+            assert kept == 0
+
+
 @pytest.mark.parametrize("model,opts", [("test_model", "bos:eos"), ("test_model", "reverse:bos"),
                                          ("bpe1k", "eos:reverse:bos"), ("uni1k_bf", "reverse")])
 def test_emu_extra_options(model, opts, emu, oracle, corpora):
