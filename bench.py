@@ -79,7 +79,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--sentences", type=int, default=10_000_000, help="sentences per GPU per step")
-    ap.add_argument("--model", default="uni32k")
+    ap.add_argument("--model", default="uni32k",
+                    help="uni32k | bpe32k (configs[1]/[2], ASCII corpus) | c5_250k | c5_250k_bf (configs[4], "
+                         "250k-piece unigram on the mixed-script power-law corpus)")
     ap.add_argument("--gather", choices=["ids", "none"], default="ids")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -102,12 +104,20 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    with open(os.path.join(ROOT, "tests", "golden", args.model + ".model"), "rb") as f:
-        blob = f.read()
+    c5 = args.model.startswith("c5_")
+    if c5:
+        from tests import fixtures
+        blob = fixtures.model_blob(args.model)      # synthesized 250k-piece model, cached under the temp dir
+    else:
+        with open(os.path.join(ROOT, "tests", "golden", args.model + ".model"), "rb") as f:
+            blob = f.read()
     sp = SentencePieceProcessor(model_proto=blob, device=local)
 
     # weak scaling: every rank draws its own shard of the generator (seed + rank)
-    text, offs = synth.ascii_corpus(args.sentences, seed=20250227 + rank)
+    if c5:
+        text, offs = synth.mixed_corpus(args.sentences, seed=20250228 + rank)
+    else:
+        text, offs = synth.ascii_corpus(args.sentences, seed=20250227 + rank)
     n = len(offs) - 1
     d_text = torch.from_numpy(text).to(dev)
     d_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
@@ -166,7 +176,8 @@ def main():
             with open(tpath) as f:
                 traffic = json.load(f).get("%s:%d:%s" % (args.model, args.sentences, kname))
         out = {
-            "metric": "sentences/sec EncodeBatch, 32k %s, MI355X" % ("unigram" if sp.model_type() == 1 else "bpe"),
+            "metric": "sentences/sec EncodeBatch, %s %s, MI355X" % ("250k" if c5 else "32k",
+                                                                     "unigram" if sp.model_type() == 1 else "bpe"),
             "value": world * n * args.steps / dt,
             "unit": "sentences/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -175,8 +186,10 @@ def main():
                      else "u8 text -> i32 ids; f32 compares",
             "data": "synthetic",
             "gb_text_per_s": job_bytes * args.steps / dt / 1e9,
-            "config": {"workload": "configs[1]: %s model, %d synthetic ASCII sentences per GPU, mean %.1f B, "
-                                   "length-bucketed, resident in HBM" % (args.model, n, len(text) / n),
+            "config": {"workload": "configs[%d]: %s model, %d synthetic %s sentences per GPU, mean %.1f B, "
+                                   "length-bucketed, resident in HBM"
+                                   % (4 if c5 else (1 if sp.model_type() == 1 else 2), args.model, n,
+                                      "mixed-script power-law [16, 4096] B" if c5 else "ASCII", len(text) / n),
                        "model": args.model, "sentences_per_gpu": n, "ids_per_sentence": job_ids / (world * n),
                        "gather": args.gather if world > 1 else "n/a", "sharding": "dp%d by sentence" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -138,7 +138,10 @@ MODELS = ["test_model", "test_ja_model", "uni1k", "bpe1k", "uni1k_bf", "bpe1k_bf
           "uni1k_ident", "uni1k_suffix", "bpe1k_noesc", "uni32k", "bpe32k"]
 PAIRS = [(m, c) for m in MODELS for c in ("botchan", "edge", "mixed2k")] + \
         [("test_ja_model", "ja"), ("uni1k_bf", "ja"), ("bpe1k_bf_uds", "ja"),
-         ("uni32k", "synth20k"), ("bpe32k", "synth20k"), ("test_model", "synth20k")]
+         ("uni32k", "synth20k"), ("bpe32k", "synth20k"), ("test_model", "synth20k"),
+         # BASELINE.json configs[4]: 250k-piece unigram (synthesized, see synth.c5_model) on mixed-script text
+         ("c5_250k", "mixed2k"), ("c5_250k_bf", "mixed2k"), ("c5_250k", "edge"), ("c5_250k_bf", "edge"),
+         ("c5_250k", "ja")]
 EXTRA = [("test_model", "botchan", "bos:eos"), ("test_model", "botchan", "reverse:bos"),
          ("bpe1k", "edge", "eos:reverse:bos")]
 
@@ -150,8 +153,8 @@ def make_ids():
     arrays = {}
     for m, c, *opt in [p + ("",) if len(p) == 2 else p for p in PAIRS + EXTRA]:
         opt = opt[0] if opt else ""
-        with open(f"{G}/{m}.model", "rb") as f:
-            blob = f.read()
+        from tests import fixtures
+        blob = fixtures.model_blob(m)
         h = ref.load(blob)
         if opt:
             h.set_encode_extra_options(opt)

@@ -244,3 +244,129 @@ def mixed_corpus(n_sentences: int, seed: int = 20250228, lo: int = 16, hi: int =
     if sort_by_length:
         return sort_packed_by_length(out, offs)
     return out, offs
+
+
+# ------------------------------------------------- config 5: 250k vocabulary --
+def _varint(n: int) -> bytes:
+    out = bytearray()
+    while True:
+        b = n & 0x7F
+        n >>= 7
+        if n:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _top_level_fields(blob: bytes):
+    """proto2 wire format: yields (field number, wire type, payload bytes incl. nothing of the key)."""
+    i, n = 0, len(blob)
+    while i < n:
+        key = 0
+        shift = 0
+        while True:
+            b = blob[i]; i += 1
+            key |= (b & 0x7F) << shift
+            shift += 7
+            if not b & 0x80:
+                break
+        field, wt = key >> 3, key & 7
+        if wt == 2:
+            ln = 0
+            shift = 0
+            while True:
+                b = blob[i]; i += 1
+                ln |= (b & 0x7F) << shift
+                shift += 7
+                if not b & 0x80:
+                    break
+            yield field, wt, blob[i:i + ln]
+            i += ln
+        elif wt == 0:
+            j = i
+            while blob[j] & 0x80:
+                j += 1
+            yield field, wt, blob[i:j + 1]
+            i = j + 1
+        elif wt == 5:
+            yield field, wt, blob[i:i + 4]
+            i += 4
+        elif wt == 1:
+            yield field, wt, blob[i:i + 8]
+            i += 8
+        else:
+            raise ValueError("unsupported wire type %d" % wt)
+
+
+def _piece_msg(piece: bytes, score: float, ptype: int) -> bytes:
+    # SentencePiece { 1: piece, 2: score (float), 3: type } (src/sentencepiece_model.proto:293-310)
+    body = b"\x0a" + _varint(len(piece)) + piece + b"\x15" + np.float32(score).tobytes()
+    if ptype != 1:
+        body += b"\x18" + _varint(ptype)
+    return b"\x0a" + _varint(len(body)) + body
+
+
+def c5_model(template_model: bytes, vocab_size: int = 250_000, seed: int = 20250228,
+             byte_fallback: bool = False, sample_sentences: int = 30_000) -> bytes:
+    """A ``vocab_size``-piece unigram ModelProto for BASELINE.json configs[4].
+
+    No training corpus of that size exists here, so the vocabulary is synthesized: every character of a
+    ``mixed_corpus`` sample, then random 2-6 character substrings of it (spaces written as U+2581), most
+    frequent first, with log-rank scores partly quantized so that equal-score candidates occur.  trainer_spec
+    and normalizer_spec (nmt_nfkc charsmap) are taken verbatim from ``template_model`` (a serialized 32k
+    model); ``byte_fallback`` appends the 256 byte pieces and sets trainer_spec.byte_fallback.
+    Deterministic for a given numpy version."""
+    rng = np.random.default_rng(seed)
+    text, offs = mixed_corpus(sample_sentences, seed=seed + 1, sort_by_length=False)
+    raw = text.tobytes()
+    s = raw.decode("utf-8").replace(" ", "▁")
+    chars = np.array(list(s))
+    # single characters by frequency
+    uniq, cnt = np.unique(chars, return_counts=True)
+    order = np.argsort(-cnt, kind="stable")
+    pieces = ["<unk>", "<s>", "</s>"]
+    types = [2, 3, 3]
+    scores = [0.0, 0.0, 0.0]
+    if byte_fallback:
+        for b in range(256):
+            pieces.append("<0x%02X>" % b); types.append(6); scores.append(0.0)
+    seen = set(pieces)
+    singles = [str(uniq[i]) for i in order]
+    # substrings: sample (start, length) pairs, count, keep the most frequent
+    n_draw = vocab_size * 12
+    st = rng.integers(0, len(chars) - 8, size=n_draw)
+    ln = rng.integers(2, 7, size=n_draw)
+    from collections import Counter
+    c = Counter("".join(chars[a:a + l]) for a, l in zip(st.tolist(), ln.tolist()))
+    # a piece never has U+2581 after its first character (as with split_by_whitespace=true)
+    subs = [w for w, _ in c.most_common() if "▁" not in w[1:]]
+    body = []
+    for w in singles:
+        if w not in seen:
+            seen.add(w); body.append(w)
+    n_single = len(body)
+    for w in subs:
+        if len(pieces) + len(body) >= vocab_size:
+            break
+        if w not in seen:
+            seen.add(w); body.append(w)
+    rank = np.arange(1, len(body) + 1, dtype=np.float64)
+    sc = -(2.5 + 1.15 * np.log(rank)) - 0.35 * np.array([len(w) for w in body])
+    sc[:n_single] -= 1.5                       # single characters are the fallback, not the preferred split
+    sc += rng.normal(0.0, 0.2, size=len(body))
+    q = rng.random(len(body)) < 0.5
+    sc[q] = np.round(sc[q] * 4.0) / 4.0        # exact ties between candidates
+    out = bytearray()
+    for p, t, v in zip(pieces, types, scores):
+        out += _piece_msg(p.encode("utf-8"), v, t)
+    for w, v in zip(body, sc.tolist()):
+        out += _piece_msg(w.encode("utf-8"), v, 1)
+    for field, wt, payload in _top_level_fields(template_model):
+        if field == 2:      # trainer_spec
+            if byte_fallback:
+                payload = payload + b"\x98\x02\x01"      # field 35 (byte_fallback) = true, last one wins
+            out += b"\x12" + _varint(len(payload)) + payload
+        elif field == 3:    # normalizer_spec
+            out += b"\x1a" + _varint(len(payload)) + payload
+    return bytes(out)

@@ -10,6 +10,20 @@ GOLDEN = mf.G
 
 
 def model_blob(name):
+    """Serialized ModelProto of a fixture model.  The 250k-piece C5 models (BASELINE.json configs[4]) are
+    synthesized deterministically (sentencepiece_amd/synth.py c5_model) and cached under the temp dir
+    instead of being stored in the repository (4.7 MB each)."""
+    if name in ("c5_250k", "c5_250k_bf"):
+        import tempfile
+        from sentencepiece_amd import synth
+        path = os.path.join(tempfile.gettempdir(), "spmx_%s_v1.model" % name)
+        if not os.path.exists(path):
+            blob = synth.c5_model(model_blob("uni32k"), byte_fallback=name.endswith("_bf"))
+            with open(path + ".tmp%d" % os.getpid(), "wb") as f:
+                f.write(blob)
+            os.replace(path + ".tmp%d" % os.getpid(), path)
+        with open(path, "rb") as f:
+            return f.read()
     with open(os.path.join(GOLDEN, name + ".model"), "rb") as f:
         return f.read()
 

@@ -8,7 +8,7 @@ import pytest
 from tests import fixtures
 
 MODELS = ["test_model", "test_ja_model", "uni1k", "bpe1k", "uni1k_bf", "bpe1k_bf_uds", "uni1k_uds",
-          "uni1k_ident", "uni1k_suffix", "bpe1k_noesc", "uni32k", "bpe32k"]
+          "uni1k_ident", "uni1k_suffix", "bpe1k_noesc", "uni32k", "bpe32k", "c5_250k", "c5_250k_bf"]
 
 
 @pytest.fixture(scope="module")
