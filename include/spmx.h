@@ -95,9 +95,10 @@ int spmx_encode(spmx_handle *h, const char *text, uint64_t len, int32_t *ids, ui
 /* ---- measurement --------------------------------------------------------
  * Per-kernel timing of the encode kernels of the LAST
  * spmx_encode_batch_device call, measured with hipEvents on the caller's
- * stream (enable first).  Arrays hold 8 entries ("kernel slots": one per
- * length class, plus the GENERAL tile kernels that follow a FAST tile kernel;
- * unused slots are zero); returns the number of slots.
+ * stream (enable first).  Arrays hold 16 entries ("kernel slots": slot c < 8
+ * is length class c's encode kernel, slot 8 + c the GENERAL kernel that
+ * follows a FAST kernel of class c; unused slots are zero); returns the
+ * number of slots.
  * spmx_last_profile_name() gives the kernel symbol of a slot as rocprofv3
  * prints it.  bytes[] is the algorithmic byte count SURVEY.md section 8d
  * defines (raw bytes + 8 + 4 * ids + 8 per sentence). */
@@ -107,8 +108,8 @@ int spmx_last_profile(const spmx_handle *h, float *kernel_ms, uint64_t *sentence
                       uint64_t *ids, uint64_t *bytes, uint32_t *rcap, float *total_ms);
 
 /* Shader-clock cycles the waves of the LAST profiled call spent per phase, summed
- * over waves: cycles[5 * class + {0 load, 1 normalize, 2 segment, 3 emit}]; entry 4 is the
- * number of search-loop iterations the waves of the tile form executed. */
+ * over waves: cycles[5 * slot + {0 load, 1 normalize, 2 segment, 3 emit}] (80 entries); entry 4 is
+ * the number of search-loop iterations the waves of the lane-per-sentence forms executed. */
 int spmx_last_phase_cycles(const spmx_handle *h, uint64_t *cycles);
 
 #ifdef __cplusplus

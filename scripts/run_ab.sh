@@ -1,4 +1,4 @@
-# usage: bash scripts/run_ab.sh [sentences]  -- A/B of the tile-kernel variants on one box (no CPU baseline)
+# usage: bash scripts/run_ab.sh [sentences]  -- A/B of the unigram kernel variants on one box (no CPU baseline)
 N=${1:-4000000}
 run() {
   env "$@" timeout 600 python bench.py --sentences $N --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "
@@ -10,9 +10,7 @@ except Exception as e:
     print('$*', 'FAILED', e)"
 }
 run SPMX_AB=default
+run SPMX_NO_STREAM=1
+run SPMX_TILE_WAVES=8
+run SPMX_TILE_WAVES=12
 run SPMX_NO_FAST=1
-run SPMX_NO_COMPRESS=1
-run SPMX_TILE_WAVES=4
-run SPMX_TILE_AREA0=12288
-run SPMX_TILE_AREA0=20480
-run SPMX_TILE_AREA0=24832

@@ -42,7 +42,7 @@ struct Ctrl {
   uint32_t status;
   uint32_t pad;
   unsigned long long arena_head;
-  unsigned long long stats[kStatsPerClass * kMaxClasses];
+  unsigned long long stats[kStatsPerClass * 2 * kMaxClasses];   // per kernel slot (see Profile)
   uint64_t total_ids;   // copied from id_offs[n] by the final D2H
 };
 
@@ -62,16 +62,17 @@ struct DevBuf {
   void Free() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-// One entry per kernel slot: slot c < number of classes is the class's encode kernel (the FAST tile kernel where
-// one runs); slot kSlotGeneral + c is the GENERAL tile kernel that follows a FAST kernel of tile class c.
-constexpr int kSlotGeneral = kMaxClasses - kNumTileClasses;
+// One entry per kernel slot: slot c < kMaxClasses is length class c's encode kernel (the FAST kernel where one
+// runs); slot kSlotGeneral + c is the GENERAL kernel that follows a FAST kernel of class c.
+constexpr int kSlotGeneral = kMaxClasses;
+constexpr int kMaxSlots = 2 * kMaxClasses;
 struct Profile {
   int n = 0;
-  char name[kMaxClasses][40] = {{0}};
-  float kernel_ms[kMaxClasses] = {0};
-  uint64_t sentences[kMaxClasses] = {0}, raw_bytes[kMaxClasses] = {0}, ids[kMaxClasses] = {0};
-  uint32_t rcap[kMaxClasses] = {0};
-  uint64_t cycles[kMaxClasses][5] = {{0}};
+  char name[kMaxSlots][40] = {{0}};
+  float kernel_ms[kMaxSlots] = {0};
+  uint64_t sentences[kMaxSlots] = {0}, raw_bytes[kMaxSlots] = {0}, ids[kMaxSlots] = {0};
+  uint32_t rcap[kMaxSlots] = {0};
+  uint64_t cycles[kMaxSlots][5] = {{0}};
   float total_ms = 0.f;
 };
 
@@ -109,9 +110,12 @@ struct spmx_handle {
   DevBuf<int32_t> d_ids;
   // profiling
   bool profiling = false;
-  hipEvent_t ev[kMaxClasses + 1][2] = {};   // per kernel slot (see Profile) + the whole call
-  char slot_name[kMaxClasses][40] = {{0}};
-  bool slot_used[kMaxClasses] = {false};
+  hipEvent_t ev[kMaxSlots + 1][2] = {};   // per kernel slot (see Profile) + the whole call
+  char slot_name[kMaxSlots][40] = {{0}};
+  bool slot_used[kMaxSlots] = {false};
+  bool no_stream = false;            // SPMX_NO_STREAM=1: tile / sentence-per-wave forms for unigram (A/B measurements)
+  uint64_t stream_scratch_limit = 4ull << 30;   // SPMX_STREAM_SCRATCH_MB: cap on the streaming kernels' HBM scratch
+  DevBuf<uint32_t> d_stream;         // scratch of the streaming kernels (text columns + back-pointer words)
   bool ev_ready = false;
   Profile prof;
 };
@@ -189,7 +193,7 @@ void DestroyHandle(spmx_handle *h) {
   (void)hipSetDevice(h->device);
   h->d_ndarts.Free(); h->d_sym_final.Free(); h->d_nblob.Free(); h->d_ptrie.Free(); h->d_idtab.Free(); h->d_chartab.Free();
   h->d_pairtab.Free(); h->d_utrie.Free(); h->d_sym_len.Free(); h->d_byte_ids.Free();
-  h->d_lists.Free(); h->d_counts.Free(); h->d_tmp_off.Free(); h->d_tile_sums.Free(); h->d_arena.Free();
+  h->d_stream.Free(); h->d_lists.Free(); h->d_counts.Free(); h->d_tmp_off.Free(); h->d_tile_sums.Free(); h->d_arena.Free();
   h->d_text.Free(); h->d_offs.Free(); h->d_id_offs.Free(); h->d_ids.Free();
   if (h->d_ctrl) (void)hipFree(h->d_ctrl);
   if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);
@@ -200,6 +204,40 @@ void DestroyHandle(spmx_handle *h) {
 
 int NumClasses(const spmx_handle *h) { return h->model.model_type == kBpe ? kNumClassesBpe : kNumClassesUnigram; }
 const LengthClass *Classes(const spmx_handle *h) { return h->model.model_type == kBpe ? kClassesBpe : kClassesUnigram; }
+
+// Launch shape of one streaming kernel (kernels_stream.h) on a class list of `known` sentences: as many
+// wavefronts per workgroup as the LDS of a CU holds (one workgroup per CU), fewer workgroups when the list is
+// short (at least one sentence per wave) or when the HBM scratch would pass the handle's limit.
+struct StreamPlan {
+  int grid = 1, waves = 1;
+  uint32_t lds = 0, tcap = 0;
+  uint64_t text_words = 0, scratch_words = 0;
+};
+StreamPlan PlanStream(const spmx_handle *h, const LengthClass &lc, bool fast, uint64_t known) {
+  StreamPlan sp;
+  const uint32_t ring = TileRing(h->tables.max_piece_len);
+  // a FAST text column never exceeds raw length + 1 (one-byte space symbol); GENERAL: the class's normalized capacity
+  sp.tcap = fast ? lc.rcap + 1 : lc.ncap;
+  const uint32_t priv = StreamPrivateBytes(fast, lc.rcap, lc.ncap, ring);
+  int waves = static_cast<int>((kLdsPerCu - kTileSharedBytes) / priv);
+  const int wmax = fast ? 16 : 8;   // __launch_bounds__ of the two kernels
+  if (waves > wmax) waves = wmax;
+  if (waves < 1) waves = 1;
+  if (h->tile_waves_override > 0 && h->tile_waves_override < waves) waves = h->tile_waves_override;
+  uint64_t grid = static_cast<uint64_t>(h->n_cu);
+  if (grid * waves > known) grid = (known + waves - 1) / waves;
+  if (grid < 1) grid = 1;
+  const uint64_t per_wave = StreamTextDwords(sp.tcap, ring) + StreamBpWords(sp.tcap);
+  const uint64_t max_waves = h->stream_scratch_limit / (per_wave * 4);
+  if (grid * waves > max_waves) grid = max_waves / waves;
+  if (grid < 1) grid = 1;
+  sp.grid = static_cast<int>(grid);
+  sp.waves = waves;
+  sp.lds = StreamLdsBytes(fast, lc.rcap, lc.ncap, ring, static_cast<uint32_t>(waves));
+  sp.text_words = grid * waves * StreamTextDwords(sp.tcap, ring);
+  sp.scratch_words = grid * waves * per_wave;
+  return sp;
+}
 
 // The launch sequence.  Caller holds h->mu and has set the device.
 int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, const uint64_t *d_offsets, uint64_t n,
@@ -215,11 +253,13 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
   }
   const int ncls = NumClasses(h);
   const LengthClass *cls = Classes(h);
-  HIP_OR_RETURN(h, h->d_lists.Reserve(static_cast<size_t>(ncls + kNumTileClasses) * n));
+  HIP_OR_RETURN(h, h->d_lists.Reserve(static_cast<size_t>(2 * ncls) * n));   // class lists + FAST hand-over lists
   HIP_OR_RETURN(h, h->d_counts.Reserve(n + 1));
   HIP_OR_RETURN(h, h->d_tmp_off.Reserve(n + 1));
   HIP_OR_RETURN(h, h->d_tile_sums.Reserve((n + kScanTile - 1) / kScanTile + 2));
-  uint64_t arena_need = text_bytes + (2 + static_cast<uint64_t>(h->dev.n_prefix + h->dev.n_suffix)) * n + 64;
+  // ids are at most one per normalized byte; the streaming kernels reserve a sentence's slot by that bound
+  const uint64_t expand = (h->dev.flags & kNfCompressSp) || !(h->dev.flags & kNfEscapeWs) ? 1 : 3;
+  uint64_t arena_need = expand * text_bytes + (4 + static_cast<uint64_t>(h->dev.n_prefix + h->dev.n_suffix)) * n + 64;
   if (h->profiling && !h->ev_ready) {
     for (auto &pair : h->ev) {
       HIP_OR_RETURN(h, hipEventCreate(&pair[0]));
@@ -230,7 +270,7 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
   const bool prof = h->profiling;
   for (int attempt = 0; attempt < 3; ++attempt) {
     HIP_OR_RETURN(h, h->d_arena.Reserve(arena_need));
-    if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[kMaxClasses][0], stream));
+    if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[kMaxSlots][0], stream));
     HIP_OR_RETURN(h, hipMemsetAsync(h->d_ctrl, 0, sizeof(Ctrl), stream));
     for (bool &u : h->slot_used) u = false;
     const uint32_t n32 = static_cast<uint32_t>(n);
@@ -243,6 +283,28 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
       const uint32_t tiles = (n32 + 63) / 64;
       HIP_OR_RETURN(h, LaunchClassify(ca, static_cast<int>(tiles < static_cast<uint32_t>(wide) ? tiles : wide), stream));
     }
+    const bool streaming = h->model.model_type == kUnigram && !h->no_stream;
+    uint32_t known[kMaxClasses] = {0};   // class sizes after classify (escalations from a GENERAL kernel come on top)
+    if (streaming) {
+      HIP_OR_RETURN(h, hipMemcpyAsync(h->h_ctrl->list_counts, h->d_ctrl->list_counts, sizeof(h->h_ctrl->list_counts),
+                                      hipMemcpyDeviceToHost, stream));
+      HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+      for (int c = 0; c < ncls; ++c) known[c] = h->h_ctrl->list_counts[c];
+      // one scratch buffer serves every launch of the call (they run one after another): size it for the largest
+      uint64_t need = 0;
+      bool prev_general = false;
+      for (int c = 0; c < ncls; ++c) {
+        if (known[c] == 0 && !prev_general) continue;
+        const bool fast = StreamFastEligible(h->dev.flags) && !h->no_fast && known[c] > 0;
+        for (int pass = fast ? 0 : 1; pass < 2; ++pass) {
+          StreamPlan sp = PlanStream(h, cls[c], pass == 0, known[c]);
+          if (sp.scratch_words > need) need = sp.scratch_words;
+        }
+        prev_general = true;
+      }
+      HIP_OR_RETURN(h, h->d_stream.Reserve(need));
+    }
+    bool prev_general = false;
     for (int c = 0; c < ncls; ++c) {
       EncodeArgs a{};
       a.dev = h->dev; a.text = d_text; a.offs = d_offsets;
@@ -253,6 +315,35 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
       a.tmp_off = h->d_tmp_off.p; a.counts = h->d_counts.p; a.status = &h->d_ctrl->status;
       a.stats = &h->d_ctrl->stats[kStatsPerClass * c];
       a.rcap = cls[c].rcap; a.ncap = cls[c].ncap;
+      if (streaming) {
+        if (known[c] == 0 && !prev_general) continue;
+        a.ring = TileRing(h->tables.max_piece_len);
+        const bool fast = StreamFastEligible(h->dev.flags) && !h->no_fast && known[c] > 0;
+        for (int pass = fast ? 0 : 1; pass < 2; ++pass) {
+          const bool is_fast = pass == 0;
+          const StreamPlan sp = PlanStream(h, cls[c], is_fast, known[c]);
+          if (is_fast) {
+            a.hard_list = h->d_lists.p + static_cast<size_t>(ncls + c) * n;
+            a.hard_count = &h->d_ctrl->hard_counts[c];
+          } else if (fast) {
+            a.list = h->d_lists.p + static_cast<size_t>(ncls + c) * n;
+            a.list_count = &h->d_ctrl->hard_counts[c];
+            a.hard_list = nullptr; a.hard_count = nullptr;
+          }
+          a.stream_tcap = sp.tcap;
+          a.stream_text = h->d_stream.p;
+          a.stream_bp = h->d_stream.p + sp.text_words;
+          const int slot = (fast && !is_fast) ? kSlotGeneral + c : c;
+          a.stats = &h->d_ctrl->stats[kStatsPerClass * slot];
+          snprintf(h->slot_name[slot], sizeof(h->slot_name[slot]), "EncodeStreamKernel<%d, %s>", c, is_fast ? "true" : "false");
+          if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[slot][0], stream));
+          HIP_OR_RETURN(h, LaunchEncodeStream(c, is_fast, a, sp.grid, sp.waves, sp.lds, stream));
+          if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[slot][1], stream));
+          h->slot_used[slot] = true;
+        }
+        prev_general = true;
+        continue;
+      }
       const bool tile = h->model.model_type == kUnigram && c < kNumTileClasses && !h->no_tile;
       if (!tile) snprintf(h->slot_name[c], sizeof(h->slot_name[c]), "EncodeKernel<%d, %d>", h->model.model_type, c);
       if (prof && !tile) HIP_OR_RETURN(h, hipEventRecord(h->ev[c][0], stream));
@@ -310,7 +401,7 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
       const uint64_t cgrid = n < static_cast<uint64_t>(h->n_cu) * 32 ? n : static_cast<uint64_t>(h->n_cu) * 32;
       HIP_OR_RETURN(h, LaunchCompact(pa, static_cast<int>(cgrid), stream));
     }
-    if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[kMaxClasses][1], stream));
+    if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[kMaxSlots][1], stream));
     HIP_OR_RETURN(h, hipMemcpyAsync(h->h_ctrl, h->d_ctrl, offsetof(Ctrl, total_ids), hipMemcpyDeviceToHost, stream));
     HIP_OR_RETURN(h, hipMemcpyAsync(&h->h_ctrl->total_ids, d_id_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
     HIP_OR_RETURN(h, hipStreamSynchronize(stream));
@@ -325,8 +416,8 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
     if (prof) {
       Profile &p = h->prof;
       p = Profile();
-      p.n = kMaxClasses;
-      for (int c = 0; c < kMaxClasses; ++c) {
+      p.n = kMaxSlots;
+      for (int c = 0; c < kMaxSlots; ++c) {
         if (!h->slot_used[c]) continue;
         memcpy(p.name[c], h->slot_name[c], sizeof(p.name[c]));
         HIP_OR_RETURN(h, hipEventElapsedTime(&p.kernel_ms[c], h->ev[c][0], h->ev[c][1]));
@@ -335,9 +426,9 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
         p.raw_bytes[c] = s[1];
         p.ids[c] = s[2];
         for (int k = 0; k < 5; ++k) p.cycles[c][k] = s[3 + k];
-        p.rcap[c] = cls[c < ncls ? c : c - kSlotGeneral].rcap;
+        p.rcap[c] = cls[c < kSlotGeneral ? c : c - kSlotGeneral].rcap;
       }
-      HIP_OR_RETURN(h, hipEventElapsedTime(&p.total_ms, h->ev[kMaxClasses][0], h->ev[kMaxClasses][1]));
+      HIP_OR_RETURN(h, hipEventElapsedTime(&p.total_ms, h->ev[kMaxSlots][0], h->ev[kMaxSlots][1]));
     }
     if (total_ids) *total_ids = h->h_ctrl->total_ids;
     if (h->h_ctrl->total_ids > ids_capacity || !d_ids) {
@@ -390,6 +481,8 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
   h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char *e = getenv("SPMX_NO_TILE")) h->no_tile = e[0] == '1';
   if (const char *e = getenv("SPMX_NO_FAST")) h->no_fast = e[0] == '1';
+  if (const char *e = getenv("SPMX_NO_STREAM")) h->no_stream = e[0] == '1';
+  if (const char *e = getenv("SPMX_STREAM_SCRATCH_MB")) h->stream_scratch_limit = static_cast<uint64_t>(atoll(e)) << 20;
   if (const char *e = getenv("SPMX_TILE_WAVES")) h->tile_waves_override = atoi(e);
   if (const char *e = getenv("SPMX_TILE_AREA0")) h->tile_area_override[0] = static_cast<uint32_t>(atoi(e));
   if (const char *e = getenv("SPMX_TILE_AREA1")) h->tile_area_override[1] = static_cast<uint32_t>(atoi(e));

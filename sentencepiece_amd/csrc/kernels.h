@@ -47,6 +47,10 @@ struct EncodeArgs {
   uint32_t ring, tile_area;     // tile form (kernels_tile.h): score ring entries (power of two), bytes of the text area
   uint32_t *hard_list;          // tile form, FAST kernel: sentences it leaves to the GENERAL kernel of the class
   uint32_t *hard_count;
+  // streaming form (kernels_stream.h): HBM scratch, one slab per wavefront of the launch
+  uint32_t *stream_text;        // [waves][StreamTextDwords(stream_tcap, ring)]
+  uint32_t *stream_bp;          // [waves][StreamBpWords(stream_tcap)]
+  uint32_t stream_tcap;         // bytes a text column holds
 };
 
 constexpr int kStatsPerClass = 8;
@@ -763,5 +767,6 @@ SPMX_DEVICE void compact_block(const CompactArgs &a) {
 }  // namespace spmx
 
 #include "kernels_tile.h"
+#include "kernels_stream.h"
 
 #endif

@@ -21,6 +21,13 @@ __global__ __launch_bounds__(FAST ? 1024 : 512) void EncodeTileKernel(EncodeArgs
   encode_tile_block<FAST>(a, smem);
 }
 
+// Streaming form (kernels_stream.h): same workgroup shape as the tile form.
+template <int CLS, bool FAST>
+__global__ __launch_bounds__(FAST ? 1024 : 512) void EncodeStreamKernel(EncodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  encode_stream_block<FAST>(a, smem);
+}
+
 __global__ __launch_bounds__(64) void ClassifyKernel(ClassifyArgs a) { classify_block(a); }
 __global__ __launch_bounds__(64) void ScanTilesKernel(ScanArgs a) { scan_tiles_block(a); }
 __global__ __launch_bounds__(64) void ScanSumsKernel(ScanArgs a) { scan_sums_block(a); }
@@ -57,6 +64,31 @@ hipError_t LaunchEncodeTile(int cls, bool fast, const EncodeArgs &a, int grid, i
                             hipStream_t stream) {
   EncodeFn fn = cls == 0 ? (fast ? EncodeTileKernel<0, true> : EncodeTileKernel<0, false>)
                          : (fast ? EncodeTileKernel<1, true> : EncodeTileKernel<1, false>);
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds_bytes));
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * waves), lds_bytes, stream, a);
+  return hipGetLastError();
+}
+
+namespace {
+template <bool FAST>
+EncodeFn PickStream(int cls) {
+  switch (cls) {
+    case 0: return EncodeStreamKernel<0, FAST>;
+    case 1: return EncodeStreamKernel<1, FAST>;
+    case 2: return EncodeStreamKernel<2, FAST>;
+    case 3: return EncodeStreamKernel<3, FAST>;
+    default: return EncodeStreamKernel<4, FAST>;
+  }
+}
+}  // namespace
+
+hipError_t LaunchEncodeStream(int cls, bool fast, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes,
+                              hipStream_t stream) {
+  EncodeFn fn = fast ? PickStream<true>(cls) : PickStream<false>(cls);
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds_bytes));

@@ -1,0 +1,460 @@
+// Unigram segmentation, streaming form: one SENTENCE PER LANE like the tile
+// form (kernels_tile.h), but with a per-lane working set in LDS that does not
+// depend on the sentence length, so that (a) 15-16 wavefronts fit a CU whatever
+// the length class and (b) sentences of any length up to the class capacity run
+// lane-parallel (the sentence-per-wave form spends its time in a serial loop
+// over end positions).
+//
+// Per lane, in LDS (lane-interleaved or lane-strided, see StreamLds):
+//   * a ring of the R most recent positions' best_path_ends_at entries
+//     (src/unigram_model.cc:944-952): score (float) and a packed back-pointer
+//     word  id | piece length << 24 | unknown << 31  (0 = position not reached);
+//   * a W-byte window of the normalized text around the current start.
+// Per lane, in HBM scratch (one slab per wavefront, position-major so that the
+// lanes of a wave, which advance at similar speeds, touch the same lines):
+//   * the normalized text, as dwords   text[pos >> 2][lane];
+//   * the FINAL back-pointer word of every character start   bp[pos][lane],
+//     stored once, when the start reaches that position (all candidates into a
+//     position are folded before any piece starting there is scored, :960-1008).
+// The backtrack (:1010-1018) follows bp[] from the end and writes ids straight
+// into the arena, last piece first.
+//
+// Two kernels, as in the tile form: FAST (each lane normalizes its own ASCII
+// sentence from HBM into its text column) and GENERAL (normalize_wave into an
+// LDS buffer, one sentence at a time, then a copy into the lane's column).
+#ifndef SPMX_KERNELS_STREAM_H_
+#define SPMX_KERNELS_STREAM_H_
+
+namespace spmx {
+
+constexpr uint32_t kBwUnk = 0x80000000u;   // back-pointer word: the UNK candidate won this position
+constexpr int kBwLenShift = 24;
+constexpr uint32_t kBwLenMask = 0x7Fu;
+constexpr uint32_t kBwIdMask = 0x00FFFFFFu;
+
+struct StreamLds {
+  U4 *roottab;        // [256] first trie level (shared by the workgroup, read-only)
+  uint8_t *bcls;      // [256] byte classes of the FAST normalizer (shared, read-only)
+  uint8_t *raw;       // GENERAL: one raw sentence (rcap + 16)
+  uint8_t *norm;      // GENERAL: its normalized form (ncap + 16)
+  float *ring_s;      // [R][64]
+  uint32_t *ring_b;   // [R][64]
+  uint8_t *win;       // [64][W + 4]: lane l's window starts at win + l * (W + 4)
+};
+
+SPMX_HD inline uint32_t StreamWindow(uint32_t ring) { return 2u * ring; }
+SPMX_HD inline uint32_t StreamPrivateBytes(bool fast, uint32_t rcap, uint32_t ncap, uint32_t ring) {
+  const uint32_t stage = fast ? 0u : (((rcap + 16 + 15) & ~15u) + ((ncap + 16 + 15) & ~15u));
+  return stage + 64u * ring * 8u + 64u * (StreamWindow(ring) + 4u);
+}
+SPMX_HD inline uint32_t StreamLdsBytes(bool fast, uint32_t rcap, uint32_t ncap, uint32_t ring, uint32_t waves) {
+  return kTileSharedBytes + waves * StreamPrivateBytes(fast, rcap, ncap, ring);
+}
+// HBM scratch of one wavefront for a class whose normalized sentences have at most tcap bytes
+SPMX_HD inline uint64_t StreamTextDwords(uint32_t tcap, uint32_t ring) {      // uint32 [dw][64]
+  return (static_cast<uint64_t>(tcap + 3) / 4 + StreamWindow(ring) / 4 + 4) * 64u;
+}
+SPMX_HD inline uint64_t StreamBpWords(uint32_t tcap) { return (static_cast<uint64_t>(tcap) + 2) * 64u; }   // uint32 [pos][64]
+
+SPMX_DEVICE StreamLds carve_stream(unsigned char *base, bool fast, uint32_t rcap, uint32_t ncap, uint32_t ring, int wave) {
+  StreamLds t;
+  t.roottab = reinterpret_cast<U4 *>(base);
+  t.bcls = base + 256u * 16u;
+  unsigned char *mine = base + kTileSharedBytes + static_cast<uint32_t>(wave) * StreamPrivateBytes(fast, rcap, ncap, ring);
+  t.raw = mine;
+  t.norm = mine + ((rcap + 16 + 15) & ~15u);
+  if (!fast) mine += ((rcap + 16 + 15) & ~15u) + ((ncap + 16 + 15) & ~15u);
+  t.ring_s = reinterpret_cast<float *>(mine);
+  t.ring_b = reinterpret_cast<uint32_t *>(mine + 64u * ring * 4u);
+  t.win = mine + 64u * ring * 8u;
+  return t;
+}
+
+// Normalize() of one all-ASCII sentence by ONE lane, as fast_norm_lane (kernels_tile.h), with the output going to
+// the lane's text column gt[dw * 64] in HBM four bytes at a time.  Not for whitespace-as-suffix models (the suffix
+// would have to be patched into a dword that is already stored).
+SPMX_DEVICE int fast_norm_stream(const SpmxDev &d, const uint8_t *gtext, uint64_t beg, int L, uint32_t *gt,
+                                 const uint8_t *bcls) {
+  const uint32_t F = d.flags;
+  const bool rm = (F & kNfRemoveExtraWs) != 0;
+  const uint32_t sp = (F & kNfCompressSp) ? kSpByte : 0x20u;
+  int w = 0;
+  uint32_t acc = 0;
+  if (F & kNfAddDummyPrefix) { acc = sp; w = 1; }   // :128
+  bool P = rm;                    // is_prev_space (:130)
+  int wl = w;                     // output length up to the last non-space byte (:166-176 trailing spaces)
+  bool seen = false;              // some prefix is not " " (:86-100)
+  uint32_t bad = 0;
+  const uint64_t q0 = beg & ~15ull;
+  const uint8_t *blk = gtext + q0;
+  int rel = static_cast<int>(q0 - beg);         // index of the block's first byte within the sentence (<= 0 at first)
+  Q4 cur = *reinterpret_cast<const Q4 *>(blk);
+  while (rel < L) {
+    Q4 nxt = cur;
+    if (rel + 16 < L) nxt = *reinterpret_cast<const Q4 *>(blk + 16);
+    const uint32_t wd[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const uint32_t c = (wd[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+      if (static_cast<uint32_t>(rel + k) < static_cast<uint32_t>(L)) {
+        bad |= bcls[c];
+        const bool is_sp = c == 0x20u;
+        if (!is_sp || !P) {                     // :137-138 a space after a space is dropped
+          acc |= (is_sp ? sp : c) << (8 * (w & 3));
+          ++w;
+          if ((w & 3) == 0) { gt[((w >> 2) - 1) * 64] = acc; acc = 0; }
+        }
+        P = is_sp && rm;                        // :154-162
+        if (!is_sp) { wl = w; seen = true; }
+      }
+    }
+    cur = nxt;
+    blk += 16;
+    rel += 16;
+  }
+  gt[(w >> 2) * 64] = acc;                      // the last, partial dword
+  if (bad & kBcComplex) return -1;
+  if (rm) {
+    if (!seen) return 0;                        // :86-100 nothing but spaces
+    w = wl;
+  }
+  return w;
+}
+
+SPMX_HD inline bool StreamFastEligible(uint32_t flags) {
+  return TileFastEligible(flags) && !((flags & kNfAddDummyPrefix) && (flags & kNfWsSuffix));
+}
+
+// Byte pos of this lane's text column.
+SPMX_DEVICE uint32_t stream_text_byte(const uint32_t *gt, int pos) {
+  return (gt[(pos >> 2) * 64] >> (8 * (pos & 3))) & 0xFFu;
+}
+
+// EncodeOptimized for this lane's sentence (see unigram_lane in kernels_tile.h for the flattened loop and its
+// control / data halves; the relaxations (A), (B), (C) and their order are the same).  Differences:
+//   * text comes from the W-byte LDS window `win` (position p at win[p & wmask]), refilled one dword per
+//     iteration from the lane's text column gt[] -- the load is issued next to the trie probe and lands in the
+//     window at the top of the next iteration, by which time the probe wait has covered it;
+//   * best_path_ends_at lives in the rings only: ring_s / ring_b slot of position e is [(e & rm) * 64];
+//     ring_b == 0 means "not reached" (:984);
+//   * when the start moves from s to s2, position s2's back-pointer word is final: it is stored to gb[s2 * 64],
+//     and the ring slots of the positions (s, s2] are cleared for the positions that will reuse them R later.
+// Returns the number of iterations (wave-uniform).
+SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const uint32_t *gt, uint32_t *gb, int nlen, float *ring_s,
+                                    uint32_t *ring_b, uint32_t rm, uint8_t *win, uint32_t wmask, const U4 *roottab,
+                                    bool active_in) {
+  const U4 *__restrict__ ptrie = d.ptrie;
+  const float unk_score = d.unk_score, max_score = d.max_score;
+  const uint32_t spb = SpByteOf(d);
+  const int W = static_cast<int>(wmask) + 1;
+  int trips = 0;
+  bool active = active_in && nlen > 0;
+  if (!active) nlen = 0;                          // all indices of an idle lane stay 0
+  int s = 0, mb = 0, dep = 0;
+  bool walking = false, single = true;
+  uint32_t c = 0;
+  float sbest = 0.f;
+  U4 u{0, 0, 0, 0};
+  uint32_t cs = 0, cs1 = 0;
+  U4 rn{0, 0, 0, 0};
+  uint32_t cq = 0;
+  int nf = 0;                                     // next text dword to fetch; the window holds dwords [nf - W/4, nf)
+  bool pf_pend = false;
+  uint32_t pf = 0;
+  if (active) {
+    for (uint32_t k = 0; k <= rm; ++k) ring_b[k * 64] = 0u;
+    ring_s[0] = 0.f;                              // best_path_ends_at[0].best_path_score = 0
+    for (int k = 0; k < W / 4; ++k) *reinterpret_cast<uint32_t *>(win + 4 * k) = gt[k * 64];
+    nf = W / 4;
+    cs = win[0];
+    cs1 = win[1];
+    rn = roottab[cs];
+  }
+  while (wv::any(active)) {
+    ++trips;
+    if (pf_pend) *reinterpret_cast<uint32_t *>(win + ((4u * static_cast<uint32_t>(nf - 1)) & wmask)) = pf;
+    // ---------------- control ----------------
+    const int dep1 = dep + 1;
+    const bool matchA = active && walking && (u.x & 0x1FFu) == (0x100u | c);           // :969-971
+    const bool termA = matchA && (u.x & kDatTerminalDev) && !(u.y & kPtUnused);          // :973-974
+    const bool cont = matchA && s + dep1 < nlen && ((u.w >> ChildBit(cq)) & 1u);
+    const bool ended = active && !cont;
+    const int s2 = s + mb;                        // :1007 the next start
+    const bool begin = ended && s2 < nlen;
+    int mb2 = cs == spb ? 1 : OneCharLenDev(cs);  // :962-963
+    if (mb2 > nlen - s2) mb2 = nlen - s2;
+    const U4 r = rn;
+    const bool rootC = begin && (r.x & 0x1FFu) == (0x100u | cs);
+    const bool termC = rootC && (r.x & kDatTerminalDev) && !(r.y & kPtUnused);
+    const bool contC = rootC && s2 + 1 < nlen && ((r.w >> ChildBit(cs1)) & 1u);
+    const bool nwalking = cont || contC;
+    const uint32_t nnode = cont ? (u.x >> kDatBaseShiftDev) : (r.x >> kDatBaseShiftDev);
+    const uint32_t nc = cont ? cq : cs1;
+    const U4 uA = u;
+    // window refill: dword nf may replace positions [4 nf - W, 4 nf - W + 4), which are dead once they lie below s
+    pf_pend = active && 4 * nf + 4 <= s + W && 4 * nf < nlen + 8;
+    if (pf_pend) { pf = gt[nf * 64]; ++nf; }
+    if (nwalking) u = ptrie[nnode ^ nc];          // next probe
+    // ---------------- data ----------------
+    const int eA = s + dep1;
+    const int eB = s2;
+    const int eC = s2 + 1 <= nlen ? s2 + 1 : nlen;
+    const uint32_t oA = (static_cast<uint32_t>(matchA ? eA : 0) & rm) << 6;
+    const uint32_t oB = (static_cast<uint32_t>(eB) & rm) << 6;
+    const uint32_t oC = (static_cast<uint32_t>(eC) & rm) << 6;
+    uint32_t bA = ring_b[oA], bB = ring_b[oB], bC = ring_b[oC];
+    float rA = ring_s[oA], rB = ring_s[oB], rC = ring_s[oC];
+    // (A) the piece that just matched
+    const double candA = piece_score(uA, dep1, max_score) + static_cast<double>(sbest);  // :982-983
+    const bool updA = termA && (bA == 0 || candA > static_cast<double>(rA));             // :984-989
+    const float nvA = static_cast<float>(candA);
+    const uint32_t wA = (uA.y & kBwIdMask) | (static_cast<uint32_t>(dep1) << kBwLenShift);
+    if (updA && eB == eA) { rB = nvA; bB = wA; }
+    if (updA && eC == eA) { rC = nvA; bC = wA; }
+    const bool single2 = single || (termA && dep1 == mb);                                // :990
+    // (B) UNK for the start that is over
+    const float candB = unk_score + sbest;                                               // :997-1001, float
+    const bool updB = ended && !single2 && (bB == 0 || candB > rB);
+    const float sbest2 = updB ? candB : rB;
+    const uint32_t finB = updB ? ((static_cast<uint32_t>(mb) << kBwLenShift) | kBwUnk) : bB;
+    // (C) a one-byte piece of the next start
+    const double candC = piece_score(r, 1, max_score) + static_cast<double>(sbest2);
+    const bool updC = termC && (bC == 0 || candC > static_cast<double>(rC));
+    if (updA) { ring_s[oA] = nvA; ring_b[oA] = wA; }
+    if (updC) { ring_s[oC] = static_cast<float>(candC); ring_b[oC] = (r.y & kBwIdMask) | (1u << kBwLenShift); }
+    if (ended) {
+      gb[eB * 64] = finB;                         // position s2 is final
+      // the positions just passed, (s, s2], are dead: free their ring slots (after this iteration's reads and writes)
+      if (mb > 0) ring_b[oB] = 0u;
+      if (mb > 1) ring_b[(static_cast<uint32_t>(s2 - 1) & rm) << 6] = 0u;
+      if (mb > 2) ring_b[(static_cast<uint32_t>(s2 - 2) & rm) << 6] = 0u;
+      if (mb > 3) ring_b[(static_cast<uint32_t>(s2 - 3) & rm) << 6] = 0u;
+    }
+    // ---------------- commit ----------------
+    if (ended) {
+      active = begin;
+      s = s2;
+      mb = begin ? mb2 : 0;
+      sbest = sbest2;
+      single = termC && mb2 == 1;
+      dep = rootC ? 1 : 0;
+      if (begin) {
+        cs = win[static_cast<uint32_t>(s2 + mb2) & wmask];
+        cs1 = win[static_cast<uint32_t>(s2 + mb2 + 1) & wmask];
+        rn = roottab[cs];
+      }
+    } else {
+      dep = dep1;
+      single = single2;
+    }
+    walking = nwalking;
+    c = nc;
+    if (nwalking) cq = win[static_cast<uint32_t>(s + dep + 1) & wmask];
+  }
+  return trips;
+}
+
+// Backtrack (:1010-1018) + id post-processing (sentencepiece_processor.cc:581-613) of this lane's sentence:
+// follows gb[] from position nlen to 0 and writes the ids as it goes, last piece first, into slot[0, cap):
+// forward order fills the slot from its END (ids end up in slot[cap - n, cap)), `reverse` fills it from the start.
+// Returns n, or -1 on a broken chain / overflow.
+SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const uint32_t *gt, const uint32_t *gb, int nlen, int32_t *slot,
+                                 int cap, bool active) {
+  const bool bf = (d.flags & kNfByteFallback) != 0;
+  const bool reverse = (d.flags & kNfReverse) != 0;
+  const uint32_t spb = SpByteOf(d);
+  int e = nlen, n = 0;
+  bool right_unk = false, ok = true;
+  active = active && nlen > 0;
+  while (wv::any(active)) {
+    if (active) {
+      const uint32_t w = gb[e * 64];
+      const int len = static_cast<int>((w >> kBwLenShift) & kBwLenMask);
+      if (len == 0 || len > e) { ok = false; active = false; continue; }
+      const int tb = e - len;
+      if (w & kBwUnk) {
+        if (bf) {                                   // one BYTE id per byte of the unknown piece (:581-603)
+          const bool sp = stream_text_byte(gt, tb) == spb;
+          const int nb = sp ? 3 : len;
+          if (n + nb > cap) { ok = false; active = false; continue; }
+          for (int x = nb - 1; x >= 0; --x) {
+            const uint32_t byte = sp ? (x == 0 ? 0xE2u : (x == 1 ? 0x96u : 0x81u)) : stream_text_byte(gt, tb + x);
+            slot[reverse ? n : cap - 1 - n] = d.byte_ids[byte];
+            ++n;
+          }
+        } else if (!right_unk) {                    // a run of unknown pieces yields one id (:609-613)
+          if (n >= cap) { ok = false; active = false; continue; }
+          slot[reverse ? n : cap - 1 - n] = d.unk_id;
+          ++n;
+        }
+        right_unk = true;
+      } else {
+        right_unk = false;
+        if (n >= cap) { ok = false; active = false; continue; }
+        slot[reverse ? n : cap - 1 - n] = static_cast<int32_t>(w & kBwIdMask);
+        ++n;
+      }
+      e = tb;
+      if (e <= 0) active = false;
+    }
+  }
+  return ok ? n : -1;
+}
+
+// Persistent body of both streaming kernels.
+template <bool FAST>
+SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
+  const int lane = wv::lane();
+  const SpmxDev &d = a.dev;
+  const StreamLds T = carve_stream(smem, FAST, a.rcap, a.ncap, a.ring, wv::wave_in_block());
+  const uint32_t rm = a.ring - 1;
+  const uint32_t W = StreamWindow(a.ring);
+  float *my_rs = T.ring_s + lane;
+  uint32_t *my_rb = T.ring_b + lane;
+  uint8_t *my_win = T.win + static_cast<uint32_t>(lane) * (W + 4u);
+  {   // shared read-only tables; every wave writes all of both (same values): no workgroup barrier
+    const uint32_t root = d.ptrie[0].x >> kDatBaseShiftDev;
+    for (uint32_t cb = static_cast<uint32_t>(lane); cb < 256u; cb += 64u) {
+      U4 r = d.ptrie[root ^ cb];
+      if ((r.x & 0x1FFu) != (0x100u | cb)) r = U4{0, 0, 0, 0};
+      T.roottab[cb] = r;
+      const bool safe = cb < 128u && ((d.ascii_safe[cb >> 5] >> (cb & 31u)) & 1u);
+      T.bcls[cb] = static_cast<uint8_t>(safe ? 0u : kBcComplex);
+    }
+    wv::sync();
+  }
+  const uint32_t count = *a.list_count;
+  const uint32_t wave_id = static_cast<uint32_t>(wv::block_id() * wv::waves_per_block() + wv::wave_in_block());
+  const uint32_t n_waves = static_cast<uint32_t>(wv::grid_size() * wv::waves_per_block());
+  // this wave's scratch slab; tcap = capacity of a text column in bytes
+  const uint32_t tcap = a.stream_tcap;
+  uint32_t *gt = a.stream_text + static_cast<uint64_t>(wave_id) * StreamTextDwords(tcap, a.ring) + static_cast<uint32_t>(lane);
+  uint32_t *gb = a.stream_bp + static_cast<uint64_t>(wave_id) * StreamBpWords(tcap) + static_cast<uint32_t>(lane);
+  // sentences per tile: 64, or fewer when the list is too short to give every wave a full tile
+  uint32_t tw = (count + n_waves - 1) / n_waves;
+  tw = tw < 1u ? 1u : (tw > 64u ? 64u : tw);
+  const uint32_t tiles = (count + tw - 1) / tw;
+  const int n_extra = d.n_prefix + d.n_suffix;
+  TileCounters tc;
+  for (uint32_t tile = wave_id; tile < tiles; tile += n_waves) {
+    const uint32_t first = tile * tw;
+    const int cnt = static_cast<int>(count - first < tw ? count - first : tw);
+    uint32_t my_sid = 0;
+    uint64_t my_beg = 0;
+    uint32_t my_len = 0;
+    bool too_long = false;
+    if (lane < cnt) {
+      my_sid = a.list[first + lane];
+      my_beg = a.offs[my_sid];
+      my_len = static_cast<uint32_t>(a.offs[my_sid + 1] - my_beg);
+      too_long = a.offs[my_sid + 1] - my_beg > a.rcap;                    // only reachable in the last class
+    }
+    const unsigned long long c0 = wv::clock();
+    unsigned long long t_load = 0;
+    bool mine = false;
+    int my_nlen = 0;
+    if (wv::any(too_long)) {
+      uint64_t m = wv::ballot(too_long);
+      while (m) { const int i = wv::ffs64(m) - 1; m &= m - 1; fail_sentence(a, wv::shfl(my_sid, i), kStTooLong, lane); }
+    }
+    if (FAST) {
+      const bool go = lane < cnt && !too_long;
+      int nlen = 0;
+      if (go && my_len > 0) nlen = fast_norm_stream(d, a.text, my_beg, static_cast<int>(my_len), gt, T.bcls);
+      const bool hard = go && nlen < 0;
+      if (go && nlen >= 0) { mine = true; my_nlen = nlen; }
+      const uint64_t hm = wv::ballot(hard);
+      if (hm) {                                 // hand the sentence to the GENERAL kernel of this class
+        const int leader = wv::ffs64(hm) - 1;
+        uint32_t hb = 0;
+        if (lane == leader) hb = wv::atomic_add(a.hard_count, static_cast<uint32_t>(wv::popc64(hm)));
+        hb = wv::shfl(hb, leader);
+        if (hard) a.hard_list[hb + static_cast<uint32_t>(wv::popc64(hm & ((1ull << lane) - 1ull)))] = my_sid;
+      }
+    } else {
+      for (int i = 0; i < cnt; ++i) {
+        const unsigned long long l0 = wv::clock();
+        if (wv::shfl(too_long ? 1 : 0, i)) continue;
+        const uint32_t L = wv::shfl(my_len, i);
+        const uint32_t sid = wv::shfl(my_sid, i);
+        const uint64_t beg = static_cast<uint64_t>(wv::shfl(static_cast<uint32_t>(my_beg >> 32), i)) << 32 |
+                             wv::shfl(static_cast<uint32_t>(my_beg), i);
+        const uint8_t *src = a.text + beg;
+        for (uint32_t p = static_cast<uint32_t>(lane); p < L; p += 64) T.raw[p] = src[p];
+        wv::sync();
+        t_load += wv::clock() - l0;
+        int nlen = 0;
+        if (L > 0) nlen = normalize_wave(d, T.raw, static_cast<int>(L), T.norm, static_cast<int>(a.ncap < tcap ? a.ncap : tcap), lane);
+        wv::sync();
+        if (nlen < 0) {                         // does not fit this class: hand it on (or fail in the last class)
+          if (a.next_list) { if (lane == 0) a.next_list[wv::atomic_add(a.next_count, 1u)] = sid; }
+          else fail_sentence(a, sid, kStTooLong, lane);
+          continue;
+        }
+        // norm[0, nlen) -> lane i's text column, a dword per lane per step
+        uint32_t *col = gt - lane + i;
+        for (int p4 = lane; p4 * 4 < nlen; p4 += 64) col[p4 * 64] = *reinterpret_cast<const uint32_t *>(T.norm + 4 * p4);
+        if (lane == i) { mine = true; my_nlen = nlen; }
+        wv::sync();                             // norm is rewritten by the next sentence
+      }
+    }
+    wv::sync_global();                          // text columns written by other lanes are read below
+    const unsigned long long c1 = wv::clock();
+    tc.cyc[0] += t_load; tc.cyc[1] += (c1 - c0) - t_load;
+    // ---- segment ----
+    tc.n_trips += static_cast<unsigned long long>(
+        unigram_stream_lane(d, gt, gb, my_nlen, my_rs, my_rb, rm, my_win, W - 1u, T.roottab, mine));
+    const unsigned long long c2 = wv::clock();
+    // ---- ids: slot of cap ids per sentence, filled from its end (or from its start when reversing) ----
+    int cap = 0;
+    if (mine) cap = ((d.flags & kNfByteFallback) && (d.flags & kNfCompressSp)) ? 3 * my_nlen : my_nlen;
+    const int room = mine ? cap + n_extra : 0;
+    int total = 0;
+    const int excl = wave_excl_scan(room, lane, &total);
+    unsigned long long base = 0;
+    if (lane == 0 && total > 0) base = wv::atomic_add(a.arena_head, static_cast<unsigned long long>(total));
+    base = (static_cast<unsigned long long>(wv::shfl(static_cast<uint32_t>(base >> 32), 0)) << 32) |
+           wv::shfl(static_cast<uint32_t>(base), 0);
+    const bool overflow = base + static_cast<unsigned long long>(total) > a.arena_cap;
+    bool broken = false;
+    int n = 0;
+    if (overflow) {
+      if (lane == 0) wv::atomic_or(a.status, kStArenaOverflow);
+    } else {
+      int32_t *slot = a.arena + base + static_cast<unsigned long long>(excl) + d.n_prefix;
+      n = emit_stream_lane(d, gt, gb, my_nlen, slot, cap, mine);
+      broken = n < 0;
+      if (broken) n = 0;
+      if (mine && !broken) {
+        const bool reverse = (d.flags & kNfReverse) != 0;
+        int32_t *ids = reverse ? slot : slot + (cap - n);
+        for (int x = 0; x < d.n_prefix; ++x) ids[x - d.n_prefix] = d.prefix_ids[x];
+        for (int x = 0; x < d.n_suffix; ++x) ids[n + x] = d.suffix_ids[x];
+        a.tmp_off[my_sid] = static_cast<unsigned long long>(ids - d.n_prefix - a.arena);
+      }
+    }
+    if (mine) {
+      a.counts[my_sid] = (broken || overflow) ? 0u : static_cast<uint32_t>(n + n_extra);
+      if (broken || overflow) a.tmp_off[my_sid] = 0;
+    }
+    if (wv::any(broken) && lane == 0) wv::atomic_or(a.status, kStInternal);
+    const unsigned long long c3 = wv::clock();
+    if (mine && !broken) { ++tc.n_sent; tc.n_raw += my_len; tc.n_ids += static_cast<unsigned long long>(n + n_extra); }
+    tc.cyc[2] += c2 - c1; tc.cyc[3] += c3 - c2;
+  }
+  if (a.stats) {
+    unsigned long long v[3] = {tc.n_sent, tc.n_raw, tc.n_ids};
+    for (int k = 0; k < 3; ++k) {
+      uint64_t tot = 0;
+      wave_excl_scan64(v[k], lane, &tot);
+      if (lane == 0 && tot) wv::atomic_add(&a.stats[k], static_cast<unsigned long long>(tot));
+    }
+    if (lane == 0) {
+      for (int k = 0; k < 4; ++k) wv::atomic_add(&a.stats[3 + k], tc.cyc[k]);
+      wv::atomic_add(&a.stats[7], tc.n_trips);
+    }
+  }
+}
+
+}  // namespace spmx
+#endif

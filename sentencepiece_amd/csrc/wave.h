@@ -43,6 +43,14 @@ SPMX_DEVICE void sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// As sync(), for HBM: this wave's global stores before the call are visible to every lane's loads after it
+// (all lanes of a wave share one vector L1; the fence drains the store queue).
+SPMX_DEVICE void sync_global() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 SPMX_DEVICE uint32_t atomic_add(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 SPMX_DEVICE unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
 SPMX_DEVICE void atomic_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }

@@ -257,13 +257,13 @@ class SentencePieceProcessor:
         """Per kernel slot (length class; GENERAL tile kernels after a FAST one sit in the last slots):
         dict(kernel, kernel_ms, sentences, raw_bytes, ids, bytes, rcap, phase_cycles) + total_ms."""
         self._need()
-        ms = np.zeros(8, dtype=np.float32)
-        sent, raw, ids, byt = (np.zeros(8, dtype=np.uint64) for _ in range(4))
-        rcap = np.zeros(8, dtype=np.uint32)
+        ms = np.zeros(16, dtype=np.float32)
+        sent, raw, ids, byt = (np.zeros(16, dtype=np.uint64) for _ in range(4))
+        rcap = np.zeros(16, dtype=np.uint32)
         tot = C.c_float(0)
         k = self._lib.spmx_last_profile(self._h, ms.ctypes.data, sent.ctypes.data, raw.ctypes.data, ids.ctypes.data,
                                         byt.ctypes.data, rcap.ctypes.data, C.byref(tot))
-        cyc = np.zeros(40, dtype=np.uint64)
+        cyc = np.zeros(80, dtype=np.uint64)
         self._lib.spmx_last_phase_cycles(self._h, cyc.ctypes.data)
         names = []
         for c in range(k):

@@ -205,7 +205,7 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
   ca.lists = lists.data(); ca.list_counts = list_counts.data();
   for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { classify_block(ca); });
   const uint64_t text_bytes = offs[n];
-  std::vector<int32_t> arena(text_bytes + (2 + dev.n_prefix + dev.n_suffix) * n + 64);
+  std::vector<int32_t> arena(4 * text_bytes + (8 + dev.n_prefix + dev.n_suffix) * n + 64);
   unsigned long long arena_head = 0;
   uint32_t status = 0;
   unsigned long long stats[kStatsPerClass * kMaxClasses] = {0};
@@ -218,12 +218,36 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
     a.arena = arena.data(); a.arena_head = &arena_head; a.arena_cap = arena.size();
     a.tmp_off = tmp_off.data(); a.counts = counts.data(); a.status = &status; a.stats = &stats[kStatsPerClass * c];
     a.rcap = cls[c].rcap; a.ncap = cls[c].ncap;
-    // tile form for the first unigram classes, as in csrc/api.cc (small areas here to exercise the rounds):
-    // the FAST kernel first (when the model allows it), then the GENERAL kernel on what it left over
+    a.ring = 16;
+    while (a.ring < static_cast<uint32_t>(h->tables.max_piece_len) + 1) a.ring <<= 1;
+    // streaming form for every unigram class, as in csrc/api.cc: the FAST kernel first (when the model allows
+    // it), then the GENERAL kernel on what it left over.  SPMX_NO_STREAM: tile / sentence-per-wave forms.
+    if (!bpe && !getenv("SPMX_NO_STREAM")) {
+      std::vector<uint32_t> hard(n ? n : 1);
+      uint32_t hard_count = 0;
+      const int waves = grid;   // one wave per block in the emulator
+      if (StreamFastEligible(dev.flags) && !getenv("SPMX_NO_FAST")) {
+        a.hard_list = hard.data(); a.hard_count = &hard_count;
+        a.stream_tcap = a.rcap + 1;
+        std::vector<uint32_t> st(StreamTextDwords(a.stream_tcap, a.ring) * waves, 0xCDCDCDCDu), sb(StreamBpWords(a.stream_tcap) * waves, 0xCDCDCDCDu);
+        a.stream_text = st.data(); a.stream_bp = sb.data();
+        std::vector<unsigned char> fsmem(StreamLdsBytes(true, a.rcap, a.ncap, a.ring, 1) + 64, 0xCD);
+        for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, fsmem.data(), [&] { encode_stream_block<true>(a, fsmem.data()); });
+        g_fast_kept += list_counts[c] - hard_count;
+        g_fast_handed += hard_count;
+        a.list = hard.data(); a.list_count = &hard_count;
+        a.hard_list = nullptr; a.hard_count = nullptr;
+      }
+      a.stream_tcap = a.ncap;
+      std::vector<uint32_t> st(StreamTextDwords(a.stream_tcap, a.ring) * waves, 0xCDCDCDCDu), sb(StreamBpWords(a.stream_tcap) * waves, 0xCDCDCDCDu);
+      a.stream_text = st.data(); a.stream_bp = sb.data();
+      std::vector<unsigned char> gsmem(StreamLdsBytes(false, a.rcap, a.ncap, a.ring, 1) + 64, 0xCD);
+      for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, gsmem.data(), [&] { encode_stream_block<false>(a, gsmem.data()); });
+      continue;
+    }
+    // tile form for the first unigram classes (small areas here to exercise the rounds)
     const bool tile = !bpe && c < 3 && !getenv("SPMX_NO_TILE");
     if (tile) {
-      a.ring = 16;
-      while (a.ring < static_cast<uint32_t>(h->tables.max_piece_len) + 1) a.ring <<= 1;
       a.tile_area = c == 0 ? 512 : (c == 1 ? 4096 : 6144);
       if (a.tile_area < 2 * a.ncap + 1) a.tile_area = 2 * a.ncap + 1;
       if (a.tile_area < 2 * (a.rcap + 1) + 1) a.tile_area = 2 * (a.rcap + 1) + 1;

@@ -86,6 +86,7 @@ inline int shfl_up(int v, int delta) {
   return static_cast<int>(static_cast<uint32_t>(emu::Collective(emu::kShflUp, static_cast<uint32_t>(v), static_cast<uint64_t>(delta))));
 }
 inline void sync() { emu::Collective(emu::kSync, 0, 0); }
+inline void sync_global() { emu::Collective(emu::kSync, 0, 0); }
 
 inline uint32_t atomic_add(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
 inline unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { const unsigned long long o = *p; *p = o + v; return o; }
