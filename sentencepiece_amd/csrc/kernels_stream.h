@@ -13,9 +13,12 @@
 // Per lane, in HBM scratch (one slab per wavefront, position-major so that the
 // lanes of a wave, which advance at similar speeds, touch the same lines):
 //   * the normalized text, as dwords   text[pos >> 2][lane];
-//   * the FINAL back-pointer word of every character start   bp[pos][lane],
-//     stored once, when the start reaches that position (all candidates into a
-//     position are folded before any piece starting there is scored, :960-1008).
+//   * the FINAL back-pointer word of every character start   bp[lane][pos]: a
+//     position is final when the start reaches it (all candidates into a
+//     position are folded before any piece starting there is scored,
+//     :960-1008); final words are staged in LDS and leave for HBM as whole
+//     32-byte blocks of 8 positions (a 4-byte store per position dirtied a
+//     32-byte sector each: measured 9x write amplification, profiles/).
 // The backtrack (:1010-1018) follows bp[] from the end and writes ids straight
 // into the arena, last piece first.
 //
@@ -40,12 +43,13 @@ struct StreamLds {
   float *ring_s;      // [R][64]
   uint32_t *ring_b;   // [R][64]
   uint8_t *win;       // [64][W + 4]: lane l's window starts at win + l * (W + 4)
+  uint32_t *stage;    // [2][64][4]: final back-pointer words of the lane's current block of 8 positions
 };
 
 SPMX_HD inline uint32_t StreamWindow(uint32_t ring) { return 2u * ring; }
 SPMX_HD inline uint32_t StreamPrivateBytes(bool fast, uint32_t rcap, uint32_t ncap, uint32_t ring) {
   const uint32_t stage = fast ? 0u : (((rcap + 16 + 15) & ~15u) + ((ncap + 16 + 15) & ~15u));
-  return stage + 64u * ring * 8u + 64u * (StreamWindow(ring) + 4u);
+  return stage + 64u * ring * 8u + 64u * (StreamWindow(ring) + 4u) + 2u * 64u * 16u;
 }
 SPMX_HD inline uint32_t StreamLdsBytes(bool fast, uint32_t rcap, uint32_t ncap, uint32_t ring, uint32_t waves) {
   return kTileSharedBytes + waves * StreamPrivateBytes(fast, rcap, ncap, ring);
@@ -54,7 +58,8 @@ SPMX_HD inline uint32_t StreamLdsBytes(bool fast, uint32_t rcap, uint32_t ncap, 
 SPMX_HD inline uint64_t StreamTextDwords(uint32_t tcap, uint32_t ring) {      // uint32 [dw][64]
   return (static_cast<uint64_t>(tcap + 3) / 4 + StreamWindow(ring) / 4 + 4) * 64u;
 }
-SPMX_HD inline uint64_t StreamBpWords(uint32_t tcap) { return (static_cast<uint64_t>(tcap) + 2) * 64u; }   // uint32 [pos][64]
+SPMX_HD inline uint32_t StreamBpStride(uint32_t tcap) { return (tcap + 16u) & ~7u; }   // words per lane, whole blocks of 8
+SPMX_HD inline uint64_t StreamBpWords(uint32_t tcap) { return static_cast<uint64_t>(StreamBpStride(tcap)) * 64u; }   // uint32 [lane][stride]
 
 SPMX_DEVICE StreamLds carve_stream(unsigned char *base, bool fast, uint32_t rcap, uint32_t ncap, uint32_t ring, int wave) {
   StreamLds t;
@@ -67,6 +72,7 @@ SPMX_DEVICE StreamLds carve_stream(unsigned char *base, bool fast, uint32_t rcap
   t.ring_s = reinterpret_cast<float *>(mine);
   t.ring_b = reinterpret_cast<uint32_t *>(mine + 64u * ring * 4u);
   t.win = mine + 64u * ring * 8u;
+  t.stage = reinterpret_cast<uint32_t *>(t.win + 64u * (StreamWindow(ring) + 4u));
   return t;
 }
 
@@ -137,12 +143,14 @@ SPMX_DEVICE uint32_t stream_text_byte(const uint32_t *gt, int pos) {
 //     window at the top of the next iteration, by which time the probe wait has covered it;
 //   * best_path_ends_at lives in the rings only: ring_s / ring_b slot of position e is [(e & rm) * 64];
 //     ring_b == 0 means "not reached" (:984);
-//   * when the start moves from s to s2, position s2's back-pointer word is final: it is stored to gb[s2 * 64],
-//     and the ring slots of the positions (s, s2] are cleared for the positions that will reuse them R later.
+//   * when the start moves from s to s2, position s2's back-pointer word is final: it goes to the lane's staging
+//     block st[] (position p at st[((p >> 2) & 1) * 256 + (p & 3)]), the block of 8 positions that s2 leaves behind
+//     is written to gb[] as two 16-byte stores, and the ring slots of the positions (s, s2] are cleared for the
+//     positions that will reuse them R later.  gb[] is this lane's row: gb[p] for position p.
 // Returns the number of iterations (wave-uniform).
 SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const uint32_t *gt, uint32_t *gb, int nlen, float *ring_s,
-                                    uint32_t *ring_b, uint32_t rm, uint8_t *win, uint32_t wmask, const U4 *roottab,
-                                    bool active_in) {
+                                    uint32_t *ring_b, uint32_t rm, uint8_t *win, uint32_t wmask, uint32_t *st,
+                                    const U4 *roottab, bool active_in) {
   const U4 *__restrict__ ptrie = d.ptrie;
   const float unk_score = d.unk_score, max_score = d.max_score;
   const uint32_t spb = SpByteOf(d);
@@ -223,7 +231,13 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const uint32_t *gt, uint32
     if (updA) { ring_s[oA] = nvA; ring_b[oA] = wA; }
     if (updC) { ring_s[oC] = static_cast<float>(candC); ring_b[oC] = (r.y & kBwIdMask) | (1u << kBwLenShift); }
     if (ended) {
-      gb[eB * 64] = finB;                         // position s2 is final
+      if ((s2 >> 3) != (s >> 3)) {                // the block of 8 positions behind s2 is complete
+        const Q4 lo = *reinterpret_cast<const Q4 *>(st), hi = *reinterpret_cast<const Q4 *>(st + 256);
+        uint32_t *blk = gb + ((s >> 3) << 3);
+        *reinterpret_cast<Q4 *>(blk) = lo;
+        *reinterpret_cast<Q4 *>(blk + 4) = hi;
+      }
+      st[((static_cast<uint32_t>(eB) >> 2) & 1u) * 256u + (static_cast<uint32_t>(eB) & 3u)] = finB;   // position s2 is final
       // the positions just passed, (s, s2], are dead: free their ring slots (after this iteration's reads and writes)
       if (mb > 0) ring_b[oB] = 0u;
       if (mb > 1) ring_b[(static_cast<uint32_t>(s2 - 1) & rm) << 6] = 0u;
@@ -251,11 +265,17 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const uint32_t *gt, uint32
     c = nc;
     if (nwalking) cq = win[static_cast<uint32_t>(s + dep + 1) & wmask];
   }
+  if (active_in && nlen > 0) {                    // the last block (it holds position nlen)
+    const Q4 lo = *reinterpret_cast<const Q4 *>(st), hi = *reinterpret_cast<const Q4 *>(st + 256);
+    uint32_t *blk = gb + ((nlen >> 3) << 3);
+    *reinterpret_cast<Q4 *>(blk) = lo;
+    *reinterpret_cast<Q4 *>(blk + 4) = hi;
+  }
   return trips;
 }
 
 // Backtrack (:1010-1018) + id post-processing (sentencepiece_processor.cc:581-613) of this lane's sentence:
-// follows gb[] from position nlen to 0 and writes the ids as it goes, last piece first, into slot[0, cap):
+// follows the lane's row gb[] from position nlen to 0 and writes the ids as it goes, last piece first, into slot[0, cap):
 // forward order fills the slot from its END (ids end up in slot[cap - n, cap)), `reverse` fills it from the start.
 // Returns n, or -1 on a broken chain / overflow.
 SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const uint32_t *gt, const uint32_t *gb, int nlen, int32_t *slot,
@@ -268,7 +288,7 @@ SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const uint32_t *gt, const uin
   active = active && nlen > 0;
   while (wv::any(active)) {
     if (active) {
-      const uint32_t w = gb[e * 64];
+      const uint32_t w = gb[e];
       const int len = static_cast<int>((w >> kBwLenShift) & kBwLenMask);
       if (len == 0 || len > e) { ok = false; active = false; continue; }
       const int tb = e - len;
@@ -329,7 +349,8 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
   // this wave's scratch slab; tcap = capacity of a text column in bytes
   const uint32_t tcap = a.stream_tcap;
   uint32_t *gt = a.stream_text + static_cast<uint64_t>(wave_id) * StreamTextDwords(tcap, a.ring) + static_cast<uint32_t>(lane);
-  uint32_t *gb = a.stream_bp + static_cast<uint64_t>(wave_id) * StreamBpWords(tcap) + static_cast<uint32_t>(lane);
+  uint32_t *gb = a.stream_bp + static_cast<uint64_t>(wave_id) * StreamBpWords(tcap) + static_cast<uint32_t>(lane) * StreamBpStride(tcap);
+  uint32_t *my_st = T.stage + static_cast<uint32_t>(lane) * 4u;
   // sentences per tile: 64, or fewer when the list is too short to give every wave a full tile
   uint32_t tw = (count + n_waves - 1) / n_waves;
   tw = tw < 1u ? 1u : (tw > 64u ? 64u : tw);
@@ -403,7 +424,7 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     tc.cyc[0] += t_load; tc.cyc[1] += (c1 - c0) - t_load;
     // ---- segment ----
     tc.n_trips += static_cast<unsigned long long>(
-        unigram_stream_lane(d, gt, gb, my_nlen, my_rs, my_rb, rm, my_win, W - 1u, T.roottab, mine));
+        unigram_stream_lane(d, gt, gb, my_nlen, my_rs, my_rb, rm, my_win, W - 1u, my_st, T.roottab, mine));
     const unsigned long long c2 = wv::clock();
     // ---- ids: slot of cap ids per sentence, filled from its end (or from its start when reversing) ----
     int cap = 0;
