@@ -38,7 +38,8 @@ std::string g_create_error;
 // ctrl block layout (device + pinned host mirror), zeroed before every call
 struct Ctrl {
   uint32_t list_counts[kMaxClasses];
-  uint32_t hard_counts[kMaxClasses];   // tile classes: sentences the FAST kernel left to the GENERAL kernel
+  uint32_t hard_counts[kMaxClasses];   // sentences a FAST kernel left to the GENERAL kernel of its class
+  uint32_t wave_counts[kMaxClasses];   // BPE: sentences the streaming kernels left to the sentence-per-wave kernel
   uint32_t status;
   uint32_t pad;
   unsigned long long arena_head;
@@ -214,11 +215,12 @@ struct StreamPlan {
   uint64_t text_words = 0, scratch_words = 0;
 };
 StreamPlan PlanStream(const spmx_handle *h, const LengthClass &lc, bool fast, uint64_t known) {
+  const int model = h->model.model_type;
   StreamPlan sp;
   const uint32_t ring = TileRing(h->tables.max_piece_len);
   // a FAST text column never exceeds raw length + 1 (one-byte space symbol); GENERAL: the class's normalized capacity
   sp.tcap = fast ? lc.rcap + 1 : lc.ncap;
-  const uint32_t priv = StreamPrivateBytes(fast, lc.rcap, lc.ncap, ring);
+  const uint32_t priv = StreamPrivateBytes(fast, model, lc.rcap, lc.ncap, ring);
   int waves = static_cast<int>((kLdsPerCu - kTileSharedBytes) / priv);
   const int wmax = fast ? 16 : 8;   // __launch_bounds__ of the two kernels
   if (waves > wmax) waves = wmax;
@@ -233,7 +235,7 @@ StreamPlan PlanStream(const spmx_handle *h, const LengthClass &lc, bool fast, ui
   if (grid < 1) grid = 1;
   sp.grid = static_cast<int>(grid);
   sp.waves = waves;
-  sp.lds = StreamLdsBytes(fast, lc.rcap, lc.ncap, ring, static_cast<uint32_t>(waves));
+  sp.lds = StreamLdsBytes(fast, model, lc.rcap, lc.ncap, ring, static_cast<uint32_t>(waves));
   sp.text_words = grid * waves * StreamTextDwords(sp.tcap, ring);
   sp.scratch_words = grid * waves * per_wave;
   return sp;
@@ -253,7 +255,7 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
   }
   const int ncls = NumClasses(h);
   const LengthClass *cls = Classes(h);
-  HIP_OR_RETURN(h, h->d_lists.Reserve(static_cast<size_t>(2 * ncls) * n));   // class lists + FAST hand-over lists
+  HIP_OR_RETURN(h, h->d_lists.Reserve(static_cast<size_t>(3 * ncls) * n));   // class lists + two hand-over lists each
   HIP_OR_RETURN(h, h->d_counts.Reserve(n + 1));
   HIP_OR_RETURN(h, h->d_tmp_off.Reserve(n + 1));
   HIP_OR_RETURN(h, h->d_tile_sums.Reserve((n + kScanTile - 1) / kScanTile + 2));
@@ -283,7 +285,9 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
       const uint32_t tiles = (n32 + 63) / 64;
       HIP_OR_RETURN(h, LaunchClassify(ca, static_cast<int>(tiles < static_cast<uint32_t>(wide) ? tiles : wide), stream));
     }
-    const bool streaming = h->model.model_type == kUnigram && !h->no_stream;
+    // streaming (lane-per-sentence) kernels: every unigram model; BPE models that can be segmented word by word
+    const bool bpe_stream = h->model.model_type == kBpe && (h->dev.flags & kNfBpeWordwise) && !(h->dev.flags & kNfHasUnused);
+    const bool streaming = (h->model.model_type == kUnigram || bpe_stream) && !h->no_stream;
     uint32_t known[kMaxClasses] = {0};   // class sizes after classify (escalations from a GENERAL kernel come on top)
     if (streaming) {
       HIP_OR_RETURN(h, hipMemcpyAsync(h->h_ctrl->list_counts, h->d_ctrl->list_counts, sizeof(h->h_ctrl->list_counts),
@@ -335,13 +339,34 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
           a.stream_bp = h->d_stream.p + sp.text_words;
           const int slot = (fast && !is_fast) ? kSlotGeneral + c : c;
           a.stats = &h->d_ctrl->stats[kStatsPerClass * slot];
-          snprintf(h->slot_name[slot], sizeof(h->slot_name[slot]), "EncodeStreamKernel<%d, %s>", c, is_fast ? "true" : "false");
+          a.wave_list = h->d_lists.p + static_cast<size_t>(2 * ncls + c) * n;
+          a.wave_count = &h->d_ctrl->wave_counts[c];
+          snprintf(h->slot_name[slot], sizeof(h->slot_name[slot]), "Encode%sStreamKernel<%d, %s>", bpe_stream ? "Bpe" : "", c,
+                   is_fast ? "true" : "false");
           if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[slot][0], stream));
-          HIP_OR_RETURN(h, LaunchEncodeStream(c, is_fast, a, sp.grid, sp.waves, sp.lds, stream));
+          HIP_OR_RETURN(h, LaunchEncodeStream(h->model.model_type, c, is_fast, a, sp.grid, sp.waves, sp.lds, stream));
           if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[slot][1], stream));
           h->slot_used[slot] = true;
         }
         prev_general = true;
+        if (bpe_stream) {   // what the lane form could not take (a word longer than kBpeWordMax): sentence per wave
+          a.list = h->d_lists.p + static_cast<size_t>(2 * ncls + c) * n;
+          a.list_count = &h->d_ctrl->wave_counts[c];
+          const int slot = kMaxClasses / 2 + c;
+          a.stats = &h->d_ctrl->stats[kStatsPerClass * slot];
+          snprintf(h->slot_name[slot], sizeof(h->slot_name[slot]), "EncodeKernel<2, %d>", c);
+          const uint32_t lds = EncodeLdsBytes(kBpe, a.rcap, a.ncap);
+          int per_cu = static_cast<int>(kLdsPerCu / lds);
+          if (per_cu > 32) per_cu = 32;
+          if (per_cu < 1) per_cu = 1;
+          uint64_t grid = static_cast<uint64_t>(h->n_cu) * per_cu;
+          const uint64_t most = known[c] > 64 ? known[c] : 64;
+          if (grid > most) grid = most;
+          if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[slot][0], stream));
+          HIP_OR_RETURN(h, LaunchEncode(kBpe, c, a, static_cast<int>(grid), lds, stream));
+          if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[slot][1], stream));
+          h->slot_used[slot] = true;
+        }
         continue;
       }
       const bool tile = h->model.model_type == kUnigram && c < kNumTileClasses && !h->no_tile;
@@ -426,7 +451,7 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
         p.raw_bytes[c] = s[1];
         p.ids[c] = s[2];
         for (int k = 0; k < 5; ++k) p.cycles[c][k] = s[3 + k];
-        p.rcap[c] = cls[c < kSlotGeneral ? c : c - kSlotGeneral].rcap;
+        p.rcap[c] = cls[(c < kSlotGeneral ? c : c - kSlotGeneral) % ncls].rcap;
       }
       HIP_OR_RETURN(h, hipEventElapsedTime(&p.total_ms, h->ev[kMaxSlots][0], h->ev[kMaxSlots][1]));
     }

@@ -27,9 +27,13 @@ enum : uint32_t {
   kNfReverse = 1u << 6,      // net effect of the extra options (see tables.cc)
   kNfHasUserDefined = 1u << 7,
   kNfHasUnused = 1u << 8,    // some piece is currently UNUSED (BPE resegmentation armed)
-  // unigram only: the space symbol U+2581 (E2 96 81) is ONE byte, kSpByte, in the normalized text held in LDS and
+  // the space symbol U+2581 (E2 96 81) is ONE byte, kSpByte, in the normalized text held in LDS and
   // in the keys of the piece trie (tables.cc decides; ids do not depend on the encoding of the text)
   kNfCompressSp = 1u << 9,
+  // BPE only: no piece has U+2581 after its first character (and kNfCompressSp holds, no whitespace-as-suffix, no
+  // user-defined symbols), so no merge ever joins two whitespace-delimited words and a sentence can be segmented
+  // word by word (kernels_bpe_stream.h)
+  kNfBpeWordwise = 1u << 10,
 };
 
 // One-byte stand-in for U+2581 under kNfCompressSp.  0xFF never occurs in valid UTF-8, and the normalizer's

@@ -51,6 +51,8 @@ struct EncodeArgs {
   uint32_t *stream_text;        // [waves][StreamTextDwords(stream_tcap, ring)]
   uint32_t *stream_bp;          // [waves][StreamBpWords(stream_tcap)]
   uint32_t stream_tcap;         // bytes a text column holds
+  uint32_t *wave_list;          // BPE streaming kernels: sentences they leave to the sentence-per-wave kernel
+  uint32_t *wave_count;
 };
 
 constexpr int kStatsPerClass = 8;
@@ -767,6 +769,7 @@ SPMX_DEVICE void compact_block(const CompactArgs &a) {
 }  // namespace spmx
 
 #include "kernels_tile.h"
+#include "kernels_bpe_stream.h"
 #include "kernels_stream.h"
 
 #endif

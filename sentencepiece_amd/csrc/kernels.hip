@@ -25,7 +25,12 @@ __global__ __launch_bounds__(FAST ? 1024 : 512) void EncodeTileKernel(EncodeArgs
 template <int CLS, bool FAST>
 __global__ __launch_bounds__(FAST ? 1024 : 512) void EncodeStreamKernel(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  encode_stream_block<FAST>(a, smem);
+  encode_stream_block<FAST, 1>(a, smem);
+}
+template <int CLS, bool FAST>
+__global__ __launch_bounds__(FAST ? 1024 : 512) void EncodeBpeStreamKernel(EncodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  encode_stream_block<FAST, 2>(a, smem);
 }
 
 __global__ __launch_bounds__(64) void ClassifyKernel(ClassifyArgs a) { classify_block(a); }
@@ -84,11 +89,21 @@ EncodeFn PickStream(int cls) {
     default: return EncodeStreamKernel<4, FAST>;
   }
 }
+template <bool FAST>
+EncodeFn PickBpeStream(int cls) {
+  switch (cls) {
+    case 0: return EncodeBpeStreamKernel<0, FAST>;
+    case 1: return EncodeBpeStreamKernel<1, FAST>;
+    case 2: return EncodeBpeStreamKernel<2, FAST>;
+    default: return EncodeBpeStreamKernel<3, FAST>;
+  }
+}
 }  // namespace
 
-hipError_t LaunchEncodeStream(int cls, bool fast, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes,
-                              hipStream_t stream) {
-  EncodeFn fn = fast ? PickStream<true>(cls) : PickStream<false>(cls);
+hipError_t LaunchEncodeStream(int model_type, int cls, bool fast, const EncodeArgs &a, int grid, int waves,
+                              uint32_t lds_bytes, hipStream_t stream) {
+  EncodeFn fn = model_type == 2 ? (fast ? PickBpeStream<true>(cls) : PickBpeStream<false>(cls))
+                                : (fast ? PickStream<true>(cls) : PickStream<false>(cls));
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds_bytes));

@@ -124,7 +124,7 @@ SPMX_DEVICE bool bpe_wave(const EncodeArgs &a, const uint8_t *norm, int nlen, in
     int step = 1;
     if (valid) {
       if (uds_len > 0) step = uds_len;
-      else { step = OneCharLenDev(norm[p]); if (step > nlen - p) step = nlen - p; }
+      else { step = norm[p] == SpByteOf(d) ? 1 : OneCharLenDev(norm[p]); if (step > nlen - p) step = nlen - p; }
     }
     const uint64_t S = resolve_chain(b, step, valid, &next_start);
     if (valid) {

@@ -44,15 +44,21 @@ struct StreamLds {
   uint32_t *ring_b;   // [R][64]
   uint8_t *win;       // [64][W + 4]: lane l's window starts at win + l * (W + 4)
   uint32_t *stage;    // [2][64][4]: final back-pointer words of the lane's current block of 8 positions
+  // BPE (kernels_bpe_stream.h) instead of the rings / window / staging block:
+  uint32_t *asym;     // [256] symbol of every one-byte character (shared, aliases roottab)
+  BpeWordLds bw;      // the lane's current word
 };
 
 SPMX_HD inline uint32_t StreamWindow(uint32_t ring) { return 2u * ring; }
-SPMX_HD inline uint32_t StreamPrivateBytes(bool fast, uint32_t rcap, uint32_t ncap, uint32_t ring) {
+// model: 1 unigram, 2 BPE
+SPMX_HD inline uint32_t StreamPrivateBytes(bool fast, int model, uint32_t rcap, uint32_t ncap, uint32_t ring) {
   const uint32_t stage = fast ? 0u : (((rcap + 16 + 15) & ~15u) + ((ncap + 16 + 15) & ~15u));
-  return stage + 64u * ring * 8u + 64u * (StreamWindow(ring) + 4u) + 2u * 64u * 16u;
+  const uint32_t work = model == 2 ? BpeWordLdsBytes()
+                                   : 64u * ring * 8u + 64u * (StreamWindow(ring) + 4u) + 2u * 64u * 16u;
+  return stage + work;
 }
-SPMX_HD inline uint32_t StreamLdsBytes(bool fast, uint32_t rcap, uint32_t ncap, uint32_t ring, uint32_t waves) {
-  return kTileSharedBytes + waves * StreamPrivateBytes(fast, rcap, ncap, ring);
+SPMX_HD inline uint32_t StreamLdsBytes(bool fast, int model, uint32_t rcap, uint32_t ncap, uint32_t ring, uint32_t waves) {
+  return kTileSharedBytes + waves * StreamPrivateBytes(fast, model, rcap, ncap, ring);
 }
 // HBM scratch of one wavefront for a class whose normalized sentences have at most tcap bytes
 SPMX_HD inline uint64_t StreamTextDwords(uint32_t tcap, uint32_t ring) {      // uint32 [dw][64]
@@ -61,11 +67,13 @@ SPMX_HD inline uint64_t StreamTextDwords(uint32_t tcap, uint32_t ring) {      //
 SPMX_HD inline uint32_t StreamBpStride(uint32_t tcap) { return (tcap + 16u) & ~7u; }   // words per lane, whole blocks of 8
 SPMX_HD inline uint64_t StreamBpWords(uint32_t tcap) { return static_cast<uint64_t>(StreamBpStride(tcap)) * 64u; }   // uint32 [lane][stride]
 
-SPMX_DEVICE StreamLds carve_stream(unsigned char *base, bool fast, uint32_t rcap, uint32_t ncap, uint32_t ring, int wave) {
+SPMX_DEVICE StreamLds carve_stream(unsigned char *base, bool fast, int model, uint32_t rcap, uint32_t ncap, uint32_t ring,
+                                   int wave) {
   StreamLds t;
   t.roottab = reinterpret_cast<U4 *>(base);
+  t.asym = reinterpret_cast<uint32_t *>(base);
   t.bcls = base + 256u * 16u;
-  unsigned char *mine = base + kTileSharedBytes + static_cast<uint32_t>(wave) * StreamPrivateBytes(fast, rcap, ncap, ring);
+  unsigned char *mine = base + kTileSharedBytes + static_cast<uint32_t>(wave) * StreamPrivateBytes(fast, model, rcap, ncap, ring);
   t.raw = mine;
   t.norm = mine + ((rcap + 16 + 15) & ~15u);
   if (!fast) mine += ((rcap + 16 + 15) & ~15u) + ((ncap + 16 + 15) & ~15u);
@@ -73,6 +81,9 @@ SPMX_DEVICE StreamLds carve_stream(unsigned char *base, bool fast, uint32_t rcap
   t.ring_b = reinterpret_cast<uint32_t *>(mine + 64u * ring * 4u);
   t.win = mine + 64u * ring * 8u;
   t.stage = reinterpret_cast<uint32_t *>(t.win + 64u * (StreamWindow(ring) + 4u));
+  t.bw.sym = reinterpret_cast<uint32_t *>(mine);
+  t.bw.pair = reinterpret_cast<U2 *>(mine + kBpeWordMax * 64u * 4u);
+  t.bw.len = mine + kBpeWordMax * 64u * 12u;
   return t;
 }
 
@@ -129,11 +140,6 @@ SPMX_DEVICE int fast_norm_stream(const SpmxDev &d, const uint8_t *gtext, uint64_
 
 SPMX_HD inline bool StreamFastEligible(uint32_t flags) {
   return TileFastEligible(flags) && !((flags & kNfAddDummyPrefix) && (flags & kNfWsSuffix));
-}
-
-// Byte pos of this lane's text column.
-SPMX_DEVICE uint32_t stream_text_byte(const uint32_t *gt, int pos) {
-  return (gt[(pos >> 2) * 64] >> (8 * (pos & 3))) & 0xFFu;
 }
 
 // EncodeOptimized for this lane's sentence (see unigram_lane in kernels_tile.h for the flattened loop and its
@@ -321,23 +327,27 @@ SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const uint32_t *gt, const uin
   return ok ? n : -1;
 }
 
-// Persistent body of both streaming kernels.
-template <bool FAST>
+// Persistent body of the streaming kernels.  MODEL: 1 unigram, 2 BPE (word-wise models only).
+template <bool FAST, int MODEL>
 SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
   const int lane = wv::lane();
   const SpmxDev &d = a.dev;
-  const StreamLds T = carve_stream(smem, FAST, a.rcap, a.ncap, a.ring, wv::wave_in_block());
+  const StreamLds T = carve_stream(smem, FAST, MODEL, a.rcap, a.ncap, a.ring, wv::wave_in_block());
   const uint32_t rm = a.ring - 1;
   const uint32_t W = StreamWindow(a.ring);
   float *my_rs = T.ring_s + lane;
   uint32_t *my_rb = T.ring_b + lane;
   uint8_t *my_win = T.win + static_cast<uint32_t>(lane) * (W + 4u);
   {   // shared read-only tables; every wave writes all of both (same values): no workgroup barrier
-    const uint32_t root = d.ptrie[0].x >> kDatBaseShiftDev;
+    const uint32_t root = MODEL == 1 ? d.ptrie[0].x >> kDatBaseShiftDev : 0u;
     for (uint32_t cb = static_cast<uint32_t>(lane); cb < 256u; cb += 64u) {
-      U4 r = d.ptrie[root ^ cb];
-      if ((r.x & 0x1FFu) != (0x100u | cb)) r = U4{0, 0, 0, 0};
-      T.roottab[cb] = r;
+      if (MODEL == 1) {
+        U4 r = d.ptrie[root ^ cb];
+        if ((r.x & 0x1FFu) != (0x100u | cb)) r = U4{0, 0, 0, 0};
+        T.roottab[cb] = r;
+      } else {
+        T.asym[cb] = char_lookup(d, cb, 1u);
+      }
       const bool safe = cb < 128u && ((d.ascii_safe[cb >> 5] >> (cb & 31u)) & 1u);
       T.bcls[cb] = static_cast<uint8_t>(safe ? 0u : kBcComplex);
     }
@@ -422,11 +432,7 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     wv::sync_global();                          // text columns written by other lanes are read below
     const unsigned long long c1 = wv::clock();
     tc.cyc[0] += t_load; tc.cyc[1] += (c1 - c0) - t_load;
-    // ---- segment ----
-    tc.n_trips += static_cast<unsigned long long>(
-        unigram_stream_lane(d, gt, gb, my_nlen, my_rs, my_rb, rm, my_win, W - 1u, my_st, T.roottab, mine));
-    const unsigned long long c2 = wv::clock();
-    // ---- ids: slot of cap ids per sentence, filled from its end (or from its start when reversing) ----
+    // ---- a slot of cap ids per sentence in the arena ----
     int cap = 0;
     if (mine) cap = ((d.flags & kNfByteFallback) && (d.flags & kNfCompressSp)) ? 3 * my_nlen : my_nlen;
     const int room = mine ? cap + n_extra : 0;
@@ -437,22 +443,44 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     base = (static_cast<unsigned long long>(wv::shfl(static_cast<uint32_t>(base >> 32), 0)) << 32) |
            wv::shfl(static_cast<uint32_t>(base), 0);
     const bool overflow = base + static_cast<unsigned long long>(total) > a.arena_cap;
-    bool broken = false;
+    if (overflow && lane == 0) wv::atomic_or(a.status, kStArenaOverflow);
+    int32_t *slot = a.arena + base + static_cast<unsigned long long>(excl) + d.n_prefix;
+    bool broken = false, handed = false;
     int n = 0;
-    if (overflow) {
-      if (lane == 0) wv::atomic_or(a.status, kStArenaOverflow);
-    } else {
-      int32_t *slot = a.arena + base + static_cast<unsigned long long>(excl) + d.n_prefix;
-      n = emit_stream_lane(d, gt, gb, my_nlen, slot, cap, mine);
-      broken = n < 0;
-      if (broken) n = 0;
-      if (mine && !broken) {
-        const bool reverse = (d.flags & kNfReverse) != 0;
-        int32_t *ids = reverse ? slot : slot + (cap - n);
-        for (int x = 0; x < d.n_prefix; ++x) ids[x - d.n_prefix] = d.prefix_ids[x];
-        for (int x = 0; x < d.n_suffix; ++x) ids[n + x] = d.suffix_ids[x];
-        a.tmp_off[my_sid] = static_cast<unsigned long long>(ids - d.n_prefix - a.arena);
+    bool at_end = false;      // the ids sit at the end of the slot
+    unsigned long long c2 = c1;
+    if (MODEL == 1) {
+      // ---- segment, then backtrack: the slot is filled from its end (or from its start when reversing) ----
+      tc.n_trips += static_cast<unsigned long long>(
+          unigram_stream_lane(d, gt, gb, my_nlen, my_rs, my_rb, rm, my_win, W - 1u, my_st, T.roottab, mine));
+      c2 = wv::clock();
+      if (!overflow) {
+        n = emit_stream_lane(d, gt, gb, my_nlen, slot, cap, mine);
+        at_end = (d.flags & kNfReverse) == 0;
       }
+    } else {
+      // ---- word by word, ids written as the words complete: the slot is filled from its start (end when reversing) ----
+      n = bpe_stream_lane(d, gt, my_nlen, slot, cap, T.bw, T.asym, lane, mine && !overflow);
+      c2 = wv::clock();
+      at_end = (d.flags & kNfReverse) != 0;
+      handed = n == -2;
+      const uint64_t wm = wv::ballot(handed);
+      if (wm) {                                 // words too long for the lane form: the sentence-per-wave kernel takes it
+        const int leader = wv::ffs64(wm) - 1;
+        uint32_t wb = 0;
+        if (lane == leader) wb = wv::atomic_add(a.wave_count, static_cast<uint32_t>(wv::popc64(wm)));
+        wb = wv::shfl(wb, leader);
+        if (handed) a.wave_list[wb + static_cast<uint32_t>(wv::popc64(wm & ((1ull << lane) - 1ull)))] = my_sid;
+      }
+      if (handed) { mine = false; n = 0; }
+    }
+    broken = n < 0;
+    if (broken) n = 0;
+    if (mine && !broken && !overflow) {
+      int32_t *ids = at_end ? slot + (cap - n) : slot;
+      for (int x = 0; x < d.n_prefix; ++x) ids[x - d.n_prefix] = d.prefix_ids[x];
+      for (int x = 0; x < d.n_suffix; ++x) ids[n + x] = d.suffix_ids[x];
+      a.tmp_off[my_sid] = static_cast<unsigned long long>(ids - d.n_prefix - a.arena);
     }
     if (mine) {
       a.counts[my_sid] = (broken || overflow) ? 0u : static_cast<uint32_t>(n + n_extra);

@@ -21,8 +21,13 @@ void PackTrie2(const DatTrie &d, const std::vector<uint32_t> &payload, std::vect
 
 uint32_t FloatBits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
-bool IsCharLike(const std::string &s) {
-  return !s.empty() && s.size() <= 4 && s.size() <= static_cast<size_t>(OneCharLen(static_cast<unsigned char>(s[0])));
+// Strings the BPE symbol splitter can produce for one character: up to OneCharLen(first byte) bytes
+// (src/normalizer.cc:336-344); under kNfCompressSp the byte kSpByte is a whole character.
+bool IsCharLike(const std::string &s, bool compress) {
+  if (s.empty() || s.size() > 4) return false;
+  const unsigned char c = static_cast<unsigned char>(s[0]);
+  const size_t mb = (compress && c == kSpByte) ? 1 : static_cast<size_t>(OneCharLen(c));
+  return s.size() <= mb;
 }
 uint32_t PackChar(const std::string &s) {
   uint32_t v = 0;
@@ -34,6 +39,14 @@ uint32_t NextPow2(size_t n) { uint32_t p = 16; while (p < n) p <<= 1; return p; 
 const char kSpaceSymbol[] = "\xE2\x96\x81";   // U+2581 (src/normalizer.cc:109)
 
 // kNfCompressSp: every U+2581 of a piece becomes the single byte kSpByte.
+std::string ExpandSp(const std::string &s) {
+  std::string o;
+  for (unsigned char c : s) {
+    if (c == kSpByte) o += kSpaceSymbol; else o.push_back(static_cast<char>(c));
+  }
+  return o;
+}
+
 std::string CompressSp(const std::string &s) {
   std::string o;
   o.reserve(s.size());
@@ -128,7 +141,7 @@ Status CompileTables(const ModelData &m, HostTables *t) {
   // route and every U+2581 in it is produced where the device normalizer can see it: escaped spaces and literal
   // U+2581 characters of the raw text.  So: no user-defined symbols (their raw spans are copied verbatim), no
   // 0xFF / U+2581 inside the charsmap's replacement strings, no 0xFF inside a piece.
-  bool compress = m.model_type == kUnigram && m.escape_ws && uds_keys.empty() && !getenv("SPMX_NO_COMPRESS");
+  bool compress = m.escape_ws && uds_keys.empty() && !getenv("SPMX_NO_COMPRESS");
   if (compress) {
     const std::string blob(t->nblob.begin(), t->nblob.end());
     if (blob.find(static_cast<char>(kSpByte)) != std::string::npos || blob.find(kSpaceSymbol) != std::string::npos)
@@ -216,6 +229,17 @@ Status CompileTables(const ModelData &m, HostTables *t) {
   t->sym_len.clear();
   if (m.model_type == kBpe) {
     const uint32_t V = static_cast<uint32_t>(m.pieces.size());
+    // Everything below works on the strings as the device sees them: with kNfCompressSp every U+2581 of a piece
+    // is the byte kSpByte.  tmap = pieces_ (src/bpe_model.cc:88-94) keyed by those strings.
+    auto dev_str = [&](const std::string &p) { return compress ? CompressSp(p) : p; };
+    std::map<std::string, int> tmap;
+    bool wordwise = compress && !m.ws_suffix && !getenv("SPMX_NO_WORDWISE");
+    for (const auto &kv : m.pieces_map) {
+      const std::string t = dev_str(kv.first);
+      tmap.emplace(t, kv.second);
+      if (t.find(static_cast<char>(kSpByte), 1) != std::string::npos) wordwise = false;
+    }
+    if (wordwise) flags |= kNfBpeWordwise;
     // symbol universe: piece ids [0, V) for strings in pieces_, then extra
     // char-like strings that are split parts of a piece or reserved names.
     std::map<std::string, uint32_t> extra;
@@ -224,13 +248,14 @@ Status CompileTables(const ModelData &m, HostTables *t) {
     for (uint32_t i = 0; i < V; ++i) {
       // PieceToId(piece string) (src/bpe_model.cc:178, src/model_interface.cc:51-61)
       t->sym_final[i] = static_cast<uint32_t>(m.PieceToId(m.pieces[i].piece));
-      if (m.pieces[i].piece.size() > 0xFFFF) return Status::Error(kUnimplemented, "piece longer than 65535 bytes");
-      t->sym_len[i] = static_cast<uint16_t>(m.pieces[i].piece.size());
+      const size_t dl = dev_str(m.pieces[i].piece).size();
+      if (dl > 0xFFFF) return Status::Error(kUnimplemented, "piece longer than 65535 bytes");
+      t->sym_len[i] = static_cast<uint16_t>(dl);
     }
     auto sym_of = [&](const std::string &s, bool create) -> uint32_t {
-      auto it = m.pieces_map.find(s);
-      if (it != m.pieces_map.end()) return static_cast<uint32_t>(it->second);
-      if (!IsCharLike(s)) return kSymNone;
+      auto it = tmap.find(s);
+      if (it != tmap.end()) return static_cast<uint32_t>(it->second);
+      if (!IsCharLike(s, compress)) return kSymNone;
       auto e = extra.find(s);
       if (e != extra.end()) return e->second;
       if (!create) return kSymNone;
@@ -239,16 +264,18 @@ Status CompileTables(const ModelData &m, HostTables *t) {
       return id;
     };
     // chars that only exist as reserved names still need their PieceToId
-    for (const auto &kv : m.reserved_map)
-      if (IsCharLike(kv.first)) sym_of(kv.first, true);
+    for (const auto &kv : m.reserved_map) {
+      const std::string t = dev_str(kv.first);
+      if (IsCharLike(t, compress)) sym_of(t, true);
+    }
     struct PairEnt { uint32_t a, b, merged; float score; };
     std::vector<PairEnt> pairs;
-    for (const auto &kv : m.pieces_map) {
+    for (const auto &kv : tmap) {
       const std::string &p = kv.first;
       for (size_t k = 1; k < p.size(); ++k) {
         const std::string a = p.substr(0, k), b = p.substr(k);
-        const bool a_ok = m.pieces_map.count(a) || IsCharLike(a);
-        const bool b_ok = m.pieces_map.count(b) || IsCharLike(b);
+        const bool a_ok = tmap.count(a) || IsCharLike(a, compress);
+        const bool b_ok = tmap.count(b) || IsCharLike(b, compress);
         if (!a_ok || !b_ok) continue;
         pairs.push_back({sym_of(a, true), sym_of(b, true), static_cast<uint32_t>(kv.second), m.pieces[kv.second].score});
       }
@@ -256,12 +283,12 @@ Status CompileTables(const ModelData &m, HostTables *t) {
     t->sym_final.resize(V + extra.size());
     t->sym_len.resize(V + extra.size());
     for (const auto &kv : extra) {
-      t->sym_final[kv.second] = static_cast<uint32_t>(m.PieceToId(kv.first));
+      t->sym_final[kv.second] = static_cast<uint32_t>(m.PieceToId(compress ? ExpandSp(kv.first) : kv.first));
       t->sym_len[kv.second] = static_cast<uint16_t>(kv.first.size());
     }
     // char table: every char-like string that has a symbol
     std::vector<std::pair<std::string, uint32_t>> chars;
-    for (const auto &kv : m.pieces_map) if (IsCharLike(kv.first)) chars.emplace_back(kv.first, static_cast<uint32_t>(kv.second));
+    for (const auto &kv : tmap) if (IsCharLike(kv.first, compress)) chars.emplace_back(kv.first, static_cast<uint32_t>(kv.second));
     for (const auto &kv : extra) chars.emplace_back(kv.first, kv.second);
     const uint32_t csz = NextPow2(chars.size() * 2 + 16);
     t->chartab.assign(csz, U4{0, 0, kSymNone, 0});

@@ -138,7 +138,7 @@ const LengthClass kBpeCls[] = {{24, 40}, {192, 448}, {576, 1280}, {1536, 3328}, 
 }  // namespace
 
 extern "C" {
-extern uint64_t g_fast_kept, g_fast_handed;
+extern uint64_t g_fast_kept, g_fast_handed, g_wave_handed;
 
 void *emu_load(const void *bytes, uint64_t n, char *err, uint64_t errcap) {
   auto *h = new EmuHandle;
@@ -196,7 +196,7 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
   const LengthClass *cls = bpe ? kBpeCls : kUniCls;
   const int ncls = bpe ? static_cast<int>(sizeof(kBpeCls) / sizeof(kBpeCls[0])) : static_cast<int>(sizeof(kUniCls) / sizeof(kUniCls[0]));
   if (grid < 1) grid = 1;
-  g_fast_kept = g_fast_handed = 0;
+  g_fast_kept = g_fast_handed = g_wave_handed = 0;
   std::vector<uint32_t> lists(static_cast<size_t>(ncls) * (n ? n : 1)), list_counts(kMaxClasses, 0), counts(n + 1, 0);
   std::vector<uint64_t> tmp_off(n + 1, 0);
   ClassifyArgs ca{};
@@ -222,17 +222,23 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
     while (a.ring < static_cast<uint32_t>(h->tables.max_piece_len) + 1) a.ring <<= 1;
     // streaming form for every unigram class, as in csrc/api.cc: the FAST kernel first (when the model allows
     // it), then the GENERAL kernel on what it left over.  SPMX_NO_STREAM: tile / sentence-per-wave forms.
-    if (!bpe && !getenv("SPMX_NO_STREAM")) {
-      std::vector<uint32_t> hard(n ? n : 1);
-      uint32_t hard_count = 0;
+    const bool bpe_stream = bpe && (dev.flags & kNfBpeWordwise) && !(dev.flags & kNfHasUnused);
+    if ((!bpe || bpe_stream) && !getenv("SPMX_NO_STREAM")) {
+      std::vector<uint32_t> hard(n ? n : 1), wavel(n ? n : 1);
+      uint32_t hard_count = 0, wave_count = 0;
       const int waves = grid;   // one wave per block in the emulator
+      const int model = bpe ? 2 : 1;
+      a.wave_list = wavel.data(); a.wave_count = &wave_count;
       if (StreamFastEligible(dev.flags) && !getenv("SPMX_NO_FAST")) {
         a.hard_list = hard.data(); a.hard_count = &hard_count;
         a.stream_tcap = a.rcap + 1;
         std::vector<uint32_t> st(StreamTextDwords(a.stream_tcap, a.ring) * waves, 0xCDCDCDCDu), sb(StreamBpWords(a.stream_tcap) * waves, 0xCDCDCDCDu);
         a.stream_text = st.data(); a.stream_bp = sb.data();
-        std::vector<unsigned char> fsmem(StreamLdsBytes(true, a.rcap, a.ncap, a.ring, 1) + 64, 0xCD);
-        for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, fsmem.data(), [&] { encode_stream_block<true>(a, fsmem.data()); });
+        std::vector<unsigned char> fsmem(StreamLdsBytes(true, model, a.rcap, a.ncap, a.ring, 1) + 64, 0xCD);
+        for (int b = 0; b < grid; ++b) {
+          if (bpe) emu::RunWave(b, grid, fsmem.data(), [&] { encode_stream_block<true, 2>(a, fsmem.data()); });
+          else emu::RunWave(b, grid, fsmem.data(), [&] { encode_stream_block<true, 1>(a, fsmem.data()); });
+        }
         g_fast_kept += list_counts[c] - hard_count;
         g_fast_handed += hard_count;
         a.list = hard.data(); a.list_count = &hard_count;
@@ -241,8 +247,17 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
       a.stream_tcap = a.ncap;
       std::vector<uint32_t> st(StreamTextDwords(a.stream_tcap, a.ring) * waves, 0xCDCDCDCDu), sb(StreamBpWords(a.stream_tcap) * waves, 0xCDCDCDCDu);
       a.stream_text = st.data(); a.stream_bp = sb.data();
-      std::vector<unsigned char> gsmem(StreamLdsBytes(false, a.rcap, a.ncap, a.ring, 1) + 64, 0xCD);
-      for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, gsmem.data(), [&] { encode_stream_block<false>(a, gsmem.data()); });
+      std::vector<unsigned char> gsmem(StreamLdsBytes(false, model, a.rcap, a.ncap, a.ring, 1) + 64, 0xCD);
+      for (int b = 0; b < grid; ++b) {
+        if (bpe) emu::RunWave(b, grid, gsmem.data(), [&] { encode_stream_block<false, 2>(a, gsmem.data()); });
+        else emu::RunWave(b, grid, gsmem.data(), [&] { encode_stream_block<false, 1>(a, gsmem.data()); });
+      }
+      if (bpe) {   // sentences with a word too long for the lane form: sentence per wave
+        g_wave_handed += wave_count;
+        a.list = wavel.data(); a.list_count = &wave_count;
+        std::vector<unsigned char> smem(EncodeLdsBytes(dev.model_type, a.rcap, a.ncap) + 64, 0xCD);
+        for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, smem.data(), [&] { encode_block<2>(a, smem.data()); });
+      }
       continue;
     }
     // tile form for the first unigram classes (small areas here to exercise the rounds)
@@ -288,7 +303,8 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
 uint64_t emu_collectives() { return emu::g_wave.n_collectives; }
 uint32_t emu_flags(void *hv) { return static_cast<EmuHandle *>(hv)->tables.scalars.flags; }
 // sentences the FAST tile kernel kept / handed to the GENERAL kernel in the last emu_encode_batch
-uint64_t g_fast_kept = 0, g_fast_handed = 0;
+uint64_t g_fast_kept = 0, g_fast_handed = 0, g_wave_handed = 0;
+uint64_t emu_wave_handed() { return g_wave_handed; }
 uint64_t emu_fast_kept() { return g_fast_kept; }
 uint64_t emu_fast_handed() { return g_fast_handed; }
 

@@ -29,6 +29,7 @@ class EmuLib:
         lib.emu_flags.argtypes = [C.c_void_p]
         lib.emu_fast_kept.restype = C.c_uint64
         lib.emu_fast_handed.restype = C.c_uint64
+        lib.emu_wave_handed.restype = C.c_uint64
 
     def load(self, model_bytes):
         err = C.create_string_buffer(512)
@@ -54,6 +55,10 @@ class EmuHandle:
     def fast_split(self):
         """(sentences the FAST tile kernel kept, sentences it handed to the GENERAL kernel) in the last call."""
         return int(self.lib.emu_fast_kept()), int(self.lib.emu_fast_handed())
+
+    def wave_handed(self):
+        """BPE: sentences the lane form handed to the sentence-per-wave kernel in the last call."""
+        return int(self.lib.emu_wave_handed())
 
     def set_encode_extra_options(self, opts):
         rc = self.lib.emu_set_encode_extra_options(self.h, opts.encode())

@@ -82,6 +82,35 @@ def test_emu_tile_variants(model, env, emu, oracle, corpora, monkeypatch):
             assert kept == 0
 
 
+K_WORDWISE = 1 << 10   # dev.h kNfBpeWordwise
+
+
+@pytest.mark.parametrize("model", ["bpe1k", "bpe32k", "bpe1k_bf_uds", "bpe1k_noesc"])
+@pytest.mark.parametrize("env", [{}, {"SPMX_NO_WORDWISE": "1"}, {"SPMX_NO_COMPRESS": "1"}, {"SPMX_NO_FAST": "1"},
+                                 {"SPMX_NO_STREAM": "1"}])
+def test_emu_bpe_variants(model, env, emu, oracle, corpora, monkeypatch):
+    """BPE: lane-per-sentence word-by-word form (word-wise models) vs sentence-per-wave form: same ids; long
+    words are handed to the sentence-per-wave kernel."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    blob = fixtures.model_blob(model)
+    h = emu.load(blob)
+    wordwise = bool(h.flags() & K_WORDWISE)
+    assert wordwise == (model in ("bpe1k", "bpe32k") and "SPMX_NO_WORDWISE" not in env and "SPMX_NO_COMPRESS" not in env)
+    o = oracle.load(blob)
+    for name, k in (("edge", 10 ** 6), ("synth20k", 200), ("mixed2k", 40), ("botchan", 120)):
+        text, offs = fixtures.head(*corpora[name], k)
+        ids, io = h.encode_batch(text, offs, grid=2)
+        assert h.status == 0
+        oids, oio = o.encode_batch(text, offs)
+        np.testing.assert_array_equal(io, oio)
+        np.testing.assert_array_equal(ids, oids)
+        if name == "edge" and wordwise and "SPMX_NO_STREAM" not in env:
+            assert h.wave_handed() >= 3      # "a" * 300, "0123456789" * 40, a long CJK run ...
+        if name == "synth20k" and wordwise and not env:
+            assert h.fast_split()[0] > 0.9 * (len(offs) - 1) and h.wave_handed() == 0
+
+
 @pytest.mark.parametrize("model,opts", [("test_model", "bos:eos"), ("test_model", "reverse:bos"),
                                          ("bpe1k", "eos:reverse:bos"), ("uni1k_bf", "reverse")])
 def test_emu_extra_options(model, opts, emu, oracle, corpora):
