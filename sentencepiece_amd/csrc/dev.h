@@ -87,6 +87,7 @@ struct SpmxDev {
   const uint32_t *sym_final;  // per symbol: final id | flags
   const uint16_t *sym_len;    // per symbol: byte length
   uint32_t chartab_mask, pairtab_mask;
+  uint32_t n_pieces;      // symbols below this are piece ids (their own final id); the rest are extra characters
   int32_t model_type;     // 1 unigram, 2 bpe
 };
 

@@ -30,6 +30,7 @@
 namespace spmx {
 
 constexpr int kBpeWordMax = 24;
+constexpr uint32_t kBpeWindow = 32;   // bytes of text a lane keeps in LDS
 
 // Byte pos of a lane's text column (kernels_stream.h: dwords text[pos >> 2][lane]).
 SPMX_DEVICE uint32_t stream_text_byte(const uint32_t *gt, int pos) {
@@ -37,130 +38,177 @@ SPMX_DEVICE uint32_t stream_text_byte(const uint32_t *gt, int pos) {
 }
 
 struct BpeWordLds {
-  uint32_t *sym;     // [kBpeWordMax][64] symbol ids (kSsUnknown: a character without a symbol)
-  U2 *pair;          // [kBpeWordMax][64] {merged symbol | kSymNone, score bits} of (k, k + 1)
-  uint8_t *len;      // [kBpeWordMax][64] byte length of symbol k
+  uint32_t *sym;     // [kBpeWordMax][64] symbol at character slot k (kSsUnknown: a character without a symbol)
+  float *score;      // [kBpeWordMax][64] score of the live pair whose left symbol sits at slot k
+  uint32_t *merged;  // [kBpeWordMax][64] the symbol that pair merges into
+  uint8_t *len;      // [kBpeWordMax][64] byte length of the symbol at slot k
 };
-SPMX_HD inline uint32_t BpeWordLdsBytes() { return kBpeWordMax * 64u * (4u + 8u + 1u); }
+SPMX_HD inline uint32_t BpeWordLdsBytes() { return kBpeWordMax * 64u * (4u + 4u + 4u + 1u); }
 
-// Byte `pos` of the lane's text column through a two-dword register window [4 q, 4 q + 8).
-struct TextCursor {
-  const uint32_t *gt;
-  int q;
-  uint32_t cur, nxt;
+// pieces_.find(left + right) (src/bpe_model.cc:88-94) split in two so that several probes are in flight at once:
+// issue computes the slot and starts the load, resolve consumes it (and walks on after a hash collision).
+struct PairProbe {
+  uint32_t a = 0, b = 0, slot = 0;
+  int idx = 0;        // character slot of the left symbol
+  bool live = false;
+  U4 e{0, 0, 0, 0};
 };
-SPMX_DEVICE void cursor_init(TextCursor *t, const uint32_t *gt) {
-  t->gt = gt; t->q = 0; t->cur = gt[0]; t->nxt = gt[64];
+SPMX_DEVICE void pair_issue(const SpmxDev &d, PairProbe *p, uint32_t a, uint32_t b, int idx) {
+  p->live = a < kSsUnknown && b < kSsUnknown;       // an unknown character (or frozen symbol) never merges
+  if (!p->live) return;
+  p->a = a; p->b = b; p->idx = idx;
+  p->slot = HashPair(a, b) & d.pairtab_mask;
+  p->e = d.pairtab[p->slot];
 }
-SPMX_DEVICE void cursor_seek(TextCursor *t, int pos) {            // pos never moves back
-  while (pos >= 4 * t->q + 4) { t->cur = t->nxt; ++t->q; t->nxt = t->gt[(t->q + 1) * 64]; }
-}
-SPMX_DEVICE uint32_t cursor_byte(const TextCursor &t, int pos) {  // 4 q <= pos < 4 q + 8
-  const int i = pos - 4 * t.q;
-  return ((i < 4 ? t.cur : t.nxt) >> (8 * (i & 3))) & 0xFFu;
+// Returns true (and the merged symbol / score) if the pair is a piece.
+SPMX_DEVICE bool pair_resolve(const SpmxDev &d, PairProbe *p, uint32_t *merged, float *score) {
+  if (!p->live) return false;
+  p->live = false;
+  for (;;) {
+    if (p->e.x == kSymNone) return false;
+    if (p->e.x == p->a && p->e.y == p->b) {
+      *merged = p->e.z;
+      *score = wv::bits_to_float(p->e.w);
+      return true;
+    }
+    p->slot = (p->slot + 1) & d.pairtab_mask;
+    p->e = d.pairtab[p->slot];
+  }
 }
 
 // Segments this lane's sentence (text column gt, nlen bytes) and writes its ids into slot[0, cap): forward order
 // fills the slot from its START, `reverse` from its end.  Returns the number of ids, -1 on an error status
 // (control piece, overflow), -2 if the sentence has to go to the sentence-per-wave kernel (a word too long).
+//
+// The word lives in character slots 0 .. n0-1 of the LDS arrays; `alive` has a bit per slot that still starts a
+// symbol, `pmask` a bit per slot whose pair with the next live slot is a piece.  A merge clears the right slot's
+// bit: nothing is moved.  Every iteration first lands the (at most two) pair probes issued by the previous one.
+//
+// Text comes through a W-byte LDS window (position p at win[p & wmask]) refilled one dword per iteration from the
+// lane's text column; that load and the pair probes are issued at the END of an iteration and land at the top of
+// the next one, so an iteration waits for memory once.
 SPMX_DEVICE int bpe_stream_lane(const SpmxDev &d, const uint32_t *gt, int nlen, int32_t *slot, int cap,
-                                const BpeWordLds &B, const uint32_t *asym, int lane, bool active_in) {
+                                const BpeWordLds &B, const uint32_t *asym, uint8_t *win, uint32_t wmask, int lane,
+                                bool active_in) {
   const bool bf = (d.flags & kNfByteFallback) != 0;
   const bool reverse = (d.flags & kNfReverse) != 0;
   const uint32_t spb = SpByteOf(d);
   uint32_t *sym = B.sym + lane;
-  U2 *pr = B.pair + lane;
+  float *scr = B.score + lane;
+  uint32_t *mrg = B.merged + lane;
   uint8_t *ln = B.len + lane;
   bool active = active_in && nlen > 0;
   int pos = 0;          // next byte of the text to read
-  int n = 0;            // symbols of the current word
+  int n0 = 0;           // character slots of the current word
   int wstart = 0;       // byte offset of the current word
+  uint32_t alive = 0, pmask = 0;
   bool merging = false; // the current word has been read completely
   bool right_unk = false;
   int n_out = 0, ret = 0;
-  TextCursor tc{gt, 0, 0, 0};
-  if (active) cursor_init(&tc, gt);
+  PairProbe p0, p1;
+  const int W = static_cast<int>(wmask) + 1;
+  int nf = 0;                                     // next text dword to fetch; the window holds dwords [nf - W/4, nf)
+  bool pf_pend = false;
+  uint32_t pf = 0;
+  if (active) {
+    for (int k = 0; k < W / 4; ++k) *reinterpret_cast<uint32_t *>(win + 4 * k) = gt[k * 64];
+    nf = W / 4;
+  }
   while (wv::any(active)) {
     if (!active) continue;
-    if (!merging) {
-      // ---- read one character of the current word (:109-129) ----
-      cursor_seek(&tc, pos);
-      const uint32_t c0 = cursor_byte(tc, pos);
-      if (n > 0 && c0 == spb) { merging = true; continue; }                 // the next word begins here
-      if (n == kBpeWordMax) { ret = -2; active = false; continue; }          // too long for the LDS working set
-      int mb = c0 == spb ? 1 : OneCharLenDev(c0);
-      if (mb > nlen - pos) mb = nlen - pos;
-      uint32_t s;
-      if (mb == 1) {
-        s = asym[c0];
-      } else {
-        uint32_t bytes = c0;
-        for (int k = 1; k < mb; ++k) bytes |= cursor_byte(tc, pos + k) << (8 * k);
-        s = char_lookup(d, bytes, static_cast<uint32_t>(mb));
-      }
-      if (n == 0) wstart = pos;
-      sym[n * 64] = s;
-      ln[n * 64] = static_cast<uint8_t>(mb);
-      pr[n * 64] = U2{kSymNone, 0};
-      if (n > 0) {
-        uint32_t merged = 0;
-        float sc = 0.f;
-        if (pair_lookup(d, sym[(n - 1) * 64], s, &merged, &sc)) pr[(n - 1) * 64] = U2{merged, __builtin_bit_cast(uint32_t, sc)};
-      }
-      ++n;
-      pos += mb;
-      if (pos >= nlen) merging = true;
-      continue;
+    {   // land what the previous iteration issued: a text dword and up to two pair probes
+      if (pf_pend) *reinterpret_cast<uint32_t *>(win + ((4u * static_cast<uint32_t>(nf - 1)) & wmask)) = pf;
+      pf_pend = false;
+      uint32_t m = 0;
+      float sc = 0.f;
+      if (pair_resolve(d, &p0, &m, &sc)) { mrg[p0.idx * 64] = m; scr[p0.idx * 64] = sc; pmask |= 1u << p0.idx; }
+      if (pair_resolve(d, &p1, &m, &sc)) { mrg[p1.idx * 64] = m; scr[p1.idx * 64] = sc; pmask |= 1u << p1.idx; }
     }
+    bool do_merge = merging;
+    if (!merging) {
+      // ---- read up to two characters of the current word (:109-129) ----
+      // (two explicit calls: the probe objects must stay in registers, so no run-time choice between them)
+      auto read_char = [&](PairProbe *pp) {
+        if (merging || ret != 0) return;
+        if (pos + 4 > 4 * nf && 4 * nf < nlen) return;                       // its bytes have not landed yet
+        const uint32_t c0 = win[static_cast<uint32_t>(pos) & wmask];
+        if (n0 > 0 && c0 == spb) { merging = true; return; }                 // the next word begins here
+        if (n0 == kBpeWordMax) { ret = -2; return; }                          // too long for the LDS working set
+        int mb = c0 == spb ? 1 : OneCharLenDev(c0);
+        if (mb > nlen - pos) mb = nlen - pos;
+        uint32_t s;
+        if (mb == 1) {
+          s = asym[c0];
+        } else {
+          uint32_t bytes = c0;
+          for (int k = 1; k < mb; ++k) bytes |= static_cast<uint32_t>(win[static_cast<uint32_t>(pos + k) & wmask]) << (8 * k);
+          s = char_lookup(d, bytes, static_cast<uint32_t>(mb));
+        }
+        if (n0 == 0) wstart = pos;
+        sym[n0 * 64] = s;
+        ln[n0 * 64] = static_cast<uint8_t>(mb);
+        if (n0 > 0) pair_issue(d, pp, sym[(n0 - 1) * 64], s, n0 - 1);
+        alive |= 1u << n0;
+        ++n0;
+        pos += mb;
+        if (pos >= nlen) merging = true;
+      };
+      read_char(&p0);
+      read_char(&p1);
+      if (ret != 0) active = false;
+    }
+    if (do_merge) {
     // ---- one merge (:142-173): best live pair, highest score first, then leftmost ----
     int best = -1;
     float bs = 0.f;
-    uint32_t bm = 0;
-    for (int k = 0; k + 1 < n; ++k) {
-      const U2 e = pr[k * 64];
-      if (e.x != kSymNone) {
-        const float sc = wv::bits_to_float(e.y);
-        if (best < 0 || sc > bs) { best = k; bs = sc; bm = e.x; }
-      }
+    for (int base = 0; base < kBpeWordMax; base += 8) {
+      const uint32_t mm = (pmask >> base) & 0xFFu;
+      if (mm == 0) continue;
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = scr[(base + k) * 64];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (((mm >> k) & 1u) && (best < 0 || v[k] > bs)) { best = base + k; bs = v[k]; }
     }
     if (best >= 0) {
+      const uint32_t above = alive & ~((2u << best) - 1u);                   // live slots right of `best`
+      const int j = wv::ffs64(above) - 1;                                     // the right symbol (exists: the pair is live)
+      const uint32_t bm = mrg[best * 64];
       sym[best * 64] = bm;
-      ln[best * 64] = static_cast<uint8_t>(ln[best * 64] + ln[(best + 1) * 64]);
-      for (int k = best + 1; k + 1 < n; ++k) {                               // close the gap
-        sym[k * 64] = sym[(k + 1) * 64];
-        ln[k * 64] = ln[(k + 1) * 64];
-        pr[k * 64] = pr[(k + 1) * 64];
-      }
-      --n;
+      ln[best * 64] = static_cast<uint8_t>(ln[best * 64] + ln[j * 64]);
+      alive &= ~(1u << j);
+      pmask &= ~((1u << best) | (1u << j));
       // :171-172 the two new neighbours
-      uint32_t merged = 0;
-      float sc = 0.f;
-      if (best > 0) {
-        if (pair_lookup(d, sym[(best - 1) * 64], bm, &merged, &sc)) pr[(best - 1) * 64] = U2{merged, __builtin_bit_cast(uint32_t, sc)};
-        else pr[(best - 1) * 64] = U2{kSymNone, 0};
+      const uint32_t below = alive & ((1u << best) - 1u);
+      if (below) {
+        const int p = 31 - static_cast<int>(wv::clz64(static_cast<uint64_t>(below)) - 32);
+        pmask &= ~(1u << p);
+        pair_issue(d, &p0, sym[p * 64], bm, p);
       }
-      if (best + 1 < n) {
-        if (pair_lookup(d, bm, sym[(best + 1) * 64], &merged, &sc)) pr[best * 64] = U2{merged, __builtin_bit_cast(uint32_t, sc)};
-        else pr[best * 64] = U2{kSymNone, 0};
-      } else {
-        pr[best * 64] = U2{kSymNone, 0};
-      }
-      continue;
-    }
+      const uint32_t after = alive & ~((2u << best) - 1u);
+      if (after) pair_issue(d, &p1, bm, sym[(wv::ffs64(after) - 1) * 64], best);
+    } else {
     // ---- no pair left: the word's symbols are its pieces (:175-200, no UNUSED pieces here) ----
     int off = wstart;
-    for (int k = 0; k < n && ret == 0; ++k) {
+    for (uint32_t m = alive; m != 0 && ret == 0; m &= m - 1) {
+      const int k = wv::ffs64(m) - 1;
       const uint32_t s = sym[k * 64];
       const int len = ln[k * 64];
-      uint32_t f = static_cast<uint32_t>(d.unk_id);
-      if (s != kSsUnknown) {
-        f = d.sym_final[s];
-        if (f & kSfControl) { ret = -1; break; }
-        f &= kSfIdMask;
+      // PieceToId (:178): a symbol below n_pieces is a member of pieces_ and its own id (never a control piece);
+      // only the extra characters (split parts that are no pieces themselves) go through sym_final
+      uint32_t f = s;
+      if (s >= d.n_pieces) {
+        f = static_cast<uint32_t>(d.unk_id);
+        if (s != kSsUnknown) {
+          f = d.sym_final[s];
+          if (f & kSfControl) { ret = -1; break; }
+          f &= kSfIdMask;
+        }
       }
       if (static_cast<int32_t>(f) == d.unk_id) {
         if (bf) {                                   // one BYTE id per byte of the unknown piece (:581-603)
-          for (int x = 0; x < len; ++x) {
+          for (int x = 0; x < len && ret == 0; ++x) {
             const uint32_t b = stream_text_byte(gt, off + x);
             const int nb = b == spb ? 3 : 1;
             if (n_out + nb > cap) { ret = -1; break; }
@@ -184,9 +232,15 @@ SPMX_DEVICE int bpe_stream_lane(const SpmxDev &d, const uint32_t *gt, int nlen, 
       }
       off += len;
     }
-    n = 0;
+    n0 = 0;
+    alive = 0;
+    pmask = 0;
     merging = false;
     if (ret != 0 || pos >= nlen) active = false;
+    }
+    }
+    // window refill: dword nf may replace positions [4 nf - W, 4 nf - W + 4), dead once they lie below pos
+    if (active && 4 * nf + 4 <= pos + W && 4 * nf < nlen + 8) { pf = gt[nf * 64]; ++nf; pf_pend = true; }
   }
   return ret != 0 ? ret : n_out;
 }

@@ -47,13 +47,14 @@ struct StreamLds {
   // BPE (kernels_bpe_stream.h) instead of the rings / window / staging block:
   uint32_t *asym;     // [256] symbol of every one-byte character (shared, aliases roottab)
   BpeWordLds bw;      // the lane's current word
+  uint8_t *bwin;      // [64][kBpeWindow + 4] text windows
 };
 
 SPMX_HD inline uint32_t StreamWindow(uint32_t ring) { return 2u * ring; }
 // model: 1 unigram, 2 BPE
 SPMX_HD inline uint32_t StreamPrivateBytes(bool fast, int model, uint32_t rcap, uint32_t ncap, uint32_t ring) {
   const uint32_t stage = fast ? 0u : (((rcap + 16 + 15) & ~15u) + ((ncap + 16 + 15) & ~15u));
-  const uint32_t work = model == 2 ? BpeWordLdsBytes()
+  const uint32_t work = model == 2 ? BpeWordLdsBytes() + 64u * (kBpeWindow + 4u)
                                    : 64u * ring * 8u + 64u * (StreamWindow(ring) + 4u) + 2u * 64u * 16u;
   return stage + work;
 }
@@ -82,8 +83,10 @@ SPMX_DEVICE StreamLds carve_stream(unsigned char *base, bool fast, int model, ui
   t.win = mine + 64u * ring * 8u;
   t.stage = reinterpret_cast<uint32_t *>(t.win + 64u * (StreamWindow(ring) + 4u));
   t.bw.sym = reinterpret_cast<uint32_t *>(mine);
-  t.bw.pair = reinterpret_cast<U2 *>(mine + kBpeWordMax * 64u * 4u);
+  t.bw.score = reinterpret_cast<float *>(mine + kBpeWordMax * 64u * 4u);
+  t.bw.merged = reinterpret_cast<uint32_t *>(mine + kBpeWordMax * 64u * 8u);
   t.bw.len = mine + kBpeWordMax * 64u * 12u;
+  t.bwin = mine + BpeWordLdsBytes();
   return t;
 }
 
@@ -460,7 +463,8 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
       }
     } else {
       // ---- word by word, ids written as the words complete: the slot is filled from its start (end when reversing) ----
-      n = bpe_stream_lane(d, gt, my_nlen, slot, cap, T.bw, T.asym, lane, mine && !overflow);
+      n = bpe_stream_lane(d, gt, my_nlen, slot, cap, T.bw, T.asym, T.bwin + static_cast<uint32_t>(lane) * (kBpeWindow + 4u),
+                          kBpeWindow - 1u, lane, mine && !overflow);
       c2 = wv::clock();
       at_end = (d.flags & kNfReverse) != 0;
       handed = n == -2;

@@ -317,6 +317,7 @@ Status CompileTables(const ModelData &m, HostTables *t) {
     t->sym_final.assign(1, 0);
     t->sym_len.assign(1, 0);
   }
+  sc.n_pieces = static_cast<uint32_t>(m.pieces.size());
   sc.flags = flags;
   RefreshTypeFlags(m, t);
   return Status::OK();
