@@ -282,8 +282,8 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
       ca.offs = d_offsets; ca.n = n32; ca.n_classes = static_cast<uint32_t>(ncls);
       for (int c = 0; c < ncls; ++c) ca.rcap[c] = cls[c].rcap;
       ca.lists = h->d_lists.p; ca.list_counts = h->d_ctrl->list_counts;
-      const uint32_t tiles = (n32 + 63) / 64;
-      HIP_OR_RETURN(h, LaunchClassify(ca, static_cast<int>(tiles < static_cast<uint32_t>(wide) ? tiles : wide), stream));
+      const uint32_t chunks = (n32 + 64 * kClassifyChunk - 1) / (64 * kClassifyChunk);
+      HIP_OR_RETURN(h, LaunchClassify(ca, static_cast<int>(chunks < static_cast<uint32_t>(wide) ? chunks : wide), stream));
     }
     // streaming (lane-per-sentence) kernels: every unigram model; BPE models that can be segmented word by word
     const bool bpe_stream = h->model.model_type == kBpe && (h->dev.flags & kNfBpeWordwise) && !(h->dev.flags & kNfHasUnused);
@@ -423,7 +423,8 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
       const uint32_t tiles = (n32 + kScanTile - 1) / kScanTile;
       HIP_OR_RETURN(h, LaunchScan(sa, static_cast<int>(tiles < static_cast<uint32_t>(wide) ? tiles : wide), stream));
       CompactArgs pa{h->d_arena.p, h->d_tmp_off.p, h->d_counts.p, d_id_offsets, d_ids, d_ids ? ids_capacity : 0, n32};
-      const uint64_t cgrid = n < static_cast<uint64_t>(h->n_cu) * 32 ? n : static_cast<uint64_t>(h->n_cu) * 32;
+      const uint64_t cblocks = (n + 63) / 64;
+      const uint64_t cgrid = cblocks < static_cast<uint64_t>(h->n_cu) * 32 ? cblocks : static_cast<uint64_t>(h->n_cu) * 32;
       HIP_OR_RETURN(h, LaunchCompact(pa, static_cast<int>(cgrid), stream));
     }
     if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[kMaxSlots][1], stream));

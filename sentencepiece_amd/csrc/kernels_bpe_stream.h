@@ -53,27 +53,34 @@ struct PairProbe {
   bool live = false;
   U4 e{0, 0, 0, 0};
 };
-SPMX_DEVICE void pair_issue(const SpmxDev &d, PairProbe *p, uint32_t a, uint32_t b, int idx) {
+// request: remember the pair; the load itself is issued by pair_issue at the end of the iteration, for both probe
+// objects unconditionally (a dead probe reads entry 0), so that the memory pipeline is the same on every path and
+// the wait at the top of the next iteration is the only one.
+SPMX_DEVICE void pair_request(const SpmxDev &d, PairProbe *p, uint32_t a, uint32_t b, int idx) {
   p->live = a < kSsUnknown && b < kSsUnknown;       // an unknown character (or frozen symbol) never merges
-  if (!p->live) return;
   p->a = a; p->b = b; p->idx = idx;
-  p->slot = HashPair(a, b) & d.pairtab_mask;
-  p->e = d.pairtab[p->slot];
+  p->slot = p->live ? (HashPair(a, b) & d.pairtab_mask) : 0u;
 }
+SPMX_DEVICE void pair_issue(const SpmxDev &d, PairProbe *p) { p->e = d.pairtab[p->slot]; }
 // Returns true (and the merged symbol / score) if the pair is a piece.
 SPMX_DEVICE bool pair_resolve(const SpmxDev &d, PairProbe *p, uint32_t *merged, float *score) {
-  if (!p->live) return false;
+  U4 e = p->e;
+  bool hit = (e.x == p->a) & (e.y == p->b), none = e.x == kSymNone;   // consumes the load on every path
+  const bool live = p->live;
+  uint32_t slot = p->slot;
   p->live = false;
-  for (;;) {
-    if (p->e.x == kSymNone) return false;
-    if (p->e.x == p->a && p->e.y == p->b) {
-      *merged = p->e.z;
-      *score = wv::bits_to_float(p->e.w);
-      return true;
-    }
-    p->slot = (p->slot + 1) & d.pairtab_mask;
-    p->e = d.pairtab[p->slot];
+  p->slot = 0;
+  if (!live) return false;
+  while (!hit && !none) {                           // hash collision: walk on
+    slot = (slot + 1) & d.pairtab_mask;
+    e = d.pairtab[slot];
+    hit = (e.x == p->a) & (e.y == p->b);
+    none = e.x == kSymNone;
   }
+  if (!hit) return false;
+  *merged = e.z;
+  *score = wv::bits_to_float(e.w);
+  return true;
 }
 
 // Segments this lane's sentence (text column gt, nlen bytes) and writes its ids into slot[0, cap): forward order
@@ -147,7 +154,7 @@ SPMX_DEVICE int bpe_stream_lane(const SpmxDev &d, const uint32_t *gt, int nlen, 
         if (n0 == 0) wstart = pos;
         sym[n0 * 64] = s;
         ln[n0 * 64] = static_cast<uint8_t>(mb);
-        if (n0 > 0) pair_issue(d, pp, sym[(n0 - 1) * 64], s, n0 - 1);
+        if (n0 > 0) pair_request(d, pp, sym[(n0 - 1) * 64], s, n0 - 1);
         alive |= 1u << n0;
         ++n0;
         pos += mb;
@@ -184,10 +191,10 @@ SPMX_DEVICE int bpe_stream_lane(const SpmxDev &d, const uint32_t *gt, int nlen, 
       if (below) {
         const int p = 31 - static_cast<int>(wv::clz64(static_cast<uint64_t>(below)) - 32);
         pmask &= ~(1u << p);
-        pair_issue(d, &p0, sym[p * 64], bm, p);
+        pair_request(d, &p0, sym[p * 64], bm, p);
       }
       const uint32_t after = alive & ~((2u << best) - 1u);
-      if (after) pair_issue(d, &p1, bm, sym[(wv::ffs64(after) - 1) * 64], best);
+      if (after) pair_request(d, &p1, bm, sym[(wv::ffs64(after) - 1) * 64], best);
     } else {
     // ---- no pair left: the word's symbols are its pieces (:175-200, no UNUSED pieces here) ----
     int off = wstart;
@@ -241,6 +248,8 @@ SPMX_DEVICE int bpe_stream_lane(const SpmxDev &d, const uint32_t *gt, int nlen, 
     }
     // window refill: dword nf may replace positions [4 nf - W, 4 nf - W + 4), dead once they lie below pos
     if (active && 4 * nf + 4 <= pos + W && 4 * nf < nlen + 8) { pf = gt[nf * 64]; ++nf; pf_pend = true; }
+    pair_issue(d, &p0);
+    pair_issue(d, &p1);
   }
   return ret != 0 ? ret : n_out;
 }
