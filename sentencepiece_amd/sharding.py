@@ -36,8 +36,13 @@ class IdGatherer:
     the host) until the last one has finished.  ``result()`` returns the
     per-rank ``(ids, id_offsets)`` views of the last gather."""
 
-    def __init__(self, dist, device, group=None):
+    def __init__(self, dist, device, group=None, wire_dtype=None):
+        """``wire_dtype``: dtype the ids travel in (default: as given).  xGMI is point-to-point, so a ring
+        all-gather is bound by one link; a vocabulary below 32768 fits ``torch.int16`` and halves the payload.
+        ``result()`` widens back to the dtype of the ids passed in."""
         self.dist, self.device, self.group = dist, device, group
+        self.wire = wire_dtype
+        self._dtype = None
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self._work = []
@@ -46,6 +51,8 @@ class IdGatherer:
         self._pad = self._opad = None
 
     def _all_gather(self, out, inp):
+        if out.dtype == torch.int16:      # no 16-bit integer type in NCCL / gloo: an all-gather only moves bytes
+            out, inp = out.view(torch.uint8), inp.view(torch.uint8)
         if self.dist.get_backend(self.group) == "nccl":
             return self.dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
         return self.dist.all_gather(list(out.view(self.world, -1).unbind(0)), inp, group=self.group, async_op=True)
@@ -59,10 +66,12 @@ class IdGatherer:
         self.wait()
         # capacities are agreed once and only grow (a MAX all-reduce, off the steady-state path)
         need = self._agree(max(int(total), 1))
+        self._dtype = ids.dtype
+        wire = self.wire or ids.dtype
         if need > self._cap:
             self._cap = need + need // 8
-            self._out = torch.empty(self.world * self._cap, dtype=ids.dtype, device=self.device)
-            self._pad = torch.empty(self._cap, dtype=ids.dtype, device=self.device)
+            self._out = torch.empty(self.world * self._cap, dtype=wire, device=self.device)
+            self._pad = torch.empty(self._cap, dtype=wire, device=self.device)
         # staged copy: ranks hold different totals (padding), and the caller's
         # buffer is free for the next batch while the collective is in flight
         self._pad[:int(total)].copy_(ids[:int(total)])
@@ -92,7 +101,7 @@ class IdGatherer:
     def result(self):
         self.wait()
         tot = self._tot.cpu().tolist()
-        ids = [self._out[r * self._cap: r * self._cap + tot[r]] for r in range(self.world)]
+        ids = [self._out[r * self._cap: r * self._cap + tot[r]].to(self._dtype) for r in range(self.world)]
         offs = None
         if self._n is not None:
             ns = self._n.cpu().tolist()

@@ -40,14 +40,14 @@ def _worker(rank, world, port, model, corpus_name, n_sent, out_dir):
         np.save(os.path.join(out_dir, "ids%d.npy" % rank), ids.numpy())
         np.save(os.path.join(out_dir, "io%d.npy" % rank), io.numpy())
         # steady-state gatherer: two batches of different size through one IdGatherer
-        g = sharding.IdGatherer(dist, torch.device("cpu"))
+        g = sharding.IdGatherer(dist, torch.device("cpu"), wire_dtype=torch.int16)
         for k in (3 + rank, 7 - rank):
             part = torch.arange(k, dtype=torch.int32) + 100 * rank
             g(part, k, torch.tensor([0, k], dtype=torch.int64))
             got, goffs = g.result()
             for r in range(world):
                 kk = (3 + r) if k == 3 + rank else (7 - r)
-                assert got[r].tolist() == [100 * r + i for i in range(kk)]
+                assert got[r].tolist() == [100 * r + i for i in range(kk)] and got[r].dtype == torch.int32
                 assert goffs[r].tolist() == [0, kk]
     finally:
         dist.destroy_process_group()
