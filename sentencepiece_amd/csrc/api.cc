@@ -114,6 +114,7 @@ struct spmx_handle {
   hipEvent_t ev[kMaxSlots + 1][2] = {};   // per kernel slot (see Profile) + the whole call
   char slot_name[kMaxSlots][40] = {{0}};
   bool slot_used[kMaxSlots] = {false};
+  bool no_lane_general = false;      // SPMX_NO_LANE_GENERAL=1: FAST kernels hand every non-ASCII sentence to GENERAL
   bool no_stream = false;            // SPMX_NO_STREAM=1: tile / sentence-per-wave forms for unigram (A/B measurements)
   uint64_t stream_scratch_limit = 4ull << 30;   // SPMX_STREAM_SCRATCH_MB: cap on the streaming kernels' HBM scratch
   DevBuf<uint32_t> d_stream;         // scratch of the streaming kernels (text columns + back-pointer words)
@@ -319,6 +320,7 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
       a.tmp_off = h->d_tmp_off.p; a.counts = h->d_counts.p; a.status = &h->d_ctrl->status;
       a.stats = &h->d_ctrl->stats[kStatsPerClass * c];
       a.rcap = cls[c].rcap; a.ncap = cls[c].ncap;
+      a.no_lane_general = h->no_lane_general ? 1u : 0u;
       if (streaming) {
         if (known[c] == 0 && !prev_general) continue;
         a.ring = TileRing(h->tables.max_piece_len);
@@ -508,6 +510,7 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
   if (const char *e = getenv("SPMX_NO_TILE")) h->no_tile = e[0] == '1';
   if (const char *e = getenv("SPMX_NO_FAST")) h->no_fast = e[0] == '1';
   if (const char *e = getenv("SPMX_NO_STREAM")) h->no_stream = e[0] == '1';
+  if (const char *e = getenv("SPMX_NO_LANE_GENERAL")) h->no_lane_general = e[0] == '1';
   if (const char *e = getenv("SPMX_STREAM_SCRATCH_MB")) h->stream_scratch_limit = static_cast<uint64_t>(atoll(e)) << 20;
   if (const char *e = getenv("SPMX_TILE_WAVES")) h->tile_waves_override = atoi(e);
   if (const char *e = getenv("SPMX_TILE_AREA0")) h->tile_area_override[0] = static_cast<uint32_t>(atoi(e));

@@ -51,6 +51,7 @@ struct EncodeArgs {
   uint32_t *stream_text;        // [waves][StreamTextDwords(stream_tcap, ring)]
   uint32_t *stream_bp;          // [waves][StreamBpWords(stream_tcap)]
   uint32_t stream_tcap;         // bytes a text column holds
+  uint32_t no_lane_general;     // A/B switch: FAST kernels hand every non-ASCII sentence to the GENERAL kernel
   uint32_t *wave_list;          // BPE streaming kernels: sentences they leave to the sentence-per-wave kernel
   uint32_t *wave_count;
 };

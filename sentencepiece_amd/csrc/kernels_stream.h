@@ -141,6 +141,152 @@ SPMX_DEVICE int fast_norm_stream(const SpmxDev &d, const uint8_t *gtext, uint64_
   return w;
 }
 
+// ---- Normalize() of one sentence of ANY content by ONE lane (src/normalizer.cc:71-253) ------------------------
+// The same loop as the reference's: one NormalizePrefix result after another -- longest charsmap rule by a Darts
+// walk (darts.h:467-513), else one UTF-8 character, else U+FFFD for a malformed byte (util.cc:51-84) -- through
+// the whitespace state machine, with the output going to the lane's text column four bytes at a time.  Same
+// preconditions as fast_norm_stream (one-byte space symbol, no user-defined symbols, no whitespace-as-suffix).
+// Raw bytes come through a kRawWin-byte LDS window filled 16 bytes at a time; a rule walk that would outrun the
+// window, or an output longer than tcap, makes the lane give up (-1) and the sentence goes to the GENERAL kernel.
+constexpr int kRawWin = 64;
+constexpr uint32_t kLaneGeneralMaxRaw = 576;   // length classes whose sentences norm_lane_general takes
+
+SPMX_DEVICE int norm_lane_general(const SpmxDev &d, const uint8_t *gtext, uint64_t beg, int L, uint32_t *gt, int tcap,
+                                  uint8_t *rawwin) {
+  const uint32_t F = d.flags;
+  const bool rm = (F & kNfRemoveExtraWs) != 0;
+  const bool one = (F & kNfCompressSp) != 0;
+  const uint32_t sp1 = one ? kSpByte : 0x20u;              // the space symbol (one byte wide here)
+  const bool has_map = (F & kNfHasCharsmap) != 0;
+  const uint32_t droot = has_map ? DartsOffset(d.ndarts[0]) : 0u;
+  // raw byte i of the sentence (0 <= i < L, within kRawWin - 16 of every byte still needed) through the LDS window,
+  // which is indexed by the low bits of the absolute address and filled one aligned 16-byte block at a time
+  int hi;                                                  // raw bytes [0, hi) have been loaded
+  {
+    const uint64_t q0 = beg & ~15ull;
+    *reinterpret_cast<Q4 *>(rawwin + (q0 & (kRawWin - 1))) = *reinterpret_cast<const Q4 *>(gtext + q0);
+    hi = static_cast<int>(q0 + 16 - beg);
+  }
+  auto raw = [&](int i) __attribute__((always_inline)) -> uint32_t {
+    while (i >= hi) {
+      const uint64_t q = beg + static_cast<uint64_t>(hi);                // 16-byte aligned
+      *reinterpret_cast<Q4 *>(rawwin + (q & (kRawWin - 1))) = *reinterpret_cast<const Q4 *>(gtext + q);
+      hi += 16;
+    }
+    return rawwin[(beg + static_cast<uint64_t>(i)) & (kRawWin - 1)];
+  };
+  int w = 0, wl = 0;
+  uint32_t acc = 0;
+  bool giveup = false;
+  auto emit = [&](uint32_t b) __attribute__((always_inline)) {
+    if (w >= tcap) { giveup = true; return; }
+    acc |= b << (8 * (w & 3));
+    ++w;
+    if ((w & 3) == 0) { gt[((w >> 2) - 1) * 64] = acc; acc = 0; }
+    if (b != sp1) wl = w;                                  // :166-176 trailing space symbols are cut at the end
+  };
+  // NormalizePrefix at raw offset p (:195-253): kind 0 raw bytes [src, src + len), 1 rule string
+  // nblob[src, src + len), 2 U+FFFD, 3 the space symbol (a literal U+2581 under kNfCompressSp)
+  struct Pfx { int kind, len, consumed; uint32_t src; };
+  auto prefix = [&](int p) __attribute__((always_inline)) -> Pfx {
+    const uint32_t b0 = raw(p);
+    const int rem = L - p;
+    int rule_len = 0;
+    uint32_t rule_off = 0;
+    bool walk = has_map;
+    if (walk && b0 < 0x80u) {                              // ASCII followed by ASCII (or the end): tables.cc ascii_safe
+      const uint32_t b1 = rem >= 2 ? raw(p + 1) : 0u;
+      const uint32_t word = b0 < 64u ? (b0 < 32u ? d.ascii_safe[0] : d.ascii_safe[1]) : (b0 < 96u ? d.ascii_safe[2] : d.ascii_safe[3]);
+      if (b1 < 0x80u && ((word >> (b0 & 31u)) & 1u)) walk = false;
+    }
+    if (walk) {                                            // commonPrefixSearch, longest key (:218-228)
+      uint32_t pos = droot;
+      for (int depth = 0; p + depth < L;) {
+        if (depth >= kRawWin - 20) { giveup = true; break; }
+        const uint32_t c = raw(p + depth);
+        pos ^= c;
+        if (pos >= d.ndarts_n) break;
+        const uint32_t u = d.ndarts[pos];
+        if ((u & 0x800000FFu) != c) break;                 // unit.label() == c
+        pos ^= DartsOffset(u);
+        ++depth;
+        if ((u >> 8) & 1u) {                               // has_leaf: the value sits in the unit at pos
+          if (pos >= d.ndarts_n) break;
+          rule_len = depth;
+          rule_off = d.ndarts[pos] & 0x7FFFFFFFu;
+        }
+      }
+    }
+    Pfx r{0, 0, 0, 0};
+    if (rule_len > 0) {                                    // :245-250 the C string at normalized_[value]
+      int n = 0;
+      while (rule_off + static_cast<uint32_t>(n) < d.nblob_n && d.nblob[rule_off + n] != 0) ++n;
+      r = Pfx{1, n, rule_len, rule_off};
+    } else {
+      // :231-244 one UTF-8 character (DecodeUTF8, util.cc:51-84)
+      int mb = 1;
+      bool ok = b0 < 0x80u, lit_sp = false;
+      if (!ok) {
+        const uint32_t b1 = rem >= 2 ? raw(p + 1) : 0u, b2 = rem >= 3 ? raw(p + 2) : 0u, b3 = rem >= 4 ? raw(p + 3) : 0u;
+        const bool t1 = (b1 & 0xC0u) == 0x80u, t2 = (b2 & 0xC0u) == 0x80u, t3 = (b3 & 0xC0u) == 0x80u;
+        if (rem >= 2 && (b0 & 0xE0u) == 0xC0u) {
+          const uint32_t cp = (b0 & 0x1Fu) << 6 | (b1 & 0x3Fu);
+          if (t1 && cp >= 0x80u) { ok = true; mb = 2; }
+        } else if (rem >= 3 && (b0 & 0xF0u) == 0xE0u) {
+          const uint32_t cp = (b0 & 0x0Fu) << 12 | (b1 & 0x3Fu) << 6 | (b2 & 0x3Fu);
+          if (t1 && t2 && cp >= 0x800u && (cp < 0xD800u || cp >= 0xE000u)) { ok = true; mb = 3; }
+          lit_sp = ok && one && b0 == 0xE2u && b1 == 0x96u && b2 == 0x81u;
+        } else if (rem >= 4 && (b0 & 0xF8u) == 0xF0u) {
+          const uint32_t cp = (b0 & 0x07u) << 18 | (b1 & 0x3Fu) << 12 | (b2 & 0x3Fu) << 6 | (b3 & 0x3Fu);
+          if (t1 && t2 && t3 && cp >= 0x10000u && cp <= 0x10FFFFu) { ok = true; mb = 4; }
+        }
+      }
+      if (lit_sp) r = Pfx{3, 1, 3, 0};
+      else if (ok) r = Pfx{0, mb, mb, static_cast<uint32_t>(p)};
+      else r = Pfx{2, 3, 1, 0};
+    }
+    return r;
+  };
+  auto sp_byte = [&](const Pfx &x, int k) __attribute__((always_inline)) -> uint32_t {
+    if (x.kind == 0) return raw(static_cast<int>(x.src) + k);
+    if (x.kind == 1) return d.nblob[x.src + static_cast<uint32_t>(k)];
+    if (x.kind == 2) return k == 0 ? 0xEFu : (k == 1 ? 0xBFu : 0xBDu);
+    return kSpByte;
+  };
+  int p = 0;
+  if (rm) {                                                // :84-95 prefixes that normalize to exactly " "
+    while (p < L && !giveup) {
+      const Pfx x = prefix(p);
+      if (!(x.len == 1 && x.kind != 3 && sp_byte(x, 0) == 0x20u)) break;
+      p += x.consumed;
+    }
+  }
+  if (giveup) return -1;
+  if (p >= L) { gt[0] = 0; return 0; }                     // :98-100 nothing but whitespace
+  if (F & kNfAddDummyPrefix) emit(sp1);                    // :128
+  bool is_prev_space = rm;                                 // :130
+  while (p < L && !giveup) {
+    const Pfx x = prefix(p);
+    if (giveup) break;
+    int k = 0;
+    if (x.kind != 3) while (is_prev_space && k < x.len && sp_byte(x, k) == 0x20u) ++k;      // :137-138
+    if (k < x.len) {
+      uint32_t last = 0;
+      for (; k < x.len; ++k) {
+        last = sp_byte(x, k);
+        emit((x.kind != 3 && last == 0x20u) ? sp1 : last);  // :143-152 (whitespace escaping = the one-byte symbol)
+      }
+      is_prev_space = x.kind != 3 && last == 0x20u;        // :154
+    }
+    p += x.consumed;
+    if (!rm) is_prev_space = false;                        // :160-162
+  }
+  if (giveup) return -1;
+  gt[(w >> 2) * 64] = acc;                                 // the last, partial dword
+  if (rm) w = wl;
+  return w;
+}
+
 SPMX_HD inline bool StreamFastEligible(uint32_t flags) {
   return TileFastEligible(flags) && !((flags & kNfAddDummyPrefix) && (flags & kNfWsSuffix));
 }
@@ -395,6 +541,14 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
       const bool go = lane < cnt && !too_long;
       int nlen = 0;
       if (go && my_len > 0) nlen = fast_norm_stream(d, a.text, my_beg, static_cast<int>(my_len), gt, T.bcls);
+      // Not plain ASCII.  A tile that is mostly such sentences (CJK text ...) normalizes them here, one per lane
+      // (the raw window borrows the rings, idle until the search); a stray one in an ASCII tile would hold the
+      // other 63 lanes up for its whole length, and long sentences are better off position-parallel: both go to
+      // the GENERAL kernel.
+      const bool many = wv::popc64(wv::ballot(nlen < 0)) >= 16 && a.rcap <= kLaneGeneralMaxRaw && !a.no_lane_general;
+      if (many && nlen < 0)
+        nlen = norm_lane_general(d, a.text, my_beg, static_cast<int>(my_len), gt, static_cast<int>(tcap),
+                                 reinterpret_cast<uint8_t *>(T.ring_s) + static_cast<uint32_t>(lane) * (kRawWin + 16));
       const bool hard = go && nlen < 0;
       if (go && nlen >= 0) { mine = true; my_nlen = nlen; }
       const uint64_t hm = wv::ballot(hard);

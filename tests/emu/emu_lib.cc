@@ -218,6 +218,7 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
     a.arena = arena.data(); a.arena_head = &arena_head; a.arena_cap = arena.size();
     a.tmp_off = tmp_off.data(); a.counts = counts.data(); a.status = &status; a.stats = &stats[kStatsPerClass * c];
     a.rcap = cls[c].rcap; a.ncap = cls[c].ncap;
+    a.no_lane_general = getenv("SPMX_NO_LANE_GENERAL") ? 1u : 0u;
     a.ring = 16;
     while (a.ring < static_cast<uint32_t>(h->tables.max_piece_len) + 1) a.ring <<= 1;
     // streaming form for every unigram class, as in csrc/api.cc: the FAST kernel first (when the model allows

@@ -85,6 +85,30 @@ def test_emu_tile_variants(model, env, emu, oracle, corpora, monkeypatch):
 K_WORDWISE = 1 << 10   # dev.h kNfBpeWordwise
 
 
+@pytest.mark.parametrize("model,corpus,k", [("test_ja_model", "ja", 200), ("c5_250k", "mixed2k", 200),
+                                             ("uni1k_bf", "edge", 10 ** 6), ("bpe32k", "mixed2k", 40)])
+@pytest.mark.parametrize("env", [{}, {"SPMX_NO_LANE_GENERAL": "1"}])
+def test_emu_lane_general_normalizer(model, corpus, k, env, emu, oracle, corpora, monkeypatch):
+    """Non-ASCII text: the per-lane general normalizer keeps the sentences in the FAST kernel (charsmap rules,
+    malformed UTF-8, literal U+2581 ...); with it switched off they go through normalize_wave.  Same ids."""
+    for kk, v in env.items():
+        monkeypatch.setenv(kk, v)
+    blob = fixtures.model_blob(model)
+    h = emu.load(blob)
+    o = oracle.load(blob)
+    text, offs = fixtures.head(*corpora[corpus], k)
+    ids, io = h.encode_batch(text, offs, grid=2)
+    assert h.status == 0
+    oids, oio = o.encode_batch(text, offs)
+    np.testing.assert_array_equal(io, oio)
+    np.testing.assert_array_equal(ids, oids)
+    kept, handed = h.fast_split()
+    if env:
+        assert handed > 0.5 * (len(offs) - 1)
+    elif model != "uni1k_bf":      # (the edge cases are mostly ASCII tiles: stray non-ASCII sentences are handed over)
+        assert kept > 0.3 * (len(offs) - 1)
+
+
 @pytest.mark.parametrize("model", ["bpe1k", "bpe32k", "bpe1k_bf_uds", "bpe1k_noesc"])
 @pytest.mark.parametrize("env", [{}, {"SPMX_NO_WORDWISE": "1"}, {"SPMX_NO_COMPRESS": "1"}, {"SPMX_NO_FAST": "1"},
                                  {"SPMX_NO_STREAM": "1"}])
