@@ -10,7 +10,6 @@ except Exception as e:
     print('$*', 'FAILED', e)"
 }
 run SPMX_AB=default
-run SPMX_NO_STREAM=1
 run SPMX_TILE_WAVES=8
-run SPMX_TILE_WAVES=12
 run SPMX_NO_FAST=1
+run SPMX_NO_COMPRESS=1

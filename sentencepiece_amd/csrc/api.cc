@@ -87,14 +87,12 @@ struct spmx_handle {
   std::string extra_options;
   int device = 0;
   int n_cu = 256;
-  uint32_t tile_area_override[kNumTileClasses] = {0, 0};
-  bool no_tile = false;   // SPMX_NO_TILE=1: sentence-per-wave form for every class (A/B measurements)
-  bool no_fast = false;   // SPMX_NO_FAST=1: GENERAL tile kernel only
-  int tile_waves_override = 0;   // SPMX_TILE_WAVES: cap on wavefronts per tile workgroup
+  bool no_fast = false;   // SPMX_NO_FAST=1: GENERAL kernels only (A/B measurements)
+  int tile_waves_override = 0;   // SPMX_TILE_WAVES: cap on wavefronts per workgroup of the streaming kernels
   // device copies of the tables
   DevBuf<uint32_t> d_ndarts, d_sym_final;
   DevBuf<uint8_t> d_nblob;
-  DevBuf<U4> d_ptrie, d_idtab, d_chartab, d_pairtab;
+  DevBuf<U4> d_ptrie, d_chartab, d_pairtab;
   DevBuf<U2> d_utrie;
   DevBuf<uint16_t> d_sym_len;
   DevBuf<int32_t> d_byte_ids;
@@ -115,7 +113,7 @@ struct spmx_handle {
   char slot_name[kMaxSlots][40] = {{0}};
   bool slot_used[kMaxSlots] = {false};
   bool no_lane_general = false;      // SPMX_NO_LANE_GENERAL=1: FAST kernels hand every non-ASCII sentence to GENERAL
-  bool no_stream = false;            // SPMX_NO_STREAM=1: tile / sentence-per-wave forms for unigram (A/B measurements)
+  bool no_stream = false;            // SPMX_NO_STREAM=1: BPE in the sentence-per-wave form only (A/B measurements)
   uint64_t stream_scratch_limit = 4ull << 30;   // SPMX_STREAM_SCRATCH_MB: cap on the streaming kernels' HBM scratch
   DevBuf<uint32_t> d_stream;         // scratch of the streaming kernels (text columns + back-pointer words)
   bool ev_ready = false;
@@ -153,7 +151,6 @@ int UploadTables(spmx_handle *h) {
   HIP_OR_RETURN(h, Upload(&h->d_ndarts, t.ndarts));
   HIP_OR_RETURN(h, Upload(&h->d_nblob, t.nblob));
   HIP_OR_RETURN(h, Upload(&h->d_ptrie, t.ptrie));
-  HIP_OR_RETURN(h, Upload(&h->d_idtab, t.idtab));
   HIP_OR_RETURN(h, Upload(&h->d_utrie, t.utrie));
   HIP_OR_RETURN(h, Upload(&h->d_chartab, t.chartab));
   HIP_OR_RETURN(h, Upload(&h->d_pairtab, t.pairtab));
@@ -164,7 +161,6 @@ int UploadTables(spmx_handle *h) {
   h->dev.ndarts = h->d_ndarts.p;
   h->dev.nblob = h->d_nblob.p;
   h->dev.ptrie = h->d_ptrie.p;
-  h->dev.idtab = h->d_idtab.p;
   h->dev.utrie = h->d_utrie.p;
   h->dev.chartab = h->d_chartab.p;
   h->dev.pairtab = h->d_pairtab.p;
@@ -183,7 +179,7 @@ int RefreshDevice(spmx_handle *h, bool types_changed) {
     else HIP_OR_RETURN(h, Upload(&h->d_sym_final, t.sym_final));
   }
   SpmxDev d = t.scalars;
-  d.ndarts = h->dev.ndarts; d.nblob = h->dev.nblob; d.ptrie = h->d_ptrie.p; d.idtab = h->d_idtab.p; d.utrie = h->dev.utrie;
+  d.ndarts = h->dev.ndarts; d.nblob = h->dev.nblob; d.ptrie = h->d_ptrie.p; d.utrie = h->dev.utrie;
   d.chartab = h->dev.chartab; d.pairtab = h->dev.pairtab; d.sym_final = h->d_sym_final.p;
   d.sym_len = h->dev.sym_len; d.byte_ids = h->dev.byte_ids;
   h->dev = d;
@@ -193,7 +189,7 @@ int RefreshDevice(spmx_handle *h, bool types_changed) {
 void DestroyHandle(spmx_handle *h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
-  h->d_ndarts.Free(); h->d_sym_final.Free(); h->d_nblob.Free(); h->d_ptrie.Free(); h->d_idtab.Free(); h->d_chartab.Free();
+  h->d_ndarts.Free(); h->d_sym_final.Free(); h->d_nblob.Free(); h->d_ptrie.Free(); h->d_chartab.Free();
   h->d_pairtab.Free(); h->d_utrie.Free(); h->d_sym_len.Free(); h->d_byte_ids.Free();
   h->d_stream.Free(); h->d_lists.Free(); h->d_counts.Free(); h->d_tmp_off.Free(); h->d_tile_sums.Free(); h->d_arena.Free();
   h->d_text.Free(); h->d_offs.Free(); h->d_id_offs.Free(); h->d_ids.Free();
@@ -218,11 +214,11 @@ struct StreamPlan {
 StreamPlan PlanStream(const spmx_handle *h, const LengthClass &lc, bool fast, uint64_t known) {
   const int model = h->model.model_type;
   StreamPlan sp;
-  const uint32_t ring = TileRing(h->tables.max_piece_len);
+  const uint32_t ring = ScoreRing(h->tables.max_piece_len);
   // a FAST text column never exceeds raw length + 1 (one-byte space symbol); GENERAL: the class's normalized capacity
   sp.tcap = fast ? lc.rcap + 1 : lc.ncap;
   const uint32_t priv = StreamPrivateBytes(fast, model, lc.rcap, lc.ncap, ring);
-  int waves = static_cast<int>((kLdsPerCu - kTileSharedBytes) / priv);
+  int waves = static_cast<int>((kLdsPerCu - kStreamSharedBytes) / priv);
   const int wmax = fast ? 16 : 8;   // __launch_bounds__ of the two kernels
   if (waves > wmax) waves = wmax;
   if (waves < 1) waves = 1;
@@ -288,7 +284,7 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
     }
     // streaming (lane-per-sentence) kernels: every unigram model; BPE models that can be segmented word by word
     const bool bpe_stream = h->model.model_type == kBpe && (h->dev.flags & kNfBpeWordwise) && !(h->dev.flags & kNfHasUnused);
-    const bool streaming = (h->model.model_type == kUnigram || bpe_stream) && !h->no_stream;
+    const bool streaming = h->model.model_type == kUnigram || (bpe_stream && !h->no_stream);
     uint32_t known[kMaxClasses] = {0};   // class sizes after classify (escalations from a GENERAL kernel come on top)
     if (streaming) {
       HIP_OR_RETURN(h, hipMemcpyAsync(h->h_ctrl->list_counts, h->d_ctrl->list_counts, sizeof(h->h_ctrl->list_counts),
@@ -323,7 +319,7 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
       a.no_lane_general = h->no_lane_general ? 1u : 0u;
       if (streaming) {
         if (known[c] == 0 && !prev_general) continue;
-        a.ring = TileRing(h->tables.max_piece_len);
+        a.ring = ScoreRing(h->tables.max_piece_len);
         const bool fast = StreamFastEligible(h->dev.flags) && !h->no_fast && known[c] > 0;
         for (int pass = fast ? 0 : 1; pass < 2; ++pass) {
           const bool is_fast = pass == 0;
@@ -371,54 +367,18 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
         }
         continue;
       }
-      const bool tile = h->model.model_type == kUnigram && c < kNumTileClasses && !h->no_tile;
-      if (!tile) snprintf(h->slot_name[c], sizeof(h->slot_name[c]), "EncodeKernel<%d, %d>", h->model.model_type, c);
-      if (prof && !tile) HIP_OR_RETURN(h, hipEventRecord(h->ev[c][0], stream));
-      if (tile) {
-        // FAST kernel on the class list (when the model allows it), then the GENERAL kernel on what it left over
-        a.ring = TileRing(h->tables.max_piece_len);
-        const bool fast = TileFastEligible(h->dev.flags) && !h->no_fast;
-        for (int pass = fast ? 0 : 1; pass < 2; ++pass) {
-          const bool is_fast = pass == 0;
-          a.tile_area = is_fast ? kTileClasses[c].fast_area : kTileClasses[c].area;
-          if (h->tile_area_override[c] && is_fast == fast) a.tile_area = h->tile_area_override[c];   // SPMX_TILE_AREA0/1
-          const uint32_t floor_area = is_fast ? 2 * (a.rcap + 1) + 1 : 2 * a.ncap + 1;
-          if (a.tile_area < floor_area) a.tile_area = floor_area;
-          if (is_fast) {
-            a.hard_list = h->d_lists.p + static_cast<size_t>(ncls + c) * n;
-            a.hard_count = &h->d_ctrl->hard_counts[c];
-          } else if (fast) {
-            a.list = h->d_lists.p + static_cast<size_t>(ncls + c) * n;
-            a.list_count = &h->d_ctrl->hard_counts[c];
-            a.hard_list = nullptr; a.hard_count = nullptr;
-          }
-          const uint32_t priv = TilePrivateBytes(is_fast, a.rcap, a.ring, a.tile_area);
-          int waves = static_cast<int>((kLdsPerCu - kTileSharedBytes) / priv);
-          if (waves > (is_fast ? 16 : 8)) waves = is_fast ? 16 : 8;   // __launch_bounds__ of the two kernels
-          if (waves < 1) waves = 1;
-          if (h->tile_waves_override > 0 && h->tile_waves_override < waves) waves = h->tile_waves_override;
-          uint64_t grid = static_cast<uint64_t>(h->n_cu);          // one workgroup per CU; short batches: one
-          if (grid * waves > n) grid = (n + waves - 1) / waves;    // sentence per wave (the kernel sizes its tiles)
-          const uint32_t lds = TileLdsBytes(is_fast, a.rcap, a.ring, a.tile_area, static_cast<uint32_t>(waves));
-          const int slot = (fast && !is_fast) ? kSlotGeneral + c : c;
-          a.stats = &h->d_ctrl->stats[kStatsPerClass * slot];
-          snprintf(h->slot_name[slot], sizeof(h->slot_name[slot]), "EncodeTileKernel<%d, %s>", c, is_fast ? "true" : "false");
-          if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[slot][0], stream));
-          HIP_OR_RETURN(h, LaunchEncodeTile(c, is_fast, a, static_cast<int>(grid), waves, lds, stream));
-          if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[slot][1], stream));
-          h->slot_used[slot] = true;
-        }
-      } else {
-        const uint32_t lds = EncodeLdsBytes(h->model.model_type, a.rcap, a.ncap);
-        int per_cu = static_cast<int>(kLdsPerCu / lds);
-        if (per_cu > 32) per_cu = 32;
-        if (per_cu < 1) per_cu = 1;
-        uint64_t grid = static_cast<uint64_t>(h->n_cu) * per_cu;
-        if (grid > n) grid = n;
-        HIP_OR_RETURN(h, LaunchEncode(h->model.model_type, c, a, static_cast<int>(grid), lds, stream));
-        if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[c][1], stream));
-        h->slot_used[c] = true;
-      }
+      // BPE, sentence-per-wave form (models that are not word-wise, or SPMX_NO_STREAM)
+      snprintf(h->slot_name[c], sizeof(h->slot_name[c]), "EncodeKernel<%d, %d>", h->model.model_type, c);
+      const uint32_t lds = EncodeLdsBytes(h->model.model_type, a.rcap, a.ncap);
+      int per_cu = static_cast<int>(kLdsPerCu / lds);
+      if (per_cu > 32) per_cu = 32;
+      if (per_cu < 1) per_cu = 1;
+      uint64_t grid = static_cast<uint64_t>(h->n_cu) * per_cu;
+      if (grid > n) grid = n;
+      if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[c][0], stream));
+      HIP_OR_RETURN(h, LaunchEncode(h->model.model_type, c, a, static_cast<int>(grid), lds, stream));
+      if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[c][1], stream));
+      h->slot_used[c] = true;
     }
     {
       ScanArgs sa{h->d_counts.p, n32, h->d_tile_sums.p, d_id_offsets};
@@ -507,14 +467,11 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
   hipDeviceProp_t prop;
   if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
   h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if (const char *e = getenv("SPMX_NO_TILE")) h->no_tile = e[0] == '1';
   if (const char *e = getenv("SPMX_NO_FAST")) h->no_fast = e[0] == '1';
   if (const char *e = getenv("SPMX_NO_STREAM")) h->no_stream = e[0] == '1';
   if (const char *e = getenv("SPMX_NO_LANE_GENERAL")) h->no_lane_general = e[0] == '1';
   if (const char *e = getenv("SPMX_STREAM_SCRATCH_MB")) h->stream_scratch_limit = static_cast<uint64_t>(atoll(e)) << 20;
   if (const char *e = getenv("SPMX_TILE_WAVES")) h->tile_waves_override = atoi(e);
-  if (const char *e = getenv("SPMX_TILE_AREA0")) h->tile_area_override[0] = static_cast<uint32_t>(atoi(e));
-  if (const char *e = getenv("SPMX_TILE_AREA1")) h->tile_area_override[1] = static_cast<uint32_t>(atoi(e));
   if ((e = hipMalloc(reinterpret_cast<void **>(&h->d_ctrl), sizeof(Ctrl))) != hipSuccess) return bail(e, "hipMalloc(ctrl)");
   if ((e = hipHostMalloc(reinterpret_cast<void **>(&h->h_ctrl), sizeof(Ctrl), hipHostMallocDefault)) != hipSuccess)
     return bail(e, "hipHostMalloc(ctrl)");

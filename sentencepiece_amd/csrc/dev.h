@@ -71,8 +71,6 @@ struct SpmxDev {
   uint32_t flags;
   // ---- unigram (reference: src/unigram_model.cc:889-1020) ----
   const U4 *ptrie;        // piece trie with inline id / flags / score
-  const U4 *idtab;        // piece bytes -> id by 64-bit fingerprint {fa, fb, id, 0}; open addressing, empty: z == kSymNone
-  uint32_t idtab_mask, id_seed;
   float unk_score;        // min_score - 10.0f
   float max_score;
   int32_t unk_id;
@@ -95,19 +93,6 @@ struct SpmxDev {
 // A clear bit proves "no child c" without a probe (the walk's last, failing probe is usually predictable:
 // 97 % on the round-1 bench corpus); a set bit means "probe".
 SPMX_HD inline uint32_t ChildBit(uint32_t c) { return ((c * 37u) >> 3) & 31u; }
-
-// Fingerprint of a piece's bytes (as held in LDS, i.e. after the kNfCompressSp substitution), one byte at a time.
-// tables.cc checks at load that no two pieces share a fingerprint (and re-seeds if they do), so a match of both
-// words identifies the piece; the backtrack uses it instead of re-walking the trie (kernels_tile.h write_lane).
-SPMX_HD inline void PieceHashInit(uint32_t seed, uint32_t *a, uint32_t *b) {
-  *a = 0x811C9DC5u ^ seed;
-  *b = 0x9E3779B9u + seed * 0x85EBCA6Bu;
-}
-SPMX_HD inline void PieceHashStep(uint32_t *a, uint32_t *b, uint32_t c) {
-  *a = (*a ^ c) * 0x01000193u;
-  *b = (*b + c + 1u) * 0x85EBCA6Bu;
-}
-SPMX_HD inline uint32_t PieceHashSlot(uint32_t a, uint32_t b) { return a ^ (b >> 11) ^ (a >> 17); }
 
 SPMX_HD inline uint32_t HashPair(uint32_t a, uint32_t b) {
   uint64_t h = (static_cast<uint64_t>(a) << 32 | b) * 0x9E3779B97F4A7C15ull;

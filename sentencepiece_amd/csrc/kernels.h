@@ -1,9 +1,10 @@
 // Device bodies of the encode path: one sentence per 64-lane wavefront, the
 // whole sentence resident in LDS between the raw-byte load and the id store.
 //
-//   normalize_wave   Normalizer::Normalize          (src/normalizer.cc:71-253)
-//   unigram_wave     unigram::Model::EncodeOptimized (src/unigram_model.cc:889-1020)
-//   bpe_wave         bpe::Model::SampleEncode(a=0)   (src/bpe_model.cc:38-203)
+//   normalize_wave   Normalizer::Normalize          (src/normalizer.cc:71-253), position-parallel
+//   bpe_wave         bpe::Model::SampleEncode(a=0)   (src/bpe_model.cc:38-203), sentence per wave
+//   (the lane-per-sentence kernels -- unigram EncodeOptimized, word-wise BPE -- are in kernels_stream.h /
+//    kernels_bpe_stream.h)
 //   emit_wave        PopulateSentencePieceText + ApplyExtraOptions, ids only
 //                    (src/sentencepiece_processor.cc:547-636, :1019-1064)
 //
@@ -44,8 +45,8 @@ struct EncodeArgs {
   uint32_t *status;
   unsigned long long *stats;    // kStatsPerClass words: {sentences, raw bytes, ids, cycles load, normalize, segment, emit}
   uint32_t rcap, ncap;          // LDS capacities of this class: raw bytes, normalized bytes
-  uint32_t ring, tile_area;     // tile form (kernels_tile.h): score ring entries (power of two), bytes of the text area
-  uint32_t *hard_list;          // tile form, FAST kernel: sentences it leaves to the GENERAL kernel of the class
+  uint32_t ring;                // streaming form: score ring entries (power of two > longest piece)
+  uint32_t *hard_list;          // FAST kernel: sentences it leaves to the GENERAL kernel of the class
   uint32_t *hard_count;
   // streaming form (kernels_stream.h): HBM scratch, one slab per wavefront of the launch
   uint32_t *stream_text;        // [waves][StreamTextDwords(stream_tcap, ring)]
@@ -334,114 +335,6 @@ SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint
   return out;
 }
 
-// ---------------------------------------------------------------- unigram --
-// EncodeOptimized transposed for a wavefront: time t walks the END positions
-// serially; lane (s mod 64) owns the trie walk that started at character start
-// s and advances it by the one byte norm[t] that every live walk consumes at
-// time t.  All pieces (s, t+1) ending at t+1 therefore surface in the same
-// step, and best[t+1] is folded from them in increasing s -- the order the
-// reference visits them in -- with the reference's arithmetic: a piece
-// candidate is a double sum compared against the float-rounded best (:979-989),
-// the UNK candidate is a float sum (:997-1001).  Pieces are <= 64 bytes
-// (checked at load), so a lane is free again before its slot is reused.
-// Outputs the back-pointers: bid[e] = id, blen[e] = byte length of the piece
-// ending at e on the best path into e.
-SPMX_DEVICE void unigram_wave(const SpmxDev &d, const uint8_t *norm, int nlen, int32_t *bid, uint16_t *blen, int lane) {
-  const uint32_t root = d.ptrie[0].x >> kDatBaseShiftDev;
-  bool alive = false, pending = false;
-  uint32_t nb = 0;
-  float s_best = 0.f;
-  int s_start = 0, unk_t = -1;
-  float cur_best = 0.f;   // best_path_ends_at[t].best_path_score for a start at t (uniform)
-  int next_cstart = 0;
-  uint32_t vb = 0;
-  const uint32_t spb = SpByteOf(d);
-  for (int t = 0; t < nlen; ++t) {
-    if ((t & 63) == 0) vb = (t + lane < nlen) ? norm[t + lane] : 0u;
-    const uint32_t c = wv::shfl(vb, t & 63);
-    if (t == next_cstart) {                                // :960-968 a new character start
-      int mb = c == spb ? 1 : OneCharLenDev(c);
-      if (mb > nlen - t) mb = nlen - t;
-      next_cstart = t + mb;
-      if (lane == (t & 63)) {
-        alive = true; pending = true; nb = root; s_best = cur_best; s_start = t; unk_t = t + mb - 1;
-      }
-    }
-    bool has = false;
-    double cd = 0.0;
-    int32_t cid = 0;
-    if (alive) {                                           // :970-971 traverse one byte
-      const U4 u = d.ptrie[nb ^ c];
-      if ((u.x & 0x1FFu) == (0x100u | c)) {
-        nb = u.x >> kDatBaseShiftDev;
-        if ((u.x & kDatTerminalDev) && !(u.y & kPtUnused)) {   // :973-974
-          has = true;
-          cid = static_cast<int32_t>(u.y & kPtIdMask);
-          const int length = t + 1 - s_start;
-          double score;
-          if (u.y & kPtUserDefined) {                      // :979-981 (length * max_score_ - 0.1)
-            const float prod = static_cast<float>(length) * d.max_score;
-            score = static_cast<double>(prod) - 0.1;
-          } else {
-            score = static_cast<double>(wv::bits_to_float(u.z));
-          }
-          cd = score + static_cast<double>(s_best);        // :982-983
-        }
-      } else {
-        alive = false;                                     // ret == -2
-      }
-    }
-    if (pending && t == unk_t) {                           // :990-1005 no single-character piece -> UNK
-      pending = false;
-      if (!has) {
-        has = true;
-        cid = d.unk_id;
-        const float cf = d.unk_score + s_best;             // float arithmetic
-        cd = static_cast<double>(cf);
-      }
-    }
-    const uint64_t m = wv::ballot(has);
-    if (m) {
-      const int r = (t + 1) & 63;                          // lane of the oldest possible start
-      uint64_t rot = r ? ((m >> r) | (m << (64 - r))) : m;
-      bool set = false;
-      float acc = 0.f;
-      int win = 0;
-      while (rot) {
-        const int k = wv::ffs64(rot) - 1;
-        rot &= rot - 1;
-        const int l = (k + r) & 63;
-        const double v = wv::shfl(cd, l);
-        if (!set || v > static_cast<double>(acc)) {        // :984-989
-          acc = static_cast<float>(v);
-          win = l;
-          set = true;
-        }
-      }
-      cur_best = acc;
-      if (lane == win) {
-        bid[t + 1] = cid;
-        blen[t + 1] = static_cast<uint16_t>(t + 1 - s_start);
-      }
-    }
-  }
-  wv::sync();
-}
-
-// Marks the token ends of the best path (:1010-1018). Returns false on a broken chain.
-SPMX_DEVICE bool backtrack_wave(int nlen, uint16_t *blen, int lane) {
-  int e = nlen;
-  bool ok = true;
-  while (e > 0) {
-    const uint32_t l = blen[e] & (kTokEnd - 1);
-    if (l == 0 || static_cast<int>(l) > e) { ok = false; break; }
-    if (lane == 0) blen[e] = static_cast<uint16_t>(l | kTokEnd);
-    e -= static_cast<int>(l);
-  }
-  wv::sync();
-  return ok;
-}
-
 // ------------------------------------------------------------------- emit --
 // ids of the marked tokens in forward order, with the unknown-run merge or the
 // byte-fallback expansion (sentencepiece_processor.cc:581-613) and the net
@@ -557,7 +450,7 @@ SPMX_DEVICE void fail_sentence(const EncodeArgs &a, uint32_t sid, uint32_t bit, 
 
 namespace spmx {
 
-// Encodes sentence `sid` with this wave. MODEL: 1 unigram, 2 BPE.
+// Encodes sentence `sid` with this wave. MODEL: 2 (BPE).
 // Returns the number of ids written, or -1 if the sentence was handed on / failed.
 template <int MODEL>
 SPMX_DEVICE int encode_sentence(const EncodeArgs &a, uint32_t sid, const WaveLds &w, int lane, int *raw_len,
@@ -590,12 +483,8 @@ SPMX_DEVICE int encode_sentence(const EncodeArgs &a, uint32_t sid, const WaveLds
   if (nlen > 0) {
     for (int e = lane; e <= nlen; e += 64) w.blen[e] = 0;
     wv::sync();
-    if (MODEL == 1) {
-      unigram_wave(a.dev, w.norm, nlen, w.bid, w.blen, lane);
-      ok = backtrack_wave(nlen, w.blen, lane);
-    } else {
-      ok = bpe_wave(a, w.norm, nlen, w.bid, w.blen, carve_bpe(w.extra, a.ncap), lane);
-    }
+    static_assert(MODEL == 2, "the sentence-per-wave form serves BPE only");
+    ok = bpe_wave(a, w.norm, nlen, w.bid, w.blen, carve_bpe(w.extra, a.ncap), lane);
   }
   if (!ok) {
     fail_sentence(a, sid, kStInternal, lane);
@@ -811,7 +700,6 @@ SPMX_DEVICE void compact_block(const CompactArgs &a) {
 
 }  // namespace spmx
 
-#include "kernels_tile.h"
 #include "kernels_bpe_stream.h"
 #include "kernels_stream.h"
 

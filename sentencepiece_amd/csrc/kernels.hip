@@ -1,5 +1,4 @@
-// __global__ entry points for gfx950.  One 64-thread workgroup = one wavefront
-// = one sentence at a time; grids are persistent (grid-stride over work lists
+// __global__ entry points for gfx950.  Grids are persistent (grid-stride over work lists
 // whose lengths live in device memory, so no host round trip sits between the
 // classify, encode, scan and compact launches).
 #include "launch.h"
@@ -14,14 +13,7 @@ __global__ __launch_bounds__(64) void EncodeKernel(EncodeArgs a) {
   encode_block<MODEL>(a, smem);
 }
 
-// Tile form (kernels_tile.h): workgroups of up to 16 wavefronts, each wave on its own tiles.
-template <int CLS, bool FAST>
-__global__ __launch_bounds__(FAST ? 1024 : 512) void EncodeTileKernel(EncodeArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  encode_tile_block<FAST>(a, smem);
-}
-
-// Streaming form (kernels_stream.h): same workgroup shape as the tile form.
+// Streaming form (kernels_stream.h): workgroups of up to 16 wavefronts, each wave on its own tiles.
 template <int CLS, bool FAST>
 __global__ __launch_bounds__(FAST ? 1024 : 512) void EncodeStreamKernel(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -55,26 +47,14 @@ EncodeFn PickEncode(int cls) {
 }  // namespace
 
 hipError_t LaunchEncode(int model_type, int cls, const EncodeArgs &a, int grid, uint32_t lds_bytes, hipStream_t stream) {
-  EncodeFn fn = model_type == 2 ? PickEncode<2>(cls) : PickEncode<1>(cls);
+  (void)model_type;   // the sentence-per-wave form serves BPE only
+  EncodeFn fn = PickEncode<2>(cls);
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds_bytes));
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds_bytes, stream, a);
-  return hipGetLastError();
-}
-
-hipError_t LaunchEncodeTile(int cls, bool fast, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes,
-                            hipStream_t stream) {
-  EncodeFn fn = cls == 0 ? (fast ? EncodeTileKernel<0, true> : EncodeTileKernel<0, false>)
-                         : (fast ? EncodeTileKernel<1, true> : EncodeTileKernel<1, false>);
-  if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(lds_bytes));
-    if (e != hipSuccess) return e;
-  }
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * waves), lds_bytes, stream, a);
   return hipGetLastError();
 }
 

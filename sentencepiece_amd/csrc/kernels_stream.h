@@ -1,9 +1,18 @@
-// Unigram segmentation, streaming form: one SENTENCE PER LANE like the tile
-// form (kernels_tile.h), but with a per-lane working set in LDS that does not
-// depend on the sentence length, so that (a) 15-16 wavefronts fit a CU whatever
-// the length class and (b) sentences of any length up to the class capacity run
-// lane-parallel (the sentence-per-wave form spends its time in a serial loop
-// over end positions).
+// Unigram (and word-wise BPE) segmentation, streaming form: a wavefront takes a
+// tile of up to 64 sentences and runs ONE SENTENCE PER LANE, so that all 64
+// lanes carry an independent EncodeOptimized recurrence
+// (src/unigram_model.cc:889-1020), with a per-lane working set in LDS that does
+// not depend on the sentence length: 12 wavefronts fit a CU whatever the length
+// class, and sentences of any length up to the class capacity run lane-parallel.
+// (History, profiles/: a sentence-per-wave form spent 91 % of its cycles in a
+// serial loop over end positions; a form with text + back-pointers in LDS was
+// held to one wave per SIMD by its 2 B per byte per sentence.)
+//
+// The two nested loops of the reference (for each start: for each prefix) are
+// flattened into one loop in which every lane does exactly one trie probe per
+// iteration; a lane whose walk dies relaxes UNK and moves to its next start in
+// the same iteration, so lanes stay busy regardless of how deep their
+// neighbours' walks go.
 //
 // Per lane, in LDS (lane-interleaved or lane-strided, see StreamLds):
 //   * a ring of the R most recent positions' best_path_ends_at entries
@@ -22,13 +31,38 @@
 // The backtrack (:1010-1018) follows bp[] from the end and writes ids straight
 // into the arena, last piece first.
 //
-// Two kernels, as in the tile form: FAST (each lane normalizes its own ASCII
-// sentence from HBM into its text column) and GENERAL (normalize_wave into an
-// LDS buffer, one sentence at a time, then a copy into the lane's column).
+// Two kernels per length class: FAST (each lane normalizes its own sentence from
+// HBM into its text column: fast_norm_stream for ASCII, norm_lane_general for
+// tiles of mostly non-ASCII text) and GENERAL (normalize_wave into an LDS buffer,
+// one sentence at a time, then a copy into the lane's column) for what FAST
+// hands over through a device-side list and for models FAST cannot take.
+// A workgroup is W wavefronts that share nothing but two read-only LDS tables
+// (first trie level, byte classes; every wave writes identical copies, so no
+// workgroup barrier is ever needed); each wave owns a private slice of LDS.
 #ifndef SPMX_KERNELS_STREAM_H_
 #define SPMX_KERNELS_STREAM_H_
 
 namespace spmx {
+
+// byte classes of the FAST normalizer (StreamLds::bcls)
+constexpr uint32_t kBcComplex = 1u;    // not handled by fast_norm_stream: non-ASCII, or a charsmap rule may start here
+constexpr uint32_t kStreamSharedBytes = 256u * 16u + 256u;   // roottab + bcls
+
+// per-wave profiling counters
+struct WaveCounters {
+  unsigned long long n_sent = 0, n_raw = 0, n_ids = 0, n_trips = 0;
+  unsigned long long cyc[4] = {0, 0, 0, 0};
+};
+
+// :979-983 score of the piece in unit u (byte length len) as the reference's double
+SPMX_DEVICE double piece_score(const U4 &u, int len, float max_score) {
+  double score = static_cast<double>(wv::bits_to_float(u.z));
+  if (u.y & kPtUserDefined) {                                      // (length * max_score_ - 0.1)
+    const float prod = static_cast<float>(len) * max_score;
+    score = static_cast<double>(prod) - 0.1;
+  }
+  return score;
+}
 
 constexpr uint32_t kBwUnk = 0x80000000u;   // back-pointer word: the UNK candidate won this position
 constexpr int kBwLenShift = 24;
@@ -59,7 +93,7 @@ SPMX_HD inline uint32_t StreamPrivateBytes(bool fast, int model, uint32_t rcap, 
   return stage + work;
 }
 SPMX_HD inline uint32_t StreamLdsBytes(bool fast, int model, uint32_t rcap, uint32_t ncap, uint32_t ring, uint32_t waves) {
-  return kTileSharedBytes + waves * StreamPrivateBytes(fast, model, rcap, ncap, ring);
+  return kStreamSharedBytes + waves * StreamPrivateBytes(fast, model, rcap, ncap, ring);
 }
 // HBM scratch of one wavefront for a class whose normalized sentences have at most tcap bytes
 SPMX_HD inline uint64_t StreamTextDwords(uint32_t tcap, uint32_t ring) {      // uint32 [dw][64]
@@ -74,7 +108,7 @@ SPMX_DEVICE StreamLds carve_stream(unsigned char *base, bool fast, int model, ui
   t.roottab = reinterpret_cast<U4 *>(base);
   t.asym = reinterpret_cast<uint32_t *>(base);
   t.bcls = base + 256u * 16u;
-  unsigned char *mine = base + kTileSharedBytes + static_cast<uint32_t>(wave) * StreamPrivateBytes(fast, model, rcap, ncap, ring);
+  unsigned char *mine = base + kStreamSharedBytes + static_cast<uint32_t>(wave) * StreamPrivateBytes(fast, model, rcap, ncap, ring);
   t.raw = mine;
   t.norm = mine + ((rcap + 16 + 15) & ~15u);
   if (!fast) mine += ((rcap + 16 + 15) & ~15u) + ((ncap + 16 + 15) & ~15u);
@@ -90,9 +124,13 @@ SPMX_DEVICE StreamLds carve_stream(unsigned char *base, bool fast, int model, ui
   return t;
 }
 
-// Normalize() of one all-ASCII sentence by ONE lane, as fast_norm_lane (kernels_tile.h), with the output going to
-// the lane's text column gt[dw * 64] in HBM four bytes at a time.  Not for whitespace-as-suffix models (the suffix
-// would have to be patched into a dword that is already stored).
+// Normalize() of one all-ASCII sentence by ONE lane (src/normalizer.cc:71-186 with every NormalizePrefix result
+// being the byte itself, :231-244): raw text in HBM (16-byte aligned loads; a block that holds a byte of the
+// sentence lies in the same page as that byte, so the over-read at either end stays inside the caller's mapping)
+// -> the lane's text column gt[dw * 64], four bytes at a time.  Valid when the space symbol is one byte wide
+// (kNfCompressSp, or no whitespace escaping) and the model has no user-defined symbols; not for
+// whitespace-as-suffix models (the suffix would have to be patched into a dword that is already stored).  A byte
+// whose bcls entry says kBcComplex makes the lane give up (-1).
 SPMX_DEVICE int fast_norm_stream(const SpmxDev &d, const uint8_t *gtext, uint64_t beg, int L, uint32_t *gt,
                                  const uint8_t *bcls) {
   const uint32_t F = d.flags;
@@ -287,12 +325,32 @@ SPMX_DEVICE int norm_lane_general(const SpmxDev &d, const uint8_t *gtext, uint64
   return w;
 }
 
+// True when the preconditions of the per-lane normalizers hold for this model (host and device agree on it).
 SPMX_HD inline bool StreamFastEligible(uint32_t flags) {
-  return TileFastEligible(flags) && !((flags & kNfAddDummyPrefix) && (flags & kNfWsSuffix));
+  return !(flags & kNfHasUserDefined) && ((flags & kNfCompressSp) || !(flags & kNfEscapeWs)) &&
+         !((flags & kNfAddDummyPrefix) && (flags & kNfWsSuffix));
 }
 
-// EncodeOptimized for this lane's sentence (see unigram_lane in kernels_tile.h for the flattened loop and its
-// control / data halves; the relaxations (A), (B), (C) and their order are the same).  Differences:
+// piece_score with the user-defined branch under a wave-uniform flag
+SPMX_DEVICE double piece_score_u(const U4 &u, int len, float max_score, bool uds) {
+  if (uds) return piece_score(u, len, max_score);
+  return static_cast<double>(wv::bits_to_float(u.z));
+}
+
+// EncodeOptimized for this lane's sentence.  One iteration costs ONE global trie probe per lane, split into a
+// control half and a data half:
+//   control  (registers only) -- consume the probe in flight (:969-971); the child-label summary in the unit
+//            tells whether the next byte can match at all, so a walk's last, failing probe is usually never
+//            issued; if the walk of this start is over, move to the next start (:1007) and take its first
+//            trie level from the root-table unit that was fetched from LDS when the previous start began;
+//            issue the next probe;
+//   data     (LDS, under the shadow of that probe) -- up to three relaxations of best_path_ends_at, in the
+//            reference's order: (A) the piece just matched (double add, double compare against the
+//            float-rounded best, :979-989), (B) UNK for the start that is over unless a one-character piece
+//            was seen (float add, :990-1005), (C) a one-byte piece of the next start.  Their LDS reads are
+//            issued together; where two of them hit the same position the later one is forwarded the earlier
+//            one's result in registers.
+// State:
 //   * text comes from the W-byte LDS window `win` (position p at win[p & wmask]), refilled one dword per
 //     iteration from the lane's text column gt[] -- the load is issued next to the trie probe and lands in the
 //     window at the top of the next iteration, by which time the probe wait has covered it;
@@ -308,7 +366,7 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const uint32_t *gt, uint32
                                     const U4 *roottab, bool active_in) {
   const U4 *__restrict__ ptrie = d.ptrie;
   const float unk_score = d.unk_score, max_score = d.max_score;
-  const uint32_t spb = SpByteOf(d);
+  const bool uds = (d.flags & kNfHasUserDefined) != 0;   // wave-uniform: the user-defined score path is a scalar branch
   const int W = static_cast<int>(wmask) + 1;
   int trips = 0;
   bool active = active_in && nlen > 0;
@@ -344,10 +402,10 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const uint32_t *gt, uint32
     const bool ended = active && !cont;
     const int s2 = s + mb;                        // :1007 the next start
     const bool begin = ended && s2 < nlen;
-    int mb2 = cs == spb ? 1 : OneCharLenDev(cs);  // :962-963
-    if (mb2 > nlen - s2) mb2 = nlen - s2;
     const U4 r = rn;
-    const bool rootC = begin && (r.x & 0x1FFu) == (0x100u | cs);
+    int mb2 = static_cast<int>(r.x & 7u);         // :962-963 the character's byte length rides in the root-table entry
+    if (mb2 > nlen - s2) mb2 = nlen - s2;
+    const bool rootC = begin && (r.x & 0x100u);   // a piece starts with cs (entries without one have the bit clear)
     const bool termC = rootC && (r.x & kDatTerminalDev) && !(r.y & kPtUnused);
     const bool contC = rootC && s2 + 1 < nlen && ((r.w >> ChildBit(cs1)) & 1u);
     const bool nwalking = cont || contC;
@@ -368,7 +426,7 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const uint32_t *gt, uint32
     uint32_t bA = ring_b[oA], bB = ring_b[oB], bC = ring_b[oC];
     float rA = ring_s[oA], rB = ring_s[oB], rC = ring_s[oC];
     // (A) the piece that just matched
-    const double candA = piece_score(uA, dep1, max_score) + static_cast<double>(sbest);  // :982-983
+    const double candA = piece_score_u(uA, dep1, max_score, uds) + static_cast<double>(sbest);  // :982-983
     const bool updA = termA && (bA == 0 || candA > static_cast<double>(rA));             // :984-989
     const float nvA = static_cast<float>(candA);
     const uint32_t wA = (uA.y & kBwIdMask) | (static_cast<uint32_t>(dep1) << kBwLenShift);
@@ -381,7 +439,7 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const uint32_t *gt, uint32
     const float sbest2 = updB ? candB : rB;
     const uint32_t finB = updB ? ((static_cast<uint32_t>(mb) << kBwLenShift) | kBwUnk) : bB;
     // (C) a one-byte piece of the next start
-    const double candC = piece_score(r, 1, max_score) + static_cast<double>(sbest2);
+    const double candC = piece_score_u(r, 1, max_score, uds) + static_cast<double>(sbest2);
     const bool updC = termC && (bC == 0 || candC > static_cast<double>(rC));
     if (updA) { ring_s[oA] = nvA; ring_b[oA] = wA; }
     if (updC) { ring_s[oC] = static_cast<float>(candC); ring_b[oC] = (r.y & kBwIdMask) | (1u << kBwLenShift); }
@@ -493,6 +551,9 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
       if (MODEL == 1) {
         U4 r = d.ptrie[root ^ cb];
         if ((r.x & 0x1FFu) != (0x100u | cb)) r = U4{0, 0, 0, 0};
+        // the label byte is redundant here (it is the index): it carries the byte length of a character that
+        // starts with cb instead (src/util.h:151-153; the one-byte space symbol is one character)
+        r.x = (r.x & ~0xFFu) | static_cast<uint32_t>(cb == SpByteOf(d) ? 1 : OneCharLenDev(cb));
         T.roottab[cb] = r;
       } else {
         T.asym[cb] = char_lookup(d, cb, 1u);
@@ -515,7 +576,7 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
   tw = tw < 1u ? 1u : (tw > 64u ? 64u : tw);
   const uint32_t tiles = (count + tw - 1) / tw;
   const int n_extra = d.n_prefix + d.n_suffix;
-  TileCounters tc;
+  WaveCounters tc;
   for (uint32_t tile = wave_id; tile < tiles; tile += n_waves) {
     const uint32_t first = tile * tw;
     const int cnt = static_cast<int>(count - first < tw ? count - first : tw);

@@ -4,7 +4,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
-#include <set>
 
 #include "dat.h"
 
@@ -195,31 +194,8 @@ Status CompileTables(const ModelData &m, HostTables *t) {
         if (base < owner.size() && owner[base] != 0xFFFFFFFFu) t->ptrie[owner[base]].w |= 1u << ChildBit(c);
       }
     }
-    // piece bytes -> id by fingerprint, for the backtrack (kernels_tile.h write_lane)
-    for (uint32_t seed = 0;; ++seed) {
-      if (seed == 64) return Status::Error(kInternal, "piece fingerprints keep colliding");
-      std::set<std::pair<uint32_t, uint32_t>> seen;
-      const uint32_t sz = NextPow2(keys.size() * 2 + 16);
-      t->idtab.assign(sz, U4{0, 0, kSymNone, 0});
-      bool clash = false;
-      for (const auto &kv : keys) {
-        uint32_t a, b;
-        PieceHashInit(seed, &a, &b);
-        for (unsigned char c : kv.first) PieceHashStep(&a, &b, c);
-        if (!seen.emplace(a, b).second) { clash = true; break; }
-        uint32_t s = PieceHashSlot(a, b) & (sz - 1);
-        while (t->idtab[s].z != kSymNone) s = (s + 1) & (sz - 1);
-        t->idtab[s] = U4{a, b, kv.second, 0};
-      }
-      if (clash) continue;
-      sc.id_seed = seed;
-      sc.idtab_mask = sz - 1;
-      break;
-    }
   } else {
     t->ptrie.assign(256, U4{0, 0, 0, 0});
-    t->idtab.assign(16, U4{0, 0, kSymNone, 0});
-    sc.idtab_mask = 15;
   }
 
   // ------------------------------------------------------------------- BPE --
@@ -391,7 +367,6 @@ void BindHostPointers(HostTables *t) {
   sc.ndarts = t->ndarts.data();
   sc.nblob = t->nblob.data();
   sc.ptrie = t->ptrie.data();
-  sc.idtab = t->idtab.data();
   sc.byte_ids = t->byte_ids.data();
   sc.utrie = t->utrie.data();
   sc.chartab = t->chartab.data();

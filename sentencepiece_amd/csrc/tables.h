@@ -16,7 +16,6 @@ struct HostTables {
   std::vector<uint8_t> nblob;
   // unigram
   std::vector<U4> ptrie;
-  std::vector<U4> idtab;   // piece fingerprint -> id (dev.h PieceHash*)
   // bpe
   std::vector<U2> utrie;
   std::vector<U4> chartab, pairtab;

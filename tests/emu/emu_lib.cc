@@ -221,10 +221,10 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
     a.no_lane_general = getenv("SPMX_NO_LANE_GENERAL") ? 1u : 0u;
     a.ring = 16;
     while (a.ring < static_cast<uint32_t>(h->tables.max_piece_len) + 1) a.ring <<= 1;
-    // streaming form for every unigram class, as in csrc/api.cc: the FAST kernel first (when the model allows
-    // it), then the GENERAL kernel on what it left over.  SPMX_NO_STREAM: tile / sentence-per-wave forms.
+    // streaming form, as in csrc/api.cc: the FAST kernel first (when the model allows it), then the GENERAL
+    // kernel on what it left over.
     const bool bpe_stream = bpe && (dev.flags & kNfBpeWordwise) && !(dev.flags & kNfHasUnused);
-    if ((!bpe || bpe_stream) && !getenv("SPMX_NO_STREAM")) {
+    if (!bpe || (bpe_stream && !getenv("SPMX_NO_STREAM"))) {
       std::vector<uint32_t> hard(n ? n : 1), wavel(n ? n : 1);
       uint32_t hard_count = 0, wave_count = 0;
       const int waves = grid;   // one wave per block in the emulator
@@ -261,31 +261,10 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
       }
       continue;
     }
-    // tile form for the first unigram classes (small areas here to exercise the rounds)
-    const bool tile = !bpe && c < 3 && !getenv("SPMX_NO_TILE");
-    if (tile) {
-      a.tile_area = c == 0 ? 512 : (c == 1 ? 4096 : 6144);
-      if (a.tile_area < 2 * a.ncap + 1) a.tile_area = 2 * a.ncap + 1;
-      if (a.tile_area < 2 * (a.rcap + 1) + 1) a.tile_area = 2 * (a.rcap + 1) + 1;
-      std::vector<uint32_t> hard(n ? n : 1);
-      uint32_t hard_count = 0;
-      if (TileFastEligible(dev.flags) && !getenv("SPMX_NO_FAST")) {
-        a.hard_list = hard.data(); a.hard_count = &hard_count;
-        std::vector<unsigned char> fsmem(TileLdsBytes(true, a.rcap, a.ring, a.tile_area, 1) + 64, 0xCD);
-        for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, fsmem.data(), [&] { encode_tile_block<true>(a, fsmem.data()); });
-        g_fast_kept += list_counts[c] - hard_count;
-        g_fast_handed += hard_count;
-        a.list = hard.data(); a.list_count = &hard_count;
-        a.hard_list = nullptr; a.hard_count = nullptr;
-      }
-      std::vector<unsigned char> tsmem(TileLdsBytes(false, a.rcap, a.ring, a.tile_area, 1) + 64, 0xCD);
-      for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, tsmem.data(), [&] { encode_tile_block<false>(a, tsmem.data()); });
-      continue;
-    }
+    // BPE, sentence-per-wave form (models that are not word-wise, or SPMX_NO_STREAM)
     std::vector<unsigned char> smem(EncodeLdsBytes(dev.model_type, a.rcap, a.ncap) + 64, 0xCD);
     for (int b = 0; b < grid; ++b) {
-      if (bpe) emu::RunWave(b, grid, smem.data(), [&] { encode_block<2>(a, smem.data()); });
-      else emu::RunWave(b, grid, smem.data(), [&] { encode_block<1>(a, smem.data()); });
+      emu::RunWave(b, grid, smem.data(), [&] { encode_block<2>(a, smem.data()); });
     }
   }
   std::vector<uint64_t> tile_sums((n + kScanTile - 1) / kScanTile + 2, 0);

@@ -56,12 +56,10 @@ def test_emu_long_sentences(model, emu, oracle, corpora):
 
 @pytest.mark.parametrize("model", ["test_model", "uni1k_bf", "uni1k_suffix", "uni1k_ident", "uni32k"])
 @pytest.mark.parametrize("env", [{}, {"SPMX_NO_COMPRESS": "1"}, {"SPMX_NO_FAST": "1"},
-                                 {"SPMX_NO_COMPRESS": "1", "SPMX_NO_FAST": "1"}, {"SPMX_NO_STREAM": "1"},
-                                 {"SPMX_NO_STREAM": "1", "SPMX_NO_FAST": "1"},
-                                 {"SPMX_NO_STREAM": "1", "SPMX_NO_TILE": "1"}])
+                                 {"SPMX_NO_COMPRESS": "1", "SPMX_NO_FAST": "1"}])
 def test_emu_tile_variants(model, env, emu, oracle, corpora, monkeypatch):
-    """Streaming / tile / sentence-per-wave forms x one-byte space symbol on/off x FAST per-lane normalizer
-    on/off: same ids; with everything on, ASCII sentences stay in the FAST kernel and the rest is handed over."""
+    """One-byte space symbol on/off x FAST per-lane normalizer on/off: same ids; with both on, ASCII sentences
+    stay in the FAST kernel and the rest is handed over."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     blob = fixtures.model_blob(model)
@@ -78,7 +76,7 @@ def test_emu_tile_variants(model, env, emu, oracle, corpora, monkeypatch):
         kept, handed = h.fast_split()
         if not env and name == "synth20k" and model != "uni1k_suffix":   # suffix mode: GENERAL kernel only
             assert kept > 0.9 * (len(offs) - 1)
-        if "SPMX_NO_FAST" in env or "SPMX_NO_COMPRESS" in env or "SPMX_NO_TILE" in env:
+        if "SPMX_NO_FAST" in env or "SPMX_NO_COMPRESS" in env:
             assert kept == 0
 
 
