@@ -10,3 +10,5 @@ python scripts/rocpd_summary.py "$DB" > $O/uni32k_10m_kernel_stats.txt 2>> $O/pr
 rm -rf $O/prof
 
 
+timeout 600 python bench.py --model bpe32k --steps 3 --warmup 1 > $O/bench_bpe32k_10m.json 2> $O/bench_bpe.err; tail -c 1500 $O/bench_bpe32k_10m.json
+timeout 900 python bench.py --model c5_250k --sentences 1000000 --steps 3 --warmup 1 > $O/bench_c5_250k_1m.json 2> $O/bench_c5.err; tail -c 1500 $O/bench_c5_250k_1m.json
