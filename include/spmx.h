@@ -92,6 +92,24 @@ void spmx_free(void *p);
  * RESOURCE_EXHAUSTED with the needed size in *n_ids if cap is too small. */
 int spmx_encode(spmx_handle *h, const char *text, uint64_t len, int32_t *ids, uint64_t cap, uint64_t *n_ids);
 
+/* ---- decode -------------------------------------------------------------
+ * Element-wise identical to SentencePieceProcessor::Decode(const std::vector<int>& ids, std::string*)
+ *   (src/sentencepiece_processor.h:330-331, .cc:761-925): control pieces vanish, the unknown piece becomes
+ *   trainer_spec.unk_surface, byte pieces are reassembled into UTF-8 (a structurally invalid byte -> U+FFFD),
+ *   U+2581 -> ' ', leading whitespace handled as the normalizer_spec asks.  An id outside [0, GetPieceSize())
+ *   fails the call with OUT_OF_RANGE (11) "Invalid id: N"; a model with a denormalizer_spec is UNIMPLEMENTED (12).
+ * Ids are CSR (as produced by the encode calls); text comes back packed with text_offsets (n + 1 entries). */
+
+/* Device-resident form: every pointer is HIP device memory.  If text_capacity is too small (or d_text is NULL)
+ * returns RESOURCE_EXHAUSTED (8) with the required capacity in *total_bytes (d_text_offsets is valid). */
+int spmx_decode_batch_device(spmx_handle *h, const int32_t *d_ids, const uint64_t *d_id_offsets, uint64_t n, void *d_text,
+                             uint64_t text_capacity, uint64_t *d_text_offsets, void *stream, uint64_t *total_bytes);
+/* Host-buffer form; *text (total bytes) and *text_offsets (n + 1) are released with spmx_free(). */
+int spmx_decode_batch(spmx_handle *h, const int32_t *ids, const uint64_t *id_offsets, uint64_t n, char **text,
+                      uint64_t **text_offsets);
+/* Single sentence, caller-provided buffer (Decode(ids, &text)); RESOURCE_EXHAUSTED with the needed size in *len. */
+int spmx_decode(spmx_handle *h, const int32_t *ids, uint64_t n_ids, char *out, uint64_t cap, uint64_t *len);
+
 /* ---- measurement --------------------------------------------------------
  * Per-kernel timing of the encode kernels of the LAST
  * spmx_encode_batch_device call, measured with hipEvents on the caller's

@@ -157,6 +157,46 @@ class SentencePieceProcessor {
                                                d_id_offsets, stream, total_ids));
   }
 
+  // ---- decode (sentencepiece_processor.h:330-331, :480-482) ----
+  util::Status Decode(const std::vector<int> &ids, std::string *detokenized) const {
+    if (!h_) return status();
+    if (!detokenized) return util::Status(util::StatusCode::kInternal, "output container is null");
+    detokenized->clear();
+    char *text = nullptr;
+    uint64_t *offs = nullptr;
+    const uint64_t io[2] = {0, ids.size()};
+    static_assert(sizeof(int) == sizeof(int32_t), "ids are 32-bit");
+    const int32_t none = 0;
+    const int rc = spmx_decode_batch(h_, ids.empty() ? &none : reinterpret_cast<const int32_t *>(ids.data()), io, 1, &text, &offs);
+    if (rc != 0) return FromHandle(rc);
+    detokenized->assign(text, text + offs[1]);
+    spmx_free(text);
+    spmx_free(offs);
+    return util::Status();
+  }
+  std::string DecodeIds(const std::vector<int> &ids) const {   // errors are swallowed, as in the reference
+    std::string out;
+    (void)Decode(ids, &out);
+    return out;
+  }
+  // Flat form: CSR ids in, packed text + offsets out.
+  util::Status DecodeBatchFlat(const int32_t *ids, const uint64_t *id_offsets, uint64_t n, std::string *text,
+                               std::vector<uint64_t> *text_offsets) const {
+    if (!h_) return status();
+    if (!text || !text_offsets) return util::Status(util::StatusCode::kInternal, "output container is null");
+    text->clear();
+    text_offsets->clear();
+    char *t = nullptr;
+    uint64_t *offs = nullptr;
+    const int rc = spmx_decode_batch(h_, ids, id_offsets, n, &t, &offs);
+    if (rc != 0) return FromHandle(rc);
+    text_offsets->assign(offs, offs + n + 1);
+    text->assign(t, t + offs[n]);
+    spmx_free(t);
+    spmx_free(offs);
+    return util::Status();
+  }
+
   // ---- vocabulary ----
   int GetPieceSize() const { return h_ ? spmx_piece_size(h_) : 0; }
   int PieceToId(std::string_view piece) const { return h_ ? spmx_piece_to_id(h_, piece.data(), piece.size()) : 0; }

@@ -185,6 +185,26 @@ int64_t spmref_encode_count(void *handle, const char *text,
   return total;
 }
 
+// SentencePieceProcessor::Decode(const std::vector<int>&, std::string*) per sentence of a CSR id buffer.
+// Returns total bytes, -1 on a Status error, -(needed) - 2 if cap is too small.
+int64_t spmref_decode_batch(void *handle, const int32_t *ids, const uint64_t *id_offsets, uint64_t n,
+                            char *text, uint64_t cap, uint64_t *text_offsets) {
+  auto *h = static_cast<RefHandle *>(handle);
+  std::string all;
+  for (uint64_t i = 0; i < n; ++i) {
+    text_offsets[i] = all.size();
+    std::vector<int> v(ids + id_offsets[i], ids + id_offsets[i + 1]);
+    std::string out;
+    const auto st = h->sp.Decode(v, &out);
+    if (!st.ok()) { h->last_error = st.ToString(); return -1; }
+    all += out;
+  }
+  text_offsets[n] = all.size();
+  if (all.size() > cap) return -static_cast<int64_t>(all.size()) - 2;
+  memcpy(text, all.data(), all.size());
+  return static_cast<int64_t>(all.size());
+}
+
 int spmref_piece_size(void *handle) {
   return static_cast<RefHandle *>(handle)->sp.GetPieceSize();
 }

@@ -53,6 +53,8 @@ struct Oracle {
   /* trainer_spec */
   int model_type, byte_fallback, ws_suffix;
   sv unk_piece, bos_piece, eos_piece, pad_piece;
+  sv unk_surface; int has_unk_surface;   /* trainer_spec.unk_surface (sentencepiece_model.proto:228) */
+  int has_denormalizer;                   /* denormalizer_spec with a charsmap (sentencepiece_processor.cc:248-252) */
   /* normalizer_spec */
   sv charsmap; int add_dummy_prefix, remove_extra_ws, escape_ws;
   const uint32_t *nunits; size_t n_nunits; const char *nstrings; size_t nstrings_n;
@@ -596,6 +598,7 @@ Oracle *oracle_load(const void *model_bytes, uint64_t n, char *err, uint64_t err
         if (g == 3 && wt == 0) o->model_type = (int)v;
         else if (g == 24 && wt == 0) o->ws_suffix = v != 0;
         else if (g == 35 && wt == 0) o->byte_fallback = v != 0;
+        else if (g == 44 && wt == 2) { o->unk_surface = ts; o->has_unk_surface = 1; }
         else if (g == 45 && wt == 2 && ts.n) o->unk_piece = ts;   /* RETURN_PIECE: empty -> default */
         else if (g == 46 && wt == 2 && ts.n) o->bos_piece = ts;
         else if (g == 47 && wt == 2 && ts.n) o->eos_piece = ts;
@@ -610,6 +613,10 @@ Oracle *oracle_load(const void *model_bytes, uint64_t n, char *err, uint64_t err
         else if (g == 4 && wt == 0) o->remove_extra_ws = v != 0;
         else if (g == 5 && wt == 0) o->escape_ws = v != 0;
       }
+      if (t.err) b.err = 1;
+    } else if (f == 5 && wt == 2) {                          /* denormalizer_spec */
+      PB t = { s.p, s.p + s.n, 0 }; int g; sv ts;
+      while ((g = pb_next(&t, &wt, &v, &ts))) if (g == 2 && wt == 2 && ts.n) o->has_denormalizer = 1;
       if (t.err) b.err = 1;
     }
   }
@@ -720,6 +727,100 @@ int64_t oracle_encode_batch(const Oracle *o, const char *text, const uint64_t *o
   if (failed) return -1;
   if (total > cap) return -(int64_t)total - 2;
   return (int64_t)total;
+}
+
+
+/* ------------------------------------------------------------------ decode */
+/* SentencePieceProcessor::Decode(const std::vector<int>& ids, std::string*)
+ * (sentencepiece_processor.cc:761-925): ids -> IdToPiece -> the piece-level Decode, text only.
+ * Returns 0, 11 (OUT_OF_RANGE "Invalid id"), 12 (a denormalizer is not restated). */
+static const uint8_t kSpaceSym[3] = { 0xE2, 0x96, 0x81 };
+static void buf_put(Buf *b, const uint8_t *p, size_t n) {
+  if (b->n + n > b->cap) { b->cap = (b->n + n) * 2 + 64; b->p = realloc(b->p, b->cap); }
+  memcpy(b->p + b->n, p, n); b->n += n;
+}
+/* ProcessBytePieces (:825-880): one Unicode character at a time; a structurally invalid byte -> U+FFFD */
+static void flush_bytes(Buf *bytes, Buf *text) {
+  size_t off = 0;
+  while (off < bytes->n) {
+    size_t consumed;
+    if (!is_valid_decode_utf8(bytes->p + off, bytes->n - off, &consumed)) {
+      static const uint8_t rep[3] = { 0xEF, 0xBF, 0xBD };
+      buf_put(text, rep, 3);                               /* consumed == 1 */
+    } else {
+      buf_put(text, bytes->p + off, consumed);
+    }
+    off += consumed;
+  }
+  bytes->n = 0;
+}
+static int decode_ids(const Oracle *o, const int32_t *ids, size_t n, Buf *text) {
+  static const uint8_t kDefaultUnk[] = { ' ', 0xE2, 0x81, 0x87, ' ' };   /* kDefaultUnknownSymbol (:52) */
+  sv unk_surface = { kDefaultUnk, 5 };
+  if (o->has_unk_surface) {                                /* .c_str(): up to the first NUL (:772-773) */
+    unk_surface = o->unk_surface;
+    const void *z = memchr(unk_surface.p, 0, unk_surface.n);
+    if (z) unk_surface.n = (size_t)((const uint8_t *)z - unk_surface.p);
+  }
+  if (o->has_denormalizer) return 12;
+  for (size_t i = 0; i < n; ++i) if (ids[i] < 0 || ids[i] >= o->n_pieces) return 11;   /* :913-917 */
+  Buf bytes = { 0, 0, 0 };
+  const size_t text0 = text->n;
+  int is_bos_ws = 1, bos_ws_seen = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const sv piece = o->pieces[ids[i]].piece;
+    const int id = piece_to_id(o, piece);                  /* sp->set_id(PieceToId(w)) (:812) */
+    const int type = o->pieces[id].type;
+    if (type == T_BYTE) {                                  /* PieceToByte("<0xHH>") (:836) */
+      unsigned v = 0;
+      for (int k = 3; k < 5; ++k) {
+        const uint8_t c = piece.p[k];
+        v = v * 16 + (c <= '9' ? c - '0' : (c | 0x20) - 'a' + 10);
+      }
+      const uint8_t bb = (uint8_t)v;
+      buf_put(&bytes, &bb, 1);
+      continue;
+    }
+    flush_bytes(&bytes, text);
+    if (bos_ws_seen || text->n > text0) is_bos_ws = 0;     /* :893 */
+    if (type == T_CONTROL) { bos_ws_seen = 0; continue; }  /* :780-781 invisible */
+    if (type == T_UNKNOWN) {                               /* :782-788 */
+      if (sv_eq(o->pieces[id].piece, piece)) buf_put(text, unk_surface.p, unk_surface.n);
+      else buf_put(text, piece.p, piece.n);
+      bos_ws_seen = 0;
+      continue;
+    }
+    const uint8_t *p = piece.p; size_t m = piece.n;
+    int has_bos_ws = 0;
+    if (is_bos_ws && (o->add_dummy_prefix || o->remove_extra_ws)) {   /* :791-805 */
+      if (m >= 3 && memcmp(p, kSpaceSym, 3) == 0) { p += 3; m -= 3; has_bos_ws = 1; }
+      if (o->remove_extra_ws) has_bos_ws = 0;
+    }
+    for (size_t k = 0; k < m;) {                           /* StrReplaceAll(piece, {{kSpaceSymbol, " "}}) (:807) */
+      if (k + 3 <= m && memcmp(p + k, kSpaceSym, 3) == 0) { const uint8_t sp = ' '; buf_put(text, &sp, 1); k += 3; }
+      else { buf_put(text, p + k, 1); ++k; }
+    }
+    bos_ws_seen = has_bos_ws;
+  }
+  flush_bytes(&bytes, text);
+  free(bytes.p);
+  return 0;
+}
+
+int64_t oracle_decode_batch(const Oracle *o, const int32_t *ids, const uint64_t *id_offsets, uint64_t n,
+                            char *text, uint64_t cap, uint64_t *text_offsets) {
+  Buf b = { 0, 0, 0 };
+  for (uint64_t i = 0; i < n; ++i) {
+    text_offsets[i] = b.n;
+    const int rc = decode_ids(o, ids + id_offsets[i], (size_t)(id_offsets[i + 1] - id_offsets[i]), &b);
+    if (rc) { free(b.p); return -rc * 1000; }
+  }
+  text_offsets[n] = b.n;
+  const int64_t total = (int64_t)b.n;
+  if ((uint64_t)total > cap) { free(b.p); return -total - 2; }
+  if (total) memcpy(text, b.p, (size_t)total);
+  free(b.p);
+  return total;
 }
 
 int oracle_piece_size(const Oracle *o) { return o->n_pieces; }

@@ -134,6 +134,19 @@ def edge_sentences():
     ]
 
 
+def decode_fuzz_ids(vocab_size, seed=20250301):
+    """Seeded random CSR ids for the Decode parity tests: 600 sentences of 0..150 ids, two thirds of them drawn
+    from the first 300 ids (where the control, unknown and byte pieces live)."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0, 150, size=600)
+    total = int(lens.sum())
+    low = rng.integers(0, min(vocab_size, 300), size=total)
+    high = rng.integers(0, vocab_size, size=total)
+    ids = np.where(rng.random(total) < 0.67, low, high).astype(np.int32)
+    io = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    return ids, io
+
+
 MODELS = ["test_model", "test_ja_model", "uni1k", "bpe1k", "uni1k_bf", "bpe1k_bf_uds", "uni1k_uds",
           "uni1k_ident", "uni1k_suffix", "bpe1k_noesc", "uni32k", "bpe32k"]
 PAIRS = [(m, c) for m in MODELS for c in ("botchan", "edge", "mixed2k")] + \
@@ -168,7 +181,21 @@ def make_ids():
         arrays[key + "__cnt"] = np.diff(id_offs.astype(np.int64)).astype(np.uint16)
         manifest[key] = dict(model=m, corpus=c, options=opt, n=int(len(offs) - 1), tokens=int(len(ids)),
                              sha256=hashlib.sha256(ids.astype("<i4").tobytes()).hexdigest())
+        # Decode(ids) of the same ids by the compiled reference: bytes + digest of (text, offsets)
+        dtext, doffs = h.decode_batch(ids, id_offs)
+        manifest[key]["decode_bytes"] = int(len(dtext))
+        manifest[key]["decode_sha256"] = hashlib.sha256(dtext.tobytes() + doffs.astype("<u8").tobytes()).hexdigest()
         print(key, manifest[key]["tokens"])
+    # Decode of seeded random id sequences (byte pieces in any order, control / unknown pieces, empty sentences)
+    fuzz = {}
+    for m in sorted(set(p[0] for p in PAIRS)):
+        from tests import fixtures
+        h = ref.load(fixtures.model_blob(m))
+        ids, io = decode_fuzz_ids(h.lib.spmref_piece_size(h.h))
+        dtext, doffs = h.decode_batch(ids, io)
+        fuzz[m] = dict(bytes=int(len(dtext)),
+                       sha256=hashlib.sha256(dtext.tobytes() + doffs.astype("<u8").tobytes()).hexdigest())
+    manifest["_decode_fuzz"] = fuzz
     np.savez_compressed(f"{G}/golden_ids.npz", **arrays)
     with open(f"{G}/manifest.json", "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)

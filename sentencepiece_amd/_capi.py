@@ -34,6 +34,11 @@ SYMBOLS = [
      [_H, C.c_void_p, C.c_void_p, _U64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     ("spmx_free", None, [C.c_void_p]),
     ("spmx_encode", C.c_int, [_H, C.c_char_p, _U64, C.c_void_p, _U64, C.POINTER(_U64)]),
+    ("spmx_decode_batch_device", C.c_int,
+     [_H, C.c_void_p, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, C.c_void_p, C.POINTER(_U64)]),
+    ("spmx_decode_batch", C.c_int,
+     [_H, C.c_void_p, C.c_void_p, _U64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    ("spmx_decode", C.c_int, [_H, C.c_void_p, _U64, C.c_void_p, _U64, C.POINTER(_U64)]),
     ("spmx_set_profiling", C.c_int, [_H, C.c_int]),
     ("spmx_last_profile_name", C.c_int, [_H, C.c_int, C.c_char_p, _U64]),
     ("spmx_last_phase_cycles", C.c_int, [_H, C.c_void_p]),

@@ -44,6 +44,7 @@ struct Ctrl {
   uint32_t pad;
   unsigned long long arena_head;
   unsigned long long stats[kStatsPerClass * 2 * kMaxClasses];   // per kernel slot (see Profile)
+  unsigned long long bad_key;   // decode: min over offending (sentence << 32 | id)
   uint64_t total_ids;   // copied from id_offs[n] by the final D2H
 };
 
@@ -90,7 +91,8 @@ struct spmx_handle {
   bool no_fast = false;   // SPMX_NO_FAST=1: GENERAL kernels only (A/B measurements)
   int tile_waves_override = 0;   // SPMX_TILE_WAVES: cap on wavefronts per workgroup of the streaming kernels
   // device copies of the tables
-  DevBuf<uint32_t> d_ndarts, d_sym_final;
+  DevBuf<uint32_t> d_ndarts, d_sym_final, d_dec_info, d_dec_off;
+  DevBuf<uint8_t> d_dec_bytes;
   DevBuf<uint8_t> d_nblob;
   DevBuf<U4> d_ptrie, d_chartab, d_pairtab;
   DevBuf<U2> d_utrie;
@@ -157,6 +159,9 @@ int UploadTables(spmx_handle *h) {
   HIP_OR_RETURN(h, Upload(&h->d_sym_final, t.sym_final));
   HIP_OR_RETURN(h, Upload(&h->d_sym_len, t.sym_len));
   HIP_OR_RETURN(h, Upload(&h->d_byte_ids, t.byte_ids));
+  HIP_OR_RETURN(h, Upload(&h->d_dec_info, t.dec_info));
+  HIP_OR_RETURN(h, Upload(&h->d_dec_off, t.dec_off));
+  HIP_OR_RETURN(h, Upload(&h->d_dec_bytes, t.dec_bytes));
   h->dev = t.scalars;
   h->dev.ndarts = h->d_ndarts.p;
   h->dev.nblob = h->d_nblob.p;
@@ -167,6 +172,9 @@ int UploadTables(spmx_handle *h) {
   h->dev.sym_final = h->d_sym_final.p;
   h->dev.sym_len = h->d_sym_len.p;
   h->dev.byte_ids = h->d_byte_ids.p;
+  h->dev.dec_info = h->d_dec_info.p;
+  h->dev.dec_off = h->d_dec_off.p;
+  h->dev.dec_bytes = h->d_dec_bytes.p;
   return kOk;
 }
 
@@ -182,6 +190,7 @@ int RefreshDevice(spmx_handle *h, bool types_changed) {
   d.ndarts = h->dev.ndarts; d.nblob = h->dev.nblob; d.ptrie = h->d_ptrie.p; d.utrie = h->dev.utrie;
   d.chartab = h->dev.chartab; d.pairtab = h->dev.pairtab; d.sym_final = h->d_sym_final.p;
   d.sym_len = h->dev.sym_len; d.byte_ids = h->dev.byte_ids;
+  d.dec_info = h->dev.dec_info; d.dec_off = h->dev.dec_off; d.dec_bytes = h->dev.dec_bytes;
   h->dev = d;
   return kOk;
 }
@@ -191,6 +200,7 @@ void DestroyHandle(spmx_handle *h) {
   (void)hipSetDevice(h->device);
   h->d_ndarts.Free(); h->d_sym_final.Free(); h->d_nblob.Free(); h->d_ptrie.Free(); h->d_chartab.Free();
   h->d_pairtab.Free(); h->d_utrie.Free(); h->d_sym_len.Free(); h->d_byte_ids.Free();
+  h->d_dec_info.Free(); h->d_dec_off.Free(); h->d_dec_bytes.Free();
   h->d_stream.Free(); h->d_lists.Free(); h->d_counts.Free(); h->d_tmp_off.Free(); h->d_tile_sums.Free(); h->d_arena.Free();
   h->d_text.Free(); h->d_offs.Free(); h->d_id_offs.Free(); h->d_ids.Free();
   if (h->d_ctrl) (void)hipFree(h->d_ctrl);
@@ -428,6 +438,52 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
   return Fail(h, kInternal, "id arena kept overflowing");
 }
 
+// Batch Decode on the device (kernels_decode.h): count pass -> scan -> (host checks status / capacity) -> write pass.
+// Caller holds h->mu and has set the device.
+int DecodeDevice(spmx_handle *h, const int32_t *d_ids, const uint64_t *d_id_offsets, uint64_t n, uint8_t *d_text,
+                 uint64_t text_capacity, uint64_t *d_text_offsets, hipStream_t stream, uint64_t *total_bytes) {
+  if (total_bytes) *total_bytes = 0;
+  if (h->model.has_denormalizer)
+    return Fail(h, kUnimplemented, "the model has a denormalizer_spec; Decode with a denormalizer is not on the device path");
+  if (n >= (1ull << 32) - 64) return Fail(h, kInvalidArgument, "more than 2^32 - 64 sentences in one batch");
+  if (!d_id_offsets || !d_text_offsets) return Fail(h, kInvalidArgument, "null offsets");
+  if (n == 0) {
+    HIP_OR_RETURN(h, hipMemsetAsync(d_text_offsets, 0, sizeof(uint64_t), stream));
+    HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+    return kOk;
+  }
+  HIP_OR_RETURN(h, h->d_counts.Reserve(n + 1));
+  HIP_OR_RETURN(h, h->d_tile_sums.Reserve((n + kScanTile - 1) / kScanTile + 2));
+  HIP_OR_RETURN(h, hipMemsetAsync(h->d_ctrl, 0, sizeof(Ctrl), stream));
+  HIP_OR_RETURN(h, hipMemsetAsync(&h->d_ctrl->bad_key, 0xFF, sizeof(unsigned long long), stream));
+  DecodeArgs a{};
+  a.dev = h->dev; a.ids = d_ids; a.id_offs = d_id_offsets; a.n = static_cast<uint32_t>(n);
+  a.counts = h->d_counts.p; a.text_offs = d_text_offsets; a.text = d_text; a.text_cap = d_text ? text_capacity : 0;
+  a.status = &h->d_ctrl->status; a.bad_key = &h->d_ctrl->bad_key;
+  const uint64_t wide = static_cast<uint64_t>(h->n_cu) * 32;
+  const int grid = static_cast<int>(n < wide ? n : wide);
+  HIP_OR_RETURN(h, LaunchDecode(false, a, grid, stream));
+  {
+    ScanArgs sa{h->d_counts.p, static_cast<uint32_t>(n), h->d_tile_sums.p, d_text_offsets};
+    const uint32_t tiles = (static_cast<uint32_t>(n) + kScanTile - 1) / kScanTile;
+    HIP_OR_RETURN(h, LaunchScan(sa, static_cast<int>(tiles < static_cast<uint32_t>(h->n_cu * 8) ? tiles : h->n_cu * 8), stream));
+  }
+  HIP_OR_RETURN(h, hipMemcpyAsync(h->h_ctrl, h->d_ctrl, offsetof(Ctrl, total_ids), hipMemcpyDeviceToHost, stream));
+  HIP_OR_RETURN(h, hipMemcpyAsync(&h->h_ctrl->total_ids, d_text_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+  HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+  if (h->h_ctrl->status & kStBadId) {   // sentencepiece_processor.cc:913-917 (the id reported is one of the batch's first failing sentence)
+    const int id = static_cast<int>(static_cast<uint32_t>(h->h_ctrl->bad_key));
+    return Fail(h, kOutOfRange, "Invalid id: " + std::to_string(id));
+  }
+  const uint64_t total = h->h_ctrl->total_ids;
+  if (total_bytes) *total_bytes = total;
+  if (total == 0) return kOk;
+  if (!d_text || total > text_capacity) return Fail(h, kResourceExhausted, "text_capacity is too small");
+  HIP_OR_RETURN(h, LaunchDecode(true, a, grid, stream));
+  HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+  return kOk;
+}
+
 bool ReadFile(const char *path, std::string *out) {
   std::ifstream f(path, std::ios::binary);
   if (!f) return false;
@@ -621,6 +677,73 @@ int spmx_encode(spmx_handle *h, const char *text, uint64_t len, int32_t *ids, ui
   else if (total) memcpy(ids, out, total * sizeof(int32_t));
   free(out);
   free(oo);
+  return ret;
+}
+
+int spmx_decode_batch_device(spmx_handle *h, const int32_t *d_ids, const uint64_t *d_id_offsets, uint64_t n, void *d_text,
+                             uint64_t text_capacity, uint64_t *d_text_offsets, void *stream, uint64_t *total_bytes) {
+  if (!h) return kInvalidArgument;
+  std::lock_guard<std::mutex> l(h->mu);
+  HIP_OR_RETURN(h, hipSetDevice(h->device));
+  return DecodeDevice(h, d_ids, d_id_offsets, n, static_cast<uint8_t *>(d_text), text_capacity, d_text_offsets,
+                      static_cast<hipStream_t>(stream), total_bytes);
+}
+
+int spmx_decode_batch(spmx_handle *h, const int32_t *ids, const uint64_t *id_offsets, uint64_t n, char **text,
+                      uint64_t **text_offsets) {
+  if (!h) return kInvalidArgument;
+  std::lock_guard<std::mutex> l(h->mu);
+  if (!text || !text_offsets) return Fail(h, kInternal, "output container is null");
+  *text = nullptr; *text_offsets = nullptr;
+  if (n && !id_offsets) return Fail(h, kInvalidArgument, "null offsets");
+  HIP_OR_RETURN(h, hipSetDevice(h->device));
+  uint64_t *ho = static_cast<uint64_t *>(malloc((n + 1) * sizeof(uint64_t)));
+  if (!ho) return Fail(h, kResourceExhausted, "out of host memory");
+  if (n == 0) { ho[0] = 0; *text_offsets = ho; *text = static_cast<char *>(malloc(1)); return kOk; }
+  const uint64_t base = id_offsets[0], n_ids = id_offsets[n] - base;
+  if (hipError_t e = h->d_ids.Reserve(n_ids + 16); e != hipSuccess) { free(ho); return FailHip(h, e, "hipMalloc(ids)"); }
+  if (hipError_t e = h->d_offs.Reserve(n + 1); e != hipSuccess) { free(ho); return FailHip(h, e, "hipMalloc(offsets)"); }
+  if (hipError_t e = h->d_id_offs.Reserve(n + 1); e != hipSuccess) { free(ho); return FailHip(h, e, "hipMalloc(offsets)"); }
+  hipError_t e = hipSuccess;
+  if (n_ids) e = hipMemcpyAsync(h->d_ids.p, ids + base, n_ids * sizeof(int32_t), hipMemcpyHostToDevice, nullptr);
+  if (e == hipSuccess) e = hipMemcpyAsync(h->d_offs.p, id_offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, nullptr);
+  if (e != hipSuccess) { free(ho); return FailHip(h, e, "hipMemcpy(ids)"); }
+  const int32_t *d_ids = h->d_ids.p - base;     // the kernels address ids + id_offsets[i]
+  uint64_t cap = n_ids * 6 + 64, total = 0;
+  int rc = kOk;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (hipError_t e2 = h->d_text.Reserve(cap); e2 != hipSuccess) { free(ho); return FailHip(h, e2, "hipMalloc(text)"); }
+    rc = DecodeDevice(h, d_ids, h->d_offs.p, n, h->d_text.p, h->d_text.cap, h->d_id_offs.p, nullptr, &total);
+    if (rc != kResourceExhausted || total <= h->d_text.cap) break;
+    cap = total;
+  }
+  if (rc != kOk) { free(ho); return rc; }
+  char *ht = static_cast<char *>(malloc(total ? total : 1));
+  if (!ht) { free(ho); return Fail(h, kResourceExhausted, "out of host memory"); }
+  e = hipMemcpy(ho, h->d_id_offs.p, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && total) e = hipMemcpy(ht, h->d_text.p, total, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { free(ho); free(ht); return FailHip(h, e, "hipMemcpy(text)"); }
+  *text = ht;
+  *text_offsets = ho;
+  return kOk;
+}
+
+int spmx_decode(spmx_handle *h, const int32_t *ids, uint64_t n_ids, char *out, uint64_t cap, uint64_t *len) {
+  if (!h) return kInvalidArgument;
+  if (!len || (!out && cap)) return Fail(h, kInternal, "output container is null");
+  const uint64_t offs[2] = {0, n_ids};
+  char *t = nullptr;
+  uint64_t *to = nullptr;
+  const int32_t dummy = 0;
+  const int rc = spmx_decode_batch(h, ids ? ids : &dummy, offs, 1, &t, &to);
+  if (rc != kOk) return rc;
+  const uint64_t total = to[1];
+  *len = total;
+  int ret = kOk;
+  if (total > cap) ret = Fail(h, kResourceExhausted, "text buffer is too small");
+  else if (total) memcpy(out, t, total);
+  free(t);
+  free(to);
   return ret;
 }
 

@@ -78,6 +78,10 @@ struct SpmxDev {
   const int32_t *byte_ids;   // [256]
   int32_t n_prefix, n_suffix;
   int32_t prefix_ids[kMaxExtra], suffix_ids[kMaxExtra];
+  // ---- decode (reference: src/sentencepiece_processor.cc:761-925; kernels_decode.h) ----
+  const uint32_t *dec_info;  // per id: kind | flags | byte value
+  const uint32_t *dec_off;   // per id + 1: offsets into dec_bytes
+  const uint8_t *dec_bytes;  // decoded piece bytes (U+2581 -> ' ', unknown -> unk_surface)
   // ---- BPE (reference: src/bpe_model.cc:38-203) ----
   const U2 *utrie;        // user-defined symbols only (PrefixMatcher; normalizer and BPE both use it)
   const U4 *chartab;      // {bytes, len, sym, 0}   open addressing, empty: len == 0

@@ -702,5 +702,6 @@ SPMX_DEVICE void compact_block(const CompactArgs &a) {
 
 #include "kernels_bpe_stream.h"
 #include "kernels_stream.h"
+#include "kernels_decode.h"
 
 #endif

@@ -25,6 +25,8 @@ __global__ __launch_bounds__(FAST ? 1024 : 512) void EncodeBpeStreamKernel(Encod
   encode_stream_block<FAST, 2>(a, smem);
 }
 
+__global__ __launch_bounds__(64) void DecodeCountKernel(DecodeArgs a) { decode_block<false>(a); }
+__global__ __launch_bounds__(64) void DecodeWriteKernel(DecodeArgs a) { decode_block<true>(a); }
 __global__ __launch_bounds__(64) void ClassifyKernel(ClassifyArgs a) { classify_block(a); }
 __global__ __launch_bounds__(64) void ScanTilesKernel(ScanArgs a) { scan_tiles_block(a); }
 __global__ __launch_bounds__(64) void ScanSumsKernel(ScanArgs a) { scan_sums_block(a); }
@@ -90,6 +92,12 @@ hipError_t LaunchEncodeStream(int model_type, int cls, bool fast, const EncodeAr
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * waves), lds_bytes, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t LaunchDecode(bool write, const DecodeArgs &a, int grid, hipStream_t stream) {
+  if (write) hipLaunchKernelGGL(DecodeWriteKernel, dim3(grid), dim3(64), 0, stream, a);
+  else hipLaunchKernelGGL(DecodeCountKernel, dim3(grid), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
 

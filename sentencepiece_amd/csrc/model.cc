@@ -79,6 +79,7 @@ Status ParseModelProto(const void *data, size_t n, ModelData *m) {
         else if (g == 24 && wt == 0) m->ws_suffix = v != 0;
         else if (g == 35 && wt == 0) m->byte_fallback = v != 0;
         // RETURN_PIECE (src/model_interface.cc:29-31): an empty field means the default.
+        else if (g == 44 && wt == 2) m->unk_surface = std::string(str().c_str());   // used as a C string (:772-773)
         else if (g == 45 && wt == 2 && tl) m->unk_piece = str();
         else if (g == 46 && wt == 2 && tl) m->bos_piece = str();
         else if (g == 47 && wt == 2 && tl) m->eos_piece = str();
@@ -94,6 +95,12 @@ Status ParseModelProto(const void *data, size_t n, ModelData *m) {
         else if (g == 4 && wt == 0) m->remove_extra_ws = v != 0;
         else if (g == 5 && wt == 0) m->escape_ws = v != 0;
       }
+      if (t.bad) c.bad = true;
+    } else if (f == 5) {  // denormalizer_spec
+      Cursor t{s, s + sl};
+      const uint8_t *ts = nullptr; size_t tl = 0;
+      while (int g = t.Next(&wt, &v, &ts, &tl))
+        if (g == 2 && wt == 2 && tl) m->has_denormalizer = true;
       if (t.bad) c.bad = true;
     } else if (f == 4) {  // self_test_data { repeated Sample samples = 1 { input = 1; expected = 2 } }
       Cursor t{s, s + sl};

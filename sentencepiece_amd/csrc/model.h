@@ -45,6 +45,8 @@ struct ModelData {
   bool byte_fallback = false;
   bool ws_suffix = false;  // treat_whitespace_as_suffix
   std::string unk_piece = "<unk>", bos_piece = "<s>", eos_piece = "</s>", pad_piece = "<pad>";
+  std::string unk_surface = " \xE2\x81\x87 ";   // trainer_spec.unk_surface (sentencepiece_model.proto:228), for Decode
+  bool has_denormalizer = false;              // denormalizer_spec with a charsmap (sentencepiece_processor.cc:248-252)
   std::string charsmap;    // normalizer_spec.precompiled_charsmap
   bool add_dummy_prefix = true, remove_extra_ws = true, escape_ws = true;
   std::vector<std::pair<std::string, std::string>> self_test;

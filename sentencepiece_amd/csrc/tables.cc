@@ -293,6 +293,43 @@ Status CompileTables(const ModelData &m, HostTables *t) {
     t->sym_final.assign(1, 0);
     t->sym_len.assign(1, 0);
   }
+  // ---------------------------------------------------------------- decode --
+  // Per id, what Decode(ids) appends for it (src/sentencepiece_processor.cc:776-808): the kind is taken from
+  // PieceToId(IdToPiece(id)) as the reference does (:812); U+2581 -> ' ' is applied here, the leading-whitespace
+  // rule at run time.
+  {
+    const size_t V = m.pieces.size();
+    t->dec_info.assign(V, 0);
+    t->dec_off.assign(V + 1, 0);
+    t->dec_bytes.clear();
+    for (size_t i = 0; i < V; ++i) {
+      const std::string &piece = m.pieces[i].piece;
+      const int id = m.PieceToId(piece);
+      const int type = m.pieces[id].type;
+      uint32_t info = 0;
+      t->dec_off[i] = static_cast<uint32_t>(t->dec_bytes.size());
+      if (type == kControl) {
+        info = 1u;                                                     // kDkEmpty
+      } else if (type == kByte) {
+        unsigned v = 0;                                                // PieceToByte("<0xHH>") (model_interface.cc:214-229)
+        if (piece.size() == 6) v = static_cast<unsigned>(strtoul(piece.substr(3, 2).c_str(), nullptr, 16));
+        info = 2u | (v << 8);                                          // kDkByte
+      } else if (type == kUnknown_) {
+        const std::string &sfc = (m.pieces[id].piece == piece) ? m.unk_surface : piece;
+        t->dec_bytes.insert(t->dec_bytes.end(), sfc.begin(), sfc.end());
+        info = 3u;                                                     // kDkLiteral
+      } else {
+        if (piece.compare(0, 3, kSpaceSymbol) == 0) info |= 1u << 2;   // kDiStartsSp
+        for (size_t k = 0; k < piece.size();) {
+          if (piece.compare(k, 3, kSpaceSymbol) == 0) { t->dec_bytes.push_back(' '); k += 3; }
+          else t->dec_bytes.push_back(static_cast<uint8_t>(piece[k++]));
+        }
+      }
+      t->dec_info[i] = info;
+    }
+    t->dec_off[V] = static_cast<uint32_t>(t->dec_bytes.size());
+    if (t->dec_bytes.empty()) t->dec_bytes.push_back(0);
+  }
   sc.n_pieces = static_cast<uint32_t>(m.pieces.size());
   sc.flags = flags;
   RefreshTypeFlags(m, t);
@@ -368,6 +405,9 @@ void BindHostPointers(HostTables *t) {
   sc.nblob = t->nblob.data();
   sc.ptrie = t->ptrie.data();
   sc.byte_ids = t->byte_ids.data();
+  sc.dec_info = t->dec_info.data();
+  sc.dec_off = t->dec_off.data();
+  sc.dec_bytes = t->dec_bytes.data();
   sc.utrie = t->utrie.data();
   sc.chartab = t->chartab.data();
   sc.pairtab = t->pairtab.data();

@@ -22,6 +22,9 @@ struct HostTables {
   std::vector<uint32_t> sym_final;
   std::vector<uint16_t> sym_len;
   std::vector<int32_t> byte_ids;
+  // decode (kernels_decode.h)
+  std::vector<uint32_t> dec_info, dec_off;
+  std::vector<uint8_t> dec_bytes;
   // scalars (pointers are filled in by whoever owns the memory)
   SpmxDev scalars{};
   int max_piece_len = 0;

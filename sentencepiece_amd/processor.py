@@ -248,6 +248,70 @@ class SentencePieceProcessor:
         self._check(rc)
         return d_ids, d_id_offsets, total.value
 
+    # ----------------------------------------------------------- decode ----
+    def Decode(self, input, out_type=str, num_threads=None):
+        """list[int] -> str; list[list[int]] -> list[str] (``Decode`` / ``_DecodeIdsBatch``,
+        python/src/sentencepiece/__init__.py:808-870).  ``out_type=bytes`` returns the raw bytes."""
+        self._need()
+        single = not input or isinstance(input[0], (int, np.integer))
+        items = [input] if single else input
+        offs = np.zeros(len(items) + 1, dtype=np.uint64)
+        if items:
+            np.cumsum([len(x) for x in items], out=offs[1:])
+        ids = np.fromiter((t for x in items for t in x), dtype=np.int32, count=int(offs[-1]))
+        text, to = self.DecodePacked(ids, offs)
+        b = text.tobytes()
+        to = to.astype(np.int64)
+        out = [b[to[i]:to[i + 1]] for i in range(len(items))]
+        if out_type is str:
+            out = [x.decode("utf-8", errors="replace") for x in out]
+        return out[0] if single else out
+
+    decode = DecodeIds = decode_ids = Decode
+
+    def DecodePacked(self, ids, id_offsets):
+        """CSR host arrays ``(ids int32, id_offsets uint64[n + 1])`` -> packed ``(text uint8, text_offsets uint64)``."""
+        self._need()
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        id_offsets = np.ascontiguousarray(id_offsets, dtype=np.uint64)
+        n = len(id_offsets) - 1
+        p_text, p_off = C.c_void_p(), C.c_void_p()
+        ip = ids.ctypes.data if len(ids) else None
+        self._check(self._lib.spmx_decode_batch(self._h, ip, id_offsets.ctypes.data, n, C.byref(p_text), C.byref(p_off)))
+        try:
+            to = np.ctypeslib.as_array(C.cast(p_off, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+            total = int(to[n])
+            text = (np.ctypeslib.as_array(C.cast(p_text, C.POINTER(C.c_uint8)), shape=(total,)).copy()
+                    if total else np.zeros(0, dtype=np.uint8))
+        finally:
+            self._lib.spmx_free(p_text)
+            self._lib.spmx_free(p_off)
+        return text, to
+
+    def DecodeDevice(self, d_ids, d_id_offsets, d_text=None, d_text_offsets=None, stream=None):
+        """Device-resident form over torch tensors: ``d_ids`` int32, ``d_id_offsets`` int64[n + 1] ->
+        ``(d_text uint8, d_text_offsets int64[n + 1], total_bytes)``; ``d_text[:total_bytes]`` is valid."""
+        import torch
+        self._need()
+        n = d_id_offsets.numel() - 1
+        if d_text_offsets is None:
+            d_text_offsets = torch.empty(n + 1, dtype=torch.int64, device=d_ids.device)
+        if d_text is None:
+            d_text = torch.empty(d_ids.numel() * 6 + 64, dtype=torch.uint8, device=d_ids.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(d_ids.device).cuda_stream
+        total = C.c_uint64(0)
+        for _ in range(2):
+            rc = self._lib.spmx_decode_batch_device(self._h, d_ids.data_ptr(), d_id_offsets.data_ptr(), n,
+                                                    d_text.data_ptr(), d_text.numel(), d_text_offsets.data_ptr(),
+                                                    stream, C.byref(total))
+            if rc == _RESOURCE_EXHAUSTED and total.value > d_text.numel():
+                d_text = torch.empty(total.value, dtype=torch.uint8, device=d_ids.device)
+                continue
+            break
+        self._check(rc)
+        return d_text, d_text_offsets, total.value
+
     # ------------------------------------------------------ measurement ----
     def SetProfiling(self, enabled):
         self._need()

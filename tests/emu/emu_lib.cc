@@ -280,6 +280,33 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
   return static_cast<int64_t>(total);
 }
 
+// Batch Decode as csrc/api.cc runs it: count pass -> scan -> write pass.  Returns total bytes, -(needed) - 2 if cap
+// is too small, -1 with the device status in *status_out on a bad id.
+int64_t emu_decode_batch(void *hv, const int32_t *ids, const uint64_t *id_offs, uint64_t n, uint8_t *text, uint64_t cap,
+                         uint64_t *text_offs, int grid, uint32_t *status_out) {
+  auto *h = static_cast<EmuHandle *>(hv);
+  if (grid < 1) grid = 1;
+  std::vector<uint32_t> counts(n + 1, 0);
+  uint32_t status = 0;
+  unsigned long long bad_key = ~0ull;
+  DecodeArgs a{};
+  a.dev = h->tables.scalars; a.ids = ids; a.id_offs = id_offs; a.n = static_cast<uint32_t>(n);
+  a.counts = counts.data(); a.text_offs = text_offs; a.text = text; a.text_cap = cap;
+  a.status = &status; a.bad_key = &bad_key;
+  for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { decode_block<false>(a); });
+  std::vector<uint64_t> tile_sums((n + kScanTile - 1) / kScanTile + 2, 0);
+  ScanArgs sa{counts.data(), static_cast<uint32_t>(n), tile_sums.data(), text_offs};
+  for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { scan_tiles_block(sa); });
+  emu::RunWave(0, 1, nullptr, [&] { scan_sums_block(sa); });
+  for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { scan_final_block(sa); });
+  if (status_out) *status_out = status;
+  if (status) return -1;
+  const uint64_t total = text_offs[n];
+  if (total > cap) return -static_cast<int64_t>(total) - 2;
+  for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { decode_block<true>(a); });
+  return static_cast<int64_t>(total);
+}
+
 uint64_t emu_collectives() { return emu::g_wave.n_collectives; }
 uint32_t emu_flags(void *hv) { return static_cast<EmuHandle *>(hv)->tables.scalars.flags; }
 // sentences the FAST tile kernel kept / handed to the GENERAL kernel in the last emu_encode_batch

@@ -25,6 +25,9 @@ class EmuLib:
         lib.emu_encode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                          C.c_void_p, C.c_int, C.c_void_p]
         lib.emu_collectives.restype = C.c_uint64
+        lib.emu_decode_batch.restype = C.c_int64
+        lib.emu_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                         C.c_void_p, C.c_int, C.c_void_p]
         lib.emu_flags.restype = C.c_uint32
         lib.emu_flags.argtypes = [C.c_void_p]
         lib.emu_fast_kept.restype = C.c_uint64
@@ -87,3 +90,23 @@ class EmuHandle:
         if tot < 0:
             raise RuntimeError("emu_encode_batch failed: %d status %d" % (tot, st.value))
         return ids[:tot].copy(), id_offs
+
+
+def _emu_decode_batch(self, ids, id_offsets, grid=3):
+    """Device decode kernels under the emulator -> (text uint8, text_offsets uint64); raises on a bad id."""
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    id_offsets = np.ascontiguousarray(id_offsets, dtype=np.uint64)
+    n = len(id_offsets) - 1
+    cap = int(len(ids)) * 64 + 64
+    text = np.empty(cap, dtype=np.uint8)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    st = C.c_uint32(0)
+    tot = self.lib.emu_decode_batch(self.h, ids.ctypes.data if len(ids) else None, id_offsets.ctypes.data, n,
+                                    text.ctypes.data, cap, offs.ctypes.data, grid, C.byref(st))
+    self.status = st.value
+    if tot < 0:
+        raise RuntimeError("emu_decode_batch failed: %d status %d" % (tot, st.value))
+    return text[:tot].copy(), offs
+
+
+EmuHandle.decode_batch = _emu_decode_batch

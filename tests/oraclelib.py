@@ -37,6 +37,8 @@ class OracleLib:
         lib.oracle_encode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                             C.c_uint64, C.c_void_p]
         lib.oracle_piece_size.argtypes = [C.c_void_p]
+        lib.oracle_decode_batch.restype = C.c_int64
+        lib.oracle_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]
         lib.oracle_model_type.argtypes = [C.c_void_p]
 
     def load(self, model_bytes):
@@ -109,3 +111,21 @@ class OracleHandle:
         if tot < 0:
             raise RuntimeError("oracle_encode_batch failed")
         return ids[:tot].copy(), id_offs
+
+
+def _oracle_decode_batch(self, ids, id_offsets):
+    """Oracle Decode(ids) per sentence -> (text uint8, text_offsets uint64); raises on an invalid id."""
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    id_offsets = np.ascontiguousarray(id_offsets, dtype=np.uint64)
+    n = len(id_offsets) - 1
+    cap = int(len(ids)) * 64 + 64
+    text = np.empty(cap, dtype=np.uint8)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    tot = self.lib.oracle_decode_batch(self.h, ids.ctypes.data if len(ids) else None, id_offsets.ctypes.data, n,
+                                       text.ctypes.data, cap, offs.ctypes.data)
+    if tot < 0:
+        raise RuntimeError("oracle_decode_batch failed: %d" % tot)
+    return text[:tot].copy(), offs
+
+
+OracleHandle.decode_batch = _oracle_decode_batch

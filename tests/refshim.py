@@ -37,6 +37,8 @@ class RefLib:
         lib.spmref_encode_count.restype = C.c_int64
         lib.spmref_encode_count.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
         lib.spmref_piece_size.argtypes = [C.c_void_p]
+        lib.spmref_decode_batch.restype = C.c_int64
+        lib.spmref_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]
 
     def load(self, model_bytes):
         h = self.lib.spmref_load(model_bytes, len(model_bytes))
@@ -115,3 +117,25 @@ class RefHandle:
         offs = np.ascontiguousarray(offs, dtype=np.uint64)
         return self.lib.spmref_encode_count(self.h, text.ctypes.data, offs.ctypes.data,
                                             len(offs) - 1, threads)
+
+
+def _decode_batch(fn, h, ids, id_offsets):
+    import numpy as np
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    id_offsets = np.ascontiguousarray(id_offsets, dtype=np.uint64)
+    n = len(id_offsets) - 1
+    cap = int(len(ids)) * 64 + 64
+    text = np.empty(cap, dtype=np.uint8)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    tot = fn(h, ids.ctypes.data if len(ids) else None, id_offsets.ctypes.data, n, text.ctypes.data, cap, offs.ctypes.data)
+    if tot < 0:
+        raise RuntimeError("decode_batch failed: %d" % tot)
+    return text[:tot].copy(), offs
+
+
+def _ref_decode_batch(self, ids, id_offsets):
+    """Reference Decode(ids) per sentence -> (text uint8, text_offsets uint64)."""
+    return _decode_batch(self.lib.spmref_decode_batch, self.h, ids, id_offsets)
+
+
+RefHandle.decode_batch = _ref_decode_batch

@@ -1,0 +1,174 @@
+"""Batch Decode (ids -> text).  Reference: SentencePieceProcessor::Decode(ids, &text),
+src/sentencepiece_processor.cc:761-925.
+
+ * the oracle restatement (oracle/spm_oracle.c decode_ids) against digests the COMPILED REFERENCE produced for the
+   golden ids of every manifest pair and for seeded random id sequences (scripts/make_fixtures.py), and against
+   the compiled reference itself where it is built (this container);
+ * the device kernels (csrc/kernels_decode.h) under the emulator against the oracle;
+ * -m gpu: the HIP path through the C ABI against the same digests, its error behaviour, and
+   encode(decode(encode(x))) == encode(x) on a large batch."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from scripts import make_fixtures as mf
+from tests import fixtures, refshim
+
+
+def _manifest():
+    with open(os.path.join(fixtures.GOLDEN, "manifest.json")) as f:
+        return json.load(f)
+
+
+def _keys():
+    return sorted(k for k in _manifest() if not k.startswith("_"))
+
+
+def _digest(text, offs):
+    return hashlib.sha256(np.ascontiguousarray(text).tobytes() + np.ascontiguousarray(offs).astype("<u8").tobytes()).hexdigest()
+
+
+def _golden_ids(key, m, oracle, corpora):
+    """The ids of a golden pair (the oracle's encode is pinned to them by tests/test_oracle.py)."""
+    o = oracle.load(fixtures.model_blob(m["model"]))
+    if m["options"]:
+        o.set_encode_extra_options(m["options"])
+    return o.encode_batch(*corpora[m["corpus"]])
+
+
+@pytest.mark.parametrize("key", _keys())
+def test_oracle_decode_matches_reference_digest(key, oracle, corpora):
+    m = _manifest()[key]
+    ids, io = _golden_ids(key, m, oracle, corpora)
+    text, offs = oracle.load(fixtures.model_blob(m["model"])).decode_batch(ids, io)
+    assert len(text) == m["decode_bytes"]
+    assert _digest(text, offs) == m["decode_sha256"]
+
+
+@pytest.mark.parametrize("model", sorted(_manifest()["_decode_fuzz"]))
+def test_oracle_decode_fuzz(model, oracle):
+    g = _manifest()["_decode_fuzz"][model]
+    o = oracle.load(fixtures.model_blob(model))
+    ids, io = mf.decode_fuzz_ids(o.lib.oracle_piece_size(o.h))
+    text, offs = o.decode_batch(ids, io)
+    assert len(text) == g["bytes"] and _digest(text, offs) == g["sha256"]
+    if refshim.available():
+        rt, ro = refshim.RefLib().load(fixtures.model_blob(model)).decode_batch(ids, io)
+        np.testing.assert_array_equal(ro, offs)
+        np.testing.assert_array_equal(rt, text)
+
+
+def test_oracle_decode_invalid_id(oracle):
+    o = oracle.load(fixtures.model_blob("test_model"))
+    with pytest.raises(RuntimeError):
+        o.decode_batch(np.array([5, 100000], dtype=np.int32), np.array([0, 2], dtype=np.uint64))
+    with pytest.raises(RuntimeError):
+        o.decode_batch(np.array([-1], dtype=np.int32), np.array([0, 1], dtype=np.uint64))
+
+
+EMU_MODELS = ["test_model", "test_ja_model", "uni1k_bf", "bpe1k_bf_uds", "uni1k_ident", "uni1k_suffix", "bpe1k_noesc",
+              "c5_250k_bf"]
+
+
+@pytest.mark.parametrize("model", EMU_MODELS)
+def test_emu_decode(model, oracle, corpora):
+    from tests import emulib
+    blob = fixtures.model_blob(model)
+    e = emulib.EmuLib().load(blob)
+    o = oracle.load(blob)
+    for name, k in (("edge", 10 ** 6), ("botchan", 150), ("mixed2k", 60)):
+        ids, io = o.encode_batch(*fixtures.head(*corpora[name], k))
+        ot, oo = o.decode_batch(ids, io)
+        et, eo = e.decode_batch(ids, io, grid=2)
+        np.testing.assert_array_equal(eo, oo)
+        np.testing.assert_array_equal(et, ot)
+    ids, io = mf.decode_fuzz_ids(o.lib.oracle_piece_size(o.h))
+    ot, oo = o.decode_batch(ids, io)
+    et, eo = e.decode_batch(ids, io, grid=3)
+    np.testing.assert_array_equal(eo, oo)
+    np.testing.assert_array_equal(et, ot)
+    with pytest.raises(RuntimeError):
+        e.decode_batch(np.array([1, 2, 10 ** 7], dtype=np.int32), np.array([0, 1, 3], dtype=np.uint64))
+    assert e.status != 0
+
+
+# ------------------------------------------------------------------ GPU ----
+@pytest.fixture(scope="module")
+def procs():
+    from sentencepiece_amd.processor import SentencePieceProcessor
+    cache = {}
+
+    def get(model):
+        if model not in cache:
+            cache[model] = SentencePieceProcessor(model_proto=fixtures.model_blob(model))
+        return cache[model]
+    return get
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", _keys())
+def test_gpu_decode_golden(key, procs, corpora):
+    m = _manifest()[key]
+    sp = procs(m["model"])
+    sp.SetEncodeExtraOptions(m["options"])
+    ids, io = sp.EncodePacked(*corpora[m["corpus"]])
+    sp.SetEncodeExtraOptions("")
+    text, offs = sp.DecodePacked(ids, io)
+    assert len(text) == m["decode_bytes"]
+    assert _digest(text, offs) == m["decode_sha256"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", sorted(_manifest()["_decode_fuzz"]))
+def test_gpu_decode_fuzz(model, procs, oracle):
+    g = _manifest()["_decode_fuzz"][model]
+    sp = procs(model)
+    ids, io = mf.decode_fuzz_ids(sp.GetPieceSize())
+    text, offs = sp.DecodePacked(ids, io)
+    assert len(text) == g["bytes"] and _digest(text, offs) == g["sha256"]
+    ot, oo = oracle.load(fixtures.model_blob(model)).decode_batch(ids, io)
+    np.testing.assert_array_equal(offs, oo)
+    np.testing.assert_array_equal(text, ot)
+
+
+@pytest.mark.gpu
+def test_gpu_decode_api_and_errors(procs):
+    sp = procs("test_model")
+    ids = sp.Encode("I saw a girl with a telescope.")
+    assert sp.Decode(ids) == "I saw a girl with a telescope."
+    assert sp.Decode([ids, [], ids[:3]])[1] == ""
+    assert sp.Decode([]) == ""
+    with pytest.raises(Exception) as ei:
+        sp.Decode([1, 2, sp.GetPieceSize()])
+    assert "Invalid id" in str(ei.value)
+    with pytest.raises(Exception):
+        sp.Decode([[-1]])
+
+
+@pytest.mark.gpu
+def test_gpu_decode_round_trip_large(procs):
+    """Size-independent property on 2 M sentences, device-resident: for every sentence without an unknown piece,
+    encode(decode(encode(x))) == encode(x)."""
+    import torch
+    from sentencepiece_amd import synth
+    sp = procs("uni32k")
+    text, offs = synth.ascii_corpus(2_000_000, seed=4242)
+    dev = torch.device("cuda", 0)
+    d_ids, d_io, total = sp.EncodeDevice(torch.from_numpy(text).to(dev), torch.from_numpy(offs.view(np.int64)).to(dev))
+    d_text, d_to, nbytes = sp.DecodeDevice(d_ids[:total], d_io)
+    assert nbytes > 0
+    d_ids2, d_io2, total2 = sp.EncodeDevice(d_text[:nbytes], d_to)
+    ids, io = d_ids[:total].cpu().numpy(), d_io.cpu().numpy()
+    ids2, io2 = d_ids2[:total2].cpu().numpy(), d_io2.cpu().numpy()
+    has_unk = np.add.reduceat((ids == sp.unk_id()).astype(np.int64), io[:-1].clip(max=len(ids) - 1)) > 0
+    has_unk &= np.diff(io) > 0
+    assert has_unk.mean() < 0.05
+    cnt, cnt2 = np.diff(io), np.diff(io2)
+    ok = ~has_unk
+    assert np.array_equal(cnt[ok], cnt2[ok])
+    keep = np.repeat(ok, cnt)
+    keep2 = np.repeat(ok, cnt2)
+    assert np.array_equal(ids[keep], ids2[keep2])
