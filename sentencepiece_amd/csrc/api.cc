@@ -349,8 +349,11 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
           a.stats = &h->d_ctrl->stats[kStatsPerClass * slot];
           a.wave_list = h->d_lists.p + static_cast<size_t>(2 * ncls + c) * n;
           a.wave_count = &h->d_ctrl->wave_counts[c];
-          snprintf(h->slot_name[slot], sizeof(h->slot_name[slot]), "Encode%sStreamKernel<%d, %s>", bpe_stream ? "Bpe" : "", c,
-                   is_fast ? "true" : "false");
+          if (!bpe_stream && is_fast && a.ring == 16)
+            snprintf(h->slot_name[slot], sizeof(h->slot_name[slot]), "EncodeStreamKernelR16<%d>", c);
+          else
+            snprintf(h->slot_name[slot], sizeof(h->slot_name[slot]), "Encode%sStreamKernel<%d, %s>", bpe_stream ? "Bpe" : "", c,
+                     is_fast ? "true" : "false");
           if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[slot][0], stream));
           HIP_OR_RETURN(h, LaunchEncodeStream(h->model.model_type, c, is_fast, a, sp.grid, sp.waves, sp.lds, stream));
           if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[slot][1], stream));

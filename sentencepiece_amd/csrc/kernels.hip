@@ -19,6 +19,12 @@ __global__ __launch_bounds__(FAST ? 1024 : 512) void EncodeStreamKernel(EncodeAr
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   encode_stream_block<FAST, 1>(a, smem);
 }
+// The FAST kernel specialized for a score ring of 16 entries (models whose longest piece is <= 15 bytes).
+template <int CLS>
+__global__ __launch_bounds__(1024) void EncodeStreamKernelR16(EncodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  encode_stream_block<true, 1, 16>(a, smem);
+}
 template <int CLS, bool FAST>
 __global__ __launch_bounds__(FAST ? 1024 : 512) void EncodeBpeStreamKernel(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -71,6 +77,15 @@ EncodeFn PickStream(int cls) {
     default: return EncodeStreamKernel<4, FAST>;
   }
 }
+EncodeFn PickStreamR16(int cls) {
+  switch (cls) {
+    case 0: return EncodeStreamKernelR16<0>;
+    case 1: return EncodeStreamKernelR16<1>;
+    case 2: return EncodeStreamKernelR16<2>;
+    case 3: return EncodeStreamKernelR16<3>;
+    default: return EncodeStreamKernelR16<4>;
+  }
+}
 template <bool FAST>
 EncodeFn PickBpeStream(int cls) {
   switch (cls) {
@@ -85,7 +100,7 @@ EncodeFn PickBpeStream(int cls) {
 hipError_t LaunchEncodeStream(int model_type, int cls, bool fast, const EncodeArgs &a, int grid, int waves,
                               uint32_t lds_bytes, hipStream_t stream) {
   EncodeFn fn = model_type == 2 ? (fast ? PickBpeStream<true>(cls) : PickBpeStream<false>(cls))
-                                : (fast ? PickStream<true>(cls) : PickStream<false>(cls));
+                                : (fast ? (a.ring == 16 ? PickStreamR16(cls) : PickStream<true>(cls)) : PickStream<false>(cls));
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds_bytes));

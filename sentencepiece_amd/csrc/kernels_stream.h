@@ -361,9 +361,14 @@ SPMX_DEVICE double piece_score_u(const U4 &u, int len, float max_score, bool uds
 //     is written to gb[] as two 16-byte stores, and the ring slots of the positions (s, s2] are cleared for the
 //     positions that will reuse them R later.  gb[] is this lane's row: gb[p] for position p.
 // Returns the number of iterations (wave-uniform).
+// RING > 0: the ring size is a compile-time constant (index masks and the distances between the LDS arrays fold
+// into immediates); RING == 0: taken from rm_in / wmask_in.
+template <int RING>
 SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const uint32_t *gt, uint32_t *gb, int nlen, float *ring_s,
-                                    uint32_t *ring_b, uint32_t rm, uint8_t *win, uint32_t wmask, uint32_t *st,
+                                    uint32_t *ring_b, uint32_t rm_in, uint8_t *win, uint32_t wmask_in, uint32_t *st,
                                     const U4 *roottab, bool active_in) {
+  const uint32_t rm = RING ? static_cast<uint32_t>(RING - 1) : rm_in;
+  const uint32_t wmask = RING ? static_cast<uint32_t>(2 * RING - 1) : wmask_in;
   const U4 *__restrict__ ptrie = d.ptrie;
   const float unk_score = d.unk_score, max_score = d.max_score;
   const bool uds = (d.flags & kNfHasUserDefined) != 0;   // wave-uniform: the user-defined score path is a scalar branch
@@ -534,14 +539,16 @@ SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const uint32_t *gt, const uin
   return ok ? n : -1;
 }
 
-// Persistent body of the streaming kernels.  MODEL: 1 unigram, 2 BPE (word-wise models only).
-template <bool FAST, int MODEL>
+// Persistent body of the streaming kernels.  MODEL: 1 unigram, 2 BPE (word-wise models only).  RING: see
+// unigram_stream_lane (0 = a.ring).
+template <bool FAST, int MODEL, int RING = 0>
 SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
   const int lane = wv::lane();
   const SpmxDev &d = a.dev;
-  const StreamLds T = carve_stream(smem, FAST, MODEL, a.rcap, a.ncap, a.ring, wv::wave_in_block());
-  const uint32_t rm = a.ring - 1;
-  const uint32_t W = StreamWindow(a.ring);
+  const uint32_t ring = RING ? static_cast<uint32_t>(RING) : a.ring;
+  const StreamLds T = carve_stream(smem, FAST, MODEL, a.rcap, a.ncap, ring, wv::wave_in_block());
+  const uint32_t rm = ring - 1;
+  const uint32_t W = StreamWindow(ring);
   float *my_rs = T.ring_s + lane;
   uint32_t *my_rb = T.ring_b + lane;
   uint8_t *my_win = T.win + static_cast<uint32_t>(lane) * (W + 4u);
@@ -568,7 +575,7 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
   const uint32_t n_waves = static_cast<uint32_t>(wv::grid_size() * wv::waves_per_block());
   // this wave's scratch slab; tcap = capacity of a text column in bytes
   const uint32_t tcap = a.stream_tcap;
-  uint32_t *gt = a.stream_text + static_cast<uint64_t>(wave_id) * StreamTextDwords(tcap, a.ring) + static_cast<uint32_t>(lane);
+  uint32_t *gt = a.stream_text + static_cast<uint64_t>(wave_id) * StreamTextDwords(tcap, ring) + static_cast<uint32_t>(lane);
   uint32_t *gb = a.stream_bp + static_cast<uint64_t>(wave_id) * StreamBpWords(tcap) + static_cast<uint32_t>(lane) * StreamBpStride(tcap);
   uint32_t *my_st = T.stage + static_cast<uint32_t>(lane) * 4u;
   // sentences per tile: 64, or fewer when the list is too short to give every wave a full tile
@@ -670,7 +677,7 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     if (MODEL == 1) {
       // ---- segment, then backtrack: the slot is filled from its end (or from its start when reversing) ----
       tc.n_trips += static_cast<unsigned long long>(
-          unigram_stream_lane(d, gt, gb, my_nlen, my_rs, my_rb, rm, my_win, W - 1u, my_st, T.roottab, mine));
+          unigram_stream_lane<RING>(d, gt, gb, my_nlen, my_rs, my_rb, rm, my_win, W - 1u, my_st, T.roottab, mine));
       c2 = wv::clock();
       if (!overflow) {
         n = emit_stream_lane(d, gt, gb, my_nlen, slot, cap, mine);

@@ -238,6 +238,7 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
         std::vector<unsigned char> fsmem(StreamLdsBytes(true, model, a.rcap, a.ncap, a.ring, 1) + 64, 0xCD);
         for (int b = 0; b < grid; ++b) {
           if (bpe) emu::RunWave(b, grid, fsmem.data(), [&] { encode_stream_block<true, 2>(a, fsmem.data()); });
+          else if (a.ring == 16) emu::RunWave(b, grid, fsmem.data(), [&] { encode_stream_block<true, 1, 16>(a, fsmem.data()); });   // as LaunchEncodeStream picks
           else emu::RunWave(b, grid, fsmem.data(), [&] { encode_stream_block<true, 1>(a, fsmem.data()); });
         }
         g_fast_kept += list_counts[c] - hard_count;
