@@ -331,9 +331,10 @@ SPMX_HD inline bool StreamFastEligible(uint32_t flags) {
          !((flags & kNfAddDummyPrefix) && (flags & kNfWsSuffix));
 }
 
-// piece_score with the user-defined branch under a wave-uniform flag
-SPMX_DEVICE double piece_score_u(const U4 &u, int len, float max_score, bool uds) {
-  if (uds) return piece_score(u, len, max_score);
+// piece_score; UDS = false drops the user-defined branch (FAST kernels: such models never reach them)
+template <bool UDS>
+SPMX_DEVICE double piece_score_u(const U4 &u, int len, float max_score) {
+  if (UDS) return piece_score(u, len, max_score);
   return static_cast<double>(wv::bits_to_float(u.z));
 }
 
@@ -362,8 +363,8 @@ SPMX_DEVICE double piece_score_u(const U4 &u, int len, float max_score, bool uds
 //     positions that will reuse them R later.  gb[] is this lane's row: gb[p] for position p.
 // Returns the number of iterations (wave-uniform).
 // RING > 0: the ring size is a compile-time constant (index masks and the distances between the LDS arrays fold
-// into immediates); RING == 0: taken from rm_in / wmask_in.
-template <int RING>
+// into immediates); RING == 0: taken from rm_in / wmask_in.  UDS: the model may have USER_DEFINED pieces.
+template <int RING, bool UDS>
 SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const uint32_t *gt, uint32_t *gb, int nlen, float *ring_s,
                                     uint32_t *ring_b, uint32_t rm_in, uint8_t *win, uint32_t wmask_in, uint32_t *st,
                                     const U4 *roottab, bool active_in) {
@@ -371,7 +372,6 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const uint32_t *gt, uint32
   const uint32_t wmask = RING ? static_cast<uint32_t>(2 * RING - 1) : wmask_in;
   const U4 *__restrict__ ptrie = d.ptrie;
   const float unk_score = d.unk_score, max_score = d.max_score;
-  const bool uds = (d.flags & kNfHasUserDefined) != 0;   // wave-uniform: the user-defined score path is a scalar branch
   const int W = static_cast<int>(wmask) + 1;
   int trips = 0;
   bool active = active_in && nlen > 0;
@@ -431,7 +431,7 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const uint32_t *gt, uint32
     uint32_t bA = ring_b[oA], bB = ring_b[oB], bC = ring_b[oC];
     float rA = ring_s[oA], rB = ring_s[oB], rC = ring_s[oC];
     // (A) the piece that just matched
-    const double candA = piece_score_u(uA, dep1, max_score, uds) + static_cast<double>(sbest);  // :982-983
+    const double candA = piece_score_u<UDS>(uA, dep1, max_score) + static_cast<double>(sbest);  // :982-983
     const bool updA = termA && (bA == 0 || candA > static_cast<double>(rA));             // :984-989
     const float nvA = static_cast<float>(candA);
     const uint32_t wA = (uA.y & kBwIdMask) | (static_cast<uint32_t>(dep1) << kBwLenShift);
@@ -444,7 +444,7 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const uint32_t *gt, uint32
     const float sbest2 = updB ? candB : rB;
     const uint32_t finB = updB ? ((static_cast<uint32_t>(mb) << kBwLenShift) | kBwUnk) : bB;
     // (C) a one-byte piece of the next start
-    const double candC = piece_score_u(r, 1, max_score, uds) + static_cast<double>(sbest2);
+    const double candC = piece_score_u<UDS>(r, 1, max_score) + static_cast<double>(sbest2);
     const bool updC = termC && (bC == 0 || candC > static_cast<double>(rC));
     if (updA) { ring_s[oA] = nvA; ring_b[oA] = wA; }
     if (updC) { ring_s[oC] = static_cast<float>(candC); ring_b[oC] = (r.y & kBwIdMask) | (1u << kBwLenShift); }
@@ -458,9 +458,8 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const uint32_t *gt, uint32
       st[((static_cast<uint32_t>(eB) >> 2) & 1u) * 256u + (static_cast<uint32_t>(eB) & 3u)] = finB;   // position s2 is final
       // the positions just passed, (s, s2], are dead: free their ring slots (after this iteration's reads and writes)
       if (mb > 0) ring_b[oB] = 0u;
-      if (mb > 1) ring_b[(static_cast<uint32_t>(s2 - 1) & rm) << 6] = 0u;
-      if (mb > 2) ring_b[(static_cast<uint32_t>(s2 - 2) & rm) << 6] = 0u;
-      if (mb > 3) ring_b[(static_cast<uint32_t>(s2 - 3) & rm) << 6] = 0u;
+      if (mb > 1)                                  // a multi-byte character: its inner positions too (rare in ASCII text)
+        for (int k = 1; k < mb; ++k) ring_b[(static_cast<uint32_t>(s2 - k) & rm) << 6] = 0u;
     }
     // ---------------- commit ----------------
     if (ended) {
@@ -677,7 +676,7 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     if (MODEL == 1) {
       // ---- segment, then backtrack: the slot is filled from its end (or from its start when reversing) ----
       tc.n_trips += static_cast<unsigned long long>(
-          unigram_stream_lane<RING>(d, gt, gb, my_nlen, my_rs, my_rb, rm, my_win, W - 1u, my_st, T.roottab, mine));
+          unigram_stream_lane<RING, !FAST>(d, gt, gb, my_nlen, my_rs, my_rb, rm, my_win, W - 1u, my_st, T.roottab, mine));
       c2 = wv::clock();
       if (!overflow) {
         n = emit_stream_lane(d, gt, gb, my_nlen, slot, cap, mine);
