@@ -84,6 +84,8 @@ def main():
                          "250k-piece unigram on the mixed-script power-law corpus)")
     ap.add_argument("--gather", choices=["ids", "none"], default="ids")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unsorted", action="store_true",
+                    help="do not length-bucket the synthetic corpus (BASELINE.json's configs are length-bucketed)")
     args = ap.parse_args()
 
     import torch
@@ -117,7 +119,7 @@ def main():
     if c5:
         text, offs = synth.mixed_corpus(args.sentences, seed=20250228 + rank)
     else:
-        text, offs = synth.ascii_corpus(args.sentences, seed=20250227 + rank)
+        text, offs = synth.ascii_corpus(args.sentences, seed=20250227 + rank, sort_by_length=not args.unsorted)
     n = len(offs) - 1
     d_text = torch.from_numpy(text).to(dev)
     d_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
@@ -189,9 +191,10 @@ def main():
             "data": "synthetic",
             "gb_text_per_s": job_bytes * args.steps / dt / 1e9,
             "config": {"workload": "configs[%d]: %s model, %d synthetic %s sentences per GPU, mean %.1f B, "
-                                   "length-bucketed, resident in HBM"
+                                   "%s, resident in HBM"
                                    % (4 if c5 else (1 if sp.model_type() == 1 else 2), args.model, n,
-                                      "mixed-script power-law [16, 4096] B" if c5 else "ASCII", len(text) / n),
+                                      "mixed-script power-law [16, 4096] B" if c5 else "ASCII", len(text) / n,
+                                      "in generator order (not length-bucketed)" if args.unsorted else "length-bucketed"),
                        "model": args.model, "sentences_per_gpu": n, "ids_per_sentence": job_ids / (world * n),
                        "gather": ("%s (%s on the wire)" % (args.gather, "int16" if wire is not None else "int32")
                                   if args.gather == "ids" else args.gather) if world > 1 else "n/a",

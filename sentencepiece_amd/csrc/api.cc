@@ -39,7 +39,8 @@ std::string g_create_error;
 struct Ctrl {
   uint32_t list_counts[kMaxClasses];
   uint32_t hard_counts[kMaxClasses];   // sentences a FAST kernel left to the GENERAL kernel of its class
-  uint32_t wave_counts[kMaxClasses];   // BPE: sentences the streaming kernels left to the sentence-per-wave kernel
+  uint32_t wave_counts[kMaxClasses];
+  uint32_t key_totals[kSortKeys], key_cursor[kSortKeys];   // classify: counting sort by (class, length sub-bucket)   // BPE: sentences the streaming kernels left to the sentence-per-wave kernel
   uint32_t status;
   uint32_t pad;
   unsigned long long arena_head;
@@ -289,6 +290,7 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
       ca.offs = d_offsets; ca.n = n32; ca.n_classes = static_cast<uint32_t>(ncls);
       for (int c = 0; c < ncls; ++c) ca.rcap[c] = cls[c].rcap;
       ca.lists = h->d_lists.p; ca.list_counts = h->d_ctrl->list_counts;
+      ca.key_totals = h->d_ctrl->key_totals; ca.key_cursor = h->d_ctrl->key_cursor;
       const uint32_t chunks = (n32 + 64 * kClassifyChunk - 1) / (64 * kClassifyChunk);
       HIP_OR_RETURN(h, LaunchClassify(ca, static_cast<int>(chunks < static_cast<uint32_t>(wide) ? chunks : wide), stream));
     }

@@ -530,57 +530,88 @@ inline uint32_t EncodeLdsBytes(int model_type, uint32_t rcap, uint32_t ncap) {
 // ---------------------------------------------------- bookkeeping kernels --
 constexpr int kMaxClasses = 8;
 
+// Length classification = a two-pass counting sort of the sentence indices by (length class, length sub-bucket):
+// the class decides which kernels / scratch stride a sentence gets, the sub-bucket only orders the class list so
+// that the 64 sentences of a tile have similar lengths whatever the order of the input (the lanes of a tile run
+// in lock step: an unsorted corpus cost 1.6x the search iterations of a length-bucketed one, profiles/).
+constexpr int kSubBuckets = 16;
+constexpr int kSortKeys = kMaxClasses * kSubBuckets;
+constexpr int kClassifyChunk = 16;   // a wave takes chunks of 16 x 64 sentences
+
 struct ClassifyArgs {
   const uint64_t *offs;
   uint32_t n;
   uint32_t n_classes;
   uint32_t rcap[kMaxClasses];   // ascending; sentences longer than the last go to the last class
   uint32_t *lists;              // n_classes x n
-  uint32_t *list_counts;        // n_classes (zeroed before launch)
+  uint32_t *list_counts;        // n_classes (zeroed before launch; written by the scatter pass)
+  uint32_t *key_totals;         // kSortKeys (zeroed): sentences per (class, sub-bucket), from the count pass
+  uint32_t *key_cursor;         // kSortKeys (zeroed): scatter pass progress
 };
 
-// Buckets sentence indices by raw byte length.  A wave takes chunks of kClassifyChunk x 64 sentences: it
-// classifies them (class numbers stay in registers), reserves the chunk's range in every class list with ONE
-// atomic per class (the per-tile atomics of the first version serialized on five hot counters: 1.85 ms for 10 M
-// sentences), then writes the indices in order.  Lists keep the input order within a chunk.
-constexpr int kClassifyChunk = 16;
+// (class << 4 | sub-bucket) of a sentence of len raw bytes
+SPMX_DEVICE uint32_t classify_key(const ClassifyArgs &a, uint64_t len) {
+  int cls = static_cast<int>(a.n_classes) - 1;
+  for (int c = static_cast<int>(a.n_classes) - 2; c >= 0; --c) if (len <= a.rcap[c]) cls = c;
+  const uint64_t lo = cls > 0 ? a.rcap[cls - 1] : 0, hi = a.rcap[cls];
+  uint64_t sub = len > lo ? (len - lo - 1) * kSubBuckets / (hi - lo) : 0;
+  if (sub > kSubBuckets - 1) sub = kSubBuckets - 1;
+  return static_cast<uint32_t>(cls) * kSubBuckets + static_cast<uint32_t>(sub);
+}
 
-SPMX_DEVICE void classify_block(const ClassifyArgs &a) {
+// PASS 0 counts, PASS 1 scatters.  hist is kSortKeys * 3 words of LDS (per wave).
+template <int PASS>
+SPMX_DEVICE void classify_block(const ClassifyArgs &a, uint32_t *hist) {
   const int lane = wv::lane();
+  uint32_t *start = hist + kSortKeys, *base = hist + 2 * kSortKeys;
+  if (PASS == 1) {
+    // where every key's run begins: its class list + the keys of the same class before it
+    for (int k = lane; k < kSortKeys; k += 64) {
+      const int c = k / kSubBuckets;
+      uint32_t before = 0;
+      for (int j = c * kSubBuckets; j < k; ++j) before += a.key_totals[j];
+      base[k] = before;
+      if (wv::block_id() == 0 && k % kSubBuckets == kSubBuckets - 1 && static_cast<uint32_t>(c) < a.n_classes)
+        a.list_counts[c] = before + a.key_totals[k];
+    }
+  }
   const uint32_t per_chunk = 64u * kClassifyChunk;
   const uint32_t chunks = (a.n + per_chunk - 1) / per_chunk;
   for (uint32_t ch = static_cast<uint32_t>(wv::block_id()); ch < chunks; ch += static_cast<uint32_t>(wv::grid_size())) {
     const uint32_t first = ch * per_chunk;
-    uint64_t packed = 0;                 // 4 bits per sentence: class + 1, 0 = past the end
-    uint32_t tot[kMaxClasses];
-    for (uint32_t c = 0; c < kMaxClasses; ++c) tot[c] = 0;
+    for (int k = lane; k < kSortKeys; k += 64) hist[k] = 0;
+    wv::sync();
+    uint32_t keys[kClassifyChunk];
+#pragma unroll
     for (int k = 0; k < kClassifyChunk; ++k) {
       const uint32_t i = first + static_cast<uint32_t>(k) * 64u + static_cast<uint32_t>(lane);
-      int cls = -1;
+      keys[k] = 0xFFFFFFFFu;
       if (i < a.n) {
-        const uint64_t len = a.offs[i + 1] - a.offs[i];
-        cls = static_cast<int>(a.n_classes) - 1;
-        for (int c = static_cast<int>(a.n_classes) - 2; c >= 0; --c) if (len <= a.rcap[c]) cls = c;
-      }
-      packed |= static_cast<uint64_t>(cls + 1) << (4 * k);
-      for (uint32_t c = 0; c < a.n_classes; ++c) tot[c] += static_cast<uint32_t>(wv::popc64(wv::ballot(cls == static_cast<int>(c))));
-    }
-    uint32_t base[kMaxClasses];
-    for (uint32_t c = 0; c < a.n_classes; ++c) {
-      uint32_t b = 0;
-      if (lane == 0 && tot[c]) b = wv::atomic_add(&a.list_counts[c], tot[c]);
-      base[c] = wv::shfl(b, 0);
-    }
-    for (int k = 0; k < kClassifyChunk; ++k) {
-      const uint32_t i = first + static_cast<uint32_t>(k) * 64u + static_cast<uint32_t>(lane);
-      const int cls = static_cast<int>((packed >> (4 * k)) & 15u) - 1;
-      for (uint32_t c = 0; c < a.n_classes; ++c) {
-        const uint64_t m = wv::ballot(cls == static_cast<int>(c));
-        if (cls == static_cast<int>(c))
-          a.lists[static_cast<uint64_t>(c) * a.n + base[c] + static_cast<uint32_t>(wv::popc64(m & ((1ull << lane) - 1ull)))] = i;
-        base[c] += static_cast<uint32_t>(wv::popc64(m));
+        keys[k] = classify_key(a, a.offs[i + 1] - a.offs[i]);
+        wv::lds_atomic_add(&hist[keys[k]], 1u);
       }
     }
+    wv::sync();
+    if (PASS == 0) {
+      for (int k = lane; k < kSortKeys; k += 64) if (hist[k]) wv::atomic_add(&a.key_totals[k], hist[k]);
+    } else {
+      // reserve this chunk's slice of every key's run, then hand out the slots (order inside a slice is arbitrary)
+      for (int k = lane; k < kSortKeys; k += 64) {
+        start[k] = hist[k] ? wv::atomic_add(&a.key_cursor[k], hist[k]) : 0u;
+        hist[k] = 0;
+      }
+      wv::sync();
+#pragma unroll
+      for (int k = 0; k < kClassifyChunk; ++k) {
+        const uint32_t i = first + static_cast<uint32_t>(k) * 64u + static_cast<uint32_t>(lane);
+        if (keys[k] != 0xFFFFFFFFu) {
+          const uint32_t key = keys[k], c = key / kSubBuckets;
+          const uint32_t r = wv::lds_atomic_add(&hist[key], 1u);
+          a.lists[static_cast<uint64_t>(c) * a.n + base[key] + start[key] + r] = i;
+        }
+      }
+    }
+    wv::sync();
   }
 }
 

@@ -33,7 +33,14 @@ __global__ __launch_bounds__(FAST ? 1024 : 512) void EncodeBpeStreamKernel(Encod
 
 __global__ __launch_bounds__(64) void DecodeCountKernel(DecodeArgs a) { decode_block<false>(a); }
 __global__ __launch_bounds__(64) void DecodeWriteKernel(DecodeArgs a) { decode_block<true>(a); }
-__global__ __launch_bounds__(64) void ClassifyKernel(ClassifyArgs a) { classify_block(a); }
+__global__ __launch_bounds__(64) void ClassifyCountKernel(ClassifyArgs a) {
+  __shared__ uint32_t hist[3 * kSortKeys];
+  classify_block<0>(a, hist);
+}
+__global__ __launch_bounds__(64) void ClassifyScatterKernel(ClassifyArgs a) {
+  __shared__ uint32_t hist[3 * kSortKeys];
+  classify_block<1>(a, hist);
+}
 __global__ __launch_bounds__(64) void ScanTilesKernel(ScanArgs a) { scan_tiles_block(a); }
 __global__ __launch_bounds__(64) void ScanSumsKernel(ScanArgs a) { scan_sums_block(a); }
 __global__ __launch_bounds__(64) void ScanFinalKernel(ScanArgs a) { scan_final_block(a); }
@@ -117,7 +124,8 @@ hipError_t LaunchDecode(bool write, const DecodeArgs &a, int grid, hipStream_t s
 }
 
 hipError_t LaunchClassify(const ClassifyArgs &a, int grid, hipStream_t stream) {
-  hipLaunchKernelGGL(ClassifyKernel, dim3(grid), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL(ClassifyCountKernel, dim3(grid), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL(ClassifyScatterKernel, dim3(grid), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
 

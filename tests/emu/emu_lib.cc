@@ -203,7 +203,10 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
   ca.offs = offs; ca.n = static_cast<uint32_t>(n); ca.n_classes = static_cast<uint32_t>(ncls);
   for (int c = 0; c < ncls; ++c) ca.rcap[c] = cls[c].rcap;
   ca.lists = lists.data(); ca.list_counts = list_counts.data();
-  for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { classify_block(ca); });
+  std::vector<uint32_t> key_totals(kSortKeys, 0), key_cursor(kSortKeys, 0), hist(3 * kSortKeys, 0);
+  ca.key_totals = key_totals.data(); ca.key_cursor = key_cursor.data();
+  for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { classify_block<0>(ca, hist.data()); });
+  for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { classify_block<1>(ca, hist.data()); });
   const uint64_t text_bytes = offs[n];
   std::vector<int32_t> arena(4 * text_bytes + (8 + dev.n_prefix + dev.n_suffix) * n + 64);
   unsigned long long arena_head = 0;

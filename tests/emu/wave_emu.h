@@ -91,6 +91,7 @@ inline void sync_global() { emu::Collective(emu::kSync, 0, 0); }
 inline uint32_t atomic_add(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
 inline unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { const unsigned long long o = *p; *p = o + v; return o; }
 inline void atomic_or(uint32_t *p, uint32_t v) { *p |= v; }
+inline uint32_t lds_atomic_add(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
 inline void atomic_min(unsigned long long *p, unsigned long long v) { if (v < *p) *p = v; }
 
 inline unsigned long long clock() { return 0; }
