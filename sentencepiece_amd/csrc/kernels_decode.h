@@ -30,6 +30,7 @@ constexpr uint32_t kDkEmpty = 1u;    // control piece
 constexpr uint32_t kDkByte = 2u;     // byte piece, value in bits 8..15
 constexpr uint32_t kDkLiteral = 3u;  // unknown piece: dec_bytes verbatim, never stripped
 constexpr uint32_t kDiStartsSp = 1u << 2;   // kDkText: the piece starts with U+2581 (its decoded form with ' ')
+constexpr int kDiLenShift = 16;             // bits 16..31: number of decoded bytes (so the count pass needs this word only)
 
 constexpr uint32_t kStBadId = 1u << 4;   // DecodeArgs::status: an id outside [0, GetPieceSize())
 
@@ -74,8 +75,8 @@ SPMX_DEVICE void decode_block(const DecodeArgs &a) {
           wv::atomic_min(a.bad_key, (static_cast<unsigned long long>(s) << 32) | static_cast<uint32_t>(id));
         } else {
           info = d.dec_info[id];
-          off = d.dec_off[id];
-          full = d.dec_off[id + 1] - off;
+          full = info >> kDiLenShift;
+          if (WRITE) off = d.dec_off[id];
         }
       }
       const bool is_byte = valid && (info & kDkMask) == kDkByte;

@@ -325,7 +325,9 @@ Status CompileTables(const ModelData &m, HostTables *t) {
           else t->dec_bytes.push_back(static_cast<uint8_t>(piece[k++]));
         }
       }
-      t->dec_info[i] = info;
+      const size_t dl = t->dec_bytes.size() - t->dec_off[i];
+      if (dl > 0xFFFF) return Status::Error(kUnimplemented, "piece longer than 65535 bytes");
+      t->dec_info[i] = info | static_cast<uint32_t>(dl) << 16;        // kDiLenShift
     }
     t->dec_off[V] = static_cast<uint32_t>(t->dec_bytes.size());
     if (t->dec_bytes.empty()) t->dec_bytes.push_back(0);
