@@ -68,6 +68,10 @@ int spmx_model_type(const spmx_handle *h);   /* 1 unigram, 2 bpe */
  *   _EncodeAsIdsBatch (python/src/sentencepiece/sentencepiece.i:439-446) --
  * computes with a thread pool.
  *
+ * Length limits of the device path (OUT_OF_RANGE beyond them; the reference has none): 1 MiB per sentence for
+ * unigram models without user-defined symbols / whitespace-as-suffix, 8192 bytes for other unigram models, 4096
+ * bytes for BPE models.
+ *
  * Sentences are passed packed: `text` holds the bytes of all sentences back to
  * back, offsets[i] .. offsets[i+1] delimit sentence i (n + 1 entries).
  * Ids come back as CSR: ids[id_offsets[i] .. id_offsets[i+1]). */

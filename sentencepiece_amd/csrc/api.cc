@@ -227,7 +227,7 @@ StreamPlan PlanStream(const spmx_handle *h, const LengthClass &lc, bool fast, ui
   StreamPlan sp;
   const uint32_t ring = ScoreRing(h->tables.max_piece_len);
   // a FAST text column never exceeds raw length + 1 (one-byte space symbol); GENERAL: the class's normalized capacity
-  sp.tcap = fast ? lc.rcap + 1 : lc.ncap;
+  sp.tcap = fast ? (lc.rcap > kMaxStagedRaw ? lc.ncap : lc.rcap + 1) : lc.ncap;
   const uint32_t priv = StreamPrivateBytes(fast, model, lc.rcap, lc.ncap, ring);
   int waves = static_cast<int>((kLdsPerCu - kStreamSharedBytes) / priv);
   const int wmax = fast ? 16 : 8;   // __launch_bounds__ of the two kernels
@@ -309,7 +309,12 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
       for (int c = 0; c < ncls; ++c) {
         if (known[c] == 0 && !prev_general) continue;
         const bool fast = StreamFastEligible(h->dev.flags) && !h->no_fast && known[c] > 0;
-        for (int pass = fast ? 0 : 1; pass < 2; ++pass) {
+        const bool staged = cls[c].rcap <= kMaxStagedRaw;   // document-length classes: FAST kernel only
+        if (!staged && known[c] > 0 && !fast)
+          return Fail(h, kOutOfRange, "a sentence is longer than 8192 bytes: this model (user-defined symbols, whitespace-as-suffix "
+                                      "or unescaped U+2581 rules) is limited to that on the device path");
+        if (!staged && !fast) continue;
+        for (int pass = fast ? 0 : 1; pass < (staged ? 2 : 1); ++pass) {
           StreamPlan sp = PlanStream(h, cls[c], pass == 0, known[c]);
           if (sp.scratch_words > need) need = sp.scratch_words;
         }
@@ -322,8 +327,11 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
       EncodeArgs a{};
       a.dev = h->dev; a.text = d_text; a.offs = d_offsets;
       a.list = h->d_lists.p + static_cast<size_t>(c) * n; a.list_count = &h->d_ctrl->list_counts[c];
-      a.next_list = c + 1 < ncls ? h->d_lists.p + static_cast<size_t>(c + 1) * n : nullptr;
-      a.next_count = c + 1 < ncls ? &h->d_ctrl->list_counts[c + 1] : nullptr;
+      // a sentence whose normalized form overflows its class goes to the next one -- among the classes whose
+      // GENERAL kernel can stage it; past the last of those it fails the call
+      const bool has_next = c + 1 < ncls && cls[c + 1].rcap <= kMaxStagedRaw;
+      a.next_list = has_next ? h->d_lists.p + static_cast<size_t>(c + 1) * n : nullptr;
+      a.next_count = has_next ? &h->d_ctrl->list_counts[c + 1] : nullptr;
       a.arena = h->d_arena.p; a.arena_head = &h->d_ctrl->arena_head; a.arena_cap = h->d_arena.cap;
       a.tmp_off = h->d_tmp_off.p; a.counts = h->d_counts.p; a.status = &h->d_ctrl->status;
       a.stats = &h->d_ctrl->stats[kStatsPerClass * c];
@@ -333,11 +341,13 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
         if (known[c] == 0 && !prev_general) continue;
         a.ring = ScoreRing(h->tables.max_piece_len);
         const bool fast = StreamFastEligible(h->dev.flags) && !h->no_fast && known[c] > 0;
-        for (int pass = fast ? 0 : 1; pass < 2; ++pass) {
+        const bool staged = cls[c].rcap <= kMaxStagedRaw;
+        if (!staged && !fast) continue;
+        for (int pass = fast ? 0 : 1; pass < (staged ? 2 : 1); ++pass) {
           const bool is_fast = pass == 0;
           const StreamPlan sp = PlanStream(h, cls[c], is_fast, known[c]);
           if (is_fast) {
-            a.hard_list = h->d_lists.p + static_cast<size_t>(ncls + c) * n;
+            a.hard_list = staged ? h->d_lists.p + static_cast<size_t>(ncls + c) * n : nullptr;   // no GENERAL kernel to hand over to
             a.hard_count = &h->d_ctrl->hard_counts[c];
           } else if (fast) {
             a.list = h->d_lists.p + static_cast<size_t>(ncls + c) * n;
@@ -413,7 +423,7 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
       arena_need = h->h_ctrl->arena_head + 64;
       continue;
     }
-    if (st & kStTooLong) return Fail(h, kOutOfRange, "a sentence is too long for the device path (normalized form exceeds the largest length class)");
+    if (st & kStTooLong) return Fail(h, kOutOfRange, "a sentence is too long for the device path (more than 1 MiB, or its normalized form exceeds the largest length class)");
     if (st & kStRevMergeOverflow) return Fail(h, kResourceExhausted, "BPE: more than 64 distinct unused merged pieces in one sentence");
     if (st & kStInternal) return Fail(h, kInternal, "all normalized characters are not consumed.");   // sentencepiece_processor.cc:628
     if (prof) {

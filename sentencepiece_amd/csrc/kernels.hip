@@ -81,7 +81,9 @@ EncodeFn PickStream(int cls) {
     case 1: return EncodeStreamKernel<1, FAST>;
     case 2: return EncodeStreamKernel<2, FAST>;
     case 3: return EncodeStreamKernel<3, FAST>;
-    default: return EncodeStreamKernel<4, FAST>;
+    case 4: return EncodeStreamKernel<4, FAST>;
+    case 5: return EncodeStreamKernel<5, FAST>;
+    default: return EncodeStreamKernel<6, FAST>;
   }
 }
 EncodeFn PickStreamR16(int cls) {
@@ -90,7 +92,9 @@ EncodeFn PickStreamR16(int cls) {
     case 1: return EncodeStreamKernelR16<1>;
     case 2: return EncodeStreamKernelR16<2>;
     case 3: return EncodeStreamKernelR16<3>;
-    default: return EncodeStreamKernelR16<4>;
+    case 4: return EncodeStreamKernelR16<4>;
+    case 5: return EncodeStreamKernelR16<5>;
+    default: return EncodeStreamKernelR16<6>;
   }
 }
 template <bool FAST>

@@ -612,14 +612,21 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
       // (the raw window borrows the rings, idle until the search); a stray one in an ASCII tile would hold the
       // other 63 lanes up for its whole length, and long sentences are better off position-parallel: both go to
       // the GENERAL kernel.
-      const bool many = wv::popc64(wv::ballot(nlen < 0)) >= 16 && a.rcap <= kLaneGeneralMaxRaw && !a.no_lane_general;
+      // Document-length classes have no GENERAL kernel (its LDS staging holds one whole sentence): every
+      // non-ASCII sentence is normalized here, and one that cannot be fails the call.
+      const bool no_general = a.hard_list == nullptr;
+      const bool many = no_general ||
+                        (wv::popc64(wv::ballot(nlen < 0)) >= 16 && a.rcap <= kLaneGeneralMaxRaw && !a.no_lane_general);
       if (many && nlen < 0)
         nlen = norm_lane_general(d, a.text, my_beg, static_cast<int>(my_len), gt, static_cast<int>(tcap),
                                  reinterpret_cast<uint8_t *>(T.ring_s) + static_cast<uint32_t>(lane) * (kRawWin + 16));
       const bool hard = go && nlen < 0;
       if (go && nlen >= 0) { mine = true; my_nlen = nlen; }
       const uint64_t hm = wv::ballot(hard);
-      if (hm) {                                 // hand the sentence to the GENERAL kernel of this class
+      if (hm && no_general) {
+        uint64_t m = hm;
+        while (m) { const int i = wv::ffs64(m) - 1; m &= m - 1; fail_sentence(a, wv::shfl(my_sid, i), kStTooLong, lane); }
+      } else if (hm) {                          // hand the sentence to the GENERAL kernel of this class
         const int leader = wv::ffs64(hm) - 1;
         uint32_t hb = 0;
         if (lane == leader) hb = wv::atomic_add(a.hard_count, static_cast<uint32_t>(wv::popc64(hm)));

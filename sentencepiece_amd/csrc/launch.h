@@ -12,10 +12,14 @@ struct LengthClass { uint32_t rcap, ncap; };
 // (the stride of the streaming kernels' HBM scratch; the LDS workspace of the
 // sentence-per-wave BPE kernel).  A sentence whose normalized form overflows
 // ncap is handed to the next class; past the last class it is an error.
-constexpr int kNumClassesUnigram = 5;
+// Unigram: the last two classes are for document-length inputs (up to 1 MiB per sentence).  Only the FAST
+// kernel runs there (per-lane normalizers; its working set does not depend on the length), so they need a model
+// it can take (kernels_stream.h StreamFastEligible); ncap is the capacity of a text column there.
+constexpr int kNumClassesUnigram = 7;
 constexpr int kNumClassesBpe = 4;
+constexpr uint32_t kMaxStagedRaw = 8192;   // GENERAL kernels stage one sentence in LDS: classes up to this raw size
 constexpr LengthClass kClassesUnigram[kNumClassesUnigram] = {
-    {192, 448}, {576, 1280}, {1536, 3328}, {4096, 8704}, {8192, 20480}};
+    {192, 448}, {576, 1280}, {1536, 3328}, {4096, 8704}, {8192, 20480}, {65536, 98304}, {1048576, 1572864}};
 constexpr LengthClass kClassesBpe[kNumClassesBpe] = {{192, 448}, {576, 1280}, {1536, 3328}, {4096, 6400}};
 
 // score ring entries for a model whose longest piece has max_piece_len bytes

@@ -133,7 +133,9 @@ struct LengthClass { uint32_t rcap, ncap; };
 // keep in sync with csrc/launch.h (the test compares the emulated pipeline with
 // the oracle, not with these numbers; small classes are added to exercise the
 // escalation path on short inputs)
-const LengthClass kUniCls[] = {{24, 40}, {192, 448}, {576, 1280}, {1536, 3328}, {4096, 8704}, {8192, 20480}};
+// (the last class stands for the document-length classes: FAST kernel only, no staging)
+const LengthClass kUniCls[] = {{24, 40}, {192, 448}, {576, 1280}, {1536, 3328}, {4096, 8704}, {8192, 20480}, {65536, 98304}};
+const uint32_t kEmuMaxStagedRaw = 8192;
 const LengthClass kBpeCls[] = {{24, 40}, {192, 448}, {576, 1280}, {1536, 3328}, {4096, 6400}};
 }  // namespace
 
@@ -216,8 +218,9 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
     EncodeArgs a{};
     a.dev = dev; a.text = text; a.offs = offs;
     a.list = lists.data() + static_cast<size_t>(c) * n; a.list_count = &list_counts[c];
-    a.next_list = c + 1 < ncls ? lists.data() + static_cast<size_t>(c + 1) * n : nullptr;
-    a.next_count = c + 1 < ncls ? &list_counts[c + 1] : nullptr;
+    const bool has_next = c + 1 < ncls && cls[c + 1].rcap <= kEmuMaxStagedRaw;
+    a.next_list = has_next ? lists.data() + static_cast<size_t>(c + 1) * n : nullptr;
+    a.next_count = has_next ? &list_counts[c + 1] : nullptr;
     a.arena = arena.data(); a.arena_head = &arena_head; a.arena_cap = arena.size();
     a.tmp_off = tmp_off.data(); a.counts = counts.data(); a.status = &status; a.stats = &stats[kStatsPerClass * c];
     a.rcap = cls[c].rcap; a.ncap = cls[c].ncap;
@@ -233,9 +236,14 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
       const int waves = grid;   // one wave per block in the emulator
       const int model = bpe ? 2 : 1;
       a.wave_list = wavel.data(); a.wave_count = &wave_count;
+      const bool staged = a.rcap <= kEmuMaxStagedRaw;
+      if (!staged && !(StreamFastEligible(dev.flags) && !getenv("SPMX_NO_FAST"))) {
+        if (list_counts[c]) status |= kStTooLong;      // csrc/api.cc fails the call here
+        continue;
+      }
       if (StreamFastEligible(dev.flags) && !getenv("SPMX_NO_FAST")) {
-        a.hard_list = hard.data(); a.hard_count = &hard_count;
-        a.stream_tcap = a.rcap + 1;
+        a.hard_list = staged ? hard.data() : nullptr; a.hard_count = &hard_count;
+        a.stream_tcap = staged ? a.rcap + 1 : a.ncap;
         std::vector<uint32_t> st(StreamTextDwords(a.stream_tcap, a.ring) * waves, 0xCDCDCDCDu), sb(StreamBpWords(a.stream_tcap) * waves, 0xCDCDCDCDu);
         a.stream_text = st.data(); a.stream_bp = sb.data();
         std::vector<unsigned char> fsmem(StreamLdsBytes(true, model, a.rcap, a.ncap, a.ring, 1) + 64, 0xCD);
@@ -249,6 +257,7 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
         a.list = hard.data(); a.list_count = &hard_count;
         a.hard_list = nullptr; a.hard_count = nullptr;
       }
+      if (!staged) continue;
       a.stream_tcap = a.ncap;
       std::vector<uint32_t> st(StreamTextDwords(a.stream_tcap, a.ring) * waves, 0xCDCDCDCDu), sb(StreamBpWords(a.stream_tcap) * waves, 0xCDCDCDCDu);
       a.stream_text = st.data(); a.stream_bp = sb.data();

@@ -186,3 +186,34 @@ def test_emu_capacity_report(emu, corpora):
     assert tot == -len(full) - 2
     assert (ids == -7).all()
     np.testing.assert_array_equal(id_offs, io)
+
+
+@pytest.mark.parametrize("model", ["test_model", "c5_250k_bf", "test_ja_model"])
+def test_emu_document_length(model, emu, oracle, corpora):
+    """Sentences beyond the staged classes (> 8192 B raw): the FAST kernel alone, per-lane normalizers for ASCII and
+    for everything else."""
+    from sentencepiece_amd import synth
+    blob = fixtures.model_blob(model)
+    h = emu.load(blob)
+    o = oracle.load(blob)
+    bot, boffs = corpora["botchan"]
+    ja, joffs = corpora["ja"]
+    docs = [bot[:int(boffs[220])].tobytes().replace(b"\n", b" "),          # ~14 KB of ASCII
+            ja[:int(joffs[60])].tobytes(),                                  # Japanese, well over 8 KB
+            b"x" * 9000, ("猫 " * 3000).encode()]
+    assert all(len(d) > 8192 for d in docs)
+    text, offs = synth.pack(docs)
+    ids, io = h.encode_batch(text, offs, grid=2)
+    assert h.status == 0
+    oids, oio = o.encode_batch(text, offs)
+    np.testing.assert_array_equal(io, oio)
+    np.testing.assert_array_equal(ids, oids)
+
+
+def test_emu_document_length_needs_fast_model(emu, corpora):
+    """A model the per-lane normalizers cannot take (user-defined symbols) is limited to the staged classes."""
+    from sentencepiece_amd import synth
+    h = emu.load(fixtures.model_blob("uni1k_uds"))
+    text, offs = synth.pack([b"y" * 9000])
+    h.encode_batch(text, offs, grid=1)
+    assert h.status & 2          # kStTooLong: csrc/api.cc turns it into OUT_OF_RANGE

@@ -51,3 +51,26 @@ def test_golden(key, manifest, golden_arrays, corpora, procs, oracle):
     oids, oio = o.encode_batch(text, offs)
     np.testing.assert_array_equal(io, oio)
     np.testing.assert_array_equal(ids, oids)
+
+
+def test_document_length_sentences(procs, oracle, corpora):
+    """Inputs far beyond the staged length classes (SentencePiece is routinely fed whole documents): 100 KB of ASCII,
+    60 KB of Japanese, 1 MiB of one character; a model the per-lane normalizers cannot take stops at 8192 bytes."""
+    from sentencepiece_amd import synth
+    bot, boffs = corpora["botchan"]
+    ja, joffs = corpora["ja"]
+    docs = [bot[:int(boffs[1600])].tobytes().replace(b"\n", b" "), ja[:int(joffs[300])].tobytes()[:60000 // 3 * 3],
+            b"ab " * 349525, "短い".encode()]
+    assert len(docs[0]) > 90000 and len(docs[2]) > 1000000
+    text, offs = synth.pack(docs)
+    for model in ("test_model", "test_ja_model", "uni32k"):
+        sp = procs(model)
+        ids, io = sp.EncodePacked(text, offs)
+        oids, oio = oracle.load(fixtures.model_blob(model)).encode_batch(text, offs)
+        np.testing.assert_array_equal(io, oio)
+        np.testing.assert_array_equal(ids, oids)
+    with pytest.raises(Exception) as ei:
+        procs("uni1k_uds").EncodePacked(*synth.pack([b"y" * 9000]))
+    assert "8192" in str(ei.value)
+    with pytest.raises(Exception):
+        procs("test_model").EncodePacked(*synth.pack([b"z" * (1 << 20) + b"!"]))
