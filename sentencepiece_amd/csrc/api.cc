@@ -92,7 +92,7 @@ struct spmx_handle {
   bool no_fast = false;   // SPMX_NO_FAST=1: GENERAL kernels only (A/B measurements)
   int tile_waves_override = 0;   // SPMX_TILE_WAVES: cap on wavefronts per workgroup of the streaming kernels
   // device copies of the tables
-  DevBuf<uint32_t> d_ndarts, d_sym_final, d_dec_info, d_dec_off;
+  DevBuf<uint32_t> d_ndarts, d_npair, d_sym_final, d_dec_info, d_dec_off;
   DevBuf<uint8_t> d_dec_bytes;
   DevBuf<uint8_t> d_nblob;
   DevBuf<U4> d_ptrie, d_chartab, d_pairtab;
@@ -153,6 +153,7 @@ int UploadTables(spmx_handle *h) {
   HostTables &t = h->tables;
   HIP_OR_RETURN(h, Upload(&h->d_ndarts, t.ndarts));
   HIP_OR_RETURN(h, Upload(&h->d_nblob, t.nblob));
+  HIP_OR_RETURN(h, Upload(&h->d_npair, t.npair));
   HIP_OR_RETURN(h, Upload(&h->d_ptrie, t.ptrie));
   HIP_OR_RETURN(h, Upload(&h->d_utrie, t.utrie));
   HIP_OR_RETURN(h, Upload(&h->d_chartab, t.chartab));
@@ -166,6 +167,7 @@ int UploadTables(spmx_handle *h) {
   h->dev = t.scalars;
   h->dev.ndarts = h->d_ndarts.p;
   h->dev.nblob = h->d_nblob.p;
+  h->dev.npair = h->d_npair.p;
   h->dev.ptrie = h->d_ptrie.p;
   h->dev.utrie = h->d_utrie.p;
   h->dev.chartab = h->d_chartab.p;
@@ -188,7 +190,7 @@ int RefreshDevice(spmx_handle *h, bool types_changed) {
     else HIP_OR_RETURN(h, Upload(&h->d_sym_final, t.sym_final));
   }
   SpmxDev d = t.scalars;
-  d.ndarts = h->dev.ndarts; d.nblob = h->dev.nblob; d.ptrie = h->d_ptrie.p; d.utrie = h->dev.utrie;
+  d.ndarts = h->dev.ndarts; d.nblob = h->dev.nblob; d.npair = h->dev.npair; d.ptrie = h->d_ptrie.p; d.utrie = h->dev.utrie;
   d.chartab = h->dev.chartab; d.pairtab = h->dev.pairtab; d.sym_final = h->d_sym_final.p;
   d.sym_len = h->dev.sym_len; d.byte_ids = h->dev.byte_ids;
   d.dec_info = h->dev.dec_info; d.dec_off = h->dev.dec_off; d.dec_bytes = h->dev.dec_bytes;
@@ -199,7 +201,7 @@ int RefreshDevice(spmx_handle *h, bool types_changed) {
 void DestroyHandle(spmx_handle *h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
-  h->d_ndarts.Free(); h->d_sym_final.Free(); h->d_nblob.Free(); h->d_ptrie.Free(); h->d_chartab.Free();
+  h->d_ndarts.Free(); h->d_npair.Free(); h->d_sym_final.Free(); h->d_nblob.Free(); h->d_ptrie.Free(); h->d_chartab.Free();
   h->d_pairtab.Free(); h->d_utrie.Free(); h->d_sym_len.Free(); h->d_byte_ids.Free();
   h->d_dec_info.Free(); h->d_dec_off.Free(); h->d_dec_bytes.Free();
   h->d_stream.Free(); h->d_lists.Free(); h->d_counts.Free(); h->d_tmp_off.Free(); h->d_tile_sums.Free(); h->d_arena.Free();

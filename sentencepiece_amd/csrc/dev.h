@@ -68,6 +68,10 @@ struct SpmxDev {
   // bit b (b < 128): no charsmap key is `b` alone or `b` followed by another ASCII byte, so an ASCII byte b
   // whose successor is ASCII (or the end of the input) cannot begin a rule and needs no trie probe
   uint32_t ascii_safe[4];
+  // bit (b0 << 8 | b1): some charsmap key starts with the bytes b0 b1, or is b0 alone (then the whole row b0 is
+  // set); b1 = 0 stands for "no second byte".  A clear bit proves that no rule starts at a position without a
+  // single Darts probe -- most CJK ideographs and ASCII pairs (tables.cc)
+  const uint32_t *npair;   // [2048]
   uint32_t flags;
   // ---- unigram (reference: src/unigram_model.cc:889-1020) ----
   const U4 *ptrie;        // piece trie with inline id / flags / score

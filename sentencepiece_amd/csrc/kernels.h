@@ -185,10 +185,10 @@ SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint
     }
     if (has_map) {                         // trie_->commonPrefixSearch (:218-228; darts.h:467-513), longest key
       bool alive = valid;
-      if (valid) {                         // ASCII followed by ASCII: no key can match (tables.cc ascii_safe)
+      if (valid) {                         // no key starts with these two bytes (tables.cc npair): nothing to walk
         const uint32_t b0 = raw[p];
         const uint32_t b1 = p + 1 < L ? raw[p + 1] : 0u;
-        if (b0 < 0x80u && b1 < 0x80u && ((d.ascii_safe[b0 >> 5] >> (b0 & 31u)) & 1u)) alive = false;
+        if (!((d.npair[(b0 << 8 | b1) >> 5] >> (b1 & 31u)) & 1u)) alive = false;
       }
       uint32_t pos = droot;
       int depth = 0;

@@ -232,10 +232,9 @@ SPMX_DEVICE int norm_lane_general(const SpmxDev &d, const uint8_t *gtext, uint64
     int rule_len = 0;
     uint32_t rule_off = 0;
     bool walk = has_map;
-    if (walk && b0 < 0x80u) {                              // ASCII followed by ASCII (or the end): tables.cc ascii_safe
+    if (walk) {                                            // no key starts with these two bytes (tables.cc npair)
       const uint32_t b1 = rem >= 2 ? raw(p + 1) : 0u;
-      const uint32_t word = b0 < 64u ? (b0 < 32u ? d.ascii_safe[0] : d.ascii_safe[1]) : (b0 < 96u ? d.ascii_safe[2] : d.ascii_safe[3]);
-      if (b1 < 0x80u && ((word >> (b0 & 31u)) & 1u)) walk = false;
+      walk = ((d.npair[(b0 << 8 | b1) >> 5] >> (b1 & 31u)) & 1u) != 0;
     }
     if (walk) {                                            // commonPrefixSearch, longest key (:218-228)
       uint32_t pos = droot;

@@ -113,6 +113,23 @@ Status CompileTables(const ModelData &m, HostTables *t) {
       if (safe) sc.ascii_safe[b >> 5] |= 1u << (b & 31);
     }
   }
+  // two-byte prefix filter of the charsmap keys (dev.h npair), from the same two-level walk
+  t->npair.assign(2048, 0);
+  {
+    const std::vector<uint32_t> &u = t->ndarts;
+    auto offset = [](uint32_t x) { return (x >> 10) << ((x & (1u << 9)) >> 6); };
+    for (uint32_t b0 = 1; b0 < 256 && !u.empty(); ++b0) {
+      const uint32_t pos = offset(u[0]) ^ b0;
+      if (pos >= u.size() || (u[pos] & 0x800000FFu) != b0) continue;       // no key starts with b0
+      const bool alone = (u[pos] >> 8) & 1u;                               // b0 alone is a key
+      const uint32_t base = pos ^ offset(u[pos]);
+      for (uint32_t b1 = 0; b1 < 256; ++b1) {
+        bool hit = alone;
+        if (!hit && b1 != 0) { const uint32_t p2 = base ^ b1; hit = p2 < u.size() && (u[p2] & 0x800000FFu) == b1; }
+        if (hit) t->npair[(b0 << 8 | b1) >> 5] |= 1u << (b1 & 31u);
+      }
+    }
+  }
   if (t->ndarts.empty()) t->ndarts.push_back(0);
   if (t->nblob.empty()) t->nblob.push_back(0);
   sc.ndarts_n = static_cast<uint32_t>(t->ndarts.size());
@@ -405,6 +422,7 @@ void BindHostPointers(HostTables *t) {
   SpmxDev &sc = t->scalars;
   sc.ndarts = t->ndarts.data();
   sc.nblob = t->nblob.data();
+  sc.npair = t->npair.data();
   sc.ptrie = t->ptrie.data();
   sc.byte_ids = t->byte_ids.data();
   sc.dec_info = t->dec_info.data();

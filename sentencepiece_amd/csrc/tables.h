@@ -14,6 +14,7 @@ struct HostTables {
   // normalizer
   std::vector<uint32_t> ndarts;
   std::vector<uint8_t> nblob;
+  std::vector<uint32_t> npair;   // 65536 bits, see SpmxDev::npair
   // unigram
   std::vector<U4> ptrie;
   // bpe
