@@ -76,6 +76,19 @@ def make_models():
           normalization_rule_name="nfkc_cf", treat_whitespace_as_suffix=True)
     train("bpe1k_noesc", bot, vocab_size=1000, model_type="bpe",
           normalization_rule_name="nmt_nfkc_cf", split_by_whitespace=False)
+    # Llama-style BPE: identity normalizer, no whitespace removal, byte fallback, whitespace-only pieces (runs of
+    # U+2581), digits split -- trained on botchan plus an indented copy of it so that space runs are frequent
+    with open(bot, "rb") as f:
+        lines = f.read().split(b"\n")
+    with tempfile.NamedTemporaryFile("wb", suffix=".txt", delete=False) as f:
+        for i, ln in enumerate(lines):
+            f.write(ln + b"\n")
+            f.write(b" " * (2 * (i % 9)) + ln.replace(b" ", b"  " if i % 5 == 0 else b" ") + b"\n")
+        llama_in = f.name
+    train("bpe1k_llama", llama_in, vocab_size=1000, model_type="bpe", byte_fallback=True, character_coverage=0.98,
+          normalization_rule_name="identity", remove_extra_whitespaces=False, allow_whitespace_only_pieces=True,
+          split_digits=True, add_dummy_prefix=True)
+    os.remove(llama_in)
     # configs 2 / 3: 32k unigram + BPE on a sample of the synthetic generator
     text, offs = synth.ascii_corpus(300_000, seed=777)
     with tempfile.NamedTemporaryFile("wb", suffix=".txt", delete=False) as f:
@@ -148,7 +161,7 @@ def decode_fuzz_ids(vocab_size, seed=20250301):
 
 
 MODELS = ["test_model", "test_ja_model", "uni1k", "bpe1k", "uni1k_bf", "bpe1k_bf_uds", "uni1k_uds",
-          "uni1k_ident", "uni1k_suffix", "bpe1k_noesc", "uni32k", "bpe32k"]
+          "uni1k_ident", "uni1k_suffix", "bpe1k_noesc", "uni32k", "bpe32k", "bpe1k_llama"]
 PAIRS = [(m, c) for m in MODELS for c in ("botchan", "edge", "mixed2k")] + \
         [("test_ja_model", "ja"), ("uni1k_bf", "ja"), ("bpe1k_bf_uds", "ja"),
          ("uni32k", "synth20k"), ("bpe32k", "synth20k"), ("test_model", "synth20k"),

@@ -270,7 +270,8 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
   HIP_OR_RETURN(h, h->d_tmp_off.Reserve(n + 1));
   HIP_OR_RETURN(h, h->d_tile_sums.Reserve((n + kScanTile - 1) / kScanTile + 2));
   // ids are at most one per normalized byte; the streaming kernels reserve a sentence's slot by that bound
-  const uint64_t expand = (h->dev.flags & kNfCompressSp) || !(h->dev.flags & kNfEscapeWs) ? 1 : 3;
+  uint64_t expand = (h->dev.flags & kNfCompressSp) || !(h->dev.flags & kNfEscapeWs) ? 1 : 3;
+  if ((h->dev.flags & kNfCompressSp) && (h->dev.flags & kNfByteFallback)) expand = 2;   // slots: bytes + 2 per space symbol
   uint64_t arena_need = expand * text_bytes + (4 + static_cast<uint64_t>(h->dev.n_prefix + h->dev.n_suffix)) * n + 64;
   if (h->profiling && !h->ev_ready) {
     for (auto &pair : h->ev) {

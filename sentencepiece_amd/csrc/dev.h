@@ -30,9 +30,10 @@ enum : uint32_t {
   // the space symbol U+2581 (E2 96 81) is ONE byte, kSpByte, in the normalized text held in LDS and
   // in the keys of the piece trie (tables.cc decides; ids do not depend on the encoding of the text)
   kNfCompressSp = 1u << 9,
-  // BPE only: no piece has U+2581 after its first character (and kNfCompressSp holds, no whitespace-as-suffix, no
-  // user-defined symbols), so no merge ever joins two whitespace-delimited words and a sentence can be segmented
-  // word by word (kernels_bpe_stream.h)
+  // BPE only: every piece is either a run of U+2581 or has no U+2581 after its first character (and kNfCompressSp
+  // holds, no whitespace-as-suffix, no user-defined symbols), so no merge ever joins a character that is not
+  // U+2581 with a U+2581 to its right: a sentence can be segmented word by word, a word being a run of U+2581
+  // plus what follows up to the next one (kernels_bpe_stream.h)
   kNfBpeWordwise = 1u << 10,
 };
 

@@ -1,13 +1,15 @@
 // BPE segmentation, streaming form: one SENTENCE PER LANE, one WORD at a time.
 // Reference: bpe::Model::SampleEncode with alpha = 0 (src/bpe_model.cc:38-203).
 //
-// When no piece has the space symbol after its first character (dev.h
-// kNfBpeWordwise; the default split_by_whitespace training guarantees it), a
-// pair whose right symbol starts a word -- i.e. starts with U+2581 -- can never
-// be in the vocabulary (:88-94), so the agenda never joins two words and the
-// merges of different words do not interact: the reference's global
-// best-first order restricted to one word is that word's own best-first
-// order.  A lane therefore segments its sentence word by word with a working
+// When every piece is either a run of space symbols or has none after its
+// first character (dev.h kNfBpeWordwise; the default split_by_whitespace
+// training guarantees it, with or without allow_whitespace_only_pieces), a pair
+// (x, U+2581...) whose left symbol ends in another character can never be in
+// the vocabulary (:88-94).  With a WORD = a run of U+2581 and the characters
+// that follow it up to the next U+2581, the agenda therefore never joins two
+// words and the merges of different words do not interact: the reference's
+// global best-first order restricted to one word is that word's own
+// best-first order.  A lane therefore segments its sentence word by word with a working
 // set of kBpeWordMax symbols in LDS, whatever the sentence length:
 //
 //   read      one character per iteration: symbol id from an LDS table (ASCII)
@@ -110,6 +112,7 @@ SPMX_DEVICE int bpe_stream_lane(const SpmxDev &d, const uint32_t *gt, int nlen, 
   int wstart = 0;       // byte offset of the current word
   uint32_t alive = 0, pmask = 0;
   bool merging = false; // the current word has been read completely
+  bool prev_sp = false; // the last character read was U+2581
   bool right_unk = false;
   int n_out = 0, ret = 0;
   PairProbe p0, p1;
@@ -139,7 +142,7 @@ SPMX_DEVICE int bpe_stream_lane(const SpmxDev &d, const uint32_t *gt, int nlen, 
         if (merging || ret != 0) return;
         if (pos + 4 > 4 * nf && 4 * nf < nlen) return;                       // its bytes have not landed yet
         const uint32_t c0 = win[static_cast<uint32_t>(pos) & wmask];
-        if (n0 > 0 && c0 == spb) { merging = true; return; }                 // the next word begins here
+        if (n0 > 0 && c0 == spb && !prev_sp) { merging = true; return; }     // a U+2581 after another character: the next word
         if (n0 == kBpeWordMax) { ret = -2; return; }                          // too long for the LDS working set
         int mb = c0 == spb ? 1 : OneCharLenDev(c0);
         if (mb > nlen - pos) mb = nlen - pos;
@@ -158,6 +161,7 @@ SPMX_DEVICE int bpe_stream_lane(const SpmxDev &d, const uint32_t *gt, int nlen, 
         alive |= 1u << n0;
         ++n0;
         pos += mb;
+        prev_sp = c0 == spb;
         if (pos >= nlen) merging = true;
       };
       read_char(&p0);

@@ -131,14 +131,15 @@ SPMX_DEVICE StreamLds carve_stream(unsigned char *base, bool fast, int model, ui
 // (kNfCompressSp, or no whitespace escaping) and the model has no user-defined symbols; not for
 // whitespace-as-suffix models (the suffix would have to be patched into a dword that is already stored).  A byte
 // whose bcls entry says kBcComplex makes the lane give up (-1).
+// *n_sp: how many bytes of the result are the space symbol (sizes the id slot under byte fallback).
 SPMX_DEVICE int fast_norm_stream(const SpmxDev &d, const uint8_t *gtext, uint64_t beg, int L, uint32_t *gt,
-                                 const uint8_t *bcls) {
+                                 const uint8_t *bcls, int *n_sp) {
   const uint32_t F = d.flags;
   const bool rm = (F & kNfRemoveExtraWs) != 0;
   const uint32_t sp = (F & kNfCompressSp) ? kSpByte : 0x20u;
-  int w = 0;
+  int w = 0, nsp = 0;
   uint32_t acc = 0;
-  if (F & kNfAddDummyPrefix) { acc = sp; w = 1; }   // :128
+  if (F & kNfAddDummyPrefix) { acc = sp; w = 1; nsp = 1; }   // :128
   bool P = rm;                    // is_prev_space (:130)
   int wl = w;                     // output length up to the last non-space byte (:166-176 trailing spaces)
   bool seen = false;              // some prefix is not " " (:86-100)
@@ -160,6 +161,7 @@ SPMX_DEVICE int fast_norm_stream(const SpmxDev &d, const uint8_t *gtext, uint64_
         if (!is_sp || !P) {                     // :137-138 a space after a space is dropped
           acc |= (is_sp ? sp : c) << (8 * (w & 3));
           ++w;
+          nsp += is_sp ? 1 : 0;
           if ((w & 3) == 0) { gt[((w >> 2) - 1) * 64] = acc; acc = 0; }
         }
         P = is_sp && rm;                        // :154-162
@@ -174,8 +176,10 @@ SPMX_DEVICE int fast_norm_stream(const SpmxDev &d, const uint8_t *gtext, uint64_
   if (bad & kBcComplex) return -1;
   if (rm) {
     if (!seen) return 0;                        // :86-100 nothing but spaces
+    nsp -= w - wl;                              // the trimmed tail is nothing but space symbols
     w = wl;
   }
+  *n_sp = nsp;
   return w;
 }
 
@@ -190,7 +194,7 @@ constexpr int kRawWin = 64;
 constexpr uint32_t kLaneGeneralMaxRaw = 576;   // length classes whose sentences norm_lane_general takes
 
 SPMX_DEVICE int norm_lane_general(const SpmxDev &d, const uint8_t *gtext, uint64_t beg, int L, uint32_t *gt, int tcap,
-                                  uint8_t *rawwin) {
+                                  uint8_t *rawwin, int *n_sp) {
   const uint32_t F = d.flags;
   const bool rm = (F & kNfRemoveExtraWs) != 0;
   const bool one = (F & kNfCompressSp) != 0;
@@ -213,7 +217,7 @@ SPMX_DEVICE int norm_lane_general(const SpmxDev &d, const uint8_t *gtext, uint64
     }
     return rawwin[(beg + static_cast<uint64_t>(i)) & (kRawWin - 1)];
   };
-  int w = 0, wl = 0;
+  int w = 0, wl = 0, nsp = 0;
   uint32_t acc = 0;
   bool giveup = false;
   auto emit = [&](uint32_t b) __attribute__((always_inline)) {
@@ -222,6 +226,7 @@ SPMX_DEVICE int norm_lane_general(const SpmxDev &d, const uint8_t *gtext, uint64
     ++w;
     if ((w & 3) == 0) { gt[((w >> 2) - 1) * 64] = acc; acc = 0; }
     if (b != sp1) wl = w;                                  // :166-176 trailing space symbols are cut at the end
+    else ++nsp;
   };
   // NormalizePrefix at raw offset p (:195-253): kind 0 raw bytes [src, src + len), 1 rule string
   // nblob[src, src + len), 2 U+FFFD, 3 the space symbol (a literal U+2581 under kNfCompressSp)
@@ -320,7 +325,8 @@ SPMX_DEVICE int norm_lane_general(const SpmxDev &d, const uint8_t *gtext, uint64
   }
   if (giveup) return -1;
   gt[(w >> 2) * 64] = acc;                                 // the last, partial dword
-  if (rm) w = wl;
+  if (rm) { nsp -= w - wl; w = wl; }
+  *n_sp = nsp;
   return w;
 }
 
@@ -598,7 +604,7 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     const unsigned long long c0 = wv::clock();
     unsigned long long t_load = 0;
     bool mine = false;
-    int my_nlen = 0;
+    int my_nlen = 0, my_nsp = 0;     // normalized length; how many of its bytes are the space symbol
     if (wv::any(too_long)) {
       uint64_t m = wv::ballot(too_long);
       while (m) { const int i = wv::ffs64(m) - 1; m &= m - 1; fail_sentence(a, wv::shfl(my_sid, i), kStTooLong, lane); }
@@ -606,7 +612,7 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     if (FAST) {
       const bool go = lane < cnt && !too_long;
       int nlen = 0;
-      if (go && my_len > 0) nlen = fast_norm_stream(d, a.text, my_beg, static_cast<int>(my_len), gt, T.bcls);
+      if (go && my_len > 0) nlen = fast_norm_stream(d, a.text, my_beg, static_cast<int>(my_len), gt, T.bcls, &my_nsp);
       // Not plain ASCII.  A tile that is mostly such sentences (CJK text ...) normalizes them here, one per lane
       // (the raw window borrows the rings, idle until the search); a stray one in an ASCII tile would hold the
       // other 63 lanes up for its whole length, and long sentences are better off position-parallel: both go to
@@ -618,7 +624,7 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
                         (wv::popc64(wv::ballot(nlen < 0)) >= 16 && a.rcap <= kLaneGeneralMaxRaw && !a.no_lane_general);
       if (many && nlen < 0)
         nlen = norm_lane_general(d, a.text, my_beg, static_cast<int>(my_len), gt, static_cast<int>(tcap),
-                                 reinterpret_cast<uint8_t *>(T.ring_s) + static_cast<uint32_t>(lane) * (kRawWin + 16));
+                                 reinterpret_cast<uint8_t *>(T.ring_s) + static_cast<uint32_t>(lane) * (kRawWin + 16), &my_nsp);
       const bool hard = go && nlen < 0;
       if (go && nlen >= 0) { mine = true; my_nlen = nlen; }
       const uint64_t hm = wv::ballot(hard);
@@ -655,7 +661,13 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
         // norm[0, nlen) -> lane i's text column, a dword per lane per step
         uint32_t *col = gt - lane + i;
         for (int p4 = lane; p4 * 4 < nlen; p4 += 64) col[p4 * 64] = *reinterpret_cast<const uint32_t *>(T.norm + 4 * p4);
-        if (lane == i) { mine = true; my_nlen = nlen; }
+        int nsp = 0;
+        if ((d.flags & kNfByteFallback) && (d.flags & kNfCompressSp)) {          // sizes the id slot below
+          int cnt_sp = 0;
+          for (int p = lane; p < nlen; p += 64) cnt_sp += T.norm[p] == kSpByte ? 1 : 0;
+          wave_excl_scan(cnt_sp, lane, &nsp);
+        }
+        if (lane == i) { mine = true; my_nlen = nlen; my_nsp = nsp; }
         wv::sync();                             // norm is rewritten by the next sentence
       }
     }
@@ -664,7 +676,8 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     tc.cyc[0] += t_load; tc.cyc[1] += (c1 - c0) - t_load;
     // ---- a slot of cap ids per sentence in the arena ----
     int cap = 0;
-    if (mine) cap = ((d.flags & kNfByteFallback) && (d.flags & kNfCompressSp)) ? 3 * my_nlen : my_nlen;
+    // at most one id per normalized byte -- three for a space symbol that falls back to its bytes
+    if (mine) cap = ((d.flags & kNfByteFallback) && (d.flags & kNfCompressSp)) ? my_nlen + 2 * my_nsp : my_nlen;
     const int room = mine ? cap + n_extra : 0;
     int total = 0;
     const int excl = wave_excl_scan(room, lane, &total);

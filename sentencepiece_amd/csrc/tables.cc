@@ -230,7 +230,9 @@ Status CompileTables(const ModelData &m, HostTables *t) {
     for (const auto &kv : m.pieces_map) {
       const std::string t = dev_str(kv.first);
       tmap.emplace(t, kv.second);
-      if (t.find(static_cast<char>(kSpByte), 1) != std::string::npos) wordwise = false;
+      // a piece is either a run of space symbols (allow_whitespace_only_pieces) or has none after its first character
+      const bool all_sp = t.find_first_not_of(static_cast<char>(kSpByte)) == std::string::npos;
+      if (!all_sp && t.find(static_cast<char>(kSpByte), 1) != std::string::npos) wordwise = false;
     }
     if (wordwise) flags |= kNfBpeWordwise;
     // symbol universe: piece ids [0, V) for strings in pieces_, then extra

@@ -210,7 +210,7 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
   for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { classify_block<0>(ca, hist.data()); });
   for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { classify_block<1>(ca, hist.data()); });
   const uint64_t text_bytes = offs[n];
-  std::vector<int32_t> arena(4 * text_bytes + (8 + dev.n_prefix + dev.n_suffix) * n + 64);
+  std::vector<int32_t> arena(12 * text_bytes + (8 + dev.n_prefix + dev.n_suffix) * n + 64);
   unsigned long long arena_head = 0;
   uint32_t status = 0;
   unsigned long long stats[kStatsPerClass * kMaxClasses] = {0};

@@ -70,7 +70,7 @@ def test_oracle_decode_invalid_id(oracle):
 
 
 EMU_MODELS = ["test_model", "test_ja_model", "uni1k_bf", "bpe1k_bf_uds", "uni1k_ident", "uni1k_suffix", "bpe1k_noesc",
-              "c5_250k_bf"]
+              "c5_250k_bf", "bpe1k_llama"]
 
 
 @pytest.mark.parametrize("model", EMU_MODELS)

@@ -8,7 +8,7 @@ import pytest
 from tests import fixtures
 
 MODELS = ["test_model", "test_ja_model", "uni1k", "bpe1k", "uni1k_bf", "bpe1k_bf_uds", "uni1k_uds",
-          "uni1k_ident", "uni1k_suffix", "bpe1k_noesc", "uni32k", "bpe32k", "c5_250k", "c5_250k_bf"]
+          "uni1k_ident", "uni1k_suffix", "bpe1k_noesc", "uni32k", "bpe32k", "c5_250k", "c5_250k_bf", "bpe1k_llama"]
 
 
 @pytest.fixture(scope="module")
@@ -107,7 +107,7 @@ def test_emu_lane_general_normalizer(model, corpus, k, env, emu, oracle, corpora
         assert kept > 0.3 * (len(offs) - 1)
 
 
-@pytest.mark.parametrize("model", ["bpe1k", "bpe32k", "bpe1k_bf_uds", "bpe1k_noesc"])
+@pytest.mark.parametrize("model", ["bpe1k", "bpe32k", "bpe1k_bf_uds", "bpe1k_noesc", "bpe1k_llama"])
 @pytest.mark.parametrize("env", [{}, {"SPMX_NO_WORDWISE": "1"}, {"SPMX_NO_COMPRESS": "1"}, {"SPMX_NO_FAST": "1"},
                                  {"SPMX_NO_STREAM": "1"}])
 def test_emu_bpe_variants(model, env, emu, oracle, corpora, monkeypatch):
@@ -118,7 +118,8 @@ def test_emu_bpe_variants(model, env, emu, oracle, corpora, monkeypatch):
     blob = fixtures.model_blob(model)
     h = emu.load(blob)
     wordwise = bool(h.flags() & K_WORDWISE)
-    assert wordwise == (model in ("bpe1k", "bpe32k") and "SPMX_NO_WORDWISE" not in env and "SPMX_NO_COMPRESS" not in env)
+    assert wordwise == (model in ("bpe1k", "bpe32k", "bpe1k_llama") and "SPMX_NO_WORDWISE" not in env
+                        and "SPMX_NO_COMPRESS" not in env)
     o = oracle.load(blob)
     for name, k in (("edge", 10 ** 6), ("synth20k", 200), ("mixed2k", 40), ("botchan", 120)):
         text, offs = fixtures.head(*corpora[name], k)

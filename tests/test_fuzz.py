@@ -10,7 +10,7 @@ from sentencepiece_amd import synth
 from tests import fixtures, refshim
 
 MODELS = ["test_model", "test_ja_model", "uni1k_bf", "uni1k_uds", "uni1k_ident", "uni1k_suffix", "bpe1k", "bpe1k_bf_uds",
-          "bpe1k_noesc", "uni32k", "bpe32k", "c5_250k_bf"]
+          "bpe1k_noesc", "uni32k", "bpe32k", "c5_250k_bf", "bpe1k_llama"]
 
 
 def fuzz_corpus(n, seed, corpora):
