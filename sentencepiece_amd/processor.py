@@ -318,7 +318,7 @@ class SentencePieceProcessor:
         self._lib.spmx_set_profiling(self._h, 1 if enabled else 0)
 
     def LastProfile(self):
-        """Per kernel slot (length class; GENERAL tile kernels after a FAST one sit in the last slots):
+        """Per kernel slot (length class; GENERAL kernels after a FAST one sit in slots 8 + class):
         dict(kernel, kernel_ms, sentences, raw_bytes, ids, bytes, rcap, phase_cycles) + total_ms."""
         self._need()
         ms = np.zeros(16, dtype=np.float32)
