@@ -114,6 +114,16 @@ int spmx_decode_batch(spmx_handle *h, const int32_t *ids, const uint64_t *id_off
 /* Single sentence, caller-provided buffer (Decode(ids, &text)); RESOURCE_EXHAUSTED with the needed size in *len. */
 int spmx_decode(spmx_handle *h, const int32_t *ids, uint64_t n_ids, char *out, uint64_t cap, uint64_t *len);
 
+/* ---- corpus packer ------------------------------------------------------
+ * The caller-side step of the reference's spm_encode (src/spm_encode_main.cc:159-165: std::getline over the input
+ * file, one Encode per line) on the device: a file image with '\n'-terminated lines -> the packed text (without
+ * the terminators; '\r' is kept, as getline keeps it) + n_lines + 1 offsets that the encode calls take.  A last line
+ * without '\n' counts; "a\n" is one line.  d_file must be 16-byte aligned device memory.  Too small a capacity ->
+ * RESOURCE_EXHAUSTED (8) with the needed sizes in *n_lines (+ 1 offsets) and *text_bytes. */
+int spmx_split_lines_device(spmx_handle *h, const void *d_file, uint64_t bytes, void *d_text, uint64_t text_capacity,
+                            uint64_t *d_offsets, uint64_t offsets_capacity, void *stream, uint64_t *n_lines,
+                            uint64_t *text_bytes);
+
 /* ---- measurement --------------------------------------------------------
  * Per-kernel timing of the encode kernels of the LAST
  * spmx_encode_batch_device call, measured with hipEvents on the caller's

@@ -102,7 +102,7 @@ struct spmx_handle {
   SpmxDev dev{};   // scalars + device pointers
   // workspace
   DevBuf<uint32_t> d_lists, d_counts;
-  DevBuf<uint64_t> d_tmp_off, d_tile_sums;
+  DevBuf<uint64_t> d_tmp_off, d_tile_sums, d_chunk_base;
   DevBuf<int32_t> d_arena;
   Ctrl *d_ctrl = nullptr;
   Ctrl *h_ctrl = nullptr;   // pinned
@@ -204,7 +204,7 @@ void DestroyHandle(spmx_handle *h) {
   h->d_ndarts.Free(); h->d_npair.Free(); h->d_sym_final.Free(); h->d_nblob.Free(); h->d_ptrie.Free(); h->d_chartab.Free();
   h->d_pairtab.Free(); h->d_utrie.Free(); h->d_sym_len.Free(); h->d_byte_ids.Free();
   h->d_dec_info.Free(); h->d_dec_off.Free(); h->d_dec_bytes.Free();
-  h->d_stream.Free(); h->d_lists.Free(); h->d_counts.Free(); h->d_tmp_off.Free(); h->d_tile_sums.Free(); h->d_arena.Free();
+  h->d_stream.Free(); h->d_lists.Free(); h->d_counts.Free(); h->d_tmp_off.Free(); h->d_tile_sums.Free(); h->d_chunk_base.Free(); h->d_arena.Free();
   h->d_text.Free(); h->d_offs.Free(); h->d_id_offs.Free(); h->d_ids.Free();
   if (h->d_ctrl) (void)hipFree(h->d_ctrl);
   if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);
@@ -763,6 +763,53 @@ int spmx_decode(spmx_handle *h, const int32_t *ids, uint64_t n_ids, char *out, u
   free(t);
   free(to);
   return ret;
+}
+
+int spmx_split_lines_device(spmx_handle *h, const void *d_file, uint64_t bytes, void *d_text, uint64_t text_capacity,
+                            uint64_t *d_offsets, uint64_t offsets_capacity, void *stream_v, uint64_t *n_lines,
+                            uint64_t *text_bytes) {
+  if (!h) return kInvalidArgument;
+  std::lock_guard<std::mutex> l(h->mu);
+  if (n_lines) *n_lines = 0;
+  if (text_bytes) *text_bytes = 0;
+  if (!n_lines || !text_bytes) return Fail(h, kInternal, "output container is null");
+  if (bytes && (!d_file || (reinterpret_cast<uintptr_t>(d_file) & 15u))) return Fail(h, kInvalidArgument, "d_file must be 16-byte aligned");
+  HIP_OR_RETURN(h, hipSetDevice(h->device));
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
+  if (bytes == 0) {
+    if (d_offsets && offsets_capacity) HIP_OR_RETURN(h, hipMemsetAsync(d_offsets, 0, sizeof(uint64_t), stream));
+    HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+    return kOk;
+  }
+  const uint64_t chunks = (bytes + kSplitChunk - 1) / kSplitChunk;
+  if (chunks >= (1ull << 32) - 64) return Fail(h, kInvalidArgument, "file image too large for one call");
+  HIP_OR_RETURN(h, h->d_counts.Reserve(chunks + 1));
+  HIP_OR_RETURN(h, h->d_chunk_base.Reserve(chunks + 1));
+  HIP_OR_RETURN(h, h->d_tile_sums.Reserve((chunks + kScanTile - 1) / kScanTile + 2));
+  SplitArgs a{};
+  a.file = static_cast<const uint8_t *>(d_file); a.bytes = bytes; a.counts = h->d_counts.p;
+  a.chunk_base = h->d_chunk_base.p; a.text = static_cast<uint8_t *>(d_text); a.offsets = d_offsets;
+  const uint64_t wide = static_cast<uint64_t>(h->n_cu) * 16;
+  const int grid = static_cast<int>(chunks < wide ? chunks : wide);
+  HIP_OR_RETURN(h, LaunchSplit(false, a, grid, stream));
+  {
+    ScanArgs sa{h->d_counts.p, static_cast<uint32_t>(chunks), h->d_tile_sums.p, h->d_chunk_base.p};
+    const uint32_t tiles = (static_cast<uint32_t>(chunks) + kScanTile - 1) / kScanTile;
+    HIP_OR_RETURN(h, LaunchScan(sa, static_cast<int>(tiles < static_cast<uint32_t>(h->n_cu * 8) ? tiles : h->n_cu * 8), stream));
+  }
+  uint8_t last = 0;
+  HIP_OR_RETURN(h, hipMemcpyAsync(&h->h_ctrl->total_ids, h->d_chunk_base.p + chunks, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+  HIP_OR_RETURN(h, hipMemcpyAsync(&last, static_cast<const uint8_t *>(d_file) + bytes - 1, 1, hipMemcpyDeviceToHost, stream));
+  HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+  const uint64_t nl = h->h_ctrl->total_ids;
+  const uint64_t lines = nl + (last != 0x0A ? 1 : 0);      // std::getline: a last line without '\n' counts
+  *n_lines = lines;
+  *text_bytes = bytes - nl;
+  if (!d_text || !d_offsets || text_capacity < bytes - nl || offsets_capacity < lines + 1)
+    return Fail(h, kResourceExhausted, "text_capacity / offsets_capacity is too small");
+  HIP_OR_RETURN(h, LaunchSplit(true, a, grid, stream));
+  HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+  return kOk;
 }
 
 int spmx_set_profiling(spmx_handle *h, int enabled) {

@@ -734,5 +734,6 @@ SPMX_DEVICE void compact_block(const CompactArgs &a) {
 #include "kernels_bpe_stream.h"
 #include "kernels_stream.h"
 #include "kernels_decode.h"
+#include "kernels_split.h"
 
 #endif

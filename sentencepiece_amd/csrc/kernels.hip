@@ -31,6 +31,11 @@ __global__ __launch_bounds__(FAST ? 1024 : 512) void EncodeBpeStreamKernel(Encod
   encode_stream_block<FAST, 2>(a, smem);
 }
 
+__global__ __launch_bounds__(64) void SplitCountKernel(SplitArgs a) { split_block<false>(a, nullptr); }
+__global__ __launch_bounds__(64) void SplitWriteKernel(SplitArgs a) {
+  __shared__ __attribute__((aligned(16))) uint8_t stage[kSplitLdsBytes];
+  split_block<true>(a, stage);
+}
 __global__ __launch_bounds__(64) void DecodeCountKernel(DecodeArgs a) { decode_block<false>(a); }
 __global__ __launch_bounds__(64) void DecodeWriteKernel(DecodeArgs a) { decode_block<true>(a); }
 __global__ __launch_bounds__(64) void ClassifyCountKernel(ClassifyArgs a) {
@@ -118,6 +123,12 @@ hipError_t LaunchEncodeStream(int model_type, int cls, bool fast, const EncodeAr
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * waves), lds_bytes, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t LaunchSplit(bool write, const SplitArgs &a, int grid, hipStream_t stream) {
+  if (write) hipLaunchKernelGGL(SplitWriteKernel, dim3(grid), dim3(64), 0, stream, a);
+  else hipLaunchKernelGGL(SplitCountKernel, dim3(grid), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
 

@@ -312,6 +312,28 @@ class SentencePieceProcessor:
         self._check(rc)
         return d_text, d_text_offsets, total.value
 
+    # ---------------------------------------------------- corpus packer ----
+    def SplitLinesDevice(self, d_file, stream=None):
+        """A file image on the GPU (torch uint8 tensor, '\\n'-terminated lines, std::getline semantics) ->
+        ``(d_text uint8, d_offsets int64[n + 1], n_lines)``: the packed form ``EncodeDevice`` takes."""
+        import torch
+        self._need()
+        nbytes = d_file.numel()
+        if stream is None:
+            stream = torch.cuda.current_stream(d_file.device).cuda_stream
+        n, tb = C.c_uint64(0), C.c_uint64(0)
+        d_text = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=d_file.device)
+        d_offs = torch.empty(nbytes // 24 + 1024, dtype=torch.int64, device=d_file.device)
+        for _ in range(2):
+            rc = self._lib.spmx_split_lines_device(self._h, d_file.data_ptr(), nbytes, d_text.data_ptr(), d_text.numel(),
+                                                   d_offs.data_ptr(), d_offs.numel(), stream, C.byref(n), C.byref(tb))
+            if rc == _RESOURCE_EXHAUSTED:
+                d_offs = torch.empty(n.value + 1, dtype=torch.int64, device=d_file.device)
+                continue
+            break
+        self._check(rc)
+        return d_text[:tb.value], d_offs[:n.value + 1], n.value
+
     # ------------------------------------------------------ measurement ----
     def SetProfiling(self, enabled):
         self._need()

@@ -320,6 +320,28 @@ int64_t emu_decode_batch(void *hv, const int32_t *ids, const uint64_t *id_offs, 
   return static_cast<int64_t>(total);
 }
 
+// The corpus packer as csrc/api.cc runs it: count pass -> scan -> write pass.  `file` must be 16-byte aligned and
+// readable to the next multiple of 16.  Returns the number of lines; *text_bytes = bytes of packed text.
+int64_t emu_split_lines(const uint8_t *file, uint64_t bytes, uint8_t *text, uint64_t *offsets, int grid, uint64_t *text_bytes) {
+  if (grid < 1) grid = 1;
+  if (bytes == 0) { offsets[0] = 0; *text_bytes = 0; return 0; }
+  const uint64_t chunks = (bytes + kSplitChunk - 1) / kSplitChunk;
+  std::vector<uint32_t> counts(chunks + 1, 0);
+  std::vector<uint64_t> base(chunks + 1, 0), tile_sums((chunks + kScanTile - 1) / kScanTile + 2, 0);
+  SplitArgs a{};
+  a.file = file; a.bytes = bytes; a.counts = counts.data(); a.chunk_base = base.data(); a.text = text; a.offsets = offsets;
+  for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { split_block<false>(a, nullptr); });
+  ScanArgs sa{counts.data(), static_cast<uint32_t>(chunks), tile_sums.data(), base.data()};
+  for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { scan_tiles_block(sa); });
+  emu::RunWave(0, 1, nullptr, [&] { scan_sums_block(sa); });
+  for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { scan_final_block(sa); });
+  const uint64_t nl = base[chunks];
+  alignas(16) static unsigned char stage[kSplitLdsBytes];
+  for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, stage, [&] { split_block<true>(a, stage); });
+  *text_bytes = bytes - nl;
+  return static_cast<int64_t>(nl + (file[bytes - 1] != 0x0A ? 1 : 0));
+}
+
 uint64_t emu_collectives() { return emu::g_wave.n_collectives; }
 uint32_t emu_flags(void *hv) { return static_cast<EmuHandle *>(hv)->tables.scalars.flags; }
 // sentences the FAST tile kernel kept / handed to the GENERAL kernel in the last emu_encode_batch

@@ -28,11 +28,29 @@ class EmuLib:
         lib.emu_decode_batch.restype = C.c_int64
         lib.emu_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                          C.c_void_p, C.c_int, C.c_void_p]
+        lib.emu_split_lines.restype = C.c_int64
+        lib.emu_split_lines.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         lib.emu_flags.restype = C.c_uint32
         lib.emu_flags.argtypes = [C.c_void_p]
         lib.emu_fast_kept.restype = C.c_uint64
         lib.emu_fast_handed.restype = C.c_uint64
         lib.emu_wave_handed.restype = C.c_uint64
+
+    def split_lines(self, data, grid=3):
+        """bytes -> (packed text bytes, offsets uint64[n + 1]) through the device splitter."""
+        n = len(data)
+        raw = np.zeros(n + 64, dtype=np.uint8)
+        shift = (-raw.ctypes.data) & 15
+        buf = raw[shift:shift + n + 16]
+        buf[:n] = np.frombuffer(data, dtype=np.uint8)
+        buf[n:] = 0x0A            # padding must not count
+        text = np.full(n + 32, 0xCD, dtype=np.uint8)
+        offs = np.full(data.count(b"\n") + 3, 0xCDCDCDCD, dtype=np.uint64)
+        tb = C.c_uint64(0)
+        lines = self.lib.emu_split_lines(buf.ctypes.data, n, text.ctypes.data, offs.ctypes.data, grid, C.byref(tb))
+        assert (text[tb.value:] == 0xCD).all(), "write past the packed text"
+        assert (offs[lines + 1:] == 0xCDCDCDCD).all(), "write past the offsets"
+        return text[:tb.value].tobytes(), offs[:lines + 1].copy()
 
     def load(self, model_bytes):
         err = C.create_string_buffer(512)
