@@ -114,6 +114,20 @@ int spmx_decode_batch(spmx_handle *h, const int32_t *ids, const uint64_t *id_off
 /* Single sentence, caller-provided buffer (Decode(ids, &text)); RESOURCE_EXHAUSTED with the needed size in *len. */
 int spmx_decode(spmx_handle *h, const int32_t *ids, uint64_t n_ids, char *out, uint64_t cap, uint64_t *len);
 
+/* ---- spans form ---------------------------------------------------------
+ * The ids plus, for every id, the byte range [begin, end) of its sentence that it covers: pieces(i).begin() /
+ * .end() of the SentencePieceText that Encode(absl::string_view, SentencePieceText *) fills
+ * (src/sentencepiece_processor.cc:639-653, PopulateSentencePieceText :547-636, bos / eos spans :1029-1048).
+ * Offsets are relative to the start of the sentence, in bytes (the C++ convention; the Python wrapper converts to
+ * characters, sentencepiece.i ConvertToUnicodeSpans).  surface = input[begin, end); the piece of a known id is
+ * IdToPiece(id).  Sentences are limited to 8192 bytes here (OUT_OF_RANGE beyond).
+ * d_begin / d_end: ids_capacity entries each; begin / end of the host form are released with spmx_free(). */
+int spmx_encode_batch_spans_device(spmx_handle *h, const void *d_text, uint64_t text_bytes, const uint64_t *d_offsets,
+                                   uint64_t n, int32_t *d_ids, uint64_t ids_capacity, uint64_t *d_id_offsets,
+                                   uint32_t *d_begin, uint32_t *d_end, void *stream, uint64_t *total_ids);
+int spmx_encode_batch_spans(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
+                            uint64_t **id_offsets, uint32_t **begin, uint32_t **end);
+
 /* ---- corpus packer ------------------------------------------------------
  * The caller-side step of the reference's spm_encode (src/spm_encode_main.cc:159-165: std::getline over the input
  * file, one Encode per line) on the device: a file image with '\n'-terminated lines -> the packed text (without

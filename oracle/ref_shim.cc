@@ -16,6 +16,7 @@
 #include <thread>
 #include <vector>
 
+#include "builtin_pb/sentencepiece.pb.h"
 #include "sentencepiece_processor.h"
 
 namespace {
@@ -203,6 +204,31 @@ int64_t spmref_decode_batch(void *handle, const int32_t *ids, const uint64_t *id
   if (all.size() > cap) return -static_cast<int64_t>(all.size()) - 2;
   memcpy(text, all.data(), all.size());
   return static_cast<int64_t>(all.size());
+}
+
+// Encode(input, SentencePieceText *) per sentence (sentencepiece_processor.h:303-304): ids and
+// pieces(i).begin() / .end().  Returns total pieces, -1 on a Status error, -(needed) - 2 if cap is too small.
+int64_t spmref_encode_spans_batch(void *handle, const char *text, const uint64_t *offsets, uint64_t n, int32_t *ids,
+                                  uint32_t *begin, uint32_t *end, uint64_t cap, uint64_t *id_offsets) {
+  auto *h = static_cast<RefHandle *>(handle);
+  uint64_t total = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    id_offsets[i] = total;
+    sentencepiece::SentencePieceText spt;
+    const auto st = h->sp.Encode(absl::string_view(text + offsets[i], offsets[i + 1] - offsets[i]), &spt);
+    if (!st.ok()) { h->last_error = st.ToString(); return -1; }
+    for (int k = 0; k < spt.pieces_size(); ++k) {
+      if (total < cap) {
+        ids[total] = static_cast<int32_t>(spt.pieces(k).id());
+        begin[total] = spt.pieces(k).begin();
+        end[total] = spt.pieces(k).end();
+      }
+      ++total;
+    }
+  }
+  id_offsets[n] = total;
+  if (total > cap) return -static_cast<int64_t>(total) - 2;
+  return static_cast<int64_t>(total);
 }
 
 int spmref_piece_size(void *handle) {

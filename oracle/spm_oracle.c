@@ -255,22 +255,35 @@ static void buf_push(Buf *b, const void *src, size_t n) {
   memcpy(b->p + b->n, src, n); b->n += n;
 }
 
-/* Normalizer::Normalize (normalizer.cc:71-186), without the alignment vector. */
-static void normalize(const Oracle *o, const uint8_t *in, size_t n, Buf *out) {
+/* norm_to_orig (normalizer.cc:73): one uint32 per normalized byte + the closing entry */
+typedef struct { uint32_t *p; size_t n, cap; } Align;
+static void align_push(Align *a, uint32_t v, size_t times) {
+  if (!a) return;
+  for (size_t i = 0; i < times; ++i) {
+    if (a->n == a->cap) { a->cap = a->cap ? a->cap * 2 : 256; a->p = realloc(a->p, sizeof(uint32_t) * a->cap); }
+    a->p[a->n++] = v;
+  }
+}
+
+/* Normalizer::Normalize (normalizer.cc:71-186); n2o (optional) receives the alignment vector. */
+static void normalize_aligned(const Oracle *o, const uint8_t *in, size_t n, Buf *out, Align *n2o) {
   static const uint8_t kSpaceSymbol[] = {0xE2, 0x96, 0x81};
   out->n = 0;
+  if (n2o) n2o->n = 0;
   if (n == 0) return;
   sv sp;
+  uint32_t consumed = 0;                                                                /* :83 */
   if (o->remove_extra_ws) {
     while (n > 0) {
       size_t c = normalize_prefix(o, in, n, &sp);
       if (!(sp.n == 1 && sp.p[0] == ' ')) break;
-      in += c; n -= c;
+      in += c; n -= c; consumed += (uint32_t)c;                                         /* :92-93 */
     }
   }
   if (n == 0) return;
   if (!o->ws_suffix && o->add_dummy_prefix) {
-    if (o->escape_ws) buf_push(out, kSpaceSymbol, 3); else buf_push(out, " ", 1);
+    if (o->escape_ws) { buf_push(out, kSpaceSymbol, 3); align_push(n2o, consumed, 3); }  /* :109-120 */
+    else { buf_push(out, " ", 1); align_push(n2o, consumed, 1); }
   }
   int is_prev_space = o->remove_extra_ws;
   while (n > 0) {
@@ -278,22 +291,29 @@ static void normalize(const Oracle *o, const uint8_t *in, size_t n, Buf *out) {
     while (is_prev_space && sp.n > 0 && sp.p[0] == ' ') { sp.p++; sp.n--; }
     if (sp.n > 0) {
       for (size_t k = 0; k < sp.n; ++k) {
-        if (o->escape_ws && sp.p[k] == ' ') buf_push(out, kSpaceSymbol, 3); else buf_push(out, sp.p + k, 1);
+        if (o->escape_ws && sp.p[k] == ' ') { buf_push(out, kSpaceSymbol, 3); align_push(n2o, consumed, 3); }   /* :143-148 */
+        else { buf_push(out, sp.p + k, 1); align_push(n2o, consumed, 1); }                                         /* :150-151 */
       }
       is_prev_space = sp.p[sp.n - 1] == ' ';
     }
-    in += c; n -= c;
+    in += c; n -= c; consumed += (uint32_t)c;                                           /* :158 */
     if (!o->remove_extra_ws) is_prev_space = 0;
   }
   if (o->remove_extra_ws) {
     const uint8_t *space = o->escape_ws ? kSpaceSymbol : (const uint8_t *)" ";
     size_t sl = o->escape_ws ? 3 : 1;
-    while (out->n >= sl && memcmp(out->p + out->n - sl, space, sl) == 0) out->n -= sl;
+    while (out->n >= sl && memcmp(out->p + out->n - sl, space, sl) == 0) {
+      out->n -= sl;
+      if (n2o) { consumed = n2o->p[out->n]; n2o->n = out->n; }                          /* :172-174 */
+    }
   }
   if (o->ws_suffix && o->add_dummy_prefix) {
-    if (o->escape_ws) buf_push(out, kSpaceSymbol, 3); else buf_push(out, " ", 1);
+    if (o->escape_ws) { buf_push(out, kSpaceSymbol, 3); align_push(n2o, consumed, 3); }
+    else { buf_push(out, " ", 1); align_push(n2o, consumed, 1); }
   }
+  align_push(n2o, consumed, 1);                                                         /* :181 */
 }
+static void normalize(const Oracle *o, const uint8_t *in, size_t n, Buf *out) { normalize_aligned(o, in, n, out, NULL); }
 
 /* --------------------------------------------------------------- results */
 typedef struct { int begin, len, id; } Tok;   /* piece = normalized[begin, begin+len) */
@@ -501,6 +521,63 @@ static int populate_ids(const Oracle *o, const uint8_t *norm, int norm_size, con
         break;
       case OPT_EOS: { sv e = o->eos_piece; e.n = strnlen((const char *)e.p, e.n); ids_push(out, piece_to_id(o, e)); break; }
       case OPT_BOS: { sv b = o->bos_piece; b.n = strnlen((const char *)b.p, b.n); ids_insert_front(out, piece_to_id(o, b)); break; }
+    }
+  }
+  return 0;
+}
+
+/* PopulateSentencePieceText with the spans (sentencepiece_processor.cc:547-636): pieces(i).id / begin / end.
+ * input_size = bytes of the raw sentence (the bos / eos spans, :1029-1048). */
+typedef struct { int32_t id; uint32_t begin, end; } Span;
+typedef struct { Span *p; size_t n, cap; } Spans;
+static void spans_push(Spans *v, int32_t id, uint32_t b, uint32_t e) {
+  if (v->n == v->cap) { v->cap = v->cap ? v->cap * 2 : 64; v->p = realloc(v->p, sizeof(Span) * v->cap); }
+  v->p[v->n].id = id; v->p[v->n].begin = b; v->p[v->n].end = e; v->n++;
+}
+static int populate_spans(const Oracle *o, const uint8_t *norm, int norm_size, const Align *n2o, uint32_t input_size,
+                          const Toks *res, Spans *out) {
+  size_t consumed = 0; int is_prev_unk = 0;
+  out->n = 0;
+  for (size_t k = 0; k < res->n; ++k) {
+    const Tok *t = &res->p[k];
+    if (t->len == 0) return -1;                             /* :557 */
+    const int id = t->id;
+    const int type = (id >= 0 && id < o->n_pieces) ? o->pieces[id].type : 0;
+    const int is_unk = type == T_UNKNOWN;
+    if (type == T_CONTROL) {                                /* :561-567 begin == end */
+      if (consumed >= n2o->n) return -1;
+      spans_push(out, id, n2o->p[consumed], n2o->p[consumed]);
+    } else {
+      const size_t begin = consumed, end = consumed + (size_t)t->len;
+      if (begin >= n2o->n || end >= n2o->n) return -1;      /* :570-571 */
+      const uint32_t ob = n2o->p[begin], oe = n2o->p[end];
+      if (ob > input_size || oe > input_size || ob > oe) return -1;   /* :574-576 */
+      if (is_unk && o->byte_fallback) {                     /* :581-603: the last byte piece holds the surface */
+        for (int i = 0; i < t->len; ++i)
+          spans_push(out, o->byte_ids[norm[t->begin + i]], ob, i == t->len - 1 ? oe : ob);
+      } else if (is_prev_unk && is_unk) {                   /* :609-613 */
+        out->p[out->n - 1].end = oe;
+      } else {
+        spans_push(out, id, ob, oe);
+      }
+      consumed = end;
+    }
+    is_prev_unk = is_unk;
+  }
+  if (consumed != (size_t)norm_size) return -1;             /* :628 */
+  for (int k = 0; k < o->n_opts; ++k) {                     /* ApplyExtraOptions (:1019-1064) */
+    switch (o->opts[k]) {
+      case OPT_REVERSE:
+        for (size_t i = 0, j = out->n ? out->n - 1 : 0; i < j; ++i, --j) { Span t = out->p[i]; out->p[i] = out->p[j]; out->p[j] = t; }
+        break;
+      case OPT_EOS: { sv e = o->eos_piece; e.n = strnlen((const char *)e.p, e.n); spans_push(out, piece_to_id(o, e), input_size, input_size); break; }
+      case OPT_BOS: {
+        sv b = o->bos_piece; b.n = strnlen((const char *)b.p, b.n);
+        spans_push(out, 0, 0, 0);
+        memmove(out->p + 1, out->p, sizeof(Span) * (out->n - 1));
+        out->p[0].id = piece_to_id(o, b); out->p[0].begin = 0; out->p[0].end = 0;
+        break;
+      }
     }
   }
   return 0;
@@ -729,6 +806,29 @@ int64_t oracle_encode_batch(const Oracle *o, const char *text, const uint64_t *o
   return (int64_t)total;
 }
 
+/* Encode(input, SentencePieceText*) per sentence: ids + pieces(i).begin / .end (bytes, relative to the sentence). */
+int64_t oracle_encode_spans_batch(const Oracle *o, const char *text, const uint64_t *offsets, uint64_t n,
+                                  int32_t *out, uint32_t *begin, uint32_t *end, uint64_t cap, uint64_t *id_offsets) {
+  Buf norm = {0}; Toks toks = {0}; Spans sp = {0}; Align n2o = {0};
+  uint64_t total = 0; int failed = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    id_offsets[i] = total;
+    const uint8_t *in = (const uint8_t *)text + offsets[i];
+    const size_t len = (size_t)(offsets[i + 1] - offsets[i]);
+    normalize_aligned(o, in, len, &norm, &n2o);
+    if (o->model_type == M_UNIGRAM) unigram_encode(o, norm.p, (int)norm.n, &toks);
+    else bpe_encode(o, norm.p, (int)norm.n, &toks);
+    if (populate_spans(o, norm.p, (int)norm.n, &n2o, (uint32_t)len, &toks, &sp)) { failed = 1; break; }
+    if (total + sp.n <= cap)
+      for (size_t k = 0; k < sp.n; ++k) { out[total + k] = sp.p[k].id; begin[total + k] = sp.p[k].begin; end[total + k] = sp.p[k].end; }
+    total += sp.n;
+  }
+  id_offsets[n] = total;
+  free(norm.p); free(toks.p); free(sp.p); free(n2o.p);
+  if (failed) return -1;
+  if (total > cap) return -(int64_t)total - 2;
+  return (int64_t)total;
+}
 
 /* ------------------------------------------------------------------ decode */
 /* SentencePieceProcessor::Decode(const std::vector<int>& ids, std::string*)

@@ -32,6 +32,11 @@ int64_t oracle_encode(const Oracle *o, const char *in, uint64_t n, int32_t *out,
 int64_t oracle_encode_batch(const Oracle *o, const char *text, const uint64_t *offsets, uint64_t n,
                             int32_t *ids, uint64_t cap, uint64_t *id_offsets);
 
+/* Encode(input, SentencePieceText*) per sentence (sentencepiece_processor.cc:547-653): the ids and, for every id,
+ * pieces(i).begin() / .end() -- bytes of the sentence. Same returns as oracle_encode_batch. */
+int64_t oracle_encode_spans_batch(const Oracle *o, const char *text, const uint64_t *offsets, uint64_t n,
+                                  int32_t *out, uint32_t *begin, uint32_t *end, uint64_t cap, uint64_t *id_offsets);
+
 /* Per-sentence Decode(ids, std::string*) over CSR ids -> packed text + offsets (n + 1). Returns total bytes,
  * -11000 for an invalid id (OUT_OF_RANGE), -12000 if the model has a denormalizer, -(needed)-2 if cap too small. */
 int64_t oracle_decode_batch(const Oracle *o, const int32_t *ids, const uint64_t *id_offsets, uint64_t n,

@@ -39,6 +39,12 @@ SYMBOLS = [
     ("spmx_decode_batch", C.c_int,
      [_H, C.c_void_p, C.c_void_p, _U64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     ("spmx_decode", C.c_int, [_H, C.c_void_p, _U64, C.c_void_p, _U64, C.POINTER(_U64)]),
+    ("spmx_encode_batch_spans_device", C.c_int,
+     [_H, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+      C.POINTER(_U64)]),
+    ("spmx_encode_batch_spans", C.c_int,
+     [_H, C.c_void_p, C.c_void_p, _U64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+      C.POINTER(C.c_void_p)]),
     ("spmx_split_lines_device", C.c_int,
      [_H, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, C.POINTER(_U64), C.POINTER(_U64)]),
     ("spmx_set_profiling", C.c_int, [_H, C.c_int]),

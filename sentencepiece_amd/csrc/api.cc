@@ -103,6 +103,8 @@ struct spmx_handle {
   // workspace
   DevBuf<uint32_t> d_lists, d_counts;
   DevBuf<uint64_t> d_tmp_off, d_tile_sums, d_chunk_base;
+  DevBuf<int32_t> d_arena_tb, d_tok_begin;      // spans form
+  DevBuf<uint32_t> d_span_begin, d_span_end;
   DevBuf<int32_t> d_arena;
   Ctrl *d_ctrl = nullptr;
   Ctrl *h_ctrl = nullptr;   // pinned
@@ -204,7 +206,7 @@ void DestroyHandle(spmx_handle *h) {
   h->d_ndarts.Free(); h->d_npair.Free(); h->d_sym_final.Free(); h->d_nblob.Free(); h->d_ptrie.Free(); h->d_chartab.Free();
   h->d_pairtab.Free(); h->d_utrie.Free(); h->d_sym_len.Free(); h->d_byte_ids.Free();
   h->d_dec_info.Free(); h->d_dec_off.Free(); h->d_dec_bytes.Free();
-  h->d_stream.Free(); h->d_lists.Free(); h->d_counts.Free(); h->d_tmp_off.Free(); h->d_tile_sums.Free(); h->d_chunk_base.Free(); h->d_arena.Free();
+  h->d_stream.Free(); h->d_lists.Free(); h->d_counts.Free(); h->d_tmp_off.Free(); h->d_tile_sums.Free(); h->d_chunk_base.Free(); h->d_arena_tb.Free(); h->d_tok_begin.Free(); h->d_span_begin.Free(); h->d_span_end.Free(); h->d_arena.Free();
   h->d_text.Free(); h->d_offs.Free(); h->d_id_offs.Free(); h->d_ids.Free();
   if (h->d_ctrl) (void)hipFree(h->d_ctrl);
   if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);
@@ -252,9 +254,11 @@ StreamPlan PlanStream(const spmx_handle *h, const LengthClass &lc, bool fast, ui
 }
 
 // The launch sequence.  Caller holds h->mu and has set the device.
+// d_begin / d_end (both or neither): the spans form (kernels_align.h).
 int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, const uint64_t *d_offsets, uint64_t n,
                  int32_t *d_ids, uint64_t ids_capacity, uint64_t *d_id_offsets, hipStream_t stream,
-                 uint64_t *total_ids) {
+                 uint64_t *total_ids, uint32_t *d_begin = nullptr, uint32_t *d_end = nullptr) {
+  const bool spans = d_begin != nullptr && d_end != nullptr;
   if (total_ids) *total_ids = 0;
   if (n >= (1ull << 32) - 64) return Fail(h, kInvalidArgument, "more than 2^32 - 64 sentences in one batch");
   if (!d_offsets || !d_id_offsets) return Fail(h, kInvalidArgument, "null offsets");
@@ -283,6 +287,7 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
   const bool prof = h->profiling;
   for (int attempt = 0; attempt < 3; ++attempt) {
     HIP_OR_RETURN(h, h->d_arena.Reserve(arena_need));
+    if (spans) HIP_OR_RETURN(h, h->d_arena_tb.Reserve(h->d_arena.cap));
     if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[kMaxSlots][0], stream));
     HIP_OR_RETURN(h, hipMemsetAsync(h->d_ctrl, 0, sizeof(Ctrl), stream));
     for (bool &u : h->slot_used) u = false;
@@ -316,6 +321,8 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
         if (!staged && known[c] > 0 && !fast)
           return Fail(h, kOutOfRange, "a sentence is longer than 8192 bytes: this model (user-defined symbols, whitespace-as-suffix "
                                       "or unescaped U+2581 rules) is limited to that on the device path");
+        if (!staged && known[c] > 0 && spans)
+          return Fail(h, kOutOfRange, "a sentence is longer than 8192 bytes: the spans form is limited to that");
         if (!staged && !fast) continue;
         for (int pass = fast ? 0 : 1; pass < (staged ? 2 : 1); ++pass) {
           StreamPlan sp = PlanStream(h, cls[c], pass == 0, known[c]);
@@ -340,6 +347,7 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
       a.stats = &h->d_ctrl->stats[kStatsPerClass * c];
       a.rcap = cls[c].rcap; a.ncap = cls[c].ncap;
       a.no_lane_general = h->no_lane_general ? 1u : 0u;
+      a.arena_tb = spans ? h->d_arena_tb.p : nullptr;
       if (streaming) {
         if (known[c] == 0 && !prev_general) continue;
         a.ring = ScoreRing(h->tables.max_piece_len);
@@ -450,6 +458,39 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
     if (h->h_ctrl->total_ids > ids_capacity || !d_ids) {
       if (h->h_ctrl->total_ids == 0) return kOk;
       return Fail(h, kResourceExhausted, "ids_capacity is too small");
+    }
+    if (spans && h->h_ctrl->total_ids > 0) {
+      // token begins to CSR order, then one align launch per length class over the encode's own lists
+      const uint64_t total = h->h_ctrl->total_ids;
+      HIP_OR_RETURN(h, h->d_tok_begin.Reserve(total));
+      CompactArgs pa{h->d_arena_tb.p, h->d_tmp_off.p, h->d_counts.p, d_id_offsets, h->d_tok_begin.p, total, n32};
+      const uint64_t cblocks = (n + 63) / 64;
+      const uint64_t cgrid = cblocks < static_cast<uint64_t>(h->n_cu) * 32 ? cblocks : static_cast<uint64_t>(h->n_cu) * 32;
+      HIP_OR_RETURN(h, LaunchCompact(pa, static_cast<int>(cgrid), stream));
+      HIP_OR_RETURN(h, hipMemsetAsync(&h->d_ctrl->status, 0, sizeof(uint32_t), stream));
+      for (int c = 0; c < ncls; ++c) {
+        const uint32_t cnt = h->h_ctrl->list_counts[c];
+        if (cnt == 0) continue;
+        if (cls[c].rcap > kMaxStagedRaw) return Fail(h, kOutOfRange, "a sentence is longer than 8192 bytes: the spans form is limited to that");
+        AlignArgs aa{};
+        aa.dev = h->dev; aa.text = d_text; aa.offs = d_offsets;
+        aa.list = h->d_lists.p + static_cast<size_t>(c) * n; aa.list_count = &h->d_ctrl->list_counts[c];
+        aa.id_offs = d_id_offsets; aa.tok_begin = h->d_tok_begin.p; aa.begin = d_begin; aa.end = d_end;
+        aa.status = &h->d_ctrl->status; aa.rcap = cls[c].rcap; aa.ncap = cls[c].ncap;
+        aa.has_next = (c + 1 < ncls && cls[c + 1].rcap <= kMaxStagedRaw) ? 1u : 0u;
+        const uint32_t lds = AlignLdsBytes(aa.rcap, aa.ncap);
+        int per_cu = static_cast<int>(kLdsPerCu / lds);
+        if (per_cu > 32) per_cu = 32;
+        if (per_cu < 1) per_cu = 1;
+        uint64_t grid = static_cast<uint64_t>(h->n_cu) * per_cu;
+        if (grid > cnt) grid = cnt;
+        HIP_OR_RETURN(h, LaunchAlign(aa, static_cast<int>(grid), lds, stream));
+      }
+      uint32_t st2 = 0;
+      HIP_OR_RETURN(h, hipMemcpyAsync(&st2, &h->d_ctrl->status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+      if (st2 & kStTooLong) return Fail(h, kOutOfRange, "a sentence is too long for the spans form");
+      if (st2) return Fail(h, kInternal, "token boundaries do not tile the normalized text");
     }
     return kOk;
   }
@@ -640,17 +681,25 @@ int spmx_encode_batch_device(spmx_handle *h, const void *d_text, uint64_t text_b
                       d_id_offsets, static_cast<hipStream_t>(stream), total_ids);
 }
 
-int spmx_encode_batch(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
-                      uint64_t **id_offsets) {
+namespace {
+// Host-buffer form of the batch encode, with (begin / end non-null) or without the spans.
+int EncodeBatchHost(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
+                    uint64_t **id_offsets, uint32_t **begin, uint32_t **end) {
   if (!h) return kInvalidArgument;
   std::lock_guard<std::mutex> l(h->mu);
-  if (!ids || !id_offsets) return Fail(h, kInternal, "output container is null");   // sentencepiece_processor.cc:367-370
+  const bool spans = begin != nullptr;
+  if (!ids || !id_offsets || (spans && !end)) return Fail(h, kInternal, "output container is null");   // sentencepiece_processor.cc:367-370
   *ids = nullptr; *id_offsets = nullptr;
+  if (spans) { *begin = nullptr; *end = nullptr; }
   if (n && !offsets) return Fail(h, kInvalidArgument, "null offsets");
   HIP_OR_RETURN(h, hipSetDevice(h->device));
   uint64_t *ho = static_cast<uint64_t *>(malloc((n + 1) * sizeof(uint64_t)));
   if (!ho) return Fail(h, kResourceExhausted, "out of host memory");
-  if (n == 0) { ho[0] = 0; *id_offsets = ho; *ids = static_cast<int32_t *>(malloc(sizeof(int32_t))); return kOk; }
+  if (n == 0) {
+    ho[0] = 0; *id_offsets = ho; *ids = static_cast<int32_t *>(malloc(sizeof(int32_t)));
+    if (spans) { *begin = static_cast<uint32_t *>(malloc(sizeof(uint32_t))); *end = static_cast<uint32_t *>(malloc(sizeof(uint32_t))); }
+    return kOk;
+  }
   const uint64_t base = offsets[0], text_bytes = offsets[n] - base;
   HIP_OR_RETURN(h, h->d_text.Reserve(text_bytes + 16));
   HIP_OR_RETURN(h, h->d_offs.Reserve(n + 1));
@@ -663,7 +712,13 @@ int spmx_encode_batch(spmx_handle *h, const char *text, const uint64_t *offsets,
   int rc = kOk;
   for (int attempt = 0; attempt < 2; ++attempt) {
     if (hipError_t e = h->d_ids.Reserve(cap); e != hipSuccess) { free(ho); return FailHip(h, e, "hipMalloc(ids)"); }
-    rc = EncodeDevice(h, d_text, text_bytes, h->d_offs.p, n, h->d_ids.p, h->d_ids.cap, h->d_id_offs.p, nullptr, &total);
+    if (spans) {
+      hipError_t e = h->d_span_begin.Reserve(h->d_ids.cap);
+      if (e == hipSuccess) e = h->d_span_end.Reserve(h->d_ids.cap);
+      if (e != hipSuccess) { free(ho); return FailHip(h, e, "hipMalloc(spans)"); }
+    }
+    rc = EncodeDevice(h, d_text, text_bytes, h->d_offs.p, n, h->d_ids.p, h->d_ids.cap, h->d_id_offs.p, nullptr, &total,
+                      spans ? h->d_span_begin.p : nullptr, spans ? h->d_span_end.p : nullptr);
     if (rc != kResourceExhausted || total <= h->d_ids.cap) break;
     cap = total;
   }
@@ -673,9 +728,42 @@ int spmx_encode_batch(spmx_handle *h, const char *text, const uint64_t *offsets,
   hipError_t e = hipMemcpy(ho, h->d_id_offs.p, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost);
   if (e == hipSuccess && total) e = hipMemcpy(hi, h->d_ids.p, total * sizeof(int32_t), hipMemcpyDeviceToHost);
   if (e != hipSuccess) { free(ho); free(hi); return FailHip(h, e, "hipMemcpy(ids)"); }
+  if (spans) {
+    uint32_t *hb = static_cast<uint32_t *>(malloc((total ? total : 1) * sizeof(uint32_t)));
+    uint32_t *he = static_cast<uint32_t *>(malloc((total ? total : 1) * sizeof(uint32_t)));
+    if (!hb || !he) { free(ho); free(hi); free(hb); free(he); return Fail(h, kResourceExhausted, "out of host memory"); }
+    if (total) e = hipMemcpy(hb, h->d_span_begin.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && total) e = hipMemcpy(he, h->d_span_end.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { free(ho); free(hi); free(hb); free(he); return FailHip(h, e, "hipMemcpy(spans)"); }
+    *begin = hb;
+    *end = he;
+  }
   *ids = hi;
   *id_offsets = ho;
   return kOk;
+}
+}  // namespace
+
+int spmx_encode_batch(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
+                      uint64_t **id_offsets) {
+  return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, nullptr, nullptr);
+}
+
+int spmx_encode_batch_spans(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
+                            uint64_t **id_offsets, uint32_t **begin, uint32_t **end) {
+  if (h && (!begin || !end)) return Fail(h, kInternal, "output container is null");
+  return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, begin, end);
+}
+
+int spmx_encode_batch_spans_device(spmx_handle *h, const void *d_text, uint64_t text_bytes, const uint64_t *d_offsets,
+                                   uint64_t n, int32_t *d_ids, uint64_t ids_capacity, uint64_t *d_id_offsets,
+                                   uint32_t *d_begin, uint32_t *d_end, void *stream, uint64_t *total_ids) {
+  if (!h) return kInvalidArgument;
+  std::lock_guard<std::mutex> l(h->mu);
+  if (d_ids && (!d_begin || !d_end)) return Fail(h, kInvalidArgument, "null span buffers");
+  HIP_OR_RETURN(h, hipSetDevice(h->device));
+  return EncodeDevice(h, static_cast<const uint8_t *>(d_text), text_bytes, d_offsets, n, d_ids, ids_capacity,
+                      d_id_offsets, static_cast<hipStream_t>(stream), total_ids, d_begin, d_end);
 }
 
 void spmx_free(void *p) { free(p); }

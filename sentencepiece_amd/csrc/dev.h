@@ -83,6 +83,8 @@ struct SpmxDev {
   const int32_t *byte_ids;   // [256]
   int32_t n_prefix, n_suffix;
   int32_t prefix_ids[kMaxExtra], suffix_ids[kMaxExtra];
+  uint32_t extra_eos;               // bit i: prefix_ids[i] is an eos (its span is the end of the input, a bos's is 0);
+                                    // bit kMaxExtra + i: the same for suffix_ids[i]
   // ---- decode (reference: src/sentencepiece_processor.cc:761-925; kernels_decode.h) ----
   const uint32_t *dec_info;  // per id: kind | flags | byte value
   const uint32_t *dec_off;   // per id + 1: offsets into dec_bytes

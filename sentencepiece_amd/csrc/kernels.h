@@ -55,6 +55,8 @@ struct EncodeArgs {
   uint32_t no_lane_general;     // A/B switch: FAST kernels hand every non-ASCII sentence to the GENERAL kernel
   uint32_t *wave_list;          // BPE streaming kernels: sentences they leave to the sentence-per-wave kernel
   uint32_t *wave_count;
+  int32_t *arena_tb;            // spans form (kernels_align.h), else null: next to every body id in `arena`, the
+                                // position in the normalized (device) text where its token begins
 };
 
 constexpr int kStatsPerClass = 8;
@@ -135,7 +137,10 @@ SPMX_DEVICE uint64_t resolve_chain(int base, int step, bool valid, int *next_sta
 // real prefix starts is resolved on wave-uniform bitmasks; (3) the whitespace
 // state machine (is_prev_space) becomes a "last writer" lookup on ballot masks;
 // (4) a prefix sum places every prefix's output.
-SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint8_t *norm, int ncap, int lane) {
+// `orig` (optional, LDS, ncap entries): norm_to_orig (:105-120, :142-152) -- for every normalized byte the raw offset
+// at which the prefix that produced it starts; *orig_end receives the closing entry (:181).
+SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint8_t *norm, int ncap, int lane,
+                               uint16_t *orig = nullptr, int *orig_end = nullptr) {
   const uint32_t F = d.flags;
   const bool rm = (F & kNfRemoveExtraWs) != 0;
   const bool one = (F & kNfCompressSp) != 0;             // U+2581 is the single byte kSpByte (dev.h)
@@ -150,6 +155,7 @@ SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint
   }
   bool P = rm;                       // is_prev_space (:130), wave-uniform between sweeps
   bool any_other = false;            // some prefix normalizes to something other than exactly " "
+  int first_other = -1;              // raw offset of the first such prefix: `consumed` after the leading loop (:85-94)
   int next_start = 0;
   const bool has_map = (F & kNfHasCharsmap) != 0, has_uds = (F & kNfHasUserDefined) != 0;
   const uint32_t droot = has_map ? DartsOffset(d.ndarts[0]) : 0u;
@@ -275,7 +281,11 @@ SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint
     }
     // (3) whitespace state machine (:131-163)
     const bool single_sp = len == 1 && lead == 1;                 // p.first == " "
-    any_other = any_other || wv::any(is_start && !single_sp);
+    {
+      const uint64_t om = wv::ballot(is_start && !single_sp);
+      if (om && first_other < 0) first_other = b + wv::ffs64(om) - 1;
+      any_other = any_other || om != 0;
+    }
     const bool clsA = is_start && len > 0 && lead == len;          // all spaces: leaves is_prev_space true
     const bool clsN = is_start && lead < len;                      // has a non-space byte
     bool Pl = false;
@@ -306,8 +316,10 @@ SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint
         if (one && ch == 0x20u) ch = kSpByte;
         if (esc && ch == 0x20u) {                                  // :143-148
           norm[w] = 0xE2; norm[w + 1] = 0x96; norm[w + 2] = 0x81;
+          if (orig) orig[w] = orig[w + 1] = orig[w + 2] = static_cast<uint16_t>(p);
           w += 3;
         } else {
+          if (orig) orig[w] = static_cast<uint16_t>(p);
           norm[w++] = static_cast<uint8_t>(ch);
         }
         ++k;
@@ -317,6 +329,12 @@ SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint
   }
   wv::sync();
   if (rm && !any_other) return 0;      // :86-100 every prefix was " ": empty result, no dummy prefix
+  int fin = L;                         // `consumed` when the closing entry is pushed (:181)
+  if (orig && (F & kNfAddDummyPrefix) && !(F & kNfWsSuffix)) {
+    // the dummy prefix maps to `consumed` after the leading-space loop (:85-94, :128)
+    if (lane < spw) orig[lane] = static_cast<uint16_t>(rm && first_other > 0 ? first_other : 0);
+    wv::sync();
+  }
   if (rm) {                            // :166-176 trailing space symbols
     for (;;) {
       if (out < spw) break;
@@ -324,14 +342,19 @@ SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint
                              : (norm[out - 1] == sp1);
       if (!is_sp) break;
       out -= spw;
+      if (orig) fin = orig[out];       // :172
     }
   }
   if ((F & kNfAddDummyPrefix) && (F & kNfWsSuffix)) {   // :179
     if (out + spw > ncap) return -1;
-    if (lane < spw) norm[out + lane] = static_cast<uint8_t>(esc ? (lane == 0 ? 0xE2u : (lane == 1 ? 0x96u : 0x81u)) : sp1);
+    if (lane < spw) {
+      norm[out + lane] = static_cast<uint8_t>(esc ? (lane == 0 ? 0xE2u : (lane == 1 ? 0x96u : 0x81u)) : sp1);
+      if (orig) orig[out + lane] = static_cast<uint16_t>(fin);
+    }
     out += spw;
     wv::sync();
   }
+  if (orig_end) *orig_end = fin;
   return out;
 }
 
@@ -379,6 +402,7 @@ SPMX_DEVICE int emit_wave(const EncodeArgs &a, uint32_t sid, const uint8_t *norm
     return n_out;
   }
   int32_t *dst = a.arena + off;
+  int32_t *dtb = a.arena_tb ? a.arena_tb + off : nullptr;
   if (lane < d.n_prefix) dst[lane] = d.prefix_ids[lane];
   if (lane < d.n_suffix) dst[d.n_prefix + total + lane] = d.suffix_ids[lane];
   int done = 0;
@@ -404,12 +428,14 @@ SPMX_DEVICE int emit_wave(const EncodeArgs &a, uint32_t sid, const uint8_t *norm
     done += t;
     if (cnt == 1 && !(bf && id == d.unk_id)) {
       dst[d.n_prefix + (reverse ? total - 1 - pos : pos)] = id;
+      if (dtb) dtb[d.n_prefix + (reverse ? total - 1 - pos : pos)] = e - len;
     } else if (cnt > 0) {          // byte fallback: one BYTE id per byte of the unknown piece
       const bool sp = norm[e - len] == spb;
       for (int k = 0; k < cnt; ++k) {
         const int j = pos + k;
         const uint32_t byte = sp ? (k == 0 ? 0xE2u : (k == 1 ? 0x96u : 0x81u)) : norm[e - len + k];
         dst[d.n_prefix + (reverse ? total - 1 - j : j)] = d.byte_ids[byte];
+        if (dtb) dtb[d.n_prefix + (reverse ? total - 1 - j : j)] = e - len;
       }
     }
   }
@@ -735,5 +761,6 @@ SPMX_DEVICE void compact_block(const CompactArgs &a) {
 #include "kernels_stream.h"
 #include "kernels_decode.h"
 #include "kernels_split.h"
+#include "kernels_align.h"
 
 #endif

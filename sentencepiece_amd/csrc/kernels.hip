@@ -31,6 +31,10 @@ __global__ __launch_bounds__(FAST ? 1024 : 512) void EncodeBpeStreamKernel(Encod
   encode_stream_block<FAST, 2>(a, smem);
 }
 
+__global__ __launch_bounds__(64) void AlignKernel(AlignArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  align_block(a, smem);
+}
 __global__ __launch_bounds__(64) void SplitCountKernel(SplitArgs a) { split_block<false>(a, nullptr); }
 __global__ __launch_bounds__(64) void SplitWriteKernel(SplitArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t stage[kSplitLdsBytes];
@@ -123,6 +127,16 @@ hipError_t LaunchEncodeStream(int model_type, int cls, bool fast, const EncodeAr
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * waves), lds_bytes, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t LaunchAlign(const AlignArgs &a, int grid, uint32_t lds_bytes, hipStream_t stream) {
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(AlignKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds_bytes));
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(AlignKernel, dim3(grid), dim3(64), lds_bytes, stream, a);
   return hipGetLastError();
 }
 

@@ -96,7 +96,7 @@ SPMX_DEVICE bool pair_resolve(const SpmxDev &d, PairProbe *p, uint32_t *merged, 
 // Text comes through a W-byte LDS window (position p at win[p & wmask]) refilled one dword per iteration from the
 // lane's text column; that load and the pair probes are issued at the END of an iteration and land at the top of
 // the next one, so an iteration waits for memory once.
-SPMX_DEVICE int bpe_stream_lane(const SpmxDev &d, const uint32_t *gt, int nlen, int32_t *slot, int cap,
+SPMX_DEVICE int bpe_stream_lane(const SpmxDev &d, const uint32_t *gt, int nlen, int32_t *slot, int32_t *tslot, int cap,
                                 const BpeWordLds &B, const uint32_t *asym, uint8_t *win, uint32_t wmask, int lane,
                                 bool active_in) {
   const bool bf = (d.flags & kNfByteFallback) != 0;
@@ -226,18 +226,21 @@ SPMX_DEVICE int bpe_stream_lane(const SpmxDev &d, const uint32_t *gt, int nlen, 
             for (int y = 0; y < nb; ++y) {
               const uint32_t byte = b == spb ? (y == 0 ? 0xE2u : (y == 1 ? 0x96u : 0x81u)) : b;
               slot[reverse ? cap - 1 - n_out : n_out] = d.byte_ids[byte];
+              if (tslot) tslot[reverse ? cap - 1 - n_out : n_out] = off;
               ++n_out;
             }
           }
         } else if (!right_unk) {                    // a run of unknown pieces yields one id (:609-613)
           if (n_out >= cap) { ret = -1; break; }
           slot[reverse ? cap - 1 - n_out : n_out] = d.unk_id;
+          if (tslot) tslot[reverse ? cap - 1 - n_out : n_out] = off;
           ++n_out;
         }
         right_unk = true;
       } else {
         if (n_out >= cap) { ret = -1; break; }
         slot[reverse ? cap - 1 - n_out : n_out] = static_cast<int32_t>(f);
+        if (tslot) tslot[reverse ? cap - 1 - n_out : n_out] = off;
         ++n_out;
         right_unk = false;
       }

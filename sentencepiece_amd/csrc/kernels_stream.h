@@ -500,8 +500,9 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const uint32_t *gt, uint32
 // follows the lane's row gb[] from position nlen to 0 and writes the ids as it goes, last piece first, into slot[0, cap):
 // forward order fills the slot from its END (ids end up in slot[cap - n, cap)), `reverse` fills it from the start.
 // Returns n, or -1 on a broken chain / overflow.
+// `tslot` (spans form, else null): the slot's twin in EncodeArgs::arena_tb, receives every token's begin.
 SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const uint32_t *gt, const uint32_t *gb, int nlen, int32_t *slot,
-                                 int cap, bool active) {
+                                 int32_t *tslot, int cap, bool active) {
   const bool bf = (d.flags & kNfByteFallback) != 0;
   const bool reverse = (d.flags & kNfReverse) != 0;
   const uint32_t spb = SpByteOf(d);
@@ -522,18 +523,23 @@ SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const uint32_t *gt, const uin
           for (int x = nb - 1; x >= 0; --x) {
             const uint32_t byte = sp ? (x == 0 ? 0xE2u : (x == 1 ? 0x96u : 0x81u)) : stream_text_byte(gt, tb + x);
             slot[reverse ? n : cap - 1 - n] = d.byte_ids[byte];
+            if (tslot) tslot[reverse ? n : cap - 1 - n] = tb;
             ++n;
           }
         } else if (!right_unk) {                    // a run of unknown pieces yields one id (:609-613)
           if (n >= cap) { ok = false; active = false; continue; }
           slot[reverse ? n : cap - 1 - n] = d.unk_id;
+          if (tslot) tslot[reverse ? n : cap - 1 - n] = tb;
           ++n;
+        } else if (tslot) {                         // the run grows to the left: so does the merged token
+          tslot[reverse ? n - 1 : cap - n] = tb;
         }
         right_unk = true;
       } else {
         right_unk = false;
         if (n >= cap) { ok = false; active = false; continue; }
         slot[reverse ? n : cap - 1 - n] = static_cast<int32_t>(w & kBwIdMask);
+        if (tslot) tslot[reverse ? n : cap - 1 - n] = tb;
         ++n;
       }
       e = tb;
@@ -688,6 +694,7 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     const bool overflow = base + static_cast<unsigned long long>(total) > a.arena_cap;
     if (overflow && lane == 0) wv::atomic_or(a.status, kStArenaOverflow);
     int32_t *slot = a.arena + base + static_cast<unsigned long long>(excl) + d.n_prefix;
+    int32_t *tslot = a.arena_tb ? a.arena_tb + base + static_cast<unsigned long long>(excl) + d.n_prefix : nullptr;
     bool broken = false, handed = false;
     int n = 0;
     bool at_end = false;      // the ids sit at the end of the slot
@@ -698,12 +705,12 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
           unigram_stream_lane<RING, !FAST>(d, gt, gb, my_nlen, my_rs, my_rb, rm, my_win, W - 1u, my_st, T.roottab, mine));
       c2 = wv::clock();
       if (!overflow) {
-        n = emit_stream_lane(d, gt, gb, my_nlen, slot, cap, mine);
+        n = emit_stream_lane(d, gt, gb, my_nlen, slot, tslot, cap, mine);
         at_end = (d.flags & kNfReverse) == 0;
       }
     } else {
       // ---- word by word, ids written as the words complete: the slot is filled from its start (end when reversing) ----
-      n = bpe_stream_lane(d, gt, my_nlen, slot, cap, T.bw, T.asym, T.bwin + static_cast<uint32_t>(lane) * (kBpeWindow + 4u),
+      n = bpe_stream_lane(d, gt, my_nlen, slot, tslot, cap, T.bw, T.asym, T.bwin + static_cast<uint32_t>(lane) * (kBpeWindow + 4u),
                           kBpeWindow - 1u, lane, mine && !overflow);
       c2 = wv::clock();
       at_end = (d.flags & kNfReverse) != 0;

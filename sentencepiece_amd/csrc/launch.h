@@ -32,6 +32,7 @@ inline uint32_t ScoreRing(int max_piece_len) {
 hipError_t LaunchEncodeStream(int model_type, int cls, bool fast, const EncodeArgs &a, int grid, int waves,
                               uint32_t lds_bytes, hipStream_t stream);
 hipError_t LaunchEncode(int model_type, int cls, const EncodeArgs &a, int grid, uint32_t lds_bytes, hipStream_t stream);
+hipError_t LaunchAlign(const AlignArgs &a, int grid, uint32_t lds_bytes, hipStream_t stream);
 hipError_t LaunchSplit(bool write, const SplitArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchDecode(bool write, const DecodeArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchClassify(const ClassifyArgs &a, int grid, hipStream_t stream);

@@ -382,6 +382,7 @@ Status CompileExtraOptions(const ModelData &m, const std::string &opts, HostTabl
   // Simulate ApplyExtraOptions on a symbolic list: ids < 0 stand for the
   // sentence body; the net effect is always prefix + (body | reversed body) + suffix.
   std::vector<int> pre, suf;
+  std::vector<int> pre_eos, suf_eos;      // parallel: 1 for an eos
   bool reversed = false;
   size_t pos = 0;
   if (!opts.empty()) {
@@ -394,11 +395,15 @@ Status CompileExtraOptions(const ModelData &m, const std::string &opts, HostTabl
         const int id = m.PieceToId(std::string(name.c_str()));
         if (m.pieces[id].type == kUnknown_)
           return Status::Error(kInternal, "id for `" + name + "` is not defined.");
-        if (o == "bos") pre.insert(pre.begin(), id); else suf.push_back(id);
+        if (o == "bos") { pre.insert(pre.begin(), id); pre_eos.insert(pre_eos.begin(), 0); }
+        else { suf.push_back(id); suf_eos.push_back(1); }
       } else if (o == "reverse") {
         std::vector<int> np(suf.rbegin(), suf.rend()), ns(pre.rbegin(), pre.rend());
         pre.swap(np);
         suf.swap(ns);
+        std::vector<int> npe(suf_eos.rbegin(), suf_eos.rend()), nse(pre_eos.rbegin(), pre_eos.rend());
+        pre_eos.swap(npe);
+        suf_eos.swap(nse);
         reversed = !reversed;
       } else if (o == "unk" || o == "unk_piece") {
         // only rewrites piece strings; ids unchanged
@@ -416,6 +421,9 @@ Status CompileExtraOptions(const ModelData &m, const std::string &opts, HostTabl
   sc.n_suffix = static_cast<int32_t>(suf.size());
   for (size_t i = 0; i < pre.size(); ++i) sc.prefix_ids[i] = pre[i];
   for (size_t i = 0; i < suf.size(); ++i) sc.suffix_ids[i] = suf[i];
+  sc.extra_eos = 0;
+  for (size_t i = 0; i < pre.size(); ++i) sc.extra_eos |= static_cast<uint32_t>(pre_eos[i]) << i;
+  for (size_t i = 0; i < suf.size(); ++i) sc.extra_eos |= static_cast<uint32_t>(suf_eos[i]) << (kMaxExtra + i);
   sc.flags = (sc.flags & ~kNfReverse) | (reversed ? kNfReverse : 0);
   return Status::OK();
 }

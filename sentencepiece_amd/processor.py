@@ -248,6 +248,81 @@ class SentencePieceProcessor:
         self._check(rc)
         return d_ids, d_id_offsets, total.value
 
+    # ------------------------------------------------------- spans form ----
+    def EncodeSpansPacked(self, text, offsets):
+        """Packed host arrays -> ``(ids int32, begin uint32, end uint32, id_offsets uint64)``: next to every id the
+        byte range of its sentence it covers -- ``pieces[i].begin / .end`` of the ``SentencePieceText`` that
+        ``Encode(input, SentencePieceText*)`` fills (src/sentencepiece_processor.cc:547-653), in bytes as in C++
+        (the reference's Python wrapper converts to characters).  ``add_bos`` / ``add_eos`` / ``reverse`` are not
+        taken here, as in the reference's proto API (sentencepiece.i:166-186); ``SetEncodeExtraOptions`` applies."""
+        self._need()
+        self._apply(False, False, False)
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offs) - 1
+        p_ids, p_off, p_b, p_e = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        tp = text.ctypes.data if len(text) else None
+        self._check(self._lib.spmx_encode_batch_spans(self._h, tp, offs.ctypes.data, n, C.byref(p_ids), C.byref(p_off),
+                                                      C.byref(p_b), C.byref(p_e)))
+        try:
+            io = np.ctypeslib.as_array(C.cast(p_off, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+            total = int(io[n])
+
+            def take(p, ct, dt):
+                return np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(total,)).copy() if total else np.zeros(0, dtype=dt)
+            ids = take(p_ids, C.c_int32, np.int32)
+            b = take(p_b, C.c_uint32, np.uint32)
+            e = take(p_e, C.c_uint32, np.uint32)
+        finally:
+            for p in (p_ids, p_off, p_b, p_e):
+                self._lib.spmx_free(p)
+        return ids, b, e, io
+
+    def EncodeSpansDevice(self, d_text, d_offsets, stream=None):
+        """Device-resident spans form: ``(d_ids int32, d_id_offsets int64[n + 1], d_begin int32, d_end int32, total)``
+        (the span tensors hold uint32 values; torch has no uint32 arithmetic, so they are typed int32)."""
+        import torch
+        self._need()
+        self._apply(False, False, False)
+        n = d_offsets.numel() - 1
+        dev = d_text.device
+        d_id_offsets = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        cap = d_text.numel() // 2 + 4 * n + 64
+        if stream is None:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        total = C.c_uint64(0)
+        for _ in range(2):
+            d_ids = torch.empty(cap, dtype=torch.int32, device=dev)
+            d_b = torch.empty(cap, dtype=torch.int32, device=dev)
+            d_e = torch.empty(cap, dtype=torch.int32, device=dev)
+            rc = self._lib.spmx_encode_batch_spans_device(
+                self._h, d_text.data_ptr(), d_text.numel(), d_offsets.data_ptr(), n, d_ids.data_ptr(), cap,
+                d_id_offsets.data_ptr(), d_b.data_ptr(), d_e.data_ptr(), stream, C.byref(total))
+            if rc == _RESOURCE_EXHAUSTED and total.value > cap:
+                cap = total.value
+                continue
+            break
+        self._check(rc)
+        return d_ids, d_id_offsets, d_b, d_e, total.value
+
+    def EncodeWithOffsets(self, input):
+        """str | list[str] -> list of ``(id, piece, surface, begin, end)`` per sentence: the fields of
+        ``SentencePieceText.pieces`` (byte offsets).  ``piece`` is ``IdToPiece(id)`` -- for an unknown token the
+        reference stores the normalized text there instead (sentencepiece_processor.cc:614-617); use ``surface``."""
+        single = isinstance(input, (str, bytes))
+        items = [input] if single else list(input)
+        raw = [x.encode("utf-8") if isinstance(x, str) else bytes(x) for x in items]
+        offs = np.zeros(len(raw) + 1, dtype=np.uint64)
+        if raw:
+            np.cumsum([len(x) for x in raw], out=offs[1:])
+        ids, b, e, io = self.EncodeSpansPacked(np.frombuffer(b"".join(raw), dtype=np.uint8), offs)
+        out = []
+        for i, r in enumerate(raw):
+            lo, hi = int(io[i]), int(io[i + 1])
+            out.append([(int(ids[k]), self.IdToPiece(int(ids[k])), r[int(b[k]):int(e[k])], int(b[k]), int(e[k]))
+                        for k in range(lo, hi)])
+        return out[0] if single else out
+
     # ----------------------------------------------------------- decode ----
     def Decode(self, input, out_type=str, num_threads=None):
         """list[int] -> str; list[list[int]] -> list[str] (``Decode`` / ``_DecodeIdsBatch``,

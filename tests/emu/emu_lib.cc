@@ -190,9 +190,12 @@ int emu_reset_vocabulary(void *hv) {
 // Runs classify -> encode (every class) -> scan -> compact with `grid` waves
 // per launch.  Returns total ids, or -(needed) - 2 if cap is too small; the
 // device status word is returned in *status.
+static uint32_t *g_span_begin = nullptr, *g_span_end = nullptr;   // set by emu_encode_spans_batch around its call
+
 int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, uint64_t n, int32_t *ids, uint64_t cap,
                          uint64_t *id_offs, int grid, uint32_t *status_out) {
   auto *h = static_cast<EmuHandle *>(hv);
+  const bool spans = g_span_begin != nullptr;
   const SpmxDev &dev = h->tables.scalars;
   const bool bpe = dev.model_type == 2;
   const LengthClass *cls = bpe ? kBpeCls : kUniCls;
@@ -211,6 +214,7 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
   for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { classify_block<1>(ca, hist.data()); });
   const uint64_t text_bytes = offs[n];
   std::vector<int32_t> arena(12 * text_bytes + (8 + dev.n_prefix + dev.n_suffix) * n + 64);
+  std::vector<int32_t> arena_tb(spans ? arena.size() : 0, -7);
   unsigned long long arena_head = 0;
   uint32_t status = 0;
   unsigned long long stats[kStatsPerClass * kMaxClasses] = {0};
@@ -225,6 +229,7 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
     a.tmp_off = tmp_off.data(); a.counts = counts.data(); a.status = &status; a.stats = &stats[kStatsPerClass * c];
     a.rcap = cls[c].rcap; a.ncap = cls[c].ncap;
     a.no_lane_general = getenv("SPMX_NO_LANE_GENERAL") ? 1u : 0u;
+    a.arena_tb = spans ? arena_tb.data() : nullptr;
     a.ring = 16;
     while (a.ring < static_cast<uint32_t>(h->tables.max_piece_len) + 1) a.ring <<= 1;
     // streaming form, as in csrc/api.cc: the FAST kernel first (when the model allows it), then the GENERAL
@@ -290,7 +295,35 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
   if (status_out) *status_out = status;
   const uint64_t total = id_offs[n];
   if (total > cap) return -static_cast<int64_t>(total) - 2;
+  if (spans && status == 0 && total > 0) {   // as csrc/api.cc: token begins to CSR order, then the align kernel per class
+    std::vector<int32_t> tokb(total, -9);
+    CompactArgs pb{arena_tb.data(), tmp_off.data(), counts.data(), id_offs, tokb.data(), total, static_cast<uint32_t>(n)};
+    for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { compact_block(pb); });
+    for (int c = 0; c < ncls; ++c) {
+      if (list_counts[c] == 0) continue;
+      if (cls[c].rcap > kEmuMaxStagedRaw) { status |= kStTooLong; break; }
+      AlignArgs aa{};
+      aa.dev = dev; aa.text = text; aa.offs = offs;
+      aa.list = lists.data() + static_cast<size_t>(c) * n; aa.list_count = &list_counts[c];
+      aa.id_offs = id_offs; aa.tok_begin = tokb.data(); aa.begin = g_span_begin; aa.end = g_span_end;
+      aa.status = &status; aa.rcap = cls[c].rcap; aa.ncap = cls[c].ncap;
+      aa.has_next = (c + 1 < ncls && cls[c + 1].rcap <= kEmuMaxStagedRaw) ? 1u : 0u;
+      std::vector<unsigned char> smem(AlignLdsBytes(aa.rcap, aa.ncap) + 64, 0xCD);
+      for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, smem.data(), [&] { align_block(aa, smem.data()); });
+    }
+    if (status_out) *status_out = status;
+    if (status) return -1;
+  }
   return static_cast<int64_t>(total);
+}
+
+// The spans form (kernels_align.h): begin / end hold cap entries.
+int64_t emu_encode_spans_batch(void *hv, const uint8_t *text, const uint64_t *offs, uint64_t n, int32_t *ids, uint32_t *begin,
+                               uint32_t *end, uint64_t cap, uint64_t *id_offs, int grid, uint32_t *status_out) {
+  g_span_begin = begin; g_span_end = end;
+  const int64_t r = emu_encode_batch(hv, text, offs, n, ids, cap, id_offs, grid, status_out);
+  g_span_begin = g_span_end = nullptr;
+  return r;
 }
 
 // Batch Decode as csrc/api.cc runs it: count pass -> scan -> write pass.  Returns total bytes, -(needed) - 2 if cap

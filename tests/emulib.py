@@ -28,6 +28,9 @@ class EmuLib:
         lib.emu_decode_batch.restype = C.c_int64
         lib.emu_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                          C.c_void_p, C.c_int, C.c_void_p]
+        lib.emu_encode_spans_batch.restype = C.c_int64
+        lib.emu_encode_spans_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
         lib.emu_split_lines.restype = C.c_int64
         lib.emu_split_lines.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         lib.emu_flags.restype = C.c_uint32
@@ -108,6 +111,29 @@ class EmuHandle:
         if tot < 0:
             raise RuntimeError("emu_encode_batch failed: %d status %d" % (tot, st.value))
         return ids[:tot].copy(), id_offs
+
+
+def _emu_encode_spans(self, text, offs, grid=3):
+    """-> (ids, begin, end, id_offsets) through the device kernels (encode in spans form + align)."""
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    n = len(offs) - 1
+    cap = int(len(text)) * 3 + 8 * n + 64
+    ids = np.empty(cap, dtype=np.int32)
+    begin = np.full(cap, 0xCDCDCDCD, dtype=np.uint32)
+    end = np.full(cap, 0xCDCDCDCD, dtype=np.uint32)
+    id_offs = np.zeros(n + 1, dtype=np.uint64)
+    st = C.c_uint32(0)
+    tot = self.lib.emu_encode_spans_batch(self.h, text.ctypes.data if len(text) else None, offs.ctypes.data, n,
+                                          ids.ctypes.data, begin.ctypes.data, end.ctypes.data, cap, id_offs.ctypes.data,
+                                          grid, C.byref(st))
+    self.status = st.value
+    if tot < 0:
+        raise RuntimeError("emu_encode_spans_batch failed: %d status %d" % (tot, st.value))
+    return ids[:tot].copy(), begin[:tot].copy(), end[:tot].copy(), id_offs
+
+
+EmuHandle.encode_spans = _emu_encode_spans
 
 
 def _emu_decode_batch(self, ids, id_offsets, grid=3):

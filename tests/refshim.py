@@ -139,3 +139,26 @@ def _ref_decode_batch(self, ids, id_offsets):
 
 
 RefHandle.decode_batch = _ref_decode_batch
+
+
+def _ref_encode_spans(self, text, offs):
+    """Encode(input, SentencePieceText*) per sentence -> (ids, begin, end, id_offsets)."""
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    n = len(offs) - 1
+    cap = int(len(text)) * 3 + 8 * n + 64
+    ids = np.empty(cap, dtype=np.int32)
+    begin = np.empty(cap, dtype=np.uint32)
+    end = np.empty(cap, dtype=np.uint32)
+    id_offs = np.zeros(n + 1, dtype=np.uint64)
+    fn = self.lib.spmref_encode_spans_batch
+    fn.restype = C.c_int64
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    tot = fn(self.h, text.ctypes.data if len(text) else None, offs.ctypes.data, n, ids.ctypes.data, begin.ctypes.data,
+             end.ctypes.data, cap, id_offs.ctypes.data)
+    if tot < 0:
+        raise RuntimeError("spmref_encode_spans_batch failed: %d" % tot)
+    return ids[:tot].copy(), begin[:tot].copy(), end[:tot].copy(), id_offs
+
+
+RefHandle.encode_spans = _ref_encode_spans

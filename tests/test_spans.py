@@ -1,0 +1,147 @@
+"""The spans form: ids plus pieces(i).begin() / .end() of the SentencePieceText that
+Encode(input, SentencePieceText*) fills (src/sentencepiece_processor.cc:547-653).
+
+  oracle (C restatement)   vs  the compiled reference          -- pins the oracle
+  device kernels (emulator) vs oracle                          -- CPU
+  device kernels (GPU, through the C ABI) vs oracle            -- -m gpu
+"""
+import numpy as np
+import pytest
+
+from tests import fixtures
+
+MODELS = ["test_model", "test_ja_model", "uni1k", "bpe1k", "uni1k_bf", "bpe1k_bf_uds", "uni1k_uds",
+          "uni1k_ident", "uni1k_suffix", "bpe1k_noesc", "bpe1k_llama"]
+BIG = ["uni32k", "bpe32k", "c5_250k", "c5_250k_bf"]
+OPTIONS = ["", "bos:eos", "reverse", "eos:reverse:bos", "reverse:bos:eos"]
+
+
+def extra_cases():
+    """Whitespace shapes that move norm_to_orig: leading / trailing / doubled spaces, NFKC expansions and
+    compositions, characters that normalize to nothing, malformed bytes, unknown runs."""
+    s = ["", " ", "   ", "a", " a", "a ", "  a  b   c  ", "　a　　b　", "▁a ▁", "a▁▁b",
+         "ＡＢＣ ①②", "ﬁx ﬃ", "a­b", "­", " ­ ", "é é",
+         "ẛ̣", "㌀ ㌁", "ﷺ", "x​y", "\xe2\x96", "\xff\xfe a", "a\xf0\x9f\x98", "\U0001f600\U0001f601 zz \U0001f602",
+         "一丁丂", "hello 一二 world", "  \t\n x", "a\tb", "a\r\n", "\r", "1 2  3   4    5"]
+    out = []
+    for x in s:
+        out.append(x.encode("utf-8", "surrogateescape") if isinstance(x, str) else x)
+    out += [b"\xe2\x96", b"\xff\xfe a", b"a\xf0\x9f\x98", b"\xc0\xaf", b"\xed\xa0\x80x", b" \xe3\x80", b"\x80\x80 \x80"]
+    return out
+
+
+def packed(lines):
+    offs = np.zeros(len(lines) + 1, dtype=np.uint64)
+    if lines:
+        offs[1:] = np.cumsum([len(x) for x in lines])
+    return np.frombuffer(b"".join(lines), dtype=np.uint8), offs
+
+
+def inputs(corpora, big=False):
+    yield "extra", packed(extra_cases())
+    for name, k in (("edge", 10 ** 6), ("botchan", 60 if big else 150), ("mixed2k", 12 if big else 40), ("ja", 6 if big else 15)):
+        yield name, fixtures.head(*corpora[name], k)
+
+
+def same(a, b, what):
+    for x, y, nm in zip(a, b, ("ids", "begin", "end", "id_offsets")):
+        np.testing.assert_array_equal(np.asarray(x).astype(np.int64), np.asarray(y).astype(np.int64), err_msg="%s: %s" % (what, nm))
+
+
+@pytest.fixture(scope="module")
+def ref():
+    from tests import refshim
+    if not refshim.available():
+        pytest.skip("oracle/_ref/libspm_ref.so not built")
+    return refshim.RefLib()
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from tests import emulib
+    return emulib.EmuLib()
+
+
+@pytest.mark.parametrize("model", MODELS + BIG)
+def test_oracle_spans_match_reference(model, oracle, ref, corpora):
+    blob = fixtures.model_blob(model)
+    o, r = oracle.load(blob), ref.load(blob)
+    for opts in OPTIONS if model in ("test_model", "bpe1k", "uni1k_bf") else ["", "eos:reverse:bos"]:
+        o.set_encode_extra_options(opts)
+        r.set_encode_extra_options(opts)
+        for name, (text, offs) in inputs(corpora, big=model in BIG):
+            same(o.encode_spans(text, offs), r.encode_spans(text, offs), "%s %s [%s]" % (model, name, opts))
+            ids, _, _, io = o.encode_spans(text, offs)
+            pids, pio = o.encode_batch(text, offs)
+            np.testing.assert_array_equal(ids, pids)
+            np.testing.assert_array_equal(io, pio)
+
+
+@pytest.mark.parametrize("model", MODELS + BIG)
+def test_emu_spans(model, emu, oracle, corpora):
+    blob = fixtures.model_blob(model)
+    h, o = emu.load(blob), oracle.load(blob)
+    for opts in OPTIONS if model in ("test_model", "bpe1k", "uni1k_bf") else ["", "eos:reverse:bos"]:
+        h.set_encode_extra_options(opts)
+        o.set_encode_extra_options(opts)
+        for name, (text, offs) in inputs(corpora, big=model in BIG):
+            got = h.encode_spans(text, offs, grid=2)
+            assert h.status == 0
+            same(got, o.encode_spans(text, offs), "%s %s [%s]" % (model, name, opts))
+
+
+@pytest.mark.parametrize("model", ["test_model", "uni1k_uds", "bpe1k_bf_uds", "c5_250k_bf"])
+def test_emu_spans_long(model, emu, oracle, corpora):
+    """Sentences of the long length classes (escalation between classes included)."""
+    from sentencepiece_amd import synth
+    blob = fixtures.model_blob(model)
+    h, o = emu.load(blob), oracle.load(blob)
+    t, of = corpora["mixed2k"]
+    n = len(of) - 1
+    pick = np.concatenate([np.arange(n - 3, n), np.arange(n - 300, n - 3, 100)])
+    text, offs = synth.gather_packed(t, of, pick)
+    got = h.encode_spans(text, offs, grid=2)
+    assert h.status == 0
+    same(got, o.encode_spans(text, offs), model)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", MODELS + BIG)
+def test_gpu_spans(model, oracle, corpora):
+    from sentencepiece_amd.processor import SentencePieceProcessor
+    blob = fixtures.model_blob(model)
+    sp, o = SentencePieceProcessor(model_proto=blob), oracle.load(blob)
+    for opts in OPTIONS if model in ("test_model", "bpe1k", "uni1k_bf") else ["", "eos:reverse:bos"]:
+        sp.SetEncodeExtraOptions(opts)
+        o.set_encode_extra_options(opts)
+        yielded = list(inputs(corpora))
+        for name, k in (("botchan", 10 ** 6), ("synth20k", 20000), ("mixed2k", 2000)):
+            yielded.append((name + "_full", fixtures.head(*corpora[name], k)))
+        for name, (text, offs) in yielded:
+            if model in BIG and name == "mixed2k_full" and opts:
+                continue
+            got = sp.EncodeSpansPacked(text, offs)
+            same(got, o.encode_spans(text, offs), "%s %s [%s]" % (model, name, opts))
+
+
+@pytest.mark.gpu
+def test_gpu_spans_device_form_and_limits(oracle, corpora):
+    import torch
+    from sentencepiece_amd.processor import SentencePieceProcessor
+    blob = fixtures.model_blob("uni32k")
+    sp, o = SentencePieceProcessor(model_proto=blob), oracle.load(blob)
+    text, offs = fixtures.head(*corpora["synth20k"], 5000)
+    d_text = torch.from_numpy(np.ascontiguousarray(text)).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    d_ids, d_io, d_b, d_e, total = sp.EncodeSpansDevice(d_text, d_offs)
+    want = o.encode_spans(text, offs)
+    same((d_ids[:total].cpu().numpy(), d_b[:total].cpu().numpy(), d_e[:total].cpu().numpy(), d_io.cpu().numpy()), want, "device form")
+    # the surface of every piece is the input slice (PopulateSentencePieceText :577-578); spot-check monotonicity
+    b, e = want[1].astype(np.int64), want[2].astype(np.int64)
+    assert (b <= e).all()
+    # a sentence beyond the staged classes: OUT_OF_RANGE, as documented in include/spmx.h
+    long_text = np.frombuffer(b"ab " * 4000, dtype=np.uint8)
+    with pytest.raises(Exception):
+        sp.EncodeSpansPacked(long_text, np.array([0, len(long_text)], dtype=np.uint64))
+    ids, io = sp.EncodePacked(long_text, np.array([0, len(long_text)], dtype=np.uint64))   # the ids form still takes it
+    assert len(ids) > 0
