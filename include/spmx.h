@@ -55,6 +55,10 @@ int spmx_piece_to_id(const spmx_handle *h, const char *piece, uint64_t len);/* P
 /* IdToPiece: copies up to cap bytes, returns the piece length (or -1). */
 int64_t spmx_id_to_piece(const spmx_handle *h, int id, char *out, uint64_t cap);
 int spmx_unk_id(const spmx_handle *h);
+/* SentencePiece::Type of a piece (src/sentencepiece_model.proto:296-303): 1 NORMAL, 2 UNKNOWN, 3 CONTROL,
+ * 4 USER_DEFINED, 5 UNUSED, 6 BYTE -- IsUnknown / IsControl / IsUnused / IsByte (sentencepiece_processor.h:660-672);
+ * -1 for an id out of range. */
+int spmx_piece_type(const spmx_handle *h, int id);
 int spmx_bos_id(const spmx_handle *h);
 int spmx_eos_id(const spmx_handle *h);
 int spmx_pad_id(const spmx_handle *h);
@@ -121,12 +125,29 @@ int spmx_decode(spmx_handle *h, const int32_t *ids, uint64_t n_ids, char *out, u
  * Offsets are relative to the start of the sentence, in bytes (the C++ convention; the Python wrapper converts to
  * characters, sentencepiece.i ConvertToUnicodeSpans).  surface = input[begin, end); the piece of a known id is
  * IdToPiece(id).  Sentences are limited to 8192 bytes here (OUT_OF_RANGE beyond).
- * d_begin / d_end: ids_capacity entries each; begin / end of the host form are released with spmx_free(). */
+ * nbegin / nend (optional, both or neither): the same tokens as byte ranges of the NORMALIZED sentence
+ * (spmx_normalize_batch): the piece of an unknown token is that text (:614-617); 0, 0 for a bos / eos.
+ * d_begin / d_end / d_nbegin / d_nend: ids_capacity entries each; the arrays of the host form are released with
+ * spmx_free(). */
 int spmx_encode_batch_spans_device(spmx_handle *h, const void *d_text, uint64_t text_bytes, const uint64_t *d_offsets,
                                    uint64_t n, int32_t *d_ids, uint64_t ids_capacity, uint64_t *d_id_offsets,
-                                   uint32_t *d_begin, uint32_t *d_end, void *stream, uint64_t *total_ids);
+                                   uint32_t *d_begin, uint32_t *d_end, uint32_t *d_nbegin, uint32_t *d_nend, void *stream,
+                                   uint64_t *total_ids);
 int spmx_encode_batch_spans(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
-                            uint64_t **id_offsets, uint32_t **begin, uint32_t **end);
+                            uint64_t **id_offsets, uint32_t **begin, uint32_t **end, uint32_t **nbegin, uint32_t **nend);
+
+/* ---- batch Normalize ----------------------------------------------------
+ * SentencePieceProcessor::Normalize(input, &normalized, &norm_to_orig) (src/sentencepiece_processor.cc:1102-1113 ->
+ * Normalizer::Normalize, src/normalizer.cc:71-186) per sentence: the packed normalized text + n + 1 offsets and,
+ * optionally, the alignment vectors: sentence s owns entries [norm_offsets[s] + s, norm_offsets[s + 1] + s + 1) of
+ * norm_to_orig -- one per normalized byte plus the closing one, which is 0xFFFFFFFF where the reference's vector
+ * is empty (empty or all-whitespace input).  Sentences are limited to 8192 bytes (OUT_OF_RANGE beyond).
+ * Device form: d_norm_to_orig (nullable) holds norm_capacity + n + 1 entries. */
+int spmx_normalize_batch_device(spmx_handle *h, const void *d_text, const uint64_t *d_offsets, uint64_t n, void *d_norm,
+                                uint64_t norm_capacity, uint64_t *d_norm_offsets, uint32_t *d_norm_to_orig, void *stream,
+                                uint64_t *total_bytes);
+int spmx_normalize_batch(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, char **norm,
+                         uint64_t **norm_offsets, uint32_t **norm_to_orig);
 
 /* ---- corpus packer ------------------------------------------------------
  * The caller-side step of the reference's spm_encode (src/spm_encode_main.cc:159-165: std::getline over the input

@@ -57,6 +57,19 @@ class Status {
 
 }  // namespace util
 
+// The fields of the reference's SentencePieceText message (src/sentencepiece.proto) that Encode(input, spt) fills,
+// as a plain struct: text, and per piece its string, id, surface and byte range of the input.
+struct SentencePieceText {
+  struct SentencePiece {
+    std::string piece;
+    uint32_t id = 0;
+    std::string surface;
+    uint32_t begin = 0, end = 0;
+  };
+  std::string text;
+  std::vector<SentencePiece> pieces;
+};
+
 class SentencePieceProcessor {
  public:
   explicit SentencePieceProcessor(int device = 0) : device_(device) {}
@@ -83,7 +96,18 @@ class SentencePieceProcessor {
   util::Status SetEncodeExtraOptions(std::string_view extra_option) {
     if (!h_) return status();
     const std::string o(extra_option);
-    return FromHandle(spmx_set_encode_extra_options(h_, o.c_str()));
+    const int rc = spmx_set_encode_extra_options(h_, o.c_str());
+    if (rc == 0) {
+      unk_piece_option_ = false;
+      for (size_t p = 0; p <= o.size();) {
+        const size_t q = o.find(':', p);
+        const std::string f = o.substr(p, q == std::string::npos ? std::string::npos : q - p);
+        if (f == "unk" || f == "unk_piece") unk_piece_option_ = true;
+        if (q == std::string::npos) break;
+        p = q + 1;
+      }
+    }
+    return FromHandle(rc);
   }
   util::Status SetVocabulary(const std::vector<std::string_view> &valid_vocab) {
     if (!h_) return status();
@@ -157,6 +181,83 @@ class SentencePieceProcessor {
                                                d_id_offsets, stream, total_ids));
   }
 
+  // ---- pieces / SentencePieceText (sentencepiece_processor.h:296-297, :303-304, :462-466) ----
+  // The device returns ids, input spans and normalized-text spans (spmx_encode_batch_spans) and the normalized text
+  // (spmx_normalize_batch); a piece is its normalized text, the piece name for a byte-fallback piece and a bos / eos,
+  // or unk_piece for an unknown token under the `unk_piece` extra option (sentencepiece_processor.cc:547-636, :1019-1064).
+  util::Status Encode(std::string_view input, SentencePieceText *spt) const {
+    if (!h_) return status();
+    if (!spt) return util::Status(util::StatusCode::kInternal, "output proto is null");   // CHECK_OR_RETURN_STATUS_PROTO
+    spt->text.clear();
+    spt->pieces.clear();
+    const uint64_t offs[2] = {0, input.size()};
+    int32_t *ids = nullptr;
+    uint64_t *io = nullptr, *no = nullptr;
+    uint32_t *b = nullptr, *e = nullptr, *nb = nullptr, *ne = nullptr;
+    char *norm = nullptr;
+    int rc = spmx_encode_batch_spans(h_, input.data() ? input.data() : "", offs, 1, &ids, &io, &b, &e, &nb, &ne);
+    if (rc == 0) rc = spmx_normalize_batch(h_, input.data() ? input.data() : "", offs, 1, &norm, &no, nullptr);
+    if (rc == 0) {
+      spt->text.assign(input.data(), input.size());
+      for (uint64_t k = 0; k < io[1]; ++k) {
+        SentencePieceText::SentencePiece p;
+        p.id = static_cast<uint32_t>(ids[k]);
+        p.begin = b[k];
+        p.end = e[k];
+        p.surface.assign(input.data() + b[k], e[k] - b[k]);
+        const int type = spmx_piece_type(h_, ids[k]);
+        if (type == 6 || type == 3 || (type == 2 && unk_piece_option_)) p.piece = IdToPiece(ids[k]);
+        else p.piece.assign(norm + nb[k], ne[k] - nb[k]);
+        spt->pieces.push_back(std::move(p));
+      }
+    }
+    spmx_free(ids); spmx_free(io); spmx_free(b); spmx_free(e); spmx_free(nb); spmx_free(ne); spmx_free(norm); spmx_free(no);
+    return FromHandle(rc);
+  }
+  util::Status Encode(std::string_view input, std::vector<std::string> *pieces) const {
+    if (!h_) return status();
+    if (!pieces) return util::Status(util::StatusCode::kInternal, "output container is null");
+    pieces->clear();
+    SentencePieceText spt;
+    const util::Status st = Encode(input, &spt);
+    if (!st.ok()) return st;
+    for (auto &p : spt.pieces) pieces->push_back(std::move(p.piece));
+    return util::Status();
+  }
+  std::vector<std::string> EncodeAsPieces(std::string_view input) const {   // errors are swallowed, as in the reference
+    std::vector<std::string> pieces;
+    (void)Encode(input, &pieces);
+    return pieces;
+  }
+
+  // ---- Normalize (sentencepiece_processor.h:326-336) ----
+  util::Status Normalize(std::string_view input, std::string *normalized, std::vector<size_t> *norm_to_orig) const {
+    if (!h_) return status();
+    if (!normalized || !norm_to_orig) return util::Status(util::StatusCode::kInternal, "output container is null");
+    normalized->clear();
+    norm_to_orig->clear();
+    const uint64_t offs[2] = {0, input.size()};
+    char *norm = nullptr;
+    uint64_t *no = nullptr;
+    uint32_t *a = nullptr;
+    const int rc = spmx_normalize_batch(h_, input.data() ? input.data() : "", offs, 1, &norm, &no, &a);
+    if (rc == 0) {
+      normalized->assign(norm, no[1]);
+      if (!(no[1] == 0 && a[0] == 0xFFFFFFFFu)) norm_to_orig->assign(a, a + no[1] + 1);
+    }
+    spmx_free(norm); spmx_free(no); spmx_free(a);
+    return FromHandle(rc);
+  }
+  util::Status Normalize(std::string_view input, std::string *normalized) const {
+    std::vector<size_t> a;
+    return Normalize(input, normalized, &a);
+  }
+  std::string Normalize(std::string_view input) const {
+    std::string out;
+    (void)Normalize(input, &out);
+    return out;
+  }
+
   // ---- decode (sentencepiece_processor.h:330-331, :480-482) ----
   util::Status Decode(const std::vector<int> &ids, std::string *detokenized) const {
     if (!h_) return status();
@@ -209,6 +310,10 @@ class SentencePieceProcessor {
     spmx_id_to_piece(h_, id, s.data(), s.size());
     return s;
   }
+  bool IsUnknown(int id) const { return h_ && spmx_piece_type(h_, id) == 2; }   // sentencepiece_processor.h:660-672
+  bool IsControl(int id) const { return h_ && spmx_piece_type(h_, id) == 3; }
+  bool IsUnused(int id) const { return h_ && spmx_piece_type(h_, id) == 5; }
+  bool IsByte(int id) const { return h_ && spmx_piece_type(h_, id) == 6; }
   int unk_id() const { return h_ ? spmx_unk_id(h_) : 0; }
   int bos_id() const { return h_ ? spmx_bos_id(h_) : 0; }
   int eos_id() const { return h_ ? spmx_eos_id(h_) : 0; }
@@ -231,6 +336,7 @@ class SentencePieceProcessor {
     return util::Status(static_cast<util::StatusCode>(rc), spmx_last_error(h_));
   }
   int device_ = 0;
+  bool unk_piece_option_ = false;   // the `unk` / `unk_piece` extra option: piece strings only (:1050-1058)
   spmx_handle *h_ = nullptr;
 };
 

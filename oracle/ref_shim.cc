@@ -231,6 +231,68 @@ int64_t spmref_encode_spans_batch(void *handle, const char *text, const uint64_t
   return static_cast<int64_t>(total);
 }
 
+// The same with pieces(i).piece(), packed (piece k at [piece_offsets[k], piece_offsets[k + 1]), cap + 1 entries).
+int64_t spmref_encode_pieces_batch(void *handle, const char *text, const uint64_t *offsets, uint64_t n, int32_t *ids,
+                                   uint32_t *begin, uint32_t *end, uint64_t cap, uint64_t *id_offsets, char *pieces,
+                                   uint64_t pieces_cap, uint64_t *piece_offsets) {
+  auto *h = static_cast<RefHandle *>(handle);
+  uint64_t total = 0, pbytes = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    id_offsets[i] = total;
+    sentencepiece::SentencePieceText spt;
+    const auto st = h->sp.Encode(absl::string_view(text + offsets[i], offsets[i + 1] - offsets[i]), &spt);
+    if (!st.ok()) { h->last_error = st.ToString(); return -1; }
+    for (int k = 0; k < spt.pieces_size(); ++k) {
+      const std::string &pc = spt.pieces(k).piece();
+      if (total < cap) {
+        ids[total] = static_cast<int32_t>(spt.pieces(k).id());
+        begin[total] = spt.pieces(k).begin();
+        end[total] = spt.pieces(k).end();
+        piece_offsets[total] = pbytes;
+        if (pbytes + pc.size() <= pieces_cap) memcpy(pieces + pbytes, pc.data(), pc.size());
+        // surface must be the input slice (:577-578)
+        if (spt.pieces(k).surface() != std::string(text + offsets[i] + spt.pieces(k).begin(), spt.pieces(k).end() - spt.pieces(k).begin())) {
+          h->last_error = "surface is not input[begin, end)";
+          return -1;
+        }
+      }
+      pbytes += pc.size();
+      ++total;
+    }
+  }
+  id_offsets[n] = total;
+  if (total > cap) return -static_cast<int64_t>(total) - 2;
+  piece_offsets[total] = pbytes;
+  if (pbytes > pieces_cap) return -static_cast<int64_t>(pbytes) - 3;
+  return static_cast<int64_t>(total);
+}
+
+// Normalize(input, &normalized, &norm_to_orig) per sentence (sentencepiece_processor.h:330-332); layout as
+// oracle_normalize_batch.
+int64_t spmref_normalize_batch(void *handle, const char *text, const uint64_t *offsets, uint64_t n, char *out,
+                               uint64_t cap, uint64_t *norm_offsets, uint32_t *n2o) {
+  auto *h = static_cast<RefHandle *>(handle);
+  uint64_t total = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    norm_offsets[i] = total;
+    std::string norm;
+    std::vector<size_t> a;
+    const auto st = h->sp.Normalize(absl::string_view(text + offsets[i], offsets[i + 1] - offsets[i]), &norm, &a);
+    if (!st.ok()) { h->last_error = st.ToString(); return -1; }
+    if (total + norm.size() <= cap) {
+      if (!norm.empty()) memcpy(out + total, norm.data(), norm.size());
+      if (n2o) {
+        if (a.empty()) n2o[total + i] = 0xFFFFFFFFu;
+        else for (size_t k = 0; k < a.size(); ++k) n2o[total + i + k] = static_cast<uint32_t>(a[k]);
+      }
+    }
+    total += norm.size();
+  }
+  norm_offsets[n] = total;
+  if (total > cap) return -static_cast<int64_t>(total) - 2;
+  return static_cast<int64_t>(total);
+}
+
 int spmref_piece_size(void *handle) {
   return static_cast<RefHandle *>(handle)->sp.GetPieceSize();
 }

@@ -66,6 +66,7 @@ struct Oracle {
   Trie ptrie; float min_score, max_score;
   int byte_ids[256];
   int opts[16]; int n_opts;
+  int opt_unk_piece;                 /* UNK_PIECE ("unk" / "unk_piece"): piece strings only */
 };
 
 /* ------------------------------------------------------------- tiny proto */
@@ -528,11 +529,13 @@ static int populate_ids(const Oracle *o, const uint8_t *norm, int norm_size, con
 
 /* PopulateSentencePieceText with the spans (sentencepiece_processor.cc:547-636): pieces(i).id / begin / end.
  * input_size = bytes of the raw sentence (the bos / eos spans, :1029-1048). */
-typedef struct { int32_t id; uint32_t begin, end; } Span;
+typedef struct { int32_t id; uint32_t begin, end; uint32_t nb, ne; int lit; } Span;   /* piece = normalized[nb, ne), or the
+                                                                                        piece name of id when lit */
 typedef struct { Span *p; size_t n, cap; } Spans;
-static void spans_push(Spans *v, int32_t id, uint32_t b, uint32_t e) {
+static void spans_push(Spans *v, int32_t id, uint32_t b, uint32_t e, uint32_t nb, uint32_t ne, int lit) {
   if (v->n == v->cap) { v->cap = v->cap ? v->cap * 2 : 64; v->p = realloc(v->p, sizeof(Span) * v->cap); }
-  v->p[v->n].id = id; v->p[v->n].begin = b; v->p[v->n].end = e; v->n++;
+  Span *s = &v->p[v->n++];
+  s->id = id; s->begin = b; s->end = e; s->nb = nb; s->ne = ne; s->lit = lit;
 }
 static int populate_spans(const Oracle *o, const uint8_t *norm, int norm_size, const Align *n2o, uint32_t input_size,
                           const Toks *res, Spans *out) {
@@ -546,7 +549,7 @@ static int populate_spans(const Oracle *o, const uint8_t *norm, int norm_size, c
     const int is_unk = type == T_UNKNOWN;
     if (type == T_CONTROL) {                                /* :561-567 begin == end */
       if (consumed >= n2o->n) return -1;
-      spans_push(out, id, n2o->p[consumed], n2o->p[consumed]);
+      spans_push(out, id, n2o->p[consumed], n2o->p[consumed], (uint32_t)t->begin, (uint32_t)(t->begin + t->len), 0);
     } else {
       const size_t begin = consumed, end = consumed + (size_t)t->len;
       if (begin >= n2o->n || end >= n2o->n) return -1;      /* :570-571 */
@@ -554,11 +557,12 @@ static int populate_spans(const Oracle *o, const uint8_t *norm, int norm_size, c
       if (ob > input_size || oe > input_size || ob > oe) return -1;   /* :574-576 */
       if (is_unk && o->byte_fallback) {                     /* :581-603: the last byte piece holds the surface */
         for (int i = 0; i < t->len; ++i)
-          spans_push(out, o->byte_ids[norm[t->begin + i]], ob, i == t->len - 1 ? oe : ob);
+          spans_push(out, o->byte_ids[norm[t->begin + i]], ob, i == t->len - 1 ? oe : ob, (uint32_t)begin, (uint32_t)end, 1);
       } else if (is_prev_unk && is_unk) {                   /* :609-613 */
         out->p[out->n - 1].end = oe;
+        out->p[out->n - 1].ne = (uint32_t)end;
       } else {
-        spans_push(out, id, ob, oe);
+        spans_push(out, id, ob, oe, (uint32_t)begin, (uint32_t)end, 0);
       }
       consumed = end;
     }
@@ -570,12 +574,13 @@ static int populate_spans(const Oracle *o, const uint8_t *norm, int norm_size, c
       case OPT_REVERSE:
         for (size_t i = 0, j = out->n ? out->n - 1 : 0; i < j; ++i, --j) { Span t = out->p[i]; out->p[i] = out->p[j]; out->p[j] = t; }
         break;
-      case OPT_EOS: { sv e = o->eos_piece; e.n = strnlen((const char *)e.p, e.n); spans_push(out, piece_to_id(o, e), input_size, input_size); break; }
+      case OPT_EOS: { sv e = o->eos_piece; e.n = strnlen((const char *)e.p, e.n); spans_push(out, piece_to_id(o, e), input_size, input_size, 0, 0, 1); break; }
       case OPT_BOS: {
         sv b = o->bos_piece; b.n = strnlen((const char *)b.p, b.n);
-        spans_push(out, 0, 0, 0);
+        spans_push(out, 0, 0, 0, 0, 0, 1);
         memmove(out->p + 1, out->p, sizeof(Span) * (out->n - 1));
         out->p[0].id = piece_to_id(o, b); out->p[0].begin = 0; out->p[0].end = 0;
+        out->p[0].nb = out->p[0].ne = 0; out->p[0].lit = 1;
         break;
       }
     }
@@ -727,6 +732,7 @@ void oracle_free(Oracle *o) {
  * only changes piece strings and is a no-op for ids. */
 int oracle_set_encode_extra_options(Oracle *o, const char *opts) {
   o->n_opts = 0;
+  o->opt_unk_piece = 0;
   const char *p = opts;
   while (*p) {
     const char *q = strchr(p, ':'); size_t n = q ? (size_t)(q - p) : strlen(p);
@@ -741,6 +747,7 @@ int oracle_set_encode_extra_options(Oracle *o, const char *opts) {
       if (o->pieces[id].type == T_UNKNOWN) return 13;       /* "id for `<s>` is not defined." */
     }
     if (code >= 0 && o->n_opts < 16) o->opts[o->n_opts++] = code;
+    if (code < 0) o->opt_unk_piece = 1;
     if (!q) break;
     p = q + 1;
   }
@@ -779,6 +786,30 @@ int64_t oracle_normalize(const Oracle *o, const char *in, uint64_t n, char *out,
   return r;
 }
 
+/* Normalize(input, &normalized, &norm_to_orig) per sentence.  n2o (optional): sentence s owns entries
+ * [norm_offsets[s] + s, norm_offsets[s + 1] + s + 1); 0xFFFFFFFF stands for "the reference's vector is empty". */
+int64_t oracle_normalize_batch(const Oracle *o, const char *text, const uint64_t *offsets, uint64_t n,
+                               char *out, uint64_t cap, uint64_t *norm_offsets, uint32_t *n2o) {
+  Buf b = {0}; Align a = {0};
+  uint64_t total = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    norm_offsets[i] = total;
+    normalize_aligned(o, (const uint8_t *)text + offsets[i], (size_t)(offsets[i + 1] - offsets[i]), &b, &a);
+    if (total + b.n <= cap) {
+      if (b.n) memcpy(out + total, b.p, b.n);
+      if (n2o) {
+        if (a.n == 0) n2o[total + i] = 0xFFFFFFFFu;
+        else memcpy(n2o + total + i, a.p, sizeof(uint32_t) * a.n);
+      }
+    }
+    total += b.n;
+  }
+  norm_offsets[n] = total;
+  free(b.p); free(a.p);
+  if (total > cap) return -(int64_t)total - 2;
+  return (int64_t)total;
+}
+
 int64_t oracle_encode(const Oracle *o, const char *in, uint64_t n, int32_t *out, uint64_t cap) {
   Buf norm = {0}; Toks toks = {0}; Ids ids = {0};
   int64_t r;
@@ -807,10 +838,21 @@ int64_t oracle_encode_batch(const Oracle *o, const char *text, const uint64_t *o
 }
 
 /* Encode(input, SentencePieceText*) per sentence: ids + pieces(i).begin / .end (bytes, relative to the sentence). */
+int64_t oracle_encode_pieces_batch(const Oracle *o, const char *text, const uint64_t *offsets, uint64_t n,
+                                   int32_t *out, uint32_t *begin, uint32_t *end, uint64_t cap, uint64_t *id_offsets,
+                                   char *pieces, uint64_t pieces_cap, uint64_t *piece_offsets);
 int64_t oracle_encode_spans_batch(const Oracle *o, const char *text, const uint64_t *offsets, uint64_t n,
                                   int32_t *out, uint32_t *begin, uint32_t *end, uint64_t cap, uint64_t *id_offsets) {
+  return oracle_encode_pieces_batch(o, text, offsets, n, out, begin, end, cap, id_offsets, NULL, 0, NULL);
+}
+
+/* The same with pieces(i).piece(): packed into `pieces`, piece k of the batch at [piece_offsets[k], piece_offsets[k + 1])
+ * (piece_offsets holds cap + 1 entries).  Returns -3 - (bytes needed) if pieces_cap is too small. */
+int64_t oracle_encode_pieces_batch(const Oracle *o, const char *text, const uint64_t *offsets, uint64_t n,
+                                   int32_t *out, uint32_t *begin, uint32_t *end, uint64_t cap, uint64_t *id_offsets,
+                                   char *pieces, uint64_t pieces_cap, uint64_t *piece_offsets) {
   Buf norm = {0}; Toks toks = {0}; Spans sp = {0}; Align n2o = {0};
-  uint64_t total = 0; int failed = 0;
+  uint64_t total = 0, pbytes = 0; int failed = 0;
   for (uint64_t i = 0; i < n; ++i) {
     id_offsets[i] = total;
     const uint8_t *in = (const uint8_t *)text + offsets[i];
@@ -820,13 +862,27 @@ int64_t oracle_encode_spans_batch(const Oracle *o, const char *text, const uint6
     else bpe_encode(o, norm.p, (int)norm.n, &toks);
     if (populate_spans(o, norm.p, (int)norm.n, &n2o, (uint32_t)len, &toks, &sp)) { failed = 1; break; }
     if (total + sp.n <= cap)
-      for (size_t k = 0; k < sp.n; ++k) { out[total + k] = sp.p[k].id; begin[total + k] = sp.p[k].begin; end[total + k] = sp.p[k].end; }
+      for (size_t k = 0; k < sp.n; ++k) {
+        const Span *x = &sp.p[k];
+        out[total + k] = x->id; begin[total + k] = x->begin; end[total + k] = x->end;
+        if (piece_offsets) {
+          /* :563 / :592 / :616 the normalized text; ByteToPiece (:590); bos / eos names (:1033, :1045); UNK_PIECE (:1050-1058) */
+          const int unk = x->id >= 0 && x->id < o->n_pieces && o->pieces[x->id].type == T_UNKNOWN;
+          sv ps; ps.p = norm.p + x->nb; ps.n = x->ne - x->nb;
+          if (x->lit || (unk && o->opt_unk_piece)) ps = o->pieces[x->id].piece;
+          piece_offsets[total + k] = pbytes;
+          if (pbytes + ps.n <= pieces_cap && ps.n) memcpy(pieces + pbytes, ps.p, ps.n);
+          pbytes += ps.n;
+        }
+      }
     total += sp.n;
   }
   id_offsets[n] = total;
+  if (piece_offsets && total <= cap) piece_offsets[total] = pbytes;
   free(norm.p); free(toks.p); free(sp.p); free(n2o.p);
   if (failed) return -1;
   if (total > cap) return -(int64_t)total - 2;
+  if (pbytes > pieces_cap) return -(int64_t)pbytes - 3;
   return (int64_t)total;
 }
 

@@ -37,6 +37,17 @@ int64_t oracle_encode_batch(const Oracle *o, const char *text, const uint64_t *o
 int64_t oracle_encode_spans_batch(const Oracle *o, const char *text, const uint64_t *offsets, uint64_t n,
                                   int32_t *out, uint32_t *begin, uint32_t *end, uint64_t cap, uint64_t *id_offsets);
 
+/* The same plus pieces(i).piece(), packed: piece k of the batch is pieces[piece_offsets[k], piece_offsets[k + 1]).
+ * -(bytes needed) - 3 if pieces_cap is too small. */
+int64_t oracle_encode_pieces_batch(const Oracle *o, const char *text, const uint64_t *offsets, uint64_t n,
+                                   int32_t *out, uint32_t *begin, uint32_t *end, uint64_t cap, uint64_t *id_offsets,
+                                   char *pieces, uint64_t pieces_cap, uint64_t *piece_offsets);
+/* Normalize(input, &normalized, &norm_to_orig) per sentence (normalizer.cc:71-186) -> packed text + offsets and
+ * (optional) the alignment vectors, sentence s at n2o[norm_offsets[s] + s ...]: one entry per byte + the closing one;
+ * a single 0xFFFFFFFF where the reference's vector is empty. */
+int64_t oracle_normalize_batch(const Oracle *o, const char *text, const uint64_t *offsets, uint64_t n,
+                               char *out, uint64_t cap, uint64_t *norm_offsets, uint32_t *n2o);
+
 /* Per-sentence Decode(ids, std::string*) over CSR ids -> packed text + offsets (n + 1). Returns total bytes,
  * -11000 for an invalid id (OUT_OF_RANGE), -12000 if the model has a denormalizer, -(needed)-2 if cap too small. */
 int64_t oracle_decode_batch(const Oracle *o, const int32_t *ids, const uint64_t *id_offsets, uint64_t n,

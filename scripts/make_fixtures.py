@@ -214,11 +214,40 @@ def make_ids():
         json.dump(manifest, f, indent=1, sort_keys=True)
 
 
+def spans_digest(b, e):
+    return hashlib.sha256(np.asarray(b).astype("<u4").tobytes() + np.asarray(e).astype("<u4").tobytes()).hexdigest()
+
+
+def make_spans():
+    """Adds to every pair of the manifest the digest of pieces(i).begin / .end that the compiled reference's
+    Encode(input, SentencePieceText*) gives (the ids of that call are checked against the stored digest)."""
+    from tests import fixtures
+    ref = refshim.RefLib()
+    cs = corpora()
+    with open(f"{G}/manifest.json") as f:
+        manifest = json.load(f)
+    for key, m in sorted(manifest.items()):
+        if key.startswith("_"):
+            continue
+        h = ref.load(fixtures.model_blob(m["model"]))
+        if m["options"]:
+            h.set_encode_extra_options(m["options"])
+        text, offs = cs[m["corpus"]]
+        ids, b, e, io = h.encode_spans(text, offs)
+        assert hashlib.sha256(ids.astype("<i4").tobytes()).hexdigest() == m["sha256"], key
+        m["spans_sha256"] = spans_digest(b, e)
+        print(key, m["spans_sha256"][:12])
+    with open(f"{G}/manifest.json", "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", choices=["models", "ids"], default=None)
+    ap.add_argument("--only", choices=["models", "ids", "spans"], default=None)
     a = ap.parse_args()
     if a.only in (None, "models"):
         make_models()
     if a.only in (None, "ids"):
         make_ids()
+    if a.only in (None, "spans"):
+        make_spans()

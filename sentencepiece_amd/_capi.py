@@ -5,6 +5,7 @@ gfx950).  If it is missing this module raises: the product has no CPU path.
 """
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspmx.so")
@@ -24,6 +25,7 @@ SYMBOLS = [
     ("spmx_piece_to_id", C.c_int, [_H, C.c_char_p, _U64]),
     ("spmx_id_to_piece", C.c_int64, [_H, C.c_int, C.c_char_p, _U64]),
     ("spmx_unk_id", C.c_int, [_H]),
+    ("spmx_piece_type", C.c_int, [_H, C.c_int]),
     ("spmx_bos_id", C.c_int, [_H]),
     ("spmx_eos_id", C.c_int, [_H]),
     ("spmx_pad_id", C.c_int, [_H]),
@@ -41,10 +43,14 @@ SYMBOLS = [
     ("spmx_decode", C.c_int, [_H, C.c_void_p, _U64, C.c_void_p, _U64, C.POINTER(_U64)]),
     ("spmx_encode_batch_spans_device", C.c_int,
      [_H, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-      C.POINTER(_U64)]),
+      C.c_void_p, C.c_void_p, C.POINTER(_U64)]),
     ("spmx_encode_batch_spans", C.c_int,
      [_H, C.c_void_p, C.c_void_p, _U64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
-      C.POINTER(C.c_void_p)]),
+      C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    ("spmx_normalize_batch_device", C.c_int,
+     [_H, C.c_void_p, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_U64)]),
+    ("spmx_normalize_batch", C.c_int,
+     [_H, C.c_void_p, C.c_void_p, _U64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     ("spmx_split_lines_device", C.c_int,
      [_H, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, C.POINTER(_U64), C.POINTER(_U64)]),
     ("spmx_set_profiling", C.c_int, [_H, C.c_int]),
@@ -65,6 +71,15 @@ def lib():
             raise RuntimeError(
                 "%s is missing: build it with `make -C sentencepiece_amd/csrc` "
                 "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 / HSA runtime under torch/lib, libspmx
+        # resolves /opt/rocm's.  If libspmx initialises HIP first, a later torch.cuda init finds "No HIP GPUs"
+        # (seen on the MI355X box); with torch's libraries loaded first both share them.  The device-resident forms
+        # take torch tensors anyway, so torch is imported first when it is installed.
+        if "torch" not in sys.modules and not os.environ.get("SPMX_NO_TORCH_PRELOAD"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         l = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(l, name)   # AttributeError if the .so does not export it

@@ -104,7 +104,8 @@ struct spmx_handle {
   DevBuf<uint32_t> d_lists, d_counts;
   DevBuf<uint64_t> d_tmp_off, d_tile_sums, d_chunk_base;
   DevBuf<int32_t> d_arena_tb, d_tok_begin;      // spans form
-  DevBuf<uint32_t> d_span_begin, d_span_end;
+  DevBuf<uint32_t> d_span_begin, d_span_end, d_nspan_begin, d_nspan_end;
+  DevBuf<uint8_t> d_norm;
   DevBuf<int32_t> d_arena;
   Ctrl *d_ctrl = nullptr;
   Ctrl *h_ctrl = nullptr;   // pinned
@@ -206,7 +207,7 @@ void DestroyHandle(spmx_handle *h) {
   h->d_ndarts.Free(); h->d_npair.Free(); h->d_sym_final.Free(); h->d_nblob.Free(); h->d_ptrie.Free(); h->d_chartab.Free();
   h->d_pairtab.Free(); h->d_utrie.Free(); h->d_sym_len.Free(); h->d_byte_ids.Free();
   h->d_dec_info.Free(); h->d_dec_off.Free(); h->d_dec_bytes.Free();
-  h->d_stream.Free(); h->d_lists.Free(); h->d_counts.Free(); h->d_tmp_off.Free(); h->d_tile_sums.Free(); h->d_chunk_base.Free(); h->d_arena_tb.Free(); h->d_tok_begin.Free(); h->d_span_begin.Free(); h->d_span_end.Free(); h->d_arena.Free();
+  h->d_stream.Free(); h->d_lists.Free(); h->d_counts.Free(); h->d_tmp_off.Free(); h->d_tile_sums.Free(); h->d_chunk_base.Free(); h->d_arena_tb.Free(); h->d_tok_begin.Free(); h->d_span_begin.Free(); h->d_span_end.Free(); h->d_nspan_begin.Free(); h->d_nspan_end.Free(); h->d_norm.Free(); h->d_arena.Free();
   h->d_text.Free(); h->d_offs.Free(); h->d_id_offs.Free(); h->d_ids.Free();
   if (h->d_ctrl) (void)hipFree(h->d_ctrl);
   if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);
@@ -257,7 +258,8 @@ StreamPlan PlanStream(const spmx_handle *h, const LengthClass &lc, bool fast, ui
 // d_begin / d_end (both or neither): the spans form (kernels_align.h).
 int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, const uint64_t *d_offsets, uint64_t n,
                  int32_t *d_ids, uint64_t ids_capacity, uint64_t *d_id_offsets, hipStream_t stream,
-                 uint64_t *total_ids, uint32_t *d_begin = nullptr, uint32_t *d_end = nullptr) {
+                 uint64_t *total_ids, uint32_t *d_begin = nullptr, uint32_t *d_end = nullptr,
+                 uint32_t *d_nbegin = nullptr, uint32_t *d_nend = nullptr) {
   const bool spans = d_begin != nullptr && d_end != nullptr;
   if (total_ids) *total_ids = 0;
   if (n >= (1ull << 32) - 64) return Fail(h, kInvalidArgument, "more than 2^32 - 64 sentences in one batch");
@@ -476,9 +478,10 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
         aa.dev = h->dev; aa.text = d_text; aa.offs = d_offsets;
         aa.list = h->d_lists.p + static_cast<size_t>(c) * n; aa.list_count = &h->d_ctrl->list_counts[c];
         aa.id_offs = d_id_offsets; aa.tok_begin = h->d_tok_begin.p; aa.begin = d_begin; aa.end = d_end;
+        aa.nbegin = d_nbegin; aa.nend = d_nbegin ? d_nend : nullptr;
         aa.status = &h->d_ctrl->status; aa.rcap = cls[c].rcap; aa.ncap = cls[c].ncap;
         aa.has_next = (c + 1 < ncls && cls[c + 1].rcap <= kMaxStagedRaw) ? 1u : 0u;
-        const uint32_t lds = AlignLdsBytes(aa.rcap, aa.ncap);
+        const uint32_t lds = AlignLdsBytes(aa.rcap, aa.ncap, aa.nbegin != nullptr && aa.nend != nullptr);
         int per_cu = static_cast<int>(kLdsPerCu / lds);
         if (per_cu > 32) per_cu = 32;
         if (per_cu < 1) per_cu = 1;
@@ -495,6 +498,79 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
     return kOk;
   }
   return Fail(h, kInternal, "id arena kept overflowing");
+}
+
+// Batch Normalize on the device (kernels_normalize.h): classify -> count pass per class -> scan -> write pass per class.
+// Caller holds h->mu and has set the device.
+int NormalizeDevice(spmx_handle *h, const uint8_t *d_text, const uint64_t *d_offsets, uint64_t n, uint8_t *d_norm,
+                    uint64_t norm_capacity, uint64_t *d_norm_offsets, uint32_t *d_n2o, hipStream_t stream,
+                    uint64_t *total_bytes) {
+  if (total_bytes) *total_bytes = 0;
+  if (n >= (1ull << 32) - 64) return Fail(h, kInvalidArgument, "more than 2^32 - 64 sentences in one batch");
+  if (!d_offsets || !d_norm_offsets) return Fail(h, kInvalidArgument, "null offsets");
+  if (n == 0) {
+    HIP_OR_RETURN(h, hipMemsetAsync(d_norm_offsets, 0, sizeof(uint64_t), stream));
+    HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+    return kOk;
+  }
+  const int ncls = NumClasses(h);
+  const LengthClass *cls = Classes(h);
+  HIP_OR_RETURN(h, h->d_lists.Reserve(static_cast<size_t>(3 * ncls) * n));
+  HIP_OR_RETURN(h, h->d_counts.Reserve(n + 1));
+  HIP_OR_RETURN(h, h->d_tile_sums.Reserve((n + kScanTile - 1) / kScanTile + 2));
+  HIP_OR_RETURN(h, hipMemsetAsync(h->d_ctrl, 0, sizeof(Ctrl), stream));
+  const uint32_t n32 = static_cast<uint32_t>(n);
+  const int wide = h->n_cu * 8;
+  {
+    ClassifyArgs ca{};
+    ca.offs = d_offsets; ca.n = n32; ca.n_classes = static_cast<uint32_t>(ncls);
+    for (int c = 0; c < ncls; ++c) ca.rcap[c] = cls[c].rcap;
+    ca.lists = h->d_lists.p; ca.list_counts = h->d_ctrl->list_counts;
+    ca.key_totals = h->d_ctrl->key_totals; ca.key_cursor = h->d_ctrl->key_cursor;
+    const uint32_t chunks = (n32 + 64 * kClassifyChunk - 1) / (64 * kClassifyChunk);
+    HIP_OR_RETURN(h, LaunchClassify(ca, static_cast<int>(chunks < static_cast<uint32_t>(wide) ? chunks : wide), stream));
+  }
+  auto pass = [&](bool write) -> int {
+    for (int c = 0; c < ncls; ++c) {
+      if (cls[c].rcap > kMaxStagedRaw) continue;             // checked below
+      NormalizeArgs a{};
+      a.dev = h->dev; a.text = d_text; a.offs = d_offsets;
+      a.list = h->d_lists.p + static_cast<size_t>(c) * n; a.list_count = &h->d_ctrl->list_counts[c];
+      const bool has_next = c + 1 < ncls && cls[c + 1].rcap <= kMaxStagedRaw;
+      a.next_list = has_next ? h->d_lists.p + static_cast<size_t>(c + 1) * n : nullptr;
+      a.next_count = has_next ? &h->d_ctrl->list_counts[c + 1] : nullptr;
+      a.counts = h->d_counts.p; a.norm_offs = d_norm_offsets; a.norm = d_norm; a.n2o = d_n2o;
+      a.status = &h->d_ctrl->status; a.rcap = cls[c].rcap; a.ncap = cls[c].ncap;
+      const uint32_t lds = NormalizeLdsBytes(a.rcap, a.ncap);
+      int per_cu = static_cast<int>(kLdsPerCu / lds);
+      if (per_cu > 32) per_cu = 32;
+      if (per_cu < 1) per_cu = 1;
+      uint64_t grid = static_cast<uint64_t>(h->n_cu) * per_cu;
+      if (grid > n) grid = n;
+      HIP_OR_RETURN(h, LaunchNormalize(write, a, static_cast<int>(grid), lds, stream));
+    }
+    return kOk;
+  };
+  if (int rc = pass(false); rc != kOk) return rc;
+  {
+    ScanArgs sa{h->d_counts.p, n32, h->d_tile_sums.p, d_norm_offsets};
+    const uint32_t tiles = (n32 + kScanTile - 1) / kScanTile;
+    HIP_OR_RETURN(h, LaunchScan(sa, static_cast<int>(tiles < static_cast<uint32_t>(wide) ? tiles : wide), stream));
+  }
+  HIP_OR_RETURN(h, hipMemcpyAsync(h->h_ctrl, h->d_ctrl, offsetof(Ctrl, total_ids), hipMemcpyDeviceToHost, stream));
+  HIP_OR_RETURN(h, hipMemcpyAsync(&h->h_ctrl->total_ids, d_norm_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+  HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+  for (int c = 0; c < ncls; ++c)
+    if (cls[c].rcap > kMaxStagedRaw && h->h_ctrl->list_counts[c])
+      return Fail(h, kOutOfRange, "a sentence is longer than 8192 bytes: Normalize on the device is limited to that");
+  if (h->h_ctrl->status & kStTooLong) return Fail(h, kOutOfRange, "the normalized form of a sentence exceeds the largest length class");
+  const uint64_t total = h->h_ctrl->total_ids;
+  if (total_bytes) *total_bytes = total;
+  if (total == 0 && !d_n2o) return kOk;
+  if ((!d_norm && total) || total > norm_capacity) return Fail(h, kResourceExhausted, "norm_capacity is too small");
+  if (int rc = pass(true); rc != kOk) return rc;
+  HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+  return kOk;
 }
 
 // Batch Decode on the device (kernels_decode.h): count pass -> scan -> (host checks status / capacity) -> write pass.
@@ -660,6 +736,10 @@ int64_t spmx_id_to_piece(const spmx_handle *h, int id, char *out, uint64_t cap) 
   return static_cast<int64_t>(p.size());
 }
 int spmx_unk_id(const spmx_handle *h) { return h ? h->model.unk_id : -1; }
+int spmx_piece_type(const spmx_handle *h, int id) {
+  if (!h || id < 0 || id >= static_cast<int>(h->model.pieces.size())) return -1;
+  return h->model.pieces[id].type;
+}
 // bos_id / eos_id / pad_id (src/sentencepiece_processor.cc:1002-1017): PieceToId, -1 if it resolves to unk
 static int ReservedId(const spmx_handle *h, const std::string &piece) {
   if (!h) return -1;
@@ -684,13 +764,16 @@ int spmx_encode_batch_device(spmx_handle *h, const void *d_text, uint64_t text_b
 namespace {
 // Host-buffer form of the batch encode, with (begin / end non-null) or without the spans.
 int EncodeBatchHost(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
-                    uint64_t **id_offsets, uint32_t **begin, uint32_t **end) {
+                    uint64_t **id_offsets, uint32_t **begin, uint32_t **end, uint32_t **nbegin = nullptr,
+                    uint32_t **nend = nullptr) {
   if (!h) return kInvalidArgument;
   std::lock_guard<std::mutex> l(h->mu);
   const bool spans = begin != nullptr;
   if (!ids || !id_offsets || (spans && !end)) return Fail(h, kInternal, "output container is null");   // sentencepiece_processor.cc:367-370
   *ids = nullptr; *id_offsets = nullptr;
   if (spans) { *begin = nullptr; *end = nullptr; }
+  const bool nspans = spans && nbegin && nend;
+  if (nspans) { *nbegin = nullptr; *nend = nullptr; }
   if (n && !offsets) return Fail(h, kInvalidArgument, "null offsets");
   HIP_OR_RETURN(h, hipSetDevice(h->device));
   uint64_t *ho = static_cast<uint64_t *>(malloc((n + 1) * sizeof(uint64_t)));
@@ -698,6 +781,7 @@ int EncodeBatchHost(spmx_handle *h, const char *text, const uint64_t *offsets, u
   if (n == 0) {
     ho[0] = 0; *id_offsets = ho; *ids = static_cast<int32_t *>(malloc(sizeof(int32_t)));
     if (spans) { *begin = static_cast<uint32_t *>(malloc(sizeof(uint32_t))); *end = static_cast<uint32_t *>(malloc(sizeof(uint32_t))); }
+    if (nspans) { *nbegin = static_cast<uint32_t *>(malloc(sizeof(uint32_t))); *nend = static_cast<uint32_t *>(malloc(sizeof(uint32_t))); }
     return kOk;
   }
   const uint64_t base = offsets[0], text_bytes = offsets[n] - base;
@@ -715,10 +799,13 @@ int EncodeBatchHost(spmx_handle *h, const char *text, const uint64_t *offsets, u
     if (spans) {
       hipError_t e = h->d_span_begin.Reserve(h->d_ids.cap);
       if (e == hipSuccess) e = h->d_span_end.Reserve(h->d_ids.cap);
+      if (e == hipSuccess && nspans) e = h->d_nspan_begin.Reserve(h->d_ids.cap);
+      if (e == hipSuccess && nspans) e = h->d_nspan_end.Reserve(h->d_ids.cap);
       if (e != hipSuccess) { free(ho); return FailHip(h, e, "hipMalloc(spans)"); }
     }
     rc = EncodeDevice(h, d_text, text_bytes, h->d_offs.p, n, h->d_ids.p, h->d_ids.cap, h->d_id_offs.p, nullptr, &total,
-                      spans ? h->d_span_begin.p : nullptr, spans ? h->d_span_end.p : nullptr);
+                      spans ? h->d_span_begin.p : nullptr, spans ? h->d_span_end.p : nullptr,
+                      nspans ? h->d_nspan_begin.p : nullptr, nspans ? h->d_nspan_end.p : nullptr);
     if (rc != kResourceExhausted || total <= h->d_ids.cap) break;
     cap = total;
   }
@@ -737,6 +824,19 @@ int EncodeBatchHost(spmx_handle *h, const char *text, const uint64_t *offsets, u
     if (e != hipSuccess) { free(ho); free(hi); free(hb); free(he); return FailHip(h, e, "hipMemcpy(spans)"); }
     *begin = hb;
     *end = he;
+    if (nspans) {
+      uint32_t *nb = static_cast<uint32_t *>(malloc((total ? total : 1) * sizeof(uint32_t)));
+      uint32_t *ne = static_cast<uint32_t *>(malloc((total ? total : 1) * sizeof(uint32_t)));
+      if (nb && ne && total) e = hipMemcpy(nb, h->d_nspan_begin.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost);
+      if (nb && ne && e == hipSuccess && total) e = hipMemcpy(ne, h->d_nspan_end.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost);
+      if (!nb || !ne || e != hipSuccess) {
+        free(ho); free(hi); free(hb); free(he); free(nb); free(ne);
+        *begin = nullptr; *end = nullptr;
+        return e != hipSuccess ? FailHip(h, e, "hipMemcpy(spans)") : Fail(h, kResourceExhausted, "out of host memory");
+      }
+      *nbegin = nb;
+      *nend = ne;
+    }
   }
   *ids = hi;
   *id_offsets = ho;
@@ -750,20 +850,79 @@ int spmx_encode_batch(spmx_handle *h, const char *text, const uint64_t *offsets,
 }
 
 int spmx_encode_batch_spans(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
-                            uint64_t **id_offsets, uint32_t **begin, uint32_t **end) {
-  if (h && (!begin || !end)) return Fail(h, kInternal, "output container is null");
-  return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, begin, end);
+                            uint64_t **id_offsets, uint32_t **begin, uint32_t **end, uint32_t **nbegin, uint32_t **nend) {
+  if (h && (!begin || !end || (nbegin != nullptr) != (nend != nullptr))) return Fail(h, kInternal, "output container is null");
+  return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, begin, end, nbegin, nend);
 }
 
 int spmx_encode_batch_spans_device(spmx_handle *h, const void *d_text, uint64_t text_bytes, const uint64_t *d_offsets,
                                    uint64_t n, int32_t *d_ids, uint64_t ids_capacity, uint64_t *d_id_offsets,
-                                   uint32_t *d_begin, uint32_t *d_end, void *stream, uint64_t *total_ids) {
+                                   uint32_t *d_begin, uint32_t *d_end, uint32_t *d_nbegin, uint32_t *d_nend, void *stream,
+                                   uint64_t *total_ids) {
   if (!h) return kInvalidArgument;
   std::lock_guard<std::mutex> l(h->mu);
   if (d_ids && (!d_begin || !d_end)) return Fail(h, kInvalidArgument, "null span buffers");
   HIP_OR_RETURN(h, hipSetDevice(h->device));
   return EncodeDevice(h, static_cast<const uint8_t *>(d_text), text_bytes, d_offsets, n, d_ids, ids_capacity,
-                      d_id_offsets, static_cast<hipStream_t>(stream), total_ids, d_begin, d_end);
+                      d_id_offsets, static_cast<hipStream_t>(stream), total_ids, d_begin, d_end, d_nbegin, d_nend);
+}
+
+int spmx_normalize_batch_device(spmx_handle *h, const void *d_text, const uint64_t *d_offsets, uint64_t n, void *d_norm,
+                                uint64_t norm_capacity, uint64_t *d_norm_offsets, uint32_t *d_norm_to_orig, void *stream,
+                                uint64_t *total_bytes) {
+  if (!h) return kInvalidArgument;
+  std::lock_guard<std::mutex> l(h->mu);
+  HIP_OR_RETURN(h, hipSetDevice(h->device));
+  return NormalizeDevice(h, static_cast<const uint8_t *>(d_text), d_offsets, n, static_cast<uint8_t *>(d_norm), norm_capacity,
+                         d_norm_offsets, d_norm_to_orig, static_cast<hipStream_t>(stream), total_bytes);
+}
+
+int spmx_normalize_batch(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, char **norm,
+                         uint64_t **norm_offsets, uint32_t **norm_to_orig) {
+  if (!h) return kInvalidArgument;
+  std::lock_guard<std::mutex> l(h->mu);
+  if (!norm || !norm_offsets) return Fail(h, kInternal, "output container is null");
+  *norm = nullptr; *norm_offsets = nullptr;
+  if (norm_to_orig) *norm_to_orig = nullptr;
+  if (n && !offsets) return Fail(h, kInvalidArgument, "null offsets");
+  HIP_OR_RETURN(h, hipSetDevice(h->device));
+  uint64_t *ho = static_cast<uint64_t *>(malloc((n + 1) * sizeof(uint64_t)));
+  if (!ho) return Fail(h, kResourceExhausted, "out of host memory");
+  if (n == 0) {
+    ho[0] = 0; *norm_offsets = ho; *norm = static_cast<char *>(malloc(1));
+    if (norm_to_orig) *norm_to_orig = static_cast<uint32_t *>(malloc(sizeof(uint32_t)));
+    return kOk;
+  }
+  const uint64_t base = offsets[0], text_bytes = offsets[n] - base;
+  HIP_OR_RETURN(h, h->d_text.Reserve(text_bytes + 16));
+  HIP_OR_RETURN(h, h->d_offs.Reserve(n + 1));
+  HIP_OR_RETURN(h, h->d_id_offs.Reserve(n + 1));
+  if (text_bytes) HIP_OR_RETURN(h, hipMemcpyAsync(h->d_text.p, text + base, text_bytes, hipMemcpyHostToDevice, nullptr));
+  HIP_OR_RETURN(h, hipMemcpyAsync(h->d_offs.p, offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, nullptr));
+  const uint8_t *d_text = h->d_text.p - base;
+  uint64_t cap = 2 * text_bytes + 4 * n + 64, total = 0;
+  int rc = kOk;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    hipError_t e = h->d_norm.Reserve(cap);
+    if (e == hipSuccess && norm_to_orig) e = h->d_span_begin.Reserve(cap + n + 1);
+    if (e != hipSuccess) { free(ho); return FailHip(h, e, "hipMalloc(norm)"); }
+    rc = NormalizeDevice(h, d_text, h->d_offs.p, n, h->d_norm.p, h->d_norm.cap, h->d_id_offs.p,
+                         norm_to_orig ? h->d_span_begin.p : nullptr, nullptr, &total);
+    if (rc != kResourceExhausted || total <= h->d_norm.cap) break;
+    cap = total;
+  }
+  if (rc != kOk) { free(ho); return rc; }
+  char *ht = static_cast<char *>(malloc(total ? total : 1));
+  uint32_t *hn = norm_to_orig ? static_cast<uint32_t *>(malloc((total + n + 1) * sizeof(uint32_t))) : nullptr;
+  if (!ht || (norm_to_orig && !hn)) { free(ho); free(ht); free(hn); return Fail(h, kResourceExhausted, "out of host memory"); }
+  hipError_t e = hipMemcpy(ho, h->d_id_offs.p, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && total) e = hipMemcpy(ht, h->d_norm.p, total, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && hn) e = hipMemcpy(hn, h->d_span_begin.p, (total + n) * sizeof(uint32_t), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) { free(ho); free(ht); free(hn); return FailHip(h, e, "hipMemcpy(norm)"); }
+  *norm = ht;
+  *norm_offsets = ho;
+  if (norm_to_orig) *norm_to_orig = hn;
+  return kOk;
 }
 
 void spmx_free(void *p) { free(p); }

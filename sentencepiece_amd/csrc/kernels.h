@@ -138,7 +138,8 @@ SPMX_DEVICE uint64_t resolve_chain(int base, int step, bool valid, int *next_sta
 // state machine (is_prev_space) becomes a "last writer" lookup on ballot masks;
 // (4) a prefix sum places every prefix's output.
 // `orig` (optional, LDS, ncap entries): norm_to_orig (:105-120, :142-152) -- for every normalized byte the raw offset
-// at which the prefix that produced it starts; *orig_end receives the closing entry (:181).
+// at which the prefix that produced it starts; *orig_end receives the closing entry (:181), -1 where the reference
+// returns before pushing one (all-whitespace input, :96-99).
 SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint8_t *norm, int ncap, int lane,
                                uint16_t *orig = nullptr, int *orig_end = nullptr) {
   const uint32_t F = d.flags;
@@ -328,7 +329,10 @@ SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint
     out += total;
   }
   wv::sync();
-  if (rm && !any_other) return 0;      // :86-100 every prefix was " ": empty result, no dummy prefix
+  if (rm && !any_other) {              // :86-100 every prefix was " ": empty result, no dummy prefix,
+    if (orig_end) *orig_end = -1;      // and no closing entry in norm_to_orig either
+    return 0;
+  }
   int fin = L;                         // `consumed` when the closing entry is pushed (:181)
   if (orig && (F & kNfAddDummyPrefix) && !(F & kNfWsSuffix)) {
     // the dummy prefix maps to `consumed` after the leading-space loop (:85-94, :128)
@@ -762,5 +766,6 @@ SPMX_DEVICE void compact_block(const CompactArgs &a) {
 #include "kernels_decode.h"
 #include "kernels_split.h"
 #include "kernels_align.h"
+#include "kernels_normalize.h"
 
 #endif

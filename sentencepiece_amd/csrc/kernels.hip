@@ -35,6 +35,14 @@ __global__ __launch_bounds__(64) void AlignKernel(AlignArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   align_block(a, smem);
 }
+__global__ __launch_bounds__(64) void NormalizeCountKernel(NormalizeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  normalize_block<false>(a, smem);
+}
+__global__ __launch_bounds__(64) void NormalizeWriteKernel(NormalizeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  normalize_block<true>(a, smem);
+}
 __global__ __launch_bounds__(64) void SplitCountKernel(SplitArgs a) { split_block<false>(a, nullptr); }
 __global__ __launch_bounds__(64) void SplitWriteKernel(SplitArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t stage[kSplitLdsBytes];
@@ -137,6 +145,17 @@ hipError_t LaunchAlign(const AlignArgs &a, int grid, uint32_t lds_bytes, hipStre
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(AlignKernel, dim3(grid), dim3(64), lds_bytes, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t LaunchNormalize(bool write, const NormalizeArgs &a, int grid, uint32_t lds_bytes, hipStream_t stream) {
+  void (*fn)(NormalizeArgs) = write ? NormalizeWriteKernel : NormalizeCountKernel;
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds_bytes));
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds_bytes, stream, a);
   return hipGetLastError();
 }
 

@@ -23,13 +23,16 @@ struct AlignArgs {
   const uint64_t *id_offs;      // n + 1: CSR of the ids
   const int32_t *tok_begin;     // CSR, same shape as the ids: token begins in the normalized (device) text
   uint32_t *begin, *end;        // CSR out
+  uint32_t *nbegin, *nend;      // optional CSR out: the same tokens as ranges of the normalized text (as Normalize()
+                                // returns it: U+2581 takes three bytes there); 0, 0 for a bos / eos
   uint32_t *status;
   uint32_t rcap, ncap;          // LDS capacities, those of the encode class
   uint32_t has_next;            // a sentence that overflows ncap is also in a later class's list: leave it to that
 };
 
-inline uint32_t AlignLdsBytes(uint32_t rcap, uint32_t ncap) {
-  return ((rcap + 16 + 15) & ~15u) + ((ncap + 16 + 15) & ~15u) + (((ncap + 8) * 2 + 15) & ~15u);
+inline uint32_t AlignLdsBytes(uint32_t rcap, uint32_t ncap, bool norm_spans) {
+  const uint32_t n2 = ((ncap + 8) * 2 + 15) & ~15u;
+  return ((rcap + 16 + 15) & ~15u) + ((ncap + 16 + 15) & ~15u) + n2 + (norm_spans ? n2 : 0u);
 }
 
 SPMX_DEVICE void align_block(const AlignArgs &a, unsigned char *smem) {
@@ -38,6 +41,9 @@ SPMX_DEVICE void align_block(const AlignArgs &a, unsigned char *smem) {
   uint8_t *raw = smem;
   uint8_t *norm = smem + ((a.rcap + 16 + 15) & ~15u);
   uint16_t *orig = reinterpret_cast<uint16_t *>(norm + ((a.ncap + 16 + 15) & ~15u));
+  uint16_t *spc = orig + (((a.ncap + 8) * 2 + 15) & ~15u) / 2;     // (norm spans) one-byte space symbols before p
+  const bool nspans = a.nbegin != nullptr && a.nend != nullptr;
+  const bool one = (d.flags & kNfCompressSp) != 0;
   const bool reverse = (d.flags & kNfReverse) != 0;
   const uint32_t count = *a.list_count;
   for (uint32_t item = static_cast<uint32_t>(wv::block_id()); item < count; item += static_cast<uint32_t>(wv::grid_size())) {
@@ -63,15 +69,28 @@ SPMX_DEVICE void align_block(const AlignArgs &a, unsigned char *smem) {
       wv::sync();
       continue;
     }
-    if (lane == 0) orig[nlen] = static_cast<uint16_t>(fin);
+    if (lane == 0) orig[nlen] = static_cast<uint16_t>(fin < 0 ? L : fin);
+    if (nspans && one) {
+      int run = 0;
+      for (int p0 = 0; p0 <= nlen; p0 += 64) {
+        const int p = p0 + lane;
+        const int c = (p < nlen && norm[p] == kSpByte) ? 1 : 0;
+        int t = 0;
+        const int before = run + wave_excl_scan(c, lane, &t);
+        if (p <= nlen) spc[p] = static_cast<uint16_t>(before);
+        run += t;
+      }
+    }
     wv::sync();
     if (lane < d.n_prefix) {
       const uint32_t v = ((d.extra_eos >> lane) & 1u) ? static_cast<uint32_t>(L) : 0u;
       a.begin[ib + lane] = v; a.end[ib + lane] = v;
+      if (nspans) { a.nbegin[ib + lane] = 0; a.nend[ib + lane] = 0; }
     }
     if (lane < d.n_suffix) {
       const uint32_t v = ((d.extra_eos >> (kMaxExtra + lane)) & 1u) ? static_cast<uint32_t>(L) : 0u;
       a.begin[ib + d.n_prefix + body + lane] = v; a.end[ib + d.n_prefix + body + lane] = v;
+      if (nspans) { a.nbegin[ib + d.n_prefix + body + lane] = 0; a.nend[ib + d.n_prefix + body + lane] = 0; }
     }
     bool bad = false;
     for (int i0 = 0; i0 < body; i0 += 64) {
@@ -81,7 +100,13 @@ SPMX_DEVICE void align_block(const AlignArgs &a, unsigned char *smem) {
         const int b = a.tok_begin[slot];
         const int e = i + 1 < body ? a.tok_begin[reverse ? slot - 1 : slot + 1] : nlen;
         if (b < 0 || e < b || e > nlen) { bad = true; }
-        else { a.begin[slot] = orig[b]; a.end[slot] = orig[e]; }
+        else {
+          a.begin[slot] = orig[b]; a.end[slot] = orig[e];
+          if (nspans) {
+            a.nbegin[slot] = static_cast<uint32_t>(b) + (one ? 2u * spc[b] : 0u);
+            a.nend[slot] = static_cast<uint32_t>(e) + (one ? 2u * spc[e] : 0u);
+          }
+        }
       }
     }
     if (wv::any(bad) && lane == 0) wv::atomic_or(a.status, kStInternal);

@@ -144,6 +144,24 @@ class SentencePieceProcessor:
         self._need()
         return self._lib.spmx_unk_id(self._h)
 
+    def _type(self, id):
+        self._need()
+        return self._lib.spmx_piece_type(self._h, id)
+
+    def IsUnknown(self, id):
+        return self._type(id) == 2
+
+    def IsControl(self, id):
+        return self._type(id) == 3
+
+    def IsUnused(self, id):
+        return self._type(id) == 5
+
+    def IsByte(self, id):
+        return self._type(id) == 6
+
+    is_unknown, is_control, is_unused, is_byte = IsUnknown, IsControl, IsUnused, IsByte
+
     def bos_id(self):
         self._need()
         return self._lib.spmx_bos_id(self._h)
@@ -249,21 +267,24 @@ class SentencePieceProcessor:
         return d_ids, d_id_offsets, total.value
 
     # ------------------------------------------------------- spans form ----
-    def EncodeSpansPacked(self, text, offsets):
+    def EncodeSpansPacked(self, text, offsets, norm_spans=False):
         """Packed host arrays -> ``(ids int32, begin uint32, end uint32, id_offsets uint64)``: next to every id the
         byte range of its sentence it covers -- ``pieces[i].begin / .end`` of the ``SentencePieceText`` that
         ``Encode(input, SentencePieceText*)`` fills (src/sentencepiece_processor.cc:547-653), in bytes as in C++
         (the reference's Python wrapper converts to characters).  ``add_bos`` / ``add_eos`` / ``reverse`` are not
-        taken here, as in the reference's proto API (sentencepiece.i:166-186); ``SetEncodeExtraOptions`` applies."""
+        taken here, as in the reference's proto API (sentencepiece.i:166-186); ``SetEncodeExtraOptions`` applies.
+        ``norm_spans=True`` appends ``(nbegin, nend)``: the same tokens as ranges of the normalized sentence."""
         self._need()
         self._apply(False, False, False)
         text = np.ascontiguousarray(text, dtype=np.uint8)
         offs = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = len(offs) - 1
-        p_ids, p_off, p_b, p_e = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        p_ids, p_off, p_b, p_e, p_nb, p_ne = (C.c_void_p() for _ in range(6))
         tp = text.ctypes.data if len(text) else None
         self._check(self._lib.spmx_encode_batch_spans(self._h, tp, offs.ctypes.data, n, C.byref(p_ids), C.byref(p_off),
-                                                      C.byref(p_b), C.byref(p_e)))
+                                                      C.byref(p_b), C.byref(p_e),
+                                                      C.byref(p_nb) if norm_spans else None,
+                                                      C.byref(p_ne) if norm_spans else None))
         try:
             io = np.ctypeslib.as_array(C.cast(p_off, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
             total = int(io[n])
@@ -273,10 +294,13 @@ class SentencePieceProcessor:
             ids = take(p_ids, C.c_int32, np.int32)
             b = take(p_b, C.c_uint32, np.uint32)
             e = take(p_e, C.c_uint32, np.uint32)
+            if norm_spans:
+                nb = take(p_nb, C.c_uint32, np.uint32)
+                ne = take(p_ne, C.c_uint32, np.uint32)
         finally:
-            for p in (p_ids, p_off, p_b, p_e):
+            for p in (p_ids, p_off, p_b, p_e, p_nb, p_ne):
                 self._lib.spmx_free(p)
-        return ids, b, e, io
+        return (ids, b, e, io, nb, ne) if norm_spans else (ids, b, e, io)
 
     def EncodeSpansDevice(self, d_text, d_offsets, stream=None):
         """Device-resident spans form: ``(d_ids int32, d_id_offsets int64[n + 1], d_begin int32, d_end int32, total)``
@@ -297,7 +321,7 @@ class SentencePieceProcessor:
             d_e = torch.empty(cap, dtype=torch.int32, device=dev)
             rc = self._lib.spmx_encode_batch_spans_device(
                 self._h, d_text.data_ptr(), d_text.numel(), d_offsets.data_ptr(), n, d_ids.data_ptr(), cap,
-                d_id_offsets.data_ptr(), d_b.data_ptr(), d_e.data_ptr(), stream, C.byref(total))
+                d_id_offsets.data_ptr(), d_b.data_ptr(), d_e.data_ptr(), None, None, stream, C.byref(total))
             if rc == _RESOURCE_EXHAUSTED and total.value > cap:
                 cap = total.value
                 continue
@@ -305,23 +329,95 @@ class SentencePieceProcessor:
         self._check(rc)
         return d_ids, d_id_offsets, d_b, d_e, total.value
 
-    def EncodeWithOffsets(self, input):
-        """str | list[str] -> list of ``(id, piece, surface, begin, end)`` per sentence: the fields of
-        ``SentencePieceText.pieces`` (byte offsets).  ``piece`` is ``IdToPiece(id)`` -- for an unknown token the
-        reference stores the normalized text there instead (sentencepiece_processor.cc:614-617); use ``surface``."""
+    def EncodeAsSentencePieceText(self, input):
+        """str | bytes | list of them -> per sentence the list of ``(piece, id, surface, begin, end)`` -- the fields of
+        ``SentencePieceText.pieces`` (src/sentencepiece.proto, PopulateSentencePieceText
+        sentencepiece_processor.cc:547-636), all bytes.  ``piece`` is the token's normalized text (so an unknown
+        token shows its characters, :614-617), the ``<0x..>`` name for a byte-fallback piece and the piece name for
+        a bos / eos; the ``unk_piece`` extra option replaces the piece of unknown tokens (:1050-1058)."""
         single = isinstance(input, (str, bytes))
         items = [input] if single else list(input)
         raw = [x.encode("utf-8") if isinstance(x, str) else bytes(x) for x in items]
         offs = np.zeros(len(raw) + 1, dtype=np.uint64)
         if raw:
             np.cumsum([len(x) for x in raw], out=offs[1:])
-        ids, b, e, io = self.EncodeSpansPacked(np.frombuffer(b"".join(raw), dtype=np.uint8), offs)
+        text = np.frombuffer(b"".join(raw), dtype=np.uint8)
+        ids, b, e, io, nb, ne = self.EncodeSpansPacked(text, offs, norm_spans=True)
+        norm, no, _ = self.NormalizePacked(text, offs)
+        norm = norm.tobytes()
+        unk = self.unk_id()
+        unk_opt = any(o in ("unk", "unk_piece") for o in (self._extra or "").split(":"))
         out = []
         for i, r in enumerate(raw):
-            lo, hi = int(io[i]), int(io[i + 1])
-            out.append([(int(ids[k]), self.IdToPiece(int(ids[k])), r[int(b[k]):int(e[k])], int(b[k]), int(e[k]))
-                        for k in range(lo, hi)])
+            base = int(no[i])
+            row = []
+            for k in range(int(io[i]), int(io[i + 1])):
+                t = int(ids[k])
+                if self.IsByte(t) or self.IsControl(t) or (unk_opt and t == unk):
+                    piece = self.IdToPiece(t).encode("utf-8")
+                else:
+                    piece = norm[base + int(nb[k]):base + int(ne[k])]
+                row.append((piece, t, r[int(b[k]):int(e[k])], int(b[k]), int(e[k])))
+            out.append(row)
         return out[0] if single else out
+
+    def EncodeAsPieces(self, input):
+        """``EncodeAsPieces`` (sentencepiece_processor.h:462-466) / ``encode(out_type=str)``: the piece strings."""
+        single = isinstance(input, (str, bytes))
+        rows = self.EncodeAsSentencePieceText([input] if single else input)
+        out = [[p.decode("utf-8", "surrogateescape") for p, *_ in row] for row in rows]
+        return out[0] if single else out
+
+    encode_as_pieces = EncodeAsPieces
+
+    # -------------------------------------------------------- normalize ----
+    def NormalizePacked(self, text, offsets, with_offsets=False):
+        """Packed host arrays -> ``(normalized uint8, norm_offsets uint64[n + 1], norm_to_orig | None)``.
+        ``norm_to_orig`` (uint32): sentence s owns ``[norm_offsets[s] + s, norm_offsets[s + 1] + s + 1)`` -- one entry
+        per normalized byte plus the closing one (0xFFFFFFFF where the reference's vector is empty)."""
+        self._need()
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offs) - 1
+        p_t, p_o, p_a = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._check(self._lib.spmx_normalize_batch(self._h, text.ctypes.data if len(text) else None, offs.ctypes.data, n,
+                                                   C.byref(p_t), C.byref(p_o), C.byref(p_a) if with_offsets else None))
+        try:
+            no = np.ctypeslib.as_array(C.cast(p_o, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+            total = int(no[n])
+            norm = (np.ctypeslib.as_array(C.cast(p_t, C.POINTER(C.c_uint8)), shape=(total,)).copy()
+                    if total else np.zeros(0, dtype=np.uint8))
+            n2o = None
+            if with_offsets:
+                n2o = (np.ctypeslib.as_array(C.cast(p_a, C.POINTER(C.c_uint32)), shape=(total + n,)).copy()
+                       if total + n else np.zeros(0, dtype=np.uint32))
+        finally:
+            for p in (p_t, p_o, p_a):
+                self._lib.spmx_free(p)
+        return norm, no, n2o
+
+    def Normalize(self, input, with_offsets=None):
+        """``Normalize`` (python/src/sentencepiece/__init__.py:907-915): str -> str, or ``(str, list[int])`` with
+        ``with_offsets`` (byte offsets, the C++ norm_to_orig); a list gives a list."""
+        single = not isinstance(input, list)
+        items = [input] if single else input
+        raw = [x.encode("utf-8") if isinstance(x, str) else bytes(x) for x in items]
+        offs = np.zeros(len(raw) + 1, dtype=np.uint64)
+        if raw:
+            np.cumsum([len(x) for x in raw], out=offs[1:])
+        norm, no, n2o = self.NormalizePacked(np.frombuffer(b"".join(raw), dtype=np.uint8), offs, bool(with_offsets))
+        nb = norm.tobytes()
+        out = []
+        for i in range(len(raw)):
+            s = nb[int(no[i]):int(no[i + 1])].decode("utf-8", "surrogateescape")
+            if with_offsets:
+                a = n2o[int(no[i]) + i:int(no[i + 1]) + i + 1]
+                out.append((s, [] if (len(a) == 1 and a[0] == 0xFFFFFFFF) else [int(v) for v in a]))
+            else:
+                out.append(s)
+        return out[0] if single else out
+
+    normalize = Normalize
 
     # ----------------------------------------------------------- decode ----
     def Decode(self, input, out_type=str, num_threads=None):

@@ -14,7 +14,7 @@
 namespace sentencepiece = sentencepiece_amd;   // the one-line switch INTEGRATION.md describes
 
 int main(int argc, char **argv) {
-  if (argc < 3) { fprintf(stderr, "usage: facade_test MODEL TEXTFILE|--expect-unavailable [extra_options]\n"); return 2; }
+  if (argc < 3) { fprintf(stderr, "usage: facade_test MODEL TEXTFILE|--expect-unavailable [extra_options [--pieces]]\n"); return 2; }
   sentencepiece::SentencePieceProcessor sp;
   if (sp.status().ok()) { fprintf(stderr, "status() must fail before Load\n"); return 1; }
   const sentencepiece::util::Status st = sp.Load(argv[1]);
@@ -32,6 +32,28 @@ int main(int argc, char **argv) {
   std::ifstream f(argv[2], std::ios::binary);
   std::vector<std::string> lines;
   for (std::string line; std::getline(f, line);) lines.push_back(line);
+  if (argc > 4 && std::string(argv[4]) == "--pieces") {
+    // one line per sentence: hex(piece):id:begin:end ..., then "N " + hex(normalized) + the norm_to_orig entries
+    auto hex = [](const std::string &x) { static const char *d = "0123456789abcdef"; std::string o; for (unsigned char c : x) { o += d[c >> 4]; o += d[c & 15]; } return o.empty() ? std::string("-") : o; };
+    for (const std::string &line : lines) {
+      sentencepiece::SentencePieceText spt;
+      if (!sp.Encode(line, &spt).ok() || spt.text != line) { fprintf(stderr, "Encode(spt) failed\n"); return 1; }
+      std::ostringstream os;
+      for (const auto &p : spt.pieces) {
+        if (p.surface != line.substr(p.begin, p.end - p.begin)) { fprintf(stderr, "surface\n"); return 1; }
+        os << hex(p.piece) << ":" << p.id << ":" << p.begin << ":" << p.end << " ";
+      }
+      std::vector<std::string> pcs = sp.EncodeAsPieces(line);
+      if (pcs.size() != spt.pieces.size()) { fprintf(stderr, "EncodeAsPieces\n"); return 1; }
+      std::string norm;
+      std::vector<size_t> n2o;
+      if (!sp.Normalize(line, &norm, &n2o).ok() || sp.Normalize(line) != norm) { fprintf(stderr, "Normalize failed\n"); return 1; }
+      os << "N " << hex(norm);
+      for (size_t v : n2o) os << " " << v;
+      std::cout << os.str() << "\n";
+    }
+    return 0;
+  }
   std::vector<std::string_view> views(lines.begin(), lines.end());
   std::vector<std::vector<int>> batch;
   if (!sp.EncodeBatch(views, &batch).ok() || batch.size() != lines.size()) { fprintf(stderr, "EncodeBatch failed\n"); return 1; }
@@ -45,6 +67,6 @@ int main(int argc, char **argv) {
     std::cout << os.str() << "\n";
   }
   if (sp.GetPieceSize() <= 0 || sp.IdToPiece(sp.unk_id()).empty() || sp.PieceToId(sp.IdToPiece(5)) != 5) { fprintf(stderr, "vocab accessors\n"); return 1; }
-  if (sp.Encode("x", nullptr).ok()) { fprintf(stderr, "null output accepted\n"); return 1; }
+  if (sp.Encode("x", static_cast<std::vector<int> *>(nullptr)).ok()) { fprintf(stderr, "null output accepted\n"); return 1; }
   return 0;
 }

@@ -191,6 +191,7 @@ int emu_reset_vocabulary(void *hv) {
 // per launch.  Returns total ids, or -(needed) - 2 if cap is too small; the
 // device status word is returned in *status.
 static uint32_t *g_span_begin = nullptr, *g_span_end = nullptr;   // set by emu_encode_spans_batch around its call
+static uint32_t *g_nspan_begin = nullptr, *g_nspan_end = nullptr;
 
 int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, uint64_t n, int32_t *ids, uint64_t cap,
                          uint64_t *id_offs, int grid, uint32_t *status_out) {
@@ -306,9 +307,10 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
       aa.dev = dev; aa.text = text; aa.offs = offs;
       aa.list = lists.data() + static_cast<size_t>(c) * n; aa.list_count = &list_counts[c];
       aa.id_offs = id_offs; aa.tok_begin = tokb.data(); aa.begin = g_span_begin; aa.end = g_span_end;
+      aa.nbegin = g_nspan_begin; aa.nend = g_nspan_end;
       aa.status = &status; aa.rcap = cls[c].rcap; aa.ncap = cls[c].ncap;
       aa.has_next = (c + 1 < ncls && cls[c + 1].rcap <= kEmuMaxStagedRaw) ? 1u : 0u;
-      std::vector<unsigned char> smem(AlignLdsBytes(aa.rcap, aa.ncap) + 64, 0xCD);
+      std::vector<unsigned char> smem(AlignLdsBytes(aa.rcap, aa.ncap, aa.nbegin != nullptr) + 64, 0xCD);
       for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, smem.data(), [&] { align_block(aa, smem.data()); });
     }
     if (status_out) *status_out = status;
@@ -319,11 +321,65 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
 
 // The spans form (kernels_align.h): begin / end hold cap entries.
 int64_t emu_encode_spans_batch(void *hv, const uint8_t *text, const uint64_t *offs, uint64_t n, int32_t *ids, uint32_t *begin,
-                               uint32_t *end, uint64_t cap, uint64_t *id_offs, int grid, uint32_t *status_out) {
-  g_span_begin = begin; g_span_end = end;
+                               uint32_t *end, uint64_t cap, uint64_t *id_offs, int grid, uint32_t *status_out,
+                               uint32_t *nbegin, uint32_t *nend) {
+  g_span_begin = begin; g_span_end = end; g_nspan_begin = nbegin; g_nspan_end = nbegin ? nend : nullptr;
   const int64_t r = emu_encode_batch(hv, text, offs, n, ids, cap, id_offs, grid, status_out);
-  g_span_begin = g_span_end = nullptr;
+  g_span_begin = g_span_end = g_nspan_begin = g_nspan_end = nullptr;
   return r;
+}
+
+// Batch Normalize as csrc/api.cc runs it: classify -> count pass per class -> scan -> write pass per class.
+// Returns total normalized bytes, -(needed) - 2 if cap is too small, -1 with the status on a failure.
+int64_t emu_normalize_batch(void *hv, const uint8_t *text, const uint64_t *offs, uint64_t n, uint8_t *norm, uint64_t cap,
+                            uint64_t *norm_offs, uint32_t *n2o, int grid, uint32_t *status_out) {
+  auto *h = static_cast<EmuHandle *>(hv);
+  const SpmxDev &dev = h->tables.scalars;
+  const bool bpe = dev.model_type == 2;
+  const LengthClass *cls = bpe ? kBpeCls : kUniCls;
+  const int ncls = bpe ? static_cast<int>(sizeof(kBpeCls) / sizeof(kBpeCls[0])) : static_cast<int>(sizeof(kUniCls) / sizeof(kUniCls[0]));
+  if (grid < 1) grid = 1;
+  std::vector<uint32_t> lists(static_cast<size_t>(ncls) * (n ? n : 1)), list_counts(kMaxClasses, 0), counts(n + 1, 0);
+  ClassifyArgs ca{};
+  ca.offs = offs; ca.n = static_cast<uint32_t>(n); ca.n_classes = static_cast<uint32_t>(ncls);
+  for (int c = 0; c < ncls; ++c) ca.rcap[c] = cls[c].rcap;
+  ca.lists = lists.data(); ca.list_counts = list_counts.data();
+  std::vector<uint32_t> key_totals(kSortKeys, 0), key_cursor(kSortKeys, 0), hist(3 * kSortKeys, 0);
+  ca.key_totals = key_totals.data(); ca.key_cursor = key_cursor.data();
+  for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { classify_block<0>(ca, hist.data()); });
+  for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { classify_block<1>(ca, hist.data()); });
+  uint32_t status = 0;
+  auto pass = [&](bool write) {
+    for (int c = 0; c < ncls; ++c) {
+      if (cls[c].rcap > kEmuMaxStagedRaw) { if (list_counts[c]) status |= kStTooLong; continue; }
+      NormalizeArgs a{};
+      a.dev = dev; a.text = text; a.offs = offs;
+      a.list = lists.data() + static_cast<size_t>(c) * n; a.list_count = &list_counts[c];
+      const bool has_next = c + 1 < ncls && cls[c + 1].rcap <= kEmuMaxStagedRaw;
+      a.next_list = has_next ? lists.data() + static_cast<size_t>(c + 1) * n : nullptr;
+      a.next_count = has_next ? &list_counts[c + 1] : nullptr;
+      a.counts = counts.data(); a.norm_offs = norm_offs; a.norm = norm; a.n2o = n2o; a.status = &status;
+      a.rcap = cls[c].rcap; a.ncap = cls[c].ncap;
+      std::vector<unsigned char> smem(NormalizeLdsBytes(a.rcap, a.ncap) + 64, 0xCD);
+      for (int b = 0; b < grid; ++b) {
+        if (write) emu::RunWave(b, grid, smem.data(), [&] { normalize_block<true>(a, smem.data()); });
+        else emu::RunWave(b, grid, smem.data(), [&] { normalize_block<false>(a, smem.data()); });
+      }
+    }
+  };
+  pass(false);
+  std::vector<uint64_t> tile_sums((n + kScanTile - 1) / kScanTile + 2, 0);
+  ScanArgs sa{counts.data(), static_cast<uint32_t>(n), tile_sums.data(), norm_offs};
+  for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { scan_tiles_block(sa); });
+  emu::RunWave(0, 1, nullptr, [&] { scan_sums_block(sa); });
+  for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { scan_final_block(sa); });
+  if (status_out) *status_out = status;
+  if (status) return -1;
+  const uint64_t total = norm_offs[n];
+  if (total > cap) return -static_cast<int64_t>(total) - 2;
+  pass(true);
+  if (status_out) *status_out = status;
+  return status ? -1 : static_cast<int64_t>(total);
 }
 
 // Batch Decode as csrc/api.cc runs it: count pass -> scan -> write pass.  Returns total bytes, -(needed) - 2 if cap

@@ -30,7 +30,11 @@ class EmuLib:
                                          C.c_void_p, C.c_int, C.c_void_p]
         lib.emu_encode_spans_batch.restype = C.c_int64
         lib.emu_encode_spans_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
-                                               C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
+                                               C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                               C.c_void_p]
+        lib.emu_normalize_batch.restype = C.c_int64
+        lib.emu_normalize_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                            C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         lib.emu_split_lines.restype = C.c_int64
         lib.emu_split_lines.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         lib.emu_flags.restype = C.c_uint32
@@ -113,8 +117,30 @@ class EmuHandle:
         return ids[:tot].copy(), id_offs
 
 
-def _emu_encode_spans(self, text, offs, grid=3):
-    """-> (ids, begin, end, id_offsets) through the device kernels (encode in spans form + align)."""
+def _emu_normalize_batch(self, text, offs, grid=3):
+    """-> (normalized uint8, norm_offsets, n2o) through the device normalize kernels."""
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    n = len(offs) - 1
+    cap = int(len(text)) * 20 + 8 * n + 64
+    out = np.full(cap, 0xCD, dtype=np.uint8)
+    no = np.zeros(n + 1, dtype=np.uint64)
+    n2o = np.full(cap + n + 1, 0xCDCDCDCD, dtype=np.uint32)
+    st = C.c_uint32(0)
+    tot = self.lib.emu_normalize_batch(self.h, text.ctypes.data if len(text) else None, offs.ctypes.data, n,
+                                       out.ctypes.data, cap, no.ctypes.data, n2o.ctypes.data, grid, C.byref(st))
+    self.status = st.value
+    if tot < 0:
+        raise RuntimeError("emu_normalize_batch failed: %d status %d" % (tot, st.value))
+    assert (out[tot:] == 0xCD).all() and (n2o[tot + n:] == 0xCDCDCDCD).all(), "write past the end"
+    return out[:tot].copy(), no, n2o[:tot + n].copy()
+
+
+EmuHandle.normalize_batch = _emu_normalize_batch
+
+
+def _emu_encode_spans(self, text, offs, grid=3, norm_spans=False):
+    """-> (ids, begin, end, id_offsets[, nbegin, nend]) through the device kernels (encode in spans form + align)."""
     text = np.ascontiguousarray(text, dtype=np.uint8)
     offs = np.ascontiguousarray(offs, dtype=np.uint64)
     n = len(offs) - 1
@@ -124,12 +150,17 @@ def _emu_encode_spans(self, text, offs, grid=3):
     end = np.full(cap, 0xCDCDCDCD, dtype=np.uint32)
     id_offs = np.zeros(n + 1, dtype=np.uint64)
     st = C.c_uint32(0)
+    nb = np.full(cap, 0xCDCDCDCD, dtype=np.uint32)
+    ne = np.full(cap, 0xCDCDCDCD, dtype=np.uint32)
     tot = self.lib.emu_encode_spans_batch(self.h, text.ctypes.data if len(text) else None, offs.ctypes.data, n,
                                           ids.ctypes.data, begin.ctypes.data, end.ctypes.data, cap, id_offs.ctypes.data,
-                                          grid, C.byref(st))
+                                          grid, C.byref(st), nb.ctypes.data if norm_spans else None,
+                                          ne.ctypes.data if norm_spans else None)
     self.status = st.value
     if tot < 0:
         raise RuntimeError("emu_encode_spans_batch failed: %d status %d" % (tot, st.value))
+    if norm_spans:
+        return ids[:tot].copy(), begin[:tot].copy(), end[:tot].copy(), id_offs, nb[:tot].copy(), ne[:tot].copy()
     return ids[:tot].copy(), begin[:tot].copy(), end[:tot].copy(), id_offs
 
 

@@ -152,3 +152,17 @@ def _oracle_encode_spans(self, text, offs):
 
 
 OracleHandle.encode_spans = _oracle_encode_spans
+
+
+def _oracle_encode_pieces(self, text, offs):
+    from tests import pieceslib
+    return pieceslib.encode_pieces(self.lib.oracle_encode_pieces_batch, self.h, text, offs)
+
+
+def _oracle_normalize_batch(self, text, offs):
+    from tests import pieceslib
+    return pieceslib.normalize_batch(self.lib.oracle_normalize_batch, self.h, text, offs)
+
+
+OracleHandle.encode_pieces = _oracle_encode_pieces
+OracleHandle.normalize_batch = _oracle_normalize_batch

@@ -162,3 +162,17 @@ def _ref_encode_spans(self, text, offs):
 
 
 RefHandle.encode_spans = _ref_encode_spans
+
+
+def _spmref_encode_pieces(self, text, offs):
+    from tests import pieceslib
+    return pieceslib.encode_pieces(self.lib.spmref_encode_pieces_batch, self.h, text, offs)
+
+
+def _spmref_normalize_batch(self, text, offs):
+    from tests import pieceslib
+    return pieceslib.normalize_batch(self.lib.spmref_normalize_batch, self.h, text, offs)
+
+
+RefHandle.encode_pieces = _spmref_encode_pieces
+RefHandle.normalize_batch = _spmref_normalize_batch

@@ -46,3 +46,39 @@ def test_facade_matches_golden(model, opts, key, golden_arrays, tmp_path):
     assert out.returncode == 0, out.stderr
     ids = np.array([int(x) for line in out.stdout.split("\n") for x in line.split()], dtype=np.int32)
     np.testing.assert_array_equal(ids, golden_arrays[key + "__ids"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,opts", [("test_model", ""), ("uni1k_bf", "bos:eos:unk_piece"), ("bpe1k", "reverse"), ("test_ja_model", "")])
+def test_facade_pieces_and_normalize(model, opts, oracle, tmp_path):
+    """Encode(input, SentencePieceText*), EncodeAsPieces and Normalize of the facade against the oracle."""
+    b = _build()
+    src = open(os.path.join(fixtures.GOLDEN, "botchan.txt"), "rb").read().split(b"\n")[:300]
+    src += ["吾輩は猫である。 名前は まだ無い".encode(), b"  lead and trail  ", b"", b"\xff\xfe broken", "ＡＢＣ㍿".encode()]
+    path = tmp_path / "in.txt"
+    path.write_bytes(b"\n".join(src) + b"\n")
+    out = subprocess.run([b, os.path.join(fixtures.GOLDEN, model + ".model"), str(path), opts, "--pieces"], capture_output=True)
+    assert out.returncode == 0, out.stderr
+    o = oracle.load(fixtures.model_blob(model))
+    o.set_encode_extra_options(opts)
+    offs = np.zeros(len(src) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(x) for x in src])
+    text = np.frombuffer(b"".join(src), dtype=np.uint8)
+    ids, bg, en, io, pblob, poffs = o.encode_pieces(text, offs)
+    norm, no, n2o = o.normalize_batch(text, offs)
+    lines = out.stdout.decode().split("\n")
+    assert len(lines) == len(src) + 1
+    for i in range(len(src)):
+        toks, rest = lines[i].split("N ")
+        got = [t.split(":") for t in toks.split()]
+        want = []
+        for k in range(int(io[i]), int(io[i + 1])):
+            pc = pblob[int(poffs[k]):int(poffs[k + 1])]
+            want.append([pc.hex() or "-", str(int(ids[k])), str(int(bg[k])), str(int(en[k]))])
+        assert got == want, i
+        f = rest.split()
+        nb = norm[int(no[i]):int(no[i + 1])].tobytes()
+        assert f[0] == (nb.hex() or "-"), i
+        a = n2o[int(no[i]) + i:int(no[i + 1]) + i + 1]
+        want_a = [] if (len(a) == 1 and a[0] == 0xFFFFFFFF) else [str(int(v)) for v in a]
+        assert f[1:] == want_a, i

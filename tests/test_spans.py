@@ -145,3 +145,38 @@ def test_gpu_spans_device_form_and_limits(oracle, corpora):
         sp.EncodeSpansPacked(long_text, np.array([0, len(long_text)], dtype=np.uint64))
     ids, io = sp.EncodePacked(long_text, np.array([0, len(long_text)], dtype=np.uint64))   # the ids form still takes it
     assert len(ids) > 0
+
+
+# ---- golden digests made by the compiled reference (scripts/make_fixtures.py --only spans) ----
+def _keys():
+    import json
+    import os
+    with open(os.path.join(fixtures.GOLDEN, "manifest.json")) as f:
+        return sorted(k for k in json.load(f) if not k.startswith("_"))
+
+
+def _digest(b, e):
+    import hashlib
+    return hashlib.sha256(np.asarray(b).astype("<u4").tobytes() + np.asarray(e).astype("<u4").tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("key", _keys())
+def test_oracle_spans_golden(key, manifest, oracle, corpora):
+    m = manifest[key]
+    o = oracle.load(fixtures.model_blob(m["model"]))
+    o.set_encode_extra_options(m["options"])
+    ids, b, e, _ = o.encode_spans(*corpora[m["corpus"]])
+    assert len(ids) == m["tokens"]
+    assert _digest(b, e) == m["spans_sha256"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", _keys())
+def test_gpu_spans_golden(key, manifest, corpora):
+    from sentencepiece_amd.processor import SentencePieceProcessor
+    m = manifest[key]
+    sp = SentencePieceProcessor(model_proto=fixtures.model_blob(m["model"]))
+    sp.SetEncodeExtraOptions(m["options"])
+    ids, b, e, _ = sp.EncodeSpansPacked(*corpora[m["corpus"]])
+    assert len(ids) == m["tokens"]
+    assert _digest(b, e) == m["spans_sha256"]
