@@ -119,6 +119,8 @@ struct spmx_handle {
   char slot_name[kMaxSlots][40] = {{0}};
   bool slot_used[kMaxSlots] = {false};
   bool no_lane_general = false;      // SPMX_NO_LANE_GENERAL=1: FAST kernels hand every non-ASCII sentence to GENERAL
+  uint32_t lane_general_max_raw = kLaneGeneralMaxRaw, lane_general_min_lanes = 0;   // SPMX_LANE_GENERAL_MAX_RAW / _MIN_LANES (0: per class)
+  bool no_merge_general = false;     // SPMX_NO_MERGE_GENERAL=1: a GENERAL launch per class (A/B measurements)
   bool no_stream = false;            // SPMX_NO_STREAM=1: BPE in the sentence-per-wave form only (A/B measurements)
   uint64_t stream_scratch_limit = 4ull << 30;   // SPMX_STREAM_SCRATCH_MB: cap on the streaming kernels' HBM scratch
   DevBuf<uint32_t> d_stream;         // scratch of the streaming kernels (text columns + back-pointer words)
@@ -308,6 +310,12 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
     const bool bpe_stream = h->model.model_type == kBpe && (h->dev.flags & kNfBpeWordwise) && !(h->dev.flags & kNfHasUnused);
     const bool streaming = h->model.model_type == kUnigram || (bpe_stream && !h->no_stream);
     uint32_t known[kMaxClasses] = {0};   // class sizes after classify (escalations from a GENERAL kernel come on top)
+    // The GENERAL kernel of a class is latency-bound (a few thousand leftover sentences, one serial recurrence each:
+    // 0.7 ms for class 0 of the C2 bench whatever the count), so the two short classes share one: class 0's FAST
+    // kernel appends to the same hand-over list as class 1's and the GENERAL launch of class 1 (whose capacities
+    // cover both) takes them all.
+    const bool merge01 = streaming && StreamFastEligible(h->dev.flags) && !h->no_fast && !h->no_merge_general && ncls >= 2 &&
+                         cls[1].rcap <= kMaxStagedRaw;
     if (streaming) {
       HIP_OR_RETURN(h, hipMemcpyAsync(h->h_ctrl->list_counts, h->d_ctrl->list_counts, sizeof(h->h_ctrl->list_counts),
                                       hipMemcpyDeviceToHost, stream));
@@ -317,7 +325,8 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
       uint64_t need = 0;
       bool prev_general = false;
       for (int c = 0; c < ncls; ++c) {
-        if (known[c] == 0 && !prev_general) continue;
+        const bool shared01 = merge01 && c == 1 && known[0] > 0;   // class 1's GENERAL launch also takes class 0's leftovers
+        if (known[c] == 0 && !prev_general && !shared01) continue;
         const bool fast = StreamFastEligible(h->dev.flags) && !h->no_fast && known[c] > 0;
         const bool staged = cls[c].rcap <= kMaxStagedRaw;   // document-length classes: FAST kernel only
         if (!staged && known[c] > 0 && !fast)
@@ -326,11 +335,12 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
         if (!staged && known[c] > 0 && spans)
           return Fail(h, kOutOfRange, "a sentence is longer than 8192 bytes: the spans form is limited to that");
         if (!staged && !fast) continue;
-        for (int pass = fast ? 0 : 1; pass < (staged ? 2 : 1); ++pass) {
-          StreamPlan sp = PlanStream(h, cls[c], pass == 0, known[c]);
+        const bool general = staged && !(merge01 && c == 0);
+        for (int pass = fast ? 0 : 1; pass < (general ? 2 : 1); ++pass) {
+          StreamPlan sp = PlanStream(h, cls[c], pass == 0, pass == 1 && shared01 ? known[0] + known[1] : known[c]);
           if (sp.scratch_words > need) need = sp.scratch_words;
         }
-        prev_general = true;
+        prev_general = general;
       }
       HIP_OR_RETURN(h, h->d_stream.Reserve(need));
     }
@@ -349,22 +359,30 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
       a.stats = &h->d_ctrl->stats[kStatsPerClass * c];
       a.rcap = cls[c].rcap; a.ncap = cls[c].ncap;
       a.no_lane_general = h->no_lane_general ? 1u : 0u;
+      a.lane_general_max_raw = h->lane_general_max_raw;
+      // short classes: a stray non-ASCII sentence would hold 63 ASCII lanes up, so a tile needs 16 of them to keep
+      // them; long classes: the position-parallel normalizer of the GENERAL kernel takes one sentence per wave at
+      // a time, so 4 are enough (C5, 1 M sentences: 51.8 -> 45.2 ms per step)
+      a.lane_general_min_lanes = h->lane_general_min_lanes ? h->lane_general_min_lanes : (cls[c].rcap <= 576 ? 16u : 4u);
       a.arena_tb = spans ? h->d_arena_tb.p : nullptr;
       if (streaming) {
-        if (known[c] == 0 && !prev_general) continue;
+        const bool shared01 = merge01 && c == 1 && known[0] > 0;
+        if (known[c] == 0 && !prev_general && !shared01) continue;
         a.ring = ScoreRing(h->tables.max_piece_len);
         const bool fast = StreamFastEligible(h->dev.flags) && !h->no_fast && known[c] > 0;
         const bool staged = cls[c].rcap <= kMaxStagedRaw;
         if (!staged && !fast) continue;
-        for (int pass = fast ? 0 : 1; pass < (staged ? 2 : 1); ++pass) {
+        const bool general = staged && !(merge01 && c == 0);
+        const int hl = (merge01 && c <= 1) ? 0 : c;          // which hand-over list this class uses
+        for (int pass = fast ? 0 : 1; pass < (general ? 2 : 1); ++pass) {
           const bool is_fast = pass == 0;
-          const StreamPlan sp = PlanStream(h, cls[c], is_fast, known[c]);
+          const StreamPlan sp = PlanStream(h, cls[c], is_fast, !is_fast && shared01 ? known[0] + known[1] : known[c]);
           if (is_fast) {
-            a.hard_list = staged ? h->d_lists.p + static_cast<size_t>(ncls + c) * n : nullptr;   // no GENERAL kernel to hand over to
-            a.hard_count = &h->d_ctrl->hard_counts[c];
-          } else if (fast) {
-            a.list = h->d_lists.p + static_cast<size_t>(ncls + c) * n;
-            a.list_count = &h->d_ctrl->hard_counts[c];
+            a.hard_list = staged ? h->d_lists.p + static_cast<size_t>(ncls + hl) * n : nullptr;   // no GENERAL kernel to hand over to
+            a.hard_count = &h->d_ctrl->hard_counts[hl];
+          } else if (fast || shared01) {
+            a.list = h->d_lists.p + static_cast<size_t>(ncls + hl) * n;
+            a.list_count = &h->d_ctrl->hard_counts[hl];
             a.hard_list = nullptr; a.hard_count = nullptr;
           }
           a.stream_tcap = sp.tcap;
@@ -384,7 +402,7 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
           if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[slot][1], stream));
           h->slot_used[slot] = true;
         }
-        prev_general = true;
+        prev_general = general;
         if (bpe_stream) {   // what the lane form could not take (a word longer than kBpeWordMax): sentence per wave
           a.list = h->d_lists.p + static_cast<size_t>(2 * ncls + c) * n;
           a.list_count = &h->d_ctrl->wave_counts[c];
@@ -470,24 +488,39 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
       const uint64_t cgrid = cblocks < static_cast<uint64_t>(h->n_cu) * 32 ? cblocks : static_cast<uint64_t>(h->n_cu) * 32;
       HIP_OR_RETURN(h, LaunchCompact(pa, static_cast<int>(cgrid), stream));
       HIP_OR_RETURN(h, hipMemsetAsync(&h->d_ctrl->status, 0, sizeof(uint32_t), stream));
+      // the hand-over lists of the encode are dead by now: they serve as the align kernels' escalation lists
+      HIP_OR_RETURN(h, hipMemsetAsync(h->d_ctrl->hard_counts, 0, sizeof(h->d_ctrl->hard_counts), stream));
+      bool prev = false;
       for (int c = 0; c < ncls; ++c) {
         const uint32_t cnt = h->h_ctrl->list_counts[c];
-        if (cnt == 0) continue;
-        if (cls[c].rcap > kMaxStagedRaw) return Fail(h, kOutOfRange, "a sentence is longer than 8192 bytes: the spans form is limited to that");
+        if (cls[c].rcap > kMaxStagedRaw) {
+          if (cnt) return Fail(h, kOutOfRange, "a sentence is longer than 8192 bytes: the spans form is limited to that");
+          continue;
+        }
+        if (cnt == 0 && !prev) continue;
+        const bool has_next = c + 1 < ncls && cls[c + 1].rcap <= kMaxStagedRaw;
         AlignArgs aa{};
         aa.dev = h->dev; aa.text = d_text; aa.offs = d_offsets;
-        aa.list = h->d_lists.p + static_cast<size_t>(c) * n; aa.list_count = &h->d_ctrl->list_counts[c];
         aa.id_offs = d_id_offsets; aa.tok_begin = h->d_tok_begin.p; aa.begin = d_begin; aa.end = d_end;
         aa.nbegin = d_nbegin; aa.nend = d_nbegin ? d_nend : nullptr;
         aa.status = &h->d_ctrl->status; aa.rcap = cls[c].rcap; aa.ncap = cls[c].ncap;
-        aa.has_next = (c + 1 < ncls && cls[c + 1].rcap <= kMaxStagedRaw) ? 1u : 0u;
+        aa.next_list = has_next ? h->d_lists.p + static_cast<size_t>(ncls + c + 1) * n : nullptr;
+        aa.next_count = has_next ? &h->d_ctrl->hard_counts[c + 1] : nullptr;
+        aa.list_cap = n32;
         const uint32_t lds = AlignLdsBytes(aa.rcap, aa.ncap, aa.nbegin != nullptr && aa.nend != nullptr);
         int per_cu = static_cast<int>(kLdsPerCu / lds);
         if (per_cu > 32) per_cu = 32;
         if (per_cu < 1) per_cu = 1;
-        uint64_t grid = static_cast<uint64_t>(h->n_cu) * per_cu;
-        if (grid > cnt) grid = cnt;
-        HIP_OR_RETURN(h, LaunchAlign(aa, static_cast<int>(grid), lds, stream));
+        const uint64_t full = static_cast<uint64_t>(h->n_cu) * per_cu;
+        if (cnt) {                       // the class's own sentences
+          aa.list = h->d_lists.p + static_cast<size_t>(c) * n; aa.list_count = &h->d_ctrl->list_counts[c];
+          HIP_OR_RETURN(h, LaunchAlign(aa, static_cast<int>(full < cnt ? full : cnt), lds, stream));
+        }
+        if (prev) {                      // what the previous class's align kernels could not hold (count on the device)
+          aa.list = h->d_lists.p + static_cast<size_t>(ncls + c) * n; aa.list_count = &h->d_ctrl->hard_counts[c];
+          HIP_OR_RETURN(h, LaunchAlign(aa, static_cast<int>(full < 256 ? full : 256), lds, stream));
+        }
+        prev = true;
       }
       uint32_t st2 = 0;
       HIP_OR_RETURN(h, hipMemcpyAsync(&st2, &h->d_ctrl->status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -661,6 +694,9 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
   if (const char *e = getenv("SPMX_NO_FAST")) h->no_fast = e[0] == '1';
   if (const char *e = getenv("SPMX_NO_STREAM")) h->no_stream = e[0] == '1';
   if (const char *e = getenv("SPMX_NO_LANE_GENERAL")) h->no_lane_general = e[0] == '1';
+  if (const char *e = getenv("SPMX_NO_MERGE_GENERAL")) h->no_merge_general = e[0] == '1';
+  if (const char *e = getenv("SPMX_LANE_GENERAL_MAX_RAW")) h->lane_general_max_raw = static_cast<uint32_t>(atoi(e));
+  if (const char *e = getenv("SPMX_LANE_GENERAL_MIN_LANES")) h->lane_general_min_lanes = static_cast<uint32_t>(atoi(e));
   if (const char *e = getenv("SPMX_STREAM_SCRATCH_MB")) h->stream_scratch_limit = static_cast<uint64_t>(atoll(e)) << 20;
   if (const char *e = getenv("SPMX_TILE_WAVES")) h->tile_waves_override = atoi(e);
   if ((e = hipMalloc(reinterpret_cast<void **>(&h->d_ctrl), sizeof(Ctrl))) != hipSuccess) return bail(e, "hipMalloc(ctrl)");

@@ -53,6 +53,8 @@ struct EncodeArgs {
   uint32_t *stream_bp;          // [waves][StreamBpWords(stream_tcap)]
   uint32_t stream_tcap;         // bytes a text column holds
   uint32_t no_lane_general;     // A/B switch: FAST kernels hand every non-ASCII sentence to the GENERAL kernel
+  uint32_t lane_general_max_raw;   // FAST kernels: length classes (rcap) whose tiles may use the per-lane general normalizer
+  uint32_t lane_general_min_lanes; // ... when at least this many lanes of the tile need it
   uint32_t *wave_list;          // BPE streaming kernels: sentences they leave to the sentence-per-wave kernel
   uint32_t *wave_count;
   int32_t *arena_tb;            // spans form (kernels_align.h), else null: next to every body id in `arena`, the

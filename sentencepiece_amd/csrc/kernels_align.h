@@ -9,6 +9,8 @@
 // encode kernels record b only (EncodeArgs::arena_tb; the byte pieces of a character share theirs), and this
 // kernel -- a second, cold pass, one sentence per wavefront -- runs the position-parallel normalizer again with its
 // norm_to_orig output switched on and translates.  The hot kernels carry no alignment state.
+// It walks the length-class lists of the classify kernels with an escalation list of its own (a sentence the
+// encode moved to a later class is simply seen twice: the writes are idempotent).
 #ifndef SPMX_KERNELS_ALIGN_H_
 #define SPMX_KERNELS_ALIGN_H_
 
@@ -27,7 +29,9 @@ struct AlignArgs {
                                 // returns it: U+2581 takes three bytes there); 0, 0 for a bos / eos
   uint32_t *status;
   uint32_t rcap, ncap;          // LDS capacities, those of the encode class
-  uint32_t has_next;            // a sentence that overflows ncap is also in a later class's list: leave it to that
+  uint32_t *next_list;          // a sentence whose normalized form overflows ncap goes to the next class's align
+  uint32_t *next_count;         // list (null past the last staged class: the call fails)
+  uint32_t list_cap;            // entries a list holds
 };
 
 inline uint32_t AlignLdsBytes(uint32_t rcap, uint32_t ncap, bool norm_spans) {
@@ -45,7 +49,7 @@ SPMX_DEVICE void align_block(const AlignArgs &a, unsigned char *smem) {
   const bool nspans = a.nbegin != nullptr && a.nend != nullptr;
   const bool one = (d.flags & kNfCompressSp) != 0;
   const bool reverse = (d.flags & kNfReverse) != 0;
-  const uint32_t count = *a.list_count;
+  const uint32_t count = *a.list_count < a.list_cap ? *a.list_count : a.list_cap;
   for (uint32_t item = static_cast<uint32_t>(wv::block_id()); item < count; item += static_cast<uint32_t>(wv::grid_size())) {
     const uint32_t sid = a.list[item];
     const uint64_t beg = a.offs[sid];
@@ -65,7 +69,15 @@ SPMX_DEVICE void align_block(const AlignArgs &a, unsigned char *smem) {
     int fin = L, nlen = 0;
     if (L > 0) nlen = normalize_wave(d, raw, L, norm, static_cast<int>(a.ncap), lane, orig, &fin);
     if (nlen < 0) {
-      if (!a.has_next && lane == 0) wv::atomic_or(a.status, kStTooLong);
+      if (lane == 0) {
+        if (a.next_list) {
+          const uint32_t at = wv::atomic_add(a.next_count, 1u);
+          if (at < a.list_cap) a.next_list[at] = sid;
+          else wv::atomic_or(a.status, kStInternal);
+        } else {
+          wv::atomic_or(a.status, kStTooLong);
+        }
+      }
       wv::sync();
       continue;
     }

@@ -133,10 +133,11 @@ SPMX_DEVICE StreamLds carve_stream(unsigned char *base, bool fast, int model, ui
 // whose bcls entry says kBcComplex makes the lane give up (-1).
 // *n_sp: how many bytes of the result are the space symbol (sizes the id slot under byte fallback).
 SPMX_DEVICE int fast_norm_stream(const SpmxDev &d, const uint8_t *gtext, uint64_t beg, int L, uint32_t *gt,
-                                 const uint8_t *bcls, int *n_sp) {
+                                 const uint8_t *bcls, int tcap, int *n_sp) {
   const uint32_t F = d.flags;
   const bool rm = (F & kNfRemoveExtraWs) != 0;
   const uint32_t sp = (F & kNfCompressSp) ? kSpByte : 0x20u;
+  const bool has_map = (F & kNfHasCharsmap) != 0;
   int w = 0, nsp = 0;
   uint32_t acc = 0;
   if (F & kNfAddDummyPrefix) { acc = sp; w = 1; nsp = 1; }   // :128
@@ -144,6 +145,8 @@ SPMX_DEVICE int fast_norm_stream(const SpmxDev &d, const uint8_t *gtext, uint64_
   int wl = w;                     // output length up to the last non-space byte (:166-176 trailing spaces)
   bool seen = false;              // some prefix is not " " (:86-100)
   uint32_t bad = 0;
+  uint32_t carry = 0x80u;         // the last byte of the previous block
+  int skip = 0;                   // continuation bytes of a validated character still to copy
   const uint64_t q0 = beg & ~15ull;
   const uint8_t *blk = gtext + q0;
   int rel = static_cast<int>(q0 - beg);         // index of the block's first byte within the sentence (<= 0 at first)
@@ -151,23 +154,100 @@ SPMX_DEVICE int fast_norm_stream(const SpmxDev &d, const uint8_t *gtext, uint64_
   while (rel < L) {
     Q4 nxt = cur;
     if (rel + 16 < L) nxt = *reinterpret_cast<const Q4 *>(blk + 16);
-    const uint32_t wd[4] = {cur.x, cur.y, cur.z, cur.w};
+    const uint32_t wd[8] = {cur.x, cur.y, cur.z, cur.w, nxt.x, nxt.y, nxt.z, nxt.w};
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const uint32_t c = (wd[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-      if (static_cast<uint32_t>(rel + k) < static_cast<uint32_t>(L)) {
-        bad |= bcls[c];
-        const bool is_sp = c == 0x20u;
-        if (!is_sp || !P) {                     // :137-138 a space after a space is dropped
-          acc |= (is_sp ? sp : c) << (8 * (w & 3));
-          ++w;
-          nsp += is_sp ? 1 : 0;
-          if ((w & 3) == 0) { gt[((w >> 2) - 1) * 64] = acc; acc = 0; }
+    for (int q = 0; q < 4; ++q) {
+      if ((wd[q] & 0x80808080u) == 0u) {
+        // ---- four ASCII bytes: every NormalizePrefix result is the byte itself ----
+#pragma unroll
+        for (int k = 4 * q; k < 4 * q + 4; ++k) {
+          const uint32_t c = (wd[q] >> (8 * (k & 3))) & 0xFFu;
+          if (static_cast<uint32_t>(rel + k) < static_cast<uint32_t>(L)) {
+            bad |= bcls[c];
+            const bool is_sp = c == 0x20u;
+            if (!is_sp || !P) {                     // :137-138 a space after a space is dropped
+              acc |= (is_sp ? sp : c) << (8 * (w & 3));
+              ++w;
+              nsp += is_sp ? 1 : 0;
+              if ((w & 3) == 0) { gt[((w >> 2) - 1) * 64] = acc; acc = 0; }
+            }
+            P = is_sp && rm;                        // :154-162
+            if (!is_sp) { wl = w; seen = true; }
+          }
         }
-        P = is_sp && rm;                        // :154-162
-        if (!is_sp) { wl = w; seen = true; }
+      } else {
+        // ---- a dword with a non-ASCII byte (rare in this kernel's tiles).  A character whose first two bytes
+        // start no charsmap key (tables.cc npair -- the filter of the position-parallel normalizer) normalizes to
+        // itself (:231-244), a malformed byte to U+FFFD (util.cc:51-84); a possible rule, or a literal U+2581,
+        // leaves the sentence to the general normalizers. ----
+#pragma unroll
+        for (int k = 4 * q; k < 4 * q + 4; ++k) {
+          const uint32_t c = (wd[q] >> (8 * (k & 3))) & 0xFFu;
+          if (static_cast<uint32_t>(rel + k) < static_cast<uint32_t>(L)) {
+            if (c < 0x80u) {
+              bad |= bcls[c];
+              const bool is_sp = c == 0x20u;
+              if (!is_sp || !P) {
+                acc |= (is_sp ? sp : c) << (8 * (w & 3));
+                ++w;
+                nsp += is_sp ? 1 : 0;
+                if ((w & 3) == 0) { gt[((w >> 2) - 1) * 64] = acc; acc = 0; }
+              }
+              P = is_sp && rm;
+              if (!is_sp) { wl = w; seen = true; }
+            } else {
+              uint32_t o0 = c, o1 = 0, o2 = 0;
+              int n_out = 1;
+              const int rem = L - (rel + k);
+              if (skip > 0) {
+                --skip;
+              } else {
+                const uint32_t b1 = rem >= 2 ? (wd[(k + 1) >> 2] >> (8 * ((k + 1) & 3))) & 0xFFu : 0u;
+                const uint32_t b2 = rem >= 3 ? (wd[(k + 2) >> 2] >> (8 * ((k + 2) & 3))) & 0xFFu : 0u;
+                const uint32_t b3 = rem >= 4 ? (wd[(k + 3) >> 2] >> (8 * ((k + 3) & 3))) & 0xFFu : 0u;
+                const uint32_t pb = k > 0 ? (wd[(k > 0 ? k - 1 : 0) >> 2] >> (8 * ((k > 0 ? k - 1 : 0) & 3))) & 0xFFu : carry;
+                const uint32_t prevc = rel + k > 0 ? pb : 0x80u;      // nothing before the first byte of the sentence
+                const bool t1 = (b1 & 0xC0u) == 0x80u, t2 = (b2 & 0xC0u) == 0x80u, t3 = (b3 & 0xC0u) == 0x80u;
+                int mb = 0;
+                if (rem >= 2 && (c & 0xE0u) == 0xC0u) {
+                  if (t1 && ((c & 0x1Fu) << 6 | (b1 & 0x3Fu)) >= 0x80u) mb = 2;
+                } else if (rem >= 3 && (c & 0xF0u) == 0xE0u) {
+                  const uint32_t cp = (c & 0x0Fu) << 12 | (b1 & 0x3Fu) << 6 | (b2 & 0x3Fu);
+                  if (t1 && t2 && cp >= 0x800u && (cp < 0xD800u || cp >= 0xE000u)) mb = 3;
+                  if (c == 0xE2u && b1 == 0x96u && b2 == 0x81u) bad |= kBcComplex;
+                } else if (rem >= 4 && (c & 0xF8u) == 0xF0u) {
+                  const uint32_t cp = (c & 0x07u) << 18 | (b1 & 0x3Fu) << 12 | (b2 & 0x3Fu) << 6 | (b3 & 0x3Fu);
+                  if (t1 && t2 && t3 && cp >= 0x10000u && cp <= 0x10FFFFu) mb = 4;
+                }
+                if (has_map) {
+                  if ((d.npair[(c << 8 | b1) >> 5] >> (b1 & 31u)) & 1u) bad |= kBcComplex;          // a key may start here
+                  if (prevc < 0x80u && ((d.npair[(prevc << 8 | c) >> 5] >> (c & 31u)) & 1u)) bad |= kBcComplex;   // or at the ASCII byte before
+                }
+                if (mb) skip = mb - 1;
+                else { o0 = 0xEFu; o1 = 0xBFu; o2 = 0xBDu; n_out = 3; }
+              }
+              // a malformed byte grows into three: keep "what is written + what is left to read" within the
+              // column (all other bytes produce at most one), else leave the sentence to the general normalizers
+              if (w + rem + 2 > tcap) bad |= kBcComplex;
+              else {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                  if (j < n_out) {
+                    acc |= (j == 0 ? o0 : (j == 1 ? o1 : o2)) << (8 * (w & 3));
+                    ++w;
+                    if ((w & 3) == 0) { gt[((w >> 2) - 1) * 64] = acc; acc = 0; }
+                  }
+                }
+              }
+              P = false;
+              wl = w;
+              seen = true;
+            }
+          }
+        }
       }
     }
+    carry = cur.w >> 24;
     cur = nxt;
     blk += 16;
     rel += 16;
@@ -191,7 +271,7 @@ SPMX_DEVICE int fast_norm_stream(const SpmxDev &d, const uint8_t *gtext, uint64_
 // Raw bytes come through a kRawWin-byte LDS window filled 16 bytes at a time; a rule walk that would outrun the
 // window, or an output longer than tcap, makes the lane give up (-1) and the sentence goes to the GENERAL kernel.
 constexpr int kRawWin = 64;
-constexpr uint32_t kLaneGeneralMaxRaw = 576;   // length classes whose sentences norm_lane_general takes
+constexpr uint32_t kLaneGeneralMaxRaw = 4096;  // length classes whose sentences norm_lane_general takes (EncodeArgs::lane_general_max_raw)
 
 SPMX_DEVICE int norm_lane_general(const SpmxDev &d, const uint8_t *gtext, uint64_t beg, int L, uint32_t *gt, int tcap,
                                   uint8_t *rawwin, int *n_sp) {
@@ -618,7 +698,7 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     if (FAST) {
       const bool go = lane < cnt && !too_long;
       int nlen = 0;
-      if (go && my_len > 0) nlen = fast_norm_stream(d, a.text, my_beg, static_cast<int>(my_len), gt, T.bcls, &my_nsp);
+      if (go && my_len > 0) nlen = fast_norm_stream(d, a.text, my_beg, static_cast<int>(my_len), gt, T.bcls, static_cast<int>(tcap), &my_nsp);
       // Not plain ASCII.  A tile that is mostly such sentences (CJK text ...) normalizes them here, one per lane
       // (the raw window borrows the rings, idle until the search); a stray one in an ASCII tile would hold the
       // other 63 lanes up for its whole length, and long sentences are better off position-parallel: both go to
@@ -627,7 +707,8 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
       // non-ASCII sentence is normalized here, and one that cannot be fails the call.
       const bool no_general = a.hard_list == nullptr;
       const bool many = no_general ||
-                        (wv::popc64(wv::ballot(nlen < 0)) >= 16 && a.rcap <= kLaneGeneralMaxRaw && !a.no_lane_general);
+                        (wv::popc64(wv::ballot(nlen < 0)) >= static_cast<int>(a.lane_general_min_lanes) &&
+                         a.rcap <= a.lane_general_max_raw && !a.no_lane_general);
       if (many && nlen < 0)
         nlen = norm_lane_general(d, a.text, my_beg, static_cast<int>(my_len), gt, static_cast<int>(tcap),
                                  reinterpret_cast<uint8_t *>(T.ring_s) + static_cast<uint32_t>(lane) * (kRawWin + 16), &my_nsp);

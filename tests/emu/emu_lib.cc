@@ -230,6 +230,8 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
     a.tmp_off = tmp_off.data(); a.counts = counts.data(); a.status = &status; a.stats = &stats[kStatsPerClass * c];
     a.rcap = cls[c].rcap; a.ncap = cls[c].ncap;
     a.no_lane_general = getenv("SPMX_NO_LANE_GENERAL") ? 1u : 0u;
+    a.lane_general_max_raw = getenv("SPMX_LANE_GENERAL_MAX_RAW") ? static_cast<uint32_t>(atoi(getenv("SPMX_LANE_GENERAL_MAX_RAW"))) : kLaneGeneralMaxRaw;
+    a.lane_general_min_lanes = getenv("SPMX_LANE_GENERAL_MIN_LANES") ? static_cast<uint32_t>(atoi(getenv("SPMX_LANE_GENERAL_MIN_LANES"))) : (a.rcap <= 576 ? 16u : 4u);
     a.arena_tb = spans ? arena_tb.data() : nullptr;
     a.ring = 16;
     while (a.ring < static_cast<uint32_t>(h->tables.max_piece_len) + 1) a.ring <<= 1;
@@ -300,17 +302,22 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
     std::vector<int32_t> tokb(total, -9);
     CompactArgs pb{arena_tb.data(), tmp_off.data(), counts.data(), id_offs, tokb.data(), total, static_cast<uint32_t>(n)};
     for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { compact_block(pb); });
+    std::vector<uint32_t> alists(static_cast<size_t>(ncls + 1) * (n ? n : 1)), acounts(kMaxClasses + 1, 0);   // align escalation lists
     for (int c = 0; c < ncls; ++c) {
-      if (list_counts[c] == 0) continue;
-      if (cls[c].rcap > kEmuMaxStagedRaw) { status |= kStTooLong; break; }
+      if (cls[c].rcap > kEmuMaxStagedRaw) { if (list_counts[c]) status |= kStTooLong; continue; }
+      const bool has_next = c + 1 < ncls && cls[c + 1].rcap <= kEmuMaxStagedRaw;
       AlignArgs aa{};
       aa.dev = dev; aa.text = text; aa.offs = offs;
-      aa.list = lists.data() + static_cast<size_t>(c) * n; aa.list_count = &list_counts[c];
       aa.id_offs = id_offs; aa.tok_begin = tokb.data(); aa.begin = g_span_begin; aa.end = g_span_end;
       aa.nbegin = g_nspan_begin; aa.nend = g_nspan_end;
       aa.status = &status; aa.rcap = cls[c].rcap; aa.ncap = cls[c].ncap;
-      aa.has_next = (c + 1 < ncls && cls[c + 1].rcap <= kEmuMaxStagedRaw) ? 1u : 0u;
+      aa.next_list = has_next ? alists.data() + static_cast<size_t>(c + 1) * n : nullptr;
+      aa.next_count = has_next ? &acounts[c + 1] : nullptr;
+      aa.list_cap = static_cast<uint32_t>(n);
       std::vector<unsigned char> smem(AlignLdsBytes(aa.rcap, aa.ncap, aa.nbegin != nullptr) + 64, 0xCD);
+      aa.list = lists.data() + static_cast<size_t>(c) * n; aa.list_count = &list_counts[c];
+      for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, smem.data(), [&] { align_block(aa, smem.data()); });
+      aa.list = alists.data() + static_cast<size_t>(c) * n; aa.list_count = &acounts[c];
       for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, smem.data(), [&] { align_block(aa, smem.data()); });
     }
     if (status_out) *status_out = status;

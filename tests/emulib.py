@@ -144,7 +144,7 @@ def _emu_encode_spans(self, text, offs, grid=3, norm_spans=False):
     text = np.ascontiguousarray(text, dtype=np.uint8)
     offs = np.ascontiguousarray(offs, dtype=np.uint64)
     n = len(offs) - 1
-    cap = int(len(text)) * 3 + 8 * n + 64
+    cap = int(len(text)) * 12 + 8 * n + 64          # NFKC expansions x byte fallback
     ids = np.empty(cap, dtype=np.int32)
     begin = np.full(cap, 0xCDCDCDCD, dtype=np.uint32)
     end = np.full(cap, 0xCDCDCDCD, dtype=np.uint32)

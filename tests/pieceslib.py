@@ -10,8 +10,8 @@ def encode_pieces(fn, h, text, offs):
     text = np.ascontiguousarray(text, dtype=np.uint8)
     offs = np.ascontiguousarray(offs, dtype=np.uint64)
     n = len(offs) - 1
-    cap = int(len(text)) * 3 + 8 * n + 64
-    pcap = int(len(text)) * 8 + 64 * n + 256
+    cap = int(len(text)) * 12 + 8 * n + 64          # NFKC expansions x byte fallback
+    pcap = int(len(text)) * 80 + 64 * n + 256
     ids = np.empty(cap, dtype=np.int32)
     begin = np.empty(cap, dtype=np.uint32)
     end = np.empty(cap, dtype=np.uint32)

@@ -156,6 +156,13 @@ def _ref_encode_spans(self, text, offs):
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     tot = fn(self.h, text.ctypes.data if len(text) else None, offs.ctypes.data, n, ids.ctypes.data, begin.ctypes.data,
              end.ctypes.data, cap, id_offs.ctypes.data)
+    if tot < -1:           # -(needed) - 2: expansions + byte fallback can exceed the first guess
+        cap = -tot - 2
+        ids = np.empty(cap, dtype=np.int32)
+        begin = np.empty(cap, dtype=np.uint32)
+        end = np.empty(cap, dtype=np.uint32)
+        tot = fn(self.h, text.ctypes.data if len(text) else None, offs.ctypes.data, n, ids.ctypes.data, begin.ctypes.data,
+                 end.ctypes.data, cap, id_offs.ctypes.data)
     if tot < 0:
         raise RuntimeError("spmref_encode_spans_batch failed: %d" % tot)
     return ids[:tot].copy(), begin[:tot].copy(), end[:tot].copy(), id_offs

@@ -101,8 +101,8 @@ def test_emu_lane_general_normalizer(model, corpus, k, env, emu, oracle, corpora
     np.testing.assert_array_equal(io, oio)
     np.testing.assert_array_equal(ids, oids)
     kept, handed = h.fast_split()
-    if env:
-        assert handed > 0.5 * (len(offs) - 1)
+    if env:      # (characters that start no charsmap key stay in the FAST kernel's own normalizer either way)
+        assert handed > 0.25 * (len(offs) - 1)
     elif model != "uni1k_bf":      # (the edge cases are mostly ASCII tiles: stray non-ASCII sentences are handed over)
         assert kept > 0.3 * (len(offs) - 1)
 
@@ -218,3 +218,39 @@ def test_emu_document_length_needs_fast_model(emu, corpora):
     text, offs = synth.pack([b"y" * 9000])
     h.encode_batch(text, offs, grid=1)
     assert h.status & 2          # kStTooLong: csrc/api.cc turns it into OUT_OF_RANGE
+
+
+@pytest.mark.parametrize("model", ["uni32k", "uni1k_ident", "bpe1k", "uni1k_bf"])
+def test_emu_fast_keeps_identity_characters(model, emu, oracle):
+    """ASCII sentences with a stray character that starts no charsmap key (e-acute, CJK, emoji ...), a malformed
+    byte or a truncated character stay in the FAST kernel's own normalizer; compatibility characters, U+3000 and a
+    literal U+2581 go to the general normalizers.  Same ids either way."""
+    from sentencepiece_amd import synth
+    rng = np.random.default_rng(5)
+    words = [b"hello", b"world", b"the", b"cat", b"sat", b"on", b"a", b"mat"]
+    keep = ["é", "ü", "日本", "€", "\U0001f600", "ñ"]
+    leave = ["ＡＢ", "　", "▁", "㍿"]
+    sent, n_leave = [], 0
+    for i in range(300):
+        ws = [words[int(k)] for k in rng.integers(0, len(words), size=int(rng.integers(1, 30)))]
+        r = rng.random()
+        if r < 0.4:
+            ws.insert(int(rng.integers(0, len(ws) + 1)), keep[int(rng.integers(0, len(keep)))].encode())
+        elif r < 0.5:
+            ws.insert(int(rng.integers(0, len(ws) + 1)), leave[int(rng.integers(0, len(leave)))].encode())
+            n_leave += 1
+        elif r < 0.7:
+            ws.insert(int(rng.integers(0, len(ws) + 1)), bytes([int(rng.integers(0x80, 0x100))]))
+        elif r < 0.8:
+            ws.append("日".encode()[:int(rng.integers(1, 3))])      # truncated at the end of the sentence
+        sent.append(b" ".join(ws))
+    text, offs = synth.pack(sent)
+    blob = fixtures.model_blob(model)
+    h, o = emu.load(blob), oracle.load(blob)
+    ids, io = h.encode_batch(text, offs, grid=2)
+    assert h.status == 0
+    oids, oio = o.encode_batch(text, offs)
+    np.testing.assert_array_equal(io, oio)
+    np.testing.assert_array_equal(ids, oids)
+    kept, handed = h.fast_split()
+    assert kept >= 0.7 * 300 and handed >= n_leave // 2     # (a stray byte can start a key together with its neighbour)

@@ -22,7 +22,9 @@ def extra_cases():
     s = ["", " ", "   ", "a", " a", "a ", "  a  b   c  ", "　a　　b　", "▁a ▁", "a▁▁b",
          "ＡＢＣ ①②", "ﬁx ﬃ", "a­b", "­", " ­ ", "é é",
          "ẛ̣", "㌀ ㌁", "ﷺ", "x​y", "\xe2\x96", "\xff\xfe a", "a\xf0\x9f\x98", "\U0001f600\U0001f601 zz \U0001f602",
-         "一丁丂", "hello 一二 world", "  \t\n x", "a\tb", "a\r\n", "\r", "1 2  3   4    5"]
+         "一丁丂", "hello 一二 world", "  \t\n x", "a\tb", "a\r\n", "\r", "1 2  3   4    5",
+         # normalized forms that overflow the capacity of their length class (escalation chains in every kernel pair)
+         "㌀" * 60, "ﷺ" * 50, "x ﷺ" * 40 + " tail", "㍿ " * 180]
     out = []
     for x in s:
         out.append(x.encode("utf-8", "surrogateescape") if isinstance(x, str) else x)
