@@ -31,6 +31,7 @@ class SentencePieceProcessor:
         self._out_type = out_type
         self._add_bos, self._add_eos, self._reverse = add_bos, add_eos, reverse
         self._enable_sampling = enable_sampling
+        self._emit_unk_piece = emit_unk_piece
         self._extra = ""          # SetEncodeExtraOptions string
         self._applied = ""        # option string currently compiled into the handle
         if model_file or model_proto:
@@ -187,10 +188,31 @@ class SentencePieceProcessor:
         sequence, not a host thread pool."""
         self._need()
         out_type = self._out_type if out_type is None else out_type
-        if out_type is not int:
-            raise NotImplementedError("only out_type=int is on the device path")
         if (self._enable_sampling if enable_sampling is None else enable_sampling):
             raise NotImplementedError("sampling is not on the device path")
+        if out_type is str or out_type == "str":
+            # _EncodeAsPiecesBatch (sentencepiece.i:448-456): EncodeAsPieces per element, then RewriteIds on the
+            # piece lists (:147-164): reverse, bos piece in front, eos piece at the back, unknown pieces -> unk piece
+            single = not isinstance(input, list)
+            rows = self.EncodeAsPieces([input] if single else input)
+            a_bos = self._add_bos if add_bos is None else add_bos
+            a_eos = self._add_eos if add_eos is None else add_eos
+            rev = self._reverse if reverse is None else reverse
+            emit = self._emit_unk_piece if emit_unk_piece is None else emit_unk_piece
+            if a_bos or a_eos or rev or emit:
+                unk = self.IdToPiece(self.unk_id())
+                for row in rows:
+                    if rev:
+                        row.reverse()
+                    if a_bos:
+                        row.insert(0, self.IdToPiece(self.bos_id()))
+                    if a_eos:
+                        row.append(self.IdToPiece(self.eos_id()))
+                    if emit:
+                        row[:] = [unk if self.PieceToId(p) == self.unk_id() else p for p in row]
+            return rows[0] if single else rows
+        if out_type is not int:
+            raise NotImplementedError("out_type int and str are on the device path; proto outputs are not")
         self._apply(self._add_bos if add_bos is None else add_bos,
                     self._add_eos if add_eos is None else add_eos,
                     self._reverse if reverse is None else reverse)

@@ -130,3 +130,19 @@ def test_gpu_normalize_api_shapes(oracle):
     s, a = out[2]
     assert s == o.normalize("㍿ x".encode()).decode() and len(a) == len(s.encode()) + 1
     assert sp.EncodeAsPieces("hello world") == [p.decode() for p, *_ in sp.EncodeAsSentencePieceText("hello world")]
+
+
+@pytest.mark.gpu
+def test_gpu_encode_out_type_str_matches_wheel():
+    """encode(out_type=str, add_bos / add_eos / reverse / emit_unk_piece) against the installed sentencepiece wheel
+    on a BPE model (the wheel's BPE path is identical to the reference's, SURVEY finding 4)."""
+    spm = pytest.importorskip("sentencepiece")
+    from sentencepiece_amd.processor import SentencePieceProcessor
+    blob = fixtures.model_blob("bpe1k")
+    sp = SentencePieceProcessor(model_proto=blob)
+    ref = spm.SentencePieceProcessor(model_proto=blob)
+    lines = ["Hello world.", "  two  spaces ", "吾輩は猫 cat", "", "I saw a girl with a telescope."]
+    for kw in ({}, {"add_bos": True, "add_eos": True}, {"reverse": True, "add_eos": True}, {"emit_unk_piece": True},
+               {"add_bos": True, "reverse": True, "emit_unk_piece": True}):
+        assert sp.encode(lines, out_type=str, **kw) == ref.encode(lines, out_type=str, **kw), kw
+        assert sp.encode(lines[2], out_type=str, **kw) == ref.encode(lines[2], out_type=str, **kw), kw
