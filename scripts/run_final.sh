@@ -13,3 +13,10 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o uni -- python bench.p
 DB=$(ls $O/prof/*/uni_results.db $O/prof/uni_results.db 2>/dev/null | head -1)
 python scripts/rocpd_summary.py "$DB" > $O/uni32k_10m_kernel_stats.txt 2>> $O/prof.err; head -14 $O/uni32k_10m_kernel_stats.txt
 rm -rf $O/prof
+# A/B of the tile queue (SPMX_TILE_ORDER=asc: shortest tiles first; SPMX_STATIC_TILES=1: fixed stride)
+SPMX_TILE_ORDER=asc timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_tiles_asc.json 2>> $O/prof.err
+python - $O <<'PY'
+import json, sys
+for f in ("bench_uni32k_10m", "bench_tiles_asc"):
+    d = json.load(open(sys.argv[1] + "/" + f + ".json")); print(f, round(d["value"] / 1e6, 1), round(d["ms_per_step"], 2), d["roofline"]["all_kernels_ms"])
+PY

@@ -43,6 +43,7 @@ struct Ctrl {
   uint32_t key_totals[kSortKeys], key_cursor[kSortKeys];   // classify: counting sort by (class, length sub-bucket)   // BPE: sentences the streaming kernels left to the sentence-per-wave kernel
   uint32_t status;
   uint32_t pad;
+  uint32_t tile_cursor[2 * kMaxClasses];   // per kernel slot: the streaming kernels' tile queue
   unsigned long long arena_head;
   unsigned long long stats[kStatsPerClass * 2 * kMaxClasses];   // per kernel slot (see Profile)
   unsigned long long bad_key;   // decode: min over offending (sentence << 32 | id)
@@ -120,6 +121,8 @@ struct spmx_handle {
   bool slot_used[kMaxSlots] = {false};
   bool no_lane_general = false;      // SPMX_NO_LANE_GENERAL=1: FAST kernels hand every non-ASCII sentence to GENERAL
   uint32_t lane_general_max_raw = kLaneGeneralMaxRaw, lane_general_min_lanes = 0;   // SPMX_LANE_GENERAL_MAX_RAW / _MIN_LANES (0: per class)
+  bool tiles_ascending = false;      // SPMX_TILE_ORDER=asc
+  bool static_tiles = false;         // SPMX_STATIC_TILES=1: fixed-stride tiles in the streaming kernels (A/B measurements)
   bool no_merge_general = false;     // SPMX_NO_MERGE_GENERAL=1: a GENERAL launch per class (A/B measurements)
   bool no_stream = false;            // SPMX_NO_STREAM=1: BPE in the sentence-per-wave form only (A/B measurements)
   uint64_t stream_scratch_limit = 4ull << 30;   // SPMX_STREAM_SCRATCH_MB: cap on the streaming kernels' HBM scratch
@@ -390,6 +393,8 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
           a.stream_bp = h->d_stream.p + sp.text_words;
           const int slot = (fast && !is_fast) ? kSlotGeneral + c : c;
           a.stats = &h->d_ctrl->stats[kStatsPerClass * slot];
+          a.tile_cursor = h->static_tiles ? nullptr : &h->d_ctrl->tile_cursor[slot];
+          a.tiles_ascending = h->tiles_ascending ? 1u : 0u;
           a.wave_list = h->d_lists.p + static_cast<size_t>(2 * ncls + c) * n;
           a.wave_count = &h->d_ctrl->wave_counts[c];
           if (!bpe_stream && is_fast && a.ring == 16)
@@ -695,6 +700,8 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
   if (const char *e = getenv("SPMX_NO_STREAM")) h->no_stream = e[0] == '1';
   if (const char *e = getenv("SPMX_NO_LANE_GENERAL")) h->no_lane_general = e[0] == '1';
   if (const char *e = getenv("SPMX_NO_MERGE_GENERAL")) h->no_merge_general = e[0] == '1';
+  if (const char *e = getenv("SPMX_STATIC_TILES")) h->static_tiles = e[0] == '1';
+  if (const char *e = getenv("SPMX_TILE_ORDER")) h->tiles_ascending = e[0] == 'a';
   if (const char *e = getenv("SPMX_LANE_GENERAL_MAX_RAW")) h->lane_general_max_raw = static_cast<uint32_t>(atoi(e));
   if (const char *e = getenv("SPMX_LANE_GENERAL_MIN_LANES")) h->lane_general_min_lanes = static_cast<uint32_t>(atoi(e));
   if (const char *e = getenv("SPMX_STREAM_SCRATCH_MB")) h->stream_scratch_limit = static_cast<uint64_t>(atoll(e)) << 20;

@@ -674,7 +674,19 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
   const uint32_t tiles = (count + tw - 1) / tw;
   const int n_extra = d.n_prefix + d.n_suffix;
   WaveCounters tc;
-  for (uint32_t tile = wave_id; tile < tiles; tile += n_waves) {
+  // Tiles come from a queue (one atomic per tile), not from a fixed stride: a wave that starts late -- its CU was
+  // held by another stream's kernel, e.g. the RCCL all-gather of the previous batch -- takes fewer tiles instead of
+  // finishing its fixed share after everybody else, and uneven tiles even out.
+  for (uint32_t tile = wave_id;; tile += n_waves) {
+    if (a.tile_cursor) {
+      uint32_t t = 0;
+      if (lane == 0) t = wv::atomic_add(a.tile_cursor, 1u);
+      tile = wv::shfl(t, 0);
+      // the class lists are sorted by length (classify's sub-buckets): longest tiles first, so that the tiles
+      // still running when the queue empties are the short ones
+      if (tile < tiles && !a.tiles_ascending) tile = tiles - 1u - tile;
+    }
+    if (tile >= tiles) break;
     const uint32_t first = tile * tw;
     const int cnt = static_cast<int>(count - first < tw ? count - first : tw);
     uint32_t my_sid = 0;

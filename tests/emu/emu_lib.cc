@@ -255,6 +255,8 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
         std::vector<uint32_t> st(StreamTextDwords(a.stream_tcap, a.ring) * waves, 0xCDCDCDCDu), sb(StreamBpWords(a.stream_tcap) * waves, 0xCDCDCDCDu);
         a.stream_text = st.data(); a.stream_bp = sb.data();
         std::vector<unsigned char> fsmem(StreamLdsBytes(true, model, a.rcap, a.ncap, a.ring, 1) + 64, 0xCD);
+        uint32_t fast_cursor = 0;
+        a.tile_cursor = getenv("SPMX_STATIC_TILES") ? nullptr : &fast_cursor;
         for (int b = 0; b < grid; ++b) {
           if (bpe) emu::RunWave(b, grid, fsmem.data(), [&] { encode_stream_block<true, 2>(a, fsmem.data()); });
           else if (a.ring == 16) emu::RunWave(b, grid, fsmem.data(), [&] { encode_stream_block<true, 1, 16>(a, fsmem.data()); });   // as LaunchEncodeStream picks
@@ -270,6 +272,8 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
       std::vector<uint32_t> st(StreamTextDwords(a.stream_tcap, a.ring) * waves, 0xCDCDCDCDu), sb(StreamBpWords(a.stream_tcap) * waves, 0xCDCDCDCDu);
       a.stream_text = st.data(); a.stream_bp = sb.data();
       std::vector<unsigned char> gsmem(StreamLdsBytes(false, model, a.rcap, a.ncap, a.ring, 1) + 64, 0xCD);
+      uint32_t general_cursor = 0;
+      a.tile_cursor = getenv("SPMX_STATIC_TILES") ? nullptr : &general_cursor;
       for (int b = 0; b < grid; ++b) {
         if (bpe) emu::RunWave(b, grid, gsmem.data(), [&] { encode_stream_block<false, 2>(a, gsmem.data()); });
         else emu::RunWave(b, grid, gsmem.data(), [&] { encode_stream_block<false, 1>(a, gsmem.data()); });
