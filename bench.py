@@ -98,6 +98,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    # The corpus first: the generator forks a process pool, which is safest before this process has a HIP context
+    # or an RCCL communicator.  Weak scaling: every rank draws its own shard of the generator (seed + rank).
+    c5 = args.model.startswith("c5_")
+    if c5:
+        text, offs = synth.mixed_corpus(args.sentences, seed=20250228 + rank)
+    else:
+        text, offs = synth.ascii_corpus(args.sentences, seed=20250227 + rank, sort_by_length=not args.unsorted)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -106,7 +113,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    c5 = args.model.startswith("c5_")
     if c5:
         from tests import fixtures
         blob = fixtures.model_blob(args.model)      # synthesized 250k-piece model, cached under the temp dir
@@ -115,11 +121,6 @@ def main():
             blob = f.read()
     sp = SentencePieceProcessor(model_proto=blob, device=local)
 
-    # weak scaling: every rank draws its own shard of the generator (seed + rank)
-    if c5:
-        text, offs = synth.mixed_corpus(args.sentences, seed=20250228 + rank)
-    else:
-        text, offs = synth.ascii_corpus(args.sentences, seed=20250227 + rank, sort_by_length=not args.unsorted)
     n = len(offs) - 1
     d_text = torch.from_numpy(text).to(dev)
     d_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
