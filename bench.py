@@ -33,8 +33,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
-def cpu_baseline(text, offs, model_blob, gpu_counts):
-    """Reference CPU path on a bounded strided sample of the bench corpus."""
+def cpu_baseline(text, offs, model_blob, gpu_counts, gpu_ids=None, gpu_id_offsets=None):
+    """Reference CPU path on a bounded strided sample of the bench corpus.  gpu_ids / gpu_id_offsets (host CSR of the
+    GPU's output): a 20 k-sentence strided probe is also compared id by id."""
     from sentencepiece_amd import synth
     from tests import refshim
     n = len(offs) - 1
@@ -70,6 +71,18 @@ def cpu_baseline(text, offs, model_blob, gpu_counts):
            "gb_per_s": len(st) / dt / 1e9}
     if gpu_counts is not None:
         out["sample_ids_match_gpu"] = bool(int(gpu_counts[pick].sum()) == int(total))
+    if gpu_ids is not None:
+        try:
+            cids, cio = h.encode_batch(pt, po)
+            io = np.asarray(gpu_id_offsets).astype(np.int64)
+            lens = (io[1:] - io[:-1])[probe]
+            idx = np.repeat(io[:-1][probe] - np.concatenate([[0], np.cumsum(lens)[:-1]]), lens) + np.arange(int(lens.sum()))
+            out["probe_ids_bit_exact"] = bool(np.array_equal(lens, np.diff(np.asarray(cio).astype(np.int64))) and
+                                              np.array_equal(np.asarray(gpu_ids)[idx], np.asarray(cids)))
+            out["probe"] = "%d sentences strided over the bench corpus, ids compared one by one" % len(probe)
+        except Exception as e:      # the check must not cost the bench line
+            out["probe_ids_bit_exact"] = None
+            out["probe"] = "failed: %r" % (e,)
     return out
 
 
@@ -208,8 +221,8 @@ def main():
                                             for c in range(ncls) if prof[-1]["classes"][c]["kernel"]}, "phase_cycles": cls.get("phase_cycles"), "pipeline_ms": sum(p["total_ms"] for p in prof) / len(prof)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            counts = np.diff(d_io.cpu().numpy())
-            out["cpu_baseline"] = cpu_baseline(text, offs, blob, counts)
+            io_h = d_io.cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(text, offs, blob, np.diff(io_h), d_ids[:int(io_h[-1])].cpu().numpy(), io_h)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
