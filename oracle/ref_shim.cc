@@ -293,6 +293,28 @@ int64_t spmref_normalize_batch(void *handle, const char *text, const uint64_t *o
   return static_cast<int64_t>(total);
 }
 
+// NBestEncode(input, nbest_size, &ids) + the scores of NBestEncode(input, nbest_size, NBestSentencePieceText*)
+// (sentencepiece_processor.h:360-366).  Layout as oracle_nbest_encode.
+int64_t spmref_nbest_encode(void *handle, const char *text, uint64_t len, int nbest_size, int32_t *ids, uint64_t cap,
+                            uint64_t *offs, float *scores) {
+  auto *h = static_cast<RefHandle *>(handle);
+  sentencepiece::NBestSentencePieceText nb;
+  const auto st = h->sp.NBestEncode(absl::string_view(text, len), nbest_size, &nb);
+  if (!st.ok()) { h->last_error = st.ToString(); return -1; }
+  uint64_t total = 0;
+  for (int k = 0; k < nb.nbests_size(); ++k) {
+    offs[k] = total;
+    scores[k] = nb.nbests(k).score();
+    for (int i = 0; i < nb.nbests(k).pieces_size(); ++i) {
+      if (total < cap) ids[total] = static_cast<int32_t>(nb.nbests(k).pieces(i).id());
+      ++total;
+    }
+  }
+  offs[nb.nbests_size()] = total;
+  if (total > cap) return -static_cast<int64_t>(total) - 2;
+  return nb.nbests_size();
+}
+
 int spmref_piece_size(void *handle) {
   return static_cast<RefHandle *>(handle)->sp.GetPieceSize();
 }

@@ -886,6 +886,192 @@ int64_t oracle_encode_pieces_batch(const Oracle *o, const char *text, const uint
   return (int64_t)total;
 }
 
+/* ------------------------------------------------------------------ n-best */
+/* unigram::Model::NBestEncode (unigram_model.cc:686-717): Lattice::SetSentence (:114-152), Model::PopulateNodes
+ * (:547-596), Lattice::Viterbi (:167-198, all float, first best wins ties) and the A* of Lattice::NBest (:345-515).
+ * The agenda is std::priority_queue over fx: its order among equal keys is the order libstdc++'s push_heap /
+ * pop_heap produce, so those two are restated step by step (bits/stl_heap.h __push_heap / __adjust_heap). */
+typedef struct { int pos, length, id, byte_begin, byte_len; float score, backtrace_score; int prev; } LNode;
+typedef struct { LNode *p; size_t n, cap; } LNodes;
+typedef struct { int *p; size_t n, cap; } IVec;
+static void ivec_push(IVec *v, int x) {
+  if (v->n == v->cap) { v->cap = v->cap ? v->cap * 2 : 16; v->p = realloc(v->p, sizeof(int) * v->cap); }
+  v->p[v->n++] = x;
+}
+static int lnode_new(LNodes *v) {
+  if (v->n == v->cap) { v->cap = v->cap ? v->cap * 2 : 256; v->p = realloc(v->p, sizeof(LNode) * v->cap); }
+  memset(&v->p[v->n], 0, sizeof(LNode));            /* FreeList hands out zeroed nodes */
+  v->p[v->n].prev = -1;
+  return (int)v->n++;
+}
+typedef struct { int node, next; float fx, gx; } Hyp;
+typedef struct { Hyp *p; size_t n, cap; } Hyps;
+static int hyp_new(Hyps *v) {
+  if (v->n == v->cap) { v->cap = v->cap ? v->cap * 2 : 512; v->p = realloc(v->p, sizeof(Hyp) * v->cap); }
+  return (int)v->n++;
+}
+/* std::push_heap / std::pop_heap with comp(a, b) = a->fx < b->fx on an array of hypothesis indices */
+static void heap_push_fx(IVec *h, const Hyps *hy, int value) {
+  ivec_push(h, value);
+  long hole = (long)h->n - 1, parent = (hole - 1) / 2;
+  while (hole > 0 && hy->p[h->p[parent]].fx < hy->p[value].fx) {
+    h->p[hole] = h->p[parent]; hole = parent; parent = (hole - 1) / 2;
+  }
+  h->p[hole] = value;
+}
+static int heap_pop_fx(IVec *h, const Hyps *hy) {
+  const int top = h->p[0];
+  const int value = h->p[h->n - 1];
+  const long len = (long)h->n - 1;                  /* the range the hole is sifted in */
+  h->n--;
+  if (len == 0) return top;
+  long hole = 0, child = 0;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (hy->p[h->p[child]].fx < hy->p[h->p[child - 1]].fx) child--;
+    h->p[hole] = h->p[child]; hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    h->p[hole] = h->p[child - 1]; hole = child - 1;
+  }
+  long parent = (hole - 1) / 2;
+  while (hole > 0 && hy->p[h->p[parent]].fx < hy->p[value].fx) {
+    h->p[hole] = h->p[parent]; hole = parent; parent = (hole - 1) / 2;
+  }
+  h->p[hole] = value;
+  return top;
+}
+
+typedef struct { Toks toks; float score; } NBestOne;
+/* Fills results (caller frees each toks.p); returns the number of results. */
+static int unigram_nbest(const Oracle *o, const uint8_t *norm, int size, int nbest_size, NBestOne *results) {
+  /* SetSentence: character starts */
+  IVec surf = {0};
+  for (int p = 0; p < size;) { ivec_push(&surf, p); int mb = one_char_len(norm[p]); if (mb > size - p) mb = size - p; p += mb; }
+  ivec_push(&surf, size);
+  const int len = (int)surf.n - 1;
+  LNodes nodes = {0};
+  IVec *begin_nodes = calloc((size_t)len + 1, sizeof(IVec)), *end_nodes = calloc((size_t)len + 1, sizeof(IVec));
+  const int bos = lnode_new(&nodes); nodes.p[bos].id = -1; nodes.p[bos].pos = 0; ivec_push(&end_nodes[0], bos);
+  const int eos = lnode_new(&nodes); nodes.p[eos].id = -1; nodes.p[eos].pos = len; ivec_push(&begin_nodes[len], eos);
+  /* PopulateNodes */
+  const float unk_score = o->min_score - 10.0f;
+  for (int begin_pos = 0; begin_pos < len; ++begin_pos) {
+    const int b0 = surf.p[begin_pos];
+    int has_single_node = 0, node = 0;
+    for (int key_pos = b0; key_pos < size;) {                 /* commonPrefixSearch: matches in increasing length */
+      node = trie_child(&o->ptrie, node, norm[key_pos]);
+      if (node < 0) break;
+      ++key_pos;
+      const int id = o->ptrie.value[node];
+      if (id < 0) continue;
+      int pos = begin_pos;                                    /* get_chars_length (:548-552) */
+      while (surf.p[pos] < key_pos) ++pos;
+      const int length = pos - begin_pos;
+      if (o->pieces[id].type == T_UNUSED) continue;
+      const int nd = lnode_new(&nodes);
+      LNode *x = &nodes.p[nd];
+      x->pos = begin_pos; x->length = length; x->byte_begin = b0; x->byte_len = surf.p[begin_pos + length] - b0;
+      x->id = id;
+      x->score = o->pieces[id].type == T_USER_DEFINED ? (float)((double)((float)length * o->max_score) - 0.1)
+                                                       : o->pieces[id].score;
+      ivec_push(&begin_nodes[begin_pos], nd); ivec_push(&end_nodes[begin_pos + length], nd);
+      if (!has_single_node && length == 1) has_single_node = 1;
+    }
+    if (!has_single_node) {
+      const int nd = lnode_new(&nodes);
+      LNode *x = &nodes.p[nd];
+      x->pos = begin_pos; x->length = 1; x->byte_begin = b0; x->byte_len = surf.p[begin_pos + 1] - b0;
+      x->id = o->unk_id; x->score = unk_score;
+      ivec_push(&begin_nodes[begin_pos], nd); ivec_push(&end_nodes[begin_pos + 1], nd);
+    }
+  }
+  /* Viterbi: fills backtrace_score = h(node) */
+  for (int pos = 0; pos <= len; ++pos) {
+    for (size_t r = 0; r < begin_nodes[pos].n; ++r) {
+      LNode *rn = &nodes.p[begin_nodes[pos].p[r]];
+      float best_score = 0.0f; int best_node = -1;
+      for (size_t l = 0; l < end_nodes[pos].n; ++l) {
+        const int ln = end_nodes[pos].p[l];
+        const float sc = nodes.p[ln].backtrace_score + rn->score;
+        if (best_node < 0 || sc > best_score) { best_node = ln; best_score = sc; }
+      }
+      rn->prev = best_node; rn->backtrace_score = best_score;
+    }
+  }
+  /* A* from EOS */
+  Hyps hy = {0}; IVec agenda = {0};
+  int n_res = 0;
+  { const int e = hyp_new(&hy); hy.p[e].node = eos; hy.p[e].next = -1; hy.p[e].gx = 0.0f; hy.p[e].fx = nodes.p[eos].backtrace_score;
+    heap_push_fx(&agenda, &hy, e); }
+  while (agenda.n) {
+    const int top = heap_pop_fx(&agenda, &hy);
+    const int node = hy.p[top].node;
+    if (node == bos) {
+      NBestOne *r = &results[n_res++];
+      memset(r, 0, sizeof(*r));
+      for (int h = hy.p[top].next; hy.p[h].next != -1; h = hy.p[h].next) {
+        const LNode *x = &nodes.p[hy.p[h].node];
+        toks_push(&r->toks, x->byte_begin, x->byte_len, x->id);
+      }
+      r->score = hy.p[top].fx;
+      if (n_res == nbest_size) break;
+      continue;
+    }
+    const IVec *en = &end_nodes[nodes.p[node].pos];
+    for (size_t i = 0; i < en->n; ++i) {
+      const LNode *ln = &nodes.p[en->p[i]];
+      const int h = hyp_new(&hy);
+      hy.p[h].node = en->p[i];
+      hy.p[h].gx = ln->score + hy.p[top].gx;
+      hy.p[h].fx = ln->backtrace_score + hy.p[top].gx;
+      hy.p[h].next = top;
+      heap_push_fx(&agenda, &hy, h);
+    }
+    if (agenda.n >= 10000) {                                  /* :487-514 keep the best min(512, 10 nbest) */
+      int keep = nbest_size * 10 < 512 ? nbest_size * 10 : 512;
+      IVec na = {0};
+      for (int i = 0; i < keep; ++i) heap_push_fx(&na, &hy, heap_pop_fx(&agenda, &hy));
+      free(agenda.p); agenda = na;
+    }
+  }
+  for (int i = 0; i <= len; ++i) { free(begin_nodes[i].p); free(end_nodes[i].p); }
+  free(begin_nodes); free(end_nodes); free(nodes.p); free(hy.p); free(agenda.p); free(surf.p);
+  return n_res;
+}
+
+/* SentencePieceProcessor::NBestEncode(input, nbest_size, std::vector<std::vector<int>>*)
+ * (sentencepiece_processor.cc:478-492, :655-680).  ids of result k at out[offs[k], offs[k + 1]); scores[k].
+ * Returns the number of results, -1 on an error status (not a unigram model, ...), -(needed) - 2 if cap is small. */
+int64_t oracle_nbest_encode(const Oracle *o, const char *in, uint64_t n, int nbest_size, int32_t *out, uint64_t cap,
+                            uint64_t *offs, float *scores) {
+  if (o->model_type != M_UNIGRAM) return -1;                  /* IsNBestEncodeAvailable (:662) */
+  Buf norm = {0}; Ids ids = {0};
+  normalize(o, (const uint8_t *)in, (size_t)n, &norm);
+  if (nbest_size > 1024) nbest_size = 1024;                   /* unigram_model.cc:692 */
+  if (nbest_size < 1) nbest_size = 1;
+  NBestOne *res = calloc((size_t)nbest_size, sizeof(NBestOne));
+  int n_res;
+  if (norm.n == 0) { n_res = 1; res[0].score = 0.0f; }        /* :688-690 one empty result */
+  else if (nbest_size <= 1) { n_res = 1; unigram_encode(o, norm.p, (int)norm.n, &res[0].toks); res[0].score = 0.0f; }   /* :694-696 */
+  else n_res = unigram_nbest(o, norm.p, (int)norm.n, nbest_size, res);
+  uint64_t total = 0; int failed = n_res == 0;                /* "NBestEncode returns empty result." (:666) */
+  for (int k = 0; k < n_res && !failed; ++k) {
+    offs[k] = total;
+    if (populate_ids(o, norm.p, (int)norm.n, &res[k].toks, &ids)) { failed = 1; break; }
+    if (total + ids.n <= cap && ids.n) memcpy(out + total, ids.p, sizeof(int32_t) * ids.n);
+    total += ids.n;
+    scores[k] = res[k].score;
+  }
+  offs[n_res] = total;
+  for (int k = 0; k < nbest_size; ++k) free(res[k].toks.p);
+  free(res); free(norm.p); free(ids.p);
+  if (failed) return -1;
+  if (total > cap) return -(int64_t)total - 2;
+  return n_res;
+}
+
 /* ------------------------------------------------------------------ decode */
 /* SentencePieceProcessor::Decode(const std::vector<int>& ids, std::string*)
  * (sentencepiece_processor.cc:761-925): ids -> IdToPiece -> the piece-level Decode, text only.

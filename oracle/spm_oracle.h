@@ -48,6 +48,13 @@ int64_t oracle_encode_pieces_batch(const Oracle *o, const char *text, const uint
 int64_t oracle_normalize_batch(const Oracle *o, const char *text, const uint64_t *offsets, uint64_t n,
                                char *out, uint64_t cap, uint64_t *norm_offsets, uint32_t *n2o);
 
+/* NBestEncode(input, nbest_size, std::vector<std::vector<int>>*) (sentencepiece_processor.cc:478-492, :655-680;
+ * Lattice::NBest unigram_model.cc:345-515): result k's ids at out[offs[k], offs[k + 1]) and its score.  offs holds
+ * min(max(nbest_size, 1), 1024) + 1 entries.  Returns the number of results, -1 on an error status,
+ * -(needed) - 2 if cap is too small. */
+int64_t oracle_nbest_encode(const Oracle *o, const char *in, uint64_t n, int nbest_size, int32_t *out, uint64_t cap,
+                            uint64_t *offs, float *scores);
+
 /* Per-sentence Decode(ids, std::string*) over CSR ids -> packed text + offsets (n + 1). Returns total bytes,
  * -11000 for an invalid id (OUT_OF_RANGE), -12000 if the model has a denormalizer, -(needed)-2 if cap too small. */
 int64_t oracle_decode_batch(const Oracle *o, const int32_t *ids, const uint64_t *id_offsets, uint64_t n,

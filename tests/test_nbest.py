@@ -1,0 +1,78 @@
+"""NBestEncode -- the ORACLE only, pinned to the compiled reference: the lattice
+(Lattice::SetSentence / PopulateNodes), the float Viterbi and the A* of Lattice::NBest with libstdc++'s heap order.
+The device kernel for it does not exist yet; this is the checker it will be held to."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import fixtures
+
+UNIGRAM = ["test_model", "test_ja_model", "uni1k", "uni1k_bf", "uni1k_uds", "uni1k_ident", "uni1k_suffix", "uni32k"]
+ARG = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+
+
+def nbest(fn, h, text, k):
+    fn.restype = C.c_int64
+    fn.argtypes = ARG
+    cap = (len(text) + 8) * 4 * max(k, 1) + 64
+    ids = np.empty(cap, dtype=np.int32)
+    offs = np.zeros(min(max(k, 1), 1024) + 2, dtype=np.uint64)
+    scores = np.zeros(min(max(k, 1), 1024) + 1, dtype=np.float32)
+    n = fn(h, text, len(text), k, ids.ctypes.data, cap, offs.ctypes.data, scores.ctypes.data)
+    if n < 0:
+        return n, None, None
+    return n, [ids[int(offs[i]):int(offs[i + 1])].tolist() for i in range(n)], scores[:n].copy()
+
+
+@pytest.fixture(scope="module")
+def ref():
+    from tests import refshim
+    if not refshim.available():
+        pytest.skip("oracle/_ref/libspm_ref.so not built")
+    return refshim.RefLib()
+
+
+def sentences(corpora):
+    out = [b"", b" ", b"a", b"hello world", b"aaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaa", ("吾輩は猫である" * 3).encode(), b"\xff\xfe", "ＡＢＣ ① ㍿".encode(),
+           b"the the the the the the the the the the the the the the the the the the the the the the the the the"]
+    for name, k in (("edge", 10 ** 6), ("botchan", 60), ("ja", 8), ("mixed2k", 10)):
+        text, offs = fixtures.head(*corpora[name], k)
+        tb = np.asarray(text).tobytes()
+        out += [tb[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
+    return [s[:600] for s in out]
+
+
+@pytest.mark.parametrize("model", UNIGRAM)
+def test_oracle_nbest_matches_reference(model, oracle, ref, corpora):
+    blob = fixtures.model_blob(model)
+    o, r = oracle.load(blob), ref.load(blob)
+    for opts in ("", "bos:eos"):
+        o.set_encode_extra_options(opts)
+        r.set_encode_extra_options(opts)
+        for s in sentences(corpora):
+            for k in (1, 2, 5, 17):
+                n1, a, sa = nbest(o.lib.oracle_nbest_encode, o.h, s, k)
+                n2, b, sb = nbest(r.lib.spmref_nbest_encode, r.h, s, k)
+                assert n1 == n2, (model, s[:40], k)
+                assert a == b, (model, s[:40], k)
+                np.testing.assert_array_equal(sa, sb)
+
+
+def test_oracle_nbest_agenda_shrink(oracle, ref):
+    """A long ambiguous input drives the agenda past 10000 entries: the shrink to min(512, 10 nbest) (:487-514)."""
+    blob = fixtures.model_blob("test_model")
+    o, r = oracle.load(blob), ref.load(blob)
+    s = (b"this is a test of the emergency broadcast system " * 6)[:280]
+    for k in (64, 400):
+        n1, a, sa = nbest(o.lib.oracle_nbest_encode, o.h, s, k)
+        n2, b, sb = nbest(r.lib.spmref_nbest_encode, r.h, s, k)
+        assert n1 == n2 and a == b
+        np.testing.assert_array_equal(sa, sb)
+
+
+def test_nbest_is_unigram_only(oracle, ref):
+    blob = fixtures.model_blob("bpe1k")
+    o, r = oracle.load(blob), ref.load(blob)
+    assert nbest(o.lib.oracle_nbest_encode, o.h, b"hello", 3)[0] == -1
+    assert nbest(r.lib.spmref_nbest_encode, r.h, b"hello", 3)[0] == -1
