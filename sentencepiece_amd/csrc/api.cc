@@ -106,7 +106,7 @@ struct spmx_handle {
   DevBuf<uint64_t> d_tmp_off, d_tile_sums, d_chunk_base;
   DevBuf<int32_t> d_arena_tb, d_tok_begin;      // spans form
   DevBuf<uint32_t> d_span_begin, d_span_end, d_nspan_begin, d_nspan_end;
-  DevBuf<uint8_t> d_norm;
+  DevBuf<uint8_t> d_norm, d_bpe_long;
   DevBuf<int32_t> d_arena;
   Ctrl *d_ctrl = nullptr;
   Ctrl *h_ctrl = nullptr;   // pinned
@@ -212,7 +212,7 @@ void DestroyHandle(spmx_handle *h) {
   h->d_ndarts.Free(); h->d_npair.Free(); h->d_sym_final.Free(); h->d_nblob.Free(); h->d_ptrie.Free(); h->d_chartab.Free();
   h->d_pairtab.Free(); h->d_utrie.Free(); h->d_sym_len.Free(); h->d_byte_ids.Free();
   h->d_dec_info.Free(); h->d_dec_off.Free(); h->d_dec_bytes.Free();
-  h->d_stream.Free(); h->d_lists.Free(); h->d_counts.Free(); h->d_tmp_off.Free(); h->d_tile_sums.Free(); h->d_chunk_base.Free(); h->d_arena_tb.Free(); h->d_tok_begin.Free(); h->d_span_begin.Free(); h->d_span_end.Free(); h->d_nspan_begin.Free(); h->d_nspan_end.Free(); h->d_norm.Free(); h->d_arena.Free();
+  h->d_stream.Free(); h->d_lists.Free(); h->d_counts.Free(); h->d_tmp_off.Free(); h->d_tile_sums.Free(); h->d_chunk_base.Free(); h->d_arena_tb.Free(); h->d_tok_begin.Free(); h->d_span_begin.Free(); h->d_span_end.Free(); h->d_nspan_begin.Free(); h->d_nspan_end.Free(); h->d_norm.Free(); h->d_bpe_long.Free(); h->d_arena.Free();
   h->d_text.Free(); h->d_offs.Free(); h->d_id_offs.Free(); h->d_ids.Free();
   if (h->d_ctrl) (void)hipFree(h->d_ctrl);
   if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);
@@ -319,11 +319,16 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
     // cover both) takes them all.
     const bool merge01 = streaming && StreamFastEligible(h->dev.flags) && !h->no_fast && !h->no_merge_general && ncls >= 2 &&
                          cls[1].rcap <= kMaxStagedRaw;
+    HIP_OR_RETURN(h, hipMemcpyAsync(h->h_ctrl->list_counts, h->d_ctrl->list_counts, sizeof(h->h_ctrl->list_counts),
+                                    hipMemcpyDeviceToHost, stream));
+    HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+    for (int c = 0; c < ncls; ++c) known[c] = h->h_ctrl->list_counts[c];
+    if (!streaming)      // the sentence-per-wave kernels stage a whole sentence in LDS
+      for (int c = 0; c < ncls; ++c)
+        if (cls[c].rcap > kMaxStagedRaw && known[c] > 0)
+          return Fail(h, kOutOfRange, "a sentence is longer than 4096 bytes: this BPE model (not segmentable word by word, or with "
+                                      "unused pieces) is limited to that on the device path");
     if (streaming) {
-      HIP_OR_RETURN(h, hipMemcpyAsync(h->h_ctrl->list_counts, h->d_ctrl->list_counts, sizeof(h->h_ctrl->list_counts),
-                                      hipMemcpyDeviceToHost, stream));
-      HIP_OR_RETURN(h, hipStreamSynchronize(stream));
-      for (int c = 0; c < ncls; ++c) known[c] = h->h_ctrl->list_counts[c];
       // one scratch buffer serves every launch of the call (they run one after another): size it for the largest
       uint64_t need = 0;
       bool prev_general = false;
@@ -333,8 +338,11 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
         const bool fast = StreamFastEligible(h->dev.flags) && !h->no_fast && known[c] > 0;
         const bool staged = cls[c].rcap <= kMaxStagedRaw;   // document-length classes: FAST kernel only
         if (!staged && known[c] > 0 && !fast)
-          return Fail(h, kOutOfRange, "a sentence is longer than 8192 bytes: this model (user-defined symbols, whitespace-as-suffix "
-                                      "or unescaped U+2581 rules) is limited to that on the device path");
+          return Fail(h, kOutOfRange, h->model.model_type == kBpe
+                          ? "a sentence is longer than 4096 bytes: this BPE model (user-defined symbols, whitespace-as-suffix or "
+                            "unescaped U+2581 rules) is limited to that on the device path"
+                          : "a sentence is longer than 8192 bytes: this model (user-defined symbols, whitespace-as-suffix "
+                            "or unescaped U+2581 rules) is limited to that on the device path");
         if (!staged && known[c] > 0 && spans)
           return Fail(h, kOutOfRange, "a sentence is longer than 8192 bytes: the spans form is limited to that");
         if (!staged && !fast) continue;
@@ -346,6 +354,16 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
         prev_general = general;
       }
       HIP_OR_RETURN(h, h->d_stream.Reserve(need));
+      if (bpe_stream) {      // document-length classes: HBM slices for words that outgrow the LDS slots
+        uint64_t long_waves = 0;
+        for (int c = 0; c < ncls; ++c) {
+          if (cls[c].rcap <= kMaxStagedRaw || known[c] == 0) continue;
+          const StreamPlan sp = PlanStream(h, cls[c], true, known[c]);
+          const uint64_t w = static_cast<uint64_t>(sp.grid) * sp.waves;
+          if (w > long_waves) long_waves = w;
+        }
+        if (long_waves) HIP_OR_RETURN(h, h->d_bpe_long.Reserve(long_waves * 64u * kBpeLongBytes));
+      }
     }
     bool prev_general = false;
     for (int c = 0; c < ncls; ++c) {
@@ -394,6 +412,7 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
           const int slot = (fast && !is_fast) ? kSlotGeneral + c : c;
           a.stats = &h->d_ctrl->stats[kStatsPerClass * slot];
           a.tile_cursor = h->static_tiles ? nullptr : &h->d_ctrl->tile_cursor[slot];
+          a.bpe_long = (bpe_stream && !staged) ? h->d_bpe_long.p : nullptr;
           a.tiles_ascending = h->tiles_ascending ? 1u : 0u;
           a.wave_list = h->d_lists.p + static_cast<size_t>(2 * ncls + c) * n;
           a.wave_count = &h->d_ctrl->wave_counts[c];
@@ -408,10 +427,10 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
           h->slot_used[slot] = true;
         }
         prev_general = general;
-        if (bpe_stream) {   // what the lane form could not take (a word longer than kBpeWordMax): sentence per wave
+        if (bpe_stream && staged) {   // what the lane form could not take (a word longer than kBpeWordMax): sentence per wave
           a.list = h->d_lists.p + static_cast<size_t>(2 * ncls + c) * n;
           a.list_count = &h->d_ctrl->wave_counts[c];
-          const int slot = kMaxClasses / 2 + c;
+          const int slot = kSlotGeneral + 4 + c;     // (staged BPE classes are 0..3; GENERAL slots end at kSlotGeneral + 3)
           a.stats = &h->d_ctrl->stats[kStatsPerClass * slot];
           snprintf(h->slot_name[slot], sizeof(h->slot_name[slot]), "EncodeKernel<2, %d>", c);
           const uint32_t lds = EncodeLdsBytes(kBpe, a.rcap, a.ncap);
@@ -429,6 +448,7 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
         continue;
       }
       // BPE, sentence-per-wave form (models that are not word-wise, or SPMX_NO_STREAM)
+      if (cls[c].rcap > kMaxStagedRaw) continue;      // (empty: checked above)
       snprintf(h->slot_name[c], sizeof(h->slot_name[c]), "EncodeKernel<%d, %d>", h->model.model_type, c);
       const uint32_t lds = EncodeLdsBytes(h->model.model_type, a.rcap, a.ncap);
       int per_cu = static_cast<int>(kLdsPerCu / lds);

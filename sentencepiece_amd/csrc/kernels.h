@@ -57,6 +57,8 @@ struct EncodeArgs {
   uint32_t lane_general_min_lanes; // ... when at least this many lanes of the tile need it
   uint32_t *wave_list;          // BPE streaming kernels: sentences they leave to the sentence-per-wave kernel
   uint32_t *wave_count;
+  uint8_t *bpe_long;            // BPE streaming kernels, document-length classes: kBpeLongBytes per lane per wavefront
+                                // of the launch for words that outgrow the LDS slots; null: such a sentence goes to wave_list
   uint32_t *tile_cursor;        // streaming kernels: the launch's tile queue (zero at launch); null: fixed stride
   uint32_t tiles_ascending;     // A/B switch: hand the queue's tiles out shortest first
   int32_t *arena_tb;            // spans form (kernels_align.h), else null: next to every body id in `arena`, the

@@ -120,7 +120,9 @@ EncodeFn PickBpeStream(int cls) {
     case 0: return EncodeBpeStreamKernel<0, FAST>;
     case 1: return EncodeBpeStreamKernel<1, FAST>;
     case 2: return EncodeBpeStreamKernel<2, FAST>;
-    default: return EncodeBpeStreamKernel<3, FAST>;
+    case 3: return EncodeBpeStreamKernel<3, FAST>;
+    case 4: return EncodeBpeStreamKernel<4, FAST>;
+    default: return EncodeBpeStreamKernel<5, FAST>;
   }
 }
 }  // namespace

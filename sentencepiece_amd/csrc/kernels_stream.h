@@ -804,10 +804,15 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     } else {
       // ---- word by word, ids written as the words complete: the slot is filled from its start (end when reversing) ----
       n = bpe_stream_lane(d, gt, my_nlen, slot, tslot, cap, T.bw, T.asym, T.bwin + static_cast<uint32_t>(lane) * (kBpeWindow + 4u),
-                          kBpeWindow - 1u, lane, mine && !overflow);
+                          kBpeWindow - 1u, lane, mine && !overflow,
+                          a.bpe_long ? a.bpe_long + (static_cast<uint64_t>(wave_id) * 64u + static_cast<uint32_t>(lane)) * kBpeLongBytes : nullptr);
       c2 = wv::clock();
       at_end = (d.flags & kNfReverse) != 0;
       handed = n == -2;
+      if (wv::any(n == -4)) {                     // a word of more than kBpeLongMax characters: OUT_OF_RANGE for the call
+        if (lane == 0) wv::atomic_or(a.status, kStTooLong);
+        if (n == -4) { n = 0; mine = false; a.counts[my_sid] = 0; a.tmp_off[my_sid] = 0; }
+      }
       const uint64_t wm = wv::ballot(handed);
       if (wm) {                                 // words too long for the lane form: the sentence-per-wave kernel takes it
         const int leader = wv::ffs64(wm) - 1;

@@ -16,11 +16,14 @@ struct LengthClass { uint32_t rcap, ncap; };
 // kernel runs there (per-lane normalizers; its working set does not depend on the length), so they need a model
 // it can take (kernels_stream.h StreamFastEligible); ncap is the capacity of a text column there.
 constexpr int kNumClassesUnigram = 7;
-constexpr int kNumClassesBpe = 4;
+constexpr int kNumClassesBpe = 6;
 constexpr uint32_t kMaxStagedRaw = 8192;   // GENERAL kernels stage one sentence in LDS: classes up to this raw size
 constexpr LengthClass kClassesUnigram[kNumClassesUnigram] = {
     {192, 448}, {576, 1280}, {1536, 3328}, {4096, 8704}, {8192, 20480}, {65536, 98304}, {1048576, 1572864}};
-constexpr LengthClass kClassesBpe[kNumClassesBpe] = {{192, 448}, {576, 1280}, {1536, 3328}, {4096, 6400}};
+// BPE: the last two classes are document-length as well (word-wise models the FAST kernel can take: the lane form's
+// working set is one word; a word that outgrows the LDS slots is merged in HBM, kernels_bpe_stream.h).
+constexpr LengthClass kClassesBpe[kNumClassesBpe] = {{192, 448}, {576, 1280}, {1536, 3328}, {4096, 6400},
+                                                     {65536, 98304}, {1048576, 1572864}};
 
 // score ring entries for a model whose longest piece has max_piece_len bytes
 inline uint32_t ScoreRing(int max_piece_len) {

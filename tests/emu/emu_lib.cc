@@ -136,7 +136,7 @@ struct LengthClass { uint32_t rcap, ncap; };
 // (the last class stands for the document-length classes: FAST kernel only, no staging)
 const LengthClass kUniCls[] = {{24, 40}, {192, 448}, {576, 1280}, {1536, 3328}, {4096, 8704}, {8192, 20480}, {65536, 98304}};
 const uint32_t kEmuMaxStagedRaw = 8192;
-const LengthClass kBpeCls[] = {{24, 40}, {192, 448}, {576, 1280}, {1536, 3328}, {4096, 6400}};
+const LengthClass kBpeCls[] = {{24, 40}, {192, 448}, {576, 1280}, {1536, 3328}, {4096, 6400}, {65536, 98304}};
 }  // namespace
 
 extern "C" {
@@ -257,6 +257,8 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
         std::vector<unsigned char> fsmem(StreamLdsBytes(true, model, a.rcap, a.ncap, a.ring, 1) + 64, 0xCD);
         uint32_t fast_cursor = 0;
         a.tile_cursor = getenv("SPMX_STATIC_TILES") ? nullptr : &fast_cursor;
+        std::vector<uint8_t> bpe_long((bpe && !staged) ? static_cast<size_t>(waves) * 64u * kBpeLongBytes : 0, 0xCD);
+        a.bpe_long = (bpe && !staged) ? bpe_long.data() : nullptr;
         for (int b = 0; b < grid; ++b) {
           if (bpe) emu::RunWave(b, grid, fsmem.data(), [&] { encode_stream_block<true, 2>(a, fsmem.data()); });
           else if (a.ring == 16) emu::RunWave(b, grid, fsmem.data(), [&] { encode_stream_block<true, 1, 16>(a, fsmem.data()); });   // as LaunchEncodeStream picks
@@ -287,6 +289,7 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
       continue;
     }
     // BPE, sentence-per-wave form (models that are not word-wise, or SPMX_NO_STREAM)
+    if (a.rcap > kEmuMaxStagedRaw) { if (list_counts[c]) status |= kStTooLong; continue; }   // csrc/api.cc fails the call
     std::vector<unsigned char> smem(EncodeLdsBytes(dev.model_type, a.rcap, a.ncap) + 64, 0xCD);
     for (int b = 0; b < grid; ++b) {
       emu::RunWave(b, grid, smem.data(), [&] { encode_block<2>(a, smem.data()); });

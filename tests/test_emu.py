@@ -254,3 +254,18 @@ def test_emu_fast_keeps_identity_characters(model, emu, oracle):
     np.testing.assert_array_equal(ids, oids)
     kept, handed = h.fast_split()
     assert kept >= 0.7 * 300 and handed >= n_leave // 2     # (a stray byte can start a key together with its neighbour)
+
+
+@pytest.mark.parametrize("model", ["bpe1k", "bpe1k_llama"])
+def test_emu_bpe_documents(model, emu, oracle):
+    """BPE document-length class: the lane form with the HBM merge for words that outgrow the LDS slots."""
+    from tests.test_gpu_parity import bpe_documents
+    text, offs = bpe_documents()
+    text, offs = fixtures.head(text, offs, 8)
+    blob = fixtures.model_blob(model)
+    h, o = emu.load(blob), oracle.load(blob)
+    ids, io = h.encode_batch(text, offs, grid=2)
+    assert h.status == 0
+    oids, oio = o.encode_batch(text, offs)
+    np.testing.assert_array_equal(io, oio)
+    np.testing.assert_array_equal(ids, oids)

@@ -74,3 +74,56 @@ def test_document_length_sentences(procs, oracle, corpora):
     assert "8192" in str(ei.value)
     with pytest.raises(Exception):
         procs("test_model").EncodePacked(*synth.pack([b"z" * (1 << 20) + b"!"]))
+
+
+def bpe_documents():
+    """Documents of 4-20 KB with URL-like words (20-200 characters), blobs of 300-1500 characters, CJK and accented runs."""
+    from sentencepiece_amd import synth
+    rng = np.random.default_rng(11)
+    words = [b"hello", b"world", b"the", b"tokenizer", b"a", b"of"]
+    al = b"abcdefghijklmnopqrstuvwxyz0123456789/_-.%"
+
+    def longword(n):
+        return bytes(al[int(k)] for k in rng.integers(0, len(al), size=n))
+    docs = []
+    for i in range(24):
+        parts, ln, target = [], 0, int(rng.integers(4200, 20000))
+        while ln < target:
+            r = rng.random()
+            if r < 0.03:
+                w = b"https://" + longword(int(rng.integers(20, 200)))
+            elif r < 0.035:
+                w = longword(int(rng.integers(300, 1500)))
+            elif r < 0.05:
+                w = "日本語のテキスト".encode()
+            elif r < 0.06:
+                w = ("é" * int(rng.integers(1, 40))).encode()
+            else:
+                w = words[int(rng.integers(0, len(words)))]
+            parts.append(w)
+            ln += len(w) + 1
+        docs.append(b" ".join(parts))
+    return synth.pack(docs)
+
+
+def test_bpe_document_length_sentences(procs, oracle, corpora):
+    """BPE models take documents too (the lane form works word by word; a word that outgrows its LDS slots is merged in
+    HBM): ids equal to the oracle's; a word of more than 4096 characters, and models that cannot be segmented word by
+    word, stop with OUT_OF_RANGE."""
+    from sentencepiece_amd import synth
+    text, offs = bpe_documents()
+    bot, boffs = corpora["botchan"]
+    big = synth.pack([bot[:int(boffs[1600])].tobytes().replace(b"\n", b" "), b"ab " * 300000])
+    for model in ("bpe1k", "bpe32k", "bpe1k_llama"):
+        sp = procs(model)
+        o = oracle.load(fixtures.model_blob(model))
+        for t, of in ((text, offs), big):
+            ids, io = sp.EncodePacked(t, of)
+            oids, oio = o.encode_batch(t, of)
+            np.testing.assert_array_equal(io, oio)
+            np.testing.assert_array_equal(ids, oids)
+    with pytest.raises(Exception):
+        procs("bpe1k").EncodePacked(*synth.pack([b"x" * 5000]))
+    with pytest.raises(Exception) as ei:
+        procs("bpe1k_bf_uds").EncodePacked(*synth.pack([b"hello world " * 500]))
+    assert "4096" in str(ei.value)
