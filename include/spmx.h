@@ -73,8 +73,9 @@ int spmx_model_type(const spmx_handle *h);   /* 1 unigram, 2 bpe */
  * computes with a thread pool.
  *
  * Length limits of the device path (OUT_OF_RANGE beyond them; the reference has none): 1 MiB per sentence for
- * unigram models without user-defined symbols / whitespace-as-suffix, 8192 bytes for other unigram models, 4096
- * bytes for BPE models.
+ * models without user-defined symbols / whitespace-as-suffix -- unigram, and BPE whose pieces do not span words
+ * (the usual case; a single word may have up to 4096 characters); 8192 bytes for the other unigram models, 4096
+ * bytes for the other BPE models.
  *
  * Sentences are passed packed: `text` holds the bytes of all sentences back to
  * back, offsets[i] .. offsets[i+1] delimit sentence i (n + 1 entries).
