@@ -315,6 +315,23 @@ int64_t spmref_nbest_encode(void *handle, const char *text, uint64_t len, int nb
   return nb.nbests_size();
 }
 
+// EncodeAsSerializedProto(input) per sentence (sentencepiece_processor.h:493-494): the serialized SentencePieceText
+// messages back to back, message i at out[out_offs[i], out_offs[i + 1]).
+int64_t spmref_encode_serialized_batch(void *handle, const char *text, const uint64_t *offsets, uint64_t n, char *out,
+                                       uint64_t cap, uint64_t *out_offs) {
+  auto *h = static_cast<RefHandle *>(handle);
+  uint64_t total = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    out_offs[i] = total;
+    const std::string s = h->sp.EncodeAsSerializedProto(absl::string_view(text + offsets[i], offsets[i + 1] - offsets[i]));
+    if (total + s.size() <= cap && !s.empty()) memcpy(out + total, s.data(), s.size());
+    total += s.size();
+  }
+  out_offs[n] = total;
+  if (total > cap) return -static_cast<int64_t>(total) - 2;
+  return static_cast<int64_t>(total);
+}
+
 int spmref_piece_size(void *handle) {
   return static_cast<RefHandle *>(handle)->sp.GetPieceSize();
 }

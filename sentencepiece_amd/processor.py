@@ -211,8 +211,12 @@ class SentencePieceProcessor:
                     if emit:
                         row[:] = [unk if self.PieceToId(p) == self.unk_id() else p for p in row]
             return rows[0] if single else rows
+        if out_type == "serialized_proto":
+            if any([add_bos, add_eos, reverse, emit_unk_piece]):     # sentencepiece.i:166-175
+                raise NotImplementedError("add_bos, add_eos, reverse, and emit_unk_piece is not supported in proto API")
+            return self.EncodeAsSerializedProto(input)
         if out_type is not int:
-            raise NotImplementedError("out_type int and str are on the device path; proto outputs are not")
+            raise NotImplementedError("out_type int, str and 'serialized_proto' are on the device path")
         self._apply(self._add_bos if add_bos is None else add_bos,
                     self._add_eos if add_eos is None else add_eos,
                     self._reverse if reverse is None else reverse)
@@ -381,6 +385,28 @@ class SentencePieceProcessor:
                     piece = norm[base + int(nb[k]):base + int(ne[k])]
                 row.append((piece, t, r[int(b[k]):int(e[k])], int(b[k]), int(e[k])))
             out.append(row)
+        return out[0] if single else out
+
+    def EncodeAsSerializedProto(self, input):
+        """``EncodeAsSerializedProto`` (src/sentencepiece_processor.h:528-531) / ``encode(out_type="serialized_proto")``:
+        the serialized ``SentencePieceText`` of every sentence (bytes; a list gives a list)."""
+        from . import spt_proto
+        single = isinstance(input, (str, bytes))
+        items = [input] if single else list(input)
+        raw = [x.encode("utf-8") if isinstance(x, str) else bytes(x) for x in items]
+        offs = np.zeros(len(raw) + 1, dtype=np.uint64)
+        if raw:
+            np.cumsum([len(x) for x in raw], out=offs[1:])
+        text = np.frombuffer(b"".join(raw), dtype=np.uint8)
+        ids, b, e, io, nb, ne = self.EncodeSpansPacked(text, offs, norm_spans=True)
+        rows = self.EncodeAsSentencePieceText(raw)
+        rev = sum(1 for o in (self._extra or "").split(":") if o == "reverse") % 2 == 1
+        out = []
+        for i, r in enumerate(raw):
+            lo, hi = int(io[i]), int(io[i + 1])
+            has = spt_proto.surface_flags(ids[lo:hi], nb[lo:hi], self.IsByte, self.IsControl, rev)
+            out.append(spt_proto.serialize(r, [(p, t, sf if has[k] else None, pb, pe)
+                                               for k, (p, t, sf, pb, pe) in enumerate(rows[i])]))
         return out[0] if single else out
 
     def EncodeAsPieces(self, input):

@@ -1,0 +1,65 @@
+"""Wire format of the reference's ``SentencePieceText`` message (src/sentencepiece.proto): what
+``EncodeAsSerializedProto`` (src/sentencepiece_processor.h:528-531) returns.  Host-side assembly only: the fields come
+from the device (ids, byte ranges, normalized-text ranges, normalized text); no protobuf runtime is needed.
+
+  message SentencePieceText {
+    optional string text = 1;
+    message SentencePiece { optional string piece = 1; optional uint32 id = 2; optional string surface = 3;
+                            optional uint32 begin = 4; optional uint32 end = 5; }
+    repeated SentencePiece pieces = 2;
+    optional float score = 3;          // not set by Encode
+  }
+
+proto2 presence: a field is written iff it was set.  PopulateSentencePieceText (src/sentencepiece_processor.cc:547-636)
+sets piece / id / begin / end on every piece and surface on every piece except the byte-fallback pieces before the last
+one of their character (:598-603); the bos / eos pieces of the extra options carry no surface (:1029-1048)."""
+
+
+def _varint(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _bytes_field(num, b):
+    return _varint(num << 3 | 2) + _varint(len(b)) + b
+
+
+def _uint_field(num, v):
+    return _varint(num << 3) + _varint(v)
+
+
+def serialize(text, pieces):
+    """``text`` bytes; ``pieces`` iterable of ``(piece bytes, id, surface bytes | None, begin, end)``."""
+    out = bytearray(_bytes_field(1, text))
+    for piece, pid, surface, begin, end in pieces:
+        m = _bytes_field(1, piece) + _uint_field(2, pid)
+        if surface is not None:
+            m += _bytes_field(3, surface)
+        m += _uint_field(4, begin) + _uint_field(5, end)
+        out += _bytes_field(2, m)
+    return bytes(out)
+
+
+def surface_flags(ids, nbegin, is_byte, is_control, reversed_order):
+    """Which pieces of one sentence carry a surface.  ``ids`` / ``nbegin`` in output order; ``is_byte(id)`` /
+    ``is_control(id)`` piece-type predicates; ``reversed_order``: the ``reverse`` extra option is in effect.
+    The byte pieces of one unknown character are consecutive and share their normalized begin; only the one that
+    was last in text order has the surface."""
+    n = len(ids)
+    has = [True] * n
+    for k in range(n):
+        t = int(ids[k])
+        if is_control(t):
+            has[k] = False
+        elif is_byte(t):
+            nxt = k - 1 if reversed_order else k + 1       # the piece that follows in text order
+            if 0 <= nxt < n and is_byte(int(ids[nxt])) and int(nbegin[nxt]) == int(nbegin[k]):
+                has[k] = False
+    return has

@@ -146,3 +146,107 @@ def test_gpu_encode_out_type_str_matches_wheel():
                {"add_bos": True, "reverse": True, "emit_unk_piece": True}):
         assert sp.encode(lines, out_type=str, **kw) == ref.encode(lines, out_type=str, **kw), kw
         assert sp.encode(lines[2], out_type=str, **kw) == ref.encode(lines[2], out_type=str, **kw), kw
+
+
+def _ref_serialized(r, text, offs):
+    import ctypes as C
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    n = len(offs) - 1
+    cap = int(len(text)) * 120 + 64 * n + 256
+    out = np.empty(cap, dtype=np.uint8)
+    oo = np.zeros(n + 1, dtype=np.uint64)
+    fn = r.lib.spmref_encode_serialized_batch
+    fn.restype = C.c_int64
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]
+    tot = fn(r.h, text.ctypes.data if len(text) else None, offs.ctypes.data, n, out.ctypes.data, cap, oo.ctypes.data)
+    assert tot >= 0
+    b = out[:tot].tobytes()
+    return [b[int(oo[i]):int(oo[i + 1])] for i in range(n)]
+
+
+@pytest.mark.parametrize("model", ["test_model", "uni1k_bf", "bpe1k", "bpe1k_llama", "uni1k_uds", "test_ja_model"])
+def test_emu_serialized_proto(model, emu, ref, corpora):
+    """EncodeAsSerializedProto: the device outputs (emulated) through the host-side wire-format assembly
+    (sentencepiece_amd/spt_proto.py) against the compiled reference's SerializeAsString, byte for byte."""
+    from sentencepiece_amd import spt_proto
+    blob = fixtures.model_blob(model)
+    h, r = emu.load(blob), ref.load(blob)
+    types, names = piece_types(model)
+    for opts in ("", "reverse:bos:eos", "unk_piece"):
+        h.set_encode_extra_options(opts)
+        r.set_encode_extra_options(opts)
+        rev = opts.split(":").count("reverse") % 2 == 1
+        lit = literal_fn(types, "unk" in opts)
+        for name, (text, offs) in inputs(corpora):
+            want = _ref_serialized(r, text, offs)
+            norm, no, _ = h.normalize_batch(text, offs, grid=2)
+            ids, b, e, io, nb, ne = h.encode_spans(text, offs, grid=2, norm_spans=True)
+            nbytes = norm.tobytes()
+            tb = np.asarray(text).tobytes()
+            for i in range(len(offs) - 1):
+                raw = tb[int(offs[i]):int(offs[i + 1])]
+                lo, hi = int(io[i]), int(io[i + 1])
+                has = spt_proto.surface_flags(ids[lo:hi], nb[lo:hi], lambda t: types[t] == 6, lambda t: types[t] == 3, rev)
+                pcs = []
+                for k in range(lo, hi):
+                    t = int(ids[k])
+                    piece = names[t] if lit(t) else nbytes[int(no[i]) + int(nb[k]):int(no[i]) + int(ne[k])]
+                    pcs.append((piece, t, raw[int(b[k]):int(e[k])] if has[k - lo] else None, int(b[k]), int(e[k])))
+                assert spt_proto.serialize(raw, pcs) == want[i], (model, name, opts, i)
+
+
+@pytest.mark.gpu
+def test_gpu_serialized_proto(ref, corpora):
+    from sentencepiece_amd.processor import SentencePieceProcessor
+    for model in ("test_model", "uni1k_bf", "bpe1k"):
+        blob = fixtures.model_blob(model)
+        sp, r = SentencePieceProcessor(model_proto=blob), ref.load(blob)
+        for opts in ("", "reverse:bos:eos"):
+            sp.SetEncodeExtraOptions(opts)
+            r.set_encode_extra_options(opts)
+            for name, (text, offs) in inputs(corpora):
+                tb = np.asarray(text).tobytes()
+                lines = [tb[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
+                assert sp.EncodeAsSerializedProto(lines) == _ref_serialized(r, text, offs), (model, name, opts)
+
+
+def test_processor_glue_with_emulated_device(emu, ref, corpora):
+    """The Python facade's own assembly code (EncodeAsSentencePieceText / EncodeAsPieces / EncodeAsSerializedProto /
+    Normalize) with the device calls answered by the emulator: what runs on a GPU box, minus the GPU."""
+    from sentencepiece_amd.processor import SentencePieceProcessor
+    for model, opts in (("uni1k_bf", "reverse:bos:eos"), ("test_model", ""), ("bpe1k", "unk_piece")):
+        blob = fixtures.model_blob(model)
+        h, r = emu.load(blob), ref.load(blob)
+        h.set_encode_extra_options(opts)
+        r.set_encode_extra_options(opts)
+        types, names = piece_types(model)
+        sp = SentencePieceProcessor.__new__(SentencePieceProcessor)
+        sp._extra = opts
+        sp.EncodeSpansPacked = lambda text, offs, norm_spans=False: h.encode_spans(text, offs, grid=2, norm_spans=norm_spans)
+        sp.NormalizePacked = lambda text, offs, with_offsets=False: h.normalize_batch(text, offs, grid=2)
+        sp.IsByte = lambda t: types[t] == 6
+        sp.IsControl = lambda t: types[t] == 3
+        sp.IdToPiece = lambda t: names[t].decode("utf-8")
+        sp.unk_id = lambda: types.index(2)
+        text, offs = next(x for nm, x in inputs(corpora) if nm == "extra")
+        tb = np.asarray(text).tobytes()
+        lines = [tb[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
+        assert sp.EncodeAsSerializedProto(lines) == _ref_serialized(r, text, offs)
+        assert sp.EncodeAsSerializedProto(lines[3]) == _ref_serialized(r, text, offs)[3]
+        ids, b, e, io, pblob, poffs = r.encode_pieces(text, offs)
+        got = sp.EncodeAsPieces(lines)
+        k = 0
+        for row in got:
+            for p in row:
+                assert p.encode("utf-8", "surrogateescape") == pblob[int(poffs[k]):int(poffs[k + 1])]
+                k += 1
+        assert k == len(ids)
+        if not opts:
+            s, a = sp.Normalize(lines[7].decode("utf-8", "surrogateescape"), with_offsets=True)
+            nn, no, n2o = r.normalize_batch(*packed_one(lines[7]))
+            assert s.encode("utf-8", "surrogateescape") == nn.tobytes() and a == [int(v) for v in n2o]
+
+
+def packed_one(b):
+    return np.frombuffer(b, dtype=np.uint8), np.array([0, len(b)], dtype=np.uint64)
