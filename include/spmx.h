@@ -150,6 +150,16 @@ int spmx_normalize_batch_device(spmx_handle *h, const void *d_text, const uint64
 int spmx_normalize_batch(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, char **norm,
                          uint64_t **norm_offsets, uint32_t **norm_to_orig);
 
+/* ---- n-best -------------------------------------------------------------
+ * NBestEncode(input, nbest_size, std::vector<std::vector<int>>*) (src/sentencepiece_processor.h:360-362;
+ * unigram::Model::NBestEncode src/unigram_model.cc:686-717, Lattice::NBest :345-515) per sentence, unigram models
+ * only (INTERNAL otherwise, as the reference).  nbest_size is clamped to [1, 1024]; 1 is the plain encoder with
+ * score 0.  Result r of the batch: ids[id_offsets[r], id_offsets[r + 1]) and scores[r]; sentence s owns the
+ * results [result_offsets[s], result_offsets[s + 1]) (n + 1 entries), best first.  The four arrays are released
+ * with spmx_free().  Sentences are limited to 8192 bytes and 1024 normalized bytes (OUT_OF_RANGE beyond). */
+int spmx_nbest_encode_batch(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int nbest_size,
+                            int32_t **ids, uint64_t **id_offsets, float **scores, uint64_t **result_offsets);
+
 /* ---- corpus packer ------------------------------------------------------
  * The caller-side step of the reference's spm_encode (src/spm_encode_main.cc:159-165: std::getline over the input
  * file, one Encode per line) on the device: a file image with '\n'-terminated lines -> the packed text (without

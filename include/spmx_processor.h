@@ -230,6 +230,27 @@ class SentencePieceProcessor {
     return pieces;
   }
 
+  // ---- n-best (sentencepiece_processor.h:360-362; unigram models) ----
+  util::Status NBestEncode(std::string_view input, int nbest_size, std::vector<std::vector<int>> *ids) const {
+    if (!h_) return status();
+    if (!ids) return util::Status(util::StatusCode::kInternal, "output container is null");
+    ids->clear();
+    const uint64_t offs[2] = {0, input.size()};
+    int32_t *i = nullptr;
+    uint64_t *io = nullptr, *ro = nullptr;
+    float *sc = nullptr;
+    const int rc = spmx_nbest_encode_batch(h_, input.data() ? input.data() : "", offs, 1, nbest_size, &i, &io, &sc, &ro);
+    if (rc == 0)
+      for (uint64_t r = ro[0]; r < ro[1]; ++r) ids->emplace_back(i + io[r], i + io[r + 1]);
+    spmx_free(i); spmx_free(io); spmx_free(sc); spmx_free(ro);
+    return FromHandle(rc);
+  }
+  std::vector<std::vector<int>> NBestEncodeAsIds(std::string_view input, int nbest_size) const {   // errors are swallowed
+    std::vector<std::vector<int>> ids;
+    (void)NBestEncode(input, nbest_size, &ids);
+    return ids;
+  }
+
   // ---- Normalize (sentencepiece_processor.h:326-336) ----
   util::Status Normalize(std::string_view input, std::string *normalized, std::vector<size_t> *norm_to_orig) const {
     if (!h_) return status();

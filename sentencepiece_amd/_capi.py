@@ -51,6 +51,9 @@ SYMBOLS = [
      [_H, C.c_void_p, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_U64)]),
     ("spmx_normalize_batch", C.c_int,
      [_H, C.c_void_p, C.c_void_p, _U64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    ("spmx_nbest_encode_batch", C.c_int,
+     [_H, C.c_void_p, C.c_void_p, _U64, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+      C.POINTER(C.c_void_p)]),
     ("spmx_split_lines_device", C.c_int,
      [_H, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, C.POINTER(_U64), C.POINTER(_U64)]),
     ("spmx_set_profiling", C.c_int, [_H, C.c_int]),

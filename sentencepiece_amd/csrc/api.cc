@@ -106,7 +106,9 @@ struct spmx_handle {
   DevBuf<uint64_t> d_tmp_off, d_tile_sums, d_chunk_base;
   DevBuf<int32_t> d_arena_tb, d_tok_begin;      // spans form
   DevBuf<uint32_t> d_span_begin, d_span_end, d_nspan_begin, d_nspan_end;
-  DevBuf<uint8_t> d_norm, d_bpe_long;
+  DevBuf<uint8_t> d_norm, d_bpe_long, d_nbest_scratch;
+  DevBuf<unsigned long long> d_res_off;
+  DevBuf<float> d_res_score;
   DevBuf<int32_t> d_arena;
   Ctrl *d_ctrl = nullptr;
   Ctrl *h_ctrl = nullptr;   // pinned
@@ -212,7 +214,7 @@ void DestroyHandle(spmx_handle *h) {
   h->d_ndarts.Free(); h->d_npair.Free(); h->d_sym_final.Free(); h->d_nblob.Free(); h->d_ptrie.Free(); h->d_chartab.Free();
   h->d_pairtab.Free(); h->d_utrie.Free(); h->d_sym_len.Free(); h->d_byte_ids.Free();
   h->d_dec_info.Free(); h->d_dec_off.Free(); h->d_dec_bytes.Free();
-  h->d_stream.Free(); h->d_lists.Free(); h->d_counts.Free(); h->d_tmp_off.Free(); h->d_tile_sums.Free(); h->d_chunk_base.Free(); h->d_arena_tb.Free(); h->d_tok_begin.Free(); h->d_span_begin.Free(); h->d_span_end.Free(); h->d_nspan_begin.Free(); h->d_nspan_end.Free(); h->d_norm.Free(); h->d_bpe_long.Free(); h->d_arena.Free();
+  h->d_stream.Free(); h->d_lists.Free(); h->d_counts.Free(); h->d_tmp_off.Free(); h->d_tile_sums.Free(); h->d_chunk_base.Free(); h->d_arena_tb.Free(); h->d_tok_begin.Free(); h->d_span_begin.Free(); h->d_span_end.Free(); h->d_nspan_begin.Free(); h->d_nspan_end.Free(); h->d_norm.Free(); h->d_bpe_long.Free(); h->d_nbest_scratch.Free(); h->d_res_off.Free(); h->d_res_score.Free(); h->d_arena.Free();
   h->d_text.Free(); h->d_offs.Free(); h->d_id_offs.Free(); h->d_ids.Free();
   if (h->d_ctrl) (void)hipFree(h->d_ctrl);
   if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);
@@ -562,7 +564,7 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
 // Caller holds h->mu and has set the device.
 int NormalizeDevice(spmx_handle *h, const uint8_t *d_text, const uint64_t *d_offsets, uint64_t n, uint8_t *d_norm,
                     uint64_t norm_capacity, uint64_t *d_norm_offsets, uint32_t *d_n2o, hipStream_t stream,
-                    uint64_t *total_bytes) {
+                    uint64_t *total_bytes, bool device_text = false) {
   if (total_bytes) *total_bytes = 0;
   if (n >= (1ull << 32) - 64) return Fail(h, kInvalidArgument, "more than 2^32 - 64 sentences in one batch");
   if (!d_offsets || !d_norm_offsets) return Fail(h, kInvalidArgument, "null offsets");
@@ -599,6 +601,7 @@ int NormalizeDevice(spmx_handle *h, const uint8_t *d_text, const uint64_t *d_off
       a.next_count = has_next ? &h->d_ctrl->list_counts[c + 1] : nullptr;
       a.counts = h->d_counts.p; a.norm_offs = d_norm_offsets; a.norm = d_norm; a.n2o = d_n2o;
       a.status = &h->d_ctrl->status; a.rcap = cls[c].rcap; a.ncap = cls[c].ncap;
+      a.device_text = device_text ? 1u : 0u;
       const uint32_t lds = NormalizeLdsBytes(a.rcap, a.ncap);
       int per_cu = static_cast<int>(kLdsPerCu / lds);
       if (per_cu > 32) per_cu = 32;
@@ -928,6 +931,121 @@ int spmx_encode_batch_spans_device(spmx_handle *h, const void *d_text, uint64_t 
   HIP_OR_RETURN(h, hipSetDevice(h->device));
   return EncodeDevice(h, static_cast<const uint8_t *>(d_text), text_bytes, d_offsets, n, d_ids, ids_capacity,
                       d_id_offsets, static_cast<hipStream_t>(stream), total_ids, d_begin, d_end, d_nbegin, d_nend);
+}
+
+// NBestEncode (kernels_nbest.h), host-buffer form.
+int spmx_nbest_encode_batch(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int nbest_size,
+                            int32_t **ids, uint64_t **id_offsets, float **scores, uint64_t **result_offsets) {
+  if (!h) return kInvalidArgument;
+  if (!ids || !id_offsets || !scores || !result_offsets) {
+    std::lock_guard<std::mutex> l(h->mu);
+    return Fail(h, kInternal, "output container is null");
+  }
+  *ids = nullptr; *id_offsets = nullptr; *scores = nullptr; *result_offsets = nullptr;
+  if (h->model.model_type != kUnigram) {
+    std::lock_guard<std::mutex> l(h->mu);
+    return Fail(h, kInternal, "NBestEncode is not available for the current model.");   // sentencepiece_processor.cc:662
+  }
+  if (nbest_size > 1024) nbest_size = 1024;                                              // unigram_model.cc:692
+  if (nbest_size < 1) nbest_size = 1;
+  if (nbest_size == 1 || n == 0) {          // :694-696 the plain encoder, score 0.0; one result per sentence
+    int32_t *i1 = nullptr;
+    uint64_t *o1 = nullptr;
+    const int rc = EncodeBatchHost(h, text, offsets, n, &i1, &o1, nullptr, nullptr);
+    if (rc != kOk) return rc;
+    uint64_t *ro = static_cast<uint64_t *>(malloc((n + 1) * sizeof(uint64_t)));
+    float *sc = static_cast<float *>(calloc(n + 1, sizeof(float)));
+    if (!ro || !sc) { free(i1); free(o1); free(ro); free(sc); std::lock_guard<std::mutex> l(h->mu); return Fail(h, kResourceExhausted, "out of host memory"); }
+    for (uint64_t s = 0; s <= n; ++s) ro[s] = s;
+    *ids = i1; *id_offsets = o1; *scores = sc; *result_offsets = ro;
+    return kOk;
+  }
+  std::lock_guard<std::mutex> l(h->mu);
+  if (!offsets) return Fail(h, kInvalidArgument, "null offsets");
+  HIP_OR_RETURN(h, hipSetDevice(h->device));
+  const uint64_t base = offsets[0], text_bytes = offsets[n] - base;
+  HIP_OR_RETURN(h, h->d_text.Reserve(text_bytes + 16));
+  HIP_OR_RETURN(h, h->d_offs.Reserve(n + 1));
+  HIP_OR_RETURN(h, h->d_id_offs.Reserve(n + 1));
+  if (text_bytes) HIP_OR_RETURN(h, hipMemcpyAsync(h->d_text.p, text + base, text_bytes, hipMemcpyHostToDevice, nullptr));
+  HIP_OR_RETURN(h, hipMemcpyAsync(h->d_offs.p, offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, nullptr));
+  const uint8_t *d_text = h->d_text.p - base;
+  uint64_t ncap = 2 * text_bytes + 4 * n + 64, ntotal = 0;
+  int rc = kOk;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    HIP_OR_RETURN(h, h->d_norm.Reserve(ncap));
+    rc = NormalizeDevice(h, d_text, h->d_offs.p, n, h->d_norm.p, h->d_norm.cap, h->d_id_offs.p, nullptr, nullptr, &ntotal, true);
+    if (rc != kResourceExhausted || ntotal <= h->d_norm.cap) break;
+    ncap = ntotal;
+  }
+  if (rc != kOk) return rc;
+  const uint32_t K = static_cast<uint32_t>(nbest_size);
+  NBestArgs a{};
+  a.dev = h->dev; a.norm = h->d_norm.p; a.norm_offs = h->d_id_offs.p; a.n = static_cast<uint32_t>(n); a.nbest = K;
+  uint64_t hyps = static_cast<uint64_t>(K) * 2048;
+  a.max_hyps = static_cast<uint32_t>(hyps < 16384 ? 16384 : (hyps > 262144 ? 262144 : hyps));
+  a.lane_bytes = (NbestLaneBytes(a.max_hyps) + 15) / 16 * 16;
+  uint64_t waves = (n + 63) / 64;
+  const uint64_t budget = 8ull << 30;                       // HBM for the lanes' slices
+  if (waves * 64 * a.lane_bytes > budget) waves = budget / (64 * a.lane_bytes);
+  if (waves > static_cast<uint64_t>(h->n_cu) * 8) waves = static_cast<uint64_t>(h->n_cu) * 8;
+  if (waves < 1) waves = 1;
+  HIP_OR_RETURN(h, h->d_nbest_scratch.Reserve(waves * 64 * a.lane_bytes));
+  HIP_OR_RETURN(h, h->d_res_off.Reserve(n * K + 1));
+  HIP_OR_RETURN(h, h->d_span_begin.Reserve(n * K + 1));     // result lengths
+  HIP_OR_RETURN(h, h->d_res_score.Reserve(n * K + 1));
+  HIP_OR_RETURN(h, h->d_counts.Reserve(n + 1));
+  a.scratch = h->d_nbest_scratch.p;
+  a.res_off = h->d_res_off.p; a.res_len = h->d_span_begin.p; a.res_score = h->d_res_score.p; a.res_count = h->d_counts.p;
+  a.status = &h->d_ctrl->status; a.arena_head = &h->d_ctrl->arena_head;
+  uint64_t arena_need = (ntotal + (4 + static_cast<uint64_t>(h->dev.n_prefix + h->dev.n_suffix)) * n) * (K < 8 ? K : 8) + 1024;
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    HIP_OR_RETURN(h, h->d_arena.Reserve(arena_need));
+    a.arena = h->d_arena.p; a.arena_cap = h->d_arena.cap;
+    HIP_OR_RETURN(h, hipMemsetAsync(h->d_ctrl, 0, sizeof(Ctrl), nullptr));
+    HIP_OR_RETURN(h, LaunchNBest(a, static_cast<int>(waves), nullptr));
+    HIP_OR_RETURN(h, hipMemcpyAsync(h->h_ctrl, h->d_ctrl, offsetof(Ctrl, total_ids), hipMemcpyDeviceToHost, nullptr));
+    HIP_OR_RETURN(h, hipStreamSynchronize(nullptr));
+    const uint32_t st = h->h_ctrl->status;
+    if (st & kStTooLong) return Fail(h, kOutOfRange, "NBestEncode on the device is limited to 1024 normalized bytes per sentence");
+    if (st & kStNbestOverflow) return Fail(h, kResourceExhausted, "NBestEncode: the lattice or the agenda of a sentence exceeds the device capacities");
+    if (st & kStArenaOverflow) { arena_need = h->h_ctrl->arena_head + 1024; continue; }
+    // results -> host CSR
+    std::vector<uint32_t> cnt(n), len(n * K);
+    std::vector<unsigned long long> off(n * K);
+    std::vector<float> sc(n * K);
+    const uint64_t used = h->h_ctrl->arena_head;
+    std::vector<int32_t> arena(used ? used : 1);
+    HIP_OR_RETURN(h, hipMemcpy(cnt.data(), h->d_counts.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_OR_RETURN(h, hipMemcpy(len.data(), h->d_span_begin.p, n * K * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_OR_RETURN(h, hipMemcpy(off.data(), h->d_res_off.p, n * K * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_OR_RETURN(h, hipMemcpy(sc.data(), h->d_res_score.p, n * K * sizeof(float), hipMemcpyDeviceToHost));
+    if (used) HIP_OR_RETURN(h, hipMemcpy(arena.data(), h->d_arena.p, used * sizeof(int32_t), hipMemcpyDeviceToHost));
+    uint64_t R = 0, total = 0;
+    for (uint64_t s = 0; s < n; ++s) for (uint32_t k = 0; k < cnt[s]; ++k) { ++R; total += len[s * K + k]; }
+    int32_t *hi = static_cast<int32_t *>(malloc((total ? total : 1) * sizeof(int32_t)));
+    uint64_t *ho = static_cast<uint64_t *>(malloc((R + 1) * sizeof(uint64_t)));
+    float *hs = static_cast<float *>(malloc((R ? R : 1) * sizeof(float)));
+    uint64_t *hr = static_cast<uint64_t *>(malloc((n + 1) * sizeof(uint64_t)));
+    if (!hi || !ho || !hs || !hr) { free(hi); free(ho); free(hs); free(hr); return Fail(h, kResourceExhausted, "out of host memory"); }
+    uint64_t r = 0, t = 0;
+    for (uint64_t s = 0; s < n; ++s) {
+      hr[s] = r;
+      for (uint32_t k = 0; k < cnt[s]; ++k) {
+        ho[r] = t;
+        hs[r] = sc[s * K + k];
+        const uint32_t ln = len[s * K + k];
+        if (ln) memcpy(hi + t, arena.data() + off[s * K + k], ln * sizeof(int32_t));
+        t += ln;
+        ++r;
+      }
+    }
+    hr[n] = r;
+    ho[r] = t;
+    *ids = hi; *id_offsets = ho; *scores = hs; *result_offsets = hr;
+    return kOk;
+  }
+  return Fail(h, kInternal, "id arena kept overflowing");
 }
 
 int spmx_normalize_batch_device(spmx_handle *h, const void *d_text, const uint64_t *d_offsets, uint64_t n, void *d_norm,

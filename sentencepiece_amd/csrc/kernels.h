@@ -773,5 +773,6 @@ SPMX_DEVICE void compact_block(const CompactArgs &a) {
 #include "kernels_split.h"
 #include "kernels_align.h"
 #include "kernels_normalize.h"
+#include "kernels_nbest.h"
 
 #endif

@@ -43,6 +43,7 @@ __global__ __launch_bounds__(64) void NormalizeWriteKernel(NormalizeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   normalize_block<true>(a, smem);
 }
+__global__ __launch_bounds__(64) void NBestKernel(NBestArgs a) { nbest_block(a); }
 __global__ __launch_bounds__(64) void SplitCountKernel(SplitArgs a) { split_block<false>(a, nullptr); }
 __global__ __launch_bounds__(64) void SplitWriteKernel(SplitArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t stage[kSplitLdsBytes];
@@ -158,6 +159,11 @@ hipError_t LaunchNormalize(bool write, const NormalizeArgs &a, int grid, uint32_
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds_bytes, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t LaunchNBest(const NBestArgs &a, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL(NBestKernel, dim3(grid), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
 

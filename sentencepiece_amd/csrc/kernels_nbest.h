@@ -1,0 +1,285 @@
+// NBestEncode on the device: unigram::Model::NBestEncode
+// (src/unigram_model.cc:686-717) = Lattice::SetSentence (:114-152) + Model::PopulateNodes (:547-596) +
+// Lattice::NBest (:345-515: float Viterbi for the exact heuristic, then A* from EOS), followed per result by the id
+// rules of PopulateSentencePieceText (src/sentencepiece_processor.cc:547-636) and the extra options (:1019-1064).
+//
+// One SENTENCE PER LANE, everything in the lane's own slice of an HBM scratch buffer: the lattice (character starts,
+// nodes, the nodes ending at every position), the hypotheses and the agenda.  The agenda is a binary heap that
+// performs exactly the element moves of libstdc++'s push_heap / pop_heap (bits/stl_heap.h __push_heap /
+// __adjust_heap): std::priority_queue's order among equal keys is part of the reference's output.  A cold path --
+// no LDS, no cross-lane step, the lanes of a wave simply diverge; its input is the normalized text in device form
+// (U+2581 as one byte under kNfCompressSp) written by the Normalize kernels.
+#ifndef SPMX_KERNELS_NBEST_H_
+#define SPMX_KERNELS_NBEST_H_
+
+namespace spmx {
+
+constexpr uint32_t kNbMaxLen = 1024;        // normalized (device) bytes per sentence
+constexpr uint32_t kNbMaxNodes = 16384;     // lattice nodes per sentence (node indices are 16-bit)
+constexpr uint32_t kNbAgendaCap = 10000 + 512;   // :487 kMaxAgendaSize + the largest fan-in handled
+constexpr uint32_t kStNbestOverflow = 1u << 5;   // status: a per-sentence capacity was exceeded
+
+struct NbNode { uint16_t pos, length, byte_begin, byte_len; int32_t id; float score, backtrace; };   // 20 bytes
+struct NbHyp { uint32_t next; uint32_t node; float fx, gx; };                                      // 16 bytes
+
+// bytes of one lane's slice for max_hyps hypotheses
+SPMX_HD inline uint64_t NbestLaneBytes(uint32_t max_hyps) {
+  return (kNbMaxLen + 2) * 2ull                  // surf: character starts
+       + kNbMaxNodes * sizeof(NbNode)            // nodes
+       + (kNbMaxLen + 3) * 4ull                  // end_off: CSR offsets of the nodes ending at a position
+       + kNbMaxNodes * 2ull                      // end_idx
+       + kNbMaxNodes * 2ull                      // scratch cursor per position (reuses u16 [kNbMaxLen + 2] actually)
+       + static_cast<uint64_t>(max_hyps) * sizeof(NbHyp)
+       + kNbAgendaCap * 4ull + 64;
+}
+
+struct NBestArgs {
+  SpmxDev dev;
+  const uint8_t *norm;          // packed normalized text, device form
+  const uint64_t *norm_offs;    // n + 1
+  uint32_t n;
+  uint32_t nbest;               // 2 .. 1024
+  uint8_t *scratch;             // [lanes of the launch][lane_bytes]
+  uint64_t lane_bytes;
+  uint32_t max_hyps;
+  int32_t *arena;               // ids of all results, allocated by atomics
+  unsigned long long *arena_head;
+  uint64_t arena_cap;
+  unsigned long long *res_off;  // [n][nbest] where result k of sentence s sits in the arena
+  uint32_t *res_len;            // [n][nbest]
+  float *res_score;             // [n][nbest]
+  uint32_t *res_count;          // [n]
+  uint32_t *status;
+};
+
+// std::push_heap with comp(a, b) = a->fx < b->fx
+SPMX_DEVICE void nb_heap_push(uint32_t *heap, uint32_t *hn, const NbHyp *hy, uint32_t value) {
+  int hole = static_cast<int>((*hn)++);
+  const float fx = hy[value].fx;
+  while (hole > 0) {
+    const int parent = (hole - 1) / 2;
+    if (!(hy[heap[parent]].fx < fx)) break;
+    heap[hole] = heap[parent];
+    hole = parent;
+  }
+  heap[hole] = value;
+}
+// top(), then std::pop_heap + pop_back
+SPMX_DEVICE uint32_t nb_heap_pop(uint32_t *heap, uint32_t *hn, const NbHyp *hy) {
+  const uint32_t top = heap[0];
+  const uint32_t value = heap[*hn - 1];
+  const int len = static_cast<int>(--(*hn));
+  if (len == 0) return top;
+  int hole = 0, child = 0;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (hy[heap[child]].fx < hy[heap[child - 1]].fx) --child;
+    heap[hole] = heap[child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    heap[hole] = heap[child - 1];
+    hole = child - 1;
+  }
+  const float fx = hy[value].fx;
+  while (hole > 0) {
+    const int parent = (hole - 1) / 2;
+    if (!(hy[heap[parent]].fx < fx)) break;
+    heap[hole] = heap[parent];
+    hole = parent;
+  }
+  heap[hole] = value;
+  return top;
+}
+
+SPMX_DEVICE void nbest_lane(const NBestArgs &a, uint32_t s, uint8_t *mine) {
+  const SpmxDev &d = a.dev;
+  const uint8_t *norm = a.norm + a.norm_offs[s];
+  const int size = static_cast<int>(a.norm_offs[s + 1] - a.norm_offs[s]);
+  const bool bf = (d.flags & kNfByteFallback) != 0;
+  const bool reverse = (d.flags & kNfReverse) != 0;
+  const uint32_t spb = SpByteOf(d);
+  const int n_extra = d.n_prefix + d.n_suffix;
+  unsigned long long *res_off = a.res_off + static_cast<uint64_t>(s) * a.nbest;
+  uint32_t *res_len = a.res_len + static_cast<uint64_t>(s) * a.nbest;
+  float *res_score = a.res_score + static_cast<uint64_t>(s) * a.nbest;
+  a.res_count[s] = 0;
+  // one result = the extra ids around `body` ids produced by `emit`
+  auto alloc = [&](int n_ids) -> int32_t * {
+    const unsigned long long at = wv::atomic_add(a.arena_head, static_cast<unsigned long long>(n_ids));
+    const uint32_t k = a.res_count[s];
+    res_off[k] = at;
+    res_len[k] = static_cast<uint32_t>(n_ids);
+    if (at + static_cast<unsigned long long>(n_ids) > a.arena_cap) { wv::atomic_or(a.status, kStArenaOverflow); return nullptr; }
+    return a.arena + at;
+  };
+  if (size == 0) {                               // unigram_model.cc:688-690: one empty result, score 0
+    int32_t *dst = alloc(n_extra);
+    if (dst) {
+      for (int x = 0; x < d.n_prefix; ++x) dst[x] = d.prefix_ids[x];
+      for (int x = 0; x < d.n_suffix; ++x) dst[d.n_prefix + x] = d.suffix_ids[x];
+    }
+    res_score[0] = 0.f;
+    a.res_count[s] = 1;
+    return;
+  }
+  if (static_cast<uint32_t>(size) > kNbMaxLen) { wv::atomic_or(a.status, kStTooLong); return; }
+  uint16_t *surf = reinterpret_cast<uint16_t *>(mine);
+  NbNode *nodes = reinterpret_cast<NbNode *>(mine + ((kNbMaxLen + 2) * 2 + 15) / 16 * 16);
+  uint32_t *end_off = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(nodes) + kNbMaxNodes * sizeof(NbNode));
+  uint16_t *end_idx = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(end_off) + (kNbMaxLen + 3) * 4);
+  uint16_t *cursor = end_idx + kNbMaxNodes;
+  NbHyp *hy = reinterpret_cast<NbHyp *>(reinterpret_cast<uint8_t *>(cursor) + ((kNbMaxNodes * 2 + 15) / 16 * 16));
+  uint32_t *heap = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(hy) + static_cast<uint64_t>(a.max_hyps) * sizeof(NbHyp));
+  // ---- SetSentence (:114-152): character starts ----
+  int len = 0;
+  for (int p = 0; p < size;) {
+    surf[len++] = static_cast<uint16_t>(p);
+    const uint32_t c = norm[p];
+    int mb = c == spb ? 1 : OneCharLenDev(c);
+    if (mb > size - p) mb = size - p;
+    p += mb;
+  }
+  surf[len] = static_cast<uint16_t>(size);
+  // ---- PopulateNodes (:547-596).  Nodes 0 = BOS, 1 = EOS, then in insertion order (begin position, then length):
+  // the order of end_nodes(pos) that Viterbi's "first best wins" and the A* expansion follow ----
+  uint32_t n_nodes = 2;
+  nodes[0] = NbNode{0, 0, 0, 0, -1, 0.f, 0.f};
+  nodes[1] = NbNode{static_cast<uint16_t>(len), 0, 0, 0, -1, 0.f, 0.f};
+  const float unk_score = d.unk_score;                         // :555 min_score() - kUnkPenalty
+  const uint32_t root = d.ptrie[0].x >> kDatBaseShiftDev;
+  bool over = false;
+  for (int bp = 0; bp < len && !over; ++bp) {
+    const int b0 = surf[bp];
+    bool single = false;
+    uint32_t nb = root;
+    int pos_c = bp;                                            // get_chars_length (:548-552), monotone in the key length
+    for (int kp = b0; kp < size;) {                            // commonPrefixSearch: matches in increasing length
+      const uint32_t c = norm[kp];
+      const U4 u = d.ptrie[nb ^ c];
+      if ((u.x & 0x1FFu) != (0x100u | c)) break;
+      ++kp;
+      nb = u.x >> kDatBaseShiftDev;
+      if (!(u.x & kDatTerminalDev)) continue;
+      while (surf[pos_c] < kp) ++pos_c;
+      const int length = pos_c - bp;
+      if (u.y & kPtUnused) continue;                           // :576
+      if (n_nodes >= kNbMaxNodes) { over = true; break; }
+      float sc = wv::bits_to_float(u.z);
+      if (u.y & kPtUserDefined) sc = static_cast<float>(static_cast<double>(static_cast<float>(length) * d.max_score) - 0.1);   // :580
+      nodes[n_nodes++] = NbNode{static_cast<uint16_t>(bp), static_cast<uint16_t>(length), static_cast<uint16_t>(b0),
+                                static_cast<uint16_t>(surf[bp + length] - b0), static_cast<int32_t>(u.y & kPtIdMask), sc, 0.f};
+      if (length == 1) single = true;
+    }
+    if (!single && !over) {                                    // :589-593 the UNK node
+      if (n_nodes >= kNbMaxNodes) { over = true; break; }
+      nodes[n_nodes++] = NbNode{static_cast<uint16_t>(bp), 1, static_cast<uint16_t>(b0), static_cast<uint16_t>(surf[bp + 1] - b0),
+                                d.unk_id, unk_score, 0.f};
+    }
+  }
+  if (over) { wv::atomic_or(a.status, kStNbestOverflow); return; }
+  // end_nodes as CSR over positions (insertion order within a position): BOS ends at 0
+  for (int p = 0; p <= len + 1; ++p) end_off[p] = 0;
+  end_off[0 + 1] = 1;
+  for (uint32_t i = 2; i < n_nodes; ++i) ++end_off[nodes[i].pos + nodes[i].length + 1];
+  for (int p = 0; p <= len; ++p) end_off[p + 1] += end_off[p];
+  for (int p = 0; p <= len; ++p) cursor[p] = 0;
+  end_idx[end_off[0] + cursor[0]++] = 0;
+  for (uint32_t i = 2; i < n_nodes; ++i) {
+    const int e = nodes[i].pos + nodes[i].length;
+    end_idx[end_off[e] + cursor[e]++] = static_cast<uint16_t>(i);
+  }
+  // ---- Viterbi (:167-198): backtrace_score of every node, begin positions in order (nodes are sorted by pos) ----
+  auto best_into = [&](int pos, float score) -> float {
+    float best = 0.f;
+    bool have = false;
+    for (uint32_t l = end_off[pos]; l < end_off[pos + 1]; ++l) {
+      const float sc = nodes[end_idx[l]].backtrace + score;
+      if (!have || sc > best) { best = sc; have = true; }
+    }
+    return best;
+  };
+  for (uint32_t i = 2; i < n_nodes; ++i) nodes[i].backtrace = best_into(nodes[i].pos, nodes[i].score);
+  nodes[1].backtrace = best_into(len, 0.f);
+  // ---- A* (:375-515) ----
+  uint32_t n_hyp = 0, hn = 0;
+  hy[0] = NbHyp{0xFFFFFFFFu, 1u, nodes[1].backtrace, 0.f};
+  n_hyp = 1;
+  nb_heap_push(heap, &hn, hy, 0);
+  uint32_t n_res = 0;
+  while (hn > 0) {
+    const uint32_t top = nb_heap_pop(heap, &hn, hy);
+    const uint32_t node = hy[top].node;
+    if (node == 0) {                                           // reached BOS: a complete path
+      // ids of the path, left to right (PopulateSentencePieceText :581-613)
+      int body = 0;
+      for (int pass = 0; pass < 2; ++pass) {
+        int32_t *dst = nullptr;
+        if (pass == 1) {
+          dst = alloc(body + n_extra);
+          if (!dst) return;
+          for (int x = 0; x < d.n_prefix; ++x) dst[x] = d.prefix_ids[x];
+          for (int x = 0; x < d.n_suffix; ++x) dst[d.n_prefix + body + x] = d.suffix_ids[x];
+          dst += d.n_prefix;
+        }
+        int k = 0;
+        bool prev_unk = false;
+        for (uint32_t h = hy[top].next; hy[h].next != 0xFFFFFFFFu; h = hy[h].next) {
+          const NbNode &x = nodes[hy[h].node];
+          const bool unk = x.id == d.unk_id;
+          if (unk && bf) {
+            for (int t = 0; t < x.byte_len; ++t) {
+              const uint32_t b = norm[x.byte_begin + t];
+              const int nbt = b == spb ? 3 : 1;
+              for (int y = 0; y < nbt; ++y) {
+                if (pass == 1) dst[reverse ? body - 1 - k : k] = d.byte_ids[b == spb ? (y == 0 ? 0xE2u : (y == 1 ? 0x96u : 0x81u)) : b];
+                ++k;
+              }
+            }
+          } else if (!(unk && prev_unk)) {
+            if (pass == 1) dst[reverse ? body - 1 - k : k] = x.id;
+            ++k;
+          }
+          prev_unk = unk;
+        }
+        body = k;
+      }
+      res_score[n_res] = hy[top].fx;
+      a.res_count[s] = ++n_res;
+      if (n_res == a.nbest) break;
+      continue;
+    }
+    const int pos = nodes[node].pos;
+    const uint32_t fan = end_off[pos + 1] - end_off[pos];
+    if (n_hyp + fan > a.max_hyps || hn + fan > kNbAgendaCap) { wv::atomic_or(a.status, kStNbestOverflow); return; }
+    const float gx = hy[top].gx;
+    for (uint32_t l = end_off[pos]; l < end_off[pos + 1]; ++l) {
+      const uint32_t ln = end_idx[l];
+      hy[n_hyp] = NbHyp{top, ln, nodes[ln].backtrace + gx, nodes[ln].score + gx};
+      nb_heap_push(heap, &hn, hy, n_hyp);
+      ++n_hyp;
+    }
+    if (hn >= 10000u) {                                        // :487-514 keep the best min(512, 10 nbest)
+      const uint32_t keep = a.nbest * 10u < 512u ? a.nbest * 10u : 512u;
+      // pop the best `keep` into the (free) tail of the hypothesis slice, then rebuild the heap from them in that order
+      if (n_hyp + keep > a.max_hyps) { wv::atomic_or(a.status, kStNbestOverflow); return; }
+      uint32_t *tmp = reinterpret_cast<uint32_t *>(hy + n_hyp);
+      for (uint32_t i = 0; i < keep; ++i) tmp[i] = nb_heap_pop(heap, &hn, hy);
+      hn = 0;
+      for (uint32_t i = 0; i < keep; ++i) nb_heap_push(heap, &hn, hy, tmp[i]);
+    }
+  }
+}
+
+// Persistent body: lane l of wave w takes sentences w * 64 + l, + lanes of the launch, ...
+SPMX_DEVICE void nbest_block(const NBestArgs &a) {
+  const uint32_t lane_id = static_cast<uint32_t>(wv::block_id() * wv::waves_per_block() + wv::wave_in_block()) * 64u +
+                           static_cast<uint32_t>(wv::lane());
+  const uint32_t lanes = static_cast<uint32_t>(wv::grid_size() * wv::waves_per_block()) * 64u;
+  uint8_t *mine = a.scratch + static_cast<uint64_t>(lane_id) * a.lane_bytes;
+  for (uint32_t s = lane_id; s < a.n; s += lanes) nbest_lane(a, s, mine);
+}
+
+}  // namespace spmx
+#endif

@@ -26,6 +26,7 @@ struct NormalizeArgs {
                                 // per normalized byte + the closing one (kNoClosingEntry where the reference has none)
   uint32_t *status;
   uint32_t rcap, ncap;
+  uint32_t device_text;         // keep the device form (U+2581 as one byte under kNfCompressSp): the input of kernels_nbest.h
 };
 
 inline uint32_t NormalizeLdsBytes(uint32_t rcap, uint32_t ncap) {
@@ -39,7 +40,7 @@ SPMX_DEVICE void normalize_block(const NormalizeArgs &a, unsigned char *smem) {
   uint8_t *raw = smem;
   uint8_t *norm = smem + ((a.rcap + 16 + 15) & ~15u);
   uint16_t *orig = reinterpret_cast<uint16_t *>(norm + ((a.ncap + 16 + 15) & ~15u));
-  const bool one = (d.flags & kNfCompressSp) != 0;
+  const bool one = (d.flags & kNfCompressSp) != 0 && !a.device_text;
   const bool want_n2o = WRITE && a.n2o != nullptr;
   const uint32_t count = *a.list_count;
   for (uint32_t item = static_cast<uint32_t>(wv::block_id()); item < count; item += static_cast<uint32_t>(wv::grid_size())) {

@@ -418,6 +418,49 @@ class SentencePieceProcessor:
 
     encode_as_pieces = EncodeAsPieces
 
+    # ------------------------------------------------------------ n-best ----
+    def NBestPacked(self, text, offsets, nbest_size):
+        """Packed host arrays -> ``(ids int32, id_offsets uint64[R + 1], scores float32[R], result_offsets uint64[n + 1])``:
+        result r has ``ids[id_offsets[r]:id_offsets[r + 1]]`` and ``scores[r]``; sentence s owns results
+        ``result_offsets[s]:result_offsets[s + 1]``, best first (``NBestEncode``, unigram models only)."""
+        self._need()
+        self._apply(False, False, False)
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offs) - 1
+        p_ids, p_io, p_sc, p_ro = (C.c_void_p() for _ in range(4))
+        self._check(self._lib.spmx_nbest_encode_batch(self._h, text.ctypes.data if len(text) else None, offs.ctypes.data, n,
+                                                      int(nbest_size), C.byref(p_ids), C.byref(p_io), C.byref(p_sc),
+                                                      C.byref(p_ro)))
+        try:
+            ro = np.ctypeslib.as_array(C.cast(p_ro, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+            R = int(ro[n])
+            io = np.ctypeslib.as_array(C.cast(p_io, C.POINTER(C.c_uint64)), shape=(R + 1,)).copy()
+            total = int(io[R])
+            ids = (np.ctypeslib.as_array(C.cast(p_ids, C.POINTER(C.c_int32)), shape=(total,)).copy()
+                   if total else np.zeros(0, dtype=np.int32))
+            sc = (np.ctypeslib.as_array(C.cast(p_sc, C.POINTER(C.c_float)), shape=(R,)).copy()
+                  if R else np.zeros(0, dtype=np.float32))
+        finally:
+            for p in (p_ids, p_io, p_sc, p_ro):
+                self._lib.spmx_free(p)
+        return ids, io, sc, ro
+
+    def NBestEncodeAsIds(self, input, nbest_size):
+        """``NBestEncodeAsIds`` (python/src/sentencepiece/__init__.py ``nbest_encode_as_ids``): str -> list of id lists,
+        best first; a list of str gives a list of those."""
+        single = isinstance(input, (str, bytes))
+        items = [input] if single else list(input)
+        raw = [x.encode("utf-8") if isinstance(x, str) else bytes(x) for x in items]
+        offs = np.zeros(len(raw) + 1, dtype=np.uint64)
+        if raw:
+            np.cumsum([len(x) for x in raw], out=offs[1:])
+        ids, io, _, ro = self.NBestPacked(np.frombuffer(b"".join(raw), dtype=np.uint8), offs, nbest_size)
+        out = [[ids[int(io[r]):int(io[r + 1])].tolist() for r in range(int(ro[s]), int(ro[s + 1]))] for s in range(len(raw))]
+        return out[0] if single else out
+
+    nbest_encode_as_ids = NBestEncodeAsIds
+
     # -------------------------------------------------------- normalize ----
     def NormalizePacked(self, text, offsets, with_offsets=False):
         """Packed host arrays -> ``(normalized uint8, norm_offsets uint64[n + 1], norm_to_orig | None)``.

@@ -345,6 +345,8 @@ int64_t emu_encode_spans_batch(void *hv, const uint8_t *text, const uint64_t *of
 
 // Batch Normalize as csrc/api.cc runs it: classify -> count pass per class -> scan -> write pass per class.
 // Returns total normalized bytes, -(needed) - 2 if cap is too small, -1 with the status on a failure.
+static uint32_t g_device_text = 0;    // set by emu_nbest_batch around its normalize call
+
 int64_t emu_normalize_batch(void *hv, const uint8_t *text, const uint64_t *offs, uint64_t n, uint8_t *norm, uint64_t cap,
                             uint64_t *norm_offs, uint32_t *n2o, int grid, uint32_t *status_out) {
   auto *h = static_cast<EmuHandle *>(hv);
@@ -374,6 +376,7 @@ int64_t emu_normalize_batch(void *hv, const uint8_t *text, const uint64_t *offs,
       a.next_count = has_next ? &list_counts[c + 1] : nullptr;
       a.counts = counts.data(); a.norm_offs = norm_offs; a.norm = norm; a.n2o = n2o; a.status = &status;
       a.rcap = cls[c].rcap; a.ncap = cls[c].ncap;
+      a.device_text = g_device_text;
       std::vector<unsigned char> smem(NormalizeLdsBytes(a.rcap, a.ncap) + 64, 0xCD);
       for (int b = 0; b < grid; ++b) {
         if (write) emu::RunWave(b, grid, smem.data(), [&] { normalize_block<true>(a, smem.data()); });
@@ -443,6 +446,59 @@ int64_t emu_split_lines(const uint8_t *file, uint64_t bytes, uint8_t *text, uint
   for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, stage, [&] { split_block<true>(a, stage); });
   *text_bytes = bytes - nl;
   return static_cast<int64_t>(nl + (file[bytes - 1] != 0x0A ? 1 : 0));
+}
+
+// NBestEncode as csrc/api.cc runs it: Normalize kernels (device text) -> NBest kernel -> host CSR.
+// Outputs: result r of the batch has ids out[id_offs[r], id_offs[r + 1]) and scores[r]; sentence s owns results
+// [res_offs[s], res_offs[s + 1]).  id_offs / scores hold n * nbest (+ 1) entries.  Returns the number of results,
+// -1 with the status on a failure, -(ids needed) - 2 if cap is too small.
+int64_t emu_nbest_batch(void *hv, const uint8_t *text, const uint64_t *offs, uint64_t n, int nbest, int32_t *out, uint64_t cap,
+                        uint64_t *id_offs, float *scores, uint64_t *res_offs, int grid, uint32_t *status_out) {
+  auto *h = static_cast<EmuHandle *>(hv);
+  if (grid < 1) grid = 1;
+  const uint64_t tbytes = offs[n] - offs[0];
+  std::vector<uint8_t> norm(tbytes * 20 + 64);
+  std::vector<uint64_t> norm_offs(n + 1, 0);
+  uint32_t status = 0;
+  g_device_text = 1;
+  const int64_t tot = emu_normalize_batch(hv, text, offs, n, norm.data(), norm.size(), norm_offs.data(), nullptr, grid, &status);
+  g_device_text = 0;
+  if (status_out) *status_out = status;
+  if (tot < 0) return -1;
+  NBestArgs a{};
+  a.dev = h->tables.scalars; a.norm = norm.data(); a.norm_offs = norm_offs.data(); a.n = static_cast<uint32_t>(n);
+  a.nbest = static_cast<uint32_t>(nbest);
+  a.max_hyps = 65536;
+  a.lane_bytes = (NbestLaneBytes(a.max_hyps) + 15) / 16 * 16;
+  std::vector<uint8_t> scratch(static_cast<size_t>(grid) * 64 * a.lane_bytes, 0xCD);
+  a.scratch = scratch.data();
+  std::vector<int32_t> arena(static_cast<size_t>(tot + 8 * n + 64) * nbest + 1024);
+  unsigned long long head = 0;
+  a.arena = arena.data(); a.arena_head = &head; a.arena_cap = arena.size();
+  std::vector<unsigned long long> roff(n * nbest + 1, 0);
+  std::vector<uint32_t> rlen(n * nbest + 1, 0), rcount(n + 1, 0);
+  std::vector<float> rscore(n * nbest + 1, 0.f);
+  a.res_off = roff.data(); a.res_len = rlen.data(); a.res_score = rscore.data(); a.res_count = rcount.data();
+  a.status = &status;
+  for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { nbest_block(a); });
+  if (status_out) *status_out = status;
+  if (status) return -1;
+  uint64_t r = 0, total = 0;
+  for (uint64_t s = 0; s < n; ++s) {
+    res_offs[s] = r;
+    for (uint32_t k = 0; k < rcount[s]; ++k) {
+      id_offs[r] = total;
+      scores[r] = rscore[s * nbest + k];
+      const uint32_t len = rlen[s * nbest + k];
+      if (total + len <= cap) for (uint32_t i = 0; i < len; ++i) out[total + i] = arena[roff[s * nbest + k] + i];
+      total += len;
+      ++r;
+    }
+  }
+  res_offs[n] = r;
+  id_offs[r] = total;
+  if (total > cap) return -static_cast<int64_t>(total) - 2;
+  return static_cast<int64_t>(r);
 }
 
 uint64_t emu_collectives() { return emu::g_wave.n_collectives; }

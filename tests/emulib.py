@@ -117,6 +117,36 @@ class EmuHandle:
         return ids[:tot].copy(), id_offs
 
 
+def _emu_nbest(self, text, offs, nbest, grid=2):
+    """NBestEncode of every sentence through the device kernels -> per sentence a list of (ids list, score)."""
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    n = len(offs) - 1
+    cap = (int(len(text)) * 4 + 16 * n + 64) * nbest
+    ids = np.empty(cap, dtype=np.int32)
+    id_offs = np.zeros(n * nbest + 2, dtype=np.uint64)
+    scores = np.zeros(n * nbest + 1, dtype=np.float32)
+    res_offs = np.zeros(n + 1, dtype=np.uint64)
+    st = C.c_uint32(0)
+    fn = self.lib.emu_nbest_batch
+    fn.restype = C.c_int64
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p,
+                   C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    r = fn(self.h, text.ctypes.data if len(text) else None, offs.ctypes.data, n, nbest, ids.ctypes.data, cap,
+           id_offs.ctypes.data, scores.ctypes.data, res_offs.ctypes.data, grid, C.byref(st))
+    self.status = st.value
+    if r < 0:
+        raise RuntimeError("emu_nbest_batch failed: %d status %d" % (r, st.value))
+    out = []
+    for s in range(n):
+        out.append([(ids[int(id_offs[k]):int(id_offs[k + 1])].tolist(), float(scores[k]))
+                    for k in range(int(res_offs[s]), int(res_offs[s + 1]))])
+    return out
+
+
+EmuHandle.nbest = _emu_nbest
+
+
 def _emu_normalize_batch(self, text, offs, grid=3):
     """-> (normalized uint8, norm_offsets, n2o) through the device normalize kernels."""
     text = np.ascontiguousarray(text, dtype=np.uint8)

@@ -76,3 +76,70 @@ def test_nbest_is_unigram_only(oracle, ref):
     o, r = oracle.load(blob), ref.load(blob)
     assert nbest(o.lib.oracle_nbest_encode, o.h, b"hello", 3)[0] == -1
     assert nbest(r.lib.spmref_nbest_encode, r.h, b"hello", 3)[0] == -1
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from tests import emulib
+    return emulib.EmuLib()
+
+
+@pytest.mark.parametrize("model", UNIGRAM)
+def test_emu_nbest_matches_oracle(model, emu, oracle, corpora):
+    """The device NBest kernel (kernels_nbest.h, emulated) against the oracle: ids and scores of every result."""
+    from sentencepiece_amd import synth
+    blob = fixtures.model_blob(model)
+    h, o = emu.load(blob), oracle.load(blob)
+    sents = [s for s in sentences(corpora) if len(s) <= 250]
+    text, offs = synth.pack(sents)
+    for opts in ("", "reverse:bos:eos"):
+        h.set_encode_extra_options(opts)
+        o.set_encode_extra_options(opts)
+        for k in (2, 5, 17):
+            got = h.nbest(text, offs, k)
+            assert h.status == 0
+            for s, res in zip(sents, got):
+                n, want, sc = nbest(o.lib.oracle_nbest_encode, o.h, s, k)
+                assert [r[0] for r in res] == want, (model, s[:40], k, opts)
+                np.testing.assert_array_equal(np.array([r[1] for r in res], dtype=np.float32), sc)
+
+
+def test_emu_nbest_agenda_shrink_and_limits(emu, oracle):
+    from sentencepiece_amd import synth
+    blob = fixtures.model_blob("test_model")
+    h, o = emu.load(blob), oracle.load(blob)
+    s = (b"this is a test of the emergency broadcast system " * 6)[:280]
+    text, offs = synth.pack([s, b"", b"a"])
+    for k in (64, 400):
+        got = h.nbest(text, offs, k, grid=1)
+        for sent, res in zip([s, b"", b"a"], got):
+            n, want, sc = nbest(o.lib.oracle_nbest_encode, o.h, sent, k)
+            assert [r[0] for r in res] == want
+            np.testing.assert_array_equal(np.array([r[1] for r in res], dtype=np.float32), sc)
+    with pytest.raises(RuntimeError):                      # beyond kNbMaxLen normalized bytes: status, no results
+        h.nbest(*synth.pack([b"word " * 400]), 4, grid=1)
+
+
+# The device path on hardware.  The kernel is new this round and was validated under the emulator only (the round's
+# GPU minutes were spent before it existed), so these do not gate the suite yet: xfail(strict=False).
+@pytest.mark.gpu
+@pytest.mark.xfail(reason="NBest kernel not yet run on hardware (emulator-validated)", strict=False)
+@pytest.mark.parametrize("model", ["test_model", "uni1k_bf", "uni32k"])
+def test_gpu_nbest_matches_oracle(model, oracle, corpora):
+    from sentencepiece_amd import synth
+    from sentencepiece_amd.processor import SentencePieceProcessor
+    blob = fixtures.model_blob(model)
+    sp, o = SentencePieceProcessor(model_proto=blob), oracle.load(blob)
+    sents = [s for s in sentences(corpora) if len(s) <= 250]
+    text, offs = synth.pack(sents)
+    for opts in ("", "reverse:bos:eos"):
+        sp.SetEncodeExtraOptions(opts)
+        o.set_encode_extra_options(opts)
+        for k in (1, 2, 5, 17):
+            ids, io, sc, ro = sp.NBestPacked(text, offs, k)
+            for i, s in enumerate(sents):
+                n, want, wsc = nbest(o.lib.oracle_nbest_encode, o.h, s, k)
+                got = [ids[int(io[r]):int(io[r + 1])].tolist() for r in range(int(ro[i]), int(ro[i + 1]))]
+                assert got == want, (model, s[:40], k, opts)
+                np.testing.assert_array_equal(sc[int(ro[i]):int(ro[i + 1])], wsc)
+    assert sp.NBestEncodeAsIds("hello world", 3) == nbest(o.lib.oracle_nbest_encode, o.h, b"hello world", 3)[1]
