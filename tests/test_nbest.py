@@ -120,10 +120,8 @@ def test_emu_nbest_agenda_shrink_and_limits(emu, oracle):
         h.nbest(*synth.pack([b"word " * 400]), 4, grid=1)
 
 
-# The device path on hardware.  The kernel is new this round and was validated under the emulator only (the round's
-# GPU minutes were spent before it existed), so these do not gate the suite yet: xfail(strict=False).
+# The device path on hardware (through the C ABI).
 @pytest.mark.gpu
-@pytest.mark.xfail(reason="NBest kernel not yet run on hardware (emulator-validated)", strict=False)
 @pytest.mark.parametrize("model", ["test_model", "uni1k_bf", "uni32k"])
 def test_gpu_nbest_matches_oracle(model, oracle, corpora):
     from sentencepiece_amd import synth
