@@ -332,6 +332,26 @@ int64_t spmref_encode_serialized_batch(void *handle, const char *text, const uin
   return static_cast<int64_t>(total);
 }
 
+// EncodeAsImmutableProto(input) + ConvertToUnicodeSpans() (sentencepiece_processor.h:573-576, .cc:63-89, :168-170):
+// what the reference's Python wrapper returns for out_type="immutable_proto": begin / end in characters.
+int64_t spmref_encode_unicode_spans_batch(void *handle, const char *text, const uint64_t *offsets, uint64_t n,
+                                          uint32_t *begin, uint32_t *end, uint64_t cap, uint64_t *id_offsets) {
+  auto *h = static_cast<RefHandle *>(handle);
+  uint64_t total = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    id_offsets[i] = total;
+    auto spt = h->sp.EncodeAsImmutableProto(absl::string_view(text + offsets[i], offsets[i + 1] - offsets[i]));
+    spt.ConvertToUnicodeSpans();
+    for (size_t k = 0; k < spt.pieces_size(); ++k) {
+      if (total < cap) { begin[total] = spt.pieces(k).begin(); end[total] = spt.pieces(k).end(); }
+      ++total;
+    }
+  }
+  id_offsets[n] = total;
+  if (total > cap) return -static_cast<int64_t>(total) - 2;
+  return static_cast<int64_t>(total);
+}
+
 int spmref_piece_size(void *handle) {
   return static_cast<RefHandle *>(handle)->sp.GetPieceSize();
 }

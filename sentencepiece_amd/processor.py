@@ -211,6 +211,10 @@ class SentencePieceProcessor:
                     if emit:
                         row[:] = [unk if self.PieceToId(p) == self.unk_id() else p for p in row]
             return rows[0] if single else rows
+        if out_type == "immutable_proto":
+            if any([add_bos, add_eos, reverse, emit_unk_piece]):     # sentencepiece.i:177-186
+                raise NotImplementedError("add_bos, add_eos, reverse, and emit_unk_piece is not supported in proto API")
+            return self.EncodeAsImmutableProto(input)
         if out_type == "serialized_proto":
             if any([add_bos, add_eos, reverse, emit_unk_piece]):     # sentencepiece.i:166-175
                 raise NotImplementedError("add_bos, add_eos, reverse, and emit_unk_piece is not supported in proto API")
@@ -409,6 +413,20 @@ class SentencePieceProcessor:
                                                for k, (p, t, sf, pb, pe) in enumerate(rows[i])]))
         return out[0] if single else out
 
+    def EncodeAsImmutableProto(self, input):
+        """``encode(out_type="immutable_proto")``: per sentence an object with ``.text``, ``.pieces[i].piece / .id /
+        .surface / .begin / .end`` and ``SerializeAsString()``.  As in the reference's Python wrapper, begin / end are
+        converted from bytes to Unicode characters (``ConvertToUnicodeSpans``, src/sentencepiece_processor.cc:63-89);
+        the serialized form keeps bytes."""
+        from . import spt_proto
+        single = isinstance(input, (str, bytes))
+        items = [input] if single else list(input)
+        raw = [x.encode("utf-8") if isinstance(x, str) else bytes(x) for x in items]
+        rows = self.EncodeAsSentencePieceText(raw)
+        blobs = self.EncodeAsSerializedProto(raw)
+        out = [spt_proto.ImmutableSentencePieceText(r, rows[i], blobs[i]) for i, r in enumerate(raw)]
+        return out[0] if single else out
+
     def EncodeAsPieces(self, input):
         """``EncodeAsPieces`` (sentencepiece_processor.h:462-466) / ``encode(out_type=str)``: the piece strings."""
         single = isinstance(input, (str, bytes))
@@ -417,6 +435,8 @@ class SentencePieceProcessor:
         return out[0] if single else out
 
     encode_as_pieces = EncodeAsPieces
+    encode_as_serialized_proto = EncodeAsSerializedProto
+    encode_as_immutable_proto = EncodeAsImmutableProto
 
     # ------------------------------------------------------------ n-best ----
     def NBestPacked(self, text, offsets, nbest_size):

@@ -63,3 +63,55 @@ def surface_flags(ids, nbegin, is_byte, is_control, reversed_order):
             if 0 <= nxt < n and is_byte(int(ids[nxt])) and int(nbegin[nxt]) == int(nbegin[k]):
                 has[k] = False
     return has
+
+
+_CHAR_LEN = (1,) * 12 + (2, 2, 3, 4)      # string_util::OneCharLen (src/util.h:151-153) by the lead byte's high nibble
+
+
+def utf8_to_unicode(text):
+    """ConvertToUnicodeSpansInternal's table (src/sentencepiece_processor.cc:66-79): byte offset -> character index."""
+    n = len(text)
+    tab = [0] * (n + 1)
+    prev = ulen = 0
+    while prev < n:
+        mb = _CHAR_LEN[text[prev] >> 4]
+        for i in range(prev, min(prev + mb, n + 1)):
+            tab[i] = ulen
+        ulen += 1
+        prev += mb
+    tab[min(prev, n)] = ulen
+    return tab
+
+
+class ImmutableSentencePiece:
+    __slots__ = ("piece", "id", "surface", "begin", "end")
+
+    def __init__(self, piece, pid, surface, begin, end):
+        self.piece, self.id, self.surface, self.begin, self.end = piece, pid, surface, begin, end
+
+    def __repr__(self):
+        return "piece: %r\nid: %d\nsurface: %r\nbegin: %d\nend: %d\n" % (self.piece, self.id, self.surface, self.begin, self.end)
+
+
+class ImmutableSentencePieceText:
+    """The read-only view the reference's Python wrapper returns for ``out_type="immutable_proto"``: strings decoded,
+    spans in characters."""
+
+    def __init__(self, text, rows, serialized):
+        tab = utf8_to_unicode(text) if text else [0]
+        hi = len(tab) - 1
+        self.text = text.decode("utf-8", "surrogateescape")
+        self.pieces = [ImmutableSentencePiece(p.decode("utf-8", "surrogateescape"), t, sf.decode("utf-8", "surrogateescape"),
+                                              tab[min(max(b, 0), hi)] if text else b, tab[min(max(e, 0), hi)] if text else e)
+                       for p, t, sf, b, e in rows]
+        self.score = 0.0
+        self._blob = serialized
+
+    def SerializeAsString(self):
+        return self._blob
+
+    def __len__(self):
+        return len(self.pieces)
+
+    def __iter__(self):
+        return iter(self.pieces)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from tests import fixtures, pieceslib
-from tests.test_spans import BIG, MODELS, inputs
+from tests.test_spans import BIG, MODELS, inputs, packed
 
 OPTS = ["", "unk_piece:bos:eos", "reverse:unk"]
 
@@ -250,3 +250,54 @@ def test_processor_glue_with_emulated_device(emu, ref, corpora):
 
 def packed_one(b):
     return np.frombuffer(b, dtype=np.uint8), np.array([0, len(b)], dtype=np.uint64)
+
+
+def test_immutable_proto_glue(emu, ref, corpora):
+    """encode(out_type="immutable_proto"): the character spans of the reference's Python wrapper
+    (EncodeAsImmutableProto + ConvertToUnicodeSpans of the compiled reference), strings and SerializeAsString; device
+    calls emulated."""
+    import ctypes as C
+    from sentencepiece_amd.processor import SentencePieceProcessor
+    for model in ("bpe1k", "test_model", "uni1k_bf"):
+        blob = fixtures.model_blob(model)
+        h, r = emu.load(blob), ref.load(blob)
+        types, names = piece_types(model)
+        sp = SentencePieceProcessor.__new__(SentencePieceProcessor)
+        sp._extra = ""
+        sp.EncodeSpansPacked = lambda text, offs, norm_spans=False: h.encode_spans(text, offs, grid=2, norm_spans=norm_spans)
+        sp.NormalizePacked = lambda text, offs, with_offsets=False: h.normalize_batch(text, offs, grid=2)
+        sp.IsByte = lambda t: types[t] == 6
+        sp.IsControl = lambda t: types[t] == 3
+        sp.IdToPiece = lambda t: names[t].decode("utf-8")
+        sp.unk_id = lambda: types.index(2)
+        text, offs = next(x for nm, x in inputs(corpora) if nm == "extra")
+        tb = np.asarray(text).tobytes()
+        lines = [tb[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
+
+        def valid(x):       # (the reference's ConvertToUnicodeSpans writes past its table on a truncated last character)
+            try:
+                x.decode("utf-8")
+                return True
+            except UnicodeDecodeError:
+                return False
+        lines = [x for x in lines if valid(x)]
+        text, offs = packed(lines)
+        tb = np.asarray(text).tobytes()
+        got = sp.EncodeAsImmutableProto(lines)
+        n = len(lines)
+        cap = len(tb) * 12 + 8 * n + 64
+        b = np.zeros(cap, dtype=np.uint32)
+        e = np.zeros(cap, dtype=np.uint32)
+        io = np.zeros(n + 1, dtype=np.uint64)
+        fn = r.lib.spmref_encode_unicode_spans_batch
+        fn.restype = C.c_int64
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        offs64 = np.ascontiguousarray(offs, dtype=np.uint64)
+        tot = fn(r.h, np.ascontiguousarray(text).ctypes.data, offs64.ctypes.data, n, b.ctypes.data, e.ctypes.data, cap, io.ctypes.data)
+        assert tot >= 0
+        ser = _ref_serialized(r, text, offs)
+        for i, g in enumerate(got):
+            lo, hi = int(io[i]), int(io[i + 1])
+            assert [p.begin for p in g.pieces] == b[lo:hi].tolist(), (model, i, lines[i][:30])
+            assert [p.end for p in g.pieces] == e[lo:hi].tolist(), (model, i, lines[i][:30])
+            assert g.SerializeAsString() == ser[i]
