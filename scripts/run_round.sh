@@ -12,3 +12,9 @@ rm -rf $O/prof
 
 timeout 600 python bench.py --model bpe32k --steps 3 --warmup 1 > $O/bench_bpe32k_10m.json 2> $O/bench_bpe.err; tail -c 1500 $O/bench_bpe32k_10m.json
 timeout 900 python bench.py --model c5_250k --sentences 1000000 --steps 3 --warmup 1 > $O/bench_c5_250k_1m.json 2> $O/bench_c5.err; tail -c 1500 $O/bench_c5_250k_1m.json
+
+# the rows next to the hot path: decode, spans / normalize, line splitter, n-best
+timeout 300 python scripts/decode_rate.py > $O/decode_rate.json 2>> $O/side.err; tail -c 600 $O/decode_rate.json
+timeout 300 python scripts/spans_rate.py > $O/spans_rate.json 2>> $O/side.err; tail -c 600 $O/spans_rate.json
+timeout 300 python scripts/split_rate.py > $O/split_rate.json 2>> $O/side.err; tail -c 600 $O/split_rate.json
+timeout 300 python scripts/nbest_rate.py > $O/nbest_rate.json 2>> $O/side.err; tail -c 600 $O/nbest_rate.json
