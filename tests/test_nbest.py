@@ -141,3 +141,24 @@ def test_gpu_nbest_matches_oracle(model, oracle, corpora):
                 assert got == want, (model, s[:40], k, opts)
                 np.testing.assert_array_equal(sc[int(ro[i]):int(ro[i + 1])], wsc)
     assert sp.NBestEncodeAsIds("hello world", 3) == nbest(o.lib.oracle_nbest_encode, o.h, b"hello world", 3)[1]
+
+
+def test_nbest_with_restricted_vocabulary(emu, oracle, ref, corpora):
+    """SetVocabulary marks pieces UNUSED; PopulateNodes skips them (src/unigram_model.cc:576)."""
+    from sentencepiece import sentencepiece_model_pb2 as pb
+    from sentencepiece_amd import synth
+    blob = fixtures.model_blob("test_model")
+    m = pb.ModelProto()
+    m.ParseFromString(blob)
+    keep = [p.piece for i, p in enumerate(m.pieces) if i % 3 != 1]
+    h, o, r = emu.load(blob), oracle.load(blob), ref.load(blob)
+    for x in (h, o, r):
+        x.set_vocabulary(keep)
+    sents = [s for s in sentences(corpora) if 0 < len(s) <= 200][:60]
+    got = h.nbest(*synth.pack(sents), 6)
+    for s, res in zip(sents, got):
+        n1, a, sa = nbest(o.lib.oracle_nbest_encode, o.h, s, 6)
+        n2, b, sb = nbest(r.lib.spmref_nbest_encode, r.h, s, 6)
+        assert a == b and [x[0] for x in res] == a
+        np.testing.assert_array_equal(sa, sb)
+        np.testing.assert_array_equal(np.array([x[1] for x in res], dtype=np.float32), sa)
