@@ -124,6 +124,7 @@ struct spmx_handle {
   bool no_lane_general = false;      // SPMX_NO_LANE_GENERAL=1: FAST kernels hand every non-ASCII sentence to GENERAL
   uint32_t lane_general_max_raw = kLaneGeneralMaxRaw, lane_general_min_lanes = 0;   // SPMX_LANE_GENERAL_MAX_RAW / _MIN_LANES (0: per class)
   bool tiles_ascending = false;      // SPMX_TILE_ORDER=asc
+  uint32_t sub_buckets = kSubBuckets;   // SPMX_SUB_BUCKETS: length sub-buckets per class in the classify sort (1..64)
   bool static_tiles = false;         // SPMX_STATIC_TILES=1: fixed-stride tiles in the streaming kernels (A/B measurements)
   bool no_merge_general = false;     // SPMX_NO_MERGE_GENERAL=1: a GENERAL launch per class (A/B measurements)
   bool no_stream = false;            // SPMX_NO_STREAM=1: BPE in the sentence-per-wave form only (A/B measurements)
@@ -308,6 +309,7 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
       for (int c = 0; c < ncls; ++c) ca.rcap[c] = cls[c].rcap;
       ca.lists = h->d_lists.p; ca.list_counts = h->d_ctrl->list_counts;
       ca.key_totals = h->d_ctrl->key_totals; ca.key_cursor = h->d_ctrl->key_cursor;
+      ca.sub_buckets = h->sub_buckets;
       const uint32_t chunks = (n32 + 64 * kClassifyChunk - 1) / (64 * kClassifyChunk);
       HIP_OR_RETURN(h, LaunchClassify(ca, static_cast<int>(chunks < static_cast<uint32_t>(wide) ? chunks : wide), stream));
     }
@@ -587,6 +589,7 @@ int NormalizeDevice(spmx_handle *h, const uint8_t *d_text, const uint64_t *d_off
     for (int c = 0; c < ncls; ++c) ca.rcap[c] = cls[c].rcap;
     ca.lists = h->d_lists.p; ca.list_counts = h->d_ctrl->list_counts;
     ca.key_totals = h->d_ctrl->key_totals; ca.key_cursor = h->d_ctrl->key_cursor;
+      ca.sub_buckets = h->sub_buckets;
     const uint32_t chunks = (n32 + 64 * kClassifyChunk - 1) / (64 * kClassifyChunk);
     HIP_OR_RETURN(h, LaunchClassify(ca, static_cast<int>(chunks < static_cast<uint32_t>(wide) ? chunks : wide), stream));
   }
@@ -724,6 +727,10 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
   if (const char *e = getenv("SPMX_NO_LANE_GENERAL")) h->no_lane_general = e[0] == '1';
   if (const char *e = getenv("SPMX_NO_MERGE_GENERAL")) h->no_merge_general = e[0] == '1';
   if (const char *e = getenv("SPMX_STATIC_TILES")) h->static_tiles = e[0] == '1';
+  if (const char *e = getenv("SPMX_SUB_BUCKETS")) {
+    const int v = atoi(e);
+    h->sub_buckets = static_cast<uint32_t>(v < 1 ? 1 : (v > kMaxSubBuckets ? kMaxSubBuckets : v));
+  }
   if (const char *e = getenv("SPMX_TILE_ORDER")) h->tiles_ascending = e[0] == 'a';
   if (const char *e = getenv("SPMX_LANE_GENERAL_MAX_RAW")) h->lane_general_max_raw = static_cast<uint32_t>(atoi(e));
   if (const char *e = getenv("SPMX_LANE_GENERAL_MIN_LANES")) h->lane_general_min_lanes = static_cast<uint32_t>(atoi(e));

@@ -570,8 +570,9 @@ constexpr int kMaxClasses = 8;
 // the class decides which kernels / scratch stride a sentence gets, the sub-bucket only orders the class list so
 // that the 64 sentences of a tile have similar lengths whatever the order of the input (the lanes of a tile run
 // in lock step: an unsorted corpus cost 1.6x the search iterations of a length-bucketed one, profiles/).
-constexpr int kSubBuckets = 16;
-constexpr int kSortKeys = kMaxClasses * kSubBuckets;
+constexpr int kSubBuckets = 16;                        // default number of length sub-buckets per class
+constexpr int kMaxSubBuckets = 64;                     // ClassifyArgs::sub_buckets may go up to this
+constexpr int kSortKeys = kMaxClasses * kMaxSubBuckets;   // capacity of the key tables
 constexpr int kClassifyChunk = 16;   // a wave takes chunks of 16 x 64 sentences
 
 struct ClassifyArgs {
@@ -583,6 +584,8 @@ struct ClassifyArgs {
   uint32_t *list_counts;        // n_classes (zeroed before launch; written by the scatter pass)
   uint32_t *key_totals;         // kSortKeys (zeroed): sentences per (class, sub-bucket), from the count pass
   uint32_t *key_cursor;         // kSortKeys (zeroed): scatter pass progress
+  uint32_t sub_buckets;         // length sub-buckets per class (1 .. kMaxSubBuckets): the tiles of the encode kernels
+                                // are the more homogeneous the finer the sort
 };
 
 // (class << 4 | sub-bucket) of a sentence of len raw bytes
@@ -590,9 +593,10 @@ SPMX_DEVICE uint32_t classify_key(const ClassifyArgs &a, uint64_t len) {
   int cls = static_cast<int>(a.n_classes) - 1;
   for (int c = static_cast<int>(a.n_classes) - 2; c >= 0; --c) if (len <= a.rcap[c]) cls = c;
   const uint64_t lo = cls > 0 ? a.rcap[cls - 1] : 0, hi = a.rcap[cls];
-  uint64_t sub = len > lo ? (len - lo - 1) * kSubBuckets / (hi - lo) : 0;
-  if (sub > kSubBuckets - 1) sub = kSubBuckets - 1;
-  return static_cast<uint32_t>(cls) * kSubBuckets + static_cast<uint32_t>(sub);
+  const uint64_t nsub = a.sub_buckets;
+  uint64_t sub = len > lo ? (len - lo - 1) * nsub / (hi - lo) : 0;
+  if (sub > nsub - 1) sub = nsub - 1;
+  return static_cast<uint32_t>(cls) * a.sub_buckets + static_cast<uint32_t>(sub);
 }
 
 // PASS 0 counts, PASS 1 scatters.  hist is kSortKeys * 3 words of LDS (per wave).
@@ -600,22 +604,23 @@ template <int PASS>
 SPMX_DEVICE void classify_block(const ClassifyArgs &a, uint32_t *hist) {
   const int lane = wv::lane();
   uint32_t *start = hist + kSortKeys, *base = hist + 2 * kSortKeys;
+  const int nsub = static_cast<int>(a.sub_buckets);
+  const int n_keys = static_cast<int>(a.n_classes) * nsub;
   if (PASS == 1) {
     // where every key's run begins: its class list + the keys of the same class before it
-    for (int k = lane; k < kSortKeys; k += 64) {
-      const int c = k / kSubBuckets;
+    for (int k = lane; k < n_keys; k += 64) {
+      const int c = k / nsub;
       uint32_t before = 0;
-      for (int j = c * kSubBuckets; j < k; ++j) before += a.key_totals[j];
+      for (int j = c * nsub; j < k; ++j) before += a.key_totals[j];
       base[k] = before;
-      if (wv::block_id() == 0 && k % kSubBuckets == kSubBuckets - 1 && static_cast<uint32_t>(c) < a.n_classes)
-        a.list_counts[c] = before + a.key_totals[k];
+      if (wv::block_id() == 0 && k % nsub == nsub - 1) a.list_counts[c] = before + a.key_totals[k];
     }
   }
   const uint32_t per_chunk = 64u * kClassifyChunk;
   const uint32_t chunks = (a.n + per_chunk - 1) / per_chunk;
   for (uint32_t ch = static_cast<uint32_t>(wv::block_id()); ch < chunks; ch += static_cast<uint32_t>(wv::grid_size())) {
     const uint32_t first = ch * per_chunk;
-    for (int k = lane; k < kSortKeys; k += 64) hist[k] = 0;
+    for (int k = lane; k < n_keys; k += 64) hist[k] = 0;
     wv::sync();
     uint32_t keys[kClassifyChunk];
 #pragma unroll
@@ -629,10 +634,10 @@ SPMX_DEVICE void classify_block(const ClassifyArgs &a, uint32_t *hist) {
     }
     wv::sync();
     if (PASS == 0) {
-      for (int k = lane; k < kSortKeys; k += 64) if (hist[k]) wv::atomic_add(&a.key_totals[k], hist[k]);
+      for (int k = lane; k < n_keys; k += 64) if (hist[k]) wv::atomic_add(&a.key_totals[k], hist[k]);
     } else {
       // reserve this chunk's slice of every key's run, then hand out the slots (order inside a slice is arbitrary)
-      for (int k = lane; k < kSortKeys; k += 64) {
+      for (int k = lane; k < n_keys; k += 64) {
         start[k] = hist[k] ? wv::atomic_add(&a.key_cursor[k], hist[k]) : 0u;
         hist[k] = 0;
       }
@@ -641,7 +646,7 @@ SPMX_DEVICE void classify_block(const ClassifyArgs &a, uint32_t *hist) {
       for (int k = 0; k < kClassifyChunk; ++k) {
         const uint32_t i = first + static_cast<uint32_t>(k) * 64u + static_cast<uint32_t>(lane);
         if (keys[k] != 0xFFFFFFFFu) {
-          const uint32_t key = keys[k], c = key / kSubBuckets;
+          const uint32_t key = keys[k], c = key / a.sub_buckets;
           const uint32_t r = wv::lds_atomic_add(&hist[key], 1u);
           a.lists[static_cast<uint64_t>(c) * a.n + base[key] + start[key] + r] = i;
         }

@@ -211,6 +211,7 @@ int64_t emu_encode_batch(void *hv, const uint8_t *text, const uint64_t *offs, ui
   ca.lists = lists.data(); ca.list_counts = list_counts.data();
   std::vector<uint32_t> key_totals(kSortKeys, 0), key_cursor(kSortKeys, 0), hist(3 * kSortKeys, 0);
   ca.key_totals = key_totals.data(); ca.key_cursor = key_cursor.data();
+  ca.sub_buckets = getenv("SPMX_SUB_BUCKETS") ? static_cast<uint32_t>(atoi(getenv("SPMX_SUB_BUCKETS"))) : static_cast<uint32_t>(kSubBuckets);
   for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { classify_block<0>(ca, hist.data()); });
   for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { classify_block<1>(ca, hist.data()); });
   const uint64_t text_bytes = offs[n];
@@ -362,6 +363,7 @@ int64_t emu_normalize_batch(void *hv, const uint8_t *text, const uint64_t *offs,
   ca.lists = lists.data(); ca.list_counts = list_counts.data();
   std::vector<uint32_t> key_totals(kSortKeys, 0), key_cursor(kSortKeys, 0), hist(3 * kSortKeys, 0);
   ca.key_totals = key_totals.data(); ca.key_cursor = key_cursor.data();
+  ca.sub_buckets = getenv("SPMX_SUB_BUCKETS") ? static_cast<uint32_t>(atoi(getenv("SPMX_SUB_BUCKETS"))) : static_cast<uint32_t>(kSubBuckets);
   for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { classify_block<0>(ca, hist.data()); });
   for (int b = 0; b < grid; ++b) emu::RunWave(b, grid, nullptr, [&] { classify_block<1>(ca, hist.data()); });
   uint32_t status = 0;
