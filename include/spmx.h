@@ -56,7 +56,7 @@ int spmx_piece_to_id(const spmx_handle *h, const char *piece, uint64_t len);/* P
 int64_t spmx_id_to_piece(const spmx_handle *h, int id, char *out, uint64_t cap);
 int spmx_unk_id(const spmx_handle *h);
 /* SentencePiece::Type of a piece (src/sentencepiece_model.proto:296-303): 1 NORMAL, 2 UNKNOWN, 3 CONTROL,
- * 4 USER_DEFINED, 5 UNUSED, 6 BYTE -- IsUnknown / IsControl / IsUnused / IsByte (sentencepiece_processor.h:660-672);
+ * 4 USER_DEFINED, 5 UNUSED, 6 BYTE -- IsUnknown / IsControl / IsUnused / IsByte (sentencepiece_processor.h:653-662);
  * -1 for an id out of range. */
 int spmx_piece_type(const spmx_handle *h, int id);
 int spmx_bos_id(const spmx_handle *h);
@@ -103,7 +103,7 @@ int spmx_encode(spmx_handle *h, const char *text, uint64_t len, int32_t *ids, ui
 
 /* ---- decode -------------------------------------------------------------
  * Element-wise identical to SentencePieceProcessor::Decode(const std::vector<int>& ids, std::string*)
- *   (src/sentencepiece_processor.h:330-331, .cc:761-925): control pieces vanish, the unknown piece becomes
+ *   (src/sentencepiece_processor.h:311-312, .cc:761-925): control pieces vanish, the unknown piece becomes
  *   trainer_spec.unk_surface, byte pieces are reassembled into UTF-8 (a structurally invalid byte -> U+FFFD),
  *   U+2581 -> ' ', leading whitespace handled as the normalizer_spec asks.  An id outside [0, GetPieceSize())
  *   fails the call with OUT_OF_RANGE (11) "Invalid id: N"; a model with a denormalizer_spec is UNIMPLEMENTED (12).
@@ -122,7 +122,7 @@ int spmx_decode(spmx_handle *h, const int32_t *ids, uint64_t n_ids, char *out, u
 /* ---- spans form ---------------------------------------------------------
  * The ids plus, for every id, the byte range [begin, end) of its sentence that it covers: pieces(i).begin() /
  * .end() of the SentencePieceText that Encode(absl::string_view, SentencePieceText *) fills
- * (src/sentencepiece_processor.cc:639-653, PopulateSentencePieceText :547-636, bos / eos spans :1029-1048).
+ * (src/sentencepiece_processor.cc:638-651, PopulateSentencePieceText :547-636, bos / eos spans :1029-1048).
  * Offsets are relative to the start of the sentence, in bytes (the C++ convention; the Python wrapper converts to
  * characters, sentencepiece.i ConvertToUnicodeSpans).  surface = input[begin, end); the piece of a known id is
  * IdToPiece(id).  Sentences are limited to 8192 bytes here (OUT_OF_RANGE beyond).
@@ -138,7 +138,7 @@ int spmx_encode_batch_spans(spmx_handle *h, const char *text, const uint64_t *of
                             uint64_t **id_offsets, uint32_t **begin, uint32_t **end, uint32_t **nbegin, uint32_t **nend);
 
 /* ---- batch Normalize ----------------------------------------------------
- * SentencePieceProcessor::Normalize(input, &normalized, &norm_to_orig) (src/sentencepiece_processor.cc:1102-1113 ->
+ * SentencePieceProcessor::Normalize(input, &normalized, &norm_to_orig) (src/sentencepiece_processor.cc:933-945 ->
  * Normalizer::Normalize, src/normalizer.cc:71-186) per sentence: the packed normalized text + n + 1 offsets and,
  * optionally, the alignment vectors: sentence s owns entries [norm_offsets[s] + s, norm_offsets[s + 1] + s + 1) of
  * norm_to_orig -- one per normalized byte plus the closing one, which is 0xFFFFFFFF where the reference's vector
@@ -151,7 +151,7 @@ int spmx_normalize_batch(spmx_handle *h, const char *text, const uint64_t *offse
                          uint64_t **norm_offsets, uint32_t **norm_to_orig);
 
 /* ---- n-best -------------------------------------------------------------
- * NBestEncode(input, nbest_size, std::vector<std::vector<int>>*) (src/sentencepiece_processor.h:360-362;
+ * NBestEncode(input, nbest_size, std::vector<std::vector<int>>*) (src/sentencepiece_processor.h:323-324;
  * unigram::Model::NBestEncode src/unigram_model.cc:686-717, Lattice::NBest :345-515) per sentence, unigram models
  * only (INTERNAL otherwise, as the reference).  nbest_size is clamped to [1, 1024]; 1 is the plain encoder with
  * score 0.  Result r of the batch: ids[id_offsets[r], id_offsets[r + 1]) and scores[r]; sentence s owns the

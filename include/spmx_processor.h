@@ -181,7 +181,7 @@ class SentencePieceProcessor {
                                                d_id_offsets, stream, total_ids));
   }
 
-  // ---- pieces / SentencePieceText (sentencepiece_processor.h:296-297, :303-304, :462-466) ----
+  // ---- pieces / SentencePieceText (sentencepiece_processor.h:295-296, :401-402, :453-456) ----
   // The device returns ids, input spans and normalized-text spans (spmx_encode_batch_spans) and the normalized text
   // (spmx_normalize_batch); a piece is its normalized text, the piece name for a byte-fallback piece and a bos / eos,
   // or unk_piece for an unknown token under the `unk_piece` extra option (sentencepiece_processor.cc:547-636, :1019-1064).
@@ -230,7 +230,7 @@ class SentencePieceProcessor {
     return pieces;
   }
 
-  // ---- n-best (sentencepiece_processor.h:360-362; unigram models) ----
+  // ---- n-best (sentencepiece_processor.h:323-324; unigram models) ----
   util::Status NBestEncode(std::string_view input, int nbest_size, std::vector<std::vector<int>> *ids) const {
     if (!h_) return status();
     if (!ids) return util::Status(util::StatusCode::kInternal, "output container is null");
@@ -251,7 +251,7 @@ class SentencePieceProcessor {
     return ids;
   }
 
-  // ---- Normalize (sentencepiece_processor.h:326-336) ----
+  // ---- Normalize (sentencepiece_processor.h:622-631) ----
   util::Status Normalize(std::string_view input, std::string *normalized, std::vector<size_t> *norm_to_orig) const {
     if (!h_) return status();
     if (!normalized || !norm_to_orig) return util::Status(util::StatusCode::kInternal, "output container is null");
@@ -279,7 +279,7 @@ class SentencePieceProcessor {
     return out;
   }
 
-  // ---- decode (sentencepiece_processor.h:330-331, :480-482) ----
+  // ---- decode (sentencepiece_processor.h:311-312, :515-517) ----
   util::Status Decode(const std::vector<int> &ids, std::string *detokenized) const {
     if (!h_) return status();
     if (!detokenized) return util::Status(util::StatusCode::kInternal, "output container is null");
@@ -331,7 +331,7 @@ class SentencePieceProcessor {
     spmx_id_to_piece(h_, id, s.data(), s.size());
     return s;
   }
-  bool IsUnknown(int id) const { return h_ && spmx_piece_type(h_, id) == 2; }   // sentencepiece_processor.h:660-672
+  bool IsUnknown(int id) const { return h_ && spmx_piece_type(h_, id) == 2; }   // sentencepiece_processor.h:653-662
   bool IsControl(int id) const { return h_ && spmx_piece_type(h_, id) == 3; }
   bool IsUnused(int id) const { return h_ && spmx_piece_type(h_, id) == 5; }
   bool IsByte(int id) const { return h_ && spmx_piece_type(h_, id) == 6; }

@@ -206,7 +206,7 @@ int64_t spmref_decode_batch(void *handle, const int32_t *ids, const uint64_t *id
   return static_cast<int64_t>(all.size());
 }
 
-// Encode(input, SentencePieceText *) per sentence (sentencepiece_processor.h:303-304): ids and
+// Encode(input, SentencePieceText *) per sentence (sentencepiece_processor.h:401-402): ids and
 // pieces(i).begin() / .end().  Returns total pieces, -1 on a Status error, -(needed) - 2 if cap is too small.
 int64_t spmref_encode_spans_batch(void *handle, const char *text, const uint64_t *offsets, uint64_t n, int32_t *ids,
                                   uint32_t *begin, uint32_t *end, uint64_t cap, uint64_t *id_offsets) {
@@ -267,7 +267,7 @@ int64_t spmref_encode_pieces_batch(void *handle, const char *text, const uint64_
   return static_cast<int64_t>(total);
 }
 
-// Normalize(input, &normalized, &norm_to_orig) per sentence (sentencepiece_processor.h:330-332); layout as
+// Normalize(input, &normalized, &norm_to_orig) per sentence (sentencepiece_processor.h:627-629); layout as
 // oracle_normalize_batch.
 int64_t spmref_normalize_batch(void *handle, const char *text, const uint64_t *offsets, uint64_t n, char *out,
                                uint64_t cap, uint64_t *norm_offsets, uint32_t *n2o) {
@@ -294,7 +294,7 @@ int64_t spmref_normalize_batch(void *handle, const char *text, const uint64_t *o
 }
 
 // NBestEncode(input, nbest_size, &ids) + the scores of NBestEncode(input, nbest_size, NBestSentencePieceText*)
-// (sentencepiece_processor.h:360-366).  Layout as oracle_nbest_encode.
+// (sentencepiece_processor.h:323-324, :404-405).  Layout as oracle_nbest_encode.
 int64_t spmref_nbest_encode(void *handle, const char *text, uint64_t len, int nbest_size, int32_t *ids, uint64_t cap,
                             uint64_t *offs, float *scores) {
   auto *h = static_cast<RefHandle *>(handle);
@@ -315,7 +315,7 @@ int64_t spmref_nbest_encode(void *handle, const char *text, uint64_t len, int nb
   return nb.nbests_size();
 }
 
-// EncodeAsSerializedProto(input) per sentence (sentencepiece_processor.h:493-494): the serialized SentencePieceText
+// EncodeAsSerializedProto(input) per sentence (sentencepiece_processor.h:528-531): the serialized SentencePieceText
 // messages back to back, message i at out[out_offs[i], out_offs[i + 1]).
 int64_t spmref_encode_serialized_batch(void *handle, const char *text, const uint64_t *offsets, uint64_t n, char *out,
                                        uint64_t cap, uint64_t *out_offs) {

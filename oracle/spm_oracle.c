@@ -1042,7 +1042,7 @@ static int unigram_nbest(const Oracle *o, const uint8_t *norm, int size, int nbe
 }
 
 /* SentencePieceProcessor::NBestEncode(input, nbest_size, std::vector<std::vector<int>>*)
- * (sentencepiece_processor.cc:478-492, :655-680).  ids of result k at out[offs[k], offs[k + 1]); scores[k].
+ * (sentencepiece_processor.cc:451-467, :653-678).  ids of result k at out[offs[k], offs[k + 1]); scores[k].
  * Returns the number of results, -1 on an error status (not a unigram model, ...), -(needed) - 2 if cap is small. */
 int64_t oracle_nbest_encode(const Oracle *o, const char *in, uint64_t n, int nbest_size, int32_t *out, uint64_t cap,
                             uint64_t *offs, float *scores) {

@@ -48,7 +48,7 @@ int64_t oracle_encode_pieces_batch(const Oracle *o, const char *text, const uint
 int64_t oracle_normalize_batch(const Oracle *o, const char *text, const uint64_t *offsets, uint64_t n,
                                char *out, uint64_t cap, uint64_t *norm_offsets, uint32_t *n2o);
 
-/* NBestEncode(input, nbest_size, std::vector<std::vector<int>>*) (sentencepiece_processor.cc:478-492, :655-680;
+/* NBestEncode(input, nbest_size, std::vector<std::vector<int>>*) (sentencepiece_processor.cc:451-467, :653-678;
  * Lattice::NBest unigram_model.cc:345-515): result k's ids at out[offs[k], offs[k + 1]) and its score.  offs holds
  * min(max(nbest_size, 1), 1024) + 1 entries.  Returns the number of results, -1 on an error status,
  * -(needed) - 2 if cap is too small. */

@@ -1,5 +1,5 @@
 // Batch Normalize on the device: SentencePieceProcessor::Normalize(input, &normalized, &norm_to_orig)
-// (src/sentencepiece_processor.cc:1102-1113 -> Normalizer::Normalize, src/normalizer.cc:71-186) for a packed batch:
+// (src/sentencepiece_processor.cc:933-945 -> Normalizer::Normalize, src/normalizer.cc:71-186) for a packed batch:
 // the normalized text as the reference returns it (U+2581 in its three bytes) and, optionally, the alignment vector.
 // One sentence per wavefront over the length-class lists of the classify kernels, the position-parallel normalizer
 // of kernels.h; count pass -> scan -> write pass, as the decode kernels.  A cold path: it feeds the piece strings

@@ -428,7 +428,7 @@ class SentencePieceProcessor:
         return out[0] if single else out
 
     def EncodeAsPieces(self, input):
-        """``EncodeAsPieces`` (sentencepiece_processor.h:462-466) / ``encode(out_type=str)``: the piece strings."""
+        """``EncodeAsPieces`` (sentencepiece_processor.h:453-456) / ``encode(out_type=str)``: the piece strings."""
         single = isinstance(input, (str, bytes))
         rows = self.EncodeAsSentencePieceText([input] if single else input)
         out = [[p.decode("utf-8", "surrogateescape") for p, *_ in row] for row in rows]
