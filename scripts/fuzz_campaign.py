@@ -1,0 +1,59 @@
+# Extended differential campaign on CPU (not part of the test suite): device kernels under the emulator vs the oracle -- encode, spans, normalize, decode, n-best -- over fresh seeds until the time is up.  usage: python scripts/fuzz_campaign.py SECONDS FIRST_SEED
+import sys, time, ctypes as C
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from sentencepiece_amd import synth
+from tests import fixtures, oraclelib, emulib
+from tests.test_fuzz import fuzz_corpus
+from tests.test_nbest import nbest as nb_call
+
+corp = fixtures.Corpora()
+em = emulib.EmuLib(); orc = oraclelib.OracleLib()
+MODELS = ["test_model", "uni1k_bf", "uni32k", "bpe1k", "bpe32k", "bpe1k_llama", "uni1k_uds", "uni1k_ident", "test_ja_model", "bpe1k_noesc", "uni1k_suffix", "bpe1k_bf_uds"]
+t_end = time.time() + float(sys.argv[1]) if len(sys.argv) > 1 else time.time() + 1800
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+bad = 0
+handles = {m: (em.load(fixtures.model_blob(m)), orc.load(fixtures.model_blob(m))) for m in MODELS}
+while time.time() < t_end:
+    seed += 1
+    text, offs = fuzz_corpus(120, seed, corp)
+    for m in MODELS:
+        h, o = handles[m]
+        try:
+            ids, io = h.encode_batch(text, offs, grid=2)
+            oi, oo = o.encode_batch(text, offs)
+            if h.status or not (np.array_equal(ids, oi) and np.array_equal(io, oo)):
+                bad += 1; print("ENCODE MISMATCH", m, seed, h.status, flush=True)
+            # spans + pieces on sentences up to 8192 bytes (the spans limit)
+            lens = np.diff(np.asarray(offs).astype(np.int64))
+            got = h.encode_spans(text, offs, grid=2)
+            want = o.encode_spans(text, offs)
+            if h.status or not all(np.array_equal(np.asarray(a).astype(np.int64), np.asarray(b).astype(np.int64)) for a, b in zip(got, want)):
+                bad += 1; print("SPANS MISMATCH", m, seed, h.status, flush=True)
+            a = h.normalize_batch(text, offs, grid=2); b = o.normalize_batch(text, offs)
+            if not all(np.array_equal(x, y) for x, y in zip(a, b)):
+                bad += 1; print("NORMALIZE MISMATCH", m, seed, flush=True)
+            dt, do = h.decode_batch(oi, oo); ot, od = o.decode_batch(oi, oo)
+            if not (np.array_equal(dt, ot) and np.array_equal(do, od)):
+                bad += 1; print("DECODE MISMATCH", m, seed, flush=True)
+        except Exception as e:
+            bad += 1; print("EXC", m, seed, repr(e)[:200], flush=True)
+    # n-best on short sentences for the unigram models
+    tb = np.asarray(text).tobytes()
+    sents = [tb[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
+    sents = [s for s in sents if len(s) <= 120][:25]
+    if sents:
+        t2, o2 = synth.pack(sents)
+        for m in ("test_model", "uni1k_bf", "uni1k_uds"):
+            h, o = handles[m]
+            try:
+                got = h.nbest(t2, o2, 7, grid=1)
+                for s, res in zip(sents, got):
+                    n, want, sc = nb_call(o.lib.oracle_nbest_encode, o.h, s, 7)
+                    if [r[0] for r in res] != want or not np.array_equal(np.array([r[1] for r in res], dtype=np.float32), sc):
+                        bad += 1; print("NBEST MISMATCH", m, seed, s[:40], flush=True)
+            except Exception as e:
+                # sentences whose normalized form exceeds the NBest capacity raise: acceptable only for long normalized text
+                print("NBEST EXC", m, seed, repr(e)[:120], flush=True)
+    print("seed", seed, "bad", bad, flush=True)
+print("DONE bad =", bad)
