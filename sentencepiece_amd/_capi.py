@@ -66,6 +66,18 @@ SYMBOLS = [
 _lib = None
 
 
+def bind(path):
+    """ctypes handle of a library exporting include/spmx.h, with every prototype set.  Besides lib() below the only
+    caller is the test suite, which binds tests/emu/libspmx_emu.so (the same api.cc over a CPU model of the
+    wavefront) explicitly; the product never does."""
+    l = C.CDLL(path)
+    for name, res, args in SYMBOLS:
+        fn = getattr(l, name)   # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return l
+
+
 def lib():
     """Loads libspmx.so once.  Raises if it has not been built."""
     global _lib
@@ -83,10 +95,5 @@ def lib():
                 import torch  # noqa: F401
             except ImportError:
                 pass
-        l = C.CDLL(LIB_PATH)
-        for name, res, args in SYMBOLS:
-            fn = getattr(l, name)   # AttributeError if the .so does not export it
-            fn.restype = res
-            fn.argtypes = args
-        _lib = l
+        _lib = bind(LIB_PATH)
     return _lib

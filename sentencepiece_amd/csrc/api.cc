@@ -128,6 +128,7 @@ struct spmx_handle {
   bool static_tiles = false;         // SPMX_STATIC_TILES=1: fixed-stride tiles in the streaming kernels (A/B measurements)
   bool no_merge_general = false;     // SPMX_NO_MERGE_GENERAL=1: a GENERAL launch per class (A/B measurements)
   bool no_stream = false;            // SPMX_NO_STREAM=1: BPE in the sentence-per-wave form only (A/B measurements)
+  uint32_t ring_override = 0;        // SPMX_FORCE_RING: score-ring entries (A/B measurements; must exceed the longest piece)
   uint64_t stream_scratch_limit = 4ull << 30;   // SPMX_STREAM_SCRATCH_MB: cap on the streaming kernels' HBM scratch
   DevBuf<uint32_t> d_stream;         // scratch of the streaming kernels (text columns + back-pointer words)
   bool ev_ready = false;
@@ -227,6 +228,12 @@ void DestroyHandle(spmx_handle *h) {
 int NumClasses(const spmx_handle *h) { return h->model.model_type == kBpe ? kNumClassesBpe : kNumClassesUnigram; }
 const LengthClass *Classes(const spmx_handle *h) { return h->model.model_type == kBpe ? kClassesBpe : kClassesUnigram; }
 
+// score-ring entries of the streaming unigram kernels for this handle's model
+uint32_t HandleRing(const spmx_handle *h) {
+  const uint32_t r = ScoreRing(h->tables.max_piece_len);
+  return h->ring_override > r ? h->ring_override : r;
+}
+
 // Launch shape of one streaming kernel (kernels_stream.h) on a class list of `known` sentences: as many
 // wavefronts per workgroup as the LDS of a CU holds (one workgroup per CU), fewer workgroups when the list is
 // short (at least one sentence per wave) or when the HBM scratch would pass the handle's limit.
@@ -238,7 +245,7 @@ struct StreamPlan {
 StreamPlan PlanStream(const spmx_handle *h, const LengthClass &lc, bool fast, uint64_t known) {
   const int model = h->model.model_type;
   StreamPlan sp;
-  const uint32_t ring = ScoreRing(h->tables.max_piece_len);
+  const uint32_t ring = HandleRing(h);
   // a FAST text column never exceeds raw length + 1 (one-byte space symbol); GENERAL: the class's normalized capacity
   sp.tcap = fast ? (lc.rcap > kMaxStagedRaw ? lc.ncap : lc.rcap + 1) : lc.ncap;
   const uint32_t priv = StreamPrivateBytes(fast, model, lc.rcap, lc.ncap, ring);
@@ -393,7 +400,7 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
       if (streaming) {
         const bool shared01 = merge01 && c == 1 && known[0] > 0;
         if (known[c] == 0 && !prev_general && !shared01) continue;
-        a.ring = ScoreRing(h->tables.max_piece_len);
+        a.ring = HandleRing(h);
         const bool fast = StreamFastEligible(h->dev.flags) && !h->no_fast && known[c] > 0;
         const bool staged = cls[c].rcap <= kMaxStagedRaw;
         if (!staged && !fast) continue;
@@ -736,6 +743,7 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
   if (const char *e = getenv("SPMX_LANE_GENERAL_MIN_LANES")) h->lane_general_min_lanes = static_cast<uint32_t>(atoi(e));
   if (const char *e = getenv("SPMX_STREAM_SCRATCH_MB")) h->stream_scratch_limit = static_cast<uint64_t>(atoll(e)) << 20;
   if (const char *e = getenv("SPMX_TILE_WAVES")) h->tile_waves_override = atoi(e);
+  if (const char *e = getenv("SPMX_FORCE_RING")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) h->ring_override = static_cast<uint32_t>(v); }
   if ((e = hipMalloc(reinterpret_cast<void **>(&h->d_ctrl), sizeof(Ctrl))) != hipSuccess) return bail(e, "hipMalloc(ctrl)");
   if ((e = hipHostMalloc(reinterpret_cast<void **>(&h->h_ctrl), sizeof(Ctrl), hipHostMallocDefault)) != hipSuccess)
     return bail(e, "hipHostMalloc(ctrl)");

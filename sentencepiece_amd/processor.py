@@ -24,8 +24,8 @@ _RESOURCE_EXHAUSTED = 8
 class SentencePieceProcessor:
     def __init__(self, model_file=None, model_proto=None, out_type=int, add_bos=False, add_eos=False,
                  reverse=False, emit_unk_piece=False, enable_sampling=False, nbest_size=-1, alpha=0.1,
-                 num_threads=-1, device=0):
-        self._lib = _capi.lib()
+                 num_threads=-1, device=0, _lib=None):
+        self._lib = _lib if _lib is not None else _capi.lib()   # _lib: test seam (tests/emu), never set by the product
         self._h = None
         self._device = device
         self._out_type = out_type
@@ -283,7 +283,7 @@ class SentencePieceProcessor:
         if d_ids is None:
             d_ids = torch.empty(d_text.numel() // 2 + 4 * n + 64, dtype=torch.int32, device=d_text.device)
         if stream is None:
-            stream = torch.cuda.current_stream(d_text.device).cuda_stream
+            stream = torch.cuda.current_stream(d_text.device).cuda_stream if d_text.is_cuda else 0
         total = C.c_uint64(0)
         for _ in range(2):
             rc = self._lib.spmx_encode_batch_device(

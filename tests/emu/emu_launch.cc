@@ -1,0 +1,87 @@
+// TEST INFRASTRUCTURE ONLY (see wave_emu.h, fakehip/hip/hip_runtime.h): csrc/launch.h implemented on the lock-step
+// wave model, standing in for csrc/kernels.hip so that csrc/api.cc -- the product's launch sequence, unchanged --
+// runs on the CPU.  A launch runs the wavefronts of the grid one after another (workgroup by workgroup, wave by wave);
+// the waves of a workgroup share one LDS block, as on the device.
+#include "wave_emu.h"
+
+#include <vector>
+
+#include "../../sentencepiece_amd/csrc/launch.h"
+
+namespace spmx {
+namespace {
+template <typename F>
+void RunGrid(int grid, int waves, uint32_t lds_bytes, F body) {
+  std::vector<unsigned char> raw(lds_bytes + 128);
+  unsigned char *smem = raw.data() + ((64 - (reinterpret_cast<uintptr_t>(raw.data()) & 63)) & 63);
+  for (int b = 0; b < grid; ++b) {
+    memset(smem, 0xCD, lds_bytes + 32);
+    for (int w = 0; w < waves; ++w) {
+      emu::g_wave.wib = w;
+      emu::g_wave.wpb = waves;
+      emu::RunWave(b, grid, smem, [&] { body(smem); });
+    }
+  }
+  emu::g_wave.wib = 0;
+  emu::g_wave.wpb = 1;
+}
+}  // namespace
+
+hipError_t LaunchEncodeStream(int model_type, int cls, bool fast, const EncodeArgs &a, int grid, int waves,
+                              uint32_t lds_bytes, hipStream_t) {
+  (void)cls;
+  if (model_type == 2) {
+    if (fast) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<true, 2>(a, s); });
+    else RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<false, 2>(a, s); });
+  } else if (fast) {
+    if (a.ring == 16) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<true, 1, 16>(a, s); });
+    else RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<true, 1>(a, s); });
+  } else {
+    RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<false, 1>(a, s); });
+  }
+  return hipSuccess;
+}
+
+hipError_t LaunchEncode(int, int, const EncodeArgs &a, int grid, uint32_t lds_bytes, hipStream_t) {
+  RunGrid(grid, 1, lds_bytes, [&](unsigned char *s) { encode_block<2>(a, s); });
+  return hipSuccess;
+}
+hipError_t LaunchAlign(const AlignArgs &a, int grid, uint32_t lds_bytes, hipStream_t) {
+  RunGrid(grid, 1, lds_bytes, [&](unsigned char *s) { align_block(a, s); });
+  return hipSuccess;
+}
+hipError_t LaunchNormalize(bool write, const NormalizeArgs &a, int grid, uint32_t lds_bytes, hipStream_t) {
+  if (write) RunGrid(grid, 1, lds_bytes, [&](unsigned char *s) { normalize_block<true>(a, s); });
+  else RunGrid(grid, 1, lds_bytes, [&](unsigned char *s) { normalize_block<false>(a, s); });
+  return hipSuccess;
+}
+hipError_t LaunchNBest(const NBestArgs &a, int grid, hipStream_t) {
+  RunGrid(grid, 1, 0, [&](unsigned char *) { nbest_block(a); });
+  return hipSuccess;
+}
+hipError_t LaunchSplit(bool write, const SplitArgs &a, int grid, hipStream_t) {
+  if (write) RunGrid(grid, 1, kSplitLdsBytes, [&](unsigned char *s) { split_block<true>(a, s); });
+  else RunGrid(grid, 1, 0, [&](unsigned char *) { split_block<false>(a, nullptr); });
+  return hipSuccess;
+}
+hipError_t LaunchDecode(bool write, const DecodeArgs &a, int grid, hipStream_t) {
+  if (write) RunGrid(grid, 1, 0, [&](unsigned char *) { decode_block<true>(a); });
+  else RunGrid(grid, 1, 0, [&](unsigned char *) { decode_block<false>(a); });
+  return hipSuccess;
+}
+hipError_t LaunchClassify(const ClassifyArgs &a, int grid, hipStream_t) {
+  RunGrid(grid, 1, 3 * kSortKeys * 4, [&](unsigned char *s) { classify_block<0>(a, reinterpret_cast<uint32_t *>(s)); });
+  RunGrid(grid, 1, 3 * kSortKeys * 4, [&](unsigned char *s) { classify_block<1>(a, reinterpret_cast<uint32_t *>(s)); });
+  return hipSuccess;
+}
+hipError_t LaunchScan(const ScanArgs &a, int grid, hipStream_t) {
+  RunGrid(grid, 1, 0, [&](unsigned char *) { scan_tiles_block(a); });
+  RunGrid(1, 1, 0, [&](unsigned char *) { scan_sums_block(a); });
+  RunGrid(grid, 1, 0, [&](unsigned char *) { scan_final_block(a); });
+  return hipSuccess;
+}
+hipError_t LaunchCompact(const CompactArgs &a, int grid, hipStream_t) {
+  RunGrid(grid, 1, 0, [&](unsigned char *) { compact_block(a); });
+  return hipSuccess;
+}
+}  // namespace spmx

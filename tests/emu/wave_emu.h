@@ -43,6 +43,7 @@ struct Wave {
   void *sched_sp = nullptr;
   int cur = 0;
   int block = 0, grid = 1;
+  int wib = 0, wpb = 1;      // wave index within its workgroup, waves per workgroup
   std::function<void()> body;
   unsigned char *smem = nullptr;
   uint64_t n_collectives = 0;
@@ -67,8 +68,8 @@ namespace wv {
 inline int lane() { return emu::g_wave.cur; }
 inline int block_id() { return emu::g_wave.block; }
 inline int grid_size() { return emu::g_wave.grid; }
-inline int wave_in_block() { return 0; }
-inline int waves_per_block() { return 1; }
+inline int wave_in_block() { return emu::g_wave.wib; }
+inline int waves_per_block() { return emu::g_wave.wpb; }
 
 inline uint64_t ballot(bool p) { return emu::Collective(emu::kBallot, p ? 1 : 0, 0); }
 inline bool any(bool p) { return ballot(p) != 0; }
