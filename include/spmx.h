@@ -10,10 +10,11 @@
  * of the last error is available from spmx_last_error().  No C++ exception
  * crosses the boundary, as in the reference (only Status values).
  *
- * Thread safety: like SentencePieceProcessor, a loaded handle may be used
- * for encoding from several host threads (calls are serialized inside the
- * handle); the mutators (set_encode_extra_options, set_vocabulary, ...) must
- * not race with encodes.
+ * Thread safety: like SentencePieceProcessor's const methods, a loaded handle
+ * may be used for encoding / decoding from several host threads at once: every
+ * call leases its own workspace and stream, so the calls overlap on the GPU.
+ * The mutators (set_encode_extra_options, set_vocabulary, ...) must not race
+ * with them, as in the reference.  spmx_last_error() is per calling thread.
  */
 #ifndef SPMX_H_
 #define SPMX_H_
@@ -38,8 +39,7 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
 int spmx_create_from_file(const char *filename, int device, spmx_handle **out);
 void spmx_destroy(spmx_handle *h);
 
-/* util::Status::ToString() of the last failing call on this handle (or of the
- * last failed spmx_create when h is NULL). */
+/* util::Status::ToString() of the calling thread's last failing call (h is ignored and may be NULL). */
 const char *spmx_last_error(const spmx_handle *h);
 
 /* ---- configuration ------------------------------------------------------
@@ -63,6 +63,12 @@ int spmx_bos_id(const spmx_handle *h);
 int spmx_eos_id(const spmx_handle *h);
 int spmx_pad_id(const spmx_handle *h);
 int spmx_model_type(const spmx_handle *h);   /* 1 unigram, 2 bpe */
+/* Diagnostic: the kNf* bits the table compiler derived for this model (csrc/dev.h): which normalizer switches are on,
+ * whether the one-byte space symbol / the word-wise BPE form apply. */
+uint32_t spmx_model_flags(const spmx_handle *h);
+/* trainer_spec.unk_piece (src/sentencepiece_model.proto:220), the string the `unk_piece` extra option writes
+ * (src/sentencepiece_processor.cc:1050-1058): copies up to cap bytes, returns its length. */
+int64_t spmx_unk_piece(const spmx_handle *h, char *out, uint64_t cap);
 
 /* ---- encode -------------------------------------------------------------
  * All three are element-wise identical to calling
@@ -72,10 +78,16 @@ int spmx_model_type(const spmx_handle *h);   /* 1 unigram, 2 bpe */
  *   _EncodeAsIdsBatch (python/src/sentencepiece/sentencepiece.i:439-446) --
  * computes with a thread pool.
  *
- * Length limits of the device path (OUT_OF_RANGE beyond them; the reference has none): 1 MiB per sentence for
- * models without user-defined symbols / whitespace-as-suffix -- unigram, and BPE whose pieces do not span words
- * (the usual case; a single word may have up to 4096 characters); 8192 bytes for the other unigram models, 4096
- * bytes for the other BPE models.
+ * No length limits: a sentence of any size is encoded (the fast kernels take what fits their length classes; what
+ * does not -- documents, words of thousands of characters, BPE models whose pieces span words -- runs in kernels
+ * whose working set lives in HBM, sized from the sentence).  The only bound is the reference's own int arithmetic:
+ * the NORMALIZED form of one sentence must stay below 2^31 bytes.
+ *
+ * Per-sentence status: a sentence the reference's Encode would fail (kInternal "all normalized characters are not
+ * consumed", e.g. a CONTROL piece among BPE symbols), or one beyond the bound above (OUT_OF_RANGE), yields NO ids;
+ * the other sentences of the batch are unaffected -- what the reference's batch form does, whose workers call
+ * EncodeAsIds and drop the Status (python/src/sentencepiece/sentencepiece.i:249-265).  The batch calls return OK;
+ * the _ex forms report a util::StatusCode byte per sentence (0 = OK) and the number of failed sentences.
  *
  * Sentences are passed packed: `text` holds the bytes of all sentences back to
  * back, offsets[i] .. offsets[i+1] delimit sentence i (n + 1 entries).
@@ -90,15 +102,24 @@ int spmx_encode_batch_device(spmx_handle *h, const void *d_text, uint64_t text_b
                              uint64_t n, int32_t *d_ids, uint64_t ids_capacity, uint64_t *d_id_offsets, void *stream,
                              uint64_t *total_ids);
 
+/* As above, plus d_status (nullable): n status bytes in device memory; *n_failed (nullable): sentences with a
+ * non-zero status. */
+int spmx_encode_batch_device_ex(spmx_handle *h, const void *d_text, uint64_t text_bytes, const uint64_t *d_offsets,
+                                uint64_t n, int32_t *d_ids, uint64_t ids_capacity, uint64_t *d_id_offsets,
+                                uint8_t *d_status, void *stream, uint64_t *total_ids, uint64_t *n_failed);
+
 /* Host-buffer form: copies text to the GPU, encodes, copies ids back.
  * *ids (total ids) and *id_offsets (n + 1) are allocated by the library and
  * released with spmx_free(). */
 int spmx_encode_batch(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
                       uint64_t **id_offsets);
+/* As above, plus *status (nullable): n status bytes, released with spmx_free(); *n_failed (nullable). */
+int spmx_encode_batch_ex(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
+                         uint64_t **id_offsets, uint8_t **status, uint64_t *n_failed);
 void spmx_free(void *p);
 
-/* Single sentence, caller-provided buffer (Encode(input, &ids)).  Returns
- * RESOURCE_EXHAUSTED with the needed size in *n_ids if cap is too small. */
+/* Single sentence, caller-provided buffer (Encode(input, &ids)): returns the sentence's own Status, as the
+ * reference does.  RESOURCE_EXHAUSTED with the needed size in *n_ids if cap is too small. */
 int spmx_encode(spmx_handle *h, const char *text, uint64_t len, int32_t *ids, uint64_t cap, uint64_t *n_ids);
 
 /* ---- decode -------------------------------------------------------------
@@ -125,7 +146,7 @@ int spmx_decode(spmx_handle *h, const int32_t *ids, uint64_t n_ids, char *out, u
  * (src/sentencepiece_processor.cc:638-651, PopulateSentencePieceText :547-636, bos / eos spans :1029-1048).
  * Offsets are relative to the start of the sentence, in bytes (the C++ convention; the Python wrapper converts to
  * characters, sentencepiece.i ConvertToUnicodeSpans).  surface = input[begin, end); the piece of a known id is
- * IdToPiece(id).  Sentences are limited to 8192 bytes here (OUT_OF_RANGE beyond).
+ * IdToPiece(id).  Offsets are 32-bit: sentences below 4 GiB.
  * nbegin / nend (optional, both or neither): the same tokens as byte ranges of the NORMALIZED sentence
  * (spmx_normalize_batch): the piece of an unknown token is that text (:614-617); 0, 0 for a bos / eos.
  * d_begin / d_end / d_nbegin / d_nend: ids_capacity entries each; the arrays of the host form are released with
@@ -142,7 +163,8 @@ int spmx_encode_batch_spans(spmx_handle *h, const char *text, const uint64_t *of
  * Normalizer::Normalize, src/normalizer.cc:71-186) per sentence: the packed normalized text + n + 1 offsets and,
  * optionally, the alignment vectors: sentence s owns entries [norm_offsets[s] + s, norm_offsets[s + 1] + s + 1) of
  * norm_to_orig -- one per normalized byte plus the closing one, which is 0xFFFFFFFF where the reference's vector
- * is empty (empty or all-whitespace input).  Sentences are limited to 8192 bytes (OUT_OF_RANGE beyond).
+ * is empty (empty or all-whitespace input).  No length limit (OUT_OF_RANGE only where the normalized form of a
+ * sentence would exceed 2^31 bytes).
  * Device form: d_norm_to_orig (nullable) holds norm_capacity + n + 1 entries. */
 int spmx_normalize_batch_device(spmx_handle *h, const void *d_text, const uint64_t *d_offsets, uint64_t n, void *d_norm,
                                 uint64_t norm_capacity, uint64_t *d_norm_offsets, uint32_t *d_norm_to_orig, void *stream,
@@ -171,23 +193,21 @@ int spmx_split_lines_device(spmx_handle *h, const void *d_file, uint64_t bytes, 
                             uint64_t *text_bytes);
 
 /* ---- measurement --------------------------------------------------------
- * Per-kernel timing of the encode kernels of the LAST
- * spmx_encode_batch_device call, measured with hipEvents on the caller's
- * stream (enable first).  Arrays hold 16 entries ("kernel slots": slot c < 8
- * is length class c's encode kernel, slot 8 + c the GENERAL kernel that
- * follows a FAST kernel of class c; unused slots are zero); returns the
- * number of slots.
- * spmx_last_profile_name() gives the kernel symbol of a slot as rocprofv3
- * prints it.  bytes[] is the algorithmic byte count SURVEY.md section 8d
- * defines (raw bytes + 8 + 4 * ids + 8 per sentence). */
+ * Per-kernel timing of the encode kernels of the LAST profiled encode call on the handle, measured with hipEvents
+ * on the call's stream (enable first).  Arrays hold 5 entries ("kernel slots": 0 the streaming launch over the
+ * classes up to 16 KiB, 1 the streaming launch over the document classes, 2 the overflow launch, 3 the
+ * sentence-per-wave BPE launches, 4 the long form; unused slots are zero); returns the number of slots.
+ * spmx_last_profile_name() gives the kernel symbol of a slot as rocprofv3 prints it.  bytes[] is the algorithmic
+ * byte count SURVEY.md section 8d defines (raw bytes + 8 + 4 * ids + 8 per sentence).  path[4]: sentences the main
+ * tiles set aside on hard lists, sentences on the overflow list, sentences that took the long form, failed sentences. */
 int spmx_set_profiling(spmx_handle *h, int enabled);
 int spmx_last_profile_name(const spmx_handle *h, int slot, char *out, uint64_t cap);
 int spmx_last_profile(const spmx_handle *h, float *kernel_ms, uint64_t *sentences, uint64_t *raw_bytes,
-                      uint64_t *ids, uint64_t *bytes, uint32_t *rcap, float *total_ms);
+                      uint64_t *ids, uint64_t *bytes, uint64_t *path, float *total_ms);
 
-/* Shader-clock cycles the waves of the LAST profiled call spent per phase, summed
- * over waves: cycles[5 * slot + {0 load, 1 normalize, 2 segment, 3 emit}] (80 entries); entry 4 is
- * the number of search-loop iterations the waves of the lane-per-sentence forms executed. */
+/* Shader-clock cycles the waves of the LAST profiled call spent per phase, summed over waves:
+ * cycles[5 * slot + {0 load, 1 normalize, 2 segment, 3 emit}] (25 entries); entry 4 is the number of search-loop
+ * iterations the waves of the lane-per-sentence forms executed. */
 int spmx_last_phase_cycles(const spmx_handle *h, uint64_t *cycles);
 
 #ifdef __cplusplus

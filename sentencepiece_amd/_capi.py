@@ -30,10 +30,18 @@ SYMBOLS = [
     ("spmx_eos_id", C.c_int, [_H]),
     ("spmx_pad_id", C.c_int, [_H]),
     ("spmx_model_type", C.c_int, [_H]),
+    ("spmx_model_flags", C.c_uint32, [_H]),
     ("spmx_encode_batch_device", C.c_int,
      [_H, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, C.c_void_p, C.POINTER(_U64)]),
     ("spmx_encode_batch", C.c_int,
      [_H, C.c_void_p, C.c_void_p, _U64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    ("spmx_encode_batch_ex", C.c_int,
+     [_H, C.c_void_p, C.c_void_p, _U64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+      C.POINTER(_U64)]),
+    ("spmx_encode_batch_device_ex", C.c_int,
+     [_H, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_U64),
+      C.POINTER(_U64)]),
+    ("spmx_unk_piece", C.c_int64, [_H, C.c_char_p, _U64]),
     ("spmx_free", None, [C.c_void_p]),
     ("spmx_encode", C.c_int, [_H, C.c_char_p, _U64, C.c_void_p, _U64, C.POINTER(_U64)]),
     ("spmx_decode_batch_device", C.c_int,

@@ -1,22 +1,28 @@
 // libspmx.so: the C ABI of include/spmx.h over the HIP kernels of kernels.hip.
 //
-// One handle = one loaded model on one GPU: the compiled tables live in HBM for
-// the life of the handle, a grow-only workspace (class lists, id arena, scan
-// scratch) is reused from call to call, and one encode call is a fixed
-// sequence of launches on the caller's stream with a single small read-back at
-// the end:
+// One handle = one loaded model on one GPU: the compiled tables live in HBM for the life of the handle.  Every call
+// leases a WORKSPACE from the handle's pool (grow-only device buffers: class lists, id arena, scan scratch, host
+// staging; a control block mirrored in pinned host memory; a stream of its own for the host-buffer forms), so calls
+// from several host threads run concurrently, as SentencePieceProcessor's const methods do.  One encode call is a
+// fixed sequence of launches on one stream with two small read-backs:
 //
-//   memset ctrl -> classify -> encode[class 0..k) -> scan x3 -> compact -> D2H {ctrl, total}
+//   memset ctrl -> classify -> D2H class sizes -> streaming launch(es) -> scan x3 -> compact -> D2H {ctrl, total}
 //
-// There is no CPU path: without a usable HIP device spmx_create fails with
-// UNAVAILABLE.
+// and, only when the fast kernels set sentences aside (a normalized form that overflows its class's column, a BPE word
+// longer than the lane form's slots ...): an overflow launch with exact capacities / the long form, then scan and
+// compact again.  No sentence fails for its length; a sentence that does fail (a control piece among BPE symbols)
+// yields no ids and a status byte, and the rest of the batch is unaffected.
+//
+// There is no CPU path: without a usable HIP device spmx_create fails with UNAVAILABLE.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <memory>
 #include <mutex>
+#include <new>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -32,22 +38,25 @@ namespace {
 
 constexpr uint32_t kLdsPerCu = 160u * 1024u;   // gfx950 (MI355X_MICROARCH.md)
 
-std::mutex g_err_mu;
-std::string g_create_error;
+thread_local std::string t_error;              // text of the calling thread's last failing call
+
+// kernel slots of the per-call profile
+enum { kSlotMain = 0, kSlotDoc = 1, kSlotExact = 2, kSlotWave = 3, kSlotLong = 4, kNumSlots = 5 };
 
 // ctrl block layout (device + pinned host mirror), zeroed before every call
 struct Ctrl {
   uint32_t list_counts[kMaxClasses];
-  uint32_t hard_counts[kMaxClasses];   // sentences a FAST kernel left to the GENERAL kernel of its class
-  uint32_t wave_counts[kMaxClasses];
-  uint32_t key_totals[kSortKeys], key_cursor[kSortKeys];   // classify: counting sort by (class, length sub-bucket)   // BPE: sentences the streaming kernels left to the sentence-per-wave kernel
+  uint32_t key_totals[kSortKeys], key_cursor[kSortKeys];   // classify: counting sort by (class, length sub-bucket)
   uint32_t status;
+  uint32_t retry_count[2];            // long form: sentences that found the pool exhausted (ping-pong)
   uint32_t pad;
-  uint32_t tile_cursor[2 * kMaxClasses];   // per kernel slot: the streaming kernels' tile queue
+  StreamQueue q[3];                   // tile queues of the main / document / overflow launches
+  SideLists side;
   unsigned long long arena_head;
-  unsigned long long stats[kStatsPerClass * 2 * kMaxClasses];   // per kernel slot (see Profile)
-  unsigned long long bad_key;   // decode: min over offending (sentence << 32 | id)
-  uint64_t total_ids;   // copied from id_offs[n] by the final D2H
+  unsigned long long pool_head;       // long form: bytes of slices asked for
+  unsigned long long stats[kStatsPerClass * kNumSlots];
+  unsigned long long bad_key;         // decode: min over offending (sentence << 32 | id)
+  uint64_t total_ids;                 // copied from id_offs[n] by the final D2H
 };
 
 template <typename T>
@@ -66,32 +75,76 @@ struct DevBuf {
   void Free() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-// One entry per kernel slot: slot c < kMaxClasses is length class c's encode kernel (the FAST kernel where one
-// runs); slot kSlotGeneral + c is the GENERAL kernel that follows a FAST kernel of class c.
-constexpr int kSlotGeneral = kMaxClasses;
-constexpr int kMaxSlots = 2 * kMaxClasses;
+// pinned host staging (host-buffer forms)
+template <typename T>
+struct PinBuf {
+  T *p = nullptr;
+  size_t cap = 0;
+  hipError_t Reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    const size_t want = n + n / 4 + 64;
+    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&p), want * sizeof(T), hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+    cap = want;
+    return hipSuccess;
+  }
+  void Free() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 struct Profile {
   int n = 0;
-  char name[kMaxSlots][40] = {{0}};
-  float kernel_ms[kMaxSlots] = {0};
-  uint64_t sentences[kMaxSlots] = {0}, raw_bytes[kMaxSlots] = {0}, ids[kMaxSlots] = {0};
-  uint32_t rcap[kMaxSlots] = {0};
-  uint64_t cycles[kMaxSlots][5] = {{0}};
+  char name[kNumSlots][48] = {{0}};
+  float kernel_ms[kNumSlots] = {0};
+  uint64_t sentences[kNumSlots] = {0}, raw_bytes[kNumSlots] = {0}, ids[kNumSlots] = {0};
+  uint64_t cycles[kNumSlots][5] = {{0}};
+  uint64_t path[8] = {0};     // {hard-list sentences, overflow-list sentences, long-form sentences, failed sentences}
   float total_ms = 0.f;
+};
+
+// Everything one call needs besides the model: leased from the handle's pool for the duration of the call.
+struct Workspace {
+  DevBuf<uint32_t> d_lists, d_counts;
+  DevBuf<uint64_t> d_tmp_off, d_tile_sums, d_chunk_base;
+  DevBuf<int32_t> d_arena, d_arena_tb, d_tok_begin;
+  DevBuf<uint32_t> d_span_begin, d_span_end, d_nspan_begin, d_nspan_end;
+  DevBuf<uint8_t> d_norm, d_nbest_scratch, d_slab, d_pool, d_sent_status;
+  DevBuf<unsigned long long> d_res_off;
+  DevBuf<float> d_res_score;
+  Ctrl *d_ctrl = nullptr;
+  Ctrl *h_ctrl = nullptr;   // pinned
+  // host-buffer forms
+  DevBuf<uint8_t> d_text;
+  DevBuf<uint64_t> d_offs, d_id_offs;
+  DevBuf<int32_t> d_ids;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[kNumSlots + 1][2] = {};   // per kernel slot + the whole call
+  bool ev_ready = false;
+  bool slot_used[kNumSlots] = {false};
+  char slot_name[kNumSlots][48] = {{0}};
+  Profile prof;
+
+  ~Workspace() {
+    d_lists.Free(); d_counts.Free(); d_tmp_off.Free(); d_tile_sums.Free(); d_chunk_base.Free(); d_arena.Free();
+    d_arena_tb.Free(); d_tok_begin.Free(); d_span_begin.Free(); d_span_end.Free(); d_nspan_begin.Free(); d_nspan_end.Free();
+    d_norm.Free(); d_nbest_scratch.Free(); d_slab.Free(); d_pool.Free(); d_sent_status.Free(); d_res_off.Free();
+    d_res_score.Free(); d_text.Free(); d_offs.Free(); d_id_offs.Free(); d_ids.Free();
+    if (d_ctrl) (void)hipFree(d_ctrl);
+    if (h_ctrl) (void)hipHostFree(h_ctrl);
+    if (stream) (void)hipStreamDestroy(stream);
+    if (ev_ready) for (auto &pair : ev) { (void)hipEventDestroy(pair[0]); (void)hipEventDestroy(pair[1]); }
+  }
 };
 
 }  // namespace
 
 struct spmx_handle {
-  std::mutex mu;
-  std::string error;
+  std::mutex mu;                 // the workspace pool, the last profile
   ModelData model;
   HostTables tables;
   std::string extra_options;
   int device = 0;
   int n_cu = 256;
-  bool no_fast = false;   // SPMX_NO_FAST=1: GENERAL kernels only (A/B measurements)
-  int tile_waves_override = 0;   // SPMX_TILE_WAVES: cap on wavefronts per workgroup of the streaming kernels
   // device copies of the tables
   DevBuf<uint32_t> d_ndarts, d_npair, d_sym_final, d_dec_info, d_dec_off;
   DevBuf<uint8_t> d_dec_bytes;
@@ -101,45 +154,27 @@ struct spmx_handle {
   DevBuf<uint16_t> d_sym_len;
   DevBuf<int32_t> d_byte_ids;
   SpmxDev dev{};   // scalars + device pointers
-  // workspace
-  DevBuf<uint32_t> d_lists, d_counts;
-  DevBuf<uint64_t> d_tmp_off, d_tile_sums, d_chunk_base;
-  DevBuf<int32_t> d_arena_tb, d_tok_begin;      // spans form
-  DevBuf<uint32_t> d_span_begin, d_span_end, d_nspan_begin, d_nspan_end;
-  DevBuf<uint8_t> d_norm, d_bpe_long, d_nbest_scratch;
-  DevBuf<unsigned long long> d_res_off;
-  DevBuf<float> d_res_score;
-  DevBuf<int32_t> d_arena;
-  Ctrl *d_ctrl = nullptr;
-  Ctrl *h_ctrl = nullptr;   // pinned
-  // host-form staging
-  DevBuf<uint8_t> d_text;
-  DevBuf<uint64_t> d_offs, d_id_offs;
-  DevBuf<int32_t> d_ids;
-  // profiling
+  std::vector<std::unique_ptr<Workspace>> pool;   // idle workspaces
   bool profiling = false;
-  hipEvent_t ev[kMaxSlots + 1][2] = {};   // per kernel slot (see Profile) + the whole call
-  char slot_name[kMaxSlots][40] = {{0}};
-  bool slot_used[kMaxSlots] = {false};
-  bool no_lane_general = false;      // SPMX_NO_LANE_GENERAL=1: FAST kernels hand every non-ASCII sentence to GENERAL
-  uint32_t lane_general_max_raw = kLaneGeneralMaxRaw, lane_general_min_lanes = 0;   // SPMX_LANE_GENERAL_MAX_RAW / _MIN_LANES (0: per class)
-  bool tiles_ascending = false;      // SPMX_TILE_ORDER=asc
-  uint32_t sub_buckets = kSubBuckets;   // SPMX_SUB_BUCKETS: length sub-buckets per class in the classify sort (1..64)
-  bool static_tiles = false;         // SPMX_STATIC_TILES=1: fixed-stride tiles in the streaming kernels (A/B measurements)
-  bool no_merge_general = false;     // SPMX_NO_MERGE_GENERAL=1: a GENERAL launch per class (A/B measurements)
-  bool no_stream = false;            // SPMX_NO_STREAM=1: BPE in the sentence-per-wave form only (A/B measurements)
-  uint32_t ring_override = 0;        // SPMX_FORCE_RING: score-ring entries (A/B measurements; must exceed the longest piece)
-  uint64_t stream_scratch_limit = 4ull << 30;   // SPMX_STREAM_SCRATCH_MB: cap on the streaming kernels' HBM scratch
-  DevBuf<uint32_t> d_stream;         // scratch of the streaming kernels (text columns + back-pointer words)
-  bool ev_ready = false;
-  Profile prof;
+  Profile prof;                  // of the last profiled encode call
+  // A/B switches (environment, read once at load)
+  bool no_fast = false;          // SPMX_NO_FAST=1: every tile runs the general normalizer
+  bool no_lane_general = false;  // SPMX_NO_LANE_GENERAL=1: main tiles set every non-ASCII sentence aside
+  bool no_stream = false;        // SPMX_NO_STREAM=1: BPE in the sentence-per-wave form only
+  bool no_wave = false;          // SPMX_NO_WAVE=1: BPE models that are not word-wise use the long form only
+  int tile_waves_override = 0;   // SPMX_TILE_WAVES: cap on wavefronts per workgroup of the streaming kernels
+  uint32_t lane_general_min_lanes = 0;   // SPMX_LANE_GENERAL_MIN_LANES (0: per class)
+  uint32_t sub_buckets = kSubBuckets;    // SPMX_SUB_BUCKETS: length sub-buckets per class in the classify sort (1..64)
+  uint32_t ring_override = 0;    // SPMX_FORCE_RING: score-ring entries (must exceed the longest piece)
+  uint64_t stream_scratch_limit = 16ull << 30;   // SPMX_STREAM_SCRATCH_MB: cap on the streaming kernels' HBM scratch
+  uint32_t main_max_raw = kStreamMainMaxRaw;     // SPMX_MAIN_MAX_RAW: classes up to this size share the main launch
+  LengthClass classes[kNumClasses];              // SPMX_CLASSES="r:n,r:n,...": the class table (tests shrink it)
 };
 
 namespace {
 
-int Fail(spmx_handle *h, int code, const std::string &msg) {
-  if (h) h->error = msg;
-  else { std::lock_guard<std::mutex> l(g_err_mu); g_create_error = msg; }
+int Fail(spmx_handle *, int code, const std::string &msg) {
+  t_error = msg;
   return code;
 }
 int FailHip(spmx_handle *h, hipError_t e, const char *what) {
@@ -151,6 +186,31 @@ int FailHip(spmx_handle *h, hipError_t e, const char *what) {
     hipError_t e_ = (expr);                                      \
     if (e_ != hipSuccess) return FailHip((h), e_, #expr);        \
   } while (0)
+
+// RAII lease of a workspace
+struct Lease {
+  spmx_handle *h;
+  std::unique_ptr<Workspace> ws;
+  explicit Lease(spmx_handle *hh) : h(hh) {
+    std::lock_guard<std::mutex> l(h->mu);
+    if (!h->pool.empty()) { ws = std::move(h->pool.back()); h->pool.pop_back(); }
+  }
+  // creates the workspace's fixed parts on first use; the device must be current
+  int Ready() {
+    if (ws) return kOk;
+    ws.reset(new (std::nothrow) Workspace);
+    if (!ws) return Fail(h, kResourceExhausted, "out of host memory");
+    HIP_OR_RETURN(h, hipMalloc(reinterpret_cast<void **>(&ws->d_ctrl), sizeof(Ctrl)));
+    HIP_OR_RETURN(h, hipHostMalloc(reinterpret_cast<void **>(&ws->h_ctrl), sizeof(Ctrl), hipHostMallocDefault));
+    HIP_OR_RETURN(h, hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
+    return kOk;
+  }
+  ~Lease() {
+    if (!ws) return;
+    std::lock_guard<std::mutex> l(h->mu);
+    h->pool.push_back(std::move(ws));
+  }
+};
 
 template <typename T>
 hipError_t Upload(DevBuf<T> *b, const std::vector<T> &v) {
@@ -193,19 +253,22 @@ int UploadTables(spmx_handle *h) {
   return kOk;
 }
 
-// After SetVocabulary / ResetVocabulary / SetEncodeExtraOptions: only the
-// type-dependent words and the scalars change.
+// After SetVocabulary / ResetVocabulary / SetEncodeExtraOptions: only the type-dependent words and the scalars
+// change (the decode tables follow the piece types too: a BYTE piece turned UNUSED decodes as its literal text).
 int RefreshDevice(spmx_handle *h, bool types_changed) {
   HostTables &t = h->tables;
   if (types_changed) {
     if (h->model.model_type == kUnigram) HIP_OR_RETURN(h, Upload(&h->d_ptrie, t.ptrie));
     else HIP_OR_RETURN(h, Upload(&h->d_sym_final, t.sym_final));
+    HIP_OR_RETURN(h, Upload(&h->d_dec_info, t.dec_info));
+    HIP_OR_RETURN(h, Upload(&h->d_dec_off, t.dec_off));
+    HIP_OR_RETURN(h, Upload(&h->d_dec_bytes, t.dec_bytes));
   }
   SpmxDev d = t.scalars;
   d.ndarts = h->dev.ndarts; d.nblob = h->dev.nblob; d.npair = h->dev.npair; d.ptrie = h->d_ptrie.p; d.utrie = h->dev.utrie;
   d.chartab = h->dev.chartab; d.pairtab = h->dev.pairtab; d.sym_final = h->d_sym_final.p;
   d.sym_len = h->dev.sym_len; d.byte_ids = h->dev.byte_ids;
-  d.dec_info = h->dev.dec_info; d.dec_off = h->dev.dec_off; d.dec_bytes = h->dev.dec_bytes;
+  d.dec_info = h->d_dec_info.p; d.dec_off = h->d_dec_off.p; d.dec_bytes = h->d_dec_bytes.p;
   h->dev = d;
   return kOk;
 }
@@ -216,17 +279,9 @@ void DestroyHandle(spmx_handle *h) {
   h->d_ndarts.Free(); h->d_npair.Free(); h->d_sym_final.Free(); h->d_nblob.Free(); h->d_ptrie.Free(); h->d_chartab.Free();
   h->d_pairtab.Free(); h->d_utrie.Free(); h->d_sym_len.Free(); h->d_byte_ids.Free();
   h->d_dec_info.Free(); h->d_dec_off.Free(); h->d_dec_bytes.Free();
-  h->d_stream.Free(); h->d_lists.Free(); h->d_counts.Free(); h->d_tmp_off.Free(); h->d_tile_sums.Free(); h->d_chunk_base.Free(); h->d_arena_tb.Free(); h->d_tok_begin.Free(); h->d_span_begin.Free(); h->d_span_end.Free(); h->d_nspan_begin.Free(); h->d_nspan_end.Free(); h->d_norm.Free(); h->d_bpe_long.Free(); h->d_nbest_scratch.Free(); h->d_res_off.Free(); h->d_res_score.Free(); h->d_arena.Free();
-  h->d_text.Free(); h->d_offs.Free(); h->d_id_offs.Free(); h->d_ids.Free();
-  if (h->d_ctrl) (void)hipFree(h->d_ctrl);
-  if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);
-  if (h->ev_ready)
-    for (auto &pair : h->ev) { (void)hipEventDestroy(pair[0]); (void)hipEventDestroy(pair[1]); }
+  h->pool.clear();
   delete h;
 }
-
-int NumClasses(const spmx_handle *h) { return h->model.model_type == kBpe ? kNumClassesBpe : kNumClassesUnigram; }
-const LengthClass *Classes(const spmx_handle *h) { return h->model.model_type == kBpe ? kClassesBpe : kClassesUnigram; }
 
 // score-ring entries of the streaming unigram kernels for this handle's model
 uint32_t HandleRing(const spmx_handle *h) {
@@ -234,49 +289,131 @@ uint32_t HandleRing(const spmx_handle *h) {
   return h->ring_override > r ? h->ring_override : r;
 }
 
-// Launch shape of one streaming kernel (kernels_stream.h) on a class list of `known` sentences: as many
-// wavefronts per workgroup as the LDS of a CU holds (one workgroup per CU), fewer workgroups when the list is
-// short (at least one sentence per wave) or when the HBM scratch would pass the handle's limit.
+hipError_t EnsureEvents(Workspace *ws) {
+  if (ws->ev_ready) return hipSuccess;
+  for (auto &pair : ws->ev) {
+    hipError_t e = hipEventCreate(&pair[0]);
+    if (e == hipSuccess) e = hipEventCreate(&pair[1]);
+    if (e != hipSuccess) return e;
+  }
+  ws->ev_ready = true;
+  return hipSuccess;
+}
+
+int RunClassify(spmx_handle *h, Workspace *ws, const uint64_t *d_offsets, uint32_t n32, hipStream_t stream) {
+  ClassifyArgs ca{};
+  ca.offs = d_offsets; ca.n = n32; ca.n_classes = static_cast<uint32_t>(kNumClasses);
+  for (int c = 0; c < kNumClasses; ++c) ca.rcap[c] = h->classes[c].rcap;
+  ca.lists = ws->d_lists.p; ca.list_counts = ws->d_ctrl->list_counts;
+  ca.key_totals = ws->d_ctrl->key_totals; ca.key_cursor = ws->d_ctrl->key_cursor;
+  ca.sub_buckets = h->sub_buckets;
+  const uint32_t chunks = (n32 + 64 * kClassifyChunk - 1) / (64 * kClassifyChunk);
+  const uint32_t wide = static_cast<uint32_t>(h->n_cu) * 8u;
+  HIP_OR_RETURN(h, LaunchClassify(ca, static_cast<int>(chunks < wide ? chunks : wide), stream));
+  return kOk;
+}
+
+// ---- planning of one streaming launch ---------------------------------------------------------------------------
 struct StreamPlan {
-  int grid = 1, waves = 1;
-  uint32_t lds = 0, tcap = 0;
-  uint64_t text_words = 0, scratch_words = 0;
+  int grid = 0, waves = 1;
+  uint32_t lds = 0;
+  uint64_t slab_bytes = 0;       // per wavefront
+  uint32_t open = 0;             // non-empty classes
 };
-StreamPlan PlanStream(const spmx_handle *h, const LengthClass &lc, bool fast, uint64_t known) {
-  const int model = h->model.model_type;
+
+// Fills a->cls / n_classes / total_main / ring / slab_bytes for the classes [c_lo, c_hi) whose sizes are `counts`
+// (classes outside the range get no tiles); tcap_of(c) gives a class's text-column capacity.
+template <typename TcapFn>
+StreamPlan PlanStream(const spmx_handle *h, EncodeArgs *a, const uint32_t *counts, int c_lo, int c_hi, int n_classes,
+                      const uint32_t *rcaps, TcapFn tcap_of, bool all_general) {
   StreamPlan sp;
+  const int model = h->model.model_type;
   const uint32_t ring = HandleRing(h);
-  // a FAST text column never exceeds raw length + 1 (one-byte space symbol); GENERAL: the class's normalized capacity
-  sp.tcap = fast ? (lc.rcap > kMaxStagedRaw ? lc.ncap : lc.rcap + 1) : lc.ncap;
-  const uint32_t priv = StreamPrivateBytes(fast, model, lc.rcap, lc.ncap, ring);
+  a->ring = ring;
+  const uint32_t priv = StreamPrivateBytes(model, ring);
   int waves = static_cast<int>((kLdsPerCu - kStreamSharedBytes) / priv);
-  const int wmax = fast ? 16 : 8;   // __launch_bounds__ of the two kernels
-  if (waves > wmax) waves = wmax;
+  if (waves > 16) waves = 16;            // __launch_bounds__(1024)
   if (waves < 1) waves = 1;
   if (h->tile_waves_override > 0 && h->tile_waves_override < waves) waves = h->tile_waves_override;
+  uint64_t total = 0;
+  for (int c = c_lo; c < c_hi; ++c) total += counts[c];
   uint64_t grid = static_cast<uint64_t>(h->n_cu);
-  if (grid * waves > known) grid = (known + waves - 1) / waves;
+  if (grid * waves > total) grid = (total + waves - 1) / waves;
   if (grid < 1) grid = 1;
-  const uint64_t per_wave = StreamTextDwords(sp.tcap, ring) + StreamBpWords(sp.tcap);
-  const uint64_t max_waves = h->stream_scratch_limit / (per_wave * 4);
-  if (grid * waves > max_waves) grid = max_waves / waves;
-  if (grid < 1) grid = 1;
+  // the slab of a wavefront must hold one lane of the largest class present: fewer wavefronts if the limit says so
+  uint64_t need1 = 0;
+  for (int c = c_lo; c < c_hi; ++c)
+    if (counts[c]) { const uint64_t b = StreamSlabBytes(tcap_of(c), ring, 0); if (b > need1) need1 = b; }
+  if (need1 && grid * waves * need1 > h->stream_scratch_limit) {
+    uint64_t w = h->stream_scratch_limit / need1;
+    if (w < 1) w = 1;
+    if (w < static_cast<uint64_t>(waves)) { waves = static_cast<int>(w); grid = 1; }
+    else grid = w / waves;
+  }
+  uint64_t n_waves = grid * waves;
+  // no more wavefronts than tiles: a first pass at full tiles tells how many there can be
+  {
+    uint64_t tiles = 0;
+    for (int c = c_lo; c < c_hi; ++c) {
+      if (!counts[c]) continue;
+      uint64_t tw = (static_cast<uint64_t>(counts[c]) + n_waves - 1) / n_waves;
+      if (tw > 64) tw = 64;
+      tiles += (static_cast<uint64_t>(counts[c]) + tw - 1) / tw;
+    }
+    if (tiles < n_waves) {
+      if (grid > 1) { grid = (tiles + waves - 1) / waves; if (grid < 1) grid = 1; }
+      if (grid == 1 && tiles < static_cast<uint64_t>(waves)) waves = static_cast<int>(tiles < 1 ? 1 : tiles);
+      n_waves = grid * waves;
+    }
+  }
+  const uint64_t budget = h->stream_scratch_limit / n_waves;
+  a->n_classes = static_cast<uint32_t>(n_classes);
+  uint32_t tile_base = 0;
+  for (int c = n_classes - 1; c >= 0; --c) {          // tiles are handed out longest class first
+    StreamClass &sc = a->cls[c];
+    sc = StreamClass{};
+    sc.rcap = rcaps[c];
+    if (c < c_lo || c >= c_hi || counts[c] == 0) continue;
+    sc.tcap = tcap_of(c);
+    uint64_t tw = (static_cast<uint64_t>(counts[c]) + n_waves - 1) / n_waves;   // sentences per main tile
+    if (tw > 64) tw = 64;
+    if (tw < 1) tw = 1;
+    uint32_t sh = 0;                                   // lanes of a tile: enough for tw, as many as the budget allows
+    while ((1ull << sh) < tw) ++sh;
+    while (sh > 0 && StreamSlabBytes(sc.tcap, ring, sh) > budget) --sh;
+    if (tw > (1ull << sh)) tw = 1ull << sh;
+    sc.lane_shift = sh;
+    const uint64_t slab = StreamSlabBytes(sc.tcap, ring, sh);
+    if (slab > sp.slab_bytes) sp.slab_bytes = slab;
+    sc.count = counts[c];
+    sc.tw = static_cast<uint32_t>(tw);
+    sc.main_tiles = static_cast<uint32_t>((static_cast<uint64_t>(counts[c]) + tw - 1) / tw);
+    sc.tile_base = tile_base;
+    tile_base += sc.main_tiles;
+    sc.general = all_general ? 1u : 0u;
+    // short classes: a stray non-ASCII sentence would hold 63 ASCII lanes up, so a tile needs 16 of them to keep
+    // them; longer classes: 4; tiles of a few lanes keep everything
+    sc.min_lanes = h->lane_general_min_lanes ? h->lane_general_min_lanes : (sh < 6 ? 0u : (sc.rcap <= 576 ? 16u : 4u));
+    ++sp.open;
+  }
+  a->total_main = tile_base;
+  sp.slab_bytes = (sp.slab_bytes + 255u) & ~static_cast<uint64_t>(255);
+  a->slab_bytes = sp.slab_bytes;
   sp.grid = static_cast<int>(grid);
   sp.waves = waves;
-  sp.lds = StreamLdsBytes(fast, model, lc.rcap, lc.ncap, ring, static_cast<uint32_t>(waves));
-  sp.text_words = grid * waves * StreamTextDwords(sp.tcap, ring);
-  sp.scratch_words = grid * waves * per_wave;
+  sp.lds = StreamLdsBytes(model, ring, static_cast<uint32_t>(waves));
   return sp;
 }
 
-// The launch sequence.  Caller holds h->mu and has set the device.
-// d_begin / d_end (both or neither): the spans form (kernels_align.h).
-int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, const uint64_t *d_offsets, uint64_t n,
-                 int32_t *d_ids, uint64_t ids_capacity, uint64_t *d_id_offsets, hipStream_t stream,
-                 uint64_t *total_ids, uint32_t *d_begin = nullptr, uint32_t *d_end = nullptr,
-                 uint32_t *d_nbegin = nullptr, uint32_t *d_nend = nullptr) {
+// ---- the encode launch sequence ----------------------------------------------------------------------------------
+// d_begin / d_end (both or neither): the spans form (kernels_align.h).  d_status (optional): n status bytes.
+int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t text_bytes, const uint64_t *d_offsets,
+                 uint64_t n, int32_t *d_ids, uint64_t ids_capacity, uint64_t *d_id_offsets, uint8_t *d_status,
+                 hipStream_t stream, uint64_t *total_ids, uint64_t *n_failed, uint32_t *d_begin = nullptr,
+                 uint32_t *d_end = nullptr, uint32_t *d_nbegin = nullptr, uint32_t *d_nend = nullptr) {
   const bool spans = d_begin != nullptr && d_end != nullptr;
   if (total_ids) *total_ids = 0;
+  if (n_failed) *n_failed = 0;
   if (n >= (1ull << 32) - 64) return Fail(h, kInvalidArgument, "more than 2^32 - 64 sentences in one batch");
   if (!d_offsets || !d_id_offsets) return Fail(h, kInvalidArgument, "null offsets");
   if (n == 0) {
@@ -284,284 +421,309 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
     HIP_OR_RETURN(h, hipStreamSynchronize(stream));
     return kOk;
   }
-  const int ncls = NumClasses(h);
-  const LengthClass *cls = Classes(h);
-  HIP_OR_RETURN(h, h->d_lists.Reserve(static_cast<size_t>(3 * ncls) * n));   // class lists + two hand-over lists each
-  HIP_OR_RETURN(h, h->d_counts.Reserve(n + 1));
-  HIP_OR_RETURN(h, h->d_tmp_off.Reserve(n + 1));
-  HIP_OR_RETURN(h, h->d_tile_sums.Reserve((n + kScanTile - 1) / kScanTile + 2));
+  const LengthClass *cls = h->classes;
+  const int ncls = kNumClasses;
+  // lists: kMaxClasses class lists (the last one is the overflow list), kMaxClasses hard lists, the long list, two retry lists
+  HIP_OR_RETURN(h, ws->d_lists.Reserve(static_cast<size_t>(2 * kMaxClasses + 3) * n));
+  HIP_OR_RETURN(h, ws->d_counts.Reserve(n + 1));
+  HIP_OR_RETURN(h, ws->d_tmp_off.Reserve(n + 1));
+  HIP_OR_RETURN(h, ws->d_tile_sums.Reserve((n + kScanTile - 1) / kScanTile + 2));
+  if (!d_status) { HIP_OR_RETURN(h, ws->d_sent_status.Reserve(n)); d_status = ws->d_sent_status.p; }
+  uint32_t *const class_lists = ws->d_lists.p;
+  uint32_t *const over_list = class_lists + static_cast<size_t>(kMaxClasses - 1) * n;
+  uint32_t *const hard_lists = class_lists + static_cast<size_t>(kMaxClasses) * n;
+  uint32_t *const long_list = class_lists + static_cast<size_t>(2 * kMaxClasses) * n;
+  uint32_t *const retry_lists[2] = {long_list + n, long_list + 2 * n};
   // ids are at most one per normalized byte; the streaming kernels reserve a sentence's slot by that bound
   uint64_t expand = (h->dev.flags & kNfCompressSp) || !(h->dev.flags & kNfEscapeWs) ? 1 : 3;
   if ((h->dev.flags & kNfCompressSp) && (h->dev.flags & kNfByteFallback)) expand = 2;   // slots: bytes + 2 per space symbol
   uint64_t arena_need = expand * text_bytes + (4 + static_cast<uint64_t>(h->dev.n_prefix + h->dev.n_suffix)) * n + 64;
-  if (h->profiling && !h->ev_ready) {
-    for (auto &pair : h->ev) {
-      HIP_OR_RETURN(h, hipEventCreate(&pair[0]));
-      HIP_OR_RETURN(h, hipEventCreate(&pair[1]));
-    }
-    h->ev_ready = true;
-  }
   const bool prof = h->profiling;
+  if (prof) HIP_OR_RETURN(h, EnsureEvents(ws));
+  const uint32_t n32 = static_cast<uint32_t>(n);
+  const int wide = h->n_cu * 8;
+  const bool is_bpe = h->model.model_type == kBpe;
+  // streaming (lane-per-sentence) kernels: every unigram model; BPE models that can be segmented word by word
+  const bool bpe_stream = is_bpe && (h->dev.flags & kNfBpeWordwise) && !(h->dev.flags & kNfHasUnused) && !h->no_stream;
+  const bool streaming = !is_bpe || bpe_stream;
+  const bool fast_ok = StreamFastEligible(h->dev.flags) && !h->no_fast;
+  const bool uds = (h->dev.flags & kNfHasUserDefined) != 0;
+  uint32_t rcaps[kMaxClasses] = {0};
+  for (int c = 0; c < ncls; ++c) rcaps[c] = cls[c].rcap;
+  rcaps[ncls - 1] = cls[ncls - 1].rcap;
+  // the largest raw sentence any launch can take: its normalized form must stay below 2^31 bytes
+  const uint64_t max_raw = (0x7FFFFF00ull - 16) / h->dev.expand_max;
+  auto record = [&](int slot, int which) -> hipError_t {
+    return prof ? hipEventRecord(ws->ev[slot][which], stream) : hipSuccess;
+  };
+  auto scan_compact = [&]() -> int {
+    ScanArgs sa{ws->d_counts.p, n32, ws->d_tile_sums.p, d_id_offsets};
+    const uint32_t tiles = (n32 + kScanTile - 1) / kScanTile;
+    HIP_OR_RETURN(h, LaunchScan(sa, static_cast<int>(tiles < static_cast<uint32_t>(wide) ? tiles : wide), stream));
+    CompactArgs pa{ws->d_arena.p, ws->d_tmp_off.p, ws->d_counts.p, d_id_offsets, d_ids, d_ids ? ids_capacity : 0, n32};
+    const uint64_t cblocks = (n + 63) / 64;
+    const uint64_t cgrid = cblocks < static_cast<uint64_t>(h->n_cu) * 32 ? cblocks : static_cast<uint64_t>(h->n_cu) * 32;
+    HIP_OR_RETURN(h, LaunchCompact(pa, static_cast<int>(cgrid), stream));
+    HIP_OR_RETURN(h, hipMemcpyAsync(ws->h_ctrl, ws->d_ctrl, offsetof(Ctrl, total_ids), hipMemcpyDeviceToHost, stream));
+    HIP_OR_RETURN(h, hipMemcpyAsync(&ws->h_ctrl->total_ids, d_id_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+    return kOk;
+  };
   for (int attempt = 0; attempt < 3; ++attempt) {
-    HIP_OR_RETURN(h, h->d_arena.Reserve(arena_need));
-    if (spans) HIP_OR_RETURN(h, h->d_arena_tb.Reserve(h->d_arena.cap));
-    if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[kMaxSlots][0], stream));
-    HIP_OR_RETURN(h, hipMemsetAsync(h->d_ctrl, 0, sizeof(Ctrl), stream));
-    for (bool &u : h->slot_used) u = false;
-    const uint32_t n32 = static_cast<uint32_t>(n);
-    const int wide = h->n_cu * 8;
-    {
-      ClassifyArgs ca{};
-      ca.offs = d_offsets; ca.n = n32; ca.n_classes = static_cast<uint32_t>(ncls);
-      for (int c = 0; c < ncls; ++c) ca.rcap[c] = cls[c].rcap;
-      ca.lists = h->d_lists.p; ca.list_counts = h->d_ctrl->list_counts;
-      ca.key_totals = h->d_ctrl->key_totals; ca.key_cursor = h->d_ctrl->key_cursor;
-      ca.sub_buckets = h->sub_buckets;
-      const uint32_t chunks = (n32 + 64 * kClassifyChunk - 1) / (64 * kClassifyChunk);
-      HIP_OR_RETURN(h, LaunchClassify(ca, static_cast<int>(chunks < static_cast<uint32_t>(wide) ? chunks : wide), stream));
-    }
-    // streaming (lane-per-sentence) kernels: every unigram model; BPE models that can be segmented word by word
-    const bool bpe_stream = h->model.model_type == kBpe && (h->dev.flags & kNfBpeWordwise) && !(h->dev.flags & kNfHasUnused);
-    const bool streaming = h->model.model_type == kUnigram || (bpe_stream && !h->no_stream);
-    uint32_t known[kMaxClasses] = {0};   // class sizes after classify (escalations from a GENERAL kernel come on top)
-    // The GENERAL kernel of a class is latency-bound (a few thousand leftover sentences, one serial recurrence each:
-    // 0.7 ms for class 0 of the C2 bench whatever the count), so the two short classes share one: class 0's FAST
-    // kernel appends to the same hand-over list as class 1's and the GENERAL launch of class 1 (whose capacities
-    // cover both) takes them all.
-    const bool merge01 = streaming && StreamFastEligible(h->dev.flags) && !h->no_fast && !h->no_merge_general && ncls >= 2 &&
-                         cls[1].rcap <= kMaxStagedRaw;
-    HIP_OR_RETURN(h, hipMemcpyAsync(h->h_ctrl->list_counts, h->d_ctrl->list_counts, sizeof(h->h_ctrl->list_counts),
+    HIP_OR_RETURN(h, ws->d_arena.Reserve(arena_need));
+    if (spans) HIP_OR_RETURN(h, ws->d_arena_tb.Reserve(ws->d_arena.cap));
+    if (prof) HIP_OR_RETURN(h, hipEventRecord(ws->ev[kNumSlots][0], stream));
+    HIP_OR_RETURN(h, hipMemsetAsync(ws->d_ctrl, 0, sizeof(Ctrl), stream));
+    HIP_OR_RETURN(h, hipMemsetAsync(d_status, 0, n, stream));
+    for (bool &u : ws->slot_used) u = false;
+    if (int rc = RunClassify(h, ws, d_offsets, n32, stream); rc != kOk) return rc;
+    HIP_OR_RETURN(h, hipMemcpyAsync(ws->h_ctrl->list_counts, ws->d_ctrl->list_counts, sizeof(ws->h_ctrl->list_counts),
                                     hipMemcpyDeviceToHost, stream));
     HIP_OR_RETURN(h, hipStreamSynchronize(stream));
-    for (int c = 0; c < ncls; ++c) known[c] = h->h_ctrl->list_counts[c];
-    if (!streaming)      // the sentence-per-wave kernels stage a whole sentence in LDS
-      for (int c = 0; c < ncls; ++c)
-        if (cls[c].rcap > kMaxStagedRaw && known[c] > 0)
-          return Fail(h, kOutOfRange, "a sentence is longer than 4096 bytes: this BPE model (not segmentable word by word, or with "
-                                      "unused pieces) is limited to that on the device path");
+    uint32_t known[kMaxClasses] = {0};
+    for (int c = 0; c < ncls; ++c) known[c] = ws->h_ctrl->list_counts[c];
+    // what every encode launch shares
+    EncodeArgs a{};
+    a.dev = h->dev; a.text = d_text; a.offs = d_offsets;
+    a.arena = ws->d_arena.p; a.arena_head = &ws->d_ctrl->arena_head; a.arena_cap = ws->d_arena.cap;
+    a.tmp_off = ws->d_tmp_off.p; a.counts = ws->d_counts.p; a.sent_status = d_status; a.status = &ws->d_ctrl->status;
+    a.arena_tb = spans ? ws->d_arena_tb.p : nullptr;
+    a.long_list = long_list; a.side = &ws->d_ctrl->side;
+    a.lists = class_lists; a.hard_lists = hard_lists; a.over_list = over_list;
+    a.n = n32;
+    a.fast_ok = fast_ok ? 1u : 0u;
+    a.no_lane_general = h->no_lane_general ? 1u : 0u;
+    // one streaming launch over the classes [c_lo, c_hi) (or, exact: over the overflow list with exact capacities)
+    auto stream_launch = [&](int slot, int qi, int c_lo, int c_hi, const uint32_t *counts, bool exact, uint64_t exact_raw) -> int {
+      EncodeArgs la = a;
+      uint32_t rc2[kMaxClasses];
+      for (int c = 0; c < kMaxClasses; ++c) rc2[c] = rcaps[c];
+      const bool esc3 = (h->dev.flags & kNfEscapeWs) && !(h->dev.flags & kNfCompressSp);
+      StreamPlan sp;
+      if (exact) {
+        rc2[kMaxClasses - 1] = static_cast<uint32_t>(exact_raw < max_raw ? exact_raw : max_raw);
+        const uint32_t tc = static_cast<uint32_t>(static_cast<uint64_t>(rc2[kMaxClasses - 1]) * h->dev.expand_max + 16);
+        sp = PlanStream(h, &la, counts, kMaxClasses - 1, kMaxClasses, kMaxClasses, rc2, [&](int) { return tc; }, true);
+        la.over_list = nullptr;
+      } else {
+        // the last class of the table takes every longer sentence too: those go straight to the overflow list
+        sp = PlanStream(h, &la, counts, c_lo, c_hi, ncls, rc2,
+                        [&](int c) { return esc3 ? 2u * cls[c].rcap + 64u : cls[c].ncap; }, !fast_ok);
+      }
+      if (la.total_main == 0) return kOk;
+      la.n_open = sp.open;
+      la.q = &ws->d_ctrl->q[qi];
+      la.stats = &ws->d_ctrl->stats[kStatsPerClass * slot];
+      const uint64_t slab_total = static_cast<uint64_t>(sp.grid) * sp.waves * sp.slab_bytes;
+      HIP_OR_RETURN(h, ws->d_slab.Reserve(slab_total));
+      la.slab = ws->d_slab.p;
+      snprintf(ws->slot_name[slot], sizeof(ws->slot_name[slot]), "%s", is_bpe ? "EncodeBpeStreamKernel"
+               : (la.ring == 16 ? (uds ? "EncodeStreamKernel<16, true>" : "EncodeStreamKernel<16, false>")
+                                : (uds ? "EncodeStreamKernel<0, true>" : "EncodeStreamKernel<0, false>")));
+      HIP_OR_RETURN(h, record(slot, 0));
+      HIP_OR_RETURN(h, LaunchEncodeStream(h->model.model_type, uds, la, sp.grid, sp.waves, sp.lds, stream));
+      HIP_OR_RETURN(h, record(slot, 1));
+      ws->slot_used[slot] = true;
+      return kOk;
+    };
+    // the long form over one device-side list (BPE), growing the slice pool until every sentence has had its turn
+    auto long_launch = [&](const uint32_t *list, const uint32_t *d_count, uint32_t count) -> int {
+      if (count == 0) return kOk;
+      LongArgs la{};
+      la.dev = h->dev; la.text = d_text; la.offs = d_offsets;
+      la.arena = ws->d_arena.p; la.arena_head = &ws->d_ctrl->arena_head; la.arena_cap = ws->d_arena.cap;
+      la.tmp_off = ws->d_tmp_off.p; la.counts = ws->d_counts.p; la.sent_status = d_status; la.status = &ws->d_ctrl->status;
+      la.side = &ws->d_ctrl->side; la.arena_tb = spans ? ws->d_arena_tb.p : nullptr;
+      la.stack_cap = static_cast<uint32_t>(h->tables.max_piece_len) + 8u;
+      la.pool_head = &ws->d_ctrl->pool_head;
+      uint64_t want = 96ull * text_bytes / (n > count ? n / count : 1) + 4096ull * count + (1ull << 20);
+      if (want > (4ull << 30)) want = 4ull << 30;
+      int turn = 0;
+      uint32_t left = count;
+      for (int round = 0; round < 40 && left > 0; ++round) {
+        HIP_OR_RETURN(h, ws->d_pool.Reserve(want));
+        la.pool = ws->d_pool.p; la.pool_cap = ws->d_pool.cap;
+        la.list = list; la.list_count = d_count;
+        la.retry_list = retry_lists[turn]; la.retry_count = &ws->d_ctrl->retry_count[turn];
+        HIP_OR_RETURN(h, hipMemsetAsync(&ws->d_ctrl->pool_head, 0, sizeof(unsigned long long), stream));
+        HIP_OR_RETURN(h, hipMemsetAsync(&ws->d_ctrl->retry_count[turn], 0, sizeof(uint32_t), stream));
+        uint64_t g = (static_cast<uint64_t>(left) + 63) / 64;
+        if (g > static_cast<uint64_t>(h->n_cu) * 16) g = static_cast<uint64_t>(h->n_cu) * 16;
+        snprintf(ws->slot_name[kSlotLong], sizeof(ws->slot_name[kSlotLong]), "BpeLongKernel");
+        if (!ws->slot_used[kSlotLong]) HIP_OR_RETURN(h, record(kSlotLong, 0));
+        HIP_OR_RETURN(h, LaunchBpeLong(la, static_cast<int>(g), stream));
+        HIP_OR_RETURN(h, record(kSlotLong, 1));
+        ws->slot_used[kSlotLong] = true;
+        HIP_OR_RETURN(h, hipMemcpyAsync(&ws->h_ctrl->pool_head, &ws->d_ctrl->pool_head, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        HIP_OR_RETURN(h, hipMemcpyAsync(&ws->h_ctrl->retry_count[turn], &ws->d_ctrl->retry_count[turn], sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+        const uint32_t again = ws->h_ctrl->retry_count[turn];
+        if (again == 0) return kOk;
+        // the pool was too small for `again` sentences; pool_head is what all of this round's asked for
+        want = ws->h_ctrl->pool_head + (1ull << 20);
+        list = retry_lists[turn]; d_count = &ws->d_ctrl->retry_count[turn];
+        left = again;
+        turn ^= 1;
+      }
+      return left ? Fail(h, kResourceExhausted, "the long form's slice pool kept overflowing") : kOk;
+    };
     if (streaming) {
-      // one scratch buffer serves every launch of the call (they run one after another): size it for the largest
-      uint64_t need = 0;
-      bool prev_general = false;
-      for (int c = 0; c < ncls; ++c) {
-        const bool shared01 = merge01 && c == 1 && known[0] > 0;   // class 1's GENERAL launch also takes class 0's leftovers
-        if (known[c] == 0 && !prev_general && !shared01) continue;
-        const bool fast = StreamFastEligible(h->dev.flags) && !h->no_fast && known[c] > 0;
-        const bool staged = cls[c].rcap <= kMaxStagedRaw;   // document-length classes: FAST kernel only
-        if (!staged && known[c] > 0 && !fast)
-          return Fail(h, kOutOfRange, h->model.model_type == kBpe
-                          ? "a sentence is longer than 4096 bytes: this BPE model (user-defined symbols, whitespace-as-suffix or "
-                            "unescaped U+2581 rules) is limited to that on the device path"
-                          : "a sentence is longer than 8192 bytes: this model (user-defined symbols, whitespace-as-suffix "
-                            "or unescaped U+2581 rules) is limited to that on the device path");
-        if (!staged && known[c] > 0 && spans)
-          return Fail(h, kOutOfRange, "a sentence is longer than 8192 bytes: the spans form is limited to that");
-        if (!staged && !fast) continue;
-        const bool general = staged && !(merge01 && c == 0);
-        for (int pass = fast ? 0 : 1; pass < (general ? 2 : 1); ++pass) {
-          StreamPlan sp = PlanStream(h, cls[c], pass == 0, pass == 1 && shared01 ? known[0] + known[1] : known[c]);
-          if (sp.scratch_words > need) need = sp.scratch_words;
-        }
-        prev_general = general;
+      int c_doc = ncls;                    // first class of the document launch
+      for (int c = 0; c < ncls; ++c) if (cls[c].rcap > h->main_max_raw) { c_doc = c; break; }
+      if (int rc = stream_launch(kSlotMain, 0, 0, c_doc, known, false, 0); rc != kOk) return rc;
+      if (int rc = stream_launch(kSlotDoc, 1, c_doc, ncls, known, false, 0); rc != kOk) return rc;
+    } else {
+      // BPE, sentence-per-wave form (models that are not word-wise, or with UNUSED pieces): the staged classes; a
+      // sentence whose normalized form overflows its class escalates to the next staged one, then to the long form
+      int c_staged = 0;
+      while (c_staged < ncls && cls[c_staged].rcap <= kMaxStagedRaw && !h->no_wave) ++c_staged;
+      bool first = true;
+      for (int c = 0; c < c_staged; ++c) {
+        EncodeArgs la = a;
+        la.list = class_lists + static_cast<size_t>(c) * n; la.list_count = &ws->d_ctrl->list_counts[c];
+        const bool has_next = c + 1 < c_staged;
+        la.next_list = has_next ? class_lists + static_cast<size_t>(c + 1) * n : nullptr;
+        la.next_count = has_next ? &ws->d_ctrl->list_counts[c + 1] : nullptr;
+        la.rcap = cls[c].rcap; la.ncap = cls[c].ncap;
+        if (la.rcap == kMaxStagedRaw && la.ncap > kBpeWaveNcap3) la.ncap = kBpeWaveNcap3;
+        la.stats = &ws->d_ctrl->stats[kStatsPerClass * kSlotWave];
+        const uint32_t lds = EncodeLdsBytes(kBpe, la.rcap, la.ncap);
+        int per_cu = static_cast<int>(kLdsPerCu / lds);
+        if (per_cu > 32) per_cu = 32;
+        if (per_cu < 1) per_cu = 1;
+        uint64_t grid = static_cast<uint64_t>(h->n_cu) * per_cu;
+        if (grid > n) grid = n;
+        snprintf(ws->slot_name[kSlotWave], sizeof(ws->slot_name[kSlotWave]), "EncodeKernel<2, *>");
+        if (first) HIP_OR_RETURN(h, record(kSlotWave, 0));
+        first = false;
+        HIP_OR_RETURN(h, LaunchEncode(kBpe, c, la, static_cast<int>(grid), lds, stream));
+        HIP_OR_RETURN(h, record(kSlotWave, 1));
+        ws->slot_used[kSlotWave] = true;
       }
-      HIP_OR_RETURN(h, h->d_stream.Reserve(need));
-      if (bpe_stream) {      // document-length classes: HBM slices for words that outgrow the LDS slots
-        uint64_t long_waves = 0;
-        for (int c = 0; c < ncls; ++c) {
-          if (cls[c].rcap <= kMaxStagedRaw || known[c] == 0) continue;
-          const StreamPlan sp = PlanStream(h, cls[c], true, known[c]);
-          const uint64_t w = static_cast<uint64_t>(sp.grid) * sp.waves;
-          if (w > long_waves) long_waves = w;
-        }
-        if (long_waves) HIP_OR_RETURN(h, h->d_bpe_long.Reserve(long_waves * 64u * kBpeLongBytes));
-      }
+      for (int c = c_staged; c < ncls; ++c)
+        if (int rc = long_launch(class_lists + static_cast<size_t>(c) * n, &ws->d_ctrl->list_counts[c], known[c]); rc != kOk) return rc;
     }
-    bool prev_general = false;
-    for (int c = 0; c < ncls; ++c) {
-      EncodeArgs a{};
-      a.dev = h->dev; a.text = d_text; a.offs = d_offsets;
-      a.list = h->d_lists.p + static_cast<size_t>(c) * n; a.list_count = &h->d_ctrl->list_counts[c];
-      // a sentence whose normalized form overflows its class goes to the next one -- among the classes whose
-      // GENERAL kernel can stage it; past the last of those it fails the call
-      const bool has_next = c + 1 < ncls && cls[c + 1].rcap <= kMaxStagedRaw;
-      a.next_list = has_next ? h->d_lists.p + static_cast<size_t>(c + 1) * n : nullptr;
-      a.next_count = has_next ? &h->d_ctrl->list_counts[c + 1] : nullptr;
-      a.arena = h->d_arena.p; a.arena_head = &h->d_ctrl->arena_head; a.arena_cap = h->d_arena.cap;
-      a.tmp_off = h->d_tmp_off.p; a.counts = h->d_counts.p; a.status = &h->d_ctrl->status;
-      a.stats = &h->d_ctrl->stats[kStatsPerClass * c];
-      a.rcap = cls[c].rcap; a.ncap = cls[c].ncap;
-      a.no_lane_general = h->no_lane_general ? 1u : 0u;
-      a.lane_general_max_raw = h->lane_general_max_raw;
-      // short classes: a stray non-ASCII sentence would hold 63 ASCII lanes up, so a tile needs 16 of them to keep
-      // them; long classes: the position-parallel normalizer of the GENERAL kernel takes one sentence per wave at
-      // a time, so 4 are enough (C5, 1 M sentences: 51.8 -> 45.2 ms per step)
-      a.lane_general_min_lanes = h->lane_general_min_lanes ? h->lane_general_min_lanes : (cls[c].rcap <= 576 ? 16u : 4u);
-      a.arena_tb = spans ? h->d_arena_tb.p : nullptr;
-      if (streaming) {
-        const bool shared01 = merge01 && c == 1 && known[0] > 0;
-        if (known[c] == 0 && !prev_general && !shared01) continue;
-        a.ring = HandleRing(h);
-        const bool fast = StreamFastEligible(h->dev.flags) && !h->no_fast && known[c] > 0;
-        const bool staged = cls[c].rcap <= kMaxStagedRaw;
-        if (!staged && !fast) continue;
-        const bool general = staged && !(merge01 && c == 0);
-        const int hl = (merge01 && c <= 1) ? 0 : c;          // which hand-over list this class uses
-        for (int pass = fast ? 0 : 1; pass < (general ? 2 : 1); ++pass) {
-          const bool is_fast = pass == 0;
-          const StreamPlan sp = PlanStream(h, cls[c], is_fast, !is_fast && shared01 ? known[0] + known[1] : known[c]);
-          if (is_fast) {
-            a.hard_list = staged ? h->d_lists.p + static_cast<size_t>(ncls + hl) * n : nullptr;   // no GENERAL kernel to hand over to
-            a.hard_count = &h->d_ctrl->hard_counts[hl];
-          } else if (fast || shared01) {
-            a.list = h->d_lists.p + static_cast<size_t>(ncls + hl) * n;
-            a.list_count = &h->d_ctrl->hard_counts[hl];
-            a.hard_list = nullptr; a.hard_count = nullptr;
-          }
-          a.stream_tcap = sp.tcap;
-          a.stream_text = h->d_stream.p;
-          a.stream_bp = h->d_stream.p + sp.text_words;
-          const int slot = (fast && !is_fast) ? kSlotGeneral + c : c;
-          a.stats = &h->d_ctrl->stats[kStatsPerClass * slot];
-          a.tile_cursor = h->static_tiles ? nullptr : &h->d_ctrl->tile_cursor[slot];
-          a.bpe_long = (bpe_stream && !staged) ? h->d_bpe_long.p : nullptr;
-          a.tiles_ascending = h->tiles_ascending ? 1u : 0u;
-          a.wave_list = h->d_lists.p + static_cast<size_t>(2 * ncls + c) * n;
-          a.wave_count = &h->d_ctrl->wave_counts[c];
-          if (!bpe_stream && is_fast && a.ring == 16)
-            snprintf(h->slot_name[slot], sizeof(h->slot_name[slot]), "EncodeStreamKernelR16<%d>", c);
-          else
-            snprintf(h->slot_name[slot], sizeof(h->slot_name[slot]), "Encode%sStreamKernel<%d, %s>", bpe_stream ? "Bpe" : "", c,
-                     is_fast ? "true" : "false");
-          if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[slot][0], stream));
-          HIP_OR_RETURN(h, LaunchEncodeStream(h->model.model_type, c, is_fast, a, sp.grid, sp.waves, sp.lds, stream));
-          if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[slot][1], stream));
-          h->slot_used[slot] = true;
-        }
-        prev_general = general;
-        if (bpe_stream && staged) {   // what the lane form could not take (a word longer than kBpeWordMax): sentence per wave
-          a.list = h->d_lists.p + static_cast<size_t>(2 * ncls + c) * n;
-          a.list_count = &h->d_ctrl->wave_counts[c];
-          const int slot = kSlotGeneral + 4 + c;     // (staged BPE classes are 0..3; GENERAL slots end at kSlotGeneral + 3)
-          a.stats = &h->d_ctrl->stats[kStatsPerClass * slot];
-          snprintf(h->slot_name[slot], sizeof(h->slot_name[slot]), "EncodeKernel<2, %d>", c);
-          const uint32_t lds = EncodeLdsBytes(kBpe, a.rcap, a.ncap);
-          int per_cu = static_cast<int>(kLdsPerCu / lds);
-          if (per_cu > 32) per_cu = 32;
-          if (per_cu < 1) per_cu = 1;
-          uint64_t grid = static_cast<uint64_t>(h->n_cu) * per_cu;
-          const uint64_t most = known[c] > 64 ? known[c] : 64;
-          if (grid > most) grid = most;
-          if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[slot][0], stream));
-          HIP_OR_RETURN(h, LaunchEncode(kBpe, c, a, static_cast<int>(grid), lds, stream));
-          if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[slot][1], stream));
-          h->slot_used[slot] = true;
-        }
-        continue;
-      }
-      // BPE, sentence-per-wave form (models that are not word-wise, or SPMX_NO_STREAM)
-      if (cls[c].rcap > kMaxStagedRaw) continue;      // (empty: checked above)
-      snprintf(h->slot_name[c], sizeof(h->slot_name[c]), "EncodeKernel<%d, %d>", h->model.model_type, c);
-      const uint32_t lds = EncodeLdsBytes(h->model.model_type, a.rcap, a.ncap);
-      int per_cu = static_cast<int>(kLdsPerCu / lds);
-      if (per_cu > 32) per_cu = 32;
-      if (per_cu < 1) per_cu = 1;
-      uint64_t grid = static_cast<uint64_t>(h->n_cu) * per_cu;
-      if (grid > n) grid = n;
-      if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[c][0], stream));
-      HIP_OR_RETURN(h, LaunchEncode(h->model.model_type, c, a, static_cast<int>(grid), lds, stream));
-      if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[c][1], stream));
-      h->slot_used[c] = true;
-    }
-    {
-      ScanArgs sa{h->d_counts.p, n32, h->d_tile_sums.p, d_id_offsets};
-      const uint32_t tiles = (n32 + kScanTile - 1) / kScanTile;
-      HIP_OR_RETURN(h, LaunchScan(sa, static_cast<int>(tiles < static_cast<uint32_t>(wide) ? tiles : wide), stream));
-      CompactArgs pa{h->d_arena.p, h->d_tmp_off.p, h->d_counts.p, d_id_offsets, d_ids, d_ids ? ids_capacity : 0, n32};
-      const uint64_t cblocks = (n + 63) / 64;
-      const uint64_t cgrid = cblocks < static_cast<uint64_t>(h->n_cu) * 32 ? cblocks : static_cast<uint64_t>(h->n_cu) * 32;
-      HIP_OR_RETURN(h, LaunchCompact(pa, static_cast<int>(cgrid), stream));
-    }
-    if (prof) HIP_OR_RETURN(h, hipEventRecord(h->ev[kMaxSlots][1], stream));
-    HIP_OR_RETURN(h, hipMemcpyAsync(h->h_ctrl, h->d_ctrl, offsetof(Ctrl, total_ids), hipMemcpyDeviceToHost, stream));
-    HIP_OR_RETURN(h, hipMemcpyAsync(&h->h_ctrl->total_ids, d_id_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-    HIP_OR_RETURN(h, hipStreamSynchronize(stream));
-    const uint32_t st = h->h_ctrl->status;
-    if (st & kStArenaOverflow) {   // rare: byte fallback of multi-byte unknowns; arena_head holds what was asked for
-      arena_need = h->h_ctrl->arena_head + 64;
+    if (int rc = scan_compact(); rc != kOk) return rc;
+    if (ws->h_ctrl->status & kStArenaOverflow) {   // rare: byte fallback of multi-byte unknowns; arena_head holds what was asked for
+      arena_need = ws->h_ctrl->arena_head + ws->h_ctrl->arena_head / 8 + 64;
       continue;
     }
-    if (st & kStTooLong) return Fail(h, kOutOfRange, "a sentence is too long for the device path (more than 1 MiB, or its normalized form exceeds the largest length class)");
-    if (st & kStRevMergeOverflow) return Fail(h, kResourceExhausted, "BPE: more than 64 distinct unused merged pieces in one sentence");
-    if (st & kStInternal) return Fail(h, kInternal, "all normalized characters are not consumed.");   // sentencepiece_processor.cc:628
+    bool extra = false;
+    if (ws->h_ctrl->side.over_count) {             // sentences that fit no column of their launch: exact capacities
+      uint32_t counts[kMaxClasses] = {0};
+      counts[kMaxClasses - 1] = ws->h_ctrl->side.over_count;
+      if (int rc = stream_launch(kSlotExact, 2, 0, 0, counts, true, ws->h_ctrl->side.over_max_raw); rc != kOk) return rc;
+      extra = true;
+      if (is_bpe) {                                // it may have added to the long list
+        HIP_OR_RETURN(h, hipMemcpyAsync(&ws->h_ctrl->side, &ws->d_ctrl->side, sizeof(SideLists), hipMemcpyDeviceToHost, stream));
+        HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+      }
+    }
+    if (ws->h_ctrl->side.long_count) {             // BPE: what the lane / sentence-per-wave forms handed to the long form
+      if (int rc = long_launch(long_list, &ws->d_ctrl->side.long_count, ws->h_ctrl->side.long_count); rc != kOk) return rc;
+      extra = true;
+    }
+    if (extra) {
+      if (int rc = scan_compact(); rc != kOk) return rc;
+      if (ws->h_ctrl->status & kStArenaOverflow) {
+        arena_need = ws->h_ctrl->arena_head + ws->h_ctrl->arena_head / 8 + 64;
+        continue;
+      }
+    }
     if (prof) {
-      Profile &p = h->prof;
+      HIP_OR_RETURN(h, hipEventRecord(ws->ev[kNumSlots][1], stream));
+      HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+      Profile &p = ws->prof;
       p = Profile();
-      p.n = kMaxSlots;
-      for (int c = 0; c < kMaxSlots; ++c) {
-        if (!h->slot_used[c]) continue;
-        memcpy(p.name[c], h->slot_name[c], sizeof(p.name[c]));
-        HIP_OR_RETURN(h, hipEventElapsedTime(&p.kernel_ms[c], h->ev[c][0], h->ev[c][1]));
-        const unsigned long long *s = &h->h_ctrl->stats[kStatsPerClass * c];
+      p.n = kNumSlots;
+      for (int c = 0; c < kNumSlots; ++c) {
+        if (!ws->slot_used[c]) continue;
+        memcpy(p.name[c], ws->slot_name[c], sizeof(p.name[c]));
+        HIP_OR_RETURN(h, hipEventElapsedTime(&p.kernel_ms[c], ws->ev[c][0], ws->ev[c][1]));
+        const unsigned long long *s = &ws->h_ctrl->stats[kStatsPerClass * c];
         p.sentences[c] = s[0];
         p.raw_bytes[c] = s[1];
         p.ids[c] = s[2];
         for (int k = 0; k < 5; ++k) p.cycles[c][k] = s[3 + k];
-        p.rcap[c] = cls[(c < kSlotGeneral ? c : c - kSlotGeneral) % ncls].rcap;
       }
-      HIP_OR_RETURN(h, hipEventElapsedTime(&p.total_ms, h->ev[kMaxSlots][0], h->ev[kMaxSlots][1]));
+      uint64_t hard = 0;
+      for (int qi = 0; qi < 3; ++qi) for (int c = 0; c < kMaxClasses; ++c) hard += ws->h_ctrl->q[qi].hard_count[c];
+      p.path[0] = hard; p.path[1] = ws->h_ctrl->side.over_count; p.path[2] = ws->h_ctrl->side.long_count;
+      p.path[3] = ws->h_ctrl->side.n_failed;
+      HIP_OR_RETURN(h, hipEventElapsedTime(&p.total_ms, ws->ev[kNumSlots][0], ws->ev[kNumSlots][1]));
+      std::lock_guard<std::mutex> l(h->mu);
+      h->prof = p;
     }
-    if (total_ids) *total_ids = h->h_ctrl->total_ids;
-    if (h->h_ctrl->total_ids > ids_capacity || !d_ids) {
-      if (h->h_ctrl->total_ids == 0) return kOk;
+    if (total_ids) *total_ids = ws->h_ctrl->total_ids;
+    if (n_failed) *n_failed = ws->h_ctrl->side.n_failed;
+    if (ws->h_ctrl->total_ids > ids_capacity || !d_ids) {
+      if (ws->h_ctrl->total_ids == 0) return kOk;
       return Fail(h, kResourceExhausted, "ids_capacity is too small");
     }
-    if (spans && h->h_ctrl->total_ids > 0) {
-      // token begins to CSR order, then one align launch per length class over the encode's own lists
-      const uint64_t total = h->h_ctrl->total_ids;
-      HIP_OR_RETURN(h, h->d_tok_begin.Reserve(total));
-      CompactArgs pa{h->d_arena_tb.p, h->d_tmp_off.p, h->d_counts.p, d_id_offsets, h->d_tok_begin.p, total, n32};
+    if (spans && ws->h_ctrl->total_ids > 0) {
+      // token begins to CSR order, then one align launch per staged length class over the classify lists
+      const uint64_t total = ws->h_ctrl->total_ids;
+      HIP_OR_RETURN(h, ws->d_tok_begin.Reserve(total));
+      CompactArgs pa{ws->d_arena_tb.p, ws->d_tmp_off.p, ws->d_counts.p, d_id_offsets, ws->d_tok_begin.p, total, n32};
       const uint64_t cblocks = (n + 63) / 64;
       const uint64_t cgrid = cblocks < static_cast<uint64_t>(h->n_cu) * 32 ? cblocks : static_cast<uint64_t>(h->n_cu) * 32;
       HIP_OR_RETURN(h, LaunchCompact(pa, static_cast<int>(cgrid), stream));
-      HIP_OR_RETURN(h, hipMemsetAsync(&h->d_ctrl->status, 0, sizeof(uint32_t), stream));
-      // the hand-over lists of the encode are dead by now: they serve as the align kernels' escalation lists
-      HIP_OR_RETURN(h, hipMemsetAsync(h->d_ctrl->hard_counts, 0, sizeof(h->d_ctrl->hard_counts), stream));
+      HIP_OR_RETURN(h, hipMemsetAsync(&ws->d_ctrl->status, 0, sizeof(uint32_t), stream));
+      // the hard lists of the encode are dead by now: they serve as the align kernels' escalation lists, with the
+      // queue words of the main launch as their counters
+      HIP_OR_RETURN(h, hipMemsetAsync(ws->d_ctrl->q[0].hard_count, 0, sizeof(ws->d_ctrl->q[0].hard_count), stream));
+      HIP_OR_RETURN(h, hipMemsetAsync(&ws->d_ctrl->side.long_count, 0, sizeof(uint32_t), stream));
+      AlignArgs base{};
+      base.dev = h->dev; base.text = d_text; base.offs = d_offsets;
+      base.id_offs = d_id_offsets; base.tok_begin = ws->d_tok_begin.p; base.begin = d_begin; base.end = d_end;
+      base.nbegin = d_nbegin; base.nend = d_nbegin ? d_nend : nullptr;
+      base.status = &ws->d_ctrl->status; base.list_cap = n32;
       bool prev = false;
-      for (int c = 0; c < ncls; ++c) {
-        const uint32_t cnt = h->h_ctrl->list_counts[c];
-        if (cls[c].rcap > kMaxStagedRaw) {
-          if (cnt) return Fail(h, kOutOfRange, "a sentence is longer than 8192 bytes: the spans form is limited to that");
-          continue;
-        }
+      int c_staged = 0;
+      while (c_staged < ncls && cls[c_staged].rcap <= kMaxStagedRaw) ++c_staged;
+      for (int c = 0; c < c_staged; ++c) {
+        const uint32_t cnt = known[c];
         if (cnt == 0 && !prev) continue;
-        const bool has_next = c + 1 < ncls && cls[c + 1].rcap <= kMaxStagedRaw;
-        AlignArgs aa{};
-        aa.dev = h->dev; aa.text = d_text; aa.offs = d_offsets;
-        aa.id_offs = d_id_offsets; aa.tok_begin = h->d_tok_begin.p; aa.begin = d_begin; aa.end = d_end;
-        aa.nbegin = d_nbegin; aa.nend = d_nbegin ? d_nend : nullptr;
-        aa.status = &h->d_ctrl->status; aa.rcap = cls[c].rcap; aa.ncap = cls[c].ncap;
-        aa.next_list = has_next ? h->d_lists.p + static_cast<size_t>(ncls + c + 1) * n : nullptr;
-        aa.next_count = has_next ? &h->d_ctrl->hard_counts[c + 1] : nullptr;
-        aa.list_cap = n32;
+        const bool has_next = c + 1 < c_staged;
+        AlignArgs aa = base;
+        aa.rcap = cls[c].rcap; aa.ncap = cls[c].ncap;
+        // past the last staged class the sentence goes to the lane-per-sentence align kernel's list
+        aa.next_list = has_next ? hard_lists + static_cast<size_t>(c + 1) * n : long_list;
+        aa.next_count = has_next ? &ws->d_ctrl->q[0].hard_count[c + 1] : &ws->d_ctrl->side.long_count;
         const uint32_t lds = AlignLdsBytes(aa.rcap, aa.ncap, aa.nbegin != nullptr && aa.nend != nullptr);
         int per_cu = static_cast<int>(kLdsPerCu / lds);
         if (per_cu > 32) per_cu = 32;
         if (per_cu < 1) per_cu = 1;
         const uint64_t full = static_cast<uint64_t>(h->n_cu) * per_cu;
         if (cnt) {                       // the class's own sentences
-          aa.list = h->d_lists.p + static_cast<size_t>(c) * n; aa.list_count = &h->d_ctrl->list_counts[c];
+          aa.list = class_lists + static_cast<size_t>(c) * n; aa.list_count = &ws->d_ctrl->list_counts[c];
           HIP_OR_RETURN(h, LaunchAlign(aa, static_cast<int>(full < cnt ? full : cnt), lds, stream));
         }
         if (prev) {                      // what the previous class's align kernels could not hold (count on the device)
-          aa.list = h->d_lists.p + static_cast<size_t>(ncls + c) * n; aa.list_count = &h->d_ctrl->hard_counts[c];
+          aa.list = hard_lists + static_cast<size_t>(c) * n; aa.list_count = &ws->d_ctrl->q[0].hard_count[c];
           HIP_OR_RETURN(h, LaunchAlign(aa, static_cast<int>(full < 256 ? full : 256), lds, stream));
         }
         prev = true;
       }
+      // lane per sentence (kernels_long.h): the classes beyond the staged ones, and what the staged kernels passed on
+      auto align_long = [&](const uint32_t *list, const uint32_t *d_count, uint64_t most) -> int {
+        if (most == 0) return kOk;
+        AlignLongArgs la{};
+        la.dev = h->dev; la.text = d_text; la.offs = d_offsets; la.list = list; la.list_count = d_count;
+        la.id_offs = d_id_offsets; la.tok_begin = ws->d_tok_begin.p; la.begin = d_begin; la.end = d_end;
+        la.nbegin = d_nbegin; la.nend = d_nbegin ? d_nend : nullptr;
+        la.status = &ws->d_ctrl->status;
+        uint64_t g = (most + 63) / 64;
+        if (g > static_cast<uint64_t>(h->n_cu) * 16) g = static_cast<uint64_t>(h->n_cu) * 16;
+        HIP_OR_RETURN(h, LaunchAlignLong(la, static_cast<int>(g), stream));
+        return kOk;
+      };
+      for (int c = c_staged; c < ncls; ++c)
+        if (int rc = align_long(class_lists + static_cast<size_t>(c) * n, &ws->d_ctrl->list_counts[c], known[c]); rc != kOk) return rc;
+      if (prev) if (int rc = align_long(long_list, &ws->d_ctrl->side.long_count, 256 * 64); rc != kOk) return rc;
       uint32_t st2 = 0;
-      HIP_OR_RETURN(h, hipMemcpyAsync(&st2, &h->d_ctrl->status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      HIP_OR_RETURN(h, hipMemcpyAsync(&st2, &ws->d_ctrl->status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
       HIP_OR_RETURN(h, hipStreamSynchronize(stream));
-      if (st2 & kStTooLong) return Fail(h, kOutOfRange, "a sentence is too long for the spans form");
       if (st2) return Fail(h, kInternal, "token boundaries do not tile the normalized text");
     }
     return kOk;
@@ -569,9 +731,10 @@ int EncodeDevice(spmx_handle *h, const uint8_t *d_text, uint64_t text_bytes, con
   return Fail(h, kInternal, "id arena kept overflowing");
 }
 
-// Batch Normalize on the device (kernels_normalize.h): classify -> count pass per class -> scan -> write pass per class.
-// Caller holds h->mu and has set the device.
-int NormalizeDevice(spmx_handle *h, const uint8_t *d_text, const uint64_t *d_offsets, uint64_t n, uint8_t *d_norm,
+// Batch Normalize on the device: classify -> count pass -> scan -> write pass.  The staged classes run the
+// position-parallel kernels (kernels_normalize.h); longer sentences, and what overflows the last staged class, the
+// lane-per-sentence ones (kernels_long.h).
+int NormalizeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, const uint64_t *d_offsets, uint64_t n, uint8_t *d_norm,
                     uint64_t norm_capacity, uint64_t *d_norm_offsets, uint32_t *d_n2o, hipStream_t stream,
                     uint64_t *total_bytes, bool device_text = false) {
   if (total_bytes) *total_bytes = 0;
@@ -582,36 +745,32 @@ int NormalizeDevice(spmx_handle *h, const uint8_t *d_text, const uint64_t *d_off
     HIP_OR_RETURN(h, hipStreamSynchronize(stream));
     return kOk;
   }
-  const int ncls = NumClasses(h);
-  const LengthClass *cls = Classes(h);
-  HIP_OR_RETURN(h, h->d_lists.Reserve(static_cast<size_t>(3 * ncls) * n));
-  HIP_OR_RETURN(h, h->d_counts.Reserve(n + 1));
-  HIP_OR_RETURN(h, h->d_tile_sums.Reserve((n + kScanTile - 1) / kScanTile + 2));
-  HIP_OR_RETURN(h, hipMemsetAsync(h->d_ctrl, 0, sizeof(Ctrl), stream));
+  const int ncls = kNumClasses;
+  const LengthClass *cls = h->classes;
+  HIP_OR_RETURN(h, ws->d_lists.Reserve(static_cast<size_t>(2 * kMaxClasses + 3) * n));
+  HIP_OR_RETURN(h, ws->d_counts.Reserve(n + 1));
+  HIP_OR_RETURN(h, ws->d_tile_sums.Reserve((n + kScanTile - 1) / kScanTile + 2));
+  HIP_OR_RETURN(h, hipMemsetAsync(ws->d_ctrl, 0, sizeof(Ctrl), stream));
   const uint32_t n32 = static_cast<uint32_t>(n);
   const int wide = h->n_cu * 8;
-  {
-    ClassifyArgs ca{};
-    ca.offs = d_offsets; ca.n = n32; ca.n_classes = static_cast<uint32_t>(ncls);
-    for (int c = 0; c < ncls; ++c) ca.rcap[c] = cls[c].rcap;
-    ca.lists = h->d_lists.p; ca.list_counts = h->d_ctrl->list_counts;
-    ca.key_totals = h->d_ctrl->key_totals; ca.key_cursor = h->d_ctrl->key_cursor;
-      ca.sub_buckets = h->sub_buckets;
-    const uint32_t chunks = (n32 + 64 * kClassifyChunk - 1) / (64 * kClassifyChunk);
-    HIP_OR_RETURN(h, LaunchClassify(ca, static_cast<int>(chunks < static_cast<uint32_t>(wide) ? chunks : wide), stream));
-  }
+  uint32_t *const class_lists = ws->d_lists.p;
+  uint32_t *const long_list = class_lists + static_cast<size_t>(2 * kMaxClasses) * n;
+  if (int rc = RunClassify(h, ws, d_offsets, n32, stream); rc != kOk) return rc;
+  int c_staged = 0;
+  while (c_staged < ncls && cls[c_staged].rcap <= kMaxStagedRaw) ++c_staged;
   auto pass = [&](bool write) -> int {
-    for (int c = 0; c < ncls; ++c) {
-      if (cls[c].rcap > kMaxStagedRaw) continue;             // checked below
-      NormalizeArgs a{};
-      a.dev = h->dev; a.text = d_text; a.offs = d_offsets;
-      a.list = h->d_lists.p + static_cast<size_t>(c) * n; a.list_count = &h->d_ctrl->list_counts[c];
-      const bool has_next = c + 1 < ncls && cls[c + 1].rcap <= kMaxStagedRaw;
-      a.next_list = has_next ? h->d_lists.p + static_cast<size_t>(c + 1) * n : nullptr;
-      a.next_count = has_next ? &h->d_ctrl->list_counts[c + 1] : nullptr;
-      a.counts = h->d_counts.p; a.norm_offs = d_norm_offsets; a.norm = d_norm; a.n2o = d_n2o;
-      a.status = &h->d_ctrl->status; a.rcap = cls[c].rcap; a.ncap = cls[c].ncap;
-      a.device_text = device_text ? 1u : 0u;
+    NormalizeArgs base{};
+    base.dev = h->dev; base.text = d_text; base.offs = d_offsets;
+    base.counts = ws->d_counts.p; base.norm_offs = d_norm_offsets; base.norm = d_norm; base.n2o = d_n2o;
+    base.status = &ws->d_ctrl->status;
+    base.device_text = device_text ? 1u : 0u;
+    for (int c = 0; c < c_staged; ++c) {
+      NormalizeArgs a = base;
+      a.list = class_lists + static_cast<size_t>(c) * n; a.list_count = &ws->d_ctrl->list_counts[c];
+      const bool has_next = c + 1 < c_staged;
+      a.next_list = has_next ? class_lists + static_cast<size_t>(c + 1) * n : long_list;
+      a.next_count = has_next ? &ws->d_ctrl->list_counts[c + 1] : &ws->d_ctrl->side.long_count;
+      a.rcap = cls[c].rcap; a.ncap = cls[c].ncap;
       const uint32_t lds = NormalizeLdsBytes(a.rcap, a.ncap);
       int per_cu = static_cast<int>(kLdsPerCu / lds);
       if (per_cu > 32) per_cu = 32;
@@ -620,22 +779,27 @@ int NormalizeDevice(spmx_handle *h, const uint8_t *d_text, const uint64_t *d_off
       if (grid > n) grid = n;
       HIP_OR_RETURN(h, LaunchNormalize(write, a, static_cast<int>(grid), lds, stream));
     }
+    uint64_t g = (n + 63) / 64;
+    if (g > static_cast<uint64_t>(h->n_cu) * 16) g = static_cast<uint64_t>(h->n_cu) * 16;
+    for (int c = c_staged; c <= ncls; ++c) {            // c == ncls: what the last staged class passed on
+      NormalizeArgs a = base;
+      a.list = c < ncls ? class_lists + static_cast<size_t>(c) * n : long_list;
+      a.list_count = c < ncls ? &ws->d_ctrl->list_counts[c] : &ws->d_ctrl->side.long_count;
+      HIP_OR_RETURN(h, LaunchNormalizeLong(write, a, static_cast<int>(g), stream));
+    }
     return kOk;
   };
   if (int rc = pass(false); rc != kOk) return rc;
   {
-    ScanArgs sa{h->d_counts.p, n32, h->d_tile_sums.p, d_norm_offsets};
+    ScanArgs sa{ws->d_counts.p, n32, ws->d_tile_sums.p, d_norm_offsets};
     const uint32_t tiles = (n32 + kScanTile - 1) / kScanTile;
     HIP_OR_RETURN(h, LaunchScan(sa, static_cast<int>(tiles < static_cast<uint32_t>(wide) ? tiles : wide), stream));
   }
-  HIP_OR_RETURN(h, hipMemcpyAsync(h->h_ctrl, h->d_ctrl, offsetof(Ctrl, total_ids), hipMemcpyDeviceToHost, stream));
-  HIP_OR_RETURN(h, hipMemcpyAsync(&h->h_ctrl->total_ids, d_norm_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+  HIP_OR_RETURN(h, hipMemcpyAsync(ws->h_ctrl, ws->d_ctrl, offsetof(Ctrl, total_ids), hipMemcpyDeviceToHost, stream));
+  HIP_OR_RETURN(h, hipMemcpyAsync(&ws->h_ctrl->total_ids, d_norm_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
   HIP_OR_RETURN(h, hipStreamSynchronize(stream));
-  for (int c = 0; c < ncls; ++c)
-    if (cls[c].rcap > kMaxStagedRaw && h->h_ctrl->list_counts[c])
-      return Fail(h, kOutOfRange, "a sentence is longer than 8192 bytes: Normalize on the device is limited to that");
-  if (h->h_ctrl->status & kStTooLong) return Fail(h, kOutOfRange, "the normalized form of a sentence exceeds the largest length class");
-  const uint64_t total = h->h_ctrl->total_ids;
+  if (ws->h_ctrl->status & kStTooLong) return Fail(h, kOutOfRange, "the normalized form of a sentence would exceed 2^31 bytes");
+  const uint64_t total = ws->h_ctrl->total_ids;
   if (total_bytes) *total_bytes = total;
   if (total == 0 && !d_n2o) return kOk;
   if ((!d_norm && total) || total > norm_capacity) return Fail(h, kResourceExhausted, "norm_capacity is too small");
@@ -645,8 +809,7 @@ int NormalizeDevice(spmx_handle *h, const uint8_t *d_text, const uint64_t *d_off
 }
 
 // Batch Decode on the device (kernels_decode.h): count pass -> scan -> (host checks status / capacity) -> write pass.
-// Caller holds h->mu and has set the device.
-int DecodeDevice(spmx_handle *h, const int32_t *d_ids, const uint64_t *d_id_offsets, uint64_t n, uint8_t *d_text,
+int DecodeDevice(spmx_handle *h, Workspace *ws, const int32_t *d_ids, const uint64_t *d_id_offsets, uint64_t n, uint8_t *d_text,
                  uint64_t text_capacity, uint64_t *d_text_offsets, hipStream_t stream, uint64_t *total_bytes) {
   if (total_bytes) *total_bytes = 0;
   if (h->model.has_denormalizer)
@@ -658,30 +821,30 @@ int DecodeDevice(spmx_handle *h, const int32_t *d_ids, const uint64_t *d_id_offs
     HIP_OR_RETURN(h, hipStreamSynchronize(stream));
     return kOk;
   }
-  HIP_OR_RETURN(h, h->d_counts.Reserve(n + 1));
-  HIP_OR_RETURN(h, h->d_tile_sums.Reserve((n + kScanTile - 1) / kScanTile + 2));
-  HIP_OR_RETURN(h, hipMemsetAsync(h->d_ctrl, 0, sizeof(Ctrl), stream));
-  HIP_OR_RETURN(h, hipMemsetAsync(&h->d_ctrl->bad_key, 0xFF, sizeof(unsigned long long), stream));
+  HIP_OR_RETURN(h, ws->d_counts.Reserve(n + 1));
+  HIP_OR_RETURN(h, ws->d_tile_sums.Reserve((n + kScanTile - 1) / kScanTile + 2));
+  HIP_OR_RETURN(h, hipMemsetAsync(ws->d_ctrl, 0, sizeof(Ctrl), stream));
+  HIP_OR_RETURN(h, hipMemsetAsync(&ws->d_ctrl->bad_key, 0xFF, sizeof(unsigned long long), stream));
   DecodeArgs a{};
   a.dev = h->dev; a.ids = d_ids; a.id_offs = d_id_offsets; a.n = static_cast<uint32_t>(n);
-  a.counts = h->d_counts.p; a.text_offs = d_text_offsets; a.text = d_text; a.text_cap = d_text ? text_capacity : 0;
-  a.status = &h->d_ctrl->status; a.bad_key = &h->d_ctrl->bad_key;
+  a.counts = ws->d_counts.p; a.text_offs = d_text_offsets; a.text = d_text; a.text_cap = d_text ? text_capacity : 0;
+  a.status = &ws->d_ctrl->status; a.bad_key = &ws->d_ctrl->bad_key;
   const uint64_t wide = static_cast<uint64_t>(h->n_cu) * 32;
   const int grid = static_cast<int>(n < wide ? n : wide);
   HIP_OR_RETURN(h, LaunchDecode(false, a, grid, stream));
   {
-    ScanArgs sa{h->d_counts.p, static_cast<uint32_t>(n), h->d_tile_sums.p, d_text_offsets};
+    ScanArgs sa{ws->d_counts.p, static_cast<uint32_t>(n), ws->d_tile_sums.p, d_text_offsets};
     const uint32_t tiles = (static_cast<uint32_t>(n) + kScanTile - 1) / kScanTile;
     HIP_OR_RETURN(h, LaunchScan(sa, static_cast<int>(tiles < static_cast<uint32_t>(h->n_cu * 8) ? tiles : h->n_cu * 8), stream));
   }
-  HIP_OR_RETURN(h, hipMemcpyAsync(h->h_ctrl, h->d_ctrl, offsetof(Ctrl, total_ids), hipMemcpyDeviceToHost, stream));
-  HIP_OR_RETURN(h, hipMemcpyAsync(&h->h_ctrl->total_ids, d_text_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+  HIP_OR_RETURN(h, hipMemcpyAsync(ws->h_ctrl, ws->d_ctrl, offsetof(Ctrl, total_ids), hipMemcpyDeviceToHost, stream));
+  HIP_OR_RETURN(h, hipMemcpyAsync(&ws->h_ctrl->total_ids, d_text_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
   HIP_OR_RETURN(h, hipStreamSynchronize(stream));
-  if (h->h_ctrl->status & kStBadId) {   // sentencepiece_processor.cc:913-917 (the id reported is one of the batch's first failing sentence)
-    const int id = static_cast<int>(static_cast<uint32_t>(h->h_ctrl->bad_key));
+  if (ws->h_ctrl->status & kStBadId) {   // sentencepiece_processor.cc:913-917 (the id reported is one of the batch's first failing sentence)
+    const int id = static_cast<int>(static_cast<uint32_t>(ws->h_ctrl->bad_key));
     return Fail(h, kOutOfRange, "Invalid id: " + std::to_string(id));
   }
-  const uint64_t total = h->h_ctrl->total_ids;
+  const uint64_t total = ws->h_ctrl->total_ids;
   if (total_bytes) *total_bytes = total;
   if (total == 0) return kOk;
   if (!d_text || total > text_capacity) return Fail(h, kResourceExhausted, "text_capacity is too small");
@@ -699,6 +862,28 @@ bool ReadFile(const char *path, std::string *out) {
   return true;
 }
 
+const char *StatusText(int code) {
+  switch (code) {
+    case kOutOfRange: return "the sentence is too long for the device path (its normalized form would exceed 2^31 bytes)";
+    case kResourceExhausted: return "out of device memory for the sentence's working set";
+    default: return "all normalized characters are not consumed.";   // sentencepiece_processor.cc:628
+  }
+}
+
+// Every extern "C" body runs under this: no C++ exception crosses the boundary (include/spmx.h).
+template <typename F>
+int Guard(spmx_handle *h, F f) {
+  try {
+    return f();
+  } catch (const std::bad_alloc &) {
+    return Fail(h, kResourceExhausted, "out of host memory");
+  } catch (const std::exception &e) {
+    return Fail(h, kInternal, e.what());
+  } catch (...) {
+    return Fail(h, kInternal, "unknown exception");
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -706,109 +891,111 @@ extern "C" {
 int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_handle **out) {
   if (!out) return Fail(nullptr, kInvalidArgument, "null output handle");
   *out = nullptr;
-  if (!model_bytes || n_bytes == 0) return Fail(nullptr, kInvalidArgument, "empty model");   // "model file is empty" analogue
-  int n_dev = 0;
-  hipError_t e = hipGetDeviceCount(&n_dev);
-  if (e != hipSuccess || n_dev <= 0)
-    return Fail(nullptr, kUnavailable, std::string("no HIP device is available (libspmx has no CPU path): ") +
-                                           (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
-  if (device < 0 || device >= n_dev) return Fail(nullptr, kInvalidArgument, "device ordinal out of range");
-  spmx_handle *h = new spmx_handle;
-  h->device = device;
-  Status st = ParseModelProto(model_bytes, n_bytes, &h->model);
-  if (st.ok()) st = InitializeModel(&h->model);
-  if (st.ok()) st = CompileTables(h->model, &h->tables);
-  if (st.ok()) st = CompileExtraOptions(h->model, "", &h->tables);
-  if (!st.ok()) { const int c = Fail(nullptr, st.code, st.message); delete h; return c; }
-  auto bail = [&](hipError_t err, const char *what) {
-    const int c = FailHip(nullptr, err, what);
-    DestroyHandle(h);
-    return c;
-  };
-  if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
-  hipDeviceProp_t prop;
-  if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
-  h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if (const char *e = getenv("SPMX_NO_FAST")) h->no_fast = e[0] == '1';
-  if (const char *e = getenv("SPMX_NO_STREAM")) h->no_stream = e[0] == '1';
-  if (const char *e = getenv("SPMX_NO_LANE_GENERAL")) h->no_lane_general = e[0] == '1';
-  if (const char *e = getenv("SPMX_NO_MERGE_GENERAL")) h->no_merge_general = e[0] == '1';
-  if (const char *e = getenv("SPMX_STATIC_TILES")) h->static_tiles = e[0] == '1';
-  if (const char *e = getenv("SPMX_SUB_BUCKETS")) {
-    const int v = atoi(e);
-    h->sub_buckets = static_cast<uint32_t>(v < 1 ? 1 : (v > kMaxSubBuckets ? kMaxSubBuckets : v));
-  }
-  if (const char *e = getenv("SPMX_TILE_ORDER")) h->tiles_ascending = e[0] == 'a';
-  if (const char *e = getenv("SPMX_LANE_GENERAL_MAX_RAW")) h->lane_general_max_raw = static_cast<uint32_t>(atoi(e));
-  if (const char *e = getenv("SPMX_LANE_GENERAL_MIN_LANES")) h->lane_general_min_lanes = static_cast<uint32_t>(atoi(e));
-  if (const char *e = getenv("SPMX_STREAM_SCRATCH_MB")) h->stream_scratch_limit = static_cast<uint64_t>(atoll(e)) << 20;
-  if (const char *e = getenv("SPMX_TILE_WAVES")) h->tile_waves_override = atoi(e);
-  if (const char *e = getenv("SPMX_FORCE_RING")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) h->ring_override = static_cast<uint32_t>(v); }
-  if ((e = hipMalloc(reinterpret_cast<void **>(&h->d_ctrl), sizeof(Ctrl))) != hipSuccess) return bail(e, "hipMalloc(ctrl)");
-  if ((e = hipHostMalloc(reinterpret_cast<void **>(&h->h_ctrl), sizeof(Ctrl), hipHostMallocDefault)) != hipSuccess)
-    return bail(e, "hipHostMalloc(ctrl)");
-  if (UploadTables(h) != kOk) {
-    const std::string msg = h->error;
-    DestroyHandle(h);
-    return Fail(nullptr, kInternal, msg);
-  }
-  *out = h;
-  return kOk;
+  return Guard(nullptr, [&]() -> int {
+    if (!model_bytes || n_bytes == 0) return Fail(nullptr, kInvalidArgument, "empty model");   // "model file is empty" analogue
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0)
+      return Fail(nullptr, kUnavailable, std::string("no HIP device is available (libspmx has no CPU path): ") +
+                                             (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+    if (device < 0 || device >= n_dev) return Fail(nullptr, kInvalidArgument, "device ordinal out of range");
+    std::unique_ptr<spmx_handle, void (*)(spmx_handle *)> h(new spmx_handle, DestroyHandle);
+    h->device = device;
+    Status st = ParseModelProto(model_bytes, n_bytes, &h->model);
+    if (st.ok()) st = InitializeModel(&h->model);
+    if (st.ok()) st = CompileTables(h->model, &h->tables);
+    if (st.ok()) st = CompileExtraOptions(h->model, "", &h->tables);
+    if (!st.ok()) return Fail(nullptr, st.code, st.message);
+    HIP_OR_RETURN(nullptr, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_OR_RETURN(nullptr, hipGetDeviceProperties(&prop, device));
+    h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    for (int c = 0; c < kNumClasses; ++c) h->classes[c] = kClasses[c];
+    if (const char *e = getenv("SPMX_NO_FAST")) h->no_fast = e[0] == '1';
+    if (const char *e = getenv("SPMX_NO_STREAM")) h->no_stream = e[0] == '1';
+    if (const char *e = getenv("SPMX_NO_WAVE")) h->no_wave = e[0] == '1';
+    if (const char *e = getenv("SPMX_NO_LANE_GENERAL")) h->no_lane_general = e[0] == '1';
+    if (const char *e = getenv("SPMX_SUB_BUCKETS")) {
+      const int v = atoi(e);
+      h->sub_buckets = static_cast<uint32_t>(v < 1 ? 1 : (v > kMaxSubBuckets ? kMaxSubBuckets : v));
+    }
+    if (const char *e = getenv("SPMX_LANE_GENERAL_MIN_LANES")) h->lane_general_min_lanes = static_cast<uint32_t>(atoi(e));
+    if (const char *e = getenv("SPMX_STREAM_SCRATCH_MB")) h->stream_scratch_limit = static_cast<uint64_t>(atoll(e)) << 20;
+    if (const char *e = getenv("SPMX_TILE_WAVES")) h->tile_waves_override = atoi(e);
+    if (const char *e = getenv("SPMX_MAIN_MAX_RAW")) h->main_max_raw = static_cast<uint32_t>(atoll(e));
+    if (const char *e = getenv("SPMX_FORCE_RING")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) h->ring_override = static_cast<uint32_t>(v); }
+    if (const char *e = getenv("SPMX_CLASSES")) {          // "raw:norm,raw:norm,..." (ascending; tests shrink the table)
+      int c = 0;
+      const char *p = e;
+      while (*p && c < kNumClasses) {
+        char *q = nullptr;
+        const unsigned long r = strtoul(p, &q, 10);
+        if (q == p || *q != ':') break;
+        p = q + 1;
+        const unsigned long nn = strtoul(p, &q, 10);
+        if (q == p) break;
+        h->classes[c++] = LengthClass{static_cast<uint32_t>(r), static_cast<uint32_t>(nn)};
+        p = *q == ',' ? q + 1 : q;
+      }
+    }
+    if (int rc = UploadTables(h.get()); rc != kOk) return rc;
+    *out = h.release();
+    return kOk;
+  });
 }
 
 int spmx_create_from_file(const char *filename, int device, spmx_handle **out) {
   if (out) *out = nullptr;
-  std::string blob;
-  if (!filename || !ReadFile(filename, &blob))   // io::LoadModelProto (sentencepiece_processor.cc:1131-1149)
-    return Fail(nullptr, kNotFound, std::string("\"") + (filename ? filename : "") + "\": No such file or directory");
-  return spmx_create(blob.data(), blob.size(), device, out);
+  return Guard(nullptr, [&]() -> int {
+    std::string blob;
+    if (!filename || !ReadFile(filename, &blob))   // io::LoadModelProto (sentencepiece_processor.cc:1131-1149)
+      return Fail(nullptr, kNotFound, std::string("\"") + (filename ? filename : "") + "\": No such file or directory");
+    return spmx_create(blob.data(), blob.size(), device, out);
+  });
 }
 
 void spmx_destroy(spmx_handle *h) { DestroyHandle(h); }
 
-const char *spmx_last_error(const spmx_handle *h) {
-  if (h) return h->error.c_str();
-  static thread_local std::string copy;
-  std::lock_guard<std::mutex> l(g_err_mu);
-  copy = g_create_error;
-  return copy.c_str();
-}
+const char *spmx_last_error(const spmx_handle *) { return t_error.c_str(); }
 
 int spmx_set_encode_extra_options(spmx_handle *h, const char *options) {
   if (!h) return kInvalidArgument;
-  std::lock_guard<std::mutex> l(h->mu);
-  Status st = CompileExtraOptions(h->model, options ? options : "", &h->tables);
-  if (!st.ok()) return Fail(h, st.code, st.message);
-  HIP_OR_RETURN(h, hipSetDevice(h->device));
-  return RefreshDevice(h, false);
+  return Guard(h, [&]() -> int {
+    Status st = CompileExtraOptions(h->model, options ? options : "", &h->tables);
+    if (!st.ok()) return Fail(h, st.code, st.message);
+    HIP_OR_RETURN(h, hipSetDevice(h->device));
+    return RefreshDevice(h, false);
+  });
 }
 
 int spmx_set_vocabulary(spmx_handle *h, const char *const *pieces, const uint64_t *piece_lens, uint64_t n) {
   if (!h) return kInvalidArgument;
-  std::lock_guard<std::mutex> l(h->mu);
-  std::vector<std::string> v;
-  v.reserve(n);
-  for (uint64_t i = 0; i < n; ++i) v.emplace_back(pieces[i], piece_lens[i]);
-  Status st = SetVocabulary(&h->model, v);
-  if (!st.ok()) return Fail(h, st.code, st.message);
-  RefreshTypeFlags(h->model, &h->tables);
-  HIP_OR_RETURN(h, hipSetDevice(h->device));
-  return RefreshDevice(h, true);
+  return Guard(h, [&]() -> int {
+    std::vector<std::string> v;
+    v.reserve(n);
+    for (uint64_t i = 0; i < n; ++i) v.emplace_back(pieces[i], piece_lens[i]);
+    Status st = SetVocabulary(&h->model, v);
+    if (!st.ok()) return Fail(h, st.code, st.message);
+    RefreshTypeFlags(h->model, &h->tables);
+    HIP_OR_RETURN(h, hipSetDevice(h->device));
+    return RefreshDevice(h, true);
+  });
 }
 
 int spmx_reset_vocabulary(spmx_handle *h) {
   if (!h) return kInvalidArgument;
-  std::lock_guard<std::mutex> l(h->mu);
-  ResetVocabulary(&h->model);
-  RefreshTypeFlags(h->model, &h->tables);
-  HIP_OR_RETURN(h, hipSetDevice(h->device));
-  return RefreshDevice(h, true);
+  return Guard(h, [&]() -> int {
+    ResetVocabulary(&h->model);
+    RefreshTypeFlags(h->model, &h->tables);
+    HIP_OR_RETURN(h, hipSetDevice(h->device));
+    return RefreshDevice(h, true);
+  });
 }
 
 int spmx_piece_size(const spmx_handle *h) { return h ? static_cast<int>(h->model.pieces.size()) : 0; }
 int spmx_piece_to_id(const spmx_handle *h, const char *piece, uint64_t len) {
   if (!h) return 0;
-  return h->model.PieceToId(std::string(piece ? piece : "", piece ? len : 0));
+  try { return h->model.PieceToId(std::string(piece ? piece : "", piece ? len : 0)); } catch (...) { return h->model.unk_id; }
 }
 int64_t spmx_id_to_piece(const spmx_handle *h, int id, char *out, uint64_t cap) {
   if (!h || id < 0 || id >= static_cast<int>(h->model.pieces.size())) return -1;
@@ -821,119 +1008,147 @@ int spmx_piece_type(const spmx_handle *h, int id) {
   if (!h || id < 0 || id >= static_cast<int>(h->model.pieces.size())) return -1;
   return h->model.pieces[id].type;
 }
-// bos_id / eos_id / pad_id (src/sentencepiece_processor.cc:1002-1017): PieceToId, -1 if it resolves to unk
+// bos_id / eos_id / pad_id (src/sentencepiece_processor.cc:1000-1017): PieceToId, -1 unless that piece IsControl
 static int ReservedId(const spmx_handle *h, const std::string &piece) {
   if (!h) return -1;
-  const int id = h->model.PieceToId(std::string(piece.c_str()));
-  return h->model.pieces[id].type == kUnknown_ ? -1 : id;
+  try {
+    const int id = h->model.PieceToId(std::string(piece.c_str()));
+    return h->model.pieces[id].type == kControl ? id : -1;
+  } catch (...) { return -1; }
 }
 int spmx_bos_id(const spmx_handle *h) { return h ? ReservedId(h, h->model.bos_piece) : -1; }
 int spmx_eos_id(const spmx_handle *h) { return h ? ReservedId(h, h->model.eos_piece) : -1; }
 int spmx_pad_id(const spmx_handle *h) { return h ? ReservedId(h, h->model.pad_piece) : -1; }
 int spmx_model_type(const spmx_handle *h) { return h ? h->model.model_type : 0; }
+uint32_t spmx_model_flags(const spmx_handle *h) { return h ? h->dev.flags : 0u; }
+int64_t spmx_unk_piece(const spmx_handle *h, char *out, uint64_t cap) {
+  if (!h) return -1;
+  const std::string &p = h->model.unk_piece;
+  if (out && cap) memcpy(out, p.data(), p.size() < cap ? p.size() : cap);
+  return static_cast<int64_t>(p.size());
+}
+
+int spmx_encode_batch_device_ex(spmx_handle *h, const void *d_text, uint64_t text_bytes, const uint64_t *d_offsets,
+                                uint64_t n, int32_t *d_ids, uint64_t ids_capacity, uint64_t *d_id_offsets,
+                                uint8_t *d_status, void *stream, uint64_t *total_ids, uint64_t *n_failed) {
+  if (!h) return kInvalidArgument;
+  return Guard(h, [&]() -> int {
+    HIP_OR_RETURN(h, hipSetDevice(h->device));
+    Lease L(h);
+    if (int rc = L.Ready(); rc != kOk) return rc;
+    return EncodeDevice(h, L.ws.get(), static_cast<const uint8_t *>(d_text), text_bytes, d_offsets, n, d_ids, ids_capacity,
+                        d_id_offsets, d_status, static_cast<hipStream_t>(stream), total_ids, n_failed);
+  });
+}
 
 int spmx_encode_batch_device(spmx_handle *h, const void *d_text, uint64_t text_bytes, const uint64_t *d_offsets,
                              uint64_t n, int32_t *d_ids, uint64_t ids_capacity, uint64_t *d_id_offsets, void *stream,
                              uint64_t *total_ids) {
-  if (!h) return kInvalidArgument;
-  std::lock_guard<std::mutex> l(h->mu);
-  HIP_OR_RETURN(h, hipSetDevice(h->device));
-  return EncodeDevice(h, static_cast<const uint8_t *>(d_text), text_bytes, d_offsets, n, d_ids, ids_capacity,
-                      d_id_offsets, static_cast<hipStream_t>(stream), total_ids);
+  return spmx_encode_batch_device_ex(h, d_text, text_bytes, d_offsets, n, d_ids, ids_capacity, d_id_offsets, nullptr, stream,
+                                     total_ids, nullptr);
 }
 
 namespace {
 // Host-buffer form of the batch encode, with (begin / end non-null) or without the spans.
 int EncodeBatchHost(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
-                    uint64_t **id_offsets, uint32_t **begin, uint32_t **end, uint32_t **nbegin = nullptr,
-                    uint32_t **nend = nullptr) {
+                    uint64_t **id_offsets, uint8_t **status, uint64_t *n_failed, uint32_t **begin, uint32_t **end,
+                    uint32_t **nbegin = nullptr, uint32_t **nend = nullptr) {
   if (!h) return kInvalidArgument;
-  std::lock_guard<std::mutex> l(h->mu);
   const bool spans = begin != nullptr;
   if (!ids || !id_offsets || (spans && !end)) return Fail(h, kInternal, "output container is null");   // sentencepiece_processor.cc:367-370
   *ids = nullptr; *id_offsets = nullptr;
+  if (status) *status = nullptr;
+  if (n_failed) *n_failed = 0;
   if (spans) { *begin = nullptr; *end = nullptr; }
   const bool nspans = spans && nbegin && nend;
   if (nspans) { *nbegin = nullptr; *nend = nullptr; }
   if (n && !offsets) return Fail(h, kInvalidArgument, "null offsets");
   HIP_OR_RETURN(h, hipSetDevice(h->device));
-  uint64_t *ho = static_cast<uint64_t *>(malloc((n + 1) * sizeof(uint64_t)));
+  Lease L(h);
+  if (int rc = L.Ready(); rc != kOk) return rc;
+  Workspace *ws = L.ws.get();
+  hipStream_t st = ws->stream;
+  // everything the caller gets is malloc'd here and freed on any failure
+  void *outs[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  auto drop = [&]() { for (void *&p : outs) { free(p); p = nullptr; } };
+  uint64_t *ho = static_cast<uint64_t *>(outs[0] = malloc((n + 1) * sizeof(uint64_t)));
   if (!ho) return Fail(h, kResourceExhausted, "out of host memory");
   if (n == 0) {
     ho[0] = 0; *id_offsets = ho; *ids = static_cast<int32_t *>(malloc(sizeof(int32_t)));
+    if (status) *status = static_cast<uint8_t *>(malloc(1));
     if (spans) { *begin = static_cast<uint32_t *>(malloc(sizeof(uint32_t))); *end = static_cast<uint32_t *>(malloc(sizeof(uint32_t))); }
     if (nspans) { *nbegin = static_cast<uint32_t *>(malloc(sizeof(uint32_t))); *nend = static_cast<uint32_t *>(malloc(sizeof(uint32_t))); }
     return kOk;
   }
   const uint64_t base = offsets[0], text_bytes = offsets[n] - base;
-  HIP_OR_RETURN(h, h->d_text.Reserve(text_bytes + 16));
-  HIP_OR_RETURN(h, h->d_offs.Reserve(n + 1));
-  HIP_OR_RETURN(h, h->d_id_offs.Reserve(n + 1));
-  if (text_bytes) HIP_OR_RETURN(h, hipMemcpyAsync(h->d_text.p, text + base, text_bytes, hipMemcpyHostToDevice, nullptr));
-  HIP_OR_RETURN(h, hipMemcpyAsync(h->d_offs.p, offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, nullptr));
-  // offsets are used as given: the kernels address text + offs[i], so rebase the text pointer instead
-  const uint8_t *d_text = h->d_text.p - base;
-  uint64_t cap = text_bytes / 2 + 4 * n + 64, total = 0;
+  auto hip_fail = [&](hipError_t e, const char *what) { drop(); return FailHip(h, e, what); };
+  hipError_t e = ws->d_text.Reserve(text_bytes + 32);
+  if (e == hipSuccess) e = ws->d_offs.Reserve(n + 1);
+  if (e == hipSuccess) e = ws->d_id_offs.Reserve(n + 1);
+  if (e == hipSuccess && status) e = ws->d_sent_status.Reserve(n);
+  if (e == hipSuccess && text_bytes) e = hipMemcpyAsync(ws->d_text.p, text + base, text_bytes, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(ws->d_offs.p, offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return hip_fail(e, "staging the batch");
+  // offsets are used as given: the kernels address text + offs[i], so rebase the text pointer instead (they read
+  // aligned 16-byte blocks of the absolute address: nothing before the staging buffer, at most 15 bytes of its slack after)
+  const uint8_t *d_text = ws->d_text.p - base;
+  uint64_t cap = text_bytes / 2 + 4 * n + 64, total = 0, failed = 0;
   int rc = kOk;
   for (int attempt = 0; attempt < 2; ++attempt) {
-    if (hipError_t e = h->d_ids.Reserve(cap); e != hipSuccess) { free(ho); return FailHip(h, e, "hipMalloc(ids)"); }
-    if (spans) {
-      hipError_t e = h->d_span_begin.Reserve(h->d_ids.cap);
-      if (e == hipSuccess) e = h->d_span_end.Reserve(h->d_ids.cap);
-      if (e == hipSuccess && nspans) e = h->d_nspan_begin.Reserve(h->d_ids.cap);
-      if (e == hipSuccess && nspans) e = h->d_nspan_end.Reserve(h->d_ids.cap);
-      if (e != hipSuccess) { free(ho); return FailHip(h, e, "hipMalloc(spans)"); }
-    }
-    rc = EncodeDevice(h, d_text, text_bytes, h->d_offs.p, n, h->d_ids.p, h->d_ids.cap, h->d_id_offs.p, nullptr, &total,
-                      spans ? h->d_span_begin.p : nullptr, spans ? h->d_span_end.p : nullptr,
-                      nspans ? h->d_nspan_begin.p : nullptr, nspans ? h->d_nspan_end.p : nullptr);
-    if (rc != kResourceExhausted || total <= h->d_ids.cap) break;
+    e = ws->d_ids.Reserve(cap);
+    if (e == hipSuccess && spans) e = ws->d_span_begin.Reserve(ws->d_ids.cap);
+    if (e == hipSuccess && spans) e = ws->d_span_end.Reserve(ws->d_ids.cap);
+    if (e == hipSuccess && nspans) e = ws->d_nspan_begin.Reserve(ws->d_ids.cap);
+    if (e == hipSuccess && nspans) e = ws->d_nspan_end.Reserve(ws->d_ids.cap);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(ids)");
+    rc = EncodeDevice(h, ws, d_text, text_bytes, ws->d_offs.p, n, ws->d_ids.p, ws->d_ids.cap, ws->d_id_offs.p,
+                      status ? ws->d_sent_status.p : nullptr, st, &total, &failed,
+                      spans ? ws->d_span_begin.p : nullptr, spans ? ws->d_span_end.p : nullptr,
+                      nspans ? ws->d_nspan_begin.p : nullptr, nspans ? ws->d_nspan_end.p : nullptr);
+    if (rc != kResourceExhausted || total <= ws->d_ids.cap) break;
     cap = total;
   }
-  if (rc != kOk) { free(ho); return rc; }
-  int32_t *hi = static_cast<int32_t *>(malloc((total ? total : 1) * sizeof(int32_t)));
-  if (!hi) { free(ho); return Fail(h, kResourceExhausted, "out of host memory"); }
-  hipError_t e = hipMemcpy(ho, h->d_id_offs.p, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost);
-  if (e == hipSuccess && total) e = hipMemcpy(hi, h->d_ids.p, total * sizeof(int32_t), hipMemcpyDeviceToHost);
-  if (e != hipSuccess) { free(ho); free(hi); return FailHip(h, e, "hipMemcpy(ids)"); }
-  if (spans) {
-    uint32_t *hb = static_cast<uint32_t *>(malloc((total ? total : 1) * sizeof(uint32_t)));
-    uint32_t *he = static_cast<uint32_t *>(malloc((total ? total : 1) * sizeof(uint32_t)));
-    if (!hb || !he) { free(ho); free(hi); free(hb); free(he); return Fail(h, kResourceExhausted, "out of host memory"); }
-    if (total) e = hipMemcpy(hb, h->d_span_begin.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost);
-    if (e == hipSuccess && total) e = hipMemcpy(he, h->d_span_end.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost);
-    if (e != hipSuccess) { free(ho); free(hi); free(hb); free(he); return FailHip(h, e, "hipMemcpy(spans)"); }
-    *begin = hb;
-    *end = he;
-    if (nspans) {
-      uint32_t *nb = static_cast<uint32_t *>(malloc((total ? total : 1) * sizeof(uint32_t)));
-      uint32_t *ne = static_cast<uint32_t *>(malloc((total ? total : 1) * sizeof(uint32_t)));
-      if (nb && ne && total) e = hipMemcpy(nb, h->d_nspan_begin.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost);
-      if (nb && ne && e == hipSuccess && total) e = hipMemcpy(ne, h->d_nspan_end.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost);
-      if (!nb || !ne || e != hipSuccess) {
-        free(ho); free(hi); free(hb); free(he); free(nb); free(ne);
-        *begin = nullptr; *end = nullptr;
-        return e != hipSuccess ? FailHip(h, e, "hipMemcpy(spans)") : Fail(h, kResourceExhausted, "out of host memory");
-      }
-      *nbegin = nb;
-      *nend = ne;
-    }
-  }
-  *ids = hi;
-  *id_offsets = ho;
+  if (rc != kOk) { drop(); return rc; }
+  const size_t tn = total ? total : 1;
+  int32_t *hi = static_cast<int32_t *>(outs[1] = malloc(tn * sizeof(int32_t)));
+  uint8_t *hs = status ? static_cast<uint8_t *>(outs[2] = malloc(n)) : nullptr;
+  uint32_t *hb = spans ? static_cast<uint32_t *>(outs[3] = malloc(tn * sizeof(uint32_t))) : nullptr;
+  uint32_t *he = spans ? static_cast<uint32_t *>(outs[4] = malloc(tn * sizeof(uint32_t))) : nullptr;
+  uint32_t *nb = nspans ? static_cast<uint32_t *>(outs[5] = malloc(tn * sizeof(uint32_t))) : nullptr;
+  uint32_t *ne = nspans ? static_cast<uint32_t *>(outs[6] = malloc(tn * sizeof(uint32_t))) : nullptr;
+  if (!hi || (status && !hs) || (spans && (!hb || !he)) || (nspans && (!nb || !ne))) { drop(); return Fail(h, kResourceExhausted, "out of host memory"); }
+  e = hipMemcpyAsync(ho, ws->d_id_offs.p, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && total) e = hipMemcpyAsync(hi, ws->d_ids.p, total * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && hs) e = hipMemcpyAsync(hs, ws->d_sent_status.p, n, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && hb && total) e = hipMemcpyAsync(hb, ws->d_span_begin.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && he && total) e = hipMemcpyAsync(he, ws->d_span_end.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && nb && total) e = hipMemcpyAsync(nb, ws->d_nspan_begin.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && ne && total) e = hipMemcpyAsync(ne, ws->d_nspan_end.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return hip_fail(e, "hipMemcpy(ids)");
+  *id_offsets = ho; *ids = hi;
+  if (status) *status = hs;
+  if (n_failed) *n_failed = failed;
+  if (spans) { *begin = hb; *end = he; }
+  if (nspans) { *nbegin = nb; *nend = ne; }
   return kOk;
 }
 }  // namespace
 
+int spmx_encode_batch_ex(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
+                         uint64_t **id_offsets, uint8_t **status, uint64_t *n_failed) {
+  return Guard(h, [&]() -> int { return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, status, n_failed, nullptr, nullptr); });
+}
+
 int spmx_encode_batch(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
                       uint64_t **id_offsets) {
-  return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, nullptr, nullptr);
+  return spmx_encode_batch_ex(h, text, offsets, n, ids, id_offsets, nullptr, nullptr);
 }
 
 int spmx_encode_batch_spans(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
                             uint64_t **id_offsets, uint32_t **begin, uint32_t **end, uint32_t **nbegin, uint32_t **nend) {
   if (h && (!begin || !end || (nbegin != nullptr) != (nend != nullptr))) return Fail(h, kInternal, "output container is null");
-  return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, begin, end, nbegin, nend);
+  return Guard(h, [&]() -> int { return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, nullptr, nullptr, begin, end, nbegin, nend); });
 }
 
 int spmx_encode_batch_spans_device(spmx_handle *h, const void *d_text, uint64_t text_bytes, const uint64_t *d_offsets,
@@ -941,184 +1156,199 @@ int spmx_encode_batch_spans_device(spmx_handle *h, const void *d_text, uint64_t 
                                    uint32_t *d_begin, uint32_t *d_end, uint32_t *d_nbegin, uint32_t *d_nend, void *stream,
                                    uint64_t *total_ids) {
   if (!h) return kInvalidArgument;
-  std::lock_guard<std::mutex> l(h->mu);
-  if (d_ids && (!d_begin || !d_end)) return Fail(h, kInvalidArgument, "null span buffers");
-  HIP_OR_RETURN(h, hipSetDevice(h->device));
-  return EncodeDevice(h, static_cast<const uint8_t *>(d_text), text_bytes, d_offsets, n, d_ids, ids_capacity,
-                      d_id_offsets, static_cast<hipStream_t>(stream), total_ids, d_begin, d_end, d_nbegin, d_nend);
+  return Guard(h, [&]() -> int {
+    if (d_ids && (!d_begin || !d_end)) return Fail(h, kInvalidArgument, "null span buffers");
+    HIP_OR_RETURN(h, hipSetDevice(h->device));
+    Lease L(h);
+    if (int rc = L.Ready(); rc != kOk) return rc;
+    return EncodeDevice(h, L.ws.get(), static_cast<const uint8_t *>(d_text), text_bytes, d_offsets, n, d_ids, ids_capacity,
+                        d_id_offsets, nullptr, static_cast<hipStream_t>(stream), total_ids, nullptr, d_begin, d_end, d_nbegin, d_nend);
+  });
 }
 
 // NBestEncode (kernels_nbest.h), host-buffer form.
 int spmx_nbest_encode_batch(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int nbest_size,
                             int32_t **ids, uint64_t **id_offsets, float **scores, uint64_t **result_offsets) {
   if (!h) return kInvalidArgument;
-  if (!ids || !id_offsets || !scores || !result_offsets) {
-    std::lock_guard<std::mutex> l(h->mu);
-    return Fail(h, kInternal, "output container is null");
-  }
+  if (!ids || !id_offsets || !scores || !result_offsets) return Fail(h, kInternal, "output container is null");
   *ids = nullptr; *id_offsets = nullptr; *scores = nullptr; *result_offsets = nullptr;
-  if (h->model.model_type != kUnigram) {
-    std::lock_guard<std::mutex> l(h->mu);
+  if (h->model.model_type != kUnigram)
     return Fail(h, kInternal, "NBestEncode is not available for the current model.");   // sentencepiece_processor.cc:662
-  }
   if (nbest_size > 1024) nbest_size = 1024;                                              // unigram_model.cc:692
   if (nbest_size < 1) nbest_size = 1;
-  if (nbest_size == 1 || n == 0) {          // :694-696 the plain encoder, score 0.0; one result per sentence
-    int32_t *i1 = nullptr;
-    uint64_t *o1 = nullptr;
-    const int rc = EncodeBatchHost(h, text, offsets, n, &i1, &o1, nullptr, nullptr);
-    if (rc != kOk) return rc;
-    uint64_t *ro = static_cast<uint64_t *>(malloc((n + 1) * sizeof(uint64_t)));
-    float *sc = static_cast<float *>(calloc(n + 1, sizeof(float)));
-    if (!ro || !sc) { free(i1); free(o1); free(ro); free(sc); std::lock_guard<std::mutex> l(h->mu); return Fail(h, kResourceExhausted, "out of host memory"); }
-    for (uint64_t s = 0; s <= n; ++s) ro[s] = s;
-    *ids = i1; *id_offsets = o1; *scores = sc; *result_offsets = ro;
-    return kOk;
-  }
-  std::lock_guard<std::mutex> l(h->mu);
-  if (!offsets) return Fail(h, kInvalidArgument, "null offsets");
-  HIP_OR_RETURN(h, hipSetDevice(h->device));
-  const uint64_t base = offsets[0], text_bytes = offsets[n] - base;
-  HIP_OR_RETURN(h, h->d_text.Reserve(text_bytes + 16));
-  HIP_OR_RETURN(h, h->d_offs.Reserve(n + 1));
-  HIP_OR_RETURN(h, h->d_id_offs.Reserve(n + 1));
-  if (text_bytes) HIP_OR_RETURN(h, hipMemcpyAsync(h->d_text.p, text + base, text_bytes, hipMemcpyHostToDevice, nullptr));
-  HIP_OR_RETURN(h, hipMemcpyAsync(h->d_offs.p, offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, nullptr));
-  const uint8_t *d_text = h->d_text.p - base;
-  uint64_t ncap = 2 * text_bytes + 4 * n + 64, ntotal = 0;
-  int rc = kOk;
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    HIP_OR_RETURN(h, h->d_norm.Reserve(ncap));
-    rc = NormalizeDevice(h, d_text, h->d_offs.p, n, h->d_norm.p, h->d_norm.cap, h->d_id_offs.p, nullptr, nullptr, &ntotal, true);
-    if (rc != kResourceExhausted || ntotal <= h->d_norm.cap) break;
-    ncap = ntotal;
-  }
-  if (rc != kOk) return rc;
-  const uint32_t K = static_cast<uint32_t>(nbest_size);
-  NBestArgs a{};
-  a.dev = h->dev; a.norm = h->d_norm.p; a.norm_offs = h->d_id_offs.p; a.n = static_cast<uint32_t>(n); a.nbest = K;
-  uint64_t hyps = static_cast<uint64_t>(K) * 2048;
-  a.max_hyps = static_cast<uint32_t>(hyps < 16384 ? 16384 : (hyps > 262144 ? 262144 : hyps));
-  a.lane_bytes = (NbestLaneBytes(a.max_hyps) + 15) / 16 * 16;
-  uint64_t waves = (n + 63) / 64;
-  const uint64_t budget = 8ull << 30;                       // HBM for the lanes' slices
-  if (waves * 64 * a.lane_bytes > budget) waves = budget / (64 * a.lane_bytes);
-  if (waves > static_cast<uint64_t>(h->n_cu) * 8) waves = static_cast<uint64_t>(h->n_cu) * 8;
-  if (waves < 1) waves = 1;
-  HIP_OR_RETURN(h, h->d_nbest_scratch.Reserve(waves * 64 * a.lane_bytes));
-  HIP_OR_RETURN(h, h->d_res_off.Reserve(n * K + 1));
-  HIP_OR_RETURN(h, h->d_span_begin.Reserve(n * K + 1));     // result lengths
-  HIP_OR_RETURN(h, h->d_res_score.Reserve(n * K + 1));
-  HIP_OR_RETURN(h, h->d_counts.Reserve(n + 1));
-  a.scratch = h->d_nbest_scratch.p;
-  a.res_off = h->d_res_off.p; a.res_len = h->d_span_begin.p; a.res_score = h->d_res_score.p; a.res_count = h->d_counts.p;
-  a.status = &h->d_ctrl->status; a.arena_head = &h->d_ctrl->arena_head;
-  uint64_t arena_need = (ntotal + (4 + static_cast<uint64_t>(h->dev.n_prefix + h->dev.n_suffix)) * n) * (K < 8 ? K : 8) + 1024;
-  for (int attempt = 0; attempt < 3; ++attempt) {
-    HIP_OR_RETURN(h, h->d_arena.Reserve(arena_need));
-    a.arena = h->d_arena.p; a.arena_cap = h->d_arena.cap;
-    HIP_OR_RETURN(h, hipMemsetAsync(h->d_ctrl, 0, sizeof(Ctrl), nullptr));
-    HIP_OR_RETURN(h, LaunchNBest(a, static_cast<int>(waves), nullptr));
-    HIP_OR_RETURN(h, hipMemcpyAsync(h->h_ctrl, h->d_ctrl, offsetof(Ctrl, total_ids), hipMemcpyDeviceToHost, nullptr));
-    HIP_OR_RETURN(h, hipStreamSynchronize(nullptr));
-    const uint32_t st = h->h_ctrl->status;
-    if (st & kStTooLong) return Fail(h, kOutOfRange, "NBestEncode on the device is limited to 1024 normalized bytes per sentence");
-    if (st & kStNbestOverflow) return Fail(h, kResourceExhausted, "NBestEncode: the lattice or the agenda of a sentence exceeds the device capacities");
-    if (st & kStArenaOverflow) { arena_need = h->h_ctrl->arena_head + 1024; continue; }
-    // results -> host CSR
-    std::vector<uint32_t> cnt(n), len(n * K);
-    std::vector<unsigned long long> off(n * K);
-    std::vector<float> sc(n * K);
-    const uint64_t used = h->h_ctrl->arena_head;
-    std::vector<int32_t> arena(used ? used : 1);
-    HIP_OR_RETURN(h, hipMemcpy(cnt.data(), h->d_counts.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    HIP_OR_RETURN(h, hipMemcpy(len.data(), h->d_span_begin.p, n * K * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    HIP_OR_RETURN(h, hipMemcpy(off.data(), h->d_res_off.p, n * K * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    HIP_OR_RETURN(h, hipMemcpy(sc.data(), h->d_res_score.p, n * K * sizeof(float), hipMemcpyDeviceToHost));
-    if (used) HIP_OR_RETURN(h, hipMemcpy(arena.data(), h->d_arena.p, used * sizeof(int32_t), hipMemcpyDeviceToHost));
-    uint64_t R = 0, total = 0;
-    for (uint64_t s = 0; s < n; ++s) for (uint32_t k = 0; k < cnt[s]; ++k) { ++R; total += len[s * K + k]; }
-    int32_t *hi = static_cast<int32_t *>(malloc((total ? total : 1) * sizeof(int32_t)));
-    uint64_t *ho = static_cast<uint64_t *>(malloc((R + 1) * sizeof(uint64_t)));
-    float *hs = static_cast<float *>(malloc((R ? R : 1) * sizeof(float)));
-    uint64_t *hr = static_cast<uint64_t *>(malloc((n + 1) * sizeof(uint64_t)));
-    if (!hi || !ho || !hs || !hr) { free(hi); free(ho); free(hs); free(hr); return Fail(h, kResourceExhausted, "out of host memory"); }
-    uint64_t r = 0, t = 0;
-    for (uint64_t s = 0; s < n; ++s) {
-      hr[s] = r;
-      for (uint32_t k = 0; k < cnt[s]; ++k) {
-        ho[r] = t;
-        hs[r] = sc[s * K + k];
-        const uint32_t ln = len[s * K + k];
-        if (ln) memcpy(hi + t, arena.data() + off[s * K + k], ln * sizeof(int32_t));
-        t += ln;
-        ++r;
-      }
+  return Guard(h, [&]() -> int {
+    if (nbest_size == 1 || n == 0) {          // :694-696 the plain encoder, score 0.0; one result per sentence
+      int32_t *i1 = nullptr;
+      uint64_t *o1 = nullptr;
+      const int rc = EncodeBatchHost(h, text, offsets, n, &i1, &o1, nullptr, nullptr, nullptr, nullptr);
+      if (rc != kOk) return rc;
+      uint64_t *ro = static_cast<uint64_t *>(malloc((n + 1) * sizeof(uint64_t)));
+      float *sc = static_cast<float *>(calloc(n + 1, sizeof(float)));
+      if (!ro || !sc) { free(i1); free(o1); free(ro); free(sc); return Fail(h, kResourceExhausted, "out of host memory"); }
+      for (uint64_t s = 0; s <= n; ++s) ro[s] = s;
+      *ids = i1; *id_offsets = o1; *scores = sc; *result_offsets = ro;
+      return kOk;
     }
-    hr[n] = r;
-    ho[r] = t;
-    *ids = hi; *id_offsets = ho; *scores = hs; *result_offsets = hr;
-    return kOk;
-  }
-  return Fail(h, kInternal, "id arena kept overflowing");
+    if (!offsets) return Fail(h, kInvalidArgument, "null offsets");
+    HIP_OR_RETURN(h, hipSetDevice(h->device));
+    Lease L(h);
+    if (int rc = L.Ready(); rc != kOk) return rc;
+    Workspace *ws = L.ws.get();
+    hipStream_t st = ws->stream;
+    const uint64_t base = offsets[0], text_bytes = offsets[n] - base;
+    HIP_OR_RETURN(h, ws->d_text.Reserve(text_bytes + 32));
+    HIP_OR_RETURN(h, ws->d_offs.Reserve(n + 1));
+    HIP_OR_RETURN(h, ws->d_id_offs.Reserve(n + 1));
+    if (text_bytes) HIP_OR_RETURN(h, hipMemcpyAsync(ws->d_text.p, text + base, text_bytes, hipMemcpyHostToDevice, st));
+    HIP_OR_RETURN(h, hipMemcpyAsync(ws->d_offs.p, offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    const uint8_t *d_text = ws->d_text.p - base;
+    uint64_t ncap = 2 * text_bytes + 4 * n + 64, ntotal = 0;
+    int rc = kOk;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      HIP_OR_RETURN(h, ws->d_norm.Reserve(ncap));
+      rc = NormalizeDevice(h, ws, d_text, ws->d_offs.p, n, ws->d_norm.p, ws->d_norm.cap, ws->d_id_offs.p, nullptr, st, &ntotal, true);
+      if (rc != kResourceExhausted || ntotal <= ws->d_norm.cap) break;
+      ncap = ntotal;
+    }
+    if (rc != kOk) return rc;
+    const uint32_t K = static_cast<uint32_t>(nbest_size);
+    if (n * K + 1 > (1ull << 32)) return Fail(h, kInvalidArgument, "too many results for one batch");
+    NBestArgs a{};
+    a.dev = h->dev; a.norm = ws->d_norm.p; a.norm_offs = ws->d_id_offs.p; a.n = static_cast<uint32_t>(n); a.nbest = K;
+    uint64_t hyps = static_cast<uint64_t>(K) * 2048;
+    a.max_hyps = static_cast<uint32_t>(hyps < 16384 ? 16384 : (hyps > 262144 ? 262144 : hyps));
+    a.lane_bytes = (NbestLaneBytes(a.max_hyps) + 15) / 16 * 16;
+    uint64_t waves = (n + 63) / 64;
+    const uint64_t budget = 8ull << 30;                       // HBM for the lanes' slices
+    if (waves * 64 * a.lane_bytes > budget) waves = budget / (64 * a.lane_bytes);
+    if (waves > static_cast<uint64_t>(h->n_cu) * 8) waves = static_cast<uint64_t>(h->n_cu) * 8;
+    if (waves < 1) waves = 1;
+    HIP_OR_RETURN(h, ws->d_nbest_scratch.Reserve(waves * 64 * a.lane_bytes));
+    HIP_OR_RETURN(h, ws->d_res_off.Reserve(n * K + 1));
+    HIP_OR_RETURN(h, ws->d_span_begin.Reserve(n * K + 1));     // result lengths
+    HIP_OR_RETURN(h, ws->d_res_score.Reserve(n * K + 1));
+    HIP_OR_RETURN(h, ws->d_counts.Reserve(n + 1));
+    a.scratch = ws->d_nbest_scratch.p;
+    a.res_off = ws->d_res_off.p; a.res_len = ws->d_span_begin.p; a.res_score = ws->d_res_score.p; a.res_count = ws->d_counts.p;
+    a.status = &ws->d_ctrl->status; a.arena_head = &ws->d_ctrl->arena_head;
+    uint64_t arena_need = (ntotal + (4 + static_cast<uint64_t>(h->dev.n_prefix + h->dev.n_suffix)) * n) * (K < 8 ? K : 8) + 1024;
+    for (int attempt = 0; attempt < 12; ++attempt) {
+      HIP_OR_RETURN(h, ws->d_arena.Reserve(arena_need));
+      a.arena = ws->d_arena.p; a.arena_cap = ws->d_arena.cap;
+      HIP_OR_RETURN(h, hipMemsetAsync(ws->d_ctrl, 0, sizeof(Ctrl), st));
+      HIP_OR_RETURN(h, LaunchNBest(a, static_cast<int>(waves), st));
+      HIP_OR_RETURN(h, hipMemcpyAsync(ws->h_ctrl, ws->d_ctrl, offsetof(Ctrl, total_ids), hipMemcpyDeviceToHost, st));
+      HIP_OR_RETURN(h, hipStreamSynchronize(st));
+      const uint32_t stw = ws->h_ctrl->status;
+      if (stw & kStTooLong) return Fail(h, kOutOfRange, "NBestEncode on the device is limited to 1024 normalized bytes per sentence");
+      if (stw & kStNbestOverflow) return Fail(h, kResourceExhausted, "NBestEncode: the lattice or the agenda of a sentence exceeds the device capacities");
+      // (a lane stops at its first result that does not fit, so arena_head is a lower bound: grow geometrically)
+      if (stw & kStArenaOverflow) { arena_need = 4 * ws->d_arena.cap > ws->h_ctrl->arena_head + 1024 ? 4 * ws->d_arena.cap : ws->h_ctrl->arena_head + 1024; continue; }
+      // results -> host CSR
+      std::vector<uint32_t> cnt(n), len(n * K);
+      std::vector<unsigned long long> off(n * K);
+      std::vector<float> sc(n * K);
+      const uint64_t used = ws->h_ctrl->arena_head;
+      std::vector<int32_t> arena(used ? used : 1);
+      HIP_OR_RETURN(h, hipMemcpy(cnt.data(), ws->d_counts.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      HIP_OR_RETURN(h, hipMemcpy(len.data(), ws->d_span_begin.p, n * K * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      HIP_OR_RETURN(h, hipMemcpy(off.data(), ws->d_res_off.p, n * K * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      HIP_OR_RETURN(h, hipMemcpy(sc.data(), ws->d_res_score.p, n * K * sizeof(float), hipMemcpyDeviceToHost));
+      if (used) HIP_OR_RETURN(h, hipMemcpy(arena.data(), ws->d_arena.p, used * sizeof(int32_t), hipMemcpyDeviceToHost));
+      uint64_t R = 0, total = 0;
+      for (uint64_t s = 0; s < n; ++s) for (uint32_t k = 0; k < cnt[s]; ++k) { ++R; total += len[s * K + k]; }
+      int32_t *hi = static_cast<int32_t *>(malloc((total ? total : 1) * sizeof(int32_t)));
+      uint64_t *ho = static_cast<uint64_t *>(malloc((R + 1) * sizeof(uint64_t)));
+      float *hs = static_cast<float *>(malloc((R ? R : 1) * sizeof(float)));
+      uint64_t *hr = static_cast<uint64_t *>(malloc((n + 1) * sizeof(uint64_t)));
+      if (!hi || !ho || !hs || !hr) { free(hi); free(ho); free(hs); free(hr); return Fail(h, kResourceExhausted, "out of host memory"); }
+      uint64_t r = 0, t = 0;
+      for (uint64_t s = 0; s < n; ++s) {
+        hr[s] = r;
+        for (uint32_t k = 0; k < cnt[s]; ++k) {
+          ho[r] = t;
+          hs[r] = sc[s * K + k];
+          const uint32_t ln = len[s * K + k];
+          if (ln) memcpy(hi + t, arena.data() + off[s * K + k], ln * sizeof(int32_t));
+          t += ln;
+          ++r;
+        }
+      }
+      hr[n] = r;
+      ho[r] = t;
+      *ids = hi; *id_offsets = ho; *scores = hs; *result_offsets = hr;
+      return kOk;
+    }
+    return Fail(h, kInternal, "id arena kept overflowing");
+  });
 }
 
 int spmx_normalize_batch_device(spmx_handle *h, const void *d_text, const uint64_t *d_offsets, uint64_t n, void *d_norm,
                                 uint64_t norm_capacity, uint64_t *d_norm_offsets, uint32_t *d_norm_to_orig, void *stream,
                                 uint64_t *total_bytes) {
   if (!h) return kInvalidArgument;
-  std::lock_guard<std::mutex> l(h->mu);
-  HIP_OR_RETURN(h, hipSetDevice(h->device));
-  return NormalizeDevice(h, static_cast<const uint8_t *>(d_text), d_offsets, n, static_cast<uint8_t *>(d_norm), norm_capacity,
-                         d_norm_offsets, d_norm_to_orig, static_cast<hipStream_t>(stream), total_bytes);
+  return Guard(h, [&]() -> int {
+    HIP_OR_RETURN(h, hipSetDevice(h->device));
+    Lease L(h);
+    if (int rc = L.Ready(); rc != kOk) return rc;
+    return NormalizeDevice(h, L.ws.get(), static_cast<const uint8_t *>(d_text), d_offsets, n, static_cast<uint8_t *>(d_norm),
+                           norm_capacity, d_norm_offsets, d_norm_to_orig, static_cast<hipStream_t>(stream), total_bytes);
+  });
 }
 
 int spmx_normalize_batch(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, char **norm,
                          uint64_t **norm_offsets, uint32_t **norm_to_orig) {
   if (!h) return kInvalidArgument;
-  std::lock_guard<std::mutex> l(h->mu);
   if (!norm || !norm_offsets) return Fail(h, kInternal, "output container is null");
   *norm = nullptr; *norm_offsets = nullptr;
   if (norm_to_orig) *norm_to_orig = nullptr;
   if (n && !offsets) return Fail(h, kInvalidArgument, "null offsets");
-  HIP_OR_RETURN(h, hipSetDevice(h->device));
-  uint64_t *ho = static_cast<uint64_t *>(malloc((n + 1) * sizeof(uint64_t)));
-  if (!ho) return Fail(h, kResourceExhausted, "out of host memory");
-  if (n == 0) {
-    ho[0] = 0; *norm_offsets = ho; *norm = static_cast<char *>(malloc(1));
-    if (norm_to_orig) *norm_to_orig = static_cast<uint32_t *>(malloc(sizeof(uint32_t)));
+  return Guard(h, [&]() -> int {
+    HIP_OR_RETURN(h, hipSetDevice(h->device));
+    Lease L(h);
+    if (int rc = L.Ready(); rc != kOk) return rc;
+    Workspace *ws = L.ws.get();
+    hipStream_t st = ws->stream;
+    uint64_t *ho = static_cast<uint64_t *>(malloc((n + 1) * sizeof(uint64_t)));
+    if (!ho) return Fail(h, kResourceExhausted, "out of host memory");
+    if (n == 0) {
+      ho[0] = 0; *norm_offsets = ho; *norm = static_cast<char *>(malloc(1));
+      if (norm_to_orig) *norm_to_orig = static_cast<uint32_t *>(malloc(sizeof(uint32_t)));
+      return kOk;
+    }
+    const uint64_t base = offsets[0], text_bytes = offsets[n] - base;
+    hipError_t e = ws->d_text.Reserve(text_bytes + 32);
+    if (e == hipSuccess) e = ws->d_offs.Reserve(n + 1);
+    if (e == hipSuccess) e = ws->d_id_offs.Reserve(n + 1);
+    if (e == hipSuccess && text_bytes) e = hipMemcpyAsync(ws->d_text.p, text + base, text_bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(ws->d_offs.p, offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) { free(ho); return FailHip(h, e, "staging the batch"); }
+    const uint8_t *d_text = ws->d_text.p - base;
+    uint64_t cap = 2 * text_bytes + 4 * n + 64, total = 0;
+    int rc = kOk;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      e = ws->d_norm.Reserve(cap);
+      if (e == hipSuccess && norm_to_orig) e = ws->d_span_begin.Reserve(cap + n + 1);
+      if (e != hipSuccess) { free(ho); return FailHip(h, e, "hipMalloc(norm)"); }
+      rc = NormalizeDevice(h, ws, d_text, ws->d_offs.p, n, ws->d_norm.p, ws->d_norm.cap, ws->d_id_offs.p,
+                           norm_to_orig ? ws->d_span_begin.p : nullptr, st, &total);
+      if (rc != kResourceExhausted || total <= ws->d_norm.cap) break;
+      cap = total;
+    }
+    if (rc != kOk) { free(ho); return rc; }
+    char *ht = static_cast<char *>(malloc(total ? total : 1));
+    uint32_t *hn = norm_to_orig ? static_cast<uint32_t *>(malloc((total + n + 1) * sizeof(uint32_t))) : nullptr;
+    if (!ht || (norm_to_orig && !hn)) { free(ho); free(ht); free(hn); return Fail(h, kResourceExhausted, "out of host memory"); }
+    e = hipMemcpyAsync(ho, ws->d_id_offs.p, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && total) e = hipMemcpyAsync(ht, ws->d_norm.p, total, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && hn) e = hipMemcpyAsync(hn, ws->d_span_begin.p, (total + n) * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { free(ho); free(ht); free(hn); return FailHip(h, e, "hipMemcpy(norm)"); }
+    *norm = ht;
+    *norm_offsets = ho;
+    if (norm_to_orig) *norm_to_orig = hn;
     return kOk;
-  }
-  const uint64_t base = offsets[0], text_bytes = offsets[n] - base;
-  HIP_OR_RETURN(h, h->d_text.Reserve(text_bytes + 16));
-  HIP_OR_RETURN(h, h->d_offs.Reserve(n + 1));
-  HIP_OR_RETURN(h, h->d_id_offs.Reserve(n + 1));
-  if (text_bytes) HIP_OR_RETURN(h, hipMemcpyAsync(h->d_text.p, text + base, text_bytes, hipMemcpyHostToDevice, nullptr));
-  HIP_OR_RETURN(h, hipMemcpyAsync(h->d_offs.p, offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, nullptr));
-  const uint8_t *d_text = h->d_text.p - base;
-  uint64_t cap = 2 * text_bytes + 4 * n + 64, total = 0;
-  int rc = kOk;
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    hipError_t e = h->d_norm.Reserve(cap);
-    if (e == hipSuccess && norm_to_orig) e = h->d_span_begin.Reserve(cap + n + 1);
-    if (e != hipSuccess) { free(ho); return FailHip(h, e, "hipMalloc(norm)"); }
-    rc = NormalizeDevice(h, d_text, h->d_offs.p, n, h->d_norm.p, h->d_norm.cap, h->d_id_offs.p,
-                         norm_to_orig ? h->d_span_begin.p : nullptr, nullptr, &total);
-    if (rc != kResourceExhausted || total <= h->d_norm.cap) break;
-    cap = total;
-  }
-  if (rc != kOk) { free(ho); return rc; }
-  char *ht = static_cast<char *>(malloc(total ? total : 1));
-  uint32_t *hn = norm_to_orig ? static_cast<uint32_t *>(malloc((total + n + 1) * sizeof(uint32_t))) : nullptr;
-  if (!ht || (norm_to_orig && !hn)) { free(ho); free(ht); free(hn); return Fail(h, kResourceExhausted, "out of host memory"); }
-  hipError_t e = hipMemcpy(ho, h->d_id_offs.p, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost);
-  if (e == hipSuccess && total) e = hipMemcpy(ht, h->d_norm.p, total, hipMemcpyDeviceToHost);
-  if (e == hipSuccess && hn) e = hipMemcpy(hn, h->d_span_begin.p, (total + n) * sizeof(uint32_t), hipMemcpyDeviceToHost);
-  if (e != hipSuccess) { free(ho); free(ht); free(hn); return FailHip(h, e, "hipMemcpy(norm)"); }
-  *norm = ht;
-  *norm_offsets = ho;
-  if (norm_to_orig) *norm_to_orig = hn;
-  return kOk;
+  });
 }
 
 void spmx_free(void *p) { free(p); }
@@ -1129,64 +1359,76 @@ int spmx_encode(spmx_handle *h, const char *text, uint64_t len, int32_t *ids, ui
   const uint64_t offs[2] = {0, len};
   int32_t *out = nullptr;
   uint64_t *oo = nullptr;
-  const int rc = spmx_encode_batch(h, text ? text : "", offs, 1, &out, &oo);
+  uint8_t *st = nullptr;
+  uint64_t failed = 0;
+  const int rc = spmx_encode_batch_ex(h, text ? text : "", offs, 1, &out, &oo, &st, &failed);
   if (rc != kOk) return rc;
   const uint64_t total = oo[1];
   *n_ids = total;
   int ret = kOk;
-  if (total > cap) ret = Fail(h, kResourceExhausted, "ids buffer is too small");
+  if (failed && st[0]) ret = Fail(h, st[0], StatusText(st[0]));           // Encode(input, &ids) returns the Status
+  else if (total > cap) ret = Fail(h, kResourceExhausted, "ids buffer is too small");
   else if (total) memcpy(ids, out, total * sizeof(int32_t));
   free(out);
   free(oo);
+  free(st);
   return ret;
 }
 
 int spmx_decode_batch_device(spmx_handle *h, const int32_t *d_ids, const uint64_t *d_id_offsets, uint64_t n, void *d_text,
                              uint64_t text_capacity, uint64_t *d_text_offsets, void *stream, uint64_t *total_bytes) {
   if (!h) return kInvalidArgument;
-  std::lock_guard<std::mutex> l(h->mu);
-  HIP_OR_RETURN(h, hipSetDevice(h->device));
-  return DecodeDevice(h, d_ids, d_id_offsets, n, static_cast<uint8_t *>(d_text), text_capacity, d_text_offsets,
-                      static_cast<hipStream_t>(stream), total_bytes);
+  return Guard(h, [&]() -> int {
+    HIP_OR_RETURN(h, hipSetDevice(h->device));
+    Lease L(h);
+    if (int rc = L.Ready(); rc != kOk) return rc;
+    return DecodeDevice(h, L.ws.get(), d_ids, d_id_offsets, n, static_cast<uint8_t *>(d_text), text_capacity, d_text_offsets,
+                        static_cast<hipStream_t>(stream), total_bytes);
+  });
 }
 
 int spmx_decode_batch(spmx_handle *h, const int32_t *ids, const uint64_t *id_offsets, uint64_t n, char **text,
                       uint64_t **text_offsets) {
   if (!h) return kInvalidArgument;
-  std::lock_guard<std::mutex> l(h->mu);
   if (!text || !text_offsets) return Fail(h, kInternal, "output container is null");
   *text = nullptr; *text_offsets = nullptr;
   if (n && !id_offsets) return Fail(h, kInvalidArgument, "null offsets");
-  HIP_OR_RETURN(h, hipSetDevice(h->device));
-  uint64_t *ho = static_cast<uint64_t *>(malloc((n + 1) * sizeof(uint64_t)));
-  if (!ho) return Fail(h, kResourceExhausted, "out of host memory");
-  if (n == 0) { ho[0] = 0; *text_offsets = ho; *text = static_cast<char *>(malloc(1)); return kOk; }
-  const uint64_t base = id_offsets[0], n_ids = id_offsets[n] - base;
-  if (hipError_t e = h->d_ids.Reserve(n_ids + 16); e != hipSuccess) { free(ho); return FailHip(h, e, "hipMalloc(ids)"); }
-  if (hipError_t e = h->d_offs.Reserve(n + 1); e != hipSuccess) { free(ho); return FailHip(h, e, "hipMalloc(offsets)"); }
-  if (hipError_t e = h->d_id_offs.Reserve(n + 1); e != hipSuccess) { free(ho); return FailHip(h, e, "hipMalloc(offsets)"); }
-  hipError_t e = hipSuccess;
-  if (n_ids) e = hipMemcpyAsync(h->d_ids.p, ids + base, n_ids * sizeof(int32_t), hipMemcpyHostToDevice, nullptr);
-  if (e == hipSuccess) e = hipMemcpyAsync(h->d_offs.p, id_offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, nullptr);
-  if (e != hipSuccess) { free(ho); return FailHip(h, e, "hipMemcpy(ids)"); }
-  const int32_t *d_ids = h->d_ids.p - base;     // the kernels address ids + id_offsets[i]
-  uint64_t cap = n_ids * 6 + 64, total = 0;
-  int rc = kOk;
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    if (hipError_t e2 = h->d_text.Reserve(cap); e2 != hipSuccess) { free(ho); return FailHip(h, e2, "hipMalloc(text)"); }
-    rc = DecodeDevice(h, d_ids, h->d_offs.p, n, h->d_text.p, h->d_text.cap, h->d_id_offs.p, nullptr, &total);
-    if (rc != kResourceExhausted || total <= h->d_text.cap) break;
-    cap = total;
-  }
-  if (rc != kOk) { free(ho); return rc; }
-  char *ht = static_cast<char *>(malloc(total ? total : 1));
-  if (!ht) { free(ho); return Fail(h, kResourceExhausted, "out of host memory"); }
-  e = hipMemcpy(ho, h->d_id_offs.p, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost);
-  if (e == hipSuccess && total) e = hipMemcpy(ht, h->d_text.p, total, hipMemcpyDeviceToHost);
-  if (e != hipSuccess) { free(ho); free(ht); return FailHip(h, e, "hipMemcpy(text)"); }
-  *text = ht;
-  *text_offsets = ho;
-  return kOk;
+  return Guard(h, [&]() -> int {
+    HIP_OR_RETURN(h, hipSetDevice(h->device));
+    Lease L(h);
+    if (int rc = L.Ready(); rc != kOk) return rc;
+    Workspace *ws = L.ws.get();
+    hipStream_t st = ws->stream;
+    uint64_t *ho = static_cast<uint64_t *>(malloc((n + 1) * sizeof(uint64_t)));
+    if (!ho) return Fail(h, kResourceExhausted, "out of host memory");
+    if (n == 0) { ho[0] = 0; *text_offsets = ho; *text = static_cast<char *>(malloc(1)); return kOk; }
+    const uint64_t base = id_offsets[0], n_ids = id_offsets[n] - base;
+    hipError_t e = ws->d_ids.Reserve(n_ids + 16);
+    if (e == hipSuccess) e = ws->d_offs.Reserve(n + 1);
+    if (e == hipSuccess) e = ws->d_id_offs.Reserve(n + 1);
+    if (e == hipSuccess && n_ids) e = hipMemcpyAsync(ws->d_ids.p, ids + base, n_ids * sizeof(int32_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(ws->d_offs.p, id_offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) { free(ho); return FailHip(h, e, "staging the ids"); }
+    const int32_t *d_ids = ws->d_ids.p - base;     // the kernels address ids + id_offsets[i]
+    uint64_t cap = n_ids * 6 + 64, total = 0;
+    int rc = kOk;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      if (hipError_t e2 = ws->d_text.Reserve(cap); e2 != hipSuccess) { free(ho); return FailHip(h, e2, "hipMalloc(text)"); }
+      rc = DecodeDevice(h, ws, d_ids, ws->d_offs.p, n, ws->d_text.p, ws->d_text.cap, ws->d_id_offs.p, st, &total);
+      if (rc != kResourceExhausted || total <= ws->d_text.cap) break;
+      cap = total;
+    }
+    if (rc != kOk) { free(ho); return rc; }
+    char *ht = static_cast<char *>(malloc(total ? total : 1));
+    if (!ht) { free(ho); return Fail(h, kResourceExhausted, "out of host memory"); }
+    e = hipMemcpyAsync(ho, ws->d_id_offs.p, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && total) e = hipMemcpyAsync(ht, ws->d_text.p, total, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { free(ho); free(ht); return FailHip(h, e, "hipMemcpy(text)"); }
+    *text = ht;
+    *text_offsets = ho;
+    return kOk;
+  });
 }
 
 int spmx_decode(spmx_handle *h, const int32_t *ids, uint64_t n_ids, char *out, uint64_t cap, uint64_t *len) {
@@ -1212,47 +1454,51 @@ int spmx_split_lines_device(spmx_handle *h, const void *d_file, uint64_t bytes, 
                             uint64_t *d_offsets, uint64_t offsets_capacity, void *stream_v, uint64_t *n_lines,
                             uint64_t *text_bytes) {
   if (!h) return kInvalidArgument;
-  std::lock_guard<std::mutex> l(h->mu);
   if (n_lines) *n_lines = 0;
   if (text_bytes) *text_bytes = 0;
   if (!n_lines || !text_bytes) return Fail(h, kInternal, "output container is null");
   if (bytes && (!d_file || (reinterpret_cast<uintptr_t>(d_file) & 15u))) return Fail(h, kInvalidArgument, "d_file must be 16-byte aligned");
-  HIP_OR_RETURN(h, hipSetDevice(h->device));
-  hipStream_t stream = static_cast<hipStream_t>(stream_v);
-  if (bytes == 0) {
-    if (d_offsets && offsets_capacity) HIP_OR_RETURN(h, hipMemsetAsync(d_offsets, 0, sizeof(uint64_t), stream));
+  return Guard(h, [&]() -> int {
+    HIP_OR_RETURN(h, hipSetDevice(h->device));
+    Lease L(h);
+    if (int rc = L.Ready(); rc != kOk) return rc;
+    Workspace *ws = L.ws.get();
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    if (bytes == 0) {
+      if (d_offsets && offsets_capacity) HIP_OR_RETURN(h, hipMemsetAsync(d_offsets, 0, sizeof(uint64_t), stream));
+      HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+      return kOk;
+    }
+    const uint64_t chunks = (bytes + kSplitChunk - 1) / kSplitChunk;
+    if (chunks >= (1ull << 32) - 64) return Fail(h, kInvalidArgument, "file image too large for one call");
+    HIP_OR_RETURN(h, ws->d_counts.Reserve(chunks + 1));
+    HIP_OR_RETURN(h, ws->d_chunk_base.Reserve(chunks + 1));
+    HIP_OR_RETURN(h, ws->d_tile_sums.Reserve((chunks + kScanTile - 1) / kScanTile + 2));
+    SplitArgs a{};
+    a.file = static_cast<const uint8_t *>(d_file); a.bytes = bytes; a.counts = ws->d_counts.p;
+    a.chunk_base = ws->d_chunk_base.p; a.text = static_cast<uint8_t *>(d_text); a.offsets = d_offsets;
+    const uint64_t wide = static_cast<uint64_t>(h->n_cu) * 16;
+    const int grid = static_cast<int>(chunks < wide ? chunks : wide);
+    HIP_OR_RETURN(h, LaunchSplit(false, a, grid, stream));
+    {
+      ScanArgs sa{ws->d_counts.p, static_cast<uint32_t>(chunks), ws->d_tile_sums.p, ws->d_chunk_base.p};
+      const uint32_t tiles = (static_cast<uint32_t>(chunks) + kScanTile - 1) / kScanTile;
+      HIP_OR_RETURN(h, LaunchScan(sa, static_cast<int>(tiles < static_cast<uint32_t>(h->n_cu * 8) ? tiles : h->n_cu * 8), stream));
+    }
+    HIP_OR_RETURN(h, hipMemcpyAsync(&ws->h_ctrl->total_ids, ws->d_chunk_base.p + chunks, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_OR_RETURN(h, hipMemcpyAsync(&ws->h_ctrl->pad, static_cast<const uint8_t *>(d_file) + bytes - 1, 1, hipMemcpyDeviceToHost, stream));
+    HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+    const uint8_t last = *reinterpret_cast<const uint8_t *>(&ws->h_ctrl->pad);
+    const uint64_t nl = ws->h_ctrl->total_ids;
+    const uint64_t lines = nl + (last != 0x0A ? 1 : 0);      // std::getline: a last line without '\n' counts
+    *n_lines = lines;
+    *text_bytes = bytes - nl;
+    if (!d_text || !d_offsets || text_capacity < bytes - nl || offsets_capacity < lines + 1)
+      return Fail(h, kResourceExhausted, "text_capacity / offsets_capacity is too small");
+    HIP_OR_RETURN(h, LaunchSplit(true, a, grid, stream));
     HIP_OR_RETURN(h, hipStreamSynchronize(stream));
     return kOk;
-  }
-  const uint64_t chunks = (bytes + kSplitChunk - 1) / kSplitChunk;
-  if (chunks >= (1ull << 32) - 64) return Fail(h, kInvalidArgument, "file image too large for one call");
-  HIP_OR_RETURN(h, h->d_counts.Reserve(chunks + 1));
-  HIP_OR_RETURN(h, h->d_chunk_base.Reserve(chunks + 1));
-  HIP_OR_RETURN(h, h->d_tile_sums.Reserve((chunks + kScanTile - 1) / kScanTile + 2));
-  SplitArgs a{};
-  a.file = static_cast<const uint8_t *>(d_file); a.bytes = bytes; a.counts = h->d_counts.p;
-  a.chunk_base = h->d_chunk_base.p; a.text = static_cast<uint8_t *>(d_text); a.offsets = d_offsets;
-  const uint64_t wide = static_cast<uint64_t>(h->n_cu) * 16;
-  const int grid = static_cast<int>(chunks < wide ? chunks : wide);
-  HIP_OR_RETURN(h, LaunchSplit(false, a, grid, stream));
-  {
-    ScanArgs sa{h->d_counts.p, static_cast<uint32_t>(chunks), h->d_tile_sums.p, h->d_chunk_base.p};
-    const uint32_t tiles = (static_cast<uint32_t>(chunks) + kScanTile - 1) / kScanTile;
-    HIP_OR_RETURN(h, LaunchScan(sa, static_cast<int>(tiles < static_cast<uint32_t>(h->n_cu * 8) ? tiles : h->n_cu * 8), stream));
-  }
-  uint8_t last = 0;
-  HIP_OR_RETURN(h, hipMemcpyAsync(&h->h_ctrl->total_ids, h->d_chunk_base.p + chunks, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-  HIP_OR_RETURN(h, hipMemcpyAsync(&last, static_cast<const uint8_t *>(d_file) + bytes - 1, 1, hipMemcpyDeviceToHost, stream));
-  HIP_OR_RETURN(h, hipStreamSynchronize(stream));
-  const uint64_t nl = h->h_ctrl->total_ids;
-  const uint64_t lines = nl + (last != 0x0A ? 1 : 0);      // std::getline: a last line without '\n' counts
-  *n_lines = lines;
-  *text_bytes = bytes - nl;
-  if (!d_text || !d_offsets || text_capacity < bytes - nl || offsets_capacity < lines + 1)
-    return Fail(h, kResourceExhausted, "text_capacity / offsets_capacity is too small");
-  HIP_OR_RETURN(h, LaunchSplit(true, a, grid, stream));
-  HIP_OR_RETURN(h, hipStreamSynchronize(stream));
-  return kOk;
+  });
 }
 
 int spmx_set_profiling(spmx_handle *h, int enabled) {
@@ -1276,7 +1522,7 @@ int spmx_last_profile_name(const spmx_handle *h, int slot, char *out, uint64_t c
 }
 
 int spmx_last_profile(const spmx_handle *h, float *kernel_ms, uint64_t *sentences, uint64_t *raw_bytes, uint64_t *ids,
-                      uint64_t *bytes, uint32_t *rcap, float *total_ms) {
+                      uint64_t *bytes, uint64_t *path, float *total_ms) {
   if (!h) return 0;
   const Profile &p = h->prof;
   for (int c = 0; c < p.n; ++c) {
@@ -1286,8 +1532,8 @@ int spmx_last_profile(const spmx_handle *h, float *kernel_ms, uint64_t *sentence
     if (ids) ids[c] = p.ids[c];
     // L + 8 + 4 T' + 8 per sentence
     if (bytes) bytes[c] = p.raw_bytes[c] + 16 * p.sentences[c] + 4 * p.ids[c];
-    if (rcap) rcap[c] = p.rcap[c];
   }
+  if (path) for (int k = 0; k < 4; ++k) path[k] = p.path[k];
   if (total_ms) *total_ms = p.total_ms;
   return p.n;
 }

@@ -74,6 +74,9 @@ struct SpmxDev {
   // single Darts probe -- most CJK ideographs and ASCII pairs (tables.cc)
   const uint32_t *npair;   // [2048]
   uint32_t flags;
+  // normalized length <= expand_max * raw length + 3: the largest growth of any NormalizePrefix result (a charsmap
+  // rule's replacement over its key, U+FFFD for one malformed byte, a space escaped to U+2581), tables.cc
+  uint32_t expand_max;
   // ---- unigram (reference: src/unigram_model.cc:889-1020) ----
   const U4 *ptrie;        // piece trie with inline id / flags / score
   float unk_score;        // min_score - 10.0f

@@ -21,48 +21,87 @@
 
 namespace spmx {
 
-// status bits written to EncodeArgs::status
+// call-level status bits written to EncodeArgs::status
 enum : uint32_t {
   kStArenaOverflow = 1u << 0,   // the scratch id arena was too small: caller retries with a bigger one
-  kStTooLong = 1u << 1,         // a sentence does not fit the largest LDS class
+  kStTooLong = 1u << 1,         // (Normalize / align kernels) a sentence does not fit the largest staged class
   kStInternal = 1u << 2,        // "all normalized characters are not consumed" and friends
-  kStRevMergeOverflow = 1u << 3 // BPE: too many distinct UNUSED merges in one sentence
+};
+// per-sentence status bytes (EncodeArgs::sent_status): util::StatusCode numbers (src/sentencepiece_processor.h:34-52).
+// A sentence that fails yields no ids, as the reference's batch form does for a failing element (EncodeAsIds swallows
+// the Status, python/src/sentencepiece/sentencepiece.i:249-265); the other sentences of the batch are unaffected.
+enum : uint32_t { kSsOk = 0, kSsResourceExhausted = 8, kSsOutOfRange = 11, kSsInternal = 13 };
+
+constexpr int kMaxClasses = 8;
+
+// One length class of the streaming launch (host-planned after classify; kernels_stream.h)
+struct StreamClass {
+  uint32_t rcap;         // sentences of the class have at most rcap raw bytes
+  uint32_t tcap;         // bytes a text column of its tiles holds (> rcap + 4)
+  uint32_t lane_shift;   // log2 of the lanes (sentences) of a tile: 6, or less when a column is too big for 64 per slab
+  uint32_t tw;           // sentences per main tile (<= 1 << lane_shift; fewer when the class is too short to give every wave a full tile)
+  uint32_t main_tiles;   // ceil(count / tw)
+  uint32_t tile_base;    // main tiles handed out before this class's (longest class first)
+  uint32_t count;        // sentences in the class list
+  uint32_t general;      // every lane of its main tiles runs norm_lane_any (models / classes the ASCII fast path cannot take)
+  uint32_t min_lanes;    // a main tile keeps its non-ASCII sentences when at least this many lanes have one
+  uint32_t pad[3];
+};
+// Device-side state of the tile queue of ONE streaming launch, zeroed before it
+struct StreamQueue {
+  uint32_t main_cursor;
+  uint32_t closed;                    // classes closed so far (main tiles done and hard tiles all claimed)
+  uint32_t hard_ready;                // bit c: class c's main tiles are done and its hard list has unclaimed tiles
+  uint32_t pad;
+  uint32_t main_done[kMaxClasses], hard_count[kMaxClasses], hard_claimed[kMaxClasses];
+};
+// Lists that outlive a launch (one set per call): what the streaming launches could not take
+struct SideLists {
+  uint32_t over_count;                // overflow list: sentences that fit no text column of their launch
+  uint32_t long_count;                // long list (BPE): sentences for the long form (kernels_long.h)
+  unsigned long long over_max_raw;    // longest raw sentence on the overflow list
+  unsigned long long long_raw;        // raw bytes on the long list
+  unsigned long long n_failed;        // sentences with a non-zero status byte
 };
 
 struct EncodeArgs {
   SpmxDev dev;
   const uint8_t *text;          // packed sentences
   const uint64_t *offs;         // n + 1 byte offsets
-  const uint32_t *list;         // sentence indices of this length class
-  const uint32_t *list_count;   // number of entries in list (device resident)
-  uint32_t *next_list;          // escalation: sentences whose normalized form overflowed ncap
-  uint32_t *next_count;
   int32_t *arena;               // scratch id arena, filled in completion order
   unsigned long long *arena_head;
   uint64_t arena_cap;
   uint64_t *tmp_off;            // per sentence: where its ids sit in the arena
   uint32_t *counts;             // per sentence: number of ids
-  uint32_t *status;
-  unsigned long long *stats;    // kStatsPerClass words: {sentences, raw bytes, ids, cycles load, normalize, segment, emit}
-  uint32_t rcap, ncap;          // LDS capacities of this class: raw bytes, normalized bytes
-  uint32_t ring;                // streaming form: score ring entries (power of two > longest piece)
-  uint32_t *hard_list;          // FAST kernel: sentences it leaves to the GENERAL kernel of the class
-  uint32_t *hard_count;
-  // streaming form (kernels_stream.h): HBM scratch, one slab per wavefront of the launch
-  uint32_t *stream_text;        // [waves][StreamTextDwords(stream_tcap, ring)]
-  uint32_t *stream_bp;          // [waves][StreamBpWords(stream_tcap)]
-  uint32_t stream_tcap;         // bytes a text column holds
-  uint32_t no_lane_general;     // A/B switch: FAST kernels hand every non-ASCII sentence to the GENERAL kernel
-  uint32_t lane_general_max_raw;   // FAST kernels: length classes (rcap) whose tiles may use the per-lane general normalizer
-  uint32_t lane_general_min_lanes; // ... when at least this many lanes of the tile need it
-  uint32_t *wave_list;          // BPE streaming kernels: sentences they leave to the sentence-per-wave kernel
-  uint32_t *wave_count;
-  uint8_t *bpe_long;            // BPE streaming kernels, document-length classes: kBpeLongBytes per lane per wavefront
-                                // of the launch for words that outgrow the LDS slots; null: such a sentence goes to wave_list
-  uint32_t *tile_cursor;        // streaming kernels: the launch's tile queue (zero at launch); null: fixed stride
-  uint32_t tiles_ascending;     // A/B switch: hand the queue's tiles out shortest first
+  uint8_t *sent_status;         // per sentence: kSs* (zeroed before the first launch of a call)
+  uint32_t *status;             // call-level kSt* bits
+  unsigned long long *stats;    // kStatsPerClass words: {sentences, raw bytes, ids, cycles load, normalize, segment, emit, search iterations}
   int32_t *arena_tb;            // spans form (kernels_align.h), else null: next to every body id in `arena`, the
                                 // position in the normalized (device) text where its token begins
+  uint32_t *long_list;          // BPE: sentences for the long form (kernels_long.h): a word too long for the lane form, a
+                                // sentence too long for the sentence-per-wave form, too many UNUSED merges
+  SideLists *side;
+  // ---- streaming launch (kernels_stream.h) ----
+  const uint32_t *lists;        // n_classes x n: the class lists of classify
+  uint32_t *hard_lists;         // n_classes x n: per class, sentences its main tiles set aside
+  uint32_t *over_list;          // sentences that fit no text column of this launch (null in the overflow launch itself)
+  StreamQueue *q;
+  uint8_t *slab;                // HBM scratch: slab_bytes per wavefront of the launch
+  uint64_t slab_bytes;
+  uint32_t n;                   // sentences of the batch = stride of lists / hard_lists
+  uint32_t n_classes;
+  uint32_t total_main;          // sum of main_tiles
+  uint32_t n_open;              // non-empty classes of this launch (the launch ends when that many are closed)
+  uint32_t ring;                // score ring entries (power of two > longest piece)
+  uint32_t fast_ok;             // the model meets fast_norm_stream's preconditions
+  uint32_t no_lane_general;     // A/B switch: main tiles set every non-ASCII sentence aside
+  StreamClass cls[kMaxClasses];
+  // ---- sentence-per-wave launch (BPE models that are not word-wise; kernels_bpe.h) ----
+  const uint32_t *list;         // sentence indices of this length class
+  const uint32_t *list_count;   // number of entries in list (device resident)
+  uint32_t *next_list;          // escalation: sentences whose normalized form overflowed ncap (null: they go to long_list)
+  uint32_t *next_count;
+  uint32_t rcap, ncap;          // LDS capacities of this class: raw bytes, normalized bytes
 };
 
 constexpr int kStatsPerClass = 8;
@@ -133,6 +172,10 @@ SPMX_DEVICE uint64_t resolve_chain(int base, int step, bool valid, int *next_sta
   }
   return S;
 }
+
+}  // namespace spmx
+#include "kernels_normlane.h"
+namespace spmx {
 
 // ------------------------------------------------------------- normalizer --
 // Returns the normalized length, or -1 if it does not fit in ncap bytes.
@@ -472,11 +515,20 @@ SPMX_DEVICE WaveLds carve_lds(unsigned char *base, uint32_t rcap, uint32_t ncap)
   return w;
 }
 
-SPMX_DEVICE void fail_sentence(const EncodeArgs &a, uint32_t sid, uint32_t bit, int lane) {
+SPMX_DEVICE void fail_sentence(const EncodeArgs &a, uint32_t sid, uint32_t code, int lane) {
   if (lane == 0) {
     a.counts[sid] = 0;
     a.tmp_off[sid] = 0;
-    wv::atomic_or(a.status, bit);
+    a.sent_status[sid] = static_cast<uint8_t>(code);
+    wv::atomic_add(&a.side->n_failed, 1ull);
+  }
+}
+// the sentence leaves the sentence-per-wave kernel for the long form (kernels_long.h)
+SPMX_DEVICE void to_long_list(const EncodeArgs &a, uint32_t sid, uint64_t raw_len, int lane) {
+  if (lane == 0) {
+    a.long_list[wv::atomic_add(&a.side->long_count, 1u)] = sid;
+    wv::atomic_add(&a.side->long_raw, static_cast<unsigned long long>(raw_len));
+    a.counts[sid] = 0u;                          // (until the long form has had it)
   }
 }
 
@@ -494,8 +546,8 @@ SPMX_DEVICE int encode_sentence(const EncodeArgs &a, uint32_t sid, const WaveLds
   const unsigned long long c0 = wv::clock();
   const uint64_t beg = a.offs[sid];
   const uint64_t L64 = a.offs[sid + 1] - beg;
-  if (L64 > a.rcap) {   // only reachable for the last class
-    fail_sentence(a, sid, kStTooLong, lane);
+  if (L64 > a.rcap) {   // only reachable for the last staged class
+    to_long_list(a, sid, L64, lane);
     return -1;
   }
   const int L = static_cast<int>(L64);
@@ -511,19 +563,23 @@ SPMX_DEVICE int encode_sentence(const EncodeArgs &a, uint32_t sid, const WaveLds
     if (a.next_list) {
       if (lane == 0) a.next_list[wv::atomic_add(a.next_count, 1u)] = sid;
     } else {
-      fail_sentence(a, sid, kStTooLong, lane);
+      to_long_list(a, sid, L64, lane);
     }
     return -1;
   }
-  bool ok = true;
+  int ok = 1;
   if (nlen > 0) {
     for (int e = lane; e <= nlen; e += 64) w.blen[e] = 0;
     wv::sync();
     static_assert(MODEL == 2, "the sentence-per-wave form serves BPE only");
     ok = bpe_wave(a, w.norm, nlen, w.bid, w.blen, carve_bpe(w.extra, a.ncap), lane);
   }
-  if (!ok) {
-    fail_sentence(a, sid, kStInternal, lane);
+  if (ok == 0) {                   // a control piece among the symbols: "all normalized characters are not consumed."
+    fail_sentence(a, sid, kSsInternal, lane);
+    return -1;
+  }
+  if (ok < 0) {                    // more distinct UNUSED merges than the LDS table holds: the long form has no such bound
+    to_long_list(a, sid, L64, lane);
     return -1;
   }
   const unsigned long long c3 = wv::clock();
@@ -564,8 +620,6 @@ inline uint32_t EncodeLdsBytes(int model_type, uint32_t rcap, uint32_t ncap) {
 }
 
 // ---------------------------------------------------- bookkeeping kernels --
-constexpr int kMaxClasses = 8;
-
 // Length classification = a two-pass counting sort of the sentence indices by (length class, length sub-bucket):
 // the class decides which kernels / scratch stride a sentence gets, the sub-bucket only orders the class list so
 // that the 64 sentences of a tile have similar lengths whatever the order of the input (the lanes of a tile run
@@ -779,5 +833,6 @@ SPMX_DEVICE void compact_block(const CompactArgs &a) {
 #include "kernels_align.h"
 #include "kernels_normalize.h"
 #include "kernels_nbest.h"
+#include "kernels_long.h"
 
 #endif

@@ -13,22 +13,34 @@ __global__ __launch_bounds__(64) void EncodeKernel(EncodeArgs a) {
   encode_block<MODEL>(a, smem);
 }
 
-// Streaming form (kernels_stream.h): workgroups of up to 16 wavefronts, each wave on its own tiles.
-template <int CLS, bool FAST>
-__global__ __launch_bounds__(FAST ? 1024 : 512) void EncodeStreamKernel(EncodeArgs a) {
+// Streaming form (kernels_stream.h): workgroups of up to 16 wavefronts, each wave on its own tiles; one launch
+// serves every length class.  RING 16: the score ring's size is a compile-time constant (models whose longest piece
+// is <= 15 bytes); 0: taken from the arguments.
+template <int RING, bool UDS>
+__global__ __launch_bounds__(1024) void EncodeStreamKernel(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  encode_stream_block<FAST, 1>(a, smem);
+  encode_stream_block<1, RING, UDS>(a, smem);
 }
-// The FAST kernel specialized for a score ring of 16 entries (models whose longest piece is <= 15 bytes).
-template <int CLS>
-__global__ __launch_bounds__(1024) void EncodeStreamKernelR16(EncodeArgs a) {
+__global__ __launch_bounds__(1024) void EncodeBpeStreamKernel(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  encode_stream_block<true, 1, 16>(a, smem);
+  encode_stream_block<2, 0, false>(a, smem);
 }
-template <int CLS, bool FAST>
-__global__ __launch_bounds__(FAST ? 1024 : 512) void EncodeBpeStreamKernel(EncodeArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  encode_stream_block<FAST, 2>(a, smem);
+__global__ __launch_bounds__(64) void BpeLongKernel(LongArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[64 * kRawWinBytes];
+  bpe_long_block(a, smem);
+}
+
+__global__ __launch_bounds__(64) void NormalizeLongCountKernel(NormalizeArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[64 * kRawWinBytes];
+  norm_long_block<false>(a, smem);
+}
+__global__ __launch_bounds__(64) void NormalizeLongWriteKernel(NormalizeArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[64 * kRawWinBytes];
+  norm_long_block<true>(a, smem);
+}
+__global__ __launch_bounds__(64) void AlignLongKernel(AlignLongArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[64 * kRawWinBytes];
+  align_long_block(a, smem);
 }
 
 __global__ __launch_bounds__(64) void AlignKernel(AlignArgs a) {
@@ -91,53 +103,32 @@ hipError_t LaunchEncode(int model_type, int cls, const EncodeArgs &a, int grid, 
   return hipGetLastError();
 }
 
-namespace {
-template <bool FAST>
-EncodeFn PickStream(int cls) {
-  switch (cls) {
-    case 0: return EncodeStreamKernel<0, FAST>;
-    case 1: return EncodeStreamKernel<1, FAST>;
-    case 2: return EncodeStreamKernel<2, FAST>;
-    case 3: return EncodeStreamKernel<3, FAST>;
-    case 4: return EncodeStreamKernel<4, FAST>;
-    case 5: return EncodeStreamKernel<5, FAST>;
-    default: return EncodeStreamKernel<6, FAST>;
-  }
-}
-EncodeFn PickStreamR16(int cls) {
-  switch (cls) {
-    case 0: return EncodeStreamKernelR16<0>;
-    case 1: return EncodeStreamKernelR16<1>;
-    case 2: return EncodeStreamKernelR16<2>;
-    case 3: return EncodeStreamKernelR16<3>;
-    case 4: return EncodeStreamKernelR16<4>;
-    case 5: return EncodeStreamKernelR16<5>;
-    default: return EncodeStreamKernelR16<6>;
-  }
-}
-template <bool FAST>
-EncodeFn PickBpeStream(int cls) {
-  switch (cls) {
-    case 0: return EncodeBpeStreamKernel<0, FAST>;
-    case 1: return EncodeBpeStreamKernel<1, FAST>;
-    case 2: return EncodeBpeStreamKernel<2, FAST>;
-    case 3: return EncodeBpeStreamKernel<3, FAST>;
-    case 4: return EncodeBpeStreamKernel<4, FAST>;
-    default: return EncodeBpeStreamKernel<5, FAST>;
-  }
-}
-}  // namespace
-
-hipError_t LaunchEncodeStream(int model_type, int cls, bool fast, const EncodeArgs &a, int grid, int waves,
+hipError_t LaunchEncodeStream(int model_type, bool uds, const EncodeArgs &a, int grid, int waves,
                               uint32_t lds_bytes, hipStream_t stream) {
-  EncodeFn fn = model_type == 2 ? (fast ? PickBpeStream<true>(cls) : PickBpeStream<false>(cls))
-                                : (fast ? (a.ring == 16 ? PickStreamR16(cls) : PickStream<true>(cls)) : PickStream<false>(cls));
+  EncodeFn fn = model_type == 2 ? EncodeBpeStreamKernel
+                                : (a.ring == 16 ? (uds ? EncodeStreamKernel<16, true> : EncodeStreamKernel<16, false>)
+                                                : (uds ? EncodeStreamKernel<0, true> : EncodeStreamKernel<0, false>));
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds_bytes));
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * waves), lds_bytes, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t LaunchBpeLong(const LongArgs &a, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL(BpeLongKernel, dim3(grid), dim3(64), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t LaunchNormalizeLong(bool write, const NormalizeArgs &a, int grid, hipStream_t stream) {
+  if (write) hipLaunchKernelGGL(NormalizeLongWriteKernel, dim3(grid), dim3(64), 0, stream, a);
+  else hipLaunchKernelGGL(NormalizeLongCountKernel, dim3(grid), dim3(64), 0, stream, a);
+  return hipGetLastError();
+}
+hipError_t LaunchAlignLong(const AlignLongArgs &a, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL(AlignLongKernel, dim3(grid), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
 

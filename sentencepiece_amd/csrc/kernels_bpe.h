@@ -81,9 +81,9 @@ SPMX_DEVICE bool rev_put(uint32_t *rev, int *n_rev, uint32_t merged, uint32_t l,
   return true;
 }
 
-// Returns false on an error status ("unused" bookkeeping overflow, control id).
-// On success bid[e] / blen[e] | kTokEnd mark every output piece's end e.
-SPMX_DEVICE bool bpe_wave(const EncodeArgs &a, const uint8_t *norm, int nlen, int32_t *bid, uint16_t *blen,
+// Returns 0 on an error status (control id), -1 when the UNUSED bookkeeping overflowed (the caller hands the sentence
+// to the long form), 1 on success: bid[e] / blen[e] | kTokEnd mark every output piece's end e.
+SPMX_DEVICE int bpe_wave(const EncodeArgs &a, const uint8_t *norm, int nlen, int32_t *bid, uint16_t *blen,
                           const BpeLds &B, int lane) {
   const SpmxDev &d = a.dev;
   const bool has_uds = (d.flags & kNfHasUserDefined) != 0;
@@ -238,12 +238,9 @@ SPMX_DEVICE bool bpe_wave(const EncodeArgs &a, const uint8_t *norm, int nlen, in
   }
   n_rev = wv::shfl(n_rev, 0);
   ok = !wv::any(!ok);
-  if (!ok) {
-    if (lane == 0) wv::atomic_or(a.status, kStRevMergeOverflow);
-    return false;
-  }
+  if (!ok) return -1;
   // ---- output pieces (:175-200): every live symbol, UNUSED ones resegmented through rev_merge
-  bool bad = false;
+  bool bad = false, deep = false;
   for (int b = 0; b < nlen; b += 64) {
     const int p = b + lane;
     if (p < nlen && B.ssym[p] != kSsDead) {
@@ -272,7 +269,8 @@ SPMX_DEVICE bool bpe_wave(const EncodeArgs &a, const uint8_t *norm, int nlen, in
             if (f & kSfUnused)
               for (int i = 0; i < n_rev; ++i) if (B.rev[3 * i] == s) { ri = i; break; }
             if (ri < 0 || sp + 2 > kMaxResegDepth) {
-              if (ri >= 0 || (f & kSfControl)) bad = true;
+              if (ri >= 0) deep = true;              // the recursion outgrew the stack: the long form has none
+              if (f & kSfControl) bad = true;
               const int len = d.sym_len[s];
               bid[pos + len] = static_cast<int32_t>(f & kSfIdMask);
               blen[pos + len] = static_cast<uint16_t>(len | kTokEnd);
@@ -287,11 +285,9 @@ SPMX_DEVICE bool bpe_wave(const EncodeArgs &a, const uint8_t *norm, int nlen, in
     }
   }
   wv::sync();
-  if (wv::any(bad)) {
-    if (lane == 0) wv::atomic_or(a.status, kStInternal);
-    return false;
-  }
-  return true;
+  if (wv::any(bad)) return 0;
+  if (wv::any(deep)) return -1;
+  return 1;
 }
 
 }  // namespace spmx

@@ -22,10 +22,10 @@
 //             unknown-run merge / byte fallback of
 //             sentencepiece_processor.cc:581-613 carried across words.
 //
-// A sentence with a word of more than kBpeWordMax characters is handed to the
-// sentence-per-wave kernel (kernels_bpe.h) through a device-side list; so is
-// everything when pieces are UNUSED (resegmentation, :175-200) or the model is
-// not word-wise.
+// A sentence with a word of more than kBpeWordMax characters (a URL, a hash) is
+// handed to the long form (kernels_long.h) through a device-side list; models
+// that are not word-wise, or with UNUSED pieces (resegmentation, :175-200), do
+// not come here at all.
 #ifndef SPMX_KERNELS_BPE_STREAM_H_
 #define SPMX_KERNELS_BPE_STREAM_H_
 
@@ -33,11 +33,6 @@ namespace spmx {
 
 constexpr int kBpeWordMax = 24;
 constexpr uint32_t kBpeWindow = 32;   // bytes of text a lane keeps in LDS
-
-// Byte pos of a lane's text column (kernels_stream.h: dwords text[pos >> 2][lane]).
-SPMX_DEVICE uint32_t stream_text_byte(const uint32_t *gt, int pos) {
-  return (gt[(pos >> 2) * 64] >> (8 * (pos & 3))) & 0xFFu;
-}
 
 struct BpeWordLds {
   uint32_t *sym;     // [kBpeWordMax][64] symbol at character slot k (kSsUnknown: a character without a symbol)
@@ -85,94 +80,10 @@ SPMX_DEVICE bool pair_resolve(const SpmxDev &d, PairProbe *p, uint32_t *merged, 
   return true;
 }
 
-// ---- a word of more than kBpeWordMax characters, by the same lane, in HBM ---------------------------------------
-// The document-length classes have no sentence-per-wave kernel to fall back on (it stages the whole sentence in
-// LDS), and real documents do contain such words (URLs, hashes, base64).  The lane runs the same best-first merge
-// on arrays in its own slice of an HBM scratch buffer: symbol, pair score / merged symbol with the next live symbol,
-// byte length, and a doubly linked list instead of the bitmasks.  O(n) per merge for the argmax scan (independent,
-// cache-line-friendly loads), so O(n^2) per word: ~0.5 ms for 100 characters -- rare, and the rest of the wave waits.
-constexpr int kBpeLongMax = 4096;                                     // characters per word
-constexpr uint32_t kBpeLongBytes = kBpeLongMax * (4u + 4u + 4u + 4u + 2u + 2u);   // per lane
-struct BpeLongWord {
-  uint32_t *sym; float *score; uint32_t *merged; uint32_t *len; uint16_t *next, *prev;
-};
-SPMX_DEVICE BpeLongWord carve_bpe_long(uint8_t *mine) {
-  BpeLongWord w;
-  w.sym = reinterpret_cast<uint32_t *>(mine);
-  w.score = reinterpret_cast<float *>(mine + kBpeLongMax * 4u);
-  w.merged = reinterpret_cast<uint32_t *>(mine + kBpeLongMax * 8u);
-  w.len = reinterpret_cast<uint32_t *>(mine + kBpeLongMax * 12u);
-  w.next = reinterpret_cast<uint16_t *>(mine + kBpeLongMax * 16u);
-  w.prev = reinterpret_cast<uint16_t *>(mine + kBpeLongMax * 18u);
-  return w;
-}
-constexpr uint32_t kNoPair = 0xFFFFFFFFu;      // BpeLongWord::merged: the pair with the next live symbol is not a piece
-
-// Reads the word that starts at byte `wstart` of the lane's text column and merges it.  Returns the number of live
-// symbols' head (always slot 0) through *n_chars = characters read and *wend = byte offset after the word;
-// false if the word has more than kBpeLongMax characters.
-SPMX_DEVICE bool bpe_long_word(const SpmxDev &d, const uint32_t *gt, int nlen, int wstart, const uint32_t *asym,
-                               const BpeLongWord &w, int *n_chars, int *wend) {
-  const uint32_t spb = SpByteOf(d);
-  int n = 0, pos = wstart;
-  bool prev_sp = false;
-  while (pos < nlen) {                                         // the reading rule of bpe_stream_lane
-    const uint32_t c0 = stream_text_byte(gt, pos);
-    if (n > 0 && c0 == spb && !prev_sp) break;                 // a U+2581 after another character: the next word
-    if (n == kBpeLongMax) return false;
-    int mb = c0 == spb ? 1 : OneCharLenDev(c0);
-    if (mb > nlen - pos) mb = nlen - pos;
-    uint32_t s;
-    if (mb == 1) {
-      s = asym[c0];
-    } else {
-      uint32_t bytes = c0;
-      for (int k = 1; k < mb; ++k) bytes |= stream_text_byte(gt, pos + k) << (8 * k);
-      s = char_lookup(d, bytes, static_cast<uint32_t>(mb));
-    }
-    w.sym[n] = s; w.len[n] = static_cast<uint32_t>(mb); w.merged[n] = kNoPair;
-    w.next[n] = static_cast<uint16_t>(n + 1); w.prev[n] = static_cast<uint16_t>(n > 0 ? n - 1 : 0);
-    ++n;
-    pos += mb;
-    prev_sp = c0 == spb;
-  }
-  *n_chars = n;
-  *wend = pos;
-  auto probe = [&](int i) __attribute__((always_inline)) {     // pieces_.find(left + right) for (i, next live of i)
-    const int j = w.next[i];
-    w.merged[i] = kNoPair;
-    if (j >= n) return;
-    PairProbe p;
-    pair_request(d, &p, w.sym[i], w.sym[j], i);
-    pair_issue(d, &p);
-    uint32_t m = 0;
-    float sc = 0.f;
-    if (pair_resolve(d, &p, &m, &sc)) { w.merged[i] = m; w.score[i] = sc; }
-  };
-  for (int i = 0; i + 1 < n; ++i) probe(i);
-  for (;;) {                                                   // :142-173 best live pair: highest score, then leftmost
-    int best = -1;
-    float bs = 0.f;
-    for (int i = 0; i < n; i = w.next[i])
-      if (w.merged[i] != kNoPair && (best < 0 || w.score[i] > bs)) { best = i; bs = w.score[i]; }
-    if (best < 0) break;
-    const int j = w.next[best];
-    w.sym[best] = w.merged[best];
-    w.len[best] += w.len[j];
-    const int nj = w.next[j];
-    w.next[best] = static_cast<uint16_t>(nj);
-    if (nj < n) w.prev[nj] = static_cast<uint16_t>(best);
-    probe(best);                                               // :171-172 the two new neighbours
-    if (best > 0) probe(w.prev[best]);
-  }
-  return true;
-}
-
 // Segments this lane's sentence (text column gt, nlen bytes) and writes its ids into slot[0, cap): forward order
 // fills the slot from its START, `reverse` from its end.  Returns the number of ids, -1 on an error status
-// (control piece, overflow), -2 if the sentence has to go to the sentence-per-wave kernel (a word too long for the
-// LDS slots and no `longbuf`), -4 if a word has more than kBpeLongMax characters.  `longbuf`: this lane's
-// kBpeLongBytes of HBM for such words (document-length classes), or null.
+// (control piece, overflow), -2 if the sentence has a word of more than kBpeWordMax characters: it goes to the long
+// form (kernels_long.h), which has no such bound.
 //
 // The word lives in character slots 0 .. n0-1 of the LDS arrays; `alive` has a bit per slot that still starts a
 // symbol, `pmask` a bit per slot whose pair with the next live slot is a piece.  A merge clears the right slot's
@@ -181,9 +92,9 @@ SPMX_DEVICE bool bpe_long_word(const SpmxDev &d, const uint32_t *gt, int nlen, i
 // Text comes through a W-byte LDS window (position p at win[p & wmask]) refilled one dword per iteration from the
 // lane's text column; that load and the pair probes are issued at the END of an iteration and land at the top of
 // the next one, so an iteration waits for memory once.
-SPMX_DEVICE int bpe_stream_lane(const SpmxDev &d, const uint32_t *gt, int nlen, int32_t *slot, int32_t *tslot, int cap,
+SPMX_DEVICE int bpe_stream_lane(const SpmxDev &d, const TextCol &gt, int nlen, int32_t *slot, int32_t *tslot, int cap,
                                 const BpeWordLds &B, const uint32_t *asym, uint8_t *win, uint32_t wmask, int lane,
-                                bool active_in, uint8_t *longbuf = nullptr) {
+                                bool active_in) {
   const bool bf = (d.flags & kNfByteFallback) != 0;
   const bool reverse = (d.flags & kNfReverse) != 0;
   const uint32_t spb = SpByteOf(d);
@@ -206,7 +117,7 @@ SPMX_DEVICE int bpe_stream_lane(const SpmxDev &d, const uint32_t *gt, int nlen, 
   bool pf_pend = false;
   uint32_t pf = 0;
   if (active) {
-    for (int k = 0; k < W / 4; ++k) *reinterpret_cast<uint32_t *>(win + 4 * k) = gt[k * 64];
+    for (int k = 0; k < W / 4; ++k) *reinterpret_cast<uint32_t *>(win + 4 * k) = gt.dw(k);
     nf = W / 4;
   }
   while (wv::any(active)) {
@@ -228,7 +139,7 @@ SPMX_DEVICE int bpe_stream_lane(const SpmxDev &d, const uint32_t *gt, int nlen, 
         if (pos + 4 > 4 * nf && 4 * nf < nlen) return;                       // its bytes have not landed yet
         const uint32_t c0 = win[static_cast<uint32_t>(pos) & wmask];
         if (n0 > 0 && c0 == spb && !prev_sp) { merging = true; return; }     // a U+2581 after another character: the next word
-        if (n0 == kBpeWordMax) { ret = longbuf ? -3 : -2; return; }           // too long for the LDS working set
+        if (n0 == kBpeWordMax) { ret = -2; return; }                         // too long for the LDS working set
         int mb = c0 == spb ? 1 : OneCharLenDev(c0);
         if (mb > nlen - pos) mb = nlen - pos;
         uint32_t s;
@@ -251,71 +162,6 @@ SPMX_DEVICE int bpe_stream_lane(const SpmxDev &d, const uint32_t *gt, int nlen, 
       };
       read_char(&p0);
       read_char(&p1);
-      if (ret == -3) {
-        // ---- the word outgrew the LDS slots: the HBM form takes the whole word (its characters are read again) ----
-        ret = 0;
-        p0.live = false; p0.slot = 0;
-        p1.live = false; p1.slot = 0;
-        const BpeLongWord LW = carve_bpe_long(longbuf);
-        int nch = 0, wend = 0;
-        if (!bpe_long_word(d, gt, nlen, wstart, asym, LW, &nch, &wend)) {
-          ret = -4;                               // more than kBpeLongMax characters
-        } else {
-          int off = wstart;
-          for (int k = 0; k < nch && ret == 0; k = LW.next[k]) {     // the output rules of the short form below
-            const uint32_t s = LW.sym[k];
-            const int len = static_cast<int>(LW.len[k]);
-            uint32_t f = s;
-            if (s >= d.n_pieces) {
-              f = static_cast<uint32_t>(d.unk_id);
-              if (s != kSsUnknown) {
-                f = d.sym_final[s];
-                if (f & kSfControl) { ret = -1; break; }
-                f &= kSfIdMask;
-              }
-            }
-            if (static_cast<int32_t>(f) == d.unk_id) {
-              if (bf) {
-                for (int x = 0; x < len && ret == 0; ++x) {
-                  const uint32_t b = stream_text_byte(gt, off + x);
-                  const int nb = b == spb ? 3 : 1;
-                  if (n_out + nb > cap) { ret = -1; break; }
-                  for (int y = 0; y < nb; ++y) {
-                    const uint32_t byte = b == spb ? (y == 0 ? 0xE2u : (y == 1 ? 0x96u : 0x81u)) : b;
-                    slot[reverse ? cap - 1 - n_out : n_out] = d.byte_ids[byte];
-                    if (tslot) tslot[reverse ? cap - 1 - n_out : n_out] = off;
-                    ++n_out;
-                  }
-                }
-              } else if (!right_unk) {
-                if (n_out >= cap) { ret = -1; break; }
-                slot[reverse ? cap - 1 - n_out : n_out] = d.unk_id;
-                if (tslot) tslot[reverse ? cap - 1 - n_out : n_out] = off;
-                ++n_out;
-              }
-              right_unk = true;
-            } else {
-              if (n_out >= cap) { ret = -1; break; }
-              slot[reverse ? cap - 1 - n_out : n_out] = static_cast<int32_t>(f);
-              if (tslot) tslot[reverse ? cap - 1 - n_out : n_out] = off;
-              ++n_out;
-              right_unk = false;
-            }
-            off += len;
-          }
-          // go on after the word: empty slots, a fresh text window
-          pos = wend;
-          n0 = 0; alive = 0; pmask = 0;
-          merging = false; prev_sp = false;
-          do_merge = false;
-          const int d0 = pos >> 2;
-          for (int k = 0; k < W / 4; ++k)
-            *reinterpret_cast<uint32_t *>(win + ((4u * static_cast<uint32_t>(d0 + k)) & wmask)) = gt[(d0 + k) * 64];
-          nf = d0 + W / 4;
-          pf_pend = false;
-          if (pos >= nlen) active = false;
-        }
-      }
       if (ret != 0) active = false;
     }
     if (do_merge) {
@@ -370,7 +216,7 @@ SPMX_DEVICE int bpe_stream_lane(const SpmxDev &d, const uint32_t *gt, int nlen, 
       if (static_cast<int32_t>(f) == d.unk_id) {
         if (bf) {                                   // one BYTE id per byte of the unknown piece (:581-603)
           for (int x = 0; x < len && ret == 0; ++x) {
-            const uint32_t b = stream_text_byte(gt, off + x);
+            const uint32_t b = col_byte(gt, off + x);
             const int nb = b == spb ? 3 : 1;
             if (n_out + nb > cap) { ret = -1; break; }
             for (int y = 0; y < nb; ++y) {
@@ -404,7 +250,7 @@ SPMX_DEVICE int bpe_stream_lane(const SpmxDev &d, const uint32_t *gt, int nlen, 
     }
     }
     // window refill: dword nf may replace positions [4 nf - W, 4 nf - W + 4), dead once they lie below pos
-    if (active && 4 * nf + 4 <= pos + W && 4 * nf < nlen + 8) { pf = gt[nf * 64]; ++nf; pf_pend = true; }
+    if (active && 4 * nf + 4 <= pos + W && 4 * nf < nlen + 8) { pf = gt.dw(nf); ++nf; pf_pend = true; }
     pair_issue(d, &p0);
     pair_issue(d, &p1);
   }

@@ -2,8 +2,7 @@
 // tile of up to 64 sentences and runs ONE SENTENCE PER LANE, so that all 64
 // lanes carry an independent EncodeOptimized recurrence
 // (src/unigram_model.cc:889-1020), with a per-lane working set in LDS that does
-// not depend on the sentence length: 12 wavefronts fit a CU whatever the length
-// class, and sentences of any length up to the class capacity run lane-parallel.
+// not depend on the sentence length.
 // (History, profiles/: a sentence-per-wave form spent 91 % of its cycles in a
 // serial loop over end positions; a form with text + back-pointers in LDS was
 // held to one wave per SIMD by its 2 B per byte per sentence.)
@@ -31,21 +30,21 @@
 // The backtrack (:1010-1018) follows bp[] from the end and writes ids straight
 // into the arena, last piece first.
 //
-// Two kernels per length class: FAST (each lane normalizes its own sentence from
-// HBM into its text column: fast_norm_stream for ASCII, norm_lane_general for
-// tiles of mostly non-ASCII text) and GENERAL (normalize_wave into an LDS buffer,
-// one sentence at a time, then a copy into the lane's column) for what FAST
-// hands over through a device-side list and for models FAST cannot take.
-// A workgroup is W wavefronts that share nothing but two read-only LDS tables
-// (first trie level, byte classes; every wave writes identical copies, so no
-// workgroup barrier is ever needed); each wave owns a private slice of LDS.
+// ONE persistent launch serves every length class of a call (encode_stream_block): the waves take tiles from a
+// queue, longest class first.  A lane normalizes its own sentence from HBM into its text column -- fast_norm_stream
+// for ASCII, norm_lane_any (kernels_normlane.h) for everything else.  A stray non-ASCII sentence in an ASCII tile
+// would hold the other 63 lanes up for its whole length, so it is set aside on the class's "hard" list instead;
+// when the main tiles of a class are done its hard list is cut into tiles of its own (all lanes in norm_lane_any)
+// and handed out by the same queue, while the shorter classes are still running.  A sentence whose normalized form
+// does not fit its class's text column goes to the call's overflow list (a second, small launch with exact
+// capacities); nothing fails for its length.
+// A workgroup is W wavefronts that share nothing but two read-only LDS tables (first trie level, byte classes;
+// every wave writes identical copies, so no workgroup barrier is ever needed); each wave owns a private slice of LDS.
 #ifndef SPMX_KERNELS_STREAM_H_
 #define SPMX_KERNELS_STREAM_H_
 
 namespace spmx {
 
-// byte classes of the FAST normalizer (StreamLds::bcls)
-constexpr uint32_t kBcComplex = 1u;    // not handled by fast_norm_stream: non-ASCII, or a charsmap rule may start here
 constexpr uint32_t kStreamSharedBytes = 256u * 16u + 256u;   // roottab + bcls
 
 // per-wave profiling counters
@@ -71,13 +70,13 @@ constexpr uint32_t kBwIdMask = 0x00FFFFFFu;
 
 struct StreamLds {
   U4 *roottab;        // [256] first trie level (shared by the workgroup, read-only)
-  uint8_t *bcls;      // [256] byte classes of the FAST normalizer (shared, read-only)
-  uint8_t *raw;       // GENERAL: one raw sentence (rcap + 16)
-  uint8_t *norm;      // GENERAL: its normalized form (ncap + 16)
+  uint8_t *bcls;      // [256] byte classes of the ASCII fast path (shared, read-only)
   float *ring_s;      // [R][64]
   uint32_t *ring_b;   // [R][64]
   uint8_t *win;       // [64][W + 4]: lane l's window starts at win + l * (W + 4)
   uint32_t *stage;    // [2][64][4]: final back-pointer words of the lane's current block of 8 positions
+  uint8_t *rawwin;    // [64][kRawWinBytes] raw-text windows of norm_lane_any (aliases the rings / the BPE word: idle
+                      // while a tile is normalized)
   // BPE (kernels_bpe_stream.h) instead of the rings / window / staging block:
   uint32_t *asym;     // [256] symbol of every one-byte character (shared, aliases roottab)
   BpeWordLds bw;      // the lane's current word
@@ -86,32 +85,33 @@ struct StreamLds {
 
 SPMX_HD inline uint32_t StreamWindow(uint32_t ring) { return 2u * ring; }
 // model: 1 unigram, 2 BPE
-SPMX_HD inline uint32_t StreamPrivateBytes(bool fast, int model, uint32_t rcap, uint32_t ncap, uint32_t ring) {
-  const uint32_t stage = fast ? 0u : (((rcap + 16 + 15) & ~15u) + ((ncap + 16 + 15) & ~15u));
-  const uint32_t work = model == 2 ? BpeWordLdsBytes() + 64u * (kBpeWindow + 4u)
-                                   : 64u * ring * 8u + 64u * (StreamWindow(ring) + 4u) + 2u * 64u * 16u;
-  return stage + work;
+SPMX_HD inline uint32_t StreamPrivateBytes(int model, uint32_t ring) {
+  uint32_t work = model == 2 ? BpeWordLdsBytes() + 64u * (kBpeWindow + 4u)
+                             : 64u * ring * 8u + 64u * (StreamWindow(ring) + 4u) + 2u * 64u * 16u;
+  if (work < 64u * kRawWinBytes) work = 64u * kRawWinBytes;
+  return (work + 15u) & ~15u;
 }
-SPMX_HD inline uint32_t StreamLdsBytes(bool fast, int model, uint32_t rcap, uint32_t ncap, uint32_t ring, uint32_t waves) {
-  return kStreamSharedBytes + waves * StreamPrivateBytes(fast, model, rcap, ncap, ring);
+SPMX_HD inline uint32_t StreamLdsBytes(int model, uint32_t ring, uint32_t waves) {
+  return kStreamSharedBytes + waves * StreamPrivateBytes(model, ring);
 }
-// HBM scratch of one wavefront for a class whose normalized sentences have at most tcap bytes
-SPMX_HD inline uint64_t StreamTextDwords(uint32_t tcap, uint32_t ring) {      // uint32 [dw][64]
-  return (static_cast<uint64_t>(tcap + 3) / 4 + StreamWindow(ring) / 4 + 4) * 64u;
+// HBM scratch of one tile whose text columns hold tcap bytes, for 1 << lane_shift lanes:
+//   uint32 text[StreamTextDwords(tcap, ring)][lanes]   then   uint32 bp[lanes][StreamBpStride(tcap)]
+SPMX_HD inline uint64_t StreamTextDwords(uint32_t tcap, uint32_t ring) {
+  return static_cast<uint64_t>(tcap + 3) / 4 + StreamWindow(ring) / 4 + 4;
 }
 SPMX_HD inline uint32_t StreamBpStride(uint32_t tcap) { return (tcap + 16u) & ~7u; }   // words per lane, whole blocks of 8
-SPMX_HD inline uint64_t StreamBpWords(uint32_t tcap) { return static_cast<uint64_t>(StreamBpStride(tcap)) * 64u; }   // uint32 [lane][stride]
+SPMX_HD inline uint64_t StreamSlabBytes(uint32_t tcap, uint32_t ring, uint32_t lane_shift) {
+  const uint64_t text = ((StreamTextDwords(tcap, ring) << lane_shift) * 4u + 31u) & ~static_cast<uint64_t>(31);
+  return text + (static_cast<uint64_t>(StreamBpStride(tcap)) << lane_shift) * 4u + 32u;
+}
 
-SPMX_DEVICE StreamLds carve_stream(unsigned char *base, bool fast, int model, uint32_t rcap, uint32_t ncap, uint32_t ring,
-                                   int wave) {
+SPMX_DEVICE StreamLds carve_stream(unsigned char *base, int model, uint32_t ring, int wave) {
   StreamLds t;
   t.roottab = reinterpret_cast<U4 *>(base);
   t.asym = reinterpret_cast<uint32_t *>(base);
   t.bcls = base + 256u * 16u;
-  unsigned char *mine = base + kStreamSharedBytes + static_cast<uint32_t>(wave) * StreamPrivateBytes(fast, model, rcap, ncap, ring);
-  t.raw = mine;
-  t.norm = mine + ((rcap + 16 + 15) & ~15u);
-  if (!fast) mine += ((rcap + 16 + 15) & ~15u) + ((ncap + 16 + 15) & ~15u);
+  unsigned char *mine = base + kStreamSharedBytes + static_cast<uint32_t>(wave) * StreamPrivateBytes(model, ring);
+  t.rawwin = mine;
   t.ring_s = reinterpret_cast<float *>(mine);
   t.ring_b = reinterpret_cast<uint32_t *>(mine + 64u * ring * 4u);
   t.win = mine + 64u * ring * 8u;
@@ -124,299 +124,7 @@ SPMX_DEVICE StreamLds carve_stream(unsigned char *base, bool fast, int model, ui
   return t;
 }
 
-// Normalize() of one all-ASCII sentence by ONE lane (src/normalizer.cc:71-186 with every NormalizePrefix result
-// being the byte itself, :231-244): raw text in HBM (16-byte aligned loads; a block that holds a byte of the
-// sentence lies in the same page as that byte, so the over-read at either end stays inside the caller's mapping)
-// -> the lane's text column gt[dw * 64], four bytes at a time.  Valid when the space symbol is one byte wide
-// (kNfCompressSp, or no whitespace escaping) and the model has no user-defined symbols; not for
-// whitespace-as-suffix models (the suffix would have to be patched into a dword that is already stored).  A byte
-// whose bcls entry says kBcComplex makes the lane give up (-1).
-// *n_sp: how many bytes of the result are the space symbol (sizes the id slot under byte fallback).
-SPMX_DEVICE int fast_norm_stream(const SpmxDev &d, const uint8_t *gtext, uint64_t beg, int L, uint32_t *gt,
-                                 const uint8_t *bcls, int tcap, int *n_sp) {
-  const uint32_t F = d.flags;
-  const bool rm = (F & kNfRemoveExtraWs) != 0;
-  const uint32_t sp = (F & kNfCompressSp) ? kSpByte : 0x20u;
-  const bool has_map = (F & kNfHasCharsmap) != 0;
-  int w = 0, nsp = 0;
-  uint32_t acc = 0;
-  if (F & kNfAddDummyPrefix) { acc = sp; w = 1; nsp = 1; }   // :128
-  bool P = rm;                    // is_prev_space (:130)
-  int wl = w;                     // output length up to the last non-space byte (:166-176 trailing spaces)
-  bool seen = false;              // some prefix is not " " (:86-100)
-  uint32_t bad = 0;
-  uint32_t carry = 0x80u;         // the last byte of the previous block
-  int skip = 0;                   // continuation bytes of a validated character still to copy
-  const uint64_t q0 = beg & ~15ull;
-  const uint8_t *blk = gtext + q0;
-  int rel = static_cast<int>(q0 - beg);         // index of the block's first byte within the sentence (<= 0 at first)
-  Q4 cur = *reinterpret_cast<const Q4 *>(blk);
-  while (rel < L) {
-    Q4 nxt = cur;
-    if (rel + 16 < L) nxt = *reinterpret_cast<const Q4 *>(blk + 16);
-    const uint32_t wd[8] = {cur.x, cur.y, cur.z, cur.w, nxt.x, nxt.y, nxt.z, nxt.w};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if ((wd[q] & 0x80808080u) == 0u) {
-        // ---- four ASCII bytes: every NormalizePrefix result is the byte itself ----
-#pragma unroll
-        for (int k = 4 * q; k < 4 * q + 4; ++k) {
-          const uint32_t c = (wd[q] >> (8 * (k & 3))) & 0xFFu;
-          if (static_cast<uint32_t>(rel + k) < static_cast<uint32_t>(L)) {
-            bad |= bcls[c];
-            const bool is_sp = c == 0x20u;
-            if (!is_sp || !P) {                     // :137-138 a space after a space is dropped
-              acc |= (is_sp ? sp : c) << (8 * (w & 3));
-              ++w;
-              nsp += is_sp ? 1 : 0;
-              if ((w & 3) == 0) { gt[((w >> 2) - 1) * 64] = acc; acc = 0; }
-            }
-            P = is_sp && rm;                        // :154-162
-            if (!is_sp) { wl = w; seen = true; }
-          }
-        }
-      } else {
-        // ---- a dword with a non-ASCII byte (rare in this kernel's tiles).  A character whose first two bytes
-        // start no charsmap key (tables.cc npair -- the filter of the position-parallel normalizer) normalizes to
-        // itself (:231-244), a malformed byte to U+FFFD (util.cc:51-84); a possible rule, or a literal U+2581,
-        // leaves the sentence to the general normalizers. ----
-#pragma unroll
-        for (int k = 4 * q; k < 4 * q + 4; ++k) {
-          const uint32_t c = (wd[q] >> (8 * (k & 3))) & 0xFFu;
-          if (static_cast<uint32_t>(rel + k) < static_cast<uint32_t>(L)) {
-            if (c < 0x80u) {
-              bad |= bcls[c];
-              const bool is_sp = c == 0x20u;
-              if (!is_sp || !P) {
-                acc |= (is_sp ? sp : c) << (8 * (w & 3));
-                ++w;
-                nsp += is_sp ? 1 : 0;
-                if ((w & 3) == 0) { gt[((w >> 2) - 1) * 64] = acc; acc = 0; }
-              }
-              P = is_sp && rm;
-              if (!is_sp) { wl = w; seen = true; }
-            } else {
-              uint32_t o0 = c, o1 = 0, o2 = 0;
-              int n_out = 1;
-              const int rem = L - (rel + k);
-              if (skip > 0) {
-                --skip;
-              } else {
-                const uint32_t b1 = rem >= 2 ? (wd[(k + 1) >> 2] >> (8 * ((k + 1) & 3))) & 0xFFu : 0u;
-                const uint32_t b2 = rem >= 3 ? (wd[(k + 2) >> 2] >> (8 * ((k + 2) & 3))) & 0xFFu : 0u;
-                const uint32_t b3 = rem >= 4 ? (wd[(k + 3) >> 2] >> (8 * ((k + 3) & 3))) & 0xFFu : 0u;
-                const uint32_t pb = k > 0 ? (wd[(k > 0 ? k - 1 : 0) >> 2] >> (8 * ((k > 0 ? k - 1 : 0) & 3))) & 0xFFu : carry;
-                const uint32_t prevc = rel + k > 0 ? pb : 0x80u;      // nothing before the first byte of the sentence
-                const bool t1 = (b1 & 0xC0u) == 0x80u, t2 = (b2 & 0xC0u) == 0x80u, t3 = (b3 & 0xC0u) == 0x80u;
-                int mb = 0;
-                if (rem >= 2 && (c & 0xE0u) == 0xC0u) {
-                  if (t1 && ((c & 0x1Fu) << 6 | (b1 & 0x3Fu)) >= 0x80u) mb = 2;
-                } else if (rem >= 3 && (c & 0xF0u) == 0xE0u) {
-                  const uint32_t cp = (c & 0x0Fu) << 12 | (b1 & 0x3Fu) << 6 | (b2 & 0x3Fu);
-                  if (t1 && t2 && cp >= 0x800u && (cp < 0xD800u || cp >= 0xE000u)) mb = 3;
-                  if (c == 0xE2u && b1 == 0x96u && b2 == 0x81u) bad |= kBcComplex;
-                } else if (rem >= 4 && (c & 0xF8u) == 0xF0u) {
-                  const uint32_t cp = (c & 0x07u) << 18 | (b1 & 0x3Fu) << 12 | (b2 & 0x3Fu) << 6 | (b3 & 0x3Fu);
-                  if (t1 && t2 && t3 && cp >= 0x10000u && cp <= 0x10FFFFu) mb = 4;
-                }
-                if (has_map) {
-                  if ((d.npair[(c << 8 | b1) >> 5] >> (b1 & 31u)) & 1u) bad |= kBcComplex;          // a key may start here
-                  if (prevc < 0x80u && ((d.npair[(prevc << 8 | c) >> 5] >> (c & 31u)) & 1u)) bad |= kBcComplex;   // or at the ASCII byte before
-                }
-                if (mb) skip = mb - 1;
-                else { o0 = 0xEFu; o1 = 0xBFu; o2 = 0xBDu; n_out = 3; }
-              }
-              // a malformed byte grows into three: keep "what is written + what is left to read" within the
-              // column (all other bytes produce at most one), else leave the sentence to the general normalizers
-              if (w + rem + 2 > tcap) bad |= kBcComplex;
-              else {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                  if (j < n_out) {
-                    acc |= (j == 0 ? o0 : (j == 1 ? o1 : o2)) << (8 * (w & 3));
-                    ++w;
-                    if ((w & 3) == 0) { gt[((w >> 2) - 1) * 64] = acc; acc = 0; }
-                  }
-                }
-              }
-              P = false;
-              wl = w;
-              seen = true;
-            }
-          }
-        }
-      }
-    }
-    carry = cur.w >> 24;
-    cur = nxt;
-    blk += 16;
-    rel += 16;
-  }
-  gt[(w >> 2) * 64] = acc;                      // the last, partial dword
-  if (bad & kBcComplex) return -1;
-  if (rm) {
-    if (!seen) return 0;                        // :86-100 nothing but spaces
-    nsp -= w - wl;                              // the trimmed tail is nothing but space symbols
-    w = wl;
-  }
-  *n_sp = nsp;
-  return w;
-}
-
-// ---- Normalize() of one sentence of ANY content by ONE lane (src/normalizer.cc:71-253) ------------------------
-// The same loop as the reference's: one NormalizePrefix result after another -- longest charsmap rule by a Darts
-// walk (darts.h:467-513), else one UTF-8 character, else U+FFFD for a malformed byte (util.cc:51-84) -- through
-// the whitespace state machine, with the output going to the lane's text column four bytes at a time.  Same
-// preconditions as fast_norm_stream (one-byte space symbol, no user-defined symbols, no whitespace-as-suffix).
-// Raw bytes come through a kRawWin-byte LDS window filled 16 bytes at a time; a rule walk that would outrun the
-// window, or an output longer than tcap, makes the lane give up (-1) and the sentence goes to the GENERAL kernel.
-constexpr int kRawWin = 64;
-constexpr uint32_t kLaneGeneralMaxRaw = 4096;  // length classes whose sentences norm_lane_general takes (EncodeArgs::lane_general_max_raw)
-
-SPMX_DEVICE int norm_lane_general(const SpmxDev &d, const uint8_t *gtext, uint64_t beg, int L, uint32_t *gt, int tcap,
-                                  uint8_t *rawwin, int *n_sp) {
-  const uint32_t F = d.flags;
-  const bool rm = (F & kNfRemoveExtraWs) != 0;
-  const bool one = (F & kNfCompressSp) != 0;
-  const uint32_t sp1 = one ? kSpByte : 0x20u;              // the space symbol (one byte wide here)
-  const bool has_map = (F & kNfHasCharsmap) != 0;
-  const uint32_t droot = has_map ? DartsOffset(d.ndarts[0]) : 0u;
-  // raw byte i of the sentence (0 <= i < L, within kRawWin - 16 of every byte still needed) through the LDS window,
-  // which is indexed by the low bits of the absolute address and filled one aligned 16-byte block at a time
-  int hi;                                                  // raw bytes [0, hi) have been loaded
-  {
-    const uint64_t q0 = beg & ~15ull;
-    *reinterpret_cast<Q4 *>(rawwin + (q0 & (kRawWin - 1))) = *reinterpret_cast<const Q4 *>(gtext + q0);
-    hi = static_cast<int>(q0 + 16 - beg);
-  }
-  auto raw = [&](int i) __attribute__((always_inline)) -> uint32_t {
-    while (i >= hi) {
-      const uint64_t q = beg + static_cast<uint64_t>(hi);                // 16-byte aligned
-      *reinterpret_cast<Q4 *>(rawwin + (q & (kRawWin - 1))) = *reinterpret_cast<const Q4 *>(gtext + q);
-      hi += 16;
-    }
-    return rawwin[(beg + static_cast<uint64_t>(i)) & (kRawWin - 1)];
-  };
-  int w = 0, wl = 0, nsp = 0;
-  uint32_t acc = 0;
-  bool giveup = false;
-  auto emit = [&](uint32_t b) __attribute__((always_inline)) {
-    if (w >= tcap) { giveup = true; return; }
-    acc |= b << (8 * (w & 3));
-    ++w;
-    if ((w & 3) == 0) { gt[((w >> 2) - 1) * 64] = acc; acc = 0; }
-    if (b != sp1) wl = w;                                  // :166-176 trailing space symbols are cut at the end
-    else ++nsp;
-  };
-  // NormalizePrefix at raw offset p (:195-253): kind 0 raw bytes [src, src + len), 1 rule string
-  // nblob[src, src + len), 2 U+FFFD, 3 the space symbol (a literal U+2581 under kNfCompressSp)
-  struct Pfx { int kind, len, consumed; uint32_t src; };
-  auto prefix = [&](int p) __attribute__((always_inline)) -> Pfx {
-    const uint32_t b0 = raw(p);
-    const int rem = L - p;
-    int rule_len = 0;
-    uint32_t rule_off = 0;
-    bool walk = has_map;
-    if (walk) {                                            // no key starts with these two bytes (tables.cc npair)
-      const uint32_t b1 = rem >= 2 ? raw(p + 1) : 0u;
-      walk = ((d.npair[(b0 << 8 | b1) >> 5] >> (b1 & 31u)) & 1u) != 0;
-    }
-    if (walk) {                                            // commonPrefixSearch, longest key (:218-228)
-      uint32_t pos = droot;
-      for (int depth = 0; p + depth < L;) {
-        if (depth >= kRawWin - 20) { giveup = true; break; }
-        const uint32_t c = raw(p + depth);
-        pos ^= c;
-        if (pos >= d.ndarts_n) break;
-        const uint32_t u = d.ndarts[pos];
-        if ((u & 0x800000FFu) != c) break;                 // unit.label() == c
-        pos ^= DartsOffset(u);
-        ++depth;
-        if ((u >> 8) & 1u) {                               // has_leaf: the value sits in the unit at pos
-          if (pos >= d.ndarts_n) break;
-          rule_len = depth;
-          rule_off = d.ndarts[pos] & 0x7FFFFFFFu;
-        }
-      }
-    }
-    Pfx r{0, 0, 0, 0};
-    if (rule_len > 0) {                                    // :245-250 the C string at normalized_[value]
-      int n = 0;
-      while (rule_off + static_cast<uint32_t>(n) < d.nblob_n && d.nblob[rule_off + n] != 0) ++n;
-      r = Pfx{1, n, rule_len, rule_off};
-    } else {
-      // :231-244 one UTF-8 character (DecodeUTF8, util.cc:51-84)
-      int mb = 1;
-      bool ok = b0 < 0x80u, lit_sp = false;
-      if (!ok) {
-        const uint32_t b1 = rem >= 2 ? raw(p + 1) : 0u, b2 = rem >= 3 ? raw(p + 2) : 0u, b3 = rem >= 4 ? raw(p + 3) : 0u;
-        const bool t1 = (b1 & 0xC0u) == 0x80u, t2 = (b2 & 0xC0u) == 0x80u, t3 = (b3 & 0xC0u) == 0x80u;
-        if (rem >= 2 && (b0 & 0xE0u) == 0xC0u) {
-          const uint32_t cp = (b0 & 0x1Fu) << 6 | (b1 & 0x3Fu);
-          if (t1 && cp >= 0x80u) { ok = true; mb = 2; }
-        } else if (rem >= 3 && (b0 & 0xF0u) == 0xE0u) {
-          const uint32_t cp = (b0 & 0x0Fu) << 12 | (b1 & 0x3Fu) << 6 | (b2 & 0x3Fu);
-          if (t1 && t2 && cp >= 0x800u && (cp < 0xD800u || cp >= 0xE000u)) { ok = true; mb = 3; }
-          lit_sp = ok && one && b0 == 0xE2u && b1 == 0x96u && b2 == 0x81u;
-        } else if (rem >= 4 && (b0 & 0xF8u) == 0xF0u) {
-          const uint32_t cp = (b0 & 0x07u) << 18 | (b1 & 0x3Fu) << 12 | (b2 & 0x3Fu) << 6 | (b3 & 0x3Fu);
-          if (t1 && t2 && t3 && cp >= 0x10000u && cp <= 0x10FFFFu) { ok = true; mb = 4; }
-        }
-      }
-      if (lit_sp) r = Pfx{3, 1, 3, 0};
-      else if (ok) r = Pfx{0, mb, mb, static_cast<uint32_t>(p)};
-      else r = Pfx{2, 3, 1, 0};
-    }
-    return r;
-  };
-  auto sp_byte = [&](const Pfx &x, int k) __attribute__((always_inline)) -> uint32_t {
-    if (x.kind == 0) return raw(static_cast<int>(x.src) + k);
-    if (x.kind == 1) return d.nblob[x.src + static_cast<uint32_t>(k)];
-    if (x.kind == 2) return k == 0 ? 0xEFu : (k == 1 ? 0xBFu : 0xBDu);
-    return kSpByte;
-  };
-  int p = 0;
-  if (rm) {                                                // :84-95 prefixes that normalize to exactly " "
-    while (p < L && !giveup) {
-      const Pfx x = prefix(p);
-      if (!(x.len == 1 && x.kind != 3 && sp_byte(x, 0) == 0x20u)) break;
-      p += x.consumed;
-    }
-  }
-  if (giveup) return -1;
-  if (p >= L) { gt[0] = 0; return 0; }                     // :98-100 nothing but whitespace
-  if (F & kNfAddDummyPrefix) emit(sp1);                    // :128
-  bool is_prev_space = rm;                                 // :130
-  while (p < L && !giveup) {
-    const Pfx x = prefix(p);
-    if (giveup) break;
-    int k = 0;
-    if (x.kind != 3) while (is_prev_space && k < x.len && sp_byte(x, k) == 0x20u) ++k;      // :137-138
-    if (k < x.len) {
-      uint32_t last = 0;
-      for (; k < x.len; ++k) {
-        last = sp_byte(x, k);
-        emit((x.kind != 3 && last == 0x20u) ? sp1 : last);  // :143-152 (whitespace escaping = the one-byte symbol)
-      }
-      is_prev_space = x.kind != 3 && last == 0x20u;        // :154
-    }
-    p += x.consumed;
-    if (!rm) is_prev_space = false;                        // :160-162
-  }
-  if (giveup) return -1;
-  gt[(w >> 2) * 64] = acc;                                 // the last, partial dword
-  if (rm) { nsp -= w - wl; w = wl; }
-  *n_sp = nsp;
-  return w;
-}
-
-// True when the preconditions of the per-lane normalizers hold for this model (host and device agree on it).
-SPMX_HD inline bool StreamFastEligible(uint32_t flags) {
-  return !(flags & kNfHasUserDefined) && ((flags & kNfCompressSp) || !(flags & kNfEscapeWs)) &&
-         !((flags & kNfAddDummyPrefix) && (flags & kNfWsSuffix));
-}
-
-// piece_score; UDS = false drops the user-defined branch (FAST kernels: such models never reach them)
+// piece_score; UDS = false drops the user-defined branch (models without USER_DEFINED pieces)
 template <bool UDS>
 SPMX_DEVICE double piece_score_u(const U4 &u, int len, float max_score) {
   if (UDS) return piece_score(u, len, max_score);
@@ -438,7 +146,7 @@ SPMX_DEVICE double piece_score_u(const U4 &u, int len, float max_score) {
 //            one's result in registers.
 // State:
 //   * text comes from the W-byte LDS window `win` (position p at win[p & wmask]), refilled one dword per
-//     iteration from the lane's text column gt[] -- the load is issued next to the trie probe and lands in the
+//     iteration from the lane's text column gt -- the load is issued next to the trie probe and lands in the
 //     window at the top of the next iteration, by which time the probe wait has covered it;
 //   * best_path_ends_at lives in the rings only: ring_s / ring_b slot of position e is [(e & rm) * 64];
 //     ring_b == 0 means "not reached" (:984);
@@ -450,7 +158,7 @@ SPMX_DEVICE double piece_score_u(const U4 &u, int len, float max_score) {
 // RING > 0: the ring size is a compile-time constant (index masks and the distances between the LDS arrays fold
 // into immediates); RING == 0: taken from rm_in / wmask_in.  UDS: the model may have USER_DEFINED pieces.
 template <int RING, bool UDS>
-SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const uint32_t *gt, uint32_t *gb, int nlen, float *ring_s,
+SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const TextCol &gt, uint32_t *gb, int nlen, float *ring_s,
                                     uint32_t *ring_b, uint32_t rm_in, uint8_t *win, uint32_t wmask_in, uint32_t *st,
                                     const U4 *roottab, bool active_in) {
   const uint32_t rm = RING ? static_cast<uint32_t>(RING - 1) : rm_in;
@@ -475,7 +183,7 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const uint32_t *gt, uint32
   if (active) {
     for (uint32_t k = 0; k <= rm; ++k) ring_b[k * 64] = 0u;
     ring_s[0] = 0.f;                              // best_path_ends_at[0].best_path_score = 0
-    for (int k = 0; k < W / 4; ++k) *reinterpret_cast<uint32_t *>(win + 4 * k) = gt[k * 64];
+    for (int k = 0; k < W / 4; ++k) *reinterpret_cast<uint32_t *>(win + 4 * k) = gt.dw(k);
     nf = W / 4;
     cs = win[0];
     cs1 = win[1];
@@ -504,7 +212,7 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const uint32_t *gt, uint32
     const U4 uA = u;
     // window refill: dword nf may replace positions [4 nf - W, 4 nf - W + 4), which are dead once they lie below s
     pf_pend = active && 4 * nf + 4 <= s + W && 4 * nf < nlen + 8;
-    if (pf_pend) { pf = gt[nf * 64]; ++nf; }
+    if (pf_pend) { pf = gt.dw(nf); ++nf; }
     if (nwalking) u = ptrie[nnode ^ nc];          // next probe
     // ---------------- data ----------------
     const int eA = s + dep1;
@@ -581,7 +289,7 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const uint32_t *gt, uint32
 // forward order fills the slot from its END (ids end up in slot[cap - n, cap)), `reverse` fills it from the start.
 // Returns n, or -1 on a broken chain / overflow.
 // `tslot` (spans form, else null): the slot's twin in EncodeArgs::arena_tb, receives every token's begin.
-SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const uint32_t *gt, const uint32_t *gb, int nlen, int32_t *slot,
+SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const TextCol &gt, const uint32_t *gb, int nlen, int32_t *slot,
                                  int32_t *tslot, int cap, bool active) {
   const bool bf = (d.flags & kNfByteFallback) != 0;
   const bool reverse = (d.flags & kNfReverse) != 0;
@@ -597,11 +305,11 @@ SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const uint32_t *gt, const uin
       const int tb = e - len;
       if (w & kBwUnk) {
         if (bf) {                                   // one BYTE id per byte of the unknown piece (:581-603)
-          const bool sp = stream_text_byte(gt, tb) == spb;
+          const bool sp = col_byte(gt, tb) == spb;
           const int nb = sp ? 3 : len;
           if (n + nb > cap) { ok = false; active = false; continue; }
           for (int x = nb - 1; x >= 0; --x) {
-            const uint32_t byte = sp ? (x == 0 ? 0xE2u : (x == 1 ? 0x96u : 0x81u)) : stream_text_byte(gt, tb + x);
+            const uint32_t byte = sp ? (x == 0 ? 0xE2u : (x == 1 ? 0x96u : 0x81u)) : col_byte(gt, tb + x);
             slot[reverse ? n : cap - 1 - n] = d.byte_ids[byte];
             if (tslot) tslot[reverse ? n : cap - 1 - n] = tb;
             ++n;
@@ -629,19 +337,76 @@ SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const uint32_t *gt, const uin
   return ok ? n : -1;
 }
 
+// ---- the tile queue of one launch ------------------------------------------------------------------------------
+enum : uint32_t { kTileExit = 0, kTileMain = 1, kTileHard = 2, kTileWait = 3 };
+
+// Lane 0 of a wave asks for its next tile.  Main tiles first (one atomic; the classes are laid out longest first in
+// the cursor's range), except that a class whose main tiles are all DONE and that has a hard list is served at once:
+// its bit in q->hard_ready costs one load per tile to check.  Nothing to take but other waves still running main
+// tiles (which may append to hard lists): kTileWait.
+SPMX_DEVICE void next_tile(const EncodeArgs &a, uint32_t *kind, uint32_t *cls, uint32_t *first, uint32_t *cnt) {
+  StreamQueue *q = a.q;
+  *kind = kTileExit;
+  for (;;) {
+    uint32_t ready = wv::atomic_load(&q->hard_ready);
+    while (ready) {
+      const int c = 31 - static_cast<int>(wv::clz64(static_cast<uint64_t>(ready)) - 32);     // longest class first
+      ready &= ~(1u << c);
+      wv::acquire_fence();
+      const uint32_t hc = wv::atomic_load(&q->hard_count[c]);
+      const uint32_t L = 1u << a.cls[c].lane_shift;
+      const uint32_t ht = (hc + L - 1u) / L;
+      if (wv::atomic_load(&q->hard_claimed[c]) >= ht) continue;
+      const uint32_t k = wv::atomic_add(&q->hard_claimed[c], 1u);
+      if (k >= ht) continue;
+      if (k == ht - 1u) {                       // the last hard tile of the class has an owner: the class is closed
+        wv::atomic_and(&q->hard_ready, ~(1u << c));
+        wv::atomic_add(&q->closed, 1u);
+      }
+      *kind = kTileHard; *cls = static_cast<uint32_t>(c); *first = k * L;
+      *cnt = hc - k * L < L ? hc - k * L : L;
+      return;
+    }
+    if (wv::atomic_load(&q->main_cursor) < a.total_main) {
+      const uint32_t t = wv::atomic_add(&q->main_cursor, 1u);
+      if (t < a.total_main) {
+        int c = static_cast<int>(a.n_classes) - 1;
+        while (c > 0 && !(t >= a.cls[c].tile_base && t - a.cls[c].tile_base < a.cls[c].main_tiles)) --c;
+        const uint32_t k = t - a.cls[c].tile_base;
+        *kind = kTileMain; *cls = static_cast<uint32_t>(c); *first = k * a.cls[c].tw;
+        *cnt = a.cls[c].count - *first < a.cls[c].tw ? a.cls[c].count - *first : a.cls[c].tw;
+        return;
+      }
+    }
+    if (wv::atomic_load(&q->closed) >= a.n_open) return;           // every class is closed
+    if (wv::atomic_load(&q->hard_ready) == 0u) { *kind = kTileWait; return; }
+  }
+}
+
+// appends the sentences of the lanes in `m` to list[*count ...] (one atomic per wave)
+SPMX_DEVICE void append_lanes(uint64_t m, bool mine, uint32_t sid, uint32_t *list, uint32_t *count, int lane) {
+  if (!m) return;
+  const int leader = wv::ffs64(m) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = wv::atomic_add(count, static_cast<uint32_t>(wv::popc64(m)));
+  base = wv::shfl(base, leader);
+  if (mine) list[base + static_cast<uint32_t>(wv::popc64(m & ((1ull << lane) - 1ull)))] = sid;
+}
+
 // Persistent body of the streaming kernels.  MODEL: 1 unigram, 2 BPE (word-wise models only).  RING: see
-// unigram_stream_lane (0 = a.ring).
-template <bool FAST, int MODEL, int RING = 0>
+// unigram_stream_lane (0 = a.ring).  UDS: the model may have USER_DEFINED pieces.
+template <int MODEL, int RING, bool UDS>
 SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
   const int lane = wv::lane();
   const SpmxDev &d = a.dev;
   const uint32_t ring = RING ? static_cast<uint32_t>(RING) : a.ring;
-  const StreamLds T = carve_stream(smem, FAST, MODEL, a.rcap, a.ncap, ring, wv::wave_in_block());
+  const StreamLds T = carve_stream(smem, MODEL, ring, wv::wave_in_block());
   const uint32_t rm = ring - 1;
   const uint32_t W = StreamWindow(ring);
   float *my_rs = T.ring_s + lane;
   uint32_t *my_rb = T.ring_b + lane;
   uint8_t *my_win = T.win + static_cast<uint32_t>(lane) * (W + 4u);
+  uint8_t *my_raw = T.rawwin + static_cast<uint32_t>(lane) * kRawWinBytes;
   {   // shared read-only tables; every wave writes all of both (same values): no workgroup barrier
     const uint32_t root = MODEL == 1 ? d.ptrie[0].x >> kDatBaseShiftDev : 0u;
     for (uint32_t cb = static_cast<uint32_t>(lane); cb < 256u; cb += 64u) {
@@ -660,123 +425,100 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     }
     wv::sync();
   }
-  const uint32_t count = *a.list_count;
   const uint32_t wave_id = static_cast<uint32_t>(wv::block_id() * wv::waves_per_block() + wv::wave_in_block());
-  const uint32_t n_waves = static_cast<uint32_t>(wv::grid_size() * wv::waves_per_block());
-  // this wave's scratch slab; tcap = capacity of a text column in bytes
-  const uint32_t tcap = a.stream_tcap;
-  uint32_t *gt = a.stream_text + static_cast<uint64_t>(wave_id) * StreamTextDwords(tcap, ring) + static_cast<uint32_t>(lane);
-  uint32_t *gb = a.stream_bp + static_cast<uint64_t>(wave_id) * StreamBpWords(tcap) + static_cast<uint32_t>(lane) * StreamBpStride(tcap);
+  uint8_t *slab = a.slab + static_cast<uint64_t>(wave_id) * a.slab_bytes;
   uint32_t *my_st = T.stage + static_cast<uint32_t>(lane) * 4u;
-  // sentences per tile: 64, or fewer when the list is too short to give every wave a full tile
-  uint32_t tw = (count + n_waves - 1) / n_waves;
-  tw = tw < 1u ? 1u : (tw > 64u ? 64u : tw);
-  const uint32_t tiles = (count + tw - 1) / tw;
+  StreamQueue *q = a.q;
   const int n_extra = d.n_prefix + d.n_suffix;
+  const bool bf_sp = (d.flags & kNfByteFallback) && (d.flags & kNfCompressSp);
   WaveCounters tc;
-  // Tiles come from a queue (one atomic per tile), not from a fixed stride: a wave that starts late -- its CU was
-  // held by another stream's kernel, e.g. the RCCL all-gather of the previous batch -- takes fewer tiles instead of
-  // finishing its fixed share after everybody else, and uneven tiles even out.
-  for (uint32_t tile = wave_id;; tile += n_waves) {
-    if (a.tile_cursor) {
-      uint32_t t = 0;
-      if (lane == 0) t = wv::atomic_add(a.tile_cursor, 1u);
-      tile = wv::shfl(t, 0);
-      // the class lists are sorted by length (classify's sub-buckets): longest tiles first, so that the tiles
-      // still running when the queue empties are the short ones
-      if (tile < tiles && !a.tiles_ascending) tile = tiles - 1u - tile;
-    }
-    if (tile >= tiles) break;
-    const uint32_t first = tile * tw;
-    const int cnt = static_cast<int>(count - first < tw ? count - first : tw);
+  for (;;) {
+    uint32_t kind = kTileExit, c = 0, first = 0, ucnt = 0;
+    if (lane == 0) next_tile(a, &kind, &c, &first, &ucnt);
+    kind = wv::shfl(kind, 0);
+    if (kind == kTileExit) break;
+    if (kind == kTileWait) { wv::nap(); continue; }
+    c = wv::shfl(c, 0); first = wv::shfl(first, 0); ucnt = wv::shfl(ucnt, 0);
+    const StreamClass sc = a.cls[c];
+    const int cnt = static_cast<int>(ucnt);
+    const uint32_t tcap = sc.tcap;
+    // this tile's view of the wave's slab
+    const uint64_t text_bytes = ((StreamTextDwords(tcap, ring) << sc.lane_shift) * 4u + 31u) & ~static_cast<uint64_t>(31);
+    const TextCol gt{reinterpret_cast<uint32_t *>(slab) + lane, sc.lane_shift};
+    uint32_t *gb = reinterpret_cast<uint32_t *>(slab + text_bytes) + static_cast<uint64_t>(lane) * StreamBpStride(tcap);
+    const uint32_t *list = (kind == kTileMain ? a.lists : a.hard_lists) + static_cast<uint64_t>(c) * a.n;
     uint32_t my_sid = 0;
     uint64_t my_beg = 0;
     uint32_t my_len = 0;
-    bool too_long = false;
+    bool over = false;               // goes to the overflow list
     if (lane < cnt) {
-      my_sid = a.list[first + lane];
+      my_sid = list[first + lane];
       my_beg = a.offs[my_sid];
-      my_len = static_cast<uint32_t>(a.offs[my_sid + 1] - my_beg);
-      too_long = a.offs[my_sid + 1] - my_beg > a.rcap;                    // only reachable in the last class
+      const uint64_t l64 = a.offs[my_sid + 1] - my_beg;
+      my_len = static_cast<uint32_t>(l64);
+      over = l64 > sc.rcap;                                              // (the last class takes every length)
     }
     const unsigned long long c0 = wv::clock();
-    unsigned long long t_load = 0;
     bool mine = false;
     int my_nlen = 0, my_nsp = 0;     // normalized length; how many of its bytes are the space symbol
-    if (wv::any(too_long)) {
-      uint64_t m = wv::ballot(too_long);
-      while (m) { const int i = wv::ffs64(m) - 1; m &= m - 1; fail_sentence(a, wv::shfl(my_sid, i), kStTooLong, lane); }
-    }
-    if (FAST) {
-      const bool go = lane < cnt && !too_long;
+    {
+      const bool go = lane < cnt && !over;
       int nlen = 0;
-      if (go && my_len > 0) nlen = fast_norm_stream(d, a.text, my_beg, static_cast<int>(my_len), gt, T.bcls, static_cast<int>(tcap), &my_nsp);
-      // Not plain ASCII.  A tile that is mostly such sentences (CJK text ...) normalizes them here, one per lane
-      // (the raw window borrows the rings, idle until the search); a stray one in an ASCII tile would hold the
-      // other 63 lanes up for its whole length, and long sentences are better off position-parallel: both go to
-      // the GENERAL kernel.
-      // Document-length classes have no GENERAL kernel (its LDS staging holds one whole sentence): every
-      // non-ASCII sentence is normalized here, and one that cannot be fails the call.
-      const bool no_general = a.hard_list == nullptr;
-      const bool many = no_general ||
-                        (wv::popc64(wv::ballot(nlen < 0)) >= static_cast<int>(a.lane_general_min_lanes) &&
-                         a.rcap <= a.lane_general_max_raw && !a.no_lane_general);
-      if (many && nlen < 0)
-        nlen = norm_lane_general(d, a.text, my_beg, static_cast<int>(my_len), gt, static_cast<int>(tcap),
-                                 reinterpret_cast<uint8_t *>(T.ring_s) + static_cast<uint32_t>(lane) * (kRawWin + 16), &my_nsp);
-      const bool hard = go && nlen < 0;
-      if (go && nlen >= 0) { mine = true; my_nlen = nlen; }
-      const uint64_t hm = wv::ballot(hard);
-      if (hm && no_general) {
-        uint64_t m = hm;
-        while (m) { const int i = wv::ffs64(m) - 1; m &= m - 1; fail_sentence(a, wv::shfl(my_sid, i), kStTooLong, lane); }
-      } else if (hm) {                          // hand the sentence to the GENERAL kernel of this class
-        const int leader = wv::ffs64(hm) - 1;
-        uint32_t hb = 0;
-        if (lane == leader) hb = wv::atomic_add(a.hard_count, static_cast<uint32_t>(wv::popc64(hm)));
-        hb = wv::shfl(hb, leader);
-        if (hard) a.hard_list[hb + static_cast<uint32_t>(wv::popc64(hm & ((1ull << lane) - 1ull)))] = my_sid;
+      bool need_any = go && my_len > 0;
+      if (kind == kTileMain && a.fast_ok && !sc.general) {
+        if (go && my_len > 0) nlen = fast_norm_stream(d, a.text, my_beg, static_cast<int>(my_len), gt, T.bcls, static_cast<int>(tcap), &my_nsp);
+        need_any = nlen < 0;
+        // Not plain ASCII.  A tile that is mostly such sentences (CJK text ...) normalizes them here, one per lane;
+        // a stray one would hold the other lanes up for its whole length: it goes to the class's hard list
+        const uint64_t hm = wv::ballot(need_any);
+        if (hm && (wv::popc64(hm) < static_cast<int>(sc.min_lanes) || a.no_lane_general)) {
+          append_lanes(hm, need_any, my_sid, a.hard_lists + static_cast<uint64_t>(c) * a.n, &q->hard_count[c], lane);
+          need_any = false;
+          if (nlen < 0) nlen = -2;
+        }
       }
-    } else {
-      for (int i = 0; i < cnt; ++i) {
-        const unsigned long long l0 = wv::clock();
-        if (wv::shfl(too_long ? 1 : 0, i)) continue;
-        const uint32_t L = wv::shfl(my_len, i);
-        const uint32_t sid = wv::shfl(my_sid, i);
-        const uint64_t beg = static_cast<uint64_t>(wv::shfl(static_cast<uint32_t>(my_beg >> 32), i)) << 32 |
-                             wv::shfl(static_cast<uint32_t>(my_beg), i);
-        const uint8_t *src = a.text + beg;
-        for (uint32_t p = static_cast<uint32_t>(lane); p < L; p += 64) T.raw[p] = src[p];
-        wv::sync();
-        t_load += wv::clock() - l0;
-        int nlen = 0;
-        if (L > 0) nlen = normalize_wave(d, T.raw, static_cast<int>(L), T.norm, static_cast<int>(a.ncap < tcap ? a.ncap : tcap), lane);
-        wv::sync();
-        if (nlen < 0) {                         // does not fit this class: hand it on (or fail in the last class)
-          if (a.next_list) { if (lane == 0) a.next_list[wv::atomic_add(a.next_count, 1u)] = sid; }
-          else fail_sentence(a, sid, kStTooLong, lane);
-          continue;
+      if (wv::any(need_any)) {
+        wv::sync();                              // the raw windows alias LDS the previous tile's search used
+        if (need_any) {
+          ColSink sink{gt, static_cast<int>(tcap)};   // (brace-init: c, cap)
+          nlen = norm_lane_any(d, a.text, my_beg, static_cast<int>(my_len), sink, my_raw, &my_nsp);
+          if (nlen < 0) over = true;
         }
-        // norm[0, nlen) -> lane i's text column, a dword per lane per step
-        uint32_t *col = gt - lane + i;
-        for (int p4 = lane; p4 * 4 < nlen; p4 += 64) col[p4 * 64] = *reinterpret_cast<const uint32_t *>(T.norm + 4 * p4);
-        int nsp = 0;
-        if ((d.flags & kNfByteFallback) && (d.flags & kNfCompressSp)) {          // sizes the id slot below
-          int cnt_sp = 0;
-          for (int p = lane; p < nlen; p += 64) cnt_sp += T.norm[p] == kSpByte ? 1 : 0;
-          wave_excl_scan(cnt_sp, lane, &nsp);
+        wv::sync();
+      }
+      if (go && nlen >= 0) { mine = true; my_nlen = nlen; }
+    }
+    {   // sentences that fit no column of this launch: the overflow launch takes them with exact capacities
+      const uint64_t om = wv::ballot(over);
+      if (om && a.over_list) {
+        append_lanes(om, over, my_sid, a.over_list, &a.side->over_count, lane);
+        if (over) {
+          wv::atomic_max(&a.side->over_max_raw, static_cast<unsigned long long>(a.offs[my_sid + 1] - my_beg));
+          a.counts[my_sid] = 0u;                 // (the scan that runs before the overflow launch sees no ids yet)
         }
-        if (lane == i) { mine = true; my_nlen = nlen; my_nsp = nsp; }
-        wv::sync();                             // norm is rewritten by the next sentence
+      } else if (over) {                         // the overflow launch itself: longer than any launch can take
+        a.counts[my_sid] = 0u;
+        a.tmp_off[my_sid] = 0;
+        a.sent_status[my_sid] = static_cast<uint8_t>(kSsOutOfRange);
+        wv::atomic_add(&a.side->n_failed, 1ull);
       }
     }
-    wv::sync_global();                          // text columns written by other lanes are read below
+    if (kind == kTileMain) {                     // this main tile has appended what it had for the hard list
+      wv::release_fence();
+      if (lane == 0) {
+        const uint32_t done = wv::atomic_add(&q->main_done[c], 1u) + 1u;
+        if (done == sc.main_tiles) {
+          if (wv::atomic_load(&q->hard_count[c]) > 0u) wv::atomic_or(&q->hard_ready, 1u << c);
+          else wv::atomic_add(&q->closed, 1u);
+        }
+      }
+    }
     const unsigned long long c1 = wv::clock();
-    tc.cyc[0] += t_load; tc.cyc[1] += (c1 - c0) - t_load;
+    tc.cyc[1] += c1 - c0;
     // ---- a slot of cap ids per sentence in the arena ----
     int cap = 0;
-    // at most one id per normalized byte -- three for a space symbol that falls back to its bytes
-    if (mine) cap = ((d.flags & kNfByteFallback) && (d.flags & kNfCompressSp)) ? my_nlen + 2 * my_nsp : my_nlen;
+    // at most one id per normalized byte -- three for a one-byte space symbol that falls back to its bytes
+    if (mine) cap = bf_sp ? my_nlen + 2 * my_nsp : my_nlen;
     const int room = mine ? cap + n_extra : 0;
     int total = 0;
     const int excl = wave_excl_scan(room, lane, &total);
@@ -788,14 +530,14 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     if (overflow && lane == 0) wv::atomic_or(a.status, kStArenaOverflow);
     int32_t *slot = a.arena + base + static_cast<unsigned long long>(excl) + d.n_prefix;
     int32_t *tslot = a.arena_tb ? a.arena_tb + base + static_cast<unsigned long long>(excl) + d.n_prefix : nullptr;
-    bool broken = false, handed = false;
+    bool broken = false;
     int n = 0;
     bool at_end = false;      // the ids sit at the end of the slot
     unsigned long long c2 = c1;
     if (MODEL == 1) {
       // ---- segment, then backtrack: the slot is filled from its end (or from its start when reversing) ----
       tc.n_trips += static_cast<unsigned long long>(
-          unigram_stream_lane<RING, !FAST>(d, gt, gb, my_nlen, my_rs, my_rb, rm, my_win, W - 1u, my_st, T.roottab, mine));
+          unigram_stream_lane<RING, UDS>(d, gt, gb, my_nlen, my_rs, my_rb, rm, my_win, W - 1u, my_st, T.roottab, mine));
       c2 = wv::clock();
       if (!overflow) {
         n = emit_stream_lane(d, gt, gb, my_nlen, slot, tslot, cap, mine);
@@ -804,24 +546,16 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     } else {
       // ---- word by word, ids written as the words complete: the slot is filled from its start (end when reversing) ----
       n = bpe_stream_lane(d, gt, my_nlen, slot, tslot, cap, T.bw, T.asym, T.bwin + static_cast<uint32_t>(lane) * (kBpeWindow + 4u),
-                          kBpeWindow - 1u, lane, mine && !overflow,
-                          a.bpe_long ? a.bpe_long + (static_cast<uint64_t>(wave_id) * 64u + static_cast<uint32_t>(lane)) * kBpeLongBytes : nullptr);
+                          kBpeWindow - 1u, lane, mine && !overflow);
       c2 = wv::clock();
       at_end = (d.flags & kNfReverse) != 0;
-      handed = n == -2;
-      if (wv::any(n == -4)) {                     // a word of more than kBpeLongMax characters: OUT_OF_RANGE for the call
-        if (lane == 0) wv::atomic_or(a.status, kStTooLong);
-        if (n == -4) { n = 0; mine = false; a.counts[my_sid] = 0; a.tmp_off[my_sid] = 0; }
+      const bool handed = n == -2;              // a word too long for the lane form: the sentence goes to the long form
+      append_lanes(wv::ballot(handed), handed, my_sid, a.long_list, &a.side->long_count, lane);
+      if (handed) {
+        wv::atomic_add(&a.side->long_raw, static_cast<unsigned long long>(my_len));
+        a.counts[my_sid] = 0u;                   // (until the long form has had it)
+        mine = false; n = 0;
       }
-      const uint64_t wm = wv::ballot(handed);
-      if (wm) {                                 // words too long for the lane form: the sentence-per-wave kernel takes it
-        const int leader = wv::ffs64(wm) - 1;
-        uint32_t wb = 0;
-        if (lane == leader) wb = wv::atomic_add(a.wave_count, static_cast<uint32_t>(wv::popc64(wm)));
-        wb = wv::shfl(wb, leader);
-        if (handed) a.wave_list[wb + static_cast<uint32_t>(wv::popc64(wm & ((1ull << lane) - 1ull)))] = my_sid;
-      }
-      if (handed) { mine = false; n = 0; }
     }
     broken = n < 0;
     if (broken) n = 0;
@@ -830,12 +564,15 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
       for (int x = 0; x < d.n_prefix; ++x) ids[x - d.n_prefix] = d.prefix_ids[x];
       for (int x = 0; x < d.n_suffix; ++x) ids[n + x] = d.suffix_ids[x];
       a.tmp_off[my_sid] = static_cast<unsigned long long>(ids - d.n_prefix - a.arena);
+      a.counts[my_sid] = static_cast<uint32_t>(n + n_extra);
+    } else if (mine) {
+      a.counts[my_sid] = 0u;
+      a.tmp_off[my_sid] = 0;
+      if (broken) {                              // "all normalized characters are not consumed." (sentencepiece_processor.cc:628)
+        a.sent_status[my_sid] = static_cast<uint8_t>(kSsInternal);
+        wv::atomic_add(&a.side->n_failed, 1ull);
+      }
     }
-    if (mine) {
-      a.counts[my_sid] = (broken || overflow) ? 0u : static_cast<uint32_t>(n + n_extra);
-      if (broken || overflow) a.tmp_off[my_sid] = 0;
-    }
-    if (wv::any(broken) && lane == 0) wv::atomic_or(a.status, kStInternal);
     const unsigned long long c3 = wv::clock();
     if (mine && !broken) { ++tc.n_sent; tc.n_raw += my_len; tc.n_ids += static_cast<unsigned long long>(n + n_extra); }
     tc.cyc[2] += c2 - c1; tc.cyc[3] += c3 - c2;

@@ -8,22 +8,21 @@
 namespace spmx {
 
 struct LengthClass { uint32_t rcap, ncap; };
-// Length classes per model type: raw-byte capacity and normalized-byte capacity
-// (the stride of the streaming kernels' HBM scratch; the LDS workspace of the
-// sentence-per-wave BPE kernel).  A sentence whose normalized form overflows
-// ncap is handed to the next class; past the last class it is an error.
-// Unigram: the last two classes are for document-length inputs (up to 1 MiB per sentence).  Only the FAST
-// kernel runs there (per-lane normalizers; its working set does not depend on the length), so they need a model
-// it can take (kernels_stream.h StreamFastEligible); ncap is the capacity of a text column there.
-constexpr int kNumClassesUnigram = 7;
-constexpr int kNumClassesBpe = 6;
-constexpr uint32_t kMaxStagedRaw = 8192;   // GENERAL kernels stage one sentence in LDS: classes up to this raw size
-constexpr LengthClass kClassesUnigram[kNumClassesUnigram] = {
-    {192, 448}, {576, 1280}, {1536, 3328}, {4096, 8704}, {8192, 20480}, {65536, 98304}, {1048576, 1572864}};
-// BPE: the last two classes are document-length as well (word-wise models the FAST kernel can take: the lane form's
-// working set is one word; a word that outgrows the LDS slots is merged in HBM, kernels_bpe_stream.h).
-constexpr LengthClass kClassesBpe[kNumClassesBpe] = {{192, 448}, {576, 1280}, {1536, 3328}, {4096, 6400},
-                                                     {65536, 98304}, {1048576, 1572864}};
+// Length classes: raw-byte capacity of a class (the classify kernels sort by it) and normalized-byte capacity.
+// Streaming kernels (unigram; BPE that segments word by word): ncap is only the stride of a tile's HBM scratch -- a
+// sentence whose normalized form overflows it goes to the call's overflow launch, which sizes its columns exactly.
+// The classes up to kStreamMainMaxRaw share ONE launch; the document classes above run in a second one (few, long
+// sentences: its own grid and slab).  Sentences longer than the last class go through the overflow launch as well.
+// Sentence-per-wave BPE kernel (models that are not word-wise): rcap / ncap are its LDS workspace; only the classes up
+// to kMaxStagedRaw run there, longer sentences -- and sentences whose normalized form overflows the last staged
+// class -- take the long form (kernels_long.h).
+constexpr int kNumClasses = 7;
+constexpr uint32_t kMaxStagedRaw = 4096;       // sentence-per-wave BPE / align / Normalize kernels stage one sentence in LDS
+constexpr uint32_t kStreamMainMaxRaw = 16384;  // streaming: classes up to this size share the main launch
+constexpr LengthClass kClasses[kNumClasses] = {
+    {192, 448}, {576, 1280}, {1536, 3328}, {4096, 8704}, {16384, 32768}, {65536, 98304}, {1048576, 1572864}};
+// BPE, sentence-per-wave: the normalized capacity of the last staged class is what fits the LDS of a CU
+constexpr uint32_t kBpeWaveNcap3 = 6400;
 
 // score ring entries for a model whose longest piece has max_piece_len bytes
 inline uint32_t ScoreRing(int max_piece_len) {
@@ -32,8 +31,12 @@ inline uint32_t ScoreRing(int max_piece_len) {
   return r;
 }
 
-hipError_t LaunchEncodeStream(int model_type, int cls, bool fast, const EncodeArgs &a, int grid, int waves,
+// One streaming launch (kernels_stream.h): model_type 1 unigram / 2 BPE; uds: the model has USER_DEFINED pieces
+hipError_t LaunchEncodeStream(int model_type, bool uds, const EncodeArgs &a, int grid, int waves,
                               uint32_t lds_bytes, hipStream_t stream);
+hipError_t LaunchBpeLong(const LongArgs &a, int grid, hipStream_t stream);
+hipError_t LaunchNormalizeLong(bool write, const NormalizeArgs &a, int grid, hipStream_t stream);
+hipError_t LaunchAlignLong(const AlignLongArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchEncode(int model_type, int cls, const EncodeArgs &a, int grid, uint32_t lds_bytes, hipStream_t stream);
 hipError_t LaunchAlign(const AlignArgs &a, int grid, uint32_t lds_bytes, hipStream_t stream);
 hipError_t LaunchNormalize(bool write, const NormalizeArgs &a, int grid, uint32_t lds_bytes, hipStream_t stream);

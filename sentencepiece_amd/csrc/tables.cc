@@ -130,6 +130,39 @@ Status CompileTables(const ModelData &m, HostTables *t) {
       }
     }
   }
+  // Largest growth of a NormalizePrefix result over the bytes it consumes (dev.h expand_max): every key of the
+  // charsmap trie by a depth-first walk of its units, the replacement's length with every ' ' counted as a
+  // three-byte U+2581; at least 3 (U+FFFD for one malformed byte, an escaped space).
+  sc.expand_max = 3;
+  if (!t->ndarts.empty()) {
+    const std::vector<uint32_t> &u = t->ndarts;
+    auto offset = [](uint32_t x) { return (x >> 10) << ((x & (1u << 9)) >> 6); };
+    struct Node { uint32_t pos, depth; };
+    std::vector<Node> todo;
+    todo.push_back({offset(u[0]), 0});                      // pos = node index after its own offset was applied
+    size_t visited = 0;
+    while (!todo.empty() && visited < 4 * u.size() + 1024) {
+      const Node nd = todo.back();
+      todo.pop_back();
+      ++visited;
+      for (uint32_t c = 1; c < 256; ++c) {
+        const uint32_t p = nd.pos ^ c;
+        if (p >= u.size() || (u[p] & 0x800000FFu) != c) continue;
+        const uint32_t child = p ^ offset(u[p]);
+        const uint32_t depth = nd.depth + 1;
+        if ((u[p] >> 8) & 1u) {                             // a key ends here: its value sits in the unit at child
+          if (child < u.size()) {
+            const uint32_t off = u[child] & 0x7FFFFFFFu;
+            uint64_t out = 0;
+            for (size_t k = off; k < t->nblob.size() && t->nblob[k] != 0; ++k) out += t->nblob[k] == ' ' ? 3 : 1;
+            const uint64_t ratio = (out + depth - 1) / depth;
+            if (ratio > sc.expand_max) sc.expand_max = static_cast<uint32_t>(ratio);
+          }
+        }
+        if (depth < 256) todo.push_back({child, depth});
+      }
+    }
+  }
   if (t->ndarts.empty()) t->ndarts.push_back(0);
   if (t->nblob.empty()) t->nblob.push_back(0);
   sc.ndarts_n = static_cast<uint32_t>(t->ndarts.size());

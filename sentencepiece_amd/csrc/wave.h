@@ -56,6 +56,16 @@ SPMX_DEVICE unsigned long long atomic_add(unsigned long long *p, unsigned long l
 SPMX_DEVICE void atomic_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }
 SPMX_DEVICE uint32_t lds_atomic_add(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }   // p in LDS
 SPMX_DEVICE void atomic_min(unsigned long long *p, unsigned long long v) { atomicMin(p, v); }
+SPMX_DEVICE void atomic_max(unsigned long long *p, unsigned long long v) { atomicMax(p, v); }
+SPMX_DEVICE void atomic_and(uint32_t *p, uint32_t v) { atomicAnd(p, v); }
+// a load that sees what other workgroups' atomics wrote (tile queue of the streaming kernels)
+SPMX_DEVICE uint32_t atomic_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// release: this wave's earlier global stores are visible device-wide before what follows; acquire: loads after the
+// call do not see lines cached before it
+SPMX_DEVICE void release_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+SPMX_DEVICE void acquire_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+// a short pause while other waves make progress
+SPMX_DEVICE void nap() { __builtin_amdgcn_s_sleep(64); }
 
 SPMX_DEVICE unsigned long long clock() { return __builtin_amdgcn_s_memtime(); }   // shader cycles
 
@@ -63,6 +73,7 @@ SPMX_DEVICE int popc64(uint64_t x) { return __popcll(x); }
 SPMX_DEVICE int ffs64(uint64_t x) { return __ffsll(static_cast<unsigned long long>(x)); }   // 1-based, 0 if none
 SPMX_DEVICE int clz64(uint64_t x) { return __clzll(static_cast<long long>(x)); }
 SPMX_DEVICE float bits_to_float(uint32_t u) { return __uint_as_float(u); }
+SPMX_DEVICE uint32_t float_to_bits(float f) { return __float_as_uint(f); }
 
 }  // namespace wv
 }  // namespace spmx

@@ -251,6 +251,32 @@ class SentencePieceProcessor:
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         return self._encode_host(text, offsets)
 
+    def EncodePackedEx(self, text, offsets, add_bos=False, add_eos=False, reverse=False):
+        """As EncodePacked, plus the per-sentence status bytes (util::StatusCode numbers, 0 = OK; a failed sentence has
+        no ids, the others are unaffected -- what the reference's batch form does with a failing element) and their
+        count: ``(ids, id_offsets, status uint8[n], n_failed)``."""
+        self._need()
+        self._apply(add_bos, add_eos, reverse)
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offs) - 1
+        p_ids, p_off, p_st = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        failed = C.c_uint64(0)
+        tp = text.ctypes.data if len(text) else None
+        self._check(self._lib.spmx_encode_batch_ex(self._h, tp, offs.ctypes.data, n, C.byref(p_ids), C.byref(p_off),
+                                                   C.byref(p_st), C.byref(failed)))
+        try:
+            io = np.ctypeslib.as_array(C.cast(p_off, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+            total = int(io[n])
+            ids = (np.ctypeslib.as_array(C.cast(p_ids, C.POINTER(C.c_int32)), shape=(total,)).copy()
+                   if total else np.zeros(0, dtype=np.int32))
+            st = (np.ctypeslib.as_array(C.cast(p_st, C.POINTER(C.c_uint8)), shape=(n,)).copy()
+                  if n else np.zeros(0, dtype=np.uint8))
+        finally:
+            for p in (p_ids, p_off, p_st):
+                self._lib.spmx_free(p)
+        return ids, io, st, int(failed.value)
+
     def _encode_host(self, text, offs):
         n = len(offs) - 1
         p_ids, p_off = C.c_void_p(), C.c_void_p()
@@ -622,15 +648,17 @@ class SentencePieceProcessor:
         self._lib.spmx_set_profiling(self._h, 1 if enabled else 0)
 
     def LastProfile(self):
-        """Per kernel slot (length class; GENERAL kernels after a FAST one sit in slots 8 + class):
-        dict(kernel, kernel_ms, sentences, raw_bytes, ids, bytes, rcap, phase_cycles) + total_ms."""
+        """Per kernel slot of the last profiled encode call (0 main streaming launch, 1 document launch, 2 overflow
+        launch, 3 sentence-per-wave BPE, 4 long form): dict(kernel, kernel_ms, sentences, raw_bytes, ids, bytes,
+        phase_cycles) + total_ms + path (sentences set aside on hard lists / on the overflow list / through the
+        long form / failed)."""
         self._need()
-        ms = np.zeros(16, dtype=np.float32)
-        sent, raw, ids, byt = (np.zeros(16, dtype=np.uint64) for _ in range(4))
-        rcap = np.zeros(16, dtype=np.uint32)
+        ms = np.zeros(8, dtype=np.float32)
+        sent, raw, ids, byt = (np.zeros(8, dtype=np.uint64) for _ in range(4))
+        path = np.zeros(8, dtype=np.uint64)
         tot = C.c_float(0)
         k = self._lib.spmx_last_profile(self._h, ms.ctypes.data, sent.ctypes.data, raw.ctypes.data, ids.ctypes.data,
-                                        byt.ctypes.data, rcap.ctypes.data, C.byref(tot))
+                                        byt.ctypes.data, path.ctypes.data, C.byref(tot))
         cyc = np.zeros(80, dtype=np.uint64)
         self._lib.spmx_last_phase_cycles(self._h, cyc.ctypes.data)
         names = []
@@ -639,8 +667,9 @@ class SentencePieceProcessor:
             self._lib.spmx_last_profile_name(self._h, c, buf, 64)
             names.append(buf.value.decode())
         return dict(classes=[dict(kernel=names[c], kernel_ms=float(ms[c]), sentences=int(sent[c]), raw_bytes=int(raw[c]),
-                                  ids=int(ids[c]), bytes=int(byt[c]), rcap=int(rcap[c]),
+                                  ids=int(ids[c]), bytes=int(byt[c]),
                                   phase_cycles=dict(zip(("load", "normalize", "segment", "emit", "search_trips"),
                                                         (int(x) for x in cyc[5 * c:5 * c + 5]))))
                              for c in range(k)],
+                    path=dict(hard=int(path[0]), overflow=int(path[1]), long=int(path[2]), failed=int(path[3])),
                     total_ms=float(tot.value))

@@ -27,21 +27,33 @@ void RunGrid(int grid, int waves, uint32_t lds_bytes, F body) {
 }
 }  // namespace
 
-hipError_t LaunchEncodeStream(int model_type, int cls, bool fast, const EncodeArgs &a, int grid, int waves,
+hipError_t LaunchEncodeStream(int model_type, bool uds, const EncodeArgs &a, int grid, int waves,
                               uint32_t lds_bytes, hipStream_t) {
-  (void)cls;
   if (model_type == 2) {
-    if (fast) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<true, 2>(a, s); });
-    else RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<false, 2>(a, s); });
-  } else if (fast) {
-    if (a.ring == 16) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<true, 1, 16>(a, s); });
-    else RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<true, 1>(a, s); });
+    RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<2, 0, false>(a, s); });
+  } else if (a.ring == 16) {
+    if (uds) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<1, 16, true>(a, s); });
+    else RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<1, 16, false>(a, s); });
   } else {
-    RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<false, 1>(a, s); });
+    if (uds) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<1, 0, true>(a, s); });
+    else RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<1, 0, false>(a, s); });
   }
   return hipSuccess;
 }
+hipError_t LaunchBpeLong(const LongArgs &a, int grid, hipStream_t) {
+  RunGrid(grid, 1, 64 * kRawWinBytes, [&](unsigned char *s) { bpe_long_block(a, s); });
+  return hipSuccess;
+}
 
+hipError_t LaunchNormalizeLong(bool write, const NormalizeArgs &a, int grid, hipStream_t) {
+  if (write) RunGrid(grid, 1, 64 * kRawWinBytes, [&](unsigned char *s) { norm_long_block<true>(a, s); });
+  else RunGrid(grid, 1, 64 * kRawWinBytes, [&](unsigned char *s) { norm_long_block<false>(a, s); });
+  return hipSuccess;
+}
+hipError_t LaunchAlignLong(const AlignLongArgs &a, int grid, hipStream_t) {
+  RunGrid(grid, 1, 64 * kRawWinBytes, [&](unsigned char *s) { align_long_block(a, s); });
+  return hipSuccess;
+}
 hipError_t LaunchEncode(int, int, const EncodeArgs &a, int grid, uint32_t lds_bytes, hipStream_t) {
   RunGrid(grid, 1, lds_bytes, [&](unsigned char *s) { encode_block<2>(a, s); });
   return hipSuccess;

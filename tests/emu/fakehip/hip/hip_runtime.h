@@ -33,7 +33,7 @@ inline hipError_t hipMalloc(void **p, size_t n) {
   // 64 bytes of slack on either side, poisoned: the kernels' aligned 16-byte loads may over-read inside an allocation
   unsigned char *b = static_cast<unsigned char *>(malloc(n + 128));
   if (!b) return hipErrorOutOfMemory;
-  memset(b, 0xCD, n + 128);
+  memset(b, 0xCD, n + 128 < (256u << 20) ? n + 128 : (256u << 20));   // poison (the first 256 MiB of a huge block)
   *p = b + 64;
   return hipSuccess;
 }

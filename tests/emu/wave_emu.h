@@ -94,6 +94,12 @@ inline unsigned long long atomic_add(unsigned long long *p, unsigned long long v
 inline void atomic_or(uint32_t *p, uint32_t v) { *p |= v; }
 inline uint32_t lds_atomic_add(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
 inline void atomic_min(unsigned long long *p, unsigned long long v) { if (v < *p) *p = v; }
+inline void atomic_max(unsigned long long *p, unsigned long long v) { if (v > *p) *p = v; }
+inline void atomic_and(uint32_t *p, uint32_t v) { *p &= v; }
+inline uint32_t atomic_load(const uint32_t *p) { return *p; }
+inline void release_fence() {}
+inline void acquire_fence() {}
+inline void nap() { static long spins = 0; if (++spins > 64000000L) { fprintf(stderr, "wave_emu: a wave waits forever\n"); abort(); } }
 
 inline unsigned long long clock() { return 0; }
 
@@ -101,6 +107,7 @@ inline int popc64(uint64_t x) { return __builtin_popcountll(x); }
 inline int ffs64(uint64_t x) { return __builtin_ffsll(static_cast<long long>(x)); }
 inline int clz64(uint64_t x) { return x ? __builtin_clzll(x) : 64; }
 inline float bits_to_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+inline uint32_t float_to_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
 }  // namespace wv
 }  // namespace spmx

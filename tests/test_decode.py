@@ -92,7 +92,7 @@ def test_emu_decode(model, oracle, corpora):
     np.testing.assert_array_equal(et, ot)
     with pytest.raises(RuntimeError):
         e.decode_batch(np.array([1, 2, 10 ** 7], dtype=np.int32), np.array([0, 1, 3], dtype=np.uint64))
-    assert e.status != 0
+    assert "Invalid id" in e.lib.spmx_last_error(None).decode()
 
 
 # ------------------------------------------------------------------ GPU ----

@@ -1,7 +1,6 @@
-"""The product's device bodies (sentencepiece_amd/csrc/kernels*.h) and host
-table compiler run on the CPU under the lock-step wavefront model of
-tests/emu/ and are compared with the oracle.  Small inputs only (the model
-executes 64 fibers per wave); the full-size parity runs are the -m gpu tests."""
+"""The product's launch sequence (csrc/api.cc), device bodies (csrc/kernels*.h) and host table compiler run on the
+CPU -- the C ABI of tests/emu/libspmx_emu.so, see tests/emulib.py -- and are compared with the oracle.  Small inputs
+only (the model executes 64 fibers per wave); the full-size parity runs are the -m gpu tests."""
 import numpy as np
 import pytest
 
@@ -24,7 +23,7 @@ def test_emu_edge_and_samples(model, emu, oracle, corpora):
     o = oracle.load(blob)
     for name, k in (("edge", 10 ** 6), ("botchan", 120), ("mixed2k", 25)):
         text, offs = fixtures.head(*corpora[name], k)
-        ids, io = h.encode_batch(text, offs, grid=3)
+        ids, io = h.encode_batch(text, offs)
         assert h.status == 0
         oids, oio = o.encode_batch(text, offs)
         np.testing.assert_array_equal(io, oio)
@@ -47,7 +46,7 @@ def test_emu_long_sentences(model, emu, oracle, corpora):
     pick = np.concatenate([np.arange(n - 5, n), np.arange(n - 400, n - 5, 80)])
     text, offs = synth.gather_packed(t, of, pick)
     for tx, ox in ((text, offs), fixtures.head(*corpora["ja"], 12)):
-        ids, io = h.encode_batch(tx, ox, grid=2)
+        ids, io = h.encode_batch(tx, ox)
         assert h.status == 0
         oids, oio = o.encode_batch(tx, ox)
         np.testing.assert_array_equal(io, oio)
@@ -58,8 +57,8 @@ def test_emu_long_sentences(model, emu, oracle, corpora):
 @pytest.mark.parametrize("env", [{}, {"SPMX_NO_COMPRESS": "1"}, {"SPMX_NO_FAST": "1"},
                                  {"SPMX_NO_COMPRESS": "1", "SPMX_NO_FAST": "1"}])
 def test_emu_tile_variants(model, env, emu, oracle, corpora, monkeypatch):
-    """One-byte space symbol on/off x FAST per-lane normalizer on/off: same ids; with both on, ASCII sentences
-    stay in the FAST kernel and the rest is handed over."""
+    """One-byte space symbol on/off x ASCII fast path on/off: same ids; with both on, ASCII sentences are normalized
+    by the tile that drew them and stray non-ASCII ones are set aside on the class's hard list."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     blob = fixtures.model_blob(model)
@@ -68,16 +67,16 @@ def test_emu_tile_variants(model, env, emu, oracle, corpora, monkeypatch):
     o = oracle.load(blob)
     for name, k in (("edge", 10 ** 6), ("synth20k", 300), ("mixed2k", 40), ("botchan", 150)):
         text, offs = fixtures.head(*corpora[name], k)
-        ids, io = h.encode_batch(text, offs, grid=2)
+        ids, io = h.encode_batch(text, offs)
         assert h.status == 0
         oids, oio = o.encode_batch(text, offs)
         np.testing.assert_array_equal(io, oio)
         np.testing.assert_array_equal(ids, oids)
-        kept, handed = h.fast_split()
-        if not env and name == "synth20k" and model != "uni1k_suffix":   # suffix mode: GENERAL kernel only
-            assert kept > 0.9 * (len(offs) - 1)
-        if "SPMX_NO_FAST" in env or "SPMX_NO_COMPRESS" in env:
-            assert kept == 0
+        hard = h.path()["hard"]
+        if not env and name == "synth20k":       # ASCII sentences stay with the tile that drew them
+            assert hard < 0.1 * (len(offs) - 1)
+        if "SPMX_NO_FAST" in env or model == "uni1k_suffix":   # every lane in norm_lane_any: nothing is set aside
+            assert hard == 0
 
 
 K_WORDWISE = 1 << 10   # dev.h kNfBpeWordwise
@@ -87,32 +86,32 @@ K_WORDWISE = 1 << 10   # dev.h kNfBpeWordwise
                                              ("uni1k_bf", "edge", 10 ** 6), ("bpe32k", "mixed2k", 40)])
 @pytest.mark.parametrize("env", [{}, {"SPMX_NO_LANE_GENERAL": "1"}])
 def test_emu_lane_general_normalizer(model, corpus, k, env, emu, oracle, corpora, monkeypatch):
-    """Non-ASCII text: the per-lane general normalizer keeps the sentences in the FAST kernel (charsmap rules,
-    malformed UTF-8, literal U+2581 ...); with it switched off they go through normalize_wave.  Same ids."""
+    """Non-ASCII text: a tile with enough such sentences normalizes them itself (norm_lane_any); with that switched
+    off they all go through the hard list.  Same ids."""
     for kk, v in env.items():
         monkeypatch.setenv(kk, v)
     blob = fixtures.model_blob(model)
     h = emu.load(blob)
     o = oracle.load(blob)
     text, offs = fixtures.head(*corpora[corpus], k)
-    ids, io = h.encode_batch(text, offs, grid=2)
+    ids, io = h.encode_batch(text, offs)
     assert h.status == 0
     oids, oio = o.encode_batch(text, offs)
     np.testing.assert_array_equal(io, oio)
     np.testing.assert_array_equal(ids, oids)
-    kept, handed = h.fast_split()
-    if env:      # (characters that start no charsmap key stay in the FAST kernel's own normalizer either way)
-        assert handed > 0.25 * (len(offs) - 1)
-    elif model != "uni1k_bf":      # (the edge cases are mostly ASCII tiles: stray non-ASCII sentences are handed over)
-        assert kept > 0.3 * (len(offs) - 1)
+    hard = h.path()["hard"]
+    if env:      # (characters that start no charsmap key stay with the ASCII fast path either way)
+        assert hard > 0.25 * (len(offs) - 1)
+    elif model != "uni1k_bf":      # (the edge cases are mostly ASCII tiles: stray non-ASCII sentences are set aside)
+        assert hard < 0.7 * (len(offs) - 1)
 
 
 @pytest.mark.parametrize("model", ["bpe1k", "bpe32k", "bpe1k_bf_uds", "bpe1k_noesc", "bpe1k_llama"])
 @pytest.mark.parametrize("env", [{}, {"SPMX_NO_WORDWISE": "1"}, {"SPMX_NO_COMPRESS": "1"}, {"SPMX_NO_FAST": "1"},
-                                 {"SPMX_NO_STREAM": "1"}])
+                                 {"SPMX_NO_STREAM": "1"}, {"SPMX_NO_WAVE": "1"}])
 def test_emu_bpe_variants(model, env, emu, oracle, corpora, monkeypatch):
-    """BPE: lane-per-sentence word-by-word form (word-wise models) vs sentence-per-wave form: same ids; long
-    words are handed to the sentence-per-wave kernel."""
+    """BPE: lane-per-sentence word-by-word form (word-wise models) vs sentence-per-wave form: same ids; sentences
+    with a word longer than the lane form's slots take the long form."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     blob = fixtures.model_blob(model)
@@ -123,15 +122,15 @@ def test_emu_bpe_variants(model, env, emu, oracle, corpora, monkeypatch):
     o = oracle.load(blob)
     for name, k in (("edge", 10 ** 6), ("synth20k", 200), ("mixed2k", 40), ("botchan", 120)):
         text, offs = fixtures.head(*corpora[name], k)
-        ids, io = h.encode_batch(text, offs, grid=2)
+        ids, io = h.encode_batch(text, offs)
         assert h.status == 0
         oids, oio = o.encode_batch(text, offs)
         np.testing.assert_array_equal(io, oio)
         np.testing.assert_array_equal(ids, oids)
         if name == "edge" and wordwise and "SPMX_NO_STREAM" not in env:
-            assert h.wave_handed() >= 3      # "a" * 300, "0123456789" * 40, a long CJK run ...
+            assert h.path()["long"] >= 3      # "a" * 300, "0123456789" * 40, a long CJK run ...
         if name == "synth20k" and wordwise and not env:
-            assert h.fast_split()[0] > 0.9 * (len(offs) - 1) and h.wave_handed() == 0
+            assert h.path()["hard"] < 0.1 * (len(offs) - 1) and h.path()["long"] == 0
 
 
 @pytest.mark.parametrize("model,opts", [("test_model", "bos:eos"), ("test_model", "reverse:bos"),
@@ -181,17 +180,18 @@ def test_emu_capacity_report(emu, corpora):
     full, io = h.encode_batch(text, offs)
     ids = np.full(8, -7, dtype=np.int32)
     id_offs = np.zeros(len(offs), dtype=np.uint64)
-    st = C.c_uint32(0)
-    tot = h.lib.emu_encode_batch(h.h, np.ascontiguousarray(text).ctypes.data, np.ascontiguousarray(offs).ctypes.data,
-                                 len(offs) - 1, ids.ctypes.data, 8, id_offs.ctypes.data, 2, C.byref(st))
-    assert tot == -len(full) - 2
+    tot = C.c_uint64(0)
+    text, offs = np.ascontiguousarray(text), np.ascontiguousarray(offs)
+    rc = h.lib.spmx_encode_batch_device(h.sp._h, text.ctypes.data, len(text), offs.ctypes.data, len(offs) - 1, ids.ctypes.data, 8,
+                                        id_offs.ctypes.data, None, C.byref(tot))
+    assert rc == 8 and tot.value == len(full)            # RESOURCE_EXHAUSTED + the needed capacity
     assert (ids == -7).all()
     np.testing.assert_array_equal(id_offs, io)
 
 
 @pytest.mark.parametrize("model", ["test_model", "c5_250k_bf", "test_ja_model"])
 def test_emu_document_length(model, emu, oracle, corpora):
-    """Sentences beyond the staged classes (> 8192 B raw): the FAST kernel alone, per-lane normalizers for ASCII and
+    """Document-length sentences: the second streaming launch (classes above 16 KiB), per-lane normalizers for ASCII and
     for everything else."""
     from sentencepiece_amd import synth
     blob = fixtures.model_blob(model)
@@ -204,20 +204,137 @@ def test_emu_document_length(model, emu, oracle, corpora):
             b"x" * 9000, ("猫 " * 3000).encode()]
     assert all(len(d) > 8192 for d in docs)
     text, offs = synth.pack(docs)
-    ids, io = h.encode_batch(text, offs, grid=2)
+    ids, io = h.encode_batch(text, offs)
     assert h.status == 0
     oids, oio = o.encode_batch(text, offs)
     np.testing.assert_array_equal(io, oio)
     np.testing.assert_array_equal(ids, oids)
 
 
-def test_emu_document_length_needs_fast_model(emu, corpora):
-    """A model the per-lane normalizers cannot take (user-defined symbols) is limited to the staged classes."""
+def long_documents(corpora, size):
+    """Documents of about `size` bytes + a few shapes that stress the capacities: a word of thousands of characters,
+    NFKC expansions (U+FDFA -> 18 characters), malformed bytes (each becomes U+FFFD), leading whitespace, nothing."""
     from sentencepiece_amd import synth
-    h = emu.load(fixtures.model_blob("uni1k_uds"))
-    text, offs = synth.pack([b"y" * 9000])
-    h.encode_batch(text, offs, grid=1)
-    assert h.status & 2          # kStTooLong: csrc/api.cc turns it into OUT_OF_RANGE
+    bot, _ = corpora["botchan"]
+    ja, _ = corpora["ja"]
+    docs = [bot[:size].tobytes(), ja[:size * 2 // 3].tobytes(), b"x" * (size // 8) + b" " + b"0123456789" * (size // 40),
+            bot[:300].tobytes(), b"", ("\ufdfa" * (size // 30)).encode(), b"\xff\xfe" * (size // 20),
+            (" " * (size // 10) + "a").encode()]
+    return synth.pack(docs)
+
+
+@pytest.mark.parametrize("classes", ["small", "default"])
+@pytest.mark.parametrize("model", ["uni1k_uds", "uni1k_suffix", "bpe1k_noesc", "bpe1k_bf_uds", "test_model", "bpe1k"])
+def test_emu_no_length_limit(model, classes, emu, oracle, corpora):
+    """Models the fast forms take only in part (user-defined symbols, whitespace as suffix, BPE pieces that span
+    words) and documents far beyond every staged class: every sentence is encoded, bit-equal to the oracle.  The
+    shrunken class table sends them through the overflow launch (exact capacities), the default one through the
+    document launch; BPE takes the long form."""
+    from tests import emulib
+    blob = fixtures.model_blob(model)
+    h = emu.load(blob, classes=emulib.SMALL_CLASSES if classes == "small" else None)
+    o = oracle.load(blob)
+    text, offs = long_documents(corpora, 24000)
+    ids, io = h.encode_batch(text, offs)
+    assert h.status == 0 and not h.sent_status.any()
+    oids, oio = o.encode_batch(text, offs)
+    np.testing.assert_array_equal(io, oio)
+    np.testing.assert_array_equal(ids, oids)
+    if model.startswith("uni") or model == "test_model":
+        assert h.path()["overflow"] >= 1          # the NFKC expansions outgrow any class column
+
+
+def test_emu_hundred_kilobyte_documents(emu, oracle, corpora):
+    """100 KB documents through a user-defined-symbol unigram model and a BPE model whose pieces span words."""
+    for model in ("uni1k_uds", "bpe1k_noesc"):
+        blob = fixtures.model_blob(model)
+        h, o = emu.load(blob, classes=None), oracle.load(blob)
+        text, offs = long_documents(corpora, 100_000)
+        ids, io = h.encode_batch(text, offs)
+        assert not h.sent_status.any()
+        oids, oio = o.encode_batch(text, offs)
+        np.testing.assert_array_equal(io, oio)
+        np.testing.assert_array_equal(ids, oids)
+
+
+@pytest.mark.parametrize("model", ["test_model", "uni1k_uds", "uni1k_suffix", "bpe1k", "bpe1k_noesc"])
+def test_emu_spans_and_normalize_of_long_documents(model, emu, oracle, corpora):
+    """The spans form and Normalize(input, &normalized, &norm_to_orig) beyond the staged classes: the lane-per-sentence
+    align / normalize kernels (kernels_long.h), which store nothing per sentence."""
+    blob = fixtures.model_blob(model)
+    h, o = emu.load(blob, classes=None), oracle.load(blob)
+    text, offs = long_documents(corpora, 20000)
+    for opts in ("", "reverse:bos:eos"):
+        h.set_encode_extra_options(opts)
+        o.set_encode_extra_options(opts)
+        got = h.encode_spans(text, offs)
+        want = o.encode_spans(text, offs)
+        for a, b, nm in zip(got, want, ("ids", "begin", "end", "id_offsets")):
+            np.testing.assert_array_equal(np.asarray(a).astype(np.int64), np.asarray(b).astype(np.int64), err_msg="%s [%s]" % (nm, opts))
+    h.set_encode_extra_options("")
+    o.set_encode_extra_options("")
+    gn = h.normalize_batch(text, offs)
+    wn = o.normalize_batch(text, offs)
+    for a, b, nm in zip(gn, wn, ("normalized", "norm_offsets", "norm_to_orig")):
+        np.testing.assert_array_equal(np.asarray(a).astype(np.int64), np.asarray(b).astype(np.int64), err_msg=nm)
+
+
+def test_emu_bpe_long_form_with_unused_pieces(emu, oracle, corpora):
+    """SetVocabulary turns most pieces UNUSED: every sentence resegments through rev_merge (bpe_model.cc:175-200); the
+    sentence-per-wave form hands what outgrows its 64-entry table to the long form, which has no such bound."""
+    import sentencepiece as spm   # only to list piece strings
+    blob = fixtures.model_blob("bpe1k")
+    sp = spm.SentencePieceProcessor(model_proto=blob)
+    vocab = [sp.id_to_piece(i) for i in range(0, sp.get_piece_size(), 7)]
+    bot, boffs = corpora["botchan"]
+    from sentencepiece_amd import synth
+    text, offs = synth.pack([bot[:3000].tobytes(), bot[3000:3500].tobytes(), bot[:12000].tobytes()])
+    for env in ({}, {"SPMX_NO_WAVE": "1"}):
+        h, o = emu.load(blob, env=env), oracle.load(blob)
+        h.set_vocabulary(vocab)
+        o.set_vocabulary(vocab)
+        ids, io = h.encode_batch(text, offs)
+        oids, oio = o.encode_batch(text, offs)
+        np.testing.assert_array_equal(io, oio)
+        np.testing.assert_array_equal(ids, oids)
+        assert not h.sent_status.any()
+
+
+def test_emu_per_sentence_status(emu, oracle, corpora):
+    """A sentence the reference's Encode fails -- a character that is a CONTROL piece among the BPE symbols consumes no
+    text, so the reference reports "all normalized characters are not consumed" (sentencepiece_processor.cc:566-571,
+    :628) -- yields no ids and a status byte; the other sentences of the batch are encoded as ever, and the
+    single-sentence call returns that Status."""
+    import ctypes as C
+    from sentencepiece import sentencepiece_model_pb2 as pb
+    from sentencepiece_amd import synth
+    m = pb.ModelProto()
+    m.ParseFromString(fixtures.model_blob("bpe1k"))
+    p = m.pieces.add()
+    p.piece, p.score, p.type = "\u2603", 0.0, 3            # a one-character CONTROL piece
+    blob = m.SerializeToString()
+    h, o = emu.load(blob), oracle.load(fixtures.model_blob("bpe1k"))
+    bot, boffs = corpora["botchan"]
+    good = [bot[int(boffs[i]):int(boffs[i + 1])].tobytes() for i in range(5)]
+    bad = "say \u2603 then".encode()
+    text, offs = synth.pack(good[:2] + [bad] + good[2:])
+    ids, io = h.encode_batch(text, offs)
+    oids, oio = o.encode_batch(*synth.pack(good))
+    assert h.sent_status.tolist() == [0, 0, 13, 0, 0, 0] and h.status == 1
+    cnt = np.diff(io.astype(np.int64))
+    assert cnt[2] == 0
+    np.testing.assert_array_equal(np.delete(cnt, 2), np.diff(oio.astype(np.int64)))
+    np.testing.assert_array_equal(ids, oids)
+    out = np.zeros(64, dtype=np.int32)
+    n_ids = C.c_uint64(0)
+    assert h.lib.spmx_encode(h.sp._h, bad, len(bad), out.ctypes.data, 64, C.byref(n_ids)) == 13
+    assert "not consumed" in h.lib.spmx_last_error(None).decode()
+    from tests import refshim
+    if refshim.available():                                # the compiled reference fails the same sentence
+        r = refshim.RefLib().load(blob)
+        with pytest.raises(RuntimeError):
+            r.encode(bad)
+        assert r.encode(good[0]).tolist() == ids[:int(io[1])].tolist()
 
 
 @pytest.mark.parametrize("model", ["uni32k", "uni1k_ident", "bpe1k", "uni1k_bf"])
@@ -247,24 +364,23 @@ def test_emu_fast_keeps_identity_characters(model, emu, oracle):
     text, offs = synth.pack(sent)
     blob = fixtures.model_blob(model)
     h, o = emu.load(blob), oracle.load(blob)
-    ids, io = h.encode_batch(text, offs, grid=2)
+    ids, io = h.encode_batch(text, offs)
     assert h.status == 0
     oids, oio = o.encode_batch(text, offs)
     np.testing.assert_array_equal(io, oio)
     np.testing.assert_array_equal(ids, oids)
-    kept, handed = h.fast_split()
-    assert kept >= 0.7 * 300 and handed >= n_leave // 2     # (a stray byte can start a key together with its neighbour)
+    assert h.path()["hard"] <= 0.3 * 300     # (set aside only when the tile has too few such sentences to keep them)
 
 
 @pytest.mark.parametrize("model", ["bpe1k", "bpe1k_llama"])
 def test_emu_bpe_documents(model, emu, oracle):
-    """BPE document-length class: the lane form with the HBM merge for words that outgrow the LDS slots."""
+    """BPE documents: the lane form word by word; a document with a word that outgrows the LDS slots takes the long form."""
     from tests.test_gpu_parity import bpe_documents
     text, offs = bpe_documents()
     text, offs = fixtures.head(text, offs, 8)
     blob = fixtures.model_blob(model)
     h, o = emu.load(blob), oracle.load(blob)
-    ids, io = h.encode_batch(text, offs, grid=2)
+    ids, io = h.encode_batch(text, offs)
     assert h.status == 0
     oids, oio = o.encode_batch(text, offs)
     np.testing.assert_array_equal(io, oio)

@@ -55,7 +55,7 @@ def test_golden(key, manifest, golden_arrays, corpora, procs, oracle):
 
 def test_document_length_sentences(procs, oracle, corpora):
     """Inputs far beyond the staged length classes (SentencePiece is routinely fed whole documents): 100 KB of ASCII,
-    60 KB of Japanese, 1 MiB of one character; a model the per-lane normalizers cannot take stops at 8192 bytes."""
+    60 KB of Japanese, 1 MiB of one character, something longer than the last class."""
     from sentencepiece_amd import synth
     bot, boffs = corpora["botchan"]
     ja, joffs = corpora["ja"]
@@ -69,11 +69,81 @@ def test_document_length_sentences(procs, oracle, corpora):
         oids, oio = oracle.load(fixtures.model_blob(model)).encode_batch(text, offs)
         np.testing.assert_array_equal(io, oio)
         np.testing.assert_array_equal(ids, oids)
-    with pytest.raises(Exception) as ei:
-        procs("uni1k_uds").EncodePacked(*synth.pack([b"y" * 9000]))
-    assert "8192" in str(ei.value)
-    with pytest.raises(Exception):
-        procs("test_model").EncodePacked(*synth.pack([b"z" * (1 << 20) + b"!"]))
+    t, of = synth.pack([b"y" * 9000, b"z" * (1 << 20) + b"!"])
+    for model in ("uni1k_uds", "test_model"):
+        ids, io = procs(model).EncodePacked(t, of)
+        oids, oio = oracle.load(fixtures.model_blob(model)).encode_batch(t, of)
+        np.testing.assert_array_equal(io, oio)
+        np.testing.assert_array_equal(ids, oids)
+
+
+def limit_documents(corpora, size):
+    """A document of `size` bytes of English, one of Japanese, a word of size / 8 characters, NFKC expansions (U+FDFA ->
+    18 characters each), malformed bytes (each becomes U+FFFD), leading whitespace, nothing, a short sentence."""
+    from sentencepiece_amd import synth
+    bot, _ = corpora["botchan"]
+    ja, _ = corpora["ja"]
+    reps = size // len(bot) + 1
+    eng = np.tile(bot, reps)[:size].tobytes()
+    jap = np.tile(ja, size // len(ja) + 1)[:size * 2 // 3].tobytes()
+    docs = [eng, jap, b"x" * (size // 8) + b" " + b"0123456789" * (size // 40), bot[:300].tobytes(), b"",
+            ("\ufdfa" * (size // 30)).encode(), b"\xff\xfe" * (size // 20), (" " * (size // 10) + "a").encode()]
+    return synth.pack(docs)
+
+
+@pytest.mark.parametrize("model", ["uni1k_uds", "uni1k_suffix", "bpe1k_noesc", "bpe1k_bf_uds"])
+def test_no_length_limit(model, procs, oracle, corpora):
+    """a 100 KB and a 1 MiB document through the models the fast forms take only in part
+    (user-defined symbols, whitespace as suffix, BPE pieces that span words): bit-equal to the reference's algorithm,
+    every status byte zero."""
+    sp = procs(model)
+    o = oracle.load(fixtures.model_blob(model))
+    for size in (100_000, 1 << 20):
+        text, offs = limit_documents(corpora, size)
+        ids, io, st, failed = sp.EncodePackedEx(text, offs)
+        assert failed == 0 and not st.any()
+        oids, oio = o.encode_batch(text, offs)
+        np.testing.assert_array_equal(io, oio)
+        np.testing.assert_array_equal(ids, oids)
+
+
+def test_spans_and_normalize_of_long_documents(procs, oracle, corpora):
+    """The spans form and Normalize on 100 KB documents (beyond every staged class): lane-per-sentence kernels."""
+    text, offs = limit_documents(corpora, 100_000)
+    for model in ("test_model", "uni1k_uds", "bpe1k", "bpe1k_noesc"):
+        sp = procs(model)
+        o = oracle.load(fixtures.model_blob(model))
+        got = sp.EncodeSpansPacked(text, offs)
+        want = o.encode_spans(text, offs)
+        for a, b, nm in zip(got, want, ("ids", "begin", "end", "id_offsets")):
+            np.testing.assert_array_equal(np.asarray(a).astype(np.int64), np.asarray(b).astype(np.int64), err_msg="%s %s" % (model, nm))
+        gn = sp.NormalizePacked(text, offs, with_offsets=True)
+        wn = o.normalize_batch(text, offs)
+        for a, b, nm in zip(gn, wn, ("normalized", "norm_offsets", "norm_to_orig")):
+            np.testing.assert_array_equal(np.asarray(a).astype(np.int64), np.asarray(b).astype(np.int64), err_msg="%s %s" % (model, nm))
+
+
+def test_failing_sentence_does_not_fail_the_batch(procs, oracle, corpora):
+    """A sentence the reference's Encode fails (a one-character CONTROL piece among BPE symbols: "all normalized
+    characters are not consumed", sentencepiece_processor.cc:628) yields no ids and status 13; the rest of the batch
+    is encoded."""
+    from sentencepiece import sentencepiece_model_pb2 as pb
+    from sentencepiece_amd import synth
+    from sentencepiece_amd.processor import SentencePieceProcessor
+    m = pb.ModelProto()
+    m.ParseFromString(fixtures.model_blob("bpe1k"))
+    p = m.pieces.add()
+    p.piece, p.score, p.type = "\u2603", 0.0, 3
+    sp = SentencePieceProcessor(model_proto=m.SerializeToString())
+    bot, boffs = corpora["botchan"]
+    good = [bot[int(boffs[i]):int(boffs[i + 1])].tobytes() for i in range(200)]
+    bad = "say \u2603 then".encode()
+    text, offs = synth.pack(good[:77] + [bad] + good[77:])
+    ids, io, st, failed = sp.EncodePackedEx(text, offs)
+    oids, oio = oracle.load(fixtures.model_blob("bpe1k")).encode_batch(*synth.pack(good))
+    assert failed == 1 and st[77] == 13 and int(st.sum()) == 13
+    np.testing.assert_array_equal(ids, oids)
+    np.testing.assert_array_equal(np.delete(np.diff(io.astype(np.int64)), 77), np.diff(oio.astype(np.int64)))
 
 
 def bpe_documents():
@@ -107,9 +177,8 @@ def bpe_documents():
 
 
 def test_bpe_document_length_sentences(procs, oracle, corpora):
-    """BPE models take documents too (the lane form works word by word; a word that outgrows its LDS slots is merged in
-    HBM): ids equal to the oracle's; a word of more than 4096 characters, and models that cannot be segmented word by
-    word, stop with OUT_OF_RANGE."""
+    """BPE models take documents too (the lane form works word by word; a sentence with a word that outgrows its LDS
+    slots, and models that cannot be segmented word by word, take the long form): ids equal to the oracle's."""
     from sentencepiece_amd import synth
     text, offs = bpe_documents()
     bot, boffs = corpora["botchan"]
@@ -122,8 +191,9 @@ def test_bpe_document_length_sentences(procs, oracle, corpora):
             oids, oio = o.encode_batch(t, of)
             np.testing.assert_array_equal(io, oio)
             np.testing.assert_array_equal(ids, oids)
-    with pytest.raises(Exception):
-        procs("bpe1k").EncodePacked(*synth.pack([b"x" * 5000]))
-    with pytest.raises(Exception) as ei:
-        procs("bpe1k_bf_uds").EncodePacked(*synth.pack([b"hello world " * 500]))
-    assert "4096" in str(ei.value)
+    t, of = synth.pack([b"x" * 5000, b"hello world " * 500])
+    for model in ("bpe1k", "bpe1k_bf_uds"):
+        ids, io = procs(model).EncodePacked(t, of)
+        oids, oio = oracle.load(fixtures.model_blob(model)).encode_batch(t, of)
+        np.testing.assert_array_equal(io, oio)
+        np.testing.assert_array_equal(ids, oids)
