@@ -206,7 +206,8 @@ class SentencePieceProcessor {
         p.end = e[k];
         p.surface.assign(input.data() + b[k], e[k] - b[k]);
         const int type = spmx_piece_type(h_, ids[k]);
-        if (type == 6 || type == 3 || (type == 2 && unk_piece_option_)) p.piece = IdToPiece(ids[k]);
+        if (type == 2 && unk_piece_option_) p.piece = UnkPiece();     // model_->unk_piece() (:1050-1058)
+        else if (type == 6 || type == 3) p.piece = IdToPiece(ids[k]);
         else p.piece.assign(norm + nb[k], ne[k] - nb[k]);
         spt->pieces.push_back(std::move(p));
       }
@@ -335,6 +336,14 @@ class SentencePieceProcessor {
   bool IsControl(int id) const { return h_ && spmx_piece_type(h_, id) == 3; }
   bool IsUnused(int id) const { return h_ && spmx_piece_type(h_, id) == 5; }
   bool IsByte(int id) const { return h_ && spmx_piece_type(h_, id) == 6; }
+  // trainer_spec.unk_piece: what the `unk_piece` extra option writes for unknown tokens
+  std::string UnkPiece() const {
+    if (!h_) return std::string();
+    const int64_t n = spmx_unk_piece(h_, nullptr, 0);
+    std::string s(static_cast<size_t>(n > 0 ? n : 0), '\0');
+    if (n > 0) spmx_unk_piece(h_, s.data(), s.size());
+    return s;
+  }
   int unk_id() const { return h_ ? spmx_unk_id(h_) : 0; }
   int bos_id() const { return h_ ? spmx_bos_id(h_) : 0; }
   int eos_id() const { return h_ ? spmx_eos_id(h_) : 0; }

@@ -51,6 +51,7 @@ struct Ctrl {
   uint32_t retry_count[2];            // long form: sentences that found the pool exhausted (ping-pong)
   uint32_t pad;
   StreamQueue q[3];                   // tile queues of the main / document / overflow launches
+  uint32_t align_counts[kMaxClasses]; // spans form: escalation lists of the staged align kernels
   SideLists side;
   unsigned long long arena_head;
   unsigned long long pool_head;       // long form: bytes of slices asked for
@@ -167,6 +168,7 @@ struct spmx_handle {
   uint32_t sub_buckets = kSubBuckets;    // SPMX_SUB_BUCKETS: length sub-buckets per class in the classify sort (1..64)
   uint32_t ring_override = 0;    // SPMX_FORCE_RING: score-ring entries (must exceed the longest piece)
   uint64_t stream_scratch_limit = 16ull << 30;   // SPMX_STREAM_SCRATCH_MB: cap on the streaming kernels' HBM scratch
+  bool tight_tcap = false;       // SPMX_TIGHT_TCAP=1: text columns of 1.125 x the class's raw size (A/B: scratch footprint)
   uint32_t main_max_raw = kStreamMainMaxRaw;     // SPMX_MAIN_MAX_RAW: classes up to this size share the main launch
   LengthClass classes[kNumClasses];              // SPMX_CLASSES="r:n,r:n,...": the class table (tests shrink it)
 };
@@ -423,7 +425,8 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
   }
   const LengthClass *cls = h->classes;
   const int ncls = kNumClasses;
-  // lists: kMaxClasses class lists (the last one is the overflow list), kMaxClasses hard lists, the long list, two retry lists
+  // lists: kMaxClasses class lists (the last one is the overflow list), kMaxClasses escalation lists of the align
+  // kernels, the long list, two retry lists
   HIP_OR_RETURN(h, ws->d_lists.Reserve(static_cast<size_t>(2 * kMaxClasses + 3) * n));
   HIP_OR_RETURN(h, ws->d_counts.Reserve(n + 1));
   HIP_OR_RETURN(h, ws->d_tmp_off.Reserve(n + 1));
@@ -431,7 +434,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
   if (!d_status) { HIP_OR_RETURN(h, ws->d_sent_status.Reserve(n)); d_status = ws->d_sent_status.p; }
   uint32_t *const class_lists = ws->d_lists.p;
   uint32_t *const over_list = class_lists + static_cast<size_t>(kMaxClasses - 1) * n;
-  uint32_t *const hard_lists = class_lists + static_cast<size_t>(kMaxClasses) * n;
+  uint32_t *const hard_lists = class_lists + static_cast<size_t>(kMaxClasses) * n;   // (escalation lists of the align kernels)
   uint32_t *const long_list = class_lists + static_cast<size_t>(2 * kMaxClasses) * n;
   uint32_t *const retry_lists[2] = {long_list + n, long_list + 2 * n};
   // ids are at most one per normalized byte; the streaming kernels reserve a sentence's slot by that bound
@@ -489,7 +492,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
     a.tmp_off = ws->d_tmp_off.p; a.counts = ws->d_counts.p; a.sent_status = d_status; a.status = &ws->d_ctrl->status;
     a.arena_tb = spans ? ws->d_arena_tb.p : nullptr;
     a.long_list = long_list; a.side = &ws->d_ctrl->side;
-    a.lists = class_lists; a.hard_lists = hard_lists; a.over_list = over_list;
+    a.lists = class_lists; a.over_list = over_list;
     a.n = n32;
     a.fast_ok = fast_ok ? 1u : 0u;
     a.no_lane_general = h->no_lane_general ? 1u : 0u;
@@ -508,10 +511,9 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       } else {
         // the last class of the table takes every longer sentence too: those go straight to the overflow list
         sp = PlanStream(h, &la, counts, c_lo, c_hi, ncls, rc2,
-                        [&](int c) { return esc3 ? 2u * cls[c].rcap + 64u : cls[c].ncap; }, !fast_ok);
+                        [&](int c) { return esc3 ? 2u * cls[c].rcap + 64u : (h->tight_tcap ? cls[c].rcap + cls[c].rcap / 8u + 16u : cls[c].ncap); }, !fast_ok);
       }
       if (la.total_main == 0) return kOk;
-      la.n_open = sp.open;
       la.q = &ws->d_ctrl->q[qi];
       la.stats = &ws->d_ctrl->stats[kStatsPerClass * slot];
       const uint64_t slab_total = static_cast<uint64_t>(sp.grid) * sp.waves * sp.slab_bytes;
@@ -646,9 +648,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         p.ids[c] = s[2];
         for (int k = 0; k < 5; ++k) p.cycles[c][k] = s[3 + k];
       }
-      uint64_t hard = 0;
-      for (int qi = 0; qi < 3; ++qi) for (int c = 0; c < kMaxClasses; ++c) hard += ws->h_ctrl->q[qi].hard_count[c];
-      p.path[0] = hard; p.path[1] = ws->h_ctrl->side.over_count; p.path[2] = ws->h_ctrl->side.long_count;
+      p.path[0] = ws->h_ctrl->side.n_backlog; p.path[1] = ws->h_ctrl->side.over_count; p.path[2] = ws->h_ctrl->side.long_count;
       p.path[3] = ws->h_ctrl->side.n_failed;
       HIP_OR_RETURN(h, hipEventElapsedTime(&p.total_ms, ws->ev[kNumSlots][0], ws->ev[kNumSlots][1]));
       std::lock_guard<std::mutex> l(h->mu);
@@ -669,9 +669,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       const uint64_t cgrid = cblocks < static_cast<uint64_t>(h->n_cu) * 32 ? cblocks : static_cast<uint64_t>(h->n_cu) * 32;
       HIP_OR_RETURN(h, LaunchCompact(pa, static_cast<int>(cgrid), stream));
       HIP_OR_RETURN(h, hipMemsetAsync(&ws->d_ctrl->status, 0, sizeof(uint32_t), stream));
-      // the hard lists of the encode are dead by now: they serve as the align kernels' escalation lists, with the
-      // queue words of the main launch as their counters
-      HIP_OR_RETURN(h, hipMemsetAsync(ws->d_ctrl->q[0].hard_count, 0, sizeof(ws->d_ctrl->q[0].hard_count), stream));
+      HIP_OR_RETURN(h, hipMemsetAsync(ws->d_ctrl->align_counts, 0, sizeof(ws->d_ctrl->align_counts), stream));
       HIP_OR_RETURN(h, hipMemsetAsync(&ws->d_ctrl->side.long_count, 0, sizeof(uint32_t), stream));
       AlignArgs base{};
       base.dev = h->dev; base.text = d_text; base.offs = d_offsets;
@@ -689,7 +687,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         aa.rcap = cls[c].rcap; aa.ncap = cls[c].ncap;
         // past the last staged class the sentence goes to the lane-per-sentence align kernel's list
         aa.next_list = has_next ? hard_lists + static_cast<size_t>(c + 1) * n : long_list;
-        aa.next_count = has_next ? &ws->d_ctrl->q[0].hard_count[c + 1] : &ws->d_ctrl->side.long_count;
+        aa.next_count = has_next ? &ws->d_ctrl->align_counts[c + 1] : &ws->d_ctrl->side.long_count;
         const uint32_t lds = AlignLdsBytes(aa.rcap, aa.ncap, aa.nbegin != nullptr && aa.nend != nullptr);
         int per_cu = static_cast<int>(kLdsPerCu / lds);
         if (per_cu > 32) per_cu = 32;
@@ -700,7 +698,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
           HIP_OR_RETURN(h, LaunchAlign(aa, static_cast<int>(full < cnt ? full : cnt), lds, stream));
         }
         if (prev) {                      // what the previous class's align kernels could not hold (count on the device)
-          aa.list = hard_lists + static_cast<size_t>(c) * n; aa.list_count = &ws->d_ctrl->q[0].hard_count[c];
+          aa.list = hard_lists + static_cast<size_t>(c) * n; aa.list_count = &ws->d_ctrl->align_counts[c];
           HIP_OR_RETURN(h, LaunchAlign(aa, static_cast<int>(full < 256 ? full : 256), lds, stream));
         }
         prev = true;
@@ -888,6 +886,8 @@ int Guard(spmx_handle *h, F f) {
 
 extern "C" {
 
+namespace { int RunSelfTest(spmx_handle *h); }
+
 int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_handle **out) {
   if (!out) return Fail(nullptr, kInvalidArgument, "null output handle");
   *out = nullptr;
@@ -914,6 +914,7 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_NO_FAST")) h->no_fast = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_STREAM")) h->no_stream = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_WAVE")) h->no_wave = e[0] == '1';
+    if (const char *e = getenv("SPMX_TIGHT_TCAP")) h->tight_tcap = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_LANE_GENERAL")) h->no_lane_general = e[0] == '1';
     if (const char *e = getenv("SPMX_SUB_BUCKETS")) {
       const int v = atoi(e);
@@ -939,6 +940,8 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
       }
     }
     if (int rc = UploadTables(h.get()); rc != kOk) return rc;
+    if (!h->model.self_test.empty())                        // "Running self-testing." (sentencepiece_processor.cc:259-278)
+      if (int rc = RunSelfTest(h.get()); rc != kOk) return rc;
     *out = h.release();
     return kOk;
   });
@@ -1132,6 +1135,70 @@ int EncodeBatchHost(spmx_handle *h, const char *text, const uint64_t *offsets, u
   if (spans) { *begin = hb; *end = he; }
   if (nspans) { *nbegin = nb; *nend = ne; }
   return kOk;
+}
+}  // namespace
+
+namespace {
+// Load()'s self-test (src/sentencepiece_processor.cc:259-278): every sample of self_test_data is encoded to pieces,
+// joined with ' ' and compared with the expected string through the model's VerifyOutputsEquivalent -- equality for
+// BPE (model_interface.h:194-197), equal path scores within kEpsilon for unigram (unigram_model.cc:857-888).
+int RunSelfTest(spmx_handle *h) {
+  const auto &samples = h->model.self_test;
+  std::string text;
+  std::vector<uint64_t> offs(1, 0);
+  for (const auto &sm : samples) { text += sm.first; offs.push_back(text.size()); }
+  const uint64_t n = samples.size();
+  int32_t *ids = nullptr;
+  uint64_t *io = nullptr, *no = nullptr;
+  uint32_t *b = nullptr, *e = nullptr, *nb = nullptr, *ne = nullptr;
+  char *norm = nullptr;
+  uint8_t *st = nullptr;
+  uint64_t failed = 0;
+  int rc = EncodeBatchHost(h, text.data(), offs.data(), n, &ids, &io, &st, &failed, &b, &e, &nb, &ne);
+  if (rc == kOk) rc = spmx_normalize_batch(h, text.data(), offs.data(), n, &norm, &no, nullptr);
+  auto done = [&](int code, const std::string &msg) {
+    free(ids); free(io); free(st); free(b); free(e); free(nb); free(ne); free(norm); free(no);
+    return code == kOk ? kOk : Fail(h, code, msg);
+  };
+  if (rc != kOk) return done(rc, t_error);
+  const ModelData &m = h->model;
+  auto score_of = [&](const std::string &joined) -> float {          // compute_unigram_model_score
+    float total = 0;
+    const float unk_score = m.min_score - 10.0f;
+    size_t p = 0;
+    for (;;) {                                                       // absl::StrSplit(s, ' '): empty fields are kept
+      const size_t q = joined.find(' ', p);
+      const std::string piece = joined.substr(p, q == std::string::npos ? std::string::npos : q - p);
+      const int id = m.PieceToId(piece);
+      if (id == m.unk_id) total += unk_score;
+      else total += m.pieces[id].type == kUserDefined ? static_cast<float>(static_cast<int>(piece.size()) * m.max_score - 0.1) : m.pieces[id].score;
+      if (q == std::string::npos) break;
+      p = q + 1;
+    }
+    return total;
+  };
+  size_t errors = 0;
+  std::string first;
+  for (uint64_t s = 0; s < n; ++s) {
+    if (st[s]) return done(st[s], StatusText(st[s]));                // RETURN_IF_ERROR(Encode(s.input(), &sps))
+    std::string result;
+    for (uint64_t k = io[s]; k < io[s + 1]; ++k) {
+      if (k > io[s]) result += ' ';
+      const int type = m.pieces[ids[k]].type;
+      if (type == kByte || type == kControl) result += m.pieces[ids[k]].piece;
+      else result.append(norm + no[s] + nb[k], ne[k] - nb[k]);
+    }
+    const std::string &expected = samples[s].second;
+    bool ok = expected == result;
+    if (!ok && m.model_type == kUnigram) {
+      const float d = score_of(expected) - score_of(result);
+      ok = !((d < 0 ? -d : d) > 1e-7f);
+    }
+    if (!ok && errors++ == 0) first = samples[s].first + "\t" + expected + "\t" + result;
+  }
+  if (errors) return done(kInternal, "Self-test failures. See LOG(INFO). " + std::to_string(errors) + "/" + std::to_string(n) +
+                                         " samples did not pass the test; first: " + first);
+  return done(kOk, "");
 }
 }  // namespace
 

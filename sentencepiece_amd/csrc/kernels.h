@@ -44,16 +44,13 @@ struct StreamClass {
   uint32_t tile_base;    // main tiles handed out before this class's (longest class first)
   uint32_t count;        // sentences in the class list
   uint32_t general;      // every lane of its main tiles runs norm_lane_any (models / classes the ASCII fast path cannot take)
-  uint32_t min_lanes;    // a main tile keeps its non-ASCII sentences when at least this many lanes have one
+  uint32_t min_lanes;    // an ASCII tile normalizes its non-ASCII sentences itself when at least this many lanes have one
   uint32_t pad[3];
 };
 // Device-side state of the tile queue of ONE streaming launch, zeroed before it
 struct StreamQueue {
-  uint32_t main_cursor;
-  uint32_t closed;                    // classes closed so far (main tiles done and hard tiles all claimed)
-  uint32_t hard_ready;                // bit c: class c's main tiles are done and its hard list has unclaimed tiles
-  uint32_t pad;
-  uint32_t main_done[kMaxClasses], hard_count[kMaxClasses], hard_claimed[kMaxClasses];
+  uint32_t main_cursor;               // next main tile
+  uint32_t pad[3];
 };
 // Lists that outlive a launch (one set per call): what the streaming launches could not take
 struct SideLists {
@@ -62,6 +59,7 @@ struct SideLists {
   unsigned long long over_max_raw;    // longest raw sentence on the overflow list
   unsigned long long long_raw;        // raw bytes on the long list
   unsigned long long n_failed;        // sentences with a non-zero status byte
+  unsigned long long n_backlog;       // sentences that waited in a wave's backlog (kernels_stream.h)
 };
 
 struct EncodeArgs {
@@ -83,18 +81,16 @@ struct EncodeArgs {
   SideLists *side;
   // ---- streaming launch (kernels_stream.h) ----
   const uint32_t *lists;        // n_classes x n: the class lists of classify
-  uint32_t *hard_lists;         // n_classes x n: per class, sentences its main tiles set aside
   uint32_t *over_list;          // sentences that fit no text column of this launch (null in the overflow launch itself)
   StreamQueue *q;
   uint8_t *slab;                // HBM scratch: slab_bytes per wavefront of the launch
   uint64_t slab_bytes;
-  uint32_t n;                   // sentences of the batch = stride of lists / hard_lists
+  uint32_t n;                   // sentences of the batch = stride of lists
   uint32_t n_classes;
   uint32_t total_main;          // sum of main_tiles
-  uint32_t n_open;              // non-empty classes of this launch (the launch ends when that many are closed)
   uint32_t ring;                // score ring entries (power of two > longest piece)
   uint32_t fast_ok;             // the model meets fast_norm_stream's preconditions
-  uint32_t no_lane_general;     // A/B switch: main tiles set every non-ASCII sentence aside
+  uint32_t no_lane_general;     // A/B switch: ASCII tiles put every non-ASCII sentence into the backlog
   StreamClass cls[kMaxClasses];
   // ---- sentence-per-wave launch (BPE models that are not word-wise; kernels_bpe.h) ----
   const uint32_t *list;         // sentence indices of this length class

@@ -33,11 +33,10 @@
 // ONE persistent launch serves every length class of a call (encode_stream_block): the waves take tiles from a
 // queue, longest class first.  A lane normalizes its own sentence from HBM into its text column -- fast_norm_stream
 // for ASCII, norm_lane_any (kernels_normlane.h) for everything else.  A stray non-ASCII sentence in an ASCII tile
-// would hold the other 63 lanes up for its whole length, so it is set aside on the class's "hard" list instead;
-// when the main tiles of a class are done its hard list is cut into tiles of its own (all lanes in norm_lane_any)
-// and handed out by the same queue, while the shorter classes are still running.  A sentence whose normalized form
-// does not fit its class's text column goes to the call's overflow list (a second, small launch with exact
-// capacities); nothing fails for its length.
+// would hold the other 63 lanes up for its whole length, so the wave keeps it in a backlog of its own and runs the
+// backlog as a tile (all lanes in norm_lane_any) when it has filled up or the queue is empty; waves share nothing but
+// the queue's cursor.  A sentence whose normalized form does not fit its class's text column goes to the call's
+// overflow list (a second, small launch with exact capacities); nothing fails for its length.
 // A workgroup is W wavefronts that share nothing but two read-only LDS tables (first trie level, byte classes;
 // every wave writes identical copies, so no workgroup barrier is ever needed); each wave owns a private slice of LDS.
 #ifndef SPMX_KERNELS_STREAM_H_
@@ -49,7 +48,7 @@ constexpr uint32_t kStreamSharedBytes = 256u * 16u + 256u;   // roottab + bcls
 
 // per-wave profiling counters
 struct WaveCounters {
-  unsigned long long n_sent = 0, n_raw = 0, n_ids = 0, n_trips = 0;
+  unsigned long long n_sent = 0, n_raw = 0, n_ids = 0, n_trips = 0, n_backlog = 0;
   unsigned long long cyc[4] = {0, 0, 0, 0};
 };
 
@@ -75,6 +74,7 @@ struct StreamLds {
   uint32_t *ring_b;   // [R][64]
   uint8_t *win;       // [64][W + 4]: lane l's window starts at win + l * (W + 4)
   uint32_t *stage;    // [2][64][4]: final back-pointer words of the lane's current block of 8 positions
+  uint32_t *backlog;  // [64] sentences waiting for a tile of their own (encode_stream_block)
   uint8_t *rawwin;    // [64][kRawWinBytes] raw-text windows of norm_lane_any (aliases the rings / the BPE word: idle
                       // while a tile is normalized)
   // BPE (kernels_bpe_stream.h) instead of the rings / window / staging block:
@@ -89,7 +89,7 @@ SPMX_HD inline uint32_t StreamPrivateBytes(int model, uint32_t ring) {
   uint32_t work = model == 2 ? BpeWordLdsBytes() + 64u * (kBpeWindow + 4u)
                              : 64u * ring * 8u + 64u * (StreamWindow(ring) + 4u) + 2u * 64u * 16u;
   if (work < 64u * kRawWinBytes) work = 64u * kRawWinBytes;
-  return (work + 15u) & ~15u;
+  return ((work + 15u) & ~15u) + 256u;                 // + the backlog
 }
 SPMX_HD inline uint32_t StreamLdsBytes(int model, uint32_t ring, uint32_t waves) {
   return kStreamSharedBytes + waves * StreamPrivateBytes(model, ring);
@@ -111,6 +111,7 @@ SPMX_DEVICE StreamLds carve_stream(unsigned char *base, int model, uint32_t ring
   t.asym = reinterpret_cast<uint32_t *>(base);
   t.bcls = base + 256u * 16u;
   unsigned char *mine = base + kStreamSharedBytes + static_cast<uint32_t>(wave) * StreamPrivateBytes(model, ring);
+  t.backlog = reinterpret_cast<uint32_t *>(mine + StreamPrivateBytes(model, ring) - 256u);
   t.rawwin = mine;
   t.ring_s = reinterpret_cast<float *>(mine);
   t.ring_b = reinterpret_cast<uint32_t *>(mine + 64u * ring * 4u);
@@ -338,49 +339,17 @@ SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const TextCol &gt, const uint
 }
 
 // ---- the tile queue of one launch ------------------------------------------------------------------------------
-enum : uint32_t { kTileExit = 0, kTileMain = 1, kTileHard = 2, kTileWait = 3 };
-
-// Lane 0 of a wave asks for its next tile.  Main tiles first (one atomic; the classes are laid out longest first in
-// the cursor's range), except that a class whose main tiles are all DONE and that has a hard list is served at once:
-// its bit in q->hard_ready costs one load per tile to check.  Nothing to take but other waves still running main
-// tiles (which may append to hard lists): kTileWait.
-SPMX_DEVICE void next_tile(const EncodeArgs &a, uint32_t *kind, uint32_t *cls, uint32_t *first, uint32_t *cnt) {
-  StreamQueue *q = a.q;
-  *kind = kTileExit;
-  for (;;) {
-    uint32_t ready = wv::atomic_load(&q->hard_ready);
-    while (ready) {
-      const int c = 31 - static_cast<int>(wv::clz64(static_cast<uint64_t>(ready)) - 32);     // longest class first
-      ready &= ~(1u << c);
-      wv::acquire_fence();
-      const uint32_t hc = wv::atomic_load(&q->hard_count[c]);
-      const uint32_t L = 1u << a.cls[c].lane_shift;
-      const uint32_t ht = (hc + L - 1u) / L;
-      if (wv::atomic_load(&q->hard_claimed[c]) >= ht) continue;
-      const uint32_t k = wv::atomic_add(&q->hard_claimed[c], 1u);
-      if (k >= ht) continue;
-      if (k == ht - 1u) {                       // the last hard tile of the class has an owner: the class is closed
-        wv::atomic_and(&q->hard_ready, ~(1u << c));
-        wv::atomic_add(&q->closed, 1u);
-      }
-      *kind = kTileHard; *cls = static_cast<uint32_t>(c); *first = k * L;
-      *cnt = hc - k * L < L ? hc - k * L : L;
-      return;
-    }
-    if (wv::atomic_load(&q->main_cursor) < a.total_main) {
-      const uint32_t t = wv::atomic_add(&q->main_cursor, 1u);
-      if (t < a.total_main) {
-        int c = static_cast<int>(a.n_classes) - 1;
-        while (c > 0 && !(t >= a.cls[c].tile_base && t - a.cls[c].tile_base < a.cls[c].main_tiles)) --c;
-        const uint32_t k = t - a.cls[c].tile_base;
-        *kind = kTileMain; *cls = static_cast<uint32_t>(c); *first = k * a.cls[c].tw;
-        *cnt = a.cls[c].count - *first < a.cls[c].tw ? a.cls[c].count - *first : a.cls[c].tw;
-        return;
-      }
-    }
-    if (wv::atomic_load(&q->closed) >= a.n_open) return;           // every class is closed
-    if (wv::atomic_load(&q->hard_ready) == 0u) { *kind = kTileWait; return; }
-  }
+// Lane 0 of a wave asks for its next main tile: one atomic; the classes are laid out longest first in the cursor's range.
+SPMX_DEVICE bool next_tile(const EncodeArgs &a, uint32_t *cls, uint32_t *first, uint32_t *cnt) {
+  const uint32_t t = wv::atomic_add(&a.q->main_cursor, 1u);
+  if (t >= a.total_main) return false;
+  int c = static_cast<int>(a.n_classes) - 1;
+  while (c > 0 && !(t >= a.cls[c].tile_base && t - a.cls[c].tile_base < a.cls[c].main_tiles)) --c;
+  const uint32_t k = t - a.cls[c].tile_base;
+  *cls = static_cast<uint32_t>(c);
+  *first = k * a.cls[c].tw;
+  *cnt = a.cls[c].count - *first < a.cls[c].tw ? a.cls[c].count - *first : a.cls[c].tw;
+  return true;
 }
 
 // appends the sentences of the lanes in `m` to list[*count ...] (one atomic per wave)
@@ -428,36 +397,49 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
   const uint32_t wave_id = static_cast<uint32_t>(wv::block_id() * wv::waves_per_block() + wv::wave_in_block());
   uint8_t *slab = a.slab + static_cast<uint64_t>(wave_id) * a.slab_bytes;
   uint32_t *my_st = T.stage + static_cast<uint32_t>(lane) * 4u;
-  StreamQueue *q = a.q;
   const int n_extra = d.n_prefix + d.n_suffix;
   const bool bf_sp = (d.flags & kNfByteFallback) && (d.flags & kNfCompressSp);
   WaveCounters tc;
+  // The wave's BACKLOG: sentences of its ASCII tiles that need norm_lane_any.  A stray one would hold the other 63 lanes
+  // of its tile up for its whole length, so it waits here (sentence index in LDS) until the wave has a tile's worth of
+  // them -- or has run out of main tiles -- and they run together, every lane in norm_lane_any.  Nothing is shared
+  // between waves.  (Only classes whose tiles have all 64 lanes put sentences here: a backlog tile uses the slab the
+  // same way.)
+  uint32_t bl_n = 0, bl_cls = 0;           // entries; the longest class among them (its text columns fit them all)
+  bool drained = false;                     // the queue has no main tile left
   for (;;) {
-    uint32_t kind = kTileExit, c = 0, first = 0, ucnt = 0;
-    if (lane == 0) next_tile(a, &kind, &c, &first, &ucnt);
-    kind = wv::shfl(kind, 0);
-    if (kind == kTileExit) break;
-    if (kind == kTileWait) { wv::nap(); continue; }
-    c = wv::shfl(c, 0); first = wv::shfl(first, 0); ucnt = wv::shfl(ucnt, 0);
+    uint32_t c = 0, first = 0, ucnt = 0;
+    bool backlog = bl_n >= 48u || (drained && bl_n > 0u);
+    if (!backlog && !drained) {
+      uint32_t got = 0;
+      if (lane == 0) got = next_tile(a, &c, &first, &ucnt) ? 1u : 0u;
+      got = wv::shfl(got, 0);
+      if (!got) { drained = true; backlog = bl_n > 0u; }
+      else { c = wv::shfl(c, 0); first = wv::shfl(first, 0); ucnt = wv::shfl(ucnt, 0); }
+    }
+    if (drained && !backlog) break;
+    if (backlog) { c = bl_cls; ucnt = bl_n; }
     const StreamClass sc = a.cls[c];
     const int cnt = static_cast<int>(ucnt);
     const uint32_t tcap = sc.tcap;
+    const uint32_t lane_shift = backlog ? 6u : sc.lane_shift;
     // this tile's view of the wave's slab
-    const uint64_t text_bytes = ((StreamTextDwords(tcap, ring) << sc.lane_shift) * 4u + 31u) & ~static_cast<uint64_t>(31);
-    const TextCol gt{reinterpret_cast<uint32_t *>(slab) + lane, sc.lane_shift};
+    const uint64_t text_bytes = ((StreamTextDwords(tcap, ring) << lane_shift) * 4u + 31u) & ~static_cast<uint64_t>(31);
+    const TextCol gt{reinterpret_cast<uint32_t *>(slab) + lane, lane_shift};
     uint32_t *gb = reinterpret_cast<uint32_t *>(slab + text_bytes) + static_cast<uint64_t>(lane) * StreamBpStride(tcap);
-    const uint32_t *list = (kind == kTileMain ? a.lists : a.hard_lists) + static_cast<uint64_t>(c) * a.n;
+    const uint32_t *list = a.lists + static_cast<uint64_t>(c) * a.n;
     uint32_t my_sid = 0;
     uint64_t my_beg = 0;
     uint32_t my_len = 0;
     bool over = false;               // goes to the overflow list
     if (lane < cnt) {
-      my_sid = list[first + lane];
+      my_sid = backlog ? T.backlog[lane] : list[first + lane];
       my_beg = a.offs[my_sid];
       const uint64_t l64 = a.offs[my_sid + 1] - my_beg;
       my_len = static_cast<uint32_t>(l64);
       over = l64 > sc.rcap;                                              // (the last class takes every length)
     }
+    if (backlog) { wv::sync(); bl_n = 0; bl_cls = 0; }                   // (the entries are in registers now)
     const unsigned long long c0 = wv::clock();
     bool mine = false;
     int my_nlen = 0, my_nsp = 0;     // normalized length; how many of its bytes are the space symbol
@@ -465,22 +447,27 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
       const bool go = lane < cnt && !over;
       int nlen = 0;
       bool need_any = go && my_len > 0;
-      if (kind == kTileMain && a.fast_ok && !sc.general) {
+      if (!backlog && a.fast_ok && !sc.general) {
         if (go && my_len > 0) nlen = fast_norm_stream(d, a.text, my_beg, static_cast<int>(my_len), gt, T.bcls, static_cast<int>(tcap), &my_nsp);
         need_any = nlen < 0;
-        // Not plain ASCII.  A tile that is mostly such sentences (CJK text ...) normalizes them here, one per lane;
-        // a stray one would hold the other lanes up for its whole length: it goes to the class's hard list
+        // Not plain ASCII.  A tile that is mostly such sentences (CJK text ...) normalizes them here, one per lane; a
+        // few stray ones wait in the backlog
         const uint64_t hm = wv::ballot(need_any);
-        if (hm && (wv::popc64(hm) < static_cast<int>(sc.min_lanes) || a.no_lane_general)) {
-          append_lanes(hm, need_any, my_sid, a.hard_lists + static_cast<uint64_t>(c) * a.n, &q->hard_count[c], lane);
+        const uint32_t k = static_cast<uint32_t>(wv::popc64(hm));
+        if (hm && (k < sc.min_lanes || a.no_lane_general) && lane_shift == 6u && bl_n + k <= 64u) {
+          if (need_any) T.backlog[bl_n + static_cast<uint32_t>(wv::popc64(hm & ((1ull << lane) - 1ull)))] = my_sid;
+          bl_n += k;
+          if (c > bl_cls) bl_cls = c;
+          tc.n_backlog += k;
           need_any = false;
           if (nlen < 0) nlen = -2;
+          wv::sync();
         }
       }
       if (wv::any(need_any)) {
         wv::sync();                              // the raw windows alias LDS the previous tile's search used
         if (need_any) {
-          ColSink sink{gt, static_cast<int>(tcap)};   // (brace-init: c, cap)
+          ColSink sink{gt, static_cast<int>(tcap)};
           nlen = norm_lane_any(d, a.text, my_beg, static_cast<int>(my_len), sink, my_raw, &my_nsp);
           if (nlen < 0) over = true;
         }
@@ -501,16 +488,6 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
         a.tmp_off[my_sid] = 0;
         a.sent_status[my_sid] = static_cast<uint8_t>(kSsOutOfRange);
         wv::atomic_add(&a.side->n_failed, 1ull);
-      }
-    }
-    if (kind == kTileMain) {                     // this main tile has appended what it had for the hard list
-      wv::release_fence();
-      if (lane == 0) {
-        const uint32_t done = wv::atomic_add(&q->main_done[c], 1u) + 1u;
-        if (done == sc.main_tiles) {
-          if (wv::atomic_load(&q->hard_count[c]) > 0u) wv::atomic_or(&q->hard_ready, 1u << c);
-          else wv::atomic_add(&q->closed, 1u);
-        }
       }
     }
     const unsigned long long c1 = wv::clock();
@@ -587,6 +564,7 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     if (lane == 0) {
       for (int k = 0; k < 4; ++k) wv::atomic_add(&a.stats[3 + k], tc.cyc[k]);
       wv::atomic_add(&a.stats[7], tc.n_trips);
+      if (tc.n_backlog) wv::atomic_add(&a.side->n_backlog, tc.n_backlog);
     }
   }
 }

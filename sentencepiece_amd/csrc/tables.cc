@@ -58,6 +58,47 @@ std::string CompressSp(const std::string &s) {
 
 }  // namespace
 
+// Per id, what Decode(ids) appends for it (src/sentencepiece_processor.cc:776-808): the kind is taken from
+// PieceToId(IdToPiece(id)) and the CURRENT piece types as the reference does (:812, IsByte / IsControl / IsUnknown read
+// the live type: after SetVocabulary a BYTE piece that became UNUSED decodes as its literal "<0xNN>" text); U+2581 ->
+// ' ' is applied here, the leading-whitespace rule at run time.  Rebuilt by RefreshTypeFlags.
+Status BuildDecodeTables(const ModelData &m, HostTables *t) {
+  const size_t V = m.pieces.size();
+  t->dec_info.assign(V, 0);
+  t->dec_off.assign(V + 1, 0);
+  t->dec_bytes.clear();
+  for (size_t i = 0; i < V; ++i) {
+    const std::string &piece = m.pieces[i].piece;
+    const int id = m.PieceToId(piece);
+    const int type = m.pieces[id].type;
+    uint32_t info = 0;
+    t->dec_off[i] = static_cast<uint32_t>(t->dec_bytes.size());
+    if (type == kControl) {
+      info = 1u;                                                     // kDkEmpty
+    } else if (type == kByte) {
+      unsigned v = 0;                                                // PieceToByte("<0xHH>") (model_interface.cc:214-229)
+      if (piece.size() == 6) v = static_cast<unsigned>(strtoul(piece.substr(3, 2).c_str(), nullptr, 16));
+      info = 2u | (v << 8);                                          // kDkByte
+    } else if (type == kUnknown_) {
+      const std::string &sfc = (m.pieces[id].piece == piece) ? m.unk_surface : piece;
+      t->dec_bytes.insert(t->dec_bytes.end(), sfc.begin(), sfc.end());
+      info = 3u;                                                     // kDkLiteral
+    } else {
+      if (piece.compare(0, 3, kSpaceSymbol) == 0) info |= 1u << 2;   // kDiStartsSp
+      for (size_t k = 0; k < piece.size();) {
+        if (piece.compare(k, 3, kSpaceSymbol) == 0) { t->dec_bytes.push_back(' '); k += 3; }
+        else t->dec_bytes.push_back(static_cast<uint8_t>(piece[k++]));
+      }
+    }
+    const size_t dl = t->dec_bytes.size() - t->dec_off[i];
+    if (dl > 0xFFFF) return Status::Error(kUnimplemented, "piece longer than 65535 bytes");
+    t->dec_info[i] = info | static_cast<uint32_t>(dl) << 16;        // kDiLenShift
+  }
+  t->dec_off[V] = static_cast<uint32_t>(t->dec_bytes.size());
+  if (t->dec_bytes.empty()) t->dec_bytes.push_back(0);
+  return Status::OK();
+}
+
 Status CompileTables(const ModelData &m, HostTables *t) {
   std::string err;
   SpmxDev &sc = t->scalars;
@@ -345,45 +386,7 @@ Status CompileTables(const ModelData &m, HostTables *t) {
     t->sym_final.assign(1, 0);
     t->sym_len.assign(1, 0);
   }
-  // ---------------------------------------------------------------- decode --
-  // Per id, what Decode(ids) appends for it (src/sentencepiece_processor.cc:776-808): the kind is taken from
-  // PieceToId(IdToPiece(id)) as the reference does (:812); U+2581 -> ' ' is applied here, the leading-whitespace
-  // rule at run time.
-  {
-    const size_t V = m.pieces.size();
-    t->dec_info.assign(V, 0);
-    t->dec_off.assign(V + 1, 0);
-    t->dec_bytes.clear();
-    for (size_t i = 0; i < V; ++i) {
-      const std::string &piece = m.pieces[i].piece;
-      const int id = m.PieceToId(piece);
-      const int type = m.pieces[id].type;
-      uint32_t info = 0;
-      t->dec_off[i] = static_cast<uint32_t>(t->dec_bytes.size());
-      if (type == kControl) {
-        info = 1u;                                                     // kDkEmpty
-      } else if (type == kByte) {
-        unsigned v = 0;                                                // PieceToByte("<0xHH>") (model_interface.cc:214-229)
-        if (piece.size() == 6) v = static_cast<unsigned>(strtoul(piece.substr(3, 2).c_str(), nullptr, 16));
-        info = 2u | (v << 8);                                          // kDkByte
-      } else if (type == kUnknown_) {
-        const std::string &sfc = (m.pieces[id].piece == piece) ? m.unk_surface : piece;
-        t->dec_bytes.insert(t->dec_bytes.end(), sfc.begin(), sfc.end());
-        info = 3u;                                                     // kDkLiteral
-      } else {
-        if (piece.compare(0, 3, kSpaceSymbol) == 0) info |= 1u << 2;   // kDiStartsSp
-        for (size_t k = 0; k < piece.size();) {
-          if (piece.compare(k, 3, kSpaceSymbol) == 0) { t->dec_bytes.push_back(' '); k += 3; }
-          else t->dec_bytes.push_back(static_cast<uint8_t>(piece[k++]));
-        }
-      }
-      const size_t dl = t->dec_bytes.size() - t->dec_off[i];
-      if (dl > 0xFFFF) return Status::Error(kUnimplemented, "piece longer than 65535 bytes");
-      t->dec_info[i] = info | static_cast<uint32_t>(dl) << 16;        // kDiLenShift
-    }
-    t->dec_off[V] = static_cast<uint32_t>(t->dec_bytes.size());
-    if (t->dec_bytes.empty()) t->dec_bytes.push_back(0);
-  }
+  if (Status ds = BuildDecodeTables(m, t); !ds.ok()) return ds;
   sc.n_pieces = static_cast<uint32_t>(m.pieces.size());
   sc.flags = flags;
   RefreshTypeFlags(m, t);
@@ -391,6 +394,7 @@ Status CompileTables(const ModelData &m, HostTables *t) {
 }
 
 void RefreshTypeFlags(const ModelData &m, HostTables *t) {
+  (void)BuildDecodeTables(m, t);        // (cannot fail here: the same pieces passed at load)
   bool any_unused = false;
   for (const PieceRec &p : m.pieces) any_unused |= p.type == kUnused;
   t->scalars.flags = (t->scalars.flags & ~kNfHasUnused) | (any_unused ? kNfHasUnused : 0);

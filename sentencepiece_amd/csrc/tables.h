@@ -34,6 +34,8 @@ struct HostTables {
 
 // Builds everything that depends only on load-time structure.
 Status CompileTables(const ModelData &m, HostTables *t);
+// The per-id decode tables (kernels_decode.h) from the current piece types.
+Status BuildDecodeTables(const ModelData &m, HostTables *t);
 // Refreshes the type-dependent bits (UNUSED / USER_DEFINED flags) after
 // SetVocabulary / ResetVocabulary without rebuilding tries.
 void RefreshTypeFlags(const ModelData &m, HostTables *t);

@@ -60,12 +60,7 @@ SPMX_DEVICE void atomic_max(unsigned long long *p, unsigned long long v) { atomi
 SPMX_DEVICE void atomic_and(uint32_t *p, uint32_t v) { atomicAnd(p, v); }
 // a load that sees what other workgroups' atomics wrote (tile queue of the streaming kernels)
 SPMX_DEVICE uint32_t atomic_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// release: this wave's earlier global stores are visible device-wide before what follows; acquire: loads after the
-// call do not see lines cached before it
-SPMX_DEVICE void release_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
-SPMX_DEVICE void acquire_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
-// a short pause while other waves make progress
-SPMX_DEVICE void nap() { __builtin_amdgcn_s_sleep(64); }
+
 
 SPMX_DEVICE unsigned long long clock() { return __builtin_amdgcn_s_memtime(); }   // shader cycles
 

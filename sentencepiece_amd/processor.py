@@ -175,6 +175,14 @@ class SentencePieceProcessor:
         self._need()
         return self._lib.spmx_pad_id(self._h)
 
+    def unk_piece(self):
+        """trainer_spec.unk_piece (the string the ``unk_piece`` extra option writes)."""
+        self._need()
+        n = self._lib.spmx_unk_piece(self._h, None, 0)
+        buf = C.create_string_buffer(int(n) + 1)
+        self._lib.spmx_unk_piece(self._h, buf, n)
+        return buf.raw[:n].decode("utf-8", "replace")
+
     def model_type(self):
         self._need()
         return self._lib.spmx_model_type(self._h)
@@ -409,7 +417,9 @@ class SentencePieceProcessor:
             row = []
             for k in range(int(io[i]), int(io[i + 1])):
                 t = int(ids[k])
-                if self.IsByte(t) or self.IsControl(t) or (unk_opt and t == unk):
+                if unk_opt and self.IsUnknown(t):             # model_->unk_piece() (:1050-1058), trainer_spec.unk_piece
+                    piece = self.unk_piece().encode("utf-8")
+                elif self.IsByte(t) or self.IsControl(t):
                     piece = self.IdToPiece(t).encode("utf-8")
                 else:
                     piece = norm[base + int(nb[k]):base + int(ne[k])]
@@ -650,8 +660,8 @@ class SentencePieceProcessor:
     def LastProfile(self):
         """Per kernel slot of the last profiled encode call (0 main streaming launch, 1 document launch, 2 overflow
         launch, 3 sentence-per-wave BPE, 4 long form): dict(kernel, kernel_ms, sentences, raw_bytes, ids, bytes,
-        phase_cycles) + total_ms + path (sentences set aside on hard lists / on the overflow list / through the
-        long form / failed)."""
+        phase_cycles) + total_ms + path (sentences that waited in a wave's backlog / went to the overflow list / took
+        the long form / failed)."""
         self._need()
         ms = np.zeros(8, dtype=np.float32)
         sent, raw, ids, byt = (np.zeros(8, dtype=np.uint64) for _ in range(4))
@@ -671,5 +681,5 @@ class SentencePieceProcessor:
                                   phase_cycles=dict(zip(("load", "normalize", "segment", "emit", "search_trips"),
                                                         (int(x) for x in cyc[5 * c:5 * c + 5]))))
                              for c in range(k)],
-                    path=dict(hard=int(path[0]), overflow=int(path[1]), long=int(path[2]), failed=int(path[3])),
+                    path=dict(backlog=int(path[0]), overflow=int(path[1]), long=int(path[2]), failed=int(path[3])),
                     total_ms=float(tot.value))

@@ -97,9 +97,6 @@ inline void atomic_min(unsigned long long *p, unsigned long long v) { if (v < *p
 inline void atomic_max(unsigned long long *p, unsigned long long v) { if (v > *p) *p = v; }
 inline void atomic_and(uint32_t *p, uint32_t v) { *p &= v; }
 inline uint32_t atomic_load(const uint32_t *p) { return *p; }
-inline void release_fence() {}
-inline void acquire_fence() {}
-inline void nap() { static long spins = 0; if (++spins > 64000000L) { fprintf(stderr, "wave_emu: a wave waits forever\n"); abort(); } }
 
 inline unsigned long long clock() { return 0; }
 

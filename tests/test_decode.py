@@ -172,3 +172,31 @@ def test_gpu_decode_round_trip_large(procs):
     keep = np.repeat(ok, cnt)
     keep2 = np.repeat(ok, cnt2)
     assert np.array_equal(ids[keep], ids2[keep2])
+
+
+def test_emu_decode_follows_set_vocabulary(corpora):
+    """SetVocabulary turns the pieces outside the vocabulary -- the BYTE pieces of a byte-fallback model among them --
+    UNUSED (src/sentencepiece_processor.cc:301-340); Decode then no longer reassembles bytes from them: IsByte(id) reads
+    the live type (:812-823).  The device's per-id decode tables are rebuilt with the types.  Against the compiled
+    reference (the oracle keeps the load-time tables)."""
+    from tests import emulib, refshim
+    if not refshim.available():
+        pytest.skip("oracle/_ref/libspm_ref.so not built")
+    import sentencepiece as spm   # only to list piece strings
+    blob = fixtures.model_blob("uni1k_bf")
+    sp = spm.SentencePieceProcessor(model_proto=blob)
+    vocab = [sp.id_to_piece(i) for i in range(300, sp.get_piece_size(), 2)]      # no <0x..> piece among them
+    e, r = emulib.EmuLib().load(blob), refshim.RefLib().load(blob)
+    text, offs = fixtures.head(*corpora["edge"], 60)
+    ids, io = e.encode_batch(text, offs)                     # (byte pieces for the unknown characters)
+    for step in ("before", "restricted", "reset"):
+        if step == "restricted":
+            e.set_vocabulary(vocab)
+            r.set_vocabulary(vocab)
+        elif step == "reset":
+            e.reset_vocabulary()
+            r.reset_vocabulary()
+        et, eo = e.decode_batch(ids, io)
+        rt, ro = r.decode_batch(ids, io)
+        np.testing.assert_array_equal(eo, ro, err_msg=step)
+        np.testing.assert_array_equal(et, rt, err_msg=step)

@@ -72,11 +72,35 @@ def test_emu_tile_variants(model, env, emu, oracle, corpora, monkeypatch):
         oids, oio = o.encode_batch(text, offs)
         np.testing.assert_array_equal(io, oio)
         np.testing.assert_array_equal(ids, oids)
-        hard = h.path()["hard"]
+        hard = h.path()["backlog"]
         if not env and name == "synth20k":       # ASCII sentences stay with the tile that drew them
             assert hard < 0.1 * (len(offs) - 1)
         if "SPMX_NO_FAST" in env or model == "uni1k_suffix":   # every lane in norm_lane_any: nothing is set aside
             assert hard == 0
+
+
+@pytest.mark.parametrize("model", ["uni32k", "bpe32k", "uni1k_bf"])
+def test_emu_backlog(model, emu, oracle, corpora):
+    """Full 64-lane ASCII tiles (one wavefront, so every tile is full): the few sentences that need the general
+    normalizer wait in the wave's backlog and run as tiles of their own; same ids."""
+    from sentencepiece_amd import synth
+    blob = fixtures.model_blob(model)
+    h = emu.load(blob, cus=1, classes=None, env={"SPMX_TILE_WAVES": "1"})
+    o = oracle.load(blob)
+    t1, o1 = fixtures.head(*corpora["synth20k"], 1500)
+    t2, o2 = corpora["edge"]
+    tb1, tb2 = np.asarray(t1).tobytes(), np.asarray(t2).tobytes()
+    sents = [tb1[int(o1[i]):int(o1[i + 1])] for i in range(len(o1) - 1)]
+    extra = [tb2[int(o2[i]):int(o2[i + 1])] for i in range(len(o2) - 1)]
+    for k, e in enumerate(extra):                      # sprinkle the edge cases over the ASCII sentences
+        sents.insert(7 + 19 * k, e)
+    text, offs = synth.pack(sents)
+    ids, io = h.encode_batch(text, offs)
+    assert h.status == 0
+    oids, oio = o.encode_batch(text, offs)
+    np.testing.assert_array_equal(io, oio)
+    np.testing.assert_array_equal(ids, oids)
+    assert h.path()["backlog"] >= 3
 
 
 K_WORDWISE = 1 << 10   # dev.h kNfBpeWordwise
@@ -99,11 +123,7 @@ def test_emu_lane_general_normalizer(model, corpus, k, env, emu, oracle, corpora
     oids, oio = o.encode_batch(text, offs)
     np.testing.assert_array_equal(io, oio)
     np.testing.assert_array_equal(ids, oids)
-    hard = h.path()["hard"]
-    if env:      # (characters that start no charsmap key stay with the ASCII fast path either way)
-        assert hard > 0.25 * (len(offs) - 1)
-    elif model != "uni1k_bf":      # (the edge cases are mostly ASCII tiles: stray non-ASCII sentences are set aside)
-        assert hard < 0.7 * (len(offs) - 1)
+    assert h.path()["backlog"] <= len(offs) - 1      # (only full 64-lane tiles use the backlog: few do at this size)
 
 
 @pytest.mark.parametrize("model", ["bpe1k", "bpe32k", "bpe1k_bf_uds", "bpe1k_noesc", "bpe1k_llama"])
@@ -130,7 +150,7 @@ def test_emu_bpe_variants(model, env, emu, oracle, corpora, monkeypatch):
         if name == "edge" and wordwise and "SPMX_NO_STREAM" not in env:
             assert h.path()["long"] >= 3      # "a" * 300, "0123456789" * 40, a long CJK run ...
         if name == "synth20k" and wordwise and not env:
-            assert h.path()["hard"] < 0.1 * (len(offs) - 1) and h.path()["long"] == 0
+            assert h.path()["backlog"] < 0.1 * (len(offs) - 1) and h.path()["long"] == 0
 
 
 @pytest.mark.parametrize("model,opts", [("test_model", "bos:eos"), ("test_model", "reverse:bos"),
@@ -369,7 +389,7 @@ def test_emu_fast_keeps_identity_characters(model, emu, oracle):
     oids, oio = o.encode_batch(text, offs)
     np.testing.assert_array_equal(io, oio)
     np.testing.assert_array_equal(ids, oids)
-    assert h.path()["hard"] <= 0.3 * 300     # (set aside only when the tile has too few such sentences to keep them)
+    assert h.path()["backlog"] <= 0.3 * 300     # (set aside only when the tile has too few such sentences to keep them)
 
 
 @pytest.mark.parametrize("model", ["bpe1k", "bpe1k_llama"])

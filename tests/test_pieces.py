@@ -75,11 +75,11 @@ def test_emu_normalize_and_pieces(model, emu, oracle, corpora):
         h.set_encode_extra_options(opts)
         o.set_encode_extra_options(opts)
         for name, (text, offs) in inputs(corpora, big=model in BIG):
-            norm, no, n2o = h.normalize_batch(text, offs, grid=2)
+            norm, no, n2o = h.normalize_batch(text, offs)
             assert h.status == 0
             if not opts:
                 same((norm, no, n2o), o.normalize_batch(text, offs), NN, "%s %s" % (model, name))
-            ids, b, e, io, nb, ne = h.encode_spans(text, offs, grid=2, norm_spans=True)
+            ids, b, e, io, nb, ne = h.encode_spans(text, offs, norm_spans=True)
             assert h.status == 0
             blob_p, poffs = pieceslib.compose_pieces(ids, nb, ne, io, norm, no, lambda t: names[t],
                                                      literal_fn(types, "unk" in opts))
@@ -180,8 +180,8 @@ def test_emu_serialized_proto(model, emu, ref, corpora):
         lit = literal_fn(types, "unk" in opts)
         for name, (text, offs) in inputs(corpora):
             want = _ref_serialized(r, text, offs)
-            norm, no, _ = h.normalize_batch(text, offs, grid=2)
-            ids, b, e, io, nb, ne = h.encode_spans(text, offs, grid=2, norm_spans=True)
+            norm, no, _ = h.normalize_batch(text, offs)
+            ids, b, e, io, nb, ne = h.encode_spans(text, offs, norm_spans=True)
             nbytes = norm.tobytes()
             tb = np.asarray(text).tobytes()
             for i in range(len(offs) - 1):
@@ -220,15 +220,7 @@ def test_processor_glue_with_emulated_device(emu, ref, corpora):
         h, r = emu.load(blob), ref.load(blob)
         h.set_encode_extra_options(opts)
         r.set_encode_extra_options(opts)
-        types, names = piece_types(model)
-        sp = SentencePieceProcessor.__new__(SentencePieceProcessor)
-        sp._extra = opts
-        sp.EncodeSpansPacked = lambda text, offs, norm_spans=False: h.encode_spans(text, offs, grid=2, norm_spans=norm_spans)
-        sp.NormalizePacked = lambda text, offs, with_offsets=False: h.normalize_batch(text, offs, grid=2)
-        sp.IsByte = lambda t: types[t] == 6
-        sp.IsControl = lambda t: types[t] == 3
-        sp.IdToPiece = lambda t: names[t].decode("utf-8")
-        sp.unk_id = lambda: types.index(2)
+        sp = h.sp                     # the product's Python facade, bound to the emulated library
         text, offs = next(x for nm, x in inputs(corpora) if nm == "extra")
         tb = np.asarray(text).tobytes()
         lines = [tb[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
@@ -261,15 +253,7 @@ def test_immutable_proto_glue(emu, ref, corpora):
     for model in ("bpe1k", "test_model", "uni1k_bf"):
         blob = fixtures.model_blob(model)
         h, r = emu.load(blob), ref.load(blob)
-        types, names = piece_types(model)
-        sp = SentencePieceProcessor.__new__(SentencePieceProcessor)
-        sp._extra = ""
-        sp.EncodeSpansPacked = lambda text, offs, norm_spans=False: h.encode_spans(text, offs, grid=2, norm_spans=norm_spans)
-        sp.NormalizePacked = lambda text, offs, with_offsets=False: h.normalize_batch(text, offs, grid=2)
-        sp.IsByte = lambda t: types[t] == 6
-        sp.IsControl = lambda t: types[t] == 3
-        sp.IdToPiece = lambda t: names[t].decode("utf-8")
-        sp.unk_id = lambda: types.index(2)
+        sp = h.sp
         text, offs = next(x for nm, x in inputs(corpora) if nm == "extra")
         tb = np.asarray(text).tobytes()
         lines = [tb[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
