@@ -93,7 +93,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--sentences", type=int, default=10_000_000, help="sentences per GPU per step")
     ap.add_argument("--model", default="uni32k",
-                    help="uni32k | bpe32k (configs[1]/[2], ASCII corpus) | c5_250k | c5_250k_bf (configs[4], "
+                    help="uni32k | bpe32k (configs[1]/[2], ASCII corpus) | uni32k_w16 (configs[1] with pieces of up to 17 bytes) | "
+                         "c5_250k | c5_250k_bf (configs[4], "
                          "250k-piece unigram on the mixed-script power-law corpus)")
     ap.add_argument("--gather", choices=["ids", "none"], default="ids")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -117,7 +118,10 @@ def main():
     if c5:
         text, offs = synth.mixed_corpus(args.sentences, seed=20250228 + rank)
     else:
-        text, offs = synth.ascii_corpus(args.sentences, seed=20250227 + rank, sort_by_length=not args.unsorted)
+        # uni32k_w16: the same generator over words of up to 16 letters (scripts/train_w16.py): pieces of up to 17 bytes,
+        # as natural text under the trainer's default max_sentencepiece_length gives -- the generic streaming kernel
+        words = synth.WordList(max_word_len=16, mean_word_len=5.5) if args.model.endswith("_w16") else None
+        text, offs = synth.ascii_corpus(args.sentences, seed=20250227 + rank, sort_by_length=not args.unsorted, words=words)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None

@@ -150,7 +150,7 @@ struct spmx_handle {
   DevBuf<uint32_t> d_ndarts, d_npair, d_sym_final, d_dec_info, d_dec_off;
   DevBuf<uint8_t> d_dec_bytes;
   DevBuf<uint8_t> d_nblob;
-  DevBuf<U4> d_ptrie, d_chartab, d_pairtab;
+  DevBuf<U4> d_ptrie, d_chartab, d_pairtab, d_wordtab;
   DevBuf<U2> d_utrie;
   DevBuf<uint16_t> d_sym_len;
   DevBuf<int32_t> d_byte_ids;
@@ -232,6 +232,7 @@ int UploadTables(spmx_handle *h) {
   HIP_OR_RETURN(h, Upload(&h->d_utrie, t.utrie));
   HIP_OR_RETURN(h, Upload(&h->d_chartab, t.chartab));
   HIP_OR_RETURN(h, Upload(&h->d_pairtab, t.pairtab));
+  HIP_OR_RETURN(h, Upload(&h->d_wordtab, t.wordtab));
   HIP_OR_RETURN(h, Upload(&h->d_sym_final, t.sym_final));
   HIP_OR_RETURN(h, Upload(&h->d_sym_len, t.sym_len));
   HIP_OR_RETURN(h, Upload(&h->d_byte_ids, t.byte_ids));
@@ -246,6 +247,7 @@ int UploadTables(spmx_handle *h) {
   h->dev.utrie = h->d_utrie.p;
   h->dev.chartab = h->d_chartab.p;
   h->dev.pairtab = h->d_pairtab.p;
+  h->dev.wordtab = h->d_wordtab.p;
   h->dev.sym_final = h->d_sym_final.p;
   h->dev.sym_len = h->d_sym_len.p;
   h->dev.byte_ids = h->d_byte_ids.p;
@@ -268,7 +270,7 @@ int RefreshDevice(spmx_handle *h, bool types_changed) {
   }
   SpmxDev d = t.scalars;
   d.ndarts = h->dev.ndarts; d.nblob = h->dev.nblob; d.npair = h->dev.npair; d.ptrie = h->d_ptrie.p; d.utrie = h->dev.utrie;
-  d.chartab = h->dev.chartab; d.pairtab = h->dev.pairtab; d.sym_final = h->d_sym_final.p;
+  d.chartab = h->dev.chartab; d.pairtab = h->dev.pairtab; d.wordtab = h->dev.wordtab; d.sym_final = h->d_sym_final.p;
   d.sym_len = h->dev.sym_len; d.byte_ids = h->dev.byte_ids;
   d.dec_info = h->d_dec_info.p; d.dec_off = h->d_dec_off.p; d.dec_bytes = h->d_dec_bytes.p;
   h->dev = d;
@@ -279,7 +281,7 @@ void DestroyHandle(spmx_handle *h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   h->d_ndarts.Free(); h->d_npair.Free(); h->d_sym_final.Free(); h->d_nblob.Free(); h->d_ptrie.Free(); h->d_chartab.Free();
-  h->d_pairtab.Free(); h->d_utrie.Free(); h->d_sym_len.Free(); h->d_byte_ids.Free();
+  h->d_pairtab.Free(); h->d_wordtab.Free(); h->d_utrie.Free(); h->d_sym_len.Free(); h->d_byte_ids.Free();
   h->d_dec_info.Free(); h->d_dec_off.Free(); h->d_dec_bytes.Free();
   h->pool.clear();
   delete h;
@@ -924,7 +926,7 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_STREAM_SCRATCH_MB")) h->stream_scratch_limit = static_cast<uint64_t>(atoll(e)) << 20;
     if (const char *e = getenv("SPMX_TILE_WAVES")) h->tile_waves_override = atoi(e);
     if (const char *e = getenv("SPMX_MAIN_MAX_RAW")) h->main_max_raw = static_cast<uint32_t>(atoll(e));
-    if (const char *e = getenv("SPMX_FORCE_RING")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) h->ring_override = static_cast<uint32_t>(v); }
+    if (const char *e = getenv("SPMX_FORCE_RING")) { const int v = atoi(e); if (v >= 16 && v <= 122) h->ring_override = static_cast<uint32_t>(v); }
     if (const char *e = getenv("SPMX_CLASSES")) {          // "raw:norm,raw:norm,..." (ascending; tests shrink the table)
       int c = 0;
       const char *p = e;

@@ -59,7 +59,7 @@ constexpr uint32_t kDatTerminalDev = 1u << 9;
 constexpr int kMaxResegDepth = 64;
 
 constexpr int kMaxExtra = 4;       // bos/eos ids on either side
-constexpr int kMaxPieceBytes = 64; // systolic unigram walk: one lane per start, 64 lanes
+constexpr int kMaxPieceBytes = 120; // unigram: the back-pointer word holds the piece length in 7 bits; the score ring lives in LDS
 
 struct SpmxDev {
   // ---- normalizer (reference: src/normalizer.cc:71-253) ----
@@ -99,6 +99,12 @@ struct SpmxDev {
   const uint32_t *sym_final;  // per symbol: final id | flags
   const uint16_t *sym_len;    // per symbol: byte length
   uint32_t chartab_mask, pairtab_mask;
+  // word table (BPE, word-wise models without UNUSED pieces): the segmentation of every vocabulary string that is a
+  // whole word, computed at load by the same merges -- a word's pieces are a pure function of its bytes, so a word found
+  // here needs no merge loop.  Slot = two U4: {16 key bytes, zero padded} {len | n_ids << 8 | piece lengths << 16 (5 bits
+  // each), id0, id1, id2}; empty: len == 0.  Open addressing on HashWord.
+  const U4 *wordtab;
+  uint32_t wordtab_mask;      // 0: no table
   uint32_t n_pieces;      // symbols below this are piece ids (their own final id); the rest are extra characters
   int32_t model_type;     // 1 unigram, 2 bpe
 };
@@ -112,6 +118,15 @@ SPMX_HD inline uint32_t HashPair(uint32_t a, uint32_t b) {
   uint64_t h = (static_cast<uint64_t>(a) << 32 | b) * 0x9E3779B97F4A7C15ull;
   return static_cast<uint32_t>(h >> 32);
 }
+SPMX_HD inline uint32_t HashWord(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
+  uint32_t h = k0 * 0x9E3779B1u;
+  h = (h ^ (h >> 15)) + k1 * 0x85EBCA77u;
+  h = (h ^ (h >> 13)) + k2 * 0xC2B2AE3Du;
+  h = (h ^ (h >> 16)) + k3 * 0x27D4EB2Fu;
+  return h ^ (h >> 15);
+}
+constexpr uint32_t kWordKeyBytes = 16;   // words longer than this are not looked up
+constexpr uint32_t kWordMaxIds = 3;
 SPMX_HD inline uint32_t HashChar(uint32_t bytes, uint32_t len) {
   uint64_t h = (static_cast<uint64_t>(len) << 32 | bytes) * 0xD6E8FEB86659FD93ull;
   return static_cast<uint32_t>(h >> 32);

@@ -80,6 +80,30 @@ SPMX_DEVICE bool pair_resolve(const SpmxDev &d, PairProbe *p, uint32_t *merged, 
   return true;
 }
 
+// ---- the word table (dev.h wordtab): a whole word's pieces by ONE probe ---------------------------------------------
+// At the start of a word the lane takes the next 17 bytes of its text window, finds the word's end (the first space
+// symbol after the word's own leading ones, or the end of the text), and looks the word up; the probe is in flight
+// like the pair probes and lands at the top of the next iteration.  A hit writes the ids and moves on to the next
+// word: no characters are read, no merges run.  A miss (a word that is no vocabulary string, or longer than 16 bytes)
+// takes the merge loop below.
+struct WordProbe {
+  uint32_t k0 = 0, k1 = 0, k2 = 0, k3 = 0, len = 0, slot = 0;
+  bool live = false;
+  U4 e0{0, 0, 0, 0}, e1{0, 0, 0, 0};
+};
+// bit b of the result: byte b of x is kSpByte (0xFF never occurs in UTF-8 otherwise)
+SPMX_DEVICE uint32_t sp_mask4(uint32_t x) {
+  const uint32_t m = x & 0x80808080u & ((x & 0x7F7F7F7Fu) + 0x01010101u);
+  return (((m >> 7) * 0x00204081u) >> 21) & 0xFu;
+}
+SPMX_DEVICE uint32_t keep_bytes(uint32_t x, int keep) {      // the low `keep` bytes of x (keep may be <= 0 or >= 4)
+  return keep >= 4 ? x : (keep <= 0 ? 0u : x & ((1u << (8 * keep)) - 1u));
+}
+SPMX_DEVICE void word_issue(const SpmxDev &d, WordProbe *p) {
+  p->e0 = d.wordtab[2 * p->slot];
+  p->e1 = d.wordtab[2 * p->slot + 1];
+}
+
 // Segments this lane's sentence (text column gt, nlen bytes) and writes its ids into slot[0, cap): forward order
 // fills the slot from its START, `reverse` from its end.  Returns the number of ids, -1 on an error status
 // (control piece, overflow), -2 if the sentence has a word of more than kBpeWordMax characters: it goes to the long
@@ -111,11 +135,20 @@ SPMX_DEVICE int bpe_stream_lane(const SpmxDev &d, const TextCol &gt, int nlen, i
   bool prev_sp = false; // the last character read was U+2581
   bool right_unk = false;
   int n_out = 0, ret = 0;
+  auto slot_out = [&](uint32_t id, int off) __attribute__((always_inline)) {
+    slot[reverse ? cap - 1 - n_out : n_out] = static_cast<int32_t>(id);
+    if (tslot) tslot[reverse ? cap - 1 - n_out : n_out] = off;
+    ++n_out;
+  };
   PairProbe p0, p1;
+  WordProbe wq;
+  const bool use_words = d.wordtab_mask != 0u;
+  int word_tried = -1;   // the word that starts at this byte missed the table (or cannot be looked up): merge loop
   const int W = static_cast<int>(wmask) + 1;
   int nf = 0;                                     // next text dword to fetch; the window holds dwords [nf - W/4, nf)
   bool pf_pend = false;
-  uint32_t pf = 0;
+  uint32_t pf = 0, pf2 = 0;
+  int pf_n = 0;                                   // text dwords in flight (the word table consumes a word per iteration)
   if (active) {
     for (int k = 0; k < W / 4; ++k) *reinterpret_cast<uint32_t *>(win + 4 * k) = gt.dw(k);
     nf = W / 4;
@@ -123,15 +156,86 @@ SPMX_DEVICE int bpe_stream_lane(const SpmxDev &d, const TextCol &gt, int nlen, i
   while (wv::any(active)) {
     if (!active) continue;
     {   // land what the previous iteration issued: a text dword and up to two pair probes
-      if (pf_pend) *reinterpret_cast<uint32_t *>(win + ((4u * static_cast<uint32_t>(nf - 1)) & wmask)) = pf;
+      if (pf_pend) *reinterpret_cast<uint32_t *>(win + ((4u * static_cast<uint32_t>(nf - pf_n)) & wmask)) = pf;
+      if (pf_n == 2) *reinterpret_cast<uint32_t *>(win + ((4u * static_cast<uint32_t>(nf - 1)) & wmask)) = pf2;
       pf_pend = false;
+      pf_n = 0;
       uint32_t m = 0;
       float sc = 0.f;
       if (pair_resolve(d, &p0, &m, &sc)) { mrg[p0.idx * 64] = m; scr[p0.idx * 64] = sc; pmask |= 1u << p0.idx; }
       if (pair_resolve(d, &p1, &m, &sc)) { mrg[p1.idx * 64] = m; scr[p1.idx * 64] = sc; pmask |= 1u << p1.idx; }
+      if (use_words) {
+        // the word probe: consumes the load on every path; walks on after a collision
+        U4 e0 = wq.e0, e1 = wq.e1;
+        const bool live = wq.live;
+        uint32_t slot = wq.slot;
+        wq.live = false;
+        wq.slot = 0;
+        if (live) {
+          bool hit = e0.x == wq.k0 && e0.y == wq.k1 && e0.z == wq.k2 && e0.w == wq.k3 && (e1.x & 0xFFu) == wq.len;
+          while (!hit && (e1.x & 0xFFu) != 0u) {
+            slot = (slot + 1) & d.wordtab_mask;
+            e0 = d.wordtab[2 * slot];
+            e1 = d.wordtab[2 * slot + 1];
+            hit = e0.x == wq.k0 && e0.y == wq.k1 && e0.z == wq.k2 && e0.w == wq.k3 && (e1.x & 0xFFu) == wq.len;
+          }
+          if (!hit) {
+            word_tried = pos;
+          } else {                                    // the word's pieces (never an unknown or a control piece)
+            const int nid = static_cast<int>((e1.x >> 8) & 0xFFu);
+            if (n_out + nid > cap) { ret = -1; active = false; }
+            else {
+              int off = pos;
+              for (int k = 0; k < nid; ++k) {
+                const uint32_t id = k == 0 ? e1.y : (k == 1 ? e1.z : e1.w);
+                slot_out(id, off);
+                off += static_cast<int>((e1.x >> (16 + 5 * k)) & 31u);
+              }
+              right_unk = false;
+              pos += static_cast<int>(wq.len);
+              prev_sp = false;
+              if (pos >= nlen) active = false;
+            }
+          }
+        }
+      }
+    }
+    bool looking = false;                      // a word probe goes out this iteration: no character is read
+    if (use_words && active && !merging && n0 == 0 && word_tried != pos) {
+      if ((pos & ~3) + 20 > 4 * nf && 4 * nf < nlen) {
+        looking = true;                          // its bytes have not landed yet
+      } else {
+        // bytes [pos, pos + 17) of the text through the window
+        const uint32_t a0 = static_cast<uint32_t>(pos) & ~3u;
+        const uint32_t d0 = *reinterpret_cast<const uint32_t *>(win + (a0 & wmask));
+        const uint32_t d1 = *reinterpret_cast<const uint32_t *>(win + ((a0 + 4u) & wmask));
+        const uint32_t d2 = *reinterpret_cast<const uint32_t *>(win + ((a0 + 8u) & wmask));
+        const uint32_t d3 = *reinterpret_cast<const uint32_t *>(win + ((a0 + 12u) & wmask));
+        const uint32_t d4 = *reinterpret_cast<const uint32_t *>(win + ((a0 + 16u) & wmask));
+        const uint32_t sh = 8u * (static_cast<uint32_t>(pos) & 3u);
+        auto funnel = [&](uint32_t hi, uint32_t lo) __attribute__((always_inline)) -> uint32_t {
+          return sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
+        };
+        const uint32_t k0 = funnel(d1, d0), k1 = funnel(d2, d1), k2 = funnel(d3, d2), k3 = funnel(d4, d3);
+        const uint32_t b16 = (d4 >> sh) & 0xFFu;
+        const uint32_t ff = sp_mask4(k0) | sp_mask4(k1) << 4 | sp_mask4(k2) << 8 | sp_mask4(k3) << 12 | (b16 == kSpByte ? 1u << 16 : 0u);
+        const int lead = wv::ffs64(static_cast<uint64_t>(~ff)) - 1;                 // the word's own leading space symbols
+        const uint32_t rest = ff & ~((1u << lead) - 1u);
+        int L = rest ? wv::ffs64(static_cast<uint64_t>(rest)) - 1 : 17;
+        if (L > nlen - pos) L = nlen - pos;
+        if (L > static_cast<int>(kWordKeyBytes) || L <= lead) {
+          word_tried = pos;                      // too long for the table / nothing but space symbols: merge loop
+        } else {
+          wq.k0 = keep_bytes(k0, L); wq.k1 = keep_bytes(k1, L - 4); wq.k2 = keep_bytes(k2, L - 8); wq.k3 = keep_bytes(k3, L - 12);
+          wq.len = static_cast<uint32_t>(L);
+          wq.slot = HashWord(wq.k0, wq.k1, wq.k2, wq.k3) & d.wordtab_mask;
+          wq.live = true;
+          looking = true;
+        }
+      }
     }
     bool do_merge = merging;
-    if (!merging) {
+    if (!merging && !looking) {
       // ---- read up to two characters of the current word (:109-129) ----
       // (two explicit calls: the probe objects must stay in registers, so no run-time choice between them)
       auto read_char = [&](PairProbe *pp) {
@@ -250,9 +354,11 @@ SPMX_DEVICE int bpe_stream_lane(const SpmxDev &d, const TextCol &gt, int nlen, i
     }
     }
     // window refill: dword nf may replace positions [4 nf - W, 4 nf - W + 4), dead once they lie below pos
-    if (active && 4 * nf + 4 <= pos + W && 4 * nf < nlen + 8) { pf = gt.dw(nf); ++nf; pf_pend = true; }
+    if (active && 4 * nf + 4 <= pos + W && 4 * nf < nlen + 8) { pf = gt.dw(nf); ++nf; pf_pend = true; pf_n = 1; }
+    if (use_words && pf_pend && 4 * nf + 4 <= pos + W && 4 * nf < nlen + 8) { pf2 = gt.dw(nf); ++nf; pf_n = 2; }
     pair_issue(d, &p0);
     pair_issue(d, &p1);
+    if (use_words) word_issue(d, &wq);
   }
   return ret != 0 ? ret : n_out;
 }

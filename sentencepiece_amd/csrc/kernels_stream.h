@@ -83,7 +83,9 @@ struct StreamLds {
   uint8_t *bwin;      // [64][kBpeWindow + 4] text windows
 };
 
-SPMX_HD inline uint32_t StreamWindow(uint32_t ring) { return 2u * ring; }
+// bytes of the text window: a power of two that holds the longest piece (< ring), the two bytes looked at beyond it
+// and the dword in flight
+SPMX_HD inline uint32_t StreamWindow(uint32_t ring) { uint32_t w = 32; while (w < ring + 6u) w <<= 1; return w; }
 // model: 1 unigram, 2 BPE
 SPMX_HD inline uint32_t StreamPrivateBytes(int model, uint32_t ring) {
   uint32_t work = model == 2 ? BpeWordLdsBytes() + 64u * (kBpeWindow + 4u)
@@ -149,21 +151,27 @@ SPMX_DEVICE double piece_score_u(const U4 &u, int len, float max_score) {
 //   * text comes from the W-byte LDS window `win` (position p at win[p & wmask]), refilled one dword per
 //     iteration from the lane's text column gt -- the load is issued next to the trie probe and lands in the
 //     window at the top of the next iteration, by which time the probe wait has covered it;
-//   * best_path_ends_at lives in the rings only: ring_s / ring_b slot of position e is [(e & rm) * 64];
+//   * best_path_ends_at lives in the rings only: ring_s / ring_b slot of position e is [(e mod R) * 64];
 //     ring_b == 0 means "not reached" (:984);
 //   * when the start moves from s to s2, position s2's back-pointer word is final: it goes to the lane's staging
 //     block st[] (position p at st[((p >> 2) & 1) * 256 + (p & 3)]), the block of 8 positions that s2 leaves behind
 //     is written to gb[] as two 16-byte stores, and the ring slots of the positions (s, s2] are cleared for the
 //     positions that will reuse them R later.  gb[] is this lane's row: gb[p] for position p.
 // Returns the number of iterations (wave-uniform).
-// RING > 0: the ring size is a compile-time constant (index masks and the distances between the LDS arrays fold
-// into immediates); RING == 0: taken from rm_in / wmask_in.  UDS: the model may have USER_DEFINED pieces.
+// RING > 0: the ring size is a compile-time power of two (index masks and the distances between the LDS arrays fold
+// into immediates); RING == 0: ANY size rm_in + 1 > the longest piece (slots by a running position-mod-R: the
+// distances involved are below R, so one conditional subtraction wraps them); the window mask is wmask_in.  UDS: the
+// model may have USER_DEFINED pieces.
 template <int RING, bool UDS>
 SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const TextCol &gt, uint32_t *gb, int nlen, float *ring_s,
                                     uint32_t *ring_b, uint32_t rm_in, uint8_t *win, uint32_t wmask_in, uint32_t *st,
                                     const U4 *roottab, bool active_in) {
   const uint32_t rm = RING ? static_cast<uint32_t>(RING - 1) : rm_in;
-  const uint32_t wmask = RING ? static_cast<uint32_t>(2 * RING - 1) : wmask_in;
+  const uint32_t wmask = RING ? StreamWindow(RING) - 1u : wmask_in;
+  const uint32_t R = rm + 1u;
+  uint32_t s_slot = 0;                            // RING == 0: s mod R
+  // slot of the position base_slot's position + d (0 <= d < R)
+  auto wrap = [&](uint32_t x) __attribute__((always_inline)) -> uint32_t { return x >= R ? x - R : x; };
   const U4 *__restrict__ ptrie = d.ptrie;
   const float unk_score = d.unk_score, max_score = d.max_score;
   const int W = static_cast<int>(wmask) + 1;
@@ -219,9 +227,10 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const TextCol &gt, uint32_
     const int eA = s + dep1;
     const int eB = s2;
     const int eC = s2 + 1 <= nlen ? s2 + 1 : nlen;
-    const uint32_t oA = (static_cast<uint32_t>(matchA ? eA : 0) & rm) << 6;
-    const uint32_t oB = (static_cast<uint32_t>(eB) & rm) << 6;
-    const uint32_t oC = (static_cast<uint32_t>(eC) & rm) << 6;
+    const uint32_t slB = RING ? (static_cast<uint32_t>(eB) & rm) : wrap(s_slot + static_cast<uint32_t>(mb));
+    const uint32_t oA = (RING ? (static_cast<uint32_t>(matchA ? eA : 0) & rm) : (matchA ? wrap(s_slot + static_cast<uint32_t>(dep1)) : 0u)) << 6;
+    const uint32_t oB = slB << 6;
+    const uint32_t oC = (RING ? (static_cast<uint32_t>(eC) & rm) : (eC != eB ? wrap(slB + 1u) : slB)) << 6;
     uint32_t bA = ring_b[oA], bB = ring_b[oB], bC = ring_b[oC];
     float rA = ring_s[oA], rB = ring_s[oB], rC = ring_s[oC];
     // (A) the piece that just matched
@@ -253,12 +262,14 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const TextCol &gt, uint32_
       // the positions just passed, (s, s2], are dead: free their ring slots (after this iteration's reads and writes)
       if (mb > 0) ring_b[oB] = 0u;
       if (mb > 1)                                  // a multi-byte character: its inner positions too (rare in ASCII text)
-        for (int k = 1; k < mb; ++k) ring_b[(static_cast<uint32_t>(s2 - k) & rm) << 6] = 0u;
+        for (int k = 1; k < mb; ++k)
+          ring_b[(RING ? (static_cast<uint32_t>(s2 - k) & rm) : (slB >= static_cast<uint32_t>(k) ? slB - static_cast<uint32_t>(k) : slB + R - static_cast<uint32_t>(k))) << 6] = 0u;
     }
     // ---------------- commit ----------------
     if (ended) {
       active = begin;
       s = s2;
+      s_slot = slB;
       mb = begin ? mb2 : 0;
       sbest = sbest2;
       single = termC && mb2 == 1;

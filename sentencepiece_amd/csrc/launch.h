@@ -24,11 +24,12 @@ constexpr LengthClass kClasses[kNumClasses] = {
 // BPE, sentence-per-wave: the normalized capacity of the last staged class is what fits the LDS of a CU
 constexpr uint32_t kBpeWaveNcap3 = 6400;
 
-// score ring entries for a model whose longest piece has max_piece_len bytes
+// score ring entries for a model whose longest piece has max_piece_len bytes: one more than that -- 16 (the
+// compile-time specialization) when that is enough, else exactly what the model needs (the ring is what bounds the
+// wavefronts per CU: 8 bytes per entry per lane of LDS)
 inline uint32_t ScoreRing(int max_piece_len) {
-  uint32_t r = 16;
-  while (r < static_cast<uint32_t>(max_piece_len) + 1) r <<= 1;
-  return r;
+  const uint32_t need = static_cast<uint32_t>(max_piece_len) + 1u;
+  return need <= 16u ? 16u : ((need + 1u) & ~1u);
 }
 
 // One streaming launch (kernels_stream.h): model_type 1 unigram / 2 BPE; uds: the model has USER_DEFINED pieces

@@ -259,7 +259,7 @@ Status CompileTables(const ModelData &m, HostTables *t) {
     t->max_piece_len = d.max_key_len;
     t->max_prefixes = d.max_prefixes;
     if (d.max_key_len > kMaxPieceBytes)
-      return Status::Error(kUnimplemented, "a piece is longer than 64 bytes; unsupported by the device unigram path");
+      return Status::Error(kUnimplemented, "a piece is longer than 120 bytes; unsupported by the device unigram path");
     t->ptrie.resize(d.w0.size());
     for (size_t i = 0; i < d.w0.size(); ++i) {
       U4 u{d.w0[i], 0, 0, 0};
@@ -380,13 +380,104 @@ Status CompileTables(const ModelData &m, HostTables *t) {
       const uint32_t fid = t->sym_final[i] & kSfIdMask;
       if (m.pieces[fid].load_type == kControl || m.pieces[fid].type == kControl) t->sym_final[i] |= kSfControl;
     }
+    // Word table (dev.h wordtab): SampleEncode(alpha = 0) of every vocabulary string that is a whole word -- at most 16
+    // bytes, an optional run of space symbols and then characters without one -- by the merge loop itself on the
+    // compiled tables (:142-173: best pair = highest score, then leftmost).  Only for models that segment word by word.
+    t->wordtab.clear();
+    sc.wordtab_mask = 0;
+    if (wordwise && !getenv("SPMX_NO_WORDTAB")) {
+      auto host_char = [&](uint32_t bytes, uint32_t len) -> uint32_t {
+        uint32_t sl = HashChar(bytes, len) & sc.chartab_mask;
+        for (;;) {
+          const U4 &e = t->chartab[sl];
+          if (e.y == 0) return kSymNone;
+          if (e.x == bytes && e.y == len) return e.z;
+          sl = (sl + 1) & sc.chartab_mask;
+        }
+      };
+      auto host_pair = [&](uint32_t a, uint32_t b, uint32_t *mg, float *score) -> bool {
+        uint32_t sl = HashPair(a, b) & sc.pairtab_mask;
+        for (;;) {
+          const U4 &e = t->pairtab[sl];
+          if (e.x == kSymNone) return false;
+          if (e.x == a && e.y == b) { *mg = e.z; memcpy(score, &e.w, 4); return true; }
+          sl = (sl + 1) & sc.pairtab_mask;
+        }
+      };
+      struct WordEnt { uint32_t k[4]; uint32_t meta, id[3]; };
+      std::vector<WordEnt> words;
+      for (const auto &kv : tmap) {
+        const std::string &w = kv.first;
+        if (w.empty() || w.size() > kWordKeyBytes) continue;
+        size_t lead = 0;
+        while (lead < w.size() && static_cast<unsigned char>(w[lead]) == kSpByte) ++lead;
+        if (lead == w.size() || w.find(static_cast<char>(kSpByte), lead) != std::string::npos) continue;
+        if (w.find('\0') != std::string::npos) continue;
+        std::vector<uint32_t> sym;
+        std::vector<uint32_t> len;
+        bool ok = true;
+        for (size_t p = 0; p < w.size() && ok;) {
+          const unsigned char c = static_cast<unsigned char>(w[p]);
+          size_t mb = c == kSpByte ? 1 : static_cast<size_t>(OneCharLen(c));
+          if (mb > w.size() - p) mb = w.size() - p;
+          const uint32_t sy = host_char(PackChar(w.substr(p, mb)), static_cast<uint32_t>(mb));
+          if (sy == kSymNone) ok = false;
+          sym.push_back(sy);
+          len.push_back(static_cast<uint32_t>(mb));
+          p += mb;
+        }
+        while (ok && sym.size() > 1) {
+          int best = -1;
+          float bs = 0.f;
+          uint32_t bm = 0;
+          for (size_t i = 0; i + 1 < sym.size(); ++i) {
+            uint32_t mg = 0;
+            float scv = 0.f;
+            if (host_pair(sym[i], sym[i + 1], &mg, &scv) && (best < 0 || scv > bs)) { best = static_cast<int>(i); bs = scv; bm = mg; }
+          }
+          if (best < 0) break;
+          sym[best] = bm;
+          len[best] += len[best + 1];
+          sym.erase(sym.begin() + best + 1);
+          len.erase(len.begin() + best + 1);
+        }
+        if (!ok || sym.size() > kWordMaxIds) continue;
+        WordEnt e{};
+        unsigned char key[kWordKeyBytes] = {0};
+        memcpy(key, w.data(), w.size());
+        memcpy(e.k, key, sizeof(key));
+        e.meta = static_cast<uint32_t>(w.size()) | static_cast<uint32_t>(sym.size()) << 8;
+        for (size_t i = 0; i < sym.size() && ok; ++i) {
+          const uint32_t f = t->sym_final[sym[i]];
+          const uint32_t fid = f & kSfIdMask;
+          if ((f & kSfControl) || static_cast<int>(fid) == m.unk_id || m.pieces[fid].type == kUnknown_) ok = false;
+          e.id[i] = fid;
+          e.meta |= len[i] << (16 + 5 * i);
+        }
+        if (ok) words.push_back(e);
+      }
+      if (!words.empty()) {
+        const uint32_t wsz = NextPow2(words.size() * 2 + 16);
+        t->wordtab.assign(static_cast<size_t>(wsz) * 2, U4{0, 0, 0, 0});
+        for (const WordEnt &e : words) {
+          uint32_t sl = HashWord(e.k[0], e.k[1], e.k[2], e.k[3]) & (wsz - 1);
+          while (t->wordtab[2 * sl + 1].x != 0) sl = (sl + 1) & (wsz - 1);
+          t->wordtab[2 * sl] = U4{e.k[0], e.k[1], e.k[2], e.k[3]};
+          t->wordtab[2 * sl + 1] = U4{e.meta, e.id[0], e.id[1], e.id[2]};
+        }
+        sc.wordtab_mask = wsz - 1;
+      }
+    }
   } else {
     t->chartab.assign(16, U4{0, 0, kSymNone, 0});
     t->pairtab.assign(16, U4{kSymNone, kSymNone, kSymNone, 0});
     t->sym_final.assign(1, 0);
     t->sym_len.assign(1, 0);
+    t->wordtab.clear();
+    sc.wordtab_mask = 0;
   }
   if (Status ds = BuildDecodeTables(m, t); !ds.ok()) return ds;
+  if (t->wordtab.empty()) t->wordtab.assign(2, U4{0, 0, 0, 0});
   sc.n_pieces = static_cast<uint32_t>(m.pieces.size());
   sc.flags = flags;
   RefreshTypeFlags(m, t);
@@ -480,6 +571,7 @@ void BindHostPointers(HostTables *t) {
   sc.pairtab = t->pairtab.data();
   sc.sym_final = t->sym_final.data();
   sc.sym_len = t->sym_len.data();
+  sc.wordtab = t->wordtab.data();
 }
 
 }  // namespace spmx

@@ -19,7 +19,7 @@ struct HostTables {
   std::vector<U4> ptrie;
   // bpe
   std::vector<U2> utrie;
-  std::vector<U4> chartab, pairtab;
+  std::vector<U4> chartab, pairtab, wordtab;
   std::vector<uint32_t> sym_final;
   std::vector<uint16_t> sym_len;
   std::vector<int32_t> byte_ids;

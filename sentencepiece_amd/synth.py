@@ -48,9 +48,9 @@ _SPECIAL_MASS = 0.012   # ~1.2 % of word draws; ~3 % of sentences carry one
 class WordList:
     """The fixed synthetic vocabulary a corpus is drawn from."""
 
-    def __init__(self, n_words: int = 50000, seed: int = 20250227):
+    def __init__(self, n_words: int = 50000, seed: int = 20250227, max_word_len: int = 12, mean_word_len: float = 4.7):
         rng = np.random.default_rng(seed)
-        lens = np.clip(rng.geometric(1.0 / 4.7, size=n_words), 1, 12).astype(np.int64)
+        lens = np.clip(rng.geometric(1.0 / mean_word_len, size=n_words), 1, max_word_len).astype(np.int64)
         # the most frequent words are short, as in natural text
         lens[:64] = np.clip(lens[:64], 1, 4)
         letters = _LETTERS[rng.choice(len(_LETTERS), size=int(lens.sum()), p=_LETTER_P)]
