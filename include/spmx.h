@@ -108,7 +108,8 @@ int spmx_encode_batch_device_ex(spmx_handle *h, const void *d_text, uint64_t tex
                                 uint64_t n, int32_t *d_ids, uint64_t ids_capacity, uint64_t *d_id_offsets,
                                 uint8_t *d_status, void *stream, uint64_t *total_ids, uint64_t *n_failed);
 
-/* Host-buffer form: copies text to the GPU, encodes, copies ids back.
+/* Host-buffer form: copies text to the GPU, encodes, copies ids back.  Big batches (from 2^20 sentences) run as a
+ * chunk pipeline on several host threads: staging copy, H2D, kernels and D2H of different chunks overlap.
  * *ids (total ids) and *id_offsets (n + 1) are allocated by the library and
  * released with spmx_free(). */
 int spmx_encode_batch(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
@@ -116,6 +117,11 @@ int spmx_encode_batch(spmx_handle *h, const char *text, const uint64_t *offsets,
 /* As above, plus *status (nullable): n status bytes, released with spmx_free(); *n_failed (nullable). */
 int spmx_encode_batch_ex(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
                          uint64_t **id_offsets, uint8_t **status, uint64_t *n_failed);
+/* The same batch given as n (pointer, length) pairs -- the layout of a std::vector<absl::string_view>'s elements as
+ * this struct spells them: no packed copy is made, the sentences are gathered into the staging buffers chunk by chunk. */
+typedef struct spmx_view { const char *data; uint64_t len; } spmx_view;
+int spmx_encode_batch_views(spmx_handle *h, const spmx_view *views, uint64_t n, int32_t **ids, uint64_t **id_offsets,
+                            uint8_t **status, uint64_t *n_failed);
 void spmx_free(void *p);
 
 /* Single sentence, caller-provided buffer (Encode(input, &ids)): returns the sentence's own Status, as the
@@ -191,6 +197,15 @@ int spmx_nbest_encode_batch(spmx_handle *h, const char *text, const uint64_t *of
 int spmx_split_lines_device(spmx_handle *h, const void *d_file, uint64_t bytes, void *d_text, uint64_t text_capacity,
                             uint64_t *d_offsets, uint64_t offsets_capacity, void *stream, uint64_t *n_lines,
                             uint64_t *text_bytes);
+
+/* ---- corpus file -> ids --------------------------------------------------
+ * What the reference's `spm_encode --output_format=id < in > out` does (src/spm_encode_main.cc:115-119, :159-165: getline,
+ * Encode, StrJoin(ids, " ")), as one call: the file is mmap'ed and goes through a pipeline of worker threads -- pinned
+ * staging, H2D, the device line splitter, the encode kernels, D2H, formatting -- chunk by chunk, in order.
+ * format "id": the reference's text output, byte for byte; "bin": out_path receives the ids (int32, flat) and
+ * out_path + ".idx" the n + 1 uint64 offsets. */
+int spmx_encode_file(spmx_handle *h, const char *in_path, const char *out_path, const char *format, uint64_t *n_sentences,
+                     uint64_t *n_ids);
 
 /* ---- measurement --------------------------------------------------------
  * Per-kernel timing of the encode kernels of the LAST profiled encode call on the handle, measured with hipEvents

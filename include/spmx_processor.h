@@ -155,21 +155,23 @@ class SentencePieceProcessor {
     spmx_free(offs);
     return util::Status();
   }
-  // Element-wise identical to Encode() per input (sentencepiece.i:245-267).
+  // Element-wise identical to Encode() per input (sentencepiece.i:245-267): a failing element yields an empty id list
+  // (the reference's workers call EncodeAsIds, which drops the Status).  The sentences are handed over as (pointer,
+  // length) pairs: the library gathers them into its pinned staging buffers chunk by chunk, no packed copy is made here.
   util::Status EncodeBatch(const std::vector<std::string_view> &ins, std::vector<std::vector<int>> *outs) const {
+    if (!h_) return status();
     if (!outs) return util::Status(util::StatusCode::kInternal, "output container is null");
     outs->clear();
-    std::string text;
-    std::vector<uint64_t> offs(ins.size() + 1, 0);
-    for (size_t i = 0; i < ins.size(); ++i) offs[i + 1] = offs[i] + ins[i].size();
-    text.reserve(offs.back());
-    for (auto s : ins) text.append(s.data(), s.size());
-    std::vector<int32_t> ids;
-    std::vector<uint64_t> io;
-    const util::Status st = EncodeBatchFlat(text.data(), offs.data(), ins.size(), &ids, &io);
-    if (!st.ok()) return st;
+    std::vector<spmx_view> views(ins.size());
+    for (size_t i = 0; i < ins.size(); ++i) views[i] = spmx_view{ins[i].data(), ins[i].size()};
+    int32_t *ids = nullptr;
+    uint64_t *io = nullptr;
+    const int rc = spmx_encode_batch_views(h_, views.data(), views.size(), &ids, &io, nullptr, nullptr);
+    if (rc != 0) return FromHandle(rc);
     outs->resize(ins.size());
-    for (size_t i = 0; i < ins.size(); ++i) (*outs)[i].assign(ids.begin() + io[i], ids.begin() + io[i + 1]);
+    for (size_t i = 0; i < ins.size(); ++i) (*outs)[i].assign(ids + io[i], ids + io[i + 1]);
+    spmx_free(ids);
+    spmx_free(io);
     return util::Status();
   }
   // Device-resident form (HIP pointers, see spmx_encode_batch_device).

@@ -42,6 +42,8 @@ SYMBOLS = [
      [_H, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_U64),
       C.POINTER(_U64)]),
     ("spmx_unk_piece", C.c_int64, [_H, C.c_char_p, _U64]),
+    ("spmx_encode_batch_views", C.c_int,
+     [_H, C.c_void_p, _U64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(_U64)]),
     ("spmx_free", None, [C.c_void_p]),
     ("spmx_encode", C.c_int, [_H, C.c_char_p, _U64, C.c_void_p, _U64, C.POINTER(_U64)]),
     ("spmx_decode_batch_device", C.c_int,
@@ -62,6 +64,7 @@ SYMBOLS = [
     ("spmx_nbest_encode_batch", C.c_int,
      [_H, C.c_void_p, C.c_void_p, _U64, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
       C.POINTER(C.c_void_p)]),
+    ("spmx_encode_file", C.c_int, [_H, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_U64), C.POINTER(_U64)]),
     ("spmx_split_lines_device", C.c_int,
      [_H, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, C.POINTER(_U64), C.POINTER(_U64)]),
     ("spmx_set_profiling", C.c_int, [_H, C.c_int]),

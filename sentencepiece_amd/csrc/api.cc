@@ -18,10 +18,18 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <condition_variable>
 #include <cstring>
 #include <fstream>
+#include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <new>
 #include <sstream>
 #include <string>
@@ -93,6 +101,52 @@ struct PinBuf {
   void Free() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
 
+// Output arrays of the big host-buffer calls are PINNED (the D2H copies land in them directly) and recycled: spmx_free()
+// of such a pointer returns it to this process-wide pool instead of unpinning ~GBs per call; plain malloc'd outputs
+// are not in the registry and go to free().
+struct PinnedPool {
+  std::mutex mu;
+  std::map<void *, size_t> live;                   // handed to a caller
+  std::multimap<size_t, void *> idle;              // by capacity
+  size_t idle_bytes = 0;
+  void *Get(size_t bytes) {
+    if (bytes == 0) bytes = 1;
+    {
+      std::lock_guard<std::mutex> l(mu);
+      auto it = idle.lower_bound(bytes);
+      if (it != idle.end() && it->first <= 2 * bytes + (1u << 20)) {
+        void *p = it->second;
+        const size_t cap = it->first;
+        idle.erase(it);
+        idle_bytes -= cap;
+        live[p] = cap;
+        return p;
+      }
+    }
+    void *p = nullptr;
+    const size_t cap = bytes + bytes / 8;
+    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> l(mu);
+    live[p] = cap;
+    return p;
+  }
+  bool Put(void *p) {                              // false: not ours
+    void *drop = nullptr;
+    {
+      std::lock_guard<std::mutex> l(mu);
+      auto it = live.find(p);
+      if (it == live.end()) return false;
+      const size_t cap = it->second;
+      live.erase(it);
+      if (idle_bytes + cap > (24ull << 30)) drop = p;         // keep at most 24 GiB around
+      else { idle.emplace(cap, p); idle_bytes += cap; }
+    }
+    if (drop) (void)hipHostFree(drop);
+    return true;
+  }
+};
+PinnedPool g_pinned;
+
 struct Profile {
   int n = 0;
   char name[kNumSlots][48] = {{0}};
@@ -118,6 +172,8 @@ struct Workspace {
   DevBuf<uint8_t> d_text;
   DevBuf<uint64_t> d_offs, d_id_offs;
   DevBuf<int32_t> d_ids;
+  PinBuf<uint8_t> h_text;       // pinned staging of the pipelined host form
+  PinBuf<uint64_t> h_offs, h_id_offs;
   hipStream_t stream = nullptr;
   hipEvent_t ev[kNumSlots + 1][2] = {};   // per kernel slot + the whole call
   bool ev_ready = false;
@@ -130,6 +186,7 @@ struct Workspace {
     d_arena_tb.Free(); d_tok_begin.Free(); d_span_begin.Free(); d_span_end.Free(); d_nspan_begin.Free(); d_nspan_end.Free();
     d_norm.Free(); d_nbest_scratch.Free(); d_slab.Free(); d_pool.Free(); d_sent_status.Free(); d_res_off.Free();
     d_res_score.Free(); d_text.Free(); d_offs.Free(); d_id_offs.Free(); d_ids.Free();
+    h_text.Free(); h_offs.Free(); h_id_offs.Free();
     if (d_ctrl) (void)hipFree(d_ctrl);
     if (h_ctrl) (void)hipHostFree(h_ctrl);
     if (stream) (void)hipStreamDestroy(stream);
@@ -166,6 +223,8 @@ struct spmx_handle {
   int tile_waves_override = 0;   // SPMX_TILE_WAVES: cap on wavefronts per workgroup of the streaming kernels
   uint32_t lane_general_min_lanes = 0;   // SPMX_LANE_GENERAL_MIN_LANES (0: per class)
   uint32_t sub_buckets = kSubBuckets;    // SPMX_SUB_BUCKETS: length sub-buckets per class in the classify sort (1..64)
+  int host_threads = 8;          // SPMX_HOST_THREADS: workers of the pipelined host form (chunks in flight)
+  uint64_t host_chunk = 1u << 19; // SPMX_HOST_CHUNK: sentences per chunk of the pipelined host form
   uint32_t ring_override = 0;    // SPMX_FORCE_RING: score-ring entries (must exceed the longest piece)
   uint64_t stream_scratch_limit = 16ull << 30;   // SPMX_STREAM_SCRATCH_MB: cap on the streaming kernels' HBM scratch
   bool tight_tcap = false;       // SPMX_TIGHT_TCAP=1: text columns of 1.125 x the class's raw size (A/B: scratch footprint)
@@ -926,6 +985,8 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_STREAM_SCRATCH_MB")) h->stream_scratch_limit = static_cast<uint64_t>(atoll(e)) << 20;
     if (const char *e = getenv("SPMX_TILE_WAVES")) h->tile_waves_override = atoi(e);
     if (const char *e = getenv("SPMX_MAIN_MAX_RAW")) h->main_max_raw = static_cast<uint32_t>(atoll(e));
+    if (const char *e = getenv("SPMX_HOST_THREADS")) { const int v = atoi(e); h->host_threads = v < 1 ? 1 : (v > 64 ? 64 : v); }
+    if (const char *e = getenv("SPMX_HOST_CHUNK")) { const long long v = atoll(e); if (v >= 1024) h->host_chunk = static_cast<uint64_t>(v); }
     if (const char *e = getenv("SPMX_FORCE_RING")) { const int v = atoi(e); if (v >= 16 && v <= 122) h->ring_override = static_cast<uint32_t>(v); }
     if (const char *e = getenv("SPMX_CLASSES")) {          // "raw:norm,raw:norm,..." (ascending; tests shrink the table)
       int c = 0;
@@ -1204,9 +1265,174 @@ int RunSelfTest(spmx_handle *h) {
 }
 }  // namespace
 
+namespace {
+// The host-buffer encode of a BIG batch as a pipeline: the batch is cut into chunks of host_chunk sentences and
+// host_threads workers take them round-robin, each with a workspace and a stream of its own:
+//   gather the chunk into pinned staging (memcpy) -> H2D -> the encode launches -> D2H straight into the (pinned,
+//   pooled) output arrays at the chunk's place in the CSR -> id offsets rebased on the way out.
+// The H2D of one chunk, the kernels of another and the D2H of a third overlap on the GPU, and the staging copies run
+// on as many host threads.  A chunk's place in the id array is the sum of the earlier chunks' id counts: a worker
+// waits for its predecessor's count (not for its copies) before it issues the D2H.
+// `views` (optional, instead of text / offsets): n (pointer, length) pairs, gathered the same way.
+struct spmx_view_ { const char *data; uint64_t len; };
+int EncodeBatchPipelined(spmx_handle *h, const char *text, const uint64_t *offsets, const spmx_view_ *views, uint64_t n,
+                         int32_t **ids, uint64_t **id_offsets, uint8_t **status, uint64_t *n_failed) {
+  const uint64_t chunk = h->host_chunk;
+  const uint64_t n_chunks = (n + chunk - 1) / chunk;
+  int T = h->host_threads;
+  if (static_cast<uint64_t>(T) > n_chunks) T = static_cast<int>(n_chunks);
+  // byte offset of every chunk's first sentence
+  std::vector<uint64_t> cbeg(n_chunks + 1, 0);
+  if (views) {
+    for (uint64_t k = 0; k < n_chunks; ++k) {
+      uint64_t b = 0;
+      const uint64_t s1 = (k + 1) * chunk < n ? (k + 1) * chunk : n;
+      for (uint64_t i = k * chunk; i < s1; ++i) b += views[i].len;
+      cbeg[k + 1] = cbeg[k] + b;
+    }
+  } else {
+    for (uint64_t k = 0; k <= n_chunks; ++k) cbeg[k] = offsets[k * chunk < n ? k * chunk : n] - offsets[0];
+  }
+  const uint64_t text_bytes = cbeg[n_chunks];
+  uint64_t cap = text_bytes / 2 + 4 * n + 64;                    // ids the output array holds (more: the plain path takes over)
+  int32_t *out_ids = static_cast<int32_t *>(g_pinned.Get(cap * sizeof(int32_t)));
+  uint64_t *out_offs = static_cast<uint64_t *>(g_pinned.Get((n + 1) * sizeof(uint64_t)));
+  uint8_t *out_st = status ? static_cast<uint8_t *>(g_pinned.Get(n)) : nullptr;
+  auto drop = [&]() { if (out_ids) g_pinned.Put(out_ids); if (out_offs) g_pinned.Put(out_offs); if (out_st) g_pinned.Put(out_st); };
+  if (!out_ids || !out_offs || (status && !out_st)) { drop(); return Fail(h, kResourceExhausted, "out of pinned host memory"); }
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<uint64_t> base(n_chunks + 1, 0);                   // ids before chunk k
+  uint64_t known = 0;                                            // base[0 .. known] are final
+  int first_rc = kOk;
+  std::string first_err;
+  bool overflow = false;
+  uint64_t failed_total = 0;
+  auto worker = [&](int w) {
+    int rc = kOk;
+    std::string err;
+    auto body = [&]() -> int {
+      HIP_OR_RETURN(h, hipSetDevice(h->device));
+      Lease L(h);
+      if (int r = L.Ready(); r != kOk) return r;
+      Workspace *ws = L.ws.get();
+      hipStream_t st = ws->stream;
+      for (uint64_t k = static_cast<uint64_t>(w); k < n_chunks; k += static_cast<uint64_t>(T)) {
+        const uint64_t s0 = k * chunk, s1 = (k + 1) * chunk < n ? (k + 1) * chunk : n, cnt = s1 - s0;
+        const uint64_t bytes = cbeg[k + 1] - cbeg[k];
+        HIP_OR_RETURN(h, ws->h_text.Reserve(bytes + 32));
+        HIP_OR_RETURN(h, ws->h_offs.Reserve(cnt + 1));
+        HIP_OR_RETURN(h, ws->h_id_offs.Reserve(cnt + 1));
+        HIP_OR_RETURN(h, ws->d_text.Reserve(bytes + 32));
+        HIP_OR_RETURN(h, ws->d_offs.Reserve(cnt + 1));
+        HIP_OR_RETURN(h, ws->d_id_offs.Reserve(cnt + 1));
+        HIP_OR_RETURN(h, ws->d_sent_status.Reserve(cnt));
+        if (views) {
+          uint64_t at = 0;
+          for (uint64_t i = 0; i < cnt; ++i) {
+            ws->h_offs.p[i] = at;
+            if (views[s0 + i].len) memcpy(ws->h_text.p + at, views[s0 + i].data, views[s0 + i].len);
+            at += views[s0 + i].len;
+          }
+          ws->h_offs.p[cnt] = at;
+        } else {
+          const uint64_t b0 = offsets[s0];
+          if (bytes) memcpy(ws->h_text.p, text + b0, bytes);
+          for (uint64_t i = 0; i <= cnt; ++i) ws->h_offs.p[i] = offsets[s0 + i] - b0;
+        }
+        if (bytes) HIP_OR_RETURN(h, hipMemcpyAsync(ws->d_text.p, ws->h_text.p, bytes, hipMemcpyHostToDevice, st));
+        HIP_OR_RETURN(h, hipMemcpyAsync(ws->d_offs.p, ws->h_offs.p, (cnt + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        uint64_t want = bytes / 2 + 4 * cnt + 64, total = 0, failed = 0;
+        int r = kOk;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+          HIP_OR_RETURN(h, ws->d_ids.Reserve(want));
+          r = EncodeDevice(h, ws, ws->d_text.p, bytes, ws->d_offs.p, cnt, ws->d_ids.p, ws->d_ids.cap, ws->d_id_offs.p,
+                           ws->d_sent_status.p, st, &total, &failed);
+          if (r != kResourceExhausted || total <= ws->d_ids.cap) break;
+          want = total;
+        }
+        if (r != kOk) return r;
+        uint64_t my_base = 0;
+        {                                                        // the chunk's place in the CSR
+          std::unique_lock<std::mutex> l(mu);
+          cv.wait(l, [&] { return known >= k || first_rc != kOk; });
+          if (first_rc != kOk) return kOk;                       // (another worker failed: stop quietly)
+          my_base = base[k];
+          base[k + 1] = my_base + total;
+          known = k + 1;
+          failed_total += failed;
+          if (my_base + total > cap) overflow = true;
+          cv.notify_all();
+          if (overflow) continue;                                // (keep the counts flowing; the plain path redoes the call)
+        }
+        if (total) HIP_OR_RETURN(h, hipMemcpyAsync(out_ids + my_base, ws->d_ids.p, total * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_OR_RETURN(h, hipMemcpyAsync(ws->h_id_offs.p, ws->d_id_offs.p, (cnt + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        if (out_st) HIP_OR_RETURN(h, hipMemcpyAsync(out_st + s0, ws->d_sent_status.p, cnt, hipMemcpyDeviceToHost, st));
+        HIP_OR_RETURN(h, hipStreamSynchronize(st));
+        for (uint64_t i = 0; i < cnt; ++i) out_offs[s0 + i] = ws->h_id_offs.p[i] + my_base;
+      }
+      return kOk;
+    };
+    try { rc = body(); } catch (const std::bad_alloc &) { rc = kResourceExhausted; t_error = "out of host memory"; } catch (...) { rc = kInternal; t_error = "unknown exception"; }
+    if (rc != kOk) {
+      err = t_error;
+      std::lock_guard<std::mutex> l(mu);
+      if (first_rc == kOk) { first_rc = rc; first_err = err; }
+      cv.notify_all();
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int w = 1; w < T; ++w) pool.emplace_back(worker, w);
+  worker(0);
+  for (auto &t : pool) t.join();
+  if (first_rc != kOk) { drop(); return Fail(h, first_rc, first_err); }
+  if (overflow) { drop(); return -1; }                           // more ids than the estimate: the caller takes the plain path
+  out_offs[n] = base[n_chunks];
+  *ids = out_ids;
+  *id_offsets = out_offs;
+  if (status) *status = out_st;
+  if (n_failed) *n_failed = failed_total;
+  return kOk;
+}
+}  // namespace
+
 int spmx_encode_batch_ex(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
                          uint64_t **id_offsets, uint8_t **status, uint64_t *n_failed) {
-  return Guard(h, [&]() -> int { return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, status, n_failed, nullptr, nullptr); });
+  return Guard(h, [&]() -> int {
+    if (h && ids && id_offsets && offsets && n >= 2 * h->host_chunk) {     // big batches: the chunk pipeline
+      *ids = nullptr; *id_offsets = nullptr;
+      if (status) *status = nullptr;
+      if (n_failed) *n_failed = 0;
+      const int rc = EncodeBatchPipelined(h, text, offsets, nullptr, n, ids, id_offsets, status, n_failed);
+      if (rc != -1) return rc;
+    }
+    return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, status, n_failed, nullptr, nullptr);
+  });
+}
+
+/* The same batch given as n (pointer, length) pairs -- what a std::vector<absl::string_view> holds: the sentences are
+ * gathered into the staging buffers directly, chunk by chunk, without an intermediate packed copy. */
+int spmx_encode_batch_views(spmx_handle *h, const spmx_view *views, uint64_t n, int32_t **ids, uint64_t **id_offsets,
+                            uint8_t **status, uint64_t *n_failed) {
+  if (!h) return kInvalidArgument;
+  if (!ids || !id_offsets) return Fail(h, kInternal, "output container is null");
+  return Guard(h, [&]() -> int {
+    *ids = nullptr; *id_offsets = nullptr;
+    if (status) *status = nullptr;
+    if (n_failed) *n_failed = 0;
+    if (n && !views) return Fail(h, kInvalidArgument, "null views");
+    if (n >= 2 * h->host_chunk) {
+      const int rc = EncodeBatchPipelined(h, nullptr, nullptr, reinterpret_cast<const spmx_view_ *>(views), n, ids, id_offsets, status, n_failed);
+      if (rc != -1) return rc;
+    }
+    std::string text;                                     // small batches (and the fallback): pack, then the plain form
+    std::vector<uint64_t> offs(n + 1, 0);
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < n; ++i) total += views[i].len;
+    text.reserve(total);
+    for (uint64_t i = 0; i < n; ++i) { text.append(views[i].data, views[i].len); offs[i + 1] = text.size(); }
+    return EncodeBatchHost(h, text.data(), offs.data(), n, ids, id_offsets, status, n_failed, nullptr, nullptr);
+  });
 }
 
 int spmx_encode_batch(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
@@ -1420,7 +1646,10 @@ int spmx_normalize_batch(spmx_handle *h, const char *text, const uint64_t *offse
   });
 }
 
-void spmx_free(void *p) { free(p); }
+void spmx_free(void *p) {
+  if (!p) return;
+  if (!g_pinned.Put(p)) free(p);
+}
 
 int spmx_encode(spmx_handle *h, const char *text, uint64_t len, int32_t *ids, uint64_t cap, uint64_t *n_ids) {
   if (!h) return kInvalidArgument;
@@ -1566,6 +1795,164 @@ int spmx_split_lines_device(spmx_handle *h, const void *d_file, uint64_t bytes, 
       return Fail(h, kResourceExhausted, "text_capacity / offsets_capacity is too small");
     HIP_OR_RETURN(h, LaunchSplit(true, a, grid, stream));
     HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+    return kOk;
+  });
+}
+
+/* ---- corpus file -> ids (the caller-side loop of spm_encode, src/spm_encode_main.cc:159-165) -------------------------
+ * mmap the input, cut it into chunks that end at a line end, and run them through a pipeline of worker threads (each
+ * with a workspace and a stream): pinned staging copy -> H2D -> spmx_split_lines (getline semantics, on the device)
+ * -> encode -> D2H -> format.  A writer keeps the chunks in order.  format "id": one line of space-separated ids per
+ * input line, as `spm_encode --output_format=id` writes; "bin": out_path gets the ids (int32, flat), out_path + ".idx"
+ * the n + 1 uint64 offsets. */
+int spmx_encode_file(spmx_handle *h, const char *in_path, const char *out_path, const char *format, uint64_t *n_sentences,
+                     uint64_t *n_ids) {
+  if (!h) return kInvalidArgument;
+  if (n_sentences) *n_sentences = 0;
+  if (n_ids) *n_ids = 0;
+  return Guard(h, [&]() -> int {
+    const bool bin = format && std::string(format) == "bin";
+    if (format && !bin && std::string(format) != "id") return Fail(h, kInvalidArgument, "format must be \"id\" or \"bin\"");
+    const int fd = open(in_path ? in_path : "", O_RDONLY);
+    if (fd < 0) return Fail(h, kNotFound, std::string("\"") + (in_path ? in_path : "") + "\": No such file or directory");
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { close(fd); return Fail(h, kInternal, "fstat failed"); }
+    const uint64_t size = static_cast<uint64_t>(sb.st_size);
+    const uint8_t *file = nullptr;
+    if (size) {
+      void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (m == MAP_FAILED) { close(fd); return Fail(h, kInternal, "mmap failed"); }
+      file = static_cast<const uint8_t *>(m);
+    }
+    close(fd);
+    FILE *out = fopen(out_path ? out_path : "", "wb");
+    FILE *idx = nullptr;
+    if (out && bin) idx = fopen((std::string(out_path) + ".idx").c_str(), "wb");
+    if (!out || (bin && !idx)) {
+      if (out) fclose(out);
+      if (file) munmap(const_cast<uint8_t *>(file), size);
+      return Fail(h, kPermissionDenied, std::string("cannot write \"") + (out_path ? out_path : "") + "\"");
+    }
+    // chunks of about 64 MiB that end after a line end
+    std::vector<uint64_t> cut(1, 0);
+    const uint64_t target = 64ull << 20;
+    while (cut.back() < size) {
+      uint64_t e = cut.back() + target;
+      if (e >= size) e = size;
+      else {
+        const void *nl = memchr(file + e, '\n', size - e);
+        e = nl ? static_cast<uint64_t>(static_cast<const uint8_t *>(nl) - file) + 1 : size;
+      }
+      cut.push_back(e);
+    }
+    const uint64_t n_chunks = cut.size() - 1;
+    int T = h->host_threads < 4 ? h->host_threads : 4;
+    if (static_cast<uint64_t>(T) > n_chunks) T = static_cast<int>(n_chunks ? n_chunks : 1);
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t next_write = 0, sent_total = 0, id_total = 0;
+    int first_rc = kOk;
+    std::string first_err;
+    auto worker = [&](int w) {
+      auto body = [&]() -> int {
+        HIP_OR_RETURN(h, hipSetDevice(h->device));
+        Lease L(h);
+        if (int r = L.Ready(); r != kOk) return r;
+        Workspace *ws = L.ws.get();
+        hipStream_t st = ws->stream;
+        DevBuf<uint8_t> d_file;
+        struct Guard2 { DevBuf<uint8_t> &b; ~Guard2() { b.Free(); } } g2{d_file};
+        std::vector<int32_t> ids;
+        std::vector<uint64_t> io;
+        std::string formatted;
+        for (uint64_t k = static_cast<uint64_t>(w); k < n_chunks; k += static_cast<uint64_t>(T)) {
+          const uint64_t bytes = cut[k + 1] - cut[k];
+          const uint8_t *src = file + cut[k];
+          uint64_t nl = 0;
+          for (const uint8_t *p = src, *e = src + bytes; p < e;) {
+            const void *q = memchr(p, '\n', static_cast<size_t>(e - p));
+            if (!q) break;
+            ++nl;
+            p = static_cast<const uint8_t *>(q) + 1;
+          }
+          const uint64_t lines = nl + (bytes && src[bytes - 1] != '\n' ? 1 : 0);
+          HIP_OR_RETURN(h, ws->h_text.Reserve(bytes + 32));
+          HIP_OR_RETURN(h, d_file.Reserve(bytes + 32));
+          HIP_OR_RETURN(h, ws->d_text.Reserve(bytes + 32));
+          HIP_OR_RETURN(h, ws->d_offs.Reserve(lines + 2));
+          HIP_OR_RETURN(h, ws->d_id_offs.Reserve(lines + 2));
+          memcpy(ws->h_text.p, src, bytes);
+          HIP_OR_RETURN(h, hipMemcpyAsync(d_file.p, ws->h_text.p, bytes, hipMemcpyHostToDevice, st));
+          uint64_t n_lines = 0, text_bytes = 0;
+          int r = spmx_split_lines_device(h, d_file.p, bytes, ws->d_text.p, ws->d_text.cap, ws->d_offs.p, ws->d_offs.cap, st, &n_lines, &text_bytes);
+          if (r != kOk) return r;
+          uint64_t want = text_bytes / 2 + 4 * n_lines + 64, total = 0;
+          for (int attempt = 0; attempt < 2; ++attempt) {
+            HIP_OR_RETURN(h, ws->d_ids.Reserve(want));
+            r = EncodeDevice(h, ws, ws->d_text.p, text_bytes, ws->d_offs.p, n_lines, ws->d_ids.p, ws->d_ids.cap, ws->d_id_offs.p,
+                             nullptr, st, &total, nullptr);
+            if (r != kResourceExhausted || total <= ws->d_ids.cap) break;
+            want = total;
+          }
+          if (r != kOk) return r;
+          ids.resize(total);
+          io.resize(n_lines + 1);
+          if (total) HIP_OR_RETURN(h, hipMemcpyAsync(ids.data(), ws->d_ids.p, total * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+          HIP_OR_RETURN(h, hipMemcpyAsync(io.data(), ws->d_id_offs.p, (n_lines + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+          HIP_OR_RETURN(h, hipStreamSynchronize(st));
+          if (!bin) {                                  // absl::StrJoin(ids, " ") per line (spm_encode_main.cc:116-119)
+            formatted.clear();
+            formatted.reserve(total * 6 + n_lines);
+            char tmp[16];
+            for (uint64_t s2 = 0; s2 < n_lines; ++s2) {
+              for (uint64_t x = io[s2]; x < io[s2 + 1]; ++x) {
+                if (x > io[s2]) formatted.push_back(' ');
+                int v = ids[x], len = 0;
+                do { tmp[len++] = static_cast<char>('0' + v % 10); v /= 10; } while (v);
+                while (len) formatted.push_back(tmp[--len]);
+              }
+              formatted.push_back('\n');
+            }
+          }
+          std::unique_lock<std::mutex> l(mu);
+          cv.wait(l, [&] { return next_write == k || first_rc != kOk; });
+          if (first_rc != kOk) return kOk;
+          bool ok = true;
+          if (bin) {
+            if (total) ok = fwrite(ids.data(), sizeof(int32_t), total, out) == total;
+            for (uint64_t s2 = 0; s2 < n_lines; ++s2) io[s2] += id_total;
+            if (n_lines) ok = ok && fwrite(io.data(), sizeof(uint64_t), n_lines, idx) == n_lines;
+          } else if (!formatted.empty()) {
+            ok = fwrite(formatted.data(), 1, formatted.size(), out) == formatted.size();
+          }
+          sent_total += n_lines;
+          id_total += total;
+          next_write = k + 1;
+          cv.notify_all();
+          if (!ok) return Fail(h, kDataLoss, "short write");
+        }
+        return kOk;
+      };
+      int rc = kOk;
+      try { rc = body(); } catch (const std::bad_alloc &) { rc = kResourceExhausted; t_error = "out of host memory"; } catch (...) { rc = kInternal; t_error = "unknown exception"; }
+      if (rc != kOk) {
+        const std::string err = t_error;
+        std::lock_guard<std::mutex> l(mu);
+        if (first_rc == kOk) { first_rc = rc; first_err = err; }
+        cv.notify_all();
+      }
+    };
+    std::vector<std::thread> pool;
+    for (int w = 1; w < T; ++w) pool.emplace_back(worker, w);
+    worker(0);
+    for (auto &t : pool) t.join();
+    if (bin && first_rc == kOk) fwrite(&id_total, sizeof(uint64_t), 1, idx);      // the closing offset
+    if (idx) fclose(idx);
+    fclose(out);
+    if (file) munmap(const_cast<uint8_t *>(file), size);
+    if (first_rc != kOk) return Fail(h, first_rc, first_err);
+    if (n_sentences) *n_sentences = sent_total;
+    if (n_ids) *n_ids = id_total;
     return kOk;
   });
 }

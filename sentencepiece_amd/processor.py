@@ -12,6 +12,7 @@ works on -- one ``uint8`` text blob + ``uint64`` offsets (host numpy arrays or
 device torch tensors) -- and returns CSR ``(ids, id_offsets)``.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -653,6 +654,18 @@ class SentencePieceProcessor:
         return d_text[:tb.value], d_offs[:n.value + 1], n.value
 
     # ------------------------------------------------------ measurement ----
+    def EncodeFile(self, in_path, out_path, output_format="id"):
+        """Corpus file -> ids, the loop of the reference's ``spm_encode --output_format=id`` (spm_encode_main.cc:115-165)
+        as one pipelined call: ``output_format="id"`` writes the reference's text (one line of space-separated ids per
+        input line), ``"bin"`` the flat int32 ids to ``out_path`` and the uint64 offsets to ``out_path + ".idx"``.
+        ``SetEncodeExtraOptions`` applies.  Returns ``(sentences, ids)``."""
+        self._need()
+        self._apply(False, False, False)
+        ns, ni = C.c_uint64(0), C.c_uint64(0)
+        self._check(self._lib.spmx_encode_file(self._h, os.fsencode(in_path), os.fsencode(out_path),
+                                               output_format.encode(), C.byref(ns), C.byref(ni)))
+        return int(ns.value), int(ni.value)
+
     def SetProfiling(self, enabled):
         self._need()
         self._lib.spmx_set_profiling(self._h, 1 if enabled else 0)

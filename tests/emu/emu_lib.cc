@@ -14,7 +14,7 @@
 namespace spmx {
 namespace emu {
 
-Wave g_wave;
+thread_local Wave g_wave;
 
 asm(R"(
 .text

@@ -49,7 +49,7 @@ struct Wave {
   uint64_t n_collectives = 0;
 };
 
-extern Wave g_wave;
+extern thread_local Wave g_wave;   // (one emulated wavefront per host thread: the pipelined host form has workers)
 extern "C" void spmx_emu_switch(void **save_sp, void *load_sp);
 
 void RunWave(int block, int grid, unsigned char *smem, const std::function<void()> &body);

@@ -12,14 +12,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "tests", "cpp", "facade_test")
 
 
-def _build():
+def _build(emu=False):
+    """emu: link the same caller against tests/emu/libspmx_emu.so (the product's api.cc over the CPU model of the
+    wavefront) instead of libspmx.so: the facade's own code runs in the CPU suite too."""
     src = os.path.join(ROOT, "tests", "cpp", "facade_test.cc")
-    lib = os.path.join(ROOT, "sentencepiece_amd")
-    if (not os.path.exists(BIN) or os.path.getmtime(BIN) < os.path.getmtime(src)
-            or os.path.getmtime(BIN) < os.path.getmtime(os.path.join(ROOT, "include", "spmx_processor.h"))):
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-o", BIN, src, "-L" + lib, "-lspmx",
-                               "-Wl,-rpath," + lib])
-    return BIN
+    lib = os.path.join(ROOT, "tests", "emu") if emu else os.path.join(ROOT, "sentencepiece_amd")
+    out = BIN + ("_emu" if emu else "")
+    if emu:
+        from tests import emulib
+        emulib.lib()                      # builds libspmx_emu.so
+    so = os.path.join(lib, "libspmx_emu.so" if emu else "libspmx.so")
+    newest = max(os.path.getmtime(src), os.path.getmtime(os.path.join(ROOT, "include", "spmx_processor.h")),
+                 os.path.getmtime(os.path.join(ROOT, "include", "spmx.h")), os.path.getmtime(so))
+    if not os.path.exists(out) or os.path.getmtime(out) < newest:
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-o", out, src, "-L" + lib,
+                               "-lspmx_emu" if emu else "-lspmx", "-Wl,-rpath," + lib])
+    return out
 
 
 def test_facade_builds_and_reports_unavailable():
@@ -31,6 +39,19 @@ def test_facade_builds_and_reports_unavailable():
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert "Unavailable" in out.stdout
+
+
+@pytest.mark.parametrize("model,opts,key", [("test_model", "bos:eos", "test_model__botchan__bos-eos"), ("bpe1k", "", "bpe1k__botchan")])
+def test_facade_matches_golden_emulated(model, opts, key, golden_arrays, tmp_path):
+    """Encode per line + EncodeBatch(vector<string_view>) of the C++ facade, device emulated: the reference's ids."""
+    b = _build(emu=True)
+    args = [b, os.path.join(fixtures.GOLDEN, model + ".model"), os.path.join(fixtures.GOLDEN, "botchan.txt")]
+    if opts:
+        args.append(opts)
+    out = subprocess.run(args, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    ids = np.array([int(x) for line in out.stdout.split("\n") for x in line.split()], dtype=np.int32)
+    np.testing.assert_array_equal(ids, golden_arrays[key + "__ids"])
 
 
 @pytest.mark.gpu
