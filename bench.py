@@ -1,27 +1,32 @@
 #!/usr/bin/env python3
 """Headline benchmark: batch encode -> ids on MI355X (BASELINE.json configs[1]).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--sentences S] [--model uni32k|bpe32k]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--sentences S] [--model uni32k|bpe32k|...]
 
-A "step" is one pass of the hot path (classify -> normalize + segment + emit ->
-scan -> compact) over one batch of S synthetic sentences (default 10 M, ASCII,
-mean 128 B, length-bucketed; 32k unigram model) whose packed text and offsets
-are already resident in HBM; ids come out as CSR in HBM.  With N > 1 every rank
-encodes its own S sentences (weak scaling, seed + rank) and the step also
-all-gathers the id streams of all ranks over RCCL, as BASELINE.json's
-north_star asks (``--gather none`` drops the collective).
+A "step" is one pass of the hot path (classify -> normalize + segment + emit -> scan -> compact) over one batch of S
+synthetic sentences (default 10 M, ASCII, mean 128 B, length-bucketed; 32k unigram model) whose packed text and offsets
+are already resident in HBM; ids come out as CSR in HBM.  With N > 1 every rank encodes its own S sentences (weak
+scaling, seed + rank; default 12.5 M per rank = configs[3] at N = 8) and the step also all-gathers the id streams of
+all ranks over RCCL, as BASELINE.json's north_star asks; the same run then times the no-collective form too
+(``value_gather_none``).
 
-Prints ONE JSON line on rank 0.  ``roofline`` is for the dominant kernel (the
-unigram encode kernel of the busiest length class): algorithmic bytes per
-launch (L + 8 + 4 T' + 8 per sentence) over the kernel's
-mean duration, measured with HIP events on the launch stream inside the timed
-region.  ``cpu_baseline`` times the compiled reference (oracle/_ref, kind
-"reference") -- or the plain-C oracle (kind "port") if that is absent -- on a
-strided sample of the same corpus on this box's host cores.
+Prints ONE JSON line on rank 0.
+  value         sentences/s of K unprofiled steps (barrier + synchronize on both sides, MAX over ranks)
+  roofline      the dominant kernel (the streaming encode launch) over a second, PROFILED loop of the same steps: HIP
+                events around the launch on its stream; algorithmic bytes = L + 8 + 4 T' + 8 per sentence;
+                `traffic` = HBM bytes per launch from the rocprofv3 PMC passes kept in profiles/pmc_traffic.json -- used
+                only if that file was made from the kernel sources this run was built from (a hash of csrc/), else null
+  long_piece_model   (N = 1, unigram headline) the same corpus recipe with words of up to 16 letters and a model trained
+                on it (pieces of up to 17 bytes, what the trainer's default max_sentencepiece_length gives on natural
+                text): the generic streaming kernel instead of the 16-entry-ring specialization
+  cpu_baseline  the compiled reference (oracle/_ref, kind "reference") on this box's host cores, bounded samples of the
+                same corpus: one thread, a thread sweep (best reported), and `spm_encode` file -> file on configs[0]
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,46 +38,92 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
+def kernel_sources_sha():
+    """Hash of the device sources: ties profiles/pmc_traffic.json to the kernels it was measured on."""
+    d = os.path.join(ROOT, "sentencepiece_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(text, offs, model_blob, gpu_counts, gpu_ids=None, gpu_id_offsets=None):
-    """Reference CPU path on a bounded strided sample of the bench corpus.  gpu_ids / gpu_id_offsets (host CSR of the
-    GPU's output): a 20 k-sentence strided probe is also compared id by id."""
+    """Reference CPU path on bounded strided samples of the bench corpus (about 20 s in all)."""
     from sentencepiece_amd import synth
     from tests import refshim
     n = len(offs) - 1
     cores = os.cpu_count() or 1
-    if refshim.available():
-        h = refshim.RefLib().load(model_blob)
-        kind, threads = "reference", cores
-
-        def run(t, o):
-            return h.encode_count(t, o, threads=threads)
-    else:
+    if not refshim.available():
         from tests import oraclelib
         h = oraclelib.OracleLib().load(model_blob)
-        kind, threads = "port", 1
+        pick = np.linspace(0, n - 1, num=min(n, 200_000)).astype(np.int64)
+        st, so = synth.gather_packed(text, offs, pick)
+        t0 = time.perf_counter()
+        h.encode_batch(st, so)
+        dt = time.perf_counter() - t0
+        return {"value": len(pick) / dt, "unit": "sentences/s", "cores": 1, "kind": "port",
+                "sample": "%d sentences strided over the bench corpus, plain-C restatement on one thread" % len(pick)}
+    h = refshim.RefLib().load(model_blob)
 
-        def run(t, o):
-            return len(h.encode_batch(t, o)[0])
-    # calibrate on 20k sentences, then size the sample for ~8 s of wall time
-    probe = np.linspace(0, n - 1, num=min(n, 20000)).astype(np.int64)
-    pt, po = synth.gather_packed(text, offs, probe)
-    t0 = time.perf_counter()
-    run(pt, po)
-    rate = len(probe) / max(time.perf_counter() - t0, 1e-6)
-    s = int(min(n, max(100_000, min(4_000_000, rate * 8.0))))
-    pick = np.linspace(0, n - 1, num=s).astype(np.int64)
-    st, so = synth.gather_packed(text, offs, pick)
-    t0 = time.perf_counter()
-    total = run(st, so)
-    dt = time.perf_counter() - t0
-    out = {"value": s / dt, "unit": "sentences/s", "cores": threads, "kind": kind,
-           "sample": "%d sentences strided over the bench corpus (%.1f MB), %.2f s wall, %d host cores present"
-                     % (s, len(st) / 1e6, dt, cores),
-           "gb_per_s": len(st) / dt / 1e9}
-    if gpu_counts is not None:
-        out["sample_ids_match_gpu"] = bool(int(gpu_counts[pick].sum()) == int(total))
+    def rate(threads, seconds):
+        """sentences/s of the reference's Encode loop on `threads` threads over a sample sized for ~`seconds`."""
+        probe = np.linspace(0, n - 1, num=min(n, 4000 * max(1, threads // 8))).astype(np.int64)
+        pt, po = synth.gather_packed(text, offs, probe)
+        t0 = time.perf_counter()
+        h.encode_count(pt, po, threads=threads)
+        r0 = len(probe) / max(time.perf_counter() - t0, 1e-6)
+        s = int(min(n, max(20_000, r0 * seconds)))
+        pick = np.linspace(0, n - 1, num=s).astype(np.int64)
+        st, so = synth.gather_packed(text, offs, pick)
+        t0 = time.perf_counter()
+        total = h.encode_count(st, so, threads=threads)
+        dt = time.perf_counter() - t0
+        return s / dt, s, dt, pick, int(total), len(st)
+    one, s1, dt1, _, _, _ = rate(1, 3.0)
+    sweep = {}
+    best = (0.0, 1, 0, 0.0, None, 0, 0)
+    for t in [t for t in (16, 32, 64, 128, 256) if t <= max(cores, 16)]:
+        r, s, dt, pick, total, nbytes = rate(t, 2.0)
+        sweep[str(t)] = r
+        if r > best[0]:
+            best = (r, t, s, dt, pick, total, nbytes)
+    out = {"value": best[0], "unit": "sentences/s", "cores": best[1], "kind": "reference",
+           "sample": "%d sentences strided over the bench corpus (%.1f MB), %.2f s wall on %d threads (best of the sweep); "
+                     "%d host cores present" % (best[2], best[6] / 1e6, best[3], best[1], cores),
+           "one_thread": {"value": one, "sentences": s1, "seconds": dt1,
+                          "what": "in-process loop over pre-loaded strings calling Encode(s, &ids) on one thread"},
+           "thread_sweep": sweep,
+           "scheme": "atomic-counter workers over pre-loaded strings, as python/src/sentencepiece/sentencepiece.i:245-267"}
+    if gpu_counts is not None and best[4] is not None:
+        out["sample_ids_match_gpu"] = bool(int(gpu_counts[best[4]].sum()) == best[5])
+    # configs[0]: spm_encode --output_format=id, file -> file, one thread (the reference's own command line)
+    exe = os.path.join(ROOT, "oracle", "_ref", "spm_encode")
+    bot = os.path.join(ROOT, "tests", "golden", "botchan.txt")
+    mdl = os.path.join(ROOT, "tests", "golden", "test_model.model")
+    if os.path.exists(exe):
+        try:
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                best_c1 = None
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    subprocess.check_call([exe, "--model=" + mdl, "--output_format=id", "--output=" + os.path.join(td, "o.txt"), bot],
+                                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                    dt = time.perf_counter() - t0
+                    best_c1 = dt if best_c1 is None else min(best_c1, dt)
+                with open(os.path.join(td, "o.txt"), "rb") as f:
+                    md5 = hashlib.md5(f.read()).hexdigest()
+            out["spm_encode_c1"] = {"what": "oracle/_ref/spm_encode --output_format=id on botchan.txt (4288 lines, 1k unigram), file -> file, "
+                                            "process start and model load included", "seconds": best_c1, "sentences_per_s": 4288 / best_c1,
+                                    "md5": md5}
+        except Exception as e:      # the check must not cost the bench line
+            out["spm_encode_c1"] = {"failed": repr(e)}
     if gpu_ids is not None:
         try:
+            probe = np.linspace(0, n - 1, num=min(n, 20000)).astype(np.int64)
+            pt, po = synth.gather_packed(text, offs, probe)
             cids, cio = h.encode_batch(pt, po)
             io = np.asarray(gpu_id_offsets).astype(np.int64)
             lens = (io[1:] - io[:-1])[probe]
@@ -80,10 +131,28 @@ def cpu_baseline(text, offs, model_blob, gpu_counts, gpu_ids=None, gpu_id_offset
             out["probe_ids_bit_exact"] = bool(np.array_equal(lens, np.diff(np.asarray(cio).astype(np.int64))) and
                                               np.array_equal(np.asarray(gpu_ids)[idx], np.asarray(cids)))
             out["probe"] = "%d sentences strided over the bench corpus, ids compared one by one" % len(probe)
-        except Exception as e:      # the check must not cost the bench line
+        except Exception as e:
             out["probe_ids_bit_exact"] = None
             out["probe"] = "failed: %r" % (e,)
     return out
+
+
+def corpus_for(model, sentences, seed, unsorted):
+    from sentencepiece_amd import synth
+    if model.startswith("c5_"):
+        return synth.mixed_corpus(sentences, seed=seed + 1)
+    # uni32k_w16: the same generator over words of up to 16 letters (scripts/train_w16.py): pieces of up to 17 bytes,
+    # as natural text under the trainer's default max_sentencepiece_length gives -- the generic streaming kernel
+    words = synth.WordList(max_word_len=16, mean_word_len=5.5) if model.endswith("_w16") else None
+    return synth.ascii_corpus(sentences, seed=seed, sort_by_length=not unsorted, words=words)
+
+
+def model_blob(model):
+    if model.startswith("c5_"):
+        from tests import fixtures
+        return fixtures.model_blob(model)      # synthesized 250k-piece model, cached under the temp dir
+    with open(os.path.join(ROOT, "tests", "golden", model + ".model"), "rb") as f:
+        return f.read()
 
 
 def main():
@@ -91,37 +160,45 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--sentences", type=int, default=10_000_000, help="sentences per GPU per step")
+    ap.add_argument("--sentences", type=int, default=None,
+                    help="sentences per GPU per step (default 10 M; 12.5 M with --gpus > 1: configs[3] is 100 M over 8 GPUs)")
     ap.add_argument("--model", default="uni32k",
                     help="uni32k | bpe32k (configs[1]/[2], ASCII corpus) | uni32k_w16 (configs[1] with pieces of up to 17 bytes) | "
-                         "c5_250k | c5_250k_bf (configs[4], "
-                         "250k-piece unigram on the mixed-script power-law corpus)")
-    ap.add_argument("--gather", choices=["ids", "none"], default="ids")
+                         "c5_250k | c5_250k_bf (configs[4], 250k-piece unigram on the mixed-script power-law corpus)")
+    ap.add_argument("--gather", choices=["both", "ids", "none"], default="both",
+                    help="N > 1: all-gather the ids over RCCL (the north star), leave it out, or time both (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-second-model", action="store_true")
     ap.add_argument("--unsorted", action="store_true",
                     help="do not length-bucket the synthetic corpus (BASELINE.json's configs are length-bucketed)")
     args = ap.parse_args()
 
-    import torch
-    from sentencepiece_amd import synth
-    from sentencepiece_amd.processor import SentencePieceProcessor
-    from sentencepiece_amd import sharding
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.sentences is None:
+        args.sentences = 12_500_000 if world > 1 else 10_000_000
+    gather_modes = ([] if world == 1 else (["ids", "none"] if args.gather == "both" else [args.gather]))
+    if world > 1 and "ids" in gather_modes:
+        # an all-gather in flight needs CUs of its own: the persistent encode grids would otherwise hold every CU until
+        # they end, and the gather of batch k would run after batch k + 1's encode instead of under it
+        os.environ.setdefault("SPMX_RESERVE_CUS", "16")
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
+
+    import torch
+    from sentencepiece_amd.processor import SentencePieceProcessor
+    from sentencepiece_amd import sharding
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     # The corpus first: the generator forks a process pool, which is safest before this process has a HIP context
     # or an RCCL communicator.  Weak scaling: every rank draws its own shard of the generator (seed + rank).
     c5 = args.model.startswith("c5_")
-    if c5:
-        text, offs = synth.mixed_corpus(args.sentences, seed=20250228 + rank)
-    else:
-        # uni32k_w16: the same generator over words of up to 16 letters (scripts/train_w16.py): pieces of up to 17 bytes,
-        # as natural text under the trainer's default max_sentencepiece_length gives -- the generic streaming kernel
-        words = synth.WordList(max_word_len=16, mean_word_len=5.5) if args.model.endswith("_w16") else None
-        text, offs = synth.ascii_corpus(args.sentences, seed=20250227 + rank, sort_by_length=not args.unsorted, words=words)
+    text, offs = corpus_for(args.model, args.sentences, 20250227 + rank, args.unsorted)
+    second = None
+    if world == 1 and args.model == "uni32k" and not args.no_second_model and \
+            os.path.exists(os.path.join(ROOT, "tests", "golden", "uni32k_w16.model")):
+        second = ("uni32k_w16",) + corpus_for("uni32k_w16", args.sentences, 20250227, args.unsorted)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -130,53 +207,70 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    if c5:
-        from tests import fixtures
-        blob = fixtures.model_blob(args.model)      # synthesized 250k-piece model, cached under the temp dir
-    else:
-        with open(os.path.join(ROOT, "tests", "golden", args.model + ".model"), "rb") as f:
-            blob = f.read()
+    blob = model_blob(args.model)
     sp = SentencePieceProcessor(model_proto=blob, device=local)
 
     n = len(offs) - 1
     d_text = torch.from_numpy(text).to(dev)
     d_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
     d_ids, d_io, total = sp.EncodeDevice(d_text, d_offs)          # sizes the output once
-    d_ids = torch.empty(int(total) + 64, dtype=torch.int32, device=dev)
+    d_ids = torch.empty(int(total) + int(total) // 16 + 64, dtype=torch.int32, device=dev)
     # ids travel as int16 when the vocabulary allows it (half the bytes on the point-to-point xGMI links)
     wire = torch.int16 if sp.GetPieceSize() <= 32768 else None
-    gather = sharding.IdGatherer(dist, dev, wire_dtype=wire) if (world > 1 and args.gather == "ids") else None
 
-    def step():
-        _, _, tot = sp.EncodeDevice(d_text, d_offs, d_ids, d_io)
-        if gather is not None:
-            gather(d_ids, tot, d_io)
-        return tot
+    def timed(run_step, wait=None):
+        for _ in range(args.warmup):
+            run_step()
+        if wait:
+            wait()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            tot = run_step()
+        if wait:
+            wait()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, tot
 
-    for _ in range(args.warmup):
-        step()
-    if gather is not None:
-        gather.wait()
+    def encode_step():
+        return sp.EncodeDevice(d_text, d_offs, d_ids, d_io)[2]
+
+    results = {}
+    if world == 1:
+        results["n/a"] = timed(encode_step)
+    else:
+        for mode in gather_modes:
+            if mode == "ids":
+                g = sharding.IdGatherer(dist, dev, wire_dtype=wire, depth=2)
+                g.reserve(d_ids.numel(), d_io.numel(), torch.int32, d_io.dtype)      # agreed once, before the loop
+
+                def step_ids():
+                    tot = sp.EncodeDevice(d_text, d_offs, d_ids, d_io)[2]
+                    g(d_ids, tot, d_io)
+                    return tot
+                results["ids"] = timed(step_ids, g.wait)
+            else:
+                results["none"] = timed(encode_step)
+    head = "ids" if "ids" in results else ("none" if "none" in results else "n/a")
+    dt, total = results[head]
+    # a second, profiled loop for the per-kernel numbers (HIP events around every encode launch)
     sp.SetProfiling(True)
     prof = []
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
     for _ in range(args.steps):
-        total = step()
+        encode_step()
         prof.append(sp.LastProfile())
-    if gather is not None:
-        gather.wait()
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
     sp.SetProfiling(False)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
         tot_t = torch.tensor([float(len(text)), float(total)], dtype=torch.float64, device=dev)
         dist.all_reduce(tot_t)
         job_bytes, job_ids = float(tot_t[0].item()), float(tot_t[1].item())
@@ -185,18 +279,24 @@ def main():
 
     if rank == 0:
         ms = dt / args.steps * 1e3
-        # dominant kernel = the length class with the largest summed kernel time
+        # dominant kernel = the slot with the largest summed kernel time
         ncls = len(prof[0]["classes"])
         k_ms = [sum(p["classes"][c]["kernel_ms"] for p in prof) / len(prof) for c in range(ncls)]
         dom = int(np.argmax(k_ms))
         cls = prof[-1]["classes"][dom]
         achieved = cls["bytes"] / (k_ms[dom] * 1e-3) / 1e9 if k_ms[dom] > 0 else 0.0
-        traffic = None
+        traffic, traffic_note = None, "no PMC pass on record for this model / size / kernel"
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         kname = cls["kernel"]
+        sha = kernel_sources_sha()
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get("%s:%d:%s" % (args.model, args.sentences, kname))
+                rec = json.load(f).get("%s:%d:%s" % (args.model, args.sentences, kname))
+            if isinstance(rec, dict):
+                if rec.get("src_sha") == sha:
+                    traffic, traffic_note = rec.get("bytes"), rec.get("note", "profiles/pmc_traffic.json, made from these kernel sources")
+                else:
+                    traffic_note = "profiles/pmc_traffic.json is from other kernel sources (%s, now %s): not used" % (rec.get("src_sha"), sha)
         out = {
             "metric": "sentences/sec EncodeBatch, %s %s, MI355X" % ("250k" if c5 else "32k",
                                                                      "unigram" if sp.model_type() == 1 else "bpe"),
@@ -210,20 +310,54 @@ def main():
             "gb_text_per_s": job_bytes * args.steps / dt / 1e9,
             "config": {"workload": "configs[%d]: %s model, %d synthetic %s sentences per GPU, mean %.1f B, "
                                    "%s, resident in HBM"
-                                   % (4 if c5 else (1 if sp.model_type() == 1 else 2), args.model, n,
+                                   % (4 if c5 else ((1 if world == 1 else 3) if sp.model_type() == 1 else 2), args.model, n,
                                       "mixed-script power-law [16, 4096] B" if c5 else "ASCII", len(text) / n,
                                       "in generator order (not length-bucketed)" if args.unsorted else "length-bucketed"),
                        "model": args.model, "sentences_per_gpu": n, "ids_per_sentence": job_ids / (world * n),
-                       "gather": ("%s (%s on the wire)" % (args.gather, "int16" if wire is not None else "int32")
-                                  if args.gather == "ids" else args.gather) if world > 1 else "n/a",
-                       "sharding": "dp%d by sentence" % world},
+                       "gather": ("%s (%s on the wire, capacities agreed once, 2 gathers in flight, %s CUs left to RCCL)"
+                                  % (head, "int16" if wire is not None else "int32", os.environ.get("SPMX_RESERVE_CUS", "0"))
+                                  if head == "ids" else head) if world > 1 else "n/a",
+                       "sharding": "dp%d by sentence" % world,
+                       "timed_loop": "profiling off; roofline.* comes from a second loop of the same steps with HIP events on"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                         "kernel_sources_sha": sha, "kernel": kname,
                          "kernel_ms": k_ms[dom], "algorithmic_bytes_per_launch": cls["bytes"],
                          "sentences_per_launch": cls["sentences"],
                          "all_kernels_ms": {prof[-1]["classes"][c]["kernel"]: round(k_ms[c], 4)
-                                            for c in range(ncls) if prof[-1]["classes"][c]["kernel"]}, "phase_cycles": cls.get("phase_cycles"), "pipeline_ms": sum(p["total_ms"] for p in prof) / len(prof)},
+                                            for c in range(ncls) if prof[-1]["classes"][c]["kernel"]},
+                         "phase_cycles": cls.get("phase_cycles"), "path": prof[-1]["path"],
+                         "pipeline_ms": sum(p["total_ms"] for p in prof) / len(prof)},
         }
+        if world > 1:
+            for mode, (mdt, _) in results.items():
+                out["value_gather_%s" % mode] = world * n * args.steps / mdt
+                out["ms_per_step_gather_%s" % mode] = mdt / args.steps * 1e3
+        io_h = None
+        if second is not None:
+            name, t2, o2 = second
+            sp2 = SentencePieceProcessor(model_proto=model_blob(name), device=local)
+            dt2_text = torch.from_numpy(t2).to(dev)
+            dt2_offs = torch.from_numpy(o2.view(np.int64)).to(dev)
+            i2, io2, tot2 = sp2.EncodeDevice(dt2_text, dt2_offs)
+            i2 = torch.empty(int(tot2) + 64, dtype=torch.int32, device=dev)
+            for _ in range(args.warmup):
+                sp2.EncodeDevice(dt2_text, dt2_offs, i2, io2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                sp2.EncodeDevice(dt2_text, dt2_offs, i2, io2)
+            torch.cuda.synchronize()
+            d2 = time.perf_counter() - t0
+            sp2.SetProfiling(True)
+            sp2.EncodeDevice(dt2_text, dt2_offs, i2, io2)
+            p2 = sp2.LastProfile()
+            out["long_piece_model"] = {"model": name, "value": (len(o2) - 1) * args.steps / d2, "unit": "sentences/s",
+                                       "ms_per_step": d2 / args.steps * 1e3, "mean_bytes": len(t2) / (len(o2) - 1),
+                                       "kernel": p2["classes"][0]["kernel"], "kernel_ms": p2["classes"][0]["kernel_ms"],
+                                       "vs_headline": ((len(o2) - 1) * args.steps / d2) / out["value"],
+                                       "what": "the C2 recipe with words of up to 16 letters: longest piece 17 bytes, score ring of 18 entries"}
+            del sp2, dt2_text, dt2_offs, i2, io2
         if world == 1 and not args.no_cpu_baseline:
             io_h = d_io.cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(text, offs, blob, np.diff(io_h), d_ids[:int(io_h[-1])].cpu().numpy(), io_h)

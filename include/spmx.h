@@ -108,7 +108,7 @@ int spmx_encode_batch_device_ex(spmx_handle *h, const void *d_text, uint64_t tex
                                 uint64_t n, int32_t *d_ids, uint64_t ids_capacity, uint64_t *d_id_offsets,
                                 uint8_t *d_status, void *stream, uint64_t *total_ids, uint64_t *n_failed);
 
-/* Host-buffer form: copies text to the GPU, encodes, copies ids back.  Big batches (from 2^20 sentences) run as a
+/* Host-buffer form: copies text to the GPU, encodes, copies ids back.  Big batches (from 2^19 sentences) run as a
  * chunk pipeline on several host threads: staging copy, H2D, kernels and D2H of different chunks overlap.
  * *ids (total ids) and *id_offsets (n + 1) are allocated by the library and
  * released with spmx_free(). */
@@ -122,6 +122,11 @@ int spmx_encode_batch_ex(spmx_handle *h, const char *text, const uint64_t *offse
 typedef struct spmx_view { const char *data; uint64_t len; } spmx_view;
 int spmx_encode_batch_views(spmx_handle *h, const spmx_view *views, uint64_t n, int32_t **ids, uint64_t **id_offsets,
                             uint8_t **status, uint64_t *n_failed);
+/* One batch over several GPUs of the node from ONE process: handles[g] = the same model on GPU g.  The chunks of the
+ * batch go round-robin over the GPUs (several in flight on each) and all land in ONE output CSR; no collective (the
+ * multi-process form with an RCCL all-gather of the ids is sentencepiece_amd/sharding.py). */
+int spmx_encode_batch_multi(spmx_handle *const *handles, int n_handles, const char *text, const uint64_t *offsets, uint64_t n,
+                            int32_t **ids, uint64_t **id_offsets, uint8_t **status, uint64_t *n_failed);
 void spmx_free(void *p);
 
 /* Single sentence, caller-provided buffer (Encode(input, &ids)): returns the sentence's own Status, as the

@@ -174,6 +174,29 @@ class SentencePieceProcessor {
     spmx_free(io);
     return util::Status();
   }
+  // One batch over several GPUs of the node: procs[g] holds the same model on GPU g (constructed with that device
+  // ordinal).  The library deals the batch's chunks round-robin over the GPUs and every GPU writes its ids into the one
+  // CSR returned here (spmx_encode_batch_multi): the single-process form of the sharded encode.
+  static util::Status EncodeBatchSharded(const std::vector<const SentencePieceProcessor *> &procs, const char *text,
+                                         const uint64_t *offsets, uint64_t n, std::vector<int32_t> *ids,
+                                         std::vector<uint64_t> *id_offsets) {
+    if (procs.empty() || !procs[0] || !procs[0]->h_) return util::Status(util::StatusCode::kInternal, "Model is not initialized.");
+    if (!ids || !id_offsets) return util::Status(util::StatusCode::kInternal, "output container is null");
+    std::vector<spmx_handle *> hs;
+    for (const SentencePieceProcessor *p : procs) {
+      if (!p || !p->h_) return util::Status(util::StatusCode::kInternal, "Model is not initialized.");
+      hs.push_back(p->h_);
+    }
+    int32_t *out = nullptr;
+    uint64_t *offs = nullptr;
+    const int rc = spmx_encode_batch_multi(hs.data(), static_cast<int>(hs.size()), text, offsets, n, &out, &offs, nullptr, nullptr);
+    if (rc != 0) return procs[0]->FromHandle(rc);
+    id_offsets->assign(offs, offs + n + 1);
+    ids->assign(out, out + offs[n]);
+    spmx_free(out);
+    spmx_free(offs);
+    return util::Status();
+  }
   // Device-resident form (HIP pointers, see spmx_encode_batch_device).
   util::Status EncodeBatchDevice(const void *d_text, uint64_t text_bytes, const uint64_t *d_offsets, uint64_t n,
                                  int32_t *d_ids, uint64_t ids_capacity, uint64_t *d_id_offsets, void *stream,

@@ -33,7 +33,7 @@ def main():
     sp = SentencePieceProcessor(model_file=mpath)
     lib = _capi.lib()
     text, offs = synth.ascii_corpus(n, seed=20250227)
-    out = {"sentences": n, "model": model, "text_mb": len(text) / 1e6, "host_threads": int(os.environ.get("SPMX_HOST_THREADS", "8"))}
+    out = {"sentences": n, "model": model, "text_mb": len(text) / 1e6, "host_threads": int(os.environ.get("SPMX_HOST_THREADS", "0")), "host_chunk": int(os.environ.get("SPMX_HOST_CHUNK", "0"))}
 
     def timed(fn, reps=4):
         best = None
@@ -55,6 +55,9 @@ def main():
         return total
     dt, total = timed(flat)
     out["flat"] = {"ms": dt * 1e3, "sentences_per_s": n / dt, "gb_text_per_s": len(text) / dt / 1e9, "ids": total}
+    if os.environ.get("HOST_RATE_ONLY") == "flat":
+        print(json.dumps(out))
+        return
 
     # the Python list form on a slice
     m = min(n, 1_000_000)

@@ -223,11 +223,13 @@ struct spmx_handle {
   int tile_waves_override = 0;   // SPMX_TILE_WAVES: cap on wavefronts per workgroup of the streaming kernels
   uint32_t lane_general_min_lanes = 0;   // SPMX_LANE_GENERAL_MIN_LANES (0: per class)
   uint32_t sub_buckets = kSubBuckets;    // SPMX_SUB_BUCKETS: length sub-buckets per class in the classify sort (1..64)
-  int host_threads = 8;          // SPMX_HOST_THREADS: workers of the pipelined host form (chunks in flight)
-  uint64_t host_chunk = 1u << 19; // SPMX_HOST_CHUNK: sentences per chunk of the pipelined host form
+  int host_threads = 24;         // SPMX_HOST_THREADS: workers of the pipelined host form (chunks in flight)
+  uint64_t host_chunk = 0;       // SPMX_HOST_CHUNK: sentences per chunk of the pipelined host form (0: by batch size)
+  int reserve_cus = 0;           // SPMX_RESERVE_CUS: CUs the persistent encode grids leave free (an RCCL gather in flight)
   uint32_t ring_override = 0;    // SPMX_FORCE_RING: score-ring entries (must exceed the longest piece)
   uint64_t stream_scratch_limit = 16ull << 30;   // SPMX_STREAM_SCRATCH_MB: cap on the streaming kernels' HBM scratch
-  bool tight_tcap = false;       // SPMX_TIGHT_TCAP=1: text columns of 1.125 x the class's raw size (A/B: scratch footprint)
+  bool wide_tcap = false;        // SPMX_WIDE_TCAP=1: text columns of the class's full normalized capacity (default: 1.25 x
+                                 // its raw size -- ASCII and CJK text do not grow; what does takes the overflow launch)
   uint32_t main_max_raw = kStreamMainMaxRaw;     // SPMX_MAIN_MAX_RAW: classes up to this size share the main launch
   LengthClass classes[kNumClasses];              // SPMX_CLASSES="r:n,r:n,...": the class table (tests shrink it)
 };
@@ -400,7 +402,7 @@ StreamPlan PlanStream(const spmx_handle *h, EncodeArgs *a, const uint32_t *count
   if (h->tile_waves_override > 0 && h->tile_waves_override < waves) waves = h->tile_waves_override;
   uint64_t total = 0;
   for (int c = c_lo; c < c_hi; ++c) total += counts[c];
-  uint64_t grid = static_cast<uint64_t>(h->n_cu);
+  uint64_t grid = static_cast<uint64_t>(h->n_cu - h->reserve_cus);
   if (grid * waves > total) grid = (total + waves - 1) / waves;
   if (grid < 1) grid = 1;
   // the slab of a wavefront must hold one lane of the largest class present: fewer wavefronts if the limit says so
@@ -572,7 +574,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       } else {
         // the last class of the table takes every longer sentence too: those go straight to the overflow list
         sp = PlanStream(h, &la, counts, c_lo, c_hi, ncls, rc2,
-                        [&](int c) { return esc3 ? 2u * cls[c].rcap + 64u : (h->tight_tcap ? cls[c].rcap + cls[c].rcap / 8u + 16u : cls[c].ncap); }, !fast_ok);
+                        [&](int c) { return esc3 ? 2u * cls[c].rcap + 64u : (h->wide_tcap ? cls[c].ncap : cls[c].rcap + cls[c].rcap / 4u + 16u); }, !fast_ok);
       }
       if (la.total_main == 0) return kOk;
       la.q = &ws->d_ctrl->q[qi];
@@ -975,7 +977,7 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_NO_FAST")) h->no_fast = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_STREAM")) h->no_stream = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_WAVE")) h->no_wave = e[0] == '1';
-    if (const char *e = getenv("SPMX_TIGHT_TCAP")) h->tight_tcap = e[0] == '1';
+    if (const char *e = getenv("SPMX_WIDE_TCAP")) h->wide_tcap = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_LANE_GENERAL")) h->no_lane_general = e[0] == '1';
     if (const char *e = getenv("SPMX_SUB_BUCKETS")) {
       const int v = atoi(e);
@@ -985,6 +987,7 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_STREAM_SCRATCH_MB")) h->stream_scratch_limit = static_cast<uint64_t>(atoll(e)) << 20;
     if (const char *e = getenv("SPMX_TILE_WAVES")) h->tile_waves_override = atoi(e);
     if (const char *e = getenv("SPMX_MAIN_MAX_RAW")) h->main_max_raw = static_cast<uint32_t>(atoll(e));
+    if (const char *e = getenv("SPMX_RESERVE_CUS")) { const int v = atoi(e); if (v >= 0 && v < h->n_cu) h->reserve_cus = v; }
     if (const char *e = getenv("SPMX_HOST_THREADS")) { const int v = atoi(e); h->host_threads = v < 1 ? 1 : (v > 64 ? 64 : v); }
     if (const char *e = getenv("SPMX_HOST_CHUNK")) { const long long v = atoll(e); if (v >= 1024) h->host_chunk = static_cast<uint64_t>(v); }
     if (const char *e = getenv("SPMX_FORCE_RING")) { const int v = atoi(e); if (v >= 16 && v <= 122) h->ring_override = static_cast<uint32_t>(v); }
@@ -1275,11 +1278,27 @@ namespace {
 // waits for its predecessor's count (not for its copies) before it issues the D2H.
 // `views` (optional, instead of text / offsets): n (pointer, length) pairs, gathered the same way.
 struct spmx_view_ { const char *data; uint64_t len; };
-int EncodeBatchPipelined(spmx_handle *h, const char *text, const uint64_t *offsets, const spmx_view_ *views, uint64_t n,
-                         int32_t **ids, uint64_t **id_offsets, uint8_t **status, uint64_t *n_failed) {
-  const uint64_t chunk = h->host_chunk;
+// sentences per chunk: about eight chunks per GPU, between 128 k and 1 M sentences (measured on 10 M C2 sentences: 1 M
+// chunks on 24 workers 52 ms, 256 k chunks 57 - 120 ms: the fixed cost of a call's launches and its two host syncs)
+uint64_t HostChunk(const spmx_handle *h, uint64_t n, int n_h) {
+  if (h->host_chunk) return h->host_chunk;
+  uint64_t c = (n + 8ull * n_h - 1) / (8ull * n_h);
+  if (c < (128u << 10)) c = 128u << 10;
+  if (c > (1u << 20)) c = 1u << 20;
+  return c;
+}
+// the pipeline pays from a few chunks on
+bool HostPipelined(const spmx_handle *h, uint64_t n) { return n >= (h->host_chunk ? 2 * h->host_chunk : (512u << 10)); }
+
+// `hs`: one handle per GPU of the node (the same model on each): worker w runs on hs[w % n_h], so the chunks are dealt
+// round-robin over the GPUs and all of them fill ONE output CSR -- the single-process form of the multi-GPU encode
+// (no collective: every GPU copies its chunks' ids to their place in the host array).
+int EncodeBatchPipelined(spmx_handle *const *hs, int n_h, const char *text, const uint64_t *offsets, const spmx_view_ *views,
+                         uint64_t n, int32_t **ids, uint64_t **id_offsets, uint8_t **status, uint64_t *n_failed) {
+  spmx_handle *h = hs[0];
+  const uint64_t chunk = HostChunk(h, n, n_h);
   const uint64_t n_chunks = (n + chunk - 1) / chunk;
-  int T = h->host_threads;
+  int T = h->host_threads * n_h;
   if (static_cast<uint64_t>(T) > n_chunks) T = static_cast<int>(n_chunks);
   // byte offset of every chunk's first sentence
   std::vector<uint64_t> cbeg(n_chunks + 1, 0);
@@ -1311,6 +1330,7 @@ int EncodeBatchPipelined(spmx_handle *h, const char *text, const uint64_t *offse
   auto worker = [&](int w) {
     int rc = kOk;
     std::string err;
+    spmx_handle *h = hs[w % n_h];                     // (shadows the first handle: this worker's GPU)
     auto body = [&]() -> int {
       HIP_OR_RETURN(h, hipSetDevice(h->device));
       Lease L(h);
@@ -1399,11 +1419,36 @@ int EncodeBatchPipelined(spmx_handle *h, const char *text, const uint64_t *offse
 int spmx_encode_batch_ex(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
                          uint64_t **id_offsets, uint8_t **status, uint64_t *n_failed) {
   return Guard(h, [&]() -> int {
-    if (h && ids && id_offsets && offsets && n >= 2 * h->host_chunk) {     // big batches: the chunk pipeline
+    if (h && ids && id_offsets && offsets && HostPipelined(h, n)) {     // big batches: the chunk pipeline
       *ids = nullptr; *id_offsets = nullptr;
       if (status) *status = nullptr;
       if (n_failed) *n_failed = 0;
-      const int rc = EncodeBatchPipelined(h, text, offsets, nullptr, n, ids, id_offsets, status, n_failed);
+      const int rc = EncodeBatchPipelined(&h, 1, text, offsets, nullptr, n, ids, id_offsets, status, n_failed);
+      if (rc != -1) return rc;
+    }
+    return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, status, n_failed, nullptr, nullptr);
+  });
+}
+
+/* One batch over several GPUs of the node from ONE process: handles[g] holds the same model on GPU g; the batch is cut
+ * into chunks that the GPUs take round-robin (several in flight per GPU), and every GPU copies its chunks' ids to their
+ * place in the one output CSR.  No collective is involved: the host array is the meeting point. */
+int spmx_encode_batch_multi(spmx_handle *const *handles, int n_handles, const char *text, const uint64_t *offsets, uint64_t n,
+                            int32_t **ids, uint64_t **id_offsets, uint8_t **status, uint64_t *n_failed) {
+  if (!handles || n_handles < 1 || !handles[0]) return kInvalidArgument;
+  spmx_handle *h = handles[0];
+  if (!ids || !id_offsets) return Fail(h, kInternal, "output container is null");
+  for (int g = 0; g < n_handles; ++g)
+    if (!handles[g] || handles[g]->model.pieces.size() != h->model.pieces.size() || handles[g]->dev.flags != h->dev.flags)
+      return Fail(h, kInvalidArgument, "the handles do not hold the same model");
+  return Guard(h, [&]() -> int {
+    *ids = nullptr; *id_offsets = nullptr;
+    if (status) *status = nullptr;
+    if (n_failed) *n_failed = 0;
+    if (n && !offsets) return Fail(h, kInvalidArgument, "null offsets");
+    if (n >= 2) {
+      // chunks small enough that every GPU gets a few
+      const int rc = EncodeBatchPipelined(handles, n_handles, text, offsets, nullptr, n, ids, id_offsets, status, n_failed);
       if (rc != -1) return rc;
     }
     return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, status, n_failed, nullptr, nullptr);
@@ -1421,8 +1466,8 @@ int spmx_encode_batch_views(spmx_handle *h, const spmx_view *views, uint64_t n, 
     if (status) *status = nullptr;
     if (n_failed) *n_failed = 0;
     if (n && !views) return Fail(h, kInvalidArgument, "null views");
-    if (n >= 2 * h->host_chunk) {
-      const int rc = EncodeBatchPipelined(h, nullptr, nullptr, reinterpret_cast<const spmx_view_ *>(views), n, ids, id_offsets, status, n_failed);
+    if (HostPipelined(h, n)) {
+      const int rc = EncodeBatchPipelined(&h, 1, nullptr, nullptr, reinterpret_cast<const spmx_view_ *>(views), n, ids, id_offsets, status, n_failed);
       if (rc != -1) return rc;
     }
     std::string text;                                     // small batches (and the fallback): pack, then the plain form

@@ -29,14 +29,19 @@ def shard_bounds(offsets, world):
 
 
 class IdGatherer:
-    """All-gatherv of (ids[:total], id_offsets) from every rank.
+    """All-gatherv of (ids[:total], id_offsets) from every rank, asynchronous and free of host synchronisation in
+    the steady state.
 
-    Call ``g(ids, total, id_offsets)`` after each encode: the collective is
-    issued asynchronously; ``wait()`` blocks the current stream (and, on CPU,
-    the host) until the last one has finished.  ``result()`` returns the
-    per-rank ``(ids, id_offsets)`` views of the last gather."""
+    ``reserve(ids_capacity, offsets_capacity)`` -- collective, ONCE (and again only if a rank's buffers grow): the ranks
+    agree on the padded sizes by one MAX all-reduce.  A rank passes what its output buffers hold: an encode can never
+    produce more ids than fit its output buffer, so no later batch can outgrow the agreement.
+    ``g(ids, total, id_offsets)`` after each encode: a staged copy on the current stream, then the collective on the
+    process group's own stream (``async_op``); ``depth`` gathers may be in flight (double buffering), so batch k's
+    gather overlaps the kernels of batches k + 1 and k + 2.  Nothing here reads a device value on the host.
+    ``wait()`` makes the current stream wait for everything in flight; ``result()`` returns the per-rank
+    ``(ids, id_offsets)`` views of the last gather (it is the consumer that synchronises, not the gatherer)."""
 
-    def __init__(self, dist, device, group=None, wire_dtype=None):
+    def __init__(self, dist, device, group=None, wire_dtype=None, depth=2):
         """``wire_dtype``: dtype the ids travel in (default: as given).  xGMI is point-to-point, so a ring
         all-gather is bound by one link; a vocabulary below 32768 fits ``torch.int16`` and halves the payload.
         ``result()`` widens back to the dtype of the ids passed in."""
@@ -45,10 +50,11 @@ class IdGatherer:
         self._dtype = None
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self._work = []
+        self.depth = max(1, int(depth))
         self._cap = self._ocap = 0
-        self._out = self._oout = self._tot = None
-        self._pad = self._opad = None
+        self._slots = []          # per slot: dict(pad, out, opad, oout, tot_in, tot, n_in, n, work)
+        self._k = 0               # gathers issued
+        self._last = None
 
     def _all_gather(self, out, inp):
         if out.dtype == torch.int16:      # no 16-bit integer type in NCCL / gloo: an all-gather only moves bytes
@@ -57,55 +63,71 @@ class IdGatherer:
             return self.dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
         return self.dist.all_gather(list(out.view(self.world, -1).unbind(0)), inp, group=self.group, async_op=True)
 
-    def _agree(self, value):
-        t = torch.tensor([int(value)], dtype=torch.int64, device=self.device)
+    def reserve(self, ids_capacity, offsets_capacity=0, ids_dtype=torch.int32, offsets_dtype=torch.int64):
+        """Collective.  Agrees the padded per-rank sizes (MAX over the ranks) and allocates the slots."""
+        self.wait()
+        t = torch.tensor([int(ids_capacity), int(offsets_capacity)], dtype=torch.int64, device=self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
-        return int(t.item())
+        cap, ocap = (int(v) for v in t.cpu().tolist())
+        if cap <= self._cap and ocap <= self._ocap and self._slots:
+            return
+        self._cap, self._ocap = max(cap, self._cap, 1), max(ocap, self._ocap)
+        wire = self.wire or ids_dtype
+        self._slots = []
+        for _ in range(self.depth):
+            sl = dict(pad=torch.zeros(self._cap, dtype=wire, device=self.device),
+                      out=torch.empty(self.world * self._cap, dtype=wire, device=self.device),
+                      tot_in=torch.zeros(1, dtype=torch.int64, device=self.device),
+                      tot=torch.zeros(self.world, dtype=torch.int64, device=self.device),
+                      n_in=torch.zeros(1, dtype=torch.int64, device=self.device),
+                      n=torch.zeros(self.world, dtype=torch.int64, device=self.device), work=[], has_offs=False)
+            if self._ocap:
+                sl["opad"] = torch.zeros(self._ocap, dtype=offsets_dtype, device=self.device)
+                sl["oout"] = torch.empty(self.world * self._ocap, dtype=offsets_dtype, device=self.device)
+            self._slots.append(sl)
 
     def __call__(self, ids, total, id_offsets=None):
-        self.wait()
-        # capacities are agreed once and only grow (a MAX all-reduce, off the steady-state path)
-        need = self._agree(max(int(total), 1))
+        total = int(total)
+        need_o = id_offsets.numel() if id_offsets is not None else 0
+        if not self._slots or total > self._cap or need_o > self._ocap:
+            # first use (or a caller that grew its buffers without reserve()): agree now -- collective, so every rank
+            # must be in the same situation; reserve() up front keeps this off the steady-state path
+            self.reserve(max(total, self._cap), max(need_o, self._ocap), ids.dtype,
+                         id_offsets.dtype if id_offsets is not None else torch.int64)
         self._dtype = ids.dtype
-        wire = self.wire or ids.dtype
-        if need > self._cap:
-            self._cap = need + need // 8
-            self._out = torch.empty(self.world * self._cap, dtype=wire, device=self.device)
-            self._pad = torch.empty(self._cap, dtype=wire, device=self.device)
-        # staged copy: ranks hold different totals (padding), and the caller's
-        # buffer is free for the next batch while the collective is in flight
-        self._pad[:int(total)].copy_(ids[:int(total)])
-        src = self._pad
-        self._tot_in = torch.tensor([int(total)], dtype=torch.int64, device=self.device)
-        self._tot = torch.empty(self.world, dtype=torch.int64, device=self.device)
-        self._work = [self._all_gather(self._tot, self._tot_in), self._all_gather(self._out, src[:self._cap])]
+        sl = self._slots[self._k % self.depth]
+        for w in sl["work"]:          # the gather issued `depth` calls ago
+            w.wait()
+        # staged copy: ranks hold different totals (padding), and the caller's buffer is free for the next batch while
+        # the collective is in flight
+        sl["pad"][:total].copy_(ids[:total])
+        sl["tot_in"].fill_(total)
+        sl["work"] = [self._all_gather(sl["tot"], sl["tot_in"]), self._all_gather(sl["out"], sl["pad"])]
+        sl["has_offs"] = id_offsets is not None
         if id_offsets is not None:
-            oneed = self._agree(id_offsets.numel())
-            if oneed > self._ocap:
-                self._ocap = oneed
-                self._oout = torch.empty(self.world * oneed, dtype=id_offsets.dtype, device=self.device)
-                self._opad = torch.zeros(oneed, dtype=id_offsets.dtype, device=self.device)
-            self._opad[:id_offsets.numel()].copy_(id_offsets)
-            osrc = self._opad
-            self._n_in = torch.tensor([id_offsets.numel() - 1], dtype=torch.int64, device=self.device)
-            self._n = torch.empty(self.world, dtype=torch.int64, device=self.device)
-            self._work += [self._all_gather(self._n, self._n_in), self._all_gather(self._oout, osrc)]
-        else:
-            self._n = None
+            sl["opad"][:need_o].copy_(id_offsets)
+            sl["n_in"].fill_(need_o - 1)
+            sl["work"] += [self._all_gather(sl["n"], sl["n_in"]), self._all_gather(sl["oout"], sl["opad"])]
+        self._last = sl
+        self._k += 1
 
     def wait(self):
-        for w in self._work:
-            w.wait()
-        self._work = []
+        for sl in self._slots:
+            for w in sl["work"]:
+                w.wait()
+            sl["work"] = []
 
     def result(self):
-        self.wait()
-        tot = self._tot.cpu().tolist()
-        ids = [self._out[r * self._cap: r * self._cap + tot[r]].to(self._dtype) for r in range(self.world)]
+        sl = self._last
+        for w in sl["work"]:
+            w.wait()
+        sl["work"] = []
+        tot = sl["tot"].cpu().tolist()
+        ids = [sl["out"][r * self._cap: r * self._cap + tot[r]].to(self._dtype) for r in range(self.world)]
         offs = None
-        if self._n is not None:
-            ns = self._n.cpu().tolist()
-            offs = [self._oout[r * self._ocap: r * self._ocap + ns[r] + 1] for r in range(self.world)]
+        if sl["has_offs"]:
+            ns = sl["n"].cpu().tolist()
+            offs = [sl["oout"][r * self._ocap: r * self._ocap + ns[r] + 1] for r in range(self.world)]
         return ids, offs
 
 
@@ -121,7 +143,9 @@ def encode_sharded(encode_fn, text, offsets, dist, device, group=None):
     b = shard_bounds(offs_np, world)
     lo, hi = int(b[rank]), int(b[rank + 1])
     o = torch.as_tensor(offs_np[lo:hi + 1].astype(np.int64) - int(offs_np[lo]), device=device)
-    t = torch.as_tensor(text, device=device)[int(offs_np[lo]):int(offs_np[hi])]
+    # the shard as a tensor of its own (a slice would hand the kernels a pointer at an arbitrary offset; they cope --
+    # their loads are aligned on the absolute address -- but a fresh tensor is also what a real caller has)
+    t = torch.as_tensor(text, device=device)[int(offs_np[lo]):int(offs_np[hi])].clone()
     ids, io, total = encode_fn(t, o)
     g = IdGatherer(dist, device, group)
     g(ids, total, io)

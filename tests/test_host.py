@@ -141,3 +141,27 @@ def test_gpu_chunk_pipeline(model, oracle):
     d_ids, d_io, total = sp.EncodeDevice(d_text, d_offs)
     np.testing.assert_array_equal(d_io.cpu().numpy().astype(np.uint64), io)
     np.testing.assert_array_equal(d_ids[:total].cpu().numpy(), ids)
+
+
+def test_emu_encode_batch_multi(emu, oracle, corpora):
+    """spmx_encode_batch_multi: three handles (three GPUs of a node; here three emulated devices) share the chunks of one
+    batch and fill one CSR."""
+    blob = fixtures.model_blob("uni32k")
+    env = {"SPMX_HOST_CHUNK": "1024", "SPMX_HOST_THREADS": "2"}
+    hs = [emu.load(blob, classes=None, env=env) for _ in range(3)]
+    text, offs = fixtures.head(*corpora["synth20k"], 9000)
+    text, offs = np.ascontiguousarray(text), np.ascontiguousarray(offs, dtype=np.uint64)
+    arr = (C.c_void_p * 3)(*[h.sp._h for h in hs])
+    p_ids, p_off, p_st = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    nf = C.c_uint64(0)
+    n = len(offs) - 1
+    lib = hs[0].lib
+    rc = lib.spmx_encode_batch_multi(arr, 3, text.ctypes.data, offs.ctypes.data, n, C.byref(p_ids), C.byref(p_off), C.byref(p_st), C.byref(nf))
+    assert rc == 0, lib.spmx_last_error(None)
+    io = np.ctypeslib.as_array(C.cast(p_off, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+    ids = np.ctypeslib.as_array(C.cast(p_ids, C.POINTER(C.c_int32)), shape=(int(io[n]),)).copy()
+    for p in (p_ids, p_off, p_st):
+        lib.spmx_free(p)
+    oids, oio = oracle.load(blob).encode_batch(text, offs)
+    np.testing.assert_array_equal(io, oio)
+    np.testing.assert_array_equal(ids, oids)

@@ -39,23 +39,29 @@ def _worker(rank, world, port, model, corpus_name, n_sent, out_dir):
         ids, io = sharding.encode_sharded(encode_fn, torch.from_numpy(text.copy()), offs, dist, torch.device("cpu"))
         np.save(os.path.join(out_dir, "ids%d.npy" % rank), ids.numpy())
         np.save(os.path.join(out_dir, "io%d.npy" % rank), io.numpy())
-        # steady-state gatherer: two batches of different size through one IdGatherer
-        g = sharding.IdGatherer(dist, torch.device("cpu"), wire_dtype=torch.int16)
-        for k in (3 + rank, 7 - rank):
+        # steady-state gatherer: capacities agreed once (reserve), then batches of different size -- an empty one among
+        # them -- through one IdGatherer, two gathers in flight
+        g = sharding.IdGatherer(dist, torch.device("cpu"), wire_dtype=torch.int16, depth=2)
+        g.reserve(16, 2)
+        sizes = lambda r, step: (3 + r, 9 - 2 * r if 9 - 2 * r > 0 else 0, 0 if r == 1 else 5)[step]      # noqa: E731
+        for step in range(3):
+            k = sizes(rank, step)
             part = torch.arange(k, dtype=torch.int32) + 100 * rank
             g(part, k, torch.tensor([0, k], dtype=torch.int64))
             got, goffs = g.result()
             for r in range(world):
-                kk = (3 + r) if k == 3 + rank else (7 - r)
+                kk = sizes(r, step)
                 assert got[r].tolist() == [100 * r + i for i in range(kk)] and got[r].dtype == torch.int32
                 assert goffs[r].tolist() == [0, kk]
+        g.wait()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("model,corpus,n", [("test_model", "botchan", 700), ("bpe1k", "edge", 66)])
-def test_two_rank_gloo(model, corpus, n, tmp_path, oracle, corpora):
-    world = 2
+@pytest.mark.parametrize("model,corpus,n,world", [("test_model", "botchan", 700, 2), ("bpe1k", "edge", 66, 2),
+                                                   ("test_model", "botchan", 301, 4), ("bpe1k", "edge", 3, 4)])
+def test_gloo_ranks(model, corpus, n, world, tmp_path, oracle, corpora):
+    """world 2 and 4; uneven shards (301 sentences over 4 ranks by bytes) and empty ones (3 sentences over 4 ranks)."""
     mp.spawn(_worker, args=(world, _free_port(), model, corpus, n, str(tmp_path)), nprocs=world, join=True)
     text, offs = fixtures.head(*corpora[corpus], n)
     ids, io = oracle.load(fixtures.model_blob(model)).encode_batch(text, offs)
