@@ -193,6 +193,25 @@ int spmx_normalize_batch(spmx_handle *h, const char *text, const uint64_t *offse
 int spmx_nbest_encode_batch(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int nbest_size,
                             int32_t **ids, uint64_t **id_offsets, float **scores, uint64_t **result_offsets);
 
+/* ---- sampling and the original encoder -----------------------------------
+ * SampleEncode(input, nbest_size, alpha, std::vector<int>*) (src/sentencepiece_processor.h:333-334, .cc:678-720) per
+ * sentence, the subword-regularization entry:
+ *   nbest_size < 0      unigram: one segmentation drawn from the lattice, Lattice::Sample(alpha) (forward filtering /
+ *                       backward sampling, src/unigram_model.cc:511-542); BPE: BPE-dropout with merge-skip probability
+ *                       alpha (src/bpe_model.cc:131-156)
+ *   nbest_size 0 or 1   the plain encoder
+ *   nbest_size > 1      unigram: one of the nbest_size best, drawn with probability ~ exp(alpha * score) (:700-716)
+ * Draws come from generators keyed by (seed, sentence index) -- reproducible per call; the reference's thread-local
+ * mt19937 stream is not (and cannot be) reproduced, its own tests pin the DISTRIBUTION (unigram_model_test.cc:429-470,
+ * bpe_model_test.cc:252-295), as tests/test_sampling.py does.  alpha = 0 under BPE is bit-equal to Encode. */
+int spmx_sample_encode_batch(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int nbest_size,
+                             float alpha, uint64_t seed, int32_t **ids, uint64_t **id_offsets);
+/* The reference's ORIGINAL unigram encoder (EncoderVersion::kOriginal, src/unigram_model.cc:674-692): the lattice of
+ * Lattice::SetSentence / Model::PopulateNodes and Lattice::Viterbi (:161-198, all-float, first best left node wins)
+ * instead of EncodeOptimized.  Same ids except where float and double arithmetic break a tie differently. */
+int spmx_encode_batch_original(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
+                               uint64_t **id_offsets);
+
 /* ---- corpus packer ------------------------------------------------------
  * The caller-side step of the reference's spm_encode (src/spm_encode_main.cc:159-165: std::getline over the input
  * file, one Encode per line) on the device: a file image with '\n'-terminated lines -> the packed text (without

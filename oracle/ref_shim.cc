@@ -12,12 +12,15 @@
 #include <atomic>
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "builtin_pb/sentencepiece.pb.h"
 #include "sentencepiece_processor.h"
+#include "normalizer.h"
+#include "unigram_model.h"
 
 namespace {
 struct RefHandle {
@@ -313,6 +316,33 @@ int64_t spmref_nbest_encode(void *handle, const char *text, uint64_t len, int nb
   offs[nb.nbests_size()] = total;
   if (total > cap) return -static_cast<int64_t>(total) - 2;
   return nb.nbests_size();
+}
+
+// Switches a unigram model to EncoderVersion::kOriginal (unigram_model.h:176-186): a fresh unigram::Model over the
+// processor's own ModelProto, installed with SetModel (sentencepiece_processor.h:683).  -1 if the model is not unigram.
+int spmref_set_encoder_original(void *handle) {
+  auto *h = static_cast<RefHandle *>(handle);
+  const auto &mp = h->sp.model_proto();
+  if (mp.trainer_spec().model_type() != sentencepiece::TrainerSpec::UNIGRAM) return -1;
+  auto m = std::make_unique<sentencepiece::unigram::Model>(mp);
+  m->SetEncoderVersion(sentencepiece::unigram::Model::kOriginal);
+  // the normalizer points at the model's prefix matcher (sentencepiece_processor.cc Load): rebuild it on the new model
+  auto nz = std::make_unique<sentencepiece::normalizer::Normalizer>(mp.normalizer_spec(), mp.trainer_spec());
+  nz->SetPrefixMatcher(m->prefix_matcher());
+  h->sp.SetNormalizer(std::move(nz));
+  h->sp.SetModel(std::move(m));
+  return 0;
+}
+
+// SampleEncode(input, nbest_size, alpha, &ids) (sentencepiece_processor.h:333-334).  Returns the id count.
+int64_t spmref_sample_encode(void *handle, const char *text, uint64_t len, int nbest_size, float alpha, int32_t *ids,
+                             uint64_t cap) {
+  auto *h = static_cast<RefHandle *>(handle);
+  std::vector<int> v;
+  const auto st = h->sp.SampleEncode(absl::string_view(text, len), nbest_size, alpha, &v);
+  if (!st.ok()) { h->last_error = st.ToString(); return -1; }
+  for (size_t i = 0; i < v.size() && i < cap; ++i) ids[i] = v[i];
+  return static_cast<int64_t>(v.size());
 }
 
 // EncodeAsSerializedProto(input) per sentence (sentencepiece_processor.h:528-531): the serialized SentencePieceText

@@ -68,6 +68,9 @@ SYMBOLS = [
      [C.POINTER(_H), C.c_int, C.c_void_p, C.c_void_p, _U64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
       C.POINTER(C.c_void_p), C.POINTER(_U64)]),
     ("spmx_encode_file", C.c_int, [_H, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_U64), C.POINTER(_U64)]),
+    ("spmx_sample_encode_batch", C.c_int,
+     [_H, C.c_void_p, C.c_void_p, _U64, C.c_int, C.c_float, _U64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    ("spmx_encode_batch_original", C.c_int, [_H, C.c_void_p, C.c_void_p, _U64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     ("spmx_split_lines_device", C.c_int,
      [_H, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, C.POINTER(_U64), C.POINTER(_U64)]),
     ("spmx_set_profiling", C.c_int, [_H, C.c_int]),

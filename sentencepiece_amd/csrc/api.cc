@@ -23,6 +23,8 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
+#include <cmath>
 #include <condition_variable>
 #include <cstring>
 #include <fstream>
@@ -174,6 +176,8 @@ struct Workspace {
   DevBuf<int32_t> d_ids;
   PinBuf<uint8_t> h_text;       // pinned staging of the pipelined host form
   PinBuf<uint64_t> h_offs, h_id_offs;
+  float bpe_dropout = 0.f;      // set around a call by spmx_sample_encode_batch: BPE-dropout through the long form
+  uint64_t sample_seed = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[kNumSlots + 1][2] = {};   // per kernel slot + the whole call
   bool ev_ready = false;
@@ -510,7 +514,8 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
   const int wide = h->n_cu * 8;
   const bool is_bpe = h->model.model_type == kBpe;
   // streaming (lane-per-sentence) kernels: every unigram model; BPE models that can be segmented word by word
-  const bool bpe_stream = is_bpe && (h->dev.flags & kNfBpeWordwise) && !(h->dev.flags & kNfHasUnused) && !h->no_stream;
+  const bool dropout = is_bpe && ws->bpe_dropout > 0.f;      // BPE-dropout: every sentence takes the long form
+  const bool bpe_stream = is_bpe && (h->dev.flags & kNfBpeWordwise) && !(h->dev.flags & kNfHasUnused) && !h->no_stream && !dropout;
   const bool streaming = !is_bpe || bpe_stream;
   const bool fast_ok = StreamFastEligible(h->dev.flags) && !h->no_fast;
   const bool uds = (h->dev.flags & kNfHasUserDefined) != 0;
@@ -600,6 +605,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       la.tmp_off = ws->d_tmp_off.p; la.counts = ws->d_counts.p; la.sent_status = d_status; la.status = &ws->d_ctrl->status;
       la.side = &ws->d_ctrl->side; la.arena_tb = spans ? ws->d_arena_tb.p : nullptr;
       la.stack_cap = static_cast<uint32_t>(h->tables.max_piece_len) + 8u;
+      la.dropout = ws->bpe_dropout; la.seed = ws->sample_seed;
       la.pool_head = &ws->d_ctrl->pool_head;
       uint64_t want = 96ull * text_bytes / (n > count ? n / count : 1) + 4096ull * count + (1ull << 20);
       if (want > (4ull << 30)) want = 4ull << 30;
@@ -641,7 +647,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       // BPE, sentence-per-wave form (models that are not word-wise, or with UNUSED pieces): the staged classes; a
       // sentence whose normalized form overflows its class escalates to the next staged one, then to the long form
       int c_staged = 0;
-      while (c_staged < ncls && cls[c_staged].rcap <= kMaxStagedRaw && !h->no_wave) ++c_staged;
+      while (c_staged < ncls && cls[c_staged].rcap <= kMaxStagedRaw && !h->no_wave && !dropout) ++c_staged;
       bool first = true;
       for (int c = 0; c < c_staged; ++c) {
         EncodeArgs la = a;
@@ -1121,7 +1127,7 @@ namespace {
 // Host-buffer form of the batch encode, with (begin / end non-null) or without the spans.
 int EncodeBatchHost(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
                     uint64_t **id_offsets, uint8_t **status, uint64_t *n_failed, uint32_t **begin, uint32_t **end,
-                    uint32_t **nbegin = nullptr, uint32_t **nend = nullptr) {
+                    uint32_t **nbegin = nullptr, uint32_t **nend = nullptr, float bpe_dropout = 0.f, uint64_t seed = 0) {
   if (!h) return kInvalidArgument;
   const bool spans = begin != nullptr;
   if (!ids || !id_offsets || (spans && !end)) return Fail(h, kInternal, "output container is null");   // sentencepiece_processor.cc:367-370
@@ -1137,6 +1143,8 @@ int EncodeBatchHost(spmx_handle *h, const char *text, const uint64_t *offsets, u
   if (int rc = L.Ready(); rc != kOk) return rc;
   Workspace *ws = L.ws.get();
   hipStream_t st = ws->stream;
+  ws->bpe_dropout = bpe_dropout; ws->sample_seed = seed;
+  struct Reset { Workspace *w; ~Reset() { w->bpe_dropout = 0.f; w->sample_seed = 0; } } reset{ws};
   // everything the caller gets is malloc'd here and freed on any failure
   void *outs[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   auto drop = [&]() { for (void *&p : outs) { free(p); p = nullptr; } };
@@ -1506,18 +1514,22 @@ int spmx_encode_batch_spans_device(spmx_handle *h, const void *d_text, uint64_t 
   });
 }
 
-// NBestEncode (kernels_nbest.h), host-buffer form.
-int spmx_nbest_encode_batch(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int nbest_size,
-                            int32_t **ids, uint64_t **id_offsets, float **scores, uint64_t **result_offsets) {
-  if (!h) return kInvalidArgument;
+namespace {
+// The lattice kernels (kernels_nbest.h), host-buffer form.  mode 0: NBestEncode; 1: Lattice::Sample(inv_theta); 2: the
+// kOriginal encoder (Lattice::Viterbi).  Modes 1 and 2 give one result per sentence.
+int LatticeBatchHost(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int mode, int nbest_size,
+                     float inv_theta, uint64_t seed, int32_t **ids, uint64_t **id_offsets, float **scores,
+                     uint64_t **result_offsets) {
   if (!ids || !id_offsets || !scores || !result_offsets) return Fail(h, kInternal, "output container is null");
   *ids = nullptr; *id_offsets = nullptr; *scores = nullptr; *result_offsets = nullptr;
   if (h->model.model_type != kUnigram)
-    return Fail(h, kInternal, "NBestEncode is not available for the current model.");   // sentencepiece_processor.cc:662
+    return Fail(h, kInternal, mode == 0 ? "NBestEncode is not available for the current model."     // sentencepiece_processor.cc:662
+                                        : "SampleEncode is not available for the current model.");  // :690
   if (nbest_size > 1024) nbest_size = 1024;                                              // unigram_model.cc:692
   if (nbest_size < 1) nbest_size = 1;
-  return Guard(h, [&]() -> int {
-    if (nbest_size == 1 || n == 0) {          // :694-696 the plain encoder, score 0.0; one result per sentence
+  if (mode != 0) nbest_size = 1;
+  {
+    if ((mode == 0 && nbest_size == 1) || n == 0) {          // :694-696 the plain encoder, score 0.0; one result per sentence
       int32_t *i1 = nullptr;
       uint64_t *o1 = nullptr;
       const int rc = EncodeBatchHost(h, text, offsets, n, &i1, &o1, nullptr, nullptr, nullptr, nullptr);
@@ -1555,6 +1567,7 @@ int spmx_nbest_encode_batch(spmx_handle *h, const char *text, const uint64_t *of
     if (n * K + 1 > (1ull << 32)) return Fail(h, kInvalidArgument, "too many results for one batch");
     NBestArgs a{};
     a.dev = h->dev; a.norm = ws->d_norm.p; a.norm_offs = ws->d_id_offs.p; a.n = static_cast<uint32_t>(n); a.nbest = K;
+    a.mode = static_cast<uint32_t>(mode); a.inv_theta = inv_theta; a.seed = seed;
     uint64_t hyps = static_cast<uint64_t>(K) * 2048;
     a.max_hyps = static_cast<uint32_t>(hyps < 16384 ? 16384 : (hyps > 262144 ? 262144 : hyps));
     a.lane_bytes = (NbestLaneBytes(a.max_hyps) + 15) / 16 * 16;
@@ -1620,6 +1633,96 @@ int spmx_nbest_encode_batch(spmx_handle *h, const char *text, const uint64_t *of
       return kOk;
     }
     return Fail(h, kInternal, "id arena kept overflowing");
+  }
+}
+}  // namespace
+
+// NBestEncode (src/sentencepiece_processor.h:323-324; unigram::Model::NBestEncode src/unigram_model.cc:686-717).
+int spmx_nbest_encode_batch(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int nbest_size,
+                            int32_t **ids, uint64_t **id_offsets, float **scores, uint64_t **result_offsets) {
+  if (!h) return kInvalidArgument;
+  return Guard(h, [&]() -> int { return LatticeBatchHost(h, text, offsets, n, 0, nbest_size, 0.f, 0, ids, id_offsets, scores, result_offsets); });
+}
+
+// The kOriginal unigram encoder (unigram::Model::Encode with EncoderVersion::kOriginal, src/unigram_model.cc:674-692:
+// Lattice::SetSentence + PopulateNodes + Lattice::Viterbi), per sentence.
+int spmx_encode_batch_original(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
+                               uint64_t **id_offsets) {
+  if (!h) return kInvalidArgument;
+  return Guard(h, [&]() -> int {
+    float *sc = nullptr;
+    uint64_t *ro = nullptr;
+    const int rc = LatticeBatchHost(h, text, offsets, n, 2, 1, 0.f, 0, ids, id_offsets, &sc, &ro);
+    free(sc);
+    free(ro);
+    return rc;
+  });
+}
+
+// SampleEncode(input, nbest_size, alpha, &ids) (src/sentencepiece_processor.cc:678-720) per sentence:
+//   nbest_size < 0      unigram: Lattice::Sample(alpha) (forward filtering, backward sampling, :511-542); BPE: BPE-dropout
+//                       with probability alpha (src/bpe_model.cc:131-156)
+//   nbest_size 0 or 1   the plain encoder
+//   nbest_size > 1      one of the nbest_size best segmentations, drawn with probability proportional to
+//                       exp(alpha * score) (:700-716; unigram only)
+// The draws come from generators keyed by (seed, sentence index): the reference's thread-local mt19937 stream is not
+// reproduced (its own tests pin SampleEncode statistically, src/unigram_model_test.cc:429-470, bpe_model_test.cc:252-295).
+int spmx_sample_encode_batch(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int nbest_size,
+                             float alpha, uint64_t seed, int32_t **ids, uint64_t **id_offsets) {
+  if (!h) return kInvalidArgument;
+  if (!ids || !id_offsets) return Fail(h, kInternal, "output container is null");
+  return Guard(h, [&]() -> int {
+    *ids = nullptr; *id_offsets = nullptr;
+    if (nbest_size == 0 || nbest_size == 1) return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, nullptr, nullptr, nullptr, nullptr);
+    if (h->model.model_type == kBpe) {
+      if (nbest_size > 1) return Fail(h, kInternal, "NBestEncode is not available for the current model.");
+      if (n && !offsets) return Fail(h, kInvalidArgument, "null offsets");
+      if (n == 0 || !(alpha > 0.f)) return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, nullptr, nullptr, nullptr, nullptr);
+      return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, alpha, seed);
+    }
+    float *sc = nullptr;
+    uint64_t *ro = nullptr;
+    if (nbest_size < 0) {
+      const int rc = LatticeBatchHost(h, text, offsets, n, 1, 1, alpha, seed, ids, id_offsets, &sc, &ro);
+      free(sc);
+      free(ro);
+      return rc;
+    }
+    int32_t *nids = nullptr;
+    uint64_t *nio = nullptr;
+    const int rc = LatticeBatchHost(h, text, offsets, n, 0, nbest_size, 0.f, 0, &nids, &nio, &sc, &ro);
+    if (rc != kOk) return rc;
+    // one of each sentence's results, with probability exp(alpha * score) / Z
+    uint64_t *oo = static_cast<uint64_t *>(malloc((n + 1) * sizeof(uint64_t)));
+    std::vector<uint64_t> pick(n);
+    uint64_t total = 0;
+    unsigned long long st = seed * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull;
+    for (uint64_t s2 = 0; oo && s2 < n; ++s2) {
+      const uint64_t r0 = ro[s2], r1 = ro[s2 + 1];
+      double mx = -1e300, z = 0.0;
+      for (uint64_t r = r0; r < r1; ++r) mx = std::max(mx, static_cast<double>(alpha) * sc[r]);
+      for (uint64_t r = r0; r < r1; ++r) z += exp(static_cast<double>(alpha) * sc[r] - mx);
+      st += 0x9E3779B97F4A7C15ull;
+      unsigned long long x = st;
+      x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+      x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+      x ^= x >> 31;
+      double u = static_cast<double>(x >> 11) * (1.0 / 9007199254740992.0) * z;
+      uint64_t c = r1 > r0 ? r1 - 1 : r0;
+      for (uint64_t r = r0; r < r1; ++r) { u -= exp(static_cast<double>(alpha) * sc[r] - mx); if (u < 0.0) { c = r; break; } }
+      pick[s2] = c;
+      oo[s2] = total;
+      if (r1 > r0) total += nio[c + 1] - nio[c];
+    }
+    int32_t *oi = static_cast<int32_t *>(malloc((total ? total : 1) * sizeof(int32_t)));
+    if (!oo || !oi) { free(oo); free(oi); free(nids); free(nio); free(sc); free(ro); return Fail(h, kResourceExhausted, "out of host memory"); }
+    oo[n] = total;
+    for (uint64_t s2 = 0; s2 < n; ++s2)
+      if (ro[s2 + 1] > ro[s2]) memcpy(oi + oo[s2], nids + nio[pick[s2]], (nio[pick[s2] + 1] - nio[pick[s2]]) * sizeof(int32_t));
+    free(nids); free(nio); free(sc); free(ro);
+    *ids = oi;
+    *id_offsets = oo;
+    return kOk;
   });
 }
 

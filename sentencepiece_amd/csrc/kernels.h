@@ -17,6 +17,8 @@
 #ifndef SPMX_WAVE_API   // tests/emu/ supplies a lock-step CPU model of wv:: (test seam)
 #include "wave.h"
 #endif
+#include <math.h>
+
 #include "dev.h"
 
 namespace spmx {

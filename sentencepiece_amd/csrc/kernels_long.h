@@ -41,6 +41,8 @@ struct LongArgs {
   SideLists *side;
   int32_t *arena_tb;            // spans form, else null
   uint32_t stack_cap;           // entries of the resegmentation stack (> longest piece in characters)
+  float dropout;                // BPE-dropout (src/bpe_model.cc:131-156): a valid merge is skipped with this probability
+  uint64_t seed;                // ... by a generator keyed by (seed, sentence index)
 };
 
 SPMX_HD inline uint64_t Align16(uint64_t x) { return (x + 15u) & ~static_cast<uint64_t>(15); }
@@ -227,12 +229,25 @@ SPMX_DEVICE void bpe_long_lane(const LongArgs &a, uint32_t sid, uint8_t *rawwin)
   };
   for (uint32_t p = 0; p < N; p = nxt[p]) add_pair(p);               // :127-129
   // ---- main loop (:142-173) ----
+  unsigned long long rng = a.seed * 0x9E3779B97F4A7C15ull + (static_cast<unsigned long long>(sid) + 1ull) * 0xD1B54A32D192ED03ull;
   while (hn > 0) {
     const U4 top = agenda_pop(heap, &hn);
     const uint32_t l = top.y;
     if (sym[l] == kLongDead) continue;                               // :147-151 stale entries
     const uint32_t r = nxt[l];
     if (r >= N || nxt[r] - l != top.z) continue;
+    if (a.dropout > 0.f) {                                           // skip_merge (:131-138, :153-156)
+      bool skip = a.dropout >= 1.f;
+      if (!skip) {
+        rng += 0x9E3779B97F4A7C15ull;
+        unsigned long long z = rng;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        skip = static_cast<double>(z >> 11) * (1.0 / 9007199254740992.0) < static_cast<double>(a.dropout);
+      }
+      if (skip) continue;
+    }
     sym[l] = top.w;                                                  // :159-168
     const uint32_t nr = nxt[r];
     nxt[l] = nr;

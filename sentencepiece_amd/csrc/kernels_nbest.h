@@ -19,7 +19,7 @@ constexpr uint32_t kNbMaxNodes = 16384;     // lattice nodes per sentence (node 
 constexpr uint32_t kNbAgendaCap = 10000 + 512;   // :487 kMaxAgendaSize + the largest fan-in handled
 constexpr uint32_t kStNbestOverflow = 1u << 5;   // status: a per-sentence capacity was exceeded
 
-struct NbNode { uint16_t pos, length, byte_begin, byte_len; int32_t id; float score, backtrace; };   // 20 bytes
+struct NbNode { uint16_t pos, length, byte_begin, byte_len; int32_t id; float score, backtrace; uint32_t prev; };   // 24 bytes
 struct NbHyp { uint32_t next; uint32_t node; float fx, gx; };                                      // 16 bytes
 
 // bytes of one lane's slice for max_hyps hypotheses
@@ -38,7 +38,11 @@ struct NBestArgs {
   const uint8_t *norm;          // packed normalized text, device form
   const uint64_t *norm_offs;    // n + 1
   uint32_t n;
-  uint32_t nbest;               // 2 .. 1024
+  uint32_t nbest;               // 2 .. 1024 (mode 0); 1 otherwise
+  uint32_t mode;                // 0 Lattice::NBest (:345-515); 1 Lattice::Sample(inv_theta) (:511-542); 2 Lattice::Viterbi
+                                // (:161-198), the kOriginal encoder (:674-692)
+  float inv_theta;              // mode 1
+  uint64_t seed;                // mode 1: the lanes' generators are keyed by (seed, sentence index)
   uint8_t *scratch;             // [lanes of the launch][lane_bytes]
   uint64_t lane_bytes;
   uint32_t max_hyps;
@@ -145,8 +149,8 @@ SPMX_DEVICE void nbest_lane(const NBestArgs &a, uint32_t s, uint8_t *mine) {
   // ---- PopulateNodes (:547-596).  Nodes 0 = BOS, 1 = EOS, then in insertion order (begin position, then length):
   // the order of end_nodes(pos) that Viterbi's "first best wins" and the A* expansion follow ----
   uint32_t n_nodes = 2;
-  nodes[0] = NbNode{0, 0, 0, 0, -1, 0.f, 0.f};
-  nodes[1] = NbNode{static_cast<uint16_t>(len), 0, 0, 0, -1, 0.f, 0.f};
+  nodes[0] = NbNode{0, 0, 0, 0, -1, 0.f, 0.f, 0u};
+  nodes[1] = NbNode{static_cast<uint16_t>(len), 0, 0, 0, -1, 0.f, 0.f, 0u};
   const float unk_score = d.unk_score;                         // :555 min_score() - kUnkPenalty
   const uint32_t root = d.ptrie[0].x >> kDatBaseShiftDev;
   bool over = false;
@@ -169,13 +173,13 @@ SPMX_DEVICE void nbest_lane(const NBestArgs &a, uint32_t s, uint8_t *mine) {
       float sc = wv::bits_to_float(u.z);
       if (u.y & kPtUserDefined) sc = static_cast<float>(static_cast<double>(static_cast<float>(length) * d.max_score) - 0.1);   // :580
       nodes[n_nodes++] = NbNode{static_cast<uint16_t>(bp), static_cast<uint16_t>(length), static_cast<uint16_t>(b0),
-                                static_cast<uint16_t>(surf[bp + length] - b0), static_cast<int32_t>(u.y & kPtIdMask), sc, 0.f};
+                                static_cast<uint16_t>(surf[bp + length] - b0), static_cast<int32_t>(u.y & kPtIdMask), sc, 0.f, 0u};
       if (length == 1) single = true;
     }
     if (!single && !over) {                                    // :589-593 the UNK node
       if (n_nodes >= kNbMaxNodes) { over = true; break; }
       nodes[n_nodes++] = NbNode{static_cast<uint16_t>(bp), 1, static_cast<uint16_t>(b0), static_cast<uint16_t>(surf[bp + 1] - b0),
-                                d.unk_id, unk_score, 0.f};
+                                d.unk_id, unk_score, 0.f, 0u};
     }
   }
   if (over) { wv::atomic_or(a.status, kStNbestOverflow); return; }
@@ -191,17 +195,126 @@ SPMX_DEVICE void nbest_lane(const NBestArgs &a, uint32_t s, uint8_t *mine) {
     end_idx[end_off[e] + cursor[e]++] = static_cast<uint16_t>(i);
   }
   // ---- Viterbi (:167-198): backtrace_score of every node, begin positions in order (nodes are sorted by pos) ----
-  auto best_into = [&](int pos, float score) -> float {
+  auto best_into = [&](int pos, float score, uint32_t *prev) -> float {      // first best left node wins (:171)
     float best = 0.f;
     bool have = false;
     for (uint32_t l = end_off[pos]; l < end_off[pos + 1]; ++l) {
       const float sc = nodes[end_idx[l]].backtrace + score;
-      if (!have || sc > best) { best = sc; have = true; }
+      if (!have || sc > best) { best = sc; have = true; *prev = end_idx[l]; }
     }
     return best;
   };
-  for (uint32_t i = 2; i < n_nodes; ++i) nodes[i].backtrace = best_into(nodes[i].pos, nodes[i].score);
-  nodes[1].backtrace = best_into(len, 0.f);
+  if (a.mode != 1u) {
+    for (uint32_t i = 2; i < n_nodes; ++i) nodes[i].backtrace = best_into(nodes[i].pos, nodes[i].score, &nodes[i].prev);
+    nodes[1].backtrace = best_into(len, 0.f, &nodes[1].prev);
+  }
+  // ids of a path given as a chain of node indices, left to right through `next_of` (PopulateSentencePieceText
+  // :581-613: a run of unknown pieces yields one id, byte fallback one id per byte), twice: count, then write
+  auto emit_path = [&](auto first_of, auto next_of, auto done_of, float score) -> bool {
+    int body = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+      int32_t *dst = nullptr;
+      if (pass == 1) {
+        dst = alloc(body + n_extra);
+        if (!dst) return false;
+        for (int x = 0; x < d.n_prefix; ++x) dst[x] = d.prefix_ids[x];
+        for (int x = 0; x < d.n_suffix; ++x) dst[d.n_prefix + body + x] = d.suffix_ids[x];
+        dst += d.n_prefix;
+      }
+      int k = 0;
+      bool prev_unk = false;
+      for (uint32_t h = first_of(); !done_of(h); h = next_of(h)) {
+        const NbNode &x = nodes[h];
+        const bool unk = x.id == d.unk_id;
+        if (unk && bf) {
+          for (int t = 0; t < x.byte_len; ++t) {
+            const uint32_t b = norm[x.byte_begin + t];
+            const int nbt = b == spb ? 3 : 1;
+            for (int y = 0; y < nbt; ++y) {
+              if (pass == 1) dst[reverse ? body - 1 - k : k] = d.byte_ids[b == spb ? (y == 0 ? 0xE2u : (y == 1 ? 0x96u : 0x81u)) : b];
+              ++k;
+            }
+          }
+        } else if (!(unk && prev_unk)) {
+          if (pass == 1) dst[reverse ? body - 1 - k : k] = x.id;
+          ++k;
+        }
+        prev_unk = unk;
+      }
+      body = k;
+    }
+    res_score[a.res_count[s]] = score;
+    a.res_count[s] = a.res_count[s] + 1;
+    return true;
+  };
+  if (a.mode == 2u) {
+    // ---- Lattice::Viterbi (:161-198): the path is the prev chain from EOS; emitted left to right by reversing it in
+    // place (prev -> next) ----
+    uint32_t nxt = 1u, cur = nodes[1].prev;             // walk from EOS's prev towards BOS, turning the links around
+    while (cur != 0u) {
+      const uint32_t pv = nodes[cur].prev;
+      nodes[cur].prev = nxt;
+      nxt = cur;
+      cur = pv;
+    }
+    emit_path([&] { return nxt; }, [&](uint32_t h) { return nodes[h].prev; }, [&](uint32_t h) { return h == 1u; }, nodes[1].backtrace);
+    return;
+  }
+  if (a.mode == 1u) {
+    // ---- Lattice::Sample(inv_theta) (:511-542): ForwardAlgorithm (:200-216) -- alpha of a node depends on its begin
+    // position only: kept per position in the (idle) hypothesis slice -- then one left node after another from EOS,
+    // each drawn with probability exp(alpha[l] + inv_theta * score[l] - Z) (std::discrete_distribution's weights) ----
+    float *alpha = reinterpret_cast<float *>(hy);
+    auto lse = [](float x, float y, bool init) -> float {                   // LogSumExp (:47-59)
+      if (init) return y;
+      const float vmin = x < y ? x : y, vmax = x < y ? y : x;
+      if (vmax > vmin + 50.f) return vmax;
+      return static_cast<float>(static_cast<double>(vmax) + log(exp(static_cast<double>(vmin - vmax)) + 1.0));
+    };
+    alpha[0] = 0.f;
+    for (int pos = 1; pos <= len; ++pos) {
+      float acc = 0.f;
+      for (uint32_t l = end_off[pos]; l < end_off[pos + 1]; ++l) {
+        const NbNode &ln = nodes[end_idx[l]];
+        acc = lse(acc, a.inv_theta * ln.score + alpha[ln.pos], l == end_off[pos]);
+      }
+      alpha[pos] = acc;
+    }
+    // a generator per sentence: splitmix64 over (seed, sentence); 53 random bits per draw
+    unsigned long long st = a.seed * 0x9E3779B97F4A7C15ull + (static_cast<unsigned long long>(s) + 1ull) * 0xD1B54A32D192ED03ull;
+    auto uniform = [&]() -> double {
+      st += 0x9E3779B97F4A7C15ull;
+      unsigned long long z = st;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      z ^= z >> 31;
+      return static_cast<double>(z >> 11) * (1.0 / 9007199254740992.0);
+    };
+    float Z = alpha[len];
+    uint32_t nxt = 1u;                                  // the chain is built right to left: prev = the node to the right
+    int pos = len;
+    for (;;) {
+      double sum = 0.0;
+      for (uint32_t l = end_off[pos]; l < end_off[pos + 1]; ++l) {
+        const NbNode &ln = nodes[end_idx[l]];
+        sum += exp(static_cast<double>(alpha[ln.pos] + a.inv_theta * ln.score - Z));
+      }
+      double r = uniform() * sum;
+      uint32_t pick = end_idx[end_off[pos + 1] - 1];
+      for (uint32_t l = end_off[pos]; l < end_off[pos + 1]; ++l) {
+        const NbNode &ln = nodes[end_idx[l]];
+        r -= exp(static_cast<double>(alpha[ln.pos] + a.inv_theta * ln.score - Z));
+        if (r < 0.0) { pick = end_idx[l]; break; }
+      }
+      if (pick == 0u) break;                            // reached BOS
+      nodes[pick].prev = nxt;
+      nxt = pick;
+      pos = nodes[pick].pos;
+      Z = alpha[pos];
+    }
+    emit_path([&] { return nxt; }, [&](uint32_t h) { return nodes[h].prev; }, [&](uint32_t h) { return h == 1u; }, 0.f);
+    return;
+  }
   // ---- A* (:375-515) ----
   uint32_t n_hyp = 0, hn = 0;
   hy[0] = NbHyp{0xFFFFFFFFu, 1u, nodes[1].backtrace, 0.f};

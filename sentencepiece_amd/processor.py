@@ -32,6 +32,7 @@ class SentencePieceProcessor:
         self._out_type = out_type
         self._add_bos, self._add_eos, self._reverse = add_bos, add_eos, reverse
         self._enable_sampling = enable_sampling
+        self._nbest_size, self._alpha = nbest_size, alpha
         self._emit_unk_piece = emit_unk_piece
         self._extra = ""          # SetEncodeExtraOptions string
         self._applied = ""        # option string currently compiled into the handle
@@ -198,7 +199,24 @@ class SentencePieceProcessor:
         self._need()
         out_type = self._out_type if out_type is None else out_type
         if (self._enable_sampling if enable_sampling is None else enable_sampling):
-            raise NotImplementedError("sampling is not on the device path")
+            if out_type is not int:
+                raise NotImplementedError("sampling is on the device path for out_type=int")
+            # _SampleEncodeAsIds (sentencepiece.i): SampleEncode + RewriteIds; the draws are keyed by a fresh seed per call
+            self._sample_calls = getattr(self, "_sample_calls", 0) + 1
+            self._apply(self._add_bos if add_bos is None else add_bos, self._add_eos if add_eos is None else add_eos,
+                        self._reverse if reverse is None else reverse)
+            single = not isinstance(input, list)
+            items = [input] if single else input
+            bs = [s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in items]
+            offs = np.zeros(len(bs) + 1, dtype=np.uint64)
+            if bs:
+                np.cumsum([len(b) for b in bs], out=offs[1:])
+            ids, io = self._csr_call(self._lib.spmx_sample_encode_batch, np.frombuffer(b"".join(bs), dtype=np.uint8), offs,
+                                     int(self._nbest_size if nbest_size is None else nbest_size),
+                                     C.c_float(self._alpha if alpha is None else alpha), int(self._sample_calls))
+            io = io.astype(np.int64)
+            out = [ids[io[i]:io[i + 1]].tolist() for i in range(len(bs))]
+            return out[0] if single else out
         if out_type is str or out_type == "str":
             # _EncodeAsPiecesBatch (sentencepiece.i:448-456): EncodeAsPieces per element, then RewriteIds on the
             # piece lists (:147-164): reverse, bos piece in front, eos piece at the back, unknown pieces -> unk piece
@@ -654,6 +672,49 @@ class SentencePieceProcessor:
         return d_text[:tb.value], d_offs[:n.value + 1], n.value
 
     # ------------------------------------------------------ measurement ----
+    def _csr_call(self, fn, text, offsets, *mid):
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offs) - 1
+        p_ids, p_off = C.c_void_p(), C.c_void_p()
+        self._check(fn(self._h, text.ctypes.data if len(text) else None, offs.ctypes.data, n, *mid, C.byref(p_ids), C.byref(p_off)))
+        try:
+            io = np.ctypeslib.as_array(C.cast(p_off, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+            total = int(io[n])
+            ids = (np.ctypeslib.as_array(C.cast(p_ids, C.POINTER(C.c_int32)), shape=(total,)).copy()
+                   if total else np.zeros(0, dtype=np.int32))
+        finally:
+            self._lib.spmx_free(p_ids)
+            self._lib.spmx_free(p_off)
+        return ids, io
+
+    def SampleEncodePacked(self, text, offsets, nbest_size=-1, alpha=0.1, seed=0):
+        """SampleEncode per sentence (subword regularization; src/sentencepiece_processor.cc:678-720): packed host arrays
+        -> CSR ``(ids, id_offsets)``.  ``nbest_size < 0`` samples from the whole lattice (unigram) / applies BPE-dropout
+        with probability ``alpha`` (BPE); ``nbest_size > 1`` draws one of the n best.  ``seed`` keys the generators."""
+        self._need()
+        self._apply(False, False, False)
+        return self._csr_call(self._lib.spmx_sample_encode_batch, text, offsets, int(nbest_size), C.c_float(alpha), int(seed))
+
+    def SampleEncodeAsIds(self, input, nbest_size=-1, alpha=0.1, seed=0):
+        single = not isinstance(input, list)
+        items = [input] if single else input
+        bs = [s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in items]
+        offs = np.zeros(len(bs) + 1, dtype=np.uint64)
+        if bs:
+            np.cumsum([len(b) for b in bs], out=offs[1:])
+        ids, io = self.SampleEncodePacked(np.frombuffer(b"".join(bs), dtype=np.uint8), offs, nbest_size, alpha, seed)
+        io = io.astype(np.int64)
+        out = [ids[io[i]:io[i + 1]].tolist() for i in range(len(bs))]
+        return out[0] if single else out
+
+    def EncodeOriginalPacked(self, text, offsets):
+        """The reference's kOriginal unigram encoder (Lattice::Viterbi, src/unigram_model.cc:161-198, :674-692) per
+        sentence -> CSR ``(ids, id_offsets)``."""
+        self._need()
+        self._apply(False, False, False)
+        return self._csr_call(self._lib.spmx_encode_batch_original, text, offsets)
+
     def EncodeFile(self, in_path, out_path, output_format="id"):
         """Corpus file -> ids, the loop of the reference's ``spm_encode --output_format=id`` (spm_encode_main.cc:115-165)
         as one pipelined call: ``output_format="id"`` writes the reference's text (one line of space-separated ids per

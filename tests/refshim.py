@@ -76,12 +76,29 @@ class RefHandle:
     def encode(self, text):
         if isinstance(text, str):
             text = text.encode()
-        cap = 4 * len(text) + 16
+        cap = 64 * len(text) + 64
         out = np.empty(cap, dtype=np.int32)
         n = self.lib.spmref_encode(self.h, text, len(text), out.ctypes.data, cap)
         if n < 0:
             raise RuntimeError("reference Encode failed: %d" % n)
         return out[:n].copy()
+
+    def set_encoder_original(self):
+        """unigram::Model::SetEncoderVersion(kOriginal) (src/unigram_model.h:176-186)."""
+        self.lib.spmref_set_encoder_original.argtypes = [C.c_void_p]
+        if self.lib.spmref_set_encoder_original(self.h) != 0:
+            raise RuntimeError("not a unigram model")
+
+    def sample_encode(self, text, nbest_size, alpha):
+        fn = self.lib.spmref_sample_encode
+        fn.restype = C.c_int64
+        fn.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_int, C.c_float, C.c_void_p, C.c_uint64]
+        cap = 64 * len(text) + 64
+        out = np.empty(cap, dtype=np.int32)
+        n = fn(self.h, text, len(text), nbest_size, alpha, out.ctypes.data, cap)
+        if n < 0:
+            raise RuntimeError("reference SampleEncode failed")
+        return out[:n].tolist()
 
     def normalize(self, text):
         if isinstance(text, str):
