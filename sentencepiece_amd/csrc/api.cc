@@ -171,8 +171,8 @@ struct Workspace {
   Ctrl *d_ctrl = nullptr;
   Ctrl *h_ctrl = nullptr;   // pinned
   // host-buffer forms
-  DevBuf<uint8_t> d_text;
-  DevBuf<uint64_t> d_offs, d_id_offs;
+  DevBuf<uint8_t> d_text, d_dn_text;       // d_dn_*: the decoded text before the denormalizer
+  DevBuf<uint64_t> d_offs, d_id_offs, d_dn_offs;
   DevBuf<int32_t> d_ids;
   PinBuf<uint8_t> h_text;       // pinned staging of the pipelined host form
   PinBuf<uint64_t> h_offs, h_id_offs;
@@ -216,6 +216,12 @@ struct spmx_handle {
   DevBuf<uint16_t> d_sym_len;
   DevBuf<int32_t> d_byte_ids;
   SpmxDev dev{};   // scalars + device pointers
+  // the denormalizer (denormalizer_spec with a charsmap): normalizer tables of its own
+  HostTables dn_tables;
+  DevBuf<uint32_t> dn_ndarts, dn_npair;
+  DevBuf<uint8_t> dn_nblob;
+  DevBuf<U2> dn_utrie;
+  SpmxDev dn_dev{};
   std::vector<std::unique_ptr<Workspace>> pool;   // idle workspaces
   bool profiling = false;
   Profile prof;                  // of the last profiled encode call
@@ -319,6 +325,18 @@ int UploadTables(spmx_handle *h) {
   h->dev.dec_info = h->d_dec_info.p;
   h->dev.dec_off = h->d_dec_off.p;
   h->dev.dec_bytes = h->d_dec_bytes.p;
+  if (h->model.has_denormalizer) {
+    const HostTables &d = h->dn_tables;
+    HIP_OR_RETURN(h, Upload(&h->dn_ndarts, d.ndarts));
+    HIP_OR_RETURN(h, Upload(&h->dn_nblob, d.nblob));
+    HIP_OR_RETURN(h, Upload(&h->dn_npair, d.npair));
+    HIP_OR_RETURN(h, Upload(&h->dn_utrie, d.utrie));
+    h->dn_dev = d.scalars;
+    h->dn_dev.ndarts = h->dn_ndarts.p;
+    h->dn_dev.nblob = h->dn_nblob.p;
+    h->dn_dev.npair = h->dn_npair.p;
+    h->dn_dev.utrie = h->dn_utrie.p;
+  }
   return kOk;
 }
 
@@ -803,7 +821,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
 // lane-per-sentence ones (kernels_long.h).
 int NormalizeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, const uint64_t *d_offsets, uint64_t n, uint8_t *d_norm,
                     uint64_t norm_capacity, uint64_t *d_norm_offsets, uint32_t *d_n2o, hipStream_t stream,
-                    uint64_t *total_bytes, bool device_text = false) {
+                    uint64_t *total_bytes, bool device_text = false, const SpmxDev *dev = nullptr) {
   if (total_bytes) *total_bytes = 0;
   if (n >= (1ull << 32) - 64) return Fail(h, kInvalidArgument, "more than 2^32 - 64 sentences in one batch");
   if (!d_offsets || !d_norm_offsets) return Fail(h, kInvalidArgument, "null offsets");
@@ -827,7 +845,7 @@ int NormalizeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, const 
   while (c_staged < ncls && cls[c_staged].rcap <= kMaxStagedRaw) ++c_staged;
   auto pass = [&](bool write) -> int {
     NormalizeArgs base{};
-    base.dev = h->dev; base.text = d_text; base.offs = d_offsets;
+    base.dev = dev ? *dev : h->dev; base.text = d_text; base.offs = d_offsets;
     base.counts = ws->d_counts.p; base.norm_offs = d_norm_offsets; base.norm = d_norm; base.n2o = d_n2o;
     base.status = &ws->d_ctrl->status;
     base.device_text = device_text ? 1u : 0u;
@@ -876,11 +894,9 @@ int NormalizeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, const 
 }
 
 // Batch Decode on the device (kernels_decode.h): count pass -> scan -> (host checks status / capacity) -> write pass.
-int DecodeDevice(spmx_handle *h, Workspace *ws, const int32_t *d_ids, const uint64_t *d_id_offsets, uint64_t n, uint8_t *d_text,
-                 uint64_t text_capacity, uint64_t *d_text_offsets, hipStream_t stream, uint64_t *total_bytes) {
+int DecodeRaw(spmx_handle *h, Workspace *ws, const int32_t *d_ids, const uint64_t *d_id_offsets, uint64_t n, uint8_t *d_text,
+              uint64_t text_capacity, uint64_t *d_text_offsets, hipStream_t stream, uint64_t *total_bytes) {
   if (total_bytes) *total_bytes = 0;
-  if (h->model.has_denormalizer)
-    return Fail(h, kUnimplemented, "the model has a denormalizer_spec; Decode with a denormalizer is not on the device path");
   if (n >= (1ull << 32) - 64) return Fail(h, kInvalidArgument, "more than 2^32 - 64 sentences in one batch");
   if (!d_id_offsets || !d_text_offsets) return Fail(h, kInvalidArgument, "null offsets");
   if (n == 0) {
@@ -918,6 +934,30 @@ int DecodeDevice(spmx_handle *h, Workspace *ws, const int32_t *d_ids, const uint
   HIP_OR_RETURN(h, LaunchDecode(true, a, grid, stream));
   HIP_OR_RETURN(h, hipStreamSynchronize(stream));
   return kOk;
+}
+
+// Decode, then the denormalizer over each decoded sentence when the model carries one (`*text = denormalizer_->
+// Normalize(*text)`, sentencepiece_processor.cc:905-907): the batch Normalize kernels with the denormalizer's tables.
+int DecodeDevice(spmx_handle *h, Workspace *ws, const int32_t *d_ids, const uint64_t *d_id_offsets, uint64_t n, uint8_t *d_text,
+                 uint64_t text_capacity, uint64_t *d_text_offsets, hipStream_t stream, uint64_t *total_bytes) {
+  if (!h->model.has_denormalizer)
+    return DecodeRaw(h, ws, d_ids, d_id_offsets, n, d_text, text_capacity, d_text_offsets, stream, total_bytes);
+  if (total_bytes) *total_bytes = 0;
+  if (!d_id_offsets || !d_text_offsets) return Fail(h, kInvalidArgument, "null offsets");
+  HIP_OR_RETURN(h, ws->d_dn_offs.Reserve(n + 1));
+  uint64_t cap = ws->d_dn_text.cap ? ws->d_dn_text.cap : (1u << 20), total = 0;
+  int rc = kOk;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    HIP_OR_RETURN(h, ws->d_dn_text.Reserve(cap));
+    rc = DecodeRaw(h, ws, d_ids, d_id_offsets, n, ws->d_dn_text.p, ws->d_dn_text.cap, ws->d_dn_offs.p, stream, &total);
+    if (rc != kResourceExhausted || total <= ws->d_dn_text.cap) break;
+    cap = total + 64;
+  }
+  if (rc != kOk) return rc;
+  rc = NormalizeDevice(h, ws, ws->d_dn_text.p, ws->d_dn_offs.p, n, d_text, d_text ? text_capacity : 0, d_text_offsets, nullptr, stream,
+                       total_bytes, false, &h->dn_dev);
+  if (rc == kResourceExhausted) t_error = "text_capacity is too small";
+  return rc;
 }
 
 bool ReadFile(const char *path, std::string *out) {
@@ -974,6 +1014,15 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (st.ok()) st = InitializeModel(&h->model);
     if (st.ok()) st = CompileTables(h->model, &h->tables);
     if (st.ok()) st = CompileExtraOptions(h->model, "", &h->tables);
+    if (st.ok() && h->model.has_denormalizer) {   // std::make_unique<normalizer::Normalizer>(denormalizer_spec) (:248-252)
+      ModelData dn;
+      dn.normalizer_only = true;
+      dn.charsmap = h->model.dn_charsmap;
+      dn.add_dummy_prefix = h->model.dn_add_dummy_prefix;
+      dn.remove_extra_ws = h->model.dn_remove_extra_ws;
+      dn.escape_ws = h->model.dn_escape_ws;
+      st = CompileTables(dn, &h->dn_tables);
+    }
     if (!st.ok()) return Fail(nullptr, st.code, st.message);
     HIP_OR_RETURN(nullptr, hipSetDevice(device));
     hipDeviceProp_t prop;

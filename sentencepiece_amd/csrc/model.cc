@@ -99,8 +99,13 @@ Status ParseModelProto(const void *data, size_t n, ModelData *m) {
     } else if (f == 5) {  // denormalizer_spec
       Cursor t{s, s + sl};
       const uint8_t *ts = nullptr; size_t tl = 0;
-      while (int g = t.Next(&wt, &v, &ts, &tl))
-        if (g == 2 && wt == 2 && tl) m->has_denormalizer = true;
+      while (int g = t.Next(&wt, &v, &ts, &tl)) {
+        if (g == 2 && wt == 2) m->dn_charsmap.assign(reinterpret_cast<const char *>(ts), tl);
+        else if (g == 3 && wt == 0) m->dn_add_dummy_prefix = v != 0;
+        else if (g == 4 && wt == 0) m->dn_remove_extra_ws = v != 0;
+        else if (g == 5 && wt == 0) m->dn_escape_ws = v != 0;
+      }
+      m->has_denormalizer = !m->dn_charsmap.empty();
       if (t.bad) c.bad = true;
     } else if (f == 4) {  // self_test_data { repeated Sample samples = 1 { input = 1; expected = 2 } }
       Cursor t{s, s + sl};

@@ -47,6 +47,9 @@ struct ModelData {
   std::string unk_piece = "<unk>", bos_piece = "<s>", eos_piece = "</s>", pad_piece = "<pad>";
   std::string unk_surface = " \xE2\x81\x87 ";   // trainer_spec.unk_surface (sentencepiece_model.proto:228), for Decode
   bool has_denormalizer = false;              // denormalizer_spec with a charsmap (sentencepiece_processor.cc:248-252)
+  std::string dn_charsmap;                    // its precompiled_charsmap and flags: a Normalizer(spec) of its own, run over
+  bool dn_add_dummy_prefix = true, dn_remove_extra_ws = true, dn_escape_ws = true;   // the decoded text (:905-907)
+  bool normalizer_only = false;               // CompileTables: stop after the normalizer tables (the denormalizer's)
   std::string charsmap;    // normalizer_spec.precompiled_charsmap
   bool add_dummy_prefix = true, remove_extra_ws = true, escape_ws = true;
   std::vector<std::pair<std::string, std::string>> self_test;

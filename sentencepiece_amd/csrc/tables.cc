@@ -104,7 +104,7 @@ Status CompileTables(const ModelData &m, HostTables *t) {
   SpmxDev &sc = t->scalars;
   sc = SpmxDev{};
   sc.model_type = m.model_type;
-  if (m.model_type != kUnigram && m.model_type != kBpe)
+  if (!m.normalizer_only && m.model_type != kUnigram && m.model_type != kBpe)
     return Status::Error(kUnimplemented, "only unigram and bpe models are on the device path");
   if (m.pieces.size() >= (1u << 30)) return Status::Error(kResourceExhausted, "vocabulary too large");
   uint32_t flags = 0;
@@ -240,6 +240,10 @@ Status CompileTables(const ModelData &m, HostTables *t) {
       if (kv.first.find(static_cast<char>(kSpByte)) != std::string::npos) { compress = false; break; }
   }
   if (compress) flags |= kNfCompressSp;
+  if (m.normalizer_only) {      // a Normalizer(spec) without a model behind it: the denormalizer
+    sc.flags = flags;
+    return Status::OK();
+  }
 
   // ------------------------------------------------------- id post-process --
   t->byte_ids.assign(m.byte_ids, m.byte_ids + 256);

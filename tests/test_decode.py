@@ -200,3 +200,54 @@ def test_emu_decode_follows_set_vocabulary(corpora):
         rt, ro = r.decode_batch(ids, io)
         np.testing.assert_array_equal(eo, ro, err_msg=step)
         np.testing.assert_array_equal(et, rt, err_msg=step)
+
+
+def _with_denormalizer(model, flags):
+    """The model plus a denormalizer_spec: the nmt_nfkc rules (taken from test_model's normalizer_spec) as the
+    'denormalization', with the three whitespace flags as given (the trainer writes False for all, sentencepiece_trainer.cc
+    :145-148; the processor honours whatever the proto holds)."""
+    from sentencepiece import sentencepiece_model_pb2 as pb
+    m, src = pb.ModelProto(), pb.ModelProto()
+    m.ParseFromString(fixtures.model_blob(model))
+    src.ParseFromString(fixtures.model_blob("test_model"))
+    m.denormalizer_spec.precompiled_charsmap = src.normalizer_spec.precompiled_charsmap
+    m.denormalizer_spec.add_dummy_prefix = flags[0]
+    m.denormalizer_spec.remove_extra_whitespaces = flags[1]
+    m.denormalizer_spec.escape_whitespaces = flags[2]
+    return m.SerializeToString()
+
+
+def _denormalizer_case(load, corpora):
+    """Decode of a model with a denormalizer_spec: `*text = denormalizer_->Normalize(*text)` (src/sentencepiece_processor.cc
+    :905-907) -- against the compiled reference (the oracle does not restate the denormalizer)."""
+    r = refshim.RefLib()
+    for model, flags in (("uni1k_ident", (False, False, False)), ("uni1k_ident", (True, True, True)),
+                         ("uni1k_bf", (False, True, False)), ("bpe1k_noesc", (False, False, False))):
+        blob = _with_denormalizer(model, flags)
+        e, rh = load(blob), r.load(blob)
+        for name, k in (("edge", 10 ** 6), ("mixed2k", 80), ("ja", 20)):
+            text, offs = fixtures.head(*corpora[name], k)
+            ids, io = rh.encode_batch(text, offs)
+            rt, ro = rh.decode_batch(ids, io)
+            et, eo = e.DecodePacked(ids, io)
+            np.testing.assert_array_equal(eo, ro, err_msg=str((model, flags, name)))
+            np.testing.assert_array_equal(et, rt, err_msg=str((model, flags, name)))
+        # the identity-normalized models keep full-width / ligature / circled characters in their ids (as UNK or bytes or
+        # pieces); what the denormalizer sees includes the unk surface U+2047, which nmt_nfkc rewrites to "??"
+        assert b"\xe2\x81\x87" not in bytes(et) or flags is None
+
+
+def test_emu_decode_with_denormalizer(corpora):
+    from tests import emulib
+    if not refshim.available():
+        pytest.skip("oracle/_ref/libspm_ref.so not built")
+    lib = emulib.EmuLib()
+    _denormalizer_case(lambda blob: lib.load(blob).sp, corpora)
+
+
+@pytest.mark.gpu
+def test_gpu_decode_with_denormalizer(corpora):
+    from sentencepiece_amd.processor import SentencePieceProcessor
+    if not refshim.available():
+        pytest.skip("oracle/_ref/libspm_ref.so not built")
+    _denormalizer_case(lambda blob: SentencePieceProcessor(model_proto=blob), corpora)
