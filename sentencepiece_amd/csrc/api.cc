@@ -210,7 +210,7 @@ struct spmx_handle {
   // device copies of the tables
   DevBuf<uint32_t> d_ndarts, d_npair, d_sym_final, d_dec_info, d_dec_off;
   DevBuf<uint8_t> d_dec_bytes;
-  DevBuf<uint8_t> d_nblob;
+  DevBuf<uint8_t> d_nblob, d_plen;
   DevBuf<U4> d_ptrie, d_chartab, d_pairtab, d_wordtab;
   DevBuf<U2> d_utrie;
   DevBuf<uint16_t> d_sym_len;
@@ -229,6 +229,7 @@ struct spmx_handle {
   bool no_fast = false;          // SPMX_NO_FAST=1: every tile runs the general normalizer
   bool no_lane_general = false;  // SPMX_NO_LANE_GENERAL=1: main tiles set every non-ASCII sentence aside
   bool no_stream = false;        // SPMX_NO_STREAM=1: BPE in the sentence-per-wave form only
+  bool no_bp_short = false;      // SPMX_NO_BP_SHORT=1: 32-bit back-pointer entries for every unigram model
   bool no_wave = false;          // SPMX_NO_WAVE=1: BPE models that are not word-wise use the long form only
   int tile_waves_override = 0;   // SPMX_TILE_WAVES: cap on wavefronts per workgroup of the streaming kernels
   uint32_t lane_general_min_lanes = 0;   // SPMX_LANE_GENERAL_MIN_LANES (0: per class)
@@ -300,6 +301,7 @@ int UploadTables(spmx_handle *h) {
   HIP_OR_RETURN(h, Upload(&h->d_nblob, t.nblob));
   HIP_OR_RETURN(h, Upload(&h->d_npair, t.npair));
   HIP_OR_RETURN(h, Upload(&h->d_ptrie, t.ptrie));
+  HIP_OR_RETURN(h, Upload(&h->d_plen, t.plen));
   HIP_OR_RETURN(h, Upload(&h->d_utrie, t.utrie));
   HIP_OR_RETURN(h, Upload(&h->d_chartab, t.chartab));
   HIP_OR_RETURN(h, Upload(&h->d_pairtab, t.pairtab));
@@ -315,6 +317,7 @@ int UploadTables(spmx_handle *h) {
   h->dev.nblob = h->d_nblob.p;
   h->dev.npair = h->d_npair.p;
   h->dev.ptrie = h->d_ptrie.p;
+  h->dev.plen = h->d_plen.p;
   h->dev.utrie = h->d_utrie.p;
   h->dev.chartab = h->d_chartab.p;
   h->dev.pairtab = h->d_pairtab.p;
@@ -352,7 +355,7 @@ int RefreshDevice(spmx_handle *h, bool types_changed) {
     HIP_OR_RETURN(h, Upload(&h->d_dec_bytes, t.dec_bytes));
   }
   SpmxDev d = t.scalars;
-  d.ndarts = h->dev.ndarts; d.nblob = h->dev.nblob; d.npair = h->dev.npair; d.ptrie = h->d_ptrie.p; d.utrie = h->dev.utrie;
+  d.ndarts = h->dev.ndarts; d.nblob = h->dev.nblob; d.npair = h->dev.npair; d.ptrie = h->d_ptrie.p; d.plen = h->d_plen.p; d.utrie = h->dev.utrie;
   d.chartab = h->dev.chartab; d.pairtab = h->dev.pairtab; d.wordtab = h->dev.wordtab; d.sym_final = h->d_sym_final.p;
   d.sym_len = h->dev.sym_len; d.byte_ids = h->dev.byte_ids;
   d.dec_info = h->d_dec_info.p; d.dec_off = h->d_dec_off.p; d.dec_bytes = h->d_dec_bytes.p;
@@ -365,7 +368,8 @@ void DestroyHandle(spmx_handle *h) {
   (void)hipSetDevice(h->device);
   h->d_ndarts.Free(); h->d_npair.Free(); h->d_sym_final.Free(); h->d_nblob.Free(); h->d_ptrie.Free(); h->d_chartab.Free();
   h->d_pairtab.Free(); h->d_wordtab.Free(); h->d_utrie.Free(); h->d_sym_len.Free(); h->d_byte_ids.Free();
-  h->d_dec_info.Free(); h->d_dec_off.Free(); h->d_dec_bytes.Free();
+  h->d_dec_info.Free(); h->d_dec_off.Free(); h->d_dec_bytes.Free(); h->d_plen.Free();
+  h->dn_ndarts.Free(); h->dn_npair.Free(); h->dn_nblob.Free(); h->dn_utrie.Free();
   h->pool.clear();
   delete h;
 }
@@ -417,7 +421,12 @@ StreamPlan PlanStream(const spmx_handle *h, EncodeArgs *a, const uint32_t *count
   const int model = h->model.model_type;
   const uint32_t ring = HandleRing(h);
   a->ring = ring;
-  const uint32_t priv = StreamPrivateBytes(model, ring);
+  // the short back-pointer form (kernels_stream.h BpShort): unigram, ring of 16, no user-defined pieces, ids that fit
+  const bool bp_short = model == kUnigram && ring == 16 && !(h->dev.flags & kNfHasUserDefined) &&
+                        h->model.pieces.size() <= kBpShortMaxVocab && !h->no_bp_short;
+  a->bp_short = bp_short ? 1u : 0u;
+  const uint32_t bpsz = bp_short ? 2u : 4u;
+  const uint32_t priv = StreamPrivateBytes(model, ring, bpsz);
   int waves = static_cast<int>((kLdsPerCu - kStreamSharedBytes) / priv);
   if (waves > 16) waves = 16;            // __launch_bounds__(1024)
   if (waves < 1) waves = 1;
@@ -430,7 +439,7 @@ StreamPlan PlanStream(const spmx_handle *h, EncodeArgs *a, const uint32_t *count
   // the slab of a wavefront must hold one lane of the largest class present: fewer wavefronts if the limit says so
   uint64_t need1 = 0;
   for (int c = c_lo; c < c_hi; ++c)
-    if (counts[c]) { const uint64_t b = StreamSlabBytes(tcap_of(c), ring, 0); if (b > need1) need1 = b; }
+    if (counts[c]) { const uint64_t b = StreamSlabBytes(tcap_of(c), ring, 0, bpsz); if (b > need1) need1 = b; }
   if (need1 && grid * waves * need1 > h->stream_scratch_limit) {
     uint64_t w = h->stream_scratch_limit / need1;
     if (w < 1) w = 1;
@@ -467,10 +476,10 @@ StreamPlan PlanStream(const spmx_handle *h, EncodeArgs *a, const uint32_t *count
     if (tw < 1) tw = 1;
     uint32_t sh = 0;                                   // lanes of a tile: enough for tw, as many as the budget allows
     while ((1ull << sh) < tw) ++sh;
-    while (sh > 0 && StreamSlabBytes(sc.tcap, ring, sh) > budget) --sh;
+    while (sh > 0 && StreamSlabBytes(sc.tcap, ring, sh, bpsz) > budget) --sh;
     if (tw > (1ull << sh)) tw = 1ull << sh;
     sc.lane_shift = sh;
-    const uint64_t slab = StreamSlabBytes(sc.tcap, ring, sh);
+    const uint64_t slab = StreamSlabBytes(sc.tcap, ring, sh, bpsz);
     if (slab > sp.slab_bytes) sp.slab_bytes = slab;
     sc.count = counts[c];
     sc.tw = static_cast<uint32_t>(tw);
@@ -488,7 +497,7 @@ StreamPlan PlanStream(const spmx_handle *h, EncodeArgs *a, const uint32_t *count
   a->slab_bytes = sp.slab_bytes;
   sp.grid = static_cast<int>(grid);
   sp.waves = waves;
-  sp.lds = StreamLdsBytes(model, ring, static_cast<uint32_t>(waves));
+  sp.lds = StreamLdsBytes(model, ring, static_cast<uint32_t>(waves), bpsz);
   return sp;
 }
 
@@ -1032,6 +1041,7 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_NO_FAST")) h->no_fast = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_STREAM")) h->no_stream = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_WAVE")) h->no_wave = e[0] == '1';
+    if (const char *e = getenv("SPMX_NO_BP_SHORT")) h->no_bp_short = e[0] == '1';
     if (const char *e = getenv("SPMX_WIDE_TCAP")) h->wide_tcap = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_LANE_GENERAL")) h->no_lane_general = e[0] == '1';
     if (const char *e = getenv("SPMX_SUB_BUCKETS")) {
@@ -1617,20 +1627,14 @@ int LatticeBatchHost(spmx_handle *h, const char *text, const uint64_t *offsets, 
     NBestArgs a{};
     a.dev = h->dev; a.norm = ws->d_norm.p; a.norm_offs = ws->d_id_offs.p; a.n = static_cast<uint32_t>(n); a.nbest = K;
     a.mode = static_cast<uint32_t>(mode); a.inv_theta = inv_theta; a.seed = seed;
-    uint64_t hyps = static_cast<uint64_t>(K) * 2048;
-    a.max_hyps = static_cast<uint32_t>(hyps < 16384 ? 16384 : (hyps > 262144 ? 262144 : hyps));
-    a.lane_bytes = (NbestLaneBytes(a.max_hyps) + 15) / 16 * 16;
-    uint64_t waves = (n + 63) / 64;
+    const uint64_t hyps0 = static_cast<uint64_t>(K) * 2048;
+    const uint32_t max_hyps0 = mode != 0 ? 512u : static_cast<uint32_t>(hyps0 < 16384 ? 16384 : (hyps0 > 262144 ? 262144 : hyps0));
     const uint64_t budget = 8ull << 30;                       // HBM for the lanes' slices
-    if (waves * 64 * a.lane_bytes > budget) waves = budget / (64 * a.lane_bytes);
-    if (waves > static_cast<uint64_t>(h->n_cu) * 8) waves = static_cast<uint64_t>(h->n_cu) * 8;
-    if (waves < 1) waves = 1;
-    HIP_OR_RETURN(h, ws->d_nbest_scratch.Reserve(waves * 64 * a.lane_bytes));
     HIP_OR_RETURN(h, ws->d_res_off.Reserve(n * K + 1));
     HIP_OR_RETURN(h, ws->d_span_begin.Reserve(n * K + 1));     // result lengths
     HIP_OR_RETURN(h, ws->d_res_score.Reserve(n * K + 1));
     HIP_OR_RETURN(h, ws->d_counts.Reserve(n + 1));
-    a.scratch = ws->d_nbest_scratch.p;
+    HIP_OR_RETURN(h, ws->d_lists.Reserve(2 * n + 2));          // the sentences beyond a launch's capacities (two lists, in turn)
     a.res_off = ws->d_res_off.p; a.res_len = ws->d_span_begin.p; a.res_score = ws->d_res_score.p; a.res_count = ws->d_counts.p;
     a.status = &ws->d_ctrl->status; a.arena_head = &ws->d_ctrl->arena_head;
     uint64_t arena_need = (ntotal + (4 + static_cast<uint64_t>(h->dev.n_prefix + h->dev.n_suffix)) * n) * (K < 8 ? K : 8) + 1024;
@@ -1638,12 +1642,60 @@ int LatticeBatchHost(spmx_handle *h, const char *text, const uint64_t *offsets, 
       HIP_OR_RETURN(h, ws->d_arena.Reserve(arena_need));
       a.arena = ws->d_arena.p; a.arena_cap = ws->d_arena.cap;
       HIP_OR_RETURN(h, hipMemsetAsync(ws->d_ctrl, 0, sizeof(Ctrl), st));
-      HIP_OR_RETURN(h, LaunchNBest(a, static_cast<int>(waves), st));
+      // first launch: every sentence, 16-bit lattice indices, fixed capacities
+      a.max_len = kNbMaxLen; a.max_nodes = kNbMaxNodes; a.max_hyps = max_hyps0;
+      a.lane_bytes = NbestLaneBytes(a.max_len, a.max_nodes, a.max_hyps, 2);
+      a.list = nullptr; a.n_list = 0;
+      a.retry_list = ws->d_lists.p; a.retry_count = &ws->d_ctrl->retry_count[0]; a.retry_max_len = &ws->d_ctrl->side.over_max_raw;
+      uint64_t waves = (n + 63) / 64;
+      if (waves * 64 * a.lane_bytes > budget) waves = budget / (64 * a.lane_bytes);
+      if (waves > static_cast<uint64_t>(h->n_cu) * 8) waves = static_cast<uint64_t>(h->n_cu) * 8;
+      if (waves < 1) waves = 1;
+      HIP_OR_RETURN(h, ws->d_nbest_scratch.Reserve(waves * 64 * a.lane_bytes));
+      a.scratch = ws->d_nbest_scratch.p;
+      HIP_OR_RETURN(h, LaunchNBest(false, a, static_cast<int>(waves), st));
       HIP_OR_RETURN(h, hipMemcpyAsync(ws->h_ctrl, ws->d_ctrl, offsetof(Ctrl, total_ids), hipMemcpyDeviceToHost, st));
       HIP_OR_RETURN(h, hipStreamSynchronize(st));
+      // further launches: 32-bit indices, capacities for the longest sentence set aside; a sentence whose A* needs more
+      // hypotheses than its slice holds is set aside again and the slice grows (the reference's agenda is unbounded too)
+      uint64_t hy_scale = 1;
+      for (int round = 0; ws->h_ctrl->retry_count[round & 1] && !(ws->h_ctrl->status & kStArenaOverflow); ++round) {
+        const uint32_t n_retry = ws->h_ctrl->retry_count[round & 1];
+        // A position starts at most max_prefixes pieces (the deepest chain of pieces that are prefixes of one another)
+        // and one UNK node.
+        const uint64_t L = ws->h_ctrl->side.over_max_raw > kNbMaxLen ? ws->h_ctrl->side.over_max_raw : kNbMaxLen;
+        const uint64_t nodes = (L + 2) * (static_cast<uint64_t>(h->tables.max_prefixes) + 1) + 2;
+        uint64_t hy = mode != 0 ? L / 4 + 512 : (static_cast<uint64_t>(K) * (L + 2) * 4 + 16384) * hy_scale;   // mode 1: alpha[L + 1] floats
+        if (hy < max_hyps0 * hy_scale) hy = max_hyps0 * hy_scale;
+        if (L >= (1ull << 31) || nodes >= (1ull << 32) || hy >= (1ull << 32)) return Fail(h, kOutOfRange, "a sentence is too long for the lattice");
+        a.max_len = static_cast<uint32_t>(L); a.max_nodes = static_cast<uint32_t>(nodes); a.max_hyps = static_cast<uint32_t>(hy);
+        a.lane_bytes = NbestLaneBytes(a.max_len, a.max_nodes, a.max_hyps, 4);
+        uint64_t lanes = budget / a.lane_bytes;
+        if (lanes < 1) return Fail(h, kResourceExhausted, "out of device memory for the lattice of a sentence of " + std::to_string(L) + " normalized bytes");
+        if (lanes > n_retry) lanes = n_retry;
+        uint64_t w2 = lanes / 64;                           // whole waves within the budget ...
+        const bool partial = w2 == 0;                       // ... or one partial wave: only its first `lanes` lanes own a slice
+        if (partial) w2 = 1;
+        if (w2 > static_cast<uint64_t>(h->n_cu) * 8) w2 = static_cast<uint64_t>(h->n_cu) * 8;
+        a.list = ws->d_lists.p + static_cast<size_t>(round & 1) * n; a.n_list = n_retry;
+        a.retry_list = ws->d_lists.p + static_cast<size_t>((round + 1) & 1) * n;
+        a.retry_count = &ws->d_ctrl->retry_count[(round + 1) & 1];
+        a.retry_max_len = &ws->d_ctrl->side.over_max_raw;
+        HIP_OR_RETURN(h, hipMemsetAsync(a.retry_count, 0, sizeof(uint32_t), st));
+        const uint64_t slices = partial ? lanes : w2 * 64;
+        HIP_OR_RETURN(h, ws->d_nbest_scratch.Reserve(slices * a.lane_bytes));
+        a.scratch = ws->d_nbest_scratch.p;
+        a.live_lanes = static_cast<uint32_t>(slices);
+        HIP_OR_RETURN(h, LaunchNBest(true, a, static_cast<int>(w2), st));
+        a.live_lanes = 0;
+        HIP_OR_RETURN(h, hipMemcpyAsync(ws->h_ctrl, ws->d_ctrl, offsetof(Ctrl, total_ids), hipMemcpyDeviceToHost, st));
+        HIP_OR_RETURN(h, hipStreamSynchronize(st));
+        hy_scale *= 4;
+        if (round == 9 && ws->h_ctrl->retry_count[(round + 1) & 1])
+          return Fail(h, kResourceExhausted, "NBestEncode: the agenda of a sentence exceeds the device capacities");
+      }
       const uint32_t stw = ws->h_ctrl->status;
-      if (stw & kStTooLong) return Fail(h, kOutOfRange, "NBestEncode on the device is limited to 1024 normalized bytes per sentence");
-      if (stw & kStNbestOverflow) return Fail(h, kResourceExhausted, "NBestEncode: the lattice or the agenda of a sentence exceeds the device capacities");
+      if (stw & kStNbestOverflow) return Fail(h, kResourceExhausted, "NBestEncode: the agenda of a sentence exceeds the device capacities");
       // (a lane stops at its first result that does not fit, so arena_head is a lower bound: grow geometrically)
       if (stw & kStArenaOverflow) { arena_need = 4 * ws->d_arena.cap > ws->h_ctrl->arena_head + 1024 ? 4 * ws->d_arena.cap : ws->h_ctrl->arena_head + 1024; continue; }
       // results -> host CSR

@@ -79,6 +79,7 @@ struct SpmxDev {
   uint32_t expand_max;
   // ---- unigram (reference: src/unigram_model.cc:889-1020) ----
   const U4 *ptrie;        // piece trie with inline id / flags / score
+  const uint8_t *plen;    // per id: the piece's byte length in the device form of the text (the short back-pointer form)
   float unk_score;        // min_score - 10.0f
   float max_score;
   int32_t unk_id;

@@ -90,6 +90,7 @@ struct EncodeArgs {
   uint32_t n;                   // sentences of the batch = stride of lists
   uint32_t n_classes;
   uint32_t total_main;          // sum of main_tiles
+  uint32_t bp_short;      // back-pointer entries are uint16 (kernels_stream.h BpShort)
   uint32_t ring;                // score ring entries (power of two > longest piece)
   uint32_t fast_ok;             // the model meets fast_norm_stream's preconditions
   uint32_t no_lane_general;     // A/B switch: ASCII tiles put every non-ASCII sentence into the backlog

@@ -21,6 +21,11 @@ __global__ __launch_bounds__(1024) void EncodeStreamKernel(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   encode_stream_block<1, RING, UDS>(a, smem);
 }
+// ring of 16, no user-defined pieces, 16-bit back-pointer entries (BpShort): 16 wavefronts per CU
+__global__ __launch_bounds__(1024) void EncodeStreamShortKernel(EncodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  encode_stream_block<1, 16, false, BpShort>(a, smem);
+}
 __global__ __launch_bounds__(1024) void EncodeBpeStreamKernel(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   encode_stream_block<2, 0, false>(a, smem);
@@ -55,7 +60,8 @@ __global__ __launch_bounds__(64) void NormalizeWriteKernel(NormalizeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   normalize_block<true>(a, smem);
 }
-__global__ __launch_bounds__(64) void NBestKernel(NBestArgs a) { nbest_block(a); }
+__global__ __launch_bounds__(64) void NBestKernel(NBestArgs a) { nbest_block<uint16_t>(a); }
+__global__ __launch_bounds__(64) void NBestWideKernel(NBestArgs a) { nbest_block<uint32_t>(a); }
 __global__ __launch_bounds__(64) void SplitCountKernel(SplitArgs a) { split_block<false>(a, nullptr); }
 __global__ __launch_bounds__(64) void SplitWriteKernel(SplitArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t stage[kSplitLdsBytes];
@@ -105,7 +111,7 @@ hipError_t LaunchEncode(int model_type, int cls, const EncodeArgs &a, int grid, 
 
 hipError_t LaunchEncodeStream(int model_type, bool uds, const EncodeArgs &a, int grid, int waves,
                               uint32_t lds_bytes, hipStream_t stream) {
-  EncodeFn fn = model_type == 2 ? EncodeBpeStreamKernel
+  EncodeFn fn = model_type == 2 ? EncodeBpeStreamKernel : a.bp_short ? EncodeStreamShortKernel
                                 : (a.ring == 16 ? (uds ? EncodeStreamKernel<16, true> : EncodeStreamKernel<16, false>)
                                                 : (uds ? EncodeStreamKernel<0, true> : EncodeStreamKernel<0, false>));
   if (lds_bytes > 64 * 1024) {
@@ -153,8 +159,9 @@ hipError_t LaunchNormalize(bool write, const NormalizeArgs &a, int grid, uint32_
   return hipGetLastError();
 }
 
-hipError_t LaunchNBest(const NBestArgs &a, int grid, hipStream_t stream) {
-  hipLaunchKernelGGL(NBestKernel, dim3(grid), dim3(64), 0, stream, a);
+hipError_t LaunchNBest(bool wide, const NBestArgs &a, int grid, hipStream_t stream) {
+  if (wide) hipLaunchKernelGGL(NBestWideKernel, dim3(grid), dim3(64), 0, stream, a);
+  else hipLaunchKernelGGL(NBestKernel, dim3(grid), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
 

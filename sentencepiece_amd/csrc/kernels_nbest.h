@@ -14,22 +14,27 @@
 
 namespace spmx {
 
-constexpr uint32_t kNbMaxLen = 1024;        // normalized (device) bytes per sentence
-constexpr uint32_t kNbMaxNodes = 16384;     // lattice nodes per sentence (node indices are 16-bit)
+// The first launch runs every sentence with 16-bit lattice indices under these capacities; what exceeds them is set
+// aside (NBestArgs::retry_list) and runs in a second launch with 32-bit indices and capacities sized for the longest
+// of them (api.cc LatticeBatchHost): no length limit.
+constexpr uint32_t kNbMaxLen = 1024;        // normalized (device) bytes per sentence, first launch
+constexpr uint32_t kNbMaxNodes = 16384;     // lattice nodes per sentence, first launch
 constexpr uint32_t kNbAgendaCap = 10000 + 512;   // :487 kMaxAgendaSize + the largest fan-in handled
 constexpr uint32_t kStNbestOverflow = 1u << 5;   // status: a per-sentence capacity was exceeded
 
-struct NbNode { uint16_t pos, length, byte_begin, byte_len; int32_t id; float score, backtrace; uint32_t prev; };   // 24 bytes
+template <typename IX>
+struct NbNodeT { IX pos, length, byte_begin, byte_len; int32_t id; float score, backtrace; uint32_t prev; };   // 24 / 32 bytes
 struct NbHyp { uint32_t next; uint32_t node; float fx, gx; };                                      // 16 bytes
 
-// bytes of one lane's slice for max_hyps hypotheses
-SPMX_HD inline uint64_t NbestLaneBytes(uint32_t max_hyps) {
-  return (kNbMaxLen + 2) * 2ull                  // surf: character starts
-       + kNbMaxNodes * sizeof(NbNode)            // nodes
-       + (kNbMaxLen + 3) * 4ull                  // end_off: CSR offsets of the nodes ending at a position
-       + kNbMaxNodes * 2ull                      // end_idx
-       + kNbMaxNodes * 2ull                      // scratch cursor per position (reuses u16 [kNbMaxLen + 2] actually)
-       + static_cast<uint64_t>(max_hyps) * sizeof(NbHyp)
+SPMX_HD inline uint64_t NbAlign16(uint64_t x) { return (x + 15u) & ~static_cast<uint64_t>(15); }
+// bytes of one lane's slice; ix = sizeof(IX)
+SPMX_HD inline uint64_t NbestLaneBytes(uint64_t max_len, uint64_t max_nodes, uint64_t max_hyps, uint32_t ix) {
+  return NbAlign16((max_len + 2) * ix)                       // surf: character starts
+       + NbAlign16(max_nodes * (4ull * ix + 16))             // nodes
+       + NbAlign16((max_len + 3) * 4ull)                     // end_off: CSR offsets of the nodes ending at a position
+       + NbAlign16(max_nodes * ix)                           // end_idx
+       + NbAlign16((max_len + 2) * ix)                       // cursor per position
+       + NbAlign16(max_hyps * sizeof(NbHyp))                 // hypotheses (mode 1: alpha, one float per position)
        + kNbAgendaCap * 4ull + 64;
 }
 
@@ -46,6 +51,13 @@ struct NBestArgs {
   uint8_t *scratch;             // [lanes of the launch][lane_bytes]
   uint64_t lane_bytes;
   uint32_t max_hyps;
+  uint32_t max_len, max_nodes;  // this launch's capacities (normalized bytes, lattice nodes)
+  const uint32_t *list;         // the sentences of this launch (null: 0 .. n - 1)
+  uint32_t n_list;
+  uint32_t live_lanes;          // lanes of the launch that own a slice (0: all)
+  uint32_t *retry_list;         // sentences beyond the capacities go here (null: they fail with kStNbestOverflow)
+  uint32_t *retry_count;
+  unsigned long long *retry_max_len;   // the longest of them (normalized bytes)
   int32_t *arena;               // ids of all results, allocated by atomics
   unsigned long long *arena_head;
   uint64_t arena_cap;
@@ -97,7 +109,9 @@ SPMX_DEVICE uint32_t nb_heap_pop(uint32_t *heap, uint32_t *hn, const NbHyp *hy) 
   return top;
 }
 
+template <typename IX>
 SPMX_DEVICE void nbest_lane(const NBestArgs &a, uint32_t s, uint8_t *mine) {
+  typedef NbNodeT<IX> NbNode;
   const SpmxDev &d = a.dev;
   const uint8_t *norm = a.norm + a.norm_offs[s];
   const int size = static_cast<int>(a.norm_offs[s + 1] - a.norm_offs[s]);
@@ -128,29 +142,39 @@ SPMX_DEVICE void nbest_lane(const NBestArgs &a, uint32_t s, uint8_t *mine) {
     a.res_count[s] = 1;
     return;
   }
-  if (static_cast<uint32_t>(size) > kNbMaxLen) { wv::atomic_or(a.status, kStTooLong); return; }
-  uint16_t *surf = reinterpret_cast<uint16_t *>(mine);
-  NbNode *nodes = reinterpret_cast<NbNode *>(mine + ((kNbMaxLen + 2) * 2 + 15) / 16 * 16);
-  uint32_t *end_off = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(nodes) + kNbMaxNodes * sizeof(NbNode));
-  uint16_t *end_idx = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(end_off) + (kNbMaxLen + 3) * 4);
-  uint16_t *cursor = end_idx + kNbMaxNodes;
-  NbHyp *hy = reinterpret_cast<NbHyp *>(reinterpret_cast<uint8_t *>(cursor) + ((kNbMaxNodes * 2 + 15) / 16 * 16));
-  uint32_t *heap = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(hy) + static_cast<uint64_t>(a.max_hyps) * sizeof(NbHyp));
+  // beyond this launch's capacities: to the second launch, or a failure when this is it
+  auto set_aside = [&]() {
+    if (a.retry_list) {
+      a.retry_list[wv::atomic_add(a.retry_count, 1u)] = s;
+      wv::atomic_max(a.retry_max_len, static_cast<unsigned long long>(size));
+    } else {
+      wv::atomic_or(a.status, kStNbestOverflow);
+    }
+  };
+  if (static_cast<uint32_t>(size) > a.max_len) { set_aside(); return; }
+  const uint64_t ML = a.max_len, MN = a.max_nodes;
+  IX *surf = reinterpret_cast<IX *>(mine);
+  NbNode *nodes = reinterpret_cast<NbNode *>(mine + NbAlign16((ML + 2) * sizeof(IX)));
+  uint32_t *end_off = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(nodes) + NbAlign16(MN * sizeof(NbNode)));
+  IX *end_idx = reinterpret_cast<IX *>(reinterpret_cast<uint8_t *>(end_off) + NbAlign16((ML + 3) * 4));
+  IX *cursor = reinterpret_cast<IX *>(reinterpret_cast<uint8_t *>(end_idx) + NbAlign16(MN * sizeof(IX)));
+  NbHyp *hy = reinterpret_cast<NbHyp *>(reinterpret_cast<uint8_t *>(cursor) + NbAlign16((ML + 2) * sizeof(IX)));
+  uint32_t *heap = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(hy) + NbAlign16(static_cast<uint64_t>(a.max_hyps) * sizeof(NbHyp)));
   // ---- SetSentence (:114-152): character starts ----
   int len = 0;
   for (int p = 0; p < size;) {
-    surf[len++] = static_cast<uint16_t>(p);
+    surf[len++] = static_cast<IX>(p);
     const uint32_t c = norm[p];
     int mb = c == spb ? 1 : OneCharLenDev(c);
     if (mb > size - p) mb = size - p;
     p += mb;
   }
-  surf[len] = static_cast<uint16_t>(size);
+  surf[len] = static_cast<IX>(size);
   // ---- PopulateNodes (:547-596).  Nodes 0 = BOS, 1 = EOS, then in insertion order (begin position, then length):
   // the order of end_nodes(pos) that Viterbi's "first best wins" and the A* expansion follow ----
   uint32_t n_nodes = 2;
   nodes[0] = NbNode{0, 0, 0, 0, -1, 0.f, 0.f, 0u};
-  nodes[1] = NbNode{static_cast<uint16_t>(len), 0, 0, 0, -1, 0.f, 0.f, 0u};
+  nodes[1] = NbNode{static_cast<IX>(len), 0, 0, 0, -1, 0.f, 0.f, 0u};
   const float unk_score = d.unk_score;                         // :555 min_score() - kUnkPenalty
   const uint32_t root = d.ptrie[0].x >> kDatBaseShiftDev;
   bool over = false;
@@ -169,20 +193,20 @@ SPMX_DEVICE void nbest_lane(const NBestArgs &a, uint32_t s, uint8_t *mine) {
       while (surf[pos_c] < kp) ++pos_c;
       const int length = pos_c - bp;
       if (u.y & kPtUnused) continue;                           // :576
-      if (n_nodes >= kNbMaxNodes) { over = true; break; }
+      if (n_nodes >= a.max_nodes) { over = true; break; }
       float sc = wv::bits_to_float(u.z);
       if (u.y & kPtUserDefined) sc = static_cast<float>(static_cast<double>(static_cast<float>(length) * d.max_score) - 0.1);   // :580
-      nodes[n_nodes++] = NbNode{static_cast<uint16_t>(bp), static_cast<uint16_t>(length), static_cast<uint16_t>(b0),
-                                static_cast<uint16_t>(surf[bp + length] - b0), static_cast<int32_t>(u.y & kPtIdMask), sc, 0.f, 0u};
+      nodes[n_nodes++] = NbNode{static_cast<IX>(bp), static_cast<IX>(length), static_cast<IX>(b0),
+                                static_cast<IX>(surf[bp + length] - b0), static_cast<int32_t>(u.y & kPtIdMask), sc, 0.f, 0u};
       if (length == 1) single = true;
     }
     if (!single && !over) {                                    // :589-593 the UNK node
-      if (n_nodes >= kNbMaxNodes) { over = true; break; }
-      nodes[n_nodes++] = NbNode{static_cast<uint16_t>(bp), 1, static_cast<uint16_t>(b0), static_cast<uint16_t>(surf[bp + 1] - b0),
+      if (n_nodes >= a.max_nodes) { over = true; break; }
+      nodes[n_nodes++] = NbNode{static_cast<IX>(bp), 1, static_cast<IX>(b0), static_cast<IX>(surf[bp + 1] - b0),
                                 d.unk_id, unk_score, 0.f, 0u};
     }
   }
-  if (over) { wv::atomic_or(a.status, kStNbestOverflow); return; }
+  if (over) { set_aside(); return; }
   // end_nodes as CSR over positions (insertion order within a position): BOS ends at 0
   for (int p = 0; p <= len + 1; ++p) end_off[p] = 0;
   end_off[0 + 1] = 1;
@@ -192,7 +216,7 @@ SPMX_DEVICE void nbest_lane(const NBestArgs &a, uint32_t s, uint8_t *mine) {
   end_idx[end_off[0] + cursor[0]++] = 0;
   for (uint32_t i = 2; i < n_nodes; ++i) {
     const int e = nodes[i].pos + nodes[i].length;
-    end_idx[end_off[e] + cursor[e]++] = static_cast<uint16_t>(i);
+    end_idx[end_off[e] + cursor[e]++] = static_cast<IX>(i);
   }
   // ---- Viterbi (:167-198): backtrace_score of every node, begin positions in order (nodes are sorted by pos) ----
   auto best_into = [&](int pos, float score, uint32_t *prev) -> float {      // first best left node wins (:171)
@@ -227,7 +251,7 @@ SPMX_DEVICE void nbest_lane(const NBestArgs &a, uint32_t s, uint8_t *mine) {
         const NbNode &x = nodes[h];
         const bool unk = x.id == d.unk_id;
         if (unk && bf) {
-          for (int t = 0; t < x.byte_len; ++t) {
+          for (uint32_t t = 0; t < x.byte_len; ++t) {
             const uint32_t b = norm[x.byte_begin + t];
             const int nbt = b == spb ? 3 : 1;
             for (int y = 0; y < nbt; ++y) {
@@ -342,7 +366,7 @@ SPMX_DEVICE void nbest_lane(const NBestArgs &a, uint32_t s, uint8_t *mine) {
           const NbNode &x = nodes[hy[h].node];
           const bool unk = x.id == d.unk_id;
           if (unk && bf) {
-            for (int t = 0; t < x.byte_len; ++t) {
+            for (uint32_t t = 0; t < x.byte_len; ++t) {
               const uint32_t b = norm[x.byte_begin + t];
               const int nbt = b == spb ? 3 : 1;
               for (int y = 0; y < nbt; ++y) {
@@ -365,7 +389,8 @@ SPMX_DEVICE void nbest_lane(const NBestArgs &a, uint32_t s, uint8_t *mine) {
     }
     const int pos = nodes[node].pos;
     const uint32_t fan = end_off[pos + 1] - end_off[pos];
-    if (n_hyp + fan > a.max_hyps || hn + fan > kNbAgendaCap) { wv::atomic_or(a.status, kStNbestOverflow); return; }
+    if (hn + fan > kNbAgendaCap) { wv::atomic_or(a.status, kStNbestOverflow); return; }
+    if (n_hyp + fan > a.max_hyps) { a.res_count[s] = 0; set_aside(); return; }      // again, with a larger hypothesis slice
     const float gx = hy[top].gx;
     for (uint32_t l = end_off[pos]; l < end_off[pos + 1]; ++l) {
       const uint32_t ln = end_idx[l];
@@ -376,7 +401,7 @@ SPMX_DEVICE void nbest_lane(const NBestArgs &a, uint32_t s, uint8_t *mine) {
     if (hn >= 10000u) {                                        // :487-514 keep the best min(512, 10 nbest)
       const uint32_t keep = a.nbest * 10u < 512u ? a.nbest * 10u : 512u;
       // pop the best `keep` into the (free) tail of the hypothesis slice, then rebuild the heap from them in that order
-      if (n_hyp + keep > a.max_hyps) { wv::atomic_or(a.status, kStNbestOverflow); return; }
+      if (n_hyp + keep > a.max_hyps) { a.res_count[s] = 0; set_aside(); return; }
       uint32_t *tmp = reinterpret_cast<uint32_t *>(hy + n_hyp);
       for (uint32_t i = 0; i < keep; ++i) tmp[i] = nb_heap_pop(heap, &hn, hy);
       hn = 0;
@@ -386,12 +411,16 @@ SPMX_DEVICE void nbest_lane(const NBestArgs &a, uint32_t s, uint8_t *mine) {
 }
 
 // Persistent body: lane l of wave w takes sentences w * 64 + l, + lanes of the launch, ...
+template <typename IX>
 SPMX_DEVICE void nbest_block(const NBestArgs &a) {
   const uint32_t lane_id = static_cast<uint32_t>(wv::block_id() * wv::waves_per_block() + wv::wave_in_block()) * 64u +
                            static_cast<uint32_t>(wv::lane());
-  const uint32_t lanes = static_cast<uint32_t>(wv::grid_size() * wv::waves_per_block()) * 64u;
+  const uint32_t lanes_all = static_cast<uint32_t>(wv::grid_size() * wv::waves_per_block()) * 64u;
   uint8_t *mine = a.scratch + static_cast<uint64_t>(lane_id) * a.lane_bytes;
-  for (uint32_t s = lane_id; s < a.n; s += lanes) nbest_lane(a, s, mine);
+  const uint32_t count = a.list ? a.n_list : a.n;
+  if (a.live_lanes) { if (lane_id >= a.live_lanes) return; }
+  const uint32_t lanes = a.live_lanes ? a.live_lanes : lanes_all;
+  for (uint32_t i = lane_id; i < count; i += lanes) nbest_lane<IX>(a, a.list ? a.list[i] : i, mine);
 }
 
 }  // namespace spmx

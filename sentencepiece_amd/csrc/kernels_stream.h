@@ -67,13 +67,41 @@ constexpr int kBwLenShift = 24;
 constexpr uint32_t kBwLenMask = 0x7Fu;
 constexpr uint32_t kBwIdMask = 0x00FFFFFFu;
 
+// Back-pointer entry of a position: which piece ends there.  Two forms, chosen per model at plan time:
+//   BpWord  (uint32)  id | length << 24 | UNK flag; 0 = not reached
+//   BpShort (uint16)  id + 1, or 0xFFFB + length for UNK (length 1..4); 0 = not reached.  The piece's length is not
+//                     stored: the backtrack reads it from SpmxDev::plen.  For vocabularies below 65531 ids and rings of
+//                     16: half the LDS of ring_b and of the staging block (16 instead of 12 wavefronts per CU) and half
+//                     the back-pointer bytes through HBM.
+struct BpWord {
+  typedef uint32_t T;
+  static SPMX_DEVICE T piece(uint32_t id_word, int len) { return (id_word & kBwIdMask) | (static_cast<uint32_t>(len) << kBwLenShift); }
+  static SPMX_DEVICE T unk(int len) { return (static_cast<uint32_t>(len) << kBwLenShift) | kBwUnk; }
+  static SPMX_DEVICE bool is_unk(T w) { return (w & kBwUnk) != 0; }
+  static SPMX_DEVICE int len(const SpmxDev &, T w) { return static_cast<int>((w >> kBwLenShift) & kBwLenMask); }
+  static SPMX_DEVICE int32_t id(T w) { return static_cast<int32_t>(w & kBwIdMask); }
+};
+struct BpShort {
+  typedef uint16_t T;
+  static SPMX_DEVICE T piece(uint32_t id_word, int) { return static_cast<T>((id_word & kBwIdMask) + 1u); }
+  static SPMX_DEVICE T unk(int len) { return static_cast<T>(0xFFFBu + static_cast<uint32_t>(len)); }
+  static SPMX_DEVICE bool is_unk(T w) { return w >= 0xFFFCu; }
+  static SPMX_DEVICE int len(const SpmxDev &d, T w) {
+    if (w == 0) return 0;
+    return w >= 0xFFFCu ? static_cast<int>(w) - 0xFFFB : static_cast<int>(d.plen[static_cast<uint32_t>(w) - 1u]);
+  }
+  static SPMX_DEVICE int32_t id(T w) { return static_cast<int32_t>(w) - 1; }
+};
+constexpr uint32_t kBpShortMaxVocab = 0xFFFAu;
+
 struct StreamLds {
   U4 *roottab;        // [256] first trie level (shared by the workgroup, read-only)
   uint8_t *bcls;      // [256] byte classes of the ASCII fast path (shared, read-only)
   float *ring_s;      // [R][64]
-  uint32_t *ring_b;   // [R][64]
+  uint32_t *ring_b;   // [R][64] back-pointer entries (uint16 in the short form)
   uint8_t *win;       // [64][W + 4]: lane l's window starts at win + l * (W + 4)
-  uint32_t *stage;    // [2][64][4]: final back-pointer words of the lane's current block of 8 positions
+  uint32_t *stage;    // final back-pointer entries of the lane's current block of 8 positions: [2][64][4] words, or
+                      // [64][8] uint16 in the short form
   uint32_t *backlog;  // [64] sentences waiting for a tile of their own (encode_stream_block)
   uint8_t *rawwin;    // [64][kRawWinBytes] raw-text windows of norm_lane_any (aliases the rings / the BPE word: idle
                       // while a tile is normalized)
@@ -87,37 +115,38 @@ struct StreamLds {
 // and the dword in flight
 SPMX_HD inline uint32_t StreamWindow(uint32_t ring) { uint32_t w = 32; while (w < ring + 6u) w <<= 1; return w; }
 // model: 1 unigram, 2 BPE
-SPMX_HD inline uint32_t StreamPrivateBytes(int model, uint32_t ring) {
+// bpsz: bytes of a back-pointer entry (4; 2 in the short form, see BpShort)
+SPMX_HD inline uint32_t StreamPrivateBytes(int model, uint32_t ring, uint32_t bpsz = 4u) {
   uint32_t work = model == 2 ? BpeWordLdsBytes() + 64u * (kBpeWindow + 4u)
-                             : 64u * ring * 8u + 64u * (StreamWindow(ring) + 4u) + 2u * 64u * 16u;
+                             : 64u * ring * (4u + bpsz) + 64u * (StreamWindow(ring) + 4u) + 64u * 8u * bpsz;
   if (work < 64u * kRawWinBytes) work = 64u * kRawWinBytes;
   return ((work + 15u) & ~15u) + 256u;                 // + the backlog
 }
-SPMX_HD inline uint32_t StreamLdsBytes(int model, uint32_t ring, uint32_t waves) {
-  return kStreamSharedBytes + waves * StreamPrivateBytes(model, ring);
+SPMX_HD inline uint32_t StreamLdsBytes(int model, uint32_t ring, uint32_t waves, uint32_t bpsz = 4u) {
+  return kStreamSharedBytes + waves * StreamPrivateBytes(model, ring, bpsz);
 }
 // HBM scratch of one tile whose text columns hold tcap bytes, for 1 << lane_shift lanes:
-//   uint32 text[StreamTextDwords(tcap, ring)][lanes]   then   uint32 bp[lanes][StreamBpStride(tcap)]
+//   uint32 text[StreamTextDwords(tcap, ring)][lanes]   then   bp[lanes][StreamBpStride(tcap)] (entries of bpsz bytes)
 SPMX_HD inline uint64_t StreamTextDwords(uint32_t tcap, uint32_t ring) {
   return static_cast<uint64_t>(tcap + 3) / 4 + StreamWindow(ring) / 4 + 4;
 }
 SPMX_HD inline uint32_t StreamBpStride(uint32_t tcap) { return (tcap + 16u) & ~7u; }   // words per lane, whole blocks of 8
-SPMX_HD inline uint64_t StreamSlabBytes(uint32_t tcap, uint32_t ring, uint32_t lane_shift) {
+SPMX_HD inline uint64_t StreamSlabBytes(uint32_t tcap, uint32_t ring, uint32_t lane_shift, uint32_t bpsz = 4u) {
   const uint64_t text = ((StreamTextDwords(tcap, ring) << lane_shift) * 4u + 31u) & ~static_cast<uint64_t>(31);
-  return text + (static_cast<uint64_t>(StreamBpStride(tcap)) << lane_shift) * 4u + 32u;
+  return text + (static_cast<uint64_t>(StreamBpStride(tcap)) << lane_shift) * bpsz + 32u;
 }
 
-SPMX_DEVICE StreamLds carve_stream(unsigned char *base, int model, uint32_t ring, int wave) {
+SPMX_DEVICE StreamLds carve_stream(unsigned char *base, int model, uint32_t ring, int wave, uint32_t bpsz = 4u) {
   StreamLds t;
   t.roottab = reinterpret_cast<U4 *>(base);
   t.asym = reinterpret_cast<uint32_t *>(base);
   t.bcls = base + 256u * 16u;
-  unsigned char *mine = base + kStreamSharedBytes + static_cast<uint32_t>(wave) * StreamPrivateBytes(model, ring);
-  t.backlog = reinterpret_cast<uint32_t *>(mine + StreamPrivateBytes(model, ring) - 256u);
+  unsigned char *mine = base + kStreamSharedBytes + static_cast<uint32_t>(wave) * StreamPrivateBytes(model, ring, bpsz);
+  t.backlog = reinterpret_cast<uint32_t *>(mine + StreamPrivateBytes(model, ring, bpsz) - 256u);
   t.rawwin = mine;
   t.ring_s = reinterpret_cast<float *>(mine);
   t.ring_b = reinterpret_cast<uint32_t *>(mine + 64u * ring * 4u);
-  t.win = mine + 64u * ring * 8u;
+  t.win = mine + 64u * ring * (4u + bpsz);
   t.stage = reinterpret_cast<uint32_t *>(t.win + 64u * (StreamWindow(ring) + 4u));
   t.bw.sym = reinterpret_cast<uint32_t *>(mine);
   t.bw.score = reinterpret_cast<float *>(mine + kBpeWordMax * 64u * 4u);
@@ -162,10 +191,12 @@ SPMX_DEVICE double piece_score_u(const U4 &u, int len, float max_score) {
 // into immediates); RING == 0: ANY size rm_in + 1 > the longest piece (slots by a running position-mod-R: the
 // distances involved are below R, so one conditional subtraction wraps them); the window mask is wmask_in.  UDS: the
 // model may have USER_DEFINED pieces.
-template <int RING, bool UDS>
-SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const TextCol &gt, uint32_t *gb, int nlen, float *ring_s,
-                                    uint32_t *ring_b, uint32_t rm_in, uint8_t *win, uint32_t wmask_in, uint32_t *st,
-                                    const U4 *roottab, bool active_in) {
+template <int RING, bool UDS, typename BP>
+SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const TextCol &gt, typename BP::T *gb, int nlen, float *ring_s,
+                                    typename BP::T *ring_b, uint32_t rm_in, uint8_t *win, uint32_t wmask_in,
+                                    typename BP::T *st, const U4 *roottab, bool active_in) {
+  typedef typename BP::T BT;
+  constexpr bool kShort = sizeof(BT) == 2;
   const uint32_t rm = RING ? static_cast<uint32_t>(RING - 1) : rm_in;
   const uint32_t wmask = RING ? StreamWindow(RING) - 1u : wmask_in;
   const uint32_t R = rm + 1u;
@@ -190,7 +221,7 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const TextCol &gt, uint32_
   bool pf_pend = false;
   uint32_t pf = 0;
   if (active) {
-    for (uint32_t k = 0; k <= rm; ++k) ring_b[k * 64] = 0u;
+    for (uint32_t k = 0; k <= rm; ++k) ring_b[k * 64] = 0;
     ring_s[0] = 0.f;                              // best_path_ends_at[0].best_path_score = 0
     for (int k = 0; k < W / 4; ++k) *reinterpret_cast<uint32_t *>(win + 4 * k) = gt.dw(k);
     nf = W / 4;
@@ -231,13 +262,13 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const TextCol &gt, uint32_
     const uint32_t oA = (RING ? (static_cast<uint32_t>(matchA ? eA : 0) & rm) : (matchA ? wrap(s_slot + static_cast<uint32_t>(dep1)) : 0u)) << 6;
     const uint32_t oB = slB << 6;
     const uint32_t oC = (RING ? (static_cast<uint32_t>(eC) & rm) : (eC != eB ? wrap(slB + 1u) : slB)) << 6;
-    uint32_t bA = ring_b[oA], bB = ring_b[oB], bC = ring_b[oC];
+    BT bA = ring_b[oA], bB = ring_b[oB], bC = ring_b[oC];
     float rA = ring_s[oA], rB = ring_s[oB], rC = ring_s[oC];
     // (A) the piece that just matched
     const double candA = piece_score_u<UDS>(uA, dep1, max_score) + static_cast<double>(sbest);  // :982-983
     const bool updA = termA && (bA == 0 || candA > static_cast<double>(rA));             // :984-989
     const float nvA = static_cast<float>(candA);
-    const uint32_t wA = (uA.y & kBwIdMask) | (static_cast<uint32_t>(dep1) << kBwLenShift);
+    const BT wA = BP::piece(uA.y, dep1);
     if (updA && eB == eA) { rB = nvA; bB = wA; }
     if (updA && eC == eA) { rC = nvA; bC = wA; }
     const bool single2 = single || (termA && dep1 == mb);                                // :990
@@ -245,25 +276,31 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const TextCol &gt, uint32_
     const float candB = unk_score + sbest;                                               // :997-1001, float
     const bool updB = ended && !single2 && (bB == 0 || candB > rB);
     const float sbest2 = updB ? candB : rB;
-    const uint32_t finB = updB ? ((static_cast<uint32_t>(mb) << kBwLenShift) | kBwUnk) : bB;
+    const BT finB = updB ? BP::unk(mb) : bB;
     // (C) a one-byte piece of the next start
     const double candC = piece_score_u<UDS>(r, 1, max_score) + static_cast<double>(sbest2);
     const bool updC = termC && (bC == 0 || candC > static_cast<double>(rC));
     if (updA) { ring_s[oA] = nvA; ring_b[oA] = wA; }
-    if (updC) { ring_s[oC] = static_cast<float>(candC); ring_b[oC] = (r.y & kBwIdMask) | (1u << kBwLenShift); }
+    if (updC) { ring_s[oC] = static_cast<float>(candC); ring_b[oC] = BP::piece(r.y, 1); }
     if (ended) {
       if ((s2 >> 3) != (s >> 3)) {                // the block of 8 positions behind s2 is complete
-        const Q4 lo = *reinterpret_cast<const Q4 *>(st), hi = *reinterpret_cast<const Q4 *>(st + 256);
-        uint32_t *blk = gb + ((s >> 3) << 3);
-        *reinterpret_cast<Q4 *>(blk) = lo;
-        *reinterpret_cast<Q4 *>(blk + 4) = hi;
+        BT *blk = gb + ((s >> 3) << 3);
+        if (kShort) {
+          *reinterpret_cast<Q4 *>(blk) = *reinterpret_cast<const Q4 *>(st);
+        } else {
+          const Q4 lo = *reinterpret_cast<const Q4 *>(st), hi = *reinterpret_cast<const Q4 *>(st + 256);
+          *reinterpret_cast<Q4 *>(blk) = lo;
+          *reinterpret_cast<Q4 *>(blk + 4) = hi;
+        }
       }
-      st[((static_cast<uint32_t>(eB) >> 2) & 1u) * 256u + (static_cast<uint32_t>(eB) & 3u)] = finB;   // position s2 is final
+      // position s2 is final
+      if (kShort) st[static_cast<uint32_t>(eB) & 7u] = finB;
+      else st[((static_cast<uint32_t>(eB) >> 2) & 1u) * 256u + (static_cast<uint32_t>(eB) & 3u)] = finB;
       // the positions just passed, (s, s2], are dead: free their ring slots (after this iteration's reads and writes)
-      if (mb > 0) ring_b[oB] = 0u;
+      if (mb > 0) ring_b[oB] = 0;
       if (mb > 1)                                  // a multi-byte character: its inner positions too (rare in ASCII text)
         for (int k = 1; k < mb; ++k)
-          ring_b[(RING ? (static_cast<uint32_t>(s2 - k) & rm) : (slB >= static_cast<uint32_t>(k) ? slB - static_cast<uint32_t>(k) : slB + R - static_cast<uint32_t>(k))) << 6] = 0u;
+          ring_b[(RING ? (static_cast<uint32_t>(s2 - k) & rm) : (slB >= static_cast<uint32_t>(k) ? slB - static_cast<uint32_t>(k) : slB + R - static_cast<uint32_t>(k))) << 6] = 0;
     }
     // ---------------- commit ----------------
     if (ended) {
@@ -288,10 +325,14 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const TextCol &gt, uint32_
     if (nwalking) cq = win[static_cast<uint32_t>(s + dep + 1) & wmask];
   }
   if (active_in && nlen > 0) {                    // the last block (it holds position nlen)
-    const Q4 lo = *reinterpret_cast<const Q4 *>(st), hi = *reinterpret_cast<const Q4 *>(st + 256);
-    uint32_t *blk = gb + ((nlen >> 3) << 3);
-    *reinterpret_cast<Q4 *>(blk) = lo;
-    *reinterpret_cast<Q4 *>(blk + 4) = hi;
+    BT *blk = gb + ((nlen >> 3) << 3);
+    if (kShort) {
+      *reinterpret_cast<Q4 *>(blk) = *reinterpret_cast<const Q4 *>(st);
+    } else {
+      const Q4 lo = *reinterpret_cast<const Q4 *>(st), hi = *reinterpret_cast<const Q4 *>(st + 256);
+      *reinterpret_cast<Q4 *>(blk) = lo;
+      *reinterpret_cast<Q4 *>(blk + 4) = hi;
+    }
   }
   return trips;
 }
@@ -301,7 +342,8 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const TextCol &gt, uint32_
 // forward order fills the slot from its END (ids end up in slot[cap - n, cap)), `reverse` fills it from the start.
 // Returns n, or -1 on a broken chain / overflow.
 // `tslot` (spans form, else null): the slot's twin in EncodeArgs::arena_tb, receives every token's begin.
-SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const TextCol &gt, const uint32_t *gb, int nlen, int32_t *slot,
+template <typename BP>
+SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const TextCol &gt, const typename BP::T *gb, int nlen, int32_t *slot,
                                  int32_t *tslot, int cap, bool active) {
   const bool bf = (d.flags & kNfByteFallback) != 0;
   const bool reverse = (d.flags & kNfReverse) != 0;
@@ -311,11 +353,11 @@ SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const TextCol &gt, const uint
   active = active && nlen > 0;
   while (wv::any(active)) {
     if (active) {
-      const uint32_t w = gb[e];
-      const int len = static_cast<int>((w >> kBwLenShift) & kBwLenMask);
+      const typename BP::T w = gb[e];
+      const int len = BP::len(d, w);
       if (len == 0 || len > e) { ok = false; active = false; continue; }
       const int tb = e - len;
-      if (w & kBwUnk) {
+      if (BP::is_unk(w)) {
         if (bf) {                                   // one BYTE id per byte of the unknown piece (:581-603)
           const bool sp = col_byte(gt, tb) == spb;
           const int nb = sp ? 3 : len;
@@ -338,7 +380,7 @@ SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const TextCol &gt, const uint
       } else {
         right_unk = false;
         if (n >= cap) { ok = false; active = false; continue; }
-        slot[reverse ? n : cap - 1 - n] = static_cast<int32_t>(w & kBwIdMask);
+        slot[reverse ? n : cap - 1 - n] = BP::id(w);
         if (tslot) tslot[reverse ? n : cap - 1 - n] = tb;
         ++n;
       }
@@ -375,16 +417,18 @@ SPMX_DEVICE void append_lanes(uint64_t m, bool mine, uint32_t sid, uint32_t *lis
 
 // Persistent body of the streaming kernels.  MODEL: 1 unigram, 2 BPE (word-wise models only).  RING: see
 // unigram_stream_lane (0 = a.ring).  UDS: the model may have USER_DEFINED pieces.
-template <int MODEL, int RING, bool UDS>
+template <int MODEL, int RING, bool UDS, typename BP = BpWord>
 SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
+  typedef typename BP::T BT;
+  constexpr uint32_t kBpSz = sizeof(BT);
   const int lane = wv::lane();
   const SpmxDev &d = a.dev;
   const uint32_t ring = RING ? static_cast<uint32_t>(RING) : a.ring;
-  const StreamLds T = carve_stream(smem, MODEL, ring, wv::wave_in_block());
+  const StreamLds T = carve_stream(smem, MODEL, ring, wv::wave_in_block(), kBpSz);
   const uint32_t rm = ring - 1;
   const uint32_t W = StreamWindow(ring);
   float *my_rs = T.ring_s + lane;
-  uint32_t *my_rb = T.ring_b + lane;
+  BT *my_rb = reinterpret_cast<BT *>(T.ring_b) + lane;
   uint8_t *my_win = T.win + static_cast<uint32_t>(lane) * (W + 4u);
   uint8_t *my_raw = T.rawwin + static_cast<uint32_t>(lane) * kRawWinBytes;
   {   // shared read-only tables; every wave writes all of both (same values): no workgroup barrier
@@ -407,7 +451,8 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
   }
   const uint32_t wave_id = static_cast<uint32_t>(wv::block_id() * wv::waves_per_block() + wv::wave_in_block());
   uint8_t *slab = a.slab + static_cast<uint64_t>(wave_id) * a.slab_bytes;
-  uint32_t *my_st = T.stage + static_cast<uint32_t>(lane) * 4u;
+  BT *my_st = kBpSz == 2 ? reinterpret_cast<BT *>(T.stage) + static_cast<uint32_t>(lane) * 8u
+                         : reinterpret_cast<BT *>(T.stage + static_cast<uint32_t>(lane) * 4u);
   const int n_extra = d.n_prefix + d.n_suffix;
   const bool bf_sp = (d.flags & kNfByteFallback) && (d.flags & kNfCompressSp);
   WaveCounters tc;
@@ -437,7 +482,7 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     // this tile's view of the wave's slab
     const uint64_t text_bytes = ((StreamTextDwords(tcap, ring) << lane_shift) * 4u + 31u) & ~static_cast<uint64_t>(31);
     const TextCol gt{reinterpret_cast<uint32_t *>(slab) + lane, lane_shift};
-    uint32_t *gb = reinterpret_cast<uint32_t *>(slab + text_bytes) + static_cast<uint64_t>(lane) * StreamBpStride(tcap);
+    BT *gb = reinterpret_cast<BT *>(slab + text_bytes) + static_cast<uint64_t>(lane) * StreamBpStride(tcap);
     const uint32_t *list = a.lists + static_cast<uint64_t>(c) * a.n;
     uint32_t my_sid = 0;
     uint64_t my_beg = 0;
@@ -525,10 +570,10 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     if (MODEL == 1) {
       // ---- segment, then backtrack: the slot is filled from its end (or from its start when reversing) ----
       tc.n_trips += static_cast<unsigned long long>(
-          unigram_stream_lane<RING, UDS>(d, gt, gb, my_nlen, my_rs, my_rb, rm, my_win, W - 1u, my_st, T.roottab, mine));
+          unigram_stream_lane<RING, UDS, BP>(d, gt, gb, my_nlen, my_rs, my_rb, rm, my_win, W - 1u, my_st, T.roottab, mine));
       c2 = wv::clock();
       if (!overflow) {
-        n = emit_stream_lane(d, gt, gb, my_nlen, slot, tslot, cap, mine);
+        n = emit_stream_lane<BP>(d, gt, gb, my_nlen, slot, tslot, cap, mine);
         at_end = (d.flags & kNfReverse) == 0;
       }
     } else {

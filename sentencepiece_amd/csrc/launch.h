@@ -41,7 +41,7 @@ hipError_t LaunchAlignLong(const AlignLongArgs &a, int grid, hipStream_t stream)
 hipError_t LaunchEncode(int model_type, int cls, const EncodeArgs &a, int grid, uint32_t lds_bytes, hipStream_t stream);
 hipError_t LaunchAlign(const AlignArgs &a, int grid, uint32_t lds_bytes, hipStream_t stream);
 hipError_t LaunchNormalize(bool write, const NormalizeArgs &a, int grid, uint32_t lds_bytes, hipStream_t stream);
-hipError_t LaunchNBest(const NBestArgs &a, int grid, hipStream_t stream);
+hipError_t LaunchNBest(bool wide, const NBestArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchSplit(bool write, const SplitArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchDecode(bool write, const DecodeArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchClassify(const ClassifyArgs &a, int grid, hipStream_t stream);

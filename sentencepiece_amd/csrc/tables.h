@@ -17,6 +17,7 @@ struct HostTables {
   std::vector<uint32_t> npair;   // 65536 bits, see SpmxDev::npair
   // unigram
   std::vector<U4> ptrie;
+  std::vector<uint8_t> plen;     // per id: byte length of the piece as the device sees it (SpmxDev::plen)
   // bpe
   std::vector<U2> utrie;
   std::vector<U4> chartab, pairtab, wordtab;

@@ -95,8 +95,14 @@ def ascii_corpus(n_sentences: int, seed: int = 20250227, words: WordList | None 
         workers = min(len(jobs), os.cpu_count() or 1, 32)
     if workers > 1 and len(jobs) > 1:
         import multiprocessing as mp
-        with mp.get_context("fork").Pool(workers) as pool:
+        # close + join, not the context manager: its terminate() SIGTERMs the workers, and under rocprofv3 (whose tool
+        # library the forked workers inherit) each one then runs the profiler's signal handler -- a --pmc pass hung there
+        pool = mp.get_context("fork").Pool(workers)
+        try:
             parts = pool.map(_ascii_job, jobs)
+        finally:
+            pool.close()
+            pool.join()
     else:
         parts = [_ascii_job(j) for j in jobs]
     text = np.concatenate([p[0] for p in parts]) if len(parts) > 1 else parts[0][0]

@@ -31,6 +31,8 @@ hipError_t LaunchEncodeStream(int model_type, bool uds, const EncodeArgs &a, int
                               uint32_t lds_bytes, hipStream_t) {
   if (model_type == 2) {
     RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<2, 0, false>(a, s); });
+  } else if (a.bp_short) {
+    RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<1, 16, false, BpShort>(a, s); });
   } else if (a.ring == 16) {
     if (uds) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<1, 16, true>(a, s); });
     else RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<1, 16, false>(a, s); });
@@ -67,8 +69,9 @@ hipError_t LaunchNormalize(bool write, const NormalizeArgs &a, int grid, uint32_
   else RunGrid(grid, 1, lds_bytes, [&](unsigned char *s) { normalize_block<false>(a, s); });
   return hipSuccess;
 }
-hipError_t LaunchNBest(const NBestArgs &a, int grid, hipStream_t) {
-  RunGrid(grid, 1, 0, [&](unsigned char *) { nbest_block(a); });
+hipError_t LaunchNBest(bool wide, const NBestArgs &a, int grid, hipStream_t) {
+  if (wide) RunGrid(grid, 1, 0, [&](unsigned char *) { nbest_block<uint32_t>(a); });
+  else RunGrid(grid, 1, 0, [&](unsigned char *) { nbest_block<uint16_t>(a); });
   return hipSuccess;
 }
 hipError_t LaunchSplit(bool write, const SplitArgs &a, int grid, hipStream_t) {

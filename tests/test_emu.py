@@ -128,7 +128,8 @@ def test_emu_lane_general_normalizer(model, corpus, k, env, emu, oracle, corpora
 
 @pytest.mark.parametrize("model", ["bpe1k", "bpe32k", "bpe1k_bf_uds", "bpe1k_noesc", "bpe1k_llama"])
 @pytest.mark.parametrize("env", [{}, {"SPMX_NO_WORDWISE": "1"}, {"SPMX_NO_COMPRESS": "1"}, {"SPMX_NO_FAST": "1"},
-                                 {"SPMX_NO_STREAM": "1"}, {"SPMX_NO_WAVE": "1"}])
+                                 {"SPMX_NO_STREAM": "1"}, {"SPMX_NO_WAVE": "1"}, {"SPMX_WORDTAB_MIN": "1"},
+                                 {"SPMX_NO_WORDTAB": "1"}])
 def test_emu_bpe_variants(model, env, emu, oracle, corpora, monkeypatch):
     """BPE: lane-per-sentence word-by-word form (word-wise models) vs sentence-per-wave form: same ids; sentences
     with a word longer than the lane form's slots take the long form."""

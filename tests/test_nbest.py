@@ -116,8 +116,13 @@ def test_emu_nbest_agenda_shrink_and_limits(emu, oracle):
             n, want, sc = nbest(o.lib.oracle_nbest_encode, o.h, sent, k)
             assert [r[0] for r in res] == want
             np.testing.assert_array_equal(np.array([r[1] for r in res], dtype=np.float32), sc)
-    with pytest.raises(RuntimeError):                      # beyond kNbMaxLen normalized bytes: status, no results
-        h.nbest(*synth.pack([b"word " * 400]), 4, grid=1)
+    # beyond the first launch's capacities (1024 normalized bytes / 16384 nodes): the wide launch, no length limit
+    long_sents = [b"word " * 400, b"a", (b"the quick brown fox jumps over the lazy dog " * 300)[:12000], s]
+    got = h.nbest(*synth.pack(long_sents), 4, grid=1)
+    for sent, res in zip(long_sents, got):
+        n, want, sc = nbest(o.lib.oracle_nbest_encode, o.h, sent, 4)
+        assert [r[0] for r in res] == want
+        np.testing.assert_array_equal(np.array([r[1] for r in res], dtype=np.float32), sc)
 
 
 # The device path on hardware (through the C ABI).

@@ -165,3 +165,24 @@ def test_python_encode_sampling_switch(emu):
     a = [tuple(h.Encode("hello world", enable_sampling=True, nbest_size=-1, alpha=0.1)) for _ in range(40)]
     assert len(set(a)) > 1
     assert h.Encode("hello world", enable_sampling=True, nbest_size=1, alpha=0.1) == h.Encode("hello world")
+
+
+def test_no_length_limit(emu, ref, oracle):
+    """Sentences beyond the first lattice launch's capacities (1024 normalized bytes) take the wide launch."""
+    from sentencepiece_amd import synth
+    blob = fixtures.model_blob("test_model")
+    h, r = emu.load(blob), ref.load(blob)
+    r.set_encoder_original()
+    sents = [(b"the quick brown fox jumps over the lazy dog " * 700)[:30000], b"short one", b"x" * 5000,
+             ("\u5409\u7965 caf\u00e9 " * 400).encode()]
+    text, offs = synth.pack(sents)
+    got = rows(*h.EncodeOriginalPacked(text, offs))
+    for s, g in zip(sents, got):
+        assert g == r.encode(s).tolist()
+    # a sampled segmentation of a long sentence is still a segmentation of it: it decodes to the same text
+    ids, io = h.SampleEncodePacked(text, offs, -1, 0.3, seed=4)
+    dt, do = h.DecodePacked(ids, io)
+    et, eo = h.DecodePacked(*h.EncodePacked(text, offs))
+    np.testing.assert_array_equal(do, eo)
+    np.testing.assert_array_equal(dt, et)
+    assert rows(ids, io) != rows(*h.EncodePacked(text, offs))
