@@ -189,7 +189,9 @@ int spmx_normalize_batch(spmx_handle *h, const char *text, const uint64_t *offse
  * only (INTERNAL otherwise, as the reference).  nbest_size is clamped to [1, 1024]; 1 is the plain encoder with
  * score 0.  Result r of the batch: ids[id_offsets[r], id_offsets[r + 1]) and scores[r]; sentence s owns the
  * results [result_offsets[s], result_offsets[s + 1]) (n + 1 entries), best first.  The four arrays are released
- * with spmx_free().  Sentences are limited to 8192 bytes and 1024 normalized bytes (OUT_OF_RANGE beyond). */
+ * with spmx_free().  No length limit: a sentence beyond the first launch's lattice capacities (1024 normalized bytes,
+ * 16384 nodes) runs in a second launch sized for it; RESOURCE_EXHAUSTED only where the device memory for one
+ * sentence's lattice and agenda runs out. */
 int spmx_nbest_encode_batch(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int nbest_size,
                             int32_t **ids, uint64_t **id_offsets, float **scores, uint64_t **result_offsets);
 
