@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <string>
 #include <string_view>
 #include <utility>
@@ -275,6 +276,57 @@ class SentencePieceProcessor {
     std::vector<std::vector<int>> ids;
     (void)NBestEncode(input, nbest_size, &ids);
     return ids;
+  }
+
+  // ---- sampling (sentencepiece_processor.h:333-334, .cc:678-720): lattice sampling / n-best sampling (unigram),
+  // BPE-dropout (BPE).  The draws are keyed by (seed, sentence); each call without a seed of its own takes the next
+  // value of a per-process counter, so repeated calls draw afresh as the reference's thread-local generator does ----
+  util::Status SampleEncode(std::string_view input, int nbest_size, float alpha, std::vector<int> *ids) const {
+    static std::atomic<uint64_t> calls{0};
+    return SampleEncode(input, nbest_size, alpha, ++calls, ids);
+  }
+  util::Status SampleEncode(std::string_view input, int nbest_size, float alpha, uint64_t seed, std::vector<int> *ids) const {
+    if (!h_) return status();
+    if (!ids) return util::Status(util::StatusCode::kInternal, "output container is null");
+    ids->clear();
+    const uint64_t offs[2] = {0, input.size()};
+    int32_t *i = nullptr;
+    uint64_t *io = nullptr;
+    const int rc = spmx_sample_encode_batch(h_, input.data() ? input.data() : "", offs, 1, nbest_size, alpha, seed, &i, &io);
+    if (rc == 0) ids->assign(i + io[0], i + io[1]);
+    spmx_free(i); spmx_free(io);
+    return FromHandle(rc);
+  }
+  std::vector<int> SampleEncodeAsIds(std::string_view input, int nbest_size, float alpha) const {   // errors are swallowed
+    std::vector<int> ids;
+    (void)SampleEncode(input, nbest_size, alpha, &ids);
+    return ids;
+  }
+  // batch form: sentence i draws from the generator keyed by (seed, i)
+  util::Status SampleEncodeBatchFlat(const char *text, const uint64_t *offsets, uint64_t n, int nbest_size, float alpha,
+                                     uint64_t seed, std::vector<int32_t> *ids, std::vector<uint64_t> *id_offsets) const {
+    if (!h_) return status();
+    if (!ids || !id_offsets) return util::Status(util::StatusCode::kInternal, "output container is null");
+    int32_t *i = nullptr;
+    uint64_t *io = nullptr;
+    const int rc = spmx_sample_encode_batch(h_, text, offsets, n, nbest_size, alpha, seed, &i, &io);
+    if (rc == 0) { id_offsets->assign(io, io + n + 1); ids->assign(i, i + io[n]); }
+    spmx_free(i); spmx_free(io);
+    return FromHandle(rc);
+  }
+  // The reference's kOriginal unigram encoder (Lattice::Viterbi, src/unigram_model.cc:161-198, :674-692; selected
+  // there by unigram::Model::SetEncoderVersion, src/unigram_model.h:176-186).
+  util::Status EncodeOriginal(std::string_view input, std::vector<int> *ids) const {
+    if (!h_) return status();
+    if (!ids) return util::Status(util::StatusCode::kInternal, "output container is null");
+    ids->clear();
+    const uint64_t offs[2] = {0, input.size()};
+    int32_t *i = nullptr;
+    uint64_t *io = nullptr;
+    const int rc = spmx_encode_batch_original(h_, input.data() ? input.data() : "", offs, 1, &i, &io);
+    if (rc == 0) ids->assign(i + io[0], i + io[1]);
+    spmx_free(i); spmx_free(io);
+    return FromHandle(rc);
   }
 
   // ---- Normalize (sentencepiece_processor.h:622-631) ----

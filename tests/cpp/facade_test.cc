@@ -66,6 +66,18 @@ int main(int argc, char **argv) {
     for (size_t k = 0; k < batch[i].size(); ++k) os << (k ? " " : "") << batch[i][k];
     std::cout << os.str() << "\n";
   }
+  {   // sampling: nbest_size 0 / 1 is Encode; a sampled segmentation decodes to the same text; the kOriginal encoder
+    const std::string &probe = lines.size() > 7 ? lines[7] : lines[0];
+    std::vector<int> plain, same, drawn, orig;
+    if (!sp.Encode(probe, &plain).ok() || !sp.SampleEncode(probe, 1, 0.5f, &same).ok() || same != plain) { fprintf(stderr, "SampleEncode(nbest 1)\n"); return 1; }
+    if (!sp.SampleEncode(probe, -1, 0.2f, 99, &drawn).ok()) { fprintf(stderr, "SampleEncode\n"); return 1; }
+    std::string t1, t2;
+    if (!sp.Decode(plain, &t1).ok() || !sp.Decode(drawn, &t2).ok() || t1 != t2) { fprintf(stderr, "sampled ids decode differently\n"); return 1; }
+    std::vector<int> again;
+    if (!sp.SampleEncode(probe, -1, 0.2f, 99, &again).ok() || again != drawn) { fprintf(stderr, "seeded draw is not reproducible\n"); return 1; }
+    const sentencepiece::util::Status so = sp.EncodeOriginal(probe, &orig);   // unigram only (INTERNAL for BPE, like NBestEncode)
+    if (so.ok()) { std::string t3; if (!sp.Decode(orig, &t3).ok() || t3 != t1) { fprintf(stderr, "EncodeOriginal\n"); return 1; } }
+  }
   if (sp.GetPieceSize() <= 0 || sp.IdToPiece(sp.unk_id()).empty() || sp.PieceToId(sp.IdToPiece(5)) != 5) { fprintf(stderr, "vocab accessors\n"); return 1; }
   if (sp.Encode("x", static_cast<std::vector<int> *>(nullptr)).ok()) { fprintf(stderr, "null output accepted\n"); return 1; }
   return 0;
