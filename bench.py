@@ -286,6 +286,7 @@ def main():
         cls = prof[-1]["classes"][dom]
         achieved = cls["bytes"] / (k_ms[dom] * 1e-3) / 1e9 if k_ms[dom] > 0 else 0.0
         traffic, traffic_note = None, "no PMC pass on record for this model / size / kernel"
+        traffic_lower = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         kname = cls["kernel"]
         sha = kernel_sources_sha()
@@ -295,6 +296,7 @@ def main():
             if isinstance(rec, dict):
                 if rec.get("src_sha") == sha:
                     traffic, traffic_note = rec.get("bytes"), rec.get("note", "profiles/pmc_traffic.json, made from these kernel sources")
+                    traffic_lower = rec.get("bytes_lower")
                 else:
                     traffic_note = "profiles/pmc_traffic.json is from other kernel sources (%s, now %s): not used" % (rec.get("src_sha"), sha)
         out = {
@@ -321,6 +323,7 @@ def main():
                        "timed_loop": "profiling off; roofline.* comes from a second loop of the same steps with HIP events on"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                         "traffic_uncorrected": traffic_lower,
                          "kernel_sources_sha": sha, "kernel": kname,
                          "kernel_ms": k_ms[dom], "algorithmic_bytes_per_launch": cls["bytes"],
                          "sentences_per_launch": cls["sentences"],

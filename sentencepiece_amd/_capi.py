@@ -99,10 +99,11 @@ def lib():
     """Loads libspmx.so once.  Raises if it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("SPMX_LIB") or LIB_PATH       # SPMX_LIB: an A/B build of the same library (csrc/Makefile `variants`)
+        if not os.path.exists(path):
             raise RuntimeError(
                 "%s is missing: build it with `make -C sentencepiece_amd/csrc` "
-                "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+                "(or __graft_entry__.build()); there is no CPU fallback" % path)
         # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 / HSA runtime under torch/lib, libspmx
         # resolves /opt/rocm's.  If libspmx initialises HIP first, a later torch.cuda init finds "No HIP GPUs"
         # (seen on the MI355X box); with torch's libraries loaded first both share them.  The device-resident forms
@@ -112,5 +113,5 @@ def lib():
                 import torch  # noqa: F401
             except ImportError:
                 pass
-        _lib = bind(LIB_PATH)
+        _lib = bind(path)
     return _lib

@@ -614,7 +614,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       const uint64_t slab_total = static_cast<uint64_t>(sp.grid) * sp.waves * sp.slab_bytes;
       HIP_OR_RETURN(h, ws->d_slab.Reserve(slab_total));
       la.slab = ws->d_slab.p;
-      snprintf(ws->slot_name[slot], sizeof(ws->slot_name[slot]), "%s", is_bpe ? "EncodeBpeStreamKernel"
+      snprintf(ws->slot_name[slot], sizeof(ws->slot_name[slot]), "%s", is_bpe ? "EncodeBpeStreamKernel" : la.bp_short ? "EncodeStreamShortKernel"
                : (la.ring == 16 ? (uds ? "EncodeStreamKernel<16, true>" : "EncodeStreamKernel<16, false>")
                                 : (uds ? "EncodeStreamKernel<0, true>" : "EncodeStreamKernel<0, false>")));
       HIP_OR_RETURN(h, record(slot, 0));

@@ -93,6 +93,18 @@ struct BpShort {
   static SPMX_DEVICE int32_t id(T w) { return static_cast<int32_t>(w) - 1; }
 };
 constexpr uint32_t kBpShortMaxVocab = 0xFFFAu;
+// A lane's view of its tile's back-pointer array: blocks of 8 positions, block k of lane l at [(k << sh) + l] --
+// position-major like the text, because the lanes of a tile advance together: the 64 blocks k of a tile are one
+// contiguous run (1 KB short form, 2 KB word form) that the lanes write within a few iterations of each other and the
+// backtrack reads the same way.  (Lane-major rows kept one open cache line per LANE for 64 positions: the L2 of an XCD
+// is about as large as the open lines of its resident lanes, so lines left for memory half written, several times.)
+template <typename BT>
+struct BpCol {
+  BT *p;            // + lane * 8 already
+  uint32_t sh;
+  SPMX_DEVICE BT *blk(int k) const { return p + ((static_cast<uint64_t>(static_cast<uint32_t>(k)) << sh) << 3); }
+  SPMX_DEVICE BT at(int pos) const { return blk(pos >> 3)[pos & 7]; }
+};
 
 struct StreamLds {
   U4 *roottab;        // [256] first trie level (shared by the workgroup, read-only)
@@ -126,7 +138,7 @@ SPMX_HD inline uint32_t StreamLdsBytes(int model, uint32_t ring, uint32_t waves,
   return kStreamSharedBytes + waves * StreamPrivateBytes(model, ring, bpsz);
 }
 // HBM scratch of one tile whose text columns hold tcap bytes, for 1 << lane_shift lanes:
-//   uint32 text[StreamTextDwords(tcap, ring)][lanes]   then   bp[lanes][StreamBpStride(tcap)] (entries of bpsz bytes)
+//   uint32 text[StreamTextDwords(tcap, ring)][lanes]   then   bp[StreamBpStride(tcap) / 8][lanes][8] (entries of bpsz bytes)
 SPMX_HD inline uint64_t StreamTextDwords(uint32_t tcap, uint32_t ring) {
   return static_cast<uint64_t>(tcap + 3) / 4 + StreamWindow(ring) / 4 + 4;
 }
@@ -185,14 +197,14 @@ SPMX_DEVICE double piece_score_u(const U4 &u, int len, float max_score) {
 //   * when the start moves from s to s2, position s2's back-pointer word is final: it goes to the lane's staging
 //     block st[] (position p at st[((p >> 2) & 1) * 256 + (p & 3)]), the block of 8 positions that s2 leaves behind
 //     is written to gb[] as two 16-byte stores, and the ring slots of the positions (s, s2] are cleared for the
-//     positions that will reuse them R later.  gb[] is this lane's row: gb[p] for position p.
+//     positions that will reuse them R later.  gb is this lane's view of the tile's back-pointer blocks (BpCol).
 // Returns the number of iterations (wave-uniform).
 // RING > 0: the ring size is a compile-time power of two (index masks and the distances between the LDS arrays fold
 // into immediates); RING == 0: ANY size rm_in + 1 > the longest piece (slots by a running position-mod-R: the
 // distances involved are below R, so one conditional subtraction wraps them); the window mask is wmask_in.  UDS: the
 // model may have USER_DEFINED pieces.
 template <int RING, bool UDS, typename BP>
-SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const TextCol &gt, typename BP::T *gb, int nlen, float *ring_s,
+SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const TextCol &gt, const BpCol<typename BP::T> &gb, int nlen, float *ring_s,
                                     typename BP::T *ring_b, uint32_t rm_in, uint8_t *win, uint32_t wmask_in,
                                     typename BP::T *st, const U4 *roottab, bool active_in) {
   typedef typename BP::T BT;
@@ -284,13 +296,13 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const TextCol &gt, typenam
     if (updC) { ring_s[oC] = static_cast<float>(candC); ring_b[oC] = BP::piece(r.y, 1); }
     if (ended) {
       if ((s2 >> 3) != (s >> 3)) {                // the block of 8 positions behind s2 is complete
-        BT *blk = gb + ((s >> 3) << 3);
+        BT *blk = gb.blk(s >> 3);
         if (kShort) {
-          *reinterpret_cast<Q4 *>(blk) = *reinterpret_cast<const Q4 *>(st);
+          wv::store_q4<4>(blk, *reinterpret_cast<const Q4 *>(st));
         } else {
           const Q4 lo = *reinterpret_cast<const Q4 *>(st), hi = *reinterpret_cast<const Q4 *>(st + 256);
-          *reinterpret_cast<Q4 *>(blk) = lo;
-          *reinterpret_cast<Q4 *>(blk + 4) = hi;
+          wv::store_q4<4>(blk, lo);
+          wv::store_q4<4>(blk + 4, hi);
         }
       }
       // position s2 is final
@@ -325,7 +337,7 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const TextCol &gt, typenam
     if (nwalking) cq = win[static_cast<uint32_t>(s + dep + 1) & wmask];
   }
   if (active_in && nlen > 0) {                    // the last block (it holds position nlen)
-    BT *blk = gb + ((nlen >> 3) << 3);
+    BT *blk = gb.blk(nlen >> 3);
     if (kShort) {
       *reinterpret_cast<Q4 *>(blk) = *reinterpret_cast<const Q4 *>(st);
     } else {
@@ -338,12 +350,12 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const TextCol &gt, typenam
 }
 
 // Backtrack (:1010-1018) + id post-processing (sentencepiece_processor.cc:581-613) of this lane's sentence:
-// follows the lane's row gb[] from position nlen to 0 and writes the ids as it goes, last piece first, into slot[0, cap):
+// follows the lane's back-pointer entries gb from position nlen to 0 and writes the ids as it goes, last piece first, into slot[0, cap):
 // forward order fills the slot from its END (ids end up in slot[cap - n, cap)), `reverse` fills it from the start.
 // Returns n, or -1 on a broken chain / overflow.
 // `tslot` (spans form, else null): the slot's twin in EncodeArgs::arena_tb, receives every token's begin.
 template <typename BP>
-SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const TextCol &gt, const typename BP::T *gb, int nlen, int32_t *slot,
+SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const TextCol &gt, const BpCol<typename BP::T> &gb, int nlen, int32_t *slot,
                                  int32_t *tslot, int cap, bool active) {
   const bool bf = (d.flags & kNfByteFallback) != 0;
   const bool reverse = (d.flags & kNfReverse) != 0;
@@ -353,7 +365,7 @@ SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const TextCol &gt, const type
   active = active && nlen > 0;
   while (wv::any(active)) {
     if (active) {
-      const typename BP::T w = gb[e];
+      const typename BP::T w = gb.at(e);
       const int len = BP::len(d, w);
       if (len == 0 || len > e) { ok = false; active = false; continue; }
       const int tb = e - len;
@@ -380,7 +392,7 @@ SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const TextCol &gt, const type
       } else {
         right_unk = false;
         if (n >= cap) { ok = false; active = false; continue; }
-        slot[reverse ? n : cap - 1 - n] = BP::id(w);
+        wv::store_nt<2>(&slot[reverse ? n : cap - 1 - n], BP::id(w));
         if (tslot) tslot[reverse ? n : cap - 1 - n] = tb;
         ++n;
       }
@@ -482,7 +494,7 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     // this tile's view of the wave's slab
     const uint64_t text_bytes = ((StreamTextDwords(tcap, ring) << lane_shift) * 4u + 31u) & ~static_cast<uint64_t>(31);
     const TextCol gt{reinterpret_cast<uint32_t *>(slab) + lane, lane_shift};
-    BT *gb = reinterpret_cast<BT *>(slab + text_bytes) + static_cast<uint64_t>(lane) * StreamBpStride(tcap);
+    const BpCol<BT> gb{reinterpret_cast<BT *>(slab + text_bytes) + static_cast<uint32_t>(lane) * 8u, lane_shift};
     const uint32_t *list = a.lists + static_cast<uint64_t>(c) * a.n;
     uint32_t my_sid = 0;
     uint64_t my_beg = 0;
