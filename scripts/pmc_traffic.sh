@@ -4,7 +4,7 @@
 TAG=${1:-r02}; N=${2:-10000000}; MODEL=${3:-uni32k}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$TAG; mkdir -p $O
-for C in FETCH_SIZE WRITE_SIZE; do
+for C in ${COUNTERS:-FETCH_SIZE WRITE_SIZE}; do
   timeout ${PASS_TIMEOUT:-200} rocprofv3 --kernel-trace --pmc $C -d $O/pmc_$C -o pmc -- python bench.py --model $MODEL --sentences $N --steps 2 --warmup 1 --no-cpu-baseline --no-second-model > $O/pmc_$C.log 2>&1
   echo "$C rc=$?"
 done

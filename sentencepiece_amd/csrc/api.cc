@@ -421,8 +421,8 @@ StreamPlan PlanStream(const spmx_handle *h, EncodeArgs *a, const uint32_t *count
   const int model = h->model.model_type;
   const uint32_t ring = HandleRing(h);
   a->ring = ring;
-  // the short back-pointer form (kernels_stream.h BpShort): unigram, ring of 16, no user-defined pieces, ids that fit
-  const bool bp_short = model == kUnigram && ring == 16 && !(h->dev.flags & kNfHasUserDefined) &&
+  // the short back-pointer form (kernels_stream.h BpShort): unigram, no user-defined pieces, ids that fit
+  const bool bp_short = model == kUnigram && !(h->dev.flags & kNfHasUserDefined) &&
                         h->model.pieces.size() <= kBpShortMaxVocab && !h->no_bp_short;
   a->bp_short = bp_short ? 1u : 0u;
   const uint32_t bpsz = bp_short ? 2u : 4u;
@@ -614,7 +614,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       const uint64_t slab_total = static_cast<uint64_t>(sp.grid) * sp.waves * sp.slab_bytes;
       HIP_OR_RETURN(h, ws->d_slab.Reserve(slab_total));
       la.slab = ws->d_slab.p;
-      snprintf(ws->slot_name[slot], sizeof(ws->slot_name[slot]), "%s", is_bpe ? "EncodeBpeStreamKernel" : la.bp_short ? "EncodeStreamShortKernel"
+      snprintf(ws->slot_name[slot], sizeof(ws->slot_name[slot]), "%s", is_bpe ? "EncodeBpeStreamKernel" : la.bp_short ? (la.ring == 16 ? "EncodeStreamShortKernel<16>" : "EncodeStreamShortKernel<0>")
                : (la.ring == 16 ? (uds ? "EncodeStreamKernel<16, true>" : "EncodeStreamKernel<16, false>")
                                 : (uds ? "EncodeStreamKernel<0, true>" : "EncodeStreamKernel<0, false>")));
       HIP_OR_RETURN(h, record(slot, 0));

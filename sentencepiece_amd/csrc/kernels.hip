@@ -21,10 +21,11 @@ __global__ __launch_bounds__(1024) void EncodeStreamKernel(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   encode_stream_block<1, RING, UDS>(a, smem);
 }
-// ring of 16, no user-defined pieces, 16-bit back-pointer entries (BpShort): 16 wavefronts per CU
+// no user-defined pieces, 16-bit back-pointer entries (BpShort): 16 wavefronts per CU at a ring of 16
+template <int RING>
 __global__ __launch_bounds__(1024) void EncodeStreamShortKernel(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  encode_stream_block<1, 16, false, BpShort>(a, smem);
+  encode_stream_block<1, RING, false, BpShort>(a, smem);
 }
 __global__ __launch_bounds__(1024) void EncodeBpeStreamKernel(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -111,7 +112,7 @@ hipError_t LaunchEncode(int model_type, int cls, const EncodeArgs &a, int grid, 
 
 hipError_t LaunchEncodeStream(int model_type, bool uds, const EncodeArgs &a, int grid, int waves,
                               uint32_t lds_bytes, hipStream_t stream) {
-  EncodeFn fn = model_type == 2 ? EncodeBpeStreamKernel : a.bp_short ? EncodeStreamShortKernel
+  EncodeFn fn = model_type == 2 ? EncodeBpeStreamKernel : a.bp_short ? (a.ring == 16 ? EncodeStreamShortKernel<16> : EncodeStreamShortKernel<0>)
                                 : (a.ring == 16 ? (uds ? EncodeStreamKernel<16, true> : EncodeStreamKernel<16, false>)
                                                 : (uds ? EncodeStreamKernel<0, true> : EncodeStreamKernel<0, false>));
   if (lds_bytes > 64 * 1024) {

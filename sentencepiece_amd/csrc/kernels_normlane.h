@@ -102,10 +102,10 @@ SPMX_DEVICE int fast_norm_stream(const SpmxDev &d, const uint8_t *gtext, uint64_
   const uintptr_t a0 = reinterpret_cast<uintptr_t>(first) & ~static_cast<uintptr_t>(15);
   const uint8_t *blk = reinterpret_cast<const uint8_t *>(a0);
   int rel = static_cast<int>(static_cast<long long>(a0) - static_cast<long long>(reinterpret_cast<uintptr_t>(first)));   // index of the block's first byte within the sentence (<= 0 at first)
-  Q4 cur = wv::load_q4<1, Q4>(blk);
+  Q4 cur = *reinterpret_cast<const Q4 *>(blk);
   while (rel < L) {
     Q4 nxt = cur;
-    if (rel + 16 < L) nxt = wv::load_q4<1, Q4>(blk + 16);
+    if (rel + 16 < L) nxt = *reinterpret_cast<const Q4 *>(blk + 16);
     const uint32_t wd[8] = {cur.x, cur.y, cur.z, cur.w, nxt.x, nxt.y, nxt.z, nxt.w};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -121,7 +121,7 @@ SPMX_DEVICE int fast_norm_stream(const SpmxDev &d, const uint8_t *gtext, uint64_
               acc |= (is_sp ? sp : c) << (8 * (w & 3));
               ++w;
               nsp += is_sp ? 1 : 0;
-              if ((w & 3) == 0) { wv::store_nt<8>(&gt.dw((w >> 2) - 1), acc); acc = 0; }
+              if ((w & 3) == 0) { if (!(SPMX_EXP & 4)) gt.dw((w >> 2) - 1) = acc; acc = 0; }
             }
             P = is_sp && rm;                        // :154-162
             if (!is_sp) { wl = w; seen = true; }
@@ -142,7 +142,7 @@ SPMX_DEVICE int fast_norm_stream(const SpmxDev &d, const uint8_t *gtext, uint64_
                 acc |= (is_sp ? sp : c) << (8 * (w & 3));
                 ++w;
                 nsp += is_sp ? 1 : 0;
-                if ((w & 3) == 0) { wv::store_nt<8>(&gt.dw((w >> 2) - 1), acc); acc = 0; }
+                if ((w & 3) == 0) { if (!(SPMX_EXP & 4)) gt.dw((w >> 2) - 1) = acc; acc = 0; }
               }
               P = is_sp && rm;
               if (!is_sp) { wl = w; seen = true; }
@@ -186,7 +186,7 @@ SPMX_DEVICE int fast_norm_stream(const SpmxDev &d, const uint8_t *gtext, uint64_
                   if (j < n_out) {
                     acc |= (j == 0 ? o0 : (j == 1 ? o1 : o2)) << (8 * (w & 3));
                     ++w;
-                    if ((w & 3) == 0) { wv::store_nt<8>(&gt.dw((w >> 2) - 1), acc); acc = 0; }
+                    if ((w & 3) == 0) { if (!(SPMX_EXP & 4)) gt.dw((w >> 2) - 1) = acc; acc = 0; }
                   }
                 }
               }

@@ -297,12 +297,13 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const TextCol &gt, const B
     if (ended) {
       if ((s2 >> 3) != (s >> 3)) {                // the block of 8 positions behind s2 is complete
         BT *blk = gb.blk(s >> 3);
-        if (kShort) {
-          wv::store_q4<4>(blk, *reinterpret_cast<const Q4 *>(st));
+        if (SPMX_EXP & 2) {
+        } else if (kShort) {
+          *reinterpret_cast<Q4 *>(blk) = *reinterpret_cast<const Q4 *>(st);
         } else {
           const Q4 lo = *reinterpret_cast<const Q4 *>(st), hi = *reinterpret_cast<const Q4 *>(st + 256);
-          wv::store_q4<4>(blk, lo);
-          wv::store_q4<4>(blk + 4, hi);
+          *reinterpret_cast<Q4 *>(blk) = lo;
+          *reinterpret_cast<Q4 *>(blk + 4) = hi;
         }
       }
       // position s2 is final
@@ -392,7 +393,7 @@ SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const TextCol &gt, const BpCo
       } else {
         right_unk = false;
         if (n >= cap) { ok = false; active = false; continue; }
-        wv::store_nt<2>(&slot[reverse ? n : cap - 1 - n], BP::id(w));
+        if (!(SPMX_EXP & 1)) slot[reverse ? n : cap - 1 - n] = BP::id(w);
         if (tslot) tslot[reverse ? n : cap - 1 - n] = tb;
         ++n;
       }

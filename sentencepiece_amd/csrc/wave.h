@@ -70,31 +70,12 @@ SPMX_DEVICE int clz64(uint64_t x) { return __clzll(static_cast<long long>(x)); }
 SPMX_DEVICE float bits_to_float(uint32_t u) { return __uint_as_float(u); }
 SPMX_DEVICE uint32_t float_to_bits(float f) { return __float_as_uint(f); }
 
-// Non-temporal variants of the streaming accesses, compiled in by -DSPMX_NT_MASK=<bits> (A/B builds; 0 = plain):
-//   1 the 16-byte loads of the input text   2 the id stores into the arena   4 the back-pointer block stores
-//   8 the text-column stores
-#ifndef SPMX_NT_MASK
-#define SPMX_NT_MASK 0
+// Experiment builds (-DSPMX_EXP=<bits>, csrc/Makefile `variants`; results are WRONG, only the counters mean something):
+// which store stream writes how much -- 1 drops the id stores into the arena, 2 the back-pointer block stores, 4 the
+// text-column stores of the ASCII normalizer.
+#ifndef SPMX_EXP
+#define SPMX_EXP 0
 #endif
-typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
-template <int BIT, typename Q4>       // Q4: the 16-byte struct of dev.h
-SPMX_DEVICE Q4 load_q4(const void *p) {
-  if (SPMX_NT_MASK & BIT) {
-    const nt_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4 *>(p));
-    return Q4{v.x, v.y, v.z, v.w};
-  }
-  return *reinterpret_cast<const Q4 *>(p);
-}
-template <int BIT, typename Q4>
-SPMX_DEVICE void store_q4(void *p, const Q4 &q) {
-  if (SPMX_NT_MASK & BIT) __builtin_nontemporal_store(nt_u32x4{q.x, q.y, q.z, q.w}, reinterpret_cast<nt_u32x4 *>(p));
-  else *reinterpret_cast<Q4 *>(p) = q;
-}
-template <int BIT, typename T>
-SPMX_DEVICE void store_nt(T *p, T v) {
-  if (SPMX_NT_MASK & BIT) __builtin_nontemporal_store(v, p);
-  else *p = v;
-}
 
 }  // namespace wv
 }  // namespace spmx

@@ -32,7 +32,8 @@ hipError_t LaunchEncodeStream(int model_type, bool uds, const EncodeArgs &a, int
   if (model_type == 2) {
     RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<2, 0, false>(a, s); });
   } else if (a.bp_short) {
-    RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<1, 16, false, BpShort>(a, s); });
+    if (a.ring == 16) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<1, 16, false, BpShort>(a, s); });
+    else RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<1, 0, false, BpShort>(a, s); });
   } else if (a.ring == 16) {
     if (uds) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<1, 16, true>(a, s); });
     else RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<1, 16, false>(a, s); });

@@ -105,9 +105,9 @@ inline int ffs64(uint64_t x) { return __builtin_ffsll(static_cast<long long>(x))
 inline int clz64(uint64_t x) { return x ? __builtin_clzll(x) : 64; }
 inline float bits_to_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 inline uint32_t float_to_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
-template <int BIT, typename Q4> inline Q4 load_q4(const void *p) { return *reinterpret_cast<const Q4 *>(p); }
-template <int BIT, typename Q4> inline void store_q4(void *p, const Q4 &q) { *reinterpret_cast<Q4 *>(p) = q; }
-template <int BIT, typename T> inline void store_nt(T *p, T v) { *p = v; }
+#ifndef SPMX_EXP
+#define SPMX_EXP 0
+#endif
 
 }  // namespace wv
 }  // namespace spmx
