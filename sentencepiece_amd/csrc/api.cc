@@ -535,8 +535,6 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
   uint64_t expand = (h->dev.flags & kNfCompressSp) || !(h->dev.flags & kNfEscapeWs) ? 1 : 3;
   if ((h->dev.flags & kNfCompressSp) && (h->dev.flags & kNfByteFallback)) expand = 2;   // slots: bytes + 2 per space symbol
   uint64_t arena_need = expand * text_bytes + (4 + static_cast<uint64_t>(h->dev.n_prefix + h->dev.n_suffix)) * n + 64;
-  // (the unigram tiles take rows x lanes: the longest sentence of a tile sets its rows; an overflow re-runs with what was asked for)
-  arena_need += arena_need / 8 + 65536;
   const bool prof = h->profiling;
   if (prof) HIP_OR_RETURN(h, EnsureEvents(ws));
   const uint32_t n32 = static_cast<uint32_t>(n);

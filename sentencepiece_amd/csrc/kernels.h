@@ -777,16 +777,6 @@ SPMX_DEVICE void scan_final_block(const ScanArgs &a) {     // pass 3
   }
 }
 
-// EncodeArgs::tmp_off: where a sentence's ids sit in the arena.  Bits 0-55: element index of its first ROW; bits 56-61:
-// log2 of the row stride (0 = the ids are contiguous); bit 63: the rows run backwards (row 0 holds the LAST id).  The
-// unigram stream kernel stores the ids of a tile's 64 sentences interleaved -- id row r of lane l at [r * 64 + l] --
-// because the lanes backtrack together: a row is one 256-byte run written within an iteration or two, where per-lane
-// slots kept one open cache line per lane for the whole backtrack and left for memory half written (4.8 bytes written
-// per id byte).  It emits last piece first, hence the backwards rows.
-constexpr uint64_t kTmpOffMask = (1ull << 56) - 1;
-constexpr int kTmpShShift = 56;
-constexpr uint64_t kTmpDesc = 1ull << 63;
-
 struct CompactArgs {
   const int32_t *arena;
   const uint64_t *tmp_off;
@@ -817,7 +807,6 @@ SPMX_DEVICE void compact_block(const CompactArgs &a) {
     const uint32_t total = static_cast<uint32_t>(a.id_offs[last] - dst0);
     const uint32_t rel = static_cast<uint32_t>(my_dst - dst0);
     const uint32_t src_lo = static_cast<uint32_t>(my_src), src_hi = static_cast<uint32_t>(my_src >> 32);
-    const uint32_t my_cnt = s < a.n ? static_cast<uint32_t>(a.id_offs[s + 1] - my_dst) : 0u;
     const uint32_t rounds = (total + 63) / 64;
     for (uint32_t r = 0; r < rounds; ++r) {
       const uint32_t j = r * 64 + static_cast<uint32_t>(lane);
@@ -828,11 +817,8 @@ SPMX_DEVICE void compact_block(const CompactArgs &a) {
         if (v <= j) lo += step;
       }
       const uint32_t r0 = wv::shfl(rel, lo);
-      const uint64_t code = (static_cast<uint64_t>(wv::shfl(src_hi, lo)) << 32) | wv::shfl(src_lo, lo);
-      const uint32_t cnt = wv::shfl(my_cnt, lo);
-      const uint32_t e = j - r0;
-      const uint32_t row = (code & kTmpDesc) ? cnt - 1u - e : e;
-      if (j < total) a.ids[dst0 + j] = a.arena[(code & kTmpOffMask) + (static_cast<uint64_t>(row) << ((code >> kTmpShShift) & 63u))];
+      const uint64_t base = (static_cast<uint64_t>(wv::shfl(src_hi, lo)) << 32) | wv::shfl(src_lo, lo);
+      if (j < total) a.ids[dst0 + j] = a.arena[base + (j - r0)];
     }
   }
 }

@@ -351,20 +351,15 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const TextCol &gt, const B
 }
 
 // Backtrack (:1010-1018) + id post-processing (sentencepiece_processor.cc:581-613) of this lane's sentence:
-// follows the lane's back-pointer entries gb from position nlen to 0 and writes the ids as it goes, last piece first, into the
-// rows row0, row0 + 1, ... of `slot` (at most cap of them).  Returns n, or -1 on a broken chain / overflow.
+// follows the lane's back-pointer entries gb from position nlen to 0 and writes the ids as it goes, last piece first, into slot[0, cap):
+// forward order fills the slot from its END (ids end up in slot[cap - n, cap)), `reverse` fills it from the start.
+// Returns n, or -1 on a broken chain / overflow.
 // `tslot` (spans form, else null): the slot's twin in EncodeArgs::arena_tb, receives every token's begin.
-// A lane's view of its tile's id rows in the arena (kernels.h kTmpOff...): row r at p[r << sh].
-struct IdCol {
-  int32_t *p;       // null: no such column
-  uint32_t sh;
-  SPMX_DEVICE int32_t &row(int r) const { return p[static_cast<uint64_t>(static_cast<uint32_t>(r)) << sh]; }
-};
-
 template <typename BP>
-SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const TextCol &gt, const BpCol<typename BP::T> &gb, int nlen, const IdCol &slot,
-                                 const IdCol &tslot, int row0, int cap, bool active) {
+SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const TextCol &gt, const BpCol<typename BP::T> &gb, int nlen, int32_t *slot,
+                                 int32_t *tslot, int cap, bool active) {
   const bool bf = (d.flags & kNfByteFallback) != 0;
+  const bool reverse = (d.flags & kNfReverse) != 0;
   const uint32_t spb = SpByteOf(d);
   int e = nlen, n = 0;
   bool right_unk = false, ok = true;
@@ -382,24 +377,24 @@ SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const TextCol &gt, const BpCo
           if (n + nb > cap) { ok = false; active = false; continue; }
           for (int x = nb - 1; x >= 0; --x) {
             const uint32_t byte = sp ? (x == 0 ? 0xE2u : (x == 1 ? 0x96u : 0x81u)) : col_byte(gt, tb + x);
-            slot.row(row0 + n) = d.byte_ids[byte];
-            if (tslot.p) tslot.row(row0 + n) = tb;
+            slot[reverse ? n : cap - 1 - n] = d.byte_ids[byte];
+            if (tslot) tslot[reverse ? n : cap - 1 - n] = tb;
             ++n;
           }
         } else if (!right_unk) {                    // a run of unknown pieces yields one id (:609-613)
           if (n >= cap) { ok = false; active = false; continue; }
-          slot.row(row0 + n) = d.unk_id;
-          if (tslot.p) tslot.row(row0 + n) = tb;
+          slot[reverse ? n : cap - 1 - n] = d.unk_id;
+          if (tslot) tslot[reverse ? n : cap - 1 - n] = tb;
           ++n;
-        } else if (tslot.p) {                       // the run grows to the left: so does the merged token
-          tslot.row(row0 + n - 1) = tb;
+        } else if (tslot) {                         // the run grows to the left: so does the merged token
+          tslot[reverse ? n - 1 : cap - n] = tb;
         }
         right_unk = true;
       } else {
         right_unk = false;
         if (n >= cap) { ok = false; active = false; continue; }
-        if (!(SPMX_EXP & 1)) slot.row(row0 + n) = BP::id(w);
-        if (tslot.p) tslot.row(row0 + n) = tb;
+        if (!(SPMX_EXP & 1)) slot[reverse ? n : cap - 1 - n] = BP::id(w);
+        if (tslot) tslot[reverse ? n : cap - 1 - n] = tb;
         ++n;
       }
       e = tb;
@@ -573,54 +568,33 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     const int room = mine ? cap + n_extra : 0;
     int total = 0;
     const int excl = wave_excl_scan(room, lane, &total);
-    // unigram: the tile's ids interleaved, room_max rows of 1 << lane_shift lanes (kernels.h kTmpOff...); BPE: a
-    // contiguous slot per sentence (its lanes emit word by word, out of step)
-    const bool rows = MODEL == 1;
-    int room_max = room;
-    if (rows) {
-#pragma unroll
-      for (int dd = 32; dd >= 1; dd >>= 1) { const int o = wv::shfl(room_max, lane ^ dd); room_max = o > room_max ? o : room_max; }
-      total = room_max << lane_shift;
-    }
     unsigned long long base = 0;
     if (lane == 0 && total > 0) base = wv::atomic_add(a.arena_head, static_cast<unsigned long long>(total));
     base = (static_cast<unsigned long long>(wv::shfl(static_cast<uint32_t>(base >> 32), 0)) << 32) |
            wv::shfl(static_cast<uint32_t>(base), 0);
     const bool overflow = base + static_cast<unsigned long long>(total) > a.arena_cap;
     if (overflow && lane == 0) wv::atomic_or(a.status, kStArenaOverflow);
+    int32_t *slot = a.arena + base + static_cast<unsigned long long>(excl) + d.n_prefix;
+    int32_t *tslot = a.arena_tb ? a.arena_tb + base + static_cast<unsigned long long>(excl) + d.n_prefix : nullptr;
     bool broken = false;
     int n = 0;
+    bool at_end = false;      // the ids sit at the end of the slot
     unsigned long long c2 = c1;
     if (MODEL == 1) {
-      // ---- segment, then backtrack.  Rows: forward order stores the sequence backwards (the backtrack's own order: row
-      // n_suffix + k for the k-th id it emits), `reverse` stores it forwards (row n_prefix + k) ----
-      const bool reverse = (d.flags & kNfReverse) != 0;
-      const unsigned long long my_base = base + static_cast<unsigned long long>(lane);
-      const IdCol slot{a.arena + my_base, lane_shift};
-      const IdCol tslot{a.arena_tb ? a.arena_tb + my_base : nullptr, lane_shift};
-      const int row0 = reverse ? d.n_prefix : d.n_suffix;
+      // ---- segment, then backtrack: the slot is filled from its end (or from its start when reversing) ----
       tc.n_trips += static_cast<unsigned long long>(
           unigram_stream_lane<RING, UDS, BP>(d, gt, gb, my_nlen, my_rs, my_rb, rm, my_win, W - 1u, my_st, T.roottab, mine));
       c2 = wv::clock();
-      if (!overflow) n = emit_stream_lane<BP>(d, gt, gb, my_nlen, slot, tslot, row0, cap, mine);
-      broken = n < 0;
-      if (broken) n = 0;
-      if (mine && !broken && !overflow) {
-        const int tot = n + n_extra;
-        // (the bos / eos rows; sequence index q sits in row q, or tot - 1 - q when the rows run backwards)
-        for (int x = 0; x < d.n_prefix; ++x) slot.row(reverse ? x : tot - 1 - x) = d.prefix_ids[x];
-        for (int x = 0; x < d.n_suffix; ++x) slot.row(reverse ? d.n_prefix + n + x : d.n_suffix - 1 - x) = d.suffix_ids[x];
-        a.tmp_off[my_sid] = my_base | (static_cast<unsigned long long>(lane_shift) << kTmpShShift) | (reverse ? 0ull : kTmpDesc);
-        a.counts[my_sid] = static_cast<uint32_t>(tot);
+      if (!overflow) {
+        n = emit_stream_lane<BP>(d, gt, gb, my_nlen, slot, tslot, cap, mine);
+        at_end = (d.flags & kNfReverse) == 0;
       }
     } else {
       // ---- word by word, ids written as the words complete: the slot is filled from its start (end when reversing) ----
-      int32_t *slot = a.arena + base + static_cast<unsigned long long>(excl) + d.n_prefix;
-      int32_t *tslot = a.arena_tb ? a.arena_tb + base + static_cast<unsigned long long>(excl) + d.n_prefix : nullptr;
       n = bpe_stream_lane(d, gt, my_nlen, slot, tslot, cap, T.bw, T.asym, T.bwin + static_cast<uint32_t>(lane) * (kBpeWindow + 4u),
                           kBpeWindow - 1u, lane, mine && !overflow);
       c2 = wv::clock();
-      const bool at_end = (d.flags & kNfReverse) != 0;    // the ids sit at the end of the slot
+      at_end = (d.flags & kNfReverse) != 0;
       const bool handed = n == -2;              // a word too long for the lane form: the sentence goes to the long form
       append_lanes(wv::ballot(handed), handed, my_sid, a.long_list, &a.side->long_count, lane);
       if (handed) {
@@ -628,17 +602,16 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
         a.counts[my_sid] = 0u;                   // (until the long form has had it)
         mine = false; n = 0;
       }
-      broken = n < 0;
-      if (broken) n = 0;
-      if (mine && !broken && !overflow) {
-        int32_t *ids = at_end ? slot + (cap - n) : slot;
-        for (int x = 0; x < d.n_prefix; ++x) ids[x - d.n_prefix] = d.prefix_ids[x];
-        for (int x = 0; x < d.n_suffix; ++x) ids[n + x] = d.suffix_ids[x];
-        a.tmp_off[my_sid] = static_cast<unsigned long long>(ids - d.n_prefix - a.arena);
-        a.counts[my_sid] = static_cast<uint32_t>(n + n_extra);
-      }
     }
-    if (mine && (broken || overflow)) {
+    broken = n < 0;
+    if (broken) n = 0;
+    if (mine && !broken && !overflow) {
+      int32_t *ids = at_end ? slot + (cap - n) : slot;
+      for (int x = 0; x < d.n_prefix; ++x) ids[x - d.n_prefix] = d.prefix_ids[x];
+      for (int x = 0; x < d.n_suffix; ++x) ids[n + x] = d.suffix_ids[x];
+      a.tmp_off[my_sid] = static_cast<unsigned long long>(ids - d.n_prefix - a.arena);
+      a.counts[my_sid] = static_cast<uint32_t>(n + n_extra);
+    } else if (mine) {
       a.counts[my_sid] = 0u;
       a.tmp_off[my_sid] = 0;
       if (broken) {                              // "all normalized characters are not consumed." (sentencepiece_processor.cc:628)
