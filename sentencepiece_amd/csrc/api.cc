@@ -534,7 +534,8 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
   // ids are at most one per normalized byte; the streaming kernels reserve a sentence's slot by that bound
   uint64_t expand = (h->dev.flags & kNfCompressSp) || !(h->dev.flags & kNfEscapeWs) ? 1 : 3;
   if ((h->dev.flags & kNfCompressSp) && (h->dev.flags & kNfByteFallback)) expand = 2;   // slots: bytes + 2 per space symbol
-  uint64_t arena_need = expand * text_bytes + (4 + static_cast<uint64_t>(h->dev.n_prefix + h->dev.n_suffix)) * n + 64;
+  // (a slot per sentence: its normalized length + the extra ids, rounded to groups of 4 with 3 ids of slack for alignment)
+  uint64_t arena_need = expand * text_bytes + (10 + static_cast<uint64_t>(h->dev.n_prefix + h->dev.n_suffix)) * n + 4096;
   const bool prof = h->profiling;
   if (prof) HIP_OR_RETURN(h, EnsureEvents(ws));
   const uint32_t n32 = static_cast<uint32_t>(n);

@@ -357,13 +357,41 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const TextCol &gt, const B
 // `tslot` (spans form, else null): the slot's twin in EncodeArgs::arena_tb, receives every token's begin.
 template <typename BP>
 SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const TextCol &gt, const BpCol<typename BP::T> &gb, int nlen, int32_t *slot,
-                                 int32_t *tslot, int cap, bool active) {
+                                 int32_t *tslot, int cap, int32_t *stage, bool active) {
   const bool bf = (d.flags & kNfByteFallback) != 0;
   const bool reverse = (d.flags & kNfReverse) != 0;
   const uint32_t spb = SpByteOf(d);
   int e = nlen, n = 0;
   bool right_unk = false, ok = true;
   active = active && nlen > 0;
+  // The ids leave in bursts of 16 (64 bytes, four aligned 16-byte stores): id k waits in the lane's LDS staging column
+  // stage[(k & 15) * 64] (the score ring, idle now) until its group is complete.  Single 4-byte stores kept one open
+  // cache line per lane for the whole backtrack -- an XCD's L2 is about the size of the open lines of its resident
+  // lanes -- and lines left for memory part written, several times over (4.8 bytes written per id byte).
+  // The caller aligns the slot so that the groups are 16-byte aligned: slot + cap (forward order) / slot (reverse).
+  auto put = [&](int32_t id, int tb) __attribute__((always_inline)) {
+    if (tslot) {                                   // the spans form keeps the simple path
+      slot[reverse ? n : cap - 1 - n] = id;
+      tslot[reverse ? n : cap - 1 - n] = tb;
+      ++n;
+      return;
+    }
+    stage[(n & 15) << 6] = id;
+    ++n;
+    if ((n & 15) == 0) {
+      if (SPMX_EXP & 1) return;
+      int32_t *p = reverse ? slot + (n - 16) : slot + (cap - n);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        Q4 v;
+        if (reverse) v = Q4{static_cast<uint32_t>(stage[(4 * q) << 6]), static_cast<uint32_t>(stage[(4 * q + 1) << 6]),
+                            static_cast<uint32_t>(stage[(4 * q + 2) << 6]), static_cast<uint32_t>(stage[(4 * q + 3) << 6])};
+        else v = Q4{static_cast<uint32_t>(stage[(15 - 4 * q) << 6]), static_cast<uint32_t>(stage[(14 - 4 * q) << 6]),
+                    static_cast<uint32_t>(stage[(13 - 4 * q) << 6]), static_cast<uint32_t>(stage[(12 - 4 * q) << 6])};
+        *reinterpret_cast<Q4 *>(p + 4 * q) = v;
+      }
+    }
+  };
   while (wv::any(active)) {
     if (active) {
       const typename BP::T w = gb.at(e);
@@ -377,15 +405,11 @@ SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const TextCol &gt, const BpCo
           if (n + nb > cap) { ok = false; active = false; continue; }
           for (int x = nb - 1; x >= 0; --x) {
             const uint32_t byte = sp ? (x == 0 ? 0xE2u : (x == 1 ? 0x96u : 0x81u)) : col_byte(gt, tb + x);
-            slot[reverse ? n : cap - 1 - n] = d.byte_ids[byte];
-            if (tslot) tslot[reverse ? n : cap - 1 - n] = tb;
-            ++n;
+            put(d.byte_ids[byte], tb);
           }
         } else if (!right_unk) {                    // a run of unknown pieces yields one id (:609-613)
           if (n >= cap) { ok = false; active = false; continue; }
-          slot[reverse ? n : cap - 1 - n] = d.unk_id;
-          if (tslot) tslot[reverse ? n : cap - 1 - n] = tb;
-          ++n;
+          put(d.unk_id, tb);
         } else if (tslot) {                         // the run grows to the left: so does the merged token
           tslot[reverse ? n - 1 : cap - n] = tb;
         }
@@ -393,14 +417,14 @@ SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const TextCol &gt, const BpCo
       } else {
         right_unk = false;
         if (n >= cap) { ok = false; active = false; continue; }
-        if (!(SPMX_EXP & 1)) slot[reverse ? n : cap - 1 - n] = BP::id(w);
-        if (tslot) tslot[reverse ? n : cap - 1 - n] = tb;
-        ++n;
+        put(BP::id(w), tb);
       }
       e = tb;
       if (e <= 0) active = false;
     }
   }
+  if (!tslot && ok)                                 // the last, incomplete group
+    for (int k = n & ~15; k < n; ++k) slot[reverse ? k : cap - 1 - k] = stage[(k & 15) << 6];
   return ok ? n : -1;
 }
 
@@ -565,17 +589,22 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     int cap = 0;
     // at most one id per normalized byte -- three for a one-byte space symbol that falls back to its bytes
     if (mine) cap = bf_sp ? my_nlen + 2 * my_nsp : my_nlen;
-    const int room = mine ? cap + n_extra : 0;
+    // rooms are whole groups of 4 ids with 3 ids of slack, so that the lane can shift its slot to the alignment
+    // emit_stream_lane's 16-byte stores want (slot + cap for the forward order, slot when reversing)
+    const int room = mine ? (cap + n_extra + 3 + 3) & ~3 : 0;
     int total = 0;
     const int excl = wave_excl_scan(room, lane, &total);
     unsigned long long base = 0;
-    if (lane == 0 && total > 0) base = wv::atomic_add(a.arena_head, static_cast<unsigned long long>(total));
+    if (lane == 0 && total > 0) base = wv::atomic_add(a.arena_head, static_cast<unsigned long long>(total + 3));
     base = (static_cast<unsigned long long>(wv::shfl(static_cast<uint32_t>(base >> 32), 0)) << 32) |
            wv::shfl(static_cast<uint32_t>(base), 0);
-    const bool overflow = base + static_cast<unsigned long long>(total) > a.arena_cap;
+    const bool overflow = base + static_cast<unsigned long long>(total + 3) > a.arena_cap;
     if (overflow && lane == 0) wv::atomic_or(a.status, kStArenaOverflow);
-    int32_t *slot = a.arena + base + static_cast<unsigned long long>(excl) + d.n_prefix;
-    int32_t *tslot = a.arena_tb ? a.arena_tb + base + static_cast<unsigned long long>(excl) + d.n_prefix : nullptr;
+    base = (base + 3ull) & ~3ull;
+    const int at = excl + d.n_prefix + ((d.flags & kNfReverse) ? 0 : cap);
+    const int shift = (4 - (at & 3)) & 3;
+    int32_t *slot = a.arena + base + static_cast<unsigned long long>(excl + shift) + d.n_prefix;
+    int32_t *tslot = a.arena_tb ? a.arena_tb + base + static_cast<unsigned long long>(excl + shift) + d.n_prefix : nullptr;
     bool broken = false;
     int n = 0;
     bool at_end = false;      // the ids sit at the end of the slot
@@ -586,7 +615,7 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
           unigram_stream_lane<RING, UDS, BP>(d, gt, gb, my_nlen, my_rs, my_rb, rm, my_win, W - 1u, my_st, T.roottab, mine));
       c2 = wv::clock();
       if (!overflow) {
-        n = emit_stream_lane<BP>(d, gt, gb, my_nlen, slot, tslot, cap, mine);
+        n = emit_stream_lane<BP>(d, gt, gb, my_nlen, slot, tslot, cap, reinterpret_cast<int32_t *>(my_rs), mine);
         at_end = (d.flags & kNfReverse) == 0;
       }
     } else {

@@ -62,3 +62,44 @@ def test_full_size_sample_and_idempotence(model, oracle):
     b, lb = _flat_clean(d_ids2, d_io2, clean)
     assert torch.equal(la, lb)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("model", ["c5_250k", "c5_250k_bf"])
+def test_c5_full_size_sample_and_idempotence(model, oracle):
+    """configs[4]: the 250k-piece models on 1 M mixed-script sentences of 16 .. 4096 bytes (power law): a strided
+    sample equals the oracle's ids, the CSR is well formed, and the sentences without an unknown piece re-encode to the
+    same ids after Decode.  (The byte-fallback model has no unknown pieces at all: every sentence takes part.)"""
+    import torch
+    from sentencepiece_amd import synth
+    from sentencepiece_amd.processor import SentencePieceProcessor
+    n = 1_000_000
+    blob = fixtures.model_blob(model)
+    text, offs = synth.mixed_corpus(n, seed=20250228)
+    sp = SentencePieceProcessor(model_proto=blob)
+    dev = torch.device("cuda", 0)
+    d_text = torch.from_numpy(text).to(dev)
+    d_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+    d_ids, d_io, total = sp.EncodeDevice(d_text, d_offs)
+    assert int(d_io[-1]) == total and int(d_io[0]) == 0
+    assert bool((d_io[1:] >= d_io[:-1]).all())
+    ids = d_ids[:total]
+    assert int(ids.min()) >= 0 and int(ids.max()) < sp.GetPieceSize()
+    pick = np.linspace(0, n - 1, num=20_000).astype(np.int64)
+    st, so = synth.gather_packed(text, offs, pick)
+    oids, oio = oracle.load(blob).encode_batch(st, so)
+    io_h = d_io.cpu().numpy()
+    lens = (io_h[1:] - io_h[:-1])[pick]
+    np.testing.assert_array_equal(lens, np.diff(np.asarray(oio).astype(np.int64)))
+    idx = torch.from_numpy(np.repeat(io_h[:-1][pick] - np.concatenate([[0], np.cumsum(lens)[:-1]]), lens)
+                           + np.arange(int(lens.sum()))).to(dev)
+    np.testing.assert_array_equal(ids[idx].cpu().numpy(), np.asarray(oids))
+    d_txt, d_to, nbytes = sp.DecodeDevice(ids, d_io)
+    d_ids2, d_io2, total2 = sp.EncodeDevice(d_txt[:nbytes], d_to)
+    unk = (ids == sp.unk_id()).to(torch.int64)
+    c = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(unk, 0)])
+    clean = (c[d_io[1:]] - c[d_io[:-1]]) == 0
+    assert int(clean.sum()) > (0.99 * n if model.endswith("_bf") else 0.3 * n)
+    a, la = _flat_clean(d_ids, d_io, clean)
+    b, lb = _flat_clean(d_ids2, d_io2, clean)
+    assert torch.equal(la, lb)
+    assert torch.equal(a, b)
