@@ -406,3 +406,18 @@ def test_emu_bpe_documents(model, emu, oracle):
     oids, oio = o.encode_batch(text, offs)
     np.testing.assert_array_equal(io, oio)
     np.testing.assert_array_equal(ids, oids)
+
+
+@pytest.mark.parametrize("model", ["test_model", "bpe1k"])
+def test_emu_first_offset_not_rebased(model, emu, oracle, corpora):
+    """offsets[0] != 0 (and not a multiple of 16): the host forms stage text[offsets[0]:] and the kernels address
+    text + offsets[i] as given."""
+    blob = fixtures.model_blob(model)
+    h, o = emu.load(blob), oracle.load(blob)
+    text, offs = fixtures.head(*corpora["botchan"], 200)
+    want, wio = o.encode_batch(text, offs)
+    for shift in (1, 7, 16, 33):
+        pad = np.concatenate([np.full(shift, 0xE3, dtype=np.uint8), text])
+        ids, io = h.encode_batch(pad, offs + np.uint64(shift))
+        np.testing.assert_array_equal(io, wio)
+        np.testing.assert_array_equal(ids, want)

@@ -197,3 +197,30 @@ def test_bpe_document_length_sentences(procs, oracle, corpora):
         oids, oio = oracle.load(fixtures.model_blob(model)).encode_batch(t, of)
         np.testing.assert_array_equal(io, oio)
         np.testing.assert_array_equal(ids, oids)
+
+
+@pytest.mark.parametrize("model", ["test_model", "bpe1k", "uni1k_uds"])
+def test_text_at_any_alignment(model, procs, oracle, corpora):
+    """The text pointer and offsets[0] are used as given: the kernels' 16-byte loads are aligned on the ABSOLUTE address
+    (csrc/kernels_normlane.h), so a buffer at an odd address, a first offset that is not a multiple of 16 and a buffer
+    that ends exactly where its allocation ends all encode like the aligned case."""
+    import torch
+    sp = procs(model)
+    text, offs = fixtures.head(*corpora["botchan"], 900)
+    want, wio = oracle.load(fixtures.model_blob(model)).encode_batch(text, offs)
+    dev = torch.device("cuda", 0)
+    for shift in (1, 5, 7, 15, 16, 33):
+        # host form: `shift` bytes of other data before the first sentence, offsets not rebased
+        pad = np.concatenate([np.full(shift, 0xE3, dtype=np.uint8), text])
+        ids, io = sp.EncodePacked(pad, offs + np.uint64(shift))
+        np.testing.assert_array_equal(io, wio)
+        np.testing.assert_array_equal(ids, want)
+        # device form: a tensor view at an odd address whose last byte is the last byte of the allocation
+        buf = torch.empty(shift + len(text), dtype=torch.uint8, device=dev)
+        buf[shift:] = torch.from_numpy(text).to(dev)
+        d_ids, d_io, total = sp.EncodeDevice(buf[shift:], torch.from_numpy(offs.view(np.int64)).to(dev))
+        np.testing.assert_array_equal(d_io.cpu().numpy().astype(np.uint64), wio)
+        np.testing.assert_array_equal(d_ids[:total].cpu().numpy(), want)
+        # spans + normalize forms read the same text
+        got = sp.EncodeSpansPacked(pad, offs + np.uint64(shift))
+        np.testing.assert_array_equal(np.asarray(got[0]), want)
