@@ -83,10 +83,10 @@ struct FlatSink {
 // wide (kNfCompressSp, or no whitespace escaping) and the model has no user-defined symbols; not for
 // whitespace-as-suffix models.  A byte whose bcls entry says kBcComplex makes the lane give up (-1).
 // *n_sp: how many bytes of the result are the space symbol (sizes the id slot under byte fallback).
-// plain_ok: no byte of 0x21 .. 0x7E is kBcComplex in bcls (true for every charsmap seen so far: the ASCII keys are
-// control characters) -- a dword of four such bytes is then appended whole.
+// (Tried: appending a dword of four plain bytes 0x21 .. 0x7E whole.  The lanes of a wave disagree on it dword by
+// dword, so the wave runs both paths: 3 % slower end to end.)
 SPMX_DEVICE int fast_norm_stream(const SpmxDev &d, const uint8_t *gtext, uint64_t beg, int L, const TextCol &gt,
-                                 const uint8_t *bcls, int tcap, int *n_sp, bool plain_ok) {
+                                 const uint8_t *bcls, int tcap, int *n_sp) {
   const uint32_t F = d.flags;
   const bool rm = (F & kNfRemoveExtraWs) != 0;
   const uint32_t sp = (F & kNfCompressSp) ? kSpByte : 0x20u;
@@ -113,24 +113,6 @@ SPMX_DEVICE int fast_norm_stream(const SpmxDev &d, const uint8_t *gtext, uint64_
     for (int q = 0; q < 4; ++q) {
       if ((wd[q] & 0x80808080u) == 0u) {
         // ---- four ASCII bytes: every NormalizePrefix result is the byte itself ----
-        {
-          const uint32_t x = wd[q];
-          const uint32_t le20 = (x - 0x21212121u) & ~x & 0x80808080u;            // some byte < 0x21 (bytes are < 0x80)
-          const uint32_t y = x ^ 0x7F7F7F7Fu;
-          const uint32_t eq7f = (y - 0x01010101u) & ~y & 0x80808080u;             // some byte == 0x7F
-          if (plain_ok && rel + 4 * q >= 0 && rel + 4 * q + 4 <= L && (le20 | eq7f) == 0u) {
-            // four bytes of 0x21 .. 0x7E, all inside the sentence: no space, nothing a rule can start at
-            const uint32_t sh = 8u * (static_cast<uint32_t>(w) & 3u);
-            acc |= x << sh;
-            if (!(SPMX_EXP & 4)) gt.dw(w >> 2) = acc;
-            acc = sh ? x >> (32u - sh) : 0u;
-            w += 4;
-            P = false;
-            wl = w;
-            seen = true;
-            continue;
-          }
-        }
 #pragma unroll
         for (int k = 4 * q; k < 4 * q + 4; ++k) {
           const uint32_t c = (wd[q] >> (8 * (k & 3))) & 0xFFu;

@@ -486,8 +486,6 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     }
     wv::sync();
   }
-  // fast_norm_stream's whole-dword path: no byte of 0x21 .. 0x7E may start a charsmap rule
-  const bool plain_ok = !wv::any((lane < 0x5E && T.bcls[0x21 + lane] != 0) || (lane + 64 < 0x5E && T.bcls[0x21 + 64 + lane] != 0));
   const uint32_t wave_id = static_cast<uint32_t>(wv::block_id() * wv::waves_per_block() + wv::wave_in_block());
   uint8_t *slab = a.slab + static_cast<uint64_t>(wave_id) * a.slab_bytes;
   BT *my_st = kBpSz == 2 ? reinterpret_cast<BT *>(T.stage) + static_cast<uint32_t>(lane) * 8u
@@ -543,7 +541,7 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
       int nlen = 0;
       bool need_any = go && my_len > 0;
       if (!backlog && a.fast_ok && !sc.general) {
-        if (go && my_len > 0) nlen = fast_norm_stream(d, a.text, my_beg, static_cast<int>(my_len), gt, T.bcls, static_cast<int>(tcap), &my_nsp, plain_ok);
+        if (go && my_len > 0) nlen = fast_norm_stream(d, a.text, my_beg, static_cast<int>(my_len), gt, T.bcls, static_cast<int>(tcap), &my_nsp);
         need_any = nlen < 0;
         // Not plain ASCII.  A tile that is mostly such sentences (CJK text ...) normalizes them here, one per lane; a
         // few stray ones wait in the backlog
