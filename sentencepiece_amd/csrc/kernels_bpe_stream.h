@@ -135,25 +135,10 @@ SPMX_DEVICE int bpe_stream_lane(const SpmxDev &d, const TextCol &gt, int nlen, i
   bool prev_sp = false; // the last character read was U+2581
   bool right_unk = false;
   int n_out = 0, ret = 0;
-  // The ids leave four at a time, as one aligned 16-byte store (the caller aligns slot, or slot + cap when reversing):
-  // single 4-byte stores into per-lane slots keep a cache line per lane open for the whole sentence and leave for
-  // memory part written, several times over (kernels_stream.h emit_stream_lane has the measurement).  The spans form
-  // (tslot) keeps the simple path.
-  uint32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0;
   auto slot_out = [&](uint32_t id, int off) __attribute__((always_inline)) {
-    if (tslot) {
-      slot[reverse ? cap - 1 - n_out : n_out] = static_cast<int32_t>(id);
-      tslot[reverse ? cap - 1 - n_out : n_out] = off;
-      ++n_out;
-      return;
-    }
-    const int k = n_out & 3;
-    g0 = k == 0 ? id : g0; g1 = k == 1 ? id : g1; g2 = k == 2 ? id : g2; g3 = k == 3 ? id : g3;
+    slot[reverse ? cap - 1 - n_out : n_out] = static_cast<int32_t>(id);
+    if (tslot) tslot[reverse ? cap - 1 - n_out : n_out] = off;
     ++n_out;
-    if (k == 3) {
-      if (reverse) *reinterpret_cast<Q4 *>(slot + (cap - n_out)) = Q4{g3, g2, g1, g0};
-      else *reinterpret_cast<Q4 *>(slot + (n_out - 4)) = Q4{g0, g1, g2, g3};
-    }
   };
   PairProbe p0, p1;
   WordProbe wq;
@@ -340,17 +325,23 @@ SPMX_DEVICE int bpe_stream_lane(const SpmxDev &d, const TextCol &gt, int nlen, i
             if (n_out + nb > cap) { ret = -1; break; }
             for (int y = 0; y < nb; ++y) {
               const uint32_t byte = b == spb ? (y == 0 ? 0xE2u : (y == 1 ? 0x96u : 0x81u)) : b;
-              slot_out(static_cast<uint32_t>(d.byte_ids[byte]), off);
+              slot[reverse ? cap - 1 - n_out : n_out] = d.byte_ids[byte];
+              if (tslot) tslot[reverse ? cap - 1 - n_out : n_out] = off;
+              ++n_out;
             }
           }
         } else if (!right_unk) {                    // a run of unknown pieces yields one id (:609-613)
           if (n_out >= cap) { ret = -1; break; }
-          slot_out(static_cast<uint32_t>(d.unk_id), off);
+          slot[reverse ? cap - 1 - n_out : n_out] = d.unk_id;
+          if (tslot) tslot[reverse ? cap - 1 - n_out : n_out] = off;
+          ++n_out;
         }
         right_unk = true;
       } else {
         if (n_out >= cap) { ret = -1; break; }
-        slot_out(f, off);
+        slot[reverse ? cap - 1 - n_out : n_out] = static_cast<int32_t>(f);
+        if (tslot) tslot[reverse ? cap - 1 - n_out : n_out] = off;
+        ++n_out;
         right_unk = false;
       }
       off += len;
@@ -369,9 +360,6 @@ SPMX_DEVICE int bpe_stream_lane(const SpmxDev &d, const TextCol &gt, int nlen, i
     pair_issue(d, &p1);
     if (use_words) word_issue(d, &wq);
   }
-  if (ret == 0 && !tslot && active_in)                 // the last, incomplete group
-    for (int k = n_out & ~3; k < n_out; ++k)
-      slot[reverse ? cap - 1 - k : k] = static_cast<int32_t>((k & 3) == 0 ? g0 : ((k & 3) == 1 ? g1 : g2));
   return ret != 0 ? ret : n_out;
 }
 

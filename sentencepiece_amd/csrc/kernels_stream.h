@@ -601,9 +601,7 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     const bool overflow = base + static_cast<unsigned long long>(total + 3) > a.arena_cap;
     if (overflow && lane == 0) wv::atomic_or(a.status, kStArenaOverflow);
     base = (base + 3ull) & ~3ull;
-    // (the unigram backtrack fills its slot from the end unless reversing; the BPE lanes from the start unless reversing)
-    const bool from_end = (MODEL == 1) != ((d.flags & kNfReverse) != 0);
-    const int at = excl + d.n_prefix + (from_end ? cap : 0);
+    const int at = excl + d.n_prefix + ((d.flags & kNfReverse) ? 0 : cap);
     const int shift = (4 - (at & 3)) & 3;
     int32_t *slot = a.arena + base + static_cast<unsigned long long>(excl + shift) + d.n_prefix;
     int32_t *tslot = a.arena_tb ? a.arena_tb + base + static_cast<unsigned long long>(excl + shift) + d.n_prefix : nullptr;
