@@ -167,6 +167,9 @@ def main():
                          "c5_250k | c5_250k_bf (configs[4], 250k-piece unigram on the mixed-script power-law corpus)")
     ap.add_argument("--gather", choices=["both", "ids", "none"], default="both",
                     help="N > 1: all-gather the ids over RCCL (the north star), leave it out, or time both (default)")
+    ap.add_argument("--gather-algo", choices=["all_gather", "p2p"], default="all_gather",
+                    help="how the ids travel with --gather ids: the library's all-gather, or world - 1 point-to-point sends per rank "
+                         "posted as one batch (sharding.IdGatherer algo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-model", action="store_true")
     ap.add_argument("--unsorted", action="store_true",
@@ -250,7 +253,7 @@ def main():
     else:
         for mode in gather_modes:
             if mode == "ids":
-                g = sharding.IdGatherer(dist, dev, wire_dtype=wire, depth=2)
+                g = sharding.IdGatherer(dist, dev, wire_dtype=wire, depth=2, algo=args.gather_algo)
                 g.reserve(d_ids.numel(), d_io.numel(), torch.int32, d_io.dtype)      # agreed once, before the loop
 
                 def step_ids():

@@ -28,6 +28,17 @@ def shard_bounds(offsets, world):
     return np.maximum.accumulate(b)
 
 
+class _Works:
+    """Several work handles behind one wait()."""
+
+    def __init__(self, works):
+        self.works = list(works)
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
 class IdGatherer:
     """All-gatherv of (ids[:total], id_offsets) from every rank, asynchronous and free of host synchronisation in
     the steady state.
@@ -41,12 +52,16 @@ class IdGatherer:
     ``wait()`` makes the current stream wait for everything in flight; ``result()`` returns the per-rank
     ``(ids, id_offsets)`` views of the last gather (it is the consumer that synchronises, not the gatherer)."""
 
-    def __init__(self, dist, device, group=None, wire_dtype=None, depth=2):
+    def __init__(self, dist, device, group=None, wire_dtype=None, depth=2, algo="all_gather"):
         """``wire_dtype``: dtype the ids travel in (default: as given).  xGMI is point-to-point, so a ring
         all-gather is bound by one link; a vocabulary below 32768 fits ``torch.int16`` and halves the payload.
-        ``result()`` widens back to the dtype of the ids passed in."""
+        ``result()`` widens back to the dtype of the ids passed in.
+        ``algo``: "all_gather" (the library's collective) or "p2p": world - 1 sends of the rank's own buffer and
+        world - 1 receives per gather, posted as one batch (``batch_isend_irecv``) -- on a fully connected xGMI node
+        every peer is one hop away, so the sends go out on all links at once instead of round a ring."""
         self.dist, self.device, self.group = dist, device, group
         self.wire = wire_dtype
+        self.algo = algo
         self._dtype = None
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -59,9 +74,21 @@ class IdGatherer:
     def _all_gather(self, out, inp):
         if out.dtype == torch.int16:      # no 16-bit integer type in NCCL / gloo: an all-gather only moves bytes
             out, inp = out.view(torch.uint8), inp.view(torch.uint8)
+        if self.algo == "p2p" and self.world > 1:
+            rows = out.view(self.world, -1)
+            rows[self.rank].copy_(inp)
+            ops = []
+            for k in range(1, self.world):           # peer order staggered by rank: no two ranks start on the same peer
+                to, frm = (self.rank + k) % self.world, (self.rank - k) % self.world
+                ops.append(self.dist.P2POp(self.dist.isend, inp, self._peer(to), self.group))
+                ops.append(self.dist.P2POp(self.dist.irecv, rows[frm], self._peer(frm), self.group))
+            return _Works(self.dist.batch_isend_irecv(ops))
         if self.dist.get_backend(self.group) == "nccl":
             return self.dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
         return self.dist.all_gather(list(out.view(self.world, -1).unbind(0)), inp, group=self.group, async_op=True)
+
+    def _peer(self, r):
+        return r if self.group is None else self.dist.get_global_rank(self.group, r)
 
     def reserve(self, ids_capacity, offsets_capacity=0, ids_dtype=torch.int32, offsets_dtype=torch.int64):
         """Collective.  Agrees the padded per-rank sizes (MAX over the ranks) and allocates the slots."""

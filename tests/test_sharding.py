@@ -41,7 +41,8 @@ def _worker(rank, world, port, model, corpus_name, n_sent, out_dir):
         np.save(os.path.join(out_dir, "io%d.npy" % rank), io.numpy())
         # steady-state gatherer: capacities agreed once (reserve), then batches of different size -- an empty one among
         # them -- through one IdGatherer, two gathers in flight
-        g = sharding.IdGatherer(dist, torch.device("cpu"), wire_dtype=torch.int16, depth=2)
+        g = sharding.IdGatherer(dist, torch.device("cpu"), wire_dtype=torch.int16, depth=2,
+                                algo="p2p" if world == 4 else "all_gather")
         g.reserve(16, 2)
         sizes = lambda r, step: (3 + r, 9 - 2 * r if 9 - 2 * r > 0 else 0, 0 if r == 1 else 5)[step]      # noqa: E731
         for step in range(3):
