@@ -1794,9 +1794,13 @@ int spmx_sample_encode_batch(spmx_handle *h, const char *text, const uint64_t *o
     uint64_t *nio = nullptr;
     const int rc = LatticeBatchHost(h, text, offsets, n, 0, nbest_size, 0.f, 0, &nids, &nio, &sc, &ro);
     if (rc != kOk) return rc;
+    struct Release {                               // (the n-best arrays, whatever way this function is left)
+      void *p[4];
+      ~Release() { for (void *q : p) free(q); }
+    } release{{nids, nio, sc, ro}};
     // one of each sentence's results, with probability exp(alpha * score) / Z
-    uint64_t *oo = static_cast<uint64_t *>(malloc((n + 1) * sizeof(uint64_t)));
     std::vector<uint64_t> pick(n);
+    uint64_t *oo = static_cast<uint64_t *>(malloc((n + 1) * sizeof(uint64_t)));
     uint64_t total = 0;
     unsigned long long st = seed * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull;
     for (uint64_t s2 = 0; oo && s2 < n; ++s2) {
@@ -1817,11 +1821,10 @@ int spmx_sample_encode_batch(spmx_handle *h, const char *text, const uint64_t *o
       if (r1 > r0) total += nio[c + 1] - nio[c];
     }
     int32_t *oi = static_cast<int32_t *>(malloc((total ? total : 1) * sizeof(int32_t)));
-    if (!oo || !oi) { free(oo); free(oi); free(nids); free(nio); free(sc); free(ro); return Fail(h, kResourceExhausted, "out of host memory"); }
+    if (!oo || !oi) { free(oo); free(oi); return Fail(h, kResourceExhausted, "out of host memory"); }
     oo[n] = total;
     for (uint64_t s2 = 0; s2 < n; ++s2)
       if (ro[s2 + 1] > ro[s2]) memcpy(oi + oo[s2], nids + nio[pick[s2]], (nio[pick[s2] + 1] - nio[pick[s2]]) * sizeof(int32_t));
-    free(nids); free(nio); free(sc); free(ro);
     *ids = oi;
     *id_offsets = oo;
     return kOk;
