@@ -14,6 +14,16 @@ t_end = time.time() + float(sys.argv[1]) if len(sys.argv) > 1 else time.time() +
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 bad = 0
 handles = {m: (em.load(fixtures.model_blob(m)), orc.load(fixtures.model_blob(m))) for m in MODELS}
+REF, ref_orig = None, {}
+try:
+    from tests import refshim
+    if refshim.available():
+        REF = refshim.RefLib()
+        for m in ("test_model", "uni1k_bf", "uni1k_uds", "uni1k_suffix"):
+            ref_orig[m] = REF.load(fixtures.model_blob(m))
+            ref_orig[m].set_encoder_original()
+except Exception:
+    REF = None
 while time.time() < t_end:
     seed += 1
     text, offs = fuzz_corpus(120, seed, corp)
@@ -40,8 +50,8 @@ while time.time() < t_end:
             bad += 1; print("EXC", m, seed, repr(e)[:200], flush=True)
     # n-best on short sentences for the unigram models
     tb = np.asarray(text).tobytes()
-    sents = [tb[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
-    sents = [s for s in sents if len(s) <= 120][:25]
+    all_sents = [tb[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
+    sents = [s for s in all_sents if len(s) <= 120][:25]
     if sents:
         t2, o2 = synth.pack(sents)
         for m in ("test_model", "uni1k_bf", "uni1k_uds"):
@@ -55,5 +65,40 @@ while time.time() < t_end:
             except Exception as e:
                 # sentences whose normalized form exceeds the NBest capacity raise: acceptable only for long normalized text
                 print("NBEST EXC", m, seed, repr(e)[:120], flush=True)
+    # the kOriginal encoder against the compiled reference switched to kOriginal; sampled segmentations decode to the same
+    # text as the plain one; nbest_size 1 / BPE alpha 0 are the plain encoder (all lengths: the lattice has no limit)
+    if REF is not None:
+        for m in ("test_model", "uni1k_bf", "uni1k_uds", "uni1k_suffix"):
+            h, o = handles[m]
+            try:
+                ids, io = h.sp.EncodeOriginalPacked(text, offs)
+                io = io.astype(np.int64)
+                r = ref_orig[m]
+                for i, s in enumerate(all_sents):
+                    if ids[io[i]:io[i + 1]].tolist() != r.encode(s).tolist():
+                        bad += 1; print("ORIGINAL MISMATCH", m, seed, s[:40], flush=True)
+                sid, sio = h.sp.SampleEncodePacked(text, offs, -1, 0.3, seed=seed)
+                a = h.decode_batch(sid, sio); b = h.decode_batch(*h.encode_batch(text, offs))
+                if not (np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])):
+                    bad += 1; print("SAMPLE DECODE MISMATCH", m, seed, flush=True)
+                pid, pio = h.sp.SampleEncodePacked(text, offs, 1, 0.3, seed=seed)
+                eid, eio = h.encode_batch(text, offs)
+                if not (np.array_equal(pid, eid) and np.array_equal(pio, eio)):
+                    bad += 1; print("SAMPLE(1) != ENCODE", m, seed, flush=True)
+            except Exception as e:
+                bad += 1; print("LATTICE EXC", m, seed, repr(e)[:200], flush=True)
+        for m in ("bpe1k", "bpe1k_bf_uds"):
+            h, o = handles[m]
+            try:
+                did, dio = h.sp.SampleEncodePacked(text, offs, -1, 0.0, seed=seed)
+                eid, eio = h.encode_batch(text, offs)
+                if not (np.array_equal(did, eid) and np.array_equal(dio, eio)):
+                    bad += 1; print("DROPOUT(0) != ENCODE", m, seed, flush=True)
+                did, dio = h.sp.SampleEncodePacked(text, offs, -1, 0.4, seed=seed)
+                a = h.decode_batch(did, dio); b = h.decode_batch(eid, eio)
+                if not (np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])):
+                    bad += 1; print("DROPOUT DECODE MISMATCH", m, seed, flush=True)
+            except Exception as e:
+                bad += 1; print("DROPOUT EXC", m, seed, repr(e)[:200], flush=True)
     print("seed", seed, "bad", bad, flush=True)
 print("DONE bad =", bad)
