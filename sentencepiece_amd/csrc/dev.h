@@ -113,7 +113,7 @@ struct SpmxDev {
 // ptrie unit word w: 32-bit summary of the node's child labels, bit ChildBit(c) set for every child byte c.
 // A clear bit proves "no child c" without a probe (the walk's last, failing probe is usually predictable:
 // 97 % on the round-1 bench corpus); a set bit means "probe".
-SPMX_HD inline uint32_t ChildBit(uint32_t c) { return ((c * 37u) >> 3) & 31u; }
+SPMX_HD inline uint32_t ChildBit(uint32_t c) { return c & 31u; }
 
 SPMX_HD inline uint32_t HashPair(uint32_t a, uint32_t b) {
   uint64_t h = (static_cast<uint64_t>(a) << 32 | b) * 0x9E3779B97F4A7C15ull;
