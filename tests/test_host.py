@@ -165,3 +165,38 @@ def test_emu_encode_batch_multi(emu, oracle, corpora):
     oids, oio = oracle.load(blob).encode_batch(text, offs)
     np.testing.assert_array_equal(io, oio)
     np.testing.assert_array_equal(ids, oids)
+
+
+def test_emu_degenerate_batches(emu, oracle):
+    """Empty batches, empty sentences and null pointers through every host form: the reference's batch is a loop of
+    Encode calls, so n = 0 gives an empty CSR and an empty sentence an empty id range (bos / eos when asked for)."""
+    blob = fixtures.model_blob("test_model")
+    h, o = emu.load(blob), oracle.load(blob)
+    lib = h.lib
+    # n = 0 through the packed form
+    p_ids, p_off = C.c_void_p(), C.c_void_p()
+    offs0 = np.zeros(1, dtype=np.uint64)
+    assert lib.spmx_encode_batch(h.sp._h, None, offs0.ctypes.data, 0, C.byref(p_ids), C.byref(p_off)) == 0
+    assert np.ctypeslib.as_array(C.cast(p_off, C.POINTER(C.c_uint64)), shape=(1,))[0] == 0
+    lib.spmx_free(p_ids); lib.spmx_free(p_off)
+    # n = 0 and empty views
+    ids, io = views_call(lib, h.sp._h, [])
+    assert len(ids) == 0 and io.tolist() == [0]
+    ids, io = views_call(lib, h.sp._h, [b"", b"a", b"", b""])
+    want, wio = o.encode_batch(*__import__("sentencepiece_amd.synth", fromlist=["pack"]).pack([b"", b"a", b"", b""]))
+    np.testing.assert_array_equal(io, wio)
+    np.testing.assert_array_equal(ids, want)
+    # empty sentences keep their bos / eos
+    h.set_encode_extra_options("bos:eos")
+    o.set_encode_extra_options("bos:eos")
+    ids, io = views_call(lib, h.sp._h, [b"", b" ", b"x"])
+    want, wio = o.encode_batch(*__import__("sentencepiece_amd.synth", fromlist=["pack"]).pack([b"", b" ", b"x"]))
+    np.testing.assert_array_equal(io, wio)
+    np.testing.assert_array_equal(ids, want)
+    # null output containers are an error, not a crash
+    assert lib.spmx_encode_batch(h.sp._h, None, offs0.ctypes.data, 0, None, None) != 0
+    # the lattice entry points on an empty batch
+    h.set_encode_extra_options("")
+    for fn in (lambda: h.sp.SampleEncodePacked(np.zeros(0, np.uint8), offs0, -1, 0.1), lambda: h.sp.EncodeOriginalPacked(np.zeros(0, np.uint8), offs0)):
+        ids, io = fn()
+        assert len(ids) == 0 and io.tolist() == [0]
