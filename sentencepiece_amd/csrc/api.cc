@@ -229,6 +229,7 @@ struct spmx_handle {
   bool no_fast = false;          // SPMX_NO_FAST=1: every tile runs the general normalizer
   bool no_lane_general = false;  // SPMX_NO_LANE_GENERAL=1: main tiles set every non-ASCII sentence aside
   bool no_stream = false;        // SPMX_NO_STREAM=1: BPE in the sentence-per-wave form only
+  uint64_t arena_first = 0;      // SPMX_ARENA_FIRST: cap on the first attempt's id arena (tests: the overflow-and-retry path)
   bool no_bp_short = false;      // SPMX_NO_BP_SHORT=1: 32-bit back-pointer entries for every unigram model
   bool no_wave = false;          // SPMX_NO_WAVE=1: BPE models that are not word-wise use the long form only
   int tile_waves_override = 0;   // SPMX_TILE_WAVES: cap on wavefronts per workgroup of the streaming kernels
@@ -559,16 +560,25 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
     ScanArgs sa{ws->d_counts.p, n32, ws->d_tile_sums.p, d_id_offsets};
     const uint32_t tiles = (n32 + kScanTile - 1) / kScanTile;
     HIP_OR_RETURN(h, LaunchScan(sa, static_cast<int>(tiles < static_cast<uint32_t>(wide) ? tiles : wide), stream));
+    // The status comes back BEFORE the compaction is launched: after an arena overflow some kernels (the long form, the
+    // sentence-per-wave BPE) leave the range they asked for in tmp_off / counts, beyond the arena's end -- compacting
+    // that would read past the allocation (seen as a memory fault on the GPU, found again under ASAN on the emulator).
+    // The caller re-runs the batch with the arena arena_head asks for.
+    HIP_OR_RETURN(h, hipMemcpyAsync(ws->h_ctrl, ws->d_ctrl, offsetof(Ctrl, total_ids), hipMemcpyDeviceToHost, stream));
+    HIP_OR_RETURN(h, hipMemcpyAsync(&ws->h_ctrl->total_ids, d_id_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+    if (ws->h_ctrl->status & kStArenaOverflow) return kOk;
     CompactArgs pa{ws->d_arena.p, ws->d_tmp_off.p, ws->d_counts.p, d_id_offsets, d_ids, d_ids ? ids_capacity : 0, n32};
     const uint64_t cblocks = (n + 63) / 64;
     const uint64_t cgrid = cblocks < static_cast<uint64_t>(h->n_cu) * 32 ? cblocks : static_cast<uint64_t>(h->n_cu) * 32;
     HIP_OR_RETURN(h, LaunchCompact(pa, static_cast<int>(cgrid), stream));
-    HIP_OR_RETURN(h, hipMemcpyAsync(ws->h_ctrl, ws->d_ctrl, offsetof(Ctrl, total_ids), hipMemcpyDeviceToHost, stream));
-    HIP_OR_RETURN(h, hipMemcpyAsync(&ws->h_ctrl->total_ids, d_id_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-    HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+    HIP_OR_RETURN(h, hipStreamSynchronize(stream));      // (as before: the call returns with its outputs complete)
     return kOk;
   };
-  for (int attempt = 0; attempt < 3; ++attempt) {
+  // SPMX_ARENA_FIRST=<ids>: the first attempt's arena is no larger than this (tests force the overflow-and-retry path)
+  uint64_t arena_cap_limit = 0;
+  if (h->arena_first && arena_need > h->arena_first) { arena_need = h->arena_first; arena_cap_limit = h->arena_first; }
+  for (int attempt = 0; attempt < 4; ++attempt) {
     HIP_OR_RETURN(h, ws->d_arena.Reserve(arena_need));
     if (spans) HIP_OR_RETURN(h, ws->d_arena_tb.Reserve(ws->d_arena.cap));
     if (prof) HIP_OR_RETURN(h, hipEventRecord(ws->ev[kNumSlots][0], stream));
@@ -584,7 +594,8 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
     // what every encode launch shares
     EncodeArgs a{};
     a.dev = h->dev; a.text = d_text; a.offs = d_offsets;
-    a.arena = ws->d_arena.p; a.arena_head = &ws->d_ctrl->arena_head; a.arena_cap = ws->d_arena.cap;
+    a.arena = ws->d_arena.p; a.arena_head = &ws->d_ctrl->arena_head;
+    a.arena_cap = attempt == 0 && arena_cap_limit && arena_cap_limit < ws->d_arena.cap ? arena_cap_limit : ws->d_arena.cap;
     a.tmp_off = ws->d_tmp_off.p; a.counts = ws->d_counts.p; a.sent_status = d_status; a.status = &ws->d_ctrl->status;
     a.arena_tb = spans ? ws->d_arena_tb.p : nullptr;
     a.long_list = long_list; a.side = &ws->d_ctrl->side;
@@ -629,7 +640,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       if (count == 0) return kOk;
       LongArgs la{};
       la.dev = h->dev; la.text = d_text; la.offs = d_offsets;
-      la.arena = ws->d_arena.p; la.arena_head = &ws->d_ctrl->arena_head; la.arena_cap = ws->d_arena.cap;
+      la.arena = ws->d_arena.p; la.arena_head = &ws->d_ctrl->arena_head; la.arena_cap = a.arena_cap;
       la.tmp_off = ws->d_tmp_off.p; la.counts = ws->d_counts.p; la.sent_status = d_status; la.status = &ws->d_ctrl->status;
       la.side = &ws->d_ctrl->side; la.arena_tb = spans ? ws->d_arena_tb.p : nullptr;
       la.stack_cap = static_cast<uint32_t>(h->tables.max_piece_len) + 8u;
@@ -1043,6 +1054,7 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_NO_STREAM")) h->no_stream = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_WAVE")) h->no_wave = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_BP_SHORT")) h->no_bp_short = e[0] == '1';
+    if (const char *e = getenv("SPMX_ARENA_FIRST")) h->arena_first = static_cast<uint64_t>(atoll(e));
     if (const char *e = getenv("SPMX_WIDE_TCAP")) h->wide_tcap = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_LANE_GENERAL")) h->no_lane_general = e[0] == '1';
     if (const char *e = getenv("SPMX_SUB_BUCKETS")) {

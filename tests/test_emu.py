@@ -421,3 +421,31 @@ def test_emu_first_offset_not_rebased(model, emu, oracle, corpora):
         ids, io = h.encode_batch(pad, offs + np.uint64(shift))
         np.testing.assert_array_equal(io, wio)
         np.testing.assert_array_equal(ids, want)
+
+
+@pytest.mark.parametrize("model", ["test_model", "uni1k_uds", "bpe1k", "bpe1k_noesc", "bpe1k_bf_uds"])
+def test_emu_arena_overflow_and_retry(model, emu, oracle, corpora):
+    """The id arena of a call is sized by an estimate; a batch that outgrows it is encoded again with the arena the first
+    attempt asked for.  SPMX_ARENA_FIRST forces that path for every kernel family (stream lanes, sentence per wave, long
+    form): same ids, and -- the round-2 bug -- nothing compacted from beyond the arena's end in between (the status comes
+    back before the compaction is launched; ASAN on the emulator and a memory fault on the GPU found it)."""
+    from sentencepiece_amd import synth
+    blob = fixtures.model_blob(model)
+    h = emu.load(blob, env={"SPMX_ARENA_FIRST": "600"})
+    o = oracle.load(blob)
+    bot, boffs = corpora["botchan"]
+    docs = [bot[:int(boffs[400])].tobytes().replace(b"\n", b" "), b"ab " * 3000, b"x" * 2500 + b" 0123456789", b"", b"short one"]
+    text, offs = synth.pack(docs)
+    ids, io = h.encode_batch(text, offs)
+    oids, oio = o.encode_batch(text, offs)
+    np.testing.assert_array_equal(io, oio)
+    np.testing.assert_array_equal(ids, oids)
+    text, offs = fixtures.head(*corpora["botchan"], 300)        # many short sentences: the staged classes
+    ids, io = h.encode_batch(text, offs)
+    oids, oio = o.encode_batch(text, offs)
+    np.testing.assert_array_equal(io, oio)
+    np.testing.assert_array_equal(ids, oids)
+    got = h.encode_spans(text, offs)
+    want = o.encode_spans(text, offs)
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(np.asarray(a).astype(np.int64), np.asarray(b).astype(np.int64))
