@@ -138,7 +138,8 @@ int spmx_encode(spmx_handle *h, const char *text, uint64_t len, int32_t *ids, ui
  *   (src/sentencepiece_processor.h:311-312, .cc:761-925): control pieces vanish, the unknown piece becomes
  *   trainer_spec.unk_surface, byte pieces are reassembled into UTF-8 (a structurally invalid byte -> U+FFFD),
  *   U+2581 -> ' ', leading whitespace handled as the normalizer_spec asks.  An id outside [0, GetPieceSize())
- *   fails the call with OUT_OF_RANGE (11) "Invalid id: N"; a model with a denormalizer_spec is UNIMPLEMENTED (12).
+ *   fails the call with OUT_OF_RANGE (11) "Invalid id: N"; a model with a denormalizer_spec has its rules applied to
+ *   the decoded text (.cc:905-907).
  * Ids are CSR (as produced by the encode calls); text comes back packed with text_offsets (n + 1 entries). */
 
 /* Device-resident form: every pointer is HIP device memory.  If text_capacity is too small (or d_text is NULL)
@@ -168,6 +169,14 @@ int spmx_encode_batch_spans_device(spmx_handle *h, const void *d_text, uint64_t 
                                    uint64_t *total_ids);
 int spmx_encode_batch_spans(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
                             uint64_t **id_offsets, uint32_t **begin, uint32_t **end, uint32_t **nbegin, uint32_t **nend);
+/* As above, plus *status (nullable): n status bytes, released with spmx_free(); *n_failed (nullable): what
+ * Encode(input, SentencePieceText *) returns per sentence (src/sentencepiece_processor.cc:638-651 -> :628). */
+int spmx_encode_batch_spans_ex(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
+                               uint64_t **id_offsets, uint32_t **begin, uint32_t **end, uint32_t **nbegin, uint32_t **nend,
+                               uint8_t **status, uint64_t *n_failed);
+/* The message of a per-sentence status byte (the _ex forms): for INTERNAL (13) the reference's "all normalized
+ * characters are not consumed." (src/sentencepiece_processor.cc:628); "" for 0. */
+const char *spmx_status_message(int code);
 
 /* ---- batch Normalize ----------------------------------------------------
  * SentencePieceProcessor::Normalize(input, &normalized, &norm_to_orig) (src/sentencepiece_processor.cc:933-945 ->
@@ -196,13 +205,16 @@ int spmx_nbest_encode_batch(spmx_handle *h, const char *text, const uint64_t *of
                             int32_t **ids, uint64_t **id_offsets, float **scores, uint64_t **result_offsets);
 
 /* ---- sampling and the original encoder -----------------------------------
- * SampleEncode(input, nbest_size, alpha, std::vector<int>*) (src/sentencepiece_processor.h:333-334, .cc:678-720) per
+ * SampleEncode(input, nbest_size, alpha, std::vector<int>*) (src/sentencepiece_processor.h:346-353, .cc:678-720) per
  * sentence, the subword-regularization entry:
- *   nbest_size < 0      unigram: one segmentation drawn from the lattice, Lattice::Sample(alpha) (forward filtering /
- *                       backward sampling, src/unigram_model.cc:511-542); BPE: BPE-dropout with merge-skip probability
- *                       alpha (src/bpe_model.cc:131-156)
- *   nbest_size 0 or 1   the plain encoder
- *   nbest_size > 1      unigram: one of the nbest_size best, drawn with probability ~ exp(alpha * score) (:700-716)
+ *   unigram models (IsNBestEncodeAvailable):
+ *     nbest_size < 0      one segmentation drawn from the lattice, Lattice::Sample(alpha) (forward filtering /
+ *                         backward sampling, src/unigram_model.cc:511-542)
+ *     nbest_size 0 or 1   the plain encoder
+ *     nbest_size > 1      one of the nbest_size best, drawn with probability ~ exp(alpha * score) (:700-716)
+ *   BPE models: EVERY nbest_size is BPE-dropout with merge-skip probability alpha (.cc:688-693 sends the call to
+ *     bpe::Model::SampleEncode, src/bpe_model.cc:131-156); alpha <= 0 is the plain encoder
+ *   nbest_size > 512    INTERNAL "nbest_size must be nbest_size <= 512" (.cc:684)
  * Draws come from generators keyed by (seed, sentence index) -- reproducible per call; the reference's thread-local
  * mt19937 stream is not (and cannot be) reproduced, its own tests pin the DISTRIBUTION (unigram_model_test.cc:429-470,
  * bpe_model_test.cc:252-295), as tests/test_sampling.py does.  alpha = 0 under BPE is bit-equal to Encode. */

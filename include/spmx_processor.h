@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <random>
 #include <string>
 #include <string_view>
 #include <utility>
@@ -126,13 +127,17 @@ class SentencePieceProcessor {
     ids->clear();
     int32_t *out = nullptr;
     uint64_t *offs = nullptr;
+    uint8_t *st = nullptr;
     const uint64_t io[2] = {0, input.size()};
-    const int rc = spmx_encode_batch(h_, input.data(), io, 1, &out, &offs);
+    const int rc = spmx_encode_batch_ex(h_, input.data() ? input.data() : "", io, 1, &out, &offs, &st, nullptr);
     if (rc != 0) return FromHandle(rc);
-    ids->assign(out, out + offs[1]);
+    // the sentence's own Status, as the reference returns it (sentencepiece_processor.cc:392-403 -> :628)
+    const int code = st ? st[0] : 0;
+    if (code == 0) ids->assign(out, out + offs[1]);
     spmx_free(out);
     spmx_free(offs);
-    return util::Status();
+    spmx_free(st);
+    return code == 0 ? util::Status() : util::Status(static_cast<util::StatusCode>(code), spmx_status_message(code));
   }
   std::vector<int> EncodeAsIds(std::string_view input) const {   // errors are swallowed, as in the reference (:427-436)
     std::vector<int> ids;
@@ -220,8 +225,15 @@ class SentencePieceProcessor {
     int32_t *ids = nullptr;
     uint64_t *io = nullptr, *no = nullptr;
     uint32_t *b = nullptr, *e = nullptr, *nb = nullptr, *ne = nullptr;
+    uint8_t *st = nullptr;
     char *norm = nullptr;
-    int rc = spmx_encode_batch_spans(h_, input.data() ? input.data() : "", offs, 1, &ids, &io, &b, &e, &nb, &ne);
+    int rc = spmx_encode_batch_spans_ex(h_, input.data() ? input.data() : "", offs, 1, &ids, &io, &b, &e, &nb, &ne, &st, nullptr);
+    const int code = rc == 0 && st ? st[0] : 0;     // the sentence's own Status (sentencepiece_processor.cc:638-651 -> :628)
+    spmx_free(st);
+    if (code != 0) {
+      spmx_free(ids); spmx_free(io); spmx_free(b); spmx_free(e); spmx_free(nb); spmx_free(ne);
+      return util::Status(static_cast<util::StatusCode>(code), spmx_status_message(code));
+    }
     if (rc == 0) rc = spmx_normalize_batch(h_, input.data() ? input.data() : "", offs, 1, &norm, &no, nullptr);
     if (rc == 0) {
       spt->text.assign(input.data(), input.size());
@@ -278,11 +290,11 @@ class SentencePieceProcessor {
     return ids;
   }
 
-  // ---- sampling (sentencepiece_processor.h:333-334, .cc:678-720): lattice sampling / n-best sampling (unigram),
+  // ---- sampling (sentencepiece_processor.h:346-353, .cc:678-720): lattice sampling / n-best sampling (unigram),
   // BPE-dropout (BPE).  The draws are keyed by (seed, sentence); each call without a seed of its own takes the next
   // value of a per-process counter, so repeated calls draw afresh as the reference's thread-local generator does ----
   util::Status SampleEncode(std::string_view input, int nbest_size, float alpha, std::vector<int> *ids) const {
-    static std::atomic<uint64_t> calls{0};
+    static std::atomic<uint64_t> calls{std::random_device{}()};   // (the reference seeds from std::random_device, src/util.cc:202-204)
     return SampleEncode(input, nbest_size, alpha, ++calls, ids);
   }
   util::Status SampleEncode(std::string_view input, int nbest_size, float alpha, uint64_t seed, std::vector<int> *ids) const {

@@ -57,6 +57,10 @@ SYMBOLS = [
     ("spmx_encode_batch_spans", C.c_int,
      [_H, C.c_void_p, C.c_void_p, _U64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
       C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    ("spmx_encode_batch_spans_ex", C.c_int,
+     [_H, C.c_void_p, C.c_void_p, _U64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+      C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(_U64)]),
+    ("spmx_status_message", C.c_char_p, [C.c_int]),
     ("spmx_normalize_batch_device", C.c_int,
      [_H, C.c_void_p, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_U64)]),
     ("spmx_normalize_batch", C.c_int,

@@ -189,7 +189,7 @@ struct Workspace {
     d_lists.Free(); d_counts.Free(); d_tmp_off.Free(); d_tile_sums.Free(); d_chunk_base.Free(); d_arena.Free();
     d_arena_tb.Free(); d_tok_begin.Free(); d_span_begin.Free(); d_span_end.Free(); d_nspan_begin.Free(); d_nspan_end.Free();
     d_norm.Free(); d_nbest_scratch.Free(); d_slab.Free(); d_pool.Free(); d_sent_status.Free(); d_res_off.Free();
-    d_res_score.Free(); d_text.Free(); d_offs.Free(); d_id_offs.Free(); d_ids.Free();
+    d_res_score.Free(); d_text.Free(); d_offs.Free(); d_id_offs.Free(); d_ids.Free(); d_dn_text.Free(); d_dn_offs.Free();
     h_text.Free(); h_offs.Free(); h_id_offs.Free();
     if (d_ctrl) (void)hipFree(d_ctrl);
     if (h_ctrl) (void)hipHostFree(h_ctrl);
@@ -275,9 +275,13 @@ struct Lease {
     if (ws) return kOk;
     ws.reset(new (std::nothrow) Workspace);
     if (!ws) return Fail(h, kResourceExhausted, "out of host memory");
-    HIP_OR_RETURN(h, hipMalloc(reinterpret_cast<void **>(&ws->d_ctrl), sizeof(Ctrl)));
-    HIP_OR_RETURN(h, hipHostMalloc(reinterpret_cast<void **>(&ws->h_ctrl), sizeof(Ctrl), hipHostMallocDefault));
-    HIP_OR_RETURN(h, hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&ws->d_ctrl), sizeof(Ctrl));
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&ws->h_ctrl), sizeof(Ctrl), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {          // a half-built workspace must not reach the pool (~Lease): the next call would lease it
+      ws.reset();
+      return FailHip(h, e, "creating a workspace");
+    }
     return kOk;
   }
   ~Lease() {
@@ -1363,7 +1367,10 @@ struct spmx_view_ { const char *data; uint64_t len; };
 uint64_t HostChunk(const spmx_handle *h, uint64_t n, int n_h) {
   if (h->host_chunk) return h->host_chunk;
   uint64_t c = (n + 8ull * n_h - 1) / (8ull * n_h);
-  if (c < (128u << 10)) c = 128u << 10;
+  // several handles (GPUs): every GPU must get chunks, so the floor drops with the batch (a 128 k floor left a batch
+  // below 128 k sentences on handles[0] alone)
+  const uint64_t floor_c = n_h > 1 ? (4u << 10) : (128u << 10);
+  if (c < floor_c) c = floor_c;
   if (c > (1u << 20)) c = 1u << 20;
   return c;
 }
@@ -1565,11 +1572,18 @@ int spmx_encode_batch(spmx_handle *h, const char *text, const uint64_t *offsets,
   return spmx_encode_batch_ex(h, text, offsets, n, ids, id_offsets, nullptr, nullptr);
 }
 
+int spmx_encode_batch_spans_ex(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
+                               uint64_t **id_offsets, uint32_t **begin, uint32_t **end, uint32_t **nbegin, uint32_t **nend,
+                               uint8_t **status, uint64_t *n_failed) {
+  if (h && (!begin || !end || (nbegin != nullptr) != (nend != nullptr))) return Fail(h, kInternal, "output container is null");
+  return Guard(h, [&]() -> int { return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, status, n_failed, begin, end, nbegin, nend); });
+}
 int spmx_encode_batch_spans(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int32_t **ids,
                             uint64_t **id_offsets, uint32_t **begin, uint32_t **end, uint32_t **nbegin, uint32_t **nend) {
-  if (h && (!begin || !end || (nbegin != nullptr) != (nend != nullptr))) return Fail(h, kInternal, "output container is null");
-  return Guard(h, [&]() -> int { return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, nullptr, nullptr, begin, end, nbegin, nend); });
+  return spmx_encode_batch_spans_ex(h, text, offsets, n, ids, id_offsets, begin, end, nbegin, nend, nullptr, nullptr);
 }
+
+const char *spmx_status_message(int code) { return code == kOk ? "" : StatusText(code); }
 
 int spmx_encode_batch_spans_device(spmx_handle *h, const void *d_text, uint64_t text_bytes, const uint64_t *d_offsets,
                                    uint64_t n, int32_t *d_ids, uint64_t ids_capacity, uint64_t *d_id_offsets,
@@ -1787,13 +1801,15 @@ int spmx_sample_encode_batch(spmx_handle *h, const char *text, const uint64_t *o
   if (!ids || !id_offsets) return Fail(h, kInternal, "output container is null");
   return Guard(h, [&]() -> int {
     *ids = nullptr; *id_offsets = nullptr;
-    if (nbest_size == 0 || nbest_size == 1) return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, nullptr, nullptr, nullptr, nullptr);
+    if (nbest_size > 512) return Fail(h, kInternal, "nbest_size must be nbest_size <= 512");   // sentencepiece_processor.cc:684
     if (h->model.model_type == kBpe) {
-      if (nbest_size > 1) return Fail(h, kInternal, "NBestEncode is not available for the current model.");
+      // !IsNBestEncodeAvailable(): every nbest_size goes to bpe::Model::SampleEncode(normalized, alpha) (:688-693),
+      // BPE-dropout with merge-skip probability alpha; alpha <= 0 is the plain merge order (bpe_model.cc:131-156)
       if (n && !offsets) return Fail(h, kInvalidArgument, "null offsets");
       if (n == 0 || !(alpha > 0.f)) return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, nullptr, nullptr, nullptr, nullptr);
       return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, alpha, seed);
     }
+    if (nbest_size == 0 || nbest_size == 1) return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, nullptr, nullptr, nullptr, nullptr);
     float *sc = nullptr;
     uint64_t *ro = nullptr;
     if (nbest_size < 0) {
@@ -1814,14 +1830,14 @@ int spmx_sample_encode_batch(spmx_handle *h, const char *text, const uint64_t *o
     std::vector<uint64_t> pick(n);
     uint64_t *oo = static_cast<uint64_t *>(malloc((n + 1) * sizeof(uint64_t)));
     uint64_t total = 0;
-    unsigned long long st = seed * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull;
     for (uint64_t s2 = 0; oo && s2 < n; ++s2) {
       const uint64_t r0 = ro[s2], r1 = ro[s2 + 1];
       double mx = -1e300, z = 0.0;
       for (uint64_t r = r0; r < r1; ++r) mx = std::max(mx, static_cast<double>(alpha) * sc[r]);
       for (uint64_t r = r0; r < r1; ++r) z += exp(static_cast<double>(alpha) * sc[r] - mx);
-      st += 0x9E3779B97F4A7C15ull;
-      unsigned long long x = st;
+      // keyed by (seed, sentence) with separate multipliers, as the device generators are (kernels_nbest.h): the
+      // draws of (seed, i) and (seed + 1, i - 1) are unrelated
+      unsigned long long x = seed * 0x9E3779B97F4A7C15ull + (s2 + 1) * 0xD1B54A32D192ED03ull;
       x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
       x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
       x ^= x >> 31;

@@ -202,7 +202,11 @@ class SentencePieceProcessor:
             if out_type is not int:
                 raise NotImplementedError("sampling is on the device path for out_type=int")
             # _SampleEncodeAsIds (sentencepiece.i): SampleEncode + RewriteIds; the draws are keyed by a fresh seed per call
-            self._sample_calls = getattr(self, "_sample_calls", 0) + 1
+            # (a per-process counter started from os.urandom: a fresh process does not replay the previous one's draws --
+            # the reference seeds its generator from std::random_device, src/util.cc:202-204)
+            if not hasattr(self, "_sample_calls"):
+                self._sample_calls = int.from_bytes(os.urandom(7), "little")
+            self._sample_calls += 1
             self._apply(self._add_bos if add_bos is None else add_bos, self._add_eos if add_eos is None else add_eos,
                         self._reverse if reverse is None else reverse)
             single = not isinstance(input, list)

@@ -14,7 +14,7 @@
 namespace sentencepiece = sentencepiece_amd;   // the one-line switch INTEGRATION.md describes
 
 int main(int argc, char **argv) {
-  if (argc < 3) { fprintf(stderr, "usage: facade_test MODEL TEXTFILE|--expect-unavailable [extra_options [--pieces]]\n"); return 2; }
+  if (argc < 3) { fprintf(stderr, "usage: facade_test MODEL TEXTFILE|--expect-unavailable [extra_options [--pieces|--status]]\n"); return 2; }
   sentencepiece::SentencePieceProcessor sp;
   if (sp.status().ok()) { fprintf(stderr, "status() must fail before Load\n"); return 1; }
   const sentencepiece::util::Status st = sp.Load(argv[1]);
@@ -32,6 +32,23 @@ int main(int argc, char **argv) {
   std::ifstream f(argv[2], std::ios::binary);
   std::vector<std::string> lines;
   for (std::string line; std::getline(f, line);) lines.push_back(line);
+  if (argc > 4 && std::string(argv[4]) == "--status") {
+    // one line per sentence: the Status of Encode(input, &ids), of Encode(input, &spt), of Encode(input, &pieces) as
+    // "code|message", then how many ids the error-swallowing EncodeAsIds returns (sentencepiece_processor.cc:392-403, :628)
+    for (const std::string &line : lines) {
+      std::vector<int> ids{7, 7, 7};
+      const sentencepiece::util::Status a = sp.Encode(line, &ids);
+      if (!a.ok() && !ids.empty()) { fprintf(stderr, "ids of a failing sentence\n"); return 1; }
+      sentencepiece::SentencePieceText spt;
+      const sentencepiece::util::Status b = sp.Encode(line, &spt);
+      std::vector<std::string> pcs{"x"};
+      const sentencepiece::util::Status c = sp.Encode(line, &pcs);
+      if (!c.ok() && !pcs.empty()) { fprintf(stderr, "pieces of a failing sentence\n"); return 1; }
+      std::cout << static_cast<int>(a.code()) << "|" << a.error_message() << "\t" << static_cast<int>(b.code()) << "|" << b.error_message()
+                << "\t" << static_cast<int>(c.code()) << "|" << c.error_message() << "\t" << sp.EncodeAsIds(line).size() << "\t" << ids.size() << "\n";
+    }
+    return 0;
+  }
   if (argc > 4 && std::string(argv[4]) == "--pieces") {
     // one line per sentence: hex(piece):id:begin:end ..., then "N " + hex(normalized) + the norm_to_orig entries
     auto hex = [](const std::string &x) { static const char *d = "0123456789abcdef"; std::string o; for (unsigned char c : x) { o += d[c >> 4]; o += d[c & 15]; } return o.empty() ? std::string("-") : o; };
@@ -66,10 +83,10 @@ int main(int argc, char **argv) {
     for (size_t k = 0; k < batch[i].size(); ++k) os << (k ? " " : "") << batch[i][k];
     std::cout << os.str() << "\n";
   }
-  {   // sampling: nbest_size 0 / 1 is Encode; a sampled segmentation decodes to the same text; the kOriginal encoder
+  {   // sampling: nbest_size 0 / 1 is Encode (unigram; BPE: dropout at alpha = 0); a sampled segmentation decodes to the same text; the kOriginal encoder
     const std::string &probe = lines.size() > 7 ? lines[7] : lines[0];
     std::vector<int> plain, same, drawn, orig;
-    if (!sp.Encode(probe, &plain).ok() || !sp.SampleEncode(probe, 1, 0.5f, &same).ok() || same != plain) { fprintf(stderr, "SampleEncode(nbest 1)\n"); return 1; }
+    if (!sp.Encode(probe, &plain).ok() || !sp.SampleEncode(probe, 1, 0.0f, &same).ok() || same != plain) { fprintf(stderr, "SampleEncode(nbest 1)\n"); return 1; }
     if (!sp.SampleEncode(probe, -1, 0.2f, 99, &drawn).ok()) { fprintf(stderr, "SampleEncode\n"); return 1; }
     std::string t1, t2;
     if (!sp.Decode(plain, &t1).ok() || !sp.Decode(drawn, &t2).ok() || t1 != t2) { fprintf(stderr, "sampled ids decode differently\n"); return 1; }

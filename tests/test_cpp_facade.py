@@ -103,3 +103,46 @@ def test_facade_pieces_and_normalize(model, opts, oracle, tmp_path):
         a = n2o[int(no[i]) + i:int(no[i + 1]) + i + 1]
         want_a = [] if (len(a) == 1 and a[0] == 0xFFFFFFFF) else [str(int(v)) for v in a]
         assert f[1:] == want_a, i
+
+
+def _status_case(tmp_path):
+    """A BPE model with a one-character CONTROL piece: a sentence that holds it is the reference's kInternal "all
+    normalized characters are not consumed." (sentencepiece_processor.cc:628)."""
+    from sentencepiece import sentencepiece_model_pb2 as pb
+    m = pb.ModelProto()
+    m.ParseFromString(fixtures.model_blob("bpe1k"))
+    p = m.pieces.add()
+    p.piece, p.score, p.type = "\u2603", 0.0, 3
+    mp = tmp_path / "ctl.model"
+    mp.write_bytes(m.SerializeToString())
+    lines = [b"hello world", "say \u2603 then".encode(), b"", b"the end", "\u2603".encode()]
+    tp = tmp_path / "in.txt"
+    tp.write_bytes(b"\n".join(lines) + b"\n")
+    return str(mp), str(tp), [0, 13, 0, 0, 13]
+
+
+def _check_status(out, want):
+    assert out.returncode == 0, out.stderr
+    rows = [r.split("\t") for r in out.stdout.split("\n") if r]
+    assert len(rows) == len(want)
+    for r, code in zip(rows, want):
+        for col in r[:3]:                 # Encode(ids), Encode(spt), Encode(pieces): the sentence's own Status
+            c, msg = col.split("|", 1)
+            assert int(c) == code, rows
+            assert msg == ("all normalized characters are not consumed." if code else ""), rows
+        if code:
+            assert r[3] == "0" and r[4] == "0"      # EncodeAsIds swallows the error and returns nothing
+
+
+def test_facade_encode_returns_the_sentence_status_emulated(tmp_path):
+    b = _build(emu=True)
+    mp, tp, want = _status_case(tmp_path)
+    _check_status(subprocess.run([b, mp, tp, "", "--status"], capture_output=True, text=True), want)
+
+
+@pytest.mark.gpu
+def test_facade_encode_returns_the_sentence_status(tmp_path):
+    """The C++ drop-in's Encode returns what the reference returns for a failing sentence: code 13 and its message, no ids."""
+    b = _build()
+    mp, tp, want = _status_case(tmp_path)
+    _check_status(subprocess.run([b, mp, tp, "", "--status"], capture_output=True, text=True), want)

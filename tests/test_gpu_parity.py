@@ -224,3 +224,73 @@ def test_text_at_any_alignment(model, procs, oracle, corpora):
         # spans + normalize forms read the same text
         got = sp.EncodeSpansPacked(pad, offs + np.uint64(shift))
         np.testing.assert_array_equal(np.asarray(got[0]), want)
+
+
+def _load_with_env(model, env):
+    """A processor whose handle reads the SPMX_* switches in `env` at load (restored afterwards)."""
+    import os
+    from sentencepiece_amd.processor import SentencePieceProcessor
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return SentencePieceProcessor(model_proto=fixtures.model_blob(model))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _escalation_inputs(corpora):
+    from sentencepiece_amd import synth
+    bot, boffs = corpora["botchan"]
+    docs = [bot[:int(boffs[400])].tobytes().replace(b"\n", b" "), b"ab " * 3000, b"x" * 2500 + b" 0123456789", b"", b"short one",
+            "日本語のテキスト ".encode() * 40, b"  lead and trail  "]
+    return synth.pack(docs), fixtures.head(*corpora["botchan"], 1200)
+
+
+@pytest.mark.parametrize("model", ["test_model", "uni1k_uds", "uni32k", "bpe1k", "bpe1k_noesc", "bpe1k_bf_uds", "bpe32k"])
+def test_arena_overflow_and_retry_on_the_gpu(model, oracle, corpora):
+    """The GPU twin of tests/test_emu.py::test_emu_arena_overflow_and_retry: SPMX_ARENA_FIRST caps the first attempt's id
+    arena, so every kernel family (lane-per-sentence, sentence-per-wave, long form, the word path) overflows, reports it
+    BEFORE the compaction runs, and the batch is encoded again with the arena the first attempt asked for."""
+    sp = _load_with_env(model, {"SPMX_ARENA_FIRST": "600"})
+    o = oracle.load(fixtures.model_blob(model))
+    for text, offs in _escalation_inputs(corpora):
+        ids, io, st, failed = sp.EncodePackedEx(text, offs)
+        assert failed == 0 and not st.any()
+        oids, oio = o.encode_batch(text, offs)
+        np.testing.assert_array_equal(io, oio)
+        np.testing.assert_array_equal(ids, oids)
+    text, offs = fixtures.head(*corpora["botchan"], 300)
+    got = sp.EncodeSpansPacked(text, offs)
+    want = o.encode_spans(text, offs)
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(np.asarray(a).astype(np.int64), np.asarray(b).astype(np.int64))
+
+
+@pytest.mark.parametrize("model", ["test_model", "uni1k_uds", "uni1k_suffix", "uni32k", "test_ja_model", "bpe1k", "bpe1k_noesc",
+                                   "bpe1k_bf_uds", "bpe1k_llama", "bpe32k"])
+def test_small_class_table_runs_every_escalation_list_on_the_gpu(model, oracle, corpora):
+    """SPMX_CLASSES with a tiny first class (the table the CPU suite uses under the emulator): short inputs overflow their
+    text columns, escalate class by class, take the overflow launch and the long form -- on hardware."""
+    from tests.emulib import SMALL_CLASSES
+    sp = _load_with_env(model, {"SPMX_CLASSES": SMALL_CLASSES})
+    o = oracle.load(fixtures.model_blob(model))
+    inputs = list(_escalation_inputs(corpora)) + [fixtures.head(*corpora["ja"], 400), corpora["edge"], fixtures.head(*corpora["mixed2k"], 300)]
+    for text, offs in inputs:
+        ids, io, st, failed = sp.EncodePackedEx(text, offs)
+        assert failed == 0 and not st.any()
+        oids, oio = o.encode_batch(text, offs)
+        np.testing.assert_array_equal(io, oio)
+        np.testing.assert_array_equal(ids, oids)
+    text, offs = fixtures.head(*corpora["botchan"], 300)
+    got = sp.EncodeSpansPacked(text, offs)
+    want = o.encode_spans(text, offs)
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(np.asarray(a).astype(np.int64), np.asarray(b).astype(np.int64))
+    gn = sp.NormalizePacked(text, offs, with_offsets=True)
+    wn = o.normalize_batch(text, offs)
+    for a, b in zip(gn, wn):
+        np.testing.assert_array_equal(np.asarray(a).astype(np.int64), np.asarray(b).astype(np.int64))

@@ -69,16 +69,44 @@ def test_original_encoder_matches_reference(model, emu, ref, corpora):
 
 @pytest.mark.parametrize("model", ["test_model", "uni1k_bf", "bpe1k", "bpe1k_bf_uds", "bpe1k_noesc"])
 def test_degenerate_sampling_is_encode(model, emu, corpora):
-    """nbest_size 0 / 1 is the plain encoder (src/sentencepiece_processor.cc:690-692); so is BPE-dropout at alpha = 0."""
+    """Unigram: nbest_size 0 / 1 is the plain encoder (src/sentencepiece_processor.cc:694-697).  BPE: every nbest_size
+    is BPE-dropout (:688-693, IsNBestEncodeAvailable() is false), which is the plain encoder at alpha = 0."""
     from sentencepiece_amd import synth
     h = emu.load(fixtures.model_blob(model))
     sents = [s for s in sentences(corpora) if len(s) <= 250]
     text, offs = synth.pack(sents)
     want = rows(*h.EncodePacked(text, offs))
-    for nb in (0, 1):
-        assert rows(*h.SampleEncodePacked(text, offs, nb, 0.5, seed=7)) == want
     if model.startswith("bpe"):
-        assert rows(*h.SampleEncodePacked(text, offs, -1, 0.0, seed=7)) == want
+        for nb in (-1, 0, 1, 5):
+            assert rows(*h.SampleEncodePacked(text, offs, nb, 0.0, seed=7)) == want
+    else:
+        for nb in (0, 1):
+            assert rows(*h.SampleEncodePacked(text, offs, nb, 0.5, seed=7)) == want
+
+
+@pytest.mark.parametrize("model", ["bpe1k", "bpe1k_noesc"])
+def test_bpe_sample_encode_ignores_nbest_size(model, emu, ref, corpora):
+    """A BPE model has no n-best: SampleEncode sends every nbest_size to BPE-dropout with alpha
+    (src/sentencepiece_processor.cc:688-693).  alpha = 1 skips every merge, so it is bit-comparable with the reference's
+    own SampleEncode at nbest_size 0, 1 and 5; nbest_size > 512 is the reference's error (:684)."""
+    from sentencepiece_amd import synth
+    blob = fixtures.model_blob(model)
+    h, r = emu.load(blob), ref.load(blob)
+    sents = [s for s in sentences(corpora) if len(s) <= 250][:60]
+    text, offs = synth.pack(sents)
+    for nb in (0, 1, 5):
+        got = rows(*h.SampleEncodePacked(text, offs, nb, 1.0, seed=3))
+        for s, g in zip(sents, got):
+            assert g == r.sample_encode(s, nb, 1.0), (model, nb, s[:40])
+    with pytest.raises(RuntimeError, match="nbest_size must be nbest_size <= 512"):
+        h.SampleEncodePacked(text, offs, 513, 0.5, seed=1)
+
+
+def test_unigram_sample_encode_rejects_large_nbest(emu, corpora):
+    from sentencepiece_amd import synth
+    h = emu.load(fixtures.model_blob("test_model"))
+    with pytest.raises(RuntimeError, match="nbest_size must be nbest_size <= 512"):
+        h.SampleEncodePacked(*synth.pack([b"hello world"]), 513, 0.5, seed=1)
 
 
 @pytest.mark.parametrize("model", ["bpe1k", "bpe1k_bf_uds", "bpe1k_noesc", "bpe1k_llama"])
