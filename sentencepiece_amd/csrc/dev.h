@@ -35,6 +35,10 @@ enum : uint32_t {
   // U+2581 with a U+2581 to its right: a sentence can be segmented word by word, a word being a run of U+2581
   // plus what follows up to the next one (kernels_bpe_stream.h)
   kNfBpeWordwise = 1u << 10,
+  // unigram only: the word form (kernels_word.h) applies -- no piece has a space symbol after its first character, the
+  // normalizer adds a dummy prefix, removes extra whitespace and escapes whitespace with the one-byte space symbol, no
+  // charsmap rule starts with a byte 0x20 .. 0x7E, and the word memo (umemo) is not empty
+  kNfUniWordwise = 1u << 11,
 };
 
 // One-byte stand-in for U+2581 under kNfCompressSp.  0xFF never occurs in valid UTF-8, and the normalizer's
@@ -106,6 +110,14 @@ struct SpmxDev {
   // each), id0, id1, id2}; empty: len == 0.  Open addressing on HashWord.
   const U4 *wordtab;
   uint32_t wordtab_mask;      // 0: no table
+  // word memo (unigram, kNfUniWordwise; kernels_word.h): EncodeOptimized of every vocabulary string that is a whole
+  // word -- the space symbol and then 1 .. 16 bytes 0x21 .. 0x7E -- computed at load in double.  Slot = two U4:
+  // {the 16 raw bytes of the word WITHOUT its space symbol, zero padded} {id0, id1 or 0xFFFFFFFF, score of id0 (float
+  // bits), bmax (float bits): the entry is valid while |best_path_score before the word| < bmax}; empty: id0 ==
+  // 0xFFFFFFFF.  Open addressing on HashWordKey.  pscore: score per piece id (the second piece's score).
+  const U4 *umemo;
+  const float *pscore;
+  uint32_t umemo_mask;        // 0: no memo
   uint32_t n_pieces;      // symbols below this are piece ids (their own final id); the rest are extra characters
   int32_t model_type;     // 1 unigram, 2 bpe
 };
@@ -125,6 +137,12 @@ SPMX_HD inline uint32_t HashWord(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t
   h = (h ^ (h >> 13)) + k2 * 0xC2B2AE3Du;
   h = (h ^ (h >> 16)) + k3 * 0x27D4EB2Fu;
   return h ^ (h >> 15);
+}
+// word memo of the unigram word form (kernels_word.h): cheap on the vector ALU -- three rotates, one multiply
+SPMX_HD inline uint32_t HashWordKey(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
+  const uint32_t h = k0 ^ ((k1 << 9) | (k1 >> 23)) ^ ((k2 << 18) | (k2 >> 14)) ^ ((k3 << 27) | (k3 >> 5));
+  const uint32_t g = h * 0x9E3779B1u;
+  return g ^ (g >> 15);
 }
 constexpr uint32_t kWordKeyBytes = 16;   // words longer than this are not looked up
 constexpr uint32_t kWordMaxIds = 3;

@@ -95,6 +95,9 @@ struct EncodeArgs {
   uint32_t fast_ok;             // the model meets fast_norm_stream's preconditions
   uint32_t no_lane_general;     // A/B switch: ASCII tiles put every non-ASCII sentence into the backlog
   StreamClass cls[kMaxClasses];
+  // ---- word kernel (kernels_word.h): what it cannot take, per length class, for the general launch that follows ----
+  uint32_t *left_lists;         // n_classes x n
+  uint32_t *left_counts;        // n_classes (zeroed before the launch)
   // ---- sentence-per-wave launch (BPE models that are not word-wise; kernels_bpe.h) ----
   const uint32_t *list;         // sentence indices of this length class
   const uint32_t *list_count;   // number of entries in list (device resident)
@@ -827,6 +830,7 @@ SPMX_DEVICE void compact_block(const CompactArgs &a) {
 
 #include "kernels_bpe_stream.h"
 #include "kernels_stream.h"
+#include "kernels_word.h"
 #include "kernels_decode.h"
 #include "kernels_split.h"
 #include "kernels_align.h"

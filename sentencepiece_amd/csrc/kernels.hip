@@ -31,6 +31,10 @@ __global__ __launch_bounds__(1024) void EncodeBpeStreamKernel(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   encode_stream_block<2, 0, false>(a, smem);
 }
+__global__ __launch_bounds__(1024) void EncodeWordKernel(EncodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  encode_word_block(a, smem);
+}
 __global__ __launch_bounds__(64) void BpeLongKernel(LongArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[64 * kRawWinBytes];
   bpe_long_block(a, smem);
@@ -121,6 +125,16 @@ hipError_t LaunchEncodeStream(int model_type, bool uds, const EncodeArgs &a, int
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * waves), lds_bytes, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t LaunchEncodeWord(const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t stream) {
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(EncodeWordKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds_bytes));
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(EncodeWordKernel, dim3(grid), dim3(64 * waves), lds_bytes, stream, a);
   return hipGetLastError();
 }
 

@@ -1,6 +1,7 @@
 #include "tables.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -494,6 +495,121 @@ Status CompileTables(const ModelData &m, HostTables *t) {
   return Status::OK();
 }
 
+// The word memo of the unigram word form (dev.h umemo, kernels_word.h): for every vocabulary string that is a whole word
+// -- U+2581 and then 1 .. 16 bytes 0x21 .. 0x7E -- EncodeOptimized (src/unigram_model.cc:889-1020) of that word alone, in
+// double, together with the margin analysis kernels_word.h states: `gap` = the smallest lead of the best candidate over
+// the second best at the positions on the word's best path, `wmag` = the largest magnitude of any candidate.  The entry
+// is valid while |best_path_score before the word| < bmax, bmax = 2^(k + 1) - wmag with 2^(k - 23) the largest float
+// ulp not above gap / (4 * nchar + 4).  Words whose best path holds an unknown piece, more than two pieces, or an exact
+// tie are left out: they take the general kernels.
+void BuildWordMemo(const ModelData &m, HostTables *t) {
+  SpmxDev &sc = t->scalars;
+  t->umemo.assign(2, U4{0, 0, 0, 0});
+  t->umemo[1].x = 0xFFFFFFFFu;
+  sc.umemo_mask = 0;
+  sc.flags &= ~kNfUniWordwise;
+  t->memo_words = t->memo_candidates = 0;
+  t->pscore.assign(m.pieces.size() + 1, 0.f);
+  for (size_t i = 0; i < m.pieces.size(); ++i) t->pscore[i] = m.pieces[i].score;
+  if (m.model_type != kUnigram || getenv("SPMX_NO_WORD")) return;
+  const uint32_t F = sc.flags;
+  if (!(F & kNfCompressSp) || !(F & kNfAddDummyPrefix) || !(F & kNfRemoveExtraWs) || (F & kNfWsSuffix) || (F & kNfHasUserDefined)) return;
+  for (uint32_t b = 0x20; b < 0x7F; ++b)
+    if (!((sc.ascii_safe[b >> 5] >> (b & 31u)) & 1u)) return;     // a charsmap rule may start with an ASCII byte
+  const std::string sp(kSpaceSymbol);
+  // no piece may reach across a word boundary; no USER_DEFINED piece (its score is not a float, :979-981)
+  for (const auto &kv : m.pieces_map) {
+    if (kv.first.find(sp, 1) != std::string::npos) return;
+    if (m.pieces[kv.second].type == kUserDefined) return;
+  }
+  const double unk_score = static_cast<double>(m.min_score - 10.0f);
+  struct Ent { uint32_t k[4]; uint32_t id0, id1; float s0, bmax; float order; };
+  std::vector<Ent> ents;
+  for (const auto &kv : m.pieces_map) {
+    const std::string &pc = kv.first;
+    if (pc.size() <= sp.size() || pc.size() > sp.size() + kWordKeyBytes || pc.compare(0, sp.size(), sp) != 0) continue;
+    const std::string body = pc.substr(sp.size());
+    bool plain = true;
+    for (unsigned char c : body) plain = plain && c >= 0x21 && c <= 0x7E;
+    if (!plain) continue;
+    ++t->memo_candidates;
+    // characters of the word: [0] = U+2581, then one byte each; cb[i] = byte offset of character i
+    const int nchar = 1 + static_cast<int>(body.size());
+    auto cb = [&](int i) -> size_t { return i == 0 ? 0 : sp.size() + static_cast<size_t>(i - 1); };
+    const double kNone = -1e300;
+    std::vector<double> best(nchar + 1, kNone), second(nchar + 1, kNone);
+    std::vector<int> bp(nchar + 1, -1), bid(nchar + 1, -1);
+    best[0] = 0.0;
+    double wmag = 0.0;
+    auto relax = [&](int e, double cand, int s, int id) {
+      if (fabs(cand) > wmag) wmag = fabs(cand);
+      if (cand > best[e]) { second[e] = best[e]; best[e] = cand; bp[e] = s; bid[e] = id; }
+      else if (cand > second[e]) second[e] = cand;
+    };
+    for (int s = 0; s < nchar; ++s) {                     // every character start is reachable (a piece or UNK, :995-1005)
+      bool single = false;
+      for (int e = s + 1; e <= nchar; ++e) {
+        const auto it = m.pieces_map.find(pc.substr(cb(s), cb(e) - cb(s)));
+        if (it == m.pieces_map.end()) continue;
+        const PieceRec &r = m.pieces[it->second];
+        if (r.type == kUnused) continue;                  // :974
+        relax(e, best[s] + static_cast<double>(r.score), s, it->second);
+        if (e == s + 1) single = true;                    // :990 a piece of exactly one character
+      }
+      if (!single) relax(s + 1, best[s] + unk_score, s, -1);
+    }
+    // the best path and its smallest lead
+    std::vector<int> ids;
+    double gap = 1e300;
+    bool ok = true;
+    for (int e = nchar; e > 0 && ok; e = bp[e]) {
+      if (bp[e] < 0 || bid[e] < 0) { ok = false; break; }   // unreachable (cannot happen) / an unknown piece on the path
+      if (second[e] > kNone) gap = std::min(gap, best[e] - second[e]);
+      ids.push_back(bid[e]);
+    }
+    if (!ok || ids.size() > 2 || !(gap > 0.0)) continue;
+    std::reverse(ids.begin(), ids.end());
+    const double thr = gap / (4.0 * nchar + 4.0);
+    int ex = 0;
+    (void)frexp(thr, &ex);                                // thr = f * 2^ex, f in [0.5, 1): floor(log2 thr) = ex - 1
+    const int k = (ex - 1) + 23;                          // the largest k with 2^(k - 23) <= thr
+    double lim = k + 1 > 126 ? 3.0e38 : ldexp(1.0, k + 1);
+    double bmax = lim - wmag * (1.0 + 1e-6) - 1e-30;
+    if (!(bmax > 0.0)) continue;
+    if (getenv("SPMX_WORDMEMO_UNSAFE")) bmax = 3.1e38;    // TEST SEAM (scripts/fuzz_wordmemo.py): no margin guard -- shows the fuzz has teeth
+    float bf = bmax > 3.0e38 ? 3.0e38f : static_cast<float>(bmax);
+    if (static_cast<double>(bf) > bmax) bf = nextafterf(bf, 0.f);
+    if (!(bf > 0.f)) continue;
+    Ent en{};
+    unsigned char key[kWordKeyBytes] = {0};
+    memcpy(key, body.data(), body.size());
+    memcpy(en.k, key, sizeof(key));
+    en.id0 = static_cast<uint32_t>(ids[0]);
+    en.id1 = ids.size() > 1 ? static_cast<uint32_t>(ids[1]) : 0xFFFFFFFFu;
+    en.s0 = m.pieces[ids[0]].score;
+    en.bmax = bf;
+    en.order = m.pieces[kv.second].score;
+    ents.push_back(en);
+  }
+  size_t min_words = 64;                                  // a handful of whole words: every sentence would miss anyway
+  if (const char *e = getenv("SPMX_WORDMEMO_MIN")) min_words = static_cast<size_t>(atoll(e));
+  if (ents.size() < min_words) return;
+  // likelier words first: they get the slots their hash names, the rest walk (the kernel's lanes wait for the longest walk)
+  std::stable_sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.order > b.order; });
+  const uint32_t wsz = NextPow2(ents.size() * 2 + 16);
+  t->umemo.assign(static_cast<size_t>(wsz) * 2, U4{0, 0, 0, 0});
+  for (uint32_t i = 0; i < wsz; ++i) t->umemo[2 * i + 1].x = 0xFFFFFFFFu;
+  for (const Ent &e : ents) {
+    uint32_t sl = HashWordKey(e.k[0], e.k[1], e.k[2], e.k[3]) & (wsz - 1);
+    while (t->umemo[2 * sl + 1].x != 0xFFFFFFFFu) sl = (sl + 1) & (wsz - 1);
+    t->umemo[2 * sl] = U4{e.k[0], e.k[1], e.k[2], e.k[3]};
+    t->umemo[2 * sl + 1] = U4{e.id0, e.id1, FloatBits(e.s0), FloatBits(e.bmax)};
+  }
+  sc.umemo_mask = wsz - 1;
+  sc.flags |= kNfUniWordwise;
+  t->memo_words = static_cast<uint32_t>(ents.size());
+}
+
 void RefreshTypeFlags(const ModelData &m, HostTables *t) {
   (void)BuildDecodeTables(m, t);        // (cannot fail here: the same pieces passed at load)
   bool any_unused = false;
@@ -514,6 +630,7 @@ void RefreshTypeFlags(const ModelData &m, HostTables *t) {
       t->sym_final[i] = (t->sym_final[i] & ~kSfUnused) | (m.pieces[fid].type == kUnused ? kSfUnused : 0);
     }
   }
+  BuildWordMemo(m, t);                  // (follows the live piece types: an UNUSED piece is no candidate)
 }
 
 Status CompileExtraOptions(const ModelData &m, const std::string &opts, HostTables *t) {
@@ -583,6 +700,8 @@ void BindHostPointers(HostTables *t) {
   sc.sym_final = t->sym_final.data();
   sc.sym_len = t->sym_len.data();
   sc.wordtab = t->wordtab.data();
+  sc.umemo = t->umemo.data();
+  sc.pscore = t->pscore.data();
 }
 
 }  // namespace spmx

@@ -18,6 +18,9 @@ struct HostTables {
   // unigram
   std::vector<U4> ptrie;
   std::vector<uint8_t> plen;     // per id: byte length of the piece as the device sees it (SpmxDev::plen)
+  std::vector<U4> umemo;         // word memo of the word form (SpmxDev::umemo)
+  std::vector<float> pscore;     // per id: score (SpmxDev::pscore)
+  uint32_t memo_words = 0, memo_candidates = 0;   // entries in the memo / vocabulary strings that are whole words
   // bpe
   std::vector<U2> utrie;
   std::vector<U4> chartab, pairtab, wordtab;
@@ -40,6 +43,8 @@ Status BuildDecodeTables(const ModelData &m, HostTables *t);
 // Refreshes the type-dependent bits (UNUSED / USER_DEFINED flags) after
 // SetVocabulary / ResetVocabulary without rebuilding tries.
 void RefreshTypeFlags(const ModelData &m, HostTables *t);
+// The word memo of the unigram word form (dev.h umemo) from the current piece types; sets / clears kNfUniWordwise.
+void BuildWordMemo(const ModelData &m, HostTables *t);
 // Net effect of ApplyExtraOptions (src/sentencepiece_processor.cc:1019-1064)
 // for an option string such as "bos:eos:reverse".
 Status CompileExtraOptions(const ModelData &m, const std::string &opts, HostTables *t);

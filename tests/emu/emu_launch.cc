@@ -43,6 +43,10 @@ hipError_t LaunchEncodeStream(int model_type, bool uds, const EncodeArgs &a, int
   }
   return hipSuccess;
 }
+hipError_t LaunchEncodeWord(const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t) {
+  RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_word_block(a, s); });
+  return hipSuccess;
+}
 hipError_t LaunchBpeLong(const LongArgs &a, int grid, hipStream_t) {
   RunGrid(grid, 1, 64 * kRawWinBytes, [&](unsigned char *s) { bpe_long_block(a, s); });
   return hipSuccess;
