@@ -120,7 +120,7 @@ def main():
         oi, oo = o.encode_batch(text, offs)
         prof = h.sp.LastProfile()
         for c in prof["classes"]:
-            if c["kernel"] == "EncodeWordKernel":
+            if c["kernel"] in ("EncodeWordKernel", "EncodeWordDpKernel"):
                 n_word += c["sentences"]
         n_all += len(offs) - 1
         if h.status or not (np.array_equal(io, oo) and np.array_equal(ids, oi)):

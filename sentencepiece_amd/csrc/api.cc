@@ -51,7 +51,7 @@ constexpr uint32_t kLdsPerCu = 160u * 1024u;   // gfx950 (MI355X_MICROARCH.md)
 thread_local std::string t_error;              // text of the calling thread's last failing call
 
 // kernel slots of the per-call profile
-enum { kSlotMain = 0, kSlotDoc = 1, kSlotExact = 2, kSlotWave = 3, kSlotLong = 4, kSlotWord = 5, kNumSlots = 6 };
+enum { kSlotMain = 0, kSlotDoc = 1, kSlotExact = 2, kSlotWave = 3, kSlotLong = 4, kSlotWord = 5, kSlotWord2 = 6, kNumSlots = 7 };
 
 // ctrl block layout (device + pinned host mirror), zeroed before every call
 struct Ctrl {
@@ -60,8 +60,8 @@ struct Ctrl {
   uint32_t status;
   uint32_t retry_count[2];            // long form: sentences that found the pool exhausted (ping-pong)
   uint32_t pad;
-  StreamQueue q[4];                   // tile queues of the main / document / overflow launches; [3]: the word kernel
-  uint32_t left_counts[kMaxClasses];  // word kernel: sentences it left to the general launches, per class
+  StreamQueue q[5];                   // tile queues of the main / document / overflow launches; [3], [4]: the word kernels
+  uint32_t left_counts[2][kMaxClasses];   // word kernels: sentences the first / second pass left to the next one, per class
   uint32_t align_counts[kMaxClasses]; // spans form: escalation lists of the staged align kernels
   SideLists side;
   unsigned long long arena_head;
@@ -212,7 +212,7 @@ struct spmx_handle {
   DevBuf<uint32_t> d_ndarts, d_npair, d_sym_final, d_dec_info, d_dec_off;
   DevBuf<uint8_t> d_dec_bytes;
   DevBuf<uint8_t> d_nblob, d_plen;
-  DevBuf<U4> d_ptrie, d_chartab, d_pairtab, d_wordtab, d_umemo;
+  DevBuf<U4> d_ptrie, d_chartab, d_pairtab, d_wordtab, d_umemo, d_umemo16, d_uhot;
   DevBuf<float> d_pscore;
   DevBuf<U2> d_utrie;
   DevBuf<uint16_t> d_sym_len;
@@ -234,7 +234,9 @@ struct spmx_handle {
   uint64_t arena_first = 0;      // SPMX_ARENA_FIRST: cap on the first attempt's id arena (tests: the overflow-and-retry path)
   bool no_bp_short = false;      // SPMX_NO_BP_SHORT=1: 32-bit back-pointer entries for every unigram model
   bool no_wave = false;          // SPMX_NO_WAVE=1: BPE models that are not word-wise use the long form only
-  bool no_word = false;          // SPMX_NO_WORD_KERNEL=1: unigram models skip the word kernel (kernels_word.h)
+  bool no_word = false;          // SPMX_NO_WORD_KERNEL=1: unigram models skip the word kernels (kernels_word.h)
+  bool no_word_dp = false;       // SPMX_NO_WORD_DP=1: ... skip the second pass only
+  bool force_word_dp = false;    // SPMX_FORCE_WORD_DP=1: the second pass runs whatever the first one left (tests)
   int tile_waves_override = 0;   // SPMX_TILE_WAVES: cap on wavefronts per workgroup of the streaming kernels
   uint32_t lane_general_min_lanes = 0;   // SPMX_LANE_GENERAL_MIN_LANES (0: per class)
   uint32_t sub_buckets = kSubBuckets;    // SPMX_SUB_BUCKETS: length sub-buckets per class in the classify sort (1..64)
@@ -315,6 +317,8 @@ int UploadTables(spmx_handle *h) {
   HIP_OR_RETURN(h, Upload(&h->d_pairtab, t.pairtab));
   HIP_OR_RETURN(h, Upload(&h->d_wordtab, t.wordtab));
   HIP_OR_RETURN(h, Upload(&h->d_umemo, t.umemo));
+  HIP_OR_RETURN(h, Upload(&h->d_umemo16, t.umemo16));
+  HIP_OR_RETURN(h, Upload(&h->d_uhot, t.uhot));
   HIP_OR_RETURN(h, Upload(&h->d_pscore, t.pscore));
   HIP_OR_RETURN(h, Upload(&h->d_sym_final, t.sym_final));
   HIP_OR_RETURN(h, Upload(&h->d_sym_len, t.sym_len));
@@ -333,6 +337,8 @@ int UploadTables(spmx_handle *h) {
   h->dev.pairtab = h->d_pairtab.p;
   h->dev.wordtab = h->d_wordtab.p;
   h->dev.umemo = h->d_umemo.p;
+  h->dev.umemo16 = h->d_umemo16.p;
+  h->dev.uhot = h->d_uhot.p;
   h->dev.pscore = h->d_pscore.p;
   h->dev.sym_final = h->d_sym_final.p;
   h->dev.sym_len = h->d_sym_len.p;
@@ -363,6 +369,8 @@ int RefreshDevice(spmx_handle *h, bool types_changed) {
     if (h->model.model_type == kUnigram) {
       HIP_OR_RETURN(h, Upload(&h->d_ptrie, t.ptrie));
       HIP_OR_RETURN(h, Upload(&h->d_umemo, t.umemo));       // (the word memo follows the live piece types)
+      HIP_OR_RETURN(h, Upload(&h->d_umemo16, t.umemo16));
+      HIP_OR_RETURN(h, Upload(&h->d_uhot, t.uhot));
       HIP_OR_RETURN(h, Upload(&h->d_pscore, t.pscore));
     } else {
       HIP_OR_RETURN(h, Upload(&h->d_sym_final, t.sym_final));
@@ -375,7 +383,7 @@ int RefreshDevice(spmx_handle *h, bool types_changed) {
   d.ndarts = h->dev.ndarts; d.nblob = h->dev.nblob; d.npair = h->dev.npair; d.ptrie = h->d_ptrie.p; d.plen = h->d_plen.p; d.utrie = h->dev.utrie;
   d.chartab = h->dev.chartab; d.pairtab = h->dev.pairtab; d.wordtab = h->dev.wordtab; d.sym_final = h->d_sym_final.p;
   d.sym_len = h->dev.sym_len; d.byte_ids = h->dev.byte_ids;
-  d.umemo = h->d_umemo.p; d.pscore = h->d_pscore.p;
+  d.umemo = h->d_umemo.p; d.umemo16 = h->d_umemo16.p; d.uhot = h->d_uhot.p; d.pscore = h->d_pscore.p;
   d.dec_info = h->d_dec_info.p; d.dec_off = h->d_dec_off.p; d.dec_bytes = h->d_dec_bytes.p;
   h->dev = d;
   return kOk;
@@ -386,7 +394,7 @@ void DestroyHandle(spmx_handle *h) {
   (void)hipSetDevice(h->device);
   h->d_ndarts.Free(); h->d_npair.Free(); h->d_sym_final.Free(); h->d_nblob.Free(); h->d_ptrie.Free(); h->d_chartab.Free();
   h->d_pairtab.Free(); h->d_wordtab.Free(); h->d_utrie.Free(); h->d_sym_len.Free(); h->d_byte_ids.Free();
-  h->d_dec_info.Free(); h->d_dec_off.Free(); h->d_dec_bytes.Free(); h->d_plen.Free(); h->d_umemo.Free(); h->d_pscore.Free();
+  h->d_dec_info.Free(); h->d_dec_off.Free(); h->d_dec_bytes.Free(); h->d_plen.Free(); h->d_umemo.Free(); h->d_umemo16.Free(); h->d_uhot.Free(); h->d_pscore.Free();
   h->dn_ndarts.Free(); h->dn_npair.Free(); h->dn_nblob.Free(); h->dn_utrie.Free();
   h->pool.clear();
   delete h;
@@ -543,7 +551,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
   // form (it records no token begins) nor under the `reverse` option
   const bool word_ok = h->model.model_type == kUnigram && (h->dev.flags & kNfUniWordwise) && !(h->dev.flags & kNfReverse) &&
                        !spans && !h->no_word;
-  HIP_OR_RETURN(h, ws->d_lists.Reserve(static_cast<size_t>(2 * kMaxClasses + 3 + (word_ok ? kMaxClasses : 0)) * n));
+  HIP_OR_RETURN(h, ws->d_lists.Reserve(static_cast<size_t>(2 * kMaxClasses + 3 + (word_ok ? 2 * kMaxClasses : 0)) * n));
   HIP_OR_RETURN(h, ws->d_counts.Reserve(n + 1));
   HIP_OR_RETURN(h, ws->d_tmp_off.Reserve(n + 1));
   HIP_OR_RETURN(h, ws->d_tile_sums.Reserve((n + kScanTile - 1) / kScanTile + 2));
@@ -553,7 +561,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
   uint32_t *const hard_lists = class_lists + static_cast<size_t>(kMaxClasses) * n;   // (escalation lists of the align kernels)
   uint32_t *const long_list = class_lists + static_cast<size_t>(2 * kMaxClasses) * n;
   uint32_t *const retry_lists[2] = {long_list + n, long_list + 2 * n};
-  uint32_t *const left_lists = long_list + 3 * n;                                    // (word_ok only) kMaxClasses lists
+  uint32_t *const left_lists[2] = {long_list + 3 * n, long_list + (3 + static_cast<size_t>(kMaxClasses)) * n};   // (word_ok only)
   // ids are at most one per normalized byte; the streaming kernels reserve a sentence's slot by that bound
   uint64_t expand = (h->dev.flags & kNfCompressSp) || !(h->dev.flags & kNfEscapeWs) ? 1 : 3;
   if ((h->dev.flags & kNfCompressSp) && (h->dev.flags & kNfByteFallback)) expand = 2;   // slots: bytes + 2 per space symbol
@@ -701,50 +709,57 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       return left ? Fail(h, kResourceExhausted, "the long form's slice pool kept overflowing") : kOk;
     };
     if (word_ok) {
-      // ---- the word kernel first: every class from one queue, longest first; what it leaves (a word that is not in the
-      // memo, a margin too small for the accumulated score, anything that is not plain ASCII words) comes back as
-      // per-class lists for the general launches below ----
-      EncodeArgs wa = a;
-      const int waves = 16;
-      uint64_t total = 0;
-      for (int c = 0; c < ncls; ++c) total += known[c];
-      uint64_t grid = static_cast<uint64_t>(h->n_cu - h->reserve_cus);
-      if (grid * waves * 64 > total) grid = (total + waves * 64 - 1) / (waves * 64);
-      if (grid < 1) grid = 1;
-      const uint64_t n_waves = grid * waves;
-      wa.n_classes = static_cast<uint32_t>(ncls);
-      uint32_t tile_base = 0;
-      for (int c = ncls - 1; c >= 0; --c) {
-        StreamClass &sc = wa.cls[c];
-        sc = StreamClass{};
-        sc.rcap = rcaps[c];
-        if (known[c] == 0) continue;
-        uint64_t tw = (static_cast<uint64_t>(known[c]) + n_waves - 1) / n_waves;
-        if (tw > 64) tw = 64;
-        if (tw < 1) tw = 1;
-        sc.lane_shift = 6;
-        sc.count = known[c];
-        sc.tw = static_cast<uint32_t>(tw);
-        sc.main_tiles = static_cast<uint32_t>((static_cast<uint64_t>(known[c]) + tw - 1) / tw);
-        sc.tile_base = tile_base;
-        tile_base += sc.main_tiles;
-      }
-      wa.total_main = tile_base;
-      if (wa.total_main) {
-        wa.q = &ws->d_ctrl->q[3];
-        wa.stats = &ws->d_ctrl->stats[kStatsPerClass * kSlotWord];
-        wa.left_lists = left_lists;
-        wa.left_counts = ws->d_ctrl->left_counts;
-        snprintf(ws->slot_name[kSlotWord], sizeof(ws->slot_name[kSlotWord]), "EncodeWordKernel");
-        HIP_OR_RETURN(h, record(kSlotWord, 0));
-        HIP_OR_RETURN(h, LaunchEncodeWord(wa, static_cast<int>(grid), waves, WordLdsBytes(waves), stream));
-        HIP_OR_RETURN(h, record(kSlotWord, 1));
-        ws->slot_used[kSlotWord] = true;
-        HIP_OR_RETURN(h, hipMemcpyAsync(ws->h_ctrl->left_counts, ws->d_ctrl->left_counts, sizeof(ws->h_ctrl->left_counts),
+      // ---- the word kernels first: every class from one queue, longest first.  Pass 1 takes the sentences whose words
+      // are all in the memo; pass 2 (over what pass 1 left) also segments the few words that are not; what is left
+      // then -- anything that is not plain ASCII words -- comes back as per-class lists for the general launches below ----
+      for (int pass = 0; pass < 2; ++pass) {
+        const bool dp = pass == 1;
+        EncodeArgs wa = a;
+        const int waves = dp ? 8 : 16;
+        uint64_t total = 0;
+        for (int c = 0; c < ncls; ++c) total += known[c];
+        if (total == 0) break;
+        // the second pass pays when the first one's misses are sparse (a rare word here and there); where most sentences
+        // came back, their words are mostly not in the memo and the general kernels are the better tool
+        if (dp && total * 4 > n && !h->force_word_dp) break;
+        uint64_t grid = static_cast<uint64_t>(h->n_cu - h->reserve_cus);
+        if (grid * waves * 64 > total) grid = (total + waves * 64 - 1) / (waves * 64);
+        if (grid < 1) grid = 1;
+        const uint64_t n_waves = grid * waves;
+        wa.n_classes = static_cast<uint32_t>(ncls);
+        uint32_t tile_base = 0;
+        for (int c = ncls - 1; c >= 0; --c) {
+          StreamClass &sc = wa.cls[c];
+          sc = StreamClass{};
+          sc.rcap = rcaps[c];
+          if (known[c] == 0) continue;
+          uint64_t tw = (static_cast<uint64_t>(known[c]) + n_waves - 1) / n_waves;
+          if (tw > 64) tw = 64;
+          if (tw < 1) tw = 1;
+          sc.lane_shift = 6;
+          sc.count = known[c];
+          sc.tw = static_cast<uint32_t>(tw);
+          sc.main_tiles = static_cast<uint32_t>((static_cast<uint64_t>(known[c]) + tw - 1) / tw);
+          sc.tile_base = tile_base;
+          tile_base += sc.main_tiles;
+        }
+        wa.total_main = tile_base;
+        const int slot = dp ? kSlotWord2 : kSlotWord;
+        wa.q = &ws->d_ctrl->q[3 + pass];
+        wa.stats = &ws->d_ctrl->stats[kStatsPerClass * slot];
+        wa.left_lists = left_lists[pass];
+        wa.left_counts = ws->d_ctrl->left_counts[pass];
+        snprintf(ws->slot_name[slot], sizeof(ws->slot_name[slot]), dp ? "EncodeWordDpKernel" : "EncodeWordKernel");
+        HIP_OR_RETURN(h, record(slot, 0));
+        HIP_OR_RETURN(h, LaunchEncodeWord(dp, wa, static_cast<int>(grid), waves, WordLdsBytes(waves, dp), stream));
+        HIP_OR_RETURN(h, record(slot, 1));
+        ws->slot_used[slot] = true;
+        HIP_OR_RETURN(h, hipMemcpyAsync(ws->h_ctrl->left_counts[pass], ws->d_ctrl->left_counts[pass], sizeof(ws->h_ctrl->left_counts[pass]),
                                         hipMemcpyDeviceToHost, stream));
         HIP_OR_RETURN(h, hipStreamSynchronize(stream));
-        for (int c = 0; c < ncls; ++c) known[c] = ws->h_ctrl->left_counts[c];
-        a.lists = left_lists;
+        for (int c = 0; c < ncls; ++c) known[c] = ws->h_ctrl->left_counts[pass][c];
+        a.lists = left_lists[pass];
+        if (h->no_word_dp) break;
       }
     }
     if (streaming) {
@@ -1124,6 +1139,8 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_NO_STREAM")) h->no_stream = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_WAVE")) h->no_wave = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_WORD_KERNEL")) h->no_word = e[0] == '1';
+    if (const char *e = getenv("SPMX_NO_WORD_DP")) h->no_word_dp = e[0] == '1';
+    if (const char *e = getenv("SPMX_FORCE_WORD_DP")) h->force_word_dp = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_BP_SHORT")) h->no_bp_short = e[0] == '1';
     if (const char *e = getenv("SPMX_ARENA_FIRST")) h->arena_first = static_cast<uint64_t>(atoll(e));
     if (const char *e = getenv("SPMX_WIDE_TCAP")) h->wide_tcap = e[0] == '1';

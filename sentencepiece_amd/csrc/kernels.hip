@@ -33,7 +33,11 @@ __global__ __launch_bounds__(1024) void EncodeBpeStreamKernel(EncodeArgs a) {
 }
 __global__ __launch_bounds__(1024) void EncodeWordKernel(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  encode_word_block(a, smem);
+  encode_word_block<false>(a, smem);
+}
+__global__ __launch_bounds__(512) void EncodeWordDpKernel(EncodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  encode_word_block<true>(a, smem);
 }
 __global__ __launch_bounds__(64) void BpeLongKernel(LongArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[64 * kRawWinBytes];
@@ -128,13 +132,14 @@ hipError_t LaunchEncodeStream(int model_type, bool uds, const EncodeArgs &a, int
   return hipGetLastError();
 }
 
-hipError_t LaunchEncodeWord(const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t stream) {
+hipError_t LaunchEncodeWord(bool dp, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t stream) {
+  void (*fn)(EncodeArgs) = dp ? EncodeWordDpKernel : EncodeWordKernel;
   if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(EncodeWordKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds_bytes));
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(EncodeWordKernel, dim3(grid), dim3(64 * waves), lds_bytes, stream, a);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * waves), lds_bytes, stream, a);
   return hipGetLastError();
 }
 

@@ -9,8 +9,8 @@
 // concatenation of the best paths of its words -- in exact arithmetic.  The reference does not compute in exact
 // arithmetic: a candidate is (double)score + (double)best[start], compared against and stored as a float (:979-989), so
 // WHICH of two close candidates wins may depend on the magnitude of the score accumulated before the word.  The word
-// memo (dev.h umemo, tables.cc BuildWordMemo) therefore stores, next to a word's best segmentation, the largest
-// magnitude of the accumulated score up to which the decision is provably the exact-arithmetic one:
+// memo (dev.h umemo16 / umemo, tables.cc BuildWordMemo) therefore stores, next to a word's best segmentation, the
+// largest magnitude of the accumulated score up to which the decision is provably the exact-arithmetic one:
 //
 //   * all float values inside the word lie within M = |B| + wmag of zero (B = best_path_score at the word's start, wmag
 //     = the largest |partial sum| of any candidate inside the word), so every stored best[e] differs from its exact
@@ -21,11 +21,20 @@
 //   * tables.cc computes, in double, the smallest such lead `gap` over the positions ON the word's best path and stores
 //     bmax = the largest |B| for which ulp_float(|B| + wmag) <= gap / (4 * nchar + 4) -- four times the bound above.
 //
-// At run time a lane keeps B exactly as the reference has it -- B = (float)((double)score + (double)B) per emitted piece,
-// the very operation of :982-989 along the winning path -- and takes a memo entry only while |B| < bmax.  Anything else
-// (a word that is not in the memo, |B| too large for its margin, a byte outside 0x21-0x7E, a word of more than 16 bytes,
-// text within 20 bytes of the end of the buffer) sends the WHOLE sentence to the general kernels (kernels_stream.h)
-// through the call's leftover lists: this kernel either produces the reference's ids or produces nothing.
+// A memo entry is taken only while |B| < bmax.  The FIRST pass (DP = false) does not even keep B: it keeps an upper
+// bound of |B| -- every emitted piece adds ceil(|score|) + 1, which also covers the float roundings of the running sum
+// -- and compares that with the power of two below bmax; the entry is 16 bytes (12 key bytes, id, those two small
+// numbers), found in a table of the likeliest words held in LDS or else by one probe of the table in HBM.  Anything the
+// first pass cannot take (a word that is not in the memo, a bound beyond its margin, a byte outside 0x21-0x7E, a word
+// of more than 16 bytes, text within 20 bytes of the end of the buffer) sends the WHOLE sentence on, through per-class
+// leftover lists: a pass either produces the reference's ids for a sentence or produces nothing for it.
+//
+// The SECOND pass (DP = true) runs over the first one's leftovers and keeps B exactly as the reference has it --
+// B = (float)((double)score + (double)B) per emitted piece, the very operation of :982-989 along the winning path.  A
+// word that is not in the memo is then segmented by the lane itself with the reference's own recurrence over the word's
+// characters from that B (uni_word_dp: exact, no margin involved); lanes wait at such a word until no lane of the wave
+// can go on, and all of them run their DP together.  What the second pass cannot take either (non-ASCII text, more than
+// kWordDpMax such words in a sentence) goes to the general kernels (kernels_stream.h).
 //
 // What the normalizer contributes is implicit: the model must add a dummy prefix, remove extra whitespace and escape
 // whitespace with the one-byte space symbol, and every byte 0x20-0x7E must be a character no charsmap rule starts with
@@ -33,19 +42,25 @@
 // front" -- a word's normalized form is the space symbol plus its raw bytes, which is how the memo is keyed (by the raw
 // bytes alone).  Leading, trailing and doubled spaces are empty words and cost an iteration each.
 //
-// Per iteration and lane: one unaligned 20-byte read of the text (issued one word ahead), one 32-byte probe of the memo.
-// No scratch in HBM, no back-pointers, no backtrack: ids leave in forward order through a 16-id LDS staging column as
-// 64-byte bursts.
+// No scratch in HBM, no back-pointers, no backtrack: ids leave in forward order through an 8-id LDS staging column as
+// 32-byte bursts.
 #ifndef SPMX_KERNELS_WORD_H_
 #define SPMX_KERNELS_WORD_H_
 
 namespace spmx {
 
-constexpr uint32_t kWordLdsShared = 18u * 16u + 32u;            // mask rows 0 .. 17 (+ padding)
-constexpr uint32_t kWordLdsPerWave = 64u * 16u * 4u;            // id staging: [16][64] int32
-SPMX_HD inline uint32_t WordLdsBytes(uint32_t waves) { return kWordLdsShared + waves * kWordLdsPerWave; }
+constexpr uint32_t kWordMaskBytes = 18u * 16u + 32u;            // mask rows 0 .. 17 (+ padding)
+constexpr uint32_t kWordHotSlots = 2048u;                       // LDS copy of the likeliest words (dev.h uhot)
+constexpr uint32_t kWordLdsShared = kWordMaskBytes + kWordHotSlots * 16u;
+constexpr uint32_t kWordStage = 8;                              // ids per burst
+constexpr uint32_t kWordDpPos = 18;                             // positions of a word in the DP: space symbol + 16 bytes + end
+constexpr int kWordDpMax = 4;                                   // words per sentence the second pass segments itself
+SPMX_HD inline uint32_t WordLdsPerWave(bool dp) {
+  return 64u * kWordStage * 4u + (dp ? 64u * (kWordDpPos * 8u + 20u) : 0u);
+}
+SPMX_HD inline uint32_t WordLdsBytes(uint32_t waves, bool dp) { return kWordLdsShared + waves * WordLdsPerWave(dp); }
 
-// 16 bytes at any address (gfx950 runs with unaligned vector memory access enabled; scripts/ubench/unaligned_probe.hip)
+// 16 / 4 bytes at any address (gfx950 runs with unaligned vector memory access enabled; scripts/ubench/unaligned_probe.hip)
 struct __attribute__((packed, aligned(1))) Q4U { uint32_t x, y, z, w; };
 struct __attribute__((packed, aligned(1))) U1U { uint32_t x; };
 
@@ -56,118 +71,304 @@ SPMX_DEVICE uint32_t space_bits(uint32_t v) {
   return (x - 0x01010101u) & ~x & 0x80808080u;
 }
 
+struct WordLds {
+  const Q4 *masks;      // [18] key masks (shared)
+  const U4 *hot;        // [kWordHotSlots] the likeliest words, umemo16 format (shared)
+  int32_t *stage;       // this lane's id staging column: entry k at stage[k << 6]
+  float *dp_best;       // (DP) this lane's best_path_score column: position i at dp_best[i << 6]
+  uint32_t *dp_bp;      // (DP) back-pointer words  id | length << 24 | unk << 31  (0: not reached)
+  uint8_t *dp_bytes;    // (DP) the word in device form: [20] bytes of this lane
+};
+
+// EncodeOptimized (src/unigram_model.cc:957-1008) of ONE word -- the space symbol and the L raw bytes in key[] -- from
+// best_path_score B at its start, by this lane alone: the reference's loops flattened, one trie probe per iteration.
+// Every byte is one character (ASCII, or the one-byte space symbol).  On return T.dp_bp holds the back-pointers and
+// T.dp_best[n] the score at the word's end (n = L + 1).  `active`: this lane has a word to do.
+SPMX_DEVICE void uni_word_dp(const SpmxDev &d, const WordLds &T, int L, float B, bool active) {
+  const U4 *__restrict__ ptrie = d.ptrie;
+  const uint32_t root = d.ptrie[0].x >> kDatBaseShiftDev;
+  const int n = L + 1;
+  if (active) {
+    for (int i = 0; i <= n; ++i) T.dp_bp[i << 6] = 0u;
+    T.dp_best[0] = B;
+  }
+  int s = 0, dep = 0;
+  uint32_t node = root;
+  float bs = B;
+  bool single = false;
+  while (wv::any(active)) {
+    if (active) {
+      const uint32_t c = T.dp_bytes[s + dep];
+      const U4 u = ptrie[node ^ c];
+      bool match = (u.x & 0x1FFu) == (0x100u | c);                                  // :969-971
+      if (match) {
+        ++dep;
+        node = u.x >> kDatBaseShiftDev;
+        if ((u.x & kDatTerminalDev) && !(u.y & kPtUnused)) {                         // :973-974
+          const int e = s + dep;
+          const double cand = static_cast<double>(wv::bits_to_float(u.z)) + static_cast<double>(bs);   // :982-983
+          if (T.dp_bp[e << 6] == 0u || cand > static_cast<double>(T.dp_best[e << 6])) {                // :984-989
+            T.dp_best[e << 6] = static_cast<float>(cand);
+            T.dp_bp[e << 6] = (u.y & kBwIdMask) | (static_cast<uint32_t>(dep) << kBwLenShift);
+          }
+          if (dep == 1) single = true;                                               // :990 (every character is one byte)
+        }
+        if (s + dep >= n) match = false;                                             // the word ends: this start is done
+      }
+      if (!match) {
+        if (!single) {                                                               // :995-1005 UNK, float arithmetic
+          const float cand = d.unk_score + bs;
+          if (T.dp_bp[(s + 1) << 6] == 0u || cand > T.dp_best[(s + 1) << 6]) {
+            T.dp_best[(s + 1) << 6] = cand;
+            T.dp_bp[(s + 1) << 6] = (1u << kBwLenShift) | kBwUnk;
+          }
+        }
+        ++s;                                                                         // :1007
+        if (s >= n) active = false;
+        else { bs = T.dp_best[s << 6]; node = root; dep = 0; single = false; }
+      }
+    }
+  }
+}
+
 // The words of this lane's sentence (raw bytes gtext[beg, beg + len)) -> ids in slot[0, n), forward order.
-// Returns n >= 0, or -1: the sentence is not for this kernel (nothing usable was written).
-// `stage`: this lane's column of the wave's id staging (entry k at stage[k << 6]); `masks`: the 18 key masks in LDS.
+// Returns n >= 0, or -1: the sentence is not for this pass (nothing usable was written).
+template <bool DP>
 SPMX_DEVICE int uni_word_lane(const SpmxDev &d, const uint8_t *gtext, uint64_t beg, int len, int32_t *slot, int cap,
-                              int32_t *stage, const Q4 *masks, bool active_in, int *n_steps) {
-  const U4 *__restrict__ memo = d.umemo;
-  const uint32_t mmask = d.umemo_mask;
+                              const WordLds &T, bool active_in, int *n_steps) {
+  const U4 *__restrict__ memo16 = d.umemo16;
+  const U4 *__restrict__ memo32 = d.umemo;
+  const uint32_t m16 = d.umemo16_mask, m32 = d.umemo_mask;
   const uint8_t *text = gtext + beg;
+  int32_t *stage = T.stage;
   bool active = active_in && len > 0;
   bool bad = false;
   int p = 0, n = 0, steps = 0;
-  float B = 0.f;                                   // best_path_score at the start of the current word
+  float B = 0.f;                                   // DP: best_path_score at the start of the current word; else a bound of its magnitude
+  int n_dp = 0;
+  // a word waiting for the DP (second pass): its length; the lane goes on once the wave has run uni_word_dp
+  bool stalled = false, stall_last = false;
+  int stall_L = 0;
+  bool prev_unk = false;                           // the last piece emitted was unknown (a run of them is ONE id, :609-613)
+  const bool bf = (d.flags & kNfByteFallback) != 0;
   Q4U w{0, 0, 0, 0};
-  uint32_t w4 = 0;
-  if (active) {
-    w = *reinterpret_cast<const Q4U *>(text);
-    w4 = reinterpret_cast<const U1U *>(text + 16)->x;
-  }
+  if (active) w = *reinterpret_cast<const Q4U *>(text);
+  auto put = [&](uint32_t id) __attribute__((always_inline)) {
+    stage[(n & 7) << 6] = static_cast<int32_t>(id);
+    ++n;
+    if ((n & 7) == 0) {
+      int32_t *q = slot + (n - 8);
+      *reinterpret_cast<Q4 *>(q) = Q4{static_cast<uint32_t>(stage[0]), static_cast<uint32_t>(stage[1 << 6]),
+                                      static_cast<uint32_t>(stage[2 << 6]), static_cast<uint32_t>(stage[3 << 6])};
+      *reinterpret_cast<Q4 *>(q + 4) = Q4{static_cast<uint32_t>(stage[4 << 6]), static_cast<uint32_t>(stage[5 << 6]),
+                                          static_cast<uint32_t>(stage[6 << 6]), static_cast<uint32_t>(stage[7 << 6])};
+    }
+  };
   while (wv::any(active)) {
-    ++steps;
-    // ---- the word that starts at p: its length = the distance to the next 0x20 (or to the end of the sentence) ----
-    const uint32_t z0 = space_bits(w.x), z1 = space_bits(w.y), z2 = space_bits(w.z), z3 = space_bits(w.w), z4 = space_bits(w4) & 0x80u;
-    const int fa = wv::ffs64(static_cast<uint64_t>(z0) | static_cast<uint64_t>(z1) << 32);
-    const int fb = wv::ffs64(static_cast<uint64_t>(z2) | static_cast<uint64_t>(z3) << 32);
-    int L = fa ? (fa - 1) >> 3 : (fb ? 8 + ((fb - 1) >> 3) : (z4 ? 16 : 17));
-    const int rem = len - p;
-    if (L > rem) L = rem;
-    const bool word = active && L > 0;               // L == 0: a space (leading, doubled): skip it
-    const bool lng = word && L > 16;
-    const int pn = p + L + 1;
-    const bool more = active && !lng && pn < len;
-    // ---- the next word's text, one iteration ahead of its use ----
-    Q4U wn = w;
-    uint32_t wn4 = w4;
-    if (more) {
-      wn = *reinterpret_cast<const Q4U *>(text + pn);
-      wn4 = reinterpret_cast<const U1U *>(text + pn + 16)->x;
-    }
-    // ---- memo probe ----
-    const Q4 mk = masks[word && !lng ? L : 0];
-    const uint32_t k0 = w.x & mk.x, k1 = w.y & mk.y, k2 = w.z & mk.z, k3 = w.w & mk.w;
-    uint32_t sl = HashWordKey(k0, k1, k2, k3) & mmask;
-    const bool probing = word && !lng;
-    U4 e0 = memo[2 * (probing ? sl : 0u)], e1 = memo[2 * (probing ? sl : 0u) + 1];
-    bool hit = probing && e0.x == k0 && e0.y == k1 && e0.z == k2 && e0.w == k3 && e1.x != 0xFFFFFFFFu;
-    bool walk = probing && !hit && e1.x != 0xFFFFFFFFu;
-    while (wv::any(walk)) {                          // a collision: walk on (rare: the table is half empty)
-      if (walk) {
-        sl = (sl + 1u) & mmask;
-        e0 = memo[2 * sl];
-        e1 = memo[2 * sl + 1];
-        hit = e0.x == k0 && e0.y == k1 && e0.z == k2 && e0.w == k3 && e1.x != 0xFFFFFFFFu;
-        walk = !hit && e1.x != 0xFFFFFFFFu;
-      }
-    }
-    // ---- take the entry while the margin holds: |B| < bmax ----
-    const float bmax = wv::bits_to_float(e1.w);
-    const bool ok = hit && fabsf(B) < bmax;
-    if (word && !ok) { bad = true; active = false; }
-    if (ok) {
-      const bool two = e1.y != 0xFFFFFFFFu;
-      if (n + (two ? 2 : 1) > cap) { bad = true; active = false; }
-      else {
-        B = static_cast<float>(static_cast<double>(wv::bits_to_float(e1.z)) + static_cast<double>(B));   // :982-989
-        stage[(n & 15) << 6] = static_cast<int32_t>(e1.x);
-        ++n;
-        if ((n & 15) == 0) {
-          int32_t *q = slot + (n - 16);
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            *reinterpret_cast<Q4 *>(q + 4 * r) = Q4{static_cast<uint32_t>(stage[(4 * r) << 6]), static_cast<uint32_t>(stage[(4 * r + 1) << 6]),
-                                                   static_cast<uint32_t>(stage[(4 * r + 2) << 6]), static_cast<uint32_t>(stage[(4 * r + 3) << 6])};
+    if (DP && !wv::any(active && !stalled)) {
+      // ---- no lane can go on: every waiting lane segments its word (exact: from the true B) ----
+      uni_word_dp(d, T, stall_L, B, active && stalled);
+      if (active && stalled) {
+        const int nn = stall_L + 1;
+        // backtrack (:1010-1018): count first, then piece by piece in forward order, with the id post-processing of
+        // sentencepiece_processor.cc:581-613 -- a run of unknown pieces is one id (the run may continue from the previous
+        // word: prev_unk), or every unknown character's bytes under byte fallback
+        int e = nn, cnt = 0, need = 0;
+        bool broken = false;
+        while (e > 0) {
+          const uint32_t bw = T.dp_bp[e << 6];
+          const int bl = static_cast<int>((bw >> kBwLenShift) & kBwLenMask);
+          if (bw == 0u || bl == 0 || bl > e) { broken = true; break; }
+          ++cnt;
+          need += (bw & kBwUnk) ? (bf ? (T.dp_bytes[e - bl] == kSpByte ? 3 : 1) : 1) : 1;
+          e -= bl;
         }
-        if (two) {                                   // (rare) the second piece: its score from the per-id table
-          B = static_cast<float>(static_cast<double>(d.pscore[e1.y]) + static_cast<double>(B));
-          stage[(n & 15) << 6] = static_cast<int32_t>(e1.y);
-          ++n;
-          if ((n & 15) == 0) {
-            int32_t *q = slot + (n - 16);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              *reinterpret_cast<Q4 *>(q + 4 * r) = Q4{static_cast<uint32_t>(stage[(4 * r) << 6]), static_cast<uint32_t>(stage[(4 * r + 1) << 6]),
-                                                     static_cast<uint32_t>(stage[(4 * r + 2) << 6]), static_cast<uint32_t>(stage[(4 * r + 3) << 6])};
+        if (broken || n + need > cap) { bad = true; active = false; }
+        else {
+          B = T.dp_best[nn << 6];
+          for (int k = 0; k < cnt; ++k) {            // (cnt <= 17: piece k is found by walking back from the end again)
+            int e2 = nn;
+            for (int j = cnt - 1; j > k; --j) e2 -= static_cast<int>((T.dp_bp[e2 << 6] >> kBwLenShift) & kBwLenMask);
+            const uint32_t bw = T.dp_bp[e2 << 6];
+            if (bw & kBwUnk) {
+              const uint32_t ch = T.dp_bytes[e2 - 1];
+              if (bf) {
+                if (ch == kSpByte) { put(static_cast<uint32_t>(d.byte_ids[0xE2])); put(static_cast<uint32_t>(d.byte_ids[0x96])); put(static_cast<uint32_t>(d.byte_ids[0x81])); }
+                else put(static_cast<uint32_t>(d.byte_ids[ch]));
+              } else if (!prev_unk) {
+                put(static_cast<uint32_t>(d.unk_id));
+              }
+              prev_unk = true;
+            } else {
+              put(bw & kBwIdMask);
+              prev_unk = false;
+            }
           }
         }
+        stalled = false;
+        if (stall_last) active = false;              // it was the sentence's last word
+      }
+      continue;
+    }
+    ++steps;
+    const bool run = active && !stalled;
+    // ---- the word that starts at p: its length = the distance to the next 0x20 (or to the end of the sentence) ----
+    const uint32_t z0 = space_bits(w.x), z1 = space_bits(w.y), z2 = space_bits(w.z), z3 = space_bits(w.w);
+    const int fa = wv::ffs64(static_cast<uint64_t>(z0) | static_cast<uint64_t>(z1) << 32);
+    const int fb = wv::ffs64(static_cast<uint64_t>(z2) | static_cast<uint64_t>(z3) << 32);
+    int L = fa ? (fa - 1) >> 3 : (fb ? 8 + ((fb - 1) >> 3) : 16);      // 16: no space among the 16 bytes
+    const int rem = len - p;
+    if (L > rem) L = rem;
+    // ---- where the next word starts; its text is asked for now and used in the next iteration ----
+    const int pn = p + L + 1;
+    const bool more = run && pn < len;
+    Q4U wn = w;
+    if (more) wn = *reinterpret_cast<const Q4U *>(text + pn);
+    U4 ent{0, 0, 0, 0xFFFFFFFFu};                    // the entry taken: umemo16 format, or {id0, id1, bound, bmax} of umemo
+    bool hit16 = false, hit32 = false;
+    uint32_t k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+    uint32_t wx4 = 0x20202020u;                      // bytes 16 .. 19 of the word's text (only words of 16 bytes and more read them)
+    const bool word = run && L > 0;                  // L == 0: a space (leading, doubled): skip it
+    bool shortw = word && L <= 12;
+    if (shortw) {
+      const Q4 mk = T.masks[L];
+      k0 = w.x & mk.x; k1 = w.y & mk.y; k2 = w.z & mk.z;
+    }
+    const uint32_t h = HashWordKey(k0, k1, k2, 0u);
+    {   // the likeliest words: LDS
+      const U4 e = T.hot[h & (kWordHotSlots - 1u)];
+      hit16 = shortw && e.x == k0 && e.y == k1 && e.z == k2 && e.w != 0xFFFFFFFFu;
+      if (hit16) ent = e;
+    }
+    bool look = shortw && !hit16;
+    if (wv::any(look)) {                             // the rest of the one-piece words of up to 12 bytes: one probe, HBM / L2
+      uint32_t sl = h & m16;
+      U4 e = memo16[look ? sl : 0u];
+      hit16 = hit16 || (look && e.x == k0 && e.y == k1 && e.z == k2 && e.w != 0xFFFFFFFFu);
+      bool walk = look && !hit16 && e.w != 0xFFFFFFFFu;
+      while (wv::any(walk)) {                        // a collision: walk on (rare: the table is half empty)
+        if (walk) {
+          sl = (sl + 1u) & m16;
+          e = memo16[sl];
+          hit16 = e.x == k0 && e.y == k1 && e.z == k2 && e.w != 0xFFFFFFFFu;
+          walk = !hit16 && e.w != 0xFFFFFFFFu;
+        }
+      }
+      if (look && hit16) ent = e;
+    }
+    bool lng = false;                                // a word of more than 16 bytes
+    if (wv::any(word && !hit16)) {
+      // ---- the other words of the memo (two pieces, 13 .. 16 bytes): 32-byte entries ----
+      const bool need = word && !hit16;
+      int L2 = L;
+      if (need && L == 16 && rem > 16) {             // the 17th byte decides whether the word ends here
+        wx4 = reinterpret_cast<const U1U *>(text + p + 16)->x;
+        if ((wx4 & 0xFFu) != 0x20u) lng = true;
+      }
+      const bool probe = need && !lng;
+      const Q4 mk = T.masks[probe ? L2 : 0];
+      k0 = w.x & mk.x; k1 = w.y & mk.y; k2 = w.z & mk.z; k3 = w.w & mk.w;
+      uint32_t sl = HashWordKey(k0, k1, k2, k3) & m32;
+      U4 e0 = memo32[2u * (probe ? sl : 0u)], e1 = memo32[2u * (probe ? sl : 0u) + 1u];
+      hit32 = probe && e0.x == k0 && e0.y == k1 && e0.z == k2 && e0.w == k3 && e1.x != 0xFFFFFFFFu;
+      bool walk = probe && !hit32 && e1.x != 0xFFFFFFFFu;
+      while (wv::any(walk)) {
+        if (walk) {
+          sl = (sl + 1u) & m32;
+          e0 = memo32[2u * sl];
+          e1 = memo32[2u * sl + 1u];
+          hit32 = e0.x == k0 && e0.y == k1 && e0.z == k2 && e0.w == k3 && e1.x != 0xFFFFFFFFu;
+          walk = !hit32 && e1.x != 0xFFFFFFFFu;
+        }
+      }
+      if (hit32) ent = e1;
+    }
+    // ---- take the entry while its margin holds ----
+    const uint32_t id0 = hit16 ? (ent.w & 0xFFFFu) : ent.x;
+    const uint32_t id1 = hit32 ? ent.y : 0xFFFFFFFFu;
+    // valid while |B| < lim: 2^e (16-byte entry: the power of two below bmax) or bmax itself
+    const float lim = hit16 ? wv::bits_to_float((((ent.w >> 16) & 0xFFu) + 127u) << 23) : wv::bits_to_float(ent.w);
+    const bool hit = hit16 || hit32;
+    const bool ok = hit && fabsf(B) < lim;
+    if (word && !ok) {
+      bool dp_ok = false;
+      if (DP && !lng && n_dp < kWordDpMax) {
+        // the lane segments the word itself if it is plain: L bytes 0x21 .. 0x7E
+        const Q4 mk = T.masks[L];
+        const uint32_t pad = 0x41414141u;
+        const uint32_t a0 = (w.x & mk.x) | (pad & ~mk.x), a1 = (w.y & mk.y) | (pad & ~mk.y), a2 = (w.z & mk.z) | (pad & ~mk.z),
+                       a3 = (w.w & mk.w) | (pad & ~mk.w);
+        auto plain = [](uint32_t x) -> bool {
+          return (((x + 0x01010101u) | x) & 0x80808080u) == 0u && (((x - 0x21212121u) & ~x) & 0x80808080u) == 0u;
+        };
+        dp_ok = plain(a0) && plain(a1) && plain(a2) && plain(a3);
+        if (dp_ok) {
+          T.dp_bytes[0] = static_cast<uint8_t>(kSpByte);
+          for (int i = 0; i < 4; ++i) {
+            T.dp_bytes[1 + i] = static_cast<uint8_t>(a0 >> (8 * i));
+            T.dp_bytes[5 + i] = static_cast<uint8_t>(a1 >> (8 * i));
+            T.dp_bytes[9 + i] = static_cast<uint8_t>(a2 >> (8 * i));
+            T.dp_bytes[13 + i] = static_cast<uint8_t>(a3 >> (8 * i));
+          }
+          stalled = true;
+          stall_L = L;
+          stall_last = !more;
+          ++n_dp;
+        }
+      }
+      if (!dp_ok) { bad = true; active = false; }
+    }
+    if (ok) {
+      const bool two = id1 != 0xFFFFFFFFu;
+      if (n + (two ? 2 : 1) > cap) { bad = true; active = false; }
+      else {
+        if (DP) {
+          B = static_cast<float>(static_cast<double>(d.pscore[id0]) + static_cast<double>(B));   // :982-989 along the path
+          if (two) B = static_cast<float>(static_cast<double>(d.pscore[id1]) + static_cast<double>(B));
+        } else {
+          // a bound of |B|: ceil(|score|) + 1 per piece (the + 1 covers the roundings of the sum)
+          B += hit16 ? static_cast<float>(ent.w >> 24) : wv::bits_to_float(ent.z);
+        }
+        put(id0);
+        if (two) put(id1);
+        prev_unk = false;
       }
     }
-    if (active && !more) active = false;             // the sentence is done
-    p = pn;
-    w = wn;
-    w4 = wn4;
+    if (run && !more && !(DP && stalled)) active = false;     // the sentence is done
+    if (run) { p = pn; w = wn; }
   }
   *n_steps = steps;
   if (bad) return -1;
   if (active_in && len > 0)
-    for (int k = n & ~15; k < n; ++k) slot[k] = stage[(k & 15) << 6];   // the last, incomplete group
+    for (int k = n & ~7; k < n; ++k) slot[k] = stage[(k & 7) << 6];   // the last, incomplete group
   return n;
 }
 
-// Persistent body of the word kernel: tiles of up to 64 sentences from the launch's queue (kernels_stream.h next_tile),
-// one sentence per lane.  What a lane cannot take goes to the leftover list of its class.
+// Persistent body of the word kernels: tiles of up to 64 sentences from the launch's queue (kernels_stream.h
+// next_tile), one sentence per lane.  What a lane cannot take goes to the leftover list of its class.
+template <bool DP>
 SPMX_DEVICE void encode_word_block(const EncodeArgs &a, unsigned char *smem) {
   const int lane = wv::lane();
   const SpmxDev &d = a.dev;
   Q4 *masks = reinterpret_cast<Q4 *>(smem);
-  int32_t *stage = reinterpret_cast<int32_t *>(smem + kWordLdsShared + static_cast<uint32_t>(wv::wave_in_block()) * kWordLdsPerWave) + lane;
-  if (lane < 18) {                                   // (every wave writes the same rows: no workgroup barrier)
-    const uint32_t L = static_cast<uint32_t>(lane);
-    auto m = [&](uint32_t i) -> uint32_t { return L >= 4u * i + 4u ? 0xFFFFFFFFu : (L <= 4u * i ? 0u : (1u << (8u * (L - 4u * i))) - 1u); };
-    masks[lane] = Q4{m(0), m(1), m(2), m(3)};
+  U4 *hot = reinterpret_cast<U4 *>(smem + kWordMaskBytes);
+  unsigned char *mine_lds = smem + kWordLdsShared + static_cast<uint32_t>(wv::wave_in_block()) * WordLdsPerWave(DP);
+  WordLds T;
+  T.masks = masks;
+  T.hot = hot;
+  T.stage = reinterpret_cast<int32_t *>(mine_lds) + lane;
+  T.dp_best = reinterpret_cast<float *>(mine_lds + 64u * kWordStage * 4u) + lane;
+  T.dp_bp = reinterpret_cast<uint32_t *>(mine_lds + 64u * kWordStage * 4u + 64u * kWordDpPos * 4u) + lane;
+  T.dp_bytes = mine_lds + 64u * kWordStage * 4u + 64u * kWordDpPos * 8u + static_cast<uint32_t>(lane) * 20u;
+  {   // shared read-only tables (every wave writes the same values: no workgroup barrier)
+    if (lane < 18) {
+      const uint32_t L = static_cast<uint32_t>(lane);
+      auto m = [&](uint32_t i) -> uint32_t { return L >= 4u * i + 4u ? 0xFFFFFFFFu : (L <= 4u * i ? 0u : (1u << (8u * (L - 4u * i))) - 1u); };
+      masks[lane] = Q4{m(0), m(1), m(2), m(3)};
+    }
+    for (uint32_t k = static_cast<uint32_t>(lane); k < kWordHotSlots; k += 64u) hot[k] = d.uhot[k];
+    wv::sync();
   }
-  wv::sync();
   const int n_extra = d.n_prefix + d.n_suffix;
   const uint64_t text_end = a.offs[a.n];
   WaveCounters tc;
@@ -189,9 +390,9 @@ SPMX_DEVICE void encode_word_block(const EncodeArgs &a, unsigned char *smem) {
     }
     // not for this kernel: beyond the int range of the lane's counters, or text that ends within the over-read of the
     // last sentences of the buffer
-    bool mine = have && l64 < (1ull << 30) && beg + l64 + 20u <= text_end;
+    const bool mine = have && l64 < (1ull << 30) && beg + l64 + 20u <= text_end;
     const int len = mine ? static_cast<int>(l64) : 0;
-    // ---- a slot of cap ids in the arena (at most two ids per word, a word per two bytes) ----
+    // ---- a slot of cap ids in the arena (at most one id per byte of the normalized form: the bytes + 1) ----
     const int cap = mine ? len + 1 : 0;
     const int room = mine ? (cap + n_extra + 3 + 3) & ~3 : 0;
     int total = 0;
@@ -207,7 +408,7 @@ SPMX_DEVICE void encode_word_block(const EncodeArgs &a, unsigned char *smem) {
     const int shift = (4 - (at & 3)) & 3;
     int32_t *slot = a.arena + base + static_cast<unsigned long long>(excl + shift) + d.n_prefix;
     int steps = 0;
-    int n = uni_word_lane(d, a.text, beg, len, slot, cap, stage, masks, mine && !overflow, &steps);
+    int n = uni_word_lane<DP>(d, a.text, beg, len, slot, cap, T, mine && !overflow, &steps);
     const unsigned long long c1 = wv::clock();
     if (overflow) n = -1;
     const bool done = mine && n >= 0;
@@ -218,7 +419,7 @@ SPMX_DEVICE void encode_word_block(const EncodeArgs &a, unsigned char *smem) {
       a.counts[sid] = static_cast<uint32_t>(n + n_extra);
     }
     const bool left = have && !done;
-    if (left) a.counts[sid] = 0u;                    // (until the general kernels have had it)
+    if (left) a.counts[sid] = 0u;                    // (until a later pass has had it)
     append_lanes(wv::ballot(left), left, sid, a.left_lists + static_cast<uint64_t>(c) * a.n, &a.left_counts[c], lane);
     if (done) { ++tc.n_sent; tc.n_raw += static_cast<unsigned long long>(len); tc.n_ids += static_cast<unsigned long long>(n + n_extra); }
     tc.n_trips += static_cast<unsigned long long>(steps);

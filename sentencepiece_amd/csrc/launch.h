@@ -36,7 +36,7 @@ inline uint32_t ScoreRing(int max_piece_len) {
 hipError_t LaunchEncodeStream(int model_type, bool uds, const EncodeArgs &a, int grid, int waves,
                               uint32_t lds_bytes, hipStream_t stream);
 // The word kernel (kernels_word.h): unigram models with kNfUniWordwise
-hipError_t LaunchEncodeWord(const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t stream);
+hipError_t LaunchEncodeWord(bool dp, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t stream);
 hipError_t LaunchBpeLong(const LongArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchNormalizeLong(bool write, const NormalizeArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchAlignLong(const AlignLongArgs &a, int grid, hipStream_t stream);

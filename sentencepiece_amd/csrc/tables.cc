@@ -506,7 +506,10 @@ void BuildWordMemo(const ModelData &m, HostTables *t) {
   SpmxDev &sc = t->scalars;
   t->umemo.assign(2, U4{0, 0, 0, 0});
   t->umemo[1].x = 0xFFFFFFFFu;
+  t->umemo16.assign(1, U4{0, 0, 0, 0xFFFFFFFFu});
+  t->uhot.assign(2048, U4{0, 0, 0, 0xFFFFFFFFu});       // kWordHotSlots (kernels_word.h)
   sc.umemo_mask = 0;
+  sc.umemo16_mask = 0;
   sc.flags &= ~kNfUniWordwise;
   t->memo_words = t->memo_candidates = 0;
   t->pscore.assign(m.pieces.size() + 1, 0.f);
@@ -596,16 +599,47 @@ void BuildWordMemo(const ModelData &m, HostTables *t) {
   if (ents.size() < min_words) return;
   // likelier words first: they get the slots their hash names, the rest walk (the kernel's lanes wait for the longest walk)
   std::stable_sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.order > b.order; });
-  const uint32_t wsz = NextPow2(ents.size() * 2 + 16);
-  t->umemo.assign(static_cast<size_t>(wsz) * 2, U4{0, 0, 0, 0});
-  for (uint32_t i = 0; i < wsz; ++i) t->umemo[2 * i + 1].x = 0xFFFFFFFFu;
+  auto bound_of = [&](uint32_t id) -> double { return ceil(fabs(static_cast<double>(m.pieces[id].score))) + 1.0; };
+  std::vector<const Ent *> small, big;
   for (const Ent &e : ents) {
-    uint32_t sl = HashWordKey(e.k[0], e.k[1], e.k[2], e.k[3]) & (wsz - 1);
-    while (t->umemo[2 * sl + 1].x != 0xFFFFFFFFu) sl = (sl + 1) & (wsz - 1);
-    t->umemo[2 * sl] = U4{e.k[0], e.k[1], e.k[2], e.k[3]};
-    t->umemo[2 * sl + 1] = U4{e.id0, e.id1, FloatBits(e.s0), FloatBits(e.bmax)};
+    const bool one = e.id1 == 0xFFFFFFFFu;
+    const bool short_key = e.k[3] == 0;                  // at most 12 bytes
+    if (one && short_key && e.id0 < 65536u && bound_of(e.id0) <= 255.0 && e.bmax >= 1.0f) small.push_back(&e);
+    else big.push_back(&e);
   }
-  sc.umemo_mask = wsz - 1;
+  auto meta16 = [&](const Ent &e) -> uint32_t {
+    int ex = 0;
+    (void)frexpf(e.bmax, &ex);                            // bmax = f * 2^ex, f in [0.5, 1): 2^(ex - 1) <= bmax
+    int pw = ex - 1;
+    if (pw > 126) pw = 126;
+    return e.id0 | static_cast<uint32_t>(pw) << 16 | static_cast<uint32_t>(bound_of(e.id0)) << 24;
+  };
+  {
+    const uint32_t wsz = NextPow2(small.size() * 2 + 16);
+    t->umemo16.assign(wsz, U4{0, 0, 0, 0xFFFFFFFFu});
+    for (const Ent *e : small) {
+      const uint32_t h = HashWordKey(e->k[0], e->k[1], e->k[2], 0u);
+      U4 &hs = t->uhot[h & (static_cast<uint32_t>(t->uhot.size()) - 1u)];
+      if (hs.w == 0xFFFFFFFFu) hs = U4{e->k[0], e->k[1], e->k[2], meta16(*e)};
+      uint32_t sl = h & (wsz - 1);
+      while (t->umemo16[sl].w != 0xFFFFFFFFu) sl = (sl + 1) & (wsz - 1);
+      t->umemo16[sl] = U4{e->k[0], e->k[1], e->k[2], meta16(*e)};
+    }
+    sc.umemo16_mask = wsz - 1;
+  }
+  {
+    const uint32_t wsz = NextPow2(big.size() * 2 + 16);
+    t->umemo.assign(static_cast<size_t>(wsz) * 2, U4{0, 0, 0, 0});
+    for (uint32_t i = 0; i < wsz; ++i) t->umemo[2 * i + 1].x = 0xFFFFFFFFu;
+    for (const Ent *e : big) {
+      uint32_t sl = HashWordKey(e->k[0], e->k[1], e->k[2], e->k[3]) & (wsz - 1);
+      while (t->umemo[2 * sl + 1].x != 0xFFFFFFFFu) sl = (sl + 1) & (wsz - 1);
+      const double b = bound_of(e->id0) + (e->id1 != 0xFFFFFFFFu ? bound_of(e->id1) : 0.0);
+      t->umemo[2 * sl] = U4{e->k[0], e->k[1], e->k[2], e->k[3]};
+      t->umemo[2 * sl + 1] = U4{e->id0, e->id1, FloatBits(static_cast<float>(b)), FloatBits(e->bmax)};
+    }
+    sc.umemo_mask = wsz - 1;
+  }
   sc.flags |= kNfUniWordwise;
   t->memo_words = static_cast<uint32_t>(ents.size());
 }
@@ -701,6 +735,8 @@ void BindHostPointers(HostTables *t) {
   sc.sym_len = t->sym_len.data();
   sc.wordtab = t->wordtab.data();
   sc.umemo = t->umemo.data();
+  sc.umemo16 = t->umemo16.data();
+  sc.uhot = t->uhot.data();
   sc.pscore = t->pscore.data();
 }
 

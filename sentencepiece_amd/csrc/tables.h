@@ -18,7 +18,7 @@ struct HostTables {
   // unigram
   std::vector<U4> ptrie;
   std::vector<uint8_t> plen;     // per id: byte length of the piece as the device sees it (SpmxDev::plen)
-  std::vector<U4> umemo;         // word memo of the word form (SpmxDev::umemo)
+  std::vector<U4> umemo, umemo16, uhot;   // word memo of the word form (SpmxDev::umemo, umemo16, uhot)
   std::vector<float> pscore;     // per id: score (SpmxDev::pscore)
   uint32_t memo_words = 0, memo_candidates = 0;   // entries in the memo / vocabulary strings that are whole words
   // bpe

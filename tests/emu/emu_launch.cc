@@ -43,8 +43,9 @@ hipError_t LaunchEncodeStream(int model_type, bool uds, const EncodeArgs &a, int
   }
   return hipSuccess;
 }
-hipError_t LaunchEncodeWord(const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t) {
-  RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_word_block(a, s); });
+hipError_t LaunchEncodeWord(bool dp, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t) {
+  if (dp) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_word_block<true>(a, s); });
+  else RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_word_block<false>(a, s); });
   return hipSuccess;
 }
 hipError_t LaunchBpeLong(const LongArgs &a, int grid, hipStream_t) {

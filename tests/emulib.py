@@ -34,6 +34,7 @@ class EmuLib:
         """env: SPMX_* switches read at load (restored afterwards)."""
         e = dict(env or {})
         e.setdefault("SPMX_EMU_CUS", str(cus))
+        e.setdefault("SPMX_FORCE_WORD_DP", "1")     # small test batches: the word form's second pass always runs
         if classes:
             e.setdefault("SPMX_CLASSES", classes)
         old = {k: os.environ.get(k) for k in e}

@@ -85,7 +85,9 @@ def test_emu_backlog(model, emu, oracle, corpora):
     normalizer wait in the wave's backlog and run as tiles of their own; same ids."""
     from sentencepiece_amd import synth
     blob = fixtures.model_blob(model)
-    h = emu.load(blob, cus=1, classes=None, env={"SPMX_TILE_WAVES": "1"})
+    # (the general streaming kernel is what is under test: the word kernels, which would take most of these sentences
+    # first, are switched off)
+    h = emu.load(blob, cus=1, classes=None, env={"SPMX_TILE_WAVES": "1", "SPMX_NO_WORD_KERNEL": "1"})
     o = oracle.load(blob)
     t1, o1 = fixtures.head(*corpora["synth20k"], 1500)
     t2, o2 = corpora["edge"]
