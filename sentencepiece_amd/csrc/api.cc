@@ -237,6 +237,8 @@ struct spmx_handle {
   bool no_word = false;          // SPMX_NO_WORD_KERNEL=1: unigram models skip the word kernels (kernels_word.h)
   bool no_word_dp = false;       // SPMX_NO_WORD_DP=1: ... skip the second pass only
   bool force_word_dp = false;    // SPMX_FORCE_WORD_DP=1: the second pass runs whatever the first one left (tests)
+  int word_wgs = 1;              // SPMX_WORD_WGS: workgroups per CU of the word kernel's first pass
+  int word_waves = 16;           // SPMX_WORD_WAVES: wavefronts per workgroup of the word kernel's first pass
   int tile_waves_override = 0;   // SPMX_TILE_WAVES: cap on wavefronts per workgroup of the streaming kernels
   uint32_t lane_general_min_lanes = 0;   // SPMX_LANE_GENERAL_MIN_LANES (0: per class)
   uint32_t sub_buckets = kSubBuckets;    // SPMX_SUB_BUCKETS: length sub-buckets per class in the classify sort (1..64)
@@ -715,14 +717,14 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       for (int pass = 0; pass < 2; ++pass) {
         const bool dp = pass == 1;
         EncodeArgs wa = a;
-        const int waves = dp ? 8 : 16;
+        const int waves = dp ? 8 : h->word_waves;
         uint64_t total = 0;
         for (int c = 0; c < ncls; ++c) total += known[c];
         if (total == 0) break;
         // the second pass pays when the first one's misses are sparse (a rare word here and there); where most sentences
         // came back, their words are mostly not in the memo and the general kernels are the better tool
         if (dp && total * 4 > n && !h->force_word_dp) break;
-        uint64_t grid = static_cast<uint64_t>(h->n_cu - h->reserve_cus);
+        uint64_t grid = static_cast<uint64_t>(h->n_cu - h->reserve_cus) * static_cast<uint64_t>(dp ? 1 : h->word_wgs);
         if (grid * waves * 64 > total) grid = (total + waves * 64 - 1) / (waves * 64);
         if (grid < 1) grid = 1;
         const uint64_t n_waves = grid * waves;
@@ -1141,6 +1143,8 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_NO_WORD_KERNEL")) h->no_word = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_WORD_DP")) h->no_word_dp = e[0] == '1';
     if (const char *e = getenv("SPMX_FORCE_WORD_DP")) h->force_word_dp = e[0] == '1';
+    if (const char *e = getenv("SPMX_WORD_WGS")) { const int v = atoi(e); if (v >= 1 && v <= 4) h->word_wgs = v; }
+    if (const char *e = getenv("SPMX_WORD_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 16) h->word_waves = v; }
     if (const char *e = getenv("SPMX_NO_BP_SHORT")) h->no_bp_short = e[0] == '1';
     if (const char *e = getenv("SPMX_ARENA_FIRST")) h->arena_first = static_cast<uint64_t>(atoll(e));
     if (const char *e = getenv("SPMX_WIDE_TCAP")) h->wide_tcap = e[0] == '1';
