@@ -237,6 +237,8 @@ struct spmx_handle {
   bool no_word = false;          // SPMX_NO_WORD_KERNEL=1: unigram models skip the word kernels (kernels_word.h)
   bool no_word_dp = false;       // SPMX_NO_WORD_DP=1: ... skip the second pass only
   bool force_word_dp = false;    // SPMX_FORCE_WORD_DP=1: the second pass runs whatever the first one left (tests)
+  bool no_uni_wave = false;      // SPMX_NO_UNI_WAVE=1: unigram models never take the wave-cooperative form (kernels_uniwave.h)
+  uint32_t uni_wave_max = 131072; // SPMX_UNI_WAVE_MAX: a staged class with fewer sentences than this takes the wave-cooperative form
   int word_wgs = 1;              // SPMX_WORD_WGS: workgroups per CU of the word kernel's first pass
   int word_waves = 16;           // SPMX_WORD_WAVES: wavefronts per workgroup of the word kernel's first pass
   int tile_waves_override = 0;   // SPMX_TILE_WAVES: cap on wavefronts per workgroup of the streaming kernels
@@ -669,7 +671,8 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       return kOk;
     };
     // the long form over one device-side list (BPE), growing the slice pool until every sentence has had its turn
-    auto long_launch = [&](const uint32_t *list, const uint32_t *d_count, uint32_t count) -> int {
+    // (uni: the wave-cooperative unigram form over the same pool, kernels_uniwave.h)
+    auto long_launch = [&](const uint32_t *list, const uint32_t *d_count, uint32_t count, bool uni = false) -> int {
       if (count == 0) return kOk;
       LongArgs la{};
       la.dev = h->dev; la.text = d_text; la.offs = d_offsets;
@@ -680,6 +683,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       la.dropout = ws->bpe_dropout; la.seed = ws->sample_seed;
       la.pool_head = &ws->d_ctrl->pool_head;
       uint64_t want = 96ull * text_bytes / (n > count ? n / count : 1) + 4096ull * count + (1ull << 20);
+      if (uni) want = 10ull * text_bytes / (n > count ? n / count : 1) + 1024ull * count + (1ull << 20);
       if (want > (4ull << 30)) want = 4ull << 30;
       int turn = 0;
       uint32_t left = count;
@@ -690,11 +694,12 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         la.retry_list = retry_lists[turn]; la.retry_count = &ws->d_ctrl->retry_count[turn];
         HIP_OR_RETURN(h, hipMemsetAsync(&ws->d_ctrl->pool_head, 0, sizeof(unsigned long long), stream));
         HIP_OR_RETURN(h, hipMemsetAsync(&ws->d_ctrl->retry_count[turn], 0, sizeof(uint32_t), stream));
-        uint64_t g = (static_cast<uint64_t>(left) + 63) / 64;
+        uint64_t g = uni ? static_cast<uint64_t>(left) : (static_cast<uint64_t>(left) + 63) / 64;   // a sentence per wave / per lane
         if (g > static_cast<uint64_t>(h->n_cu) * 16) g = static_cast<uint64_t>(h->n_cu) * 16;
-        snprintf(ws->slot_name[kSlotLong], sizeof(ws->slot_name[kSlotLong]), "BpeLongKernel");
+        snprintf(ws->slot_name[kSlotLong], sizeof(ws->slot_name[kSlotLong]), uni ? "UniLongKernel" : "BpeLongKernel");
         if (!ws->slot_used[kSlotLong]) HIP_OR_RETURN(h, record(kSlotLong, 0));
-        HIP_OR_RETURN(h, LaunchBpeLong(la, static_cast<int>(g), stream));
+        if (uni) HIP_OR_RETURN(h, LaunchUniLong(la, static_cast<uint32_t>(h->tables.max_prefixes), static_cast<int>(g), stream));
+        else HIP_OR_RETURN(h, LaunchBpeLong(la, static_cast<int>(g), stream));
         HIP_OR_RETURN(h, record(kSlotLong, 1));
         ws->slot_used[kSlotLong] = true;
         HIP_OR_RETURN(h, hipMemcpyAsync(&ws->h_ctrl->pool_head, &ws->d_ctrl->pool_head, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
@@ -710,6 +715,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       }
       return left ? Fail(h, kResourceExhausted, "the long form's slice pool kept overflowing") : kOk;
     };
+    const uint32_t *d_list_counts = ws->d_ctrl->list_counts;      // the device-side counts of a.lists
     if (word_ok) {
       // ---- the word kernels first: every class from one queue, longest first.  Pass 1 takes the sentences whose words
       // are all in the memo; pass 2 (over what pass 1 left) also segments the few words that are not; what is left
@@ -761,10 +767,24 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         HIP_OR_RETURN(h, hipStreamSynchronize(stream));
         for (int c = 0; c < ncls; ++c) known[c] = ws->h_ctrl->left_counts[pass][c];
         a.lists = left_lists[pass];
+        d_list_counts = ws->d_ctrl->left_counts[pass];
         if (h->no_word_dp) break;
       }
     }
     if (streaming) {
+      // unigram: the wave-cooperative form (a sentence per wavefront, kernels_uniwave.h) takes the classes where the
+      // lane-per-sentence kernels are the wrong tool -- documents (one lane would walk them alone: 2.5 us per byte),
+      // and classes with too few sentences to fill 64 lanes of every wavefront
+      const bool uni_wave = !is_bpe && !spans && h->tables.max_prefixes >= 1 &&
+                            h->tables.max_prefixes <= static_cast<int>(kUwMaxCands) && !h->no_uni_wave;
+      if (uni_wave) {
+        for (int c = 0; c < ncls; ++c) {
+          if (known[c] == 0) continue;
+          if (cls[c].rcap <= kMaxStagedRaw && known[c] >= h->uni_wave_max) continue;
+          if (int rc = long_launch(a.lists + static_cast<size_t>(c) * n, &d_list_counts[c], known[c], true); rc != kOk) return rc;
+          known[c] = 0;
+        }
+      }
       int c_doc = ncls;                    // first class of the document launch
       for (int c = 0; c < ncls; ++c) if (cls[c].rcap > h->main_max_raw) { c_doc = c; break; }
       if (int rc = stream_launch(kSlotMain, 0, 0, c_doc, known, false, 0); rc != kOk) return rc;
@@ -1143,6 +1163,8 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_NO_WORD_KERNEL")) h->no_word = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_WORD_DP")) h->no_word_dp = e[0] == '1';
     if (const char *e = getenv("SPMX_FORCE_WORD_DP")) h->force_word_dp = e[0] == '1';
+    if (const char *e = getenv("SPMX_NO_UNI_WAVE")) h->no_uni_wave = e[0] == '1';
+    if (const char *e = getenv("SPMX_UNI_WAVE_MAX")) h->uni_wave_max = static_cast<uint32_t>(atoll(e));
     if (const char *e = getenv("SPMX_WORD_WGS")) { const int v = atoi(e); if (v >= 1 && v <= 4) h->word_wgs = v; }
     if (const char *e = getenv("SPMX_WORD_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 16) h->word_waves = v; }
     if (const char *e = getenv("SPMX_NO_BP_SHORT")) h->no_bp_short = e[0] == '1';

@@ -417,7 +417,9 @@ SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint
 // ids of the marked tokens in forward order, with the unknown-run merge or the
 // byte-fallback expansion (sentencepiece_processor.cc:581-613) and the net
 // effect of the extra options (:1019-1064).
-SPMX_DEVICE int emit_wave(const EncodeArgs &a, uint32_t sid, const uint8_t *norm, int nlen, const int32_t *bid,
+// (Args: EncodeArgs, or LongArgs of the wave-cooperative unigram form -- the fields used here have the same names)
+template <typename Args>
+SPMX_DEVICE int emit_wave(const Args &a, uint32_t sid, const uint8_t *norm, int nlen, const int32_t *bid,
                            const uint16_t *blen, int lane) {
   const SpmxDev &d = a.dev;
   const bool bf = (d.flags & kNfByteFallback) != 0;
@@ -837,5 +839,6 @@ SPMX_DEVICE void compact_block(const CompactArgs &a) {
 #include "kernels_normalize.h"
 #include "kernels_nbest.h"
 #include "kernels_long.h"
+#include "kernels_uniwave.h"
 
 #endif

@@ -44,6 +44,11 @@ __global__ __launch_bounds__(64) void BpeLongKernel(LongArgs a) {
   bpe_long_block(a, smem);
 }
 
+__global__ __launch_bounds__(64) void UniLongKernel(LongArgs a, uint32_t cands) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uni_long_block(a, smem, cands);
+}
+
 __global__ __launch_bounds__(64) void NormalizeLongCountKernel(NormalizeArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[64 * kRawWinBytes];
   norm_long_block<false>(a, smem);
@@ -145,6 +150,11 @@ hipError_t LaunchEncodeWord(bool dp, const EncodeArgs &a, int grid, int waves, u
 
 hipError_t LaunchBpeLong(const LongArgs &a, int grid, hipStream_t stream) {
   hipLaunchKernelGGL(BpeLongKernel, dim3(grid), dim3(64), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t LaunchUniLong(const LongArgs &a, uint32_t cands, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL(UniLongKernel, dim3(grid), dim3(64), UniWaveLdsBytes(cands), stream, a, cands);
   return hipGetLastError();
 }
 

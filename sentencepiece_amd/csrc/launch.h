@@ -38,6 +38,8 @@ hipError_t LaunchEncodeStream(int model_type, bool uds, const EncodeArgs &a, int
 // The word kernel (kernels_word.h): unigram models with kNfUniWordwise
 hipError_t LaunchEncodeWord(bool dp, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t stream);
 hipError_t LaunchBpeLong(const LongArgs &a, int grid, hipStream_t stream);
+// The wave-cooperative unigram form (kernels_uniwave.h): one sentence per 64-thread workgroup; cands = candidate-row entries
+hipError_t LaunchUniLong(const LongArgs &a, uint32_t cands, int grid, hipStream_t stream);
 hipError_t LaunchNormalizeLong(bool write, const NormalizeArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchAlignLong(const AlignLongArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchEncode(int model_type, int cls, const EncodeArgs &a, int grid, uint32_t lds_bytes, hipStream_t stream);

@@ -53,6 +53,11 @@ hipError_t LaunchBpeLong(const LongArgs &a, int grid, hipStream_t) {
   return hipSuccess;
 }
 
+hipError_t LaunchUniLong(const LongArgs &a, uint32_t cands, int grid, hipStream_t) {
+  RunGrid(grid, 1, UniWaveLdsBytes(cands), [&](unsigned char *s) { uni_long_block(a, s, cands); });
+  return hipSuccess;
+}
+
 hipError_t LaunchNormalizeLong(bool write, const NormalizeArgs &a, int grid, hipStream_t) {
   if (write) RunGrid(grid, 1, 64 * kRawWinBytes, [&](unsigned char *s) { norm_long_block<true>(a, s); });
   else RunGrid(grid, 1, 64 * kRawWinBytes, [&](unsigned char *s) { norm_long_block<false>(a, s); });

@@ -35,6 +35,8 @@ class EmuLib:
         e = dict(env or {})
         e.setdefault("SPMX_EMU_CUS", str(cus))
         e.setdefault("SPMX_FORCE_WORD_DP", "1")     # small test batches: the word form's second pass always runs
+        e.setdefault("SPMX_UNI_WAVE_MAX", "0")      # ... and the staged classes keep the lane-per-sentence kernels (the
+                                                    # wave-cooperative form has tests of its own; documents always take it)
         if classes:
             e.setdefault("SPMX_CLASSES", classes)
         old = {k: os.environ.get(k) for k in e}

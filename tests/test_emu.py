@@ -451,3 +451,42 @@ def test_emu_arena_overflow_and_retry(model, emu, oracle, corpora):
     want = o.encode_spans(text, offs)
     for a, b in zip(got, want):
         np.testing.assert_array_equal(np.asarray(a).astype(np.int64), np.asarray(b).astype(np.int64))
+
+
+@pytest.mark.parametrize("model", ["test_model", "test_ja_model", "uni1k", "uni1k_bf", "uni1k_uds", "uni1k_ident", "uni1k_suffix",
+                                   "uni32k", "c5_250k_bf"])
+def test_emu_wave_cooperative_unigram(model, emu, oracle, corpora):
+    """kernels_uniwave.h: a sentence per wavefront -- parallel trie walks from 64 character starts, the relaxations
+    folded by one lane in the reference's order.  Every unigram model, every corpus, with the word kernels off so that
+    all sentences come here (SPMX_UNI_WAVE_MAX: classes below that many sentences take this form)."""
+    blob = fixtures.model_blob(model)
+    h = emu.load(blob, env={"SPMX_UNI_WAVE_MAX": "1000000", "SPMX_NO_WORD_KERNEL": "1"})
+    o = oracle.load(blob)
+    for name, k in (("edge", 10 ** 6), ("botchan", 150), ("mixed2k", 40), ("ja", 40), ("synth20k", 150)):
+        text, offs = fixtures.head(*corpora[name], k)
+        for opts in ("", "bos:eos:reverse"):
+            h.sp.SetEncodeExtraOptions(opts)
+            o.set_encode_extra_options(opts)
+            ids, io = h.encode_batch(text, offs)
+            assert h.status == 0 and not h.sent_status.any()
+            oids, oio = o.encode_batch(text, offs)
+            np.testing.assert_array_equal(io, oio)
+            np.testing.assert_array_equal(ids, oids)
+        h.sp.SetEncodeExtraOptions("")
+        o.set_encode_extra_options("")
+    assert any(c["kernel"] == "UniLongKernel" for c in h.sp.LastProfile()["classes"])
+
+
+@pytest.mark.parametrize("model", ["uni32k", "test_model"])
+def test_emu_word_kernels_then_wave_form(model, emu, oracle, corpora):
+    """The word kernels first, what they leave through the wave-cooperative form: the default order on the device."""
+    blob = fixtures.model_blob(model)
+    h = emu.load(blob, classes=None, env={"SPMX_UNI_WAVE_MAX": "1000000"})
+    o = oracle.load(blob)
+    for name, k in (("synth20k", 1500), ("edge", 10 ** 6), ("botchan", 300)):
+        text, offs = fixtures.head(*corpora[name], k)
+        ids, io = h.encode_batch(text, offs)
+        assert h.status == 0
+        oids, oio = o.encode_batch(text, offs)
+        np.testing.assert_array_equal(io, oio)
+        np.testing.assert_array_equal(ids, oids)
