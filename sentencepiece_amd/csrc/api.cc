@@ -238,7 +238,7 @@ struct spmx_handle {
   bool no_word_dp = false;       // SPMX_NO_WORD_DP=1: ... skip the second pass only
   bool force_word_dp = false;    // SPMX_FORCE_WORD_DP=1: the second pass runs whatever the first one left (tests)
   bool no_uni_wave = false;      // SPMX_NO_UNI_WAVE=1: unigram models never take the wave-cooperative form (kernels_uniwave.h)
-  uint32_t uni_wave_max = 131072; // SPMX_UNI_WAVE_MAX: a staged class with fewer sentences than this takes the wave-cooperative form
+  uint32_t uni_wave_max = 0;     // SPMX_UNI_WAVE_MAX: a staged class with fewer sentences than this takes the wave-cooperative form
   int word_wgs = 1;              // SPMX_WORD_WGS: workgroups per CU of the word kernel's first pass
   int word_waves = 16;           // SPMX_WORD_WAVES: wavefronts per workgroup of the word kernel's first pass
   int tile_waves_override = 0;   // SPMX_TILE_WAVES: cap on wavefronts per workgroup of the streaming kernels
@@ -681,6 +681,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       la.side = &ws->d_ctrl->side; la.arena_tb = spans ? ws->d_arena_tb.p : nullptr;
       la.stack_cap = static_cast<uint32_t>(h->tables.max_piece_len) + 8u;
       la.dropout = ws->bpe_dropout; la.seed = ws->sample_seed;
+      la.stats = uni ? &ws->d_ctrl->stats[kStatsPerClass * kSlotLong] : nullptr;
       la.pool_head = &ws->d_ctrl->pool_head;
       uint64_t want = 96ull * text_bytes / (n > count ? n / count : 1) + 4096ull * count + (1ull << 20);
       if (uni) want = 10ull * text_bytes / (n > count ? n / count : 1) + 1024ull * count + (1ull << 20);
@@ -745,6 +746,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
           if (tw > 64) tw = 64;
           if (tw < 1) tw = 1;
           sc.lane_shift = 6;
+          sc.general = cls[c].rcap > kMaxStagedRaw ? 1u : 0u;   // documents pass through to the wave-cooperative form
           sc.count = known[c];
           sc.tw = static_cast<uint32_t>(tw);
           sc.main_tiles = static_cast<uint32_t>((static_cast<uint64_t>(known[c]) + tw - 1) / tw);

@@ -191,6 +191,9 @@ namespace spmx {
 // `orig` (optional, LDS, ncap entries): norm_to_orig (:105-120, :142-152) -- for every normalized byte the raw offset
 // at which the prefix that produced it starts; *orig_end receives the closing entry (:181), -1 where the reference
 // returns before pushing one (all-whitespace input, :96-99).
+// HBM: raw / norm are global memory (the wave-cooperative unigram form, kernels_uniwave.h, normalizes documents in
+// place): the fences between the sweeps and the read-back of the text's tail then cover global stores too.
+template <bool HBM = false>
 SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint8_t *norm, int ncap, int lane,
                                uint16_t *orig = nullptr, int *orig_end = nullptr) {
   const uint32_t F = d.flags;
@@ -379,7 +382,7 @@ SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint
     }
     out += total;
   }
-  wv::sync();
+  if (HBM) wv::sync_global(); else wv::sync();
   if (rm && !any_other) {              // :86-100 every prefix was " ": empty result, no dummy prefix,
     if (orig_end) *orig_end = -1;      // and no closing entry in norm_to_orig either
     return 0;
@@ -388,7 +391,7 @@ SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint
   if (orig && (F & kNfAddDummyPrefix) && !(F & kNfWsSuffix)) {
     // the dummy prefix maps to `consumed` after the leading-space loop (:85-94, :128)
     if (lane < spw) orig[lane] = static_cast<uint16_t>(rm && first_other > 0 ? first_other : 0);
-    wv::sync();
+    if (HBM) wv::sync_global(); else wv::sync();
   }
   if (rm) {                            // :166-176 trailing space symbols
     for (;;) {
@@ -407,7 +410,7 @@ SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint
       if (orig) orig[out + lane] = static_cast<uint16_t>(fin);
     }
     out += spw;
-    wv::sync();
+    if (HBM) wv::sync_global(); else wv::sync();
   }
   if (orig_end) *orig_end = fin;
   return out;

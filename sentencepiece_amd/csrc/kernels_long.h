@@ -43,6 +43,7 @@ struct LongArgs {
   uint32_t stack_cap;           // entries of the resegmentation stack (> longest piece in characters)
   float dropout;                // BPE-dropout (src/bpe_model.cc:131-156): a valid merge is skipped with this probability
   uint64_t seed;                // ... by a generator keyed by (seed, sentence index)
+  unsigned long long *stats;    // (wave-cooperative unigram form, nullable) kStatsPerClass words as EncodeArgs::stats
 };
 
 SPMX_HD inline uint64_t Align16(uint64_t x) { return (x + 15u) & ~static_cast<uint64_t>(15); }

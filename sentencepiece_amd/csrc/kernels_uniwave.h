@@ -8,8 +8,8 @@
 //   walk   (parallel) lane l walks the piece trie from start c + l -- the reference's inner loop (:965-993) -- and
 //          writes what it finds, piece by piece in order of length, into its row of an LDS candidate list.  Which
 //          pieces match at a start does not depend on any score, so the 64 walks are independent;
-//   fold   (one lane) the relaxations of best_path_ends_at in the reference's order: starts ascending, for a start its
-//          candidates by length, then the UNK candidate (:995-1005); same arithmetic -- double add, double compare
+//   fold   the relaxations of best_path_ends_at in the reference's order: starts ascending one after another, a start's
+//          candidates (distinct end positions) side by side, then the UNK candidate (:995-1005); same arithmetic -- double add, double compare
 //          against the float stored, float store (:979-989).  The scores of the last 256 positions live in an LDS
 //          ring; id and length of every position's best piece go to the sentence's bid / blen arrays;
 //   then the backtrack (:1010-1018) marks the token ends and emit_wave (kernels.h) writes the ids.
@@ -23,15 +23,18 @@
 
 namespace spmx {
 
-constexpr uint32_t kUwRing = 256;       // score ring: 64 starts + the longest piece (<= kMaxPieceBytes) + slack
+constexpr uint32_t kUwRing = 256;       // score / back-pointer rings: 64 starts + the longest piece (<= kMaxPieceBytes) + slack
 constexpr uint32_t kUwWindow = 256;     // bytes of text staged per chunk: 64 starts + the longest piece
-constexpr uint32_t kUwMaxCands = 32;    // candidate rows hold SpmxDev-independent max_prefixes entries (<= this)
+constexpr uint32_t kUwMaxCands = 32;    // candidate rows hold max_prefixes entries (<= this)
+constexpr uint32_t kUwUnreached = 0xFFFFFFFFu;
 SPMX_HD inline uint32_t UniWaveLdsBytes(uint32_t J) {
-  return kUwRing * 4u + 64u * J * 8u + 64u + kUwWindow + 16u + kRawWinBytes;
+  return kUwRing * 8u + 64u * J * 8u + 64u + kUwWindow + 16u + kRawWinBytes;
 }
 
 struct UniWaveLds {
   float *ring_s;      // [kUwRing] best_path_score of position p at ring_s[p % kUwRing]
+  uint32_t *ring_b;   // [kUwRing] its best piece: id | length << 24 (kUwUnreached: no candidate yet); doubles as the
+                      //           backtrack's window of blen entries
   U2 *cands;          // [64][J]  {id | length << 24 | user-defined << 31, score bits}
   uint8_t *ncand;     // [64]
   uint8_t *win;       // [kUwWindow + 16] text window
@@ -40,26 +43,30 @@ struct UniWaveLds {
 SPMX_DEVICE UniWaveLds carve_uniwave(unsigned char *smem, uint32_t J) {
   UniWaveLds T;
   T.ring_s = reinterpret_cast<float *>(smem);
-  T.cands = reinterpret_cast<U2 *>(smem + kUwRing * 4u);
-  T.ncand = smem + kUwRing * 4u + 64u * J * 8u;
+  T.ring_b = reinterpret_cast<uint32_t *>(smem + kUwRing * 4u);
+  T.cands = reinterpret_cast<U2 *>(smem + kUwRing * 8u);
+  T.ncand = smem + kUwRing * 8u + 64u * J * 8u;
   T.win = T.ncand + 64u;
   T.rawwin = T.win + kUwWindow + 16u;
   return T;
 }
 
-// EncodeOptimized of the normalized text nt[0, nlen) (device form, HBM) by one wavefront.  bid / blen: nlen + 1
-// entries, blen zeroed by the caller.  On return blen[e] has kTokEnd | length at every token end of the best path and
-// bid[e] the token's id (unk_id for an unknown character).  false: a broken chain (cannot happen).
+// EncodeOptimized of the normalized text nt[0, nlen) (device form, HBM) by one wavefront.  bid / blen: nlen + 2
+// entries in HBM, written here.  On return blen[e] has kTokEnd | length at every token end of the best path and bid[e]
+// the token's id (unk_id for an unknown character).  false: a broken chain (cannot happen).
+// The fold touches LDS only: scores and back-pointers of the 256 most recent positions live in rings; after the chunk
+// of starts [c, c + 64) has been folded the positions up to c + 64 are final and leave for HBM as one coalesced row.
 SPMX_DEVICE bool unigram_wave(const SpmxDev &d, const uint8_t *nt, int nlen, const UniWaveLds &T, uint32_t J, int32_t *bid,
                               uint16_t *blen, int lane) {
   const U4 *__restrict__ ptrie = d.ptrie;
   const uint32_t root = d.ptrie[0].x >> kDatBaseShiftDev;
   const uint32_t spb = SpByteOf(d);
+  for (uint32_t k = static_cast<uint32_t>(lane); k < kUwRing; k += 64u) T.ring_b[k] = kUwUnreached;
   if (lane == 0) T.ring_s[0] = 0.f;                                   // best_path_ends_at[0].best_path_score = 0
   int next_start = 0;                                                // the next character start (absolute), across chunks
   for (int c = 0; c < nlen; c += 64) {
     // ---- the text of this chunk's walks: positions [c, c + kUwWindow) ----
-    wv::sync();                                                      // (the previous chunk's walks and fold are done)
+    wv::sync();                                                      // (the previous chunk's walks, fold and flush are done)
     {
       const int q = c + 4 * lane;
       uint32_t v = 0;
@@ -106,61 +113,86 @@ SPMX_DEVICE bool unigram_wave(const SpmxDev &d, const uint8_t *nt, int nlen, con
       T.ncand[lane] = static_cast<uint8_t>(k);
     }
     wv::sync();
-    // ---- fold: the relaxations in the reference's order ----
-    if (lane == 0) {
-      for (uint64_t m = S; m != 0; m &= m - 1) {
-        const int l = wv::ffs64(m) - 1;
-        const int ss = c + l;
-        const float bs = T.ring_s[static_cast<uint32_t>(ss) & (kUwRing - 1u)];
-        const uint32_t b0 = T.win[l];
-        int mb = b0 == spb ? 1 : OneCharLenDev(b0);
-        if (mb > nlen - ss) mb = nlen - ss;
-        bool single = false;
-        const uint32_t nk = T.ncand[l];
-        for (uint32_t k = 0; k < nk; ++k) {
-          const U2 cw = T.cands[static_cast<uint32_t>(l) * J + k];
-          const int len = static_cast<int>((cw.x >> 24) & 0x7Fu);
-          const int e = ss + len;
-          double score = static_cast<double>(wv::bits_to_float(cw.y));
-          if (cw.x & 0x80000000u) {                                   // (length * max_score_ - 0.1), :979-981
-            const float prod = static_cast<float>(len) * d.max_score;
-            score = static_cast<double>(prod) - 0.1;
-          }
-          const double cand = score + static_cast<double>(bs);       // :982-983
-          float *slot = &T.ring_s[static_cast<uint32_t>(e) & (kUwRing - 1u)];
-          if (blen[e] == 0 || cand > static_cast<double>(*slot)) {    // :984-989
-            *slot = static_cast<float>(cand);
-            bid[e] = static_cast<int32_t>(cw.x & 0x00FFFFFFu);
-            blen[e] = static_cast<uint16_t>(len);
-          }
-          if (len == mb) single = true;                               // :990
+    // ---- fold: the relaxations in the reference's order.  The starts one after another (a start's score must be
+    // final before its candidates are scored); the candidates of ONE start end at different positions, so lane k takes
+    // candidate k and lane 63 the UNK candidate (:995-1005, only when no piece of one character matched, so its end
+    // position is no candidate's either) ----
+    for (uint64_t m = S; m != 0; m &= m - 1) {
+      const int l = wv::ffs64(m) - 1;
+      const int ss = c + l;
+      const float bs = T.ring_s[static_cast<uint32_t>(ss) & (kUwRing - 1u)];
+      const uint32_t b0 = T.win[l];
+      int mb = b0 == spb ? 1 : OneCharLenDev(b0);
+      if (mb > nlen - ss) mb = nlen - ss;
+      const uint32_t nk = T.ncand[l];
+      const bool has = static_cast<uint32_t>(lane) < nk;
+      int len = 0;
+      if (has) {
+        const U2 cw = T.cands[static_cast<uint32_t>(l) * J + static_cast<uint32_t>(lane)];
+        len = static_cast<int>((cw.x >> 24) & 0x7Fu);
+        const uint32_t es = static_cast<uint32_t>(ss + len) & (kUwRing - 1u);
+        double score = static_cast<double>(wv::bits_to_float(cw.y));
+        if (cw.x & 0x80000000u) {                                     // (length * max_score_ - 0.1), :979-981
+          const float prod = static_cast<float>(len) * d.max_score;
+          score = static_cast<double>(prod) - 0.1;
         }
-        if (!single) {                                                // :995-1005, float arithmetic
-          const int e = ss + mb;
-          const float cand = d.unk_score + bs;
-          float *slot = &T.ring_s[static_cast<uint32_t>(e) & (kUwRing - 1u)];
-          if (blen[e] == 0 || cand > *slot) {
-            *slot = cand;
-            bid[e] = d.unk_id;
-            blen[e] = static_cast<uint16_t>(mb);
-          }
+        const double cand = score + static_cast<double>(bs);         // :982-983
+        if (T.ring_b[es] == kUwUnreached || cand > static_cast<double>(T.ring_s[es])) {      // :984-989
+          T.ring_s[es] = static_cast<float>(cand);
+          T.ring_b[es] = cw.x & 0x7FFFFFFFu;
         }
+      }
+      const bool single = wv::any(has && len == mb);                  // :990
+      if (!single && lane == 63) {                                    // :995-1005, float arithmetic
+        const uint32_t es = static_cast<uint32_t>(ss + mb) & (kUwRing - 1u);
+        const float cand = d.unk_score + bs;
+        if (T.ring_b[es] == kUwUnreached || cand > T.ring_s[es]) {
+          T.ring_s[es] = cand;
+          T.ring_b[es] = (static_cast<uint32_t>(d.unk_id) & 0x00FFFFFFu) | (static_cast<uint32_t>(mb) << 24);
+        }
+      }
+      wv::sync();
+    }
+    wv::sync();
+    // ---- positions (c, c + 64] are final: one coalesced row to HBM, their ring slots are free for c + 256 ... ----
+    {
+      const int p = c + 1 + lane;
+      if (p <= nlen) {
+        const uint32_t sl = static_cast<uint32_t>(p) & (kUwRing - 1u);
+        const uint32_t w = T.ring_b[sl];
+        bid[p] = w == kUwUnreached ? 0 : static_cast<int32_t>(w & 0x00FFFFFFu);
+        blen[p] = w == kUwUnreached ? static_cast<uint16_t>(0) : static_cast<uint16_t>((w >> 24) & 0x7Fu);
+        T.ring_b[sl] = kUwUnreached;
       }
     }
   }
-  wv::sync();
-  // ---- backtrack (:1010-1018) ----
+  wv::sync_global();
+  // ---- backtrack (:1010-1018) through windows of 256 blen entries staged in LDS (the idle back-pointer ring) ----
   uint32_t ok = 1;
-  if (lane == 0) {
-    int e = nlen;
+  {
+    int e = nlen;                                                     // wave-uniform: broadcast from lane 0 after every window
     while (e > 0) {
-      const int len = blen[e];
-      if (len == 0 || len > e) { ok = 0; break; }
-      blen[e] = static_cast<uint16_t>(kTokEnd | static_cast<uint32_t>(len));
-      e -= len;
+      const int lo = e > static_cast<int>(kUwRing) - 1 ? e - (static_cast<int>(kUwRing) - 1) : 0;   // window [lo, e]
+      wv::sync();
+      for (int p = lo + lane; p <= e; p += 64) T.ring_b[p - lo] = blen[p];
+      wv::sync();
+      int e2 = e;
+      if (lane == 0) {
+        while (e2 > lo) {
+          const int len = static_cast<int>(T.ring_b[e2 - lo] & 0x7FFFu);
+          if (len == 0 || len > e2) { ok = 0; e2 = 0; break; }
+          blen[e2] = static_cast<uint16_t>(kTokEnd | static_cast<uint32_t>(len));
+          if (e2 - len < lo) { e2 -= len; break; }                    // (cannot happen: len < 256 - 64; kept for safety)
+          e2 -= len;
+        }
+      }
+      e2 = wv::shfl(e2, 0);
+      if (e2 >= e) { ok = 0; break; }                                 // no progress: broken
+      e = e2;
     }
   }
-  return wv::shfl(ok, 0) != 0;
+  ok = wv::shfl(ok, 0);
+  return ok != 0;
 }
 
 // One sentence per wavefront over a device-side list; slices from the long form's pool (LongArgs, kernels_long.h).
@@ -172,7 +204,9 @@ SPMX_DEVICE void uni_long_block(const LongArgs &a, unsigned char *smem, uint32_t
   const uint32_t n_waves = static_cast<uint32_t>(wv::grid_size() * wv::waves_per_block());
   const uint32_t count = *a.list_count;
   const int n_extra = d.n_prefix + d.n_suffix;
+  unsigned long long st_sent = 0, st_raw = 0, st_ids = 0, st_cyc[3] = {0, 0, 0};
   for (uint32_t i = wave_id; i < count; i += n_waves) {
+    const unsigned long long t0 = wv::clock();
     const uint32_t sid = a.list[i];
     const uint64_t beg = a.offs[sid];
     const uint64_t L64 = a.offs[sid + 1] - beg;
@@ -184,15 +218,7 @@ SPMX_DEVICE void uni_long_block(const LongArgs &a, unsigned char *smem, uint32_t
       continue;
     }
     const int L = static_cast<int>(L64);
-    // ---- normalized length first (a count-only pass by lane 0), then a slice of the size it takes ----
-    int nlen = 0;
-    if (lane == 0) {
-      int nsp = 0;
-      FlatSink cs{nullptr, nullptr, 0};
-      nlen = norm_lane_any(d, a.text, beg, L, cs, T.rawwin, &nsp);
-    }
-    nlen = wv::shfl(nlen, 0);
-    if (nlen == 0) {                                                  // (empty, or nothing but whitespace)
+    auto empty_out = [&]() {                                          // (empty, or nothing but whitespace)
       if (lane == 0) {
         const unsigned long long at = wv::atomic_add(a.arena_head, static_cast<unsigned long long>(n_extra));
         a.tmp_off[sid] = at;
@@ -203,28 +229,62 @@ SPMX_DEVICE void uni_long_block(const LongArgs &a, unsigned char *smem, uint32_t
           for (int x = 0; x < d.n_suffix; ++x) a.arena[at + d.n_prefix + x] = d.suffix_ids[x];
         }
       }
-      continue;
+    };
+    // a slice for a normalized form of up to `cap` bytes; false: the pool is exhausted (the sentence is on the retry list)
+    uint8_t *norm = nullptr;
+    int32_t *bid = nullptr;
+    uint16_t *blen = nullptr;
+    auto take_slice = [&](uint64_t cap) -> bool {
+      const uint64_t b_text = Align16(cap + kUwWindow + 16);
+      const uint64_t b_bid = Align16((cap + 2) * 4);
+      const uint64_t b_len = Align16((cap + 2) * 2);
+      const uint64_t need = b_text + b_bid + b_len;
+      unsigned long long at = 0;
+      if (lane == 0) at = wv::atomic_add(a.pool_head, static_cast<unsigned long long>(need));
+      at = (static_cast<unsigned long long>(wv::shfl(static_cast<uint32_t>(at >> 32), 0)) << 32) | wv::shfl(static_cast<uint32_t>(at), 0);
+      if (at + need > a.pool_cap) {                                   // the host grows the pool and launches again
+        if (lane == 0) { a.retry_list[wv::atomic_add(a.retry_count, 1u)] = sid; a.counts[sid] = 0u; }
+        return false;
+      }
+      norm = a.pool + at;
+      bid = reinterpret_cast<int32_t *>(norm + b_text);
+      blen = reinterpret_cast<uint16_t *>(norm + b_text + b_bid);
+      return true;
+    };
+    // ---- normalize: the position-parallel normalizer (kernels.h normalize_wave) straight from / to HBM, into a slice
+    // sized for text that does not grow (ASCII, CJK: 1.5 x + 64; three-byte space symbols: 3 x); the rare sentence
+    // that outgrows it (NFKC expansions) is normalized again by one lane with norm_lane_any -- a count-only pass, a
+    // slice of exactly the size it takes, a write pass ----
+    int nlen = 0;
+    if (L > 0) {
+      const bool esc3 = (d.flags & kNfEscapeWs) && !(d.flags & kNfCompressSp);
+      uint64_t cap1 = esc3 ? 3ull * static_cast<uint64_t>(L) + 64u : static_cast<uint64_t>(L) + static_cast<uint64_t>(L) / 2u + 64u;
+      const uint64_t bound = static_cast<uint64_t>(L) * d.expand_max + 16u;
+      if (cap1 > bound) cap1 = bound;
+      if (!take_slice(cap1)) continue;
+      nlen = normalize_wave<true>(d, a.text + beg, L, norm, static_cast<int>(cap1), lane);
+      if (nlen < 0) {
+        int n2 = 0;
+        if (lane == 0) {
+          int nsp = 0;
+          FlatSink cs{nullptr, nullptr, 0};
+          n2 = norm_lane_any(d, a.text, beg, L, cs, T.rawwin, &nsp);
+        }
+        n2 = wv::shfl(n2, 0);
+        if (n2 > 0) {
+          if (!take_slice(static_cast<uint64_t>(n2))) continue;
+          if (lane == 0) {
+            FlatSink ws{norm, nullptr, n2};
+            int nsp2 = 0;
+            norm_lane_any(d, a.text, beg, L, ws, T.rawwin, &nsp2);
+          }
+        }
+        nlen = n2;
+      }
     }
-    const uint64_t b_text = Align16(static_cast<uint64_t>(nlen) + kUwWindow + 16);
-    const uint64_t b_bid = Align16((static_cast<uint64_t>(nlen) + 2) * 4);
-    const uint64_t b_len = Align16((static_cast<uint64_t>(nlen) + 2) * 2);
-    const uint64_t need = b_text + b_bid + b_len;
-    unsigned long long at = 0;
-    if (lane == 0) at = wv::atomic_add(a.pool_head, static_cast<unsigned long long>(need));
-    at = (static_cast<unsigned long long>(wv::shfl(static_cast<uint32_t>(at >> 32), 0)) << 32) | wv::shfl(static_cast<uint32_t>(at), 0);
-    if (at + need > a.pool_cap) {                                     // the host grows the pool and launches again
-      if (lane == 0) { a.retry_list[wv::atomic_add(a.retry_count, 1u)] = sid; a.counts[sid] = 0u; }
-      continue;
-    }
-    uint8_t *norm = a.pool + at;
-    int32_t *bid = reinterpret_cast<int32_t *>(norm + b_text);
-    uint16_t *blen = reinterpret_cast<uint16_t *>(norm + b_text + b_bid);
-    if (lane == 0) {
-      FlatSink ws{norm, nullptr, nlen};
-      int nsp2 = 0;
-      norm_lane_any(d, a.text, beg, L, ws, T.rawwin, &nsp2);
-    }
-    for (int e = lane; e <= nlen + 1; e += 64) blen[e] = 0;
+    if (nlen == 0) { empty_out(); ++st_sent; st_raw += static_cast<unsigned long long>(L); st_ids += static_cast<unsigned long long>(n_extra); continue; }
+    const unsigned long long t1 = wv::clock();
+    if (lane == 0) { blen[0] = 0; bid[0] = 0; }
     wv::sync_global();
     const bool ok = unigram_wave(d, norm, nlen, T, J, bid, blen, lane);
     wv::sync_global();
@@ -235,7 +295,18 @@ SPMX_DEVICE void uni_long_block(const LongArgs &a, unsigned char *smem, uint32_t
       }
       continue;
     }
-    emit_wave(a, sid, norm, nlen, bid, blen, lane);
+    const unsigned long long t2 = wv::clock();
+    const int n_out = emit_wave(a, sid, norm, nlen, bid, blen, lane);
+    ++st_sent; st_raw += static_cast<unsigned long long>(L); st_ids += static_cast<unsigned long long>(n_out);
+    st_cyc[0] += t1 - t0; st_cyc[1] += t2 - t1; st_cyc[2] += wv::clock() - t2;
+  }
+  if (a.stats && lane == 0 && st_sent) {
+    wv::atomic_add(&a.stats[0], st_sent);
+    wv::atomic_add(&a.stats[1], st_raw);
+    wv::atomic_add(&a.stats[2], st_ids);
+    wv::atomic_add(&a.stats[4], st_cyc[0]);       // normalize
+    wv::atomic_add(&a.stats[5], st_cyc[1]);       // segment
+    wv::atomic_add(&a.stats[6], st_cyc[2]);       // emit
   }
 }
 

@@ -390,7 +390,8 @@ SPMX_DEVICE void encode_word_block(const EncodeArgs &a, unsigned char *smem) {
     }
     // not for this kernel: beyond the int range of the lane's counters, or text that ends within the over-read of the
     // last sentences of the buffer
-    const bool mine = have && l64 < (1ull << 30) && beg + l64 + 20u <= text_end;
+    // (a class marked `general` passes through: documents belong to the wave-cooperative form, kernels_uniwave.h)
+    const bool mine = have && !a.cls[c].general && l64 < (1ull << 30) && beg + l64 + 20u <= text_end;
     const int len = mine ? static_cast<int>(l64) : 0;
     // ---- a slot of cap ids in the arena (at most one id per byte of the normalized form: the bytes + 1) ----
     const int cap = mine ? len + 1 : 0;
