@@ -553,8 +553,8 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
   // kernels, the long list, two retry lists
   // the word kernel (kernels_word.h): unigram models whose pieces never reach across a word boundary; not for the spans
   // form (it records no token begins) nor under the `reverse` option
-  const bool word_ok = h->model.model_type == kUnigram && (h->dev.flags & kNfUniWordwise) && !(h->dev.flags & kNfReverse) &&
-                       !spans && !h->no_word;
+  const bool word_ok = (h->dev.flags & kNfUniWordwise) && !(h->dev.flags & kNfReverse) && !spans && !h->no_word &&
+                       !(h->model.model_type == kBpe && (ws->bpe_dropout > 0.f || h->no_stream));
   HIP_OR_RETURN(h, ws->d_lists.Reserve(static_cast<size_t>(2 * kMaxClasses + 3 + (word_ok ? 2 * kMaxClasses : 0)) * n));
   HIP_OR_RETURN(h, ws->d_counts.Reserve(n + 1));
   HIP_OR_RETURN(h, ws->d_tmp_off.Reserve(n + 1));
@@ -731,6 +731,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         // the second pass pays when the first one's misses are sparse (a rare word here and there); where most sentences
         // came back, their words are mostly not in the memo and the general kernels are the better tool
         if (dp && total * 4 > n && !h->force_word_dp) break;
+        if (dp && is_bpe) break;            // (BPE: the words the memo lacks are merged by the lane-per-sentence BPE kernel)
         uint64_t grid = static_cast<uint64_t>(h->n_cu - h->reserve_cus) * static_cast<uint64_t>(dp ? 1 : h->word_wgs);
         if (grid * waves * 64 > total) grid = (total + waves * 64 - 1) / (waves * 64);
         if (grid < 1) grid = 1;

@@ -514,8 +514,10 @@ void BuildWordMemo(const ModelData &m, HostTables *t) {
   t->memo_words = t->memo_candidates = 0;
   t->pscore.assign(m.pieces.size() + 1, 0.f);
   for (size_t i = 0; i < m.pieces.size(); ++i) t->pscore[i] = m.pieces[i].score;
-  if (m.model_type != kUnigram || getenv("SPMX_NO_WORD")) return;
+  if ((m.model_type != kUnigram && m.model_type != kBpe) || getenv("SPMX_NO_WORD")) return;
   const uint32_t F = sc.flags;
+  // BPE: the word-wise models only (dev.h kNfBpeWordwise), and no UNUSED piece (resegmentation, src/bpe_model.cc:175-200)
+  if (m.model_type == kBpe && (!(F & kNfBpeWordwise) || (F & kNfHasUnused))) return;
   if (!(F & kNfCompressSp) || !(F & kNfAddDummyPrefix) || !(F & kNfRemoveExtraWs) || (F & kNfWsSuffix) || (F & kNfHasUserDefined)) return;
   for (uint32_t b = 0x20; b < 0x7F; ++b)
     if (!((sc.ascii_safe[b >> 5] >> (b & 31u)) & 1u)) return;     // a charsmap rule may start with an ASCII byte
@@ -528,6 +530,55 @@ void BuildWordMemo(const ModelData &m, HostTables *t) {
   const double unk_score = static_cast<double>(m.min_score - 10.0f);
   struct Ent { uint32_t k[4]; uint32_t id0, id1; float s0, bmax; float order; };
   std::vector<Ent> ents;
+  // BPE: bpe::Model::SampleEncode(alpha = 0) (src/bpe_model.cc:38-203) of one word on the compiled tables -- the merge
+  // loop itself (:142-173: best pair = highest score, then leftmost); exact, no margin involved (bmax = "always")
+  auto bpe_word = [&](const std::string &w, std::vector<uint32_t> *ids) -> bool {
+    auto host_char = [&](uint32_t bytes, uint32_t len) -> uint32_t {
+      uint32_t sl = HashChar(bytes, len) & sc.chartab_mask;
+      for (;;) {
+        const U4 &e = t->chartab[sl];
+        if (e.y == 0) return kSymNone;
+        if (e.x == bytes && e.y == len) return e.z;
+        sl = (sl + 1) & sc.chartab_mask;
+      }
+    };
+    auto host_pair = [&](uint32_t a, uint32_t b, uint32_t *mg, float *score) -> bool {
+      uint32_t sl = HashPair(a, b) & sc.pairtab_mask;
+      for (;;) {
+        const U4 &e = t->pairtab[sl];
+        if (e.x == kSymNone) return false;
+        if (e.x == a && e.y == b) { *mg = e.z; memcpy(score, &e.w, 4); return true; }
+        sl = (sl + 1) & sc.pairtab_mask;
+      }
+    };
+    std::vector<uint32_t> sym;
+    for (size_t p = 0; p < w.size(); ++p) {             // (the space symbol and ASCII: one byte per character)
+      const uint32_t sy = host_char(static_cast<unsigned char>(w[p]), 1u);
+      if (sy == kSymNone) return false;
+      sym.push_back(sy);
+    }
+    while (sym.size() > 1) {
+      int best = -1;
+      float bs = 0.f;
+      uint32_t bm = 0;
+      for (size_t i = 0; i + 1 < sym.size(); ++i) {
+        uint32_t mg = 0;
+        float scv = 0.f;
+        if (host_pair(sym[i], sym[i + 1], &mg, &scv) && (best < 0 || scv > bs)) { best = static_cast<int>(i); bs = scv; bm = mg; }
+      }
+      if (best < 0) break;
+      sym[best] = bm;
+      sym.erase(sym.begin() + best + 1);
+    }
+    ids->clear();
+    for (uint32_t sy : sym) {
+      const uint32_t f = t->sym_final[sy];
+      const uint32_t fid = f & kSfIdMask;
+      if ((f & kSfControl) || static_cast<int>(fid) == m.unk_id || m.pieces[fid].type == kUnknown_) return false;
+      ids->push_back(fid);
+    }
+    return true;
+  };
   for (const auto &kv : m.pieces_map) {
     const std::string &pc = kv.first;
     if (pc.size() <= sp.size() || pc.size() > sp.size() + kWordKeyBytes || pc.compare(0, sp.size(), sp) != 0) continue;
@@ -536,6 +587,21 @@ void BuildWordMemo(const ModelData &m, HostTables *t) {
     for (unsigned char c : body) plain = plain && c >= 0x21 && c <= 0x7E;
     if (!plain) continue;
     ++t->memo_candidates;
+    if (m.model_type == kBpe) {
+      std::vector<uint32_t> ids;
+      if (!bpe_word(std::string(1, static_cast<char>(kSpByte)) + body, &ids) || ids.empty() || ids.size() > 2) continue;
+      Ent en{};
+      unsigned char key[kWordKeyBytes] = {0};
+      memcpy(key, body.data(), body.size());
+      memcpy(en.k, key, sizeof(key));
+      en.id0 = ids[0];
+      en.id1 = ids.size() > 1 ? ids[1] : 0xFFFFFFFFu;
+      en.s0 = 0.f;
+      en.bmax = 3.0e38f;
+      en.order = m.pieces[kv.second].score;
+      ents.push_back(en);
+      continue;
+    }
     // characters of the word: [0] = U+2581, then one byte each; cb[i] = byte offset of character i
     const int nchar = 1 + static_cast<int>(body.size());
     auto cb = [&](int i) -> size_t { return i == 0 ? 0 : sp.size() + static_cast<size_t>(i - 1); };
@@ -599,7 +665,9 @@ void BuildWordMemo(const ModelData &m, HostTables *t) {
   if (ents.size() < min_words) return;
   // likelier words first: they get the slots their hash names, the rest walk (the kernel's lanes wait for the longest walk)
   std::stable_sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.order > b.order; });
-  auto bound_of = [&](uint32_t id) -> double { return ceil(fabs(static_cast<double>(m.pieces[id].score))) + 1.0; };
+  auto bound_of = [&](uint32_t id) -> double {          // (BPE keeps no score: its entries are valid whatever came before)
+    return m.model_type == kBpe ? 0.0 : ceil(fabs(static_cast<double>(m.pieces[id].score))) + 1.0;
+  };
   std::vector<const Ent *> small, big;
   for (const Ent &e : ents) {
     const bool one = e.id1 == 0xFFFFFFFFu;
