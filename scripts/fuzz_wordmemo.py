@@ -109,7 +109,7 @@ def main():
         for w in sorted(set(words)):
             t1, o1 = synth.pack([w.encode(), w.encode(), b"x" * 40])
             h.encode_batch(t1, o1, grid=1)
-            if any(c["kernel"] == "EncodeWordKernel" and c["sentences"] >= 2 for c in h.sp.LastProfile()["classes"]):
+            if any(c["kernel"] in ("EncodeWordKernel", "EncodeWordCollectKernel") and c["sentences"] >= 2 for c in h.sp.LastProfile()["classes"]):
                 hits.append(w)
         if len(hits) < 4:
             continue
@@ -120,7 +120,7 @@ def main():
         oi, oo = o.encode_batch(text, offs)
         prof = h.sp.LastProfile()
         for c in prof["classes"]:
-            if c["kernel"] in ("EncodeWordKernel", "EncodeWordDpKernel"):
+            if c["kernel"].startswith("EncodeWord"):
                 n_word += c["sentences"]
         n_all += len(offs) - 1
         if h.status or not (np.array_equal(io, oo) and np.array_equal(ids, oi)):

@@ -47,6 +47,8 @@ using namespace spmx;
 namespace {
 
 constexpr uint32_t kLdsPerCu = 160u * 1024u;   // gfx950 (MI355X_MICROARCH.md)
+constexpr uint32_t kDynSlots = 1u << 20;       // call-local word memo: slots (64 B each) and words per call it can take
+constexpr uint32_t kDynListCap = 1u << 18;
 
 thread_local std::string t_error;              // text of the calling thread's last failing call
 
@@ -62,6 +64,7 @@ struct Ctrl {
   uint32_t pad;
   StreamQueue q[5];                   // tile queues of the main / document / overflow launches; [3], [4]: the word kernels
   uint32_t left_counts[2][kMaxClasses];   // word kernels: sentences the first / second pass left to the next one, per class
+  uint32_t dyn_count;                     // ... words entered into the call-local memo (must follow left_counts: read together)
   uint32_t align_counts[kMaxClasses]; // spans form: escalation lists of the staged align kernels
   SideLists side;
   unsigned long long arena_head;
@@ -167,7 +170,9 @@ struct Workspace {
   DevBuf<int32_t> d_arena, d_arena_tb, d_tok_begin;
   DevBuf<uint32_t> d_span_begin, d_span_end, d_nspan_begin, d_nspan_end;
   DevBuf<uint8_t> d_norm, d_nbest_scratch, d_slab, d_pool, d_sent_status;
-  DevBuf<unsigned long long> d_res_off;
+  DevBuf<unsigned long long> d_res_off, d_dyn_tag;     // d_dyn_*: the call-local word memo (kernels_word.h)
+  DevBuf<U4> d_dyn_ent;
+  DevBuf<uint32_t> d_dyn_list;
   DevBuf<float> d_res_score;
   Ctrl *d_ctrl = nullptr;
   Ctrl *h_ctrl = nullptr;   // pinned
@@ -190,7 +195,7 @@ struct Workspace {
     d_lists.Free(); d_counts.Free(); d_tmp_off.Free(); d_tile_sums.Free(); d_chunk_base.Free(); d_arena.Free();
     d_arena_tb.Free(); d_tok_begin.Free(); d_span_begin.Free(); d_span_end.Free(); d_nspan_begin.Free(); d_nspan_end.Free();
     d_norm.Free(); d_nbest_scratch.Free(); d_slab.Free(); d_pool.Free(); d_sent_status.Free(); d_res_off.Free();
-    d_res_score.Free(); d_text.Free(); d_offs.Free(); d_id_offs.Free(); d_ids.Free(); d_dn_text.Free(); d_dn_offs.Free();
+    d_res_score.Free(); d_dyn_tag.Free(); d_dyn_ent.Free(); d_dyn_list.Free(); d_text.Free(); d_offs.Free(); d_id_offs.Free(); d_ids.Free(); d_dn_text.Free(); d_dn_offs.Free();
     h_text.Free(); h_offs.Free(); h_id_offs.Free();
     if (d_ctrl) (void)hipFree(d_ctrl);
     if (h_ctrl) (void)hipHostFree(h_ctrl);
@@ -236,6 +241,8 @@ struct spmx_handle {
   bool no_wave = false;          // SPMX_NO_WAVE=1: BPE models that are not word-wise use the long form only
   bool no_word = false;          // SPMX_NO_WORD_KERNEL=1: unigram models skip the word kernels (kernels_word.h)
   bool no_word_dp = false;       // SPMX_NO_WORD_DP=1: ... skip the second pass only
+  bool no_word_dyn = false;      // SPMX_NO_WORD_DYN=1: no call-local word memo (one word round, then the DP pass)
+  bool memo_unsafe = false;      // SPMX_WORDMEMO_UNSAFE=1: TEST SEAM, the call-local memo takes no margin either
   bool force_word_dp = false;    // SPMX_FORCE_WORD_DP=1: the second pass runs whatever the first one left (tests)
   bool no_uni_wave = false;      // SPMX_NO_UNI_WAVE=1: unigram models never take the wave-cooperative form (kernels_uniwave.h)
   uint32_t uni_wave_max = 0;     // SPMX_UNI_WAVE_MAX: a staged class with fewer sentences than this takes the wave-cooperative form
@@ -718,20 +725,23 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
     };
     const uint32_t *d_list_counts = ws->d_ctrl->list_counts;      // the device-side counts of a.lists
     if (word_ok) {
-      // ---- the word kernels first: every class from one queue, longest first.  Pass 1 takes the sentences whose words
-      // are all in the memo; pass 2 (over what pass 1 left) also segments the few words that are not; what is left
-      // then -- anything that is not plain ASCII words -- comes back as per-class lists for the general launches below ----
-      for (int pass = 0; pass < 2; ++pass) {
-        const bool dp = pass == 1;
+      // ---- the word kernels first (kernels_word.h): every class from one queue, longest first.
+      //   round 1   takes the sentences whose words are all in the load-time memo, and enters every other plain word
+      //             it meets into the call-local memo;
+      //   resolve   segments the collected words, one lane per word;
+      //   round 2   over the sentences round 1 kept for it, looking the collected words up;
+      //   (without the call-local memo, SPMX_NO_WORD_DYN=1: round 1, then the DP pass over what it left.)
+      // What is left then -- anything that is not plain ASCII words -- comes back as per-class lists for the general
+      // launches below.
+      const bool dyn = !h->no_word_dyn;
+      auto word_pass = [&](int mode, int slot, int qi, uint32_t *out_lists, uint32_t *d_out_counts, uint32_t *out2_lists,
+                           uint32_t *d_out2_counts) -> int {
+        const bool dp = mode == 3;
         EncodeArgs wa = a;
         const int waves = dp ? 8 : h->word_waves;
         uint64_t total = 0;
         for (int c = 0; c < ncls; ++c) total += known[c];
-        if (total == 0) break;
-        // the second pass pays when the first one's misses are sparse (a rare word here and there); where most sentences
-        // came back, their words are mostly not in the memo and the general kernels are the better tool
-        if (dp && total * 4 > n && !h->force_word_dp) break;
-        if (dp && is_bpe) break;            // (BPE: the words the memo lacks are merged by the lane-per-sentence BPE kernel)
+        if (total == 0) return kOk;
         uint64_t grid = static_cast<uint64_t>(h->n_cu - h->reserve_cus) * static_cast<uint64_t>(dp ? 1 : h->word_wgs);
         if (grid * waves * 64 > total) grid = (total + waves * 64 - 1) / (waves * 64);
         if (grid < 1) grid = 1;
@@ -755,23 +765,73 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
           tile_base += sc.main_tiles;
         }
         wa.total_main = tile_base;
-        const int slot = dp ? kSlotWord2 : kSlotWord;
-        wa.q = &ws->d_ctrl->q[3 + pass];
+        wa.q = &ws->d_ctrl->q[qi];
         wa.stats = &ws->d_ctrl->stats[kStatsPerClass * slot];
-        wa.left_lists = left_lists[pass];
-        wa.left_counts = ws->d_ctrl->left_counts[pass];
-        snprintf(ws->slot_name[slot], sizeof(ws->slot_name[slot]), dp ? "EncodeWordDpKernel" : "EncodeWordKernel");
+        wa.left_lists = out_lists;
+        wa.left_counts = d_out_counts;
+        wa.left2_lists = out2_lists;
+        wa.left2_counts = d_out2_counts;
+        wa.dyn_tag = ws->d_dyn_tag.p;
+        wa.dyn_ent = ws->d_dyn_ent.p;
+        wa.dyn_list = ws->d_dyn_list.p;
+        wa.dyn_count = &ws->d_ctrl->dyn_count;
+        wa.dyn_mask = kDynSlots - 1u;
+        wa.dyn_cap = kDynListCap;
+        snprintf(ws->slot_name[slot], sizeof(ws->slot_name[slot]), "%s",
+                 mode == 3 ? "EncodeWordDpKernel" : mode == 2 ? "EncodeWordAgainKernel" : mode == 1 ? "EncodeWordCollectKernel" : "EncodeWordKernel");
         HIP_OR_RETURN(h, record(slot, 0));
-        HIP_OR_RETURN(h, LaunchEncodeWord(dp, wa, static_cast<int>(grid), waves, WordLdsBytes(waves, dp), stream));
+        HIP_OR_RETURN(h, LaunchEncodeWord(mode, wa, static_cast<int>(grid), waves, WordLdsBytes(waves, dp), stream));
         HIP_OR_RETURN(h, record(slot, 1));
         ws->slot_used[slot] = true;
-        HIP_OR_RETURN(h, hipMemcpyAsync(ws->h_ctrl->left_counts[pass], ws->d_ctrl->left_counts[pass], sizeof(ws->h_ctrl->left_counts[pass]),
-                                        hipMemcpyDeviceToHost, stream));
+        return kOk;
+      };
+      auto read_counts = [&]() -> int {
+        HIP_OR_RETURN(h, hipMemcpyAsync(ws->h_ctrl->left_counts, ws->d_ctrl->left_counts, sizeof(ws->h_ctrl->left_counts) + sizeof(uint32_t),
+                                        hipMemcpyDeviceToHost, stream));      // (dyn_count follows left_counts in Ctrl)
         HIP_OR_RETURN(h, hipStreamSynchronize(stream));
-        for (int c = 0; c < ncls; ++c) known[c] = ws->h_ctrl->left_counts[pass][c];
-        a.lists = left_lists[pass];
-        d_list_counts = ws->d_ctrl->left_counts[pass];
-        if (h->no_word_dp) break;
+        return kOk;
+      };
+      if (dyn) {
+        HIP_OR_RETURN(h, ws->d_dyn_tag.Reserve(kDynSlots));
+        HIP_OR_RETURN(h, ws->d_dyn_ent.Reserve(static_cast<size_t>(kDynSlots) * 4));
+        HIP_OR_RETURN(h, ws->d_dyn_list.Reserve(kDynListCap));
+        HIP_OR_RETURN(h, hipMemsetAsync(ws->d_dyn_tag.p, 0, static_cast<size_t>(kDynSlots) * sizeof(unsigned long long), stream));
+        if (int rc = word_pass(1, kSlotWord, 3, left_lists[0], ws->d_ctrl->left_counts[0], left_lists[1], ws->d_ctrl->left_counts[1]); rc != kOk) return rc;
+        if (int rc = read_counts(); rc != kOk) return rc;
+        uint64_t again = 0;
+        for (int c = 0; c < ncls; ++c) { known[c] = ws->h_ctrl->left_counts[0][c]; again += known[c]; }
+        if (again) {
+          const uint32_t words = ws->h_ctrl->dyn_count < kDynListCap ? ws->h_ctrl->dyn_count : kDynListCap;
+          if (words) {
+            ResolveArgs ra{};
+            ra.dev = h->dev; ra.dyn_ent = ws->d_dyn_ent.p; ra.dyn_list = ws->d_dyn_list.p; ra.dyn_count = &ws->d_ctrl->dyn_count;
+            ra.dyn_cap = kDynListCap; ra.unsafe = h->memo_unsafe ? 1u : 0u;
+            uint64_t g = (static_cast<uint64_t>(words) + 63) / 64;
+            if (g > static_cast<uint64_t>(h->n_cu) * 8) g = static_cast<uint64_t>(h->n_cu) * 8;
+            HIP_OR_RETURN(h, LaunchWordResolve(ra, static_cast<int>(g), stream));
+          }
+          a.lists = left_lists[0];
+          if (int rc = word_pass(2, kSlotWord2, 4, left_lists[1], ws->d_ctrl->left_counts[1], nullptr, nullptr); rc != kOk) return rc;
+          if (int rc = read_counts(); rc != kOk) return rc;
+        }
+        for (int c = 0; c < ncls; ++c) known[c] = ws->h_ctrl->left_counts[1][c];
+        a.lists = left_lists[1];
+        d_list_counts = ws->d_ctrl->left_counts[1];
+      } else {
+        if (int rc = word_pass(0, kSlotWord, 3, left_lists[0], ws->d_ctrl->left_counts[0], nullptr, nullptr); rc != kOk) return rc;
+        if (int rc = read_counts(); rc != kOk) return rc;
+        uint64_t total = 0;
+        for (int c = 0; c < ncls; ++c) { known[c] = ws->h_ctrl->left_counts[0][c]; total += known[c]; }
+        a.lists = left_lists[0];
+        d_list_counts = ws->d_ctrl->left_counts[0];
+        // the DP pass pays when the first one's misses are sparse (a rare word here and there)
+        if (!is_bpe && !h->no_word_dp && total && (total * 4 <= n || h->force_word_dp)) {
+          if (int rc = word_pass(3, kSlotWord2, 4, left_lists[1], ws->d_ctrl->left_counts[1], nullptr, nullptr); rc != kOk) return rc;
+          if (int rc = read_counts(); rc != kOk) return rc;
+          for (int c = 0; c < ncls; ++c) known[c] = ws->h_ctrl->left_counts[1][c];
+          a.lists = left_lists[1];
+          d_list_counts = ws->d_ctrl->left_counts[1];
+        }
       }
     }
     if (streaming) {
@@ -1166,6 +1226,8 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_NO_WORD_KERNEL")) h->no_word = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_WORD_DP")) h->no_word_dp = e[0] == '1';
     if (const char *e = getenv("SPMX_FORCE_WORD_DP")) h->force_word_dp = e[0] == '1';
+    if (const char *e = getenv("SPMX_NO_WORD_DYN")) h->no_word_dyn = e[0] == '1';
+    if (getenv("SPMX_WORDMEMO_UNSAFE")) h->memo_unsafe = true;
     if (const char *e = getenv("SPMX_NO_UNI_WAVE")) h->no_uni_wave = e[0] == '1';
     if (const char *e = getenv("SPMX_UNI_WAVE_MAX")) h->uni_wave_max = static_cast<uint32_t>(atoll(e));
     if (const char *e = getenv("SPMX_WORD_WGS")) { const int v = atoi(e); if (v >= 1 && v <= 4) h->word_wgs = v; }

@@ -98,6 +98,15 @@ struct EncodeArgs {
   // ---- word kernel (kernels_word.h): what it cannot take, per length class, for the general launch that follows ----
   uint32_t *left_lists;         // n_classes x n
   uint32_t *left_counts;        // n_classes (zeroed before the launch)
+  uint32_t *left2_lists;        // (collecting pass) sentences no later word pass can take: for the general launches
+  uint32_t *left2_counts;
+  // the call-local word memo (kernels_word.h): words the load-time memo lacks, segmented once per call
+  unsigned long long *dyn_tag;  // [dyn_mask + 1] 64-bit hash of the word, 0: free
+  U4 *dyn_ent;                  // [dyn_mask + 1][4] {key} {state, n_ids, bound, bmax} {ids 0-3} {ids 4-7}
+  uint32_t *dyn_list;           // slots taken, in order of arrival
+  uint32_t *dyn_count;
+  uint32_t dyn_mask;
+  uint32_t dyn_cap;             // entries dyn_list holds
   // ---- sentence-per-wave launch (BPE models that are not word-wise; kernels_bpe.h) ----
   const uint32_t *list;         // sentence indices of this length class
   const uint32_t *list_count;   // number of entries in list (device resident)

@@ -33,11 +33,23 @@ __global__ __launch_bounds__(1024) void EncodeBpeStreamKernel(EncodeArgs a) {
 }
 __global__ __launch_bounds__(1024) void EncodeWordKernel(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  encode_word_block<false>(a, smem);
+  encode_word_block<false, kWmPlain>(a, smem);
+}
+__global__ __launch_bounds__(1024) void EncodeWordCollectKernel(EncodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  encode_word_block<false, kWmCollect>(a, smem);
+}
+__global__ __launch_bounds__(1024) void EncodeWordAgainKernel(EncodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  encode_word_block<false, kWmDyn>(a, smem);
 }
 __global__ __launch_bounds__(512) void EncodeWordDpKernel(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  encode_word_block<true>(a, smem);
+  encode_word_block<true, kWmPlain>(a, smem);
+}
+__global__ __launch_bounds__(64) void WordResolveKernel(ResolveArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[64 * (kResolvePos * 12 + 20)];
+  word_resolve_block(a, smem);
 }
 __global__ __launch_bounds__(64) void BpeLongKernel(LongArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[64 * kRawWinBytes];
@@ -137,14 +149,18 @@ hipError_t LaunchEncodeStream(int model_type, bool uds, const EncodeArgs &a, int
   return hipGetLastError();
 }
 
-hipError_t LaunchEncodeWord(bool dp, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t stream) {
-  void (*fn)(EncodeArgs) = dp ? EncodeWordDpKernel : EncodeWordKernel;
+hipError_t LaunchEncodeWord(int mode, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t stream) {
+  void (*fn)(EncodeArgs) = mode == 3 ? EncodeWordDpKernel : mode == 2 ? EncodeWordAgainKernel : mode == 1 ? EncodeWordCollectKernel : EncodeWordKernel;
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds_bytes));
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * waves), lds_bytes, stream, a);
+  return hipGetLastError();
+}
+hipError_t LaunchWordResolve(const ResolveArgs &a, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL(WordResolveKernel, dim3(grid), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
 

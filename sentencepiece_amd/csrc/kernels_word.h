@@ -36,6 +36,18 @@
 // can go on, and all of them run their DP together.  What the second pass cannot take either (non-ASCII text, more than
 // kWordDpMax such words in a sentence) goes to the general kernels (kernels_stream.h).
 //
+// The CALL-LOCAL memo.  The load-time memo knows the vocabulary's own whole words; a corpus has others (rarer words
+// that split into several pieces).  A sentence with ONE such word would otherwise leave the word form altogether, and
+// on natural text most sentences have one.  So the first pass COLLECTS: a word that is not in the memo is entered --
+// once, by a 64-bit compare-and-swap on a hash of its bytes -- into a table in HBM, the lane goes on through its
+// sentence looking for more, and the sentence is kept for a second round.  A small kernel then segments every
+// collected word ONCE, one lane per word (word_resolve_block): BPE by the merge loop (exact); unigram by
+// EncodeOptimized of the word from score 0 in float with the margin analysis above done on the device (the float
+// roundings of this DP are charged to the margin).  The second round (the same word loop, now looking a missed word
+// up in the call-local table; up to 8 pieces per word) then takes those sentences.  Two different words with the same
+// 64-bit hash: the second finds the first's bytes in the entry, which is a miss -- its sentence takes the general
+// kernels; nothing wrong can come out.
+//
 // What the normalizer contributes is implicit: the model must add a dummy prefix, remove extra whitespace and escape
 // whitespace with the one-byte space symbol, and every byte 0x20-0x7E must be a character no charsmap rule starts with
 // (tables.cc checks all of it), so Normalize() of such a sentence is "words joined by single space symbols, one in
@@ -55,6 +67,15 @@ constexpr uint32_t kWordLdsShared = kWordMaskBytes + kWordHotSlots * 16u;
 constexpr uint32_t kWordStage = 8;                              // ids per burst
 constexpr uint32_t kWordDpPos = 18;                             // positions of a word in the DP: space symbol + 16 bytes + end
 constexpr int kWordDpMax = 4;                                   // words per sentence the second pass segments itself
+constexpr uint32_t kDynMaxIds = 8;                              // pieces per word of the call-local memo
+constexpr uint32_t kDynProbes = 24;                             // slots tried before a word is given up
+// word modes of uni_word_lane: plain; collecting (first round of a call that has a call-local memo); looking the
+// call-local memo up (second round)
+enum { kWmPlain = 0, kWmCollect = 1, kWmDyn = 2 };
+SPMX_DEVICE unsigned long long DynTag(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
+  const unsigned long long t = (static_cast<unsigned long long>(HashWordKey(k0, k1, k2, k3)) << 32) | HashWord(k0, k1, k2, k3);
+  return t | 1ull;                                              // (0 means "free")
+}
 SPMX_HD inline uint32_t WordLdsPerWave(bool dp) {
   return 64u * kWordStage * 4u + (dp ? 64u * (kWordDpPos * 8u + 20u) : 0u);
 }
@@ -133,9 +154,11 @@ SPMX_DEVICE void uni_word_dp(const SpmxDev &d, const WordLds &T, int L, float B,
 
 // The words of this lane's sentence (raw bytes gtext[beg, beg + len)) -> ids in slot[0, n), forward order.
 // Returns n >= 0, or -1: the sentence is not for this pass (nothing usable was written).
-template <bool DP>
-SPMX_DEVICE int uni_word_lane(const SpmxDev &d, const uint8_t *gtext, uint64_t beg, int len, int32_t *slot, int cap,
+// MODE (kWm*): the call-local memo of `a` (dyn_*) is filled (collect) / consulted (dyn); -2: "try again in the second round".
+template <bool DP, int MODE>
+SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_t beg, int len, int32_t *slot, int cap,
                               const WordLds &T, bool active_in, int *n_steps) {
+  const SpmxDev &d = a.dev;
   const U4 *__restrict__ memo16 = d.umemo16;
   const U4 *__restrict__ memo32 = d.umemo;
   const uint32_t m16 = d.umemo16_mask, m32 = d.umemo_mask;
@@ -143,6 +166,7 @@ SPMX_DEVICE int uni_word_lane(const SpmxDev &d, const uint8_t *gtext, uint64_t b
   int32_t *stage = T.stage;
   bool active = active_in && len > 0;
   bool bad = false;
+  bool again = false;                              // (collect) every word this lane could not take is in the call-local memo now
   int p = 0, n = 0, steps = 0;
   float B = 0.f;                                   // DP: best_path_score at the start of the current word; else a bound of its magnitude
   int n_dp = 0;
@@ -283,14 +307,63 @@ SPMX_DEVICE int uni_word_lane(const SpmxDev &d, const uint8_t *gtext, uint64_t b
       }
       if (hit32) ent = e1;
     }
+    // ---- (second round) the call-local memo: words collected by the first round, segmented by word_resolve_block ----
+    bool hitd = false;
+    uint32_t dslot = 0, dn = 0;
+    if (MODE == kWmDyn && wv::any(word && !hit16 && !hit32 && !lng)) {
+      if (word && !hit16 && !hit32 && !lng) {
+        const unsigned long long tag = DynTag(k0, k1, k2, k3);
+        uint32_t sl = static_cast<uint32_t>(tag >> 32) & a.dyn_mask;
+        for (uint32_t t = 0; t < kDynProbes; ++t) {
+          const unsigned long long g = a.dyn_tag[sl];
+          if (g == 0ull) break;
+          if (g == tag) {
+            const U4 e0 = a.dyn_ent[4u * sl], e1 = a.dyn_ent[4u * sl + 1u];
+            if (e0.x == k0 && e0.y == k1 && e0.z == k2 && e0.w == k3 && e1.x == 1u) { hitd = true; dslot = sl; dn = e1.y; ent = U4{0, 0, e1.z, e1.w}; }
+            break;                                   // (same hash, other bytes or an unusable word: a miss)
+          }
+          sl = (sl + 1u) & a.dyn_mask;
+        }
+      }
+    }
     // ---- take the entry while its margin holds ----
     const uint32_t id0 = hit16 ? (ent.w & 0xFFFFu) : ent.x;
     const uint32_t id1 = hit32 ? ent.y : 0xFFFFFFFFu;
     // valid while |B| < lim: 2^e (16-byte entry: the power of two below bmax) or bmax itself
     const float lim = hit16 ? wv::bits_to_float((((ent.w >> 16) & 0xFFu) + 127u) << 23) : wv::bits_to_float(ent.w);
-    const bool hit = hit16 || hit32;
-    const bool ok = hit && fabsf(B) < lim;
-    if (word && !ok) {
+    const bool hit = hit16 || hit32 || hitd;
+    // (a collecting lane that has already given its sentence up only scouts for more words: no margin to check)
+    const bool ok = hit && ((MODE == kWmCollect && bad) || fabsf(B) < lim);
+    if (MODE == kWmCollect && word && !hit && !lng) {
+      // ---- a word the memo lacks: into the call-local memo (once per word per call), if it is plain ----
+      const Q4 mk = T.masks[L];
+      const uint32_t pad = 0x41414141u;
+      const uint32_t a0 = (w.x & mk.x) | (pad & ~mk.x), a1 = (w.y & mk.y) | (pad & ~mk.y), a2 = (w.z & mk.z) | (pad & ~mk.z),
+                     a3 = (w.w & mk.w) | (pad & ~mk.w);
+      auto plain = [](uint32_t x) -> bool {
+        return (((x + 0x01010101u) | x) & 0x80808080u) == 0u && (((x - 0x21212121u) & ~x) & 0x80808080u) == 0u;
+      };
+      bool kept = false;
+      if (plain(a0) && plain(a1) && plain(a2) && plain(a3)) {
+        const unsigned long long tag = DynTag(k0, k1, k2, k3);
+        uint32_t sl = static_cast<uint32_t>(tag >> 32) & a.dyn_mask;
+        for (uint32_t t = 0; t < kDynProbes && !kept; ++t) {
+          const unsigned long long g = wv::atomic_cas(&a.dyn_tag[sl], 0ull, tag);
+          if (g == 0ull) {                           // ours: the word's bytes, and a place in the list of words to segment
+            const uint32_t at = wv::atomic_add(a.dyn_count, 1u);
+            a.dyn_ent[4u * sl] = U4{k0, k1, k2, k3};
+            a.dyn_ent[4u * sl + 1u] = U4{at < a.dyn_cap ? 0u : 2u, 0u, 0u, 0u};     // (2: no room on the list: never usable)
+            if (at < a.dyn_cap) { a.dyn_list[at] = sl; kept = true; }
+            break;
+          }
+          if (g == tag) { kept = true; break; }      // another lane has entered it
+          sl = (sl + 1u) & a.dyn_mask;
+        }
+      }
+      bad = true;
+      if (kept) again = true; else { again = false; active = false; }
+    } else if (word && !ok) {
+      if (MODE == kWmCollect) again = false;         // (a margin that does not hold, a word of more than 16 bytes: no second round)
       bool dp_ok = false;
       if (DP && !lng && n_dp < kWordDpMax) {
         // the lane segments the word itself if it is plain: L bytes 0x21 .. 0x7E
@@ -318,7 +391,17 @@ SPMX_DEVICE int uni_word_lane(const SpmxDev &d, const uint8_t *gtext, uint64_t b
       }
       if (!dp_ok) { bad = true; active = false; }
     }
-    if (ok) {
+    if (ok && hitd) {
+      // a word of the call-local memo: up to kDynMaxIds pieces; dn = count | begins with an unknown piece << 8 | ends << 9
+      const uint32_t cntd = dn & 0xFFu;
+      if (n + static_cast<int>(cntd) > cap) { bad = true; active = false; }
+      else {
+        B += wv::bits_to_float(ent.z);
+        const uint32_t *di = reinterpret_cast<const uint32_t *>(a.dyn_ent + 4u * dslot + 2u);
+        for (uint32_t k = (prev_unk && (dn & 0x100u)) ? 1u : 0u; k < cntd; ++k) put(di[k]);   // (:609-613 the run goes on)
+        prev_unk = (dn & 0x200u) != 0u;
+      }
+    } else if (ok && !(MODE == kWmCollect && bad)) {
       const bool two = id1 != 0xFFFFFFFFu;
       if (n + (two ? 2 : 1) > cap) { bad = true; active = false; }
       else {
@@ -338,7 +421,7 @@ SPMX_DEVICE int uni_word_lane(const SpmxDev &d, const uint8_t *gtext, uint64_t b
     if (run) { p = pn; w = wn; }
   }
   *n_steps = steps;
-  if (bad) return -1;
+  if (bad) return (MODE == kWmCollect && again) ? -2 : -1;
   if (active_in && len > 0)
     for (int k = n & ~7; k < n; ++k) slot[k] = stage[(k & 7) << 6];   // the last, incomplete group
   return n;
@@ -346,7 +429,7 @@ SPMX_DEVICE int uni_word_lane(const SpmxDev &d, const uint8_t *gtext, uint64_t b
 
 // Persistent body of the word kernels: tiles of up to 64 sentences from the launch's queue (kernels_stream.h
 // next_tile), one sentence per lane.  What a lane cannot take goes to the leftover list of its class.
-template <bool DP>
+template <bool DP, int MODE>
 SPMX_DEVICE void encode_word_block(const EncodeArgs &a, unsigned char *smem) {
   const int lane = wv::lane();
   const SpmxDev &d = a.dev;
@@ -409,7 +492,7 @@ SPMX_DEVICE void encode_word_block(const EncodeArgs &a, unsigned char *smem) {
     const int shift = (4 - (at & 3)) & 3;
     int32_t *slot = a.arena + base + static_cast<unsigned long long>(excl + shift) + d.n_prefix;
     int steps = 0;
-    int n = uni_word_lane<DP>(d, a.text, beg, len, slot, cap, T, mine && !overflow, &steps);
+    int n = uni_word_lane<DP, MODE>(a, a.text, beg, len, slot, cap, T, mine && !overflow, &steps);
     const unsigned long long c1 = wv::clock();
     if (overflow) n = -1;
     const bool done = mine && n >= 0;
@@ -421,7 +504,16 @@ SPMX_DEVICE void encode_word_block(const EncodeArgs &a, unsigned char *smem) {
     }
     const bool left = have && !done;
     if (left) a.counts[sid] = 0u;                    // (until a later pass has had it)
-    append_lanes(wv::ballot(left), left, sid, a.left_lists + static_cast<uint64_t>(c) * a.n, &a.left_counts[c], lane);
+    if (MODE == kWmCollect) {
+      // the second round takes what is only short of words the call-local memo now holds; the rest goes straight to
+      // the general launches
+      const bool again = left && n == -2;
+      const bool gone = left && !again;
+      append_lanes(wv::ballot(again), again, sid, a.left_lists + static_cast<uint64_t>(c) * a.n, &a.left_counts[c], lane);
+      append_lanes(wv::ballot(gone), gone, sid, a.left2_lists + static_cast<uint64_t>(c) * a.n, &a.left2_counts[c], lane);
+    } else {
+      append_lanes(wv::ballot(left), left, sid, a.left_lists + static_cast<uint64_t>(c) * a.n, &a.left_counts[c], lane);
+    }
     if (done) { ++tc.n_sent; tc.n_raw += static_cast<unsigned long long>(len); tc.n_ids += static_cast<unsigned long long>(n + n_extra); }
     tc.n_trips += static_cast<unsigned long long>(steps);
     tc.cyc[2] += c1 - c0;
@@ -438,6 +530,243 @@ SPMX_DEVICE void encode_word_block(const EncodeArgs &a, unsigned char *smem) {
       for (int k = 0; k < 4; ++k) wv::atomic_add(&a.stats[3 + k], tc.cyc[k]);
       wv::atomic_add(&a.stats[7], tc.n_trips);
     }
+  }
+}
+
+// ---- the call-local memo's words, segmented once each: one LANE per collected word ------------------------------------
+struct ResolveArgs {
+  SpmxDev dev;
+  U4 *dyn_ent;
+  const uint32_t *dyn_list;
+  const uint32_t *dyn_count;
+  uint32_t dyn_cap;
+  uint32_t unsafe;              // TEST SEAM (SPMX_WORDMEMO_UNSAFE): no margin, as in tables.cc
+};
+constexpr uint32_t kResolvePos = 18;
+SPMX_HD inline uint32_t ResolveLdsBytes() { return 64u * (kResolvePos * 12u + 20u); }
+
+// unigram: EncodeOptimized (src/unigram_model.cc:957-1018) of the word from score 0, in float, keeping the second best
+// candidate of every position: the margin analysis of tables.cc BuildWordMemo on the device.  Every value here is
+// within n * ulp(wmag) / 2 of its exact counterpart (one rounding per piece), so the exact lead of the best candidate at
+// a position is at least (best - second) - n * ulp(wmag); that is what the margin is computed from.
+SPMX_DEVICE void resolve_unigram_lane(const ResolveArgs &a, uint32_t slot, float *best, float *second, uint32_t *bp, uint8_t *wb, bool active) {
+  const SpmxDev &d = a.dev;
+  const U4 *__restrict__ ptrie = d.ptrie;
+  const uint32_t root = d.ptrie[0].x >> kDatBaseShiftDev;
+  int L = 0;
+  if (active) {
+    const U4 k = a.dyn_ent[4u * slot];
+    const uint32_t kw[4] = {k.x, k.y, k.z, k.w};
+    wb[0] = static_cast<uint8_t>(kSpByte);
+    for (int i = 0; i < 16; ++i) {
+      const uint32_t b = (kw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+      wb[1 + i] = static_cast<uint8_t>(b);
+      if (b != 0u && L == i) L = i + 1;
+    }
+  }
+  const int n = L + 1;
+  const float kNone = -3.0e38f;
+  if (active) {
+    for (int i = 0; i <= n; ++i) { bp[i << 6] = 0u; best[i << 6] = kNone; second[i << 6] = kNone; }
+    best[0] = 0.f;
+  }
+  float wmag = 0.f;
+  int s = 0, dep = 0;
+  uint32_t node = root;
+  float bs = 0.f;
+  bool single = false;
+  bool run = active;
+  auto relax = [&](int e, float cand, uint32_t word) __attribute__((always_inline)) {
+    if (fabsf(cand) > wmag) wmag = fabsf(cand);
+    if (bp[e << 6] == 0u || cand > best[e << 6]) { second[e << 6] = bp[e << 6] == 0u ? kNone : best[e << 6]; best[e << 6] = cand; bp[e << 6] = word; }
+    else if (cand > second[e << 6]) second[e << 6] = cand;
+  };
+  while (wv::any(run)) {
+    if (run) {
+      const uint32_t c = wb[s + dep];
+      const U4 u = ptrie[node ^ c];
+      bool match = (u.x & 0x1FFu) == (0x100u | c);
+      if (match) {
+        ++dep;
+        node = u.x >> kDatBaseShiftDev;
+        if ((u.x & kDatTerminalDev) && !(u.y & kPtUnused)) {
+          relax(s + dep, wv::bits_to_float(u.z) + bs, (u.y & kBwIdMask) | (static_cast<uint32_t>(dep) << kBwLenShift));
+          if (dep == 1) single = true;
+        }
+        if (s + dep >= n) match = false;
+      }
+      if (!match) {
+        if (!single) relax(s + 1, d.unk_score + bs, (1u << kBwLenShift) | kBwUnk);
+        ++s;
+        if (s >= n) run = false;
+        else { bs = best[s << 6]; node = root; dep = 0; single = false; }
+      }
+    }
+  }
+  if (!active) return;
+  // the best path, its smallest lead, its ids
+  // (ids in backtrack order = last piece first; an unknown piece is unk_id, a run of them ONE id, or under byte fallback
+  // the bytes of every unknown character -- sentencepiece_processor.cc:581-613; whether the word begins / ends with an
+  // unknown piece is kept, so that a run can continue across words)
+  uint32_t ids[kDynMaxIds];
+  int cnt = 0;
+  float gap = 3.0e38f, bound = 0.f;
+  bool good = true;
+  const bool bf = (d.flags & kNfByteFallback) != 0;
+  bool last_unk = false, first_unk = false, right_unk = false;
+  auto push = [&](uint32_t id) __attribute__((always_inline)) { if (cnt < static_cast<int>(kDynMaxIds)) ids[cnt++] = id; else good = false; };
+  for (int e = n; e > 0 && good;) {
+    const uint32_t bw = bp[e << 6];
+    const int bl = static_cast<int>((bw >> kBwLenShift) & kBwLenMask);
+    if (bw == 0u || bl == 0 || bl > e) { good = false; break; }
+    if (second[e << 6] > kNone) { const float g = best[e << 6] - second[e << 6]; if (g < gap) gap = g; }
+    const bool unk = (bw & kBwUnk) != 0;
+    if (e == n) last_unk = unk;
+    if (e - bl == 0) first_unk = unk;
+    if (unk) {
+      bound += ceilf(fabsf(d.unk_score)) + 1.f;
+      if (bf) {
+        const uint32_t ch = wb[e - 1];
+        if (ch == kSpByte) { push(static_cast<uint32_t>(d.byte_ids[0x81])); push(static_cast<uint32_t>(d.byte_ids[0x96])); push(static_cast<uint32_t>(d.byte_ids[0xE2])); }
+        else push(static_cast<uint32_t>(d.byte_ids[ch]));
+      } else if (!right_unk) {
+        push(static_cast<uint32_t>(d.unk_id));
+      }
+      right_unk = true;
+    } else {
+      push(bw & kBwIdMask);
+      bound += ceilf(fabsf(d.pscore[bw & kBwIdMask])) + 1.f;
+      right_unk = false;
+    }
+    e -= bl;
+  }
+  if (bf) { first_unk = false; last_unk = false; }     // (no runs under byte fallback)
+  float bmax = 0.f;
+  if (good) {
+    // ulp of a float of magnitude wmag; the exact lead is at least gap - n * ulp (see above; twice the bound needed)
+    const uint32_t we = (wv::float_to_bits(wmag) >> 23) & 0xFFu;
+    const float ulp_w = we > 23u ? wv::bits_to_float((we - 23u) << 23) : 0.f;
+    const float g2 = gap >= 3.0e38f ? gap : gap - 2.f * static_cast<float>(n) * ulp_w;
+    if (!(g2 > 0.f)) good = false;
+    else if (a.unsafe || g2 >= 3.0e38f) bmax = 3.0e38f;
+    else {
+      const float thr = g2 / (4.f * static_cast<float>(n) + 4.f);
+      const int te = static_cast<int>((wv::float_to_bits(thr) >> 23) & 0xFFu) - 127;      // floor(log2 thr)
+      const int k = te + 23;                                  // the largest k with 2^(k - 23) <= thr
+      if (k + 1 > 126) bmax = 3.0e38f;
+      else if (k + 1 < -120) good = false;
+      else {
+        const float lim = wv::bits_to_float(static_cast<uint32_t>(k + 1 + 127) << 23);
+        bmax = (lim - wmag * 1.000001f) * 0.999999f;
+        if (!(bmax > 0.f)) good = false;
+      }
+    }
+  }
+  if (good) {
+    U4 ia{0, 0, 0, 0}, ib{0, 0, 0, 0};
+    uint32_t *o[8] = {&ia.x, &ia.y, &ia.z, &ia.w, &ib.x, &ib.y, &ib.z, &ib.w};
+    for (int k = 0; k < cnt; ++k) *o[k] = ids[cnt - 1 - k];
+    a.dyn_ent[4u * slot + 2u] = ia;
+    a.dyn_ent[4u * slot + 3u] = ib;
+    a.dyn_ent[4u * slot + 1u] = U4{1u, static_cast<uint32_t>(cnt) | (first_unk ? 0x100u : 0u) | (last_unk ? 0x200u : 0u),
+                                  wv::float_to_bits(bound), wv::float_to_bits(bmax)};
+  } else {
+    a.dyn_ent[4u * slot + 1u] = U4{2u, 0u, 0u, 0u};
+  }
+}
+
+// BPE: bpe::Model::SampleEncode(alpha = 0) (src/bpe_model.cc:38-203) of the word: symbols from the char table, then the
+// best adjacent pair again and again -- highest score, then leftmost (:53-56) -- until none is a piece.  Exact.
+SPMX_DEVICE void resolve_bpe_lane(const ResolveArgs &a, uint32_t slot, uint32_t *sym, float *pscore, uint32_t *pmerged, bool active) {
+  const SpmxDev &d = a.dev;
+  if (!active) return;
+  const U4 kk = a.dyn_ent[4u * slot];
+  const uint32_t kw[4] = {kk.x, kk.y, kk.z, kk.w};
+  int n = 1;
+  bool good = true;
+  sym[0] = char_lookup(d, kSpByte, 1u);
+  for (int i = 0; i < 16; ++i) {
+    const uint32_t b = (kw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+    if (b == 0u) break;
+    sym[n << 6] = char_lookup(d, b, 1u);
+    ++n;
+  }
+  for (int i = 0; i < n; ++i) if (sym[i << 6] >= kSsUnknown) good = false;          // a character without a symbol: unk
+  uint32_t alive = n >= 32 ? 0xFFFFFFFFu : (1u << n) - 1u, pmask = 0u;
+  if (good) {
+    for (int i = 0; i + 1 < n; ++i) {
+      uint32_t mg = 0; float sc = 0.f;
+      if (pair_lookup(d, sym[i << 6], sym[(i + 1) << 6], &mg, &sc)) { pmask |= 1u << i; pscore[i << 6] = sc; pmerged[i << 6] = mg; }
+    }
+    for (;;) {
+      int bi = -1;
+      float bs = 0.f;
+      for (uint32_t m = pmask; m != 0u; m &= m - 1u) {
+        const int i = wv::ffs64(static_cast<uint64_t>(m)) - 1;
+        if (bi < 0 || pscore[i << 6] > bs) { bi = i; bs = pscore[i << 6]; }
+      }
+      if (bi < 0) break;
+      const uint32_t above = alive & ~((2u << bi) - 1u);
+      const int j = wv::ffs64(static_cast<uint64_t>(above)) - 1;                    // the right symbol (the pair is live)
+      const uint32_t bm = pmerged[bi << 6];
+      sym[bi << 6] = bm;
+      alive &= ~(1u << j);
+      pmask &= ~((1u << bi) | (1u << j));
+      const uint32_t below = alive & ((1u << bi) - 1u);
+      if (below) {
+        const int q = 31 - (wv::clz64(static_cast<uint64_t>(below)) - 32);
+        pmask &= ~(1u << q);
+        uint32_t mg = 0; float sc = 0.f;
+        if (pair_lookup(d, sym[q << 6], bm, &mg, &sc)) { pmask |= 1u << q; pscore[q << 6] = sc; pmerged[q << 6] = mg; }
+      }
+      const uint32_t after = alive & ~((2u << bi) - 1u);
+      if (after) {
+        const int r = wv::ffs64(static_cast<uint64_t>(after)) - 1;
+        uint32_t mg = 0; float sc = 0.f;
+        if (pair_lookup(d, bm, sym[r << 6], &mg, &sc)) { pmask |= 1u << bi; pscore[bi << 6] = sc; pmerged[bi << 6] = mg; }
+      }
+    }
+  }
+  U4 ia{0, 0, 0, 0}, ib{0, 0, 0, 0};
+  uint32_t *o[8] = {&ia.x, &ia.y, &ia.z, &ia.w, &ib.x, &ib.y, &ib.z, &ib.w};
+  int cnt = 0;
+  for (uint32_t m = alive; good && m != 0u; m &= m - 1u) {
+    const int i = wv::ffs64(static_cast<uint64_t>(m)) - 1;
+    const uint32_t sy = sym[i << 6];
+    uint32_t f = sy;
+    if (sy >= d.n_pieces) {                          // PieceToId (:178): only the extra characters go through sym_final
+      f = d.sym_final[sy];
+      if (f & kSfControl) { good = false; break; }
+      f &= kSfIdMask;
+    }
+    if (static_cast<int32_t>(f) == d.unk_id || cnt >= static_cast<int>(kDynMaxIds)) { good = false; break; }
+    *o[cnt++] = f;
+  }
+  if (good && cnt > 0) {
+    a.dyn_ent[4u * slot + 2u] = ia;
+    a.dyn_ent[4u * slot + 3u] = ib;
+    a.dyn_ent[4u * slot + 1u] = U4{1u, static_cast<uint32_t>(cnt), 0u, wv::float_to_bits(3.0e38f)};
+  } else {
+    a.dyn_ent[4u * slot + 1u] = U4{2u, 0u, 0u, 0u};
+  }
+}
+
+SPMX_DEVICE void word_resolve_block(const ResolveArgs &a, unsigned char *smem) {
+  const int lane = wv::lane();
+  uint32_t count = *a.dyn_count;
+  if (count > a.dyn_cap) count = a.dyn_cap;
+  float *best = reinterpret_cast<float *>(smem) + lane;
+  float *second = reinterpret_cast<float *>(smem + 64u * kResolvePos * 4u) + lane;
+  uint32_t *bp = reinterpret_cast<uint32_t *>(smem + 64u * kResolvePos * 8u) + lane;
+  uint8_t *wb = smem + 64u * kResolvePos * 12u + static_cast<uint32_t>(lane) * 20u;
+  const uint32_t lanes = static_cast<uint32_t>(wv::grid_size()) * 64u;
+  for (uint32_t base = static_cast<uint32_t>(wv::block_id()) * 64u; base < count; base += lanes) {
+    const uint32_t i = base + static_cast<uint32_t>(lane);
+    const bool active = i < count;
+    const uint32_t slot = active ? a.dyn_list[i] : 0u;
+    if (a.dev.model_type == 2) resolve_bpe_lane(a, slot, reinterpret_cast<uint32_t *>(best), second, bp, active);
+    else resolve_unigram_lane(a, slot, best, second, bp, wb, active);
+    wv::sync();
   }
 }
 

@@ -36,7 +36,9 @@ inline uint32_t ScoreRing(int max_piece_len) {
 hipError_t LaunchEncodeStream(int model_type, bool uds, const EncodeArgs &a, int grid, int waves,
                               uint32_t lds_bytes, hipStream_t stream);
 // The word kernel (kernels_word.h): unigram models with kNfUniWordwise
-hipError_t LaunchEncodeWord(bool dp, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t stream);
+// mode: 0 plain first pass, 1 collecting first pass, 2 second round over the call-local memo, 3 the DP pass
+hipError_t LaunchEncodeWord(int mode, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t stream);
+hipError_t LaunchWordResolve(const ResolveArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchBpeLong(const LongArgs &a, int grid, hipStream_t stream);
 // The wave-cooperative unigram form (kernels_uniwave.h): one sentence per 64-thread workgroup; cands = candidate-row entries
 hipError_t LaunchUniLong(const LongArgs &a, uint32_t cands, int grid, hipStream_t stream);

@@ -58,6 +58,8 @@ SPMX_DEVICE uint32_t lds_atomic_add(uint32_t *p, uint32_t v) { return atomicAdd(
 SPMX_DEVICE void atomic_min(unsigned long long *p, unsigned long long v) { atomicMin(p, v); }
 SPMX_DEVICE void atomic_max(unsigned long long *p, unsigned long long v) { atomicMax(p, v); }
 SPMX_DEVICE void atomic_and(uint32_t *p, uint32_t v) { atomicAnd(p, v); }
+// compare-and-swap on a 64-bit word in HBM (the call-local word memo's tags, kernels_word.h): returns the old value
+SPMX_DEVICE unsigned long long atomic_cas(unsigned long long *p, unsigned long long expect, unsigned long long v) { return atomicCAS(p, expect, v); }
 // a load that sees what other workgroups' atomics wrote (tile queue of the streaming kernels)
 SPMX_DEVICE uint32_t atomic_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 

@@ -43,9 +43,15 @@ hipError_t LaunchEncodeStream(int model_type, bool uds, const EncodeArgs &a, int
   }
   return hipSuccess;
 }
-hipError_t LaunchEncodeWord(bool dp, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t) {
-  if (dp) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_word_block<true>(a, s); });
-  else RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_word_block<false>(a, s); });
+hipError_t LaunchEncodeWord(int mode, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t) {
+  if (mode == 3) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_word_block<true, kWmPlain>(a, s); });
+  else if (mode == 2) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_word_block<false, kWmDyn>(a, s); });
+  else if (mode == 1) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_word_block<false, kWmCollect>(a, s); });
+  else RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_word_block<false, kWmPlain>(a, s); });
+  return hipSuccess;
+}
+hipError_t LaunchWordResolve(const ResolveArgs &a, int grid, hipStream_t) {
+  RunGrid(grid, 1, ResolveLdsBytes(), [&](unsigned char *s) { word_resolve_block(a, s); });
   return hipSuccess;
 }
 hipError_t LaunchBpeLong(const LongArgs &a, int grid, hipStream_t) {

@@ -96,6 +96,11 @@ inline uint32_t lds_atomic_add(uint32_t *p, uint32_t v) { const uint32_t o = *p;
 inline void atomic_min(unsigned long long *p, unsigned long long v) { if (v < *p) *p = v; }
 inline void atomic_max(unsigned long long *p, unsigned long long v) { if (v > *p) *p = v; }
 inline void atomic_and(uint32_t *p, uint32_t v) { *p &= v; }
+inline unsigned long long atomic_cas(unsigned long long *p, unsigned long long expect, unsigned long long v) {
+  const unsigned long long o = *p;
+  if (o == expect) *p = v;
+  return o;
+}
 inline uint32_t atomic_load(const uint32_t *p) { return *p; }
 
 inline unsigned long long clock() { return 0; }
