@@ -76,10 +76,8 @@ SPMX_DEVICE unsigned long long DynTag(uint32_t k0, uint32_t k1, uint32_t k2, uin
   const unsigned long long t = (static_cast<unsigned long long>(HashWordKey(k0, k1, k2, k3)) << 32) | HashWord(k0, k1, k2, k3);
   return t | 1ull;                                              // (0 means "free")
 }
-constexpr uint32_t kWordRing = 64;                              // bytes of text a lane holds in LDS: two granules of 32
-constexpr uint32_t kWordRingBytes = kWordRing + 16u;            // ... + a copy of its first 16 bytes behind it (reads wrap)
 SPMX_HD inline uint32_t WordLdsPerWave(bool dp) {
-  return 64u * kWordStage * 4u + 64u * kWordRingBytes + (dp ? 64u * (kWordDpPos * 8u + 20u) : 0u);
+  return 64u * kWordStage * 4u + (dp ? 64u * (kWordDpPos * 8u + 20u) : 0u);
 }
 SPMX_HD inline uint32_t WordLdsBytes(uint32_t waves, bool dp) { return kWordLdsShared + waves * WordLdsPerWave(dp); }
 
@@ -98,7 +96,6 @@ struct WordLds {
   const Q4 *masks;      // [18] key masks (shared)
   const U4 *hot;        // [kWordHotSlots] the likeliest words, umemo16 format (shared)
   int32_t *stage;       // this lane's id staging column: entry k at stage[k << 6]
-  uint8_t *ring;        // this lane's text ring: kWordRingBytes, 16-byte aligned
   float *dp_best;       // (DP) this lane's best_path_score column: position i at dp_best[i << 6]
   uint32_t *dp_bp;      // (DP) back-pointer words  id | length << 24 | unk << 31  (0: not reached)
   uint8_t *dp_bytes;    // (DP) the word in device form: [20] bytes of this lane
@@ -178,34 +175,8 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
   int stall_L = 0;
   bool prev_unk = false;                           // the last piece emitted was unknown (a run of them is ONE id, :609-613)
   const bool bf = (d.flags & kNfByteFallback) != 0;
-  // ---- the text comes through a ring in LDS, 32 bytes (two aligned 16-byte loads of one half cache line) at a time: a
-  // lane asks for every byte of its sentence ONCE.  (Reading the 16 bytes of every word straight from HBM asked for a
-  // line 28 times over 90 us, while the 64 K other lanes of the XCD pushed it out of the L2 again and again: 15 L2
-  // misses per sentence, profiles/r03_pmc_sq_word1.txt.)  Granule g = the g-th aligned 32-byte block from the one that
-  // holds the sentence's first byte; it lives in ring[(g & 1) * 32 ...]; ring[64 .. 80) repeats ring[0 .. 16) so that a
-  // 16-byte read may start anywhere.  At the top of an iteration the granules of p and the one after it are in the ring.
-  uint8_t *ring = T.ring;
-  const uint32_t abs0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(text)) & 31u;
-  const uint8_t *tbase = text - abs0;
-  const int n_gran = active ? static_cast<int>((abs0 + static_cast<uint32_t>(len) + 31u) >> 5) : 0;
-  int gl = 0;                                      // granules loaded so far
-  auto ring_store = [&](int g, const Q4 &lo, const Q4 &hi) __attribute__((always_inline)) {
-    uint8_t *q = ring + ((static_cast<uint32_t>(g) & 1u) << 5);
-    *reinterpret_cast<Q4 *>(q) = lo;
-    *reinterpret_cast<Q4 *>(q + 16) = hi;
-    if ((g & 1) == 0) *reinterpret_cast<Q4 *>(ring + kWordRing) = lo;
-  };
-  if (active) {
-    const Q4 a0 = *reinterpret_cast<const Q4 *>(tbase), a1 = *reinterpret_cast<const Q4 *>(tbase + 16);
-    ring_store(0, a0, a1);
-    gl = 1;
-    if (n_gran > 1) {
-      const Q4 b0 = *reinterpret_cast<const Q4 *>(tbase + 32), b1 = *reinterpret_cast<const Q4 *>(tbase + 48);
-      ring_store(1, b0, b1);
-      gl = 2;
-    }
-  }
   Q4U w{0, 0, 0, 0};
+  if (active) w = *reinterpret_cast<const Q4U *>(text);
   auto put = [&](uint32_t id) __attribute__((always_inline)) {
     stage[(n & 7) << 6] = static_cast<int32_t>(id);
     ++n;
@@ -265,7 +236,6 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
     }
     ++steps;
     const bool run = active && !stalled;
-    if (run) w = *reinterpret_cast<const Q4U *>(ring + ((abs0 + static_cast<uint32_t>(p)) & (kWordRing - 1u)));
     // ---- the word that starts at p: its length = the distance to the next 0x20 (or to the end of the sentence) ----
     const uint32_t z0 = space_bits(w.x), z1 = space_bits(w.y), z2 = space_bits(w.z), z3 = space_bits(w.w);
     const int fa = wv::ffs64(static_cast<uint64_t>(z0) | static_cast<uint64_t>(z1) << 32);
@@ -276,14 +246,8 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
     // ---- where the next word starts; its text is asked for now and used in the next iteration ----
     const int pn = p + L + 1;
     const bool more = run && pn < len;
-    // the next word may have entered a new granule: the one after it is asked for now (it lands after this iteration's
-    // probes, one wait for all of them) and goes into the half of the ring that has just been left
-    Q4 rf0{0, 0, 0, 0}, rf1{0, 0, 0, 0};
-    const bool refill = more && gl < n_gran && gl <= static_cast<int>((abs0 + static_cast<uint32_t>(pn)) >> 5) + 1;
-    if (refill) {
-      rf0 = *reinterpret_cast<const Q4 *>(tbase + 32 * gl);
-      rf1 = *reinterpret_cast<const Q4 *>(tbase + 32 * gl + 16);
-    }
+    Q4U wn = w;
+    if (more) wn = *reinterpret_cast<const Q4U *>(text + pn);
     U4 ent{0, 0, 0, 0xFFFFFFFFu};                    // the entry taken: umemo16 format, or {id0, id1, bound, bmax} of umemo
     bool hit16 = false, hit32 = false;
     uint32_t k0 = 0, k1 = 0, k2 = 0, k3 = 0;
@@ -322,7 +286,7 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
       const bool need = word && !hit16;
       int L2 = L;
       if (need && L == 16 && rem > 16) {             // the 17th byte decides whether the word ends here
-        wx4 = reinterpret_cast<const U1U *>(ring + ((abs0 + static_cast<uint32_t>(p) + 16u) & (kWordRing - 1u)))->x;
+        wx4 = reinterpret_cast<const U1U *>(text + p + 16)->x;
         if ((wx4 & 0xFFu) != 0x20u) lng = true;
       }
       const bool probe = need && !lng;
@@ -454,8 +418,7 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
       }
     }
     if (run && !more && !(DP && stalled)) active = false;     // the sentence is done
-    if (refill) { ring_store(gl, rf0, rf1); ++gl; }
-    if (run) p = pn;
+    if (run) { p = pn; w = wn; }
   }
   *n_steps = steps;
   if (bad) return (MODE == kWmCollect && again) ? -2 : -1;
@@ -477,11 +440,9 @@ SPMX_DEVICE void encode_word_block(const EncodeArgs &a, unsigned char *smem) {
   T.masks = masks;
   T.hot = hot;
   T.stage = reinterpret_cast<int32_t *>(mine_lds) + lane;
-  T.ring = mine_lds + 64u * kWordStage * 4u + static_cast<uint32_t>(lane) * kWordRingBytes;
-  unsigned char *dp_lds = mine_lds + 64u * kWordStage * 4u + 64u * kWordRingBytes;
-  T.dp_best = reinterpret_cast<float *>(dp_lds) + lane;
-  T.dp_bp = reinterpret_cast<uint32_t *>(dp_lds + 64u * kWordDpPos * 4u) + lane;
-  T.dp_bytes = dp_lds + 64u * kWordDpPos * 8u + static_cast<uint32_t>(lane) * 20u;
+  T.dp_best = reinterpret_cast<float *>(mine_lds + 64u * kWordStage * 4u) + lane;
+  T.dp_bp = reinterpret_cast<uint32_t *>(mine_lds + 64u * kWordStage * 4u + 64u * kWordDpPos * 4u) + lane;
+  T.dp_bytes = mine_lds + 64u * kWordStage * 4u + 64u * kWordDpPos * 8u + static_cast<uint32_t>(lane) * 20u;
   {   // shared read-only tables (every wave writes the same values: no workgroup barrier)
     if (lane < 18) {
       const uint32_t L = static_cast<uint32_t>(lane);
@@ -492,6 +453,7 @@ SPMX_DEVICE void encode_word_block(const EncodeArgs &a, unsigned char *smem) {
     wv::sync();
   }
   const int n_extra = d.n_prefix + d.n_suffix;
+  const uint64_t text_end = a.offs[a.n];
   WaveCounters tc;
   for (;;) {
     uint32_t c = 0, first = 0, ucnt = 0, got = 0;
@@ -509,9 +471,10 @@ SPMX_DEVICE void encode_word_block(const EncodeArgs &a, unsigned char *smem) {
       beg = a.offs[sid];
       l64 = a.offs[sid + 1] - beg;
     }
-    // not for this kernel: beyond the int range of the lane's counters
+    // not for this kernel: beyond the int range of the lane's counters, or text that ends within the over-read of the
+    // last sentences of the buffer
     // (a class marked `general` passes through: documents belong to the wave-cooperative form, kernels_uniwave.h)
-    const bool mine = have && !a.cls[c].general && l64 < (1ull << 30);
+    const bool mine = have && !a.cls[c].general && l64 < (1ull << 30) && beg + l64 + 20u <= text_end;
     const int len = mine ? static_cast<int>(l64) : 0;
     // ---- a slot of cap ids in the arena (at most one id per byte of the normalized form: the bytes + 1) ----
     const int cap = mine ? len + 1 : 0;

@@ -683,7 +683,7 @@ void BuildWordMemo(const ModelData &m, HostTables *t) {
     return e.id0 | static_cast<uint32_t>(pw) << 16 | static_cast<uint32_t>(bound_of(e.id0)) << 24;
   };
   {
-    const uint32_t wsz = NextPow2(small.size() * 2 + 16);
+    const uint32_t wsz = NextPow2(small.size() * 6 + 16);     // sparse: a collision costs the whole wave another probe
     t->umemo16.assign(wsz, U4{0, 0, 0, 0xFFFFFFFFu});
     for (const Ent *e : small) {
       const uint32_t h = HashWordKey(e->k[0], e->k[1], e->k[2], 0u);
