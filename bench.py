@@ -137,6 +137,66 @@ def cpu_baseline(text, offs, model_blob, gpu_counts, gpu_ids=None, gpu_id_offset
     return out
 
 
+def probe_exact(text, offs, model_blob, gpu_ids, gpu_id_offsets, k=20000):
+    """ids of a strided sample of the batch, one by one, against the compiled reference (None if it is not built)."""
+    from sentencepiece_amd import synth
+    from tests import refshim
+    if not refshim.available():
+        return None
+    n = len(offs) - 1
+    h = refshim.RefLib().load(model_blob)
+    probe = np.unique(np.linspace(0, n - 1, num=min(n, k)).astype(np.int64))
+    pt, po = synth.gather_packed(text, offs, probe)
+    cids, cio = h.encode_batch(pt, po)
+    io = np.asarray(gpu_id_offsets).astype(np.int64)
+    lens = (io[1:] - io[:-1])[probe]
+    idx = np.repeat(io[:-1][probe] - np.concatenate([[0], np.cumsum(lens)[:-1]]), lens) + np.arange(int(lens.sum()))
+    return bool(np.array_equal(lens, np.diff(np.asarray(cio).astype(np.int64))) and
+                np.array_equal(np.asarray(gpu_ids)[idx], np.asarray(cids)))
+
+
+def side_bench(sp_cls, torch, dev, name, blob, text, offs, steps, warmup, what, probe_k=20000):
+    """A compact record of one more single-GPU configuration: value, kernels, roofline fraction of
+    the dominant kernel, ids of a sample against the compiled reference."""
+    sp = sp_cls(model_proto=blob, device=dev.index or 0)
+    d_text = torch.from_numpy(text).to(dev)
+    d_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+    ids, io, tot = sp.EncodeDevice(d_text, d_offs)
+    ids = torch.empty(int(tot) + 64, dtype=torch.int32, device=dev)
+    for _ in range(warmup):
+        sp.EncodeDevice(d_text, d_offs, ids, io)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sp.EncodeDevice(d_text, d_offs, ids, io)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    sp.SetProfiling(True)
+    sp.EncodeDevice(d_text, d_offs, ids, io)
+    prof = sp.LastProfile()
+    sp.SetProfiling(False)
+    n = len(offs) - 1
+    cls = [c for c in prof["classes"] if c["kernel"]]
+    dom = max(cls, key=lambda c: c["kernel_ms"]) if cls else None
+    out = {"model": name, "what": what, "value": n / dt, "unit": "sentences/s", "ms_per_step": dt * 1e3,
+           "gb_text_per_s": len(text) / dt / 1e9, "sentences": n, "mean_bytes": len(text) / max(n, 1),
+           "ids_per_sentence": float(tot) / max(n, 1),
+           "kernels_ms": {c["kernel"]: round(c["kernel_ms"], 4) for c in cls}}
+    if dom is not None and dom["kernel_ms"] > 0:
+        ach = dom["bytes"] / (dom["kernel_ms"] * 1e-3) / 1e9
+        out["roofline"] = {"kernel": dom["kernel"], "kernel_ms": dom["kernel_ms"], "sentences_per_launch": dom["sentences"],
+                           "algorithmic_bytes_per_launch": dom["bytes"], "achieved": ach, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBS, "traffic": None}
+    try:
+        io_h = io.cpu().numpy()
+        out["probe_ids_bit_exact"] = probe_exact(text, offs, blob, ids[:int(io_h[-1])].cpu().numpy(), io_h, probe_k)
+    except Exception as e:      # the check must not cost the bench line
+        out["probe_ids_bit_exact"] = None
+        out["probe_error"] = repr(e)[:200]
+    del sp, d_text, d_offs, ids, io
+    return out
+
+
 def corpus_for(model, sentences, seed, unsorted):
     from sentencepiece_amd import synth
     if model.startswith("c5_"):
@@ -167,11 +227,14 @@ def main():
                          "c5_250k | c5_250k_bf (configs[4], 250k-piece unigram on the mixed-script power-law corpus)")
     ap.add_argument("--gather", choices=["both", "ids", "none"], default="both",
                     help="N > 1: all-gather the ids over RCCL (the north star), leave it out, or time both (default)")
-    ap.add_argument("--gather-algo", choices=["all_gather", "p2p"], default="all_gather",
-                    help="how the ids travel with --gather ids: the library's all-gather, or world - 1 point-to-point sends per rank "
-                         "posted as one batch (sharding.IdGatherer algo)")
+    ap.add_argument("--gather-algo", choices=["both", "all_gather", "p2p", "p2p_exact"], default="both",
+                    help="how the ids travel: the library's all-gather (every rank padded to the largest capacity), or exact-size "
+                         "point-to-point sends (world - 1 per rank, posted as one batch); default: time BOTH in this run "
+                         "(sharding.IdGatherer algo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-model", action="store_true")
+    ap.add_argument("--no-side-configs", action="store_true",
+                    help="leave the c3 (32k BPE), c5 (250k unigram, mixed script) and document sub-records out of the line")
     ap.add_argument("--unsorted", action="store_true",
                     help="do not length-bucket the synthetic corpus (BASELINE.json's configs are length-bucketed)")
     args = ap.parse_args()
@@ -181,8 +244,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.sentences is None:
         args.sentences = 12_500_000 if world > 1 else 10_000_000
-    gather_modes = ([] if world == 1 else (["ids", "none"] if args.gather == "both" else [args.gather]))
-    if world > 1 and "ids" in gather_modes:
+    algos = ["all_gather", "p2p_exact"] if args.gather_algo == "both" else [args.gather_algo]
+    gather_modes = ([] if world == 1 else ((["ids:" + a for a in algos] + ["none"]) if args.gather == "both"
+                                           else (["ids:" + a for a in algos] if args.gather == "ids" else ["none"])))
+    if world > 1 and any(m.startswith("ids") for m in gather_modes):
         # an all-gather in flight needs CUs of its own: the persistent encode grids would otherwise hold every CU until
         # they end, and the gather of batch k would run after batch k + 1's encode instead of under it
         os.environ.setdefault("SPMX_RESERVE_CUS", "16")
@@ -252,18 +317,21 @@ def main():
         results["n/a"] = timed(encode_step)
     else:
         for mode in gather_modes:
-            if mode == "ids":
-                g = sharding.IdGatherer(dist, dev, wire_dtype=wire, depth=2, algo=args.gather_algo)
+            if mode.startswith("ids:"):
+                g = sharding.IdGatherer(dist, dev, wire_dtype=wire, depth=2, algo=mode[4:])
                 g.reserve(d_ids.numel(), d_io.numel(), torch.int32, d_io.dtype)      # agreed once, before the loop
 
-                def step_ids():
+                def step_ids(g=g):
                     tot = sp.EncodeDevice(d_text, d_offs, d_ids, d_io)[2]
                     g(d_ids, tot, d_io)
                     return tot
-                results["ids"] = timed(step_ids, g.wait)
+                results[mode] = timed(step_ids, g.wait)
+                del g
             else:
                 results["none"] = timed(encode_step)
-    head = "ids" if "ids" in results else ("none" if "none" in results else "n/a")
+    with_ids = [m for m in results if m.startswith("ids:")]
+    # the headline is WITH the gather (the north star): the faster of the algorithms timed in this run
+    head = min(with_ids, key=lambda m: results[m][0]) if with_ids else ("none" if "none" in results else "n/a")
     dt, total = results[head]
     # a second, profiled loop for the per-kernel numbers (HIP events around every encode launch)
     sp.SetProfiling(True)
@@ -321,7 +389,7 @@ def main():
                        "model": args.model, "sentences_per_gpu": n, "ids_per_sentence": job_ids / (world * n),
                        "gather": ("%s (%s on the wire, capacities agreed once, 2 gathers in flight, %s CUs left to RCCL)"
                                   % (head, "int16" if wire is not None else "int32", os.environ.get("SPMX_RESERVE_CUS", "0"))
-                                  if head == "ids" else head) if world > 1 else "n/a",
+                                  if head.startswith("ids") else head) if world > 1 else "n/a",
                        "sharding": "dp%d by sentence" % world,
                        "timed_loop": "profiling off; roofline.* comes from a second loop of the same steps with HIP events on"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -337,8 +405,9 @@ def main():
         }
         if world > 1:
             for mode, (mdt, _) in results.items():
-                out["value_gather_%s" % mode] = world * n * args.steps / mdt
-                out["ms_per_step_gather_%s" % mode] = mdt / args.steps * 1e3
+                key = mode.replace("ids:", "")
+                out["value_gather_%s" % key] = world * n * args.steps / mdt
+                out["ms_per_step_gather_%s" % key] = mdt / args.steps * 1e3
         io_h = None
         if second is not None:
             name, t2, o2 = second
@@ -360,10 +429,39 @@ def main():
             p2 = sp2.LastProfile()
             out["long_piece_model"] = {"model": name, "value": (len(o2) - 1) * args.steps / d2, "unit": "sentences/s",
                                        "ms_per_step": d2 / args.steps * 1e3, "mean_bytes": len(t2) / (len(o2) - 1),
-                                       "kernel": p2["classes"][0]["kernel"], "kernel_ms": p2["classes"][0]["kernel_ms"],
+                                       "kernel": max(p2["classes"], key=lambda c: c["kernel_ms"])["kernel"],
+                                       "kernel_ms": max(c["kernel_ms"] for c in p2["classes"]),
+                                       "kernels_ms": {c["kernel"]: round(c["kernel_ms"], 4) for c in p2["classes"] if c["kernel"]},
                                        "vs_headline": ((len(o2) - 1) * args.steps / d2) / out["value"],
                                        "what": "the C2 recipe with words of up to 16 letters: longest piece 17 bytes, score ring of 18 entries"}
             del sp2, dt2_text, dt2_offs, i2, io2
+        if world == 1 and args.model == "uni32k" and not args.no_side_configs:
+            # the other single-GPU configurations of BASELINE.json, compact: c3 (the same corpus through the 32k BPE
+            # model), c5 (250k-piece unigram, mixed script, 1 M sentences), documents (8192 x 16 KB, 256 x 1 MiB)
+            try:
+                out["c3"] = side_bench(SentencePieceProcessor, torch, dev, "bpe32k", model_blob("bpe32k"), text, offs,
+                                       args.steps, args.warmup, "configs[2]: 32k BPE, the same %d sentences" % n)
+            except Exception as e:
+                out["c3"] = {"failed": repr(e)[:300]}
+            try:
+                t5, o5 = corpus_for("c5_250k", 1_000_000, 20250227, False)
+                out["c5"] = side_bench(SentencePieceProcessor, torch, dev, "c5_250k", model_blob("c5_250k"), t5, o5,
+                                       args.steps, args.warmup,
+                                       "configs[4]: 250k-piece unigram, 1 M mixed-script sentences, power-law [16, 4096] characters")
+                del t5, o5
+            except Exception as e:
+                out["c5"] = {"failed": repr(e)[:300]}
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "scripts"))
+                import docs_rate
+                for key, nd, nb in (("docs_16k", 8192, 16384), ("docs_1m", 256, 1 << 20)):
+                    td, od = docs_rate.make_docs(nd, nb)
+                    out[key] = side_bench(SentencePieceProcessor, torch, dev, "uni32k", blob, td, od, max(1, args.steps // 2), 1,
+                                          "%d documents of ~%d bytes (C2 sentences joined by spaces), uni32k" % (nd, nb), probe_k=4)
+                    out[key]["mb_per_s"] = len(td) / 1e6 / (out[key]["ms_per_step"] * 1e-3)
+                    del td, od
+            except Exception as e:
+                out["docs"] = {"failed": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             io_h = d_io.cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(text, offs, blob, np.diff(io_h), d_ids[:int(io_h[-1])].cpu().numpy(), io_h)

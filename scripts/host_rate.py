@@ -65,6 +65,13 @@ def main():
     strs = [tb[int(offs[i]):int(offs[i + 1])].decode("utf-8", "replace") for i in range(m)]
     dt, _ = timed(lambda: sp.encode(strs), reps=3)
     out["python_list"] = {"sentences": m, "ms": dt * 1e3, "sentences_per_s": m / dt}
+    dt, _ = timed(lambda: sp.EncodeAsArrays(strs), reps=3)
+    out["python_arrays"] = {"sentences": m, "ms": dt * 1e3, "sentences_per_s": m / dt,
+                            "what": "sp.EncodeAsArrays(list[str]) -> (ids, id_offsets) numpy arrays"}
+    t0 = time.perf_counter()
+    for k in range(200):
+        sp.encode(strs[(k * 7919) % m])
+    out["python_single_encode_us"] = (time.perf_counter() - t0) / 200 * 1e6
 
     # the C++ facade and the file tool, on the corpus as a file
     with tempfile.TemporaryDirectory() as td:

@@ -34,6 +34,7 @@
 #include <thread>
 #include <new>
 #include <sstream>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -239,6 +240,7 @@ struct spmx_handle {
   uint64_t arena_first = 0;      // SPMX_ARENA_FIRST: cap on the first attempt's id arena (tests: the overflow-and-retry path)
   bool no_bp_short = false;      // SPMX_NO_BP_SHORT=1: 32-bit back-pointer entries for every unigram model
   bool no_wave = false;          // SPMX_NO_WAVE=1: BPE models that are not word-wise use the long form only
+  std::atomic<int> word_backoff{0};   // calls that leave the word rounds out (they did not pay on the last batch that tried)
   bool no_word = false;          // SPMX_NO_WORD_KERNEL=1: unigram models skip the word kernels (kernels_word.h)
   bool no_word_dp = false;       // SPMX_NO_WORD_DP=1: ... skip the second pass only
   bool no_word_dyn = false;      // SPMX_NO_WORD_DYN=1: no call-local word memo (one word round, then the DP pass)
@@ -560,8 +562,15 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
   // kernels, the long list, two retry lists
   // the word kernel (kernels_word.h): unigram models whose pieces never reach across a word boundary; not for the spans
   // form (it records no token begins) nor under the `reverse` option
-  const bool word_ok = (h->dev.flags & kNfUniWordwise) && !(h->dev.flags & kNfReverse) && !spans && !h->no_word &&
-                       !(h->model.model_type == kBpe && (ws->bpe_dropout > 0.f || h->no_stream));
+  bool word_ok = (h->dev.flags & kNfUniWordwise) && !(h->dev.flags & kNfReverse) && !spans && !h->no_word &&
+                 !(h->model.model_type == kBpe && (ws->bpe_dropout > 0.f || h->no_stream));
+  // The word kernels pay on text that is mostly plain ASCII words.  On other text (CJK, byte soup) their rounds only
+  // cost: a handle remembers when a batch went almost entirely to the general kernels and leaves the word rounds out
+  // of its next few calls, then tries again (results are the same either way).
+  if (word_ok && !h->force_word_dp && h->word_backoff.load(std::memory_order_relaxed) > 0) {
+    h->word_backoff.fetch_sub(1, std::memory_order_relaxed);
+    word_ok = false;
+  }
   HIP_OR_RETURN(h, ws->d_lists.Reserve(static_cast<size_t>(2 * kMaxClasses + 3 + (word_ok ? 2 * kMaxClasses : 0)) * n));
   HIP_OR_RETURN(h, ws->d_counts.Reserve(n + 1));
   HIP_OR_RETURN(h, ws->d_tmp_off.Reserve(n + 1));
@@ -757,7 +766,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
           if (tw > 64) tw = 64;
           if (tw < 1) tw = 1;
           sc.lane_shift = 6;
-          sc.general = cls[c].rcap > kMaxStagedRaw ? 1u : 0u;   // documents pass through to the wave-cooperative form
+          sc.general = cls[c].rcap > h->main_max_raw ? 1u : 0u;   // documents pass through to the wave-cooperative form
           sc.count = known[c];
           sc.tw = static_cast<uint32_t>(tw);
           sc.main_tiles = static_cast<uint32_t>((static_cast<uint64_t>(known[c]) + tw - 1) / tw);
@@ -834,6 +843,12 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         }
       }
     }
+    if (word_ok && n >= 4096) {          // (see word_ok above)
+      uint64_t leftover = 0;
+      uint64_t eligible = 0;
+      for (int c = 0; c < ncls; ++c) if (cls[c].rcap <= h->main_max_raw) { leftover += known[c]; eligible += ws->h_ctrl->list_counts[c]; }
+      if (eligible >= 4096 && leftover * 8 > eligible * 7) h->word_backoff.store(15, std::memory_order_relaxed);
+    }
     if (streaming) {
       // unigram: the wave-cooperative form (a sentence per wavefront, kernels_uniwave.h) takes the classes where the
       // lane-per-sentence kernels are the wrong tool -- documents (one lane would walk them alone: 2.5 us per byte),
@@ -843,7 +858,8 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       if (uni_wave) {
         for (int c = 0; c < ncls; ++c) {
           if (known[c] == 0) continue;
-          if (cls[c].rcap <= kMaxStagedRaw && known[c] >= h->uni_wave_max) continue;
+          // (documents: classes beyond the main streaming launch's, 16 KiB; a thinner class only if SPMX_UNI_WAVE_MAX says so)
+          if (cls[c].rcap <= h->main_max_raw && known[c] >= h->uni_wave_max) continue;
           if (int rc = long_launch(a.lists + static_cast<size_t>(c) * n, &d_list_counts[c], known[c], true); rc != kOk) return rc;
           known[c] = 0;
         }

@@ -1,0 +1,89 @@
+/* _spmx_py -- the two host-side loops of the Python wrapper that do not belong in Python: turning list[str] into the
+ * (pointer, length) views spmx_encode_batch_views takes (no packed copy: a str's UTF-8 form is read where CPython
+ * keeps it), and turning the CSR that comes back into list[list[int]] -- what the reference's SWIG layer does in C++
+ * (python/src/sentencepiece/sentencepiece.i:439-446, the std::vector<std::vector<int>> typemap).  The GIL is released
+ * around the device call.  The library is reached through function pointers handed over by the ctypes binding
+ * (sentencepiece_amd/_capi.py), so this module has no link-time dependency on libspmx.so. */
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+typedef struct { const char *data; uint64_t len; } view_t;
+typedef int (*views_fn)(void *h, const view_t *views, uint64_t n, int32_t **ids, uint64_t **id_offsets, uint8_t **status,
+                        uint64_t *n_failed);
+typedef void (*free_fn)(void *p);
+
+/* encode_views(fn_addr, handle_addr, seq) -> (ids_addr, offsets_addr, n, total).  seq: list / tuple of str or bytes.
+ * The two arrays belong to the library (spmx_free). */
+static PyObject *encode_views(PyObject *self, PyObject *args) {
+  unsigned long long fn_addr = 0, h_addr = 0;
+  PyObject *seq = NULL;
+  if (!PyArg_ParseTuple(args, "KKO", &fn_addr, &h_addr, &seq)) return NULL;
+  PyObject *fast = PySequence_Fast(seq, "a list of str / bytes is expected");
+  if (!fast) return NULL;
+  const Py_ssize_t n = PySequence_Fast_GET_SIZE(fast);
+  view_t *views = (view_t *)malloc((size_t)(n > 0 ? n : 1) * sizeof(view_t));
+  if (!views) { Py_DECREF(fast); return PyErr_NoMemory(); }
+  PyObject **items = PySequence_Fast_ITEMS(fast);
+  for (Py_ssize_t i = 0; i < n; ++i) {
+    PyObject *o = items[i];
+    Py_ssize_t len = 0;
+    const char *p = NULL;
+    if (PyUnicode_Check(o)) {
+      p = PyUnicode_AsUTF8AndSize(o, &len);          /* cached in the object; an ASCII str is not even copied */
+      if (!p) { free(views); Py_DECREF(fast); return NULL; }
+    } else if (PyBytes_Check(o)) {
+      char *q = NULL;
+      if (PyBytes_AsStringAndSize(o, &q, &len) < 0) { free(views); Py_DECREF(fast); return NULL; }
+      p = q;
+    } else {
+      free(views); Py_DECREF(fast);
+      PyErr_SetString(PyExc_TypeError, "sentences must be str or bytes");
+      return NULL;
+    }
+    views[i].data = p;
+    views[i].len = (uint64_t)len;
+  }
+  int32_t *ids = NULL;
+  uint64_t *offs = NULL;
+  int rc;
+  Py_BEGIN_ALLOW_THREADS
+  rc = ((views_fn)(uintptr_t)fn_addr)((void *)(uintptr_t)h_addr, views, (uint64_t)n, &ids, &offs, NULL, NULL);
+  Py_END_ALLOW_THREADS
+  free(views);
+  Py_DECREF(fast);
+  if (rc != 0) return Py_BuildValue("(KKni)", 0ULL, 0ULL, (Py_ssize_t)0, rc);
+  return Py_BuildValue("(KKnK)", (unsigned long long)(uintptr_t)ids, (unsigned long long)(uintptr_t)offs, n,
+                       (unsigned long long)(offs ? offs[n] : 0));
+}
+
+/* csr_to_lists(ids_addr, offsets_addr, n) -> list[list[int]] */
+static PyObject *csr_to_lists(PyObject *self, PyObject *args) {
+  unsigned long long ids_addr = 0, offs_addr = 0;
+  Py_ssize_t n = 0;
+  if (!PyArg_ParseTuple(args, "KKn", &ids_addr, &offs_addr, &n)) return NULL;
+  const int32_t *ids = (const int32_t *)(uintptr_t)ids_addr;
+  const uint64_t *offs = (const uint64_t *)(uintptr_t)offs_addr;
+  PyObject *outer = PyList_New(n);
+  if (!outer) return NULL;
+  for (Py_ssize_t i = 0; i < n; ++i) {
+    const uint64_t b = offs[i], e = offs[i + 1];
+    PyObject *inner = PyList_New((Py_ssize_t)(e - b));
+    if (!inner) { Py_DECREF(outer); return NULL; }
+    for (uint64_t k = b; k < e; ++k) {
+      PyObject *v = PyLong_FromLong((long)ids[k]);
+      if (!v) { Py_DECREF(inner); Py_DECREF(outer); return NULL; }
+      PyList_SET_ITEM(inner, (Py_ssize_t)(k - b), v);
+    }
+    PyList_SET_ITEM(outer, i, inner);
+  }
+  return outer;
+}
+
+static PyMethodDef methods[] = {
+    {"encode_views", encode_views, METH_VARARGS, "list[str|bytes] -> CSR held by the library (GIL released around the device call)"},
+    {"csr_to_lists", csr_to_lists, METH_VARARGS, "CSR -> list[list[int]]"},
+    {NULL, NULL, 0, NULL}};
+static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_spmx_py", "host-side loops of the Python wrapper", -1, methods};
+PyMODINIT_FUNC PyInit__spmx_py(void) { return PyModule_Create(&moddef); }

@@ -18,6 +18,20 @@ import numpy as np
 
 from . import _capi
 
+_PYEXT = [False, None]
+
+
+def _pyext():
+    """csrc/pyext.c (built by csrc/Makefile next to libspmx.so), or None."""
+    if _PYEXT[0] is False:
+        try:
+            from . import _spmx_py
+            _PYEXT[1] = _spmx_py
+        except ImportError:
+            _PYEXT[1] = None
+        _PYEXT[0] = True
+    return _PYEXT[1]
+
 _OK = 0
 _RESOURCE_EXHAUSTED = 8
 
@@ -257,15 +271,49 @@ class SentencePieceProcessor:
                     self._reverse if reverse is None else reverse)
         single = not isinstance(input, list)
         items = [input] if single else input
+        out = self._encode_items(items, as_lists=True)
+        return out[0] if single else out
+
+    def _encode_items(self, items, as_lists):
+        """list[str | bytes] -> list[list[int]] (``as_lists``) or the CSR ``(ids int32[total], id_offsets uint64[n + 1])``.
+        The str -> (pointer, length) views and the CSR -> lists loops run in C (csrc/pyext.c, the GIL released around the
+        device call) -- the loops the reference's SWIG layer has in C++ (sentencepiece.i:439-446); without the extension
+        module (not built) the same is done in Python."""
+        ext = _pyext()
+        if ext is not None and all(isinstance(s, (str, bytes)) for s in items[:1]):
+            fn = C.cast(self._lib.spmx_encode_batch_views, C.c_void_p).value
+            h = self._h.value if isinstance(self._h, C.c_void_p) else int(self._h)
+            p_ids, p_off, n, total = ext.encode_views(fn, h, items)
+            if p_ids == 0 and p_off == 0 and n == 0 and len(items):
+                self._check(int(total))
+            try:
+                if as_lists:
+                    return ext.csr_to_lists(p_ids, p_off, n)
+                io = np.ctypeslib.as_array(C.cast(p_off, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+                ids = (np.ctypeslib.as_array(C.cast(p_ids, C.POINTER(C.c_int32)), shape=(int(total),)).copy()
+                       if total else np.zeros(0, dtype=np.int32))
+                return ids, io
+            finally:
+                self._lib.spmx_free(p_ids)
+                self._lib.spmx_free(p_off)
         bs = [s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in items]
         offs = np.zeros(len(bs) + 1, dtype=np.uint64)
         if bs:
             np.cumsum([len(b) for b in bs], out=offs[1:])
         text = np.frombuffer(b"".join(bs), dtype=np.uint8)
         ids, io = self._encode_host(text, offs)
+        if not as_lists:
+            return ids, io
         io = io.astype(np.int64)
-        out = [ids[io[i]:io[i + 1]].tolist() for i in range(len(bs))]
-        return out[0] if single else out
+        return [ids[io[i]:io[i + 1]].tolist() for i in range(len(bs))]
+
+    def EncodeAsArrays(self, input, add_bos=False, add_eos=False, reverse=False):
+        """list[str] -> ``(ids int32[total], id_offsets uint64[n + 1])``: the batch as ONE flat array pair instead of n
+        Python lists of Python ints (which cost more host time than the whole device path: ~25 ns per int object).
+        Sentence i is ``ids[id_offsets[i]:id_offsets[i + 1]]``."""
+        self._need()
+        self._apply(add_bos, add_eos, reverse)
+        return self._encode_items(list(input), as_lists=False)
 
     encode = Encode
 

@@ -62,6 +62,13 @@ class IdGatherer:
         self.dist, self.device, self.group = dist, device, group
         self.wire = wire_dtype
         self.algo = algo
+        # "p2p_exact": every rank sends exactly its `total` ids (and its per-sentence id COUNTS as int32, not n + 1
+        # 64-bit offsets) straight to every peer -- no padding to the largest rank's capacity.  The receivers must know the
+        # sizes before they post their receives: two integers per rank, exchanged host-side over a gloo group of its
+        # own (the host knows its own total: EncodeDevice returns it), which does not queue behind the gathers in flight.
+        self._cpu_group = None
+        if algo == "p2p_exact" and dist.get_backend(group) != "gloo":
+            self._cpu_group = dist.new_group(backend="gloo")        # collective: every rank constructs its gatherer
         self._dtype = None
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -92,6 +99,8 @@ class IdGatherer:
 
     def reserve(self, ids_capacity, offsets_capacity=0, ids_dtype=torch.int32, offsets_dtype=torch.int64):
         """Collective.  Agrees the padded per-rank sizes (MAX over the ranks) and allocates the slots."""
+        if self.algo == "p2p_exact":
+            return                       # (exact sizes travel with every batch: nothing to agree up front)
         self.wait()
         t = torch.tensor([int(ids_capacity), int(offsets_capacity)], dtype=torch.int64, device=self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
@@ -113,8 +122,62 @@ class IdGatherer:
                 sl["oout"] = torch.empty(self.world * self._ocap, dtype=offsets_dtype, device=self.device)
             self._slots.append(sl)
 
+    def _call_exact(self, ids, total, id_offsets):
+        dist, world, rank = self.dist, self.world, self.rank
+        n = id_offsets.numel() - 1 if id_offsets is not None else 0
+        meta = torch.tensor([total, n], dtype=torch.int64)
+        metas = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(metas, meta, group=self._cpu_group if self._cpu_group is not None else self.group)
+        tots = [int(m[0]) for m in metas]
+        ns = [int(m[1]) for m in metas]
+        wire = self.wire or ids.dtype
+        self._dtype = ids.dtype
+        if not self._slots or len(self._slots) != self.depth or "xout" not in self._slots[0]:
+            self._slots = [dict(work=[], xout=None, xcnt=None, xsend=None, xcsend=None) for _ in range(self.depth)]
+        sl = self._slots[self._k % self.depth]
+        for w in sl["work"]:
+            w.wait()
+        sum_t, sum_n = sum(tots), sum(ns)
+        if sl["xout"] is None or sl["xout"].numel() < sum_t or sl["xout"].dtype != wire:
+            sl["xout"] = torch.empty(max(sum_t + sum_t // 8, 1), dtype=wire, device=self.device)
+        if sl["xsend"] is None or sl["xsend"].numel() < total or sl["xsend"].dtype != wire:
+            sl["xsend"] = torch.empty(max(total + total // 8, 1), dtype=wire, device=self.device)
+        sl["xsend"][:total].copy_(ids[:total])
+        t_base = np.concatenate([[0], np.cumsum(tots)]).astype(np.int64)
+        n_base = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+        send = sl["xsend"][:total]
+        sl["xout"][int(t_base[rank]):int(t_base[rank + 1])].copy_(send)
+        csend = None
+        if id_offsets is not None:
+            if sl["xcnt"] is None or sl["xcnt"].numel() < sum_n:
+                sl["xcnt"] = torch.empty(max(sum_n + sum_n // 8, 1), dtype=torch.int32, device=self.device)
+            csend = (id_offsets[1:] - id_offsets[:-1]).to(torch.int32)
+            sl["xcsend"] = csend
+            sl["xcnt"][int(n_base[rank]):int(n_base[rank + 1])].copy_(csend)
+
+        def as_bytes(t):
+            return t.view(torch.uint8) if t.dtype == torch.int16 else t
+        ops = []
+        for k in range(1, world):
+            to, frm = (rank + k) % world, (rank - k) % world
+            if total:
+                ops.append(dist.P2POp(dist.isend, as_bytes(send), self._peer(to), self.group))
+            if tots[frm]:
+                ops.append(dist.P2POp(dist.irecv, as_bytes(sl["xout"][int(t_base[frm]):int(t_base[frm + 1])]), self._peer(frm), self.group))
+            if csend is not None:
+                if n:
+                    ops.append(dist.P2POp(dist.isend, csend, self._peer(to), self.group))
+                if ns[frm]:
+                    ops.append(dist.P2POp(dist.irecv, sl["xcnt"][int(n_base[frm]):int(n_base[frm + 1])], self._peer(frm), self.group))
+        sl["work"] = [_Works(dist.batch_isend_irecv(ops))] if ops else []
+        sl["exact"] = (tots, ns, t_base, n_base, id_offsets is not None, id_offsets.dtype if id_offsets is not None else None)
+        self._last = sl
+        self._k += 1
+
     def __call__(self, ids, total, id_offsets=None):
         total = int(total)
+        if self.algo == "p2p_exact" and self.world > 1:
+            return self._call_exact(ids, total, id_offsets)
         need_o = id_offsets.numel() if id_offsets is not None else 0
         if not self._slots or total > self._cap or need_o > self._ocap:
             # first use (or a caller that grew its buffers without reserve()): agree now -- collective, so every rank
@@ -149,6 +212,16 @@ class IdGatherer:
         for w in sl["work"]:
             w.wait()
         sl["work"] = []
+        if "exact" in sl and sl.get("exact") is not None and self.algo == "p2p_exact" and self.world > 1:
+            tots, ns, t_base, n_base, has_offs, odt = sl["exact"]
+            ids = [sl["xout"][int(t_base[r]):int(t_base[r + 1])].to(self._dtype) for r in range(self.world)]
+            offs = None
+            if has_offs:
+                offs = []
+                for r in range(self.world):
+                    c = sl["xcnt"][int(n_base[r]):int(n_base[r + 1])].to(odt)
+                    offs.append(torch.cat([torch.zeros(1, dtype=odt, device=c.device), torch.cumsum(c, 0)]))
+            return ids, offs
         tot = sl["tot"].cpu().tolist()
         ids = [sl["out"][r * self._cap: r * self._cap + tot[r]].to(self._dtype) for r in range(self.world)]
         offs = None

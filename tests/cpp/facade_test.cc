@@ -74,6 +74,19 @@ int main(int argc, char **argv) {
   std::vector<std::string_view> views(lines.begin(), lines.end());
   std::vector<std::vector<int>> batch;
   if (!sp.EncodeBatch(views, &batch).ok() || batch.size() != lines.size()) { fprintf(stderr, "EncodeBatch failed\n"); return 1; }
+  {   // the zero-copy forms hold the same ids
+    sentencepiece::EncodedBatch eb;
+    if (!sp.EncodeBatch(views, &eb).ok() || eb.size() != lines.size()) { fprintf(stderr, "EncodeBatch(EncodedBatch) failed\n"); return 1; }
+    for (size_t i = 0; i < lines.size(); ++i)
+      if (std::vector<int>(eb.begin(i), eb.end(i)) != batch[i]) { fprintf(stderr, "EncodedBatch differs at line %zu\n", i); return 1; }
+    std::string packed;
+    std::vector<uint64_t> po(1, 0);
+    for (const std::string &l : lines) { packed += l; po.push_back(packed.size()); }
+    sentencepiece::EncodedBatch fb;
+    if (!sp.EncodeBatchFlat(packed.data(), po.data(), lines.size(), &fb).ok() || fb.total_ids() != eb.total_ids()) { fprintf(stderr, "EncodeBatchFlat(EncodedBatch) failed\n"); return 1; }
+    sentencepiece::EncodedBatch moved(std::move(fb));
+    if (moved.size() != lines.size() || fb.size() != 0) { fprintf(stderr, "EncodedBatch move\n"); return 1; }
+  }
   for (size_t i = 0; i < lines.size(); ++i) {
     if (i < 40) {   // batch == per-sentence Encode (python/test/sentencepiece_test.py:745-760)
       std::vector<int> one;

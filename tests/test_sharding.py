@@ -55,14 +55,31 @@ def _worker(rank, world, port, model, corpus_name, n_sent, out_dir):
                 assert got[r].tolist() == [100 * r + i for i in range(kk)] and got[r].dtype == torch.int32
                 assert goffs[r].tolist() == [0, kk]
         g.wait()
+        # exact sizes point to point: every rank sends its `total` ids and its per-sentence counts (int32) to every
+        # peer, nothing is padded to the largest rank; sentences per rank differ too, and one rank sends nothing
+        gx = sharding.IdGatherer(dist, torch.device("cpu"), wire_dtype=torch.int16, depth=2, algo="p2p_exact")
+        for step in range(3):
+            k = sizes(rank, step)
+            nsent = 0 if k == 0 else 1 + (rank + step) % 3
+            cuts = np.linspace(0, k, nsent + 1).astype(np.int64)
+            part = torch.arange(k, dtype=torch.int32) + 100 * rank
+            gx(part, k, torch.from_numpy(cuts))
+            got, goffs = gx.result()
+            for r in range(world):
+                kk = sizes(r, step)
+                ns = 0 if kk == 0 else 1 + (r + step) % 3
+                assert got[r].tolist() == [100 * r + i for i in range(kk)] and got[r].dtype == torch.int32
+                assert goffs[r].tolist() == np.linspace(0, kk, ns + 1).astype(np.int64).tolist()
+        gx.wait()
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("model,corpus,n,world", [("test_model", "botchan", 700, 2), ("bpe1k", "edge", 66, 2),
-                                                   ("test_model", "botchan", 301, 4), ("bpe1k", "edge", 3, 4)])
+                                                   ("test_model", "botchan", 301, 4), ("bpe1k", "edge", 3, 4),
+                                                   ("test_model", "botchan", 500, 8)])
 def test_gloo_ranks(model, corpus, n, world, tmp_path, oracle, corpora):
-    """world 2 and 4; uneven shards (301 sentences over 4 ranks by bytes) and empty ones (3 sentences over 4 ranks)."""
+    """world 2, 4 and 8; uneven shards (301 sentences over 4 ranks by bytes) and empty ones (3 sentences over 4 ranks)."""
     mp.spawn(_worker, args=(world, _free_port(), model, corpus, n, str(tmp_path)), nprocs=world, join=True)
     text, offs = fixtures.head(*corpora[corpus], n)
     ids, io = oracle.load(fixtures.model_blob(model)).encode_batch(text, offs)

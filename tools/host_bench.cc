@@ -44,6 +44,31 @@ int main(int argc, char **argv) {
     if (it > 0 && ms < flat_ms) flat_ms = ms;
     total = ids.size();
   }
+  // the zero-copy forms: the library's own CSR arrays in an EncodedBatch
+  double own_ms = 1e30, own_views_ms = 1e30, single_us = 1e30;
+  for (int it = 0; it < 4; ++it) {
+    sentencepiece_amd::EncodedBatch eb;
+    const auto t0 = now();
+    if (!sp.EncodeBatchFlat(packed.data(), offs.data(), n, &eb).ok()) return 1;
+    const double ms = std::chrono::duration<double, std::milli>(now() - t0).count();
+    if (it > 0 && ms < own_ms) own_ms = ms;
+    if (eb.total_ids() != total) return 1;
+  }
+  for (int it = 0; it < 3; ++it) {
+    sentencepiece_amd::EncodedBatch eb;
+    const auto t0 = now();
+    if (!sp.EncodeBatch(views, &eb).ok()) return 1;
+    const double ms = std::chrono::duration<double, std::milli>(now() - t0).count();
+    if (it > 0 && ms < own_views_ms) own_views_ms = ms;
+  }
+  {   // one sentence per call: Encode(input, &ids) -- the latency of a whole call (H2D, classify, launches, D2H) for one sentence
+    std::vector<int> one;
+    for (int it = 0; it < 5; ++it) (void)sp.Encode(views[it % n], &one);
+    const int reps = 200;
+    const auto t0 = now();
+    for (int it = 0; it < reps; ++it) (void)sp.Encode(views[(it * 7919) % n], &one);
+    single_us = std::chrono::duration<double, std::micro>(now() - t0).count() / reps;
+  }
   size_t total2 = 0;
   for (int it = 0; it < 3; ++it) {
     std::vector<std::vector<int>> outs;
@@ -55,7 +80,9 @@ int main(int argc, char **argv) {
     for (const auto &v : outs) total2 += v.size();
   }
   printf("{\"sentences\": %zu, \"ids\": %zu, \"ids_nested\": %zu, \"flat_ms\": %.2f, \"flat_sentences_per_s\": %.0f, "
-         "\"nested_ms\": %.2f, \"nested_sentences_per_s\": %.0f}\n",
-         n, total, total2, flat_ms, n / flat_ms * 1e3, nested_ms, n / nested_ms * 1e3);
+         "\"nested_ms\": %.2f, \"nested_sentences_per_s\": %.0f, \"flat_owned_ms\": %.2f, \"flat_owned_sentences_per_s\": %.0f, "
+         "\"views_owned_ms\": %.2f, \"views_owned_sentences_per_s\": %.0f, \"single_encode_us\": %.1f}\n",
+         n, total, total2, flat_ms, n / flat_ms * 1e3, nested_ms, n / nested_ms * 1e3, own_ms, n / own_ms * 1e3, own_views_ms,
+         n / own_views_ms * 1e3, single_us);
   return 0;
 }
