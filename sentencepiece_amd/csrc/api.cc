@@ -28,6 +28,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -63,8 +64,8 @@ struct Ctrl {
   uint32_t status;
   uint32_t retry_count[2];            // long form: sentences that found the pool exhausted (ping-pong)
   uint32_t pad;
-  StreamQueue q[5];                   // tile queues of the main / document / overflow launches; [3], [4]: the word kernels
-  uint32_t left_counts[2][kMaxClasses];   // word kernels: sentences the first / second pass left to the next one, per class
+  StreamQueue q[6];                   // tile queues of the main / document / overflow launches; [3], [4]: the word kernels; [5]: the tail launch
+  uint32_t left_counts[3][kMaxClasses];   // word kernels: second-round input / general input / what the second round left, per class
   uint32_t dyn_count;                     // ... words entered into the call-local memo (must follow left_counts: read together)
   uint32_t align_counts[kMaxClasses]; // spans form: escalation lists of the staged align kernels
   SideLists side;
@@ -186,6 +187,8 @@ struct Workspace {
   float bpe_dropout = 0.f;      // set around a call by spmx_sample_encode_batch: BPE-dropout through the long form
   uint64_t sample_seed = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;          // the general launches run here while the second word round runs on the call's stream
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev[kNumSlots + 1][2] = {};   // per kernel slot + the whole call
   bool ev_ready = false;
   bool slot_used[kNumSlots] = {false};
@@ -201,6 +204,9 @@ struct Workspace {
     if (d_ctrl) (void)hipFree(d_ctrl);
     if (h_ctrl) (void)hipHostFree(h_ctrl);
     if (stream) (void)hipStreamDestroy(stream);
+    if (stream2) (void)hipStreamDestroy(stream2);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
     if (ev_ready) for (auto &pair : ev) { (void)hipEventDestroy(pair[0]); (void)hipEventDestroy(pair[1]); }
   }
 };
@@ -243,6 +249,7 @@ struct spmx_handle {
   std::atomic<int> word_backoff{0};   // calls that leave the word rounds out (they did not pay on the last batch that tried)
   bool no_word = false;          // SPMX_NO_WORD_KERNEL=1: unigram models skip the word kernels (kernels_word.h)
   bool no_word_dp = false;       // SPMX_NO_WORD_DP=1: ... skip the second pass only
+  bool no_overlap = false;       // SPMX_NO_OVERLAP=1: the general launches do not run next to the second word round
   bool no_word_dyn = false;      // SPMX_NO_WORD_DYN=1: no call-local word memo (one word round, then the DP pass)
   bool memo_unsafe = false;      // SPMX_WORDMEMO_UNSAFE=1: TEST SEAM, the call-local memo takes no margin either
   bool force_word_dp = false;    // SPMX_FORCE_WORD_DP=1: the second pass runs whatever the first one left (tests)
@@ -296,6 +303,9 @@ struct Lease {
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&ws->d_ctrl), sizeof(Ctrl));
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&ws->h_ctrl), sizeof(Ctrl), hipHostMallocDefault);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ws->stream2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ws->ev_join, hipEventDisableTiming);
     if (e != hipSuccess) {          // a half-built workspace must not reach the pool (~Lease): the next call would lease it
       ws.reset();
       return FailHip(h, e, "creating a workspace");
@@ -571,7 +581,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
     h->word_backoff.fetch_sub(1, std::memory_order_relaxed);
     word_ok = false;
   }
-  HIP_OR_RETURN(h, ws->d_lists.Reserve(static_cast<size_t>(2 * kMaxClasses + 3 + (word_ok ? 2 * kMaxClasses : 0)) * n));
+  HIP_OR_RETURN(h, ws->d_lists.Reserve(static_cast<size_t>(2 * kMaxClasses + 3 + (word_ok ? 3 * kMaxClasses : 0)) * n));
   HIP_OR_RETURN(h, ws->d_counts.Reserve(n + 1));
   HIP_OR_RETURN(h, ws->d_tmp_off.Reserve(n + 1));
   HIP_OR_RETURN(h, ws->d_tile_sums.Reserve((n + kScanTile - 1) / kScanTile + 2));
@@ -581,7 +591,8 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
   uint32_t *const hard_lists = class_lists + static_cast<size_t>(kMaxClasses) * n;   // (escalation lists of the align kernels)
   uint32_t *const long_list = class_lists + static_cast<size_t>(2 * kMaxClasses) * n;
   uint32_t *const retry_lists[2] = {long_list + n, long_list + 2 * n};
-  uint32_t *const left_lists[2] = {long_list + 3 * n, long_list + (3 + static_cast<size_t>(kMaxClasses)) * n};   // (word_ok only)
+  uint32_t *const left_lists[3] = {long_list + 3 * n, long_list + (3 + static_cast<size_t>(kMaxClasses)) * n,
+                                   long_list + (3 + 2 * static_cast<size_t>(kMaxClasses)) * n};   // (word_ok only)
   // ids are at most one per normalized byte; the streaming kernels reserve a sentence's slot by that bound
   uint64_t expand = (h->dev.flags & kNfCompressSp) || !(h->dev.flags & kNfEscapeWs) ? 1 : 3;
   if ((h->dev.flags & kNfCompressSp) && (h->dev.flags & kNfByteFallback)) expand = 2;   // slots: bytes + 2 per space symbol
@@ -733,6 +744,30 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       return left ? Fail(h, kResourceExhausted, "the long form's slice pool kept overflowing") : kOk;
     };
     const uint32_t *d_list_counts = ws->d_ctrl->list_counts;      // the device-side counts of a.lists
+    uint32_t again_counts[kMaxClasses] = {0};                     // (call-local memo) the second word round's input, per class
+    uint64_t again_total = 0;
+    uint32_t again_words = 0;
+    std::function<int(int, int, int, uint32_t *, uint32_t *, uint32_t *, uint32_t *)> word_pass;
+    // Which classes the wave-cooperative unigram form takes (kernels_uniwave.h, a sentence per wavefront): documents --
+    // the classes beyond the main streaming launch's (16 KiB) always; the classes between 4 and 16 KiB when they are
+    // most of the batch (a batch OF documents: one lane per document would leave the chip idle), not when they are a
+    // tail of a batch of sentences (there they hide behind the main launch's other tiles).
+    const bool uni_wave = !is_bpe && !spans && h->tables.max_prefixes >= 1 &&
+                          h->tables.max_prefixes <= static_cast<int>(kUwMaxCands) && !h->no_uni_wave;
+    bool uni_class[kMaxClasses] = {false};
+    if (uni_wave) {
+      uint64_t vol_staged = 0, vol_mid = 0;
+      for (int c = 0; c < ncls; ++c) {
+        const uint64_t v = static_cast<uint64_t>(known[c]) * cls[c].rcap;
+        if (cls[c].rcap <= kMaxStagedRaw) vol_staged += v;
+        else if (cls[c].rcap <= h->main_max_raw) vol_mid += v;
+      }
+      for (int c = 0; c < ncls; ++c) {
+        if (cls[c].rcap > h->main_max_raw) uni_class[c] = true;
+        else if (cls[c].rcap > kMaxStagedRaw) uni_class[c] = vol_mid > vol_staged;
+        else uni_class[c] = known[c] > 0 && known[c] < h->uni_wave_max;
+      }
+    }
     if (word_ok) {
       // ---- the word kernels first (kernels_word.h): every class from one queue, longest first.
       //   round 1   takes the sentences whose words are all in the load-time memo, and enters every other plain word
@@ -743,7 +778,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       // What is left then -- anything that is not plain ASCII words -- comes back as per-class lists for the general
       // launches below.
       const bool dyn = !h->no_word_dyn;
-      auto word_pass = [&](int mode, int slot, int qi, uint32_t *out_lists, uint32_t *d_out_counts, uint32_t *out2_lists,
+      word_pass = [&](int mode, int slot, int qi, uint32_t *out_lists, uint32_t *d_out_counts, uint32_t *out2_lists,
                            uint32_t *d_out2_counts) -> int {
         const bool dp = mode == 3;
         EncodeArgs wa = a;
@@ -766,7 +801,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
           if (tw > 64) tw = 64;
           if (tw < 1) tw = 1;
           sc.lane_shift = 6;
-          sc.general = cls[c].rcap > h->main_max_raw ? 1u : 0u;   // documents pass through to the wave-cooperative form
+          sc.general = ((uni_class[c] && cls[c].rcap > kMaxStagedRaw) || cls[c].rcap > h->main_max_raw) ? 1u : 0u;   // documents pass through
           sc.count = known[c];
           sc.tw = static_cast<uint32_t>(tw);
           sc.main_tiles = static_cast<uint32_t>((static_cast<uint64_t>(known[c]) + tw - 1) / tw);
@@ -807,22 +842,11 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         HIP_OR_RETURN(h, hipMemsetAsync(ws->d_dyn_tag.p, 0, static_cast<size_t>(kDynSlots) * sizeof(unsigned long long), stream));
         if (int rc = word_pass(1, kSlotWord, 3, left_lists[0], ws->d_ctrl->left_counts[0], left_lists[1], ws->d_ctrl->left_counts[1]); rc != kOk) return rc;
         if (int rc = read_counts(); rc != kOk) return rc;
-        uint64_t again = 0;
-        for (int c = 0; c < ncls; ++c) { known[c] = ws->h_ctrl->left_counts[0][c]; again += known[c]; }
-        if (again) {
-          const uint32_t words = ws->h_ctrl->dyn_count < kDynListCap ? ws->h_ctrl->dyn_count : kDynListCap;
-          if (words) {
-            ResolveArgs ra{};
-            ra.dev = h->dev; ra.dyn_ent = ws->d_dyn_ent.p; ra.dyn_list = ws->d_dyn_list.p; ra.dyn_count = &ws->d_ctrl->dyn_count;
-            ra.dyn_cap = kDynListCap; ra.unsafe = h->memo_unsafe ? 1u : 0u;
-            uint64_t g = (static_cast<uint64_t>(words) + 63) / 64;
-            if (g > static_cast<uint64_t>(h->n_cu) * 8) g = static_cast<uint64_t>(h->n_cu) * 8;
-            HIP_OR_RETURN(h, LaunchWordResolve(ra, static_cast<int>(g), stream));
-          }
-          a.lists = left_lists[0];
-          if (int rc = word_pass(2, kSlotWord2, 4, left_lists[1], ws->d_ctrl->left_counts[1], nullptr, nullptr); rc != kOk) return rc;
-          if (int rc = read_counts(); rc != kOk) return rc;
-        }
+        // The second round is enqueued further down, NEXT TO the general launches over what round 1 gave up for good
+        // (non-ASCII text ...): the two work on disjoint sentences, so the general launches go to a stream of their own
+        // and the two overlap (the general kernels are bound by the latency of their longest sentences, not by the chip).
+        for (int c = 0; c < ncls; ++c) { again_counts[c] = ws->h_ctrl->left_counts[0][c]; again_total += again_counts[c]; }
+        again_words = ws->h_ctrl->dyn_count < kDynListCap ? ws->h_ctrl->dyn_count : kDynListCap;
         for (int c = 0; c < ncls; ++c) known[c] = ws->h_ctrl->left_counts[1][c];
         a.lists = left_lists[1];
         d_list_counts = ws->d_ctrl->left_counts[1];
@@ -849,17 +873,23 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       for (int c = 0; c < ncls; ++c) if (cls[c].rcap <= h->main_max_raw) { leftover += known[c]; eligible += ws->h_ctrl->list_counts[c]; }
       if (eligible >= 4096 && leftover * 8 > eligible * 7) h->word_backoff.store(15, std::memory_order_relaxed);
     }
+    // ---- fork: with a second word round pending, the general launches below go to the workspace's second stream ----
+    hipStream_t main_stream = stream;
+    uint64_t general_total = 0;
+    for (int c = 0; c < ncls; ++c) general_total += known[c];
+    const bool forked = again_total > 0 && general_total > 0 && !h->no_overlap;
+    if (forked) {
+      HIP_OR_RETURN(h, hipEventRecord(ws->ev_fork, stream));
+      HIP_OR_RETURN(h, hipStreamWaitEvent(ws->stream2, ws->ev_fork, 0));
+      stream = ws->stream2;
+    }
     if (streaming) {
       // unigram: the wave-cooperative form (a sentence per wavefront, kernels_uniwave.h) takes the classes where the
       // lane-per-sentence kernels are the wrong tool -- documents (one lane would walk them alone: 2.5 us per byte),
       // and classes with too few sentences to fill 64 lanes of every wavefront
-      const bool uni_wave = !is_bpe && !spans && h->tables.max_prefixes >= 1 &&
-                            h->tables.max_prefixes <= static_cast<int>(kUwMaxCands) && !h->no_uni_wave;
       if (uni_wave) {
         for (int c = 0; c < ncls; ++c) {
-          if (known[c] == 0) continue;
-          // (documents: classes beyond the main streaming launch's, 16 KiB; a thinner class only if SPMX_UNI_WAVE_MAX says so)
-          if (cls[c].rcap <= h->main_max_raw && known[c] >= h->uni_wave_max) continue;
+          if (known[c] == 0 || !uni_class[c]) continue;
           if (int rc = long_launch(a.lists + static_cast<size_t>(c) * n, &d_list_counts[c], known[c], true); rc != kOk) return rc;
           known[c] = 0;
         }
@@ -898,6 +928,45 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       }
       for (int c = c_staged; c < ncls; ++c)
         if (int rc = long_launch(class_lists + static_cast<size_t>(c) * n, &ws->d_ctrl->list_counts[c], known[c]); rc != kOk) return rc;
+    }
+    // ---- join: the second word round (on the call's own stream), then what it left ----
+    if (forked) {
+      HIP_OR_RETURN(h, hipEventRecord(ws->ev_join, stream));
+      stream = main_stream;
+    }
+    if (again_total > 0) {
+      if (again_words) {
+        ResolveArgs ra{};
+        ra.dev = h->dev; ra.dyn_ent = ws->d_dyn_ent.p; ra.dyn_list = ws->d_dyn_list.p; ra.dyn_count = &ws->d_ctrl->dyn_count;
+        ra.dyn_cap = kDynListCap; ra.unsafe = h->memo_unsafe ? 1u : 0u;
+        uint64_t g = (static_cast<uint64_t>(again_words) + 63) / 64;
+        if (g > static_cast<uint64_t>(h->n_cu) * 8) g = static_cast<uint64_t>(h->n_cu) * 8;
+        HIP_OR_RETURN(h, LaunchWordResolve(ra, static_cast<int>(g), stream));
+      }
+      for (int c = 0; c < ncls; ++c) known[c] = again_counts[c];
+      a.lists = left_lists[0];
+      if (int rc = word_pass(2, kSlotWord2, 4, left_lists[2], ws->d_ctrl->left_counts[2], nullptr, nullptr); rc != kOk) return rc;
+      if (forked) HIP_OR_RETURN(h, hipStreamWaitEvent(stream, ws->ev_join, 0));
+      HIP_OR_RETURN(h, hipMemcpyAsync(ws->h_ctrl->left_counts, ws->d_ctrl->left_counts, sizeof(ws->h_ctrl->left_counts) + sizeof(uint32_t),
+                                      hipMemcpyDeviceToHost, stream));
+      HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+      // the tail: what the second round could not take either (a margin that does not hold, a word of more than 8
+      // pieces): few sentences -- a sentence per wavefront where the model allows it, else one more lane-per-sentence launch
+      uint32_t tail[kMaxClasses] = {0};
+      uint64_t tail_total = 0;
+      for (int c = 0; c < ncls; ++c) { tail[c] = ws->h_ctrl->left_counts[2][c]; tail_total += tail[c]; }
+      if (tail_total) {
+        a.lists = left_lists[2];
+        d_list_counts = ws->d_ctrl->left_counts[2];
+        if (uni_wave && tail_total < 65536) {
+          for (int c = 0; c < ncls; ++c)
+            if (tail[c]) if (int rc = long_launch(a.lists + static_cast<size_t>(c) * n, &d_list_counts[c], tail[c], true); rc != kOk) return rc;
+        } else {
+          if (int rc = stream_launch(kSlotDoc, 5, 0, ncls, tail, false, 0); rc != kOk) return rc;
+        }
+      }
+    } else if (forked) {
+      HIP_OR_RETURN(h, hipStreamWaitEvent(stream, ws->ev_join, 0));
     }
     if (int rc = scan_compact(); rc != kOk) return rc;
     if (ws->h_ctrl->status & kStArenaOverflow) {   // rare: byte fallback of multi-byte unknowns; arena_head holds what was asked for
@@ -1243,6 +1312,7 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_NO_WORD_DP")) h->no_word_dp = e[0] == '1';
     if (const char *e = getenv("SPMX_FORCE_WORD_DP")) h->force_word_dp = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_WORD_DYN")) h->no_word_dyn = e[0] == '1';
+    if (const char *e = getenv("SPMX_NO_OVERLAP")) h->no_overlap = e[0] == '1';
     if (getenv("SPMX_WORDMEMO_UNSAFE")) h->memo_unsafe = true;
     if (const char *e = getenv("SPMX_NO_UNI_WAVE")) h->no_uni_wave = e[0] == '1';
     if (const char *e = getenv("SPMX_UNI_WAVE_MAX")) h->uni_wave_max = static_cast<uint32_t>(atoll(e));
