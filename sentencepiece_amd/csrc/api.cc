@@ -173,7 +173,7 @@ struct Workspace {
   DevBuf<uint32_t> d_span_begin, d_span_end, d_nspan_begin, d_nspan_end;
   DevBuf<uint8_t> d_norm, d_nbest_scratch, d_slab, d_pool, d_sent_status;
   DevBuf<unsigned long long> d_res_off, d_dyn_tag;     // d_dyn_*: the call-local word memo (kernels_word.h)
-  DevBuf<U4> d_dyn_ent;
+  DevBuf<U4> d_dyn_ent, d_resume;
   DevBuf<uint32_t> d_dyn_list;
   DevBuf<float> d_res_score;
   Ctrl *d_ctrl = nullptr;
@@ -199,7 +199,7 @@ struct Workspace {
     d_lists.Free(); d_counts.Free(); d_tmp_off.Free(); d_tile_sums.Free(); d_chunk_base.Free(); d_arena.Free();
     d_arena_tb.Free(); d_tok_begin.Free(); d_span_begin.Free(); d_span_end.Free(); d_nspan_begin.Free(); d_nspan_end.Free();
     d_norm.Free(); d_nbest_scratch.Free(); d_slab.Free(); d_pool.Free(); d_sent_status.Free(); d_res_off.Free();
-    d_res_score.Free(); d_dyn_tag.Free(); d_dyn_ent.Free(); d_dyn_list.Free(); d_text.Free(); d_offs.Free(); d_id_offs.Free(); d_ids.Free(); d_dn_text.Free(); d_dn_offs.Free();
+    d_res_score.Free(); d_dyn_tag.Free(); d_dyn_ent.Free(); d_dyn_list.Free(); d_resume.Free(); d_text.Free(); d_offs.Free(); d_id_offs.Free(); d_ids.Free(); d_dn_text.Free(); d_dn_offs.Free();
     h_text.Free(); h_offs.Free(); h_id_offs.Free();
     if (d_ctrl) (void)hipFree(d_ctrl);
     if (h_ctrl) (void)hipHostFree(h_ctrl);
@@ -821,6 +821,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         wa.dyn_count = &ws->d_ctrl->dyn_count;
         wa.dyn_mask = kDynSlots - 1u;
         wa.dyn_cap = kDynListCap;
+        wa.resume = ws->d_resume.p;
         snprintf(ws->slot_name[slot], sizeof(ws->slot_name[slot]), "%s",
                  mode == 3 ? "EncodeWordDpKernel" : mode == 2 ? "EncodeWordAgainKernel" : mode == 1 ? "EncodeWordCollectKernel" : "EncodeWordKernel");
         HIP_OR_RETURN(h, record(slot, 0));
@@ -839,6 +840,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         HIP_OR_RETURN(h, ws->d_dyn_tag.Reserve(kDynSlots));
         HIP_OR_RETURN(h, ws->d_dyn_ent.Reserve(static_cast<size_t>(kDynSlots) * 4));
         HIP_OR_RETURN(h, ws->d_dyn_list.Reserve(kDynListCap));
+        HIP_OR_RETURN(h, ws->d_resume.Reserve(n));
         HIP_OR_RETURN(h, hipMemsetAsync(ws->d_dyn_tag.p, 0, static_cast<size_t>(kDynSlots) * sizeof(unsigned long long), stream));
         if (int rc = word_pass(1, kSlotWord, 3, left_lists[0], ws->d_ctrl->left_counts[0], left_lists[1], ws->d_ctrl->left_counts[1]); rc != kOk) return rc;
         if (int rc = read_counts(); rc != kOk) return rc;

@@ -107,6 +107,7 @@ struct EncodeArgs {
   uint32_t *dyn_count;
   uint32_t dyn_mask;
   uint32_t dyn_cap;             // entries dyn_list holds
+  U4 *resume;                   // per sentence the first round keeps for the second: {position, ids written, bound, 0}
   // ---- sentence-per-wave launch (BPE models that are not word-wise; kernels_bpe.h) ----
   const uint32_t *list;         // sentence indices of this length class
   const uint32_t *list_count;   // number of entries in list (device resident)

@@ -155,9 +155,12 @@ SPMX_DEVICE void uni_word_dp(const SpmxDev &d, const WordLds &T, int L, float B,
 // The words of this lane's sentence (raw bytes gtext[beg, beg + len)) -> ids in slot[0, n), forward order.
 // Returns n >= 0, or -1: the sentence is not for this pass (nothing usable was written).
 // MODE (kWm*): the call-local memo of `a` (dyn_*) is filled (collect) / consulted (dyn); -2: "try again in the second round".
+// `rs` of uni_word_lane: (collect) out -- where the lane stood when it met its first missing word: {position, ids
+// written, bound}; (dyn) in -- where to take the sentence up again: the ids before that point are in `slot` already.
+struct WordResume { int p; int n; float B; };
 template <bool DP, int MODE>
 SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_t beg, int len, int32_t *slot, int cap,
-                              const WordLds &T, bool active_in, int *n_steps) {
+                              const WordLds &T, bool active_in, int *n_steps, WordResume *rs) {
   const SpmxDev &d = a.dev;
   const U4 *__restrict__ memo16 = d.umemo16;
   const U4 *__restrict__ memo32 = d.umemo;
@@ -169,6 +172,11 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
   bool again = false;                              // (collect) every word this lane could not take is in the call-local memo now
   int p = 0, n = 0, steps = 0;
   float B = 0.f;                                   // DP: best_path_score at the start of the current word; else a bound of its magnitude
+  if (MODE == kWmDyn && active) {                  // take the sentence up where the first round left it
+    p = rs->p; n = rs->n; B = rs->B;
+    for (int k = n & ~7; k < n; ++k) T.stage[(k & 7) << 6] = slot[k];      // the incomplete group goes back into the staging column
+    if (p >= len) active = false;                  // (cannot happen: the first round stopped AT a word)
+  }
   int n_dp = 0;
   // a word waiting for the DP (second pass): its length; the lane goes on once the wave has run uni_word_dp
   bool stalled = false, stall_last = false;
@@ -176,7 +184,7 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
   bool prev_unk = false;                           // the last piece emitted was unknown (a run of them is ONE id, :609-613)
   const bool bf = (d.flags & kNfByteFallback) != 0;
   Q4U w{0, 0, 0, 0};
-  if (active) w = *reinterpret_cast<const Q4U *>(text);
+  if (active) w = *reinterpret_cast<const Q4U *>(text + p);
   auto put = [&](uint32_t id) __attribute__((always_inline)) {
     stage[(n & 7) << 6] = static_cast<int32_t>(id);
     ++n;
@@ -360,6 +368,7 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
           sl = (sl + 1u) & a.dyn_mask;
         }
       }
+      if (!bad) { rs->p = p; rs->n = n; rs->B = B; }   // (the first missing word: the second round starts here)
       bad = true;
       if (kept) again = true; else { again = false; active = false; }
     } else if (word && !ok) {
@@ -421,7 +430,11 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
     if (run) { p = pn; w = wn; }
   }
   *n_steps = steps;
-  if (bad) return (MODE == kWmCollect && again) ? -2 : -1;
+  if (bad && MODE == kWmCollect && again) {
+    for (int k = n & ~7; k < n; ++k) slot[k] = stage[(k & 7) << 6];   // what is staged belongs to the ids the second round keeps
+    return -2;
+  }
+  if (bad) return -1;
   if (active_in && len > 0)
     for (int k = n & ~7; k < n; ++k) slot[k] = stage[(k & 7) << 6];   // the last, incomplete group
   return n;
@@ -478,7 +491,8 @@ SPMX_DEVICE void encode_word_block(const EncodeArgs &a, unsigned char *smem) {
     const int len = mine ? static_cast<int>(l64) : 0;
     // ---- a slot of cap ids in the arena (at most one id per byte of the normalized form: the bytes + 1) ----
     const int cap = mine ? len + 1 : 0;
-    const int room = mine ? (cap + n_extra + 3 + 3) & ~3 : 0;
+    // (second round: the sentence keeps the slot -- and the ids -- the first round gave it)
+    const int room = (mine && MODE != kWmDyn) ? (cap + n_extra + 3 + 3) & ~3 : 0;
     int total = 0;
     const int excl = wave_excl_scan(room, lane, &total);
     unsigned long long base = 0;
@@ -491,8 +505,14 @@ SPMX_DEVICE void encode_word_block(const EncodeArgs &a, unsigned char *smem) {
     const int at = excl + d.n_prefix;
     const int shift = (4 - (at & 3)) & 3;
     int32_t *slot = a.arena + base + static_cast<unsigned long long>(excl + shift) + d.n_prefix;
+    WordResume rs{0, 0, 0.f};
+    if (MODE == kWmDyn && mine) {
+      slot = a.arena + a.tmp_off[sid] + d.n_prefix;
+      const U4 r = a.resume[sid];
+      rs.p = static_cast<int>(r.x); rs.n = static_cast<int>(r.y); rs.B = wv::bits_to_float(r.z);
+    }
     int steps = 0;
-    int n = uni_word_lane<DP, MODE>(a, a.text, beg, len, slot, cap, T, mine && !overflow, &steps);
+    int n = uni_word_lane<DP, MODE>(a, a.text, beg, len, slot, cap, T, mine && !overflow, &steps, &rs);
     const unsigned long long c1 = wv::clock();
     if (overflow) n = -1;
     const bool done = mine && n >= 0;
@@ -509,6 +529,10 @@ SPMX_DEVICE void encode_word_block(const EncodeArgs &a, unsigned char *smem) {
       // the general launches
       const bool again = left && n == -2;
       const bool gone = left && !again;
+      if (again) {                                   // where the second round takes the sentence up again
+        a.resume[sid] = U4{static_cast<uint32_t>(rs.p), static_cast<uint32_t>(rs.n), wv::float_to_bits(rs.B), 0u};
+        a.tmp_off[sid] = static_cast<unsigned long long>(slot - d.n_prefix - a.arena);
+      }
       append_lanes(wv::ballot(again), again, sid, a.left_lists + static_cast<uint64_t>(c) * a.n, &a.left_counts[c], lane);
       append_lanes(wv::ballot(gone), gone, sid, a.left2_lists + static_cast<uint64_t>(c) * a.n, &a.left2_counts[c], lane);
     } else {
