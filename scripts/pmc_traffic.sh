@@ -5,7 +5,7 @@ TAG=${1:-r02}; N=${2:-10000000}; MODEL=${3:-uni32k}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$TAG; mkdir -p $O
 for C in ${COUNTERS:-FETCH_SIZE WRITE_SIZE}; do
-  timeout ${PASS_TIMEOUT:-200} rocprofv3 --kernel-trace --pmc $C -d $O/pmc_$C -o pmc -- python bench.py --model $MODEL --sentences $N --steps 2 --warmup 1 --no-cpu-baseline --no-second-model > $O/pmc_$C.log 2>&1
+  timeout ${PASS_TIMEOUT:-200} rocprofv3 --kernel-trace --pmc $C -d $O/pmc_$C -o pmc -- python bench.py --model $MODEL --sentences $N --steps 2 --warmup 1 --no-cpu-baseline --no-second-model --no-side-configs > $O/pmc_$C.log 2>&1
   echo "$C rc=$?"
 done
 python - "$O" "$N" "$MODEL" <<'PY'
@@ -26,7 +26,7 @@ for f in sorted(glob.glob(O + '/pmc_*/**/pmc_results.db', recursive=True)):
         rows += list(db.execute(q))
 rows.sort(key=lambda r: (r[1], -r[3]))
 with open(O + '/%s_pmc_traffic.txt' % MODEL, 'w') as f:
-    f.write("# rocprofv3 --kernel-trace --pmc <C> -- python bench.py --model %s --sentences %d --steps 2 --warmup 1 --no-cpu-baseline --no-second-model   (one pass per counter; kernel sources %s)\n" % (MODEL, N, SHA))
+    f.write("# rocprofv3 --kernel-trace --pmc <C> -- python bench.py --model %s --sentences %d --steps 2 --warmup 1 --no-cpu-baseline --no-second-model --no-side-configs   (one pass per counter; kernel sources %s)\n" % (MODEL, N, SHA))
     f.write("# values are KB per dispatch (rocprofv3 FETCH_SIZE / WRITE_SIZE units)\n")
     f.write("%-62s %-11s %3s %16s %16s %16s\n" % ("kernel", "counter", "n", "avg", "min", "max"))
     for r in rows:

@@ -465,7 +465,7 @@ struct StreamPlan {
 // (classes outside the range get no tiles); tcap_of(c) gives a class's text-column capacity.
 template <typename TcapFn>
 StreamPlan PlanStream(const spmx_handle *h, EncodeArgs *a, const uint32_t *counts, int c_lo, int c_hi, int n_classes,
-                      const uint32_t *rcaps, TcapFn tcap_of, bool all_general) {
+                      const uint32_t *rcaps, TcapFn tcap_of, bool all_general, int waves_cap = 0) {
   StreamPlan sp;
   const int model = h->model.model_type;
   const uint32_t ring = HandleRing(h);
@@ -480,6 +480,7 @@ StreamPlan PlanStream(const spmx_handle *h, EncodeArgs *a, const uint32_t *count
   if (waves > 16) waves = 16;            // __launch_bounds__(1024)
   if (waves < 1) waves = 1;
   if (h->tile_waves_override > 0 && h->tile_waves_override < waves) waves = h->tile_waves_override;
+  if (waves_cap > 0 && waves_cap < waves) waves = waves_cap;     // (a launch that shares the CUs with another kernel)
   uint64_t total = 0;
   for (int c = c_lo; c < c_hi; ++c) total += counts[c];
   uint64_t grid = static_cast<uint64_t>(h->n_cu - h->reserve_cus);
@@ -665,6 +666,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
     a.fast_ok = fast_ok ? 1u : 0u;
     a.no_lane_general = h->no_lane_general ? 1u : 0u;
     // one streaming launch over the classes [c_lo, c_hi) (or, exact: over the overflow list with exact capacities)
+    int stream_waves_cap = 0;            // (set while a launch has to share the CUs with the second word round)
     auto stream_launch = [&](int slot, int qi, int c_lo, int c_hi, const uint32_t *counts, bool exact, uint64_t exact_raw) -> int {
       EncodeArgs la = a;
       uint32_t rc2[kMaxClasses];
@@ -674,13 +676,14 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       if (exact) {
         rc2[kMaxClasses - 1] = static_cast<uint32_t>(exact_raw < max_raw ? exact_raw : max_raw);
         const uint32_t tc = static_cast<uint32_t>(static_cast<uint64_t>(rc2[kMaxClasses - 1]) * h->dev.expand_max + 16);
-        sp = PlanStream(h, &la, counts, kMaxClasses - 1, kMaxClasses, kMaxClasses, rc2, [&](int) { return tc; }, true);
+        sp = PlanStream(h, &la, counts, kMaxClasses - 1, kMaxClasses, kMaxClasses, rc2, [&](int) { return tc; }, true, stream_waves_cap);
         la.over_list = nullptr;
         la.lists = class_lists;            // (the overflow list is the last of the classify lists, whatever `a.lists` names)
       } else {
         // the last class of the table takes every longer sentence too: those go straight to the overflow list
         sp = PlanStream(h, &la, counts, c_lo, c_hi, ncls, rc2,
-                        [&](int c) { return esc3 ? 2u * cls[c].rcap + 64u : (h->wide_tcap ? cls[c].ncap : cls[c].rcap + cls[c].rcap / 4u + 16u); }, !fast_ok);
+                        [&](int c) { return esc3 ? 2u * cls[c].rcap + 64u : (h->wide_tcap ? cls[c].ncap : cls[c].rcap + cls[c].rcap / 4u + 16u); }, !fast_ok,
+                        stream_waves_cap);
       }
       if (la.total_main == 0) return kOk;
       la.q = &ws->d_ctrl->q[qi];
@@ -875,7 +878,17 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       for (int c = 0; c < ncls; ++c) if (cls[c].rcap <= h->main_max_raw) { leftover += known[c]; eligible += ws->h_ctrl->list_counts[c]; }
       if (eligible >= 4096 && leftover * 8 > eligible * 7) h->word_backoff.store(15, std::memory_order_relaxed);
     }
-    // ---- fork: with a second word round pending, the general launches below go to the workspace's second stream ----
+    if (again_total > 0 && again_words) {      // the collected words, segmented once each (a few workgroups: before anything big)
+      ResolveArgs ra{};
+      ra.dev = h->dev; ra.dyn_ent = ws->d_dyn_ent.p; ra.dyn_list = ws->d_dyn_list.p; ra.dyn_count = &ws->d_ctrl->dyn_count;
+      ra.dyn_cap = kDynListCap; ra.unsafe = h->memo_unsafe ? 1u : 0u;
+      uint64_t g = (static_cast<uint64_t>(again_words) + 63) / 64;
+      if (g > static_cast<uint64_t>(h->n_cu) * 8) g = static_cast<uint64_t>(h->n_cu) * 8;
+      HIP_OR_RETURN(h, LaunchWordResolve(ra, static_cast<int>(g), stream));
+    }
+    // ---- fork: with a second word round pending, the general launches below go to the workspace's second stream.  Both
+    // are persistent grids: for the two to share a CU the general launch is held to 8 wavefronts per workgroup (80 KB
+    // of LDS next to the word kernel's 66 KB) -- it is bound by the latency of its longest sentences, not by the chip ----
     hipStream_t main_stream = stream;
     uint64_t general_total = 0;
     for (int c = 0; c < ncls; ++c) general_total += known[c];
@@ -884,6 +897,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       HIP_OR_RETURN(h, hipEventRecord(ws->ev_fork, stream));
       HIP_OR_RETURN(h, hipStreamWaitEvent(ws->stream2, ws->ev_fork, 0));
       stream = ws->stream2;
+      stream_waves_cap = 8;
     }
     if (streaming) {
       // unigram: the wave-cooperative form (a sentence per wavefront, kernels_uniwave.h) takes the classes where the
@@ -935,16 +949,9 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
     if (forked) {
       HIP_OR_RETURN(h, hipEventRecord(ws->ev_join, stream));
       stream = main_stream;
+      stream_waves_cap = 0;
     }
     if (again_total > 0) {
-      if (again_words) {
-        ResolveArgs ra{};
-        ra.dev = h->dev; ra.dyn_ent = ws->d_dyn_ent.p; ra.dyn_list = ws->d_dyn_list.p; ra.dyn_count = &ws->d_ctrl->dyn_count;
-        ra.dyn_cap = kDynListCap; ra.unsafe = h->memo_unsafe ? 1u : 0u;
-        uint64_t g = (static_cast<uint64_t>(again_words) + 63) / 64;
-        if (g > static_cast<uint64_t>(h->n_cu) * 8) g = static_cast<uint64_t>(h->n_cu) * 8;
-        HIP_OR_RETURN(h, LaunchWordResolve(ra, static_cast<int>(g), stream));
-      }
       for (int c = 0; c < ncls; ++c) known[c] = again_counts[c];
       a.lists = left_lists[0];
       if (int rc = word_pass(2, kSlotWord2, 4, left_lists[2], ws->d_ctrl->left_counts[2], nullptr, nullptr); rc != kOk) return rc;
