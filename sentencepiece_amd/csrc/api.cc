@@ -249,6 +249,7 @@ struct spmx_handle {
   std::atomic<int> word_backoff{0};   // calls that leave the word rounds out (they did not pay on the last batch that tried)
   bool no_word = false;          // SPMX_NO_WORD_KERNEL=1: unigram models skip the word kernels (kernels_word.h)
   bool no_word_dp = false;       // SPMX_NO_WORD_DP=1: ... skip the second pass only
+  int fork_waves = 0;            // SPMX_FORK_WAVES: wavefronts per workgroup of the general launch while it runs next to the second word round (0: as planned)
   bool no_overlap = false;       // SPMX_NO_OVERLAP=1: the general launches do not run next to the second word round
   bool no_word_dyn = false;      // SPMX_NO_WORD_DYN=1: no call-local word memo (one word round, then the DP pass)
   bool memo_unsafe = false;      // SPMX_WORDMEMO_UNSAFE=1: TEST SEAM, the call-local memo takes no margin either
@@ -887,8 +888,11 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       HIP_OR_RETURN(h, LaunchWordResolve(ra, static_cast<int>(g), stream));
     }
     // ---- fork: with a second word round pending, the general launches below go to the workspace's second stream.  Both
-    // are persistent grids: for the two to share a CU the general launch is held to 8 wavefronts per workgroup (80 KB
-    // of LDS next to the word kernel's 66 KB) -- it is bound by the latency of its longest sentences, not by the chip ----
+    // are persistent grids that fill a CU's LDS, so the one enqueued second gets the CUs as the first one's workgroups
+    // retire: the general launch goes first (its tiles differ most in length: a long tail), the second round fills in
+    // behind it.  (Measured: sequential 8.68 ms per C2 step; this 8.3 - 8.4; the general launch held to 8 wavefronts per
+    // workgroup so that both fit a CU at once, SPMX_FORK_WAVES=8: 8.68 -- it takes 2.8 ms instead of 2.0 and stays the
+    // critical path.) ----
     hipStream_t main_stream = stream;
     uint64_t general_total = 0;
     for (int c = 0; c < ncls; ++c) general_total += known[c];
@@ -897,7 +901,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       HIP_OR_RETURN(h, hipEventRecord(ws->ev_fork, stream));
       HIP_OR_RETURN(h, hipStreamWaitEvent(ws->stream2, ws->ev_fork, 0));
       stream = ws->stream2;
-      stream_waves_cap = 8;
+      stream_waves_cap = h->fork_waves;
     }
     if (streaming) {
       // unigram: the wave-cooperative form (a sentence per wavefront, kernels_uniwave.h) takes the classes where the
@@ -1322,6 +1326,7 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_FORCE_WORD_DP")) h->force_word_dp = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_WORD_DYN")) h->no_word_dyn = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_OVERLAP")) h->no_overlap = e[0] == '1';
+    if (const char *e = getenv("SPMX_FORK_WAVES")) h->fork_waves = atoi(e);
     if (getenv("SPMX_WORDMEMO_UNSAFE")) h->memo_unsafe = true;
     if (const char *e = getenv("SPMX_NO_UNI_WAVE")) h->no_uni_wave = e[0] == '1';
     if (const char *e = getenv("SPMX_UNI_WAVE_MAX")) h->uni_wave_max = static_cast<uint32_t>(atoll(e));
