@@ -6,6 +6,7 @@
  * (sentencepiece_amd/_capi.py), so this module has no link-time dependency on libspmx.so. */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
+#include <string.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -58,6 +59,27 @@ static PyObject *encode_views(PyObject *self, PyObject *args) {
                        (unsigned long long)(offs ? offs[n] : 0));
 }
 
+/* One int object per piece id, made on first use and shared by every list built afterwards: a list of ids then costs
+ * a pointer store and a reference count per id instead of an object allocation (~20 ns each, which at ~28 ids per
+ * sentence was 95 % of the list form's host time).  Ids are vocabulary indices, so the table is bounded by the largest
+ * vocabulary seen (capped at 2^21 entries; ids beyond it get fresh objects). */
+#define SPMX_PY_ID_CACHE_MAX (1 << 21)
+static PyObject **g_id_cache = NULL;
+static Py_ssize_t g_id_cache_n = 0;
+
+static int grow_id_cache(Py_ssize_t want) {
+  if (want > SPMX_PY_ID_CACHE_MAX) want = SPMX_PY_ID_CACHE_MAX;
+  if (want <= g_id_cache_n) return 0;
+  Py_ssize_t cap = g_id_cache_n ? g_id_cache_n : 1024;
+  while (cap < want) cap *= 2;
+  PyObject **t = (PyObject **)realloc(g_id_cache, (size_t)cap * sizeof(PyObject *));
+  if (!t) { PyErr_NoMemory(); return -1; }
+  memset(t + g_id_cache_n, 0, (size_t)(cap - g_id_cache_n) * sizeof(PyObject *));
+  g_id_cache = t;
+  g_id_cache_n = cap;
+  return 0;
+}
+
 /* csr_to_lists(ids_addr, offsets_addr, n) -> list[list[int]] */
 static PyObject *csr_to_lists(PyObject *self, PyObject *args) {
   unsigned long long ids_addr = 0, offs_addr = 0;
@@ -67,18 +89,38 @@ static PyObject *csr_to_lists(PyObject *self, PyObject *args) {
   const uint64_t *offs = (const uint64_t *)(uintptr_t)offs_addr;
   PyObject *outer = PyList_New(n);
   if (!outer) return NULL;
-  for (Py_ssize_t i = 0; i < n; ++i) {
+  /* n new container objects would run the cycle collector every few hundred lists, each pass walking what has been
+   * built so far (measured: 2.0 s instead of 0.35 s per million sentences); none of these lists can be in a cycle */
+  const int gc_was_on = PyGC_Disable();
+  PyObject *ret = outer;
+  for (Py_ssize_t i = 0; i < n && ret; ++i) {
     const uint64_t b = offs[i], e = offs[i + 1];
     PyObject *inner = PyList_New((Py_ssize_t)(e - b));
-    if (!inner) { Py_DECREF(outer); return NULL; }
+    if (!inner) { ret = NULL; break; }
+    for (uint64_t k = b; k < e; ++k) PyList_SET_ITEM(inner, (Py_ssize_t)(k - b), NULL);
+    PyList_SET_ITEM(outer, i, inner);
     for (uint64_t k = b; k < e; ++k) {
-      PyObject *v = PyLong_FromLong((long)ids[k]);
-      if (!v) { Py_DECREF(inner); Py_DECREF(outer); return NULL; }
+      const long id = (long)ids[k];
+      PyObject *v;
+      if (id >= 0 && id < SPMX_PY_ID_CACHE_MAX) {
+        if (id >= g_id_cache_n && grow_id_cache(id + 1) < 0) { ret = NULL; break; }
+        v = g_id_cache[id];
+        if (!v) {
+          v = PyLong_FromLong(id);
+          if (!v) { ret = NULL; break; }
+          g_id_cache[id] = v; /* the table keeps one reference for the life of the module */
+        }
+        Py_INCREF(v);
+      } else {
+        v = PyLong_FromLong(id);
+        if (!v) { ret = NULL; break; }
+      }
       PyList_SET_ITEM(inner, (Py_ssize_t)(k - b), v);
     }
-    PyList_SET_ITEM(outer, i, inner);
   }
-  return outer;
+  if (gc_was_on) PyGC_Enable();
+  if (!ret) Py_DECREF(outer); /* the lists filled so far hold NULL or owned references only */
+  return ret;
 }
 
 static PyMethodDef methods[] = {
