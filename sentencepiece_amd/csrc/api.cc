@@ -242,6 +242,7 @@ struct spmx_handle {
   // A/B switches (environment, read once at load)
   bool no_fast = false;          // SPMX_NO_FAST=1: every tile runs the general normalizer
   bool no_lane_general = false;  // SPMX_NO_LANE_GENERAL=1: main tiles set every non-ASCII sentence aside
+  uint32_t char_norm_mode = 0;   // SPMX_NO_CHAR_NORM=1 -> 1: no tile takes the character-stepping normalizer; SPMX_CHAR_NORM_ALWAYS=1 -> 2 (test seam): every tile
   bool no_stream = false;        // SPMX_NO_STREAM=1: BPE in the sentence-per-wave form only
   uint64_t arena_first = 0;      // SPMX_ARENA_FIRST: cap on the first attempt's id arena (tests: the overflow-and-retry path)
   bool no_bp_short = false;      // SPMX_NO_BP_SHORT=1: 32-bit back-pointer entries for every unigram model
@@ -249,6 +250,7 @@ struct spmx_handle {
   std::atomic<int> word_backoff{0};   // calls that leave the word rounds out (they did not pay on the last batch that tried)
   bool no_word = false;          // SPMX_NO_WORD_KERNEL=1: unigram models skip the word kernels (kernels_word.h)
   bool no_word_dp = false;       // SPMX_NO_WORD_DP=1: ... skip the second pass only
+  uint32_t tile_min_lanes = 1;   // SPMX_TILE_MIN_LANES: a main tile has at least this many sentences even when that leaves wavefronts without a tile of the class
   int fork_waves = 0;            // SPMX_FORK_WAVES: wavefronts per workgroup of the general launch while it runs next to the second word round (0: as planned)
   bool no_overlap = false;       // SPMX_NO_OVERLAP=1: the general launches do not run next to the second word round
   bool no_word_dyn = false;      // SPMX_NO_WORD_DYN=1: no call-local word memo (one word round, then the DP pass)
@@ -523,6 +525,7 @@ StreamPlan PlanStream(const spmx_handle *h, EncodeArgs *a, const uint32_t *count
     if (c < c_lo || c >= c_hi || counts[c] == 0) continue;
     sc.tcap = tcap_of(c);
     uint64_t tw = (static_cast<uint64_t>(counts[c]) + n_waves - 1) / n_waves;   // sentences per main tile
+    if (tw < h->tile_min_lanes) tw = h->tile_min_lanes;
     if (tw > 64) tw = 64;
     if (tw < 1) tw = 1;
     uint32_t sh = 0;                                   // lanes of a tile: enough for tw, as many as the budget allows
@@ -666,6 +669,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
     a.n = n32;
     a.fast_ok = fast_ok ? 1u : 0u;
     a.no_lane_general = h->no_lane_general ? 1u : 0u;
+    a.no_char_norm = h->char_norm_mode;
     // one streaming launch over the classes [c_lo, c_hi) (or, exact: over the overflow list with exact capacities)
     int stream_waves_cap = 0;            // (set while a launch has to share the CUs with the second word round)
     auto stream_launch = [&](int slot, int qi, int c_lo, int c_hi, const uint32_t *counts, bool exact, uint64_t exact_raw) -> int {
@@ -1327,6 +1331,7 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_NO_WORD_DYN")) h->no_word_dyn = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_OVERLAP")) h->no_overlap = e[0] == '1';
     if (const char *e = getenv("SPMX_FORK_WAVES")) h->fork_waves = atoi(e);
+    if (const char *e = getenv("SPMX_TILE_MIN_LANES")) h->tile_min_lanes = static_cast<uint32_t>(atoi(e));
     if (getenv("SPMX_WORDMEMO_UNSAFE")) h->memo_unsafe = true;
     if (const char *e = getenv("SPMX_NO_UNI_WAVE")) h->no_uni_wave = e[0] == '1';
     if (const char *e = getenv("SPMX_UNI_WAVE_MAX")) h->uni_wave_max = static_cast<uint32_t>(atoll(e));
@@ -1336,6 +1341,8 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_ARENA_FIRST")) h->arena_first = static_cast<uint64_t>(atoll(e));
     if (const char *e = getenv("SPMX_WIDE_TCAP")) h->wide_tcap = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_LANE_GENERAL")) h->no_lane_general = e[0] == '1';
+    if (const char *e = getenv("SPMX_NO_CHAR_NORM")) h->char_norm_mode = e[0] == '1' ? 1u : 0u;
+    if (const char *e = getenv("SPMX_CHAR_NORM_ALWAYS")) { if (e[0] == '1') h->char_norm_mode = 2u; }
     if (const char *e = getenv("SPMX_SUB_BUCKETS")) {
       const int v = atoi(e);
       h->sub_buckets = static_cast<uint32_t>(v < 1 ? 1 : (v > kMaxSubBuckets ? kMaxSubBuckets : v));

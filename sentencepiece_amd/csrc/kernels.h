@@ -94,6 +94,7 @@ struct EncodeArgs {
   uint32_t ring;                // score ring entries (power of two > longest piece)
   uint32_t fast_ok;             // the model meets fast_norm_stream's preconditions
   uint32_t no_lane_general;     // A/B switch: ASCII tiles put every non-ASCII sentence into the backlog
+  uint32_t no_char_norm;        // A/B switch: 1: no tile takes the character-stepping normalizer (kernels_normlane.h char_norm_stream); 2 (test seam): every tile does
   StreamClass cls[kMaxClasses];
   // ---- word kernel (kernels_word.h): what it cannot take, per length class, for the general launch that follows ----
   uint32_t *left_lists;         // n_classes x n

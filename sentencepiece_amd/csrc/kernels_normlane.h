@@ -76,12 +76,75 @@ struct FlatSink {
   SPMX_DEVICE bool overflowed() const { return dst != nullptr && w > cap; }
 };
 
+// trie_->commonPrefixSearch, longest key (src/normalizer.cc:218-228; darts.h:467-513) at s[0, rem): the key's length
+// in the low word and its value (offset of the replacement in the blob) in the high word; length 0 when no key matches,
+// 0xFFFFFFFF when the longest key holds an ASCII byte (fast_norm_stream's bookkeeping covers keys of non-ASCII bytes
+// only).  A real call (it sits inside fast_norm_stream's unrolled byte loop), results in registers.
+SPMX_DEVICE_CALL unsigned long long charsmap_longest(const uint32_t *ndarts, uint32_t ndarts_n, const uint8_t *s, int rem) {
+  uint32_t off = 0;
+  uint32_t pos = DartsOffset(ndarts[0]);
+  int best = 0;
+  bool ascii = false, best_ascii = false;
+  for (int depth = 0; depth < rem;) {
+    const uint32_t c = s[depth];
+    pos ^= c;
+    if (pos >= ndarts_n) break;
+    const uint32_t u = ndarts[pos];
+    if ((u & 0x800000FFu) != c) break;                   // unit.label() == c
+    pos ^= DartsOffset(u);
+    ascii = ascii || c < 0x80u;
+    ++depth;
+    if ((u >> 8) & 1u) {                                 // has_leaf: the value sits in the unit at pos
+      if (pos >= ndarts_n) break;
+      best = depth;
+      best_ascii = ascii;
+      off = ndarts[pos] & 0x7FFFFFFFu;
+    }
+  }
+  return static_cast<unsigned long long>(off) << 32 | (best_ascii ? 0xFFFFFFFFu : static_cast<uint32_t>(best));
+}
+
+// The replacement string of a matched charsmap key (src/normalizer.cc:245-250: the C string at normalized_[value]) goes
+// to a text column as the reference's loop writes a NormalizePrefix result (:133-163): leading spaces dropped after a
+// space, every other ' ' written as the (one-byte) space symbol.  State of the caller's loop by reference: acc (the
+// partial dword), w (bytes written), nsp (space symbols written), wl (length up to the last byte that is no space
+// symbol), P (is_prev_space), seen (something other than a space was written).  `left`: raw bytes after the key.
+// false: the replacement does not fit the column (the caller leaves the sentence to norm_lane_any).
+SPMX_DEVICE bool write_rule(const SpmxDev &d, uint32_t rule_off, int left, uint32_t sp, bool rm, const TextCol &gt, int tcap,
+                            uint32_t &acc, int &w, int &nsp, int &wl, bool &P, bool &seen) {
+  int n = 0;
+  while (rule_off + static_cast<uint32_t>(n) < d.nblob_n && d.nblob[rule_off + n] != 0) ++n;
+  if (w + n + left > tcap) return false;
+  int j = 0;
+  while (P && j < n && d.nblob[rule_off + j] == 0x20u) ++j;          // :137-138
+  if (j < n) {
+    uint32_t last = 0;
+    for (; j < n; ++j) {
+      last = d.nblob[rule_off + j];
+      const uint32_t b = last == 0x20u ? sp : last;                  // :143-148
+      acc |= b << (8 * (w & 3));
+      ++w;
+      if ((w & 3) == 0) { gt.dw((w >> 2) - 1) = acc; acc = 0; }
+      if (b == sp) ++nsp;
+      else { wl = w; seen = true; }
+    }
+    P = last == 0x20u && rm;                                         // :154
+  }
+  if (!rm) P = false;                                                // :160-162
+  return true;
+}
+
 // Normalize() of one all-ASCII sentence by ONE lane (every NormalizePrefix result is the byte itself, :231-244): raw
 // text in HBM, read as aligned 16-byte blocks of the ABSOLUTE address (a block that holds a byte of the sentence lies
 // in the same page as that byte, so the over-read at either end stays inside the caller's mapping whatever the
 // alignment of the buffer) -> the lane's text column, four bytes at a time.  Valid when the space symbol is one byte
 // wide (kNfCompressSp, or no whitespace escaping) and the model has no user-defined symbols; not for
 // whitespace-as-suffix models.  A byte whose bcls entry says kBcComplex makes the lane give up (-1).
+// Non-ASCII characters: one whose first two bytes start no charsmap key is itself (:231-244); otherwise the longest
+// key is looked up right here (charsmap_longest) and its replacement written as the reference's loop would (:133-163:
+// leading spaces dropped after a space, every other ' ' escaped); what is left to norm_lane_any is a key that starts
+// at an ASCII byte and continues with a non-ASCII one (a letter and a combining mark), a literal U+2581, a
+// replacement that does not fit the column.
 // *n_sp: how many bytes of the result are the space symbol (sizes the id slot under byte fallback).
 // (Tried: appending a dword of four plain bytes 0x21 .. 0x7E whole.  The lanes of a wave disagree on it dword by
 // dword, so the wave runs both paths: 3 % slower end to end.)
@@ -100,6 +163,7 @@ SPMX_DEVICE int fast_norm_stream(const SpmxDev &d, const uint8_t *gtext, uint64_
   uint32_t bad = 0;
   uint32_t carry = 0x80u;         // the last byte of the previous block
   int skip = 0;                   // continuation bytes of a validated character still to copy
+  int drop = 0;                   // bytes of a matched charsmap key still to pass over (its replacement is written)
   const uint8_t *first = gtext + beg;
   const uintptr_t a0 = reinterpret_cast<uintptr_t>(first) & ~static_cast<uintptr_t>(15);
   const uint8_t *blk = reinterpret_cast<const uint8_t *>(a0);
@@ -151,8 +215,12 @@ SPMX_DEVICE int fast_norm_stream(const SpmxDev &d, const uint8_t *gtext, uint64_
             } else {
               uint32_t o0 = c, o1 = 0, o2 = 0;
               int n_out = 1;
+              bool plain = true;                    // this byte contributes n_out bytes that are not spaces
               const int rem = L - (rel + k);
-              if (skip > 0) {
+              if (drop > 0) {
+                --drop;
+                plain = false;
+              } else if (skip > 0) {
                 --skip;
               } else {
                 const uint32_t b1 = rem >= 2 ? (wd[(k + 1) >> 2] >> (8 * ((k + 1) & 3))) & 0xFFu : 0u;
@@ -160,41 +228,56 @@ SPMX_DEVICE int fast_norm_stream(const SpmxDev &d, const uint8_t *gtext, uint64_
                 const uint32_t b3 = rem >= 4 ? (wd[(k + 3) >> 2] >> (8 * ((k + 3) & 3))) & 0xFFu : 0u;
                 const uint32_t pb = k > 0 ? (wd[(k > 0 ? k - 1 : 0) >> 2] >> (8 * ((k > 0 ? k - 1 : 0) & 3))) & 0xFFu : carry;
                 const uint32_t prevc = rel + k > 0 ? pb : 0x80u;      // nothing before the first byte of the sentence
-                const bool t1 = (b1 & 0xC0u) == 0x80u, t2 = (b2 & 0xC0u) == 0x80u, t3 = (b3 & 0xC0u) == 0x80u;
-                int mb = 0;
-                if (rem >= 2 && (c & 0xE0u) == 0xC0u) {
-                  if (t1 && ((c & 0x1Fu) << 6 | (b1 & 0x3Fu)) >= 0x80u) mb = 2;
-                } else if (rem >= 3 && (c & 0xF0u) == 0xE0u) {
-                  const uint32_t cp = (c & 0x0Fu) << 12 | (b1 & 0x3Fu) << 6 | (b2 & 0x3Fu);
-                  if (t1 && t2 && cp >= 0x800u && (cp < 0xD800u || cp >= 0xE000u)) mb = 3;
-                  if (c == 0xE2u && b1 == 0x96u && b2 == 0x81u) bad |= kBcComplex;
-                } else if (rem >= 4 && (c & 0xF8u) == 0xF0u) {
-                  const uint32_t cp = (c & 0x07u) << 18 | (b1 & 0x3Fu) << 12 | (b2 & 0x3Fu) << 6 | (b3 & 0x3Fu);
-                  if (t1 && t2 && t3 && cp >= 0x10000u && cp <= 0x10FFFFu) mb = 4;
-                }
+                int rule_len = 0;
+                uint32_t rule_off = 0;
                 if (has_map) {
-                  if ((d.npair[(c << 8 | b1) >> 5] >> (b1 & 31u)) & 1u) bad |= kBcComplex;          // a key may start here
-                  if (prevc < 0x80u && ((d.npair[(prevc << 8 | c) >> 5] >> (c & 31u)) & 1u)) bad |= kBcComplex;   // or at the ASCII byte before
-                }
-                if (mb) skip = mb - 1;
-                else { o0 = 0xEFu; o1 = 0xBFu; o2 = 0xBDu; n_out = 3; }
-              }
-              // a malformed byte grows into three: keep "what is written + what is left to read" within the
-              // column (all other bytes produce at most one), else leave the sentence to norm_lane_any
-              if (w + rem + 2 > tcap) bad |= kBcComplex;
-              else {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                  if (j < n_out) {
-                    acc |= (j == 0 ? o0 : (j == 1 ? o1 : o2)) << (8 * (w & 3));
-                    ++w;
-                    if ((w & 3) == 0) { if (!(SPMX_EXP & 4)) gt.dw((w >> 2) - 1) = acc; acc = 0; }
+                  if (prevc < 0x80u && ((d.npair[(prevc << 8 | c) >> 5] >> (c & 31u)) & 1u)) bad |= kBcComplex;   // a key may start at the ASCII byte before
+                  if ((d.npair[(c << 8 | b1) >> 5] >> (b1 & 31u)) & 1u) {                            // ... or here
+                    const unsigned long long hit = charsmap_longest(d.ndarts, d.ndarts_n, first + (rel + k), rem);
+                    rule_len = static_cast<int>(static_cast<uint32_t>(hit));
+                    rule_off = static_cast<uint32_t>(hit >> 32);
+                    if (rule_len < 0) { bad |= kBcComplex; rule_len = 0; }
                   }
                 }
+                if (rule_len > 0) {
+                  plain = false;
+                  if (!write_rule(d, rule_off, rem - rule_len, sp, rm, gt, tcap, acc, w, nsp, wl, P, seen)) bad |= kBcComplex;
+                  drop = rule_len - 1;
+                } else {
+                  const bool t1 = (b1 & 0xC0u) == 0x80u, t2 = (b2 & 0xC0u) == 0x80u, t3 = (b3 & 0xC0u) == 0x80u;
+                  int mb = 0;
+                  if (rem >= 2 && (c & 0xE0u) == 0xC0u) {
+                    if (t1 && ((c & 0x1Fu) << 6 | (b1 & 0x3Fu)) >= 0x80u) mb = 2;
+                  } else if (rem >= 3 && (c & 0xF0u) == 0xE0u) {
+                    const uint32_t cp = (c & 0x0Fu) << 12 | (b1 & 0x3Fu) << 6 | (b2 & 0x3Fu);
+                    if (t1 && t2 && cp >= 0x800u && (cp < 0xD800u || cp >= 0xE000u)) mb = 3;
+                    if (c == 0xE2u && b1 == 0x96u && b2 == 0x81u) bad |= kBcComplex;
+                  } else if (rem >= 4 && (c & 0xF8u) == 0xF0u) {
+                    const uint32_t cp = (c & 0x07u) << 18 | (b1 & 0x3Fu) << 12 | (b2 & 0x3Fu) << 6 | (b3 & 0x3Fu);
+                    if (t1 && t2 && t3 && cp >= 0x10000u && cp <= 0x10FFFFu) mb = 4;
+                  }
+                  if (mb) skip = mb - 1;
+                  else { o0 = 0xEFu; o1 = 0xBFu; o2 = 0xBDu; n_out = 3; }
+                }
               }
-              P = false;
-              wl = w;
-              seen = true;
+              if (plain) {
+                // a malformed byte grows into three: keep "what is written + what is left to read" within the
+                // column (all other bytes produce at most one), else leave the sentence to norm_lane_any
+                if (w + rem + 2 > tcap) bad |= kBcComplex;
+                else {
+#pragma unroll
+                  for (int j = 0; j < 3; ++j) {
+                    if (j < n_out) {
+                      acc |= (j == 0 ? o0 : (j == 1 ? o1 : o2)) << (8 * (w & 3));
+                      ++w;
+                      if ((w & 3) == 0) { if (!(SPMX_EXP & 4)) gt.dw((w >> 2) - 1) = acc; acc = 0; }
+                    }
+                  }
+                }
+                P = false;
+                wl = w;
+                seen = true;
+              }
             }
           }
         }
@@ -207,6 +290,114 @@ SPMX_DEVICE int fast_norm_stream(const SpmxDev &d, const uint8_t *gtext, uint64_
   }
   gt.dw(w >> 2) = acc;                          // the last, partial dword
   if (bad & kBcComplex) return -1;
+  if (rm) {
+    if (!seen) return 0;                        // :86-100 nothing but spaces
+    nsp -= w - wl;                              // the trimmed tail is nothing but space symbols
+    w = wl;
+  }
+  *n_sp = nsp;
+  return w;
+}
+
+// The same contract as fast_norm_stream for text that is mostly NOT ASCII (CJK ...): one NormalizePrefix result per
+// iteration instead of one byte -- the raw bytes come through a two-dword register window of aligned loads, a
+// character that starts no charsmap key is validated and appended whole (:231-244), a possible key is looked up
+// (charsmap_longest) and its replacement written (write_rule).  Leaves to norm_lane_any (-1) what fast_norm_stream
+// leaves to it.  A tile takes this form when enough of its sentences begin with non-ASCII text (kernels_stream.h).
+SPMX_DEVICE int char_norm_stream(const SpmxDev &d, const uint8_t *gtext, uint64_t beg, int L, const TextCol &gt,
+                                 const uint8_t *bcls, int tcap, int *n_sp) {
+  const uint32_t F = d.flags;
+  const bool rm = (F & kNfRemoveExtraWs) != 0;
+  const uint32_t sp = (F & kNfCompressSp) ? kSpByte : 0x20u;
+  const bool has_map = (F & kNfHasCharsmap) != 0;
+  int w = 0, nsp = 0;
+  uint32_t acc = 0;
+  if (F & kNfAddDummyPrefix) { acc = sp; w = 1; nsp = 1; }   // :128
+  bool P = rm;                    // is_prev_space (:130)
+  int wl = w;                     // output length up to the last non-space byte (:166-176 trailing spaces)
+  bool seen = false;              // some prefix is not " " (:86-100)
+  bool bad = false;
+  const uint8_t *first = gtext + beg;
+  const uintptr_t fa = reinterpret_cast<uintptr_t>(first);
+  // window: the aligned dwords at sentence offsets wb and wb + 4 (a dword that holds a byte of the sentence lies in
+  // that byte's page: no over-read beyond the caller's mapping)
+  const uint32_t *wp = reinterpret_cast<const uint32_t *>(fa & ~static_cast<uintptr_t>(3));
+  int wb = -static_cast<int>(fa & 3u);
+  uint32_t wlo = wp[0];
+  uint32_t whi = wb + 4 < L ? wp[1] : 0u;
+  uint32_t prevc = 0x80u;         // the raw byte before p when it is ASCII (a key may start there), else 0x80
+  int p = 0;
+  while (p < L && !bad) {
+    while (p - wb >= 4) { wlo = whi; wb += 4; ++wp; whi = wb + 4 < L ? wp[1] : 0u; }
+    const int rem = L - p;
+    uint32_t v = static_cast<uint32_t>((static_cast<unsigned long long>(whi) << 32 | wlo) >> (8 * (p - wb)));   // raw bytes p .. p + 3
+    if (rem < 4) v &= (1u << (8 * rem)) - 1u;                // (what follows the sentence is the next sentence's)
+    const uint32_t c = v & 0xFFu;
+    if (c < 0x80u) {
+      // ---- an ASCII byte: the prefix is the byte itself unless bcls says a key may start here ----
+      bad = (bcls[c] & kBcComplex) != 0;
+      const bool is_sp = c == 0x20u;
+      if (!is_sp || !P) {                                    // :137-138 a space after a space is dropped
+        acc |= (is_sp ? sp : c) << (8 * (w & 3));
+        ++w;
+        nsp += is_sp ? 1 : 0;
+        if ((w & 3) == 0) { gt.dw((w >> 2) - 1) = acc; acc = 0; }
+      }
+      P = is_sp && rm;                                       // :154-162
+      if (!is_sp) { wl = w; seen = true; }
+      prevc = c;
+      ++p;
+      continue;
+    }
+    const uint32_t b1 = (v >> 8) & 0xFFu, b2 = (v >> 16) & 0xFFu, b3 = v >> 24;
+    int rule_len = 0;
+    uint32_t rule_off = 0;
+    if (has_map) {
+      if (prevc < 0x80u && ((d.npair[(prevc << 8 | c) >> 5] >> (c & 31u)) & 1u)) bad = true;   // a key may start at the ASCII byte before
+      if ((d.npair[(c << 8 | b1) >> 5] >> (b1 & 31u)) & 1u) {                                  // ... or here
+        const unsigned long long hit = charsmap_longest(d.ndarts, d.ndarts_n, first + p, rem);
+        rule_len = static_cast<int>(static_cast<uint32_t>(hit));
+        rule_off = static_cast<uint32_t>(hit >> 32);
+        if (rule_len < 0) { bad = true; rule_len = 0; }
+      }
+    }
+    prevc = 0x80u;
+    if (rule_len > 0) {
+      if (!write_rule(d, rule_off, rem - rule_len, sp, rm, gt, tcap, acc, w, nsp, wl, P, seen)) bad = true;
+      p += rule_len;
+      continue;
+    }
+    // :231-244 one UTF-8 character (DecodeUTF8, util.cc:51-84), else U+FFFD for one malformed byte
+    const bool t1 = (b1 & 0xC0u) == 0x80u, t2 = (b2 & 0xC0u) == 0x80u, t3 = (b3 & 0xC0u) == 0x80u;
+    int mb = 0;
+    if (rem >= 2 && (c & 0xE0u) == 0xC0u) {
+      if (t1 && ((c & 0x1Fu) << 6 | (b1 & 0x3Fu)) >= 0x80u) mb = 2;
+    } else if (rem >= 3 && (c & 0xF0u) == 0xE0u) {
+      const uint32_t cp = (c & 0x0Fu) << 12 | (b1 & 0x3Fu) << 6 | (b2 & 0x3Fu);
+      if (t1 && t2 && cp >= 0x800u && (cp < 0xD800u || cp >= 0xE000u)) mb = 3;
+      if (c == 0xE2u && b1 == 0x96u && b2 == 0x81u) bad = true;            // a literal U+2581
+    } else if (rem >= 4 && (c & 0xF8u) == 0xF0u) {
+      const uint32_t cp = (c & 0x07u) << 18 | (b1 & 0x3Fu) << 12 | (b2 & 0x3Fu) << 6 | (b3 & 0x3Fu);
+      if (t1 && t2 && t3 && cp >= 0x10000u && cp <= 0x10FFFFu) mb = 4;
+    }
+    const int n_out = mb ? mb : 3;
+    const int consumed = mb ? mb : 1;
+    const uint32_t out = mb ? (mb == 4 ? v : v & ((1u << (8 * mb)) - 1u)) : 0x00BDBFEFu;
+    // "what is written + what is left to read" stays within the column (a malformed byte grows into three)
+    if (w + n_out + rem - consumed > tcap) { bad = true; break; }
+    {
+      const unsigned long long a64 = static_cast<unsigned long long>(acc) | (static_cast<unsigned long long>(out) << (8 * (w & 3)));
+      if ((w & 3) + n_out >= 4) { gt.dw(w >> 2) = static_cast<uint32_t>(a64); acc = static_cast<uint32_t>(a64 >> 32); }
+      else acc = static_cast<uint32_t>(a64);
+      w += n_out;
+    }
+    P = false;
+    wl = w;
+    seen = true;
+    p += consumed;
+  }
+  if (bad) return -1;
+  gt.dw(w >> 2) = acc;                          // the last, partial dword
   if (rm) {
     if (!seen) return 0;                        // :86-100 nothing but spaces
     nsp -= w - wl;                              // the trimmed tail is nothing but space symbols

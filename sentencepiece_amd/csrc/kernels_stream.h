@@ -541,7 +541,20 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
       int nlen = 0;
       bool need_any = go && my_len > 0;
       if (!backlog && a.fast_ok && !sc.general) {
-        if (go && my_len > 0) nlen = fast_norm_stream(d, a.text, my_beg, static_cast<int>(my_len), gt, T.bcls, static_cast<int>(tcap), &my_nsp);
+        // which form: a tile where one sentence in eight begins with non-ASCII text (CJK ...) steps character by
+        // character; the byte-stepping form is for ASCII with the odd accent
+        bool na = false;
+        if (go && my_len > 0) {
+          uint32_t v0 = 0, v1 = 0;
+          if (my_len >= 4) __builtin_memcpy(&v0, a.text + my_beg, 4); else v0 = a.text[my_beg];
+          if (my_len >= 8) __builtin_memcpy(&v1, a.text + my_beg + 4, 4);
+          na = ((v0 | v1) & 0x80808080u) != 0u;
+        }
+        const bool by_char = a.no_char_norm == 2u || (a.no_char_norm == 0u && 8 * wv::popc64(wv::ballot(na)) >= cnt);
+        if (go && my_len > 0) {
+          if (by_char) nlen = char_norm_stream(d, a.text, my_beg, static_cast<int>(my_len), gt, T.bcls, static_cast<int>(tcap), &my_nsp);
+          else nlen = fast_norm_stream(d, a.text, my_beg, static_cast<int>(my_len), gt, T.bcls, static_cast<int>(tcap), &my_nsp);
+        }
         need_any = nlen < 0;
         // Not plain ASCII.  A tile that is mostly such sentences (CJK text ...) normalizes them here, one per lane; a
         // few stray ones wait in the backlog

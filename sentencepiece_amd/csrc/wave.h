@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #define SPMX_DEVICE __device__ __forceinline__
+#define SPMX_DEVICE_CALL __device__ __attribute__((noinline))   // a real call: rare paths that sit inside unrolled code
 
 namespace spmx {
 namespace wv {

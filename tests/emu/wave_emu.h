@@ -17,6 +17,7 @@
 #define SPMX_WAVE_EMU_H_
 #define SPMX_WAVE_API 1
 #define SPMX_DEVICE inline
+#define SPMX_DEVICE_CALL inline
 
 #include <stdint.h>
 #include <stdio.h>

@@ -1,5 +1,5 @@
 """Seeded random inputs beyond the fixtures: raw byte noise (malformed UTF-8), random code points from every
-plane, whitespace storms, shuffled fragments of the corpora.  Three legs on the same inputs:
+plane, whitespace storms, rule characters between ASCII words, shuffled fragments of the corpora.  Three legs on the same inputs:
   * the oracle against the compiled reference (where it is built: this container) -- pins the oracle on them;
   * the device kernels under the emulator against the oracle (a few hundred sentences per model);
   * -m gpu: the HIP path against the oracle (20 k sentences per model), encode and decode."""
@@ -19,7 +19,7 @@ def fuzz_corpus(n, seed, corpora):
     ja = corpora["ja"][0].tobytes().decode("utf-8", errors="ignore")
     out = []
     for i in range(n):
-        kind = int(rng.integers(0, 8))
+        kind = int(rng.integers(0, 9))
         ln = int(rng.integers(0, 400)) if rng.random() < 0.9 else int(rng.integers(400, 3000))
         if kind == 0:      # byte noise
             s = rng.integers(0, 256, size=ln, dtype=np.uint8).tobytes()
@@ -44,6 +44,11 @@ def fuzz_corpus(n, seed, corpora):
         elif kind == 6:    # one character repeated (long runs of one piece, ties)
             ch = ["a", ".", " ", "猫", "\U0001f600", "\x00"][int(rng.integers(0, 6))]
             s = (ch * (ln // max(1, len(ch.encode())))).encode("utf-8")
+        elif kind == 7:    # ASCII words with rule characters between them: replacements that are, begin or end with a
+            # space next to real spaces, multi-character replacements, combining marks after ASCII and after kana
+            al = ["a", "b", "cd", " ", "　", "\u00a0", "´", "¨", "Ａ", "㍿", "ｶ", "ﾞ", "é", "e\u0301", "か", "\u3099",
+                  "①", "猫", "ー", "\u200b", "\U0001f600", "я", "и\u0306"]
+            s = "".join(al[int(k)] for k in rng.integers(0, len(al), size=ln // 2)).encode("utf-8")
         else:              # user-defined-symbol lookalikes and reserved names
             al = ["<sep>", "<s>", "</s>", "<unk>", "Botchan", "the end", "...", "<0x41>", " ", "x"]
             s = "".join(al[int(k)] for k in rng.integers(0, len(al), size=ln // 4)).encode("utf-8")
