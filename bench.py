@@ -49,6 +49,22 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
+def traffic_on_record(model, sentences, kernel):
+    """(bytes, bytes_uncorrected, note) of the PMC pass on record for this model / size / kernel (profiles/pmc_traffic.json,
+    made by scripts/pmc_traffic.sh) -- used only when it was measured on exactly these kernel sources."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    sha = kernel_sources_sha()
+    if not os.path.exists(tpath):
+        return None, None, "no PMC pass on record for this model / size / kernel"
+    with open(tpath) as f:
+        rec = json.load(f).get("%s:%d:%s" % (model, sentences, kernel))
+    if not isinstance(rec, dict):
+        return None, None, "no PMC pass on record for this model / size / kernel"
+    if rec.get("src_sha") != sha:
+        return None, None, "profiles/pmc_traffic.json is from other kernel sources (%s, now %s): not used" % (rec.get("src_sha"), sha)
+    return rec.get("bytes"), rec.get("bytes_lower"), rec.get("note", "profiles/pmc_traffic.json, made from these kernel sources")
+
+
 def cpu_baseline(text, offs, model_blob, gpu_counts, gpu_ids=None, gpu_id_offsets=None):
     """Reference CPU path on bounded strided samples of the bench corpus (about 20 s in all)."""
     from sentencepiece_amd import synth
@@ -186,7 +202,8 @@ def side_bench(sp_cls, torch, dev, name, blob, text, offs, steps, warmup, what, 
         ach = dom["bytes"] / (dom["kernel_ms"] * 1e-3) / 1e9
         out["roofline"] = {"kernel": dom["kernel"], "kernel_ms": dom["kernel_ms"], "sentences_per_launch": dom["sentences"],
                            "algorithmic_bytes_per_launch": dom["bytes"], "achieved": ach, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": None}
+                           "frac": ach / HBM_PEAK_GBS}
+        out["roofline"]["traffic"], _, out["roofline"]["traffic_note"] = traffic_on_record(name, n, dom["kernel"])
     try:
         io_h = io.cpu().numpy()
         out["probe_ids_bit_exact"] = probe_exact(text, offs, blob, ids[:int(io_h[-1])].cpu().numpy(), io_h, probe_k)
@@ -356,20 +373,9 @@ def main():
         dom = int(np.argmax(k_ms))
         cls = prof[-1]["classes"][dom]
         achieved = cls["bytes"] / (k_ms[dom] * 1e-3) / 1e9 if k_ms[dom] > 0 else 0.0
-        traffic, traffic_note = None, "no PMC pass on record for this model / size / kernel"
-        traffic_lower = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         kname = cls["kernel"]
         sha = kernel_sources_sha()
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                rec = json.load(f).get("%s:%d:%s" % (args.model, args.sentences, kname))
-            if isinstance(rec, dict):
-                if rec.get("src_sha") == sha:
-                    traffic, traffic_note = rec.get("bytes"), rec.get("note", "profiles/pmc_traffic.json, made from these kernel sources")
-                    traffic_lower = rec.get("bytes_lower")
-                else:
-                    traffic_note = "profiles/pmc_traffic.json is from other kernel sources (%s, now %s): not used" % (rec.get("src_sha"), sha)
+        traffic, traffic_lower, traffic_note = traffic_on_record(args.model, args.sentences, kname)
         out = {
             "metric": "sentences/sec EncodeBatch, %s %s, MI355X" % ("250k" if c5 else "32k",
                                                                      "unigram" if sp.model_type() == 1 else "bpe"),
