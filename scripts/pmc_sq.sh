@@ -6,10 +6,11 @@ mkdir -p gpurun_out/pmc_sq
 rocprofv3 --list-avail 2>/dev/null | grep -oE "\b(TA|TCP|TD|SQ|TCC)_[A-Z0-9_a-z]+" | sort -u > gpurun_out/pmc_sq/avail.txt
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
-           "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU" \
            "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum" \
+           "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU" \
            "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_WAVES SQ_CYCLES"; do
   i=$((i+1))
+  if [ -n "$GROUPS_MAX" ] && [ $i -gt $GROUPS_MAX ]; then break; fi
   timeout 70 rocprofv3 --kernel-trace --pmc $grp -d gpurun_out/pmc_sq/g$i -o pmc -- python bench.py --sentences $N --steps 2 --warmup 1 --no-cpu-baseline --no-second-model --no-side-configs > gpurun_out/pmc_sq/g$i.log 2>&1
   echo "group $i rc=$?"
 done
