@@ -247,9 +247,10 @@ int spmx_encode_file(spmx_handle *h, const char *in_path, const char *out_path, 
 
 /* ---- measurement --------------------------------------------------------
  * Per-kernel timing of the encode kernels of the LAST profiled encode call on the handle, measured with hipEvents
- * on the call's stream (enable first).  Arrays hold 5 entries ("kernel slots": 0 the streaming launch over the
+ * on the call's stream (enable first).  Arrays hold 7 entries ("kernel slots": 0 the streaming launch over the
  * classes up to 16 KiB, 1 the streaming launch over the document classes, 2 the overflow launch, 3 the
- * sentence-per-wave BPE launches, 4 the long form; unused slots are zero); returns the number of slots.
+ * sentence-per-wave BPE launches, 4 the long form (the wave-cooperative unigram form included), 5 the first round of the
+ * word form, 6 its second round; unused slots are zero); returns the number of slots (callers size for 8).
  * spmx_last_profile_name() gives the kernel symbol of a slot as rocprofv3 prints it.  bytes[] is the algorithmic
  * byte count SURVEY.md section 8d defines (raw bytes + 8 + 4 * ids + 8 per sentence).  path[4]: sentences the main
  * tiles set aside on hard lists, sentences on the overflow list, sentences that took the long form, failed sentences. */
@@ -259,7 +260,7 @@ int spmx_last_profile(const spmx_handle *h, float *kernel_ms, uint64_t *sentence
                       uint64_t *ids, uint64_t *bytes, uint64_t *path, float *total_ms);
 
 /* Shader-clock cycles the waves of the LAST profiled call spent per phase, summed over waves:
- * cycles[5 * slot + {0 load, 1 normalize, 2 segment, 3 emit}] (25 entries); entry 4 is the number of search-loop
+ * cycles[5 * slot + {0 load, 1 normalize, 2 segment, 3 emit}] (35 entries; callers size for 40); entry 4 is the number of search-loop
  * iterations the waves of the lane-per-sentence forms executed. */
 int spmx_last_phase_cycles(const spmx_handle *h, uint64_t *cycles);
 

@@ -785,7 +785,7 @@ class SentencePieceProcessor:
 
     def LastProfile(self):
         """Per kernel slot of the last profiled encode call (0 main streaming launch, 1 document launch, 2 overflow
-        launch, 3 sentence-per-wave BPE, 4 long form): dict(kernel, kernel_ms, sentences, raw_bytes, ids, bytes,
+        launch, 3 sentence-per-wave BPE, 4 long / wave-cooperative form, 5 word form first round, 6 second round): dict(kernel, kernel_ms, sentences, raw_bytes, ids, bytes,
         phase_cycles) + total_ms + path (sentences that waited in a wave's backlog / went to the overflow list / took
         the long form / failed)."""
         self._need()

@@ -53,6 +53,36 @@ def test_emu_long_sentences(model, emu, oracle, corpora):
         np.testing.assert_array_equal(ids, oids)
 
 
+@pytest.mark.parametrize("model", ["c5_250k", "test_ja_model", "uni1k_bf", "bpe32k", "uni1k_ident", "bpe1k_llama"])
+@pytest.mark.parametrize("mode", ["always", "never", "auto"])
+def test_emu_normalizer_forms(model, mode, emu, oracle, corpora):
+    """The three lane normalizers of the streaming kernels give the reference's text: the byte-stepping form that
+    applies charsmap rules itself (fast_norm_stream), the character-stepping form for tiles of mostly non-ASCII text
+    (char_norm_stream; SPMX_CHAR_NORM_ALWAYS=1 sends every tile there, SPMX_NO_CHAR_NORM=1 none), and norm_lane_any
+    for what both give up.  Inputs: mixed-script text with real NFKC rules (full-width letters, U+3000, circled
+    digits, U+337F -> four ideographs), kana with combining marks, ASCII letters followed by combining marks (a key that
+    starts at the ASCII byte), rule results that are or begin with a space next to real spaces, malformed bytes."""
+    from sentencepiece_amd import synth
+    from tests import test_fuzz
+    blob = fixtures.model_blob(model)
+    env = {"always": {"SPMX_CHAR_NORM_ALWAYS": "1"}, "never": {"SPMX_NO_CHAR_NORM": "1"}, "auto": {}}[mode]
+    env["SPMX_NO_WORD_KERNEL"] = "1"          # (every sentence through the streaming kernels)
+    o = oracle.load(blob)
+    mt, mo = synth.mixed_corpus(160, seed=11, hi=900)
+    ft, fo = test_fuzz.fuzz_corpus(260, 21, corpora)
+    hand = ["Ａ　Ｂ", "a\u00a0\u00a0b", " ´x", "´ ´", "e\u0301e\u0301", "か\u3099き\u3099", "ｶﾞｷﾞ", "㍿㍿ ㍿", "①②③ x", "　　", "\u00a0",
+            "x　", "　x", "a\u200bb", b"\xe3\x81", b"a\xffb\xe3\x81\x8b", b"\xe3\x81\x8b\xe3",  "猫" * 40 + "Ａ", "▁a▁", "и\u0306й", "ǅ ǆ"]
+    ht, ho = synth.pack([x.encode("utf-8", errors="surrogateescape") if isinstance(x, str) else x for x in hand])
+    for classes in ("", None):
+        h = emu.load(blob, env=dict(env), **({"classes": classes} if classes is not None else {}))
+        for tx, ox in ((mt, mo), (ft, fo), (ht, ho)):
+            ids, io = h.encode_batch(tx, ox)
+            assert h.status == 0
+            oids, oio = o.encode_batch(tx, ox)
+            np.testing.assert_array_equal(io, oio)
+            np.testing.assert_array_equal(ids, oids)
+
+
 @pytest.mark.parametrize("model", ["test_model", "uni1k_bf", "uni1k_suffix", "uni1k_ident", "uni32k"])
 @pytest.mark.parametrize("env", [{}, {"SPMX_NO_COMPRESS": "1"}, {"SPMX_NO_FAST": "1"},
                                  {"SPMX_NO_COMPRESS": "1", "SPMX_NO_FAST": "1"}])
