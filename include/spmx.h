@@ -203,6 +203,14 @@ int spmx_normalize_batch(spmx_handle *h, const char *text, const uint64_t *offse
  * sentence's lattice and agenda runs out. */
 int spmx_nbest_encode_batch(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int nbest_size,
                             int32_t **ids, uint64_t **id_offsets, float **scores, uint64_t **result_offsets);
+/* NBestEncode(input, nbest_size, NBestSentencePieceText *) / (…, std::vector<std::vector<std::string>> *)
+ * (src/sentencepiece_processor.h:318-324, .cc:653-676): the same results, plus for every id of every result the byte
+ * range of the input (begin / end) and of the normalized text (nbegin / nend) its piece covers -- the four arrays of
+ * the spans form above, indexed like ids; released with spmx_free().  A run of unknown characters is one piece; of a
+ * character's byte-fallback pieces the last carries the range (sentencepiece_processor.cc:581-617). */
+int spmx_nbest_encode_batch_spans(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int nbest_size,
+                                  int32_t **ids, uint64_t **id_offsets, float **scores, uint64_t **result_offsets,
+                                  uint32_t **begin, uint32_t **end, uint32_t **nbegin, uint32_t **nend);
 
 /* ---- sampling and the original encoder -----------------------------------
  * SampleEncode(input, nbest_size, alpha, std::vector<int>*) (src/sentencepiece_processor.h:346-353, .cc:678-720) per
@@ -220,6 +228,11 @@ int spmx_nbest_encode_batch(spmx_handle *h, const char *text, const uint64_t *of
  * bpe_model_test.cc:252-295), as tests/test_sampling.py does.  alpha = 0 under BPE is bit-equal to Encode. */
 int spmx_sample_encode_batch(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int nbest_size,
                              float alpha, uint64_t seed, int32_t **ids, uint64_t **id_offsets);
+/* SampleEncode(input, nbest_size, alpha, SentencePieceText *) / (…, std::vector<std::string> *)
+ * (src/sentencepiece_processor.h:346-353, :404-408): the drawn segmentation with the four span arrays (as above). */
+int spmx_sample_encode_batch_spans(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int nbest_size,
+                                   float alpha, uint64_t seed, int32_t **ids, uint64_t **id_offsets, uint32_t **begin,
+                                   uint32_t **end, uint32_t **nbegin, uint32_t **nend);
 /* The reference's ORIGINAL unigram encoder (EncoderVersion::kOriginal, src/unigram_model.cc:674-692): the lattice of
  * Lattice::SetSentence / Model::PopulateNodes and Lattice::Viterbi (:161-198, all-float, first best left node wins)
  * instead of EncodeOptimized.  Same ids except where float and double arithmetic break a tie differently. */

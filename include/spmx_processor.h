@@ -70,6 +70,11 @@ struct SentencePieceText {
   };
   std::string text;
   std::vector<SentencePiece> pieces;
+  float score = 0.f;       // set by NBestEncode only (src/sentencepiece_processor.cc:670)
+};
+// NBestSentencePieceText (src/sentencepiece.proto): the results of NBestEncode, best first
+struct NBestSentencePieceText {
+  std::vector<SentencePieceText> nbests;
 };
 
 // An encoded batch as the library hands it over: the CSR arrays themselves (pinned host memory for big batches), owned
@@ -291,19 +296,7 @@ class SentencePieceProcessor {
     }
     if (rc == 0) rc = spmx_normalize_batch(h_, input.data() ? input.data() : "", offs, 1, &norm, &no, nullptr);
     if (rc == 0) {
-      spt->text.assign(input.data(), input.size());
-      for (uint64_t k = 0; k < io[1]; ++k) {
-        SentencePieceText::SentencePiece p;
-        p.id = static_cast<uint32_t>(ids[k]);
-        p.begin = b[k];
-        p.end = e[k];
-        p.surface.assign(input.data() + b[k], e[k] - b[k]);
-        const int type = spmx_piece_type(h_, ids[k]);
-        if (type == 2 && unk_piece_option_) p.piece = UnkPiece();     // model_->unk_piece() (:1050-1058)
-        else if (type == 6 || type == 3) p.piece = IdToPiece(ids[k]);
-        else p.piece.assign(norm + nb[k], ne[k] - nb[k]);
-        spt->pieces.push_back(std::move(p));
-      }
+      FillPieces(input, norm, ids, b, e, nb, ne, 0, io[1], spt);
     }
     spmx_free(ids); spmx_free(io); spmx_free(b); spmx_free(e); spmx_free(nb); spmx_free(ne); spmx_free(norm); spmx_free(no);
     return FromHandle(rc);
@@ -344,6 +337,50 @@ class SentencePieceProcessor {
     (void)NBestEncode(input, nbest_size, &ids);
     return ids;
   }
+  // NBestEncode(input, nbest_size, NBestSentencePieceText *) (sentencepiece_processor.h:323-324, .cc:653-676): every
+  // result with its score and the pieces / surfaces / byte ranges PopulateSentencePieceText gives it
+  util::Status NBestEncode(std::string_view input, int nbest_size, NBestSentencePieceText *nbest_spt) const {
+    if (!h_) return status();
+    if (!nbest_spt) return util::Status(util::StatusCode::kInternal, "output proto is null");
+    nbest_spt->nbests.clear();
+    const uint64_t offs[2] = {0, input.size()};
+    int32_t *ids = nullptr;
+    uint64_t *io = nullptr, *ro = nullptr, *no = nullptr;
+    float *sc = nullptr;
+    uint32_t *b = nullptr, *e = nullptr, *nb = nullptr, *ne = nullptr;
+    char *norm = nullptr;
+    const char *txt = input.data() ? input.data() : "";
+    int rc = spmx_nbest_encode_batch_spans(h_, txt, offs, 1, nbest_size, &ids, &io, &sc, &ro, &b, &e, &nb, &ne);
+    if (rc == 0) rc = spmx_normalize_batch(h_, txt, offs, 1, &norm, &no, nullptr);
+    if (rc == 0) {
+      for (uint64_t r = ro[0]; r < ro[1]; ++r) {
+        nbest_spt->nbests.emplace_back();
+        nbest_spt->nbests.back().score = sc[r];
+        FillPieces(input, norm, ids, b, e, nb, ne, io[r], io[r + 1], &nbest_spt->nbests.back());
+      }
+    }
+    spmx_free(ids); spmx_free(io); spmx_free(sc); spmx_free(ro); spmx_free(b); spmx_free(e); spmx_free(nb); spmx_free(ne);
+    spmx_free(norm); spmx_free(no);
+    return FromHandle(rc);
+  }
+  util::Status NBestEncode(std::string_view input, int nbest_size, std::vector<std::vector<std::string>> *pieces) const {
+    if (!h_) return status();
+    if (!pieces) return util::Status(util::StatusCode::kInternal, "output container is null");
+    pieces->clear();
+    NBestSentencePieceText nb;
+    const util::Status st = NBestEncode(input, nbest_size, &nb);
+    if (!st.ok()) return st;
+    for (auto &spt : nb.nbests) {
+      pieces->emplace_back();
+      for (auto &p : spt.pieces) pieces->back().push_back(std::move(p.piece));
+    }
+    return util::Status();
+  }
+  std::vector<std::vector<std::string>> NBestEncodeAsPieces(std::string_view input, int nbest_size) const {   // errors are swallowed
+    std::vector<std::vector<std::string>> pieces;
+    (void)NBestEncode(input, nbest_size, &pieces);
+    return pieces;
+  }
 
   // ---- sampling (sentencepiece_processor.h:346-353, .cc:678-720): lattice sampling / n-best sampling (unigram),
   // BPE-dropout (BPE).  The draws are keyed by (seed, sentence); each call without a seed of its own takes the next
@@ -368,6 +405,43 @@ class SentencePieceProcessor {
     std::vector<int> ids;
     (void)SampleEncode(input, nbest_size, alpha, &ids);
     return ids;
+  }
+  // SampleEncode(input, nbest_size, alpha, SentencePieceText *) (sentencepiece_processor.h:346-348, .cc:678-720)
+  util::Status SampleEncode(std::string_view input, int nbest_size, float alpha, SentencePieceText *spt) const {
+    static std::atomic<uint64_t> calls{std::random_device{}()};
+    return SampleEncode(input, nbest_size, alpha, ++calls, spt);
+  }
+  util::Status SampleEncode(std::string_view input, int nbest_size, float alpha, uint64_t seed, SentencePieceText *spt) const {
+    if (!h_) return status();
+    if (!spt) return util::Status(util::StatusCode::kInternal, "output proto is null");
+    spt->text.clear();
+    spt->pieces.clear();
+    const uint64_t offs[2] = {0, input.size()};
+    int32_t *ids = nullptr;
+    uint64_t *io = nullptr, *no = nullptr;
+    uint32_t *b = nullptr, *e = nullptr, *nb = nullptr, *ne = nullptr;
+    char *norm = nullptr;
+    const char *txt = input.data() ? input.data() : "";
+    int rc = spmx_sample_encode_batch_spans(h_, txt, offs, 1, nbest_size, alpha, seed, &ids, &io, &b, &e, &nb, &ne);
+    if (rc == 0) rc = spmx_normalize_batch(h_, txt, offs, 1, &norm, &no, nullptr);
+    if (rc == 0) FillPieces(input, norm, ids, b, e, nb, ne, io[0], io[1], spt);
+    spmx_free(ids); spmx_free(io); spmx_free(b); spmx_free(e); spmx_free(nb); spmx_free(ne); spmx_free(norm); spmx_free(no);
+    return FromHandle(rc);
+  }
+  util::Status SampleEncode(std::string_view input, int nbest_size, float alpha, std::vector<std::string> *pieces) const {
+    if (!h_) return status();
+    if (!pieces) return util::Status(util::StatusCode::kInternal, "output container is null");
+    pieces->clear();
+    SentencePieceText spt;
+    const util::Status st = SampleEncode(input, nbest_size, alpha, &spt);
+    if (!st.ok()) return st;
+    for (auto &p : spt.pieces) pieces->push_back(std::move(p.piece));
+    return util::Status();
+  }
+  std::vector<std::string> SampleEncodeAsPieces(std::string_view input, int nbest_size, float alpha) const {   // errors are swallowed
+    std::vector<std::string> pieces;
+    (void)SampleEncode(input, nbest_size, alpha, &pieces);
+    return pieces;
   }
   // batch form: sentence i draws from the generator keyed by (seed, i)
   util::Status SampleEncodeBatchFlat(const char *text, const uint64_t *offsets, uint64_t n, int nbest_size, float alpha,
@@ -508,6 +582,25 @@ class SentencePieceProcessor {
   util::Status FromHandle(int rc) const {
     if (rc == 0) return util::Status();
     return util::Status(static_cast<util::StatusCode>(rc), spmx_last_error(h_));
+  }
+  // pieces [lo, hi) of a spans-form result -> spt (PopulateSentencePieceText, sentencepiece_processor.cc:547-636): a piece
+  // is its normalized text, the piece name for a byte-fallback piece and a bos / eos, unk_piece for an unknown token
+  // under the `unk_piece` extra option (:1050-1058)
+  void FillPieces(std::string_view input, const char *norm, const int32_t *ids, const uint32_t *b, const uint32_t *e,
+                  const uint32_t *nb, const uint32_t *ne, uint64_t lo, uint64_t hi, SentencePieceText *spt) const {
+    spt->text.assign(input.data() ? input.data() : "", input.size());
+    for (uint64_t k = lo; k < hi; ++k) {
+      SentencePieceText::SentencePiece p;
+      p.id = static_cast<uint32_t>(ids[k]);
+      p.begin = b[k];
+      p.end = e[k];
+      p.surface.assign(input.data() + b[k], e[k] - b[k]);
+      const int type = spmx_piece_type(h_, ids[k]);
+      if (type == 2 && unk_piece_option_) p.piece = UnkPiece();
+      else if (type == 6 || type == 3) p.piece = IdToPiece(ids[k]);
+      else p.piece.assign(norm + nb[k], ne[k] - nb[k]);
+      spt->pieces.push_back(std::move(p));
+    }
   }
   int device_ = 0;
   bool unk_piece_option_ = false;   // the `unk` / `unk_piece` extra option: piece strings only (:1050-1058)

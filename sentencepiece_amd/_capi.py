@@ -68,6 +68,10 @@ SYMBOLS = [
     ("spmx_nbest_encode_batch", C.c_int,
      [_H, C.c_void_p, C.c_void_p, _U64, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
       C.POINTER(C.c_void_p)]),
+    ("spmx_nbest_encode_batch_spans", C.c_int,
+     [_H, C.c_void_p, C.c_void_p, _U64, C.c_int] + [C.POINTER(C.c_void_p)] * 8),
+    ("spmx_sample_encode_batch_spans", C.c_int,
+     [_H, C.c_void_p, C.c_void_p, _U64, C.c_int, C.c_float, _U64] + [C.POINTER(C.c_void_p)] * 6),
     ("spmx_encode_batch_multi", C.c_int,
      [C.POINTER(_H), C.c_int, C.c_void_p, C.c_void_p, _U64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
       C.POINTER(C.c_void_p), C.POINTER(_U64)]),

@@ -1885,11 +1885,17 @@ int spmx_encode_batch_spans_device(spmx_handle *h, const void *d_text, uint64_t 
 namespace {
 // The lattice kernels (kernels_nbest.h), host-buffer form.  mode 0: NBestEncode; 1: Lattice::Sample(inv_theta); 2: the
 // kOriginal encoder (Lattice::Viterbi).  Modes 1 and 2 give one result per sentence.
+// begin / end / nbegin / nend (all or none): the spans form -- per id of every result the byte range of the input and of
+// the normalized text its token covers, as spmx_encode_batch_spans gives them for the best path.
 int LatticeBatchHost(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int mode, int nbest_size,
                      float inv_theta, uint64_t seed, int32_t **ids, uint64_t **id_offsets, float **scores,
-                     uint64_t **result_offsets) {
+                     uint64_t **result_offsets, uint32_t **begin = nullptr, uint32_t **end = nullptr,
+                     uint32_t **nbegin = nullptr, uint32_t **nend = nullptr) {
   if (!ids || !id_offsets || !scores || !result_offsets) return Fail(h, kInternal, "output container is null");
   *ids = nullptr; *id_offsets = nullptr; *scores = nullptr; *result_offsets = nullptr;
+  const bool spans = begin != nullptr;
+  if (spans && (!end || !nbegin || !nend)) return Fail(h, kInternal, "output container is null");
+  if (spans) { *begin = nullptr; *end = nullptr; *nbegin = nullptr; *nend = nullptr; }
   if (h->model.model_type != kUnigram)
     return Fail(h, kInternal, mode == 0 ? "NBestEncode is not available for the current model."     // sentencepiece_processor.cc:662
                                         : "SampleEncode is not available for the current model.");  // :690
@@ -1900,16 +1906,31 @@ int LatticeBatchHost(spmx_handle *h, const char *text, const uint64_t *offsets, 
     if ((mode == 0 && nbest_size == 1) || n == 0) {          // :694-696 the plain encoder, score 0.0; one result per sentence
       int32_t *i1 = nullptr;
       uint64_t *o1 = nullptr;
-      const int rc = EncodeBatchHost(h, text, offsets, n, &i1, &o1, nullptr, nullptr, nullptr, nullptr);
+      const int rc = EncodeBatchHost(h, text, offsets, n, &i1, &o1, nullptr, nullptr, spans ? begin : nullptr, spans ? end : nullptr,
+                                     spans ? nbegin : nullptr, spans ? nend : nullptr);
       if (rc != kOk) return rc;
       uint64_t *ro = static_cast<uint64_t *>(malloc((n + 1) * sizeof(uint64_t)));
       float *sc = static_cast<float *>(calloc(n + 1, sizeof(float)));
-      if (!ro || !sc) { free(i1); free(o1); free(ro); free(sc); return Fail(h, kResourceExhausted, "out of host memory"); }
+      if (!ro || !sc) {
+        spmx_free(i1); spmx_free(o1); free(ro); free(sc);
+        if (spans) { spmx_free(*begin); spmx_free(*end); spmx_free(*nbegin); spmx_free(*nend); *begin = *end = *nbegin = *nend = nullptr; }
+        return Fail(h, kResourceExhausted, "out of host memory");
+      }
       for (uint64_t s = 0; s <= n; ++s) ro[s] = s;
       *ids = i1; *id_offsets = o1; *scores = sc; *result_offsets = ro;
       return kOk;
     }
     if (!offsets) return Fail(h, kInvalidArgument, "null offsets");
+    // spans form: the kernel reports token ranges in the DEVICE form of the normalized text; the reference's form of
+    // it and its norm_to_orig (Normalizer::Normalize) turn them into the ranges PopulateSentencePieceText reports
+    struct HostNorm {
+      char *text = nullptr; uint64_t *offs = nullptr; uint32_t *n2o = nullptr;
+      ~HostNorm() { spmx_free(text); spmx_free(offs); spmx_free(n2o); }
+    } hn;
+    if (spans) {
+      const int rc = spmx_normalize_batch(h, text, offsets, n, &hn.text, &hn.offs, &hn.n2o);
+      if (rc != kOk) return rc;
+    }
     HIP_OR_RETURN(h, hipSetDevice(h->device));
     Lease L(h);
     if (int rc = L.Ready(); rc != kOk) return rc;
@@ -1950,6 +1971,11 @@ int LatticeBatchHost(spmx_handle *h, const char *text, const uint64_t *offsets, 
     for (int attempt = 0; attempt < 12; ++attempt) {
       HIP_OR_RETURN(h, ws->d_arena.Reserve(arena_need));
       a.arena = ws->d_arena.p; a.arena_cap = ws->d_arena.cap;
+      if (spans) {
+        HIP_OR_RETURN(h, ws->d_arena_tb.Reserve(ws->d_arena.cap));
+        HIP_OR_RETURN(h, ws->d_tok_begin.Reserve(ws->d_arena.cap));
+        a.arena_nb = ws->d_arena_tb.p; a.arena_ne = ws->d_tok_begin.p;
+      }
       HIP_OR_RETURN(h, hipMemsetAsync(ws->d_ctrl, 0, sizeof(Ctrl), st));
       // first launch: every sentence, 16-bit lattice indices, fixed capacities
       a.max_len = kNbMaxLen; a.max_nodes = kNbMaxNodes; a.max_hyps = max_hyps0;
@@ -2018,28 +2044,87 @@ int LatticeBatchHost(spmx_handle *h, const char *text, const uint64_t *offsets, 
       HIP_OR_RETURN(h, hipMemcpy(off.data(), ws->d_res_off.p, n * K * sizeof(unsigned long long), hipMemcpyDeviceToHost));
       HIP_OR_RETURN(h, hipMemcpy(sc.data(), ws->d_res_score.p, n * K * sizeof(float), hipMemcpyDeviceToHost));
       if (used) HIP_OR_RETURN(h, hipMemcpy(arena.data(), ws->d_arena.p, used * sizeof(int32_t), hipMemcpyDeviceToHost));
+      std::vector<int32_t> arena_nb, arena_ne;
+      std::vector<uint64_t> dev_offs;                       // device-form normalized offsets (a consistency check of the mapping)
+      if (spans) {
+        arena_nb.resize(used ? used : 1); arena_ne.resize(used ? used : 1); dev_offs.resize(n + 1);
+        if (used) {
+          HIP_OR_RETURN(h, hipMemcpy(arena_nb.data(), ws->d_arena_tb.p, used * sizeof(int32_t), hipMemcpyDeviceToHost));
+          HIP_OR_RETURN(h, hipMemcpy(arena_ne.data(), ws->d_tok_begin.p, used * sizeof(int32_t), hipMemcpyDeviceToHost));
+        }
+        HIP_OR_RETURN(h, hipMemcpy(dev_offs.data(), ws->d_id_offs.p, (n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+      }
       uint64_t R = 0, total = 0;
       for (uint64_t s = 0; s < n; ++s) for (uint32_t k = 0; k < cnt[s]; ++k) { ++R; total += len[s * K + k]; }
       int32_t *hi = static_cast<int32_t *>(malloc((total ? total : 1) * sizeof(int32_t)));
       uint64_t *ho = static_cast<uint64_t *>(malloc((R + 1) * sizeof(uint64_t)));
       float *hs = static_cast<float *>(malloc((R ? R : 1) * sizeof(float)));
       uint64_t *hr = static_cast<uint64_t *>(malloc((n + 1) * sizeof(uint64_t)));
-      if (!hi || !ho || !hs || !hr) { free(hi); free(ho); free(hs); free(hr); return Fail(h, kResourceExhausted, "out of host memory"); }
+      uint32_t *sb = nullptr, *se = nullptr, *snb = nullptr, *sne = nullptr;
+      if (spans) {
+        const size_t bytes = (total ? total : 1) * sizeof(uint32_t);
+        sb = static_cast<uint32_t *>(malloc(bytes)); se = static_cast<uint32_t *>(malloc(bytes));
+        snb = static_cast<uint32_t *>(malloc(bytes)); sne = static_cast<uint32_t *>(malloc(bytes));
+      }
+      if (!hi || !ho || !hs || !hr || (spans && (!sb || !se || !snb || !sne))) {
+        free(hi); free(ho); free(hs); free(hr); free(sb); free(se); free(snb); free(sne);
+        return Fail(h, kResourceExhausted, "out of host memory");
+      }
+      const bool one = (h->dev.flags & kNfCompressSp) != 0;
+      std::vector<uint32_t> ref_of_dev;                     // position in the reference's normalized text of device byte x
+      bool map_ok = true;
       uint64_t r = 0, t = 0;
       for (uint64_t s = 0; s < n; ++s) {
         hr[s] = r;
+        const char *R_ = nullptr;
+        const uint32_t *n2o = nullptr;
+        uint64_t rlen = 0;
+        if (spans) {
+          R_ = hn.text + hn.offs[s];
+          rlen = hn.offs[s + 1] - hn.offs[s];
+          n2o = hn.n2o + hn.offs[s] + s;
+          ref_of_dev.clear();
+          for (uint64_t i = 0; i < rlen;) {
+            ref_of_dev.push_back(static_cast<uint32_t>(i));
+            const bool sp3 = one && i + 2 < rlen && static_cast<unsigned char>(R_[i]) == 0xE2u &&
+                             static_cast<unsigned char>(R_[i + 1]) == 0x96u && static_cast<unsigned char>(R_[i + 2]) == 0x81u;
+            i += sp3 ? 3 : 1;
+          }
+          ref_of_dev.push_back(static_cast<uint32_t>(rlen));
+          if (ref_of_dev.size() - 1 != dev_offs[s + 1] - dev_offs[s]) map_ok = false;
+        }
+        const uint32_t in_len = static_cast<uint32_t>(offsets[s + 1] - offsets[s]);
         for (uint32_t k = 0; k < cnt[s]; ++k) {
           ho[r] = t;
           hs[r] = sc[s * K + k];
           const uint32_t ln = len[s * K + k];
           if (ln) memcpy(hi + t, arena.data() + off[s * K + k], ln * sizeof(int32_t));
+          if (spans && map_ok) {
+            const int32_t *pnb = arena_nb.data() + off[s * K + k], *pne = arena_ne.data() + off[s * K + k];
+            for (uint32_t j = 0; j < ln; ++j) {
+              if (pnb[j] < 0) {                             // bos / eos (sentencepiece_processor.cc:1029-1048)
+                sb[t + j] = se[t + j] = pnb[j] == -1 ? in_len : 0u;
+                snb[t + j] = sne[t + j] = 0u;
+                continue;
+              }
+              if (static_cast<size_t>(pne[j]) >= ref_of_dev.size() || pnb[j] > pne[j]) { map_ok = false; break; }
+              const uint32_t rb = ref_of_dev[pnb[j]], re = ref_of_dev[pne[j]];
+              snb[t + j] = rb; sne[t + j] = re;
+              sb[t + j] = n2o[rb]; se[t + j] = n2o[re];     // :566-574
+            }
+          }
           t += ln;
           ++r;
         }
       }
       hr[n] = r;
       ho[r] = t;
+      if (!map_ok) {
+        free(hi); free(ho); free(hs); free(hr); free(sb); free(se); free(snb); free(sne);
+        return Fail(h, kInternal, "token ranges do not map onto the normalized text");
+      }
       *ids = hi; *id_offsets = ho; *scores = hs; *result_offsets = hr;
+      if (spans) { *begin = sb; *end = se; *nbegin = snb; *nend = sne; }
       return kOk;
     }
     return Fail(h, kInternal, "id arena kept overflowing");
@@ -2052,6 +2137,18 @@ int spmx_nbest_encode_batch(spmx_handle *h, const char *text, const uint64_t *of
                             int32_t **ids, uint64_t **id_offsets, float **scores, uint64_t **result_offsets) {
   if (!h) return kInvalidArgument;
   return Guard(h, [&]() -> int { return LatticeBatchHost(h, text, offsets, n, 0, nbest_size, 0.f, 0, ids, id_offsets, scores, result_offsets); });
+}
+
+// NBestEncode(input, nbest_size, NBestSentencePieceText *) (src/sentencepiece_processor.cc:653-676): every result with the
+// byte ranges of its pieces.
+int spmx_nbest_encode_batch_spans(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int nbest_size,
+                                  int32_t **ids, uint64_t **id_offsets, float **scores, uint64_t **result_offsets,
+                                  uint32_t **begin, uint32_t **end, uint32_t **nbegin, uint32_t **nend) {
+  if (!h) return kInvalidArgument;
+  if (!begin || !end || !nbegin || !nend) return Fail(h, kInternal, "output container is null");
+  return Guard(h, [&]() -> int {
+    return LatticeBatchHost(h, text, offsets, n, 0, nbest_size, 0.f, 0, ids, id_offsets, scores, result_offsets, begin, end, nbegin, nend);
+  });
 }
 
 // The kOriginal unigram encoder (unigram::Model::Encode with EncoderVersion::kOriginal, src/unigram_model.cc:674-692:
@@ -2077,37 +2174,60 @@ int spmx_encode_batch_original(spmx_handle *h, const char *text, const uint64_t 
 //                       exp(alpha * score) (:700-716; unigram only)
 // The draws come from generators keyed by (seed, sentence index): the reference's thread-local mt19937 stream is not
 // reproduced (its own tests pin SampleEncode statistically, src/unigram_model_test.cc:429-470, bpe_model_test.cc:252-295).
+namespace {
+int SampleEncodeImpl(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int nbest_size, float alpha,
+                     uint64_t seed, int32_t **ids, uint64_t **id_offsets, uint32_t **begin, uint32_t **end, uint32_t **nbegin,
+                     uint32_t **nend);
+}
 int spmx_sample_encode_batch(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int nbest_size,
                              float alpha, uint64_t seed, int32_t **ids, uint64_t **id_offsets) {
+  return SampleEncodeImpl(h, text, offsets, n, nbest_size, alpha, seed, ids, id_offsets, nullptr, nullptr, nullptr, nullptr);
+}
+// SampleEncode(input, nbest_size, alpha, SentencePieceText *) (src/sentencepiece_processor.cc:678-720): the drawn
+// segmentation with the byte ranges of its pieces.
+int spmx_sample_encode_batch_spans(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int nbest_size,
+                                   float alpha, uint64_t seed, int32_t **ids, uint64_t **id_offsets, uint32_t **begin,
+                                   uint32_t **end, uint32_t **nbegin, uint32_t **nend) {
+  if (h && (!begin || !end || !nbegin || !nend)) return Fail(h, kInternal, "output container is null");
+  return SampleEncodeImpl(h, text, offsets, n, nbest_size, alpha, seed, ids, id_offsets, begin, end, nbegin, nend);
+}
+namespace {
+int SampleEncodeImpl(spmx_handle *h, const char *text, const uint64_t *offsets, uint64_t n, int nbest_size, float alpha,
+                     uint64_t seed, int32_t **ids, uint64_t **id_offsets, uint32_t **begin, uint32_t **end, uint32_t **nbegin,
+                     uint32_t **nend) {
   if (!h) return kInvalidArgument;
   if (!ids || !id_offsets) return Fail(h, kInternal, "output container is null");
+  const bool spans = begin != nullptr;
   return Guard(h, [&]() -> int {
     *ids = nullptr; *id_offsets = nullptr;
+    if (spans) { *begin = nullptr; *end = nullptr; *nbegin = nullptr; *nend = nullptr; }
     if (nbest_size > 512) return Fail(h, kInternal, "nbest_size must be nbest_size <= 512");   // sentencepiece_processor.cc:684
     if (h->model.model_type == kBpe) {
       // !IsNBestEncodeAvailable(): every nbest_size goes to bpe::Model::SampleEncode(normalized, alpha) (:688-693),
       // BPE-dropout with merge-skip probability alpha; alpha <= 0 is the plain merge order (bpe_model.cc:131-156)
       if (n && !offsets) return Fail(h, kInvalidArgument, "null offsets");
-      if (n == 0 || !(alpha > 0.f)) return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, nullptr, nullptr, nullptr, nullptr);
-      return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, alpha, seed);
+      if (n == 0 || !(alpha > 0.f)) return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, nullptr, nullptr, begin, end, nbegin, nend);
+      return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, nullptr, nullptr, begin, end, nbegin, nend, alpha, seed);
     }
-    if (nbest_size == 0 || nbest_size == 1) return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, nullptr, nullptr, nullptr, nullptr);
+    if (nbest_size == 0 || nbest_size == 1) return EncodeBatchHost(h, text, offsets, n, ids, id_offsets, nullptr, nullptr, begin, end, nbegin, nend);
     float *sc = nullptr;
     uint64_t *ro = nullptr;
     if (nbest_size < 0) {
-      const int rc = LatticeBatchHost(h, text, offsets, n, 1, 1, alpha, seed, ids, id_offsets, &sc, &ro);
+      const int rc = LatticeBatchHost(h, text, offsets, n, 1, 1, alpha, seed, ids, id_offsets, &sc, &ro, begin, end, nbegin, nend);
       free(sc);
       free(ro);
       return rc;
     }
     int32_t *nids = nullptr;
     uint64_t *nio = nullptr;
-    const int rc = LatticeBatchHost(h, text, offsets, n, 0, nbest_size, 0.f, 0, &nids, &nio, &sc, &ro);
+    uint32_t *nb4[4] = {nullptr, nullptr, nullptr, nullptr};     // the spans of every n-best result
+    const int rc = spans ? LatticeBatchHost(h, text, offsets, n, 0, nbest_size, 0.f, 0, &nids, &nio, &sc, &ro, &nb4[0], &nb4[1], &nb4[2], &nb4[3])
+                         : LatticeBatchHost(h, text, offsets, n, 0, nbest_size, 0.f, 0, &nids, &nio, &sc, &ro);
     if (rc != kOk) return rc;
     struct Release {                               // (the n-best arrays, whatever way this function is left)
-      void *p[4];
-      ~Release() { for (void *q : p) free(q); }
-    } release{{nids, nio, sc, ro}};
+      void *p[8];
+      ~Release() { for (void *q : p) spmx_free(q); }
+    } release{{nids, nio, sc, ro, nb4[0], nb4[1], nb4[2], nb4[3]}};
     // one of each sentence's results, with probability exp(alpha * score) / Z
     std::vector<uint64_t> pick(n);
     uint64_t *oo = static_cast<uint64_t *>(malloc((n + 1) * sizeof(uint64_t)));
@@ -2131,15 +2251,24 @@ int spmx_sample_encode_batch(spmx_handle *h, const char *text, const uint64_t *o
       if (r1 > r0) total += nio[c + 1] - nio[c];
     }
     int32_t *oi = static_cast<int32_t *>(malloc((total ? total : 1) * sizeof(int32_t)));
-    if (!oo || !oi) { free(oo); free(oi); return Fail(h, kResourceExhausted, "out of host memory"); }
+    uint32_t *os[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool os_ok = true;
+    if (spans) for (auto &q : os) { q = static_cast<uint32_t *>(malloc((total ? total : 1) * sizeof(uint32_t))); os_ok = os_ok && q; }
+    if (!oo || !oi || !os_ok) { free(oo); free(oi); for (auto q : os) free(q); return Fail(h, kResourceExhausted, "out of host memory"); }
     oo[n] = total;
-    for (uint64_t s2 = 0; s2 < n; ++s2)
-      if (ro[s2 + 1] > ro[s2]) memcpy(oi + oo[s2], nids + nio[pick[s2]], (nio[pick[s2] + 1] - nio[pick[s2]]) * sizeof(int32_t));
+    for (uint64_t s2 = 0; s2 < n; ++s2) {
+      if (ro[s2 + 1] <= ro[s2]) continue;
+      const uint64_t from = nio[pick[s2]], cnt = nio[pick[s2] + 1] - from;
+      memcpy(oi + oo[s2], nids + from, cnt * sizeof(int32_t));
+      if (spans) for (int q = 0; q < 4; ++q) memcpy(os[q] + oo[s2], nb4[q] + from, cnt * sizeof(uint32_t));
+    }
     *ids = oi;
     *id_offsets = oo;
+    if (spans) { *begin = os[0]; *end = os[1]; *nbegin = os[2]; *nend = os[3]; }
     return kOk;
   });
 }
+}  // namespace
 
 int spmx_normalize_batch_device(spmx_handle *h, const void *d_text, const uint64_t *d_offsets, uint64_t n, void *d_norm,
                                 uint64_t norm_capacity, uint64_t *d_norm_offsets, uint32_t *d_norm_to_orig, void *stream,

@@ -59,6 +59,10 @@ struct NBestArgs {
   uint32_t *retry_count;
   unsigned long long *retry_max_len;   // the longest of them (normalized bytes)
   int32_t *arena;               // ids of all results, allocated by atomics
+  int32_t *arena_nb, *arena_ne; // spans form, else null: next to every id in `arena` the byte range [nb, ne) of the normalized
+                                // DEVICE text its token covers (PopulateSentencePieceText :566-617: a run of unknown
+                                // characters is one token; of a character's byte-fallback pieces the last one carries
+                                // the range, the others are empty at its begin); an eos is -1, -1 (the end of the INPUT, :1033-1034), a bos -2, -2 (0)
   unsigned long long *arena_head;
   uint64_t arena_cap;
   unsigned long long *res_off;  // [n][nbest] where result k of sentence s sits in the arena
@@ -132,12 +136,21 @@ SPMX_DEVICE void nbest_lane(const NBestArgs &a, uint32_t s, uint8_t *mine) {
     if (at + static_cast<unsigned long long>(n_ids) > a.arena_cap) { wv::atomic_or(a.status, kStArenaOverflow); return nullptr; }
     return a.arena + at;
   };
+  // the extra ids around a result's `body` ids (ApplyExtraOptions, sentencepiece_processor.cc:1019-1064); returns
+  // where the body goes
+  auto put_extras = [&](int32_t *dst, int body) -> int32_t * {
+    for (int x = 0; x < d.n_prefix; ++x) dst[x] = d.prefix_ids[x];
+    for (int x = 0; x < d.n_suffix; ++x) dst[d.n_prefix + body + x] = d.suffix_ids[x];
+    if (a.arena_nb) {
+      int32_t *nb = a.arena_nb + (dst - a.arena), *ne = a.arena_ne + (dst - a.arena);
+      for (int x = 0; x < d.n_prefix; ++x) nb[x] = ne[x] = ((d.extra_eos >> x) & 1u) ? -1 : -2;                       // (reverse after eos puts an eos in front)
+      for (int x = 0; x < d.n_suffix; ++x) nb[d.n_prefix + body + x] = ne[d.n_prefix + body + x] = ((d.extra_eos >> (kMaxExtra + x)) & 1u) ? -1 : -2;
+    }
+    return dst + d.n_prefix;
+  };
   if (size == 0) {                               // unigram_model.cc:688-690: one empty result, score 0
     int32_t *dst = alloc(n_extra);
-    if (dst) {
-      for (int x = 0; x < d.n_prefix; ++x) dst[x] = d.prefix_ids[x];
-      for (int x = 0; x < d.n_suffix; ++x) dst[d.n_prefix + x] = d.suffix_ids[x];
-    }
+    if (dst) put_extras(dst, 0);
     res_score[0] = 0.f;
     a.res_count[s] = 1;
     return;
@@ -234,6 +247,39 @@ SPMX_DEVICE void nbest_lane(const NBestArgs &a, uint32_t s, uint8_t *mine) {
   }
   // ids of a path given as a chain of node indices, left to right through `next_of` (PopulateSentencePieceText
   // :581-613: a run of unknown pieces yields one id, byte fallback one id per byte), twice: count, then write
+  // the ids of ONE lattice node of a path (dst null: count only).  k: ids so far; last: where the latest token that
+  // is not a byte-fallback piece went (a run of unknown pieces extends it)
+  auto put_node = [&](const NbNode &x, int32_t *dst, int body, int &k, bool &prev_unk, int &last) {
+    const bool unk = x.id == d.unk_id;
+    const int32_t nb0 = static_cast<int32_t>(x.byte_begin), ne0 = static_cast<int32_t>(x.byte_begin) + static_cast<int32_t>(x.byte_len);
+    int32_t *snb = dst && a.arena_nb ? a.arena_nb + (dst - a.arena) : nullptr;
+    int32_t *sne = dst && a.arena_nb ? a.arena_ne + (dst - a.arena) : nullptr;
+    if (unk && bf) {
+      int total = 0, j = 0;
+      for (uint32_t t = 0; t < x.byte_len; ++t) total += norm[x.byte_begin + t] == spb ? 3 : 1;
+      for (uint32_t t = 0; t < x.byte_len; ++t) {
+        const uint32_t b = norm[x.byte_begin + t];
+        const int nbt = b == spb ? 3 : 1;
+        for (int y = 0; y < nbt; ++y, ++j) {
+          const int at = reverse ? body - 1 - k : k;
+          if (dst) dst[at] = d.byte_ids[b == spb ? (y == 0 ? 0xE2u : (y == 1 ? 0x96u : 0x81u)) : b];
+          if (snb) { snb[at] = nb0; sne[at] = j == total - 1 ? ne0 : nb0; }       // :595-606
+          ++k;
+        }
+      }
+    } else if (!(unk && prev_unk)) {
+      const int at = reverse ? body - 1 - k : k;
+      if (dst) dst[at] = x.id;
+      if (snb) { snb[at] = nb0; sne[at] = ne0; }
+      last = at;
+      ++k;
+    } else if (sne) {
+      sne[last] = ne0;                                                             // :612-616 the run's token grows
+    }
+    prev_unk = unk;
+  };
+  // ids of a path given as a chain of node indices, left to right through `next_of` (PopulateSentencePieceText
+  // :581-613: a run of unknown pieces yields one id, byte fallback one id per byte), twice: count, then write
   auto emit_path = [&](auto first_of, auto next_of, auto done_of, float score) -> bool {
     int body = 0;
     for (int pass = 0; pass < 2; ++pass) {
@@ -241,30 +287,11 @@ SPMX_DEVICE void nbest_lane(const NBestArgs &a, uint32_t s, uint8_t *mine) {
       if (pass == 1) {
         dst = alloc(body + n_extra);
         if (!dst) return false;
-        for (int x = 0; x < d.n_prefix; ++x) dst[x] = d.prefix_ids[x];
-        for (int x = 0; x < d.n_suffix; ++x) dst[d.n_prefix + body + x] = d.suffix_ids[x];
-        dst += d.n_prefix;
+        dst = put_extras(dst, body);
       }
-      int k = 0;
+      int k = 0, last = 0;
       bool prev_unk = false;
-      for (uint32_t h = first_of(); !done_of(h); h = next_of(h)) {
-        const NbNode &x = nodes[h];
-        const bool unk = x.id == d.unk_id;
-        if (unk && bf) {
-          for (uint32_t t = 0; t < x.byte_len; ++t) {
-            const uint32_t b = norm[x.byte_begin + t];
-            const int nbt = b == spb ? 3 : 1;
-            for (int y = 0; y < nbt; ++y) {
-              if (pass == 1) dst[reverse ? body - 1 - k : k] = d.byte_ids[b == spb ? (y == 0 ? 0xE2u : (y == 1 ? 0x96u : 0x81u)) : b];
-              ++k;
-            }
-          }
-        } else if (!(unk && prev_unk)) {
-          if (pass == 1) dst[reverse ? body - 1 - k : k] = x.id;
-          ++k;
-        }
-        prev_unk = unk;
-      }
+      for (uint32_t h = first_of(); !done_of(h); h = next_of(h)) put_node(nodes[h], dst, body, k, prev_unk, last);
       body = k;
     }
     res_score[a.res_count[s]] = score;
@@ -356,30 +383,11 @@ SPMX_DEVICE void nbest_lane(const NBestArgs &a, uint32_t s, uint8_t *mine) {
         if (pass == 1) {
           dst = alloc(body + n_extra);
           if (!dst) return;
-          for (int x = 0; x < d.n_prefix; ++x) dst[x] = d.prefix_ids[x];
-          for (int x = 0; x < d.n_suffix; ++x) dst[d.n_prefix + body + x] = d.suffix_ids[x];
-          dst += d.n_prefix;
+          dst = put_extras(dst, body);
         }
-        int k = 0;
+        int k = 0, last = 0;
         bool prev_unk = false;
-        for (uint32_t h = hy[top].next; hy[h].next != 0xFFFFFFFFu; h = hy[h].next) {
-          const NbNode &x = nodes[hy[h].node];
-          const bool unk = x.id == d.unk_id;
-          if (unk && bf) {
-            for (uint32_t t = 0; t < x.byte_len; ++t) {
-              const uint32_t b = norm[x.byte_begin + t];
-              const int nbt = b == spb ? 3 : 1;
-              for (int y = 0; y < nbt; ++y) {
-                if (pass == 1) dst[reverse ? body - 1 - k : k] = d.byte_ids[b == spb ? (y == 0 ? 0xE2u : (y == 1 ? 0x96u : 0x81u)) : b];
-                ++k;
-              }
-            }
-          } else if (!(unk && prev_unk)) {
-            if (pass == 1) dst[reverse ? body - 1 - k : k] = x.id;
-            ++k;
-          }
-          prev_unk = unk;
-        }
+        for (uint32_t h = hy[top].next; hy[h].next != 0xFFFFFFFFu; h = hy[h].next) put_node(nodes[hy[h].node], dst, body, k, prev_unk, last);
         body = k;
       }
       res_score[n_res] = hy[top].fx;

@@ -588,6 +588,160 @@ class SentencePieceProcessor:
 
     nbest_encode_as_ids = NBestEncodeAsIds
 
+    def _spans_arrays(self, ptrs, total):
+        out = []
+        for p in ptrs:
+            out.append(np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(total,)).copy()
+                       if total else np.zeros(0, dtype=np.uint32))
+        return out
+
+    def NBestSpansPacked(self, text, offsets, nbest_size):
+        """As NBestPacked, plus per id of every result the byte range of the input (``begin`` / ``end``) and of the
+        normalized text (``nbegin`` / ``nend``) its piece covers: ``(ids, id_offsets, scores, result_offsets, begin, end,
+        nbegin, nend)`` (``NBestEncode(input, nbest_size, NBestSentencePieceText *)``,
+        src/sentencepiece_processor.cc:653-676)."""
+        self._need()
+        self._apply(False, False, False)
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offs) - 1
+        ps = [C.c_void_p() for _ in range(8)]
+        self._check(self._lib.spmx_nbest_encode_batch_spans(self._h, text.ctypes.data if len(text) else None, offs.ctypes.data, n,
+                                                            int(nbest_size), *[C.byref(p) for p in ps]))
+        try:
+            ro = np.ctypeslib.as_array(C.cast(ps[3], C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+            R = int(ro[n])
+            io = np.ctypeslib.as_array(C.cast(ps[1], C.POINTER(C.c_uint64)), shape=(R + 1,)).copy()
+            total = int(io[R])
+            ids = (np.ctypeslib.as_array(C.cast(ps[0], C.POINTER(C.c_int32)), shape=(total,)).copy()
+                   if total else np.zeros(0, dtype=np.int32))
+            sc = (np.ctypeslib.as_array(C.cast(ps[2], C.POINTER(C.c_float)), shape=(R,)).copy()
+                  if R else np.zeros(0, dtype=np.float32))
+            b, e, nb, ne = self._spans_arrays(ps[4:], total)
+        finally:
+            for p in ps:
+                self._lib.spmx_free(p)
+        return ids, io, sc, ro, b, e, nb, ne
+
+    def SampleSpansPacked(self, text, offsets, nbest_size, alpha, seed=0):
+        """``SampleEncode(input, nbest_size, alpha, SentencePieceText *)`` per sentence: ``(ids, id_offsets, begin, end,
+        nbegin, nend)`` of the drawn segmentations."""
+        self._need()
+        self._apply(False, False, False)
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offs) - 1
+        ps = [C.c_void_p() for _ in range(6)]
+        self._check(self._lib.spmx_sample_encode_batch_spans(self._h, text.ctypes.data if len(text) else None, offs.ctypes.data, n,
+                                                             int(nbest_size), C.c_float(alpha), int(seed), *[C.byref(p) for p in ps]))
+        try:
+            io = np.ctypeslib.as_array(C.cast(ps[1], C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+            total = int(io[n])
+            ids = (np.ctypeslib.as_array(C.cast(ps[0], C.POINTER(C.c_int32)), shape=(total,)).copy()
+                   if total else np.zeros(0, dtype=np.int32))
+            b, e, nb, ne = self._spans_arrays(ps[2:], total)
+        finally:
+            for p in ps:
+                self._lib.spmx_free(p)
+        return ids, io, b, e, nb, ne
+
+    def _rows_from_spans(self, raw, norm, no, sent_of_row, ids, io, b, e, nb, ne):
+        """Rows of ``(piece, id, surface | None, begin, end)`` (PopulateSentencePieceText's fields, all bytes) for the CSR
+        rows ``io``; row r belongs to sentence ``sent_of_row[r]``.  surface None: a field the reference leaves unset."""
+        from . import spt_proto
+        unk_opt = any(o in ("unk", "unk_piece") for o in (self._extra or "").split(":"))
+        rev = sum(1 for o in (self._extra or "").split(":") if o == "reverse") % 2 == 1
+        out = []
+        for r in range(len(io) - 1):
+            i = sent_of_row[r]
+            base = int(no[i])
+            lo, hi = int(io[r]), int(io[r + 1])
+            has = spt_proto.surface_flags(ids[lo:hi], nb[lo:hi], self.IsByte, self.IsControl, rev)
+            row = []
+            for k in range(lo, hi):
+                t = int(ids[k])
+                if unk_opt and self.IsUnknown(t):
+                    piece = self.unk_piece().encode("utf-8")
+                elif self.IsByte(t) or self.IsControl(t):
+                    piece = self.IdToPiece(t).encode("utf-8")
+                else:
+                    piece = norm[base + int(nb[k]):base + int(ne[k])]
+                row.append((piece, t, raw[i][int(b[k]):int(e[k])] if has[k - lo] else None, int(b[k]), int(e[k])))
+            out.append(row)
+        return out
+
+    def _pack_items(self, input):
+        single = isinstance(input, (str, bytes))
+        items = [input] if single else list(input)
+        raw = [x.encode("utf-8") if isinstance(x, str) else bytes(x) for x in items]
+        offs = np.zeros(len(raw) + 1, dtype=np.uint64)
+        if raw:
+            np.cumsum([len(x) for x in raw], out=offs[1:])
+        return single, raw, np.frombuffer(b"".join(raw), dtype=np.uint8), offs
+
+    def NBestEncodeAsSentencePieceText(self, input, nbest_size):
+        """Per sentence the list of its results, best first, each ``(score, rows)`` with rows of ``(piece, id, surface |
+        None, begin, end)`` (bytes): the fields of ``NBestSentencePieceText`` (src/sentencepiece.proto)."""
+        single, raw, text, offs = self._pack_items(input)
+        ids, io, sc, ro, b, e, nb, ne = self.NBestSpansPacked(text, offs, nbest_size)
+        norm, no, _ = self.NormalizePacked(text, offs)
+        sent = [s for s in range(len(raw)) for _ in range(int(ro[s]), int(ro[s + 1]))]
+        rows = self._rows_from_spans(raw, norm.tobytes(), no, sent, ids, io, b, e, nb, ne)
+        out = [[(float(sc[r]), rows[r]) for r in range(int(ro[s]), int(ro[s + 1]))] for s in range(len(raw))]
+        return out[0] if single else out
+
+    def NBestEncodeAsPieces(self, input, nbest_size):
+        """``NBestEncodeAsPieces`` (src/sentencepiece_processor.h:318-320; python ``nbest_encode_as_pieces``)."""
+        single = isinstance(input, (str, bytes))
+        res = self.NBestEncodeAsSentencePieceText([input] if single else input, nbest_size)
+        out = [[[p.decode("utf-8", "surrogateescape") for p, *_ in rows] for _, rows in per] for per in res]
+        return out[0] if single else out
+
+    def NBestEncodeAsSerializedProto(self, input, nbest_size):
+        """``NBestEncodeAsSerializedProto`` (src/sentencepiece_processor.h:545-550): the serialized
+        ``NBestSentencePieceText`` of every sentence (each result carries its score)."""
+        from . import spt_proto
+        single, raw, _, _ = self._pack_items(input)
+        res = self.NBestEncodeAsSentencePieceText(raw, nbest_size)
+        out = [spt_proto.serialize_nbest([spt_proto.serialize(raw[i], rows, score) for score, rows in per])
+               for i, per in enumerate(res)]
+        return out[0] if single else out
+
+    nbest_encode_as_pieces = NBestEncodeAsPieces
+    nbest_encode_as_serialized_proto = NBestEncodeAsSerializedProto
+
+    def SampleEncodeAsSentencePieceText(self, input, nbest_size, alpha, seed=None):
+        """The drawn segmentation of every sentence as rows of ``(piece, id, surface | None, begin, end)``
+        (``SampleEncode(input, nbest_size, alpha, SentencePieceText *)``, src/sentencepiece_processor.cc:678-720)."""
+        if seed is None:
+            if not hasattr(self, "_sample_calls"):
+                self._sample_calls = int.from_bytes(os.urandom(7), "little")
+            self._sample_calls += 1
+            seed = self._sample_calls
+        single, raw, text, offs = self._pack_items(input)
+        ids, io, b, e, nb, ne = self.SampleSpansPacked(text, offs, nbest_size, alpha, seed)
+        norm, no, _ = self.NormalizePacked(text, offs)
+        rows = self._rows_from_spans(raw, norm.tobytes(), no, list(range(len(raw))), ids, io, b, e, nb, ne)
+        return rows[0] if single else rows
+
+    def SampleEncodeAsPieces(self, input, nbest_size, alpha, seed=None):
+        """``SampleEncodeAsPieces`` (src/sentencepiece_processor.h:404-408; python ``sample_encode_as_pieces``)."""
+        single = isinstance(input, (str, bytes))
+        rows = self.SampleEncodeAsSentencePieceText([input] if single else input, nbest_size, alpha, seed)
+        out = [[p.decode("utf-8", "surrogateescape") for p, *_ in row] for row in rows]
+        return out[0] if single else out
+
+    def SampleEncodeAsSerializedProto(self, input, nbest_size, alpha, seed=None):
+        """``SampleEncodeAsSerializedProto`` (src/sentencepiece_processor.h:539-543)."""
+        from . import spt_proto
+        single, raw, _, _ = self._pack_items(input)
+        rows = self.SampleEncodeAsSentencePieceText(raw, nbest_size, alpha, seed)
+        out = [spt_proto.serialize(raw[i], rows[i]) for i in range(len(raw))]
+        return out[0] if single else out
+
+    sample_encode_as_pieces = SampleEncodeAsPieces
+    sample_encode_as_serialized_proto = SampleEncodeAsSerializedProto
+
     # -------------------------------------------------------- normalize ----
     def NormalizePacked(self, text, offsets, with_offsets=False):
         """Packed host arrays -> ``(normalized uint8, norm_offsets uint64[n + 1], norm_to_orig | None)``.

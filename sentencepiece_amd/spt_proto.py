@@ -35,8 +35,11 @@ def _uint_field(num, v):
     return _varint(num << 3) + _varint(v)
 
 
-def serialize(text, pieces):
-    """``text`` bytes; ``pieces`` iterable of ``(piece bytes, id, surface bytes | None, begin, end)``."""
+def serialize(text, pieces, score=None):
+    """``text`` bytes; ``pieces`` iterable of ``(piece bytes, id, surface bytes | None, begin, end)``; ``score``: the
+    float NBestEncode sets on every result (src/sentencepiece_processor.cc:670), None where the reference leaves the
+    field unset (Encode, SampleEncode)."""
+    import struct
     out = bytearray(_bytes_field(1, text))
     for piece, pid, surface, begin, end in pieces:
         m = _bytes_field(1, piece) + _uint_field(2, pid)
@@ -44,7 +47,14 @@ def serialize(text, pieces):
             m += _bytes_field(3, surface)
         m += _uint_field(4, begin) + _uint_field(5, end)
         out += _bytes_field(2, m)
+    if score is not None:
+        out += _varint(3 << 3 | 5) + struct.pack("<f", score)
     return bytes(out)
+
+
+def serialize_nbest(blobs):
+    """``NBestSentencePieceText { repeated SentencePieceText nbests = 1; }`` from the serialized results."""
+    return b"".join(_bytes_field(1, b) for b in blobs)
 
 
 def surface_flags(ids, nbegin, is_byte, is_control, reversed_order):

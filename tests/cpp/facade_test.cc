@@ -108,6 +108,37 @@ int main(int argc, char **argv) {
     const sentencepiece::util::Status so = sp.EncodeOriginal(probe, &orig);   // unigram only (INTERNAL for BPE, like NBestEncode)
     if (so.ok()) { std::string t3; if (!sp.Decode(orig, &t3).ok() || t3 != t1) { fprintf(stderr, "EncodeOriginal\n"); return 1; } }
   }
+  {   // piece / proto forms of NBestEncode and SampleEncode (sentencepiece_processor.h:318-324, :346-348, :404-408)
+    const std::string &probe = lines.size() > 7 ? lines[7] : lines[0];
+    std::vector<std::vector<int>> nids;
+    sentencepiece::NBestSentencePieceText nb;
+    std::vector<std::vector<std::string>> npc;
+    const sentencepiece::util::Status a = sp.NBestEncode(probe, 3, &nids), b2 = sp.NBestEncode(probe, 3, &nb), c2 = sp.NBestEncode(probe, 3, &npc);
+    if (a.ok() != b2.ok() || a.ok() != c2.ok()) { fprintf(stderr, "NBestEncode forms disagree on the status\n"); return 1; }
+    if (a.ok()) {
+      if (nb.nbests.size() != nids.size() || npc.size() != nids.size() || sp.NBestEncodeAsPieces(probe, 3) != npc) { fprintf(stderr, "NBestEncode forms disagree on the count\n"); return 1; }
+      for (size_t r = 0; r < nids.size(); ++r) {
+        const auto &spt = nb.nbests[r];
+        if (spt.text != probe || spt.pieces.size() != nids[r].size() || npc[r].size() != nids[r].size()) { fprintf(stderr, "NBestEncode(spt) shape\n"); return 1; }
+        if (r > 0 && spt.score > nb.nbests[r - 1].score) { fprintf(stderr, "NBestEncode(spt) scores are not descending\n"); return 1; }
+        for (size_t k = 0; k < spt.pieces.size(); ++k) {
+          const auto &p = spt.pieces[k];
+          if (static_cast<int>(p.id) != nids[r][k] || p.piece != npc[r][k] || p.begin > p.end || p.end > probe.size() ||
+              p.surface != probe.substr(p.begin, p.end - p.begin)) { fprintf(stderr, "NBestEncode(spt) piece %zu of result %zu\n", k, r); return 1; }
+        }
+      }
+    }
+    sentencepiece::SentencePieceText plain, s1, drawn;
+    std::vector<std::string> dp;
+    if (!sp.Encode(probe, &plain).ok() || !sp.SampleEncode(probe, 1, 0.0f, &s1).ok() || s1.pieces.size() != plain.pieces.size()) { fprintf(stderr, "SampleEncode(spt, nbest 1)\n"); return 1; }
+    for (size_t k = 0; k < plain.pieces.size(); ++k)
+      if (s1.pieces[k].piece != plain.pieces[k].piece || s1.pieces[k].id != plain.pieces[k].id || s1.pieces[k].begin != plain.pieces[k].begin ||
+          s1.pieces[k].end != plain.pieces[k].end) { fprintf(stderr, "SampleEncode(spt, nbest 1) piece %zu\n", k); return 1; }
+    std::vector<int> di;
+    if (!sp.SampleEncode(probe, -1, 0.2f, 99, &drawn).ok() || !sp.SampleEncode(probe, -1, 0.2f, 99, &di).ok() || drawn.pieces.size() != di.size()) { fprintf(stderr, "SampleEncode(spt)\n"); return 1; }
+    for (size_t k = 0; k < di.size(); ++k) if (static_cast<int>(drawn.pieces[k].id) != di[k]) { fprintf(stderr, "SampleEncode(spt) ids\n"); return 1; }
+    if (!sp.SampleEncode(probe, -1, 0.2f, &dp).ok() || dp.empty() != probe.empty()) { fprintf(stderr, "SampleEncode(pieces)\n"); return 1; }
+  }
   if (sp.GetPieceSize() <= 0 || sp.IdToPiece(sp.unk_id()).empty() || sp.PieceToId(sp.IdToPiece(5)) != 5) { fprintf(stderr, "vocab accessors\n"); return 1; }
   if (sp.Encode("x", static_cast<std::vector<int> *>(nullptr)).ok()) { fprintf(stderr, "null output accepted\n"); return 1; }
   return 0;
