@@ -32,6 +32,10 @@ def main():
         m = n if k <= 5 else n // 8
         t2, o2 = text[:int(offs[m])], offs[:m + 1]
         out["nbest%d" % k] = rate(lambda: sp.NBestPacked(t2, o2, k), m)
+    m8 = n // 8
+    t8, o8 = text[:int(offs[m8])], offs[:m8 + 1]
+    out["nbest5_eighth_of_the_batch"] = rate(lambda: sp.NBestPacked(t8, o8, 5), m8)     # (16 and 64 above run on this eighth)
+    out["nbest5_spans"] = rate(lambda: sp.NBestSpansPacked(text, offs, 5), n)
     out["sample_lattice"] = rate(lambda: sp.SampleEncodePacked(text, offs, -1, 0.1, seed=1), n)
     out["sample_nbest8"] = rate(lambda: sp.SampleEncodePacked(text, offs, 8, 0.1, seed=1), n)
     out["original_viterbi"] = rate(lambda: sp.EncodeOriginalPacked(text, offs), n)

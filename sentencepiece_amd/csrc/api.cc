@@ -250,6 +250,8 @@ struct spmx_handle {
   std::atomic<int> word_backoff{0};   // calls that leave the word rounds out (they did not pay on the last batch that tried)
   bool no_word = false;          // SPMX_NO_WORD_KERNEL=1: unigram models skip the word kernels (kernels_word.h)
   bool no_word_dp = false;       // SPMX_NO_WORD_DP=1: ... skip the second pass only
+  uint64_t nbest_budget = 32ull << 30;  // SPMX_NBEST_BUDGET_GB: HBM the lattice slices of one launch may take (200 k sentences, n-best 5: 0.83 M sentences/s at 8 GB, 1.15 M at 32, 1.19 M at 96)
+  uint32_t nbest_hyps_min = 16384;   // SPMX_NBEST_HYPS_MIN: hypotheses a lane's A* may hold in the first launch (what outgrows it runs again)
   uint32_t tile_min_lanes = 1;   // SPMX_TILE_MIN_LANES: a main tile has at least this many sentences even when that leaves wavefronts without a tile of the class
   int fork_waves = 0;            // SPMX_FORK_WAVES: wavefronts per workgroup of the general launch while it runs next to the second word round (0: as planned)
   bool no_overlap = false;       // SPMX_NO_OVERLAP=1: the general launches do not run next to the second word round
@@ -1331,6 +1333,8 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_NO_WORD_DYN")) h->no_word_dyn = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_OVERLAP")) h->no_overlap = e[0] == '1';
     if (const char *e = getenv("SPMX_FORK_WAVES")) h->fork_waves = atoi(e);
+    if (const char *e = getenv("SPMX_NBEST_BUDGET_GB")) { const long v = atol(e); if (v >= 1 && v <= 200) h->nbest_budget = static_cast<uint64_t>(v) << 30; }
+    if (const char *e = getenv("SPMX_NBEST_HYPS_MIN")) { const long v = atol(e); if (v >= 1024 && v <= 262144) h->nbest_hyps_min = static_cast<uint32_t>(v); }
     if (const char *e = getenv("SPMX_TILE_MIN_LANES")) h->tile_min_lanes = static_cast<uint32_t>(atoi(e));
     if (getenv("SPMX_WORDMEMO_UNSAFE")) h->memo_unsafe = true;
     if (const char *e = getenv("SPMX_NO_UNI_WAVE")) h->no_uni_wave = e[0] == '1';
@@ -1958,8 +1962,9 @@ int LatticeBatchHost(spmx_handle *h, const char *text, const uint64_t *offsets, 
     a.dev = h->dev; a.norm = ws->d_norm.p; a.norm_offs = ws->d_id_offs.p; a.n = static_cast<uint32_t>(n); a.nbest = K;
     a.mode = static_cast<uint32_t>(mode); a.inv_theta = inv_theta; a.seed = seed;
     const uint64_t hyps0 = static_cast<uint64_t>(K) * 2048;
-    const uint32_t max_hyps0 = mode != 0 ? 512u : static_cast<uint32_t>(hyps0 < 16384 ? 16384 : (hyps0 > 262144 ? 262144 : hyps0));
-    const uint64_t budget = 8ull << 30;                       // HBM for the lanes' slices
+    const uint64_t hyps_min = h->nbest_hyps_min;
+    const uint32_t max_hyps0 = mode != 0 ? 512u : static_cast<uint32_t>(hyps0 < hyps_min ? hyps_min : (hyps0 > 262144 ? 262144 : hyps0));
+    const uint64_t budget = h->nbest_budget;                  // HBM for the lanes' slices
     HIP_OR_RETURN(h, ws->d_res_off.Reserve(n * K + 1));
     HIP_OR_RETURN(h, ws->d_span_begin.Reserve(n * K + 1));     // result lengths
     HIP_OR_RETURN(h, ws->d_res_score.Reserve(n * K + 1));
