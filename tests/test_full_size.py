@@ -6,6 +6,8 @@ properties that do not need a CPU pass over all of it:
     (decode gives the normalized surface form; normalizing and segmenting it again must give the same ids);
   * the CSR is well formed (offsets monotone, ids in range) and the id-only, spans and split paths agree on it.
 """
+import functools
+
 import numpy as np
 import pytest
 
@@ -14,6 +16,13 @@ from tests import fixtures
 pytestmark = pytest.mark.gpu
 
 N = 10_000_000
+
+
+@functools.lru_cache(maxsize=2)
+def _corpus(kind, n, seed):
+    """The synthetic corpora are the same for both models of a pair: generated once (seconds of numpy each)."""
+    from sentencepiece_amd import synth
+    return synth.ascii_corpus(n, seed=seed) if kind == "ascii" else synth.mixed_corpus(n, seed=seed)
 
 
 def _flat_clean(d_ids, d_io, clean):
@@ -29,7 +38,7 @@ def test_full_size_sample_and_idempotence(model, oracle):
     from sentencepiece_amd import synth
     from sentencepiece_amd.processor import SentencePieceProcessor
     blob = fixtures.model_blob(model)
-    text, offs = synth.ascii_corpus(N, seed=20250227)
+    text, offs = _corpus("ascii", N, 20250227)
     sp = SentencePieceProcessor(model_proto=blob)
     dev = torch.device("cuda", 0)
     d_text = torch.from_numpy(text).to(dev)
@@ -74,7 +83,7 @@ def test_c5_full_size_sample_and_idempotence(model, oracle):
     from sentencepiece_amd.processor import SentencePieceProcessor
     n = 1_000_000
     blob = fixtures.model_blob(model)
-    text, offs = synth.mixed_corpus(n, seed=20250228)
+    text, offs = _corpus("mixed", n, 20250228)
     sp = SentencePieceProcessor(model_proto=blob)
     dev = torch.device("cuda", 0)
     d_text = torch.from_numpy(text).to(dev)
