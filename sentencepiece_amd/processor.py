@@ -214,7 +214,38 @@ class SentencePieceProcessor:
         out_type = self._out_type if out_type is None else out_type
         if (self._enable_sampling if enable_sampling is None else enable_sampling):
             if out_type is not int:
-                raise NotImplementedError("sampling is on the device path for out_type=int")
+                # _SampleEncodeAsPieces / ...AsSerializedProto / ...AsImmutableProto (sentencepiece.i): the drawn
+                # segmentation with its pieces, surfaces and byte ranges (spmx_sample_encode_batch_spans)
+                nb = int(self._nbest_size if nbest_size is None else nbest_size)
+                al = float(self._alpha if alpha is None else alpha)
+                if out_type is str or out_type == "str":
+                    self._apply(self._add_bos if add_bos is None else add_bos, self._add_eos if add_eos is None else add_eos,
+                                self._reverse if reverse is None else reverse)
+                    try:
+                        single = not isinstance(input, list)
+                        rows = self.SampleEncodeAsPieces([input] if single else input, nb, al, _keep_options=True)
+                    finally:
+                        self._apply(False, False, False)
+                    emit = self._emit_unk_piece if emit_unk_piece is None else emit_unk_piece
+                    if emit:
+                        unk = self.IdToPiece(self.unk_id())
+                        rows = [[unk if self.PieceToId(p) == self.unk_id() else p for p in row] for row in rows]
+                    return rows[0] if single else rows
+                if any([add_bos, add_eos, reverse, emit_unk_piece]):     # sentencepiece.i:177-186
+                    raise NotImplementedError("add_bos, add_eos, reverse, and emit_unk_piece is not supported in proto API")
+                if out_type == "serialized_proto":
+                    return self.SampleEncodeAsSerializedProto(input, nb, al)
+                if out_type == "immutable_proto":
+                    from . import spt_proto
+                    single, raw, _, _ = self._pack_items(input)
+                    if not hasattr(self, "_sample_calls"):
+                        self._sample_calls = int.from_bytes(os.urandom(7), "little")
+                    self._sample_calls += 1
+                    rows = self.SampleEncodeAsSentencePieceText(raw, nb, al, seed=self._sample_calls)
+                    out = [spt_proto.ImmutableSentencePieceText(r, [(p, t, sf if sf is not None else b"", b, e) for p, t, sf, b, e in rows[i]],
+                                                               spt_proto.serialize(r, rows[i])) for i, r in enumerate(raw)]
+                    return out[0] if single else out
+                raise RuntimeError("unknown out_type=%r" % (out_type,))
             # _SampleEncodeAsIds (sentencepiece.i): SampleEncode + RewriteIds; the draws are keyed by a fresh seed per call
             # (a per-process counter started from os.urandom: a fresh process does not replay the previous one's draws --
             # the reference seeds its generator from std::random_device, src/util.cc:202-204)
@@ -623,11 +654,12 @@ class SentencePieceProcessor:
                 self._lib.spmx_free(p)
         return ids, io, sc, ro, b, e, nb, ne
 
-    def SampleSpansPacked(self, text, offsets, nbest_size, alpha, seed=0):
+    def SampleSpansPacked(self, text, offsets, nbest_size, alpha, seed=0, _keep_options=False):
         """``SampleEncode(input, nbest_size, alpha, SentencePieceText *)`` per sentence: ``(ids, id_offsets, begin, end,
         nbegin, nend)`` of the drawn segmentations."""
         self._need()
-        self._apply(False, False, False)
+        if not _keep_options:         # (Encode(out_type=str, enable_sampling=True) has compiled add_bos / add_eos / reverse in)
+            self._apply(False, False, False)
         text = np.ascontiguousarray(text, dtype=np.uint8)
         offs = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = len(offs) - 1
@@ -649,8 +681,8 @@ class SentencePieceProcessor:
         """Rows of ``(piece, id, surface | None, begin, end)`` (PopulateSentencePieceText's fields, all bytes) for the CSR
         rows ``io``; row r belongs to sentence ``sent_of_row[r]``.  surface None: a field the reference leaves unset."""
         from . import spt_proto
-        unk_opt = any(o in ("unk", "unk_piece") for o in (self._extra or "").split(":"))
-        rev = sum(1 for o in (self._extra or "").split(":") if o == "reverse") % 2 == 1
+        unk_opt = any(o in ("unk", "unk_piece") for o in (self._applied or "").split(":"))
+        rev = sum(1 for o in (self._applied or "").split(":") if o == "reverse") % 2 == 1
         out = []
         for r in range(len(io) - 1):
             i = sent_of_row[r]
@@ -710,7 +742,7 @@ class SentencePieceProcessor:
     nbest_encode_as_pieces = NBestEncodeAsPieces
     nbest_encode_as_serialized_proto = NBestEncodeAsSerializedProto
 
-    def SampleEncodeAsSentencePieceText(self, input, nbest_size, alpha, seed=None):
+    def SampleEncodeAsSentencePieceText(self, input, nbest_size, alpha, seed=None, _keep_options=False):
         """The drawn segmentation of every sentence as rows of ``(piece, id, surface | None, begin, end)``
         (``SampleEncode(input, nbest_size, alpha, SentencePieceText *)``, src/sentencepiece_processor.cc:678-720)."""
         if seed is None:
@@ -719,15 +751,15 @@ class SentencePieceProcessor:
             self._sample_calls += 1
             seed = self._sample_calls
         single, raw, text, offs = self._pack_items(input)
-        ids, io, b, e, nb, ne = self.SampleSpansPacked(text, offs, nbest_size, alpha, seed)
+        ids, io, b, e, nb, ne = self.SampleSpansPacked(text, offs, nbest_size, alpha, seed, _keep_options=_keep_options)
         norm, no, _ = self.NormalizePacked(text, offs)
         rows = self._rows_from_spans(raw, norm.tobytes(), no, list(range(len(raw))), ids, io, b, e, nb, ne)
         return rows[0] if single else rows
 
-    def SampleEncodeAsPieces(self, input, nbest_size, alpha, seed=None):
+    def SampleEncodeAsPieces(self, input, nbest_size, alpha, seed=None, _keep_options=False):
         """``SampleEncodeAsPieces`` (src/sentencepiece_processor.h:404-408; python ``sample_encode_as_pieces``)."""
         single = isinstance(input, (str, bytes))
-        rows = self.SampleEncodeAsSentencePieceText([input] if single else input, nbest_size, alpha, seed)
+        rows = self.SampleEncodeAsSentencePieceText([input] if single else input, nbest_size, alpha, seed, _keep_options=_keep_options)
         out = [[p.decode("utf-8", "surrogateescape") for p, *_ in row] for row in rows]
         return out[0] if single else out
 

@@ -191,3 +191,32 @@ def test_gpu_lattice_piece_forms_options_and_tiling(corpora):
     from sentencepiece_amd.processor import SentencePieceProcessor
     check_options_and_tiling(lambda blob: SentencePieceProcessor(model_proto=blob), corpora, n_sent=120)
     check_bpe_sample_pieces(lambda blob: SentencePieceProcessor(model_proto=blob), corpora)
+
+
+def check_python_encode_sampling_out_types(make_sp):
+    """encode(enable_sampling=True, out_type=str / "serialized_proto" / "immutable_proto") (python/src/sentencepiece/
+    __init__.py Encode -> _SampleEncodeAsPieces / ...Proto): nbest_size 1 is the plain encoder's answer; drawn pieces
+    spell the normalized text; add_bos / add_eos / reverse apply to the piece form and are refused by the proto forms."""
+    sp = make_sp(fixtures.model_blob("test_model"))
+    s = "Hello world, this is a test."
+    assert sp.Encode(s, out_type=str, enable_sampling=True, nbest_size=1, alpha=0.5) == sp.Encode(s, out_type=str)
+    assert (sp.Encode([s, "x y"], out_type=str, enable_sampling=True, nbest_size=1, alpha=0.5, add_bos=True, add_eos=True, reverse=True)
+            == sp.Encode([s, "x y"], out_type=str, add_bos=True, add_eos=True, reverse=True))
+    assert sp.Encode(s, out_type="serialized_proto", enable_sampling=True, nbest_size=1, alpha=0.5) == sp.Encode(s, out_type="serialized_proto")
+    drawn = sp.Encode(s, out_type=str, enable_sampling=True, nbest_size=-1, alpha=0.2)
+    assert "".join(drawn) == "".join(sp.Encode(s, out_type=str))
+    imm = sp.Encode(s, out_type="immutable_proto", enable_sampling=True, nbest_size=-1, alpha=0.2)
+    assert imm.text == s and "".join(p.surface for p in imm.pieces) == s and len(parse_spt(imm.SerializeAsString())[1]) == len(imm.pieces)
+    with pytest.raises(NotImplementedError):
+        sp.Encode(s, out_type="serialized_proto", enable_sampling=True, nbest_size=-1, alpha=0.2, add_bos=True)
+    assert sp.Encode(s, out_type=str) == sp.EncodeAsPieces(s)            # (the options of the sampling calls did not stick)
+
+
+def test_emu_python_encode_sampling_out_types(emu):
+    check_python_encode_sampling_out_types(lambda blob: emu.load(blob).sp)
+
+
+@pytest.mark.gpu
+def test_gpu_python_encode_sampling_out_types():
+    from sentencepiece_amd.processor import SentencePieceProcessor
+    check_python_encode_sampling_out_types(lambda blob: SentencePieceProcessor(model_proto=blob))
