@@ -97,8 +97,7 @@ static PyObject *csr_to_lists(PyObject *self, PyObject *args) {
     const uint64_t b = offs[i], e = offs[i + 1];
     PyObject *inner = PyList_New((Py_ssize_t)(e - b));
     if (!inner) { ret = NULL; break; }
-    for (uint64_t k = b; k < e; ++k) PyList_SET_ITEM(inner, (Py_ssize_t)(k - b), NULL);
-    PyList_SET_ITEM(outer, i, inner);
+    PyList_SET_ITEM(outer, i, inner);      /* (PyList_New zero-fills the items: a half-built list is safe to release) */
     for (uint64_t k = b; k < e; ++k) {
       const long id = (long)ids[k];
       PyObject *v;
