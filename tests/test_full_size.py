@@ -1,7 +1,7 @@
 """BASELINE.json's full size (configs[1] / configs[2]: 10 M synthetic sentences, 32k models) on the GPU, checked through
 properties that do not need a CPU pass over all of it:
 
-  * a strided sample of the batch's ids equals the oracle's, bit for bit;
+  * a strided sample of the batch's ids equals the oracle's AND the compiled reference's (oracle/_ref), bit for bit;
   * idempotence: encode(decode(encode(x))) == encode(x) for every sentence without an unknown piece
     (decode gives the normalized surface form; normalizing and segmenting it again must give the same ids);
   * the CSR is well formed (offsets monotone, ids in range) and the id-only, spans and split paths agree on it.
@@ -23,6 +23,17 @@ def _corpus(kind, n, seed):
     """The synthetic corpora are the same for both models of a pair: generated once (seconds of numpy each)."""
     from sentencepiece_amd import synth
     return synth.ascii_corpus(n, seed=seed) if kind == "ascii" else synth.mixed_corpus(n, seed=seed)
+
+
+def _same_as_the_compiled_reference(blob, st, so, oids, oio):
+    """The sample's ids from the compiled reference itself (oracle/_ref, where it is built) next to the oracle's: the
+    full-size checks are then pinned to the reference directly, not only through the restatement."""
+    from tests import refshim
+    if not refshim.available():
+        return
+    rids, rio = refshim.RefLib().load(blob).encode_batch(st, so, threads=16)
+    np.testing.assert_array_equal(np.asarray(rio), np.asarray(oio))
+    np.testing.assert_array_equal(np.asarray(rids), np.asarray(oids))
 
 
 def _flat_clean(d_ids, d_io, clean):
@@ -53,6 +64,7 @@ def test_full_size_sample_and_idempotence(model, oracle):
     pick = np.linspace(0, N - 1, num=60_000).astype(np.int64)
     st, so = synth.gather_packed(text, offs, pick)
     oids, oio = oracle.load(blob).encode_batch(st, so)
+    _same_as_the_compiled_reference(blob, st, so, oids, oio)
     io_h = d_io.cpu().numpy()
     lens = (io_h[1:] - io_h[:-1])[pick]
     np.testing.assert_array_equal(lens, np.diff(np.asarray(oio).astype(np.int64)))
@@ -96,6 +108,7 @@ def test_c5_full_size_sample_and_idempotence(model, oracle):
     pick = np.linspace(0, n - 1, num=20_000).astype(np.int64)
     st, so = synth.gather_packed(text, offs, pick)
     oids, oio = oracle.load(blob).encode_batch(st, so)
+    _same_as_the_compiled_reference(blob, st, so, oids, oio)
     io_h = d_io.cpu().numpy()
     lens = (io_h[1:] - io_h[:-1])[pick]
     np.testing.assert_array_equal(lens, np.diff(np.asarray(oio).astype(np.int64)))
