@@ -71,10 +71,23 @@ class SentencePieceProcessor:
             raise RuntimeError(self._lib.spmx_last_error(None).decode("utf-8", "replace"))
         self._h = h
         self._extra = self._applied = ""
+        self._model_proto = bytes(model_proto)
         return True
 
     LoadFromSerializedProto = lambda self, proto: self.Load(model_proto=proto)  # noqa: E731
     load = Load
+    load_from_serialized_proto = LoadFromSerializedProto
+
+    def LoadFromFile(self, arg):
+        """``LoadFromFile`` (python/src/sentencepiece/__init__.py:315-316)."""
+        return self.Load(model_file=arg)
+
+    load_from_file = LoadFromFile
+
+    def serialized_model_proto(self):
+        """The ModelProto the processor was loaded from (src/sentencepiece_processor.h:667)."""
+        self._need()
+        return self._model_proto
 
     def _close(self):
         if self._h:
@@ -773,6 +786,136 @@ class SentencePieceProcessor:
 
     sample_encode_as_pieces = SampleEncodeAsPieces
     sample_encode_as_serialized_proto = SampleEncodeAsSerializedProto
+
+    # ---- the remaining spellings of the reference's Python wrapper for this path (python/src/sentencepiece/__init__.py) ----
+    def SampleEncodeAsIds(self, input, nbest_size=None, alpha=None, **kwargs):
+        """``SampleEncodeAsIds`` (:586-588)."""
+        return self.Encode(input, nbest_size=nbest_size, alpha=alpha, out_type=int, enable_sampling=True, **kwargs)
+
+    def SampleEncodeAsImmutableProto(self, input, nbest_size=None, alpha=None, **kwargs):
+        """``SampleEncodeAsImmutableProto`` (:596-598)."""
+        return self.Encode(input, nbest_size=nbest_size, alpha=alpha, out_type="immutable_proto", enable_sampling=True, **kwargs)
+
+    sample_encode_as_ids = SampleEncodeAsIds
+    sample_encode_as_immutable_proto = SampleEncodeAsImmutableProto
+
+    def NBestEncode(self, input, out_type=None, add_bos=None, add_eos=None, reverse=None, emit_unk_piece=None, nbest_size=None):
+        """``NBestEncode`` (:601-656): out_type int | str | "serialized_proto" | "immutable_proto"; add_bos / add_eos /
+        reverse / emit_unk_piece rewrite the id and piece forms (RewriteIds, sentencepiece.i:138-164) and are refused by
+        the proto forms (:177-186)."""
+        from . import spt_proto
+        self._need()
+        out_type = self._out_type if out_type is None else out_type
+        a_bos = self._add_bos if add_bos is None else add_bos
+        a_eos = self._add_eos if add_eos is None else add_eos
+        rev = self._reverse if reverse is None else reverse
+        emit = self._emit_unk_piece if emit_unk_piece is None else emit_unk_piece
+        nb = self._nbest_size if nbest_size is None else nbest_size
+        if nb <= 0:
+            nb = 1
+        single, raw, text, offs = self._pack_items(input)
+        if out_type is int or out_type is str or out_type == "str":
+            self._apply(a_bos, a_eos, rev)
+            try:
+                ids, io, sc, ro, b, e, nbg, nen = self._nbest_spans_keep(text, offs, nb)
+                if out_type is int:
+                    out = [[ids[int(io[r]):int(io[r + 1])].tolist() for r in range(int(ro[s]), int(ro[s + 1]))] for s in range(len(raw))]
+                else:
+                    norm, no, _ = self.NormalizePacked(text, offs)
+                    sent = [s for s in range(len(raw)) for _ in range(int(ro[s]), int(ro[s + 1]))]
+                    rows = self._rows_from_spans(raw, norm.tobytes(), no, sent, ids, io, b, e, nbg, nen)
+                    unk = self.IdToPiece(self.unk_id())
+                    out = [[[(unk if emit and self.IsUnknown(t) else p.decode("utf-8", "surrogateescape")) for p, t, *_ in rows[r]]
+                            for r in range(int(ro[s]), int(ro[s + 1]))] for s in range(len(raw))]
+            finally:
+                self._apply(False, False, False)
+            return out[0] if single else out
+        if any([a_bos, a_eos, rev, emit]):
+            raise NotImplementedError("add_bos, add_eos, reverse, and emit_unk_piece is not supported in proto API")
+        if out_type in ("serialized_proto", "proto"):
+            return self.NBestEncodeAsSerializedProto(input, nb)
+        if out_type == "immutable_proto":
+            res = self.NBestEncodeAsSentencePieceText(raw, nb)
+            out = []
+            for i, per in enumerate(res):
+                views = []
+                for score, rows in per:
+                    v = spt_proto.ImmutableSentencePieceText(raw[i], [(p, t, sf if sf is not None else b"", pb, pe) for p, t, sf, pb, pe in rows],
+                                                             spt_proto.serialize(raw[i], rows, score))
+                    v.score = score
+                    views.append(v)
+                out.append(spt_proto.ImmutableNBestSentencePieceText(views))
+            return out[0] if single else out
+        raise RuntimeError("unknown out_type")
+
+    def _nbest_spans_keep(self, text, offs, nbest_size):
+        """NBestSpansPacked without resetting the options compiled into the handle (NBestEncode has applied its own)."""
+        n = len(offs) - 1
+        ps = [C.c_void_p() for _ in range(8)]
+        self._check(self._lib.spmx_nbest_encode_batch_spans(self._h, text.ctypes.data if len(text) else None, offs.ctypes.data, n,
+                                                            int(nbest_size), *[C.byref(p) for p in ps]))
+        try:
+            ro = np.ctypeslib.as_array(C.cast(ps[3], C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+            R = int(ro[n])
+            io = np.ctypeslib.as_array(C.cast(ps[1], C.POINTER(C.c_uint64)), shape=(R + 1,)).copy()
+            total = int(io[R])
+            ids = (np.ctypeslib.as_array(C.cast(ps[0], C.POINTER(C.c_int32)), shape=(total,)).copy()
+                   if total else np.zeros(0, dtype=np.int32))
+            sc = (np.ctypeslib.as_array(C.cast(ps[2], C.POINTER(C.c_float)), shape=(R,)).copy()
+                  if R else np.zeros(0, dtype=np.float32))
+            b, e, nb, ne = self._spans_arrays(ps[4:], total)
+        finally:
+            for p in ps:
+                self._lib.spmx_free(p)
+        return ids, io, sc, ro, b, e, nb, ne
+
+    def NBestEncodeAsImmutableProto(self, input, nbest_size=None, **kwargs):
+        """``NBestEncodeAsImmutableProto`` (:674-676): ``.nbests[i]`` with ``.score``, ``.text``, ``.pieces``."""
+        return self.NBestEncode(input, nbest_size=nbest_size, out_type="immutable_proto", **kwargs)
+
+    nbest_encode = NBestEncode
+    nbest_encode_as_immutable_proto = NBestEncodeAsImmutableProto
+
+    def Tokenize(self, input, **kwargs):
+        """``Tokenize`` = ``Encode`` (:1009-1010)."""
+        return self.Encode(input, **kwargs)
+
+    def Detokenize(self, input, **kwargs):
+        """``Detokenize`` = ``Decode`` (:1013-1014)."""
+        return self.Decode(input, **kwargs)
+
+    tokenize, detokenize = Tokenize, Detokenize
+
+    def DecodePieces(self, input, out_type=str, **kwargs):
+        """``DecodePieces`` (:871-872): pieces -> text.  Every piece must be in the vocabulary (the decode kernels take
+        ids; the reference copies a piece that is not in the vocabulary through as text, which ids cannot express)."""
+        single = not input or isinstance(input[0], (str, bytes))
+        items = [input] if single else input
+        unk = self.unk_id()
+        rows = []
+        for row in items:
+            ids = [self.PieceToId(p) for p in row]
+            for p, t in zip(row, ids):
+                if t == unk and (p.decode("utf-8", "replace") if isinstance(p, bytes) else p) != self.IdToPiece(unk):
+                    raise NotImplementedError("DecodePieces: %r is not a piece of the model" % (p,))
+            rows.append(ids)
+        out = self.Decode(rows, out_type=out_type, **kwargs)
+        return out[0] if single else out
+
+    decode_pieces = DecodePieces
+
+    def GetScore(self, id):
+        """``GetScore`` (:285-286): the piece's score from the ModelProto."""
+        self._need()
+        if not hasattr(self, "_scores") or self._scores[0] is not self._model_proto:
+            from . import model_proto_scores
+            self._scores = (self._model_proto, model_proto_scores.scores(self._model_proto))
+        if id < 0 or id >= len(self._scores[1]):
+            raise IndexError("piece id is out of range.")
+        return self._scores[1][id]
+
+    get_score = GetScore
+    get_piece_size = lambda self: self.GetPieceSize()  # noqa: E731
 
     # -------------------------------------------------------- normalize ----
     def NormalizePacked(self, text, offsets, with_offsets=False):

@@ -125,3 +125,19 @@ class ImmutableSentencePieceText:
 
     def __iter__(self):
         return iter(self.pieces)
+
+
+class ImmutableNBestSentencePieceText:
+    """The read-only view of ``NBestSentencePieceText``: ``.nbests`` (each with ``.score``) and ``SerializeAsString()``."""
+
+    def __init__(self, views):
+        self.nbests = list(views)
+
+    def SerializeAsString(self):
+        return serialize_nbest([v.SerializeAsString() for v in self.nbests])
+
+    def __len__(self):
+        return len(self.nbests)
+
+    def __iter__(self):
+        return iter(self.nbests)

@@ -220,3 +220,43 @@ def test_emu_python_encode_sampling_out_types(emu):
 def test_gpu_python_encode_sampling_out_types():
     from sentencepiece_amd.processor import SentencePieceProcessor
     check_python_encode_sampling_out_types(lambda blob: SentencePieceProcessor(model_proto=blob))
+
+
+def check_wrapper_spellings(make_sp):
+    """The rest of the reference wrapper's spellings on this path, against the reference module where it is installed."""
+    blob = fixtures.model_blob("test_model")
+    sp = make_sp(blob)
+    s = "Hello world, this is a test."
+    assert sp.Tokenize(s) == sp.Encode(s) and sp.Detokenize(sp.Encode(s)) == sp.Decode(sp.Encode(s))
+    assert sp.DecodePieces(sp.EncodeAsPieces(s)) == sp.Decode(sp.Encode(s))
+    assert sp.serialized_model_proto() == blob and sp.get_piece_size() == sp.GetPieceSize()
+    assert sp.NBestEncode(s, out_type=int, nbest_size=3) == sp.NBestEncodeAsIds(s, 3)
+    assert sp.NBestEncode(s, out_type=str, nbest_size=3) == sp.NBestEncodeAsPieces(s, 3)
+    with_opts = sp.NBestEncode(s, out_type=str, nbest_size=2, add_bos=True, add_eos=True, reverse=True)
+    assert [r[0] for r in with_opts] == ["<s>"] * 2 and [r[-1] for r in with_opts] == ["</s>"] * 2
+    assert [r[1:-1][::-1] for r in with_opts] == sp.NBestEncodeAsPieces(s, 2)
+    imm = sp.NBestEncodeAsImmutableProto(s, 3)
+    assert len(imm.nbests) == 3 and imm.SerializeAsString() == sp.NBestEncodeAsSerializedProto(s, 3)
+    assert [[p.piece for p in v.pieces] for v in imm.nbests] == sp.NBestEncodeAsPieces(s, 3)
+    assert imm.nbests[0].score >= imm.nbests[1].score >= imm.nbests[2].score
+    assert sp.SampleEncodeAsIds(s, 1, 0.5) == sp.Encode(s)
+    assert sp.SampleEncodeAsImmutableProto(s, -1, 0.2).text == s
+    try:
+        import sentencepiece as ref_mod
+    except ImportError:
+        return
+    ref = ref_mod.SentencePieceProcessor(model_proto=blob)
+    assert [sp.GetScore(i) for i in range(0, sp.GetPieceSize(), 37)] == [ref.GetScore(i) for i in range(0, ref.GetPieceSize(), 37)]
+    assert sp.NBestEncode(s, out_type=str, nbest_size=4, add_bos=True, reverse=True) == ref.NBestEncode(s, out_type=str, nbest_size=4, add_bos=True, reverse=True)
+    assert sp.NBestEncode([s, "x"], out_type=int, nbest_size=2, add_eos=True) == ref.NBestEncode([s, "x"], out_type=int, nbest_size=2, add_eos=True)
+    assert sp.DecodePieces(ref.EncodeAsPieces(s)) == ref.DecodePieces(ref.EncodeAsPieces(s))
+
+
+def test_emu_wrapper_spellings(emu):
+    check_wrapper_spellings(lambda blob: emu.load(blob).sp)
+
+
+@pytest.mark.gpu
+def test_gpu_wrapper_spellings():
+    from sentencepiece_amd.processor import SentencePieceProcessor
+    check_wrapper_spellings(lambda blob: SentencePieceProcessor(model_proto=blob))
