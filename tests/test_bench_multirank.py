@@ -1,0 +1,53 @@
+"""bench.py as the driver launches it for N > 1 (python -m torch.distributed.run ... bench.py --gpus N ...), world 2 on CPU:
+the script's own control flow -- both gather algorithms and the no-gather form in one run, max-over-ranks timing, ONE JSON
+line from rank 0 -- over gloo with the emulated library (tests/bench_dryrun.py).  The second gather algorithm runs under a
+watchdog: when it never returns, every rank gives up and the line is still printed."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(world, extra_env, timeout):
+    env = dict(os.environ)
+    env.update(extra_env)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "bench_dryrun.py"), "--gpus", str(world), "--steps", "1",
+           "--warmup", "1", "--sentences", "4500", "--model", "uni32k"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, lines
+
+
+def test_bench_two_ranks_times_both_gathers_and_prints_one_line():
+    p, lines = _run(2, {}, 600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "weak" and d["unit"] == "sentences/s"
+    for k in ("value_gather_all_gather", "value_gather_p2p_exact", "value_gather_none"):
+        assert d[k] > 0, k
+    assert d["value"] == max(d["value_gather_all_gather"], d["value_gather_p2p_exact"])
+    assert d["config"]["sentences_per_gpu"] == 4500 and "dp2" in d["config"]["sharding"]
+    assert d["roofline"]["kernel"]
+
+
+def test_bench_watchdog_prints_the_line_when_the_second_gather_hangs():
+    p, lines = _run(2, {"SPMX_DRYRUN_HANG": "p2p_exact", "SPMX_BENCH_GATHER_DEADLINE_S": "8"}, 600)
+    assert len(lines) == 1, (p.stdout[-1500:], p.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert d["value"] == d["value_gather_all_gather"] > 0 and d["value_gather_none"] > 0
+    assert "given up" in d["gather_p2p_exact"] and "value_gather_p2p_exact" not in d
+    assert p.returncode == 0, p.stderr[-2000:]
