@@ -49,8 +49,8 @@ using namespace spmx;
 namespace {
 
 constexpr uint32_t kLdsPerCu = 160u * 1024u;   // gfx950 (MI355X_MICROARCH.md)
-constexpr uint32_t kDynSlots = 1u << 20;       // call-local word memo: slots (64 B each) and words per call it can take
-constexpr uint32_t kDynListCap = 1u << 18;
+constexpr uint32_t kDynSlotsDefault = 1u << 20;       // call-local word memo: slots (64 B each) and words per call it can take
+constexpr uint32_t kDynListCapDefault = 1u << 18;     // (handle fields dyn_slots / dyn_list_cap; tests shrink them)
 
 thread_local std::string t_error;              // text of the calling thread's last failing call
 
@@ -250,6 +250,8 @@ struct spmx_handle {
   std::atomic<int> word_backoff{0};   // calls that leave the word rounds out (they did not pay on the last batch that tried)
   bool no_word = false;          // SPMX_NO_WORD_KERNEL=1: unigram models skip the word kernels (kernels_word.h)
   bool no_word_dp = false;       // SPMX_NO_WORD_DP=1: ... skip the second pass only
+  uint32_t dyn_slots = kDynSlotsDefault;        // SPMX_DYN_SLOTS_LOG2: slots of the call-local word memo (a power of two)
+  uint32_t dyn_list_cap = kDynListCapDefault;   // SPMX_DYN_LIST_CAP: words it takes per call; what it cannot take stays with the general kernels
   uint64_t nbest_budget = 32ull << 30;  // SPMX_NBEST_BUDGET_GB: HBM the lattice slices of one launch may take (200 k sentences, n-best 5: 0.83 M sentences/s at 8 GB, 1.15 M at 32, 1.19 M at 96)
   uint32_t nbest_hyps_min = 16384;   // SPMX_NBEST_HYPS_MIN: hypotheses a lane's A* may hold in the first launch (what outgrows it runs again)
   uint32_t tile_min_lanes = 1;   // SPMX_TILE_MIN_LANES: a main tile has at least this many sentences even when that leaves wavefronts without a tile of the class
@@ -829,8 +831,8 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         wa.dyn_ent = ws->d_dyn_ent.p;
         wa.dyn_list = ws->d_dyn_list.p;
         wa.dyn_count = &ws->d_ctrl->dyn_count;
-        wa.dyn_mask = kDynSlots - 1u;
-        wa.dyn_cap = kDynListCap;
+        wa.dyn_mask = h->dyn_slots - 1u;
+        wa.dyn_cap = h->dyn_list_cap;
         wa.resume = ws->d_resume.p;
         snprintf(ws->slot_name[slot], sizeof(ws->slot_name[slot]), "%s",
                  mode == 3 ? "EncodeWordDpKernel" : mode == 2 ? "EncodeWordAgainKernel" : mode == 1 ? "EncodeWordCollectKernel" : "EncodeWordKernel");
@@ -847,18 +849,18 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         return kOk;
       };
       if (dyn) {
-        HIP_OR_RETURN(h, ws->d_dyn_tag.Reserve(kDynSlots));
-        HIP_OR_RETURN(h, ws->d_dyn_ent.Reserve(static_cast<size_t>(kDynSlots) * 4));
-        HIP_OR_RETURN(h, ws->d_dyn_list.Reserve(kDynListCap));
+        HIP_OR_RETURN(h, ws->d_dyn_tag.Reserve(h->dyn_slots));
+        HIP_OR_RETURN(h, ws->d_dyn_ent.Reserve(static_cast<size_t>(h->dyn_slots) * 4));
+        HIP_OR_RETURN(h, ws->d_dyn_list.Reserve(h->dyn_list_cap));
         HIP_OR_RETURN(h, ws->d_resume.Reserve(n));
-        HIP_OR_RETURN(h, hipMemsetAsync(ws->d_dyn_tag.p, 0, static_cast<size_t>(kDynSlots) * sizeof(unsigned long long), stream));
+        HIP_OR_RETURN(h, hipMemsetAsync(ws->d_dyn_tag.p, 0, static_cast<size_t>(h->dyn_slots) * sizeof(unsigned long long), stream));
         if (int rc = word_pass(1, kSlotWord, 3, left_lists[0], ws->d_ctrl->left_counts[0], left_lists[1], ws->d_ctrl->left_counts[1]); rc != kOk) return rc;
         if (int rc = read_counts(); rc != kOk) return rc;
         // The second round is enqueued further down, NEXT TO the general launches over what round 1 gave up for good
         // (non-ASCII text ...): the two work on disjoint sentences, so the general launches go to a stream of their own
         // and the two overlap (the general kernels are bound by the latency of their longest sentences, not by the chip).
         for (int c = 0; c < ncls; ++c) { again_counts[c] = ws->h_ctrl->left_counts[0][c]; again_total += again_counts[c]; }
-        again_words = ws->h_ctrl->dyn_count < kDynListCap ? ws->h_ctrl->dyn_count : kDynListCap;
+        again_words = ws->h_ctrl->dyn_count < h->dyn_list_cap ? ws->h_ctrl->dyn_count : h->dyn_list_cap;
         for (int c = 0; c < ncls; ++c) known[c] = ws->h_ctrl->left_counts[1][c];
         a.lists = left_lists[1];
         d_list_counts = ws->d_ctrl->left_counts[1];
@@ -888,7 +890,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
     if (again_total > 0 && again_words) {      // the collected words, segmented once each (a few workgroups: before anything big)
       ResolveArgs ra{};
       ra.dev = h->dev; ra.dyn_ent = ws->d_dyn_ent.p; ra.dyn_list = ws->d_dyn_list.p; ra.dyn_count = &ws->d_ctrl->dyn_count;
-      ra.dyn_cap = kDynListCap; ra.unsafe = h->memo_unsafe ? 1u : 0u;
+      ra.dyn_cap = h->dyn_list_cap; ra.unsafe = h->memo_unsafe ? 1u : 0u;
       uint64_t g = (static_cast<uint64_t>(again_words) + 63) / 64;
       if (g > static_cast<uint64_t>(h->n_cu) * 8) g = static_cast<uint64_t>(h->n_cu) * 8;
       HIP_OR_RETURN(h, LaunchWordResolve(ra, static_cast<int>(g), stream));
@@ -1333,6 +1335,8 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_NO_WORD_DYN")) h->no_word_dyn = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_OVERLAP")) h->no_overlap = e[0] == '1';
     if (const char *e = getenv("SPMX_FORK_WAVES")) h->fork_waves = atoi(e);
+    if (const char *e = getenv("SPMX_DYN_SLOTS_LOG2")) { const int v = atoi(e); if (v >= 4 && v <= 26) h->dyn_slots = 1u << v; }
+    if (const char *e = getenv("SPMX_DYN_LIST_CAP")) { const long v = atol(e); if (v >= 1 && v <= (1l << 26)) h->dyn_list_cap = static_cast<uint32_t>(v); }
     if (const char *e = getenv("SPMX_NBEST_BUDGET_GB")) { const long v = atol(e); if (v >= 1 && v <= 200) h->nbest_budget = static_cast<uint64_t>(v) << 30; }
     if (const char *e = getenv("SPMX_NBEST_HYPS_MIN")) { const long v = atol(e); if (v >= 1024 && v <= 262144) h->nbest_hyps_min = static_cast<uint32_t>(v); }
     if (const char *e = getenv("SPMX_TILE_MIN_LANES")) h->tile_min_lanes = static_cast<uint32_t>(atoi(e));

@@ -520,3 +520,27 @@ def test_emu_word_kernels_then_wave_form(model, emu, oracle, corpora):
         oids, oio = o.encode_batch(text, offs)
         np.testing.assert_array_equal(io, oio)
         np.testing.assert_array_equal(ids, oids)
+
+
+@pytest.mark.parametrize("model", ["uni32k_w16", "bpe32k"])
+@pytest.mark.parametrize("env", [{"SPMX_DYN_SLOTS_LOG2": "5", "SPMX_DYN_LIST_CAP": "7"},
+                                 {"SPMX_DYN_SLOTS_LOG2": "12", "SPMX_DYN_LIST_CAP": "40"}])
+def test_emu_call_local_word_memo_overflows(model, env, emu, oracle):
+    """The call-local word memo (kernels_word.h) with room for a handful of words: a table whose probes run out and a
+    word list that is full leave their sentences to the later rounds / the general kernels -- same ids.  (A corpus of
+    real text has more distinct words than the default 2^18 a call may enter.)"""
+    import bench
+    blob = bench.model_blob(model)
+    text, offs = bench.corpus_for(model if model.endswith("_w16") else "uni32k", 5000, 20250227, False)
+    e = dict(env)
+    e["SPMX_FORCE_WORD_DP"] = "0"
+    h = emu.load(blob, classes="", cus=4, env=e)
+    h.sp.SetProfiling(True)
+    ids, io = h.encode_batch(text, offs)
+    assert h.status == 0
+    kernels = {c["kernel"]: c["sentences"] for c in h.sp.LastProfile()["classes"] if c["kernel"]}
+    assert "EncodeWordCollectKernel" in kernels                    # the word rounds ran ...
+    assert sum(v for k, v in kernels.items() if "Word" not in k) > 0   # ... and left work to the other kernels
+    oids, oio = oracle.load(blob).encode_batch(text, offs)
+    np.testing.assert_array_equal(io, oio)
+    np.testing.assert_array_equal(ids, oids)
