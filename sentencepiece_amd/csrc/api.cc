@@ -263,7 +263,7 @@ struct spmx_handle {
   bool no_uni_wave = false;      // SPMX_NO_UNI_WAVE=1: unigram models never take the wave-cooperative form (kernels_uniwave.h)
   uint32_t uni_wave_max = 0;     // SPMX_UNI_WAVE_MAX: a staged class with fewer sentences than this takes the wave-cooperative form
   int word_wgs = 1;              // SPMX_WORD_WGS: workgroups per CU of the word kernel's first pass
-  int word_waves = 16;           // SPMX_WORD_WAVES: wavefronts per workgroup of the word kernel's first pass
+  int word_waves = 12;           // SPMX_WORD_WAVES: wavefronts per workgroup of the word kernels (C2 step: 16 -> 8.60 ms, 14 -> 8.39, 12 -> 8.37, 10 -> 8.52, 8 -> 8.90)
   int tile_waves_override = 0;   // SPMX_TILE_WAVES: cap on wavefronts per workgroup of the streaming kernels
   uint32_t lane_general_min_lanes = 0;   // SPMX_LANE_GENERAL_MIN_LANES (0: per class)
   uint32_t sub_buckets = kSubBuckets;    // SPMX_SUB_BUCKETS: length sub-buckets per class in the classify sort (1..64)
