@@ -250,6 +250,7 @@ struct spmx_handle {
   std::atomic<int> word_backoff{0};   // calls that leave the word rounds out (they did not pay on the last batch that tried)
   bool no_word = false;          // SPMX_NO_WORD_KERNEL=1: unigram models skip the word kernels (kernels_word.h)
   bool no_word_dp = false;       // SPMX_NO_WORD_DP=1: ... skip the second pass only
+  int left_merge = 0;            // SPMX_LEFT_MERGE: runs of this many neighbouring length classes of the word rounds' leftovers become one class (experiment, off)
   uint32_t dyn_slots = kDynSlotsDefault;        // SPMX_DYN_SLOTS_LOG2: slots of the call-local word memo (a power of two)
   uint32_t dyn_list_cap = kDynListCapDefault;   // SPMX_DYN_LIST_CAP: words it takes per call; what it cannot take stays with the general kernels
   uint64_t nbest_budget = 32ull << 30;  // SPMX_NBEST_BUDGET_GB: HBM the lattice slices of one launch may take (200 k sentences, n-best 5: 0.83 M sentences/s at 8 GB, 1.15 M at 32, 1.19 M at 96)
@@ -924,6 +925,25 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       }
       int c_doc = ncls;                    // first class of the document launch
       for (int c = 0; c < ncls; ++c) if (cls[c].rcap > h->main_max_raw) { c_doc = c; break; }
+      // Experiment switch (SPMX_LEFT_MERGE=g, off by default, not measured yet): what the word rounds leave is thin --
+      // a tile per wavefront per class, and a wavefront's time is the sum over its tiles of the longest sentence in
+      // each.  Runs of g neighbouring classes become one class: the shorter classes' lists are
+      // appended to the longest one's (device-to-device, a few hundred KB), whose capacities hold them all.
+      if (h->left_merge > 1 && word_ok && general_total * 4 < n) {
+        for (int top = c_doc - 1; top > 0; top -= h->left_merge) {
+          int hi = -1;                     // the longest class of the run that has sentences
+          for (int c = top; c > top - h->left_merge && c >= 0; --c)
+            if (known[c] && !uni_class[c]) { hi = c; break; }
+          for (int c = hi - 1; hi > 0 && c > top - h->left_merge && c >= 0; --c) {
+            if (known[c] == 0 || uni_class[c]) continue;
+            HIP_OR_RETURN(h, hipMemcpyAsync(const_cast<uint32_t *>(a.lists) + static_cast<size_t>(hi) * n + known[hi],
+                                            a.lists + static_cast<size_t>(c) * n, static_cast<size_t>(known[c]) * sizeof(uint32_t),
+                                            hipMemcpyDeviceToDevice, stream));
+            known[hi] += known[c];
+            known[c] = 0;
+          }
+        }
+      }
       if (int rc = stream_launch(kSlotMain, 0, 0, c_doc, known, false, 0); rc != kOk) return rc;
       if (int rc = stream_launch(kSlotDoc, 1, c_doc, ncls, known, false, 0); rc != kOk) return rc;
     } else {
@@ -1335,6 +1355,7 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_NO_WORD_DYN")) h->no_word_dyn = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_OVERLAP")) h->no_overlap = e[0] == '1';
     if (const char *e = getenv("SPMX_FORK_WAVES")) h->fork_waves = atoi(e);
+    if (const char *e = getenv("SPMX_LEFT_MERGE")) { const int v = atoi(e); if (v >= 0 && v <= kMaxClasses) h->left_merge = v; }
     if (const char *e = getenv("SPMX_DYN_SLOTS_LOG2")) { const int v = atoi(e); if (v >= 4 && v <= 26) h->dyn_slots = 1u << v; }
     if (const char *e = getenv("SPMX_DYN_LIST_CAP")) { const long v = atol(e); if (v >= 1 && v <= (1l << 26)) h->dyn_list_cap = static_cast<uint32_t>(v); }
     if (const char *e = getenv("SPMX_NBEST_BUDGET_GB")) { const long v = atol(e); if (v >= 1 && v <= 200) h->nbest_budget = static_cast<uint64_t>(v) << 30; }
