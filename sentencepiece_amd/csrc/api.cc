@@ -259,7 +259,7 @@ struct spmx_handle {
   int fork_waves = 0;            // SPMX_FORK_WAVES: wavefronts per workgroup of the general launch while it runs next to the second word round (0: as planned)
   bool no_overlap = false;       // SPMX_NO_OVERLAP=1: the general launches do not run next to the second word round
   bool no_word_dyn = false;      // SPMX_NO_WORD_DYN=1: no call-local word memo (one word round, then the DP pass)
-  bool memo_unsafe = false;      // SPMX_WORDMEMO_UNSAFE=1: TEST SEAM, the call-local memo takes no margin either
+  bool memo_unsafe = false;      // TEST SEAM of the emulator build (SPMX_TEST_SEAMS + SPMX_WORDMEMO_UNSAFE=1): the call-local memo takes no margin either
   bool force_word_dp = false;    // SPMX_FORCE_WORD_DP=1: the second pass runs whatever the first one left (tests)
   bool no_uni_wave = false;      // SPMX_NO_UNI_WAVE=1: unigram models never take the wave-cooperative form (kernels_uniwave.h)
   uint32_t uni_wave_max = 0;     // SPMX_UNI_WAVE_MAX: a staged class with fewer sentences than this takes the wave-cooperative form
@@ -399,13 +399,15 @@ int RefreshDevice(spmx_handle *h, bool types_changed) {
   if (types_changed) {
     if (h->model.model_type == kUnigram) {
       HIP_OR_RETURN(h, Upload(&h->d_ptrie, t.ptrie));
-      HIP_OR_RETURN(h, Upload(&h->d_umemo, t.umemo));       // (the word memo follows the live piece types)
-      HIP_OR_RETURN(h, Upload(&h->d_umemo16, t.umemo16));
-      HIP_OR_RETURN(h, Upload(&h->d_uhot, t.uhot));
-      HIP_OR_RETURN(h, Upload(&h->d_pscore, t.pscore));
     } else {
       HIP_OR_RETURN(h, Upload(&h->d_sym_final, t.sym_final));
     }
+    // the word memo follows the live piece types -- of BPE models too (tables.cc BuildWordMemo: an UNUSED piece
+    // switches it off, ResetVocabulary switches it back on with full-size tables and masks)
+    HIP_OR_RETURN(h, Upload(&h->d_umemo, t.umemo));
+    HIP_OR_RETURN(h, Upload(&h->d_umemo16, t.umemo16));
+    HIP_OR_RETURN(h, Upload(&h->d_uhot, t.uhot));
+    HIP_OR_RETURN(h, Upload(&h->d_pscore, t.pscore));
     HIP_OR_RETURN(h, Upload(&h->d_dec_info, t.dec_info));
     HIP_OR_RETURN(h, Upload(&h->d_dec_off, t.dec_off));
     HIP_OR_RETURN(h, Upload(&h->d_dec_bytes, t.dec_bytes));
@@ -1361,7 +1363,9 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_NBEST_BUDGET_GB")) { const long v = atol(e); if (v >= 1 && v <= 200) h->nbest_budget = static_cast<uint64_t>(v) << 30; }
     if (const char *e = getenv("SPMX_NBEST_HYPS_MIN")) { const long v = atol(e); if (v >= 1024 && v <= 262144) h->nbest_hyps_min = static_cast<uint32_t>(v); }
     if (const char *e = getenv("SPMX_TILE_MIN_LANES")) h->tile_min_lanes = static_cast<uint32_t>(atoi(e));
+#ifdef SPMX_TEST_SEAMS   // (the emulator build only)
     if (getenv("SPMX_WORDMEMO_UNSAFE")) h->memo_unsafe = true;
+#endif
     if (const char *e = getenv("SPMX_NO_UNI_WAVE")) h->no_uni_wave = e[0] == '1';
     if (const char *e = getenv("SPMX_UNI_WAVE_MAX")) h->uni_wave_max = static_cast<uint32_t>(atoll(e));
     if (const char *e = getenv("SPMX_WORD_WGS")) { const int v = atoi(e); if (v >= 1 && v <= 4) h->word_wgs = v; }

@@ -114,10 +114,10 @@ struct SpmxDev {
   // word -- the space symbol and then 1 .. 16 bytes 0x21 .. 0x7E -- computed at load in double, with the magnitude bmax
   // of the accumulated score below which the float arithmetic of the reference provably takes the same decisions.
   //   umemo16  one-piece words of up to 12 bytes, ids below 65536: one U4 {12 raw bytes of the word WITHOUT its space
-  //            symbol, zero padded; id | e << 16 | sc << 24}: valid while |score| < 2^e (the power of two below bmax);
+  //            symbol, padded with 0x20 (kernels_word.h key_dword); id | e << 16 | sc << 24}: valid while |score| < 2^e (the power of two below bmax);
   //            sc = ceil(|piece score|) + 1, what the piece adds to the first pass's bound of |score|.  empty: w ==
   //            0xFFFFFFFF.  uhot: the kWordHotSlots likeliest of them, direct-mapped (the kernels keep it in LDS).
-  //   umemo    the other words (two pieces, 13 .. 16 bytes): two U4 {16 key bytes} {id0, id1 or 0xFFFFFFFF, sc0 + sc1
+  //   umemo    the other words (two pieces, 13 .. 16 bytes): two U4 {16 key bytes, 0x20 padded} {id0, id1 or 0xFFFFFFFF, sc0 + sc1
   //            (float bits), bmax (float bits)}; empty: id0 == 0xFFFFFFFF.
   // Open addressing on HashWordKey.  pscore: score per piece id (the second pass replays the exact score).
   const U4 *umemo16;

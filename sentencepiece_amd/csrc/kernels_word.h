@@ -91,6 +91,12 @@ SPMX_DEVICE uint32_t space_bits(uint32_t v) {
   const uint32_t x = v ^ 0x20202020u;
   return (x - 0x01010101u) & ~x & 0x80808080u;
 }
+// A memo KEY is the word's L raw bytes padded with 0x20 to 12 / 16 bytes.  A word holds no 0x20 (it ends at the first
+// one), so the padding can be told from every byte a word may consist of -- 0x00 included, which the reference keeps
+// as a character of its own (src/normalizer.cc:231-244) -- and equal keys mean equal bytes AND equal length.
+// (one v_bfi_b32: the mask's bits from the text, the others from the padding)
+constexpr uint32_t kWordKeyPad = 0x20202020u;
+SPMX_DEVICE uint32_t key_dword(uint32_t text, uint32_t mask) { return (text & mask) | (kWordKeyPad & ~mask); }
 
 struct WordLds {
   const Q4 *masks;      // [18] key masks (shared)
@@ -264,7 +270,7 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
     bool shortw = word && L <= 12;
     if (shortw) {
       const Q4 mk = T.masks[L];
-      k0 = w.x & mk.x; k1 = w.y & mk.y; k2 = w.z & mk.z;
+      k0 = key_dword(w.x, mk.x); k1 = key_dword(w.y, mk.y); k2 = key_dword(w.z, mk.z);
     }
     const uint32_t h = HashWordKey(k0, k1, k2, 0u);
     {   // the likeliest words: LDS
@@ -299,7 +305,7 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
       }
       const bool probe = need && !lng;
       const Q4 mk = T.masks[probe ? L2 : 0];
-      k0 = w.x & mk.x; k1 = w.y & mk.y; k2 = w.z & mk.z; k3 = w.w & mk.w;
+      k0 = key_dword(w.x, mk.x); k1 = key_dword(w.y, mk.y); k2 = key_dword(w.z, mk.z); k3 = key_dword(w.w, mk.w);
       uint32_t sl = HashWordKey(k0, k1, k2, k3) & m32;
       U4 e0 = memo32[2u * (probe ? sl : 0u)], e1 = memo32[2u * (probe ? sl : 0u) + 1u];
       hit32 = probe && e0.x == k0 && e0.y == k1 && e0.z == k2 && e0.w == k3 && e1.x != 0xFFFFFFFFu;
@@ -585,7 +591,7 @@ SPMX_DEVICE void resolve_unigram_lane(const ResolveArgs &a, uint32_t slot, float
     for (int i = 0; i < 16; ++i) {
       const uint32_t b = (kw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
       wb[1 + i] = static_cast<uint8_t>(b);
-      if (b != 0u && L == i) L = i + 1;
+      if (b != 0x20u && L == i) L = i + 1;               // (the key's padding: key_dword)
     }
   }
   const int n = L + 1;
@@ -711,7 +717,7 @@ SPMX_DEVICE void resolve_bpe_lane(const ResolveArgs &a, uint32_t slot, uint32_t 
   sym[0] = char_lookup(d, kSpByte, 1u);
   for (int i = 0; i < 16; ++i) {
     const uint32_t b = (kw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-    if (b == 0u) break;
+    if (b == 0x20u) break;                            // (the key's padding: key_dword)
     sym[n << 6] = char_lookup(d, b, 1u);
     ++n;
   }

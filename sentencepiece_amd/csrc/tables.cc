@@ -591,7 +591,8 @@ void BuildWordMemo(const ModelData &m, HostTables *t) {
       std::vector<uint32_t> ids;
       if (!bpe_word(std::string(1, static_cast<char>(kSpByte)) + body, &ids) || ids.empty() || ids.size() > 2) continue;
       Ent en{};
-      unsigned char key[kWordKeyBytes] = {0};
+      unsigned char key[kWordKeyBytes];
+      memset(key, 0x20, sizeof(key));                     // (kernels_word.h key_dword: padded with 0x20, which no word holds)
       memcpy(key, body.data(), body.size());
       memcpy(en.k, key, sizeof(key));
       en.id0 = ids[0];
@@ -645,12 +646,15 @@ void BuildWordMemo(const ModelData &m, HostTables *t) {
     double lim = k + 1 > 126 ? 3.0e38 : ldexp(1.0, k + 1);
     double bmax = lim - wmag * (1.0 + 1e-6) - 1e-30;
     if (!(bmax > 0.0)) continue;
-    if (getenv("SPMX_WORDMEMO_UNSAFE")) bmax = 3.1e38;    // TEST SEAM (scripts/fuzz_wordmemo.py): no margin guard -- shows the fuzz has teeth
+#ifdef SPMX_TEST_SEAMS   // (the emulator build only, tests/emu/Makefile: the release library has no such switch)
+    if (getenv("SPMX_WORDMEMO_UNSAFE")) bmax = 3.1e38;    // no margin guard -- shows that tests/test_word_form.py's near-tie fuzz has teeth
+#endif
     float bf = bmax > 3.0e38 ? 3.0e38f : static_cast<float>(bmax);
     if (static_cast<double>(bf) > bmax) bf = nextafterf(bf, 0.f);
     if (!(bf > 0.f)) continue;
     Ent en{};
-    unsigned char key[kWordKeyBytes] = {0};
+    unsigned char key[kWordKeyBytes];
+    memset(key, 0x20, sizeof(key));
     memcpy(key, body.data(), body.size());
     memcpy(en.k, key, sizeof(key));
     en.id0 = static_cast<uint32_t>(ids[0]);
@@ -671,7 +675,7 @@ void BuildWordMemo(const ModelData &m, HostTables *t) {
   std::vector<const Ent *> small, big;
   for (const Ent &e : ents) {
     const bool one = e.id1 == 0xFFFFFFFFu;
-    const bool short_key = e.k[3] == 0;                  // at most 12 bytes
+    const bool short_key = e.k[3] == 0x20202020u;        // at most 12 bytes
     if (one && short_key && e.id0 < 65536u && bound_of(e.id0) <= 255.0 && e.bmax >= 1.0f) small.push_back(&e);
     else big.push_back(&e);
   }
