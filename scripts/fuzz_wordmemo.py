@@ -2,85 +2,16 @@
 # ties between segmentations) or differ by a few float ulps (decisions that flip with the magnitude of the accumulated
 # score), long all-ASCII sentences built from the models' own words (|best_path_score| up to thousands) -- the device
 # kernels under the emulator against the oracle, ids compared one by one.  The word memo's margin guard is what keeps
-# the word form bit-exact here; SPMX_WORDMEMO_UNSAFE=1 (a test seam in tables.cc that drops the guard) makes the same
+# the word form bit-exact here; SPMX_WORDMEMO_UNSAFE=1 (a seam of the EMULATOR build, -DSPMX_TEST_SEAMS, that drops the guard) makes the same
 # campaign FAIL, which is how one knows it has teeth.
 # usage: python scripts/fuzz_wordmemo.py SECONDS FIRST_SEED [--unsafe]
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from sentencepiece import sentencepiece_model_pb2 as pb
 from sentencepiece_amd import synth
 from tests import fixtures, oraclelib, emulib
 
-SP = "▁"
-
-
-def make_model(rng, base):
-    m = pb.ModelProto()
-    m.ParseFromString(base)
-    del m.pieces[:]
-    for name, typ in (("<unk>", 2), ("<s>", 3), ("</s>", 3)):
-        p = m.pieces.add(); p.piece, p.score, p.type = name, 0.0, typ
-    alpha = "abcde"[:int(rng.integers(2, 6))] + ("." if rng.random() < 0.5 else "")
-    quant = float(rng.choice([1.0, 0.5, 0.125, 2.0 ** -10, 0.0]))
-    tiny = float(rng.choice([0.0, 2.0 ** -20, 2.0 ** -16, 2.0 ** -12, 1e-3]))
-
-    def score():
-        v = -float(rng.uniform(1.0, 14.0))
-        if quant:
-            v = round(v / quant) * quant
-        if tiny and rng.random() < 0.5:
-            v += tiny * float(rng.integers(-3, 4))
-        return float(np.float32(v))
-    seen = set()
-
-    def add(s):
-        if s and s not in seen:
-            seen.add(s)
-            p = m.pieces.add(); p.piece, p.score, p.type = s, score(), 1
-    add(SP)
-    for c in alpha:
-        if rng.random() < 0.9:
-            add(c)
-        if rng.random() < 0.7:
-            add(SP + c)
-    words = []
-    scores = {}
-
-    def add_scored(s, v):
-        if s and s not in seen:
-            seen.add(s)
-            scores[s] = float(np.float32(v))
-            p = m.pieces.add(); p.piece, p.score, p.type = s, scores[s], 1
-    for _ in range(int(rng.integers(60, 300))):
-        w = "".join(alpha[int(k)] for k in rng.integers(0, len(alpha), size=int(rng.integers(2, 9))))
-        words.append(w)
-        # a split of the word into two pieces, and the whole word scored a hair above / below / exactly at the split's sum
-        k = int(rng.integers(1, len(w)))
-        a, b = SP + w[:k], w[k:]
-        for s_ in (a, b):
-            if s_ not in seen:
-                add_scored(s_, score())
-        sa = next(p.score for p in m.pieces if p.piece == a)
-        sb = next(p.score for p in m.pieces if p.piece == b)
-        if rng.random() < 0.97:
-            delta = float(rng.choice([0.0, 2.0 ** -22, -2.0 ** -22, 2.0 ** -18, -2.0 ** -18, 1e-4, -1e-4, 1e-2, -1e-2, 1.0, -1.0]))
-            add_scored(SP + w, np.float32(sa) + np.float32(sb) + np.float32(delta))
-    return m.SerializeToString(), words
-
-
-def make_corpus(rng, words, n):
-    sents = []
-    for _ in range(n):
-        k = int(rng.choice([1, 3, 10, 40, 150, 400]))
-        ws = [words[int(i)] for i in rng.integers(0, len(words), size=k)]
-        s = " ".join(ws)
-        if rng.random() < 0.1:
-            s = "  " + s + " "
-        if rng.random() < 0.05:
-            s = s.replace(" ", "  ", 1)
-        sents.append(s.encode())
-    return synth.pack(sents)
+from tests.wordfuzz import near_tie_model as make_model, near_tie_corpus as make_corpus   # (shared with tests/test_word_form.py)
 
 
 def main():
