@@ -60,6 +60,7 @@ enum { kSlotMain = 0, kSlotDoc = 1, kSlotExact = 2, kSlotWave = 3, kSlotLong = 4
 // ctrl block layout (device + pinned host mirror), zeroed before every call
 struct Ctrl {
   uint32_t list_counts[kMaxClasses];
+  uint32_t gen_counts[kMaxClasses];   // classify's plain scan: the sentences set aside for the general kernels, per class (read together with list_counts)
   uint32_t key_totals[kSortKeys], key_cursor[kSortKeys];   // classify: counting sort by (class, length sub-bucket)
   uint32_t status;
   uint32_t retry_count[2];            // long form: sentences that found the pool exhausted (ping-pong)
@@ -171,7 +172,7 @@ struct Workspace {
   DevBuf<uint64_t> d_tmp_off, d_tile_sums, d_chunk_base;
   DevBuf<int32_t> d_arena, d_arena_tb, d_tok_begin;
   DevBuf<uint32_t> d_span_begin, d_span_end, d_nspan_begin, d_nspan_end;
-  DevBuf<uint8_t> d_norm, d_nbest_scratch, d_slab, d_pool, d_sent_status;
+  DevBuf<uint8_t> d_norm, d_nbest_scratch, d_slab, d_pool, d_sent_status, d_flags;
   DevBuf<unsigned long long> d_res_off, d_dyn_tag;     // d_dyn_*: the call-local word memo (kernels_word.h)
   DevBuf<U4> d_dyn_ent, d_resume;
   DevBuf<uint32_t> d_dyn_list;
@@ -198,7 +199,7 @@ struct Workspace {
   ~Workspace() {
     d_lists.Free(); d_counts.Free(); d_tmp_off.Free(); d_tile_sums.Free(); d_chunk_base.Free(); d_arena.Free();
     d_arena_tb.Free(); d_tok_begin.Free(); d_span_begin.Free(); d_span_end.Free(); d_nspan_begin.Free(); d_nspan_end.Free();
-    d_norm.Free(); d_nbest_scratch.Free(); d_slab.Free(); d_pool.Free(); d_sent_status.Free(); d_res_off.Free();
+    d_norm.Free(); d_nbest_scratch.Free(); d_slab.Free(); d_pool.Free(); d_sent_status.Free(); d_flags.Free(); d_res_off.Free();
     d_res_score.Free(); d_dyn_tag.Free(); d_dyn_ent.Free(); d_dyn_list.Free(); d_resume.Free(); d_text.Free(); d_offs.Free(); d_id_offs.Free(); d_ids.Free(); d_dn_text.Free(); d_dn_offs.Free();
     h_text.Free(); h_offs.Free(); h_id_offs.Free();
     if (d_ctrl) (void)hipFree(d_ctrl);
@@ -250,14 +251,14 @@ struct spmx_handle {
   std::atomic<int> word_backoff{0};   // calls that leave the word rounds out (they did not pay on the last batch that tried)
   bool no_word = false;          // SPMX_NO_WORD_KERNEL=1: unigram models skip the word kernels (kernels_word.h)
   bool no_word_dp = false;       // SPMX_NO_WORD_DP=1: ... skip the second pass only
-  int left_merge = 0;            // SPMX_LEFT_MERGE: runs of this many neighbouring length classes of the word rounds' leftovers become one class (experiment, off)
   uint32_t dyn_slots = kDynSlotsDefault;        // SPMX_DYN_SLOTS_LOG2: slots of the call-local word memo (a power of two)
   uint32_t dyn_list_cap = kDynListCapDefault;   // SPMX_DYN_LIST_CAP: words it takes per call; what it cannot take stays with the general kernels
   uint64_t nbest_budget = 32ull << 30;  // SPMX_NBEST_BUDGET_GB: HBM the lattice slices of one launch may take (200 k sentences, n-best 5: 0.83 M sentences/s at 8 GB, 1.15 M at 32, 1.19 M at 96)
   uint32_t nbest_hyps_min = 16384;   // SPMX_NBEST_HYPS_MIN: hypotheses a lane's A* may hold in the first launch (what outgrows it runs again)
   uint32_t tile_min_lanes = 1;   // SPMX_TILE_MIN_LANES: a main tile has at least this many sentences even when that leaves wavefronts without a tile of the class
-  int fork_waves = 0;            // SPMX_FORK_WAVES: wavefronts per workgroup of the general launch while it runs next to the second word round (0: as planned)
-  bool no_overlap = false;       // SPMX_NO_OVERLAP=1: the general launches do not run next to the second word round
+  int fork_waves = 4;            // SPMX_FORK_WAVES: wavefronts per workgroup of the general launch while it runs next to the first word round (0: as planned)
+  bool no_overlap = false;       // SPMX_NO_OVERLAP=1: the general launches do not run next to the word rounds
+  bool no_scan = false;          // SPMX_NO_SCAN=1: classify does not set the non-plain sentences aside (the word rounds find them)
   bool no_word_dyn = false;      // SPMX_NO_WORD_DYN=1: no call-local word memo (one word round, then the DP pass)
   bool memo_unsafe = false;      // TEST SEAM of the emulator build (SPMX_TEST_SEAMS + SPMX_WORDMEMO_UNSAFE=1): the call-local memo takes no margin either
   bool force_word_dp = false;    // SPMX_FORCE_WORD_DP=1: the second pass runs whatever the first one left (tests)
@@ -450,9 +451,15 @@ hipError_t EnsureEvents(Workspace *ws) {
   return hipSuccess;
 }
 
-int RunClassify(spmx_handle *h, Workspace *ws, const uint64_t *d_offsets, uint32_t n32, hipStream_t stream) {
+// d_text / gen_lists (both or neither): the plain scan (kernels.h ClassifyArgs) -- sentences with a byte outside
+// 0x20 .. 0x7E go to gen_lists, counted in Ctrl::gen_counts
+int RunClassify(spmx_handle *h, Workspace *ws, const uint64_t *d_offsets, uint32_t n32, hipStream_t stream,
+                const uint8_t *d_text = nullptr, uint32_t *gen_lists = nullptr) {
   ClassifyArgs ca{};
   ca.offs = d_offsets; ca.n = n32; ca.n_classes = static_cast<uint32_t>(kNumClasses);
+  if (d_text && gen_lists) {
+    ca.text = d_text; ca.flags = ws->d_flags.p; ca.lists2 = gen_lists; ca.list2_counts = ws->d_ctrl->gen_counts;
+  }
   for (int c = 0; c < kNumClasses; ++c) ca.rcap[c] = h->classes[c].rcap;
   ca.lists = ws->d_lists.p; ca.list_counts = ws->d_ctrl->list_counts;
   ca.key_totals = ws->d_ctrl->key_totals; ca.key_cursor = ws->d_ctrl->key_cursor;
@@ -507,13 +514,19 @@ StreamPlan PlanStream(const spmx_handle *h, EncodeArgs *a, const uint32_t *count
     else grid = w / waves;
   }
   uint64_t n_waves = grid * waves;
+  // A THIN launch (fewer full tiles than wavefronts) takes full tiles: a wavefront's time is the sum over its tiles of
+  // the longest sentence in each, so a tile per class per wavefront (what spreading every class over every wavefront
+  // gives) costs the sum of the classes' longest sentences, one full tile per wavefront only the longest one's.
+  uint64_t full_tiles = 0;
+  for (int c = c_lo; c < c_hi; ++c) full_tiles += (static_cast<uint64_t>(counts[c]) + 63) / 64;
+  const bool thin = full_tiles <= n_waves;
   // no more wavefronts than tiles: a first pass at full tiles tells how many there can be
   {
     uint64_t tiles = 0;
     for (int c = c_lo; c < c_hi; ++c) {
       if (!counts[c]) continue;
       uint64_t tw = (static_cast<uint64_t>(counts[c]) + n_waves - 1) / n_waves;
-      if (tw > 64) tw = 64;
+      if (tw > 64 || thin) tw = 64;
       tiles += (static_cast<uint64_t>(counts[c]) + tw - 1) / tw;
     }
     if (tiles < n_waves) {
@@ -532,6 +545,7 @@ StreamPlan PlanStream(const spmx_handle *h, EncodeArgs *a, const uint32_t *count
     if (c < c_lo || c >= c_hi || counts[c] == 0) continue;
     sc.tcap = tcap_of(c);
     uint64_t tw = (static_cast<uint64_t>(counts[c]) + n_waves - 1) / n_waves;   // sentences per main tile
+    if (thin) tw = 64;
     if (tw < h->tile_min_lanes) tw = h->tile_min_lanes;
     if (tw > 64) tw = 64;
     if (tw < 1) tw = 1;
@@ -593,7 +607,16 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
     h->word_backoff.fetch_sub(1, std::memory_order_relaxed);
     word_ok = false;
   }
-  HIP_OR_RETURN(h, ws->d_lists.Reserve(static_cast<size_t>(2 * kMaxClasses + 3 + (word_ok ? 3 * kMaxClasses : 0)) * n));
+  const bool is_bpe = h->model.model_type == kBpe;
+  // streaming (lane-per-sentence) kernels: every unigram model; BPE models that can be segmented word by word
+  const bool dropout = is_bpe && ws->bpe_dropout > 0.f;      // BPE-dropout: every sentence takes the long form
+  const bool bpe_stream = is_bpe && (h->dev.flags & kNfBpeWordwise) && !(h->dev.flags & kNfHasUnused) && !h->no_stream && !dropout;
+  const bool streaming = !is_bpe || bpe_stream;
+  // With the word rounds, classify also reads the text once and sets the sentences that are not plain ASCII aside
+  // (kernels.h ClassifyArgs): the general launch over them runs NEXT TO the first word round, not after it.
+  const bool scanned = word_ok && streaming && !h->no_scan;
+  HIP_OR_RETURN(h, ws->d_lists.Reserve(static_cast<size_t>(2 * kMaxClasses + 3 + (word_ok ? 3 * kMaxClasses : 0) + (scanned ? kMaxClasses : 0)) * n));
+  if (scanned) HIP_OR_RETURN(h, ws->d_flags.Reserve(n));
   HIP_OR_RETURN(h, ws->d_counts.Reserve(n + 1));
   HIP_OR_RETURN(h, ws->d_tmp_off.Reserve(n + 1));
   HIP_OR_RETURN(h, ws->d_tile_sums.Reserve((n + kScanTile - 1) / kScanTile + 2));
@@ -605,6 +628,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
   uint32_t *const retry_lists[2] = {long_list + n, long_list + 2 * n};
   uint32_t *const left_lists[3] = {long_list + 3 * n, long_list + (3 + static_cast<size_t>(kMaxClasses)) * n,
                                    long_list + (3 + 2 * static_cast<size_t>(kMaxClasses)) * n};   // (word_ok only)
+  uint32_t *const gen_lists = long_list + (3 + 3 * static_cast<size_t>(kMaxClasses)) * n;           // (scanned only)
   // ids are at most one per normalized byte; the streaming kernels reserve a sentence's slot by that bound
   uint64_t expand = (h->dev.flags & kNfCompressSp) || !(h->dev.flags & kNfEscapeWs) ? 1 : 3;
   if ((h->dev.flags & kNfCompressSp) && (h->dev.flags & kNfByteFallback)) expand = 2;   // slots: bytes + 2 per space symbol
@@ -614,11 +638,6 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
   if (prof) HIP_OR_RETURN(h, EnsureEvents(ws));
   const uint32_t n32 = static_cast<uint32_t>(n);
   const int wide = h->n_cu * 8;
-  const bool is_bpe = h->model.model_type == kBpe;
-  // streaming (lane-per-sentence) kernels: every unigram model; BPE models that can be segmented word by word
-  const bool dropout = is_bpe && ws->bpe_dropout > 0.f;      // BPE-dropout: every sentence takes the long form
-  const bool bpe_stream = is_bpe && (h->dev.flags & kNfBpeWordwise) && !(h->dev.flags & kNfHasUnused) && !h->no_stream && !dropout;
-  const bool streaming = !is_bpe || bpe_stream;
   const bool fast_ok = StreamFastEligible(h->dev.flags) && !h->no_fast;
   const bool uds = (h->dev.flags & kNfHasUserDefined) != 0;
   uint32_t rcaps[kMaxClasses] = {0};
@@ -658,12 +677,15 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
     HIP_OR_RETURN(h, hipMemsetAsync(ws->d_ctrl, 0, sizeof(Ctrl), stream));
     HIP_OR_RETURN(h, hipMemsetAsync(d_status, 0, n, stream));
     for (bool &u : ws->slot_used) u = false;
-    if (int rc = RunClassify(h, ws, d_offsets, n32, stream); rc != kOk) return rc;
-    HIP_OR_RETURN(h, hipMemcpyAsync(ws->h_ctrl->list_counts, ws->d_ctrl->list_counts, sizeof(ws->h_ctrl->list_counts),
+    if (int rc = RunClassify(h, ws, d_offsets, n32, stream, scanned ? d_text : nullptr, scanned ? gen_lists : nullptr); rc != kOk) return rc;
+    HIP_OR_RETURN(h, hipMemcpyAsync(ws->h_ctrl->list_counts, ws->d_ctrl->list_counts,
+                                    sizeof(ws->h_ctrl->list_counts) + sizeof(ws->h_ctrl->gen_counts),       // (gen_counts follows list_counts in Ctrl)
                                     hipMemcpyDeviceToHost, stream));
     HIP_OR_RETURN(h, hipStreamSynchronize(stream));
-    uint32_t known[kMaxClasses] = {0};
-    for (int c = 0; c < ncls; ++c) known[c] = ws->h_ctrl->list_counts[c];
+    uint32_t known[kMaxClasses] = {0};       // the class lists: every sentence, or (scanned) the plain ones
+    uint32_t gen_known[kMaxClasses] = {0};   // (scanned) the sentences set aside for the general kernels
+    uint64_t gen_total = 0;
+    for (int c = 0; c < ncls; ++c) { known[c] = ws->h_ctrl->list_counts[c]; gen_known[c] = ws->h_ctrl->gen_counts[c]; gen_total += gen_known[c]; }
     // what every encode launch shares
     EncodeArgs a{};
     a.dev = h->dev; a.text = d_text; a.offs = d_offsets;
@@ -773,25 +795,132 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
     if (uni_wave) {
       uint64_t vol_staged = 0, vol_mid = 0;
       for (int c = 0; c < ncls; ++c) {
-        const uint64_t v = static_cast<uint64_t>(known[c]) * cls[c].rcap;
+        const uint64_t v = (static_cast<uint64_t>(known[c]) + gen_known[c]) * cls[c].rcap;
         if (cls[c].rcap <= kMaxStagedRaw) vol_staged += v;
         else if (cls[c].rcap <= h->main_max_raw) vol_mid += v;
       }
       for (int c = 0; c < ncls; ++c) {
         if (cls[c].rcap > h->main_max_raw) uni_class[c] = true;
         else if (cls[c].rcap > kMaxStagedRaw) uni_class[c] = vol_mid > vol_staged;
-        else uni_class[c] = known[c] > 0 && known[c] < h->uni_wave_max;
+        else uni_class[c] = known[c] + gen_known[c] > 0 && known[c] + gen_known[c] < h->uni_wave_max;
       }
     }
+    // ---- the general kernels over one set of class lists (`cnt` sentences per class; cnt is consumed) ----
+    // tail: what the word rounds left (thin lists: a sentence per wavefront where the model allows it; its streaming launch
+    // has a tile queue of its own, the early launches' may still be running on the second stream)
+    auto general_pass = [&](const uint32_t *lists, const uint32_t *d_counts, uint32_t *cnt, bool tail) -> int {
+      a.lists = lists;
+      d_list_counts = d_counts;
+      uint64_t total = 0;
+      for (int c = 0; c < ncls; ++c) total += cnt[c];
+      if (total == 0) return kOk;
+      if (streaming) {
+        // unigram: the wave-cooperative form (a sentence per wavefront, kernels_uniwave.h) takes the classes where the
+        // lane-per-sentence kernels are the wrong tool -- documents (one lane would walk them alone: 2.5 us per byte),
+        // and classes with too few sentences to fill 64 lanes of every wavefront
+        if (uni_wave) {
+          const bool few = tail && total < 4096;
+          for (int c = 0; c < ncls; ++c) {
+            if (cnt[c] == 0 || !(uni_class[c] || few)) continue;
+            if (int rc = long_launch(lists + static_cast<size_t>(c) * n, &d_counts[c], cnt[c], true); rc != kOk) return rc;
+            cnt[c] = 0;
+          }
+        }
+        if (tail) return stream_launch(kSlotDoc, 5, 0, ncls, cnt, false, 0);
+        int c_doc = ncls;                    // first class of the document launch
+        for (int c = 0; c < ncls; ++c) if (cls[c].rcap > h->main_max_raw) { c_doc = c; break; }
+        if (int rc = stream_launch(kSlotMain, 0, 0, c_doc, cnt, false, 0); rc != kOk) return rc;
+        return stream_launch(kSlotDoc, 1, c_doc, ncls, cnt, false, 0);
+      }
+      // BPE, sentence-per-wave form (models that are not word-wise, or with UNUSED pieces; never after word rounds): the
+      // staged classes; a sentence whose normalized form overflows its class escalates to the next staged one, then to
+      // the long form
+      int c_staged = 0;
+      while (c_staged < ncls && cls[c_staged].rcap <= kMaxStagedRaw && !h->no_wave && !dropout) ++c_staged;
+      bool first = true;
+      for (int c = 0; c < c_staged; ++c) {
+        EncodeArgs la = a;
+        la.list = class_lists + static_cast<size_t>(c) * n; la.list_count = &ws->d_ctrl->list_counts[c];
+        const bool has_next = c + 1 < c_staged;
+        la.next_list = has_next ? class_lists + static_cast<size_t>(c + 1) * n : nullptr;
+        la.next_count = has_next ? &ws->d_ctrl->list_counts[c + 1] : nullptr;
+        la.rcap = cls[c].rcap; la.ncap = cls[c].ncap;
+        if (la.rcap == kMaxStagedRaw && la.ncap > kBpeWaveNcap3) la.ncap = kBpeWaveNcap3;
+        la.stats = &ws->d_ctrl->stats[kStatsPerClass * kSlotWave];
+        const uint32_t lds = EncodeLdsBytes(kBpe, la.rcap, la.ncap);
+        int per_cu = static_cast<int>(kLdsPerCu / lds);
+        if (per_cu > 32) per_cu = 32;
+        if (per_cu < 1) per_cu = 1;
+        uint64_t grid = static_cast<uint64_t>(h->n_cu) * per_cu;
+        if (grid > n) grid = n;
+        snprintf(ws->slot_name[kSlotWave], sizeof(ws->slot_name[kSlotWave]), "EncodeKernel<2, *>");
+        if (first) HIP_OR_RETURN(h, record(kSlotWave, 0));
+        first = false;
+        HIP_OR_RETURN(h, LaunchEncode(kBpe, c, la, static_cast<int>(grid), lds, stream));
+        HIP_OR_RETURN(h, record(kSlotWave, 1));
+        ws->slot_used[kSlotWave] = true;
+      }
+      for (int c = c_staged; c < ncls; ++c)
+        if (int rc = long_launch(class_lists + static_cast<size_t>(c) * n, &ws->d_ctrl->list_counts[c], cnt[c]); rc != kOk) return rc;
+      return kOk;
+    };
+    // ---- fork (scanned): the general kernels over the sentences classify set aside go to the workspace's second stream
+    // and run NEXT TO the first word round -- they work on disjoint sentences.  The general launch is bound by the latency
+    // of its longest sentences, not by the chip: it is held to a few wavefronts per workgroup (SPMX_FORK_WAVES), so that
+    // its workgroups and the word kernel's fit a CU together.  Plain DOCUMENTS never take the word kernels of a unigram
+    // model (a sentence per wavefront is their form): they start here too. ----
+    hipStream_t main_stream = stream;
+    bool forked = false;
+    if (scanned) {
+      uint32_t doc_known[kMaxClasses] = {0};
+      uint64_t doc_total = 0;
+      if (uni_wave)
+        for (int c = 0; c < ncls; ++c)
+          if (known[c] && ((uni_class[c] && cls[c].rcap > kMaxStagedRaw) || cls[c].rcap > h->main_max_raw)) { doc_known[c] = known[c]; doc_total += known[c]; known[c] = 0; }
+      if (gen_total + doc_total > 0) {
+        uint64_t plain_total = 0;
+        for (int c = 0; c < ncls; ++c) plain_total += known[c];
+        forked = plain_total > 0 && !h->no_overlap;
+        if (forked) {
+          HIP_OR_RETURN(h, hipEventRecord(ws->ev_fork, stream));
+          HIP_OR_RETURN(h, hipStreamWaitEvent(ws->stream2, ws->ev_fork, 0));
+          stream = ws->stream2;
+          stream_waves_cap = h->fork_waves;
+        }
+        int rc = kOk;
+        for (int c = 0; c < ncls && rc == kOk; ++c)
+          if (doc_known[c]) rc = long_launch(class_lists + static_cast<size_t>(c) * n, &ws->d_ctrl->list_counts[c], doc_known[c], true);
+        if (rc == kOk) rc = general_pass(gen_lists, ws->d_ctrl->gen_counts, gen_known, false);
+        if (forked) {
+          // (on any error while forked: nothing of this call may still be queued on the second stream when the
+          // workspace goes back to the pool)
+          if (rc != kOk) { (void)hipStreamSynchronize(ws->stream2); return rc; }
+          HIP_OR_RETURN(h, hipEventRecord(ws->ev_join, stream));
+          stream = main_stream;
+          stream_waves_cap = 0;
+        } else if (rc != kOk) {
+          return rc;
+        }
+        a.lists = class_lists;
+        d_list_counts = ws->d_ctrl->list_counts;
+      }
+    }
+    // (from here to the join, an error return must not leave work of this call queued on the second stream)
+    auto fail_forked = [&](int rc) -> int {
+      if (forked) (void)hipStreamSynchronize(ws->stream2);
+      return rc;
+    };
+#define FORKED_OR_RETURN(expr) do { if (int rc_ = (expr); rc_ != kOk) return fail_forked(rc_); } while (0)
+#define FORKED_HIP_OR_RETURN(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail_forked(FailHip(h, e_, #expr)); } while (0)
     if (word_ok) {
-      // ---- the word kernels first (kernels_word.h): every class from one queue, longest first.
+      // ---- the word kernels (kernels_word.h): every class from one queue, longest first.
       //   round 1   takes the sentences whose words are all in the load-time memo, and enters every other plain word
       //             it meets into the call-local memo;
       //   resolve   segments the collected words, one lane per word;
       //   round 2   over the sentences round 1 kept for it, looking the collected words up;
       //   (without the call-local memo, SPMX_NO_WORD_DYN=1: round 1, then the DP pass over what it left.)
-      // What is left then -- anything that is not plain ASCII words -- comes back as per-class lists for the general
-      // launches below.
+      // What is left then -- a word of more than 16 bytes, a margin that does not hold, and without the plain scan
+      // anything that is not plain ASCII words -- comes back as per-class lists for the tail launch below.
       const bool dyn = !h->no_word_dyn;
       word_pass = [&](int mode, int slot, int qi, uint32_t *out_lists, uint32_t *d_out_counts, uint32_t *out2_lists,
                            uint32_t *d_out2_counts) -> int {
@@ -851,166 +980,66 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         HIP_OR_RETURN(h, hipStreamSynchronize(stream));
         return kOk;
       };
+      uint64_t eligible = 0;                 // sentences the first round was given (the backoff rule below)
+      for (int c = 0; c < ncls; ++c) if (cls[c].rcap <= h->main_max_raw) eligible += known[c];
+      int left_at = 0;                       // which of left_lists holds what the word rounds leave
       if (dyn) {
-        HIP_OR_RETURN(h, ws->d_dyn_tag.Reserve(h->dyn_slots));
-        HIP_OR_RETURN(h, ws->d_dyn_ent.Reserve(static_cast<size_t>(h->dyn_slots) * 4));
-        HIP_OR_RETURN(h, ws->d_dyn_list.Reserve(h->dyn_list_cap));
-        HIP_OR_RETURN(h, ws->d_resume.Reserve(n));
-        HIP_OR_RETURN(h, hipMemsetAsync(ws->d_dyn_tag.p, 0, static_cast<size_t>(h->dyn_slots) * sizeof(unsigned long long), stream));
-        if (int rc = word_pass(1, kSlotWord, 3, left_lists[0], ws->d_ctrl->left_counts[0], left_lists[1], ws->d_ctrl->left_counts[1]); rc != kOk) return rc;
-        if (int rc = read_counts(); rc != kOk) return rc;
-        // The second round is enqueued further down, NEXT TO the general launches over what round 1 gave up for good
-        // (non-ASCII text ...): the two work on disjoint sentences, so the general launches go to a stream of their own
-        // and the two overlap (the general kernels are bound by the latency of their longest sentences, not by the chip).
+        FORKED_HIP_OR_RETURN(ws->d_dyn_tag.Reserve(h->dyn_slots));
+        FORKED_HIP_OR_RETURN(ws->d_dyn_ent.Reserve(static_cast<size_t>(h->dyn_slots) * 4));
+        FORKED_HIP_OR_RETURN(ws->d_dyn_list.Reserve(h->dyn_list_cap));
+        FORKED_HIP_OR_RETURN(ws->d_resume.Reserve(n));
+        FORKED_HIP_OR_RETURN(hipMemsetAsync(ws->d_dyn_tag.p, 0, static_cast<size_t>(h->dyn_slots) * sizeof(unsigned long long), stream));
+        FORKED_OR_RETURN(word_pass(1, kSlotWord, 3, left_lists[0], ws->d_ctrl->left_counts[0], left_lists[1], ws->d_ctrl->left_counts[1]));
+        FORKED_OR_RETURN(read_counts());
         for (int c = 0; c < ncls; ++c) { again_counts[c] = ws->h_ctrl->left_counts[0][c]; again_total += again_counts[c]; }
         again_words = ws->h_ctrl->dyn_count < h->dyn_list_cap ? ws->h_ctrl->dyn_count : h->dyn_list_cap;
-        for (int c = 0; c < ncls; ++c) known[c] = ws->h_ctrl->left_counts[1][c];
-        a.lists = left_lists[1];
-        d_list_counts = ws->d_ctrl->left_counts[1];
+        left_at = 1;
+        if (again_total > 0) {
+          if (again_words) {      // the collected words, segmented once each (a few workgroups)
+            ResolveArgs ra{};
+            ra.dev = h->dev; ra.dyn_ent = ws->d_dyn_ent.p; ra.dyn_list = ws->d_dyn_list.p; ra.dyn_count = &ws->d_ctrl->dyn_count;
+            ra.dyn_cap = h->dyn_list_cap; ra.unsafe = h->memo_unsafe ? 1u : 0u;
+            uint64_t g = (static_cast<uint64_t>(again_words) + 63) / 64;
+            if (g > static_cast<uint64_t>(h->n_cu) * 8) g = static_cast<uint64_t>(h->n_cu) * 8;
+            FORKED_HIP_OR_RETURN(LaunchWordResolve(ra, static_cast<int>(g), stream));
+          }
+          // round 2 over what round 1 kept for it; what it cannot take either (a margin that does not hold, a word of
+          // more than 8 pieces) is APPENDED to the lists of what round 1 gave up for good: one tail launch takes both
+          for (int c = 0; c < ncls; ++c) known[c] = again_counts[c];
+          a.lists = left_lists[0];
+          FORKED_OR_RETURN(word_pass(2, kSlotWord2, 4, left_lists[1], ws->d_ctrl->left_counts[1], nullptr, nullptr));
+          FORKED_OR_RETURN(read_counts());
+        }
       } else {
-        if (int rc = word_pass(0, kSlotWord, 3, left_lists[0], ws->d_ctrl->left_counts[0], nullptr, nullptr); rc != kOk) return rc;
-        if (int rc = read_counts(); rc != kOk) return rc;
+        FORKED_OR_RETURN(word_pass(0, kSlotWord, 3, left_lists[0], ws->d_ctrl->left_counts[0], nullptr, nullptr));
+        FORKED_OR_RETURN(read_counts());
         uint64_t total = 0;
         for (int c = 0; c < ncls; ++c) { known[c] = ws->h_ctrl->left_counts[0][c]; total += known[c]; }
         a.lists = left_lists[0];
-        d_list_counts = ws->d_ctrl->left_counts[0];
         // the DP pass pays when the first one's misses are sparse (a rare word here and there)
         if (!is_bpe && !h->no_word_dp && total && (total * 4 <= n || h->force_word_dp)) {
-          if (int rc = word_pass(3, kSlotWord2, 4, left_lists[1], ws->d_ctrl->left_counts[1], nullptr, nullptr); rc != kOk) return rc;
-          if (int rc = read_counts(); rc != kOk) return rc;
-          for (int c = 0; c < ncls; ++c) known[c] = ws->h_ctrl->left_counts[1][c];
-          a.lists = left_lists[1];
-          d_list_counts = ws->d_ctrl->left_counts[1];
+          FORKED_OR_RETURN(word_pass(3, kSlotWord2, 4, left_lists[1], ws->d_ctrl->left_counts[1], nullptr, nullptr));
+          FORKED_OR_RETURN(read_counts());
+          left_at = 1;
         }
       }
-    }
-    if (word_ok && n >= 4096) {          // (see word_ok above)
       uint64_t leftover = 0;
-      uint64_t eligible = 0;
-      for (int c = 0; c < ncls; ++c) if (cls[c].rcap <= h->main_max_raw) { leftover += known[c]; eligible += ws->h_ctrl->list_counts[c]; }
-      if (eligible >= 4096 && leftover * 8 > eligible * 7) h->word_backoff.store(15, std::memory_order_relaxed);
-    }
-    if (again_total > 0 && again_words) {      // the collected words, segmented once each (a few workgroups: before anything big)
-      ResolveArgs ra{};
-      ra.dev = h->dev; ra.dyn_ent = ws->d_dyn_ent.p; ra.dyn_list = ws->d_dyn_list.p; ra.dyn_count = &ws->d_ctrl->dyn_count;
-      ra.dyn_cap = h->dyn_list_cap; ra.unsafe = h->memo_unsafe ? 1u : 0u;
-      uint64_t g = (static_cast<uint64_t>(again_words) + 63) / 64;
-      if (g > static_cast<uint64_t>(h->n_cu) * 8) g = static_cast<uint64_t>(h->n_cu) * 8;
-      HIP_OR_RETURN(h, LaunchWordResolve(ra, static_cast<int>(g), stream));
-    }
-    // ---- fork: with a second word round pending, the general launches below go to the workspace's second stream.  Both
-    // are persistent grids that fill a CU's LDS, so the one enqueued second gets the CUs as the first one's workgroups
-    // retire: the general launch goes first (its tiles differ most in length: a long tail), the second round fills in
-    // behind it.  (Measured: sequential 8.68 ms per C2 step; this 8.3 - 8.4; the general launch held to 8 wavefronts per
-    // workgroup so that both fit a CU at once, SPMX_FORK_WAVES=8: 8.68 -- it takes 2.8 ms instead of 2.0 and stays the
-    // critical path.) ----
-    hipStream_t main_stream = stream;
-    uint64_t general_total = 0;
-    for (int c = 0; c < ncls; ++c) general_total += known[c];
-    const bool forked = again_total > 0 && general_total > 0 && !h->no_overlap;
-    if (forked) {
-      HIP_OR_RETURN(h, hipEventRecord(ws->ev_fork, stream));
-      HIP_OR_RETURN(h, hipStreamWaitEvent(ws->stream2, ws->ev_fork, 0));
-      stream = ws->stream2;
-      stream_waves_cap = h->fork_waves;
-    }
-    if (streaming) {
-      // unigram: the wave-cooperative form (a sentence per wavefront, kernels_uniwave.h) takes the classes where the
-      // lane-per-sentence kernels are the wrong tool -- documents (one lane would walk them alone: 2.5 us per byte),
-      // and classes with too few sentences to fill 64 lanes of every wavefront
-      if (uni_wave) {
-        for (int c = 0; c < ncls; ++c) {
-          if (known[c] == 0 || !uni_class[c]) continue;
-          if (int rc = long_launch(a.lists + static_cast<size_t>(c) * n, &d_list_counts[c], known[c], true); rc != kOk) return rc;
-          known[c] = 0;
-        }
+      for (int c = 0; c < ncls; ++c) {
+        known[c] = ws->h_ctrl->left_counts[left_at][c];
+        if (cls[c].rcap <= h->main_max_raw) leftover += known[c];
       }
-      int c_doc = ncls;                    // first class of the document launch
-      for (int c = 0; c < ncls; ++c) if (cls[c].rcap > h->main_max_raw) { c_doc = c; break; }
-      // Experiment switch (SPMX_LEFT_MERGE=g, off by default, not measured yet): what the word rounds leave is thin --
-      // a tile per wavefront per class, and a wavefront's time is the sum over its tiles of the longest sentence in
-      // each.  Runs of g neighbouring classes become one class: the shorter classes' lists are
-      // appended to the longest one's (device-to-device, a few hundred KB), whose capacities hold them all.
-      if (h->left_merge > 1 && word_ok && general_total * 4 < n) {
-        for (int top = c_doc - 1; top > 0; top -= h->left_merge) {
-          int hi = -1;                     // the longest class of the run that has sentences
-          for (int c = top; c > top - h->left_merge && c >= 0; --c)
-            if (known[c] && !uni_class[c]) { hi = c; break; }
-          for (int c = hi - 1; hi > 0 && c > top - h->left_merge && c >= 0; --c) {
-            if (known[c] == 0 || uni_class[c]) continue;
-            HIP_OR_RETURN(h, hipMemcpyAsync(const_cast<uint32_t *>(a.lists) + static_cast<size_t>(hi) * n + known[hi],
-                                            a.lists + static_cast<size_t>(c) * n, static_cast<size_t>(known[c]) * sizeof(uint32_t),
-                                            hipMemcpyDeviceToDevice, stream));
-            known[hi] += known[c];
-            known[c] = 0;
-          }
-        }
-      }
-      if (int rc = stream_launch(kSlotMain, 0, 0, c_doc, known, false, 0); rc != kOk) return rc;
-      if (int rc = stream_launch(kSlotDoc, 1, c_doc, ncls, known, false, 0); rc != kOk) return rc;
+      // The word rounds pay on text that is mostly plain ASCII words: a handle remembers when a batch they were given
+      // went almost entirely on to the general kernels and leaves them out of its next few calls (see word_ok above).
+      if (n >= 4096 && eligible >= 4096 && leftover * 8 > eligible * 7) h->word_backoff.store(15, std::memory_order_relaxed);
+      // ---- the tail: what the word rounds left ----
+      FORKED_OR_RETURN(general_pass(left_lists[left_at], ws->d_ctrl->left_counts[left_at], known, true));
     } else {
-      // BPE, sentence-per-wave form (models that are not word-wise, or with UNUSED pieces): the staged classes; a
-      // sentence whose normalized form overflows its class escalates to the next staged one, then to the long form
-      int c_staged = 0;
-      while (c_staged < ncls && cls[c_staged].rcap <= kMaxStagedRaw && !h->no_wave && !dropout) ++c_staged;
-      bool first = true;
-      for (int c = 0; c < c_staged; ++c) {
-        EncodeArgs la = a;
-        la.list = class_lists + static_cast<size_t>(c) * n; la.list_count = &ws->d_ctrl->list_counts[c];
-        const bool has_next = c + 1 < c_staged;
-        la.next_list = has_next ? class_lists + static_cast<size_t>(c + 1) * n : nullptr;
-        la.next_count = has_next ? &ws->d_ctrl->list_counts[c + 1] : nullptr;
-        la.rcap = cls[c].rcap; la.ncap = cls[c].ncap;
-        if (la.rcap == kMaxStagedRaw && la.ncap > kBpeWaveNcap3) la.ncap = kBpeWaveNcap3;
-        la.stats = &ws->d_ctrl->stats[kStatsPerClass * kSlotWave];
-        const uint32_t lds = EncodeLdsBytes(kBpe, la.rcap, la.ncap);
-        int per_cu = static_cast<int>(kLdsPerCu / lds);
-        if (per_cu > 32) per_cu = 32;
-        if (per_cu < 1) per_cu = 1;
-        uint64_t grid = static_cast<uint64_t>(h->n_cu) * per_cu;
-        if (grid > n) grid = n;
-        snprintf(ws->slot_name[kSlotWave], sizeof(ws->slot_name[kSlotWave]), "EncodeKernel<2, *>");
-        if (first) HIP_OR_RETURN(h, record(kSlotWave, 0));
-        first = false;
-        HIP_OR_RETURN(h, LaunchEncode(kBpe, c, la, static_cast<int>(grid), lds, stream));
-        HIP_OR_RETURN(h, record(kSlotWave, 1));
-        ws->slot_used[kSlotWave] = true;
-      }
-      for (int c = c_staged; c < ncls; ++c)
-        if (int rc = long_launch(class_lists + static_cast<size_t>(c) * n, &ws->d_ctrl->list_counts[c], known[c]); rc != kOk) return rc;
+      FORKED_OR_RETURN(general_pass(class_lists, ws->d_ctrl->list_counts, known, false));
     }
-    // ---- join: the second word round (on the call's own stream), then what it left ----
-    if (forked) {
-      HIP_OR_RETURN(h, hipEventRecord(ws->ev_join, stream));
-      stream = main_stream;
-      stream_waves_cap = 0;
-    }
-    if (again_total > 0) {
-      for (int c = 0; c < ncls; ++c) known[c] = again_counts[c];
-      a.lists = left_lists[0];
-      if (int rc = word_pass(2, kSlotWord2, 4, left_lists[2], ws->d_ctrl->left_counts[2], nullptr, nullptr); rc != kOk) return rc;
-      if (forked) HIP_OR_RETURN(h, hipStreamWaitEvent(stream, ws->ev_join, 0));
-      HIP_OR_RETURN(h, hipMemcpyAsync(ws->h_ctrl->left_counts, ws->d_ctrl->left_counts, sizeof(ws->h_ctrl->left_counts) + sizeof(uint32_t),
-                                      hipMemcpyDeviceToHost, stream));
-      HIP_OR_RETURN(h, hipStreamSynchronize(stream));
-      // the tail: what the second round could not take either (a margin that does not hold, a word of more than 8
-      // pieces): few sentences -- a sentence per wavefront where the model allows it, else one more lane-per-sentence launch
-      uint32_t tail[kMaxClasses] = {0};
-      uint64_t tail_total = 0;
-      for (int c = 0; c < ncls; ++c) { tail[c] = ws->h_ctrl->left_counts[2][c]; tail_total += tail[c]; }
-      if (tail_total) {
-        a.lists = left_lists[2];
-        d_list_counts = ws->d_ctrl->left_counts[2];
-        if (uni_wave && tail_total < 65536) {
-          for (int c = 0; c < ncls; ++c)
-            if (tail[c]) if (int rc = long_launch(a.lists + static_cast<size_t>(c) * n, &d_list_counts[c], tail[c], true); rc != kOk) return rc;
-        } else {
-          if (int rc = stream_launch(kSlotDoc, 5, 0, ncls, tail, false, 0); rc != kOk) return rc;
-        }
-      }
-    } else if (forked) {
-      HIP_OR_RETURN(h, hipStreamWaitEvent(stream, ws->ev_join, 0));
-    }
+    // ---- join ----
+    if (forked) FORKED_HIP_OR_RETURN(hipStreamWaitEvent(stream, ws->ev_join, 0));
+#undef FORKED_OR_RETURN
+#undef FORKED_HIP_OR_RETURN
     if (int rc = scan_compact(); rc != kOk) return rc;
     if (ws->h_ctrl->status & kStArenaOverflow) {   // rare: byte fallback of multi-byte unknowns; arena_head holds what was asked for
       arena_need = ws->h_ctrl->arena_head + ws->h_ctrl->arena_head / 8 + 64;
@@ -1357,7 +1386,7 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_NO_WORD_DYN")) h->no_word_dyn = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_OVERLAP")) h->no_overlap = e[0] == '1';
     if (const char *e = getenv("SPMX_FORK_WAVES")) h->fork_waves = atoi(e);
-    if (const char *e = getenv("SPMX_LEFT_MERGE")) { const int v = atoi(e); if (v >= 0 && v <= kMaxClasses) h->left_merge = v; }
+    if (const char *e = getenv("SPMX_NO_SCAN")) h->no_scan = e[0] == '1';
     if (const char *e = getenv("SPMX_DYN_SLOTS_LOG2")) { const int v = atoi(e); if (v >= 4 && v <= 26) h->dyn_slots = 1u << v; }
     if (const char *e = getenv("SPMX_DYN_LIST_CAP")) { const long v = atol(e); if (v >= 1 && v <= (1l << 26)) h->dyn_list_cap = static_cast<uint32_t>(v); }
     if (const char *e = getenv("SPMX_NBEST_BUDGET_GB")) { const long v = atol(e); if (v >= 1 && v <= 200) h->nbest_budget = static_cast<uint64_t>(v) << 30; }

@@ -644,9 +644,17 @@ inline uint32_t EncodeLdsBytes(int model_type, uint32_t rcap, uint32_t ncap) {
 // in lock step: an unsorted corpus cost 1.6x the search iterations of a length-bucketed one, profiles/).
 constexpr int kSubBuckets = 16;                        // default number of length sub-buckets per class
 constexpr int kMaxSubBuckets = 64;                     // ClassifyArgs::sub_buckets may go up to this
-constexpr int kSortKeys = kMaxClasses * kMaxSubBuckets;   // capacity of the key tables
+constexpr int kSortKeys = 2 * kMaxClasses * kMaxSubBuckets;   // capacity of the key tables (plain + set-aside keys)
 constexpr int kClassifyChunk = 16;   // a wave takes chunks of 16 x 64 sentences
+constexpr uint32_t kClassifyLdsWords = 3u * kSortKeys + 2u * (64u * kClassifyChunk + 2u) + 64u * kClassifyChunk / 32u;
 
+// The PLAIN scan (round 4).  The word kernels (kernels_word.h) take sentences that are plain ASCII words; a sentence
+// with any other byte (below 0x20, 0x7F and above: control characters, UTF-8) leaves them for the general kernels
+// anyway -- after costing the word round an iteration per word, and with the general launch waiting for the word round
+// to name it.  When `text` is set the count pass therefore reads the chunk's text once (its 1024 sentences are
+// contiguous: coalesced 16-byte loads), flags every sentence holding such a byte, and the scatter pass sends the
+// flagged sentences to a second set of class lists (lists2): the general launch over them starts NEXT TO the first
+// word round instead of after it.  The flag only routes: both kernel families encode any sentence they are given.
 struct ClassifyArgs {
   const uint64_t *offs;
   uint32_t n;
@@ -658,6 +666,11 @@ struct ClassifyArgs {
   uint32_t *key_cursor;         // kSortKeys (zeroed): scatter pass progress
   uint32_t sub_buckets;         // length sub-buckets per class (1 .. kMaxSubBuckets): the tiles of the encode kernels
                                 // are the more homogeneous the finer the sort
+  // the plain scan (all null / unused without it)
+  const uint8_t *text;          // packed sentences
+  uint8_t *flags;               // n bytes, written by the count pass: 1 = the sentence holds a byte outside 0x20 .. 0x7E
+  uint32_t *lists2;             // n_classes x n: the flagged sentences, by class
+  uint32_t *list2_counts;       // n_classes
 };
 
 // (class << 4 | sub-bucket) of a sentence of len raw bytes
@@ -671,36 +684,110 @@ SPMX_DEVICE uint32_t classify_key(const ClassifyArgs &a, uint64_t len) {
   return static_cast<uint32_t>(cls) * a.sub_buckets + static_cast<uint32_t>(sub);
 }
 
-// PASS 0 counts, PASS 1 scatters.  hist is kSortKeys * 3 words of LDS (per wave).
+// bit 7 of every byte of v that is below 0x20 or above 0x7E (a carry / borrow may also flag the byte above a true one:
+// harmless, the flag only routes)
+SPMX_DEVICE uint32_t nonplain_bits(uint32_t v) {
+  return ((((v + 0x01010101u) | v) | ((v - 0x20202020u) & ~v)) & 0x80808080u);
+}
+
+// Flags the sentences [first, first + cnt) that hold a byte outside 0x20 .. 0x7E: bits[k >> 5] |= 1 << (k & 31).
+// rel (LDS, cnt + 1 entries): the sentences' offsets; bits (LDS): zeroed here.
+SPMX_DEVICE void plain_scan_chunk(const ClassifyArgs &a, uint32_t first, uint32_t cnt, uint64_t *rel, uint32_t *bits, int lane) {
+  for (uint32_t k = static_cast<uint32_t>(lane); k <= cnt; k += 64u) rel[k] = a.offs[first + k];
+  for (uint32_t k = static_cast<uint32_t>(lane); k < 64u * kClassifyChunk / 32u; k += 64u) bits[k] = 0u;
+  wv::sync();
+  const uint64_t t0 = rel[0], t1 = rel[cnt];
+  const uint64_t base_addr = reinterpret_cast<uint64_t>(a.text);
+  // 16-byte units aligned in MEMORY (a unit that holds a valid byte lies inside the buffer's pages; what it holds before
+  // t0 or beyond t1 belongs to no sentence of this chunk and is ignored)
+  const uint64_t u0 = (base_addr + t0) & ~15ull, u1 = base_addr + t1;
+  auto owner = [&](uint64_t off) -> uint32_t {       // the sentence k with rel[k] <= off < rel[k + 1] (off in [t0, t1))
+    uint32_t lo = 0, hi = cnt;                        // invariant: rel[lo] <= off < rel[hi]
+    while (hi - lo > 1u) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (rel[mid] <= off) lo = mid; else hi = mid;
+    }
+    return lo;
+  };
+  for (uint64_t u = u0 + static_cast<uint64_t>(lane) * 16u; u < u1; u += 64u * 16u * 4u) {
+    Q4 v[4];
+    uint32_t m[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                     // four units in flight per lane
+      const uint64_t uj = u + static_cast<uint64_t>(j) * 1024u;
+      v[j] = uj < u1 ? *reinterpret_cast<const Q4 *>(uj) : Q4{0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u};
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] = nonplain_bits(v[j].x) | nonplain_bits(v[j].y) | nonplain_bits(v[j].z) | nonplain_bits(v[j].w);
+    if ((m[0] | m[1] | m[2] | m[3]) == 0u) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (m[j] == 0u) continue;
+      const uint64_t uj = u + static_cast<uint64_t>(j) * 1024u;
+      const uint32_t z[4] = {nonplain_bits(v[j].x), nonplain_bits(v[j].y), nonplain_bits(v[j].z), nonplain_bits(v[j].w)};
+      int b_lo = -1, b_hi = -1;                       // first and last flagged byte of the unit
+      for (int d = 0; d < 4; ++d)
+        for (int q = 0; q < 4; ++q)
+          if (z[d] & (0x80u << (8 * q))) { if (b_lo < 0) b_lo = 4 * d + q; b_hi = 4 * d + q; }
+      // (a flag raised by a carry sits one byte above a true one: still inside the same or the next sentence -- a
+      // sentence flagged for nothing only takes the general kernels)
+      uint64_t o_lo = uj + static_cast<uint64_t>(b_lo) - base_addr, o_hi = uj + static_cast<uint64_t>(b_hi) - base_addr;
+      if (uj + static_cast<uint64_t>(b_lo) < base_addr + t0) o_lo = t0;
+      if (o_hi >= t1) o_hi = t1 - 1;
+      if (uj + static_cast<uint64_t>(b_hi) < base_addr + t0 || o_lo >= t1 || o_lo > o_hi) continue;
+      const uint32_t k_lo = owner(o_lo), k_hi = owner(o_hi);
+      for (uint32_t k = k_lo; k <= k_hi; ++k) wv::lds_atomic_or(&bits[k >> 5], 1u << (k & 31u));
+    }
+  }
+  wv::sync();
+}
+
+// PASS 0 counts (and scans), PASS 1 scatters.  lds: kClassifyLdsWords words (per wave).
 template <int PASS>
-SPMX_DEVICE void classify_block(const ClassifyArgs &a, uint32_t *hist) {
+SPMX_DEVICE void classify_block(const ClassifyArgs &a, uint32_t *lds) {
   const int lane = wv::lane();
-  uint32_t *start = hist + kSortKeys, *base = hist + 2 * kSortKeys;
+  uint32_t *hist = lds, *start = lds + kSortKeys, *base = lds + 2 * kSortKeys;
+  uint64_t *rel = reinterpret_cast<uint64_t *>(lds + 3 * kSortKeys);
+  uint32_t *bits = lds + 3 * kSortKeys + 2 * (64 * kClassifyChunk + 2);
+  const bool scan = a.text != nullptr;
   const int nsub = static_cast<int>(a.sub_buckets);
-  const int n_keys = static_cast<int>(a.n_classes) * nsub;
+  const int n_plain_keys = static_cast<int>(a.n_classes) * nsub;
+  const int n_keys = scan ? 2 * n_plain_keys : n_plain_keys;
   if (PASS == 1) {
-    // where every key's run begins: its class list + the keys of the same class before it
+    // where every key's run begins: its class list + the keys of the same list before it
     for (int k = lane; k < n_keys; k += 64) {
       const int c = k / nsub;
       uint32_t before = 0;
       for (int j = c * nsub; j < k; ++j) before += a.key_totals[j];
       base[k] = before;
-      if (wv::block_id() == 0 && k % nsub == nsub - 1) a.list_counts[c] = before + a.key_totals[k];
+      if (wv::block_id() == 0 && k % nsub == nsub - 1) {
+        if (c < static_cast<int>(a.n_classes)) a.list_counts[c] = before + a.key_totals[k];
+        else a.list2_counts[c - static_cast<int>(a.n_classes)] = before + a.key_totals[k];
+      }
     }
   }
   const uint32_t per_chunk = 64u * kClassifyChunk;
   const uint32_t chunks = (a.n + per_chunk - 1) / per_chunk;
   for (uint32_t ch = static_cast<uint32_t>(wv::block_id()); ch < chunks; ch += static_cast<uint32_t>(wv::grid_size())) {
     const uint32_t first = ch * per_chunk;
+    const uint32_t cnt = a.n - first < per_chunk ? a.n - first : per_chunk;
     for (int k = lane; k < n_keys; k += 64) hist[k] = 0;
     wv::sync();
+    if (PASS == 0 && scan) plain_scan_chunk(a, first, cnt, rel, bits, lane);
     uint32_t keys[kClassifyChunk];
 #pragma unroll
     for (int k = 0; k < kClassifyChunk; ++k) {
-      const uint32_t i = first + static_cast<uint32_t>(k) * 64u + static_cast<uint32_t>(lane);
+      const uint32_t j = static_cast<uint32_t>(k) * 64u + static_cast<uint32_t>(lane);
+      const uint32_t i = first + j;
       keys[k] = 0xFFFFFFFFu;
       if (i < a.n) {
         keys[k] = classify_key(a, a.offs[i + 1] - a.offs[i]);
+        if (scan) {
+          uint32_t f;
+          if (PASS == 0) { f = (bits[j >> 5] >> (j & 31u)) & 1u; a.flags[i] = static_cast<uint8_t>(f); }
+          else f = a.flags[i];
+          if (f) keys[k] += static_cast<uint32_t>(n_plain_keys);
+        }
         wv::lds_atomic_add(&hist[keys[k]], 1u);
       }
     }
@@ -720,7 +807,9 @@ SPMX_DEVICE void classify_block(const ClassifyArgs &a, uint32_t *hist) {
         if (keys[k] != 0xFFFFFFFFu) {
           const uint32_t key = keys[k], c = key / a.sub_buckets;
           const uint32_t r = wv::lds_atomic_add(&hist[key], 1u);
-          a.lists[static_cast<uint64_t>(c) * a.n + base[key] + start[key] + r] = i;
+          uint32_t *list = c < a.n_classes ? a.lists + static_cast<uint64_t>(c) * a.n
+                                           : a.lists2 + static_cast<uint64_t>(c - a.n_classes) * a.n;
+          list[base[key] + start[key] + r] = i;
         }
       }
     }

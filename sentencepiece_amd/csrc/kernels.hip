@@ -96,12 +96,12 @@ __global__ __launch_bounds__(64) void SplitWriteKernel(SplitArgs a) {
 __global__ __launch_bounds__(64) void DecodeCountKernel(DecodeArgs a) { decode_block<false>(a); }
 __global__ __launch_bounds__(64) void DecodeWriteKernel(DecodeArgs a) { decode_block<true>(a); }
 __global__ __launch_bounds__(64) void ClassifyCountKernel(ClassifyArgs a) {
-  __shared__ uint32_t hist[3 * kSortKeys];
-  classify_block<0>(a, hist);
+  __shared__ __attribute__((aligned(16))) uint32_t lds[kClassifyLdsWords];
+  classify_block<0>(a, lds);
 }
 __global__ __launch_bounds__(64) void ClassifyScatterKernel(ClassifyArgs a) {
-  __shared__ uint32_t hist[3 * kSortKeys];
-  classify_block<1>(a, hist);
+  __shared__ __attribute__((aligned(16))) uint32_t lds[kClassifyLdsWords];
+  classify_block<1>(a, lds);
 }
 __global__ __launch_bounds__(64) void ScanTilesKernel(ScanArgs a) { scan_tiles_block(a); }
 __global__ __launch_bounds__(64) void ScanSumsKernel(ScanArgs a) { scan_sums_block(a); }

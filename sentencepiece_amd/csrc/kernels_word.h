@@ -191,10 +191,13 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
   const bool bf = (d.flags & kNfByteFallback) != 0;
   Q4U w{0, 0, 0, 0};
   if (active) w = *reinterpret_cast<const Q4U *>(text + p);
+#if SPMX_EXP & (8 | 32)
+  uint32_t exp_acc = 0;
+#endif
   auto put = [&](uint32_t id) __attribute__((always_inline)) {
     stage[(n & 7) << 6] = static_cast<int32_t>(id);
     ++n;
-    if ((n & 7) == 0) {
+    if ((n & 7) == 0 && !(SPMX_EXP & 16)) {   // (16: experiment build without the id bursts)
       int32_t *q = slot + (n - 8);
       *reinterpret_cast<Q4 *>(q) = Q4{static_cast<uint32_t>(stage[0]), static_cast<uint32_t>(stage[1 << 6]),
                                       static_cast<uint32_t>(stage[2 << 6]), static_cast<uint32_t>(stage[3 << 6])};
@@ -262,6 +265,9 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
     const bool more = run && pn < len;
     Q4U wn = w;
     if (more) wn = *reinterpret_cast<const Q4U *>(text + pn);
+#if SPMX_EXP & 8      // (experiment build: what ONE more 64-lane text gather per iteration costs)
+    if (more) { const Q4U x = *reinterpret_cast<const Q4U *>(text + (pn + 160 < len ? pn + 160 : pn)); exp_acc ^= x.x ^ x.y ^ x.z ^ x.w; }
+#endif
     U4 ent{0, 0, 0, 0xFFFFFFFFu};                    // the entry taken: umemo16 format, or {id0, id1, bound, bmax} of umemo
     bool hit16 = false, hit32 = false;
     uint32_t k0 = 0, k1 = 0, k2 = 0, k3 = 0;
@@ -278,6 +284,9 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
       hit16 = shortw && e.x == k0 && e.y == k1 && e.z == k2 && e.w != 0xFFFFFFFFu;
       if (hit16) ent = e;
     }
+#if SPMX_EXP & 32     // (experiment build: one more memo16 gather per iteration, every lane with a short word)
+    { const U4 x = memo16[shortw ? ((h * 0x9E3779B1u) >> 7) & m16 : 0u]; exp_acc ^= x.x ^ x.w; }
+#endif
     bool look = shortw && !hit16;
     if (wv::any(look)) {                             // the rest of the one-piece words of up to 12 bytes: one probe, HBM / L2
       uint32_t sl = h & m16;
@@ -436,6 +445,9 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
     if (run) { p = pn; w = wn; }
   }
   *n_steps = steps;
+#if SPMX_EXP & (8 | 32)
+  if (exp_acc == 0x9E3779B1u) ++steps, *n_steps = steps;     // (keeps the experiment's loads alive)
+#endif
   if (bad && MODE == kWmCollect && again) {
     for (int k = n & ~7; k < n; ++k) slot[k] = stage[(k & 7) << 6];   // what is staged belongs to the ids the second round keeps
     return -2;

@@ -56,6 +56,7 @@ SPMX_DEVICE uint32_t atomic_add(uint32_t *p, uint32_t v) { return atomicAdd(p, v
 SPMX_DEVICE unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
 SPMX_DEVICE void atomic_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }
 SPMX_DEVICE uint32_t lds_atomic_add(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }   // p in LDS
+SPMX_DEVICE void lds_atomic_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }                  // p in LDS
 SPMX_DEVICE void atomic_min(unsigned long long *p, unsigned long long v) { atomicMin(p, v); }
 SPMX_DEVICE void atomic_max(unsigned long long *p, unsigned long long v) { atomicMax(p, v); }
 SPMX_DEVICE void atomic_and(uint32_t *p, uint32_t v) { atomicAnd(p, v); }
@@ -75,7 +76,8 @@ SPMX_DEVICE uint32_t float_to_bits(float f) { return __float_as_uint(f); }
 
 // Experiment builds (-DSPMX_EXP=<bits>, csrc/Makefile `variants`; results are WRONG, only the counters mean something):
 // which store stream writes how much -- 1 drops the id stores into the arena, 2 the back-pointer block stores, 4 the
-// text-column stores of the ASCII normalizer.
+// text-column stores of the ASCII normalizer; word kernels (kernels_word.h): 8 one more text gather per iteration, 16 no
+// id bursts, 32 one more memo gather per iteration.
 #ifndef SPMX_EXP
 #define SPMX_EXP 0
 #endif

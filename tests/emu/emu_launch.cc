@@ -102,8 +102,8 @@ hipError_t LaunchDecode(bool write, const DecodeArgs &a, int grid, hipStream_t) 
   return hipSuccess;
 }
 hipError_t LaunchClassify(const ClassifyArgs &a, int grid, hipStream_t) {
-  RunGrid(grid, 1, 3 * kSortKeys * 4, [&](unsigned char *s) { classify_block<0>(a, reinterpret_cast<uint32_t *>(s)); });
-  RunGrid(grid, 1, 3 * kSortKeys * 4, [&](unsigned char *s) { classify_block<1>(a, reinterpret_cast<uint32_t *>(s)); });
+  RunGrid(grid, 1, kClassifyLdsWords * 4, [&](unsigned char *s) { classify_block<0>(a, reinterpret_cast<uint32_t *>(s)); });
+  RunGrid(grid, 1, kClassifyLdsWords * 4, [&](unsigned char *s) { classify_block<1>(a, reinterpret_cast<uint32_t *>(s)); });
   return hipSuccess;
 }
 hipError_t LaunchScan(const ScanArgs &a, int grid, hipStream_t) {

@@ -94,6 +94,7 @@ inline uint32_t atomic_add(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p 
 inline unsigned long long atomic_add(unsigned long long *p, unsigned long long v) { const unsigned long long o = *p; *p = o + v; return o; }
 inline void atomic_or(uint32_t *p, uint32_t v) { *p |= v; }
 inline uint32_t lds_atomic_add(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
+inline void lds_atomic_or(uint32_t *p, uint32_t v) { *p |= v; }
 inline void atomic_min(unsigned long long *p, unsigned long long v) { if (v < *p) *p = v; }
 inline void atomic_max(unsigned long long *p, unsigned long long v) { if (v > *p) *p = v; }
 inline void atomic_and(uint32_t *p, uint32_t v) { *p &= v; }

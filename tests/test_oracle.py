@@ -78,3 +78,25 @@ def test_oracle_set_vocabulary_matches_reference(corpora, oracle):
         a, _ = ref.encode_batch(text, offs)
         b, _ = o.encode_batch(text, offs)
         np.testing.assert_array_equal(a, b)
+
+
+def test_whole_corpus_checker_counts_differing_sentences(oracle, corpora):
+    """tests/fullcheck.py (the all-sentences comparison of the full-size GPU tests and of bench.py's probe): equal CSRs
+    pass; an altered id and an altered length are counted, per sentence, and the first one is named."""
+    from tests import fullcheck
+    blob = fixtures.model_blob("uni32k")
+    text, offs = fixtures.head(*corpora["synth20k"], 5000)
+    ids, io = oracle.load(blob).encode_batch(text, offs)
+    r = fullcheck.compare_all(text, offs, ids, io, blob, chunk=1200)
+    assert r["compared"] == r["sentences"] == 5000 and r["differing"] == 0 and r["first"] is None
+    bad = np.array(ids, copy=True)
+    io_i = np.asarray(io).astype(np.int64)
+    bad[io_i[1300]] ^= 1                    # one id of sentence 1300
+    bad[io_i[4000] + 1] ^= 1
+    r = fullcheck.compare_all(text, offs, bad, io, blob, chunk=1200)
+    assert r["differing"] == 2 and r["first"] == 1300
+    io2 = np.array(io_i, copy=True)
+    io2[2500:] += 1                         # sentence 2499 one id longer: every later range shifts, only 2499 changes length
+    ids2 = np.insert(np.asarray(ids), io_i[2500], 7)
+    r = fullcheck.compare_all(text, offs, ids2, io2.astype(np.uint64), blob, chunk=1200)
+    assert r["differing"] == 1 and r["first"] == 2499

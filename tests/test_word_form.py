@@ -43,6 +43,9 @@ def _gpu_load(blob, variant, extra=None):
         from tests.emulib import SMALL_CLASSES
         env["SPMX_CLASSES"] = SMALL_CLASSES
     env.update(extra or {})
+    # the word rounds run in every call: a handle that saw a batch leave them almost entirely would skip them for its
+    # next calls (api.cc word_backoff), and these inputs are made to leave them
+    env.setdefault("SPMX_FORCE_WORD_DP", "1")
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
@@ -284,3 +287,81 @@ def test_gpu_vocabulary_cycle_with_word_kernels(model, oracle):
     for b2, what in ((blob, model), (_with_one_unused_piece(blob), model + " (a piece UNUSED in the file)")):
         sp, o = _gpu_load(b2, "default"), oracle.load(b2)
         _vocab_cycle(sp, o, lambda x, p: x.SetVocabulary(p), lambda x: x.ResetVocabulary(), sp.EncodePacked, words, pieces, what)
+
+
+# ---- (e) the plain scan of classify: what is not plain ASCII goes to the general kernels next to the first word round ----
+
+def _scan_corpus(words, n, seed):
+    """n sentences (more than one classify chunk of 1024): mostly plain, every 9th with a byte outside 0x20 .. 0x7E at
+    its start / middle / end, empty sentences, sentences of one byte."""
+    rng = np.random.default_rng(seed)
+    odd = [b"\x00", b"\t", b"\x1f", b"\x7f", b"\x80", "é".encode(), "日本".encode(), b"\xff", "　".encode()]
+    sents, is_odd = [], []
+    for i in range(n):
+        k = int(rng.integers(1, 30))
+        ws = [words[int(j)] for j in rng.integers(0, len(words), size=k)]
+        s = b" ".join(ws)
+        o = False
+        if i % 9 == 4:
+            x = odd[int(rng.integers(0, len(odd)))]
+            how = i % 4
+            s = x + s if how == 0 else (s + x if how == 1 else (s[:len(s) // 2] + x + s[len(s) // 2:] if how == 2 else x))
+            o = True
+        elif i % 50 == 7:
+            s = b""
+        elif i % 50 == 8:
+            s = b"a"
+        sents.append(s)
+        is_odd.append(o)
+    return sents, np.array(is_odd)
+
+
+@pytest.mark.parametrize("shift", [0, 5])
+@pytest.mark.parametrize("model", ["uni32k", "bpe32k"])
+def test_emu_plain_scan_sets_the_other_sentences_aside(model, shift, emu, oracle):
+    blob = fixtures.model_blob(model)
+    words = wordfuzz.whole_words(blob, limit=800)
+    sents, is_odd = _scan_corpus(words, 2600, seed=5)
+    text, offs = synth.pack(sents + [b"x" * 40])        # (the last 20 bytes of a buffer are not the word form's)
+    pad = np.zeros(len(text) + 16, dtype=np.uint8)      # the text at an address that is not a multiple of 16
+    pad[shift:shift + len(text)] = text
+    o = oracle.load(blob)
+    oids, oio = o.encode_batch(text, offs)
+    for env in ({}, {"SPMX_NO_SCAN": "1"}, {"SPMX_NO_OVERLAP": "1"}):
+        h = emu.load(blob, classes=None, env=env)
+        ids, io = h.encode_batch(pad[shift:shift + len(text)], offs)
+        k = wordfuzz.first_difference(ids, io, oids, oio)
+        assert k < 0, (env, k, sents[k])
+        prof = [(c["kernel"], c["sentences"]) for c in h.sp.LastProfile()["classes"] if c["kernel"]]
+        word = sum(v for kname, v in prof if kname.startswith("EncodeWord"))
+        rest = sum(v for kname, v in prof if not kname.startswith("EncodeWord"))
+        assert len(sents) + 1 - 8 <= word + rest <= len(sents) + 1      # (BPE: a sentence handed on to the long form is in no kernel's count)
+        if not env:
+            # every sentence with such a byte was set aside (a few plain neighbours may go with them: the SWAR test's
+            # carries), and the plain ones stayed with the word kernels
+            assert int(is_odd.sum()) <= rest <= int(is_odd.sum()) + 12, (prof, int(is_odd.sum()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["uni32k", "bpe32k", "uni32k_w16"])
+def test_gpu_plain_scan_sets_the_other_sentences_aside(model, oracle):
+    blob = fixtures.model_blob(model)
+    words = wordfuzz.whole_words(blob, limit=800)
+    sents, is_odd = _scan_corpus(words, 300_000, seed=6)
+    text, offs = synth.pack(sents + [b"x" * 40])
+    o = oracle.load(blob)
+    oids, oio = o.encode_batch(text, offs)
+    import torch
+    for env in ({}, {"SPMX_NO_SCAN": "1"}, {"SPMX_NO_OVERLAP": "1"}, {"SPMX_FORK_WAVES": "8"}):
+        sp = _gpu_load(blob, "default", env)
+        sp.SetProfiling(True)
+        for shift in (0, 3):
+            d = torch.zeros(len(text) + 16, dtype=torch.uint8, device="cuda")
+            d[shift:shift + len(text)] = torch.from_numpy(text).cuda()
+            d_ids, d_io, total = sp.EncodeDevice(d[shift:shift + len(text)], torch.from_numpy(offs.view(np.int64)).cuda())
+            k = wordfuzz.first_difference(d_ids[:total].cpu().numpy(), d_io.cpu().numpy().astype(np.uint64), oids, oio)
+            assert k < 0, (env, shift, k, sents[k])
+        prof = [(c["kernel"], c["sentences"]) for c in sp.LastProfile()["classes"] if c["kernel"]]
+        rest = sum(v for kname, v in prof if not kname.startswith("EncodeWord"))
+        if not env:
+            assert int(is_odd.sum()) <= rest <= int(is_odd.sum()) + 1000, (prof, int(is_odd.sum()))
