@@ -138,40 +138,38 @@ def cpu_baseline(text, offs, model_blob, gpu_counts, gpu_ids=None, gpu_id_offset
             out["spm_encode_c1"] = {"failed": repr(e)}
     if gpu_ids is not None:
         try:
-            probe = np.linspace(0, n - 1, num=min(n, 20000)).astype(np.int64)
-            pt, po = synth.gather_packed(text, offs, probe)
-            cids, cio = h.encode_batch(pt, po)
-            io = np.asarray(gpu_id_offsets).astype(np.int64)
-            lens = (io[1:] - io[:-1])[probe]
-            idx = np.repeat(io[:-1][probe] - np.concatenate([[0], np.cumsum(lens)[:-1]]), lens) + np.arange(int(lens.sum()))
-            out["probe_ids_bit_exact"] = bool(np.array_equal(lens, np.diff(np.asarray(cio).astype(np.int64))) and
-                                              np.array_equal(np.asarray(gpu_ids)[idx], np.asarray(cids)))
-            out["probe"] = "%d sentences strided over the bench corpus, ids compared one by one" % len(probe)
+            out["probe_ids_bit_exact"], out["probe"] = probe_exact(text, offs, model_blob, gpu_ids, gpu_id_offsets)
         except Exception as e:
             out["probe_ids_bit_exact"] = None
             out["probe"] = "failed: %r" % (e,)
     return out
 
 
-def probe_exact(text, offs, model_blob, gpu_ids, gpu_id_offsets, k=20000):
-    """ids of a strided sample of the batch, one by one, against the compiled reference (None if it is not built)."""
+def probe_exact(text, offs, model_blob, gpu_ids, gpu_id_offsets, k=None):
+    """EVERY sentence's ids against the compiled reference (tests/fullcheck.py: its Encode loop on all host cores over
+    chunks of the corpus; the oracle where the reference is not built).  k: only a strided sample of k sentences.
+    -> (bit_exact or None, text of what was compared)"""
     from sentencepiece_amd import synth
-    from tests import refshim
-    if not refshim.available():
-        return None
+    from tests import fullcheck
     n = len(offs) - 1
-    h = refshim.RefLib().load(model_blob)
-    probe = np.unique(np.linspace(0, n - 1, num=min(n, k)).astype(np.int64))
-    pt, po = synth.gather_packed(text, offs, probe)
-    cids, cio = h.encode_batch(pt, po)
-    io = np.asarray(gpu_id_offsets).astype(np.int64)
-    lens = (io[1:] - io[:-1])[probe]
-    idx = np.repeat(io[:-1][probe] - np.concatenate([[0], np.cumsum(lens)[:-1]]), lens) + np.arange(int(lens.sum()))
-    return bool(np.array_equal(lens, np.diff(np.asarray(cio).astype(np.int64))) and
-                np.array_equal(np.asarray(gpu_ids)[idx], np.asarray(cids)))
+    if k is not None and k < n:
+        probe = np.unique(np.linspace(0, n - 1, num=k).astype(np.int64))
+        pt, po = synth.gather_packed(text, offs, probe)
+        io = np.asarray(gpu_id_offsets).astype(np.int64)
+        lens = (io[1:] - io[:-1])[probe]
+        idx = np.repeat(io[:-1][probe] - np.concatenate([[0], np.cumsum(lens)[:-1]]), lens) + np.arange(int(lens.sum()))
+        sub_io = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        r = fullcheck.compare_all(pt, po, np.asarray(gpu_ids)[idx], sub_io, model_blob)
+        what = "%d sentences strided over the %d of the batch" % (len(probe), n)
+    else:
+        r = fullcheck.compare_all(text, offs, gpu_ids, gpu_id_offsets, model_blob, limit_seconds=90.0)
+        what = "%d sentences = the whole batch" % r["compared"] if r["compared"] == n else \
+               "%d of the batch's %d sentences (time limit)" % (r["compared"], n)
+    return r["differing"] == 0, "%s, ids compared one by one with the %s in %.1f s: %d sentences differ" % (
+        what, r["kind"], r["seconds"], r["differing"])
 
 
-def side_bench(sp_cls, torch, dev, name, blob, text, offs, steps, warmup, what, probe_k=20000):
+def side_bench(sp_cls, torch, dev, name, blob, text, offs, steps, warmup, what, probe_k=None):
     """A compact record of one more single-GPU configuration: value, kernels, roofline fraction of
     the dominant kernel, ids of a sample against the compiled reference."""
     sp = sp_cls(model_proto=blob, device=dev.index or 0)
@@ -206,7 +204,7 @@ def side_bench(sp_cls, torch, dev, name, blob, text, offs, steps, warmup, what, 
         out["roofline"]["traffic"], _, out["roofline"]["traffic_note"] = traffic_on_record(name, n, dom["kernel"])
     try:
         io_h = io.cpu().numpy()
-        out["probe_ids_bit_exact"] = probe_exact(text, offs, blob, ids[:int(io_h[-1])].cpu().numpy(), io_h, probe_k)
+        out["probe_ids_bit_exact"], out["probe"] = probe_exact(text, offs, blob, ids[:int(io_h[-1])].cpu().numpy(), io_h, probe_k)
     except Exception as e:      # the check must not cost the bench line
         out["probe_ids_bit_exact"] = None
         out["probe_error"] = repr(e)[:200]
@@ -469,6 +467,20 @@ def main():
                                        args.steps, args.warmup, "configs[2]: 32k BPE, the same %d sentences" % n)
             except Exception as e:
                 out["c3"] = {"failed": repr(e)[:300]}
+            # text the word memo does not fit by construction: the C2 recipe with 5 % of its tokens fresh random words, and
+            # the novel of the reference's own tests x 2000 (8.6 M lines), each with every sentence against the reference
+            try:
+                from sentencepiece_amd import synth
+                for key, mk, what in (("natural_open_vocab", lambda: synth.open_vocab_corpus(n, seed=20250301),
+                                       "the C2 recipe, 5 %% of the word draws replaced by fresh random words (200 k of them), %d sentences" % n),
+                                      ("natural_botchan_x2000", lambda: synth.repeated_file_corpus(os.path.join(ROOT, "tests", "golden", "botchan.txt"), 2000),
+                                       "tests/golden/botchan.txt x 2000, lines shuffled per repetition, in file order (not length-bucketed)")):
+                    tn, on = mk()
+                    out[key] = side_bench(SentencePieceProcessor, torch, dev, "uni32k", blob, tn, on, args.steps, args.warmup, what)
+                    out[key]["vs_headline"] = out[key]["value"] / out["value"]
+                    del tn, on
+            except Exception as e:
+                out["natural"] = {"failed": repr(e)[:300]}
             try:
                 t5, o5 = corpus_for("c5_250k", 1_000_000, 20250227, False)
                 out["c5"] = side_bench(SentencePieceProcessor, torch, dev, "c5_250k", model_blob("c5_250k"), t5, o5,
@@ -483,7 +495,7 @@ def main():
                 for key, nd, nb in (("docs_16k", 8192, 16384), ("docs_1m", 256, 1 << 20)):
                     td, od = docs_rate.make_docs(nd, nb)
                     out[key] = side_bench(SentencePieceProcessor, torch, dev, "uni32k", blob, td, od, max(1, args.steps // 2), 1,
-                                          "%d documents of ~%d bytes (C2 sentences joined by spaces), uni32k" % (nd, nb), probe_k=4)
+                                          "%d documents of ~%d bytes (C2 sentences joined by spaces), uni32k" % (nd, nb))
                     out[key]["mb_per_s"] = len(td) / 1e6 / (out[key]["ms_per_step"] * 1e-3)
                     del td, od
             except Exception as e:

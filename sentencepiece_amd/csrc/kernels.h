@@ -671,6 +671,7 @@ struct ClassifyArgs {
   uint8_t *flags;               // n bytes, written by the count pass: 1 = the sentence holds a byte outside 0x20 .. 0x7E
   uint32_t *lists2;             // n_classes x n: the flagged sentences, by class
   uint32_t *list2_counts;       // n_classes
+  uint32_t scan_max_rcap;       // classes beyond this size are never split (documents: the few there are go through one launch)
 };
 
 // (class << 4 | sub-bucket) of a sentence of len raw bytes
@@ -786,7 +787,7 @@ SPMX_DEVICE void classify_block(const ClassifyArgs &a, uint32_t *lds) {
           uint32_t f;
           if (PASS == 0) { f = (bits[j >> 5] >> (j & 31u)) & 1u; a.flags[i] = static_cast<uint8_t>(f); }
           else f = a.flags[i];
-          if (f) keys[k] += static_cast<uint32_t>(n_plain_keys);
+          if (f && a.rcap[keys[k] / a.sub_buckets] <= a.scan_max_rcap) keys[k] += static_cast<uint32_t>(n_plain_keys);
         }
         wv::lds_atomic_add(&hist[keys[k]], 1u);
       }

@@ -191,6 +191,48 @@ def unpack(text, offs):
     return [b[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
 
 
+
+def open_vocab_corpus(n_sentences: int, seed: int = 20250301, oov: float = 0.05, words: WordList | None = None,
+                      sort_by_length: bool = True):
+    """The C2 recipe with a share `oov` of the word draws replaced by FRESH random words (letters by frequency, length
+    geometric with mean 6, clipped to [2, 14]) that are in no word list and in no model trained on one: text the
+    load-time word memo does not fit by construction.  -> (text uint8, offsets uint64)."""
+    words = words or WordList()
+    rng = np.random.default_rng([seed, 0x00F])
+    n_fresh = 200_000
+    lens = np.clip(rng.geometric(1.0 / 6.0, size=n_fresh), 2, 14).astype(np.int64)
+    letters = _LETTERS[rng.choice(len(_LETTERS), size=int(lens.sum()), p=_LETTER_P)]
+    w2 = WordList.__new__(WordList)
+    w2.lens = np.concatenate([words.lens, lens])
+    w2.blob = np.concatenate([words.blob, letters]).astype(np.uint8)
+    w2.offs = np.concatenate([[0], np.cumsum(w2.lens)])[:-1].astype(np.int64)
+    p_old = np.diff(np.concatenate([[0.0], words.cdf])) * (1.0 - oov)
+    p_new = np.full(n_fresh, oov / n_fresh)
+    w2.cdf = np.cumsum(np.concatenate([p_old, p_new]))
+    w2.cdf[-1] = 1.0
+    w2.mean_len = float((np.concatenate([p_old, p_new]) * w2.lens).sum())
+    return ascii_corpus(n_sentences, seed=seed, words=w2, sort_by_length=sort_by_length)
+
+
+def repeated_file_corpus(path: str, times: int, seed: int = 20250302):
+    """A text file's lines, `times` over, every repetition with its lines in another order: natural text at bench size
+    (data/botchan.txt x 2000 = 8.6 M lines).  -> (text uint8, offsets uint64)."""
+    with open(path, "rb") as f:
+        lines = f.read().split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+    t0, o0 = pack(lines)
+    n = len(lines)
+    rng = np.random.default_rng(seed)
+    lens0 = np.diff(o0.astype(np.int64))
+    order = np.concatenate([rng.permutation(n) for _ in range(times)])
+    lens = lens0[order]
+    offs = np.zeros(len(order) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=offs[1:])
+    src = np.repeat(o0.astype(np.int64)[:-1][order] - offs[:-1].astype(np.int64), lens)
+    text = t0[np.arange(int(lens.sum()), dtype=np.int64) + src]
+    return text, offs
+
 # ---------------------------------------------------------------- config 5 --
 _CJK_LO, _CJK_HI = 0x4E00, 0x9FA5
 

@@ -539,7 +539,7 @@ def test_emu_call_local_word_memo_overflows(model, env, emu, oracle):
     ids, io = h.encode_batch(text, offs)
     assert h.status == 0
     kernels = {c["kernel"]: c["sentences"] for c in h.sp.LastProfile()["classes"] if c["kernel"]}
-    assert "EncodeWordCollectKernel" in kernels                    # the word rounds ran ...
+    assert any(k.startswith("EncodeWordCollect") for k in kernels)   # the word rounds ran ...
     assert sum(v for k, v in kernels.items() if "Word" not in k) > 0   # ... and left work to the other kernels
     oids, oio = oracle.load(blob).encode_batch(text, offs)
     np.testing.assert_array_equal(io, oio)
@@ -547,40 +547,17 @@ def test_emu_call_local_word_memo_overflows(model, env, emu, oracle):
 
 
 @pytest.mark.parametrize("waves", ["16", "5", "1"])
-def test_emu_word_kernels_at_other_workgroup_widths(waves, emu, oracle):
-    """The word kernels' wavefronts per workgroup (SPMX_WORD_WAVES; 12 by default, measured) only shape the launch."""
+@pytest.mark.parametrize("tx", ["1", "0"])
+def test_emu_word_kernels_at_other_workgroup_widths(waves, tx, emu, oracle):
+    """The word kernels' wavefronts per workgroup (SPMX_WORD_TX_WAVES for the forms that stage the text in LDS, 8 by
+    default; SPMX_WORD_WAVES for the round-3 forms, SPMX_WORD_TX=0) only shape the launch."""
     import bench
     blob = bench.model_blob("uni32k")
     text, offs = bench.corpus_for("uni32k", 4500, 20250301, False)
-    h = emu.load(blob, classes="", cus=3, env={"SPMX_WORD_WAVES": waves, "SPMX_FORCE_WORD_DP": "0"})
+    h = emu.load(blob, classes="", cus=3, env={"SPMX_WORD_WAVES": waves, "SPMX_WORD_TX_WAVES": str(min(int(waves), 9)), "SPMX_WORD_TX": tx,
+                                               "SPMX_FORCE_WORD_DP": "0"})
     ids, io = h.encode_batch(text, offs)
     assert h.status == 0
-    oids, oio = oracle.load(blob).encode_batch(text, offs)
-    np.testing.assert_array_equal(io, oio)
-    np.testing.assert_array_equal(ids, oids)
-
-
-@pytest.mark.parametrize("model,merge", [("uni32k", "2"), ("uni32k", "8"), ("uni32k_w16", "3"), ("bpe32k", "2")])
-def test_emu_leftover_classes_merged(model, merge, emu, oracle):
-    """SPMX_LEFT_MERGE (an experiment switch, off by default): the length classes of what the word rounds leave are
-    merged in runs before the general launch -- the shorter classes' lists appended to the longest one's.  Same ids."""
-    import bench
-    blob = bench.model_blob(model)
-    text, offs = bench.corpus_for(model if model.endswith("_w16") else "uni32k", 6000, 20250303, False)
-    # a fifth of the sentences get a non-ASCII character: they are what the word rounds leave (the switch applies to
-    # thin leftovers: less than a quarter of the batch)
-    b = bytearray(text.tobytes())
-    o = offs.astype(np.int64)
-    for i in range(0, len(o) - 1, 5):
-        if o[i + 1] - o[i] > 4:
-            b[o[i] + 2:o[i] + 4] = "é".encode()
-    text = np.frombuffer(bytes(b), dtype=np.uint8)
-    h = emu.load(blob, cus=3, env={"SPMX_LEFT_MERGE": merge, "SPMX_FORCE_WORD_DP": "0"})
-    h.sp.SetProfiling(True)
-    ids, io = h.encode_batch(text, offs)
-    assert h.status == 0
-    kernels = [(c["kernel"], c["sentences"]) for c in h.sp.LastProfile()["classes"] if c["kernel"]]
-    assert 1000 <= sum(v for k, v in kernels if "Stream" in k) < 1500, kernels   # the general launch had real, thin work
     oids, oio = oracle.load(blob).encode_batch(text, offs)
     np.testing.assert_array_equal(io, oio)
     np.testing.assert_array_equal(ids, oids)
