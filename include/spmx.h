@@ -129,6 +129,30 @@ int spmx_encode_batch_multi(spmx_handle *const *handles, int n_handles, const ch
                             int32_t **ids, uint64_t **id_offsets, uint8_t **status, uint64_t *n_failed);
 void spmx_free(void *p);
 
+/* ---- multi-GPU, one process per GPU: the ids of every rank on every rank, over RCCL ----------------------------------
+ * The reference has no multi-device form; BASELINE.json's north_star asks for "a RCCL all-gatherv of the token-id output
+ * over xGMI" behind the batch semantics of python/src/sentencepiece/sentencepiece.i:245-267 (the job's sentences in order,
+ * each with its own ids).  Every rank encodes its contiguous shard of the job's sentences with
+ * spmx_encode_batch_device and then calls spmx_all_gather_ids with its CSR; every rank gets the job's CSR:
+ *   d_all_ids[rank_ids[r] ...)            rank r's ids (rank order = sentence order),
+ *   d_all_id_offsets[0 .. total + 1)      offsets into d_all_ids, rebased to the whole job.
+ * nccl_comm: the caller's ncclComm_t (one rank per GPU), or one made by spmx_rccl_comm_init.  librccl is looked up at the
+ * first call (SPMX_RCCL_LIB names another library), it is no link-time dependency of libspmx.so.  d_scratch: 2 + 2 * world
+ * uint64 of device memory.  rank_sentences / rank_ids (host, world + 1 entries each, nullable): prefix sums over the
+ * ranks.  Stream-ordered except for one read-back of the counts; collective: every rank of the communicator calls it.
+ * Returns 0, or a util::StatusCode number (8: a capacity is too small -- the message names what is needed; 14: RCCL is
+ * not loadable) with the text in spmx_gather_last_error(). */
+int spmx_all_gather_ids(void *nccl_comm, int rank, int world, const int32_t *d_ids, uint64_t n_ids,
+                        const uint64_t *d_id_offsets, uint64_t n_sentences, int32_t *d_all_ids, uint64_t all_ids_capacity,
+                        uint64_t *d_all_id_offsets, uint64_t all_offsets_capacity, uint64_t *d_scratch,
+                        uint64_t *rank_sentences, uint64_t *rank_ids, void *stream);
+/* A communicator without linking RCCL oneself: rank 0 makes the 128-byte id and hands it to the other ranks by whatever
+ * means the job has (a file, MPI, a socket); every rank then calls spmx_rccl_comm_init with its GPU current. */
+int spmx_rccl_unique_id(void *id128);
+int spmx_rccl_comm_init(void **nccl_comm, int world, int rank, const void *id128);
+int spmx_rccl_comm_destroy(void *nccl_comm);
+const char *spmx_gather_last_error(void);
+
 /* Single sentence, caller-provided buffer (Encode(input, &ids)): returns the sentence's own Status, as the
  * reference does.  RESOURCE_EXHAUSTED with the needed size in *n_ids if cap is too small. */
 int spmx_encode(spmx_handle *h, const char *text, uint64_t len, int32_t *ids, uint64_t cap, uint64_t *n_ids);

@@ -75,6 +75,13 @@ SYMBOLS = [
     ("spmx_encode_batch_multi", C.c_int,
      [C.POINTER(_H), C.c_int, C.c_void_p, C.c_void_p, _U64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
       C.POINTER(C.c_void_p), C.POINTER(_U64)]),
+    ("spmx_all_gather_ids", C.c_int,
+     [C.c_void_p, C.c_int, C.c_int, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p,
+      C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("spmx_rccl_unique_id", C.c_int, [C.c_void_p]),
+    ("spmx_rccl_comm_init", C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p]),
+    ("spmx_rccl_comm_destroy", C.c_int, [C.c_void_p]),
+    ("spmx_gather_last_error", C.c_char_p, []),
     ("spmx_encode_file", C.c_int, [_H, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(_U64), C.POINTER(_U64)]),
     ("spmx_sample_encode_batch", C.c_int,
      [_H, C.c_void_p, C.c_void_p, _U64, C.c_int, C.c_float, _U64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),

@@ -265,8 +265,6 @@ struct spmx_handle {
   bool no_uni_wave = false;      // SPMX_NO_UNI_WAVE=1: unigram models never take the wave-cooperative form (kernels_uniwave.h)
   uint32_t uni_wave_max = 0;     // SPMX_UNI_WAVE_MAX: a staged class with fewer sentences than this takes the wave-cooperative form
   int word_wgs = 1;              // SPMX_WORD_WGS: workgroups per CU of the word kernel's first pass
-  bool word_tx = true;           // SPMX_WORD_TX=0: the word kernels read every word's bytes straight from HBM (the round-3 form) instead of staging the text in LDS
-  int word_tx_waves = 8;         // SPMX_WORD_TX_WAVES: wavefronts per workgroup of the TX word kernels (14 KB of LDS each)
   int word_waves = 12;           // SPMX_WORD_WAVES: wavefronts per workgroup of the word kernels (C2 step: 16 -> 8.60 ms, 14 -> 8.39, 12 -> 8.37, 10 -> 8.52, 8 -> 8.90)
   int tile_waves_override = 0;   // SPMX_TILE_WAVES: cap on wavefronts per workgroup of the streaming kernels
   uint32_t lane_general_min_lanes = 0;   // SPMX_LANE_GENERAL_MIN_LANES (0: per class)
@@ -929,9 +927,8 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       word_pass = [&](int mode, int slot, int qi, uint32_t *out_lists, uint32_t *d_out_counts, uint32_t *out2_lists,
                            uint32_t *d_out2_counts) -> int {
         const bool dp = mode == 3;
-        const bool tx = !dp && h->word_tx;
         EncodeArgs wa = a;
-        const int waves = dp ? 8 : (tx ? h->word_tx_waves : h->word_waves);
+        const int waves = dp ? 8 : h->word_waves;
         uint64_t total = 0;
         for (int c = 0; c < ncls; ++c) total += known[c];
         if (total == 0) return kOk;
@@ -972,10 +969,9 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         wa.dyn_cap = h->dyn_list_cap;
         wa.resume = ws->d_resume.p;
         snprintf(ws->slot_name[slot], sizeof(ws->slot_name[slot]), "%s",
-                 mode == 3 ? "EncodeWordDpKernel" : mode == 2 ? (tx ? "EncodeWordAgainTxKernel" : "EncodeWordAgainKernel")
-                 : mode == 1 ? (tx ? "EncodeWordCollectTxKernel" : "EncodeWordCollectKernel") : (tx ? "EncodeWordTxKernel" : "EncodeWordKernel"));
+                 mode == 3 ? "EncodeWordDpKernel" : mode == 2 ? "EncodeWordAgainKernel" : mode == 1 ? "EncodeWordCollectKernel" : "EncodeWordKernel");
         HIP_OR_RETURN(h, record(slot, 0));
-        HIP_OR_RETURN(h, LaunchEncodeWord(mode, tx, wa, static_cast<int>(grid), waves, WordLdsBytes(waves, dp, tx), stream));
+        HIP_OR_RETURN(h, LaunchEncodeWord(mode, wa, static_cast<int>(grid), waves, WordLdsBytes(waves, dp), stream));
         HIP_OR_RETURN(h, record(slot, 1));
         ws->slot_used[slot] = true;
         return kOk;
@@ -1404,8 +1400,6 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_NO_UNI_WAVE")) h->no_uni_wave = e[0] == '1';
     if (const char *e = getenv("SPMX_UNI_WAVE_MAX")) h->uni_wave_max = static_cast<uint32_t>(atoll(e));
     if (const char *e = getenv("SPMX_WORD_WGS")) { const int v = atoi(e); if (v >= 1 && v <= 4) h->word_wgs = v; }
-    if (const char *e = getenv("SPMX_WORD_TX")) h->word_tx = e[0] != '0';
-    if (const char *e = getenv("SPMX_WORD_TX_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 9) h->word_tx_waves = v; }
     if (const char *e = getenv("SPMX_WORD_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 16) h->word_waves = v; }
     if (const char *e = getenv("SPMX_NO_BP_SHORT")) h->no_bp_short = e[0] == '1';
     if (const char *e = getenv("SPMX_ARENA_FIRST")) h->arena_first = static_cast<uint64_t>(atoll(e));

@@ -944,5 +944,6 @@ SPMX_DEVICE void compact_block(const CompactArgs &a) {
 #include "kernels_nbest.h"
 #include "kernels_long.h"
 #include "kernels_uniwave.h"
+#include "kernels_gather.h"
 
 #endif

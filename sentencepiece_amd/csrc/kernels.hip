@@ -43,19 +43,6 @@ __global__ __launch_bounds__(1024) void EncodeWordAgainKernel(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   encode_word_block<false, kWmDyn>(a, smem);
 }
-// the TX forms: the wavefront stages its sentences' text in LDS (kernels_word.h "TEXT THROUGH LDS")
-__global__ __launch_bounds__(576) void EncodeWordTxKernel(EncodeArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  encode_word_block<false, kWmPlain, true>(a, smem);
-}
-__global__ __launch_bounds__(576) void EncodeWordCollectTxKernel(EncodeArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  encode_word_block<false, kWmCollect, true>(a, smem);
-}
-__global__ __launch_bounds__(576) void EncodeWordAgainTxKernel(EncodeArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  encode_word_block<false, kWmDyn, true>(a, smem);
-}
 __global__ __launch_bounds__(512) void EncodeWordDpKernel(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   encode_word_block<true, kWmPlain>(a, smem);
@@ -120,6 +107,7 @@ __global__ __launch_bounds__(64) void ScanTilesKernel(ScanArgs a) { scan_tiles_b
 __global__ __launch_bounds__(64) void ScanSumsKernel(ScanArgs a) { scan_sums_block(a); }
 __global__ __launch_bounds__(64) void ScanFinalKernel(ScanArgs a) { scan_final_block(a); }
 __global__ __launch_bounds__(64) void CompactKernel(CompactArgs a) { compact_block(a); }
+__global__ __launch_bounds__(64) void RebaseOffsetsKernel(RebaseArgs a) { rebase_block(a); }
 
 namespace {
 using EncodeFn = void (*)(EncodeArgs);
@@ -162,10 +150,8 @@ hipError_t LaunchEncodeStream(int model_type, bool uds, const EncodeArgs &a, int
   return hipGetLastError();
 }
 
-hipError_t LaunchEncodeWord(int mode, bool tx, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t stream) {
-  void (*fn)(EncodeArgs) = mode == 3 ? EncodeWordDpKernel
-                           : tx ? (mode == 2 ? EncodeWordAgainTxKernel : mode == 1 ? EncodeWordCollectTxKernel : EncodeWordTxKernel)
-                                : (mode == 2 ? EncodeWordAgainKernel : mode == 1 ? EncodeWordCollectKernel : EncodeWordKernel);
+hipError_t LaunchEncodeWord(int mode, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t stream) {
+  void (*fn)(EncodeArgs) = mode == 3 ? EncodeWordDpKernel : mode == 2 ? EncodeWordAgainKernel : mode == 1 ? EncodeWordCollectKernel : EncodeWordKernel;
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds_bytes));
@@ -248,6 +234,11 @@ hipError_t LaunchScan(const ScanArgs &a, int grid, hipStream_t stream) {
   hipLaunchKernelGGL(ScanTilesKernel, dim3(grid), dim3(64), 0, stream, a);
   hipLaunchKernelGGL(ScanSumsKernel, dim3(1), dim3(64), 0, stream, a);
   hipLaunchKernelGGL(ScanFinalKernel, dim3(grid), dim3(64), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t LaunchRebase(const RebaseArgs &a, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL(RebaseOffsetsKernel, dim3(grid), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
 

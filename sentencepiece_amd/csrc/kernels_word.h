@@ -76,24 +76,10 @@ SPMX_DEVICE unsigned long long DynTag(uint32_t k0, uint32_t k1, uint32_t k2, uin
   const unsigned long long t = (static_cast<unsigned long long>(HashWordKey(k0, k1, k2, k3)) << 32) | HashWord(k0, k1, k2, k3);
   return t | 1ull;                                              // (0 means "free")
 }
-// TEXT THROUGH LDS (round 4; the kernels' TX forms).  Reading a word's 16 bytes straight from HBM is one 64-lane gather
-// per iteration -- 64 lanes, 64 different cache lines, and the memory pipeline of a CU takes such an instruction at about
-// 100 cycles whatever the hit rate (scripts/ubench/gather_probe.hip; one more of them per iteration costs the C2 launch
-// 0.95 ms of 4.3, profiles/r04_word_exp.txt).  So the wavefront fetches the text of its 64 sentences TOGETHER: eight
-// lanes per sentence ask for eight consecutive 16-byte units of it (a 128-byte line per sentence and instruction), and
-// the units go into the sentence's ROW of LDS -- a ring of kTextRing bytes indexed by the unit's offset from the aligned
-// unit that holds the sentence's first byte, with its first 32 bytes repeated behind it so that the 16 + 4 bytes of a
-// word may be read at any ring offset without wrapping.  A row is topped up (all rows of the wavefront at once) when
-// the fastest lane comes within kTextNeed bytes of what its row holds; the loop reads words from the row by unaligned
-// ds_read_b128.  Nothing beyond the aligned units that hold the sentence's own bytes is ever asked for, so the word
-// form's "not within 20 bytes of the buffer's end" rule does not apply to the TX kernels.
-constexpr uint32_t kTextRing = 128;
-constexpr uint32_t kTextRowBytes = kTextRing + 32u + 16u;       // (176 = 44 dwords: the rows' first banks spread over the 64)
-constexpr uint32_t kTextNeed = 40;                              // an iteration reads up to 16 + 1 + 16 + 4 bytes from its word's start
-SPMX_HD inline uint32_t WordLdsPerWave(bool dp, bool tx = false) {
-  return 64u * kWordStage * 4u + (dp ? 64u * (kWordDpPos * 8u + 20u) : 0u) + (tx ? 65u * kTextRowBytes + 64u * 16u : 0u);
+SPMX_HD inline uint32_t WordLdsPerWave(bool dp) {
+  return 64u * kWordStage * 4u + (dp ? 64u * (kWordDpPos * 8u + 20u) : 0u);
 }
-SPMX_HD inline uint32_t WordLdsBytes(uint32_t waves, bool dp, bool tx = false) { return kWordLdsShared + waves * WordLdsPerWave(dp, tx); }
+SPMX_HD inline uint32_t WordLdsBytes(uint32_t waves, bool dp) { return kWordLdsShared + waves * WordLdsPerWave(dp); }
 
 // 16 / 4 bytes at any address (gfx950 runs with unaligned vector memory access enabled; scripts/ubench/unaligned_probe.hip)
 struct __attribute__((packed, aligned(1))) Q4U { uint32_t x, y, z, w; };
@@ -119,8 +105,6 @@ struct WordLds {
   float *dp_best;       // (DP) this lane's best_path_score column: position i at dp_best[i << 6]
   uint32_t *dp_bp;      // (DP) back-pointer words  id | length << 24 | unk << 31  (0: not reached)
   uint8_t *dp_bytes;    // (DP) the word in device form: [20] bytes of this lane
-  uint8_t *trows;       // (TX) the wavefront's 64 text rows, kTextRowBytes each
-  U4 *exch;             // (TX) [64] what a lane tells the lanes that fetch for it: {text base lo, hi, units held, units wanted}
 };
 
 // EncodeOptimized (src/unigram_model.cc:957-1008) of ONE word -- the space symbol and the L raw bytes in key[] -- from
@@ -174,44 +158,13 @@ SPMX_DEVICE void uni_word_dp(const SpmxDev &d, const WordLds &T, int L, float B,
   }
 }
 
-// (TX) one top-up of the wavefront's 64 text rows: exch[s] = {offset of sentence s's first aligned unit from the batch's
-// text pointer (lo, hi), ring coordinate its row is filled to, coordinate it wants to be filled to}.  Eight sentences
-// per pass, a 16-byte unit per lane; all eight loads are in flight before the first is waited for.  A lane with
-// nothing to fetch asks for the aligned unit
-// that holds the batch's first byte (always there) and writes it to a 65th row nobody reads.
-typedef uint32_t TxUnit __attribute__((vector_size(16)));        // a 16-byte unit as ONE value (a struct would be copied through memory)
-SPMX_DEVICE void tx_fetch_rows(const uint8_t *gtext, uint8_t *trows, const U4 *exch, int lane) {
-  const long long safe = -static_cast<long long>(reinterpret_cast<uintptr_t>(gtext) & 15u);
-  uint8_t *dump = trows + 64u * kTextRowBytes;
-  const uint32_t s0 = static_cast<uint32_t>(lane) >> 3, u16 = 16u * (static_cast<uint32_t>(lane) & 7u);
-  // (eight named values, not an array: they must stay in registers between the loads and the stores)
-#define SPMX_TX_LOAD(P)                                                                                                      \
-  const U4 e##P = exch[P * 8u + s0];                                                                                         \
-  const uint32_t c##P = e##P.z + u16;                                                                                        \
-  const bool ok##P = c##P < e##P.w;                                                                                          \
-  const long long off##P = static_cast<long long>(static_cast<unsigned long long>(e##P.y) << 32 | e##P.x) + static_cast<long long>(c##P); \
-  const TxUnit v##P = *reinterpret_cast<const TxUnit *>(gtext + (ok##P ? off##P : safe));
-#define SPMX_TX_STORE(P)                                                                                                     \
-  {                                                                                                                          \
-    uint8_t *r = trows + (P * 8u + s0) * kTextRowBytes;                                                                      \
-    const uint32_t o = c##P & (kTextRing - 1u);                                                                              \
-    *reinterpret_cast<TxUnit *>(ok##P ? r + o : dump) = v##P;                                                                  \
-    *reinterpret_cast<TxUnit *>(ok##P ? r + (o < 32u ? kTextRing + o : o) : dump) = v##P;  /* the ring's first 32 bytes again behind it */ \
-  }
-  SPMX_TX_LOAD(0) SPMX_TX_LOAD(1) SPMX_TX_LOAD(2) SPMX_TX_LOAD(3) SPMX_TX_LOAD(4) SPMX_TX_LOAD(5) SPMX_TX_LOAD(6) SPMX_TX_LOAD(7)
-  wv::fence_compiler();
-  SPMX_TX_STORE(0) SPMX_TX_STORE(1) SPMX_TX_STORE(2) SPMX_TX_STORE(3) SPMX_TX_STORE(4) SPMX_TX_STORE(5) SPMX_TX_STORE(6) SPMX_TX_STORE(7)
-#undef SPMX_TX_LOAD
-#undef SPMX_TX_STORE
-}
-
 // The words of this lane's sentence (raw bytes gtext[beg, beg + len)) -> ids in slot[0, n), forward order.
 // Returns n >= 0, or -1: the sentence is not for this pass (nothing usable was written).
 // MODE (kWm*): the call-local memo of `a` (dyn_*) is filled (collect) / consulted (dyn); -2: "try again in the second round".
 // `rs` of uni_word_lane: (collect) out -- where the lane stood when it met its first missing word: {position, ids
 // written, bound}; (dyn) in -- where to take the sentence up again: the ids before that point are in `slot` already.
 struct WordResume { int p; int n; float B; };
-template <bool DP, int MODE, bool TX>
+template <bool DP, int MODE>
 SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_t beg, int len, int32_t *slot, int cap,
                               const WordLds &T, bool active_in, int *n_steps, WordResume *rs) {
   const SpmxDev &d = a.dev;
@@ -236,40 +189,8 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
   int stall_L = 0;
   bool prev_unk = false;                           // the last piece emitted was unknown (a run of them is ONE id, :609-613)
   const bool bf = (d.flags & kNfByteFallback) != 0;
-  // ---- (TX) the sentence's row of LDS: ring coordinate of sentence byte i = a0 + i, a0 = the first byte's offset in its
-  // aligned 16-byte unit; `filled`: the row holds the units below this coordinate (and at least those from the current
-  // word's on) ----
-  const int lane = wv::lane();
-  uint32_t a0 = 0, filled = 0, qtot = 0;
-  uint8_t *trow = nullptr;
-  if (TX) {
-    a0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(text)) & 15u;
-    trow = T.trows + static_cast<uint32_t>(lane) * kTextRowBytes;
-    if (active) { qtot = a0 + static_cast<uint32_t>(len); filled = (a0 + static_cast<uint32_t>(p)) & ~15u; }
-  }
-  auto tx_refill = [&]() __attribute__((always_inline)) {     // wave-uniform: every lane calls it
-    uint32_t upto = filled;
-    if (active) {
-      upto = ((a0 + static_cast<uint32_t>(p)) & ~15u) + kTextRing;
-      const uint32_t end16 = (qtot + 15u) & ~15u;
-      if (upto > end16) upto = end16;
-      if (upto < filled) upto = filled;
-    }
-    // (offsets from the batch's text pointer, not addresses: the loads below stay global loads)
-    const long long rel = static_cast<long long>(beg) - static_cast<long long>(a0);
-    T.exch[lane] = U4{static_cast<uint32_t>(rel), static_cast<uint32_t>(static_cast<unsigned long long>(rel) >> 32), filled, upto};
-    wv::sync();
-    tx_fetch_rows(gtext, T.trows, T.exch, lane);
-    wv::sync();
-    filled = upto;
-  };
-  auto rd16 = [&](int pos) __attribute__((always_inline)) -> Q4U {
-    if (TX) return *reinterpret_cast<const Q4U *>(trow + ((a0 + static_cast<uint32_t>(pos)) & (kTextRing - 1u)));
-    return *reinterpret_cast<const Q4U *>(text + pos);
-  };
-  if (TX && wv::any(active)) tx_refill();
   Q4U w{0, 0, 0, 0};
-  if (active) w = rd16(p);
+  if (active) w = *reinterpret_cast<const Q4U *>(text + p);
 #if SPMX_EXP & (8 | 32)
   uint32_t exp_acc = 0;
 #endif
@@ -331,10 +252,6 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
       continue;
     }
     ++steps;
-    if (TX) {      // top up the rows when a lane comes close to the end of what its row holds
-      const bool low = active && filled < qtot && filled < a0 + static_cast<uint32_t>(p) + kTextNeed;
-      if (wv::any(low)) tx_refill();
-    }
     const bool run = active && !stalled;
     // ---- the word that starts at p: its length = the distance to the next 0x20 (or to the end of the sentence) ----
     const uint32_t z0 = space_bits(w.x), z1 = space_bits(w.y), z2 = space_bits(w.z), z3 = space_bits(w.w);
@@ -347,7 +264,7 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
     const int pn = p + L + 1;
     const bool more = run && pn < len;
     Q4U wn = w;
-    if (more) wn = rd16(pn);
+    if (more) wn = *reinterpret_cast<const Q4U *>(text + pn);
 #if SPMX_EXP & 8      // (experiment build: what ONE more 64-lane text gather per iteration costs)
     if (more) { const Q4U x = *reinterpret_cast<const Q4U *>(text + (pn + 160 < len ? pn + 160 : pn)); exp_acc ^= x.x ^ x.y ^ x.z ^ x.w; }
 #endif
@@ -392,8 +309,7 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
       const bool need = word && !hit16;
       int L2 = L;
       if (need && L == 16 && rem > 16) {             // the 17th byte decides whether the word ends here
-        wx4 = TX ? reinterpret_cast<const U1U *>(trow + ((a0 + static_cast<uint32_t>(p) + 16u) & (kTextRing - 1u)))->x
-                 : reinterpret_cast<const U1U *>(text + p + 16)->x;
+        wx4 = reinterpret_cast<const U1U *>(text + p + 16)->x;
         if ((wx4 & 0xFFu) != 0x20u) lng = true;
       }
       const bool probe = need && !lng;
@@ -544,13 +460,13 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
 
 // Persistent body of the word kernels: tiles of up to 64 sentences from the launch's queue (kernels_stream.h
 // next_tile), one sentence per lane.  What a lane cannot take goes to the leftover list of its class.
-template <bool DP, int MODE, bool TX = false>
+template <bool DP, int MODE>
 SPMX_DEVICE void encode_word_block(const EncodeArgs &a, unsigned char *smem) {
   const int lane = wv::lane();
   const SpmxDev &d = a.dev;
   Q4 *masks = reinterpret_cast<Q4 *>(smem);
   U4 *hot = reinterpret_cast<U4 *>(smem + kWordMaskBytes);
-  unsigned char *mine_lds = smem + kWordLdsShared + static_cast<uint32_t>(wv::wave_in_block()) * WordLdsPerWave(DP, TX);
+  unsigned char *mine_lds = smem + kWordLdsShared + static_cast<uint32_t>(wv::wave_in_block()) * WordLdsPerWave(DP);
   WordLds T;
   T.masks = masks;
   T.hot = hot;
@@ -558,8 +474,6 @@ SPMX_DEVICE void encode_word_block(const EncodeArgs &a, unsigned char *smem) {
   T.dp_best = reinterpret_cast<float *>(mine_lds + 64u * kWordStage * 4u) + lane;
   T.dp_bp = reinterpret_cast<uint32_t *>(mine_lds + 64u * kWordStage * 4u + 64u * kWordDpPos * 4u) + lane;
   T.dp_bytes = mine_lds + 64u * kWordStage * 4u + 64u * kWordDpPos * 8u + static_cast<uint32_t>(lane) * 20u;
-  T.trows = mine_lds + 64u * kWordStage * 4u + (DP ? 64u * (kWordDpPos * 8u + 20u) : 0u);
-  T.exch = reinterpret_cast<U4 *>(T.trows + 65u * kTextRowBytes);
   {   // shared read-only tables (every wave writes the same values: no workgroup barrier)
     if (lane < 18) {
       const uint32_t L = static_cast<uint32_t>(lane);
@@ -591,8 +505,7 @@ SPMX_DEVICE void encode_word_block(const EncodeArgs &a, unsigned char *smem) {
     // not for this kernel: beyond the int range of the lane's counters, or text that ends within the over-read of the
     // last sentences of the buffer
     // (a class marked `general` passes through: documents belong to the wave-cooperative form, kernels_uniwave.h)
-    // (the TX forms ask for nothing beyond the aligned units that hold the sentence's own bytes)
-    const bool mine = have && !a.cls[c].general && l64 < (1ull << 30) && (TX || beg + l64 + 20u <= text_end);
+    const bool mine = have && !a.cls[c].general && l64 < (1ull << 30) && beg + l64 + 20u <= text_end;
     const int len = mine ? static_cast<int>(l64) : 0;
     // ---- a slot of cap ids in the arena (at most one id per byte of the normalized form: the bytes + 1) ----
     const int cap = mine ? len + 1 : 0;
@@ -617,7 +530,7 @@ SPMX_DEVICE void encode_word_block(const EncodeArgs &a, unsigned char *smem) {
       rs.p = static_cast<int>(r.x); rs.n = static_cast<int>(r.y); rs.B = wv::bits_to_float(r.z);
     }
     int steps = 0;
-    int n = uni_word_lane<DP, MODE, TX>(a, a.text, beg, len, slot, cap, T, mine && !overflow, &steps, &rs);
+    int n = uni_word_lane<DP, MODE>(a, a.text, beg, len, slot, cap, T, mine && !overflow, &steps, &rs);
     const unsigned long long c1 = wv::clock();
     if (overflow) n = -1;
     const bool done = mine && n >= 0;

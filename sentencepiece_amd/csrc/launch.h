@@ -37,8 +37,7 @@ hipError_t LaunchEncodeStream(int model_type, bool uds, const EncodeArgs &a, int
                               uint32_t lds_bytes, hipStream_t stream);
 // The word kernel (kernels_word.h): unigram models with kNfUniWordwise
 // mode: 0 plain first pass, 1 collecting first pass, 2 second round over the call-local memo, 3 the DP pass
-// tx: the forms that stage the text in LDS (modes 0 - 2)
-hipError_t LaunchEncodeWord(int mode, bool tx, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t stream);
+hipError_t LaunchEncodeWord(int mode, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t stream);
 hipError_t LaunchWordResolve(const ResolveArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchBpeLong(const LongArgs &a, int grid, hipStream_t stream);
 // The wave-cooperative unigram form (kernels_uniwave.h): one sentence per 64-thread workgroup; cands = candidate-row entries
@@ -54,6 +53,7 @@ hipError_t LaunchDecode(bool write, const DecodeArgs &a, int grid, hipStream_t s
 hipError_t LaunchClassify(const ClassifyArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchScan(const ScanArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchCompact(const CompactArgs &a, int grid, hipStream_t stream);
+hipError_t LaunchRebase(const RebaseArgs &a, int grid, hipStream_t stream);   // kernels_gather.h
 
 }  // namespace spmx
 #endif

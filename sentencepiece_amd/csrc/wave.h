@@ -66,8 +66,6 @@ SPMX_DEVICE unsigned long long atomic_cas(unsigned long long *p, unsigned long l
 SPMX_DEVICE uint32_t atomic_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 
-// the instruction scheduler moves nothing across this point (no instruction is emitted; values stay in registers)
-SPMX_DEVICE void fence_compiler() { __builtin_amdgcn_sched_barrier(0); }
 SPMX_DEVICE unsigned long long clock() { return __builtin_amdgcn_s_memtime(); }   // shader cycles
 
 SPMX_DEVICE int popc64(uint64_t x) { return __popcll(x); }

@@ -43,11 +43,8 @@ hipError_t LaunchEncodeStream(int model_type, bool uds, const EncodeArgs &a, int
   }
   return hipSuccess;
 }
-hipError_t LaunchEncodeWord(int mode, bool tx, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t) {
-  if (tx && mode == 2) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_word_block<false, kWmDyn, true>(a, s); });
-  else if (tx && mode == 1) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_word_block<false, kWmCollect, true>(a, s); });
-  else if (tx && mode == 0) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_word_block<false, kWmPlain, true>(a, s); });
-  else if (mode == 3) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_word_block<true, kWmPlain>(a, s); });
+hipError_t LaunchEncodeWord(int mode, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t) {
+  if (mode == 3) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_word_block<true, kWmPlain>(a, s); });
   else if (mode == 2) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_word_block<false, kWmDyn>(a, s); });
   else if (mode == 1) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_word_block<false, kWmCollect>(a, s); });
   else RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_word_block<false, kWmPlain>(a, s); });
@@ -117,6 +114,10 @@ hipError_t LaunchScan(const ScanArgs &a, int grid, hipStream_t) {
 }
 hipError_t LaunchCompact(const CompactArgs &a, int grid, hipStream_t) {
   RunGrid(grid, 1, 0, [&](unsigned char *) { compact_block(a); });
+  return hipSuccess;
+}
+hipError_t LaunchRebase(const RebaseArgs &a, int grid, hipStream_t) {
+  RunGrid(grid, 1, 0, [&](unsigned char *) { rebase_block(a); });
   return hipSuccess;
 }
 }  // namespace spmx

@@ -105,7 +105,6 @@ inline unsigned long long atomic_cas(unsigned long long *p, unsigned long long e
 }
 inline uint32_t atomic_load(const uint32_t *p) { return *p; }
 
-inline void fence_compiler() {}
 inline unsigned long long clock() { return 0; }
 
 inline int popc64(uint64_t x) { return __builtin_popcountll(x); }

@@ -23,8 +23,7 @@ from tests import fixtures, wordfuzz
 WORD_MODELS = ["uni32k", "uni32k_w16", "bpe32k"]
 # how the handle is loaded: the default plan; the small class table of the CPU suite; no call-local memo (one word round
 # + the DP pass); the first round without the second
-VARIANTS = {"default": {}, "small_classes": {"SPMX_CLASSES": "small"}, "no_dyn": {"SPMX_NO_WORD_DYN": "1"},
-            "no_tx": {"SPMX_WORD_TX": "0"}}        # (the round-3 forms: every word's bytes straight from HBM)
+VARIANTS = {"default": {}, "small_classes": {"SPMX_CLASSES": "small"}, "no_dyn": {"SPMX_NO_WORD_DYN": "1"}}
 
 
 def _emu_load(emu, blob, variant, extra=None):
