@@ -21,7 +21,9 @@ static PyObject *encode_views(PyObject *self, PyObject *args) {
   unsigned long long fn_addr = 0, h_addr = 0;
   PyObject *seq = NULL;
   if (!PyArg_ParseTuple(args, "KKO", &fn_addr, &h_addr, &seq)) return NULL;
-  PyObject *fast = PySequence_Fast(seq, "a list of str / bytes is expected");
+  /* a TUPLE of our own: PySequence_Fast hands a list argument back as it is, and the views below point into str objects
+   * that only that list keeps alive -- another thread could drop them while the GIL is released around the device call */
+  PyObject *fast = PySequence_Tuple(seq);
   if (!fast) return NULL;
   const Py_ssize_t n = PySequence_Fast_GET_SIZE(fast);
   view_t *views = (view_t *)malloc((size_t)(n > 0 ? n : 1) * sizeof(view_t));
@@ -91,7 +93,11 @@ static PyObject *csr_to_lists(PyObject *self, PyObject *args) {
   if (!outer) return NULL;
   /* n new container objects would run the cycle collector every few hundred lists, each pass walking what has been
    * built so far (measured: 2.0 s instead of 0.35 s per million sentences); none of these lists can be in a cycle */
+#if PY_VERSION_HEX >= 0x030A0000
   const int gc_was_on = PyGC_Disable();
+#else
+  const int gc_was_on = 0;                  /* (PyGC_Disable / PyGC_Enable exist from Python 3.10) */
+#endif
   PyObject *ret = outer;
   for (Py_ssize_t i = 0; i < n && ret; ++i) {
     const uint64_t b = offs[i], e = offs[i + 1];
@@ -117,7 +123,9 @@ static PyObject *csr_to_lists(PyObject *self, PyObject *args) {
       PyList_SET_ITEM(inner, (Py_ssize_t)(k - b), v);
     }
   }
+#if PY_VERSION_HEX >= 0x030A0000
   if (gc_was_on) PyGC_Enable();
+#endif
   if (!ret) Py_DECREF(outer); /* the lists filled so far hold NULL or owned references only */
   return ret;
 }

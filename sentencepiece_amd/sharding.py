@@ -68,7 +68,9 @@ class IdGatherer:
         # own (the host knows its own total: EncodeDevice returns it), which does not queue behind the gathers in flight.
         self._cpu_group = None
         if algo == "p2p_exact" and dist.get_backend(group) != "gloo":
-            self._cpu_group = dist.new_group(backend="gloo")        # collective: every rank constructs its gatherer
+            # (construction is collective over the ranks of `group`: the side channel spans exactly those)
+            self._cpu_group = dist.new_group(ranks=dist.get_process_group_ranks(group) if group is not None else None,
+                                             backend="gloo")
         self._dtype = None
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, model, corpus_name, n_sent, out_dir):
+def _worker(rank, world, port, model, corpus_name, n_sent, out_dir, engine="oracle"):
     import torch.distributed as dist
     from sentencepiece_amd import sharding
     from tests import oraclelib
@@ -30,11 +30,15 @@ def _worker(rank, world, port, model, corpus_name, n_sent, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         text, offs = fixtures.head(*fixtures.Corpora()[corpus_name], n_sent)
-        o = oraclelib.OracleLib().load(fixtures.model_blob(model))
+        if engine == "emu":      # the PRODUCT's encode (api.cc + kernels under the emulator), not the oracle
+            from tests import emulib
+            o = emulib.EmuLib().load(fixtures.model_blob(model), classes=None)
+        else:
+            o = oraclelib.OracleLib().load(fixtures.model_blob(model))
 
         def encode_fn(t, of):
             ids, io = o.encode_batch(t.numpy(), of.numpy().astype(np.uint64))
-            return torch.from_numpy(ids), torch.from_numpy(io.astype(np.int64)), len(ids)
+            return torch.from_numpy(np.asarray(ids)), torch.from_numpy(np.asarray(io).astype(np.int64)), len(ids)
 
         ids, io = sharding.encode_sharded(encode_fn, torch.from_numpy(text.copy()), offs, dist, torch.device("cpu"))
         np.save(os.path.join(out_dir, "ids%d.npy" % rank), ids.numpy())
@@ -81,6 +85,21 @@ def _worker(rank, world, port, model, corpus_name, n_sent, out_dir):
 def test_gloo_ranks(model, corpus, n, world, tmp_path, oracle, corpora):
     """world 2, 4 and 8; uneven shards (301 sentences over 4 ranks by bytes) and empty ones (3 sentences over 4 ranks)."""
     mp.spawn(_worker, args=(world, _free_port(), model, corpus, n, str(tmp_path)), nprocs=world, join=True)
+    text, offs = fixtures.head(*corpora[corpus], n)
+    ids, io = oracle.load(fixtures.model_blob(model)).encode_batch(text, offs)
+    for r in range(world):
+        np.testing.assert_array_equal(np.load(tmp_path / ("ids%d.npy" % r)), ids)
+        np.testing.assert_array_equal(np.load(tmp_path / ("io%d.npy" % r)), io.astype(np.int64))
+
+
+@pytest.mark.parametrize("model,corpus,n,world", [("uni32k", "synth20k", 900, 2), ("bpe32k", "synth20k", 500, 3)])
+def test_gloo_ranks_drive_the_product_encode(model, corpus, n, world, tmp_path, oracle, corpora):
+    """The same N > 1 path with the product's own encode on every rank (csrc/api.cc and the kernels under the CPU
+    emulator: classify with the plain scan, word rounds, general launches) instead of the oracle; the gathered CSR of
+    every rank equals the oracle's encode of the whole batch."""
+    from tests import emulib
+    emulib.lib()            # (built once here, not by every rank at the same time)
+    mp.spawn(_worker, args=(world, _free_port(), model, corpus, n, str(tmp_path), "emu"), nprocs=world, join=True)
     text, offs = fixtures.head(*corpora[corpus], n)
     ids, io = oracle.load(fixtures.model_blob(model)).encode_batch(text, offs)
     for r in range(world):
