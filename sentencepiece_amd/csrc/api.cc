@@ -1383,7 +1383,6 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_NO_STREAM")) h->no_stream = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_WAVE")) h->no_wave = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_WORD_KERNEL")) h->no_word = e[0] == '1';
-    if (const char *e = getenv("SPMX_NO_WORD_DP")) h->no_word_dp = e[0] == '1';
     if (const char *e = getenv("SPMX_FORCE_WORD_DP")) h->force_word_dp = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_WORD_DYN")) h->no_word_dyn = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_OVERLAP")) h->no_overlap = e[0] == '1';
@@ -1392,33 +1391,35 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_DYN_SLOTS_LOG2")) { const int v = atoi(e); if (v >= 4 && v <= 26) h->dyn_slots = 1u << v; }
     if (const char *e = getenv("SPMX_DYN_LIST_CAP")) { const long v = atol(e); if (v >= 1 && v <= (1l << 26)) h->dyn_list_cap = static_cast<uint32_t>(v); }
     if (const char *e = getenv("SPMX_NBEST_BUDGET_GB")) { const long v = atol(e); if (v >= 1 && v <= 200) h->nbest_budget = static_cast<uint64_t>(v) << 30; }
+#ifdef SPMX_TEST_SEAMS   // (the emulator build and `make variant DEF=-DSPMX_TEST_SEAMS` only: the release library reads none of these)
+    if (getenv("SPMX_WORDMEMO_UNSAFE")) h->memo_unsafe = true;
+    // A/B switches of settled experiments (their measurements: DESIGN.md section 4, profiles/)
+    if (const char *e = getenv("SPMX_NO_WORD_DP")) h->no_word_dp = e[0] == '1';
     if (const char *e = getenv("SPMX_NBEST_HYPS_MIN")) { const long v = atol(e); if (v >= 1024 && v <= 262144) h->nbest_hyps_min = static_cast<uint32_t>(v); }
     if (const char *e = getenv("SPMX_TILE_MIN_LANES")) h->tile_min_lanes = static_cast<uint32_t>(atoi(e));
-#ifdef SPMX_TEST_SEAMS   // (the emulator build only)
-    if (getenv("SPMX_WORDMEMO_UNSAFE")) h->memo_unsafe = true;
-#endif
     if (const char *e = getenv("SPMX_NO_UNI_WAVE")) h->no_uni_wave = e[0] == '1';
-    if (const char *e = getenv("SPMX_UNI_WAVE_MAX")) h->uni_wave_max = static_cast<uint32_t>(atoll(e));
     if (const char *e = getenv("SPMX_WORD_WGS")) { const int v = atoi(e); if (v >= 1 && v <= 4) h->word_wgs = v; }
-    if (const char *e = getenv("SPMX_WORD_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 16) h->word_waves = v; }
     if (const char *e = getenv("SPMX_NO_BP_SHORT")) h->no_bp_short = e[0] == '1';
-    if (const char *e = getenv("SPMX_ARENA_FIRST")) h->arena_first = static_cast<uint64_t>(atoll(e));
     if (const char *e = getenv("SPMX_WIDE_TCAP")) h->wide_tcap = e[0] == '1';
-    if (const char *e = getenv("SPMX_NO_LANE_GENERAL")) h->no_lane_general = e[0] == '1';
-    if (const char *e = getenv("SPMX_NO_CHAR_NORM")) h->char_norm_mode = e[0] == '1' ? 1u : 0u;
-    if (const char *e = getenv("SPMX_CHAR_NORM_ALWAYS")) { if (e[0] == '1') h->char_norm_mode = 2u; }
     if (const char *e = getenv("SPMX_SUB_BUCKETS")) {
       const int v = atoi(e);
       h->sub_buckets = static_cast<uint32_t>(v < 1 ? 1 : (v > kMaxSubBuckets ? kMaxSubBuckets : v));
     }
     if (const char *e = getenv("SPMX_LANE_GENERAL_MIN_LANES")) h->lane_general_min_lanes = static_cast<uint32_t>(atoi(e));
     if (const char *e = getenv("SPMX_STREAM_SCRATCH_MB")) h->stream_scratch_limit = static_cast<uint64_t>(atoll(e)) << 20;
-    if (const char *e = getenv("SPMX_TILE_WAVES")) h->tile_waves_override = atoi(e);
     if (const char *e = getenv("SPMX_MAIN_MAX_RAW")) h->main_max_raw = static_cast<uint32_t>(atoll(e));
+    if (const char *e = getenv("SPMX_FORCE_RING")) { const int v = atoi(e); if (v >= 16 && v <= 122) h->ring_override = static_cast<uint32_t>(v); }
+#endif
+    if (const char *e = getenv("SPMX_UNI_WAVE_MAX")) h->uni_wave_max = static_cast<uint32_t>(atoll(e));
+    if (const char *e = getenv("SPMX_WORD_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 16) h->word_waves = v; }
+    if (const char *e = getenv("SPMX_ARENA_FIRST")) h->arena_first = static_cast<uint64_t>(atoll(e));
+    if (const char *e = getenv("SPMX_NO_LANE_GENERAL")) h->no_lane_general = e[0] == '1';
+    if (const char *e = getenv("SPMX_NO_CHAR_NORM")) h->char_norm_mode = e[0] == '1' ? 1u : 0u;
+    if (const char *e = getenv("SPMX_CHAR_NORM_ALWAYS")) { if (e[0] == '1') h->char_norm_mode = 2u; }
+    if (const char *e = getenv("SPMX_TILE_WAVES")) h->tile_waves_override = atoi(e);
     if (const char *e = getenv("SPMX_RESERVE_CUS")) { const int v = atoi(e); if (v >= 0 && v < h->n_cu) h->reserve_cus = v; }
     if (const char *e = getenv("SPMX_HOST_THREADS")) { const int v = atoi(e); h->host_threads = v < 1 ? 1 : (v > 64 ? 64 : v); }
     if (const char *e = getenv("SPMX_HOST_CHUNK")) { const long long v = atoll(e); if (v >= 1024) h->host_chunk = static_cast<uint64_t>(v); }
-    if (const char *e = getenv("SPMX_FORCE_RING")) { const int v = atoi(e); if (v >= 16 && v <= 122) h->ring_override = static_cast<uint32_t>(v); }
     if (const char *e = getenv("SPMX_CLASSES")) {          // "raw:norm,raw:norm,..." (ascending; tests shrink the table)
       int c = 0;
       const char *p = e;
