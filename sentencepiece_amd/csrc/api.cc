@@ -256,7 +256,7 @@ struct spmx_handle {
   uint64_t nbest_budget = 32ull << 30;  // SPMX_NBEST_BUDGET_GB: HBM the lattice slices of one launch may take (200 k sentences, n-best 5: 0.83 M sentences/s at 8 GB, 1.15 M at 32, 1.19 M at 96)
   uint32_t nbest_hyps_min = 16384;   // SPMX_NBEST_HYPS_MIN: hypotheses a lane's A* may hold in the first launch (what outgrows it runs again)
   uint32_t tile_min_lanes = 1;   // SPMX_TILE_MIN_LANES: a main tile has at least this many sentences even when that leaves wavefronts without a tile of the class
-  int fork_waves = 4;            // SPMX_FORK_WAVES: wavefronts per workgroup of the general launch while it runs next to the first word round (0: as planned)
+  int fork_waves = 0;            // SPMX_FORK_WAVES: wavefronts per workgroup of the general launch while it runs next to the first word round (0: by its size)
   bool no_overlap = false;       // SPMX_NO_OVERLAP=1: the general launches do not run next to the word rounds
   bool no_scan = false;          // SPMX_NO_SCAN=1: classify does not set the non-plain sentences aside (the word rounds find them)
   bool no_word_dyn = false;      // SPMX_NO_WORD_DYN=1: no call-local word memo (one word round, then the DP pass)
@@ -887,7 +887,13 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
           HIP_OR_RETURN(h, hipEventRecord(ws->ev_fork, stream));
           HIP_OR_RETURN(h, hipStreamWaitEvent(ws->stream2, ws->ev_fork, 0));
           stream = ws->stream2;
-          stream_waves_cap = h->fork_waves;
+          // wavefronts per workgroup of the general launch: enough for one full tile per wavefront (its time is then one
+          // tile's, the longest sentence's), no more -- what it takes of a CU's LDS and issue slots the word kernel next
+          // to it does not get (C2: 4 -> general 6.0 ms / word round 4.8 ms; 8 -> 3.6 / 5.2; 16 -> 2.6 / 5.2)
+          uint64_t gt = 0;
+          for (int c = 0; c < ncls; ++c) gt += (static_cast<uint64_t>(gen_known[c]) + 63) / 64;
+          const uint64_t per_cu = (gt + static_cast<uint64_t>(h->n_cu) - 1) / static_cast<uint64_t>(h->n_cu);
+          stream_waves_cap = h->fork_waves ? h->fork_waves : static_cast<int>(per_cu < 4 ? 4 : (per_cu > 12 ? 12 : per_cu));
         }
         int rc = kOk;
         for (int c = 0; c < ncls && rc == kOk; ++c)

@@ -113,10 +113,13 @@ struct SpmxDev {
   // word memo (unigram, kNfUniWordwise; kernels_word.h): EncodeOptimized of every vocabulary string that is a whole
   // word -- the space symbol and then 1 .. 16 bytes 0x21 .. 0x7E -- computed at load in double, with the magnitude bmax
   // of the accumulated score below which the float arithmetic of the reference provably takes the same decisions.
-  //   umemo16  one-piece words of up to 12 bytes, ids below 65536: one U4 {12 raw bytes of the word WITHOUT its space
-  //            symbol, padded with 0x20 (kernels_word.h key_dword); id | e << 16 | sc << 24}: valid while |score| < 2^e (the power of two below bmax);
-  //            sc = ceil(|piece score|) + 1, what the piece adds to the first pass's bound of |score|.  empty: w ==
-  //            0xFFFFFFFF.  uhot: the kWordHotSlots likeliest of them, direct-mapped (the kernels keep it in LDS).
+  //   umemo16  16-byte entries, ids below 65535.  Words of 11 / 12 bytes that are ONE piece: {12 raw bytes of the word
+  //            WITHOUT its space symbol, padded with 0x20 (kernels_word.h key_dword); id | e << 16 | sc << 24}.  Words of
+  //            up to 10 bytes that are one or TWO pieces: {8 key bytes; key bytes 8, 9 | second id << 16 (0xFFFF: none);
+  //            id | e << 16 | kMemo16TwoPiece | sc << 24}.  Valid while |score| < 2^e (the power of two below bmax; e <= 126);
+  //            sc = the sum over the pieces of ceil(|piece score|) + 1, what the word adds to the first pass's bound of
+  //            |score|.  empty: w == 0xFFFFFFFF.  uhot: the kWordHotSlots likeliest of them, direct-mapped (the kernels
+  //            keep it in LDS).
   //   umemo    the other words (two pieces, 13 .. 16 bytes): two U4 {16 key bytes, 0x20 padded} {id0, id1 or 0xFFFFFFFF, sc0 + sc1
   //            (float bits), bmax (float bits)}; empty: id0 == 0xFFFFFFFF.
   // Open addressing on HashWordKey.  pscore: score per piece id (the second pass replays the exact score).
@@ -152,6 +155,7 @@ SPMX_HD inline uint32_t HashWordKey(uint32_t k0, uint32_t k1, uint32_t k2, uint3
   return g ^ (g >> 15);
 }
 constexpr uint32_t kWordKeyBytes = 16;   // words longer than this are not looked up
+constexpr uint32_t kMemo16TwoPiece = 1u << 23;   // umemo16 meta word: the entry is of the two-piece form (a word of up to 10 bytes)
 constexpr uint32_t kWordMaxIds = 3;
 SPMX_HD inline uint32_t HashChar(uint32_t bytes, uint32_t len) {
   uint64_t h = (static_cast<uint64_t>(len) << 32 | bytes) * 0xD6E8FEB86659FD93ull;

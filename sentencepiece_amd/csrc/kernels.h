@@ -897,10 +897,14 @@ struct CompactArgs {
 };
 
 // Moves every sentence's ids from where its wave happened to put them in the arena to their place in the
-// caller's CSR.  A wave takes 64 consecutive sentences: their CSR range is contiguous, so the output is written
-// as one coalesced stream; every output element finds its sentence by a 6-step binary search over the 64
-// per-lane start offsets (cross-lane reads) and gathers from that sentence's arena slot.  (One wave per sentence,
-// the first version, used 28 of 64 lanes and re-read three offsets per sentence: 1.1 TB/s.)
+// caller's CSR.  A wave takes 64 consecutive sentences: their CSR range is contiguous, so the output is written as
+// one coalesced stream -- FOUR ids per lane and round, quads aligned on the output index (a 16-byte store each).  A
+// quad finds the sentence of its first id by a 6-step binary search over the 64 per-lane start offsets (cross-lane
+// reads); when the whole quad lies inside that sentence (6 of 7 quads at 28 ids per sentence) it is ONE 16-byte
+// read from the sentence's arena slot at whatever alignment that has, else its ids are looked up one by one.
+// (Round 3 moved one id per lane and round: a search per id, 2.7 TB/s; one wave per sentence, the first version, used
+// 28 of 64 lanes: 1.1 TB/s.)
+struct __attribute__((packed, aligned(4))) CompactQuad { int32_t x, y, z, w; };
 SPMX_DEVICE void compact_block(const CompactArgs &a) {
   const int lane = wv::lane();
   if (a.id_offs[a.n] > a.ids_cap) return;   // caller sees the needed size in id_offs[n]
@@ -914,20 +918,53 @@ SPMX_DEVICE void compact_block(const CompactArgs &a) {
                           wv::shfl(static_cast<uint32_t>(my_dst), 0);
     const uint32_t last = (b * 64 + 64 <= a.n) ? b * 64 + 64 : a.n;
     const uint32_t total = static_cast<uint32_t>(a.id_offs[last] - dst0);
-    const uint32_t rel = static_cast<uint32_t>(my_dst - dst0);
+    const uint32_t rel = static_cast<uint32_t>(my_dst - dst0);            // (lanes beyond the last sentence: rel = total)
     const uint32_t src_lo = static_cast<uint32_t>(my_src), src_hi = static_cast<uint32_t>(my_src >> 32);
-    const uint32_t rounds = (total + 63) / 64;
-    for (uint32_t r = 0; r < rounds; ++r) {
-      const uint32_t j = r * 64 + static_cast<uint32_t>(lane);
-      int lo = 0;                                              // the last sentence of the block that starts at or before j
+    // the sentence that holds output element j of the block (j < total): the last one that starts at or before j
+    auto find = [&](uint32_t j) __attribute__((always_inline)) -> int {
+      int lo = 0;
 #pragma unroll
       for (int step = 32; step >= 1; step >>= 1) {
         const uint32_t v = wv::shfl(rel, lo + step);
         if (v <= j) lo += step;
       }
+      return lo;
+    };
+    // quads aligned in MEMORY (the caller's ids pointer may sit at any multiple of 4 bytes)
+    const uint32_t head = (static_cast<uint32_t>(reinterpret_cast<uintptr_t>(a.ids) >> 2) + static_cast<uint32_t>(dst0)) & 3u;   // the block's first quad starts `head` ids before dst0
+    const uint32_t quads = (head + total + 3u) / 4u;
+    const uint32_t rounds = (quads + 63u) / 64u;
+    for (uint32_t r = 0; r < rounds; ++r) {
+      const uint32_t q = r * 64u + static_cast<uint32_t>(lane);
+      const uint32_t e0 = q * 4u;                              // index of the quad's first id, counted from dst0 - head
+      const uint32_t j_lo = e0 < head ? 0u : e0 - head;        // its first id that belongs to the block
+      const uint32_t j_hi = e0 + 4u - head < total ? e0 + 4u - head : total;    // (exclusive)
+      const bool live = q < quads && j_lo < j_hi;
+      const uint32_t jq = live ? j_lo : 0u;
+      const int lo = find(jq);                                 // (every lane takes part in the cross-lane reads)
       const uint32_t r0 = wv::shfl(rel, lo);
+      const uint32_t r1 = wv::shfl(rel, lo < 63 ? lo + 1 : 63);
+      const uint32_t end = lo < 63 ? r1 : total;               // where the sentence's ids end (the next sentence's start)
       const uint64_t base = (static_cast<uint64_t>(wv::shfl(src_hi, lo)) << 32) | wv::shfl(src_lo, lo);
-      if (j < total) a.ids[dst0 + j] = a.arena[base + (j - r0)];
+      const bool whole = live && e0 >= head && e0 + 4u - head <= total && e0 + 4u - head <= end;
+      if (whole) {
+        const CompactQuad v = *reinterpret_cast<const CompactQuad *>(a.arena + base + (jq - r0));
+        *reinterpret_cast<Q4 *>(a.ids + dst0 + jq) = Q4{static_cast<uint32_t>(v.x), static_cast<uint32_t>(v.y),
+                                                        static_cast<uint32_t>(v.z), static_cast<uint32_t>(v.w)};
+      }
+      // the quads that cross a sentence boundary (or the block's ends): id by id
+      const bool part = live && !whole;
+      if (wv::any(part)) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+          const uint32_t j = e0 + k >= head ? e0 + k - head : 0u;
+          const bool mine = part && e0 + k >= head && j < total;
+          const int l2 = find(mine ? j : 0u);
+          const uint32_t rr = wv::shfl(rel, l2);
+          const uint64_t b2 = (static_cast<uint64_t>(wv::shfl(src_hi, l2)) << 32) | wv::shfl(src_lo, l2);
+          if (mine) a.ids[dst0 + j] = a.arena[b2 + (j - rr)];
+        }
+      }
     }
   }
 }

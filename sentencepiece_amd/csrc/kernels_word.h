@@ -279,9 +279,15 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
       k0 = key_dword(w.x, mk.x); k1 = key_dword(w.y, mk.y); k2 = key_dword(w.z, mk.z);
     }
     const uint32_t h = HashWordKey(k0, k1, k2, 0u);
+    // which form of 16-byte entry a word of L bytes has (dev.h umemo16): up to 10 bytes the two-piece form -- the third
+    // dword's high half is the second id, not key bytes
+    const uint32_t zmask = L <= 10 ? 0xFFFFu : 0xFFFFFFFFu, form = L <= 10 ? kMemo16TwoPiece : 0u;
+    auto same16 = [&](const U4 &e) __attribute__((always_inline)) -> bool {
+      return e.x == k0 && e.y == k1 && ((e.z ^ k2) & zmask) == 0u && (e.w & kMemo16TwoPiece) == form && e.w != 0xFFFFFFFFu;
+    };
     {   // the likeliest words: LDS
       const U4 e = T.hot[h & (kWordHotSlots - 1u)];
-      hit16 = shortw && e.x == k0 && e.y == k1 && e.z == k2 && e.w != 0xFFFFFFFFu;
+      hit16 = shortw && same16(e);
       if (hit16) ent = e;
     }
 #if SPMX_EXP & 32     // (experiment build: one more memo16 gather per iteration, every lane with a short word)
@@ -291,13 +297,13 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
     if (wv::any(look)) {                             // the rest of the one-piece words of up to 12 bytes: one probe, HBM / L2
       uint32_t sl = h & m16;
       U4 e = memo16[look ? sl : 0u];
-      hit16 = hit16 || (look && e.x == k0 && e.y == k1 && e.z == k2 && e.w != 0xFFFFFFFFu);
+      hit16 = hit16 || (look && same16(e));
       bool walk = look && !hit16 && e.w != 0xFFFFFFFFu;
       while (wv::any(walk)) {                        // a collision: walk on (rare: the table is half empty)
         if (walk) {
           sl = (sl + 1u) & m16;
           e = memo16[sl];
-          hit16 = e.x == k0 && e.y == k1 && e.z == k2 && e.w != 0xFFFFFFFFu;
+          hit16 = same16(e);
           walk = !hit16 && e.w != 0xFFFFFFFFu;
         }
       }
@@ -351,9 +357,9 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
     }
     // ---- take the entry while its margin holds ----
     const uint32_t id0 = hit16 ? (ent.w & 0xFFFFu) : ent.x;
-    const uint32_t id1 = hit32 ? ent.y : 0xFFFFFFFFu;
+    const uint32_t id1 = hit32 ? ent.y : ((hit16 && (ent.w & kMemo16TwoPiece) && (ent.z >> 16) != 0xFFFFu) ? ent.z >> 16 : 0xFFFFFFFFu);
     // valid while |B| < lim: 2^e (16-byte entry: the power of two below bmax) or bmax itself
-    const float lim = hit16 ? wv::bits_to_float((((ent.w >> 16) & 0xFFu) + 127u) << 23) : wv::bits_to_float(ent.w);
+    const float lim = hit16 ? wv::bits_to_float((((ent.w >> 16) & 0x7Fu) + 127u) << 23) : wv::bits_to_float(ent.w);
     const bool hit = hit16 || hit32 || hitd;
     // (a collecting lane that has already given its sentence up only scouts for more words: no margin to check)
     const bool ok = hit && ((MODE == kWmCollect && bad) || fabsf(B) < lim);

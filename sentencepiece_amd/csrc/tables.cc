@@ -672,19 +672,35 @@ void BuildWordMemo(const ModelData &m, HostTables *t) {
   auto bound_of = [&](uint32_t id) -> double {          // (BPE keeps no score: its entries are valid whatever came before)
     return m.model_type == kBpe ? 0.0 : ceil(fabs(static_cast<double>(m.pieces[id].score))) + 1.0;
   };
+  // 16-byte entries (dev.h umemo16): words of up to 12 bytes that are ONE piece, and -- the TWO-PIECE form -- words of up
+  // to 10 bytes that are one or two pieces: their key needs only the low half of the third key dword, the high half holds
+  // the second id (0xFFFF: none); bit 23 of the meta word tells the forms apart (a lookup knows which one its word's
+  // length asks for).  Everything else takes the 32-byte entries.
   std::vector<const Ent *> small, big;
+  auto len_of = [](const Ent &e) -> int {
+    const unsigned char *kb = reinterpret_cast<const unsigned char *>(e.k);
+    int l = 0;
+    while (l < static_cast<int>(kWordKeyBytes) && kb[l] != 0x20) ++l;
+    return l;
+  };
+  auto bound2 = [&](const Ent &e) -> double { return bound_of(e.id0) + (e.id1 != 0xFFFFFFFFu ? bound_of(e.id1) : 0.0); };
   for (const Ent &e : ents) {
     const bool one = e.id1 == 0xFFFFFFFFu;
-    const bool short_key = e.k[3] == 0x20202020u;        // at most 12 bytes
-    if (one && short_key && e.id0 < 65536u && bound_of(e.id0) <= 255.0 && e.bmax >= 1.0f) small.push_back(&e);
+    const int len = len_of(e);
+    const bool fits = e.id0 < 65535u && (one || e.id1 < 65535u) && bound2(e) <= 255.0 && e.bmax >= 1.0f;
+    if (fits && ((one && len <= 12) || len <= 10)) small.push_back(&e);
     else big.push_back(&e);
   }
+  auto key2_16 = [&](const Ent &e) -> uint32_t {        // the third dword of a 16-byte entry
+    if (len_of(e) > 10) return e.k[2];
+    return (e.k[2] & 0xFFFFu) | (e.id1 == 0xFFFFFFFFu ? 0xFFFFu : e.id1) << 16;
+  };
   auto meta16 = [&](const Ent &e) -> uint32_t {
     int ex = 0;
     (void)frexpf(e.bmax, &ex);                            // bmax = f * 2^ex, f in [0.5, 1): 2^(ex - 1) <= bmax
     int pw = ex - 1;
     if (pw > 126) pw = 126;
-    return e.id0 | static_cast<uint32_t>(pw) << 16 | static_cast<uint32_t>(bound_of(e.id0)) << 24;
+    return e.id0 | static_cast<uint32_t>(pw) << 16 | (len_of(e) <= 10 ? kMemo16TwoPiece : 0u) | static_cast<uint32_t>(bound2(e)) << 24;
   };
   {
     const uint32_t wsz = NextPow2(small.size() * 6 + 16);     // sparse: a collision costs the whole wave another probe
@@ -692,10 +708,10 @@ void BuildWordMemo(const ModelData &m, HostTables *t) {
     for (const Ent *e : small) {
       const uint32_t h = HashWordKey(e->k[0], e->k[1], e->k[2], 0u);
       U4 &hs = t->uhot[h & (static_cast<uint32_t>(t->uhot.size()) - 1u)];
-      if (hs.w == 0xFFFFFFFFu) hs = U4{e->k[0], e->k[1], e->k[2], meta16(*e)};
+      if (hs.w == 0xFFFFFFFFu) hs = U4{e->k[0], e->k[1], key2_16(*e), meta16(*e)};
       uint32_t sl = h & (wsz - 1);
       while (t->umemo16[sl].w != 0xFFFFFFFFu) sl = (sl + 1) & (wsz - 1);
-      t->umemo16[sl] = U4{e->k[0], e->k[1], e->k[2], meta16(*e)};
+      t->umemo16[sl] = U4{e->k[0], e->k[1], key2_16(*e), meta16(*e)};
     }
     sc.umemo16_mask = wsz - 1;
   }
