@@ -258,6 +258,7 @@ struct spmx_handle {
   uint32_t tile_min_lanes = 1;   // SPMX_TILE_MIN_LANES: a main tile has at least this many sentences even when that leaves wavefronts without a tile of the class
   int fork_waves = 0;            // SPMX_FORK_WAVES: wavefronts per workgroup of the general launch while it runs next to the first word round (0: by its size)
   bool no_overlap = false;       // SPMX_NO_OVERLAP=1: the general launches do not run next to the word rounds
+  bool no_ids16 = false;         // SPMX_NO_IDS16=1: the word kernels write 32-bit ids into the arena whatever the vocabulary's size
   bool no_scan = false;          // SPMX_NO_SCAN=1: classify does not set the non-plain sentences aside (the word rounds find them)
   bool no_word_dyn = false;      // SPMX_NO_WORD_DYN=1: no call-local word memo (one word round, then the DP pass)
   bool memo_unsafe = false;      // TEST SEAM of the emulator build (SPMX_TEST_SEAMS + SPMX_WORDMEMO_UNSAFE=1): the call-local memo takes no margin either
@@ -466,7 +467,7 @@ int RunClassify(spmx_handle *h, Workspace *ws, const uint64_t *d_offsets, uint32
   ca.key_totals = ws->d_ctrl->key_totals; ca.key_cursor = ws->d_ctrl->key_cursor;
   ca.sub_buckets = h->sub_buckets;
   const uint32_t chunks = (n32 + 64 * kClassifyChunk - 1) / (64 * kClassifyChunk);
-  const uint32_t wide = static_cast<uint32_t>(h->n_cu) * 8u;
+  const uint32_t wide = static_cast<uint32_t>(h->n_cu) * 10u;     // (one-wavefront workgroups of 14.5 KB of LDS: ten fit a CU)
   HIP_OR_RETURN(h, LaunchClassify(ca, static_cast<int>(chunks < wide ? chunks : wide), stream));
   return kOk;
 }
@@ -974,6 +975,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         wa.dyn_mask = h->dyn_slots - 1u;
         wa.dyn_cap = h->dyn_list_cap;
         wa.resume = ws->d_resume.p;
+        wa.ids16 = (h->model.pieces.size() <= 65536 && !h->no_ids16) ? 1u : 0u;
         snprintf(ws->slot_name[slot], sizeof(ws->slot_name[slot]), "%s",
                  mode == 3 ? "EncodeWordDpKernel" : mode == 2 ? "EncodeWordAgainKernel" : mode == 1 ? "EncodeWordCollectKernel" : "EncodeWordKernel");
         HIP_OR_RETURN(h, record(slot, 0));
@@ -1394,6 +1396,7 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_NO_OVERLAP")) h->no_overlap = e[0] == '1';
     if (const char *e = getenv("SPMX_FORK_WAVES")) h->fork_waves = atoi(e);
     if (const char *e = getenv("SPMX_NO_SCAN")) h->no_scan = e[0] == '1';
+    if (const char *e = getenv("SPMX_NO_IDS16")) h->no_ids16 = e[0] == '1';
     if (const char *e = getenv("SPMX_DYN_SLOTS_LOG2")) { const int v = atoi(e); if (v >= 4 && v <= 26) h->dyn_slots = 1u << v; }
     if (const char *e = getenv("SPMX_DYN_LIST_CAP")) { const long v = atol(e); if (v >= 1 && v <= (1l << 26)) h->dyn_list_cap = static_cast<uint32_t>(v); }
     if (const char *e = getenv("SPMX_NBEST_BUDGET_GB")) { const long v = atol(e); if (v >= 1 && v <= 200) h->nbest_budget = static_cast<uint64_t>(v) << 30; }

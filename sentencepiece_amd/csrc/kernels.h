@@ -109,6 +109,7 @@ struct EncodeArgs {
   uint32_t dyn_mask;
   uint32_t dyn_cap;             // entries dyn_list holds
   U4 *resume;                   // per sentence the first round keeps for the second: {position, ids written, bound, 0}
+  uint32_t ids16;               // the word kernels write 16-bit ids into their arena slots (vocabularies of up to 65536 pieces)
   // ---- sentence-per-wave launch (BPE models that are not word-wise; kernels_bpe.h) ----
   const uint32_t *list;         // sentence indices of this length class
   const uint32_t *list_count;   // number of entries in list (device resident)
@@ -643,7 +644,7 @@ inline uint32_t EncodeLdsBytes(int model_type, uint32_t rcap, uint32_t ncap) {
 // that the 64 sentences of a tile have similar lengths whatever the order of the input (the lanes of a tile run
 // in lock step: an unsorted corpus cost 1.6x the search iterations of a length-bucketed one, profiles/).
 constexpr int kSubBuckets = 16;                        // default number of length sub-buckets per class
-constexpr int kMaxSubBuckets = 64;                     // ClassifyArgs::sub_buckets may go up to this
+constexpr int kMaxSubBuckets = 32;                     // ClassifyArgs::sub_buckets may go up to this
 constexpr int kSortKeys = 2 * kMaxClasses * kMaxSubBuckets;   // capacity of the key tables (plain + set-aside keys)
 constexpr int kClassifyChunk = 16;   // a wave takes chunks of 16 x 64 sentences
 constexpr uint32_t kClassifyLdsWords = 3u * kSortKeys + 2u * (64u * kClassifyChunk + 2u) + 64u * kClassifyChunk / 32u;
@@ -710,19 +711,24 @@ SPMX_DEVICE void plain_scan_chunk(const ClassifyArgs &a, uint32_t first, uint32_
     }
     return lo;
   };
-  for (uint64_t u = u0 + static_cast<uint64_t>(lane) * 16u; u < u1; u += 64u * 16u * 4u) {
-    Q4 v[4];
-    uint32_t m[4];
+  constexpr int kFlight = 8;                          // 16-byte units in flight per lane (8 KB per wavefront)
+  for (uint64_t u = u0 + static_cast<uint64_t>(lane) * 16u; u < u1; u += 64u * 16u * kFlight) {
+    Q4 v[kFlight];
+    uint32_t m[kFlight];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {                     // four units in flight per lane
+    for (int j = 0; j < kFlight; ++j) {
       const uint64_t uj = u + static_cast<uint64_t>(j) * 1024u;
       v[j] = uj < u1 ? *reinterpret_cast<const Q4 *>(uj) : Q4{0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u};
     }
+    uint32_t any_m = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) m[j] = nonplain_bits(v[j].x) | nonplain_bits(v[j].y) | nonplain_bits(v[j].z) | nonplain_bits(v[j].w);
-    if ((m[0] | m[1] | m[2] | m[3]) == 0u) continue;
+    for (int j = 0; j < kFlight; ++j) {
+      m[j] = nonplain_bits(v[j].x) | nonplain_bits(v[j].y) | nonplain_bits(v[j].z) | nonplain_bits(v[j].w);
+      any_m |= m[j];
+    }
+    if (any_m == 0u) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < kFlight; ++j) {
       if (m[j] == 0u) continue;
       const uint64_t uj = u + static_cast<uint64_t>(j) * 1024u;
       const uint32_t z[4] = {nonplain_bits(v[j].x), nonplain_bits(v[j].y), nonplain_bits(v[j].z), nonplain_bits(v[j].w)};
@@ -886,6 +892,9 @@ SPMX_DEVICE void scan_final_block(const ScanArgs &a) {     // pass 3
   }
 }
 
+// tmp_off[s] with this bit: sentence s's ids are 16-bit values, the rest of the word is their offset in 16-BIT units from
+// the arena's start (the word kernels, EncodeArgs::ids16); without it 32-bit values at an offset in 32-bit units
+constexpr unsigned long long kTmpOffHalf = 1ull << 63;
 struct CompactArgs {
   const int32_t *arena;
   const uint64_t *tmp_off;
@@ -897,18 +906,19 @@ struct CompactArgs {
 };
 
 // Moves every sentence's ids from where its wave happened to put them in the arena to their place in the
-// caller's CSR.  A wave takes 64 consecutive sentences: their CSR range is contiguous, so the output is written as
-// one coalesced stream -- FOUR ids per lane and round, quads aligned on the output index (a 16-byte store each).  A
-// quad finds the sentence of its first id by a 6-step binary search over the 64 per-lane start offsets (cross-lane
-// reads); when the whole quad lies inside that sentence (6 of 7 quads at 28 ids per sentence) it is ONE 16-byte
-// read from the sentence's arena slot at whatever alignment that has, else its ids are looked up one by one.
-// (Round 3 moved one id per lane and round: a search per id, 2.7 TB/s; one wave per sentence, the first version, used
-// 28 of 64 lanes: 1.1 TB/s.)
-struct __attribute__((packed, aligned(4))) CompactQuad { int32_t x, y, z, w; };
+// caller's CSR.  A wave takes 64 consecutive sentences: their CSR range is contiguous, so the output is written
+// as one coalesced stream; every output element finds its sentence by a 6-step binary search over the 64
+// per-lane start offsets (cross-lane reads) and gathers from that sentence's arena slot -- 32-bit ids, or 16-bit ones
+// where the word kernels wrote them (kTmpOffHalf).  (One wave per sentence, the first version, used 28 of 64 lanes and
+// re-read three offsets per sentence: 1.1 TB/s.  Round 4 tried FOUR ids per lane and round -- one search per quad, a
+// 16-byte read at the slot's alignment, a 16-byte store: 1.06 ms against this form's 0.81 on the same 10 M sentences,
+// profiles/r04_ab_kernel_stats.txt: the quads that cross a sentence boundary, one in seven, run a second path in
+// almost every round.)
 SPMX_DEVICE void compact_block(const CompactArgs &a) {
   const int lane = wv::lane();
   if (a.id_offs[a.n] > a.ids_cap) return;   // caller sees the needed size in id_offs[n]
   const uint32_t blocks = (a.n + 63) / 64;
+  const uint16_t *arena16 = reinterpret_cast<const uint16_t *>(a.arena);
   for (uint32_t b = static_cast<uint32_t>(wv::block_id()); b < blocks; b += static_cast<uint32_t>(wv::grid_size())) {
     const uint32_t s = b * 64 + static_cast<uint32_t>(lane);
     const uint32_t sc = s < a.n ? s : a.n;                     // id_offs[n] closes the last block
@@ -918,53 +928,21 @@ SPMX_DEVICE void compact_block(const CompactArgs &a) {
                           wv::shfl(static_cast<uint32_t>(my_dst), 0);
     const uint32_t last = (b * 64 + 64 <= a.n) ? b * 64 + 64 : a.n;
     const uint32_t total = static_cast<uint32_t>(a.id_offs[last] - dst0);
-    const uint32_t rel = static_cast<uint32_t>(my_dst - dst0);            // (lanes beyond the last sentence: rel = total)
+    const uint32_t rel = static_cast<uint32_t>(my_dst - dst0);
     const uint32_t src_lo = static_cast<uint32_t>(my_src), src_hi = static_cast<uint32_t>(my_src >> 32);
-    // the sentence that holds output element j of the block (j < total): the last one that starts at or before j
-    auto find = [&](uint32_t j) __attribute__((always_inline)) -> int {
-      int lo = 0;
+    const uint32_t rounds = (total + 63) / 64;
+    for (uint32_t r = 0; r < rounds; ++r) {
+      const uint32_t j = r * 64 + static_cast<uint32_t>(lane);
+      int lo = 0;                                              // the last sentence of the block that starts at or before j
 #pragma unroll
       for (int step = 32; step >= 1; step >>= 1) {
         const uint32_t v = wv::shfl(rel, lo + step);
         if (v <= j) lo += step;
       }
-      return lo;
-    };
-    // quads aligned in MEMORY (the caller's ids pointer may sit at any multiple of 4 bytes)
-    const uint32_t head = (static_cast<uint32_t>(reinterpret_cast<uintptr_t>(a.ids) >> 2) + static_cast<uint32_t>(dst0)) & 3u;   // the block's first quad starts `head` ids before dst0
-    const uint32_t quads = (head + total + 3u) / 4u;
-    const uint32_t rounds = (quads + 63u) / 64u;
-    for (uint32_t r = 0; r < rounds; ++r) {
-      const uint32_t q = r * 64u + static_cast<uint32_t>(lane);
-      const uint32_t e0 = q * 4u;                              // index of the quad's first id, counted from dst0 - head
-      const uint32_t j_lo = e0 < head ? 0u : e0 - head;        // its first id that belongs to the block
-      const uint32_t j_hi = e0 + 4u - head < total ? e0 + 4u - head : total;    // (exclusive)
-      const bool live = q < quads && j_lo < j_hi;
-      const uint32_t jq = live ? j_lo : 0u;
-      const int lo = find(jq);                                 // (every lane takes part in the cross-lane reads)
       const uint32_t r0 = wv::shfl(rel, lo);
-      const uint32_t r1 = wv::shfl(rel, lo < 63 ? lo + 1 : 63);
-      const uint32_t end = lo < 63 ? r1 : total;               // where the sentence's ids end (the next sentence's start)
-      const uint64_t base = (static_cast<uint64_t>(wv::shfl(src_hi, lo)) << 32) | wv::shfl(src_lo, lo);
-      const bool whole = live && e0 >= head && e0 + 4u - head <= total && e0 + 4u - head <= end;
-      if (whole) {
-        const CompactQuad v = *reinterpret_cast<const CompactQuad *>(a.arena + base + (jq - r0));
-        *reinterpret_cast<Q4 *>(a.ids + dst0 + jq) = Q4{static_cast<uint32_t>(v.x), static_cast<uint32_t>(v.y),
-                                                        static_cast<uint32_t>(v.z), static_cast<uint32_t>(v.w)};
-      }
-      // the quads that cross a sentence boundary (or the block's ends): id by id
-      const bool part = live && !whole;
-      if (wv::any(part)) {
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
-          const uint32_t j = e0 + k >= head ? e0 + k - head : 0u;
-          const bool mine = part && e0 + k >= head && j < total;
-          const int l2 = find(mine ? j : 0u);
-          const uint32_t rr = wv::shfl(rel, l2);
-          const uint64_t b2 = (static_cast<uint64_t>(wv::shfl(src_hi, l2)) << 32) | wv::shfl(src_lo, l2);
-          if (mine) a.ids[dst0 + j] = a.arena[b2 + (j - rr)];
-        }
-      }
+      const uint32_t hi = wv::shfl(src_hi, lo);
+      const uint64_t base = (static_cast<uint64_t>(hi & 0x7FFFFFFFu) << 32) | wv::shfl(src_lo, lo);
+      if (j < total) a.ids[dst0 + j] = (hi >> 31) ? static_cast<int32_t>(arena16[base + (j - r0)]) : a.arena[base + (j - r0)];
     }
   }
 }

@@ -164,7 +164,9 @@ SPMX_DEVICE void uni_word_dp(const SpmxDev &d, const WordLds &T, int L, float B,
 // `rs` of uni_word_lane: (collect) out -- where the lane stood when it met its first missing word: {position, ids
 // written, bound}; (dyn) in -- where to take the sentence up again: the ids before that point are in `slot` already.
 struct WordResume { int p; int n; float B; };
-template <bool DP, int MODE>
+// H16: the ids leave as 16-bit values (vocabularies of up to 65536 pieces): a burst of 8 ids is ONE 16-byte store, and
+// CompactKernel reads half the bytes.  `slot` is then an array of uint16_t at the same (16-byte aligned) address.
+template <bool DP, int MODE, bool H16>
 SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_t beg, int len, int32_t *slot, int cap,
                               const WordLds &T, bool active_in, int *n_steps, WordResume *rs) {
   const SpmxDev &d = a.dev;
@@ -180,7 +182,8 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
   float B = 0.f;                                   // DP: best_path_score at the start of the current word; else a bound of its magnitude
   if (MODE == kWmDyn && active) {                  // take the sentence up where the first round left it
     p = rs->p; n = rs->n; B = rs->B;
-    for (int k = n & ~7; k < n; ++k) T.stage[(k & 7) << 6] = slot[k];      // the incomplete group goes back into the staging column
+    for (int k = n & ~7; k < n; ++k)                 // the incomplete group goes back into the staging column
+      T.stage[(k & 7) << 6] = H16 ? static_cast<int32_t>(reinterpret_cast<const uint16_t *>(slot)[k]) : slot[k];
     if (p >= len) active = false;                  // (cannot happen: the first round stopped AT a word)
   }
   int n_dp = 0;
@@ -197,7 +200,13 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
   auto put = [&](uint32_t id) __attribute__((always_inline)) {
     stage[(n & 7) << 6] = static_cast<int32_t>(id);
     ++n;
-    if ((n & 7) == 0 && !(SPMX_EXP & 16)) {   // (16: experiment build without the id bursts)
+    if (H16 && (n & 7) == 0 && !(SPMX_EXP & 16)) {
+      const uint32_t s0 = static_cast<uint32_t>(stage[0]), s1 = static_cast<uint32_t>(stage[1 << 6]), s2 = static_cast<uint32_t>(stage[2 << 6]),
+                     s3 = static_cast<uint32_t>(stage[3 << 6]), s4 = static_cast<uint32_t>(stage[4 << 6]), s5 = static_cast<uint32_t>(stage[5 << 6]),
+                     s6 = static_cast<uint32_t>(stage[6 << 6]), s7 = static_cast<uint32_t>(stage[7 << 6]);
+      *reinterpret_cast<Q4 *>(reinterpret_cast<uint16_t *>(slot) + (n - 8)) = Q4{s0 | s1 << 16, s2 | s3 << 16, s4 | s5 << 16, s6 | s7 << 16};
+    }
+    if (!H16 && (n & 7) == 0 && !(SPMX_EXP & 16)) {   // (16: experiment build without the id bursts)
       int32_t *q = slot + (n - 8);
       *reinterpret_cast<Q4 *>(q) = Q4{static_cast<uint32_t>(stage[0]), static_cast<uint32_t>(stage[1 << 6]),
                                       static_cast<uint32_t>(stage[2 << 6]), static_cast<uint32_t>(stage[3 << 6])};
@@ -454,20 +463,25 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
 #if SPMX_EXP & (8 | 32)
   if (exp_acc == 0x9E3779B1u) ++steps, *n_steps = steps;     // (keeps the experiment's loads alive)
 #endif
+  auto flush_tail = [&]() __attribute__((always_inline)) {
+    for (int k = n & ~7; k < n; ++k) {
+      if (H16) reinterpret_cast<uint16_t *>(slot)[k] = static_cast<uint16_t>(stage[(k & 7) << 6]);
+      else slot[k] = stage[(k & 7) << 6];
+    }
+  };
   if (bad && MODE == kWmCollect && again) {
-    for (int k = n & ~7; k < n; ++k) slot[k] = stage[(k & 7) << 6];   // what is staged belongs to the ids the second round keeps
+    flush_tail();                                  // what is staged belongs to the ids the second round keeps
     return -2;
   }
   if (bad) return -1;
-  if (active_in && len > 0)
-    for (int k = n & ~7; k < n; ++k) slot[k] = stage[(k & 7) << 6];   // the last, incomplete group
+  if (active_in && len > 0) flush_tail();          // the last, incomplete group
   return n;
 }
 
 // Persistent body of the word kernels: tiles of up to 64 sentences from the launch's queue (kernels_stream.h
 // next_tile), one sentence per lane.  What a lane cannot take goes to the leftover list of its class.
-template <bool DP, int MODE>
-SPMX_DEVICE void encode_word_block(const EncodeArgs &a, unsigned char *smem) {
+template <bool DP, int MODE, bool H16>
+SPMX_DEVICE void encode_word_block_as(const EncodeArgs &a, unsigned char *smem) {
   const int lane = wv::lane();
   const SpmxDev &d = a.dev;
   Q4 *masks = reinterpret_cast<Q4 *>(smem);
@@ -536,14 +550,23 @@ SPMX_DEVICE void encode_word_block(const EncodeArgs &a, unsigned char *smem) {
       rs.p = static_cast<int>(r.x); rs.n = static_cast<int>(r.y); rs.B = wv::bits_to_float(r.z);
     }
     int steps = 0;
-    int n = uni_word_lane<DP, MODE>(a, a.text, beg, len, slot, cap, T, mine && !overflow, &steps, &rs);
+    int n = uni_word_lane<DP, MODE, H16>(a, a.text, beg, len, slot, cap, T, mine && !overflow, &steps, &rs);
     const unsigned long long c1 = wv::clock();
     if (overflow) n = -1;
     const bool done = mine && n >= 0;
     if (done) {
-      for (int x = 0; x < d.n_prefix; ++x) slot[x - d.n_prefix] = d.prefix_ids[x];
-      for (int x = 0; x < d.n_suffix; ++x) slot[n + x] = d.suffix_ids[x];
-      a.tmp_off[sid] = static_cast<unsigned long long>(slot - d.n_prefix - a.arena);
+      if (H16) {
+        // (16-bit ids: the extra ids sit right before / behind the body in 16-bit units too; the sentence's place is told
+        // to CompactKernel in 16-bit units from the arena's start, flagged by kTmpOffHalf)
+        uint16_t *s16 = reinterpret_cast<uint16_t *>(slot);
+        for (int x = 0; x < d.n_prefix; ++x) s16[x - d.n_prefix] = static_cast<uint16_t>(d.prefix_ids[x]);
+        for (int x = 0; x < d.n_suffix; ++x) s16[n + x] = static_cast<uint16_t>(d.suffix_ids[x]);
+        a.tmp_off[sid] = kTmpOffHalf | (2ull * static_cast<unsigned long long>(slot - a.arena) - static_cast<unsigned long long>(d.n_prefix));
+      } else {
+        for (int x = 0; x < d.n_prefix; ++x) slot[x - d.n_prefix] = d.prefix_ids[x];
+        for (int x = 0; x < d.n_suffix; ++x) slot[n + x] = d.suffix_ids[x];
+        a.tmp_off[sid] = static_cast<unsigned long long>(slot - d.n_prefix - a.arena);
+      }
       a.counts[sid] = static_cast<uint32_t>(n + n_extra);
     }
     const bool left = have && !done;
@@ -579,6 +602,12 @@ SPMX_DEVICE void encode_word_block(const EncodeArgs &a, unsigned char *smem) {
       wv::atomic_add(&a.stats[7], tc.n_trips);
     }
   }
+}
+
+template <bool DP, int MODE>
+SPMX_DEVICE void encode_word_block(const EncodeArgs &a, unsigned char *smem) {
+  if (a.ids16) encode_word_block_as<DP, MODE, true>(a, smem);      // (wave-uniform: one form per launch)
+  else encode_word_block_as<DP, MODE, false>(a, smem);
 }
 
 // ---- the call-local memo's words, segmented once each: one LANE per collected word ------------------------------------

@@ -688,7 +688,8 @@ void BuildWordMemo(const ModelData &m, HostTables *t) {
     const bool one = e.id1 == 0xFFFFFFFFu;
     const int len = len_of(e);
     const bool fits = e.id0 < 65535u && (one || e.id1 < 65535u) && bound2(e) <= 255.0 && e.bmax >= 1.0f;
-    if (fits && ((one && len <= 12) || len <= 10)) small.push_back(&e);
+    static const bool one_only = getenv("SPMX_MEMO16_ONE") != nullptr;   // A/B: only one-piece words in the 16-byte entries (round 3)
+    if (fits && ((one && len <= 12) || (len <= 10 && !one_only))) small.push_back(&e);
     else big.push_back(&e);
   }
   auto key2_16 = [&](const Ent &e) -> uint32_t {        // the third dword of a 16-byte entry

@@ -23,7 +23,8 @@ from tests import fixtures, wordfuzz
 WORD_MODELS = ["uni32k", "uni32k_w16", "bpe32k"]
 # how the handle is loaded: the default plan; the small class table of the CPU suite; no call-local memo (one word round
 # + the DP pass); the first round without the second
-VARIANTS = {"default": {}, "small_classes": {"SPMX_CLASSES": "small"}, "no_dyn": {"SPMX_NO_WORD_DYN": "1"}}
+VARIANTS = {"default": {}, "small_classes": {"SPMX_CLASSES": "small"}, "no_dyn": {"SPMX_NO_WORD_DYN": "1"},
+            "ids32": {"SPMX_NO_IDS16": "1"}}        # (32-bit ids in the word kernels' arena slots, as for vocabularies beyond 65536)
 
 
 def _emu_load(emu, blob, variant, extra=None):
