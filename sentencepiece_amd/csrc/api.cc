@@ -256,7 +256,7 @@ struct spmx_handle {
   uint64_t nbest_budget = 32ull << 30;  // SPMX_NBEST_BUDGET_GB: HBM the lattice slices of one launch may take (200 k sentences, n-best 5: 0.83 M sentences/s at 8 GB, 1.15 M at 32, 1.19 M at 96)
   uint32_t nbest_hyps_min = 16384;   // SPMX_NBEST_HYPS_MIN: hypotheses a lane's A* may hold in the first launch (what outgrows it runs again)
   uint32_t tile_min_lanes = 1;   // SPMX_TILE_MIN_LANES: a main tile has at least this many sentences even when that leaves wavefronts without a tile of the class
-  int fork_waves = 0;            // SPMX_FORK_WAVES: wavefronts per workgroup of the general launch while it runs next to the first word round (0: by its size)
+  int fork_waves = 4;            // SPMX_FORK_WAVES: wavefronts per workgroup of the general launch while it runs next to the first word round (0: by its size)
   bool no_overlap = false;       // SPMX_NO_OVERLAP=1: the general launches do not run next to the word rounds
   bool no_ids16 = false;         // SPMX_NO_IDS16=1: the word kernels write 32-bit ids into the arena whatever the vocabulary's size
   bool no_scan = false;          // SPMX_NO_SCAN=1: classify does not set the non-plain sentences aside (the word rounds find them)
@@ -455,11 +455,18 @@ hipError_t EnsureEvents(Workspace *ws) {
 // d_text / gen_lists (both or neither): the plain scan (kernels.h ClassifyArgs) -- sentences with a byte outside
 // 0x20 .. 0x7E go to gen_lists, counted in Ctrl::gen_counts
 int RunClassify(spmx_handle *h, Workspace *ws, const uint64_t *d_offsets, uint32_t n32, hipStream_t stream,
-                const uint8_t *d_text = nullptr, uint32_t *gen_lists = nullptr) {
+                const uint8_t *d_text = nullptr, uint64_t text_bytes = 0, uint32_t *gen_lists = nullptr) {
   ClassifyArgs ca{};
   ca.offs = d_offsets; ca.n = n32; ca.n_classes = static_cast<uint32_t>(kNumClasses);
   if (d_text && gen_lists) {
-    ca.text = d_text; ca.flags = ws->d_flags.p; ca.lists2 = gen_lists; ca.list2_counts = ws->d_ctrl->gen_counts;
+    HIP_OR_RETURN(h, hipMemsetAsync(ws->d_flags.p, 0, n32, stream));
+    PlainScanArgs pa{d_text, text_bytes, d_offsets, n32, ws->d_flags.p};
+    uint64_t g = (text_bytes + 8191) / 8192;                      // a wavefront takes 8 KB per step
+    const uint64_t most = static_cast<uint64_t>(h->n_cu) * 16u;
+    if (g > most) g = most;
+    if (g < 1) g = 1;
+    HIP_OR_RETURN(h, LaunchPlainScan(pa, static_cast<int>(g), stream));
+    ca.flags = ws->d_flags.p; ca.lists2 = gen_lists; ca.list2_counts = ws->d_ctrl->gen_counts;
     ca.scan_max_rcap = kMaxStagedRaw;
   }
   for (int c = 0; c < kNumClasses; ++c) ca.rcap[c] = h->classes[c].rcap;
@@ -467,7 +474,7 @@ int RunClassify(spmx_handle *h, Workspace *ws, const uint64_t *d_offsets, uint32
   ca.key_totals = ws->d_ctrl->key_totals; ca.key_cursor = ws->d_ctrl->key_cursor;
   ca.sub_buckets = h->sub_buckets;
   const uint32_t chunks = (n32 + 64 * kClassifyChunk - 1) / (64 * kClassifyChunk);
-  const uint32_t wide = static_cast<uint32_t>(h->n_cu) * 10u;     // (one-wavefront workgroups of 14.5 KB of LDS: ten fit a CU)
+  const uint32_t wide = static_cast<uint32_t>(h->n_cu) * 8u;
   HIP_OR_RETURN(h, LaunchClassify(ca, static_cast<int>(chunks < wide ? chunks : wide), stream));
   return kOk;
 }
@@ -679,7 +686,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
     HIP_OR_RETURN(h, hipMemsetAsync(ws->d_ctrl, 0, sizeof(Ctrl), stream));
     HIP_OR_RETURN(h, hipMemsetAsync(d_status, 0, n, stream));
     for (bool &u : ws->slot_used) u = false;
-    if (int rc = RunClassify(h, ws, d_offsets, n32, stream, scanned ? d_text : nullptr, scanned ? gen_lists : nullptr); rc != kOk) return rc;
+    if (int rc = RunClassify(h, ws, d_offsets, n32, stream, scanned ? d_text : nullptr, text_bytes, scanned ? gen_lists : nullptr); rc != kOk) return rc;
     HIP_OR_RETURN(h, hipMemcpyAsync(ws->h_ctrl->list_counts, ws->d_ctrl->list_counts,
                                     sizeof(ws->h_ctrl->list_counts) + sizeof(ws->h_ctrl->gen_counts),       // (gen_counts follows list_counts in Ctrl)
                                     hipMemcpyDeviceToHost, stream));

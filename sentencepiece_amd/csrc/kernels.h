@@ -647,15 +647,15 @@ constexpr int kSubBuckets = 16;                        // default number of leng
 constexpr int kMaxSubBuckets = 32;                     // ClassifyArgs::sub_buckets may go up to this
 constexpr int kSortKeys = 2 * kMaxClasses * kMaxSubBuckets;   // capacity of the key tables (plain + set-aside keys)
 constexpr int kClassifyChunk = 16;   // a wave takes chunks of 16 x 64 sentences
-constexpr uint32_t kClassifyLdsWords = 3u * kSortKeys + 2u * (64u * kClassifyChunk + 2u) + 64u * kClassifyChunk / 32u;
+constexpr uint32_t kClassifyLdsWords = 3u * kSortKeys;
 
 // The PLAIN scan (round 4).  The word kernels (kernels_word.h) take sentences that are plain ASCII words; a sentence
 // with any other byte (below 0x20, 0x7F and above: control characters, UTF-8) leaves them for the general kernels
 // anyway -- after costing the word round an iteration per word, and with the general launch waiting for the word round
-// to name it.  When `text` is set the count pass therefore reads the chunk's text once (its 1024 sentences are
-// contiguous: coalesced 16-byte loads), flags every sentence holding such a byte, and the scatter pass sends the
-// flagged sentences to a second set of class lists (lists2): the general launch over them starts NEXT TO the first
-// word round instead of after it.  The flag only routes: both kernel families encode any sentence they are given.
+// to name it.  PlainScanKernel (below) therefore reads the text once and flags every sentence holding such a byte; with
+// `flags` set the two classify passes send the flagged sentences to a second set of class lists (lists2): the general
+// launch over them starts NEXT TO the first word round instead of after it.  The flag only routes: both kernel families
+// encode any sentence they are given.
 struct ClassifyArgs {
   const uint64_t *offs;
   uint32_t n;
@@ -668,8 +668,7 @@ struct ClassifyArgs {
   uint32_t sub_buckets;         // length sub-buckets per class (1 .. kMaxSubBuckets): the tiles of the encode kernels
                                 // are the more homogeneous the finer the sort
   // the plain scan (all null / unused without it)
-  const uint8_t *text;          // packed sentences
-  uint8_t *flags;               // n bytes, written by the count pass: 1 = the sentence holds a byte outside 0x20 .. 0x7E
+  const uint8_t *flags;         // n bytes from PlainScanKernel: 1 = the sentence holds a byte outside 0x20 .. 0x7E
   uint32_t *lists2;             // n_classes x n: the flagged sentences, by class
   uint32_t *list2_counts;       // n_classes
   uint32_t scan_max_rcap;       // classes beyond this size are never split (documents: the few there are go through one launch)
@@ -692,27 +691,36 @@ SPMX_DEVICE uint32_t nonplain_bits(uint32_t v) {
   return ((((v + 0x01010101u) | v) | ((v - 0x20202020u) & ~v)) & 0x80808080u);
 }
 
-// Flags the sentences [first, first + cnt) that hold a byte outside 0x20 .. 0x7E: bits[k >> 5] |= 1 << (k & 31).
-// rel (LDS, cnt + 1 entries): the sentences' offsets; bits (LDS): zeroed here.
-SPMX_DEVICE void plain_scan_chunk(const ClassifyArgs &a, uint32_t first, uint32_t cnt, uint64_t *rel, uint32_t *bits, int lane) {
-  for (uint32_t k = static_cast<uint32_t>(lane); k <= cnt; k += 64u) rel[k] = a.offs[first + k];
-  for (uint32_t k = static_cast<uint32_t>(lane); k < 64u * kClassifyChunk / 32u; k += 64u) bits[k] = 0u;
-  wv::sync();
-  const uint64_t t0 = rel[0], t1 = rel[cnt];
+// The plain scan proper: the batch's text read ONCE in address order -- the wavefronts of the launch march through it
+// side by side like a copy kernel (8 KB per wavefront and step; a scan chunked by classify's 1024-sentence blocks, the
+// first version, had 2560 streams 128 KB apart in flight and ran at 2.5 TB/s: profiles/r04_ab_kernel_stats.txt) --
+// and flags[k] = 1 for every sentence k that holds a byte outside 0x20 .. 0x7E (flags zeroed before the launch).  The
+// owner of a flagged byte is found by a binary search over the offsets (rare: such bytes are).
+struct PlainScanArgs {
+  const uint8_t *text;
+  uint64_t text_bytes;
+  const uint64_t *offs;         // n + 1
+  uint32_t n;
+  uint8_t *flags;               // n
+};
+SPMX_DEVICE void plain_scan_block(const PlainScanArgs &a) {
+  const int lane = wv::lane();
+  if (a.n == 0 || a.text_bytes == 0) return;
   const uint64_t base_addr = reinterpret_cast<uint64_t>(a.text);
   // 16-byte units aligned in MEMORY (a unit that holds a valid byte lies inside the buffer's pages; what it holds before
-  // t0 or beyond t1 belongs to no sentence of this chunk and is ignored)
-  const uint64_t u0 = (base_addr + t0) & ~15ull, u1 = base_addr + t1;
-  auto owner = [&](uint64_t off) -> uint32_t {       // the sentence k with rel[k] <= off < rel[k + 1] (off in [t0, t1))
-    uint32_t lo = 0, hi = cnt;                        // invariant: rel[lo] <= off < rel[hi]
+  // the first or beyond the last byte belongs to no sentence and is ignored)
+  const uint64_t u0 = base_addr & ~15ull, u1 = base_addr + a.text_bytes;
+  constexpr int kFlight = 8;                          // 16-byte units in flight per lane (8 KB per wavefront)
+  const uint64_t step = static_cast<uint64_t>(wv::grid_size()) * 1024u * kFlight;
+  auto owner = [&](uint64_t off) -> uint32_t {       // the last sentence k with offs[k] <= off (offs[0] <= off < offs[n])
+    uint32_t lo = 0, hi = a.n;
     while (hi - lo > 1u) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (rel[mid] <= off) lo = mid; else hi = mid;
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      if (a.offs[mid] <= off) lo = mid; else hi = mid;
     }
     return lo;
   };
-  constexpr int kFlight = 8;                          // 16-byte units in flight per lane (8 KB per wavefront)
-  for (uint64_t u = u0 + static_cast<uint64_t>(lane) * 16u; u < u1; u += 64u * 16u * kFlight) {
+  for (uint64_t u = u0 + static_cast<uint64_t>(wv::block_id()) * 1024u * kFlight + static_cast<uint64_t>(lane) * 16u; u < u1; u += step) {
     Q4 v[kFlight];
     uint32_t m[kFlight];
 #pragma unroll
@@ -727,6 +735,7 @@ SPMX_DEVICE void plain_scan_chunk(const ClassifyArgs &a, uint32_t first, uint32_
       any_m |= m[j];
     }
     if (any_m == 0u) continue;
+    const uint64_t t0 = a.offs[0], t1 = a.offs[a.n];
 #pragma unroll
     for (int j = 0; j < kFlight; ++j) {
       if (m[j] == 0u) continue;
@@ -738,25 +747,25 @@ SPMX_DEVICE void plain_scan_chunk(const ClassifyArgs &a, uint32_t first, uint32_
           if (z[d] & (0x80u << (8 * q))) { if (b_lo < 0) b_lo = 4 * d + q; b_hi = 4 * d + q; }
       // (a flag raised by a carry sits one byte above a true one: still inside the same or the next sentence -- a
       // sentence flagged for nothing only takes the general kernels)
-      uint64_t o_lo = uj + static_cast<uint64_t>(b_lo) - base_addr, o_hi = uj + static_cast<uint64_t>(b_hi) - base_addr;
-      if (uj + static_cast<uint64_t>(b_lo) < base_addr + t0) o_lo = t0;
+      if (uj + static_cast<uint64_t>(b_hi) < base_addr + t0) continue;                 // all of it before the first sentence
+      uint64_t o_lo = uj + static_cast<uint64_t>(b_lo) < base_addr + t0 ? t0 : uj + static_cast<uint64_t>(b_lo) - base_addr;
+      uint64_t o_hi = uj + static_cast<uint64_t>(b_hi) - base_addr;
       if (o_hi >= t1) o_hi = t1 - 1;
-      if (uj + static_cast<uint64_t>(b_hi) < base_addr + t0 || o_lo >= t1 || o_lo > o_hi) continue;
+      if (t1 == t0 || o_lo >= t1 || o_lo > o_hi) continue;
       const uint32_t k_lo = owner(o_lo), k_hi = owner(o_hi);
-      for (uint32_t k = k_lo; k <= k_hi; ++k) wv::lds_atomic_or(&bits[k >> 5], 1u << (k & 31u));
+      a.flags[k_lo] = 1;
+      a.flags[k_hi] = 1;
+      if (k_hi - k_lo <= 17u) for (uint32_t k = k_lo + 1; k < k_hi; ++k) a.flags[k] = 1;   // (more than that between two bytes of a unit: empty sentences)
     }
   }
-  wv::sync();
 }
 
-// PASS 0 counts (and scans), PASS 1 scatters.  lds: kClassifyLdsWords words (per wave).
+// PASS 0 counts, PASS 1 scatters.  lds: kClassifyLdsWords words (per wave).
 template <int PASS>
 SPMX_DEVICE void classify_block(const ClassifyArgs &a, uint32_t *lds) {
   const int lane = wv::lane();
   uint32_t *hist = lds, *start = lds + kSortKeys, *base = lds + 2 * kSortKeys;
-  uint64_t *rel = reinterpret_cast<uint64_t *>(lds + 3 * kSortKeys);
-  uint32_t *bits = lds + 3 * kSortKeys + 2 * (64 * kClassifyChunk + 2);
-  const bool scan = a.text != nullptr;
+  const bool scan = a.flags != nullptr;
   const int nsub = static_cast<int>(a.sub_buckets);
   const int n_plain_keys = static_cast<int>(a.n_classes) * nsub;
   const int n_keys = scan ? 2 * n_plain_keys : n_plain_keys;
@@ -777,22 +786,17 @@ SPMX_DEVICE void classify_block(const ClassifyArgs &a, uint32_t *lds) {
   const uint32_t chunks = (a.n + per_chunk - 1) / per_chunk;
   for (uint32_t ch = static_cast<uint32_t>(wv::block_id()); ch < chunks; ch += static_cast<uint32_t>(wv::grid_size())) {
     const uint32_t first = ch * per_chunk;
-    const uint32_t cnt = a.n - first < per_chunk ? a.n - first : per_chunk;
     for (int k = lane; k < n_keys; k += 64) hist[k] = 0;
     wv::sync();
-    if (PASS == 0 && scan) plain_scan_chunk(a, first, cnt, rel, bits, lane);
     uint32_t keys[kClassifyChunk];
 #pragma unroll
     for (int k = 0; k < kClassifyChunk; ++k) {
-      const uint32_t j = static_cast<uint32_t>(k) * 64u + static_cast<uint32_t>(lane);
-      const uint32_t i = first + j;
+      const uint32_t i = first + static_cast<uint32_t>(k) * 64u + static_cast<uint32_t>(lane);
       keys[k] = 0xFFFFFFFFu;
       if (i < a.n) {
         keys[k] = classify_key(a, a.offs[i + 1] - a.offs[i]);
         if (scan) {
-          uint32_t f;
-          if (PASS == 0) { f = (bits[j >> 5] >> (j & 31u)) & 1u; a.flags[i] = static_cast<uint8_t>(f); }
-          else f = a.flags[i];
+          const uint32_t f = a.flags[i];
           if (f && a.rcap[keys[k] / a.sub_buckets] <= a.scan_max_rcap) keys[k] += static_cast<uint32_t>(n_plain_keys);
         }
         wv::lds_atomic_add(&hist[keys[k]], 1u);

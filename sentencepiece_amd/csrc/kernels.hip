@@ -95,6 +95,7 @@ __global__ __launch_bounds__(64) void SplitWriteKernel(SplitArgs a) {
 }
 __global__ __launch_bounds__(64) void DecodeCountKernel(DecodeArgs a) { decode_block<false>(a); }
 __global__ __launch_bounds__(64) void DecodeWriteKernel(DecodeArgs a) { decode_block<true>(a); }
+__global__ __launch_bounds__(64) void PlainScanKernel(PlainScanArgs a) { plain_scan_block(a); }
 __global__ __launch_bounds__(64) void ClassifyCountKernel(ClassifyArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[kClassifyLdsWords];
   classify_block<0>(a, lds);
@@ -221,6 +222,11 @@ hipError_t LaunchSplit(bool write, const SplitArgs &a, int grid, hipStream_t str
 hipError_t LaunchDecode(bool write, const DecodeArgs &a, int grid, hipStream_t stream) {
   if (write) hipLaunchKernelGGL(DecodeWriteKernel, dim3(grid), dim3(64), 0, stream, a);
   else hipLaunchKernelGGL(DecodeCountKernel, dim3(grid), dim3(64), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t LaunchPlainScan(const PlainScanArgs &a, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL(PlainScanKernel, dim3(grid), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
 

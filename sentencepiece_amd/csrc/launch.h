@@ -50,6 +50,7 @@ hipError_t LaunchNormalize(bool write, const NormalizeArgs &a, int grid, uint32_
 hipError_t LaunchNBest(bool wide, const NBestArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchSplit(bool write, const SplitArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchDecode(bool write, const DecodeArgs &a, int grid, hipStream_t stream);
+hipError_t LaunchPlainScan(const PlainScanArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchClassify(const ClassifyArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchScan(const ScanArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchCompact(const CompactArgs &a, int grid, hipStream_t stream);

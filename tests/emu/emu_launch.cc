@@ -101,6 +101,10 @@ hipError_t LaunchDecode(bool write, const DecodeArgs &a, int grid, hipStream_t) 
   else RunGrid(grid, 1, 0, [&](unsigned char *) { decode_block<false>(a); });
   return hipSuccess;
 }
+hipError_t LaunchPlainScan(const PlainScanArgs &a, int grid, hipStream_t) {
+  RunGrid(grid, 1, 0, [&](unsigned char *) { plain_scan_block(a); });
+  return hipSuccess;
+}
 hipError_t LaunchClassify(const ClassifyArgs &a, int grid, hipStream_t) {
   RunGrid(grid, 1, kClassifyLdsWords * 4, [&](unsigned char *s) { classify_block<0>(a, reinterpret_cast<uint32_t *>(s)); });
   RunGrid(grid, 1, kClassifyLdsWords * 4, [&](unsigned char *s) { classify_block<1>(a, reinterpret_cast<uint32_t *>(s)); });
