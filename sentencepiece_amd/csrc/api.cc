@@ -943,29 +943,25 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         const bool dp = mode == 3;
         EncodeArgs wa = a;
         const int waves = dp ? 8 : h->word_waves;
-        // (the second round's lists are keyed by remaining length, kernels_word.h AgainBucket: kMaxClasses of them)
-        const int nlist = mode == 2 ? static_cast<int>(kAgainBuckets) : ncls;
         uint64_t total = 0;
-        for (int c = 0; c < nlist; ++c) total += known[c];
+        for (int c = 0; c < ncls; ++c) total += known[c];
         if (total == 0) return kOk;
         uint64_t grid = static_cast<uint64_t>(h->n_cu - h->reserve_cus) * static_cast<uint64_t>(dp ? 1 : h->word_wgs);
         if (grid * waves * 64 > total) grid = (total + waves * 64 - 1) / (waves * 64);
         if (grid < 1) grid = 1;
         const uint64_t n_waves = grid * waves;
-        wa.n_classes = static_cast<uint32_t>(nlist);
-        wa.n_real_classes = static_cast<uint32_t>(ncls);
-        for (int c = 0; c < ncls; ++c) wa.real_rcap[c] = rcaps[c];
+        wa.n_classes = static_cast<uint32_t>(ncls);
         uint32_t tile_base = 0;
-        for (int c = nlist - 1; c >= 0; --c) {
+        for (int c = ncls - 1; c >= 0; --c) {
           StreamClass &sc = wa.cls[c];
           sc = StreamClass{};
-          sc.rcap = c < ncls ? rcaps[c] : rcaps[ncls - 1];
+          sc.rcap = rcaps[c];
           if (known[c] == 0) continue;
           uint64_t tw = (static_cast<uint64_t>(known[c]) + n_waves - 1) / n_waves;
           if (tw > 64) tw = 64;
           if (tw < 1) tw = 1;
           sc.lane_shift = 6;
-          sc.general = (mode != 2 && ((uni_class[c] && cls[c].rcap > kMaxStagedRaw) || cls[c].rcap > h->main_max_raw)) ? 1u : 0u;   // documents pass through
+          sc.general = ((uni_class[c] && cls[c].rcap > kMaxStagedRaw) || cls[c].rcap > h->main_max_raw) ? 1u : 0u;   // documents pass through
           sc.count = known[c];
           sc.tw = static_cast<uint32_t>(tw);
           sc.main_tiles = static_cast<uint32_t>((static_cast<uint64_t>(known[c]) + tw - 1) / tw);
@@ -1012,7 +1008,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         FORKED_HIP_OR_RETURN(hipMemsetAsync(ws->d_dyn_tag.p, 0, static_cast<size_t>(h->dyn_slots) * sizeof(unsigned long long), stream));
         FORKED_OR_RETURN(word_pass(1, kSlotWord, 3, left_lists[0], ws->d_ctrl->left_counts[0], left_lists[1], ws->d_ctrl->left_counts[1]));
         FORKED_OR_RETURN(read_counts());
-        for (int c = 0; c < kMaxClasses; ++c) { again_counts[c] = ws->h_ctrl->left_counts[0][c]; again_total += again_counts[c]; }
+        for (int c = 0; c < ncls; ++c) { again_counts[c] = ws->h_ctrl->left_counts[0][c]; again_total += again_counts[c]; }
         again_words = ws->h_ctrl->dyn_count < h->dyn_list_cap ? ws->h_ctrl->dyn_count : h->dyn_list_cap;
         left_at = 1;
         if (again_total > 0) {
@@ -1026,7 +1022,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
           }
           // round 2 over what round 1 kept for it; what it cannot take either (a margin that does not hold, a word of
           // more than 8 pieces) is APPENDED to the lists of what round 1 gave up for good: one tail launch takes both
-          for (int c = 0; c < kMaxClasses; ++c) known[c] = again_counts[c];
+          for (int c = 0; c < ncls; ++c) known[c] = again_counts[c];
           a.lists = left_lists[0];
           FORKED_OR_RETURN(word_pass(2, kSlotWord2, 4, left_lists[1], ws->d_ctrl->left_counts[1], nullptr, nullptr));
           FORKED_OR_RETURN(read_counts());

@@ -109,8 +109,6 @@ struct EncodeArgs {
   uint32_t dyn_mask;
   uint32_t dyn_cap;             // entries dyn_list holds
   U4 *resume;                   // per sentence the first round keeps for the second: {position, ids written, bound, 0}
-  uint32_t n_real_classes;      // (second word round, whose classes are remaining-length buckets) the length classes ...
-  uint32_t real_rcap[kMaxClasses];   // ... and their raw capacities: where its leftovers go
   uint32_t ids16;               // the word kernels write 16-bit ids into their arena slots (vocabularies of up to 65536 pieces)
   // ---- sentence-per-wave launch (BPE models that are not word-wise; kernels_bpe.h) ----
   const uint32_t *list;         // sentence indices of this length class
@@ -728,9 +726,7 @@ SPMX_DEVICE void plain_scan_block(const PlainScanArgs &a) {
 #pragma unroll
     for (int j = 0; j < kFlight; ++j) {
       const uint64_t uj = u + static_cast<uint64_t>(j) * 1024u;
-      // (an offset from the kernel's text pointer, not a bare address: a global load, not a flat one)
-      v[j] = uj < u1 ? *reinterpret_cast<const Q4 *>(a.text + static_cast<long long>(uj - base_addr))
-                     : Q4{0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u};
+      v[j] = uj < u1 ? *reinterpret_cast<const Q4 *>(uj) : Q4{0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u};
     }
     uint32_t any_m = 0;
 #pragma unroll

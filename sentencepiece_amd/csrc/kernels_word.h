@@ -72,11 +72,6 @@ constexpr uint32_t kDynProbes = 24;                             // slots tried b
 // word modes of uni_word_lane: plain; collecting (first round of a call that has a call-local memo); looking the
 // call-local memo up (second round)
 enum { kWmPlain = 0, kWmCollect = 1, kWmDyn = 2 };
-// lists of the second round: by the bytes left of the sentence from where it is taken up again
-constexpr uint32_t kAgainBuckets = 8;                           // (= kMaxClasses: the lists of one set)
-SPMX_HD inline uint32_t AgainBucket(uint32_t left) {
-  return left <= 16u ? 0u : left <= 32u ? 1u : left <= 48u ? 2u : left <= 64u ? 3u : left <= 96u ? 4u : left <= 128u ? 5u : left <= 192u ? 6u : 7u;
-}
 SPMX_DEVICE unsigned long long DynTag(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
   const unsigned long long t = (static_cast<unsigned long long>(HashWordKey(k0, k1, k2, k3)) << 32) | HashWord(k0, k1, k2, k3);
   return t | 1ull;                                              // (0 means "free")
@@ -585,23 +580,8 @@ SPMX_DEVICE void encode_word_block_as(const EncodeArgs &a, unsigned char *smem) 
         a.resume[sid] = U4{static_cast<uint32_t>(rs.p), static_cast<uint32_t>(rs.n), wv::float_to_bits(rs.B), 0u};
         a.tmp_off[sid] = static_cast<unsigned long long>(slot - d.n_prefix - a.arena);
       }
-      // The second round's lists are keyed by WHAT IS LEFT of the sentence from the word it is taken up at, not by its
-      // length: a tile of the second round lasts as long as its lane with the most text to go, and sentences of one
-      // length class stand anywhere between their first and their last word (w16: round 2 3.1 -> ... ms, section 4.0).
-      const uint32_t bucket = again ? AgainBucket(static_cast<uint32_t>(len - rs.p)) : 0u;
-      for (uint32_t b = 0; b < kAgainBuckets; ++b) {
-        const bool m = again && bucket == b;
-        append_lanes(wv::ballot(m), m, sid, a.left_lists + static_cast<uint64_t>(b) * a.n, &a.left_counts[b], lane);
-      }
+      append_lanes(wv::ballot(again), again, sid, a.left_lists + static_cast<uint64_t>(c) * a.n, &a.left_counts[c], lane);
       append_lanes(wv::ballot(gone), gone, sid, a.left2_lists + static_cast<uint64_t>(c) * a.n, &a.left2_counts[c], lane);
-    } else if (MODE == kWmDyn) {
-      // (the second round's "classes" are the buckets above: what it leaves goes to the lists of the sentences' real classes)
-      uint32_t rc = a.n_real_classes - 1u;
-      for (int k = static_cast<int>(a.n_real_classes) - 2; k >= 0; --k) if (l64 <= a.real_rcap[k]) rc = static_cast<uint32_t>(k);
-      for (uint32_t k = 0; k < a.n_real_classes; ++k) {
-        const bool m = left && rc == k;
-        append_lanes(wv::ballot(m), m, sid, a.left_lists + static_cast<uint64_t>(k) * a.n, &a.left_counts[k], lane);
-      }
     } else {
       append_lanes(wv::ballot(left), left, sid, a.left_lists + static_cast<uint64_t>(c) * a.n, &a.left_counts[c], lane);
     }
