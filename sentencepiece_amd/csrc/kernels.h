@@ -726,7 +726,9 @@ SPMX_DEVICE void plain_scan_block(const PlainScanArgs &a) {
 #pragma unroll
     for (int j = 0; j < kFlight; ++j) {
       const uint64_t uj = u + static_cast<uint64_t>(j) * 1024u;
-      v[j] = uj < u1 ? *reinterpret_cast<const Q4 *>(uj) : Q4{0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u};
+      // (an offset from the kernel's text pointer, not a bare address: a global load, not a flat one)
+      v[j] = uj < u1 ? *reinterpret_cast<const Q4 *>(a.text + static_cast<long long>(uj - base_addr))
+                     : Q4{0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u};
     }
     uint32_t any_m = 0;
 #pragma unroll
