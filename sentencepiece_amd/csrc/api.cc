@@ -461,9 +461,9 @@ int RunClassify(spmx_handle *h, Workspace *ws, const uint64_t *d_offsets, uint32
   if (d_text && gen_lists) {
     HIP_OR_RETURN(h, hipMemsetAsync(ws->d_flags.p, 0, n32, stream));
     PlainScanArgs pa{d_text, text_bytes, d_offsets, n32, ws->d_flags.p};
-    uint64_t g = (text_bytes + 8191) / 8192;                      // a wavefront takes 8 KB per step
-    const uint64_t most = static_cast<uint64_t>(h->n_cu) * 16u;
-    if (g > most) g = most;
+    // a workgroup (four wavefronts) takes 16 KB per step; one step each up to 2^20 workgroups (16 GB of text)
+    uint64_t g = (text_bytes + 16383) / 16384;
+    if (g > (1u << 20)) g = 1u << 20;
     if (g < 1) g = 1;
     HIP_OR_RETURN(h, LaunchPlainScan(pa, static_cast<int>(g), stream));
     ca.flags = ws->d_flags.p; ca.lists2 = gen_lists; ca.list2_counts = ws->d_ctrl->gen_counts;

@@ -692,10 +692,12 @@ SPMX_DEVICE uint32_t nonplain_bits(uint32_t v) {
 }
 
 // The plain scan proper: the batch's text read ONCE in address order -- the wavefronts of the launch march through it
-// side by side like a copy kernel (8 KB per wavefront and step; a scan chunked by classify's 1024-sentence blocks, the
+// side by side like a copy kernel (4 KB per wavefront and step, a wavefront a step when the text is large: the hardware's
+// own dispatch order keeps the reads in address order; a scan chunked by classify's 1024-sentence blocks, the
 // first version, had 2560 streams 128 KB apart in flight and ran at 2.5 TB/s: profiles/r04_ab_kernel_stats.txt) --
 // and flags[k] = 1 for every sentence k that holds a byte outside 0x20 .. 0x7E (flags zeroed before the launch).  The
 // owner of a flagged byte is found by a binary search over the offsets (rare: such bytes are).
+constexpr int kPlainScanFlight = 4;                   // a wavefront takes 4 KB per step: 4 units of 16 bytes per lane
 struct PlainScanArgs {
   const uint8_t *text;
   uint64_t text_bytes;
@@ -710,8 +712,10 @@ SPMX_DEVICE void plain_scan_block(const PlainScanArgs &a) {
   // 16-byte units aligned in MEMORY (a unit that holds a valid byte lies inside the buffer's pages; what it holds before
   // the first or beyond the last byte belongs to no sentence and is ignored)
   const uint64_t u0 = base_addr & ~15ull, u1 = base_addr + a.text_bytes;
-  constexpr int kFlight = 8;                          // 16-byte units in flight per lane (8 KB per wavefront)
-  const uint64_t step = static_cast<uint64_t>(wv::grid_size()) * 1024u * kFlight;
+  constexpr int kFlight = kPlainScanFlight;           // 16-byte units in flight per lane
+  const uint64_t n_waves = static_cast<uint64_t>(wv::grid_size()) * static_cast<uint64_t>(wv::waves_per_block());
+  const uint64_t my_wave = static_cast<uint64_t>(wv::block_id()) * static_cast<uint64_t>(wv::waves_per_block()) + static_cast<uint64_t>(wv::wave_in_block());
+  const uint64_t step = n_waves * 1024u * kFlight;
   auto owner = [&](uint64_t off) -> uint32_t {       // the last sentence k with offs[k] <= off (offs[0] <= off < offs[n])
     uint32_t lo = 0, hi = a.n;
     while (hi - lo > 1u) {
@@ -720,7 +724,7 @@ SPMX_DEVICE void plain_scan_block(const PlainScanArgs &a) {
     }
     return lo;
   };
-  for (uint64_t u = u0 + static_cast<uint64_t>(wv::block_id()) * 1024u * kFlight + static_cast<uint64_t>(lane) * 16u; u < u1; u += step) {
+  for (uint64_t u = u0 + my_wave * 1024u * kFlight + static_cast<uint64_t>(lane) * 16u; u < u1; u += step) {
     Q4 v[kFlight];
     uint32_t m[kFlight];
 #pragma unroll

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64) void SplitWriteKernel(SplitArgs a) {
 }
 __global__ __launch_bounds__(64) void DecodeCountKernel(DecodeArgs a) { decode_block<false>(a); }
 __global__ __launch_bounds__(64) void DecodeWriteKernel(DecodeArgs a) { decode_block<true>(a); }
-__global__ __launch_bounds__(64) void PlainScanKernel(PlainScanArgs a) { plain_scan_block(a); }
+__global__ __launch_bounds__(256) void PlainScanKernel(PlainScanArgs a) { plain_scan_block(a); }
 __global__ __launch_bounds__(64) void ClassifyCountKernel(ClassifyArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[kClassifyLdsWords];
   classify_block<0>(a, lds);
@@ -226,7 +226,7 @@ hipError_t LaunchDecode(bool write, const DecodeArgs &a, int grid, hipStream_t s
 }
 
 hipError_t LaunchPlainScan(const PlainScanArgs &a, int grid, hipStream_t stream) {
-  hipLaunchKernelGGL(PlainScanKernel, dim3(grid), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL(PlainScanKernel, dim3(grid), dim3(256), 0, stream, a);      // (four wavefronts per workgroup)
   return hipGetLastError();
 }
 

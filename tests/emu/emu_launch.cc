@@ -102,7 +102,7 @@ hipError_t LaunchDecode(bool write, const DecodeArgs &a, int grid, hipStream_t) 
   return hipSuccess;
 }
 hipError_t LaunchPlainScan(const PlainScanArgs &a, int grid, hipStream_t) {
-  RunGrid(grid, 1, 0, [&](unsigned char *) { plain_scan_block(a); });
+  RunGrid(grid, 4, 0, [&](unsigned char *) { plain_scan_block(a); });
   return hipSuccess;
 }
 hipError_t LaunchClassify(const ClassifyArgs &a, int grid, hipStream_t) {
