@@ -467,8 +467,8 @@ def main():
             p2 = sp2.LastProfile()
             out["long_piece_model"] = {"model": name, "value": (len(o2) - 1) * args.steps / d2, "unit": "sentences/s",
                                        "ms_per_step": d2 / args.steps * 1e3, "mean_bytes": len(t2) / (len(o2) - 1),
-                                       "kernel": max(p2["classes"], key=lambda c: c["kernel_ms"])["kernel"],
-                                       "kernel_ms": max(c["kernel_ms"] for c in p2["classes"]),
+                                       "kernel": max(p2["classes"], key=lambda c: c["bytes"] if c["kernel"] else 0)["kernel"],
+                                       "kernel_ms": max(p2["classes"], key=lambda c: c["bytes"] if c["kernel"] else 0)["kernel_ms"],
                                        "kernels_ms": {c["kernel"]: round(c["kernel_ms"], 4) for c in p2["classes"] if c["kernel"]},
                                        "vs_headline": ((len(o2) - 1) * args.steps / d2) / out["value"],
                                        "what": "the C2 recipe with words of up to 16 letters: longest piece 17 bytes, score ring of 18 entries"}
