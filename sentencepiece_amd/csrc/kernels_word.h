@@ -85,11 +85,11 @@ SPMX_HD inline uint32_t WordLdsBytes(uint32_t waves, bool dp) { return kWordLdsS
 struct __attribute__((packed, aligned(1))) Q4U { uint32_t x, y, z, w; };
 struct __attribute__((packed, aligned(1))) U1U { uint32_t x; };
 
-// bit 7 of every byte of v that equals 0x20 -- exact for the LOWEST such byte, which is all that is used
-// (a borrow can only flag the byte above a true one)
-SPMX_DEVICE uint32_t space_bits(uint32_t v) {
+// bit 7 of every byte of v that equals 0x20, exact for every byte (no borrow between bytes): the word loop asks for the
+// first AND the second 0x20 of its window
+SPMX_DEVICE uint32_t space_flags(uint32_t v) {
   const uint32_t x = v ^ 0x20202020u;
-  return (x - 0x01010101u) & ~x & 0x80808080u;
+  return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
 }
 // A memo KEY is the word's L raw bytes padded with 0x20 to 12 / 16 bytes.  A word holds no 0x20 (it ends at the first
 // one), so the padding can be told from every byte a word may consist of -- 0x00 included, which the reference keeps
@@ -193,6 +193,7 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
   bool prev_unk = false;                           // the last piece emitted was unknown (a run of them is ONE id, :609-613)
   const bool bf = (d.flags & kNfByteFallback) != 0;
   Q4U w{0, 0, 0, 0};
+  int wvalid = 16;                                 // bytes of `w` that are text (what a shift brought in behind them is zero)
   if (active) w = *reinterpret_cast<const Q4U *>(text + p);
 #if SPMX_EXP & (8 | 32)
   uint32_t exp_acc = 0;
@@ -263,17 +264,33 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
     ++steps;
     const bool run = active && !stalled;
     // ---- the word that starts at p: its length = the distance to the next 0x20 (or to the end of the sentence) ----
-    const uint32_t z0 = space_bits(w.x), z1 = space_bits(w.y), z2 = space_bits(w.z), z3 = space_bits(w.w);
-    const int fa = wv::ffs64(static_cast<uint64_t>(z0) | static_cast<uint64_t>(z1) << 32);
-    const int fb = wv::ffs64(static_cast<uint64_t>(z2) | static_cast<uint64_t>(z3) << 32);
+    const uint32_t z0 = space_flags(w.x), z1 = space_flags(w.y), z2 = space_flags(w.z), z3 = space_flags(w.w);
+    const uint64_t zlo = static_cast<uint64_t>(z0) | static_cast<uint64_t>(z1) << 32, zhi = static_cast<uint64_t>(z2) | static_cast<uint64_t>(z3) << 32;
+    const int fa = wv::ffs64(zlo);
+    const int fb = wv::ffs64(zhi);
     int L = fa ? (fa - 1) >> 3 : (fb ? 8 + ((fb - 1) >> 3) : 16);      // 16: no space among the 16 bytes
     const int rem = len - p;
     if (L > rem) L = rem;
-    // ---- where the next word starts; its text is asked for now and used in the next iteration ----
+    // ---- where the next word starts; its text is made ready now and used in the next iteration.  The 16 bytes the lane
+    // holds usually hold the next word too (a word and its space are 5.7 bytes on average): when they hold ALL of it --
+    // another 0x20 behind this word's, or the sentence's end -- the window is shifted down in registers instead of asked
+    // for again; a gather costs by the lane (section 4.0 of DESIGN.md), and this takes more than half the lanes out of it. ----
     const int pn = p + L + 1;
     const bool more = run && pn < len;
+    const int held = wvalid - (L + 1);                // bytes of the window behind this word and its space
+    const bool second = fa ? ((zlo & (zlo - 1ull)) != 0ull || zhi != 0ull) : ((zhi & (zhi - 1ull)) != 0ull);
+    const bool reuse = more && held > 0 && (second || pn + held >= len);
     Q4U wn = w;
-    if (more) wn = *reinterpret_cast<const Q4U *>(text + pn);
+    int wvn = wvalid;
+    if (reuse) {
+      const uint32_t sh = static_cast<uint32_t>(L + 1);        // 1 .. 15 bytes
+      uint32_t a0 = w.x, a1 = w.y, a2 = w.z, a3 = w.w;
+      if (sh & 8u) { a0 = a2; a1 = a3; a2 = 0u; a3 = 0u; }
+      if (sh & 4u) { a0 = a1; a1 = a2; a2 = a3; a3 = 0u; }
+      wn = Q4U{wv::alignbyte(a1, a0, sh), wv::alignbyte(a2, a1, sh), wv::alignbyte(a3, a2, sh), wv::alignbyte(0u, a3, sh)};
+      wvn = held;
+    }
+    if (more && !reuse) { wn = *reinterpret_cast<const Q4U *>(text + pn); wvn = 16; }
 #if SPMX_EXP & 8      // (experiment build: what ONE more 64-lane text gather per iteration costs)
     if (more) { const Q4U x = *reinterpret_cast<const Q4U *>(text + (pn + 160 < len ? pn + 160 : pn)); exp_acc ^= x.x ^ x.y ^ x.z ^ x.w; }
 #endif
@@ -457,7 +474,7 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
       }
     }
     if (run && !more && !(DP && stalled)) active = false;     // the sentence is done
-    if (run) { p = pn; w = wn; }
+    if (run) { p = pn; w = wn; wvalid = wvn; }
   }
   *n_steps = steps;
 #if SPMX_EXP & (8 | 32)

@@ -66,6 +66,8 @@ SPMX_DEVICE unsigned long long atomic_cas(unsigned long long *p, unsigned long l
 SPMX_DEVICE uint32_t atomic_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 
+// the 64-bit value hi:lo shifted right by n & 3 bytes, its low 32 bits (v_alignbyte_b32)
+SPMX_DEVICE uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t n) { return __builtin_amdgcn_alignbyte(hi, lo, n); }
 SPMX_DEVICE unsigned long long clock() { return __builtin_amdgcn_s_memtime(); }   // shader cycles
 
 SPMX_DEVICE int popc64(uint64_t x) { return __popcll(x); }
