@@ -1048,6 +1048,9 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       // The word rounds pay on text that is mostly plain ASCII words: a handle remembers when a batch they were given
       // went almost entirely on to the general kernels and leaves them out of its next few calls (see word_ok above).
       if (n >= 4096 && eligible >= 4096 && leftover * 8 > eligible * 7) h->word_backoff.store(15, std::memory_order_relaxed);
+      // ... and when most of the batch was set aside by the plain scan (CJK text): the scan, the word rounds over the
+      // plain minority and their tail only add to the one general launch that does the work
+      if (scanned && n >= 4096 && (gen_total * 8 > static_cast<uint64_t>(n) * 5)) h->word_backoff.store(15, std::memory_order_relaxed);
       // ---- the tail: what the word rounds left ----
       FORKED_OR_RETURN(general_pass(left_lists[left_at], ws->d_ctrl->left_counts[left_at], known, true));
     } else {

@@ -700,18 +700,22 @@ SPMX_DEVICE uint32_t nonplain_bits(uint32_t v) {
 constexpr int kPlainScanFlight = 4;                   // a wavefront takes 4 KB per step: 4 units of 16 bytes per lane
 struct PlainScanArgs {
   const uint8_t *text;
-  uint64_t text_bytes;
+  uint64_t text_bytes;          // (only sizes the launch: the kernel reads [offs[0], offs[n]))
   const uint64_t *offs;         // n + 1
   uint32_t n;
   uint8_t *flags;               // n
 };
 SPMX_DEVICE void plain_scan_block(const PlainScanArgs &a) {
   const int lane = wv::lane();
-  if (a.n == 0 || a.text_bytes == 0) return;
+  if (a.n == 0) return;
   const uint64_t base_addr = reinterpret_cast<uint64_t>(a.text);
-  // 16-byte units aligned in MEMORY (a unit that holds a valid byte lies inside the buffer's pages; what it holds before
-  // the first or beyond the last byte belongs to no sentence and is ignored)
-  const uint64_t u0 = base_addr & ~15ull, u1 = base_addr + a.text_bytes;
+  // What is read is the text of the batch's sentences, [offs[0], offs[n]) from the text pointer -- the pointer itself may
+  // lie before the buffer (the host forms rebase it by offs[0]).  16-byte units aligned in MEMORY: a unit that holds a
+  // sentence's byte lies inside the buffer's pages; what it holds before the first or beyond the last such byte belongs
+  // to no sentence and is ignored.
+  const uint64_t t0 = a.offs[0], t1 = a.offs[a.n];
+  if (t1 <= t0) return;
+  const uint64_t u0 = (base_addr + t0) & ~15ull, u1 = base_addr + t1;
   constexpr int kFlight = kPlainScanFlight;           // 16-byte units in flight per lane
   const uint64_t n_waves = static_cast<uint64_t>(wv::grid_size()) * static_cast<uint64_t>(wv::waves_per_block());
   const uint64_t my_wave = static_cast<uint64_t>(wv::block_id()) * static_cast<uint64_t>(wv::waves_per_block()) + static_cast<uint64_t>(wv::wave_in_block());
@@ -741,7 +745,6 @@ SPMX_DEVICE void plain_scan_block(const PlainScanArgs &a) {
       any_m |= m[j];
     }
     if (any_m == 0u) continue;
-    const uint64_t t0 = a.offs[0], t1 = a.offs[a.n];
 #pragma unroll
     for (int j = 0; j < kFlight; ++j) {
       if (m[j] == 0u) continue;
