@@ -441,6 +441,27 @@ def main():
                          "phase_cycles": cls.get("phase_cycles"), "path": prof[-1]["path"],
                          "pipeline_ms": sum(p["total_ms"] for p in prof) / len(prof)},
         }
+        if world == 1 and out["roofline"]["beside"] is not None and not dry:
+            # the dominant kernel's duration when nothing shares the CUs with it: one profiled step on a second handle that
+            # runs the general launch BEFORE the word rounds (SPMX_NO_OVERLAP=1, read at load)
+            try:
+                os.environ["SPMX_NO_OVERLAP"] = "1"
+                sp1 = SentencePieceProcessor(model_proto=blob, device=local)
+                os.environ.pop("SPMX_NO_OVERLAP", None)
+                sp1.SetProfiling(True)
+                alone = []
+                for _ in range(3):
+                    sp1.EncodeDevice(d_text, d_offs, d_ids, d_io)
+                    alone.append([c["kernel_ms"] for c in sp1.LastProfile()["classes"] if c["kernel"] == kname][0])
+                sync()
+                a_ms = sorted(alone)[1]
+                out["roofline"]["alone"] = {"kernel_ms": a_ms, "achieved": cls["bytes"] / (a_ms * 1e-3) / 1e9,
+                                            "frac": cls["bytes"] / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                            "what": "the same kernel with the general launch run before it instead of beside it"}
+                del sp1
+            except Exception as e:
+                os.environ.pop("SPMX_NO_OVERLAP", None)
+                out["roofline"]["alone"] = {"failed": repr(e)[:200]}
         if world > 1:
             for mode, (mdt, _) in results.items():
                 key = mode.replace("ids:", "")
