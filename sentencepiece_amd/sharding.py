@@ -65,7 +65,9 @@ class IdGatherer:
         # "p2p_exact": every rank sends exactly its `total` ids (and its per-sentence id COUNTS as int32, not n + 1
         # 64-bit offsets) straight to every peer -- no padding to the largest rank's capacity.  The receivers must know the
         # sizes before they post their receives: two integers per rank, exchanged host-side over a gloo group of its
-        # own (the host knows its own total: EncodeDevice returns it), which does not queue behind the gathers in flight.
+        # own (the host knows its own total: EncodeDevice returns it), which does not queue behind the gathers in flight --
+        # ASYNCHRONOUSLY: the sizes of batch k travel while batch k + 1 is encoded, and batch k's transfers are posted at
+        # the next call (_call_exact / _post_exact), so no call waits for a host round trip.
         self._cpu_group = None
         if algo == "p2p_exact" and dist.get_backend(group) != "gloo":
             # (construction is collective over the ranks of `group`: the side channel spans exactly those)
@@ -79,6 +81,7 @@ class IdGatherer:
         self._slots = []          # per slot: dict(pad, out, opad, oout, tot_in, tot, n_in, n, work)
         self._k = 0               # gathers issued
         self._last = None
+        self._pending = None      # (p2p_exact) the slot whose batch is staged and not yet posted
 
     def _all_gather(self, out, inp):
         if out.dtype == torch.int16:      # no 16-bit integer type in NCCL / gloo: an all-gather only moves bytes
@@ -125,36 +128,61 @@ class IdGatherer:
             self._slots.append(sl)
 
     def _call_exact(self, ids, total, id_offsets):
-        dist, world, rank = self.dist, self.world, self.rank
+        """Two steps per batch, one call apart.  STAGE (now): the rank's ids and per-sentence counts are copied to the
+        slot's send buffers and the two integers every receiver needs -- {total, sentences} of every rank -- start
+        travelling over the side channel ASYNCHRONOUSLY.  POST (at the next call, or at wait() / result()): the sizes of
+        the batch staged one call ago have long arrived (a whole encode lies in between), so reading them costs no round
+        trip; the exact-size sends and receives of that batch are posted as one batch.  The host-side exchange is thus
+        off the critical path of every batch (round 3 waited for it inside the call)."""
+        dist = self.dist
         n = id_offsets.numel() - 1 if id_offsets is not None else 0
-        meta = torch.tensor([total, n], dtype=torch.int64)
-        metas = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
-        dist.all_gather(metas, meta, group=self._cpu_group if self._cpu_group is not None else self.group)
-        tots = [int(m[0]) for m in metas]
-        ns = [int(m[1]) for m in metas]
         wire = self.wire or ids.dtype
         self._dtype = ids.dtype
         if not self._slots or len(self._slots) != self.depth or "xout" not in self._slots[0]:
-            self._slots = [dict(work=[], xout=None, xcnt=None, xsend=None, xcsend=None) for _ in range(self.depth)]
+            self._slots = [dict(work=[], xout=None, xcnt=None, xsend=None, xcsend=None, staged=None) for _ in range(self.depth)]
         sl = self._slots[self._k % self.depth]
+        if sl.get("staged") is not None:          # (depth 1: the slot's own batch is still waiting to be posted)
+            self._post_exact(sl)
         for w in sl["work"]:
             w.wait()
-        sum_t, sum_n = sum(tots), sum(ns)
-        if sl["xout"] is None or sl["xout"].numel() < sum_t or sl["xout"].dtype != wire:
-            sl["xout"] = torch.empty(max(sum_t + sum_t // 8, 1), dtype=wire, device=self.device)
+        sl["work"] = []
         if sl["xsend"] is None or sl["xsend"].numel() < total or sl["xsend"].dtype != wire:
             sl["xsend"] = torch.empty(max(total + total // 8, 1), dtype=wire, device=self.device)
         sl["xsend"][:total].copy_(ids[:total])
+        csend = None
+        if id_offsets is not None:
+            csend = (id_offsets[1:] - id_offsets[:-1]).to(torch.int32)
+        sl["xcsend"] = csend
+        meta = torch.tensor([total, n], dtype=torch.int64)
+        metas = [torch.zeros(2, dtype=torch.int64) for _ in range(self.world)]
+        mw = dist.all_gather(metas, meta, group=self._cpu_group if self._cpu_group is not None else self.group, async_op=True)
+        sl["staged"] = (mw, metas, meta, total, n, id_offsets is not None, id_offsets.dtype if id_offsets is not None else None)
+        prev = self._pending
+        self._pending = sl
+        if prev is not None and prev is not sl and prev.get("staged") is not None:
+            self._post_exact(prev)                # the batch staged one call ago
+        self._last = sl
+        self._k += 1
+
+    def _post_exact(self, sl):
+        dist, world, rank = self.dist, self.world, self.rank
+        mw, metas, _meta, total, n, has_offs, odtype = sl["staged"]
+        sl["staged"] = None
+        mw.wait()
+        tots = [int(m[0]) for m in metas]
+        ns = [int(m[1]) for m in metas]
+        wire = sl["xsend"].dtype
+        sum_t, sum_n = sum(tots), sum(ns)
+        if sl["xout"] is None or sl["xout"].numel() < sum_t or sl["xout"].dtype != wire:
+            sl["xout"] = torch.empty(max(sum_t + sum_t // 8, 1), dtype=wire, device=self.device)
         t_base = np.concatenate([[0], np.cumsum(tots)]).astype(np.int64)
         n_base = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
         send = sl["xsend"][:total]
         sl["xout"][int(t_base[rank]):int(t_base[rank + 1])].copy_(send)
-        csend = None
-        if id_offsets is not None:
+        csend = sl["xcsend"] if has_offs else None
+        if has_offs:
             if sl["xcnt"] is None or sl["xcnt"].numel() < sum_n:
                 sl["xcnt"] = torch.empty(max(sum_n + sum_n // 8, 1), dtype=torch.int32, device=self.device)
-            csend = (id_offsets[1:] - id_offsets[:-1]).to(torch.int32)
-            sl["xcsend"] = csend
             sl["xcnt"][int(n_base[rank]):int(n_base[rank + 1])].copy_(csend)
 
         def as_bytes(t):
@@ -172,9 +200,7 @@ class IdGatherer:
                 if ns[frm]:
                     ops.append(dist.P2POp(dist.irecv, sl["xcnt"][int(n_base[frm]):int(n_base[frm + 1])], self._peer(frm), self.group))
         sl["work"] = [_Works(dist.batch_isend_irecv(ops))] if ops else []
-        sl["exact"] = (tots, ns, t_base, n_base, id_offsets is not None, id_offsets.dtype if id_offsets is not None else None)
-        self._last = sl
-        self._k += 1
+        sl["exact"] = (tots, ns, t_base, n_base, has_offs, odtype)
 
     def __call__(self, ids, total, id_offsets=None):
         total = int(total)
@@ -203,13 +229,23 @@ class IdGatherer:
         self._last = sl
         self._k += 1
 
+    def _flush_exact(self):
+        for sl in self._slots:
+            if isinstance(sl, dict) and sl.get("staged") is not None:
+                self._post_exact(sl)
+        self._pending = None
+
     def wait(self):
+        if self.algo == "p2p_exact" and self.world > 1:
+            self._flush_exact()
         for sl in self._slots:
             for w in sl["work"]:
                 w.wait()
             sl["work"] = []
 
     def result(self):
+        if self.algo == "p2p_exact" and self.world > 1:
+            self._flush_exact()
         sl = self._last
         for w in sl["work"]:
             w.wait()
