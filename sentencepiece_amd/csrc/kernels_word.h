@@ -364,17 +364,20 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
     }
     // ---- (second round) the call-local memo: words collected by the first round, segmented by word_resolve_block ----
     bool hitd = false;
-    uint32_t dslot = 0, dn = 0;
+    uint32_t dn = 0;
+    U4 dia{0, 0, 0, 0}, dib{0, 0, 0, 0};            // the word's ids
     if (MODE == kWmDyn && wv::any(word && !hit16 && !hit32 && !lng)) {
       if (word && !hit16 && !hit32 && !lng) {
         const unsigned long long tag = DynTag(k0, k1, k2, k3);
         uint32_t sl = static_cast<uint32_t>(tag >> 32) & a.dyn_mask;
         for (uint32_t t = 0; t < kDynProbes; ++t) {
+          // the slot's tag AND its 64-byte entry are asked for together: one round trip per probe (a lane's wait is the
+          // whole wavefront's; round 3 waited for the tag, then the key, then the ids: uni32k_w16's second round 3.1 ms)
           const unsigned long long g = a.dyn_tag[sl];
+          const U4 e0 = a.dyn_ent[4u * sl], e1 = a.dyn_ent[4u * sl + 1u], e2 = a.dyn_ent[4u * sl + 2u], e3 = a.dyn_ent[4u * sl + 3u];
           if (g == 0ull) break;
           if (g == tag) {
-            const U4 e0 = a.dyn_ent[4u * sl], e1 = a.dyn_ent[4u * sl + 1u];
-            if (e0.x == k0 && e0.y == k1 && e0.z == k2 && e0.w == k3 && e1.x == 1u) { hitd = true; dslot = sl; dn = e1.y; ent = U4{0, 0, e1.z, e1.w}; }
+            if (e0.x == k0 && e0.y == k1 && e0.z == k2 && e0.w == k3 && e1.x == 1u) { hitd = true; dn = e1.y; ent = U4{0, 0, e1.z, e1.w}; dia = e2; dib = e3; }
             break;                                   // (same hash, other bytes or an unusable word: a miss)
           }
           sl = (sl + 1u) & a.dyn_mask;
@@ -403,7 +406,9 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
         const unsigned long long tag = DynTag(k0, k1, k2, k3);
         uint32_t sl = static_cast<uint32_t>(tag >> 32) & a.dyn_mask;
         for (uint32_t t = 0; t < kDynProbes && !kept; ++t) {
-          const unsigned long long g = wv::atomic_cas(&a.dyn_tag[sl], 0ull, tag);
+          // (a look first: most occurrences of a word find it entered already, and a load is cheaper than an atomic)
+          unsigned long long g = wv::atomic_load64(&a.dyn_tag[sl]);
+          if (g == 0ull) g = wv::atomic_cas(&a.dyn_tag[sl], 0ull, tag);
           if (g == 0ull) {                           // ours: the word's bytes, and a place in the list of words to segment
             const uint32_t at = wv::atomic_add(a.dyn_count, 1u);
             a.dyn_ent[4u * sl] = U4{k0, k1, k2, k3};
@@ -453,7 +458,7 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
       if (n + static_cast<int>(cntd) > cap) { bad = true; active = false; }
       else {
         B += wv::bits_to_float(ent.z);
-        const uint32_t *di = reinterpret_cast<const uint32_t *>(a.dyn_ent + 4u * dslot + 2u);
+        const uint32_t di[kDynMaxIds] = {dia.x, dia.y, dia.z, dia.w, dib.x, dib.y, dib.z, dib.w};
         for (uint32_t k = (prev_unk && (dn & 0x100u)) ? 1u : 0u; k < cntd; ++k) put(di[k]);   // (:609-613 the run goes on)
         prev_unk = (dn & 0x200u) != 0u;
       }

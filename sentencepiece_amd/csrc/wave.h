@@ -64,6 +64,7 @@ SPMX_DEVICE void atomic_and(uint32_t *p, uint32_t v) { atomicAnd(p, v); }
 SPMX_DEVICE unsigned long long atomic_cas(unsigned long long *p, unsigned long long expect, unsigned long long v) { return atomicCAS(p, expect, v); }
 // a load that sees what other workgroups' atomics wrote (tile queue of the streaming kernels)
 SPMX_DEVICE uint32_t atomic_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+SPMX_DEVICE unsigned long long atomic_load64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 
 // the 64-bit value hi:lo shifted right by n & 3 bytes, its low 32 bits (v_alignbyte_b32)
