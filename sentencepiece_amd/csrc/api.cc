@@ -21,7 +21,6 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
-#include <sys/syscall.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -69,7 +68,6 @@ struct Ctrl {
   StreamQueue q[6];                   // tile queues of the main / document / overflow launches; [3], [4]: the word kernels; [5]: the tail launch
   uint32_t left_counts[3][kMaxClasses];   // word kernels: second-round input / general input / what the second round left, per class
   uint32_t dyn_count;                     // ... words entered into the call-local memo (must follow left_counts: read together)
-  uint32_t sort_count;                    // entries of the second round's sorted list (written by the sort, not read back)
   uint32_t align_counts[kMaxClasses]; // spans form: escalation lists of the staged align kernels
   SideLists side;
   unsigned long long arena_head;
@@ -95,41 +93,6 @@ struct DevBuf {
   void Free() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-// Pinned host memory NEAR THE GPU: hipHostMalloc places its pages by the calling thread's memory policy, and on a
-// two-socket host a staging buffer on the other socket makes every H2D / D2H copy cross the inter-socket link.  While one
-// of these is alive the thread PREFERS the NUMA node the current device hangs off (its PCI function's numa_node in
-// sysfs; set_mempolicy through the raw system call: no libnuma); anything that fails leaves the default policy alone.
-// SPMX_NO_NUMA=1 switches it off.
-struct PreferGpuNode {
-  bool set = false;
-  PreferGpuNode() {
-#if defined(__linux__) && !defined(SPMX_EMULATED)
-    static const bool off = getenv("SPMX_NO_NUMA") != nullptr;
-    if (off) return;
-    int dev = 0;
-    char bus[64] = {0};
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(bus, sizeof(bus), dev) != hipSuccess) return;
-    for (char *c = bus; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = static_cast<char>(*c - 'A' + 'a');
-    char path[160];
-    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
-    FILE *f = fopen(path, "r");
-    if (!f) return;
-    int node = -1;
-    const int got = fscanf(f, "%d", &node);
-    fclose(f);
-    if (got != 1 || node < 0 || node >= 1024) return;
-    unsigned long mask[16] = {0};
-    mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
-    set = syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, sizeof(mask) * 8 + 1) == 0;
-#endif
-  }
-  ~PreferGpuNode() {
-#if defined(__linux__) && !defined(SPMX_EMULATED)
-    if (set) (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0);
-#endif
-  }
-};
-
 // pinned host staging (host-buffer forms)
 template <typename T>
 struct PinBuf {
@@ -139,7 +102,6 @@ struct PinBuf {
     if (n <= cap) return hipSuccess;
     if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
     const size_t want = n + n / 4 + 64;
-    PreferGpuNode near;
     hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&p), want * sizeof(T), hipHostMallocDefault);
     if (e != hipSuccess) return e;
     cap = want;
@@ -172,7 +134,6 @@ struct PinnedPool {
     }
     void *p = nullptr;
     const size_t cap = bytes + bytes / 8;
-    PreferGpuNode near;
     if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> l(mu);
     live[p] = cap;
@@ -985,8 +946,6 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         uint64_t total = 0;
         for (int c = 0; c < ncls; ++c) total += known[c];
         if (total == 0) return kOk;
-        wa.n_real_classes = static_cast<uint32_t>(ncls);
-        for (int c = 0; c < ncls; ++c) wa.real_rcap[c] = rcaps[c];
         uint64_t grid = static_cast<uint64_t>(h->n_cu - h->reserve_cus) * static_cast<uint64_t>(dp ? 1 : h->word_wgs);
         if (grid * waves * 64 > total) grid = (total + waves * 64 - 1) / (waves * 64);
         if (grid < 1) grid = 1;
@@ -1002,7 +961,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
           if (tw > 64) tw = 64;
           if (tw < 1) tw = 1;
           sc.lane_shift = 6;
-          sc.general = (mode != 2 && ((uni_class[c] && cls[c].rcap > kMaxStagedRaw) || cls[c].rcap > h->main_max_raw)) ? 1u : 0u;   // documents pass through
+          sc.general = ((uni_class[c] && cls[c].rcap > kMaxStagedRaw) || cls[c].rcap > h->main_max_raw) ? 1u : 0u;   // documents pass through
           sc.count = known[c];
           sc.tw = static_cast<uint32_t>(tw);
           sc.main_tiles = static_cast<uint32_t>((static_cast<uint64_t>(known[c]) + tw - 1) / tw);
@@ -1061,31 +1020,10 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
             if (g > static_cast<uint64_t>(h->n_cu) * 8) g = static_cast<uint64_t>(h->n_cu) * 8;
             FORKED_HIP_OR_RETURN(LaunchWordResolve(ra, static_cast<int>(g), stream));
           }
-          // Round 2's input SORTED by what is left of each sentence from the word it is taken up at (classify's counting
-          // sort in its list-input form, longest first): a tile of round 2 lasts as long as its lane with the most text
-          // to go, and the sentences of one length class stand anywhere between their first and their last word.
-          {
-            ClassifyArgs sa{};
-            sa.offs = d_offsets; sa.n = static_cast<uint32_t>(again_total); sa.n_classes = 1u;
-            uint32_t hi = 512u;
-            for (int c = 0; c < ncls; ++c) if (again_counts[c] && cls[c].rcap > hi) hi = cls[c].rcap;
-            sa.rcap[0] = hi;
-            sa.sub_buckets = static_cast<uint32_t>(kMaxSubBuckets);
-            sa.lists = left_lists[2]; sa.list_counts = &ws->d_ctrl->sort_count;
-            sa.key_totals = ws->d_ctrl->key_totals; sa.key_cursor = ws->d_ctrl->key_cursor;
-            sa.in_lists = left_lists[0]; sa.in_stride = n32; sa.in_n_lists = static_cast<uint32_t>(ncls);
-            for (int c = 0; c < ncls; ++c) sa.in_prefix[c + 1] = sa.in_prefix[c] + again_counts[c];
-            sa.resume = ws->d_resume.p;
-            FORKED_HIP_OR_RETURN(hipMemsetAsync(ws->d_ctrl->key_totals, 0, sizeof(ws->d_ctrl->key_totals) + sizeof(ws->d_ctrl->key_cursor), stream));
-            const uint32_t chunks = (sa.n + 64 * kClassifyChunk - 1) / (64 * kClassifyChunk);
-            const uint32_t widest = static_cast<uint32_t>(h->n_cu) * 8u;
-            FORKED_HIP_OR_RETURN(LaunchClassify(sa, static_cast<int>(chunks < widest ? chunks : widest), stream));
-          }
-          // round 2 over that one list; what it cannot take either (a margin that does not hold, a word of more than 8
-          // pieces) is APPENDED to the lists of what round 1 gave up for good: one tail launch takes both
-          for (int c = 0; c < kMaxClasses; ++c) known[c] = 0;
-          known[0] = static_cast<uint32_t>(again_total);
-          a.lists = left_lists[2];
+          // round 2 over what round 1 kept for it; what it cannot take either (a margin that does not hold, a word of
+          // more than 8 pieces) is APPENDED to the lists of what round 1 gave up for good: one tail launch takes both
+          for (int c = 0; c < ncls; ++c) known[c] = again_counts[c];
+          a.lists = left_lists[0];
           FORKED_OR_RETURN(word_pass(2, kSlotWord2, 4, left_lists[1], ws->d_ctrl->left_counts[1], nullptr, nullptr));
           FORKED_OR_RETURN(read_counts());
         }

@@ -109,8 +109,6 @@ struct EncodeArgs {
   uint32_t dyn_mask;
   uint32_t dyn_cap;             // entries dyn_list holds
   U4 *resume;                   // per sentence the first round keeps for the second: {position, ids written, bound, 0}
-  uint32_t n_real_classes;      // (second word round, whose one list is sorted by remaining length) the length classes ...
-  uint32_t real_rcap[kMaxClasses];   // ... and their raw capacities: where its leftovers go
   uint32_t ids16;               // the word kernels write 16-bit ids into their arena slots (vocabularies of up to 65536 pieces)
   // ---- sentence-per-wave launch (BPE models that are not word-wise; kernels_bpe.h) ----
   const uint32_t *list;         // sentence indices of this length class
@@ -674,14 +672,6 @@ struct ClassifyArgs {
   uint32_t *lists2;             // n_classes x n: the flagged sentences, by class
   uint32_t *list2_counts;       // n_classes
   uint32_t scan_max_rcap;       // classes beyond this size are never split (documents: the few there are go through one launch)
-  // LIST INPUT (the second word round's sentences sorted by what is left of them, kernels_word.h): element i is not
-  // sentence i but entry i of the concatenated lists in_lists[c * in_stride ...] (in_prefix[c] entries before list c),
-  // and its "length" is what lies behind resume[sentence].x -- the position the round takes the sentence up at.  One
-  // class (rcap[0] bounds the sub-buckets), LONGEST first.  n = in_prefix[in_n_lists].
-  const uint32_t *in_lists;     // null: the plain form
-  uint32_t in_stride, in_n_lists;
-  uint32_t in_prefix[kMaxClasses + 1];
-  const U4 *resume;
 };
 
 // (class << 4 | sub-bucket) of a sentence of len raw bytes
@@ -807,23 +797,13 @@ SPMX_DEVICE void classify_block(const ClassifyArgs &a, uint32_t *lds) {
     const uint32_t first = ch * per_chunk;
     for (int k = lane; k < n_keys; k += 64) hist[k] = 0;
     wv::sync();
-    uint32_t keys[kClassifyChunk], sids[kClassifyChunk];
+    uint32_t keys[kClassifyChunk];
 #pragma unroll
     for (int k = 0; k < kClassifyChunk; ++k) {
       const uint32_t i = first + static_cast<uint32_t>(k) * 64u + static_cast<uint32_t>(lane);
       keys[k] = 0xFFFFFFFFu;
-      sids[k] = 0u;
       if (i < a.n) {
-        if (a.in_lists) {
-          uint32_t c = 0;
-          while (c + 1u < a.in_n_lists && i >= a.in_prefix[c + 1u]) ++c;
-          sids[k] = a.in_lists[static_cast<uint64_t>(c) * a.in_stride + (i - a.in_prefix[c])];
-          const uint64_t len = a.offs[sids[k] + 1u] - a.offs[sids[k]], at = a.resume[sids[k]].x;
-          keys[k] = a.sub_buckets - 1u - classify_key(a, len > at ? len - at : 0u);        // (one class: the key is the sub-bucket; longest first)
-        } else {
-          sids[k] = i;
-          keys[k] = classify_key(a, a.offs[i + 1] - a.offs[i]);
-        }
+        keys[k] = classify_key(a, a.offs[i + 1] - a.offs[i]);
         if (scan) {
           const uint32_t f = a.flags[i];
           if (f && a.rcap[keys[k] / a.sub_buckets] <= a.scan_max_rcap) keys[k] += static_cast<uint32_t>(n_plain_keys);
@@ -843,12 +823,13 @@ SPMX_DEVICE void classify_block(const ClassifyArgs &a, uint32_t *lds) {
       wv::sync();
 #pragma unroll
       for (int k = 0; k < kClassifyChunk; ++k) {
+        const uint32_t i = first + static_cast<uint32_t>(k) * 64u + static_cast<uint32_t>(lane);
         if (keys[k] != 0xFFFFFFFFu) {
           const uint32_t key = keys[k], c = key / a.sub_buckets;
           const uint32_t r = wv::lds_atomic_add(&hist[key], 1u);
           uint32_t *list = c < a.n_classes ? a.lists + static_cast<uint64_t>(c) * a.n
                                            : a.lists2 + static_cast<uint64_t>(c - a.n_classes) * a.n;
-          list[base[key] + start[key] + r] = sids[k];
+          list[base[key] + start[key] + r] = i;
         }
       }
     }

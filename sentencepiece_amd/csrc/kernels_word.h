@@ -604,15 +604,6 @@ SPMX_DEVICE void encode_word_block_as(const EncodeArgs &a, unsigned char *smem) 
       }
       append_lanes(wv::ballot(again), again, sid, a.left_lists + static_cast<uint64_t>(c) * a.n, &a.left_counts[c], lane);
       append_lanes(wv::ballot(gone), gone, sid, a.left2_lists + static_cast<uint64_t>(c) * a.n, &a.left2_counts[c], lane);
-    } else if (MODE == kWmDyn) {
-      // (the second round's input is ONE list sorted by what is left of the sentences, api.cc: what it cannot take goes
-      // to the lists of the sentences' own length classes)
-      uint32_t rc = a.n_real_classes - 1u;
-      for (int k = static_cast<int>(a.n_real_classes) - 2; k >= 0; --k) if (l64 <= a.real_rcap[k]) rc = static_cast<uint32_t>(k);
-      for (uint32_t k = 0; k < a.n_real_classes; ++k) {
-        const bool m = left && rc == k;
-        append_lanes(wv::ballot(m), m, sid, a.left_lists + static_cast<uint64_t>(k) * a.n, &a.left_counts[k], lane);
-      }
     } else {
       append_lanes(wv::ballot(left), left, sid, a.left_lists + static_cast<uint64_t>(c) * a.n, &a.left_counts[c], lane);
     }
