@@ -21,6 +21,7 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -93,6 +94,41 @@ struct DevBuf {
   void Free() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// Pinned host memory NEAR THE GPU: hipHostMalloc places its pages by the calling thread's memory policy, and on a
+// two-socket host a staging buffer on the other socket makes every H2D / D2H copy cross the inter-socket link.  While one
+// of these is alive the thread PREFERS the NUMA node the current device hangs off (its PCI function's numa_node in
+// sysfs; set_mempolicy through the raw system call: no libnuma); anything that fails leaves the default policy alone.
+// SPMX_NO_NUMA=1 switches it off.
+struct PreferGpuNode {
+  bool set = false;
+  PreferGpuNode() {
+#if defined(__linux__) && !defined(SPMX_EMULATED)
+    static const bool off = getenv("SPMX_NO_NUMA") != nullptr;
+    if (off) return;
+    int dev = 0;
+    char bus[64] = {0};
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(bus, sizeof(bus), dev) != hipSuccess) return;
+    for (char *c = bus; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = static_cast<char>(*c - 'A' + 'a');
+    char path[160];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return;
+    int node = -1;
+    const int got = fscanf(f, "%d", &node);
+    fclose(f);
+    if (got != 1 || node < 0 || node >= 1024) return;
+    unsigned long mask[16] = {0};
+    mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
+    set = syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, sizeof(mask) * 8 + 1) == 0;
+#endif
+  }
+  ~PreferGpuNode() {
+#if defined(__linux__) && !defined(SPMX_EMULATED)
+    if (set) (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0);
+#endif
+  }
+};
+
 // pinned host staging (host-buffer forms)
 template <typename T>
 struct PinBuf {
@@ -102,6 +138,7 @@ struct PinBuf {
     if (n <= cap) return hipSuccess;
     if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
     const size_t want = n + n / 4 + 64;
+    PreferGpuNode near;
     hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&p), want * sizeof(T), hipHostMallocDefault);
     if (e != hipSuccess) return e;
     cap = want;
@@ -134,6 +171,7 @@ struct PinnedPool {
     }
     void *p = nullptr;
     const size_t cap = bytes + bytes / 8;
+    PreferGpuNode near;
     if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> l(mu);
     live[p] = cap;
