@@ -714,6 +714,13 @@ SPMX_DEVICE void plain_scan_block(const PlainScanArgs &a) {
   // sentence's byte lies inside the buffer's pages; what it holds before the first or beyond the last such byte belongs
   // to no sentence and is ignored.
   const uint64_t t0 = a.offs[0], t1 = a.offs[a.n];
+  // The word kernels read 16 + 4 bytes from a word's start whatever its length and therefore leave the sentences that
+  // end within 20 bytes of the batch's last byte alone (kernels_word.h): those few are set aside HERE, so that they
+  // ride with the general launch beside the first word round instead of costing a tail launch of their own after it.
+  if (wv::block_id() == 0 && wv::wave_in_block() == 0 && lane == 0) {
+    uint32_t k = a.n;
+    for (int step = 0; step < 64 && k > 0u && a.offs[k] + 20u > t1; ++step) a.flags[--k] = 1;
+  }
   if (t1 <= t0) return;
   const uint64_t u0 = (base_addr + t0) & ~15ull, u1 = base_addr + t1;
   constexpr int kFlight = kPlainScanFlight;           // 16-byte units in flight per lane
