@@ -544,7 +544,7 @@ def main():
                 import ctypes as C
                 lib = sp._lib
                 runs = []
-                for _ in range(5):               # the C call itself: the arrays it returns belong to the library (pinned, recycled)
+                for _ in range(9):               # the C call itself: the arrays it returns belong to the library (pinned, recycled)
                     p_ids, p_off = C.c_void_p(), C.c_void_p()
                     t0 = time.perf_counter()
                     rc = lib.spmx_encode_batch(sp._h, text.ctypes.data, offs.ctypes.data, n, C.byref(p_ids), C.byref(p_off))

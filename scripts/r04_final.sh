@@ -4,7 +4,7 @@
 TAG=${1:-r04f}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$TAG; mkdir -p $O
-if [ -z "$SKIP_TESTS" ]; then ( time timeout 900 python -m pytest tests -m gpu -x -q --durations=12 ) > $O/pytest_gpu.txt 2>&1; tail -4 $O/pytest_gpu.txt; fi
+if [ -z "$SKIP_TESTS" ]; then ( time timeout 900 python -m pytest tests -m gpu -x -q --durations=12 ) > $O/pytest_gpu.txt 2>&1; tail -4 $O/pytest_gpu.txt; else ( time timeout 600 python -m pytest tests/test_word_form.py tests/test_gpu_parity.py tests/test_host.py tests/test_gather.py -m gpu -x -q ) > $O/pytest_gpu_changed.txt 2>&1; tail -4 $O/pytest_gpu_changed.txt; fi
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
 PASS_TIMEOUT=120 bash scripts/pmc_traffic.sh $TAG 10000000 uni32k > $O/pmc_traffic_uni.log 2>&1; tail -3 $O/pmc_traffic_uni.log | cut -c1-200
 PASS_TIMEOUT=120 bash scripts/pmc_traffic.sh $TAG 10000000 bpe32k > $O/pmc_traffic_bpe.log 2>&1
