@@ -933,9 +933,10 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
           HIP_OR_RETURN(h, hipEventRecord(ws->ev_fork, stream));
           HIP_OR_RETURN(h, hipStreamWaitEvent(ws->stream2, ws->ev_fork, 0));
           stream = ws->stream2;
-          // wavefronts per workgroup of the general launch: enough for one full tile per wavefront (its time is then one
-          // tile's, the longest sentence's), no more -- what it takes of a CU's LDS and issue slots the word kernel next
-          // to it does not get (C2: 4 -> general 6.0 ms / word round 4.8 ms; 8 -> 3.6 / 5.2; 16 -> 2.6 / 5.2)
+          // wavefronts per workgroup of the general launch: 4 (SPMX_FORK_WAVES) -- a CU holds 16 wavefronts of the two
+          // kernels together, the word kernel's workgroup has 12; with more the general launch runs as fast as alone and the
+          // word round waits for its CUs (C2: 4 -> general 5.4 ms / word round 4.5 ms; 5 -> 3.2 / 6.1; profiles/
+          // r04_ab_kernel_stats.txt).  SPMX_FORK_WAVES=0: one full tile per wavefront, by the launch's size.
           uint64_t gt = 0;
           for (int c = 0; c < ncls; ++c) gt += (static_cast<uint64_t>(gen_known[c]) + 63) / 64;
           const uint64_t per_cu = (gt + static_cast<uint64_t>(h->n_cu) - 1) / static_cast<uint64_t>(h->n_cu);
@@ -949,7 +950,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
           // (on any error while forked: nothing of this call may still be queued on the second stream when the
           // workspace goes back to the pool)
           if (rc != kOk) { (void)hipStreamSynchronize(ws->stream2); return rc; }
-          HIP_OR_RETURN(h, hipEventRecord(ws->ev_join, stream));
+          if (hipError_t e = hipEventRecord(ws->ev_join, stream); e != hipSuccess) { (void)hipStreamSynchronize(ws->stream2); return FailHip(h, e, "hipEventRecord(join)"); }
           stream = main_stream;
           stream_waves_cap = 0;
         } else if (rc != kOk) {
@@ -1090,6 +1091,12 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       // plain minority and their tail only add to the one general launch that does the work
       if (scanned && n >= 4096 && (gen_total * 8 > static_cast<uint64_t>(n) * 5)) h->word_backoff.store(15, std::memory_order_relaxed);
       // ---- the tail: what the word rounds left ----
+      // (its launches share the workspace's streaming scratch and slice pool with the launches on the second stream: they
+      // wait for those to END -- on the host, because sizing the scratch may free what a running kernel still uses.  The
+      // tail is empty on batches of plain text; the join below then costs nothing more.)
+      uint64_t tail_total = 0;
+      for (int c = 0; c < ncls; ++c) tail_total += known[c];
+      if (forked && tail_total > 0) FORKED_HIP_OR_RETURN(hipStreamSynchronize(ws->stream2));
       FORKED_OR_RETURN(general_pass(left_lists[left_at], ws->d_ctrl->left_counts[left_at], known, true));
     } else {
       FORKED_OR_RETURN(general_pass(class_lists, ws->d_ctrl->list_counts, known, false));
