@@ -688,7 +688,11 @@ void BuildWordMemo(const ModelData &m, HostTables *t) {
     const bool one = e.id1 == 0xFFFFFFFFu;
     const int len = len_of(e);
     const bool fits = e.id0 < 65535u && (one || e.id1 < 65535u) && bound2(e) <= 255.0 && e.bmax >= 1.0f;
-    static const bool one_only = getenv("SPMX_MEMO16_ONE") != nullptr;   // A/B: only one-piece words in the 16-byte entries (round 3)
+#ifdef SPMX_TEST_SEAMS
+    static const bool one_only = getenv("SPMX_MEMO16_ONE") != nullptr;   // A/B (emulator / variant builds): only one-piece words in the 16-byte entries, as in round 3
+#else
+    constexpr bool one_only = false;
+#endif
     if (fits && ((one && len <= 12) || (len <= 10 && !one_only))) small.push_back(&e);
     else big.push_back(&e);
   }
