@@ -272,6 +272,24 @@ class SentencePieceProcessor {
                                                d_id_offsets, stream, total_ids));
   }
 
+  // One process per GPU: every rank's device CSR (what EncodeBatchDevice wrote for its contiguous shard of the job's
+  // sentences) on every rank, over RCCL (spmx_all_gather_ids: counts all-gather, exact-size grouped sends and receives,
+  // offsets rebased to the whole job).  comm: an ncclComm_t (the caller's, or spmx_rccl_comm_init's); d_scratch: 2 + 2 *
+  // world uint64 of device memory; rank_sentences / rank_ids (nullable): prefix sums over the ranks, world + 1 entries.
+  static util::Status AllGatherIds(void *comm, int rank, int world, const int32_t *d_ids, uint64_t n_ids,
+                                   const uint64_t *d_id_offsets, uint64_t n_sentences, int32_t *d_all_ids,
+                                   uint64_t all_ids_capacity, uint64_t *d_all_id_offsets, uint64_t all_offsets_capacity,
+                                   uint64_t *d_scratch, std::vector<uint64_t> *rank_sentences, std::vector<uint64_t> *rank_ids,
+                                   void *stream) {
+    if (rank_sentences) rank_sentences->assign(static_cast<size_t>(world > 0 ? world : 0) + 1, 0);
+    if (rank_ids) rank_ids->assign(static_cast<size_t>(world > 0 ? world : 0) + 1, 0);
+    const int rc = spmx_all_gather_ids(comm, rank, world, d_ids, n_ids, d_id_offsets, n_sentences, d_all_ids, all_ids_capacity,
+                                       d_all_id_offsets, all_offsets_capacity, d_scratch,
+                                       rank_sentences ? rank_sentences->data() : nullptr, rank_ids ? rank_ids->data() : nullptr, stream);
+    if (rc == 0) return util::Status();
+    return util::Status(static_cast<util::StatusCode>(rc), spmx_gather_last_error());
+  }
+
   // ---- pieces / SentencePieceText (sentencepiece_processor.h:295-296, :401-402, :453-456) ----
   // The device returns ids, input spans and normalized-text spans (spmx_encode_batch_spans) and the normalized text
   // (spmx_normalize_batch); a piece is its normalized text, the piece name for a byte-fallback piece and a bos / eos,
