@@ -289,14 +289,7 @@ struct spmx_handle {
   std::atomic<int> word_backoff{0};   // calls that leave the word rounds out (they did not pay on the last batch that tried)
   bool no_word = false;          // SPMX_NO_WORD_KERNEL=1: unigram models skip the word kernels (kernels_word.h)
   bool no_word_dp = false;       // SPMX_NO_WORD_DP=1: ... skip the second pass only
-  uint32_t dyn_slots = kDynSlotsDefault;        // SPMX_DYN_SLOTS_LOG2: slots of the call-local word memo (a power of two): the most a call uses
-  // The table a call actually spreads its words over follows what the handle's last call collected (8 slots per word,
-  // at least 2^14): 2^20 slots are 8 MB of tags and 64 MB of entries -- every probe of either word round a miss of every
-  // cache -- where a batch of C2 collects a thousand words and one of natural text some ten thousand.  Results do not
-  // depend on it: a table that turns out too small sends the sentences it cannot hold to the later rounds, and the next
-  // call's is larger.
-  std::atomic<uint32_t> dyn_slots_next{0};      // 0: no call yet (the first one uses dyn_slots)
-  uint32_t dyn_slots_min = 1u << 14;            // (SPMX_DYN_SLOTS_MIN_LOG2 in the emulator build: tests make a call outgrow the table its predecessor sized)
+  uint32_t dyn_slots = kDynSlotsDefault;        // SPMX_DYN_SLOTS_LOG2: slots of the call-local word memo (a power of two)
   uint32_t dyn_list_cap = kDynListCapDefault;   // SPMX_DYN_LIST_CAP: words it takes per call; what it cannot take stays with the general kernels
   uint64_t nbest_budget = 32ull << 30;  // SPMX_NBEST_BUDGET_GB: HBM the lattice slices of one launch may take (200 k sentences, n-best 5: 0.83 M sentences/s at 8 GB, 1.15 M at 32, 1.19 M at 96)
   uint32_t nbest_hyps_min = 16384;   // SPMX_NBEST_HYPS_MIN: hypotheses a lane's A* may hold in the first launch (what outgrows it runs again)
@@ -984,8 +977,6 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       // What is left then -- a word of more than 16 bytes, a margin that does not hold, and without the plain scan
       // anything that is not plain ASCII words -- comes back as per-class lists for the tail launch below.
       const bool dyn = !h->no_word_dyn;
-      uint32_t dyn_slots_call = h->dyn_slots_next.load(std::memory_order_relaxed);
-      if (dyn_slots_call == 0u || dyn_slots_call > h->dyn_slots) dyn_slots_call = h->dyn_slots;
       word_pass = [&](int mode, int slot, int qi, uint32_t *out_lists, uint32_t *d_out_counts, uint32_t *out2_lists,
                            uint32_t *d_out2_counts) -> int {
         const bool dp = mode == 3;
@@ -1027,7 +1018,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         wa.dyn_ent = ws->d_dyn_ent.p;
         wa.dyn_list = ws->d_dyn_list.p;
         wa.dyn_count = &ws->d_ctrl->dyn_count;
-        wa.dyn_mask = dyn_slots_call - 1u;
+        wa.dyn_mask = h->dyn_slots - 1u;
         wa.dyn_cap = h->dyn_list_cap;
         wa.resume = ws->d_resume.p;
         wa.ids16 = (h->model.pieces.size() <= 65536 && !h->no_ids16) ? 1u : 0u;
@@ -1053,17 +1044,11 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         FORKED_HIP_OR_RETURN(ws->d_dyn_ent.Reserve(static_cast<size_t>(h->dyn_slots) * 4));
         FORKED_HIP_OR_RETURN(ws->d_dyn_list.Reserve(h->dyn_list_cap));
         FORKED_HIP_OR_RETURN(ws->d_resume.Reserve(n));
-        FORKED_HIP_OR_RETURN(hipMemsetAsync(ws->d_dyn_tag.p, 0, static_cast<size_t>(dyn_slots_call) * sizeof(unsigned long long), stream));
+        FORKED_HIP_OR_RETURN(hipMemsetAsync(ws->d_dyn_tag.p, 0, static_cast<size_t>(h->dyn_slots) * sizeof(unsigned long long), stream));
         FORKED_OR_RETURN(word_pass(1, kSlotWord, 3, left_lists[0], ws->d_ctrl->left_counts[0], left_lists[1], ws->d_ctrl->left_counts[1]));
         FORKED_OR_RETURN(read_counts());
         for (int c = 0; c < ncls; ++c) { again_counts[c] = ws->h_ctrl->left_counts[0][c]; again_total += again_counts[c]; }
         again_words = ws->h_ctrl->dyn_count < h->dyn_list_cap ? ws->h_ctrl->dyn_count : h->dyn_list_cap;
-        {   // the next call's table: 8 slots per word this one collected (see dyn_slots_next)
-          uint64_t want = h->dyn_slots_min;
-          while (want < 8ull * ws->h_ctrl->dyn_count && want < h->dyn_slots) want <<= 1;
-          if (want > h->dyn_slots) want = h->dyn_slots;
-          h->dyn_slots_next.store(static_cast<uint32_t>(want), std::memory_order_relaxed);
-        }
         left_at = 1;
         if (again_total > 0) {
           if (again_words) {      // the collected words, segmented once each (a few workgroups)
@@ -1472,7 +1457,6 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_NBEST_BUDGET_GB")) { const long v = atol(e); if (v >= 1 && v <= 200) h->nbest_budget = static_cast<uint64_t>(v) << 30; }
 #ifdef SPMX_TEST_SEAMS   // (the emulator build and `make variant DEF=-DSPMX_TEST_SEAMS` only: the release library reads none of these)
     if (getenv("SPMX_WORDMEMO_UNSAFE")) h->memo_unsafe = true;
-    if (const char *e = getenv("SPMX_DYN_SLOTS_MIN_LOG2")) { const int v = atoi(e); if (v >= 4 && v <= 20) h->dyn_slots_min = 1u << v; }
     // A/B switches of settled experiments (their measurements: DESIGN.md section 4, profiles/)
     if (const char *e = getenv("SPMX_NO_WORD_DP")) h->no_word_dp = e[0] == '1';
     if (const char *e = getenv("SPMX_NBEST_HYPS_MIN")) { const long v = atol(e); if (v >= 1024 && v <= 262144) h->nbest_hyps_min = static_cast<uint32_t>(v); }

@@ -367,26 +367,3 @@ def test_gpu_plain_scan_sets_the_other_sentences_aside(model, oracle):
         if not env:
             assert int(is_odd.sum()) <= rest <= int(is_odd.sum()) + 1000, (prof, int(is_odd.sum()))
 
-
-def test_emu_call_local_table_follows_the_last_call(emu, oracle):
-    """The call-local memo's table is sized by what the handle's last call collected (api.cc dyn_slots_next): a call
-    whose words outgrow the table its predecessor sized still gives the reference's ids (what the table cannot hold
-    goes to the later rounds), and the call after it has room again."""
-    blob = fixtures.model_blob("uni32k_w16")
-    words = wordfuzz.whole_words(blob, limit=3000)
-    rng = np.random.default_rng(3)
-    alpha = "etaoinshrdlu"
-
-    def fresh(k):      # words no memo holds
-        return ["".join(alpha[int(i)] for i in rng.integers(0, len(alpha), size=int(rng.integers(5, 12)))).encode() for _ in range(k)]
-    few, many = fresh(3), fresh(900)
-    h = emu.load(blob, classes=None, env={"SPMX_DYN_SLOTS_MIN_LOG2": "5", "SPMX_FORCE_WORD_DP": "0"})
-    o = oracle.load(blob)
-    for pool in (few, many, many, few):
-        sents = []
-        for i in range(700):
-            ws = [words[int(j)] for j in rng.integers(0, len(words), size=int(rng.integers(2, 20)))]
-            ws[int(rng.integers(0, len(ws)))] = pool[i % len(pool)]
-            sents.append(b" ".join(ws))
-        _check(h.encode_batch, o, sents + [b"x" * 40], "table sized by the last call")
-        assert _word_form_sentences(h.sp) > 0
