@@ -1455,7 +1455,7 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_DYN_SLOTS_LOG2")) { const int v = atoi(e); if (v >= 4 && v <= 26) h->dyn_slots = 1u << v; }
     if (const char *e = getenv("SPMX_DYN_LIST_CAP")) { const long v = atol(e); if (v >= 1 && v <= (1l << 26)) h->dyn_list_cap = static_cast<uint32_t>(v); }
     if (const char *e = getenv("SPMX_NBEST_BUDGET_GB")) { const long v = atol(e); if (v >= 1 && v <= 200) h->nbest_budget = static_cast<uint64_t>(v) << 30; }
-#ifdef SPMX_TEST_SEAMS   // (the emulator build and `make variant DEF=-DSPMX_TEST_SEAMS` only: the release library reads none of these)
+#ifdef SPMX_TEST_SEAMS   // (the emulator build, tests/emu/Makefile: the release library reads none of these)
     if (getenv("SPMX_WORDMEMO_UNSAFE")) h->memo_unsafe = true;
     // A/B switches of settled experiments (their measurements: DESIGN.md section 4, profiles/)
     if (const char *e = getenv("SPMX_NO_WORD_DP")) h->no_word_dp = e[0] == '1';

@@ -689,7 +689,7 @@ void BuildWordMemo(const ModelData &m, HostTables *t) {
     const int len = len_of(e);
     const bool fits = e.id0 < 65535u && (one || e.id1 < 65535u) && bound2(e) <= 255.0 && e.bmax >= 1.0f;
 #ifdef SPMX_TEST_SEAMS
-    static const bool one_only = getenv("SPMX_MEMO16_ONE") != nullptr;   // A/B (emulator / variant builds): only one-piece words in the 16-byte entries, as in round 3
+    static const bool one_only = getenv("SPMX_MEMO16_ONE") != nullptr;   // A/B (emulator build): only one-piece words in the 16-byte entries, as in round 3
 #else
     constexpr bool one_only = false;
 #endif
