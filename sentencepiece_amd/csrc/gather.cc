@@ -155,14 +155,17 @@ int spmx_all_gather_ids(void *nccl_comm, int rank, int world, const int32_t *d_i
     return FailG(8, "the gathered CSR needs " + std::to_string(total_i) + " ids and " + std::to_string(total_s + 1) + " offsets");
   // ---- payload: exact sizes, point to point, one group ----
   RCCL_OR_RETURN(api, api.GroupStart());
-  for (int k = 1; k < world; ++k) {
+  int in_group = 0;                       // (a call that fails inside the group must not leave it open: the first failure is kept, the group closed)
+  for (int k = 1; k < world && in_group == 0; ++k) {
     const int to = (rank + k) % world, from = (rank - k + world) % world;    // (every rank a different peer per step)
-    if (n_ids) RCCL_OR_RETURN(api, api.Send(d_ids, n_ids, kNcclInt32, to, nccl_comm, stream));
-    if (n_sentences) RCCL_OR_RETURN(api, api.Send(d_id_offsets, n_sentences, kNcclUint64, to, nccl_comm, stream));
-    if (all[2 * from + 1]) RCCL_OR_RETURN(api, api.Recv(d_all_ids + ra.ids_before[from], all[2 * from + 1], kNcclInt32, from, nccl_comm, stream));
-    if (all[2 * from]) RCCL_OR_RETURN(api, api.Recv(d_all_id_offsets + ra.sent_before[from], all[2 * from], kNcclUint64, from, nccl_comm, stream));
+    if (n_ids && in_group == 0) in_group = api.Send(d_ids, n_ids, kNcclInt32, to, nccl_comm, stream);
+    if (n_sentences && in_group == 0) in_group = api.Send(d_id_offsets, n_sentences, kNcclUint64, to, nccl_comm, stream);
+    if (all[2 * from + 1] && in_group == 0) in_group = api.Recv(d_all_ids + ra.ids_before[from], all[2 * from + 1], kNcclInt32, from, nccl_comm, stream);
+    if (all[2 * from] && in_group == 0) in_group = api.Recv(d_all_id_offsets + ra.sent_before[from], all[2 * from], kNcclUint64, from, nccl_comm, stream);
   }
-  RCCL_OR_RETURN(api, api.GroupEnd());
+  const int ended = api.GroupEnd();
+  if (in_group != 0) return FailG(13, std::string("ncclSend / ncclRecv: ") + (api.GetErrorString ? api.GetErrorString(in_group) : "RCCL error"));
+  RCCL_OR_RETURN(api, ended);
   if (n_ids) HIPG_OR_RETURN(hipMemcpyAsync(d_all_ids + ra.ids_before[rank], d_ids, n_ids * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
   if (n_sentences) HIPG_OR_RETURN(hipMemcpyAsync(d_all_id_offsets + ra.sent_before[rank], d_id_offsets, n_sentences * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));
   // ---- rebase ----
