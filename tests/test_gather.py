@@ -130,3 +130,19 @@ def test_all_gather_ids_on_the_gpu_world_1(oracle, corpora):
     np.testing.assert_array_equal(all_ids[:total].cpu().numpy(), np.asarray(oids))
     assert int(all_ids[total]) == -7 and rs.tolist() == [0, n] and ri.tolist() == [0, total]
     assert lib.spmx_rccl_comm_destroy(comm) == 0
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_cpp_host_gathers_over_threads(world, emu_lib):
+    """tests/cpp/gather_test.cc: the C++ a host of the reference would write (facade Load / EncodeBatchDevice /
+    AllGatherIds), ranks = threads, device emulated, RCCL stood in for."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "cpp", "gather_test.cc")
+    out = os.path.join(ROOT, "tests", "cpp", "gather_test_emu")
+    emu_dir = os.path.join(ROOT, "tests", "emu")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-pthread", "-o", out, src, "-L" + emu_dir, "-lspmx_emu",
+                           "-Wl,-rpath," + emu_dir])
+    env = dict(os.environ, SPMX_RCCL_LIB=os.path.join(emu_dir, "libfake_rccl.so"), SPMX_EMU_CUS="2")
+    r = subprocess.run([out, os.path.join(fixtures.GOLDEN, "test_model.model"), os.path.join(fixtures.GOLDEN, "botchan.txt"), str(world)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and r.stdout.startswith("ok 600 "), (r.stdout, r.stderr)
