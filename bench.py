@@ -502,6 +502,13 @@ def main():
                                        args.steps, args.warmup, "configs[2]: 32k BPE, the same %d sentences" % n)
             except Exception as e:
                 out["c3"] = {"failed": repr(e)[:300]}
+            # a Llama-style BPE model (byte fallback, extra whitespace kept, pieces of space symbols only, 1000 pieces: words
+            # split finely): the word kernels with the call-local memo's wide entries (round 3: 121 M through the stream kernel)
+            try:
+                out["llama_style_bpe"] = side_bench(SentencePieceProcessor, torch, dev, "bpe1k_llama", model_blob("bpe1k_llama"), text, offs,
+                                                    max(1, args.steps // 2), 1, "bpe1k_llama (tests/golden), the same %d sentences" % n)
+            except Exception as e:
+                out["llama_style_bpe"] = {"failed": repr(e)[:300]}
             # text the word memo does not fit by construction: the C2 recipe with 5 % of its tokens fresh random words, and
             # the novel of the reference's own tests x 2000 (8.6 M lines), each with every sentence against the reference
             try:

@@ -67,7 +67,9 @@ constexpr uint32_t kWordLdsShared = kWordMaskBytes + kWordHotSlots * 16u;
 constexpr uint32_t kWordStage = 8;                              // ids per burst
 constexpr uint32_t kWordDpPos = 18;                             // positions of a word in the DP: space symbol + 16 bytes + end
 constexpr int kWordDpMax = 4;                                   // words per sentence the second pass segments itself
-constexpr uint32_t kDynMaxIds = 8;                              // pieces per word of the call-local memo
+constexpr uint32_t kDynMaxIds = 8;                              // pieces per word of the call-local memo (32-bit ids) ...
+constexpr uint32_t kDynMaxWide = 16;                            // ... or 9 .. 16 of them as 16-bit values (a WIDE entry: kDynWide in its count word)
+constexpr uint32_t kDynFirstUnk = 0x100u, kDynLastUnk = 0x200u, kDynWide = 0x400u;   // flags next to the count
 constexpr uint32_t kDynProbes = 24;                             // slots tried before a word is given up
 // word modes of uni_word_lane: plain; collecting (first round of a call that has a call-local memo); looking the
 // call-local memo up (second round)
@@ -192,6 +194,7 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
   int stall_L = 0;
   bool prev_unk = false;                           // the last piece emitted was unknown (a run of them is ONE id, :609-613)
   const bool bf = (d.flags & kNfByteFallback) != 0;
+  const bool keep_ws = (d.flags & kNfRemoveExtraWs) == 0;
   Q4U w{0, 0, 0, 0};
   int wvalid = 16;                                 // bytes of `w` that are text (what a shift brought in behind them is zero)
   if (active) w = *reinterpret_cast<const Q4U *>(text + p);
@@ -453,14 +456,19 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
       if (!dp_ok) { bad = true; active = false; }
     }
     if (ok && hitd) {
-      // a word of the call-local memo: up to kDynMaxIds pieces; dn = count | begins with an unknown piece << 8 | ends << 9
+      // a word of the call-local memo: dn = count | kDynFirstUnk (begins with an unknown piece) | kDynLastUnk | kDynWide
       const uint32_t cntd = dn & 0xFFu;
       if (n + static_cast<int>(cntd) > cap) { bad = true; active = false; }
       else {
         B += wv::bits_to_float(ent.z);
         const uint32_t di[kDynMaxIds] = {dia.x, dia.y, dia.z, dia.w, dib.x, dib.y, dib.z, dib.w};
-        for (uint32_t k = (prev_unk && (dn & 0x100u)) ? 1u : 0u; k < cntd; ++k) put(di[k]);   // (:609-613 the run goes on)
-        prev_unk = (dn & 0x200u) != 0u;
+        const uint32_t k0d = (prev_unk && (dn & kDynFirstUnk)) ? 1u : 0u;                       // (:609-613 the run goes on)
+        if (dn & kDynWide) {                         // 9 .. 16 pieces, two to a dword (small vocabularies split rare words finely)
+          for (uint32_t k = k0d; k < cntd; ++k) put((di[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu);
+        } else {
+          for (uint32_t k = k0d; k < cntd; ++k) put(di[k]);
+        }
+        prev_unk = (dn & kDynLastUnk) != 0u;
       }
     } else if (ok && !(MODE == kWmCollect && bad)) {
       const bool two = id1 != 0xFFFFFFFFu;
@@ -478,6 +486,10 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
         prev_unk = false;
       }
     }
+    // a model that KEEPS extra whitespace (remove_extra_whitespaces off, src/normalizer.cc:88-110,160-176): a leading, a
+    // doubled or a trailing space is a space symbol of its own in the normalized text, next to other space symbols --
+    // pieces made of space symbols only may match there.  Not a word: the sentence takes the general kernels.
+    if (keep_ws && run && (L == 0 || pn == len)) { bad = true; again = false; active = false; }
     if (run && !more && !(DP && stalled)) active = false;     // the sentence is done
     if (run) { p = pn; w = wn; wvalid = wvn; }
   }
@@ -707,13 +719,14 @@ SPMX_DEVICE void resolve_unigram_lane(const ResolveArgs &a, uint32_t slot, float
   // (ids in backtrack order = last piece first; an unknown piece is unk_id, a run of them ONE id, or under byte fallback
   // the bytes of every unknown character -- sentencepiece_processor.cc:581-613; whether the word begins / ends with an
   // unknown piece is kept, so that a run can continue across words)
-  uint32_t ids[kDynMaxIds];
+  uint32_t ids[kDynMaxWide];
   int cnt = 0;
+  uint32_t id_or = 0;
   float gap = 3.0e38f, bound = 0.f;
   bool good = true;
   const bool bf = (d.flags & kNfByteFallback) != 0;
   bool last_unk = false, first_unk = false, right_unk = false;
-  auto push = [&](uint32_t id) __attribute__((always_inline)) { if (cnt < static_cast<int>(kDynMaxIds)) ids[cnt++] = id; else good = false; };
+  auto push = [&](uint32_t id) __attribute__((always_inline)) { if (cnt < static_cast<int>(kDynMaxWide)) { ids[cnt++] = id; id_or |= id; } else good = false; };
   for (int e = n; e > 0 && good;) {
     const uint32_t bw = bp[e << 6];
     const int bl = static_cast<int>((bw >> kBwLenShift) & kBwLenMask);
@@ -761,13 +774,17 @@ SPMX_DEVICE void resolve_unigram_lane(const ResolveArgs &a, uint32_t slot, float
       }
     }
   }
+  const bool wide = cnt > static_cast<int>(kDynMaxIds);
+  if (wide && id_or > 0xFFFFu) good = false;           // (more than 8 pieces AND a vocabulary beyond 65536: not kept)
   if (good) {
-    U4 ia{0, 0, 0, 0}, ib{0, 0, 0, 0};
-    uint32_t *o[8] = {&ia.x, &ia.y, &ia.z, &ia.w, &ib.x, &ib.y, &ib.z, &ib.w};
-    for (int k = 0; k < cnt; ++k) *o[k] = ids[cnt - 1 - k];
-    a.dyn_ent[4u * slot + 2u] = ia;
-    a.dyn_ent[4u * slot + 3u] = ib;
-    a.dyn_ent[4u * slot + 1u] = U4{1u, static_cast<uint32_t>(cnt) | (first_unk ? 0x100u : 0u) | (last_unk ? 0x200u : 0u),
+    uint32_t o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < cnt; ++k) {
+      const uint32_t id = ids[cnt - 1 - k];
+      if (wide) o[k >> 1] |= id << (16 * (k & 1)); else o[k] = id;
+    }
+    a.dyn_ent[4u * slot + 2u] = U4{o[0], o[1], o[2], o[3]};
+    a.dyn_ent[4u * slot + 3u] = U4{o[4], o[5], o[6], o[7]};
+    a.dyn_ent[4u * slot + 1u] = U4{1u, static_cast<uint32_t>(cnt) | (first_unk ? kDynFirstUnk : 0u) | (last_unk ? kDynLastUnk : 0u) | (wide ? kDynWide : 0u),
                                   wv::float_to_bits(bound), wv::float_to_bits(bmax)};
   } else {
     a.dyn_ent[4u * slot + 1u] = U4{2u, 0u, 0u, 0u};
@@ -790,7 +807,10 @@ SPMX_DEVICE void resolve_bpe_lane(const ResolveArgs &a, uint32_t slot, uint32_t 
     sym[n << 6] = char_lookup(d, b, 1u);
     ++n;
   }
-  for (int i = 0; i < n; ++i) if (sym[i << 6] >= kSsUnknown) good = false;          // a character without a symbol: unk
+  // a character without a symbol never merges (kernels_bpe.h pair_lookup) and is the unknown piece in the end: under byte
+  // fallback its byte's piece (sentencepiece_processor.cc:581-601) -- kept; else a run of them is one id -- not kept
+  const bool bf = (d.flags & kNfByteFallback) != 0;
+  for (int i = 0; i < n; ++i) if (sym[i << 6] >= kSsUnknown && (!bf || i == 0)) good = false;
   uint32_t alive = n >= 32 ? 0xFFFFFFFFu : (1u << n) - 1u, pmask = 0u;
   if (good) {
     for (int i = 0; i + 1 < n; ++i) {
@@ -826,25 +846,37 @@ SPMX_DEVICE void resolve_bpe_lane(const ResolveArgs &a, uint32_t slot, uint32_t 
       }
     }
   }
-  U4 ia{0, 0, 0, 0}, ib{0, 0, 0, 0};
-  uint32_t *o[8] = {&ia.x, &ia.y, &ia.z, &ia.w, &ib.x, &ib.y, &ib.z, &ib.w};
+  uint32_t ids[kDynMaxWide];
+  uint32_t id_or = 0;
   int cnt = 0;
   for (uint32_t m = alive; good && m != 0u; m &= m - 1u) {
     const int i = wv::ffs64(static_cast<uint64_t>(m)) - 1;
     const uint32_t sy = sym[i << 6];
     uint32_t f = sy;
-    if (sy >= d.n_pieces) {                          // PieceToId (:178): only the extra characters go through sym_final
-      f = d.sym_final[sy];
-      if (f & kSfControl) { good = false; break; }
-      f &= kSfIdMask;
+    if (sy >= kSsUnknown) {                          // (byte fallback, i >= 1: character i is byte i - 1 of the key)
+      f = static_cast<uint32_t>(d.byte_ids[(kw[(i - 1) >> 2] >> (8 * ((i - 1) & 3))) & 0xFFu]);
+    } else {
+      if (sy >= d.n_pieces) {                        // PieceToId (:178): only the extra characters go through sym_final
+        f = d.sym_final[sy];
+        if (f & kSfControl) { good = false; break; }
+        f &= kSfIdMask;
+      }
+      if (static_cast<int32_t>(f) == d.unk_id) { good = false; break; }
     }
-    if (static_cast<int32_t>(f) == d.unk_id || cnt >= static_cast<int>(kDynMaxIds)) { good = false; break; }
-    *o[cnt++] = f;
+    if (cnt >= static_cast<int>(kDynMaxWide)) { good = false; break; }
+    ids[cnt++] = f;
+    id_or |= f;
   }
+  const bool wide = cnt > static_cast<int>(kDynMaxIds);
+  if (wide && id_or > 0xFFFFu) good = false;
   if (good && cnt > 0) {
-    a.dyn_ent[4u * slot + 2u] = ia;
-    a.dyn_ent[4u * slot + 3u] = ib;
-    a.dyn_ent[4u * slot + 1u] = U4{1u, static_cast<uint32_t>(cnt), 0u, wv::float_to_bits(3.0e38f)};
+    uint32_t o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < cnt; ++k) {
+      if (wide) o[k >> 1] |= ids[k] << (16 * (k & 1)); else o[k] = ids[k];
+    }
+    a.dyn_ent[4u * slot + 2u] = U4{o[0], o[1], o[2], o[3]};
+    a.dyn_ent[4u * slot + 3u] = U4{o[4], o[5], o[6], o[7]};
+    a.dyn_ent[4u * slot + 1u] = U4{1u, static_cast<uint32_t>(cnt) | (wide ? kDynWide : 0u), 0u, wv::float_to_bits(3.0e38f)};
   } else {
     a.dyn_ent[4u * slot + 1u] = U4{2u, 0u, 0u, 0u};
   }

@@ -518,13 +518,19 @@ void BuildWordMemo(const ModelData &m, HostTables *t) {
   const uint32_t F = sc.flags;
   // BPE: the word-wise models only (dev.h kNfBpeWordwise), and no UNUSED piece (resegmentation, src/bpe_model.cc:175-200)
   if (m.model_type == kBpe && (!(F & kNfBpeWordwise) || (F & kNfHasUnused))) return;
-  if (!(F & kNfCompressSp) || !(F & kNfAddDummyPrefix) || !(F & kNfRemoveExtraWs) || (F & kNfWsSuffix) || (F & kNfHasUserDefined)) return;
+  // (remove_extra_whitespaces may be off -- the Llama-style models: the word loop then leaves every sentence with a leading, a
+  // doubled or a trailing space to the general kernels, kernels_word.h keep_ws)
+  if (!(F & kNfCompressSp) || !(F & kNfAddDummyPrefix) || (F & kNfWsSuffix) || (F & kNfHasUserDefined)) return;
   for (uint32_t b = 0x20; b < 0x7F; ++b)
     if (!((sc.ascii_safe[b >> 5] >> (b & 31u)) & 1u)) return;     // a charsmap rule may start with an ASCII byte
   const std::string sp(kSpaceSymbol);
-  // no piece may reach across a word boundary; no USER_DEFINED piece (its score is not a float, :979-981)
+  // no piece may reach across a word boundary -- pieces of space symbols only (allow_whitespace_only_pieces) cannot: they
+  // match inside a run of space symbols, which is never part of a word here; no USER_DEFINED piece (its score is not a
+  // float, :979-981)
   for (const auto &kv : m.pieces_map) {
-    if (kv.first.find(sp, 1) != std::string::npos) return;
+    bool all_sp = kv.first.size() % sp.size() == 0;
+    for (size_t q = 0; all_sp && q < kv.first.size(); q += sp.size()) all_sp = kv.first.compare(q, sp.size(), sp) == 0;
+    if (!all_sp && kv.first.find(sp, 1) != std::string::npos) return;
     if (m.pieces[kv.second].type == kUserDefined) return;
   }
   const double unk_score = static_cast<double>(m.min_score - 10.0f);

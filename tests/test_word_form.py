@@ -367,3 +367,158 @@ def test_gpu_plain_scan_sets_the_other_sentences_aside(model, oracle):
         if not env:
             assert int(is_odd.sum()) <= rest <= int(is_odd.sum()) + 1000, (prof, int(is_odd.sum()))
 
+
+
+# ---- (f) models that KEEP extra whitespace (Llama style), and words of 9 .. 16 pieces in the call-local memo ----------
+
+def _keep_ws(blob):
+    """The model with remove_extra_whitespaces switched off: every space of the input is a space symbol of the
+    normalized text (src/normalizer.cc:88-110,160-176)."""
+    from sentencepiece import sentencepiece_model_pb2 as pb
+    m = pb.ModelProto()
+    m.ParseFromString(blob)
+    m.normalizer_spec.remove_extra_whitespaces = False
+    return m.SerializeToString()
+
+
+def _keep_ws_models():
+    return {"bpe1k_llama": fixtures.model_blob("bpe1k_llama"), "uni32k_keep_ws": _keep_ws(fixtures.model_blob("uni32k")),
+            "bpe32k_keep_ws": _keep_ws(fixtures.model_blob("bpe32k")), "uni1k_bf_keep_ws": _keep_ws(fixtures.model_blob("uni1k_bf"))}
+
+
+def _space_shapes(words, n, seed):
+    """Sentences of vocabulary words and of fresh ones with single spaces (the word form's), and with a leading, a
+    doubled, a tripled, a trailing space, spaces only, nothing (the general kernels': the run of space symbols may be a
+    piece of its own -- allow_whitespace_only_pieces)."""
+    rng = np.random.default_rng(seed)
+    sents, single = [], []
+    for i in range(n):
+        k = int(rng.choice([1, 2, 5, 12, 30]))
+        ws = []
+        for j in rng.integers(0, len(words), size=k):
+            w = words[int(j)]
+            r = rng.random()
+            if r < 0.15:
+                w = w + words[int(rng.integers(0, len(words)))][:6]          # fresh: the call-local memo's
+            elif r < 0.25:
+                w = bytes(rng.integers(97, 123, size=int(rng.integers(3, 15))).astype(np.uint8))
+            elif r < 0.30:
+                w = w.upper()
+            ws.append(w)
+        how = i % 8
+        s = b" ".join(ws)
+        ok = True
+        if how == 1:
+            s, ok = b" " + s, False
+        elif how == 2:
+            s, ok = s + b" ", False
+        elif how == 3 and k > 1:
+            at = int(rng.integers(1, k))
+            s, ok = b" ".join(ws[:at]) + b" " * int(rng.choice([2, 3, 4, 9])) + b" ".join(ws[at:]), False
+        elif how == 4 and i % 16 == 4:
+            s, ok = b" " * int(rng.integers(1, 20)), False
+        elif how == 5 and i % 32 == 5:
+            s = b""
+        sents.append(s)
+        single.append(ok)
+    return sents, np.array(single)
+
+
+@pytest.mark.parametrize("name", ["bpe1k_llama", "uni32k_keep_ws", "bpe32k_keep_ws", "uni1k_bf_keep_ws"])
+def test_emu_models_that_keep_extra_whitespace(name, emu, oracle):
+    blob = _keep_ws_models()[name]
+    words = wordfuzz.whole_words(blob, limit=600)
+    sents, single = _space_shapes(words, 900, seed=41)
+    o = oracle.load(blob)
+    for variant in ("default", "small_classes", "no_dyn", "ids32"):
+        h = _emu_load(emu, blob, variant)
+        _check(h.encode_batch, o, sents + [b"x" * 40], "%s/%s" % (name, variant))
+        if variant == "default":
+            # the word kernels took (most of) the sentences with single spaces only, and none of the others
+            took = _word_form_sentences(h.sp)
+            assert 0.5 * int(single.sum()) < took <= int(single.sum()) + 1, (took, int(single.sum()))
+    _check(_emu_load(emu, blob, "default").encode_batch, o, wordfuzz.control_corpus(words, 400, seed=42), name + " control bytes")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["bpe1k_llama", "uni32k_keep_ws", "bpe32k_keep_ws", "uni1k_bf_keep_ws"])
+def test_gpu_models_that_keep_extra_whitespace(name, oracle):
+    blob = _keep_ws_models()[name]
+    words = wordfuzz.whole_words(blob, limit=600)
+    sents, single = _space_shapes(words, 60_000, seed=43)
+    o = oracle.load(blob)
+    for variant in ("default", "ids32"):
+        sp = _gpu_load(blob, variant)
+        sp.SetProfiling(True)
+        _check(sp.EncodePacked, o, sents + [b"x" * 40], "%s/%s" % (name, variant))
+        took = _word_form_sentences(sp)
+        assert 0.5 * int(single.sum()) < took <= int(single.sum()) + 1, (took, int(single.sum()))
+    _check(_gpu_load(blob, "default").EncodePacked, o, wordfuzz.control_corpus(words, 30000, seed=44), name + " control bytes")
+
+
+def _fine_split_words(n, seed):
+    """Words a 1000-piece vocabulary splits into many pieces: 9 .. 16 letters, rare letters, digits."""
+    rng = np.random.default_rng(seed)
+    src = b"etaoinshrdlucmfwypvbgkqjxz0123456789QZ"
+    out = []
+    for _ in range(n):
+        L = int(rng.integers(6, 17))
+        out.append(bytes(src[int(i)] for i in rng.integers(0, len(src), size=L)))
+    return out
+
+
+@pytest.mark.parametrize("model", ["uni1k", "bpe1k", "uni1k_bf", "bpe1k_llama", "test_model"])
+def test_emu_words_of_nine_to_sixteen_pieces(model, emu, oracle):
+    """The call-local memo keeps a word of up to 16 pieces (kernels_word.h kDynWide: 16-bit ids, two to a dword)."""
+    import sentencepiece as spm
+    blob = fixtures.model_blob(model)
+    ref = spm.SentencePieceProcessor(model_proto=blob)
+    unk = ref.unk_id()
+    fine = [w for w in _fine_split_words(3000, seed=51) if 9 <= len(ref.encode(w.decode())) <= 16 and unk not in ref.encode(w.decode())][:120]
+    assert len(fine) >= 40
+    words = wordfuzz.whole_words(blob, limit=300)
+    rng = np.random.default_rng(52)
+    sents = []
+    for i in range(500):
+        ws = [words[int(j)] for j in rng.integers(0, len(words), size=int(rng.integers(1, 12)))]
+        for _ in range(int(rng.integers(1, 3))):
+            ws.insert(int(rng.integers(0, len(ws) + 1)), fine[int(rng.integers(0, len(fine)))])
+        sents.append(b" ".join(ws))
+    o = oracle.load(blob)
+    for variant in ("default", "small_classes", "ids32"):
+        h = _emu_load(emu, blob, variant)
+        _check(h.encode_batch, o, sents + [b"x" * 40], "%s/%s" % (model, variant))
+        again = sum(c["sentences"] for c in h.sp.LastProfile()["classes"] if c["kernel"].startswith("EncodeWordAgain"))
+        assert again > 0.8 * len(sents), (model, variant, again)
+
+
+def test_emu_wide_entries_need_a_vocabulary_within_16_bits(emu, oracle):
+    """A vocabulary beyond 65536 pieces: a word of more than 8 pieces is not kept (its ids do not fit two to a dword),
+    its sentence takes the general kernels -- same ids."""
+    blob = fixtures.model_blob("c5_250k")
+    words = wordfuzz.whole_words(blob, limit=300)
+    fine = _fine_split_words(200, seed=53)
+    rng = np.random.default_rng(54)
+    sents = [b" ".join([words[int(j)] for j in rng.integers(0, len(words), size=6)] + [fine[int(rng.integers(0, len(fine)))]])
+             for _ in range(300)]
+    _check(_emu_load(emu, blob, "default").encode_batch, oracle.load(blob), sents + [b"x" * 40], "c5_250k")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["uni1k", "bpe1k", "uni1k_bf", "bpe1k_llama", "c5_250k"])
+def test_gpu_words_of_nine_to_sixteen_pieces(model, oracle):
+    blob = fixtures.model_blob(model)
+    words = wordfuzz.whole_words(blob, limit=300)
+    fine = _fine_split_words(4000, seed=55)
+    rng = np.random.default_rng(56)
+    sents = []
+    for i in range(60_000):
+        ws = [words[int(j)] for j in rng.integers(0, len(words), size=int(rng.integers(1, 12)))]
+        ws.insert(int(rng.integers(0, len(ws) + 1)), fine[int(rng.integers(0, len(fine)))])
+        sents.append(b" ".join(ws))
+    o = oracle.load(blob)
+    for variant in ("default", "ids32"):
+        sp = _gpu_load(blob, variant)
+        sp.SetProfiling(True)
+        _check(sp.EncodePacked, o, sents + [b"x" * 40], "%s/%s" % (model, variant))
+        assert _word_form_sentences(sp) > 0
