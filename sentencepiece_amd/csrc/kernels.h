@@ -103,7 +103,7 @@ struct EncodeArgs {
   uint32_t *left2_counts;
   // the call-local word memo (kernels_word.h): words the load-time memo lacks, segmented once per call
   unsigned long long *dyn_tag;  // [dyn_mask + 1] 64-bit hash of the word, 0: free
-  U4 *dyn_ent;                  // [dyn_mask + 1][4] {key} {state, n_ids, bound, bmax} {ids 0-3} {ids 4-7}
+  U4 *dyn_ent;                  // [dyn_mask + 1][4] {key} {state, n_ids | flags, bound, bmax} {ids 0-3} {ids 4-7} (kDynWide: 16 x 16 bits)
   uint32_t *dyn_list;           // slots taken, in order of arrival
   uint32_t *dyn_count;
   uint32_t dyn_mask;

@@ -44,15 +44,17 @@
 // collected word ONCE, one lane per word (word_resolve_block): BPE by the merge loop (exact); unigram by
 // EncodeOptimized of the word from score 0 in float with the margin analysis above done on the device (the float
 // roundings of this DP are charged to the margin).  The second round (the same word loop, now looking a missed word
-// up in the call-local table; up to 8 pieces per word) then takes those sentences.  Two different words with the same
+// up in the call-local table; up to 8 pieces per word, or 9 .. 16 as 16-bit ids: kDynWide) then takes those sentences.  Two different words with the same
 // 64-bit hash: the second finds the first's bytes in the entry, which is a miss -- its sentence takes the general
 // kernels; nothing wrong can come out.
 //
-// What the normalizer contributes is implicit: the model must add a dummy prefix, remove extra whitespace and escape
-// whitespace with the one-byte space symbol, and every byte 0x20-0x7E must be a character no charsmap rule starts with
-// (tables.cc checks all of it), so Normalize() of such a sentence is "words joined by single space symbols, one in
-// front" -- a word's normalized form is the space symbol plus its raw bytes, which is how the memo is keyed (by the raw
-// bytes alone).  Leading, trailing and doubled spaces are empty words and cost an iteration each.
+// What the normalizer contributes is implicit: the model must add a dummy prefix and escape whitespace with the
+// one-byte space symbol, and every byte 0x20-0x7E must be a character no charsmap rule starts with (tables.cc checks
+// all of it), so Normalize() of such a sentence is "words joined by single space symbols, one in front" -- a word's
+// normalized form is the space symbol plus its raw bytes, which is how the memo is keyed (by the raw bytes alone).
+// Leading, trailing and doubled spaces: a model that removes extra whitespace drops them -- empty words, an iteration
+// each; a model that KEEPS it (Llama style) has runs of space symbols there, which are not words -- such a sentence is
+// left to the general kernels (keep_ws below).
 //
 // No scratch in HBM, no back-pointers, no backtrack: ids leave in forward order through an 8-id LDS staging column as
 // 32-byte bursts.
