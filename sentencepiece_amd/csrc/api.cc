@@ -498,7 +498,7 @@ int RunClassify(spmx_handle *h, Workspace *ws, const uint64_t *d_offsets, uint32
   ca.offs = d_offsets; ca.n = n32; ca.n_classes = static_cast<uint32_t>(kNumClasses);
   if (d_text && gen_lists) {
     HIP_OR_RETURN(h, hipMemsetAsync(ws->d_flags.p, 0, n32, stream));
-    PlainScanArgs pa{d_text, text_bytes, d_offsets, n32, ws->d_flags.p};
+    PlainScanArgs pa{d_text, text_bytes, d_offsets, n32, (h->dev.flags & kNfRemoveExtraWs) ? 0u : 1u, ws->d_flags.p};
     // a workgroup (four wavefronts) takes 16 KB per step; one step each up to 2^20 workgroups (16 GB of text)
     uint64_t g = (text_bytes + 16383) / 16384;
     if (g > (1u << 20)) g = 1u << 20;

@@ -691,20 +691,42 @@ SPMX_DEVICE uint32_t nonplain_bits(uint32_t v) {
   return ((((v + 0x01010101u) | v) | ((v - 0x20202020u) & ~v)) & 0x80808080u);
 }
 
+// bit 7 of every byte of v that equals 0x20 (exact for every byte: no borrow between bytes)
+SPMX_DEVICE uint32_t space_bits(uint32_t v) {
+  const uint32_t x = v ^ 0x20202020u;
+  return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+}
+// (keep_ws) bit 7 of both bytes of every pair of neighbouring 0x20 inside the 16 bytes x, y, z, w, added to m[0 .. 3]
+SPMX_DEVICE void doubled_space_bits(uint32_t x, uint32_t y, uint32_t z, uint32_t w, uint32_t *m) {
+  const uint32_t s[4] = {space_bits(x), space_bits(y), space_bits(z), space_bits(w)};
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const uint32_t in = s[d] & (s[d] >> 8);              // byte i: bytes i and i + 1 of the dword are both spaces
+    m[d] |= in | (in << 8);
+    if (d < 3 && (s[d] >> 31) && (s[d + 1] & 0x80u)) { m[d] |= 0x80000000u; m[d + 1] |= 0x80u; }
+  }
+}
+
 // The plain scan proper: the batch's text read ONCE in address order -- the wavefronts of the launch march through it
 // side by side like a copy kernel (4 KB per wavefront and step, a wavefront a step when the text is large: the hardware's
 // own dispatch order keeps the reads in address order; a scan chunked by classify's 1024-sentence blocks, the
 // first version, had 2560 streams 128 KB apart in flight and ran at 2.5 TB/s: profiles/r04_ab_kernel_stats.txt) --
 // and flags[k] = 1 for every sentence k that holds a byte outside 0x20 .. 0x7E (flags zeroed before the launch).  The
 // owner of a flagged byte is found by a binary search over the offsets (rare: such bytes are).
+// keep_ws (a model that keeps extra whitespace, kernels_word.h): a sentence with a leading, a doubled or a trailing
+// space is not the word form's either -- flagged as well (a pair of spaces that straddles two 16-byte units is not seen
+// here: the word loop meets it and hands the sentence on, one launch later).
 constexpr int kPlainScanFlight = 4;                   // a wavefront takes 4 KB per step: 4 units of 16 bytes per lane
 struct PlainScanArgs {
   const uint8_t *text;
   uint64_t text_bytes;          // (only sizes the launch: the kernel reads [offs[0], offs[n]))
   const uint64_t *offs;         // n + 1
   uint32_t n;
+  uint32_t keep_ws;             // the model does not remove extra whitespace
   uint8_t *flags;               // n
 };
+// KEEP_WS = a.keep_ws: a kernel of its own, so that the plain form keeps its registers (64: eight wavefronts per SIMD)
+template <bool KEEP_WS>
 SPMX_DEVICE void plain_scan_block(const PlainScanArgs &a) {
   const int lane = wv::lane();
   if (a.n == 0) return;
@@ -726,6 +748,13 @@ SPMX_DEVICE void plain_scan_block(const PlainScanArgs &a) {
   constexpr int kFlight = kPlainScanFlight;           // 16-byte units in flight per lane
   const uint64_t n_waves = static_cast<uint64_t>(wv::grid_size()) * static_cast<uint64_t>(wv::waves_per_block());
   const uint64_t my_wave = static_cast<uint64_t>(wv::block_id()) * static_cast<uint64_t>(wv::waves_per_block()) + static_cast<uint64_t>(wv::wave_in_block());
+  constexpr bool keep_ws = KEEP_WS;
+  if (keep_ws) {                                      // a leading / trailing space: a lane per sentence
+    for (uint64_t i = my_wave * 64u + static_cast<uint64_t>(lane); i < a.n; i += n_waves * 64u) {
+      const uint64_t b = a.offs[i], e = a.offs[i + 1];
+      if (e > b && (a.text[b] == 0x20u || a.text[e - 1] == 0x20u)) a.flags[i] = 1;
+    }
+  }
   const uint64_t step = n_waves * 1024u * kFlight;
   auto owner = [&](uint64_t off) -> uint32_t {       // the last sentence k with offs[k] <= off (offs[0] <= off < offs[n])
     uint32_t lo = 0, hi = a.n;
@@ -749,6 +778,11 @@ SPMX_DEVICE void plain_scan_block(const PlainScanArgs &a) {
 #pragma unroll
     for (int j = 0; j < kFlight; ++j) {
       m[j] = nonplain_bits(v[j].x) | nonplain_bits(v[j].y) | nonplain_bits(v[j].z) | nonplain_bits(v[j].w);
+      if (keep_ws) {
+        uint32_t dz[4] = {0u, 0u, 0u, 0u};
+        doubled_space_bits(v[j].x, v[j].y, v[j].z, v[j].w, dz);
+        m[j] |= dz[0] | dz[1] | dz[2] | dz[3];
+      }
       any_m |= m[j];
     }
     if (any_m == 0u) continue;
@@ -756,7 +790,8 @@ SPMX_DEVICE void plain_scan_block(const PlainScanArgs &a) {
     for (int j = 0; j < kFlight; ++j) {
       if (m[j] == 0u) continue;
       const uint64_t uj = u + static_cast<uint64_t>(j) * 1024u;
-      const uint32_t z[4] = {nonplain_bits(v[j].x), nonplain_bits(v[j].y), nonplain_bits(v[j].z), nonplain_bits(v[j].w)};
+      uint32_t z[4] = {nonplain_bits(v[j].x), nonplain_bits(v[j].y), nonplain_bits(v[j].z), nonplain_bits(v[j].w)};
+      if (keep_ws) doubled_space_bits(v[j].x, v[j].y, v[j].z, v[j].w, z);
       int b_lo = -1, b_hi = -1;                       // first and last flagged byte of the unit
       for (int d = 0; d < 4; ++d)
         for (int q = 0; q < 4; ++q)
@@ -768,7 +803,8 @@ SPMX_DEVICE void plain_scan_block(const PlainScanArgs &a) {
       uint64_t o_hi = uj + static_cast<uint64_t>(b_hi) - base_addr;
       if (o_hi >= t1) o_hi = t1 - 1;
       if (t1 == t0 || o_lo >= t1 || o_lo > o_hi) continue;
-      const uint32_t k_lo = owner(o_lo), k_hi = owner(o_hi);
+      const uint32_t k_lo = owner(o_lo);
+      const uint32_t k_hi = o_hi < a.offs[k_lo + 1] ? k_lo : owner(o_hi);      // (mostly the same sentence)
       a.flags[k_lo] = 1;
       a.flags[k_hi] = 1;
       if (k_hi - k_lo <= 17u) for (uint32_t k = k_lo + 1; k < k_hi; ++k) a.flags[k] = 1;   // (more than that between two bytes of a unit: empty sentences)

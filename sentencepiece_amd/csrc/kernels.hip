@@ -95,7 +95,8 @@ __global__ __launch_bounds__(64) void SplitWriteKernel(SplitArgs a) {
 }
 __global__ __launch_bounds__(64) void DecodeCountKernel(DecodeArgs a) { decode_block<false>(a); }
 __global__ __launch_bounds__(64) void DecodeWriteKernel(DecodeArgs a) { decode_block<true>(a); }
-__global__ __launch_bounds__(256) void PlainScanKernel(PlainScanArgs a) { plain_scan_block(a); }
+__global__ __launch_bounds__(256) void PlainScanKernel(PlainScanArgs a) { plain_scan_block<false>(a); }
+__global__ __launch_bounds__(256) void PlainScanKeepWsKernel(PlainScanArgs a) { plain_scan_block<true>(a); }
 __global__ __launch_bounds__(64) void ClassifyCountKernel(ClassifyArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[kClassifyLdsWords];
   classify_block<0>(a, lds);
@@ -226,7 +227,8 @@ hipError_t LaunchDecode(bool write, const DecodeArgs &a, int grid, hipStream_t s
 }
 
 hipError_t LaunchPlainScan(const PlainScanArgs &a, int grid, hipStream_t stream) {
-  hipLaunchKernelGGL(PlainScanKernel, dim3(grid), dim3(256), 0, stream, a);      // (four wavefronts per workgroup)
+  if (a.keep_ws) hipLaunchKernelGGL(PlainScanKeepWsKernel, dim3(grid), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(PlainScanKernel, dim3(grid), dim3(256), 0, stream, a);      // (four wavefronts per workgroup)
   return hipGetLastError();
 }
 

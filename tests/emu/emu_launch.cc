@@ -102,7 +102,8 @@ hipError_t LaunchDecode(bool write, const DecodeArgs &a, int grid, hipStream_t) 
   return hipSuccess;
 }
 hipError_t LaunchPlainScan(const PlainScanArgs &a, int grid, hipStream_t) {
-  RunGrid(grid, 4, 0, [&](unsigned char *) { plain_scan_block(a); });
+  if (a.keep_ws) RunGrid(grid, 4, 0, [&](unsigned char *) { plain_scan_block<true>(a); });
+  else RunGrid(grid, 4, 0, [&](unsigned char *) { plain_scan_block<false>(a); });
   return hipSuccess;
 }
 hipError_t LaunchClassify(const ClassifyArgs &a, int grid, hipStream_t) {
