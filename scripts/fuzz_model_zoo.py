@@ -123,6 +123,34 @@ def main():
             except Exception as e:
                 bad += 1
                 print("EXC seed", seed, opts, env, repr(e)[:200], flush=True)
+        # the other entry points of the path's neighbourhood against the ORACLE (which is itself compared with the compiled
+        # reference on the same input first: a model the restatement gets wrong must show up as that, not as a kernel bug)
+        try:
+            o = orc.load(blob)
+            xi, xo = o.encode_batch(text, offs)
+            if ref is not None and wordfuzz.first_difference(np.asarray(xi), np.asarray(xo), np.asarray(oi), np.asarray(oo)) >= 0:
+                bad += 1
+                print("ORACLE != REFERENCE seed", seed, opts, flush=True)
+            h = em.load(blob, cus=2)
+            short = [s for s in sents if len(s) <= 4000]
+            t2, o2 = synth.pack(short)
+            got, want = h.encode_spans(t2, o2), o.encode_spans(t2, o2)
+            if h.status or not all(np.array_equal(np.asarray(a).astype(np.int64), np.asarray(b).astype(np.int64)) for a, b in zip(got, want)):
+                bad += 1
+                print("SPANS MISMATCH seed", seed, opts, flush=True)
+            a, b = h.normalize_batch(t2, o2), o.normalize_batch(t2, o2)
+            if not all(np.array_equal(x, y) for x, y in zip(a, b)):
+                bad += 1
+                print("NORMALIZE MISMATCH seed", seed, opts, flush=True)
+            di, do = o.encode_batch(t2, o2)
+            dt, dd = h.decode_batch(di, do)
+            et, ed = o.decode_batch(di, do)
+            if not (np.array_equal(dt, et) and np.array_equal(dd, ed)):
+                bad += 1
+                print("DECODE MISMATCH seed", seed, opts, flush=True)
+        except Exception as e:
+            bad += 1
+            print("EXC(other entry points) seed", seed, opts, repr(e)[:200], flush=True)
         n_models += 1
         if n_models % 10 == 0:
             print("seed", seed, "models", n_models, "bad", bad, "sentence encodings", n_sent, "word-form share %.3f" % (n_word / max(1, n_sent)), flush=True)
