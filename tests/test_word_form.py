@@ -445,6 +445,21 @@ def test_emu_models_that_keep_extra_whitespace(name, emu, oracle):
     _check(_emu_load(emu, blob, "default").encode_batch, o, wordfuzz.control_corpus(words, 400, seed=42), name + " control bytes")
 
 
+def test_oracle_keeps_whitespace_like_the_reference(oracle):
+    """The checker itself on these models and inputs, against the compiled reference (where it is built)."""
+    from tests import refshim
+    if not refshim.available():
+        pytest.skip("compiled reference not built here")
+    for name, blob in _keep_ws_models().items():
+        words = wordfuzz.whole_words(blob, limit=600)
+        sents = _space_shapes(words, 4000, seed=45)[0] + wordfuzz.control_corpus(words, 1000, seed=46)
+        text, offs = synth.pack(sents)
+        oids, oio = oracle.load(blob).encode_batch(text, offs)
+        rids, rio = refshim.RefLib().load(blob).encode_batch(text, offs, threads=8)
+        np.testing.assert_array_equal(oio, rio, err_msg=name)
+        np.testing.assert_array_equal(oids, rids, err_msg=name)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["bpe1k_llama", "uni32k_keep_ws", "bpe32k_keep_ws", "uni1k_bf_keep_ws"])
 def test_gpu_models_that_keep_extra_whitespace(name, oracle):
