@@ -123,6 +123,33 @@ def main():
             except Exception as e:
                 bad += 1
                 print("EXC seed", seed, opts, env, repr(e)[:200], flush=True)
+        # extra options (bos / eos / reverse) and a restricted vocabulary (SetVocabulary: pieces outside it are resegmented or
+        # become unused, src/sentencepiece_processor.cc:339-372), the reference's own switches on both sides
+        try:
+            h = em.load(blob, cus=2)
+            from sentencepiece import sentencepiece_model_pb2 as pb
+            mp = pb.ModelProto()
+            mp.ParseFromString(blob)
+            normal = [p.piece for p in mp.pieces if p.type == 1]
+            keep = [normal[int(i)] for i in rng.choice(len(normal), size=max(1, len(normal) // int(rng.choice([2, 3, 10]))), replace=False)]
+            for step in ("opts", "vocab", "reset"):
+                if step == "opts":
+                    x = str(rng.choice(["bos", "eos", "bos:eos", "reverse", "reverse:bos:eos"]))
+                    h.set_encode_extra_options(x); chk.set_encode_extra_options(x)
+                elif step == "vocab":
+                    h.set_vocabulary(keep); chk.set_vocabulary(keep)
+                else:
+                    h.reset_vocabulary(); chk.reset_vocabulary()
+                ids, io = h.encode_batch(text, offs)
+                oi2, oo2 = chk.encode_batch(text, offs, threads=2) if ref is not None else chk.encode_batch(text, offs)
+                k = wordfuzz.first_difference(np.asarray(ids), np.asarray(io), np.asarray(oi2), np.asarray(oo2))
+                if h.status or k >= 0:
+                    bad += 1
+                    print("MISMATCH(%s) seed" % step, seed, opts, "sentence", k, repr(sents[k][:80]) if k >= 0 else "", "status", h.status, flush=True)
+            chk.set_encode_extra_options("")
+        except Exception as e:
+            bad += 1
+            print("EXC(options) seed", seed, opts, repr(e)[:200], flush=True)
         # the other entry points of the path's neighbourhood against the ORACLE (which is itself compared with the compiled
         # reference on the same input first: a model the restatement gets wrong must show up as that, not as a kernel bug)
         try:
