@@ -175,6 +175,22 @@ def main():
             if not (np.array_equal(dt, et) and np.array_equal(dd, ed)):
                 bad += 1
                 print("DECODE MISMATCH seed", seed, opts, flush=True)
+            # NBestEncode of short sentences (unigram models): ids and scores against the compiled reference's own
+            if opts["model_type"] == "unigram" and ref is not None:
+                from tests.test_nbest import nbest as nb_call
+                few = [s for s in sents if 0 < len(s) <= 60][:24]
+                if few:
+                    t3, o3 = synth.pack(few)
+                    kk = int(rng.choice([1, 2, 5, 9]))
+                    res = h.nbest(t3, o3, kk)
+                    for sent, r in zip(few, res):
+                        n, want, sc = nb_call(chk.lib.spmref_nbest_encode, chk.h, sent, kk)
+                        if n < 0:
+                            continue
+                        if [x[0] for x in r] != want or not np.array_equal(np.array([x[1] for x in r], dtype=np.float32), sc):
+                            bad += 1
+                            print("NBEST MISMATCH seed", seed, opts, kk, repr(sent[:60]), flush=True)
+                            break
         except Exception as e:
             bad += 1
             print("EXC(other entry points) seed", seed, opts, repr(e)[:200], flush=True)
