@@ -14,6 +14,8 @@ from tests import fixtures, oraclelib, emulib, wordfuzz
 
 MODELS = ["uni32k", "uni32k_w16", "bpe32k", "uni1k", "bpe1k", "test_model", "uni1k_bf", "bpe1k_llama",
           "uni32k+keep_ws", "bpe32k+keep_ws", "uni1k_bf+keep_ws"]     # (+keep_ws: remove_extra_whitespaces switched off)
+if os.environ.get("FUZZ_MODELS"):                       # (a campaign over other models: FUZZ_MODELS=c5_250k,c5_250k_bf)
+    MODELS = os.environ["FUZZ_MODELS"].split(",")
 EDGE_LEN = [0, 1, 2, 3, 15, 16, 17, 19, 20, 21, 23, 24, 25, 31, 32, 33, 39, 40, 41, 63, 64, 65, 127, 128, 191, 192, 193,
             447, 448, 575, 576, 577, 1279, 1535, 1536, 1537, 3328, 4095, 4096, 4097, 6000]
 WORD_LEN = [1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 10, 11, 11, 12, 13, 14, 15, 16, 16, 17, 17, 18, 20, 24, 31, 32, 33, 40, 70]

@@ -558,3 +558,34 @@ def test_emu_word_kernels_at_other_workgroup_widths(waves, emu, oracle):
     oids, oio = oracle.load(blob).encode_batch(text, offs)
     np.testing.assert_array_equal(io, oio)
     np.testing.assert_array_equal(ids, oids)
+
+
+@pytest.mark.parametrize("model", ["uni32k", "bpe32k", "bpe1k_llama", "uni1k_uds"])
+def test_offsets_beyond_four_gigabytes(model, oracle):
+    """The device form with offsets that do not start at 0 and do not fit 32 bits (a slice of a corpus of more than 4 GB
+    resident in HBM: the text pointer is the slice's address minus offsets[0], as the host forms pass it): every kernel
+    on the way -- plain scan, classify, word rounds, general launch, scan, compact -- does its offset arithmetic in 64 bits."""
+    import ctypes as C
+    from sentencepiece_amd import synth
+    from tests import emulib, wordfuzz
+    em = emulib.EmuLib()
+    lib = em.lib
+    blob = fixtures.model_blob(model)
+    h = em.load(blob, classes=None)
+    text, offs = synth.ascii_corpus(3000, seed=9)
+    oi, oo = oracle.load(blob).encode_batch(text, offs)
+    n = len(offs) - 1
+    lib.spmx_encode_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                             C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+    for base in ((1 << 32) - 3, (1 << 33) + 7, (1 << 40) + 1):
+        buf = np.zeros(len(text) + 64, dtype=np.uint8)
+        buf[16:16 + len(text)] = text
+        o2 = offs.astype(np.uint64) + np.uint64(base)
+        ptr = (buf.ctypes.data + 16 - base) & ((1 << 64) - 1)
+        ids = np.zeros(len(text) + 64, dtype=np.int32)
+        io = np.zeros(n + 1, dtype=np.uint64)
+        tot = C.c_uint64(0)
+        rc = lib.spmx_encode_batch_device(h.sp._h, C.c_void_p(ptr), len(text), o2.ctypes.data, n, ids.ctypes.data, len(ids),
+                                          io.ctypes.data, None, C.byref(tot))
+        assert rc == 0, (base, lib.spmx_last_error(None))
+        assert wordfuzz.first_difference(ids[:tot.value], io, np.asarray(oi), np.asarray(oo)) < 0, base
