@@ -263,7 +263,8 @@ struct spmx_handle {
   DevBuf<uint32_t> d_ndarts, d_npair, d_sym_final, d_dec_info, d_dec_off;
   DevBuf<uint8_t> d_dec_bytes;
   DevBuf<uint8_t> d_nblob, d_plen;
-  DevBuf<U4> d_ptrie, d_chartab, d_pairtab, d_wordtab, d_umemo, d_umemo16, d_uhot;
+  DevBuf<U4> d_ptrie, d_chartab, d_pairtab, d_wordtab, d_umemo, d_umemo16, d_uhot, d_uall, d_uhot2;
+  DevBuf<uint16_t> d_udisp;
   DevBuf<float> d_pscore;
   DevBuf<U2> d_utrie;
   DevBuf<uint16_t> d_sym_len;
@@ -294,6 +295,7 @@ struct spmx_handle {
   uint64_t nbest_budget = 32ull << 30;  // SPMX_NBEST_BUDGET_GB: HBM the lattice slices of one launch may take (200 k sentences, n-best 5: 0.83 M sentences/s at 8 GB, 1.15 M at 32, 1.19 M at 96)
   uint32_t nbest_hyps_min = 16384;   // SPMX_NBEST_HYPS_MIN: hypotheses a lane's A* may hold in the first launch (what outgrows it runs again)
   uint32_t tile_min_lanes = 1;   // SPMX_TILE_MIN_LANES: a main tile has at least this many sentences even when that leaves wavefronts without a tile of the class
+  int fork_cus = 0;              // SPMX_FORK_CUS: the general launch beside the word rounds takes at most this many CUs (0: every CU)
   int fork_waves = 4;            // SPMX_FORK_WAVES: wavefronts per workgroup of the general launch while it runs next to the first word round (0: by its size)
   bool no_overlap = false;       // SPMX_NO_OVERLAP=1: the general launches do not run next to the word rounds
   bool no_ids16 = false;         // SPMX_NO_IDS16=1: the word kernels write 32-bit ids into the arena whatever the vocabulary's size
@@ -304,6 +306,8 @@ struct spmx_handle {
   bool no_uni_wave = false;      // SPMX_NO_UNI_WAVE=1: unigram models never take the wave-cooperative form (kernels_uniwave.h)
   uint32_t uni_wave_max = 0;     // SPMX_UNI_WAVE_MAX: a staged class with fewer sentences than this takes the wave-cooperative form
   int word_wgs = 1;              // SPMX_WORD_WGS: workgroups per CU of the word kernel's first pass
+  int word_form = 3;             // SPMX_WORD_WAVE: which word rounds take the word-per-lane form (kernels_wordwave.h): bit 0 the first, bit 1 the second; 0: the sentence-per-lane loops
+  int wordwave_waves = 12;       // SPMX_WORDWAVE_WAVES: wavefronts per workgroup of the word-per-lane kernels
   int word_waves = 12;           // SPMX_WORD_WAVES: wavefronts per workgroup of the word kernels (C2 step: 16 -> 8.60 ms, 14 -> 8.39, 12 -> 8.37, 10 -> 8.52, 8 -> 8.90)
   int tile_waves_override = 0;   // SPMX_TILE_WAVES: cap on wavefronts per workgroup of the streaming kernels
   uint32_t lane_general_min_lanes = 0;   // SPMX_LANE_GENERAL_MIN_LANES (0: per class)
@@ -389,6 +393,9 @@ int UploadTables(spmx_handle *h) {
   HIP_OR_RETURN(h, Upload(&h->d_wordtab, t.wordtab));
   HIP_OR_RETURN(h, Upload(&h->d_umemo, t.umemo));
   HIP_OR_RETURN(h, Upload(&h->d_umemo16, t.umemo16));
+  HIP_OR_RETURN(h, Upload(&h->d_uall, t.uall));
+  HIP_OR_RETURN(h, Upload(&h->d_udisp, t.udisp));
+  HIP_OR_RETURN(h, Upload(&h->d_uhot2, t.uhot2));
   HIP_OR_RETURN(h, Upload(&h->d_uhot, t.uhot));
   HIP_OR_RETURN(h, Upload(&h->d_pscore, t.pscore));
   HIP_OR_RETURN(h, Upload(&h->d_sym_final, t.sym_final));
@@ -409,6 +416,9 @@ int UploadTables(spmx_handle *h) {
   h->dev.wordtab = h->d_wordtab.p;
   h->dev.umemo = h->d_umemo.p;
   h->dev.umemo16 = h->d_umemo16.p;
+  h->dev.uall = h->d_uall.p;
+  h->dev.udisp = h->d_udisp.p;
+  h->dev.uhot2 = h->d_uhot2.p;
   h->dev.uhot = h->d_uhot.p;
   h->dev.pscore = h->d_pscore.p;
   h->dev.sym_final = h->d_sym_final.p;
@@ -446,6 +456,12 @@ int RefreshDevice(spmx_handle *h, bool types_changed) {
     // switches it off, ResetVocabulary switches it back on with full-size tables and masks)
     HIP_OR_RETURN(h, Upload(&h->d_umemo, t.umemo));
     HIP_OR_RETURN(h, Upload(&h->d_umemo16, t.umemo16));
+    HIP_OR_RETURN(h, Upload(&h->d_uall, t.uall));
+    HIP_OR_RETURN(h, Upload(&h->d_udisp, t.udisp));
+    HIP_OR_RETURN(h, Upload(&h->d_uhot2, t.uhot2));
+  HIP_OR_RETURN(h, Upload(&h->d_uhot2, t.uhot2));
+  HIP_OR_RETURN(h, Upload(&h->d_udisp, t.udisp));
+  HIP_OR_RETURN(h, Upload(&h->d_uhot2, t.uhot2));
     HIP_OR_RETURN(h, Upload(&h->d_uhot, t.uhot));
     HIP_OR_RETURN(h, Upload(&h->d_pscore, t.pscore));
     HIP_OR_RETURN(h, Upload(&h->d_dec_info, t.dec_info));
@@ -456,7 +472,7 @@ int RefreshDevice(spmx_handle *h, bool types_changed) {
   d.ndarts = h->dev.ndarts; d.nblob = h->dev.nblob; d.npair = h->dev.npair; d.ptrie = h->d_ptrie.p; d.plen = h->d_plen.p; d.utrie = h->dev.utrie;
   d.chartab = h->dev.chartab; d.pairtab = h->dev.pairtab; d.wordtab = h->dev.wordtab; d.sym_final = h->d_sym_final.p;
   d.sym_len = h->dev.sym_len; d.byte_ids = h->dev.byte_ids;
-  d.umemo = h->d_umemo.p; d.umemo16 = h->d_umemo16.p; d.uhot = h->d_uhot.p; d.pscore = h->d_pscore.p;
+  d.umemo = h->d_umemo.p; d.umemo16 = h->d_umemo16.p; d.uall = h->d_uall.p; d.udisp = h->d_udisp.p; d.uhot2 = h->d_uhot2.p; d.uhot = h->d_uhot.p; d.pscore = h->d_pscore.p;
   d.dec_info = h->d_dec_info.p; d.dec_off = h->d_dec_off.p; d.dec_bytes = h->d_dec_bytes.p;
   h->dev = d;
   return kOk;
@@ -467,7 +483,7 @@ void DestroyHandle(spmx_handle *h) {
   (void)hipSetDevice(h->device);
   h->d_ndarts.Free(); h->d_npair.Free(); h->d_sym_final.Free(); h->d_nblob.Free(); h->d_ptrie.Free(); h->d_chartab.Free();
   h->d_pairtab.Free(); h->d_wordtab.Free(); h->d_utrie.Free(); h->d_sym_len.Free(); h->d_byte_ids.Free();
-  h->d_dec_info.Free(); h->d_dec_off.Free(); h->d_dec_bytes.Free(); h->d_plen.Free(); h->d_umemo.Free(); h->d_umemo16.Free(); h->d_uhot.Free(); h->d_pscore.Free();
+  h->d_dec_info.Free(); h->d_dec_off.Free(); h->d_dec_bytes.Free(); h->d_plen.Free(); h->d_umemo.Free(); h->d_umemo16.Free(); h->d_uall.Free(); h->d_udisp.Free(); h->d_uhot2.Free(); h->d_uhot.Free(); h->d_pscore.Free();
   h->dn_ndarts.Free(); h->dn_npair.Free(); h->dn_nblob.Free(); h->dn_utrie.Free();
   h->pool.clear();
   delete h;
@@ -529,7 +545,7 @@ struct StreamPlan {
 // (classes outside the range get no tiles); tcap_of(c) gives a class's text-column capacity.
 template <typename TcapFn>
 StreamPlan PlanStream(const spmx_handle *h, EncodeArgs *a, const uint32_t *counts, int c_lo, int c_hi, int n_classes,
-                      const uint32_t *rcaps, TcapFn tcap_of, bool all_general, int waves_cap = 0) {
+                      const uint32_t *rcaps, TcapFn tcap_of, bool all_general, int waves_cap = 0, int cus_cap = 0) {
   StreamPlan sp;
   const int model = h->model.model_type;
   const uint32_t ring = HandleRing(h);
@@ -748,6 +764,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
     a.no_char_norm = h->char_norm_mode;
     // one streaming launch over the classes [c_lo, c_hi) (or, exact: over the overflow list with exact capacities)
     int stream_waves_cap = 0;            // (set while a launch has to share the CUs with the second word round)
+    int stream_cus_cap = 0;
     auto stream_launch = [&](int slot, int qi, int c_lo, int c_hi, const uint32_t *counts, bool exact, uint64_t exact_raw) -> int {
       EncodeArgs la = a;
       uint32_t rc2[kMaxClasses];
@@ -764,7 +781,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         // the last class of the table takes every longer sentence too: those go straight to the overflow list
         sp = PlanStream(h, &la, counts, c_lo, c_hi, ncls, rc2,
                         [&](int c) { return esc3 ? 2u * cls[c].rcap + 64u : (h->wide_tcap ? cls[c].ncap : cls[c].rcap + cls[c].rcap / 4u + 16u); }, !fast_ok,
-                        stream_waves_cap);
+                        stream_waves_cap, stream_cus_cap);
       }
       if (la.total_main == 0) return kOk;
       la.q = &ws->d_ctrl->q[qi];
@@ -941,6 +958,16 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
           for (int c = 0; c < ncls; ++c) gt += (static_cast<uint64_t>(gen_known[c]) + 63) / 64;
           const uint64_t per_cu = (gt + static_cast<uint64_t>(h->n_cu) - 1) / static_cast<uint64_t>(h->n_cu);
           stream_waves_cap = h->fork_waves ? h->fork_waves : static_cast<int>(per_cu < 4 ? 4 : (per_cu > 12 ? 12 : per_cu));
+          stream_cus_cap = h->fork_cus;
+          // Beside the word-per-lane round (kernels_wordwave.h: 12 wavefronts and 156 KB of LDS per workgroup) nothing
+          // else fits a CU: the general launch gets CUs of its own instead -- 32 of them at full width (it is bound by
+          // the latency of its longest sentences: 2.7 ms there against 2.3 ms on all 256), the word round the others and,
+          // when those workgroups end, these (C2: 6.65 ms a step against 8.4 with 4 wavefronts on every CU;
+          // gpurun_out r05h, profiles/r05_fork_ab.txt)
+          if ((h->word_form & 1) && !h->no_word_dyn && h->fork_waves == 4 && h->fork_cus == 0) {
+            stream_waves_cap = 16;
+            stream_cus_cap = h->n_cu >= 64 ? 32 : (h->n_cu / 8 > 0 ? h->n_cu / 8 : 1);
+          }
         }
         int rc = kOk;
         for (int c = 0; c < ncls && rc == kOk; ++c)
@@ -953,6 +980,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
           if (hipError_t e = hipEventRecord(ws->ev_join, stream); e != hipSuccess) { (void)hipStreamSynchronize(ws->stream2); return FailHip(h, e, "hipEventRecord(join)"); }
           stream = main_stream;
           stream_waves_cap = 0;
+          stream_cus_cap = 0;
         } else if (rc != kOk) {
           return rc;
         }
@@ -981,7 +1009,8 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
                            uint32_t *d_out2_counts) -> int {
         const bool dp = mode == 3;
         EncodeArgs wa = a;
-        const int waves = dp ? 8 : h->word_waves;
+        const bool wform = !dp && ((mode == 2 ? h->word_form & 2 : h->word_form & 1) != 0);   // word per lane
+        const int waves = dp ? 8 : wform ? h->wordwave_waves : h->word_waves;
         uint64_t total = 0;
         for (int c = 0; c < ncls; ++c) total += known[c];
         if (total == 0) return kOk;
@@ -1023,9 +1052,11 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         wa.resume = ws->d_resume.p;
         wa.ids16 = (h->model.pieces.size() <= 65536 && !h->no_ids16) ? 1u : 0u;
         snprintf(ws->slot_name[slot], sizeof(ws->slot_name[slot]), "%s",
-                 mode == 3 ? "EncodeWordDpKernel" : mode == 2 ? "EncodeWordAgainKernel" : mode == 1 ? "EncodeWordCollectKernel" : "EncodeWordKernel");
+                 wform ? (mode == 2 ? "EncodeWordWaveAgainKernel" : mode == 1 ? "EncodeWordWaveCollectKernel" : "EncodeWordWaveKernel")
+                       : mode == 3 ? "EncodeWordDpKernel" : mode == 2 ? "EncodeWordAgainKernel" : mode == 1 ? "EncodeWordCollectKernel" : "EncodeWordKernel");
         HIP_OR_RETURN(h, record(slot, 0));
-        HIP_OR_RETURN(h, LaunchEncodeWord(mode, wa, static_cast<int>(grid), waves, WordLdsBytes(waves, dp), stream));
+        if (wform) HIP_OR_RETURN(h, LaunchEncodeWordWave(mode, wa, static_cast<int>(grid), waves, WordWaveLdsBytes(waves), stream));
+        else HIP_OR_RETURN(h, LaunchEncodeWord(mode, wa, static_cast<int>(grid), waves, WordLdsBytes(waves, dp), stream));
         HIP_OR_RETURN(h, record(slot, 1));
         ws->slot_used[slot] = true;
         return kOk;
@@ -1450,6 +1481,7 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_NO_WORD_DYN")) h->no_word_dyn = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_OVERLAP")) h->no_overlap = e[0] == '1';
     if (const char *e = getenv("SPMX_FORK_WAVES")) h->fork_waves = atoi(e);
+    if (const char *e = getenv("SPMX_FORK_CUS")) h->fork_cus = atoi(e);
     if (const char *e = getenv("SPMX_NO_SCAN")) h->no_scan = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_IDS16")) h->no_ids16 = e[0] == '1';
     if (const char *e = getenv("SPMX_DYN_SLOTS_LOG2")) { const int v = atoi(e); if (v >= 4 && v <= 26) h->dyn_slots = 1u << v; }
@@ -1475,6 +1507,8 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_FORCE_RING")) { const int v = atoi(e); if (v >= 16 && v <= 122) h->ring_override = static_cast<uint32_t>(v); }
 #endif
     if (const char *e = getenv("SPMX_UNI_WAVE_MAX")) h->uni_wave_max = static_cast<uint32_t>(atoll(e));
+    if (const char *e = getenv("SPMX_WORD_WAVE")) { const int v = atoi(e); if (v >= 0 && v <= 3) h->word_form = v; }
+    if (const char *e = getenv("SPMX_WORDWAVE_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 12) h->wordwave_waves = v; }
     if (const char *e = getenv("SPMX_WORD_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 16) h->word_waves = v; }
     if (const char *e = getenv("SPMX_ARENA_FIRST")) h->arena_first = static_cast<uint64_t>(atoll(e));
     if (const char *e = getenv("SPMX_NO_LANE_GENERAL")) h->no_lane_general = e[0] == '1';

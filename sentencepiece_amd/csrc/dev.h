@@ -123,11 +123,22 @@ struct SpmxDev {
   //   umemo    the other words (two pieces, 13 .. 16 bytes): two U4 {16 key bytes, 0x20 padded} {id0, id1 or 0xFFFFFFFF, sc0 + sc1
   //            (float bits), bmax (float bits)}; empty: id0 == 0xFFFFFFFF.
   // Open addressing on HashWordKey.  pscore: score per piece id (the second pass replays the exact score).
+  //   uhot2    the kWordHotSlots likeliest words of umemo16 again, direct-mapped on HashWordKey of the whole 16-byte key
+  //            (the word-per-lane kernels need that hash anyway).
+  //   uall     EVERY word of the memo in umemo's 32-byte format behind a PERFECT hash (hash, displace: UallSlot below):
+  //            the bucket UallHash2(key) & (kUallBuckets - 1) names a displacement udisp[bucket] (the kernels keep the
+  //            8 KB of them in LDS), and the word -- if the memo has it -- sits at exactly one slot: the word-per-lane
+  //            kernels (kernels_wordwave.h) find a word that is not in the LDS table by ONE probe, and a word the memo
+  //            lacks costs one probe too (no walk: a wavefront's lanes wait for its longest).  uall_perfect = 0 (a
+  //            vocabulary too large for 4096 buckets): open addressing on HashWordKey, walked.
   const U4 *umemo16;
   const U4 *uhot;
   const U4 *umemo;
+  const U4 *uall;
+  const U4 *uhot2;
+  const uint16_t *udisp;   // [kUallBuckets]
   const float *pscore;
-  uint32_t umemo16_mask, umemo_mask;
+  uint32_t umemo16_mask, umemo_mask, uall_mask, uall_perfect;
   uint32_t n_pieces;      // symbols below this are piece ids (their own final id); the rest are extra characters
   int32_t model_type;     // 1 unigram, 2 bpe
 };
@@ -154,6 +165,17 @@ SPMX_HD inline uint32_t HashWordKey(uint32_t k0, uint32_t k1, uint32_t k2, uint3
   const uint32_t g = h * 0x9E3779B1u;
   return g ^ (g >> 15);
 }
+// the perfect hash of `uall` (dev.h SpmxDev): where the key with hashes h1 = HashWordKey, h2 = UallHash2 sits under its
+// bucket's displacement d.  UallHash2 mixes the bytes another way than HashWordKey does (two keys that agree in one
+// differ in the other), at the cost of a few rotates: no second multiply.
+constexpr uint32_t kUallBuckets = 4096;
+SPMX_HD inline uint32_t UallHash2(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t h1) {
+  const uint32_t m = k0 ^ ((k1 << 7) | (k1 >> 25)) ^ ((k2 << 13) | (k2 >> 19)) ^ ((k3 << 21) | (k3 >> 11));
+  const uint32_t t = m ^ ((h1 << 11) | (h1 >> 21));
+  return t ^ (t >> 16) ^ (t >> 7);
+}
+SPMX_HD inline uint32_t UallBucket(uint32_t h2) { return h2 & (kUallBuckets - 1u); }
+SPMX_HD inline uint32_t UallSlot(uint32_t h1, uint32_t h2, uint32_t d, uint32_t mask) { return (h1 + d * ((h2 >> 12) | 1u)) & mask; }
 constexpr uint32_t kWordKeyBytes = 16;   // words longer than this are not looked up
 constexpr uint32_t kMemo16TwoPiece = 1u << 23;   // umemo16 meta word: the entry is of the two-piece form (a word of up to 10 bytes)
 constexpr uint32_t kWordMaxIds = 3;

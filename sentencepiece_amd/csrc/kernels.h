@@ -1008,6 +1008,7 @@ SPMX_DEVICE void compact_block(const CompactArgs &a) {
 #include "kernels_bpe_stream.h"
 #include "kernels_stream.h"
 #include "kernels_word.h"
+#include "kernels_wordwave.h"
 #include "kernels_decode.h"
 #include "kernels_split.h"
 #include "kernels_align.h"

@@ -43,6 +43,22 @@ __global__ __launch_bounds__(1024) void EncodeWordAgainKernel(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   encode_word_block<false, kWmDyn>(a, smem);
 }
+// word per lane (kernels_wordwave.h); H16: 16-bit ids in the arena slots (EncodeArgs::ids16)
+template <bool H16>
+__global__ __launch_bounds__(768) void EncodeWordWaveKernel(EncodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  encode_wordwave_block<kWmPlain, H16>(a, smem);
+}
+template <bool H16>
+__global__ __launch_bounds__(768) void EncodeWordWaveCollectKernel(EncodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  encode_wordwave_block<kWmCollect, H16>(a, smem);
+}
+template <bool H16>
+__global__ __launch_bounds__(768) void EncodeWordWaveAgainKernel(EncodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  encode_wordwave_block<kWmDyn, H16>(a, smem);
+}
 __global__ __launch_bounds__(512) void EncodeWordDpKernel(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   encode_word_block<true, kWmPlain>(a, smem);
@@ -154,6 +170,17 @@ hipError_t LaunchEncodeStream(int model_type, bool uds, const EncodeArgs &a, int
 
 hipError_t LaunchEncodeWord(int mode, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t stream) {
   void (*fn)(EncodeArgs) = mode == 3 ? EncodeWordDpKernel : mode == 2 ? EncodeWordAgainKernel : mode == 1 ? EncodeWordCollectKernel : EncodeWordKernel;
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds_bytes));
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * waves), lds_bytes, stream, a);
+  return hipGetLastError();
+}
+hipError_t LaunchEncodeWordWave(int mode, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t stream) {
+  void (*fn)(EncodeArgs) = a.ids16 ? (mode == 2 ? EncodeWordWaveAgainKernel<true> : mode == 1 ? EncodeWordWaveCollectKernel<true> : EncodeWordWaveKernel<true>)
+                                   : (mode == 2 ? EncodeWordWaveAgainKernel<false> : mode == 1 ? EncodeWordWaveCollectKernel<false> : EncodeWordWaveKernel<false>);
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds_bytes));

@@ -77,7 +77,8 @@ constexpr uint32_t kDynProbes = 24;                             // slots tried b
 // call-local memo up (second round)
 enum { kWmPlain = 0, kWmCollect = 1, kWmDyn = 2 };
 SPMX_DEVICE unsigned long long DynTag(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
-  const unsigned long long t = (static_cast<unsigned long long>(HashWordKey(k0, k1, k2, k3)) << 32) | HashWord(k0, k1, k2, k3);
+  const uint32_t h1 = HashWordKey(k0, k1, k2, k3);
+  const unsigned long long t = (static_cast<unsigned long long>(h1) << 32) | UallHash2(k0, k1, k2, k3, h1);
   return t | 1ull;                                              // (0 means "free")
 }
 SPMX_HD inline uint32_t WordLdsPerWave(bool dp) {

@@ -38,6 +38,8 @@ hipError_t LaunchEncodeStream(int model_type, bool uds, const EncodeArgs &a, int
 // The word kernel (kernels_word.h): unigram models with kNfUniWordwise
 // mode: 0 plain first pass, 1 collecting first pass, 2 second round over the call-local memo, 3 the DP pass
 hipError_t LaunchEncodeWord(int mode, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t stream);
+// the word-per-lane form of the same rounds (kernels_wordwave.h): mode 0 plain, 1 collecting, 2 second round
+hipError_t LaunchEncodeWordWave(int mode, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t stream);
 hipError_t LaunchWordResolve(const ResolveArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchBpeLong(const LongArgs &a, int grid, hipStream_t stream);
 // The wave-cooperative unigram form (kernels_uniwave.h): one sentence per 64-thread workgroup; cands = candidate-row entries

@@ -507,7 +507,13 @@ void BuildWordMemo(const ModelData &m, HostTables *t) {
   t->umemo.assign(2, U4{0, 0, 0, 0});
   t->umemo[1].x = 0xFFFFFFFFu;
   t->umemo16.assign(1, U4{0, 0, 0, 0xFFFFFFFFu});
+  t->uall.assign(2, U4{0, 0, 0, 0});
+  t->uall[1].x = 0xFFFFFFFFu;
+  sc.uall_mask = 0;
+  sc.uall_perfect = 0;
+  t->udisp.assign(kUallBuckets, 0);
   t->uhot.assign(2048, U4{0, 0, 0, 0xFFFFFFFFu});       // kWordHotSlots (kernels_word.h)
+  t->uhot2.assign(2048, U4{0, 0, 0, 0xFFFFFFFFu});
   sc.umemo_mask = 0;
   sc.umemo16_mask = 0;
   sc.flags &= ~kNfUniWordwise;
@@ -720,6 +726,8 @@ void BuildWordMemo(const ModelData &m, HostTables *t) {
       const uint32_t h = HashWordKey(e->k[0], e->k[1], e->k[2], 0u);
       U4 &hs = t->uhot[h & (static_cast<uint32_t>(t->uhot.size()) - 1u)];
       if (hs.w == 0xFFFFFFFFu) hs = U4{e->k[0], e->k[1], key2_16(*e), meta16(*e)};
+      U4 &h2s = t->uhot2[HashWordKey(e->k[0], e->k[1], e->k[2], e->k[3]) & (static_cast<uint32_t>(t->uhot2.size()) - 1u)];
+      if (h2s.w == 0xFFFFFFFFu) h2s = U4{e->k[0], e->k[1], key2_16(*e), meta16(*e)};
       uint32_t sl = h & (wsz - 1);
       while (t->umemo16[sl].w != 0xFFFFFFFFu) sl = (sl + 1) & (wsz - 1);
       t->umemo16[sl] = U4{e->k[0], e->k[1], key2_16(*e), meta16(*e)};
@@ -738,6 +746,65 @@ void BuildWordMemo(const ModelData &m, HostTables *t) {
       t->umemo[2 * sl + 1] = U4{e->id0, e->id1, FloatBits(static_cast<float>(b)), FloatBits(e->bmax)};
     }
     sc.umemo_mask = wsz - 1;
+  }
+  {   // every word in the 32-byte format (dev.h uall) behind a perfect hash: hash, displace -- the buckets largest first,
+      // each takes the first displacement that puts all of its keys on free slots
+    auto put = [&](uint32_t sl, const Ent &e) {
+      t->uall[2 * sl] = U4{e.k[0], e.k[1], e.k[2], e.k[3]};
+      t->uall[2 * sl + 1] = U4{e.id0, e.id1, FloatBits(static_cast<float>(bound2(e))), FloatBits(e.bmax)};
+    };
+    std::vector<uint32_t> h1(ents.size()), h2(ents.size());
+    std::vector<std::vector<uint32_t>> buckets(kUallBuckets);
+    for (size_t i = 0; i < ents.size(); ++i) {
+      h1[i] = HashWordKey(ents[i].k[0], ents[i].k[1], ents[i].k[2], ents[i].k[3]);
+      h2[i] = UallHash2(ents[i].k[0], ents[i].k[1], ents[i].k[2], ents[i].k[3], h1[i]);
+      buckets[UallBucket(h2[i])].push_back(static_cast<uint32_t>(i));
+    }
+    std::vector<uint32_t> order(kUallBuckets);
+    for (uint32_t b = 0; b < kUallBuckets; ++b) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return buckets[x].size() > buckets[y].size(); });
+    bool perfect = false;
+    uint32_t wsz = NextPow2(ents.size() * 2 + 16);
+    for (int attempt = 0; attempt < 4 && !perfect && wsz <= (1u << 22); ++attempt, wsz <<= 1) {
+      t->uall.assign(static_cast<size_t>(wsz) * 2, U4{0, 0, 0, 0});
+      for (uint32_t i = 0; i < wsz; ++i) t->uall[2 * i + 1].x = 0xFFFFFFFFu;
+      std::vector<uint8_t> taken(wsz, 0);
+      std::vector<uint32_t> sl;
+      perfect = true;
+      for (uint32_t b : order) {
+        const std::vector<uint32_t> &ks = buckets[b];
+        if (ks.empty()) break;
+        bool placed = false;
+        for (uint32_t dd = 0; dd < 65536u && !placed; ++dd) {
+          sl.clear();
+          bool ok = true;
+          for (uint32_t i : ks) {
+            const uint32_t q = UallSlot(h1[i], h2[i], dd, wsz - 1);
+            if (taken[q] || std::find(sl.begin(), sl.end(), q) != sl.end()) { ok = false; break; }
+            sl.push_back(q);
+          }
+          if (!ok) continue;
+          for (size_t x = 0; x < ks.size(); ++x) { taken[sl[x]] = 1; put(sl[x], ents[ks[x]]); }
+          t->udisp[b] = static_cast<uint16_t>(dd);
+          placed = true;
+        }
+        if (!placed) { perfect = false; break; }
+      }
+      if (perfect) { sc.uall_mask = wsz - 1; sc.uall_perfect = 1; }
+    }
+    if (!perfect) {   // (a vocabulary too large for the bucket table: open addressing, likelier words first)
+      wsz = NextPow2(ents.size() * 2 + 16);
+      t->uall.assign(static_cast<size_t>(wsz) * 2, U4{0, 0, 0, 0});
+      for (uint32_t i = 0; i < wsz; ++i) t->uall[2 * i + 1].x = 0xFFFFFFFFu;
+      for (const Ent &e : ents) {
+        uint32_t q = HashWordKey(e.k[0], e.k[1], e.k[2], e.k[3]) & (wsz - 1);
+        while (t->uall[2 * q + 1].x != 0xFFFFFFFFu) q = (q + 1) & (wsz - 1);
+        put(q, e);
+      }
+      std::fill(t->udisp.begin(), t->udisp.end(), 0);
+      sc.uall_mask = wsz - 1;
+      sc.uall_perfect = 0;
+    }
   }
   sc.flags |= kNfUniWordwise;
   t->memo_words = static_cast<uint32_t>(ents.size());
@@ -835,6 +902,9 @@ void BindHostPointers(HostTables *t) {
   sc.wordtab = t->wordtab.data();
   sc.umemo = t->umemo.data();
   sc.umemo16 = t->umemo16.data();
+  sc.uall = t->uall.data();
+  sc.uhot2 = t->uhot2.data();
+  sc.udisp = t->udisp.data();
   sc.uhot = t->uhot.data();
   sc.pscore = t->pscore.data();
 }

@@ -35,6 +35,47 @@ SPMX_DEVICE double shfl(double v, int src) {
 // value of lane (lane - delta); lanes < delta keep their own value
 SPMX_DEVICE int shfl_up(int v, int delta) { return __shfl_up(v, static_cast<unsigned>(delta), 64); }
 
+// ---- cross-lane moves and scans on the DPP path (no LDS traffic; gfx9 row_shr / row_bcast / wave_shr controls) ----
+// value of lane - 1; lane 0 gets `fill`
+SPMX_DEVICE uint32_t lane_up1(uint32_t v, uint32_t fill) {
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(fill), static_cast<int>(v), 0x138, 0xF, 0xF, false));   // wave_shr:1
+}
+// value of lane + 1; lane 63 gets `fill`
+SPMX_DEVICE uint32_t lane_down1(uint32_t v, uint32_t fill) {
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(fill), static_cast<int>(v), 0x130, 0xF, 0xF, false));   // wave_shl:1
+}
+template <int CTRL, int ROWS>
+SPMX_DEVICE uint32_t dpp_or0(uint32_t v) {      // the moved value, 0 where the control names no source lane / the row is masked
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, ROWS, 0xF, false));
+}
+// inclusive prefix sum / prefix maximum over the 64 lanes (unsigned; six DPP steps: row_shr 1, 2, 4, 8, row_bcast 15, 31)
+SPMX_DEVICE uint32_t scan_add(uint32_t v) {
+  v += dpp_or0<0x111, 0xF>(v);
+  v += dpp_or0<0x112, 0xF>(v);
+  v += dpp_or0<0x114, 0xF>(v);
+  v += dpp_or0<0x118, 0xF>(v);
+  v += dpp_or0<0x142, 0xA>(v);
+  v += dpp_or0<0x143, 0xC>(v);
+  return v;
+}
+SPMX_DEVICE uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+SPMX_DEVICE uint32_t scan_max(uint32_t v) {
+  v = umax(v, dpp_or0<0x111, 0xF>(v));
+  v = umax(v, dpp_or0<0x112, 0xF>(v));
+  v = umax(v, dpp_or0<0x114, 0xF>(v));
+  v = umax(v, dpp_or0<0x118, 0xF>(v));
+  v = umax(v, dpp_or0<0x142, 0xA>(v));
+  v = umax(v, dpp_or0<0x143, 0xC>(v));
+  return v;
+}
+// A marker the optimizer cannot merge with another one: at the end of the arms of an `if` whose arms run the same code on
+// DIFFERENT register sets, it keeps the arms from being folded into one block that picks its operands by address (which
+// would put both sets into scratch memory).
+template <int N>
+SPMX_DEVICE void keep_apart() { asm volatile("; keep_apart %0" ::"n"(N)); }
+// the value of ONE lane as a scalar (src wave-uniform)
+SPMX_DEVICE uint32_t read_lane(uint32_t v, int src) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), src)); }
+
 // Orders this wave's LDS traffic: writes before the call are visible to every
 // lane's reads after it.  A wave executes in lock step, so only the compiler
 // and the LDS queue need to be fenced -- no s_barrier.
@@ -57,6 +98,7 @@ SPMX_DEVICE unsigned long long atomic_add(unsigned long long *p, unsigned long l
 SPMX_DEVICE void atomic_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }
 SPMX_DEVICE uint32_t lds_atomic_add(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }   // p in LDS
 SPMX_DEVICE void lds_atomic_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }                  // p in LDS
+SPMX_DEVICE void lds_atomic_min(uint32_t *p, uint32_t v) { atomicMin(p, v); }                // p in LDS
 SPMX_DEVICE void atomic_min(unsigned long long *p, unsigned long long v) { atomicMin(p, v); }
 SPMX_DEVICE void atomic_max(unsigned long long *p, unsigned long long v) { atomicMax(p, v); }
 SPMX_DEVICE void atomic_and(uint32_t *p, uint32_t v) { atomicAnd(p, v); }

@@ -50,6 +50,18 @@ hipError_t LaunchEncodeWord(int mode, const EncodeArgs &a, int grid, int waves, 
   else RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_word_block<false, kWmPlain>(a, s); });
   return hipSuccess;
 }
+hipError_t LaunchEncodeWordWave(int mode, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t) {
+  if (a.ids16) {
+    if (mode == 2) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_wordwave_block<kWmDyn, true>(a, s); });
+    else if (mode == 1) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_wordwave_block<kWmCollect, true>(a, s); });
+    else RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_wordwave_block<kWmPlain, true>(a, s); });
+  } else {
+    if (mode == 2) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_wordwave_block<kWmDyn, false>(a, s); });
+    else if (mode == 1) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_wordwave_block<kWmCollect, false>(a, s); });
+    else RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_wordwave_block<kWmPlain, false>(a, s); });
+  }
+  return hipSuccess;
+}
 hipError_t LaunchWordResolve(const ResolveArgs &a, int grid, hipStream_t) {
   RunGrid(grid, 1, ResolveLdsBytes(), [&](unsigned char *s) { word_resolve_block(a, s); });
   return hipSuccess;

@@ -109,6 +109,22 @@ void RunWave(int block, int grid, unsigned char *smem, const std::function<void(
         }
         break;
       case kSync: break;
+      case kLaneUp1:
+        for (int i = 63; i >= 0; --i) w.lanes[i].out = i > 0 ? w.lanes[i - 1].a : w.lanes[i].b;
+        break;
+      case kLaneDown1:
+        for (int i = 0; i < 64; ++i) w.lanes[i].out = i < 63 ? w.lanes[i + 1].a : w.lanes[i].b;
+        break;
+      case kScanAdd: {
+        uint32_t acc = 0;
+        for (int i = 0; i < 64; ++i) { acc += static_cast<uint32_t>(w.lanes[i].a); w.lanes[i].out = acc; }
+        break;
+      }
+      case kScanMax: {
+        uint32_t acc = 0;
+        for (int i = 0; i < 64; ++i) { const uint32_t v = static_cast<uint32_t>(w.lanes[i].a); if (v > acc) acc = v; w.lanes[i].out = acc; }
+        break;
+      }
       default: Fail("unknown collective");
     }
   }

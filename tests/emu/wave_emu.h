@@ -29,7 +29,7 @@
 namespace spmx {
 namespace emu {
 
-enum Op { kNone = 0, kBallot, kShfl, kShflUp, kSync };
+enum Op { kNone = 0, kBallot, kShfl, kShflUp, kSync, kLaneUp1, kLaneDown1, kScanAdd, kScanMax };
 
 struct Lane {
   void *sp = nullptr;        // saved stack pointer
@@ -87,6 +87,12 @@ inline double shfl(double v, int src) {
 inline int shfl_up(int v, int delta) {
   return static_cast<int>(static_cast<uint32_t>(emu::Collective(emu::kShflUp, static_cast<uint32_t>(v), static_cast<uint64_t>(delta))));
 }
+inline uint32_t lane_up1(uint32_t v, uint32_t fill) { return static_cast<uint32_t>(emu::Collective(emu::kLaneUp1, v, fill)); }
+inline uint32_t lane_down1(uint32_t v, uint32_t fill) { return static_cast<uint32_t>(emu::Collective(emu::kLaneDown1, v, fill)); }
+inline uint32_t scan_add(uint32_t v) { return static_cast<uint32_t>(emu::Collective(emu::kScanAdd, v, 0)); }
+inline uint32_t scan_max(uint32_t v) { return static_cast<uint32_t>(emu::Collective(emu::kScanMax, v, 0)); }
+inline uint32_t read_lane(uint32_t v, int src) { return static_cast<uint32_t>(emu::Collective(emu::kShfl, v, static_cast<uint64_t>(src & 63))); }
+template <int N> inline void keep_apart() {}
 inline void sync() { emu::Collective(emu::kSync, 0, 0); }
 inline void sync_global() { emu::Collective(emu::kSync, 0, 0); }
 
@@ -95,6 +101,7 @@ inline unsigned long long atomic_add(unsigned long long *p, unsigned long long v
 inline void atomic_or(uint32_t *p, uint32_t v) { *p |= v; }
 inline uint32_t lds_atomic_add(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
 inline void lds_atomic_or(uint32_t *p, uint32_t v) { *p |= v; }
+inline void lds_atomic_min(uint32_t *p, uint32_t v) { if (v < *p) *p = v; }
 inline void atomic_min(unsigned long long *p, unsigned long long v) { if (v < *p) *p = v; }
 inline void atomic_max(unsigned long long *p, unsigned long long v) { if (v > *p) *p = v; }
 inline void atomic_and(uint32_t *p, uint32_t v) { *p &= v; }
