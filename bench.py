@@ -232,7 +232,9 @@ def model_blob(model):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks (one per GPU) of ONE node.  Launched under torch.distributed.run it must equal WORLD_SIZE; "
+                         "launched plainly with N > 1 the script starts its N ranks itself (default: WORLD_SIZE, else 1)")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--sentences", type=int, default=None,
@@ -254,7 +256,25 @@ def main():
                     help="do not length-bucket the synthetic corpus (BASELINE.json's configs are length-bucketed)")
     args = ap.parse_args()
 
+    # N ranks, whichever way the script is started: under torch.distributed.run (the contract's N > 1 form: RANK / WORLD_SIZE
+    # in the environment) --gpus must agree with it; started plainly with --gpus N > 1 the script re-executes itself under
+    # torch.distributed.run with N processes -- a plain `python bench.py --gpus 8` must never run one rank and print n_gpus 1.
+    if os.environ.get("WORLD_SIZE") is None and (args.gpus or 1) > 1:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(sys.argv[0])] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus is None:
+        args.gpus = world
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a number for another job size" % (args.gpus, world))
+    if world > 1:       # the corpus generators of the ranks share the host's cores
+        os.environ.setdefault("SPMX_SYNTH_WORKERS", str(max(1, (os.cpu_count() or 1) // world)))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.sentences is None:

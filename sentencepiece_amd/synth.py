@@ -92,7 +92,9 @@ def ascii_corpus(n_sentences: int, seed: int = 20250227, words: WordList | None 
     jobs = [(target[a:a + chunk], seed, b, words)
             for b, a in enumerate(range(0, n_sentences, chunk))]
     if workers is None:
-        workers = min(len(jobs), os.cpu_count() or 1, 32)
+        # (several ranks of one host generate at once: SPMX_SYNTH_WORKERS -- bench.py sets cpu_count // world -- caps the pool)
+        cap = int(os.environ.get("SPMX_SYNTH_WORKERS", "32") or 32)
+        workers = max(1, min(len(jobs), os.cpu_count() or 1, 32, cap))
     if workers > 1 and len(jobs) > 1:
         import multiprocessing as mp
         # close + join, not the context manager: its terminate() SIGTERMs the workers, and under rocprofv3 (whose tool

@@ -19,13 +19,19 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(world, extra_env, timeout):
+def _run(world, extra_env, timeout, torchrun=True, gpus=None):
     env = dict(os.environ)
     env.update(extra_env)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):          # (the launch decides them)
+        env.pop(k, None)
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "bench_dryrun.py"), "--gpus", str(world), "--steps", "1",
-           "--warmup", "1", "--sentences", "4500", "--model", "uni32k"]
+    args = [os.path.join(ROOT, "tests", "bench_dryrun.py"), "--gpus", str(world if gpus is None else gpus), "--steps", "1",
+            "--warmup", "1", "--sentences", "4500", "--model", "uni32k"]
+    if torchrun:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + args
+    else:
+        cmd = [sys.executable] + args
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     return p, lines
@@ -51,3 +57,19 @@ def test_bench_watchdog_prints_the_line_when_the_second_gather_hangs():
     assert d["value"] == d["value_gather_all_gather"] > 0 and d["value_gather_none"] > 0
     assert "given up" in d["gather_p2p_exact"] and "value_gather_p2p_exact" not in d
     assert p.returncode == 0, p.stderr[-2000:]
+
+
+def test_bench_started_plainly_with_gpus_2_launches_two_ranks_itself():
+    """`python bench.py --gpus 2` without torch.distributed.run: the script starts its ranks itself -- it must never run one
+    rank and print n_gpus 1 (round-4 verdict: the only multi-GPU evidence there will be is one driver command)."""
+    p, lines = _run(2, {}, 600, torchrun=False)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "dp2" in d["config"]["sharding"] and d["value_gather_none"] > 0
+
+
+def test_bench_refuses_a_gpus_flag_that_disagrees_with_the_launch():
+    p, lines = _run(2, {}, 600, torchrun=True, gpus=4)
+    assert p.returncode != 0 and not lines
+    assert "refusing" in (p.stderr + p.stdout)
