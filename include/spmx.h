@@ -45,6 +45,9 @@ const char *spmx_last_error(const spmx_handle *h);
 /* ---- configuration ------------------------------------------------------
  * SetEncodeExtraOptions("bos:eos:reverse") (src/sentencepiece_processor.h:267). */
 int spmx_set_encode_extra_options(spmx_handle *h, const char *options);
+/* SetDecodeExtraOptions("bos:eos:reverse") (src/sentencepiece_processor.h:270, .cc:288-291): applied to the pieces of
+ * every later Decode before they are turned into text (.cc:819).  Same option syntax and error text as the encode side. */
+int spmx_set_decode_extra_options(spmx_handle *h, const char *options);
 /* SetVocabulary / ResetVocabulary (src/sentencepiece_processor.h:279-283). */
 int spmx_set_vocabulary(spmx_handle *h, const char *const *pieces, const uint64_t *piece_lens, uint64_t n);
 int spmx_reset_vocabulary(spmx_handle *h);

@@ -130,6 +130,12 @@ class SentencePieceProcessor {
     return h_ ? util::Status() : util::Status(util::StatusCode::kInternal, "Model is not initialized.");
   }
 
+  // :270 SetDecodeExtraOptions (.cc:288-291): applied to the pieces of every later Decode before they become text (.cc:819)
+  util::Status SetDecodeExtraOptions(std::string_view extra_option) {
+    if (!h_) return status();
+    const std::string o(extra_option);
+    return FromHandle(spmx_set_decode_extra_options(h_, o.c_str()));
+  }
   util::Status SetEncodeExtraOptions(std::string_view extra_option) {
     if (!h_) return status();
     const std::string o(extra_option);

@@ -56,6 +56,14 @@ int spmref_set_encode_extra_options(void *handle, const char *opts) {
   return st.ok() ? 0 : static_cast<int>(st.code());
 }
 
+// SetDecodeExtraOptions (sentencepiece_processor.h:270). 0 on success.
+int spmref_set_decode_extra_options(void *handle, const char *opts) {
+  auto *h = static_cast<RefHandle *>(handle);
+  const auto st = h->sp.SetDecodeExtraOptions(opts);
+  if (!st.ok()) h->last_error = st.ToString();
+  return st.ok() ? 0 : static_cast<int>(st.code());
+}
+
 // SetVocabulary / ResetVocabulary (sentencepiece_processor.h:279-283).
 // `pieces` is a '\n'-joined list.
 int spmref_set_vocabulary(void *handle, const char *pieces, uint64_t len) {

@@ -19,6 +19,7 @@ SYMBOLS = [
     ("spmx_destroy", None, [_H]),
     ("spmx_last_error", C.c_char_p, [_H]),
     ("spmx_set_encode_extra_options", C.c_int, [_H, C.c_char_p]),
+    ("spmx_set_decode_extra_options", C.c_int, [_H, C.c_char_p]),
     ("spmx_set_vocabulary", C.c_int, [_H, C.POINTER(C.c_char_p), C.POINTER(_U64), _U64]),
     ("spmx_reset_vocabulary", C.c_int, [_H]),
     ("spmx_piece_size", C.c_int, [_H]),

@@ -295,6 +295,9 @@ struct spmx_handle {
   uint64_t nbest_budget = 32ull << 30;  // SPMX_NBEST_BUDGET_GB: HBM the lattice slices of one launch may take (200 k sentences, n-best 5: 0.83 M sentences/s at 8 GB, 1.15 M at 32, 1.19 M at 96)
   uint32_t nbest_hyps_min = 16384;   // SPMX_NBEST_HYPS_MIN: hypotheses a lane's A* may hold in the first launch (what outgrows it runs again)
   uint32_t tile_min_lanes = 1;   // SPMX_TILE_MIN_LANES: a main tile has at least this many sentences even when that leaves wavefronts without a tile of the class
+  // SetDecodeExtraOptions: the net effect of the options on a sentence's ids (kernels_decode.h DecodeArgs::x_*)
+  int32_t dx_npre = 0, dx_nsuf = 0, dx_pre[kMaxExtra] = {0}, dx_suf[kMaxExtra] = {0};
+  bool dx_reverse = false;
   int fork_cus = 0;              // SPMX_FORK_CUS: the general launch beside the word rounds takes at most this many CUs (0: every CU)
   int fork_waves = 4;            // SPMX_FORK_WAVES: wavefronts per workgroup of the general launch while it runs next to the first word round (0: by its size)
   bool no_overlap = false;       // SPMX_NO_OVERLAP=1: the general launches do not run next to the word rounds
@@ -1356,6 +1359,11 @@ int DecodeRaw(spmx_handle *h, Workspace *ws, const int32_t *d_ids, const uint64_
   a.dev = h->dev; a.ids = d_ids; a.id_offs = d_id_offsets; a.n = static_cast<uint32_t>(n);
   a.counts = ws->d_counts.p; a.text_offs = d_text_offsets; a.text = d_text; a.text_cap = d_text ? text_capacity : 0;
   a.status = &ws->d_ctrl->status; a.bad_key = &ws->d_ctrl->bad_key;
+  {
+    std::lock_guard<std::mutex> l(h->mu);
+    a.x_npre = h->dx_npre; a.x_nsuf = h->dx_nsuf; a.x_reverse = h->dx_reverse ? 1 : 0;
+    for (int i = 0; i < kMaxExtra; ++i) { a.x_pre[i] = h->dx_pre[i]; a.x_suf[i] = h->dx_suf[i]; }
+  }
   const uint64_t wide = static_cast<uint64_t>(h->n_cu) * 32;
   const int grid = static_cast<int>(n < wide ? n : wide);
   HIP_OR_RETURN(h, LaunchDecode(false, a, grid, stream));
@@ -1561,6 +1569,20 @@ int spmx_set_encode_extra_options(spmx_handle *h, const char *options) {
     if (!st.ok()) return Fail(h, st.code, st.message);
     HIP_OR_RETURN(h, hipSetDevice(h->device));
     return RefreshDevice(h, false);
+  });
+}
+
+int spmx_set_decode_extra_options(spmx_handle *h, const char *options) {
+  if (!h) return kInvalidArgument;
+  return Guard(h, [&]() -> int {
+    HostTables scratch;                  // (only the scalars the option compiler writes are read back)
+    Status st = CompileExtraOptions(h->model, options ? options : "", &scratch);
+    if (!st.ok()) return Fail(h, st.code, st.message);
+    std::lock_guard<std::mutex> l(h->mu);
+    h->dx_npre = scratch.scalars.n_prefix; h->dx_nsuf = scratch.scalars.n_suffix;
+    for (int i = 0; i < kMaxExtra; ++i) { h->dx_pre[i] = scratch.scalars.prefix_ids[i]; h->dx_suf[i] = scratch.scalars.suffix_ids[i]; }
+    h->dx_reverse = (scratch.scalars.flags & kNfReverse) != 0;
+    return kOk;
   });
 }
 

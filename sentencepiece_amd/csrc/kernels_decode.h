@@ -45,6 +45,11 @@ struct DecodeArgs {
   uint64_t text_cap;
   uint32_t *status;
   unsigned long long *bad_key;  // min over offending (sentence << 32 | id as uint32)
+  // SetDecodeExtraOptions (src/sentencepiece_processor.cc:288-291): ApplyExtraOptions(decode_extra_options_) on the piece
+  // list before it is decoded (:819, :1019-1064) -- its net effect on the ids: bos / eos ids in front / behind, the body
+  // reversed (tables.cc CompileExtraOptions; "unk" only rewrites piece strings of ids that decode to unk_surface anyway)
+  int32_t x_npre, x_nsuf, x_reverse;
+  int32_t x_pre[kMaxExtra], x_suf[kMaxExtra];
 };
 
 template <bool WRITE>
@@ -56,7 +61,8 @@ SPMX_DEVICE void decode_block(const DecodeArgs &a) {
   if (WRITE && a.text_offs[a.n] > a.text_cap) return;      // caller sees the needed size in text_offs[n]
   for (uint32_t s = static_cast<uint32_t>(wv::block_id()); s < a.n; s += static_cast<uint32_t>(wv::grid_size())) {
     const uint64_t beg = a.id_offs[s];
-    const int n_pieces = static_cast<int>(a.id_offs[s + 1] - beg);
+    const int n_body = static_cast<int>(a.id_offs[s + 1] - beg);
+    const int n_pieces = n_body + a.x_npre + a.x_nsuf;
     uint8_t *dst = WRITE ? a.text + a.text_offs[s] : nullptr;
     uint32_t out = 0;            // bytes of this sentence so far
     bool bos = true;             // is_bos_ws
@@ -69,7 +75,11 @@ SPMX_DEVICE void decode_block(const DecodeArgs &a) {
       int32_t id = 0;
       uint32_t info = kDkEmpty, off = 0, full = 0;
       if (valid) {
-        id = a.ids[beg + static_cast<uint64_t>(i)];
+        if (i < a.x_npre) id = a.x_pre[i];
+        else if (i < a.x_npre + n_body) {
+          const int k = i - a.x_npre;
+          id = a.ids[beg + static_cast<uint64_t>(a.x_reverse ? n_body - 1 - k : k)];
+        } else id = a.x_suf[i - a.x_npre - n_body];
         if (id < 0 || static_cast<uint32_t>(id) >= d.n_pieces) {
           bad = true;
           wv::atomic_min(a.bad_key, (static_cast<unsigned long long>(s) << 32) | static_cast<uint32_t>(id));

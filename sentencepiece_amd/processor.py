@@ -116,6 +116,13 @@ class SentencePieceProcessor:
         self._extra = self._applied = extra_option
         return True
 
+    def SetDecodeExtraOptions(self, extra_option):
+        """bos:eos:reverse in any order, applied to the pieces of every later Decode before they are turned into text
+        (src/sentencepiece_processor.h:270, .cc:288-291, :819)."""
+        self._need()
+        self._check(self._lib.spmx_set_decode_extra_options(self._h, extra_option.encode()))
+        return True
+
     def _apply(self, add_bos, add_eos, reverse):
         # RewriteIds (sentencepiece.i:138-145) runs after the processor's own
         # extra options: reverse, then bos in front, then eos at the back --

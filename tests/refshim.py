@@ -25,6 +25,7 @@ class RefLib:
         lib.spmref_last_error.restype = C.c_char_p
         lib.spmref_last_error.argtypes = [C.c_void_p]
         lib.spmref_set_encode_extra_options.argtypes = [C.c_void_p, C.c_char_p]
+        lib.spmref_set_decode_extra_options.argtypes = [C.c_void_p, C.c_char_p]
         lib.spmref_set_vocabulary.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
         lib.spmref_reset_vocabulary.argtypes = [C.c_void_p]
         lib.spmref_encode.restype = C.c_int64
@@ -58,6 +59,11 @@ class RefHandle:
 
     def set_encode_extra_options(self, opts):
         rc = self.lib.spmref_set_encode_extra_options(self.h, opts.encode())
+        if rc:
+            raise RuntimeError(self.lib.spmref_last_error(self.h).decode())
+
+    def set_decode_extra_options(self, opts):
+        rc = self.lib.spmref_set_decode_extra_options(self.h, opts.encode())
         if rc:
             raise RuntimeError(self.lib.spmref_last_error(self.h).decode())
 

@@ -251,3 +251,59 @@ def test_gpu_decode_with_denormalizer(corpora):
     if not refshim.available():
         pytest.skip("oracle/_ref/libspm_ref.so not built")
     _denormalizer_case(lambda blob: SentencePieceProcessor(model_proto=blob), corpora)
+
+
+# ---- SetDecodeExtraOptions (src/sentencepiece_processor.h:270, .cc:288-291, applied at :819) --------------------------
+DECODE_OPTION_MODELS = ["test_model", "uni1k_bf", "bpe1k_llama"]
+DECODE_OPTIONS = ["reverse", "bos:eos", "unk", "eos:reverse:bos", "reverse:reverse:bos", ""]
+
+
+def _decode_option_case(sp, model, oracle, corpora):
+    """sp: the product's processor (HIP or emulated).  Its Decode under every option string equals the compiled reference's."""
+    from tests import refshim
+    blob = fixtures.model_blob(model)
+    o = oracle.load(blob)
+    r = refshim.RefLib().load(blob) if refshim.available() else None
+    batches = [o.encode_batch(*fixtures.head(*corpora[name], k)) for name, k in (("edge", 10 ** 6), ("botchan", 120), ("mixed2k", 50))]
+    batches.append(mf.decode_fuzz_ids(o.lib.oracle_piece_size(o.h)))
+    try:
+        for opts in DECODE_OPTIONS:
+            sp.SetDecodeExtraOptions(opts)
+            if r is not None:
+                r.set_decode_extra_options(opts)
+            for ids, io in batches:
+                text, offs = sp.DecodePacked(ids, io)
+                if r is not None:
+                    rt, ro = r.decode_batch(ids, io)
+                    np.testing.assert_array_equal(offs, ro, err_msg="%s %r" % (model, opts))
+                    np.testing.assert_array_equal(text, rt, err_msg="%s %r" % (model, opts))
+                if opts in ("", "unk", "bos:eos"):      # (control pieces decode to nothing; `unk` only renames pieces)
+                    ot, oo = o.decode_batch(ids, io)
+                    np.testing.assert_array_equal(offs, oo)
+                    np.testing.assert_array_equal(text, ot)
+        with pytest.raises(Exception) as ei:
+            sp.SetDecodeExtraOptions("bos:nonsense")
+        assert "not available" in str(ei.value)
+    finally:
+        sp.SetDecodeExtraOptions("")
+
+
+@pytest.mark.parametrize("model", DECODE_OPTION_MODELS)
+def test_emu_decode_extra_options(model, oracle, corpora):
+    from tests import emulib
+    _decode_option_case(emulib.EmuLib().load(fixtures.model_blob(model)).sp, model, oracle, corpora)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", DECODE_OPTION_MODELS)
+def test_gpu_decode_extra_options(model, procs, oracle, corpora):
+    _decode_option_case(procs(model), model, oracle, corpora)
+    sp = procs(model)                       # the string forms go through the same entry point
+    sp.SetDecodeExtraOptions("reverse")
+    try:
+        ids = sp.Encode("I saw a girl with a telescope.")
+        got = sp.Decode(ids)
+        sp.SetDecodeExtraOptions("")
+        assert got == sp.Decode(list(reversed(ids)))
+    finally:
+        sp.SetDecodeExtraOptions("")
