@@ -94,6 +94,8 @@ int FailG(int code, const std::string &msg) {
 
 }  // namespace
 
+constexpr int kGatherWords = 5;      // per rank in the counts all-gather: sentences, ids, id capacity, offset capacity, arguments valid
+
 extern "C" {
 
 const char *spmx_gather_last_error(void) { return t_gather_error.c_str(); }
@@ -132,27 +134,42 @@ int spmx_all_gather_ids(void *nccl_comm, int rank, int world, const int32_t *d_i
   RcclApi &api = Rccl();
   if (!api.ok) return FailG(14, api.error);
   if (world < 1 || world > kMaxRanks || rank < 0 || rank >= world) return FailG(3, "world must be 1 .. 64 and rank inside it");
-  if (!nccl_comm || !d_scratch || (n_sentences && !d_id_offsets) || (n_ids && !d_ids)) return FailG(3, "null argument");
+  if (!nccl_comm || !d_scratch) return FailG(3, "null communicator or scratch");   // (the only errors decided by one rank alone)
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  // ---- counts: {sentences, ids} of every rank ----
-  const uint64_t mine[2] = {n_sentences, n_ids};
-  uint64_t *d_mine = d_scratch, *d_all = d_scratch + 2;                 // scratch: 2 + 2 * world uint64
+  // ---- counts: {sentences, ids} of every rank -- and what its output buffers hold: whether the gathered CSR fits is
+  // decided by ALL ranks from the same numbers, so that either every rank goes on to the transfers or none does (a rank
+  // that returned early on a capacity only it knew to be too small would leave its peers waiting in ncclSend / ncclRecv) ----
+  const bool args_ok = !(n_sentences && !d_id_offsets) && !(n_ids && !d_ids);
+  const uint64_t mine[kGatherWords] = {n_sentences, n_ids, d_all_ids ? all_ids_capacity : 0, d_all_id_offsets ? all_offsets_capacity : 0,
+                                       args_ok ? 1u : 0u};
+  uint64_t *d_mine = d_scratch, *d_all = d_scratch + kGatherWords;     // scratch: kGatherWords * (1 + world) uint64
   HIPG_OR_RETURN(hipMemcpyAsync(d_mine, mine, sizeof(mine), hipMemcpyHostToDevice, stream));
-  RCCL_OR_RETURN(api, api.AllGather(d_mine, d_all, 2, kNcclUint64, nccl_comm, stream));
-  uint64_t all[2 * kMaxRanks];
-  HIPG_OR_RETURN(hipMemcpyAsync(all, d_all, sizeof(uint64_t) * 2 * static_cast<size_t>(world), hipMemcpyDeviceToHost, stream));
+  RCCL_OR_RETURN(api, api.AllGather(d_mine, d_all, kGatherWords, kNcclUint64, nccl_comm, stream));
+  uint64_t got[kGatherWords * kMaxRanks];
+  HIPG_OR_RETURN(hipMemcpyAsync(got, d_all, sizeof(uint64_t) * kGatherWords * static_cast<size_t>(world), hipMemcpyDeviceToHost, stream));
   HIPG_OR_RETURN(hipStreamSynchronize(stream));
+  uint64_t all[2 * kMaxRanks];
   RebaseArgs ra{};
   ra.world = static_cast<uint32_t>(world);
   for (int r = 0; r < world; ++r) {
+    all[2 * r] = got[kGatherWords * r];
+    all[2 * r + 1] = got[kGatherWords * r + 1];
     ra.sent_before[r + 1] = ra.sent_before[r] + all[2 * r];
     ra.ids_before[r + 1] = ra.ids_before[r] + all[2 * r + 1];
   }
   if (rank_sentences) memcpy(rank_sentences, ra.sent_before, sizeof(uint64_t) * static_cast<size_t>(world + 1));
   if (rank_ids) memcpy(rank_ids, ra.ids_before, sizeof(uint64_t) * static_cast<size_t>(world + 1));
   const uint64_t total_s = ra.sent_before[world], total_i = ra.ids_before[world];
-  if (total_i > all_ids_capacity || total_s + 1 > all_offsets_capacity || (total_i && !d_all_ids) || !d_all_id_offsets)
-    return FailG(8, "the gathered CSR needs " + std::to_string(total_i) + " ids and " + std::to_string(total_s + 1) + " offsets");
+  for (int r = 0; r < world; ++r)
+    if (!got[kGatherWords * r + 4])
+      return FailG(3, "rank " + std::to_string(r) + " passed a null id / offset buffer with a non-zero size: no rank transfers anything");
+  for (int r = 0; r < world; ++r) {
+    const uint64_t cap_i = got[kGatherWords * r + 2], cap_o = got[kGatherWords * r + 3];
+    if (total_i > cap_i || total_s + 1 > cap_o)
+      return FailG(8, "the gathered CSR needs " + std::to_string(total_i) + " ids and " + std::to_string(total_s + 1) + " offsets; rank " +
+                          std::to_string(r) + "'s buffers hold " + std::to_string(cap_i) + " / " + std::to_string(cap_o) +
+                          " (every rank returns this: no rank transfers anything)");
+  }
   // ---- payload: exact sizes, point to point, one group ----
   RCCL_OR_RETURN(api, api.GroupStart());
   int in_group = 0;                       // (a call that fails inside the group must not leave it open: the first failure is kept, the group closed)

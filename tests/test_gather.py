@@ -25,7 +25,7 @@ def _gather_rank(lib, comm, rank, world, ids, io, cap_ids, cap_offs):
     io = np.ascontiguousarray(io, dtype=np.uint64)
     all_ids = np.full(cap_ids, -7, dtype=np.int32)
     all_offs = np.full(cap_offs, 0xCDCD, dtype=np.uint64)
-    scratch = np.zeros(2 + 2 * world, dtype=np.uint64)
+    scratch = np.zeros(5 * (1 + world), dtype=np.uint64)
     rs = np.zeros(world + 1, dtype=np.uint64)
     ri = np.zeros(world + 1, dtype=np.uint64)
     rc = lib.spmx_all_gather_ids(comm, rank, world, ids.ctypes.data, len(ids), io.ctypes.data, n, all_ids.ctypes.data, cap_ids,
@@ -97,6 +97,41 @@ def test_all_gather_ids_reports_a_small_capacity(emu_lib):
     lib.spmx_rccl_comm_destroy(comm)
 
 
+def test_all_gather_ids_one_rank_too_small_every_rank_returns_8(emu_lib):
+    """Ranks size their output buffers from what they know -- one of them too small: the capacities travel with the counts,
+    so EVERY rank returns 8 and none posts a transfer its peer will never match (round-4 ADVICE: the small rank used to
+    return alone, the others hung in ncclSend / ncclRecv).  Then all retry with enough room."""
+    lib = emu_lib.lib
+    world = 3
+    uid = (C.c_char * 128)()
+    assert lib.spmx_rccl_unique_id(uid) == 0
+    shards = [(np.arange(5, dtype=np.int32), np.array([0, 2, 5], dtype=np.uint64)),
+              (np.arange(5, 12, dtype=np.int32), np.array([0, 7], dtype=np.uint64)),
+              (np.zeros(0, dtype=np.int32), np.array([0], dtype=np.uint64))]
+    caps = [(12, 4), (11, 4), (12, 4)]          # rank 1's id buffer is one short of the job's 12 ids
+    first, second = [None] * world, [None] * world
+
+    def run(rank):
+        comm = C.c_void_p()
+        assert lib.spmx_rccl_comm_init(C.byref(comm), world, rank, uid) == 0
+        first[rank] = _gather_rank(lib, comm, rank, world, shards[rank][0], shards[rank][1], *caps[rank])
+        msg = lib.spmx_gather_last_error()
+        first[rank] = first[rank] + (msg,)
+        second[rank] = _gather_rank(lib, comm, rank, world, shards[rank][0], shards[rank][1], 12, 4)
+        lib.spmx_rccl_comm_destroy(comm)
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=60)
+        assert not t.is_alive(), "a rank hangs"
+    for rank in range(world):
+        assert first[rank][0] == 8 and b"rank 1" in first[rank][5], (rank, first[rank][0], first[rank][5])
+        rc, all_ids, all_offs, rs, ri = second[rank]
+        assert rc == 0 and all_ids.tolist() == list(range(12)) and all_offs.tolist() == [0, 2, 5, 12]
+
+
 @pytest.mark.gpu
 def test_all_gather_ids_on_the_gpu_world_1(oracle, corpora):
     """libspmx.so + the real librccl on the one GPU of the box: communicator through the spmx_rccl_* helpers, counts
@@ -117,7 +152,7 @@ def test_all_gather_ids_on_the_gpu_world_1(oracle, corpora):
     assert lib.spmx_rccl_comm_init(C.byref(comm), 1, 0, uid) == 0, lib.spmx_gather_last_error()
     all_ids = torch.full((total + 8,), -7, dtype=torch.int32, device=dev)
     all_offs = torch.zeros(n + 2, dtype=torch.int64, device=dev)
-    scratch = torch.zeros(4, dtype=torch.int64, device=dev)
+    scratch = torch.zeros(10, dtype=torch.int64, device=dev)
     rs = np.zeros(2, dtype=np.uint64)
     ri = np.zeros(2, dtype=np.uint64)
     stream = torch.cuda.current_stream().cuda_stream
