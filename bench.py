@@ -578,6 +578,7 @@ def main():
                     runs.append(time.perf_counter() - t0)
                     assert rc == 0, lib.spmx_last_error(None)
                     h_io = np.ctypeslib.as_array(C.cast(p_off, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+                    h_ids = np.ctypeslib.as_array(C.cast(p_ids, C.POINTER(C.c_int32)), shape=(int(h_io[-1]),)).copy() if len(runs) == 9 else None
                     lib.spmx_free(p_ids)
                     lib.spmx_free(p_off)
                 runs = sorted(runs[1:])          # (the first call sizes the pinned staging)
@@ -585,8 +586,11 @@ def main():
                                              "(H2D, kernels and D2H of successive chunks overlapped), %d sentences" % n,
                                      "value": n / runs[len(runs) // 2], "best": n / runs[0], "unit": "sentences/s",
                                      "seconds": runs, "gb_text_per_s": len(text) / runs[len(runs) // 2] / 1e9,
-                                     "ids_equal_device_run": bool(np.array_equal(np.asarray(h_io).astype(np.int64), d_io.cpu().numpy()))}
-                del h_io
+                                     # (offsets AND ids of the last call against the device-resident run's)
+                                     "ids_equal_device_run": bool(np.array_equal(np.asarray(h_io).astype(np.int64), d_io.cpu().numpy()) and
+                                                                  h_ids is not None and
+                                                                  np.array_equal(h_ids, d_ids[:int(h_io[-1])].cpu().numpy()))}
+                del h_io, h_ids
             except Exception as e:
                 out["end_to_end"] = {"failed": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:

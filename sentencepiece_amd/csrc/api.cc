@@ -117,6 +117,10 @@ struct PreferGpuNode {
     const int got = fscanf(f, "%d", &node);
     fclose(f);
     if (got != 1 || node < 0 || node >= 1024) return;
+    // (a caller that runs under its own policy -- numactl --membind / --interleave, set_mempolicy -- keeps it: the override is
+    // only for threads on the default policy, which is also what the destructor puts back)
+    int cur = 0;
+    if (syscall(SYS_get_mempolicy, &cur, nullptr, 0ul, nullptr, 0ul) != 0 || cur != 0 /* MPOL_DEFAULT */) return;
     unsigned long mask[16] = {0};
     mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
     set = syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, sizeof(mask) * 8 + 1) == 0;
@@ -1513,6 +1517,16 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_STREAM_SCRATCH_MB")) h->stream_scratch_limit = static_cast<uint64_t>(atoll(e)) << 20;
     if (const char *e = getenv("SPMX_MAIN_MAX_RAW")) h->main_max_raw = static_cast<uint32_t>(atoll(e));
     if (const char *e = getenv("SPMX_FORCE_RING")) { const int v = atoi(e); if (v >= 16 && v <= 122) h->ring_override = static_cast<uint32_t>(v); }
+#else
+    {   // (an A/B script that sets one of these against the release library would compare a configuration with itself: say so, once)
+      static const char *const kSeamOnly[] = {"SPMX_WORDMEMO_UNSAFE", "SPMX_NO_WORD_DP", "SPMX_NBEST_HYPS_MIN", "SPMX_TILE_MIN_LANES",
+          "SPMX_NO_UNI_WAVE", "SPMX_WORD_WGS", "SPMX_NO_BP_SHORT", "SPMX_WIDE_TCAP", "SPMX_SUB_BUCKETS", "SPMX_LANE_GENERAL_MIN_LANES",
+          "SPMX_STREAM_SCRATCH_MB", "SPMX_MAIN_MAX_RAW", "SPMX_FORCE_RING", "SPMX_MEMO16_ONE"};
+      static std::atomic<bool> warned{false};
+      for (const char *v : kSeamOnly)
+        if (getenv(v) && !warned.exchange(true))
+          fprintf(stderr, "libspmx: %s is read by test-seam builds only (-DSPMX_TEST_SEAMS); this library ignores it\n", v);
+    }
 #endif
     if (const char *e = getenv("SPMX_UNI_WAVE_MAX")) h->uni_wave_max = static_cast<uint32_t>(atoll(e));
     if (const char *e = getenv("SPMX_WORD_WAVE")) { const int v = atoi(e); if (v >= 0 && v <= 3) h->word_form = v; }
