@@ -513,6 +513,13 @@ def main():
                                        "kernels_ms": {c["kernel"]: round(c["kernel_ms"], 4) for c in p2["classes"] if c["kernel"]},
                                        "vs_headline": ((len(o2) - 1) * args.steps / d2) / out["value"],
                                        "what": "the C2 recipe with words of up to 16 letters: longest piece 17 bytes, score ring of 18 entries"}
+            try:      # every sentence of this corpus against the compiled reference, as for the headline (round-4 verdict: the one record without it)
+                io2_h = io2.cpu().numpy()
+                out["long_piece_model"]["probe_ids_bit_exact"], out["long_piece_model"]["probe"] = probe_exact(
+                    t2, o2, model_blob(name), i2[:int(io2_h[-1])].cpu().numpy(), io2_h)
+            except Exception as e:
+                out["long_piece_model"]["probe_ids_bit_exact"] = None
+                out["long_piece_model"]["probe_error"] = repr(e)[:200]
             del sp2, dt2_text, dt2_offs, i2, io2
         if world == 1 and args.model == "uni32k" and not args.no_side_configs:
             # the other single-GPU configurations of BASELINE.json, compact: c3 (the same corpus through the 32k BPE
@@ -548,9 +555,13 @@ def main():
                 out["c5"] = side_bench(SentencePieceProcessor, torch, dev, "c5_250k", model_blob("c5_250k"), t5, o5,
                                        args.steps, args.warmup,
                                        "configs[4]: 250k-piece unigram, 1 M mixed-script sentences, power-law [16, 4096] characters")
+                # ... and the same model with byte_fallback on ("both off and on")
+                out["c5_bf"] = side_bench(SentencePieceProcessor, torch, dev, "c5_250k_bf", model_blob("c5_250k_bf"), t5, o5,
+                                          args.steps, args.warmup, "configs[4] with byte_fallback: the same 1 M sentences")
                 del t5, o5
             except Exception as e:
-                out["c5"] = {"failed": repr(e)[:300]}
+                out.setdefault("c5", {"failed": repr(e)[:300]})
+                out.setdefault("c5_bf", {"failed": repr(e)[:300]})
             try:
                 sys.path.insert(0, os.path.join(ROOT, "scripts"))
                 import docs_rate

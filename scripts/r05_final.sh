@@ -1,0 +1,35 @@
+# usage (GPU box): bash scripts/r05_final.sh <tag>  -- the round-5 evidence on the head's sources, most important first:
+# GPU suite, smoke, PMC traffic passes (uni32k, bpe32k, c5_250k) merged into profiles/pmc_traffic.json, rocprofv3 kernel
+# stats (uni32k, bpe32k), SQ counters, then the default bench line (which picks the fresh traffic records up).
+TAG=${1:-r05m}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/$TAG; mkdir -p $O
+if [ -z "$SKIP_TESTS" ]; then ( time timeout 900 python -m pytest tests -m gpu -x -q --durations=12 ) > $O/pytest_gpu.txt 2>&1; tail -4 $O/pytest_gpu.txt; else ( time timeout 600 python -m pytest tests/test_word_form.py tests/test_gpu_parity.py tests/test_host.py tests/test_gather.py -m gpu -x -q ) > $O/pytest_gpu_changed.txt 2>&1; tail -4 $O/pytest_gpu_changed.txt; fi
+( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
+PASS_TIMEOUT=120 bash scripts/pmc_traffic.sh $TAG 10000000 uni32k > $O/pmc_traffic_uni.log 2>&1; tail -3 $O/pmc_traffic_uni.log | cut -c1-200
+PASS_TIMEOUT=120 bash scripts/pmc_traffic.sh $TAG 10000000 bpe32k > $O/pmc_traffic_bpe.log 2>&1
+PASS_TIMEOUT=120 bash scripts/pmc_traffic.sh $TAG 1000000 c5_250k > $O/pmc_traffic_c5.log 2>&1
+python - "$O" <<'PY'
+import json, sys
+O = sys.argv[1]
+out = {}
+note = ""
+for m in ("uni32k", "c5_250k", "bpe32k"):
+    try:
+        d = json.load(open("%s/pmc_traffic_%s.json" % (O, m)))
+    except Exception as e:
+        print("missing", m, e); continue
+    note = d.pop("_note", note)
+    out.update(d)
+out["_note"] = note + "; made by scripts/pmc_traffic.sh (bench.py --no-side-configs, steps 2, warmup 1) on the kernel sources whose hash each record carries"
+json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
+json.dump(out, open(O + "/pmc_traffic.json", "w"), indent=1)
+PY
+for M in uni32k bpe32k; do
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof -o x -- python bench.py --model $M --steps 5 --warmup 2 --no-cpu-baseline --no-second-model --no-side-configs > $O/trace_bench_$M.json 2> $O/trace_$M.err
+  DB=$(find $O/prof -name "x_results.db" | head -1); python scripts/rocpd_summary.py "$DB" > $O/${M}_10m_kernel_stats.txt 2>&1; rm -rf $O/prof
+done
+head -8 $O/uni32k_10m_kernel_stats.txt | cut -c1-150
+GROUPS_MAX=2 bash scripts/pmc_sq.sh 2000000 > $O/uni32k_2m_pmc_sq.txt 2>&1; rm -rf gpurun_out/pmc_sq; grep -c "EncodeWord" $O/uni32k_2m_pmc_sq.txt; cp profiles/pmc_traffic.json $O/pmc_traffic_used.json
+( time timeout 900 python bench.py > $O/bench_uni32k_10m.json 2> $O/bench.err ) 2> $O/bench_wall.txt; tail -3 $O/bench_wall.txt; tail -c 400 $O/bench_uni32k_10m.json
+ls $O

@@ -1059,7 +1059,8 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         wa.resume = ws->d_resume.p;
         wa.ids16 = (h->model.pieces.size() <= 65536 && !h->no_ids16) ? 1u : 0u;
         snprintf(ws->slot_name[slot], sizeof(ws->slot_name[slot]), "%s",
-                 wform ? (mode == 2 ? "EncodeWordWaveAgainKernel" : mode == 1 ? "EncodeWordWaveCollectKernel" : "EncodeWordWaveKernel")
+                 wform ? (wa.ids16 ? (mode == 2 ? "EncodeWordWaveAgainKernel<true>" : mode == 1 ? "EncodeWordWaveCollectKernel<true>" : "EncodeWordWaveKernel<true>")
+                                   : (mode == 2 ? "EncodeWordWaveAgainKernel<false>" : mode == 1 ? "EncodeWordWaveCollectKernel<false>" : "EncodeWordWaveKernel<false>"))
                        : mode == 3 ? "EncodeWordDpKernel" : mode == 2 ? "EncodeWordAgainKernel" : mode == 1 ? "EncodeWordCollectKernel" : "EncodeWordKernel");
         HIP_OR_RETURN(h, record(slot, 0));
         if (wform) HIP_OR_RETURN(h, LaunchEncodeWordWave(mode, wa, static_cast<int>(grid), waves, WordWaveLdsBytes(waves), stream));
