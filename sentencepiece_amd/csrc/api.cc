@@ -267,7 +267,7 @@ struct spmx_handle {
   DevBuf<uint32_t> d_ndarts, d_npair, d_sym_final, d_dec_info, d_dec_off;
   DevBuf<uint8_t> d_dec_bytes;
   DevBuf<uint8_t> d_nblob, d_plen;
-  DevBuf<U4> d_ptrie, d_chartab, d_pairtab, d_wordtab, d_umemo, d_umemo16, d_uhot, d_uall, d_uhot2;
+  DevBuf<U4> d_ptrie, d_chartab, d_pairtab, d_wordtab, d_umemo, d_umemo16, d_uhot, d_uall, d_uhot2, d_cfirst;
   DevBuf<uint16_t> d_udisp;
   DevBuf<float> d_pscore;
   DevBuf<U2> d_utrie;
@@ -393,6 +393,7 @@ int UploadTables(spmx_handle *h) {
   HIP_OR_RETURN(h, Upload(&h->d_nblob, t.nblob));
   HIP_OR_RETURN(h, Upload(&h->d_npair, t.npair));
   HIP_OR_RETURN(h, Upload(&h->d_ptrie, t.ptrie));
+  HIP_OR_RETURN(h, Upload(&h->d_cfirst, t.cfirst));
   HIP_OR_RETURN(h, Upload(&h->d_plen, t.plen));
   HIP_OR_RETURN(h, Upload(&h->d_utrie, t.utrie));
   HIP_OR_RETURN(h, Upload(&h->d_chartab, t.chartab));
@@ -416,6 +417,7 @@ int UploadTables(spmx_handle *h) {
   h->dev.nblob = h->d_nblob.p;
   h->dev.npair = h->d_npair.p;
   h->dev.ptrie = h->d_ptrie.p;
+  h->dev.cfirst = t.cfirst.empty() ? nullptr : h->d_cfirst.p;
   h->dev.plen = h->d_plen.p;
   h->dev.utrie = h->d_utrie.p;
   h->dev.chartab = h->d_chartab.p;
@@ -456,6 +458,7 @@ int RefreshDevice(spmx_handle *h, bool types_changed) {
   if (types_changed) {
     if (h->model.model_type == kUnigram) {
       HIP_OR_RETURN(h, Upload(&h->d_ptrie, t.ptrie));
+      HIP_OR_RETURN(h, Upload(&h->d_cfirst, t.cfirst));
     } else {
       HIP_OR_RETURN(h, Upload(&h->d_sym_final, t.sym_final));
     }
@@ -476,7 +479,7 @@ int RefreshDevice(spmx_handle *h, bool types_changed) {
     HIP_OR_RETURN(h, Upload(&h->d_dec_bytes, t.dec_bytes));
   }
   SpmxDev d = t.scalars;
-  d.ndarts = h->dev.ndarts; d.nblob = h->dev.nblob; d.npair = h->dev.npair; d.ptrie = h->d_ptrie.p; d.plen = h->d_plen.p; d.utrie = h->dev.utrie;
+  d.ndarts = h->dev.ndarts; d.nblob = h->dev.nblob; d.npair = h->dev.npair; d.ptrie = h->d_ptrie.p; d.cfirst = t.cfirst.empty() ? nullptr : h->d_cfirst.p; d.plen = h->d_plen.p; d.utrie = h->dev.utrie;
   d.chartab = h->dev.chartab; d.pairtab = h->dev.pairtab; d.wordtab = h->dev.wordtab; d.sym_final = h->d_sym_final.p;
   d.sym_len = h->dev.sym_len; d.byte_ids = h->dev.byte_ids;
   d.umemo = h->d_umemo.p; d.umemo16 = h->d_umemo16.p; d.uall = h->d_uall.p; d.udisp = h->d_udisp.p; d.uhot2 = h->d_uhot2.p; d.uhot = h->d_uhot.p; d.pscore = h->d_pscore.p;
@@ -490,7 +493,7 @@ void DestroyHandle(spmx_handle *h) {
   (void)hipSetDevice(h->device);
   h->d_ndarts.Free(); h->d_npair.Free(); h->d_sym_final.Free(); h->d_nblob.Free(); h->d_ptrie.Free(); h->d_chartab.Free();
   h->d_pairtab.Free(); h->d_wordtab.Free(); h->d_utrie.Free(); h->d_sym_len.Free(); h->d_byte_ids.Free();
-  h->d_dec_info.Free(); h->d_dec_off.Free(); h->d_dec_bytes.Free(); h->d_plen.Free(); h->d_umemo.Free(); h->d_umemo16.Free(); h->d_uall.Free(); h->d_udisp.Free(); h->d_uhot2.Free(); h->d_uhot.Free(); h->d_pscore.Free();
+  h->d_dec_info.Free(); h->d_dec_off.Free(); h->d_dec_bytes.Free(); h->d_plen.Free(); h->d_cfirst.Free(); h->d_umemo.Free(); h->d_umemo16.Free(); h->d_uall.Free(); h->d_udisp.Free(); h->d_uhot2.Free(); h->d_uhot.Free(); h->d_pscore.Free();
   h->dn_ndarts.Free(); h->dn_npair.Free(); h->dn_nblob.Free(); h->dn_utrie.Free();
   h->pool.clear();
   delete h;
@@ -1520,7 +1523,7 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_FORCE_RING")) { const int v = atoi(e); if (v >= 16 && v <= 122) h->ring_override = static_cast<uint32_t>(v); }
 #else
     {   // (an A/B script that sets one of these against the release library would compare a configuration with itself: say so, once)
-      static const char *const kSeamOnly[] = {"SPMX_WORDMEMO_UNSAFE", "SPMX_NO_WORD_DP", "SPMX_NBEST_HYPS_MIN", "SPMX_TILE_MIN_LANES",
+      static const char *const kSeamOnly[] = {"SPMX_NO_WORD_DP", "SPMX_NBEST_HYPS_MIN", "SPMX_TILE_MIN_LANES",
           "SPMX_NO_UNI_WAVE", "SPMX_WORD_WGS", "SPMX_NO_BP_SHORT", "SPMX_WIDE_TCAP", "SPMX_SUB_BUCKETS", "SPMX_LANE_GENERAL_MIN_LANES",
           "SPMX_STREAM_SCRATCH_MB", "SPMX_MAIN_MAX_RAW", "SPMX_FORCE_RING", "SPMX_MEMO16_ONE"};
       static std::atomic<bool> warned{false};

@@ -84,6 +84,12 @@ struct SpmxDev {
   // ---- unigram (reference: src/unigram_model.cc:889-1020) ----
   const U4 *ptrie;        // piece trie with inline id / flags / score
   const uint8_t *plen;    // per id: the piece's byte length in the device form of the text (the short back-pointer form)
+  // first-CHARACTER table (null: none): by code point U+0080 .. U+FFFF the unit of ptrie reached after the character's two
+  // or three UTF-8 bytes, its label byte replaced by the character's byte length (0x100 clear: no piece starts with the
+  // character).  Built for vocabularies with many pieces in multi-byte scripts when no piece ends inside a character
+  // (tables.cc BuildFirstCharTable); the streaming kernel starts a walk there instead of spelling the character
+  // (kernels_stream.h unigram_stream_lane).
+  const U4 *cfirst;
   float unk_score;        // min_score - 10.0f
   float max_score;
   int32_t unk_id;

@@ -228,7 +228,33 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const TextCol &gt, const B
   U4 u{0, 0, 0, 0};
   uint32_t cs = 0, cs1 = 0;
   U4 rn{0, 0, 0, 0};
+  int rd = 1;                                     // how many bytes of the next start rn stands for: 1 (root table), or the whole
+                                                  // first character (cfirst)
   uint32_t cq = 0;
+  // The unit a walk from position q starts with, and the byte the walk looks at next.  The root table (LDS) holds the
+  // first BYTE's unit.  cfirst (dev.h; models with many pieces in multi-byte scripts) holds, by code point, the unit the
+  // byte trie reaches after a whole two- or three-byte CHARACTER -- no piece ends inside a character (checked when the
+  // table is built), so the two or three dependent probes that spell a CJK character are one probe, and that one is asked
+  // for a whole start ahead: off the lane's latency chain (C5: 4.8 dependent probes per character, most of them these).
+  const U4 *__restrict__ cfirst = d.cfirst;
+  auto first_unit = [&](int q, int lim) __attribute__((always_inline)) {
+    cs = win[static_cast<uint32_t>(q) & wmask];
+    cs1 = win[static_cast<uint32_t>(q + 1) & wmask];
+    rn = roottab[cs];
+    rd = 1;
+    if (cfirst != nullptr && cs >= 0xC2u && cs < 0xF0u) {
+      const uint32_t b2 = win[static_cast<uint32_t>(q + 2) & wmask];
+      const bool three = cs >= 0xE0u;
+      const uint32_t cp = three ? ((cs & 0x0Fu) << 12) | ((cs1 & 0x3Fu) << 6) | (b2 & 0x3Fu) : ((cs & 0x1Fu) << 6) | (cs1 & 0x3Fu);
+      const bool wf = (cs1 & 0xC0u) == 0x80u && (!three || ((b2 & 0xC0u) == 0x80u && cp >= 0x800u));   // the canonical bytes of cp
+      const int dch = three ? 3 : 2;
+      if (wf && q + dch <= lim) {
+        rn = cfirst[cp];
+        rd = dch;
+        cs1 = three ? win[static_cast<uint32_t>(q + 3) & wmask] : b2;       // the byte behind the character
+      }
+    }
+  };
   int nf = 0;                                     // next text dword to fetch; the window holds dwords [nf - W/4, nf)
   bool pf_pend = false;
   uint32_t pf = 0;
@@ -237,9 +263,7 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const TextCol &gt, const B
     ring_s[0] = 0.f;                              // best_path_ends_at[0].best_path_score = 0
     for (int k = 0; k < W / 4; ++k) *reinterpret_cast<uint32_t *>(win + 4 * k) = gt.dw(k);
     nf = W / 4;
-    cs = win[0];
-    cs1 = win[1];
-    rn = roottab[cs];
+    first_unit(0, nlen);
   }
   while (wv::any(active)) {
     ++trips;
@@ -256,8 +280,9 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const TextCol &gt, const B
     int mb2 = static_cast<int>(r.x & 7u);         // :962-963 the character's byte length rides in the root-table entry
     if (mb2 > nlen - s2) mb2 = nlen - s2;
     const bool rootC = begin && (r.x & 0x100u);   // a piece starts with cs (entries without one have the bit clear)
+    const int dC = rd;                            // bytes of the start at s2 that r stands for
     const bool termC = rootC && (r.x & kDatTerminalDev) && !(r.y & kPtUnused);
-    const bool contC = rootC && s2 + 1 < nlen && ((r.w >> ChildBit(cs1)) & 1u);
+    const bool contC = rootC && s2 + dC < nlen && ((r.w >> ChildBit(cs1)) & 1u);
     const bool nwalking = cont || contC;
     const uint32_t nnode = cont ? (u.x >> kDatBaseShiftDev) : (r.x >> kDatBaseShiftDev);
     const uint32_t nc = cont ? cq : cs1;
@@ -269,11 +294,11 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const TextCol &gt, const B
     // ---------------- data ----------------
     const int eA = s + dep1;
     const int eB = s2;
-    const int eC = s2 + 1 <= nlen ? s2 + 1 : nlen;
+    const int eC = s2 + dC <= nlen ? s2 + dC : nlen;
     const uint32_t slB = RING ? (static_cast<uint32_t>(eB) & rm) : wrap(s_slot + static_cast<uint32_t>(mb));
     const uint32_t oA = (RING ? (static_cast<uint32_t>(matchA ? eA : 0) & rm) : (matchA ? wrap(s_slot + static_cast<uint32_t>(dep1)) : 0u)) << 6;
     const uint32_t oB = slB << 6;
-    const uint32_t oC = (RING ? (static_cast<uint32_t>(eC) & rm) : (eC != eB ? wrap(slB + 1u) : slB)) << 6;
+    const uint32_t oC = (RING ? (static_cast<uint32_t>(eC) & rm) : wrap(slB + static_cast<uint32_t>(eC - eB))) << 6;
     BT bA = ring_b[oA], bB = ring_b[oB], bC = ring_b[oC];
     float rA = ring_s[oA], rB = ring_s[oB], rC = ring_s[oC];
     // (A) the piece that just matched
@@ -289,11 +314,11 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const TextCol &gt, const B
     const bool updB = ended && !single2 && (bB == 0 || candB > rB);
     const float sbest2 = updB ? candB : rB;
     const BT finB = updB ? BP::unk(mb) : bB;
-    // (C) a one-byte piece of the next start
-    const double candC = piece_score_u<UDS>(r, 1, max_score) + static_cast<double>(sbest2);
+    // (C) the piece of the next start that r stands for: its first byte, or its first character (cfirst)
+    const double candC = piece_score_u<UDS>(r, dC, max_score) + static_cast<double>(sbest2);
     const bool updC = termC && (bC == 0 || candC > static_cast<double>(rC));
     if (updA) { ring_s[oA] = nvA; ring_b[oA] = wA; }
-    if (updC) { ring_s[oC] = static_cast<float>(candC); ring_b[oC] = BP::piece(r.y, 1); }
+    if (updC) { ring_s[oC] = static_cast<float>(candC); ring_b[oC] = BP::piece(r.y, dC); }
     if (ended) {
       if ((s2 >> 3) != (s >> 3)) {                // the block of 8 positions behind s2 is complete
         BT *blk = gb.blk(s >> 3);
@@ -322,13 +347,9 @@ SPMX_DEVICE int unigram_stream_lane(const SpmxDev &d, const TextCol &gt, const B
       s_slot = slB;
       mb = begin ? mb2 : 0;
       sbest = sbest2;
-      single = termC && mb2 == 1;
-      dep = rootC ? 1 : 0;
-      if (begin) {
-        cs = win[static_cast<uint32_t>(s2 + mb2) & wmask];
-        cs1 = win[static_cast<uint32_t>(s2 + mb2 + 1) & wmask];
-        rn = roottab[cs];
-      }
+      single = termC && mb2 == dC;
+      dep = rootC ? dC : 0;
+      if (begin) first_unit(s2 + mb2, nlen);
     } else {
       dep = dep1;
       single = single2;

@@ -502,6 +502,43 @@ Status CompileTables(const ModelData &m, HostTables *t) {
 // is valid while |best_path_score before the word| < bmax, bmax = 2^(k + 1) - wmag with 2^(k - 23) the largest float
 // ulp not above gap / (4 * nchar + 4).  Words whose best path holds an unknown piece, more than two pieces, or an exact
 // tie are left out: they take the general kernels.
+// The first-character table of the piece trie (dev.h SpmxDev::cfirst).  Follows the live piece types (the units carry the
+// UNUSED flag): rebuilt with them.
+void BuildFirstCharTable(const ModelData &m, HostTables *t) {
+  t->cfirst.clear();
+  t->scalars.cfirst = nullptr;
+  if (m.model_type != kUnigram || t->ptrie.empty() || getenv("SPMX_NO_CFIRST")) return;
+  size_t multi = 0;
+  for (const auto &kv : m.pieces_map) {
+    const unsigned char c0 = kv.first.empty() ? 0 : static_cast<unsigned char>(kv.first[0]);
+    if (c0 >= 0xC2 && c0 < 0xF0) ++multi;
+  }
+  if (multi < 256) return;                               // (an ASCII vocabulary: the table would only cost cache)
+  const uint32_t root = t->ptrie[0].x >> kDatBaseShiftDev;
+  std::vector<U4> tab(65536, U4{1, 0, 0, 0});
+  for (uint32_t cp = 0x80; cp < 0x10000; ++cp) {
+    unsigned char b[3];
+    int D;
+    if (cp < 0x800) { b[0] = static_cast<unsigned char>(0xC0 | (cp >> 6)); b[1] = static_cast<unsigned char>(0x80 | (cp & 0x3F)); D = 2; }
+    else { b[0] = static_cast<unsigned char>(0xE0 | (cp >> 12)); b[1] = static_cast<unsigned char>(0x80 | ((cp >> 6) & 0x3F));
+           b[2] = static_cast<unsigned char>(0x80 | (cp & 0x3F)); D = 3; }
+    uint32_t node = root;
+    U4 u{0, 0, 0, 0};
+    bool ok = true;
+    for (int k = 0; k < D && ok; ++k) {
+      const uint32_t at = node ^ b[k];
+      if (at >= t->ptrie.size()) { ok = false; break; }
+      u = t->ptrie[at];
+      if ((u.x & 0x1FFu) != (0x100u | b[k])) { ok = false; break; }
+      if (k + 1 < D && (u.x & kDatTerminalDev)) return;  // a piece that ends inside a character: no table for this model
+      node = u.x >> kDatBaseShiftDev;
+    }
+    tab[cp] = ok ? U4{(u.x & ~0xFFu) | static_cast<uint32_t>(D), u.y, u.z, u.w} : U4{static_cast<uint32_t>(D), 0, 0, 0};
+  }
+  t->cfirst.swap(tab);
+  t->scalars.cfirst = t->cfirst.data();
+}
+
 void BuildWordMemo(const ModelData &m, HostTables *t) {
   SpmxDev &sc = t->scalars;
   t->umemo.assign(2, U4{0, 0, 0, 0});
@@ -831,6 +868,7 @@ void RefreshTypeFlags(const ModelData &m, HostTables *t) {
     }
   }
   BuildWordMemo(m, t);                  // (follows the live piece types: an UNUSED piece is no candidate)
+  BuildFirstCharTable(m, t);
 }
 
 Status CompileExtraOptions(const ModelData &m, const std::string &opts, HostTables *t) {
@@ -890,6 +928,7 @@ void BindHostPointers(HostTables *t) {
   sc.nblob = t->nblob.data();
   sc.npair = t->npair.data();
   sc.ptrie = t->ptrie.data();
+  sc.cfirst = t->cfirst.empty() ? nullptr : t->cfirst.data();
   sc.byte_ids = t->byte_ids.data();
   sc.dec_info = t->dec_info.data();
   sc.dec_off = t->dec_off.data();

@@ -19,6 +19,7 @@ struct HostTables {
   std::vector<U4> ptrie;
   std::vector<uint8_t> plen;     // per id: byte length of the piece as the device sees it (SpmxDev::plen)
   std::vector<U4> umemo, umemo16, uhot, uall, uhot2;
+  std::vector<U4> cfirst;                 // first-character table of the piece trie (SpmxDev::cfirst; empty: none)
   std::vector<uint16_t> udisp;            // displacements of uall's perfect hash (SpmxDev::udisp)   // word memo of the word form (SpmxDev::umemo, umemo16, uhot)
   std::vector<float> pscore;     // per id: score (SpmxDev::pscore)
   uint32_t memo_words = 0, memo_candidates = 0;   // entries in the memo / vocabulary strings that are whole words
