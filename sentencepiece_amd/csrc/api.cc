@@ -687,7 +687,10 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
   const bool streaming = !is_bpe || bpe_stream;
   // With the word rounds, classify also reads the text once and sets the sentences that are not plain ASCII aside
   // (kernels.h ClassifyArgs): the general launch over them runs NEXT TO the first word round, not after it.
-  const bool scanned = word_ok && streaming && !h->no_scan;
+  // A model whose words normalize by themselves (dev.h kNfWordLocalNorm) needs no scan: the word-per-lane rounds take the
+  // words that are not plain ASCII through the call-local memo, and the sentences stay with them.
+  const bool any_word = (h->dev.flags & kNfWordLocalNorm) && (h->word_form & 1) && !h->no_word_dyn;
+  const bool scanned = word_ok && streaming && !h->no_scan && !any_word;
   HIP_OR_RETURN(h, ws->d_lists.Reserve(static_cast<size_t>(2 * kMaxClasses + 3 + (word_ok ? 3 * kMaxClasses : 0) + (scanned ? kMaxClasses : 0)) * n));
   if (scanned) HIP_OR_RETURN(h, ws->d_flags.Reserve(n));
   HIP_OR_RETURN(h, ws->d_counts.Reserve(n + 1));

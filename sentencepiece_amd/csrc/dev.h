@@ -39,6 +39,11 @@ enum : uint32_t {
   // normalizer adds a dummy prefix, removes extra whitespace and escapes whitespace with the one-byte space symbol, no
   // charsmap rule starts with a byte 0x20 .. 0x7E, and the word memo (umemo) is not empty
   kNfUniWordwise = 1u << 11,
+  // the word form also takes words that are NOT plain ASCII (kernels_word.h word_resolve_block normalizes a collected word
+  // by itself): the normalizer removes extra whitespace, and no charsmap key holds a 0x20 behind its first byte -- so what
+  // Normalize makes of a word (a run of bytes other than 0x20) does not depend on its neighbours, and the sentence's
+  // normalized text is the words' own, each behind one space symbol (tables.cc BuildWordMemo)
+  kNfWordLocalNorm = 1u << 12,
 };
 
 // One-byte stand-in for U+2581 under kNfCompressSp.  0xFF never occurs in valid UTF-8, and the normalizer's

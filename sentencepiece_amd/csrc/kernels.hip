@@ -64,7 +64,7 @@ __global__ __launch_bounds__(512) void EncodeWordDpKernel(EncodeArgs a) {
   encode_word_block<true, kWmPlain>(a, smem);
 }
 __global__ __launch_bounds__(64) void WordResolveKernel(ResolveArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[64 * (kResolvePos * 12 + 20)];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kResolveLdsBytesAll];
   word_resolve_block(a, smem);
 }
 __global__ __launch_bounds__(64) void BpeLongKernel(LongArgs a) {

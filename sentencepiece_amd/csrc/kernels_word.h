@@ -462,7 +462,11 @@ SPMX_DEVICE int uni_word_lane(const EncodeArgs &a, const uint8_t *gtext, uint64_
       // a word of the call-local memo: dn = count | kDynFirstUnk (begins with an unknown piece) | kDynLastUnk | kDynWide
       const uint32_t cntd = dn & 0xFFu;
       if (n + static_cast<int>(cntd) > cap) { bad = true; active = false; }
-      else {
+      else if (cntd == 0u) {
+        // a word Normalize drops altogether: the words around it are neighbours in the normalized text; an unknown-piece
+        // run that would have to continue across it is left to the general kernels (no such run: nothing to do)
+        if (prev_unk) { bad = true; active = false; }
+      } else {
         B += wv::bits_to_float(ent.z);
         const uint32_t di[kDynMaxIds] = {dia.x, dia.y, dia.z, dia.w, dib.x, dib.y, dib.z, dib.w};
         const uint32_t k0d = (prev_unk && (dn & kDynFirstUnk)) ? 1u : 0u;                       // (:609-613 the run goes on)
@@ -885,6 +889,259 @@ SPMX_DEVICE void resolve_bpe_lane(const ResolveArgs &a, uint32_t slot, uint32_t 
   }
 }
 
+// ---- collected words that are NOT plain ASCII (dev.h kNfWordLocalNorm) --------------------------------------------------
+// The word is normalized BY ITSELF, as a sentence of its own (norm_lane_any: dummy prefix, charsmap rules, U+FFFD for a
+// malformed byte, spaces a rule or a tab brings escaped / collapsed / cut at the ends) -- which is what Normalize makes of it
+// inside its sentence, one space symbol in front included (tables.cc: no charsmap key reaches across a 0x20, extra
+// whitespace is removed).  The normalized string may hold several words of the model (a tab inside the raw word); no
+// piece reaches across their boundaries (kNfUniWordwise / kNfBpeWordwise), so the segmentation of the string is the
+// concatenation of theirs, and the margin analysis of resolve_unigram_lane holds for the string as a whole.
+constexpr int kRnBytes = 96;                   // normalized bytes of a word that is kept (longer: not usable)
+constexpr int kRnChars = 32;                   // ... and characters
+constexpr uint32_t kRnLdsPerLane = (kRnChars + 2) * 12u + kRnBytes + 16u + kRnChars + 4u + kRawWinBytes;
+struct RnText { uint8_t *nb; uint8_t *cb; int n, nch; };     // bytes, byte offset of every character (cb[nch] = n)
+
+// raw key of `slot` -> its normalized text in the lane's LDS; false: not usable (empty, too long)
+SPMX_DEVICE bool resolve_normalize(const ResolveArgs &a, uint32_t slot, uint8_t *nb, uint8_t *cb, uint8_t *rawwin, RnText *out) {
+  const SpmxDev &d = a.dev;
+  const U4 k = a.dyn_ent[4u * slot];
+  const uint32_t kw[4] = {k.x, k.y, k.z, k.w};
+  int L = 0;
+  for (int i = 0; i < 16; ++i) if (((kw[i >> 2] >> (8 * (i & 3))) & 0xFFu) != 0x20u && L == i) L = i + 1;   // (the key's padding: key_dword)
+  // A literal U+2581 in the raw word is not for this path: Normalize cuts space symbols at the END OF THE SENTENCE whether
+  // they were spaces or literals (src/normalizer.cc:166-176), so what such a word normalizes to depends on whether it is
+  // the sentence's last.
+  for (int i = 0; i + 2 < L; ++i) {
+    auto kb = [&](int q) -> uint32_t { return (kw[q >> 2] >> (8 * (q & 3))) & 0xFFu; };
+    if (kb(i) == 0xE2u && kb(i + 1) == 0x96u && kb(i + 2) == 0x81u) return false;
+  }
+  FlatSink sink{nb, nullptr, kRnBytes};
+  int nsp = 0;
+  const int n = norm_lane_any(d, reinterpret_cast<const uint8_t *>(a.dyn_ent + 4u * slot), 0, L, sink, rawwin, &nsp);
+  if (n < 0 || n > kRnBytes) return false;
+  int nch = 0;                                   // (n == 0: the word is nothing but what Normalize drops -- a tab, U+3000: no ids)
+  for (int p = 0; p < n;) {
+    if (nch >= kRnChars) return false;
+    cb[nch++] = static_cast<uint8_t>(p);
+    const uint32_t c = nb[p];
+    int l = c == SpByteOf(d) ? 1 : OneCharLenDev(c);
+    if (l > n - p) l = n - p;
+    p += l;
+  }
+  cb[nch] = static_cast<uint8_t>(n);
+  out->nb = nb; out->cb = cb; out->n = n; out->nch = nch;
+  return true;
+}
+
+// unigram: resolve_unigram_lane over the CHARACTERS of the normalized text (positions = character indices)
+SPMX_DEVICE void resolve_norm_unigram_lane(const ResolveArgs &a, uint32_t slot, float *best, float *second, uint32_t *bp, const RnText &T) {
+  const SpmxDev &d = a.dev;
+  const U4 *__restrict__ ptrie = d.ptrie;
+  const uint32_t root = d.ptrie[0].x >> kDatBaseShiftDev;
+  const int n = T.nch;
+  const float kNone = -3.0e38f;
+  for (int i = 0; i <= n; ++i) { bp[i << 6] = 0u; best[i << 6] = kNone; second[i << 6] = kNone; }
+  best[0] = 0.f;
+  float wmag = 0.f;
+  auto relax = [&](int e, float cand, uint32_t word) __attribute__((always_inline)) {
+    if (fabsf(cand) > wmag) wmag = fabsf(cand);
+    if (bp[e << 6] == 0u || cand > best[e << 6]) { second[e << 6] = bp[e << 6] == 0u ? kNone : best[e << 6]; best[e << 6] = cand; bp[e << 6] = word; }
+    else if (cand > second[e << 6]) second[e << 6] = cand;
+  };
+  for (int s = 0; s < n; ++s) {                                    // :957-1008, every character start in turn
+    const float bs = best[s << 6];
+    bool single = false;
+    uint32_t node = root;
+    int e = s;                                                     // characters matched so far end at character index e
+    for (int q = T.cb[s]; q < T.n;) {
+      const uint32_t c = T.nb[q];
+      const U4 u = ptrie[node ^ c];
+      if ((u.x & 0x1FFu) != (0x100u | c)) break;                  // :969-971
+      ++q;
+      node = u.x >> kDatBaseShiftDev;
+      if (q == T.cb[e + 1]) {                                      // a character boundary (a piece ends at one)
+        ++e;
+        if ((u.x & kDatTerminalDev) && !(u.y & kPtUnused)) {       // :973-974
+          relax(e, wv::bits_to_float(u.z) + bs, (u.y & kBwIdMask) | (static_cast<uint32_t>(e - s) << kBwLenShift));
+          if (e == s + 1) single = true;                           // :990
+        }
+      }
+    }
+    if (!single) relax(s + 1, d.unk_score + bs, (1u << kBwLenShift) | kBwUnk);      // :995-1005
+  }
+  // the best path, its smallest lead, its ids (as resolve_unigram_lane)
+  uint32_t ids[kDynMaxWide];
+  int cnt = 0;
+  uint32_t id_or = 0;
+  float gap = 3.0e38f, bound = 0.f;
+  bool good = true;
+  const bool bf = (d.flags & kNfByteFallback) != 0;
+  bool last_unk = false, first_unk = false, right_unk = false;
+  auto push = [&](uint32_t id) __attribute__((always_inline)) { if (cnt < static_cast<int>(kDynMaxWide)) { ids[cnt++] = id; id_or |= id; } else good = false; };
+  for (int e = n; e > 0 && good;) {
+    const uint32_t bw = bp[e << 6];
+    const int bl = static_cast<int>((bw >> kBwLenShift) & kBwLenMask);
+    if (bw == 0u || bl == 0 || bl > e) { good = false; break; }
+    if (second[e << 6] > kNone) { const float g = best[e << 6] - second[e << 6]; if (g < gap) gap = g; }
+    const bool unk = (bw & kBwUnk) != 0;
+    if (e == n) last_unk = unk;
+    if (e - bl == 0) first_unk = unk;
+    if (unk) {
+      bound += ceilf(fabsf(d.unk_score)) + 1.f;
+      if (bf) {                                                    // the bytes of the unknown character, last first (the list is reversed below)
+        const int b0 = T.cb[e - 1], b1 = T.cb[e];
+        if (b1 - b0 == 1 && T.nb[b0] == SpByteOf(d)) { push(static_cast<uint32_t>(d.byte_ids[0x81])); push(static_cast<uint32_t>(d.byte_ids[0x96])); push(static_cast<uint32_t>(d.byte_ids[0xE2])); }
+        else for (int q = b1 - 1; q >= b0; --q) push(static_cast<uint32_t>(d.byte_ids[T.nb[q]]));
+      } else if (!right_unk) {
+        push(static_cast<uint32_t>(d.unk_id));
+      }
+      right_unk = true;
+    } else {
+      push(bw & kBwIdMask);
+      bound += ceilf(fabsf(d.pscore[bw & kBwIdMask])) + 1.f;
+      right_unk = false;
+    }
+    e -= bl;
+  }
+  if (bf) { first_unk = false; last_unk = false; }
+  float bmax = 0.f;
+  if (good) {
+    const uint32_t we = (wv::float_to_bits(wmag) >> 23) & 0xFFu;
+    const float ulp_w = we > 23u ? wv::bits_to_float((we - 23u) << 23) : 0.f;
+    const float g2 = gap >= 3.0e38f ? gap : gap - 2.f * static_cast<float>(n) * ulp_w;
+    if (!(g2 > 0.f)) good = false;
+    else if (a.unsafe || g2 >= 3.0e38f) bmax = 3.0e38f;
+    else {
+      const float thr = g2 / (4.f * static_cast<float>(n) + 4.f);
+      const int te = static_cast<int>((wv::float_to_bits(thr) >> 23) & 0xFFu) - 127;
+      const int k = te + 23;
+      if (k + 1 > 126) bmax = 3.0e38f;
+      else if (k + 1 < -120) good = false;
+      else {
+        const float lim = wv::bits_to_float(static_cast<uint32_t>(k + 1 + 127) << 23);
+        bmax = (lim - wmag * 1.000001f) * 0.999999f;
+        if (!(bmax > 0.f)) good = false;
+      }
+    }
+  }
+  const bool wide = cnt > static_cast<int>(kDynMaxIds);
+  if (wide && id_or > 0xFFFFu) good = false;
+  if (good && cnt > 0) {
+    uint32_t o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < cnt; ++k) {
+      const uint32_t id = ids[cnt - 1 - k];
+      if (wide) o[k >> 1] |= id << (16 * (k & 1)); else o[k] = id;
+    }
+    a.dyn_ent[4u * slot + 2u] = U4{o[0], o[1], o[2], o[3]};
+    a.dyn_ent[4u * slot + 3u] = U4{o[4], o[5], o[6], o[7]};
+    a.dyn_ent[4u * slot + 1u] = U4{1u, static_cast<uint32_t>(cnt) | (first_unk ? kDynFirstUnk : 0u) | (last_unk ? kDynLastUnk : 0u) | (wide ? kDynWide : 0u),
+                                  wv::float_to_bits(bound), wv::float_to_bits(bmax)};
+  } else {
+    a.dyn_ent[4u * slot + 1u] = U4{2u, 0u, 0u, 0u};
+  }
+}
+
+// BPE: resolve_bpe_lane over the characters of the normalized text
+SPMX_DEVICE void resolve_norm_bpe_lane(const ResolveArgs &a, uint32_t slot, uint32_t *sym, float *pscore, uint32_t *pmerged, const RnText &T) {
+  const SpmxDev &d = a.dev;
+  const int n = T.nch;                                             // (<= 32: the masks below)
+  bool good = true;
+  const bool bf = (d.flags & kNfByteFallback) != 0;
+  for (int i = 0; i < n; ++i) {
+    uint32_t bytes = 0;
+    const int b0 = T.cb[i], len = T.cb[i + 1] - b0;
+    for (int q = 0; q < len && q < 4; ++q) bytes |= static_cast<uint32_t>(T.nb[b0 + q]) << (8 * q);
+    sym[i << 6] = char_lookup(d, bytes, static_cast<uint32_t>(len));
+    // a character without a symbol never merges and is the unknown piece in the end: under byte fallback its bytes'
+    // pieces; else a run of them is ONE id (sentencepiece_processor.cc:609-613), which may continue into the next word:
+    // kDynFirstUnk / kDynLastUnk.  (The space symbol always has a symbol.)
+    if (sym[i << 6] >= kSsUnknown && len == 1 && T.nb[b0] == SpByteOf(d)) good = false;
+  }
+  uint32_t alive = n >= 32 ? 0xFFFFFFFFu : (1u << n) - 1u, pmask = 0u;
+  if (good) {
+    for (int i = 0; i + 1 < n; ++i) {
+      uint32_t mg = 0; float sc = 0.f;
+      if (pair_lookup(d, sym[i << 6], sym[(i + 1) << 6], &mg, &sc)) { pmask |= 1u << i; pscore[i << 6] = sc; pmerged[i << 6] = mg; }
+    }
+    for (;;) {
+      int bi = -1;
+      float bs = 0.f;
+      for (uint32_t m = pmask; m != 0u; m &= m - 1u) {
+        const int i = wv::ffs64(static_cast<uint64_t>(m)) - 1;
+        if (bi < 0 || pscore[i << 6] > bs) { bi = i; bs = pscore[i << 6]; }
+      }
+      if (bi < 0) break;
+      const uint32_t above = bi >= 31 ? 0u : alive & ~((2u << bi) - 1u);
+      const int j = wv::ffs64(static_cast<uint64_t>(above)) - 1;
+      if (j < 0) { pmask &= ~(1u << bi); continue; }
+      const uint32_t bm = pmerged[bi << 6];
+      sym[bi << 6] = bm;
+      alive &= ~(1u << j);
+      pmask &= ~((1u << bi) | (1u << j));
+      const uint32_t below = alive & ((1u << bi) - 1u);
+      if (below) {
+        const int q = 31 - (wv::clz64(static_cast<uint64_t>(below)) - 32);
+        pmask &= ~(1u << q);
+        uint32_t mg = 0; float sc = 0.f;
+        if (pair_lookup(d, sym[q << 6], bm, &mg, &sc)) { pmask |= 1u << q; pscore[q << 6] = sc; pmerged[q << 6] = mg; }
+      }
+      const uint32_t after = bi >= 31 ? 0u : alive & ~((2u << bi) - 1u);
+      if (after) {
+        const int r = wv::ffs64(static_cast<uint64_t>(after)) - 1;
+        uint32_t mg = 0; float sc = 0.f;
+        if (pair_lookup(d, bm, sym[r << 6], &mg, &sc)) { pmask |= 1u << bi; pscore[bi << 6] = sc; pmerged[bi << 6] = mg; }
+      }
+    }
+  }
+  uint32_t ids[kDynMaxWide];
+  uint32_t id_or = 0;
+  int cnt = 0;
+  auto push = [&](uint32_t id) __attribute__((always_inline)) { if (cnt < static_cast<int>(kDynMaxWide)) { ids[cnt++] = id; id_or |= id; } else good = false; };
+  bool first_unk = false, last_unk = false, any_piece = false;
+  for (uint32_t m = alive; good && m != 0u; m &= m - 1u) {
+    const int i = wv::ffs64(static_cast<uint64_t>(m)) - 1;
+    const uint32_t sy = sym[i << 6];
+    if (sy >= kSsUnknown) {
+      if (bf) {                                      // an unmerged character without a symbol is its bytes
+        for (int q = T.cb[i]; q < T.cb[i + 1]; ++q) push(static_cast<uint32_t>(d.byte_ids[T.nb[q]]));
+        last_unk = false;
+      } else {
+        if (!last_unk) push(static_cast<uint32_t>(d.unk_id));
+        if (!any_piece) first_unk = true;
+        last_unk = true;
+      }
+      any_piece = true;
+      continue;
+    }
+    any_piece = true;
+    last_unk = false;
+    uint32_t f = sy;
+    if (sy >= d.n_pieces) {                          // PieceToId (:178): only the extra characters go through sym_final
+      f = d.sym_final[sy];
+      if (f & kSfControl) { good = false; break; }
+      f &= kSfIdMask;
+    }
+    if (static_cast<int32_t>(f) == d.unk_id) { good = false; break; }
+    push(f);
+  }
+  const bool wide = cnt > static_cast<int>(kDynMaxIds);
+  if (wide && id_or > 0xFFFFu) good = false;
+  if (good && cnt > 0) {
+    uint32_t o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < cnt; ++k) {
+      if (wide) o[k >> 1] |= ids[k] << (16 * (k & 1)); else o[k] = ids[k];
+    }
+    a.dyn_ent[4u * slot + 2u] = U4{o[0], o[1], o[2], o[3]};
+    a.dyn_ent[4u * slot + 3u] = U4{o[4], o[5], o[6], o[7]};
+    a.dyn_ent[4u * slot + 1u] = U4{1u, static_cast<uint32_t>(cnt) | (first_unk ? kDynFirstUnk : 0u) | (last_unk ? kDynLastUnk : 0u) | (wide ? kDynWide : 0u),
+                                  0u, wv::float_to_bits(3.0e38f)};
+  } else {
+    a.dyn_ent[4u * slot + 1u] = U4{2u, 0u, 0u, 0u};
+  }
+}
+
+constexpr uint32_t kResolveLdsBytesAll = 64u * (kResolvePos * 12u + 20u) > 64u * kRnLdsPerLane ? 64u * (kResolvePos * 12u + 20u) : 64u * kRnLdsPerLane;
+SPMX_HD inline uint32_t ResolveLdsBytesAll() { return kResolveLdsBytesAll; }
 SPMX_DEVICE void word_resolve_block(const ResolveArgs &a, unsigned char *smem) {
   const int lane = wv::lane();
   uint32_t count = *a.dyn_count;
@@ -893,13 +1150,46 @@ SPMX_DEVICE void word_resolve_block(const ResolveArgs &a, unsigned char *smem) {
   float *second = reinterpret_cast<float *>(smem + 64u * kResolvePos * 4u) + lane;
   uint32_t *bp = reinterpret_cast<uint32_t *>(smem + 64u * kResolvePos * 8u) + lane;
   uint8_t *wb = smem + 64u * kResolvePos * 12u + static_cast<uint32_t>(lane) * 20u;
+  // (words that are not plain ASCII: the same LDS, laid out for up to kRnChars + 1 positions, the normalized bytes and
+  // norm_lane_any's raw window)
+  float *nbest = reinterpret_cast<float *>(smem) + lane;
+  float *nsecond = reinterpret_cast<float *>(smem + 64u * (kRnChars + 2) * 4u) + lane;
+  uint32_t *nbp = reinterpret_cast<uint32_t *>(smem + 64u * (kRnChars + 2) * 8u) + lane;
+  uint8_t *ntext = smem + 64u * (kRnChars + 2) * 12u + static_cast<uint32_t>(lane) * (kRnBytes + 16u + kRnChars + 4u);
+  uint8_t *nraw = smem + 64u * ((kRnChars + 2) * 12u + kRnBytes + 16u + kRnChars + 4u) + static_cast<uint32_t>(lane) * kRawWinBytes;
+  const bool norm_ok = (a.dev.flags & kNfWordLocalNorm) != 0;
   const uint32_t lanes = static_cast<uint32_t>(wv::grid_size()) * 64u;
   for (uint32_t base = static_cast<uint32_t>(wv::block_id()) * 64u; base < count; base += lanes) {
     const uint32_t i = base + static_cast<uint32_t>(lane);
     const bool active = i < count;
     const uint32_t slot = active ? a.dyn_list[i] : 0u;
-    if (a.dev.model_type == 2) resolve_bpe_lane(a, slot, reinterpret_cast<uint32_t *>(best), second, bp, active);
-    else resolve_unigram_lane(a, slot, best, second, bp, wb, active);
+    // plain: every key byte 0x20 .. 0x7E (the word's bytes 0x21 .. 0x7E and the padding)
+    bool plain = true;
+    if (active) {
+      const U4 k = a.dyn_ent[4u * slot];
+      auto pl = [](uint32_t v) -> bool {
+        return (((v + 0x01010101u) | v) & 0x80808080u) == 0u && (((v - 0x20202020u) & ~v) & 0x80808080u) == 0u;
+      };
+      plain = pl(k.x) && pl(k.y) && pl(k.z) && pl(k.w);
+    }
+    if (wv::any(active && plain)) {
+      if (a.dev.model_type == 2) resolve_bpe_lane(a, slot, reinterpret_cast<uint32_t *>(best), second, bp, active && plain);
+      else resolve_unigram_lane(a, slot, best, second, bp, wb, active && plain);
+    }
+    wv::sync();
+    if (wv::any(active && !plain)) {
+      if (active && !plain) {
+        RnText T{nullptr, nullptr, 0, 0};
+        if (!norm_ok || !resolve_normalize(a, slot, ntext, ntext + kRnBytes + 16u, nraw, &T)) a.dyn_ent[4u * slot + 1u] = U4{2u, 0u, 0u, 0u};
+        else if (T.n == 0) {                           // no ids, no share of the bound, valid whatever came before
+          a.dyn_ent[4u * slot + 2u] = U4{0, 0, 0, 0};
+          a.dyn_ent[4u * slot + 3u] = U4{0, 0, 0, 0};
+          a.dyn_ent[4u * slot + 1u] = U4{1u, 0u, 0u, wv::float_to_bits(3.0e38f)};
+        }
+        else if (a.dev.model_type == 2) resolve_norm_bpe_lane(a, slot, reinterpret_cast<uint32_t *>(nbest), nsecond, nbp, T);
+        else resolve_norm_unigram_lane(a, slot, nbest, nsecond, nbp, T);
+      }
+    }
     wv::sync();
   }
 }

@@ -111,6 +111,7 @@ SPMX_DEVICE void encode_wordwave_block(const EncodeArgs &a, unsigned char *smem)
   const bool perfect = d.uall_perfect != 0u;
   const int n_extra = d.n_prefix + d.n_suffix;
   const bool keep_ws = (d.flags & kNfRemoveExtraWs) == 0;
+  const bool any_word = (d.flags & kNfWordLocalNorm) != 0;
   const uint64_t tbase = reinterpret_cast<uint64_t>(a.text);
   WaveCounters tc;
   WwStage SA{}, SB{};                                               // the two batches of the word pipeline (below)
@@ -340,7 +341,8 @@ SPMX_DEVICE void encode_wordwave_block(const EncodeArgs &a, unsigned char *smem)
               return (((v + 0x01010101u) | v) & 0x80808080u) == 0u && (((v - 0x20202020u) & ~v) & 0x80808080u) == 0u;
             };
             bool kept = false;
-            if (plain(k0) && plain(k1) && plain(k2) && plain(k3)) {
+            // (dev.h kNfWordLocalNorm: any word goes in -- word_resolve_block normalizes the ones that are not plain)
+            if (any_word || (plain(k0) && plain(k1) && plain(k2) && plain(k3))) {
               uint32_t sl = static_cast<uint32_t>(tag >> 32) & a.dyn_mask;
               // (the first slot's tag came with the probe, stage A: most occurrences of a word find it entered)
               unsigned long long g0 = static_cast<unsigned long long>(S.tg_hi) << 32 | S.tg_lo;
@@ -393,6 +395,13 @@ SPMX_DEVICE void encode_wordwave_block(const EncodeArgs &a, unsigned char *smem)
         if (hitd && (dn & kDynFirstUnk) && prev_unk) skip = 1u;
       }
       const uint32_t cntd = dn & 0xFFu;
+      if (MODE == kWmDyn) {
+        // a word Normalize drops altogether (no ids): its neighbours are neighbours in the normalized text; an unknown-piece
+        // run that would have to continue across it is left to the general kernels
+        const uint32_t pl = wv::lane_up1(lastunk, 0u);
+        const bool prev_unk = head ? (cont && carry_unk != 0u) : pl != 0u;
+        if (word && hitd && cntd == 0u && prev_unk) gone = true;
+      }
       const uint32_t cnt = !word ? 0u : (hitd ? cntd - skip : (hit ? (id1 != 0xFFFFFFFFu ? 2u : 1u) : 0u));
       const uint32_t packed = (x << 12) | cnt;
       const uint32_t Sc = wv::scan_add(packed);

@@ -192,6 +192,7 @@ Status CompileTables(const ModelData &m, HostTables *t) {
         if (p >= u.size() || (u[p] & 0x800000FFu) != c) continue;
         const uint32_t child = p ^ offset(u[p]);
         const uint32_t depth = nd.depth + 1;
+        if (c == 0x20u && nd.depth >= 1) t->charsmap_inner_space = true;   // (every edge of the trie lies on the way to a key)
         if ((u[p] >> 8) & 1u) {                             // a key ends here: its value sits in the unit at child
           if (child < u.size()) {
             const uint32_t off = u[child] & 0x7FFFFFFFu;
@@ -509,11 +510,13 @@ void BuildFirstCharTable(const ModelData &m, HostTables *t) {
   t->scalars.cfirst = nullptr;
   if (m.model_type != kUnigram || t->ptrie.empty() || getenv("SPMX_NO_CFIRST")) return;
   size_t multi = 0;
+  const bool one_byte_sp = (t->scalars.flags & kNfCompressSp) != 0;      // (the space symbol is then the byte 0xFF in the trie's keys)
   for (const auto &kv : m.pieces_map) {
     const unsigned char c0 = kv.first.empty() ? 0 : static_cast<unsigned char>(kv.first[0]);
+    if (one_byte_sp && kv.first.compare(0, 3, kSpaceSymbol) == 0) continue;
     if (c0 >= 0xC2 && c0 < 0xF0) ++multi;
   }
-  if (multi < 256) return;                               // (an ASCII vocabulary: the table would only cost cache)
+  if (multi < 1024) return;                              // (an ASCII vocabulary: the table would only cost cache)
   const uint32_t root = t->ptrie[0].x >> kDatBaseShiftDev;
   std::vector<U4> tab(65536, U4{1, 0, 0, 0});
   for (uint32_t cp = 0x80; cp < 0x10000; ++cp) {
@@ -530,13 +533,17 @@ void BuildFirstCharTable(const ModelData &m, HostTables *t) {
       if (at >= t->ptrie.size()) { ok = false; break; }
       u = t->ptrie[at];
       if ((u.x & 0x1FFu) != (0x100u | b[k])) { ok = false; break; }
-      if (k + 1 < D && (u.x & kDatTerminalDev)) return;  // a piece that ends inside a character: no table for this model
+      if (k + 1 < D && (u.x & kDatTerminalDev)) {        // a piece that ends inside a character: no table for this model
+        if (getenv("SPMX_DEBUG_TABLES")) fprintf(stderr, "spmx: no first-character table: a piece ends inside U+%04X\n", cp);
+        return;
+      }
       node = u.x >> kDatBaseShiftDev;
     }
     tab[cp] = ok ? U4{(u.x & ~0xFFu) | static_cast<uint32_t>(D), u.y, u.z, u.w} : U4{static_cast<uint32_t>(D), 0, 0, 0};
   }
   t->cfirst.swap(tab);
   t->scalars.cfirst = t->cfirst.data();
+  if (getenv("SPMX_DEBUG_TABLES")) fprintf(stderr, "spmx: first-character table built (%zu pieces start with a multi-byte character)\n", multi);
 }
 
 void BuildWordMemo(const ModelData &m, HostTables *t) {
@@ -553,7 +560,7 @@ void BuildWordMemo(const ModelData &m, HostTables *t) {
   t->uhot2.assign(2048, U4{0, 0, 0, 0xFFFFFFFFu});
   sc.umemo_mask = 0;
   sc.umemo16_mask = 0;
-  sc.flags &= ~kNfUniWordwise;
+  sc.flags &= ~(kNfUniWordwise | kNfWordLocalNorm);
   t->memo_words = t->memo_candidates = 0;
   t->pscore.assign(m.pieces.size() + 1, 0.f);
   for (size_t i = 0; i < m.pieces.size(); ++i) t->pscore[i] = m.pieces[i].score;
@@ -844,6 +851,8 @@ void BuildWordMemo(const ModelData &m, HostTables *t) {
     }
   }
   sc.flags |= kNfUniWordwise;
+  // words that are not plain ASCII through the call-local memo (dev.h kNfWordLocalNorm)
+  if ((F & kNfRemoveExtraWs) && !t->charsmap_inner_space && !getenv("SPMX_NO_WORD_NORM")) sc.flags |= kNfWordLocalNorm;
   t->memo_words = static_cast<uint32_t>(ents.size());
 }
 

@@ -14,6 +14,7 @@ struct HostTables {
   // normalizer
   std::vector<uint32_t> ndarts;
   std::vector<uint8_t> nblob;
+  bool charsmap_inner_space = false;      // some charsmap key holds a 0x20 behind its first byte (dev.h kNfWordLocalNorm)
   std::vector<uint32_t> npair;   // 65536 bits, see SpmxDev::npair
   // unigram
   std::vector<U4> ptrie;

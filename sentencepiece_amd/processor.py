@@ -70,6 +70,7 @@ class SentencePieceProcessor:
         if rc != _OK:
             raise RuntimeError(self._lib.spmx_last_error(None).decode("utf-8", "replace"))
         self._h = h
+        self._pid = os.getpid()
         self._extra = self._applied = ""
         self._model_proto = bytes(model_proto)
         return True
@@ -91,7 +92,11 @@ class SentencePieceProcessor:
 
     def _close(self):
         if self._h:
-            self._lib.spmx_destroy(self._h)
+            # A handle belongs to the process that made it: a forked child (a multiprocessing pool started while a
+            # processor is alive) inherits the object, not the HIP context behind it -- its collector must not call into the
+            # runtime (that aborts the child, and a pool then waits for ever for the worker it lost).
+            if getattr(self, "_pid", None) == os.getpid():
+                self._lib.spmx_destroy(self._h)
             self._h = None
 
     def __del__(self):

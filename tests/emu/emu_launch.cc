@@ -63,7 +63,7 @@ hipError_t LaunchEncodeWordWave(int mode, const EncodeArgs &a, int grid, int wav
   return hipSuccess;
 }
 hipError_t LaunchWordResolve(const ResolveArgs &a, int grid, hipStream_t) {
-  RunGrid(grid, 1, ResolveLdsBytes(), [&](unsigned char *s) { word_resolve_block(a, s); });
+  RunGrid(grid, 1, ResolveLdsBytesAll(), [&](unsigned char *s) { word_resolve_block(a, s); });
   return hipSuccess;
 }
 hipError_t LaunchBpeLong(const LongArgs &a, int grid, hipStream_t) {
