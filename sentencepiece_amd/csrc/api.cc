@@ -302,6 +302,7 @@ struct spmx_handle {
   // SetDecodeExtraOptions: the net effect of the options on a sentence's ids (kernels_decode.h DecodeArgs::x_*)
   int32_t dx_npre = 0, dx_nsuf = 0, dx_pre[kMaxExtra] = {0}, dx_suf[kMaxExtra] = {0};
   bool dx_reverse = false;
+  bool no_direct = false;        // SPMX_NO_DIRECT=1: the word rounds take classify's lists even where they could do without
   int fork_cus = 0;              // SPMX_FORK_CUS: the general launch beside the word rounds takes at most this many CUs (0: every CU)
   int fork_waves = 4;            // SPMX_FORK_WAVES: wavefronts per workgroup of the general launch while it runs next to the first word round (0: by its size)
   bool no_overlap = false;       // SPMX_NO_OVERLAP=1: the general launches do not run next to the word rounds
@@ -753,15 +754,23 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
     HIP_OR_RETURN(h, hipMemsetAsync(ws->d_ctrl, 0, sizeof(Ctrl), stream));
     HIP_OR_RETURN(h, hipMemsetAsync(d_status, 0, n, stream));
     for (bool &u : ws->slot_used) u = false;
-    if (int rc = RunClassify(h, ws, d_offsets, n32, stream, scanned ? d_text : nullptr, text_bytes, scanned ? gen_lists : nullptr); rc != kOk) return rc;
-    HIP_OR_RETURN(h, hipMemcpyAsync(ws->h_ctrl->list_counts, ws->d_ctrl->list_counts,
-                                    sizeof(ws->h_ctrl->list_counts) + sizeof(ws->h_ctrl->gen_counts),       // (gen_counts follows list_counts in Ctrl)
-                                    hipMemcpyDeviceToHost, stream));
-    HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+    // DIRECT: both word rounds in the word-per-lane form over a model whose words normalize by themselves -- the first
+    // round takes the sentences in input order, 64 to a tile, and finds a sentence's length class itself where it matters
+    // (kernels.h EncodeArgs::direct): no classify pass, no read-back of its counts
+    const bool direct = word_ok && any_word && h->word_form == 3 && !h->no_direct && streaming;
     uint32_t known[kMaxClasses] = {0};       // the class lists: every sentence, or (scanned) the plain ones
     uint32_t gen_known[kMaxClasses] = {0};   // (scanned) the sentences set aside for the general kernels
     uint64_t gen_total = 0;
-    for (int c = 0; c < ncls; ++c) { known[c] = ws->h_ctrl->list_counts[c]; gen_known[c] = ws->h_ctrl->gen_counts[c]; gen_total += gen_known[c]; }
+    if (!direct) {
+      if (int rc = RunClassify(h, ws, d_offsets, n32, stream, scanned ? d_text : nullptr, text_bytes, scanned ? gen_lists : nullptr); rc != kOk) return rc;
+      HIP_OR_RETURN(h, hipMemcpyAsync(ws->h_ctrl->list_counts, ws->d_ctrl->list_counts,
+                                      sizeof(ws->h_ctrl->list_counts) + sizeof(ws->h_ctrl->gen_counts),       // (gen_counts follows list_counts in Ctrl)
+                                      hipMemcpyDeviceToHost, stream));
+      HIP_OR_RETURN(h, hipStreamSynchronize(stream));
+      for (int c = 0; c < ncls; ++c) { known[c] = ws->h_ctrl->list_counts[c]; gen_known[c] = ws->h_ctrl->gen_counts[c]; gen_total += gen_known[c]; }
+    } else {
+      known[0] = n32;                        // (one run of tiles; the classes are the kernel's business)
+    }
     // what every encode launch shares
     EncodeArgs a{};
     a.dev = h->dev; a.text = d_text; a.offs = d_offsets;
@@ -1033,10 +1042,24 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         const uint64_t n_waves = grid * waves;
         wa.n_classes = static_cast<uint32_t>(ncls);
         uint32_t tile_base = 0;
+        wa.direct = direct ? 1u : 0u;
+        if (direct && mode != 2) wa.lists = nullptr;             // (the first round: sentence = tile's first + lane)
         for (int c = ncls - 1; c >= 0; --c) {
           StreamClass &sc = wa.cls[c];
           sc = StreamClass{};
           sc.rcap = rcaps[c];
+          if (direct) {                                          // every tile from row 0; a class only names documents and lists
+            sc.lane_shift = 6;
+            sc.general = ((uni_class[c] && cls[c].rcap > kMaxStagedRaw) || cls[c].rcap > h->main_max_raw) ? 1u : 0u;
+            if (c == 0) {
+              sc.count = static_cast<uint32_t>(total);
+              sc.tw = 64;
+              sc.main_tiles = static_cast<uint32_t>((total + 63) / 64);
+              sc.tile_base = 0;
+              tile_base = sc.main_tiles;
+            }
+            continue;
+          }
           if (known[c] == 0) continue;
           uint64_t tw = (static_cast<uint64_t>(known[c]) + n_waves - 1) / n_waves;
           if (tw > 64) tw = 64;
@@ -1501,6 +1524,7 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_NO_OVERLAP")) h->no_overlap = e[0] == '1';
     if (const char *e = getenv("SPMX_FORK_WAVES")) h->fork_waves = atoi(e);
     if (const char *e = getenv("SPMX_FORK_CUS")) h->fork_cus = atoi(e);
+    if (const char *e = getenv("SPMX_NO_DIRECT")) h->no_direct = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_SCAN")) h->no_scan = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_IDS16")) h->no_ids16 = e[0] == '1';
     if (const char *e = getenv("SPMX_DYN_SLOTS_LOG2")) { const int v = atoi(e); if (v >= 4 && v <= 26) h->dyn_slots = 1u << v; }

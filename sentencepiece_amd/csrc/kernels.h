@@ -110,6 +110,10 @@ struct EncodeArgs {
   uint32_t dyn_cap;             // entries dyn_list holds
   U4 *resume;                   // per sentence the first round keeps for the second: {position, ids written, bound, 0}
   uint32_t ids16;               // the word kernels write 16-bit ids into their arena slots (vocabularies of up to 65536 pieces)
+  // word-per-lane rounds WITHOUT classify (kernels_wordwave.h): tiles are runs of 64 sentences in input order (lists ==
+  // null: sentence first + lane) or of one list (row 0 of lists); a sentence's length class -- which only says whether it
+  // is a document (cls[].general) and which list it goes to when the word form hands it on -- is found from cls[].rcap
+  uint32_t direct;
   // ---- sentence-per-wave launch (BPE models that are not word-wise; kernels_bpe.h) ----
   const uint32_t *list;         // sentence indices of this length class
   const uint32_t *list_count;   // number of entries in list (device resident)

@@ -1101,11 +1101,22 @@ SPMX_DEVICE void resolve_norm_bpe_lane(const ResolveArgs &a, uint32_t slot, uint
   for (uint32_t m = alive; good && m != 0u; m &= m - 1u) {
     const int i = wv::ffs64(static_cast<uint64_t>(m)) - 1;
     const uint32_t sy = sym[i << 6];
-    if (sy >= kSsUnknown) {
-      if (bf) {                                      // an unmerged character without a symbol is its bytes
-        for (int q = T.cb[i]; q < T.cb[i + 1]; ++q) push(static_cast<uint32_t>(d.byte_ids[T.nb[q]]));
+    uint32_t f = sy;
+    bool unk = sy >= kSsUnknown;                     // a character without a symbol: never merged, the unknown piece
+    if (!unk && sy >= d.n_pieces) {                  // PieceToId (:178): only the extra characters go through sym_final
+      f = d.sym_final[sy];
+      if (f & kSfControl) { good = false; break; }
+      f &= kSfIdMask;
+    }
+    if (!unk && static_cast<int32_t>(f) == d.unk_id) unk = true;      // (a character whose piece is not in the vocabulary: never merged either)
+    if (unk) {
+      if (bf) {                                      // its bytes' pieces (sentencepiece_processor.cc:581-601)
+        for (int q = T.cb[i]; q < T.cb[i + 1]; ++q) {
+          if (T.nb[q] == SpByteOf(d)) { push(static_cast<uint32_t>(d.byte_ids[0xE2])); push(static_cast<uint32_t>(d.byte_ids[0x96])); push(static_cast<uint32_t>(d.byte_ids[0x81])); }
+          else push(static_cast<uint32_t>(d.byte_ids[T.nb[q]]));
+        }
         last_unk = false;
-      } else {
+      } else {                                       // a run of them is ONE id (:609-613)
         if (!last_unk) push(static_cast<uint32_t>(d.unk_id));
         if (!any_piece) first_unk = true;
         last_unk = true;
@@ -1115,13 +1126,6 @@ SPMX_DEVICE void resolve_norm_bpe_lane(const ResolveArgs &a, uint32_t slot, uint
     }
     any_piece = true;
     last_unk = false;
-    uint32_t f = sy;
-    if (sy >= d.n_pieces) {                          // PieceToId (:178): only the extra characters go through sym_final
-      f = d.sym_final[sy];
-      if (f & kSfControl) { good = false; break; }
-      f &= kSfIdMask;
-    }
-    if (static_cast<int32_t>(f) == d.unk_id) { good = false; break; }
     push(f);
   }
   const bool wide = cnt > static_cast<int>(kDynMaxIds);
@@ -1172,6 +1176,9 @@ SPMX_DEVICE void word_resolve_block(const ResolveArgs &a, unsigned char *smem) {
       };
       plain = pl(k.x) && pl(k.y) && pl(k.z) && pl(k.w);
     }
+    // (BPE: the normalizing path also keeps characters the model lacks -- a plain "?!" or "3.14159" in a vocabulary without
+    // those characters -- so every word takes it where the model allows)
+    if (norm_ok && a.dev.model_type == 2) plain = false;
     if (wv::any(active && plain)) {
       if (a.dev.model_type == 2) resolve_bpe_lane(a, slot, reinterpret_cast<uint32_t *>(best), second, bp, active && plain);
       else resolve_unigram_lane(a, slot, best, second, bp, wb, active && plain);

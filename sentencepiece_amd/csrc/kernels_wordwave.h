@@ -77,7 +77,7 @@ struct WwStage {
   uint32_t e0x, e0y, e0z, e0w, e1x, e1y, e1z, e1w;   // what `uall` holds at the word's hash: {key} {ids, bound share, limit}
   // the call-local memo at the word's hash (collecting / second round): the slot's tag; (second round) its key and state
   uint32_t tg_lo, tg_hi;
-  uint32_t d0x, d0y, d0z, d0w, d1x, d1y, d1z, d1w;
+  uint32_t d0x, d0y, d0z, d0w, d1x, d1y, d1z, d1w, d2x, d2y, d2z, d2w;
 };
 constexpr uint32_t kWwHit16 = 0x100u;
 
@@ -122,17 +122,23 @@ SPMX_DEVICE void encode_wordwave_block(const EncodeArgs &a, unsigned char *smem)
     got = wv::shfl(got, 0);
     if (!got) break;
     c = wv::shfl(c, 0); first = wv::shfl(first, 0); ucnt = wv::shfl(ucnt, 0);
-    const uint32_t *list = a.lists + static_cast<uint64_t>(c) * a.n;
+    const bool direct = a.direct != 0u;
+    const uint32_t *list = a.lists ? a.lists + static_cast<uint64_t>(c) * a.n : nullptr;
     const bool have = static_cast<uint32_t>(lane) < ucnt;
     uint32_t sid = 0;
     uint64_t beg = 0, l64 = 0;
     if (have) {
-      sid = list[first + static_cast<uint32_t>(lane)];
+      sid = list ? list[first + static_cast<uint32_t>(lane)] : first + static_cast<uint32_t>(lane);
       beg = a.offs[sid];
       l64 = a.offs[sid + 1] - beg;
     }
+    uint32_t cl = c;                                 // the sentence's length class
+    if (direct) {
+      cl = a.n_classes - 1u;
+      for (int k = static_cast<int>(a.n_classes) - 2; k >= 0; --k) if (l64 <= a.cls[k].rcap) cl = static_cast<uint32_t>(k);
+    }
     // (a class marked `general` passes through: documents belong to the wave-cooperative form, kernels_uniwave.h)
-    const bool mine = have && !a.cls[c].general && l64 <= kWwMaxLen;
+    const bool mine = have && !a.cls[cl].general && l64 <= kWwMaxLen;
     // ---- a slot of cap ids in the arena per sentence, as encode_word_block_as lays them out ----
     const int cap = mine ? static_cast<int>(l64) + 1 : 0;
     const int room = (mine && MODE != kWmDyn) ? (cap + n_extra + 3 + 3) & ~3 : 0;
@@ -270,8 +276,9 @@ SPMX_DEVICE void encode_wordwave_block(const EncodeArgs &a, unsigned char *smem)
         const unsigned long long g = MODE == kWmCollect ? wv::atomic_load64(&a.dyn_tag[dsl]) : a.dyn_tag[dsl];
         S.tg_lo = static_cast<uint32_t>(g); S.tg_hi = static_cast<uint32_t>(g >> 32);
         if (MODE == kWmDyn) {
-          const U4 d0 = a.dyn_ent[4u * dsl], d1 = a.dyn_ent[4u * dsl + 1u];
+          const U4 d0 = a.dyn_ent[4u * dsl], d1 = a.dyn_ent[4u * dsl + 1u], d2 = a.dyn_ent[4u * dsl + 2u];
           S.d0x = d0.x; S.d0y = d0.y; S.d0z = d0.z; S.d0w = d0.w; S.d1x = d1.x; S.d1y = d1.y; S.d1z = d1.z; S.d1w = d1.w;
+          S.d2x = d2.x; S.d2y = d2.y; S.d2z = d2.z; S.d2w = d2.w;
         }
       }
     };
@@ -306,26 +313,29 @@ SPMX_DEVICE void encode_wordwave_block(const EncodeArgs &a, unsigned char *smem)
       uint32_t dn = 0;
       U4 dia{0, 0, 0, 0}, dib{0, 0, 0, 0};
       uint32_t dbound = 0u, dlim = 0u;
-      const unsigned long long tag = MODE == kWmPlain ? 0ull : DynTag(k0, k1, k2, k3);
       if (MODE == kWmDyn && wv::any(probe & !hit32)) {
         if (probe & !hit32) {
+          const unsigned long long tag = DynTag(k0, k1, k2, k3);
           // the slot the word's hash names came with the probe (stage A); the ids are asked for now; another slot (a
           // collision in the table) is walked to -- rare: the table is sparse
           uint32_t sl = static_cast<uint32_t>(tag >> 32) & a.dyn_mask;
           unsigned long long g = static_cast<unsigned long long>(S.tg_hi) << 32 | S.tg_lo;
-          U4 d0{S.d0x, S.d0y, S.d0z, S.d0w}, d1{S.d1x, S.d1y, S.d1z, S.d1w};
+          U4 d0{S.d0x, S.d0y, S.d0z, S.d0w}, d1{S.d1x, S.d1y, S.d1z, S.d1w}, d2{S.d2x, S.d2y, S.d2z, S.d2w};
           for (uint32_t t = 0; t < kDynProbes; ++t) {
             if (g == 0ull) break;
             if (g == tag) {
               if (d0.x == k0 && d0.y == k1 && d0.z == k2 && d0.w == k3 && d1.x == 1u) {
                 hitd = true; dn = d1.y; dbound = d1.z; dlim = d1.w;
-                dia = a.dyn_ent[4u * sl + 2u]; dib = a.dyn_ent[4u * sl + 3u];
+                dia = d2;
+                // (the second half of the ids: only a word of more than four pieces -- or more than eight under kDynWide -- has it)
+                const uint32_t cn = d1.y & 0xFFu;
+                if ((d1.y & kDynWide) ? cn > 8u : cn > 4u) dib = a.dyn_ent[4u * sl + 3u];
               }
               break;                                     // (same hash, other bytes or an unusable word: a miss)
             }
             sl = (sl + 1u) & a.dyn_mask;
             g = a.dyn_tag[sl];
-            d0 = a.dyn_ent[4u * sl]; d1 = a.dyn_ent[4u * sl + 1u];
+            d0 = a.dyn_ent[4u * sl]; d1 = a.dyn_ent[4u * sl + 1u]; d2 = a.dyn_ent[4u * sl + 2u];
           }
         }
       }
@@ -343,6 +353,7 @@ SPMX_DEVICE void encode_wordwave_block(const EncodeArgs &a, unsigned char *smem)
             bool kept = false;
             // (dev.h kNfWordLocalNorm: any word goes in -- word_resolve_block normalizes the ones that are not plain)
             if (any_word || (plain(k0) && plain(k1) && plain(k2) && plain(k3))) {
+              const unsigned long long tag = DynTag(k0, k1, k2, k3);
               uint32_t sl = static_cast<uint32_t>(tag >> 32) & a.dyn_mask;
               // (the first slot's tag came with the probe, stage A: most occurrences of a word find it entered)
               unsigned long long g0 = static_cast<unsigned long long>(S.tg_hi) << 32 | S.tg_lo;
@@ -561,14 +572,25 @@ SPMX_DEVICE void encode_wordwave_block(const EncodeArgs &a, unsigned char *smem)
     }
     const bool left = have && !done;
     if (left) a.counts[sid] = 0u;                    // (until a later pass has had it)
+    // (direct: what is handed on goes to the list of its LENGTH class -- the general kernels plan by those; what the second
+    // round takes is one list, row 0)
+    auto hand_on = [&](bool pred, uint32_t *lists, uint32_t *counts) __attribute__((always_inline)) {
+      if (!direct) { append_lanes(wv::ballot(pred), pred, sid, lists + static_cast<uint64_t>(c) * a.n, &counts[c], lane); return; }
+      if (!wv::any(pred)) return;
+      for (uint32_t k = 0; k < a.n_classes; ++k) {
+        const bool pk = pred && cl == k;
+        append_lanes(wv::ballot(pk), pk, sid, lists + static_cast<uint64_t>(k) * a.n, &counts[k], lane);
+      }
+    };
     if (MODE == kWmCollect) {
       const bool again = left && work && st == kWwAgain;
       const bool gonel = left && !again;
       if (again) a.tmp_off[sid] = static_cast<unsigned long long>(slot - d.n_prefix - a.arena);
-      append_lanes(wv::ballot(again), again, sid, a.left_lists + static_cast<uint64_t>(c) * a.n, &a.left_counts[c], lane);
-      append_lanes(wv::ballot(gonel), gonel, sid, a.left2_lists + static_cast<uint64_t>(c) * a.n, &a.left2_counts[c], lane);
+      const uint32_t ca = direct ? 0u : c;
+      append_lanes(wv::ballot(again), again, sid, a.left_lists + static_cast<uint64_t>(ca) * a.n, &a.left_counts[ca], lane);
+      hand_on(gonel, a.left2_lists, a.left2_counts);
     } else {
-      append_lanes(wv::ballot(left), left, sid, a.left_lists + static_cast<uint64_t>(c) * a.n, &a.left_counts[c], lane);
+      hand_on(left, a.left_lists, a.left_counts);
     }
     if (done) { ++tc.n_sent; tc.n_raw += static_cast<unsigned long long>(len); tc.n_ids += static_cast<unsigned long long>(n + n_extra); }
     tc.n_trips += steps;
