@@ -894,6 +894,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
     // ---- the general kernels over one set of class lists (`cnt` sentences per class; cnt is consumed) ----
     // tail: what the word rounds left (thin lists: a sentence per wavefront where the model allows it; its streaming launch
     // has a tile queue of its own, the early launches' may still be running on the second stream)
+    int tail_qi = 5;                        // the tile queue of a tail launch (a second tail launch of the call takes another: a queue is used once)
     auto general_pass = [&](const uint32_t *lists, const uint32_t *d_counts, uint32_t *cnt, bool tail) -> int {
       a.lists = lists;
       d_list_counts = d_counts;
@@ -912,7 +913,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
             cnt[c] = 0;
           }
         }
-        if (tail) return stream_launch(kSlotDoc, 5, 0, ncls, cnt, false, 0);
+        if (tail) return stream_launch(kSlotDoc, tail_qi, 0, ncls, cnt, false, 0);
         int c_doc = ncls;                    // first class of the document launch
         for (int c = 0; c < ncls; ++c) if (cls[c].rcap > h->main_max_raw) { c_doc = c; break; }
         if (int rc = stream_launch(kSlotMain, 0, 0, c_doc, cnt, false, 0); rc != kOk) return rc;
@@ -1129,9 +1130,31 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
           }
           // round 2 over what round 1 kept for it; what it cannot take either (a margin that does not hold, a word of
           // more than 8 pieces) is APPENDED to the lists of what round 1 gave up for good: one tail launch takes both
+          // DIRECT (nothing else uses the second stream): what round 1 gave up for good is known NOW -- its tail launch goes
+          // to the second stream and runs beside resolve and round 2 (a few hundred sentences on C2: 0.3 ms of launches and
+          // read-backs off the step's critical path); round 2 then keeps a list of its own for what it cannot take.
+          uint32_t gone1[kMaxClasses] = {0};
+          uint64_t gone1_total = 0;
+          for (int c = 0; c < ncls; ++c) { gone1[c] = ws->h_ctrl->left_counts[1][c]; gone1_total += gone1[c]; }
+          const bool early_tail = direct && !forked && !h->no_overlap && gone1_total > 0;
+          if (early_tail) left_at = 2;
           for (int c = 0; c < ncls; ++c) known[c] = again_counts[c];
           a.lists = left_lists[0];
-          FORKED_OR_RETURN(word_pass(2, kSlotWord2, 4, left_lists[1], ws->d_ctrl->left_counts[1], nullptr, nullptr));
+          FORKED_OR_RETURN(word_pass(2, kSlotWord2, 4, left_lists[left_at], ws->d_ctrl->left_counts[left_at], nullptr, nullptr));
+          if (early_tail) {
+            HIP_OR_RETURN(h, hipEventRecord(ws->ev_fork, stream));          // (round 1 has ended: the read-back above waited for it)
+            HIP_OR_RETURN(h, hipStreamWaitEvent(ws->stream2, ws->ev_fork, 0));
+            forked = true;
+            stream = ws->stream2;
+            tail_qi = 0;                                                     // (no main launch in a direct call: its queue is free)
+            const int rc = general_pass(left_lists[1], ws->d_ctrl->left_counts[1], gone1, true);
+            tail_qi = 5;
+            hipError_t ej = rc == kOk ? hipEventRecord(ws->ev_join, stream) : hipSuccess;
+            stream = main_stream;
+            if (rc != kOk) return fail_forked(rc);
+            if (ej != hipSuccess) return fail_forked(FailHip(h, ej, "hipEventRecord(join)"));
+            a.lists = left_lists[0];
+          }
           FORKED_OR_RETURN(read_counts());
         }
       } else {

@@ -77,6 +77,7 @@ struct WwStage {
   uint32_t e0x, e0y, e0z, e0w, e1x, e1y, e1z, e1w;   // what `uall` holds at the word's hash: {key} {ids, bound share, limit}
   // the call-local memo at the word's hash (collecting / second round): the slot's tag; (second round) its key and state
   uint32_t tg_lo, tg_hi;
+  uint32_t warm;                 // (wave-uniform) the tag was asked for in stage A
   uint32_t d0x, d0y, d0z, d0w, d1x, d1y, d1z, d1w, d2x, d2y, d2z, d2w;
 };
 constexpr uint32_t kWwHit16 = 0x100u;
@@ -115,6 +116,7 @@ SPMX_DEVICE void encode_wordwave_block(const EncodeArgs &a, unsigned char *smem)
   const uint64_t tbase = reinterpret_cast<uint64_t>(a.text);
   WaveCounters tc;
   WwStage SA{}, SB{};                                               // the two batches of the word pipeline (below)
+  uint32_t dyn_warm = 0u;                                           // (collecting round) batches for which stage A still asks the call-local memo's tags
   for (;;) {
     const unsigned long long cs = wv::clock();
     uint32_t c = 0, first = 0, ucnt = 0, got = 0;
@@ -271,10 +273,15 @@ SPMX_DEVICE void encode_wordwave_block(const EncodeArgs &a, unsigned char *smem)
       S.e0x = e0.x; S.e0y = e0.y; S.e0z = e0.z; S.e0w = e0.w; S.e1x = e1.x; S.e1y = e1.y; S.e1z = e1.z; S.e1w = e1.w;
       if (MODE != kWmPlain) {
         // the call-local memo is asked at the same time (most words that come this far are in `uall`: what this brings is
-        // then not looked at -- but a word that needs it would otherwise wait a second round trip, and its wavefront with it)
-        const uint32_t dsl = (valid & !hit16 & (L <= 16u)) ? (h1 & a.dyn_mask) : 0u;
+        // then not looked at -- but a word that needs it would otherwise wait a second round trip, and its wavefront with it).
+        // Collecting round: only while the wavefront keeps meeting words the memo lacks (dyn_warm: set by stage B, counted
+        // down here) -- on text the load-time memo fits, the slot's tag is fetched when a word needs it.
+        const bool pre = MODE == kWmDyn || dyn_warm != 0u;
+        if (MODE == kWmCollect && dyn_warm != 0u) --dyn_warm;
+        const uint32_t dsl = (pre & valid & !hit16 & (L <= 16u)) ? (h1 & a.dyn_mask) : 0u;
         const unsigned long long g = MODE == kWmCollect ? wv::atomic_load64(&a.dyn_tag[dsl]) : a.dyn_tag[dsl];
         S.tg_lo = static_cast<uint32_t>(g); S.tg_hi = static_cast<uint32_t>(g >> 32);
+        S.warm = pre ? 1u : 0u;
         if (MODE == kWmDyn) {
           const U4 d0 = a.dyn_ent[4u * dsl], d1 = a.dyn_ent[4u * dsl + 1u], d2 = a.dyn_ent[4u * dsl + 2u];
           S.d0x = d0.x; S.d0y = d0.y; S.d0z = d0.z; S.d0w = d0.w; S.d1x = d1.x; S.d1y = d1.y; S.d1z = d1.z; S.d1w = d1.w;
@@ -344,6 +351,7 @@ SPMX_DEVICE void encode_wordwave_block(const EncodeArgs &a, unsigned char *smem)
       bool miss = false;
       if (MODE == kWmCollect) {
         if (wv::any(probe && !hit32)) {
+          dyn_warm = 16u;
           if (probe && !hit32) {
             // ---- a word the memo lacks: into the call-local memo (once per word per call), if it is plain: the key is
             // the word's bytes and 0x20s, so every byte of it is within 0x20 .. 0x7E ----
@@ -355,10 +363,12 @@ SPMX_DEVICE void encode_wordwave_block(const EncodeArgs &a, unsigned char *smem)
             if (any_word || (plain(k0) && plain(k1) && plain(k2) && plain(k3))) {
               const unsigned long long tag = DynTag(k0, k1, k2, k3);
               uint32_t sl = static_cast<uint32_t>(tag >> 32) & a.dyn_mask;
-              // (the first slot's tag came with the probe, stage A: most occurrences of a word find it entered)
+              // (the first slot's tag came with the probe, stage A, while the wavefront is warm: most occurrences of a word
+              // find it entered)
               unsigned long long g0 = static_cast<unsigned long long>(S.tg_hi) << 32 | S.tg_lo;
+              const bool have0 = S.warm != 0u;
               for (uint32_t t = 0; t < kDynProbes && !kept; ++t) {
-                unsigned long long g = t == 0u ? g0 : wv::atomic_load64(&a.dyn_tag[sl]);
+                unsigned long long g = (t == 0u && have0) ? g0 : wv::atomic_load64(&a.dyn_tag[sl]);
                 if (g == 0ull) g = wv::atomic_cas(&a.dyn_tag[sl], 0ull, tag);
                 if (g == 0ull) {                         // ours: the word's bytes, and a place in the list of words to segment
                   const uint32_t at2 = wv::atomic_add(a.dyn_count, 1u);
@@ -454,8 +464,10 @@ SPMX_DEVICE void encode_wordwave_block(const EncodeArgs &a, unsigned char *smem)
           if (wide) return t < 16u ? (di[(t >> 1) & 7u] >> (16u * (t & 1u))) & 0xFFFFu : 0u;
           return t < 8u ? di[t & 7u] : 0u;
         };
+        const uint32_t maxc = wv::read_lane(wv::scan_max((emit && hitd) ? cnt : 0u), 63);     // (most such words are two or three pieces)
 #pragma unroll
         for (uint32_t t = 0; t < kDynMaxWide; ++t) {
+          if (t >= maxc) break;
           if (emit && hitd && t < cnt) {
             const uint32_t id = skip ? idc(t + 1u) : idc(t);
             if (H16) reinterpret_cast<uint16_t *>(a.arena + so)[nb + t] = static_cast<uint16_t>(id);
