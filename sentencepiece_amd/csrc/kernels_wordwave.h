@@ -47,7 +47,7 @@ constexpr uint32_t kWwUnits = kWwRing / 16u;        // 256
 constexpr uint32_t kWwMaskBytes = (kWwUnits + 4u) * 2u + 8u;   // a 16-bit space mask per unit (+ the first four again behind the end)
 constexpr uint32_t kWwRecs = 128u + 512u;           // the word queue: what the last round left (< 128) + at most 8 starts per unit
 constexpr uint32_t kWwMaxLen = 65536u;              // longer sentences are not taken (record positions have 26 bits)
-constexpr uint32_t kWwPerWave = kWwRing + kWwRingPad + kWwMaskBytes + kWwRecs * 4u + 64u * 16u + 64u * 8u + 3u * 64u * 4u;
+constexpr uint32_t kWwPerWave = kWwRing + kWwRingPad + kWwMaskBytes + kWwRecs * 4u + 64u * 16u + 64u * 8u + 5u * 64u * 4u;
 static_assert(kWwPerWave % 16u == 0u, "per-wave LDS blocks keep 16-byte alignment");
 constexpr uint32_t kWwAgain = 1u, kWwGone = 2u;     // per-sentence status bits
 constexpr uint32_t kWwKeyMaskBytes = 640u;          // 18 rows {key mask, padding under the mask's zeros} of 32 bytes (+ slack)
@@ -96,6 +96,7 @@ SPMX_DEVICE void encode_wordwave_block(const EncodeArgs &a, unsigned char *smem)
   U4 *sent = reinterpret_cast<U4 *>(recq + kWwRecs);          // per sentence of the tile: {start, end (positions in the tile's unit stream), arena slot}
   U2 *sent_ua = reinterpret_cast<U2 *>(sent + 64);            // ... the address of its first unit
   uint32_t *s_nids = reinterpret_cast<uint32_t *>(sent_ua + 64), *s_stat = s_nids + 64, *s_first = s_stat + 64;
+  uint32_t *s_n0 = s_first + 64, *s_x0 = s_n0 + 64;            // (second round) ids / bound in front of where the sentence is taken up
   {   // the shared read-only table (every wave writes the same values: no workgroup barrier)
     if (lane < 18) {
       const uint32_t L = static_cast<uint32_t>(lane);
@@ -156,9 +157,18 @@ SPMX_DEVICE void encode_wordwave_block(const EncodeArgs &a, unsigned char *smem)
     const int at = excl + d.n_prefix;
     const int shift = (4 - (at & 3)) & 3;
     int32_t *slot = a.arena + base + static_cast<unsigned long long>(excl + shift) + d.n_prefix;
-    if (MODE == kWmDyn && mine) slot = a.arena + a.tmp_off[sid] + d.n_prefix;   // (the sentence keeps the slot the first round gave it)
+    // (second round) the sentence keeps the slot the first round gave it -- and the ids in it: it is taken up at its
+    // first missing word (a.resume: where that word starts, the ids in front of it, the bound of |score| there)
+    uint32_t p0 = 0u, n0 = 0u, x0 = 0u;
+    if (MODE == kWmDyn && mine) {
+      slot = a.arena + a.tmp_off[sid] + d.n_prefix;
+      const U4 rs = a.resume[sid];
+      const float bf0 = wv::bits_to_float(rs.z);
+      if (rs.x < l64 && rs.y <= rs.x && bf0 >= 0.f && bf0 < 16777216.f) { p0 = rs.x; n0 = rs.y; x0 = static_cast<uint32_t>(bf0); }
+    }
     const bool work = mine && !overflow;
-    const uint32_t len = work ? static_cast<uint32_t>(l64) : 0u;
+    const uint32_t len = work ? static_cast<uint32_t>(l64) - p0 : 0u;
+    beg += p0;
     // ---- the tile's unit stream: sentence j's units follow sentence j - 1's ----
     const uint32_t begmod = static_cast<uint32_t>((tbase + beg) & 15ull);
     const uint32_t nun = len ? (begmod + len + 15u) >> 4 : 0u;
@@ -171,9 +181,10 @@ SPMX_DEVICE void encode_wordwave_block(const EncodeArgs &a, unsigned char *smem)
       const uint64_t so = static_cast<uint64_t>(slot - a.arena);
       sent[lane] = U4{start, start + len, static_cast<uint32_t>(so), static_cast<uint32_t>(so >> 32)};
       sent_ua[lane] = U2{static_cast<uint32_t>(ua), static_cast<uint32_t>(ua >> 32)};
-      s_nids[lane] = 0u;
+      s_nids[lane] = n0;
       s_stat[lane] = 0u;
       s_first[lane] = 0xFFFFFFFFu;
+      if (MODE == kWmDyn) { s_n0[lane] = n0; s_x0[lane] = x0; }
     }
     wv::sync();
     const unsigned long long c0 = wv::clock();
@@ -430,7 +441,10 @@ SPMX_DEVICE void encode_wordwave_block(const EncodeArgs &a, unsigned char *smem)
       const uint32_t hE = wv::scan_max(head ? E : 0u);
       const uint32_t rel = E - hE;
       uint32_t xb = rel >> 12, nb = rel & 0xFFFu;
+      uint32_t n0j = 0u;
+      if (MODE == kWmDyn) n0j = s_n0[j];
       if (cont) { xb += carry_x; nb += carry_n; }
+      else if (MODE == kWmDyn) { xb += s_x0[j]; nb += n0j; }       // (the sentence's first words here: what the first round left in front of them)
       {   // the carry for the next 64 words: what the last word's sentence has behind it now
         const int lv = static_cast<int>(S.cnt - 1u);
         carry_j = wv::read_lane(j, lv);
@@ -442,7 +456,7 @@ SPMX_DEVICE void encode_wordwave_block(const EncodeArgs &a, unsigned char *smem)
       // rounds can only round towards refusing: lim is a float)
       if (word && hit && !(xb < (1u << 24) && static_cast<float>(xb) < lim)) gone = true;
       const U4 sj = sent[j];                                         // {start, end, arena slot}
-      if (MODE == kWmDyn && word && hit && nb + cnt > sj.y - sj.x + 1u) gone = true;   // (more ids than the slot holds: byte fallback of a finely split word)
+      if (MODE == kWmDyn && word && hit && nb + cnt > sj.y - sj.x + 1u + n0j) gone = true;   // (more ids than the slot holds: byte fallback of a finely split word)
       const bool emit = word && hit && !gone;
       // ---- ids ----
       const uint64_t so = static_cast<uint64_t>(sj.w) << 32 | sj.z;
