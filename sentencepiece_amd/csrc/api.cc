@@ -906,9 +906,21 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         // lane-per-sentence kernels are the wrong tool -- documents (one lane would walk them alone: 2.5 us per byte),
         // and classes with too few sentences to fill 64 lanes of every wavefront
         if (uni_wave) {
-          const bool few = tail && total < 4096;
+          // A tail launch (what the word rounds handed on) is bound by the LATENCY of a lane-per-sentence tile's longest
+          // sentence -- about 4.5 us per byte of the largest class present, whatever the count (C2's classes: 2.3 ms) -- while a
+          // sentence per wavefront costs by the VOLUME: about 0.27 ms per MB of class capacity over the ~4000 wavefronts in
+          // flight (open-vocabulary text: 50 k sentences of C2's lengths in 0.7 ms against 2.7; botchan's short lines: 3.2 ms
+          // against 0.4 -- gpurun_out r05v / r05w).  The cheaper estimate wins; documents of a tail (no main launch to hide
+          // behind) always take the wavefront form.
+          uint64_t tail_vol = 0, rcap_max = 0;
           for (int c = 0; c < ncls; ++c) {
-            if (cnt[c] == 0 || !(uni_class[c] || few)) continue;
+            tail_vol += static_cast<uint64_t>(cnt[c]) * cls[c].rcap;
+            if (cnt[c] && cls[c].rcap <= kMaxStagedRaw && cls[c].rcap > rcap_max) rcap_max = cls[c].rcap;
+          }
+          const double est_wave_ms = 2.7e-7 * static_cast<double>(tail_vol), est_lane_ms = 4.5e-3 * static_cast<double>(rcap_max);
+          const bool few = tail && (total < 4096 || est_wave_ms < est_lane_ms);
+          for (int c = 0; c < ncls; ++c) {
+            if (cnt[c] == 0 || !(uni_class[c] || few || (tail && cls[c].rcap > kMaxStagedRaw))) continue;
             if (int rc = long_launch(lists + static_cast<size_t>(c) * n, &d_counts[c], cnt[c], true); rc != kOk) return rc;
             cnt[c] = 0;
           }
@@ -1051,7 +1063,10 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
           sc.rcap = rcaps[c];
           if (direct) {                                          // every tile from row 0; a class only names documents and lists
             sc.lane_shift = 6;
-            sc.general = ((uni_class[c] && cls[c].rcap > kMaxStagedRaw) || cls[c].rcap > h->main_max_raw) ? 1u : 0u;
+            // (without classify's counts nobody knows whether documents are the bulk of the batch: beyond the staged classes a
+            // sentence is handed on -- the bound of |score| a few thousand words add up leaves the margins of a long text's
+            // later words behind anyway -- and the tail launch gives it a wavefront)
+            sc.general = cls[c].rcap > kMaxStagedRaw ? 1u : 0u;
             if (c == 0) {
               sc.count = static_cast<uint32_t>(total);
               sc.tw = 64;
@@ -1174,6 +1189,8 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       for (int c = 0; c < ncls; ++c) {
         known[c] = ws->h_ctrl->left_counts[left_at][c];
         if (cls[c].rcap <= h->main_max_raw) leftover += known[c];
+        // (the first round's give-ups went to their own tail launch already -- left_at == 2 -- and count all the same)
+        if (left_at == 2 && cls[c].rcap <= h->main_max_raw) leftover += ws->h_ctrl->left_counts[1][c];
       }
       // The word rounds pay on text that is mostly plain ASCII words: a handle remembers when a batch they were given
       // went almost entirely on to the general kernels and leaves them out of its next few calls (see word_ok above).
