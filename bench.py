@@ -169,7 +169,7 @@ def probe_exact(text, offs, model_blob, gpu_ids, gpu_id_offsets, k=None):
         what, r["kind"], r["seconds"], r["differing"])
 
 
-def side_bench(sp_cls, torch, dev, name, blob, text, offs, steps, warmup, what, probe_k=None):
+def side_bench(sp_cls, torch, dev, name, blob, text, offs, steps, warmup, what, probe_k=None, corpus=None):
     """A compact record of one more single-GPU configuration: value, kernels, roofline fraction of
     the dominant kernel, ids of a sample against the compiled reference."""
     sp = sp_cls(model_proto=blob, device=dev.index or 0)
@@ -201,7 +201,7 @@ def side_bench(sp_cls, torch, dev, name, blob, text, offs, steps, warmup, what, 
         out["roofline"] = {"kernel": dom["kernel"], "kernel_ms": dom["kernel_ms"], "sentences_per_launch": dom["sentences"],
                            "algorithmic_bytes_per_launch": dom["bytes"], "achieved": ach, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS}
-        out["roofline"]["traffic"], _, out["roofline"]["traffic_note"] = traffic_on_record(name, n, dom["kernel"])
+        out["roofline"]["traffic"], _, out["roofline"]["traffic_note"] = traffic_on_record(name if corpus is None else name + "@" + corpus, n, dom["kernel"])
     try:
         io_h = io.cpu().numpy()
         out["probe_ids_bit_exact"], out["probe"] = probe_exact(text, offs, blob, ids[:int(io_h[-1])].cpu().numpy(), io_h, probe_k)
@@ -212,8 +212,16 @@ def side_bench(sp_cls, torch, dev, name, blob, text, offs, steps, warmup, what, 
     return out
 
 
-def corpus_for(model, sentences, seed, unsorted):
+def corpus_for(model, sentences, seed, unsorted, corpus="synthetic"):
     from sentencepiece_amd import synth
+    if corpus == "open_vocab":
+        return synth.open_vocab_corpus(sentences, seed=20250301)
+    if corpus == "botchan":
+        return synth.repeated_file_corpus(os.path.join(ROOT, "tests", "golden", "botchan.txt"), 2000)
+    if corpus in ("docs_16k", "docs_1m"):
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import docs_rate
+        return docs_rate.make_docs(*((8192, 16384) if corpus == "docs_16k" else (256, 1 << 20)))
     if model.startswith("c5_"):
         return synth.mixed_corpus(sentences, seed=seed + 1)
     # uni32k_w16: the same generator over words of up to 16 letters (scripts/train_w16.py): pieces of up to 17 bytes,
@@ -252,6 +260,9 @@ def main():
     ap.add_argument("--no-second-model", action="store_true")
     ap.add_argument("--no-side-configs", action="store_true",
                     help="leave the c3 (32k BPE), c5 (250k unigram, mixed script) and document sub-records out of the line")
+    ap.add_argument("--corpus", choices=["synthetic", "open_vocab", "botchan", "docs_16k", "docs_1m"], default="synthetic",
+                    help="one of the side configurations' corpora as the main workload (scripts/pmc_traffic.sh: the PMC passes "
+                         "behind the side records' `traffic`); the line's metric is BASELINE.json's only with `synthetic`")
     ap.add_argument("--unsorted", action="store_true",
                     help="do not length-bucket the synthetic corpus (BASELINE.json's configs are length-bucketed)")
     args = ap.parse_args()
@@ -302,7 +313,10 @@ def main():
     # The corpus first: the generator forks a process pool, which is safest before this process has a HIP context
     # or an RCCL communicator.  Weak scaling: every rank draws its own shard of the generator (seed + rank).
     c5 = args.model.startswith("c5_")
-    text, offs = corpus_for(args.model, args.sentences, 20250227 + rank, args.unsorted)
+    text, offs = corpus_for(args.model, args.sentences, 20250227 + rank, args.unsorted, args.corpus)
+    if args.corpus != "synthetic":
+        args.sentences = len(offs) - 1
+        args.no_second_model = args.no_side_configs = True
     second = None
     if world == 1 and args.model == "uni32k" and not args.no_second_model and \
             os.path.exists(os.path.join(ROOT, "tests", "golden", "uni32k_w16.model")):
@@ -418,7 +432,7 @@ def main():
         achieved = cls["bytes"] / (k_ms[dom] * 1e-3) / 1e9 if k_ms[dom] > 0 else 0.0
         kname = cls["kernel"]
         sha = kernel_sources_sha()
-        traffic, traffic_lower, traffic_note = traffic_on_record(args.model, args.sentences, kname)
+        traffic, traffic_lower, traffic_note = traffic_on_record(args.model if args.corpus == "synthetic" else args.model + "@" + args.corpus, args.sentences, kname)
         out = {
             "metric": "sentences/sec EncodeBatch, %s %s, MI355X" % ("250k" if c5 else "32k",
                                                                      "unigram" if sp.model_type() == 1 else "bpe"),
@@ -430,7 +444,9 @@ def main():
                      else "u8 text -> i32 ids; f32 compares",
             "data": "synthetic",
             "gb_text_per_s": job_bytes * args.steps / dt / 1e9,
-            "config": {"workload": "configs[%d]: %s model, %d synthetic %s sentences per GPU, mean %.1f B, "
+            "config": {"workload": ("side corpus `%s` (see the default line's record of that name), %s model, %d sentences, resident in HBM"
+                                    % (args.corpus, args.model, n)) if args.corpus != "synthetic" else
+                                   "configs[%d]: %s model, %d synthetic %s sentences per GPU, mean %.1f B, "
                                    "%s, resident in HBM"
                                    % (4 if c5 else ((1 if world == 1 else 3) if sp.model_type() == 1 else 2), args.model, n,
                                       "mixed-script power-law [16, 4096] B" if c5 else "ASCII", len(text) / n,
@@ -545,7 +561,8 @@ def main():
                                       ("natural_botchan_x2000", lambda: synth.repeated_file_corpus(os.path.join(ROOT, "tests", "golden", "botchan.txt"), 2000),
                                        "tests/golden/botchan.txt x 2000, lines shuffled per repetition, in file order (not length-bucketed)")):
                     tn, on = mk()
-                    out[key] = side_bench(SentencePieceProcessor, torch, dev, "uni32k", blob, tn, on, args.steps, args.warmup, what)
+                    out[key] = side_bench(SentencePieceProcessor, torch, dev, "uni32k", blob, tn, on, args.steps, args.warmup, what,
+                                          corpus=key.split("_", 1)[1].replace("_x2000", ""))
                     out[key]["vs_headline"] = out[key]["value"] / out["value"]
                     del tn, on
             except Exception as e:
@@ -568,7 +585,7 @@ def main():
                 for key, nd, nb in (("docs_16k", 8192, 16384), ("docs_1m", 256, 1 << 20)):
                     td, od = docs_rate.make_docs(nd, nb)
                     out[key] = side_bench(SentencePieceProcessor, torch, dev, "uni32k", blob, td, od, max(1, args.steps // 2), 1,
-                                          "%d documents of ~%d bytes (C2 sentences joined by spaces), uni32k" % (nd, nb))
+                                          "%d documents of ~%d bytes (C2 sentences joined by spaces), uni32k" % (nd, nb), corpus=key)
                     out[key]["mb_per_s"] = len(td) / 1e6 / (out[key]["ms_per_step"] * 1e-3)
                     del td, od
             except Exception as e:

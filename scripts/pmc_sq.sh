@@ -11,7 +11,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_WAVES SQ_CYCLES"; do
   i=$((i+1))
   if [ -n "$GROUPS_MAX" ] && [ $i -gt $GROUPS_MAX ]; then break; fi
-  timeout 70 rocprofv3 --kernel-trace --pmc $grp -d gpurun_out/pmc_sq/g$i -o pmc -- python bench.py --sentences $N --steps 2 --warmup 1 --no-cpu-baseline --no-second-model --no-side-configs > gpurun_out/pmc_sq/g$i.log 2>&1
+  timeout 70 rocprofv3 --kernel-trace --pmc $grp -d gpurun_out/pmc_sq/g$i -o pmc -- python bench.py --model ${MODEL:-uni32k} --sentences $N --steps 2 --warmup 1 --no-cpu-baseline --no-second-model --no-side-configs > gpurun_out/pmc_sq/g$i.log 2>&1
   echo "group $i rc=$?"
 done
 python - <<'PY'

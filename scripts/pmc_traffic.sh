@@ -1,14 +1,15 @@
 # HBM traffic of the encode kernels: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (the TCC
 # block cannot hold both; gpurun also refuses --pmc together with other trace domains), on the headline bench
 # command.  Usage on the GPU box: bash scripts/pmc_traffic.sh <tag> [sentences]
-TAG=${1:-r02}; N=${2:-10000000}; MODEL=${3:-uni32k}
+TAG=${1:-r02}; N=${2:-10000000}; MODEL=${3:-uni32k}; CORPUS=${CORPUS:-synthetic}
+KEY=$MODEL; [ "$CORPUS" != synthetic ] && KEY=$MODEL@$CORPUS
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$TAG; mkdir -p $O
 for C in ${COUNTERS:-FETCH_SIZE WRITE_SIZE}; do
-  timeout ${PASS_TIMEOUT:-200} rocprofv3 --kernel-trace --pmc $C -d $O/pmc_$C -o pmc -- python bench.py --model $MODEL --sentences $N --steps 2 --warmup 1 --no-cpu-baseline --no-second-model --no-side-configs > $O/pmc_$C.log 2>&1
+  timeout ${PASS_TIMEOUT:-200} rocprofv3 --kernel-trace --pmc $C -d $O/pmc_$C -o pmc -- python bench.py --model $MODEL --corpus $CORPUS --sentences $N --steps 2 --warmup 1 --no-cpu-baseline --no-second-model --no-side-configs > $O/pmc_$C.log 2>&1
   echo "$C rc=$?"
 done
-python - "$O" "$N" "$MODEL" <<'PY'
+python - "$O" "$N" "$KEY" <<'PY'
 import sqlite3, glob, sys, json
 O, N, MODEL = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 sys.path.insert(0, '.')
@@ -36,7 +37,7 @@ for r in rows:
     agg.setdefault(r[0], {})[r[1]] = r[3]
 out = {}
 for k, v in agg.items():
-    if 'Encode' in k and v.get('FETCH_SIZE', 0) + v.get('WRITE_SIZE', 0) > 1000:
+    if ('Encode' in k or 'UniLong' in k or 'BpeLong' in k) and v.get('FETCH_SIZE', 0) + v.get('WRITE_SIZE', 0) > 1000:
         name = k.split('(')[0].replace('void ', '').replace('spmx::', '')
         # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE counts 16 B/lane reads at half their bytes -> doubled
         out["%s:%d:%s" % (MODEL, N, name)] = {"bytes": int((2 * v.get('FETCH_SIZE', 0) + v.get('WRITE_SIZE', 0)) * 1024),

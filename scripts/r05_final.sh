@@ -9,12 +9,18 @@ if [ -z "$SKIP_TESTS" ]; then ( time timeout 900 python -m pytest tests -m gpu -
 PASS_TIMEOUT=120 bash scripts/pmc_traffic.sh $TAG 10000000 uni32k > $O/pmc_traffic_uni.log 2>&1; tail -3 $O/pmc_traffic_uni.log | cut -c1-200
 PASS_TIMEOUT=120 bash scripts/pmc_traffic.sh $TAG 10000000 bpe32k > $O/pmc_traffic_bpe.log 2>&1
 PASS_TIMEOUT=120 bash scripts/pmc_traffic.sh $TAG 1000000 c5_250k > $O/pmc_traffic_c5.log 2>&1
+PASS_TIMEOUT=120 bash scripts/pmc_traffic.sh $TAG 1000000 c5_250k_bf > $O/pmc_traffic_c5bf.log 2>&1
+PASS_TIMEOUT=120 bash scripts/pmc_traffic.sh $TAG 10000000 bpe1k_llama > $O/pmc_traffic_llama.log 2>&1
+CORPUS=open_vocab PASS_TIMEOUT=120 bash scripts/pmc_traffic.sh $TAG 10000000 uni32k > $O/pmc_traffic_ov.log 2>&1
+CORPUS=botchan PASS_TIMEOUT=120 bash scripts/pmc_traffic.sh $TAG 8576000 uni32k > $O/pmc_traffic_botchan.log 2>&1
+CORPUS=docs_16k PASS_TIMEOUT=120 bash scripts/pmc_traffic.sh $TAG 8192 uni32k > $O/pmc_traffic_docs16k.log 2>&1
+CORPUS=docs_1m PASS_TIMEOUT=150 bash scripts/pmc_traffic.sh $TAG 256 uni32k > $O/pmc_traffic_docs1m.log 2>&1
 python - "$O" <<'PY'
 import json, sys
 O = sys.argv[1]
 out = {}
 note = ""
-for m in ("uni32k", "c5_250k", "bpe32k"):
+for m in ("uni32k", "c5_250k", "bpe32k", "c5_250k_bf", "bpe1k_llama", "uni32k@open_vocab", "uni32k@botchan", "uni32k@docs_16k", "uni32k@docs_1m"):
     try:
         d = json.load(open("%s/pmc_traffic_%s.json" % (O, m)))
     except Exception as e:
@@ -30,6 +36,6 @@ for M in uni32k bpe32k; do
   DB=$(find $O/prof -name "x_results.db" | head -1); python scripts/rocpd_summary.py "$DB" > $O/${M}_10m_kernel_stats.txt 2>&1; rm -rf $O/prof
 done
 head -8 $O/uni32k_10m_kernel_stats.txt | cut -c1-150
-GROUPS_MAX=2 bash scripts/pmc_sq.sh 2000000 > $O/uni32k_2m_pmc_sq.txt 2>&1; rm -rf gpurun_out/pmc_sq; grep -c "EncodeWord" $O/uni32k_2m_pmc_sq.txt; cp profiles/pmc_traffic.json $O/pmc_traffic_used.json
+GROUPS_MAX=2 bash scripts/pmc_sq.sh 2000000 > $O/uni32k_2m_pmc_sq.txt 2>&1; rm -rf gpurun_out/pmc_sq; grep -c "EncodeWord" $O/uni32k_2m_pmc_sq.txt; MODEL=c5_250k GROUPS_MAX=2 bash scripts/pmc_sq.sh 1000000 > $O/c5_1m_pmc_sq.txt 2>&1; rm -rf gpurun_out/pmc_sq; cp profiles/pmc_traffic.json $O/pmc_traffic_used.json
 ( time timeout 900 python bench.py > $O/bench_uni32k_10m.json 2> $O/bench.err ) 2> $O/bench_wall.txt; tail -3 $O/bench_wall.txt; tail -c 400 $O/bench_uni32k_10m.json
 ls $O
