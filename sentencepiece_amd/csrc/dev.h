@@ -15,6 +15,8 @@ namespace spmx {
 struct U2 { uint32_t x, y; };
 struct U4 { uint32_t x, y, z, w; };
 struct alignas(16) Q4 { uint32_t x, y, z, w; };   // one aligned 16-byte load
+struct alignas(8) D2 { uint32_t x, y; };           // one aligned 8-byte load
+struct alignas(16) L2 { uint64_t x, y; };          // one aligned 16-byte store of two offsets
 
 // normalizer flags
 enum : uint32_t {

@@ -909,13 +909,30 @@ SPMX_DEVICE uint64_t wave_excl_scan64(uint64_t v, int lane, uint64_t *total) {
   return incl - v;
 }
 
+// Whole tiles take the coalesced form below when the two arrays are aligned for it (they are, wherever the caller's offsets
+// come from an allocator): a lane owns TWO consecutive counts of a 128-count row, 16 rows to the tile, so a wave's load is
+// 512 contiguous bytes and its store of offsets 1 KB of whole lines -- the lane-owns-32-consecutive form wrote every
+// 32-byte granule in four visits of 8 bytes (rocprofv3 WRITE_SIZE: 610 MB for the 80 MB of C2's offsets, 0.17 ms).  The
+// row's prefix sums are two DPP scans of 32-bit halves (26 + 7 bits: 64 lanes of them cannot carry out).
+SPMX_DEVICE bool scan_rows_ok(const ScanArgs &a) {
+  return ((reinterpret_cast<uintptr_t>(a.counts) & 7u) | (reinterpret_cast<uintptr_t>(a.id_offs) & 15u)) == 0;
+}
+constexpr uint32_t kScanRows = kScanTile / 128;
+
 SPMX_DEVICE void scan_tiles_block(const ScanArgs &a) {     // pass 1
   const int lane = wv::lane();
   const uint32_t tiles = (a.n + kScanTile - 1) / kScanTile;
+  const bool rows_ok = scan_rows_ok(a);
   for (uint32_t tile = static_cast<uint32_t>(wv::block_id()); tile < tiles; tile += static_cast<uint32_t>(wv::grid_size())) {
-    const uint32_t first = tile * kScanTile + static_cast<uint32_t>(lane) * 32;
     uint64_t s = 0;
-    for (uint32_t k = 0; k < 32; ++k) if (first + k < a.n) s += a.counts[first + k];
+    if (rows_ok && tile * kScanTile + kScanTile <= a.n) {
+      const D2 *src = reinterpret_cast<const D2 *>(a.counts + static_cast<size_t>(tile) * kScanTile) + lane;
+#pragma unroll
+      for (uint32_t k = 0; k < kScanRows; ++k) { const D2 c = src[k * 64]; s += static_cast<uint64_t>(c.x) + c.y; }
+    } else {
+      const uint32_t first = tile * kScanTile + static_cast<uint32_t>(lane) * 32;
+      for (uint32_t k = 0; k < 32; ++k) if (first + k < a.n) s += a.counts[first + k];
+    }
     uint64_t total = 0;
     wave_excl_scan64(s, lane, &total);
     if (lane == 0) a.tile_sums[tile] = total;
@@ -940,7 +957,28 @@ SPMX_DEVICE void scan_sums_block(const ScanArgs &a) {      // pass 2, ONE wave
 SPMX_DEVICE void scan_final_block(const ScanArgs &a) {     // pass 3
   const int lane = wv::lane();
   const uint32_t tiles = (a.n + kScanTile - 1) / kScanTile;
+  const bool rows_ok = scan_rows_ok(a);
   for (uint32_t tile = static_cast<uint32_t>(wv::block_id()); tile < tiles; tile += static_cast<uint32_t>(wv::grid_size())) {
+    if (rows_ok && tile * kScanTile + kScanTile <= a.n) {
+      const D2 *src = reinterpret_cast<const D2 *>(a.counts + static_cast<size_t>(tile) * kScanTile) + lane;
+      L2 *dst = reinterpret_cast<L2 *>(a.id_offs + static_cast<size_t>(tile) * kScanTile) + lane;
+      uint64_t carry = a.tile_sums[tile];
+      D2 c[kScanRows];
+#pragma unroll
+      for (uint32_t k = 0; k < kScanRows; ++k) c[k] = src[k * 64];
+#pragma unroll
+      for (uint32_t k = 0; k < kScanRows; ++k) {
+        const uint64_t v = static_cast<uint64_t>(c[k].x) + c[k].y;
+        const uint32_t lo = wv::scan_add(static_cast<uint32_t>(v) & 0x3FFFFFFu), hi = wv::scan_add(static_cast<uint32_t>(v >> 26));
+        const uint64_t before = carry + lo + (static_cast<uint64_t>(hi) << 26) - v;
+        L2 o;
+        o.x = before;
+        o.y = before + c[k].x;
+        dst[k * 64] = o;
+        carry += static_cast<uint64_t>(wv::read_lane(lo, 63)) + (static_cast<uint64_t>(wv::read_lane(hi, 63)) << 26);
+      }
+      continue;
+    }
     const uint32_t first = tile * kScanTile + static_cast<uint32_t>(lane) * 32;
     uint64_t s = 0;
     for (uint32_t k = 0; k < 32; ++k) if (first + k < a.n) s += a.counts[first + k];
@@ -963,7 +1001,12 @@ struct CompactArgs {
   int32_t *ids;
   uint64_t ids_cap;
   uint32_t n;
+  uint32_t staged = 1;   // blocks of 16-bit ids go through LDS (SPMX_COMPACT_STAGED=0: every block by the search form)
 };
+
+// LDS of a CompactKernel wave: the 16-bit ids of its 64 sentences, in CSR order
+constexpr uint32_t kCompactLdsIds = 4096;
+constexpr uint32_t kCompactLdsBytes = (kCompactLdsIds + 8) * 2;
 
 // Moves every sentence's ids from where its wave happened to put them in the arena to their place in the
 // caller's CSR.  A wave takes 64 consecutive sentences: their CSR range is contiguous, so the output is written
@@ -974,11 +1017,18 @@ struct CompactArgs {
 // 16-byte read at the slot's alignment, a 16-byte store: 1.06 ms against this form's 0.81 on the same 10 M sentences,
 // profiles/r04_ab_kernel_stats.txt: the quads that cross a sentence boundary, one in seven, run a second path in
 // almost every round.)
-SPMX_DEVICE void compact_block(const CompactArgs &a) {
+//
+// Blocks whose sentences all hold 16-bit ids (the word kernels' output: C2, C3) and fit the wave's LDS take the STAGED form
+// (round 5): a lane copies ITS sentence from the arena into LDS at the sentence's place in the block's CSR range -- 16-byte
+// reads at the slot's own alignment, eight ids each, four or five of them for a C2 sentence -- and the wave then streams
+// the LDS image out, four ids a lane as one aligned 16-byte store.  No search at all: about 300 instructions for a block
+// of 1900 ids against 1350 (30 rounds x (9 cross-lane reads + a 2-byte load + a 4-byte store)).
+SPMX_DEVICE void compact_block(const CompactArgs &a, uint16_t *lds) {
   const int lane = wv::lane();
   if (a.id_offs[a.n] > a.ids_cap) return;   // caller sees the needed size in id_offs[n]
   const uint32_t blocks = (a.n + 63) / 64;
   const uint16_t *arena16 = reinterpret_cast<const uint16_t *>(a.arena);
+  const bool staged_ok = a.staged != 0 && (reinterpret_cast<uintptr_t>(a.arena) & 15u) == 0;
   for (uint32_t b = static_cast<uint32_t>(wv::block_id()); b < blocks; b += static_cast<uint32_t>(wv::grid_size())) {
     const uint32_t s = b * 64 + static_cast<uint32_t>(lane);
     const uint32_t sc = s < a.n ? s : a.n;                     // id_offs[n] closes the last block
@@ -990,6 +1040,60 @@ SPMX_DEVICE void compact_block(const CompactArgs &a) {
     const uint32_t total = static_cast<uint32_t>(a.id_offs[last] - dst0);
     const uint32_t rel = static_cast<uint32_t>(my_dst - dst0);
     const uint32_t src_lo = static_cast<uint32_t>(my_src), src_hi = static_cast<uint32_t>(my_src >> 32);
+    if (staged_ok && total + 3u <= kCompactLdsIds) {
+      const uint32_t nxt = wv::shfl(rel, (lane + 1) & 63);
+      const uint32_t cnt = (lane == 63 ? total : nxt) - rel;     // (lanes past the last sentence sit at `total`: 0)
+      if (!wv::any(cnt != 0u && (src_hi >> 31) == 0u)) {
+        // where the block's first id lands within its 16-byte unit of the output: LDS entry e <-> a.ids[dst0 - m + e]
+        const uint32_t m = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(a.ids + dst0) >> 2) & 3u;
+        const uint64_t base16 = (static_cast<uint64_t>(src_hi & 0x7FFFFFFFu) << 32) | src_lo;
+        const uint32_t mis = static_cast<uint32_t>(base16) & 7u;
+        const Q4 *q = reinterpret_cast<const Q4 *>(arena16 + (base16 - mis));
+        const uint32_t groups = cnt ? (mis + cnt + 7u) >> 3 : 0u;
+        uint16_t *mine = lds + m + rel;
+        // (two reads in flight a step; a lane that has run out re-reads its last unit -- or the arena's first one if it
+        // has no ids: its tmp_off may be anything -- and places nothing: every position is past its count)
+        const Q4 *qs = groups ? q : reinterpret_cast<const Q4 *>(arena16);
+        const uint32_t glast = groups ? groups - 1u : 0u;
+        auto place = [&](const Q4 &v, uint32_t g) __attribute__((always_inline)) {
+          const int p0 = static_cast<int>(g * 8u) - static_cast<int>(mis);
+          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int pp = p0 + i;
+            if (pp >= 0 && pp < static_cast<int>(cnt)) mine[pp] = static_cast<uint16_t>(w[i >> 1] >> ((i & 1) * 16));
+          }
+        };
+        for (uint32_t g = 0; wv::any(g < groups); g += 2) {
+          const Q4 v0 = qs[g < groups ? g : glast];
+          const Q4 v1 = qs[g + 1u < groups ? g + 1u : glast];
+          place(v0, g);
+          place(v1, g + 1u);
+        }
+        wv::sync();
+        const uint32_t end = m + total;
+        int32_t *out = a.ids + dst0 - m;
+        for (uint32_t e0 = 0; e0 < end; e0 += 256u) {
+          const uint32_t e = e0 + static_cast<uint32_t>(lane) * 4u;
+          if (e < end) {
+            const D2 h = *reinterpret_cast<const D2 *>(lds + e);
+            const uint32_t i0 = h.x & 0xFFFFu, i1 = h.x >> 16, i2 = h.y & 0xFFFFu, i3 = h.y >> 16;
+            if (e >= m && e + 4u <= end) {
+              Q4 o;
+              o.x = i0; o.y = i1; o.z = i2; o.w = i3;
+              *reinterpret_cast<Q4 *>(out + e) = o;
+            } else {
+              if (e + 0u >= m && e + 0u < end) out[e + 0u] = static_cast<int32_t>(i0);
+              if (e + 1u >= m && e + 1u < end) out[e + 1u] = static_cast<int32_t>(i1);
+              if (e + 2u >= m && e + 2u < end) out[e + 2u] = static_cast<int32_t>(i2);
+              if (e + 3u >= m && e + 3u < end) out[e + 3u] = static_cast<int32_t>(i3);
+            }
+          }
+        }
+        wv::sync();                                              // (the next block's sentences overwrite the image)
+        continue;
+      }
+    }
     const uint32_t rounds = (total + 63) / 64;
     for (uint32_t r = 0; r < rounds; ++r) {
       const uint32_t j = r * 64 + static_cast<uint32_t>(lane);

@@ -124,7 +124,10 @@ __global__ __launch_bounds__(64) void ClassifyScatterKernel(ClassifyArgs a) {
 __global__ __launch_bounds__(64) void ScanTilesKernel(ScanArgs a) { scan_tiles_block(a); }
 __global__ __launch_bounds__(64) void ScanSumsKernel(ScanArgs a) { scan_sums_block(a); }
 __global__ __launch_bounds__(64) void ScanFinalKernel(ScanArgs a) { scan_final_block(a); }
-__global__ __launch_bounds__(64) void CompactKernel(CompactArgs a) { compact_block(a); }
+__global__ __launch_bounds__(64) void CompactKernel(CompactArgs a) {
+  __shared__ __attribute__((aligned(16))) uint16_t image[kCompactLdsBytes / 2];
+  compact_block(a, image);
+}
 __global__ __launch_bounds__(64) void RebaseOffsetsKernel(RebaseArgs a) { rebase_block(a); }
 
 namespace {

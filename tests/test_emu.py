@@ -591,3 +591,28 @@ def test_offsets_beyond_four_gigabytes(model, oracle):
                                           io.ctypes.data, None, C.byref(tot))
         assert rc == 0, (base, lib.spmx_last_error(None))
         assert wordfuzz.first_difference(ids[:tot.value], io, np.asarray(oi), np.asarray(oo)) < 0, base
+
+
+@pytest.mark.parametrize("model,shift", [("uni1k", 0), ("uni1k", 1), ("bpe1k", 0)])
+def test_emu_id_offsets_over_whole_scan_tiles(model, shift, emu, oracle, corpora):
+    """More than two whole tiles of the id-count scan (kernels.h kScanTile = 2048 sentences): whole tiles take the
+    coalesced row form (two counts a lane, offsets stored 16 bytes a lane), the last tile and outputs that are not
+    16-byte aligned (shift 1: the caller's offsets array starts 8 bytes off) the lane-owns-32 form."""
+    import torch
+    blob = fixtures.model_blob(model)
+    h, o = emu.load(blob), oracle.load(blob)
+    text, offs = corpora["botchan"]
+    assert len(offs) - 1 > 2 * 2048
+    want, wio = o.encode_batch(text, offs)
+    n = len(offs) - 1
+    d_text = torch.from_numpy(np.frombuffer(text, dtype=np.uint8).copy() if isinstance(text, (bytes, bytearray)) else np.ascontiguousarray(text))
+    d_offs = torch.from_numpy(np.ascontiguousarray(offs).view(np.int64))
+    raw = torch.zeros(n + 1 + 3, dtype=torch.int64)
+    base = (-(raw.data_ptr() // 8)) % 2          # first element that is 16-byte aligned
+    io = raw[base + shift: base + shift + n + 1]
+    assert (io.data_ptr() % 16 == 0) == (shift == 0)
+    ids = torch.empty(len(want) + 64, dtype=torch.int32)
+    _, io2, tot = h.sp.EncodeDevice(d_text, d_offs, ids, io)
+    assert int(tot) == len(want)
+    np.testing.assert_array_equal(io.numpy().view(np.uint64), wio)
+    np.testing.assert_array_equal(ids[:len(want)].numpy(), want)
