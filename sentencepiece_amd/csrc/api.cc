@@ -302,7 +302,7 @@ struct spmx_handle {
   // SetDecodeExtraOptions: the net effect of the options on a sentence's ids (kernels_decode.h DecodeArgs::x_*)
   int32_t dx_npre = 0, dx_nsuf = 0, dx_pre[kMaxExtra] = {0}, dx_suf[kMaxExtra] = {0};
   bool dx_reverse = false;
-  bool compact_staged = true;    // SPMX_COMPACT_STAGED=0: CompactKernel's search form for every block (A/B; results identical)
+  uint32_t compact_staged = 2048;  // ids a CompactKernel wave's LDS image holds (SPMX_COMPACT_STAGED=<ids>; 0: the search form for every block; results identical)
   bool no_direct = false;        // SPMX_NO_DIRECT=1: the word rounds take classify's lists even where they could do without
   int fork_cus = 0;              // SPMX_FORK_CUS: the general launch beside the word rounds takes at most this many CUs (0: every CU)
   int fork_waves = 4;            // SPMX_FORK_WAVES: wavefronts per workgroup of the general launch while it runs next to the first word round (0: by its size)
@@ -738,7 +738,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
     HIP_OR_RETURN(h, hipMemcpyAsync(&ws->h_ctrl->total_ids, d_id_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
     HIP_OR_RETURN(h, hipStreamSynchronize(stream));
     if (ws->h_ctrl->status & kStArenaOverflow) return kOk;
-    CompactArgs pa{ws->d_arena.p, ws->d_tmp_off.p, ws->d_counts.p, d_id_offsets, d_ids, d_ids ? ids_capacity : 0, n32, h->compact_staged ? 1u : 0u};
+    CompactArgs pa{ws->d_arena.p, ws->d_tmp_off.p, ws->d_counts.p, d_id_offsets, d_ids, d_ids ? ids_capacity : 0, n32, h->compact_staged};
     const uint64_t cblocks = (n + 63) / 64;
     const uint64_t cgrid = cblocks < static_cast<uint64_t>(h->n_cu) * 32 ? cblocks : static_cast<uint64_t>(h->n_cu) * 32;
     HIP_OR_RETURN(h, LaunchCompact(pa, static_cast<int>(cgrid), stream));
@@ -1273,7 +1273,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       // token begins to CSR order, then one align launch per staged length class over the classify lists
       const uint64_t total = ws->h_ctrl->total_ids;
       HIP_OR_RETURN(h, ws->d_tok_begin.Reserve(total));
-      CompactArgs pa{ws->d_arena_tb.p, ws->d_tmp_off.p, ws->d_counts.p, d_id_offsets, ws->d_tok_begin.p, total, n32, h->compact_staged ? 1u : 0u};
+      CompactArgs pa{ws->d_arena_tb.p, ws->d_tmp_off.p, ws->d_counts.p, d_id_offsets, ws->d_tok_begin.p, total, n32, h->compact_staged};
       const uint64_t cblocks = (n + 63) / 64;
       const uint64_t cgrid = cblocks < static_cast<uint64_t>(h->n_cu) * 32 ? cblocks : static_cast<uint64_t>(h->n_cu) * 32;
       HIP_OR_RETURN(h, LaunchCompact(pa, static_cast<int>(cgrid), stream));
@@ -1566,7 +1566,10 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_FORK_WAVES")) h->fork_waves = atoi(e);
     if (const char *e = getenv("SPMX_FORK_CUS")) h->fork_cus = atoi(e);
     if (const char *e = getenv("SPMX_NO_DIRECT")) h->no_direct = e[0] == '1';
-    if (const char *e = getenv("SPMX_COMPACT_STAGED")) h->compact_staged = e[0] != '0';
+    if (const char *e = getenv("SPMX_COMPACT_STAGED")) {
+      const long v = atol(e);
+      h->compact_staged = v <= 0 ? 0u : v < 256 ? 256u : v > static_cast<long>(kCompactLdsIdsMax) ? kCompactLdsIdsMax : static_cast<uint32_t>(v) & ~7u;
+    }
     if (const char *e = getenv("SPMX_NO_SCAN")) h->no_scan = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_IDS16")) h->no_ids16 = e[0] == '1';
     if (const char *e = getenv("SPMX_DYN_SLOTS_LOG2")) { const int v = atoi(e); if (v >= 4 && v <= 26) h->dyn_slots = 1u << v; }

@@ -1001,12 +1001,12 @@ struct CompactArgs {
   int32_t *ids;
   uint64_t ids_cap;
   uint32_t n;
-  uint32_t staged = 1;   // blocks of 16-bit ids go through LDS (SPMX_COMPACT_STAGED=0: every block by the search form)
+  uint32_t staged = 2048;   // ids the LDS image of a wave holds: blocks of 16-bit ids go through it (0: the search form for every block)
 };
 
-// LDS of a CompactKernel wave: the 16-bit ids of its 64 sentences, in CSR order
-constexpr uint32_t kCompactLdsIds = 4096;
-constexpr uint32_t kCompactLdsBytes = (kCompactLdsIds + 8) * 2;
+// LDS of a CompactKernel wave: the 16-bit ids of its 64 sentences (or of a half, a quarter of them), in CSR order
+constexpr uint32_t kCompactLdsIdsMax = 16384;
+constexpr uint32_t CompactLdsBytes(uint32_t ids) { return ids ? (ids + 8u) * 2u : 0u; }
 
 // Moves every sentence's ids from where its wave happened to put them in the arena to their place in the
 // caller's CSR.  A wave takes 64 consecutive sentences: their CSR range is contiguous, so the output is written
@@ -1028,30 +1028,55 @@ SPMX_DEVICE void compact_block(const CompactArgs &a, uint16_t *lds) {
   if (a.id_offs[a.n] > a.ids_cap) return;   // caller sees the needed size in id_offs[n]
   const uint32_t blocks = (a.n + 63) / 64;
   const uint16_t *arena16 = reinterpret_cast<const uint16_t *>(a.arena);
-  const bool staged_ok = a.staged != 0 && (reinterpret_cast<uintptr_t>(a.arena) & 15u) == 0;
-  for (uint32_t b = static_cast<uint32_t>(wv::block_id()); b < blocks; b += static_cast<uint32_t>(wv::grid_size())) {
+  const uint32_t cap = (reinterpret_cast<uintptr_t>(a.arena) & 15u) == 0 ? a.staged : 0u;   // ids the LDS image holds
+  // (a block's three reads are asked for one block ahead: they are in while the block before is being moved)
+  uint64_t my_dst = 0, my_src = 0, end_dst = 0;
+  auto ask = [&](uint32_t b, uint64_t *dst, uint64_t *src, uint64_t *end) __attribute__((always_inline)) {
     const uint32_t s = b * 64 + static_cast<uint32_t>(lane);
-    const uint32_t sc = s < a.n ? s : a.n;                     // id_offs[n] closes the last block
-    const uint64_t my_dst = a.id_offs[sc];
-    const uint64_t my_src = s < a.n ? a.tmp_off[s] : 0;
+    *dst = a.id_offs[s < a.n ? s : a.n];                       // id_offs[n] closes the last block
+    *src = a.tmp_off[s < a.n ? s : a.n - 1u];
+    *end = a.id_offs[(b * 64 + 64 <= a.n) ? b * 64 + 64 : a.n];
+  };
+  uint32_t b = static_cast<uint32_t>(wv::block_id());
+  if (b < blocks) ask(b, &my_dst, &my_src, &end_dst);
+  for (; b < blocks; b += static_cast<uint32_t>(wv::grid_size())) {
+    const uint32_t nb = b + static_cast<uint32_t>(wv::grid_size());
+    uint64_t n_dst = 0, n_src = 0, n_end = 0;
+    if (nb < blocks) ask(nb, &n_dst, &n_src, &n_end);
     const uint64_t dst0 = (static_cast<uint64_t>(wv::shfl(static_cast<uint32_t>(my_dst >> 32), 0)) << 32) |
                           wv::shfl(static_cast<uint32_t>(my_dst), 0);
-    const uint32_t last = (b * 64 + 64 <= a.n) ? b * 64 + 64 : a.n;
-    const uint32_t total = static_cast<uint32_t>(a.id_offs[last] - dst0);
+    const uint32_t total = static_cast<uint32_t>(end_dst - dst0);
     const uint32_t rel = static_cast<uint32_t>(my_dst - dst0);
     const uint32_t src_lo = static_cast<uint32_t>(my_src), src_hi = static_cast<uint32_t>(my_src >> 32);
-    if (staged_ok && total + 3u <= kCompactLdsIds) {
-      const uint32_t nxt = wv::shfl(rel, (lane + 1) & 63);
-      const uint32_t cnt = (lane == 63 ? total : nxt) - rel;     // (lanes past the last sentence sit at `total`: 0)
-      if (!wv::any(cnt != 0u && (src_hi >> 31) == 0u)) {
-        // where the block's first id lands within its 16-byte unit of the output: LDS entry e <-> a.ids[dst0 - m + e]
-        const uint32_t m = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(a.ids + dst0) >> 2) & 3u;
-        const uint64_t base16 = (static_cast<uint64_t>(src_hi & 0x7FFFFFFFu) << 32) | src_lo;
-        const uint32_t mis = static_cast<uint32_t>(base16) & 7u;
-        const Q4 *q = reinterpret_cast<const Q4 *>(arena16 + (base16 - mis));
+    my_dst = n_dst; my_src = n_src; end_dst = n_end;
+    // the block as one part, two halves or four quarters of its lanes: the fewest whose ids each fit the image
+    uint32_t parts = 0u;
+    if (cap) {
+      const uint32_t r16 = wv::shfl(rel, 16), r32 = wv::shfl(rel, 32), r48 = wv::shfl(rel, 48);
+      const uint32_t h0 = r32, h1 = total - r32;
+      const uint32_t q0 = r16, q1 = r32 - r16, q2 = r48 - r32, q3 = total - r48;
+      const uint32_t hmax = h0 > h1 ? h0 : h1;
+      const uint32_t qa = q0 > q1 ? q0 : q1, qb = q2 > q3 ? q2 : q3, qmax = qa > qb ? qa : qb;
+      parts = total + 3u <= cap ? 1u : hmax + 3u <= cap ? 2u : qmax + 3u <= cap ? 4u : 0u;
+    }
+    const uint32_t nxt = wv::shfl(rel, (lane + 1) & 63);
+    const uint32_t cnt_all = (lane == 63 ? total : nxt) - rel;   // (lanes past the last sentence sit at `total`: 0)
+    if (parts && !wv::any(cnt_all != 0u && (src_hi >> 31) == 0u)) {
+      const uint64_t base16 = (static_cast<uint64_t>(src_hi & 0x7FFFFFFFu) << 32) | src_lo;
+      const uint32_t mis = static_cast<uint32_t>(base16) & 7u;
+      const Q4 *q = reinterpret_cast<const Q4 *>(arena16 + (base16 - mis));
+      const uint32_t lanes_per = 64u / parts;
+      for (uint32_t part = 0; part < parts; ++part) {
+        const uint32_t l0 = part * lanes_per, l1 = l0 + lanes_per;
+        const uint32_t rel0 = wv::shfl(rel, static_cast<int>(l0));
+        const uint32_t ptotal = (l1 == 64u ? total : wv::shfl(rel, static_cast<int>(l1 & 63u))) - rel0;
+        const bool in = static_cast<uint32_t>(lane) >= l0 && static_cast<uint32_t>(lane) < l1;
+        const uint32_t cnt = in ? cnt_all : 0u;
+        // where the part's first id lands within its 16-byte unit of the output: LDS entry e <-> a.ids[dst0 + rel0 - m + e]
+        const uint32_t m = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(a.ids + dst0 + rel0) >> 2) & 3u;
         const uint32_t groups = cnt ? (mis + cnt + 7u) >> 3 : 0u;
-        uint16_t *mine = lds + m + rel;
-        // (two reads in flight a step; a lane that has run out re-reads its last unit -- or the arena's first one if it
+        uint16_t *mine = lds + m + (rel - rel0);                 // (only dereferenced where cnt != 0: a lane of the part)
+        // (four reads in flight a step; a lane that has run out re-reads its last unit -- or the arena's first one if it
         // has no ids: its tmp_off may be anything -- and places nothing: every position is past its count)
         const Q4 *qs = groups ? q : reinterpret_cast<const Q4 *>(arena16);
         const uint32_t glast = groups ? groups - 1u : 0u;
@@ -1064,15 +1089,19 @@ SPMX_DEVICE void compact_block(const CompactArgs &a, uint16_t *lds) {
             if (pp >= 0 && pp < static_cast<int>(cnt)) mine[pp] = static_cast<uint16_t>(w[i >> 1] >> ((i & 1) * 16));
           }
         };
-        for (uint32_t g = 0; wv::any(g < groups); g += 2) {
+        for (uint32_t g = 0; wv::any(g < groups); g += 4) {
           const Q4 v0 = qs[g < groups ? g : glast];
           const Q4 v1 = qs[g + 1u < groups ? g + 1u : glast];
+          const Q4 v2 = qs[g + 2u < groups ? g + 2u : glast];
+          const Q4 v3 = qs[g + 3u < groups ? g + 3u : glast];
           place(v0, g);
           place(v1, g + 1u);
+          place(v2, g + 2u);
+          place(v3, g + 3u);
         }
         wv::sync();
-        const uint32_t end = m + total;
-        int32_t *out = a.ids + dst0 - m;
+        const uint32_t end = m + ptotal;
+        int32_t *out = a.ids + dst0 + rel0 - m;
         for (uint32_t e0 = 0; e0 < end; e0 += 256u) {
           const uint32_t e = e0 + static_cast<uint32_t>(lane) * 4u;
           if (e < end) {
@@ -1090,9 +1119,9 @@ SPMX_DEVICE void compact_block(const CompactArgs &a, uint16_t *lds) {
             }
           }
         }
-        wv::sync();                                              // (the next block's sentences overwrite the image)
-        continue;
+        wv::sync();                                              // (the next part's sentences overwrite the image)
       }
+      continue;
     }
     const uint32_t rounds = (total + 63) / 64;
     for (uint32_t r = 0; r < rounds; ++r) {

@@ -125,8 +125,8 @@ __global__ __launch_bounds__(64) void ScanTilesKernel(ScanArgs a) { scan_tiles_b
 __global__ __launch_bounds__(64) void ScanSumsKernel(ScanArgs a) { scan_sums_block(a); }
 __global__ __launch_bounds__(64) void ScanFinalKernel(ScanArgs a) { scan_final_block(a); }
 __global__ __launch_bounds__(64) void CompactKernel(CompactArgs a) {
-  __shared__ __attribute__((aligned(16))) uint16_t image[kCompactLdsBytes / 2];
-  compact_block(a, image);
+  extern __shared__ __attribute__((aligned(16))) unsigned char compact_image[];
+  compact_block(a, reinterpret_cast<uint16_t *>(compact_image));
 }
 __global__ __launch_bounds__(64) void RebaseOffsetsKernel(RebaseArgs a) { rebase_block(a); }
 
@@ -281,7 +281,7 @@ hipError_t LaunchRebase(const RebaseArgs &a, int grid, hipStream_t stream) {
 }
 
 hipError_t LaunchCompact(const CompactArgs &a, int grid, hipStream_t stream) {
-  hipLaunchKernelGGL(CompactKernel, dim3(grid), dim3(64), 0, stream, a);
+  hipLaunchKernelGGL(CompactKernel, dim3(grid), dim3(64), CompactLdsBytes(a.staged), stream, a);
   return hipGetLastError();
 }
 

@@ -130,7 +130,7 @@ hipError_t LaunchScan(const ScanArgs &a, int grid, hipStream_t) {
   return hipSuccess;
 }
 hipError_t LaunchCompact(const CompactArgs &a, int grid, hipStream_t) {
-  RunGrid(grid, 1, kCompactLdsBytes, [&](unsigned char *s) { compact_block(a, reinterpret_cast<uint16_t *>(s)); });
+  RunGrid(grid, 1, CompactLdsBytes(a.staged), [&](unsigned char *s) { compact_block(a, reinterpret_cast<uint16_t *>(s)); });
   return hipSuccess;
 }
 hipError_t LaunchRebase(const RebaseArgs &a, int grid, hipStream_t) {

@@ -616,3 +616,21 @@ def test_emu_id_offsets_over_whole_scan_tiles(model, shift, emu, oracle, corpora
     assert int(tot) == len(want)
     np.testing.assert_array_equal(io.numpy().view(np.uint64), wio)
     np.testing.assert_array_equal(ids[:len(want)].numpy(), want)
+
+
+@pytest.mark.parametrize("model", ["uni32k", "bpe32k"])
+@pytest.mark.parametrize("cap", ["0", "256", "512", "1024", "4096"])
+def test_emu_compact_image_sizes(model, cap, emu, oracle, corpora, monkeypatch):
+    """CompactKernel's LDS image at other sizes (kernels.h compact_block): a block of 64 sentences moves as one part, two
+    halves, four quarters -- the fewest whose ids fit -- or by the search form (0, and blocks no quarter of which fits);
+    blocks with a sentence of 32-bit ids (what the tail kernels wrote) take the search form too."""
+    monkeypatch.setenv("SPMX_COMPACT_STAGED", cap)
+    blob = fixtures.model_blob(model)
+    h, o = emu.load(blob), oracle.load(blob)
+    for name, k in (("botchan", 330), ("edge", 10 ** 6), ("mixed2k", 70)):
+        text, offs = fixtures.head(*corpora[name], k)
+        ids, io = h.encode_batch(text, offs)
+        assert h.status == 0
+        oids, oio = o.encode_batch(text, offs)
+        np.testing.assert_array_equal(io, oio)
+        np.testing.assert_array_equal(ids, oids)
