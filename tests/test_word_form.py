@@ -551,3 +551,57 @@ def test_gpu_words_of_nine_to_sixteen_pieces(model, oracle):
         sp.SetProfiling(True)
         _check(sp.EncodePacked, o, sents + [b"x" * 40], "%s/%s" % (model, variant))
         assert _word_form_sentences(sp) > 0
+
+
+# ---- (g) round 5: words that are NOT plain ASCII through the word form (dev.h kNfWordLocalNorm: a collected word is
+# normalized by itself in word_resolve_block and segmented over characters) ----
+
+_ODD_WORDS = [
+    "café", "naïve", "Ångström", "日本語", "東京都", "ｆｕｌｌｗｉｄｔｈ", "ﬁne", "ﬂow", "㌔", "½", "ⅷ", "ét́",     # NFKC rules, combining marks
+    "a b", " ", "x　y", "　", "\t", "a\tb", "​", "﻿bom",                                       # characters that normalize to a space / to nothing
+    "▁", "a▁", "▁a", "a▁b", "▁▁",                                                            # the space symbol itself, literally
+    "😀", "a😀b", "𠮷野家", "ελληνικά", "русский", "עברית", "हिन्दी",                                                        # 4-byte characters, other scripts
+    "日本語のとても長い単語", "straße-überlänge-çok-uzun", "é" * 9,                                                          # longer than a 16-byte key
+]
+_ODD_BYTES = [b"\x00", b"a\x00b", b"\x7f", b"\x80", b"\xc3", b"\xe3\x81", b"\xf0\x9f\x98", b"\xff\xfe", b"ok\xc2", b"\xc2ok"]
+
+
+def _odd_word_corpus(words, n, seed):
+    """n sentences of vocabulary words with one or more of the words above at their start / middle / end, each odd word
+    used many times (the call-local memo is hit, not only filled), a few sentences of odd words only."""
+    rng = np.random.default_rng(seed)
+    odd = [w.encode("utf-8") for w in _ODD_WORDS] + _ODD_BYTES
+    sents = []
+    for i in range(n):
+        k = int(rng.integers(0, 14))
+        ws = [words[int(j)] for j in rng.integers(0, len(words), size=k)]
+        for _ in range(1 + (i % 3 == 0)):
+            ws.insert(int(rng.integers(0, len(ws) + 1)), odd[int(rng.integers(0, len(odd)))])
+        if i % 17 == 0:
+            ws = [odd[int(j)] for j in rng.integers(0, len(odd), size=1 + i % 5)]
+        sents.append(b" ".join(ws))
+    return sents
+
+
+@pytest.mark.parametrize("variant", ["default", "small_classes", "ids32"])
+@pytest.mark.parametrize("model", WORD_MODELS + ["uni1k", "bpe1k", "uni1k_bf", "test_model"])
+def test_emu_words_that_are_not_plain_ascii(model, variant, emu, oracle):
+    blob = fixtures.model_blob(model)
+    words = wordfuzz.whole_words(blob, limit=600)
+    h, o = _emu_load(emu, blob, variant), oracle.load(blob)
+    sents = _odd_word_corpus(words, 900, seed=77)
+    _check(h.encode_batch, o, sents, "%s/%s" % (model, variant))
+    if h.flags() & (1 << 12):                                       # dev.h kNfWordLocalNorm: the form is on for this model
+        assert _word_form_sentences(h.sp) > len(sents) // 2, "the word rounds left most of these sentences to the tail"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", WORD_MODELS + ["uni1k", "bpe1k", "uni1k_bf", "test_model"])
+def test_gpu_words_that_are_not_plain_ascii(model, oracle):
+    blob = fixtures.model_blob(model)
+    words = wordfuzz.whole_words(blob, limit=3000)
+    sp, o = _gpu_load(blob, "default"), oracle.load(blob)
+    sp.SetProfiling(True)
+    sents = _odd_word_corpus(words, 80000, seed=78)
+    _check(sp.EncodePacked, o, sents, model)
+    assert _word_form_sentences(sp) > 0
