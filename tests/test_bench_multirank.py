@@ -59,6 +59,18 @@ def test_bench_watchdog_prints_the_line_when_the_second_gather_hangs():
     assert p.returncode == 0, p.stderr[-2000:]
 
 
+def test_bench_watchdog_prints_the_line_when_the_first_gather_hangs():
+    """No gather algorithm has run on more than one GPU before the driver's node: the no-gather form makes the line, every
+    gather runs under the watchdog; when the first one never returns the line is still printed and says what it holds."""
+    p, lines = _run(2, {"SPMX_DRYRUN_HANG": "all_gather", "SPMX_BENCH_GATHER_DEADLINE_S": "8"}, 600)
+    assert len(lines) == 1, (p.stdout[-1500:], p.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert d["value"] == d["value_gather_none"] > 0 and d["n_gpus"] == 2
+    assert "given up" in d["gather_all_gather"] and "value_gather_all_gather" not in d
+    assert d["config"]["gather"].startswith("none")
+    assert p.returncode == 0, p.stderr[-2000:]
+
+
 def test_bench_started_plainly_with_gpus_2_launches_two_ranks_itself():
     """`python bench.py --gpus 2` without torch.distributed.run: the script starts its ranks itself -- it must never run one
     rank and print n_gpus 1 (round-4 verdict: the only multi-GPU evidence there will be is one driver command)."""
