@@ -291,9 +291,12 @@ def main():
     if args.sentences is None:
         args.sentences = 12_500_000 if world > 1 else 10_000_000
     algos = ["all_gather", "p2p_exact"] if args.gather_algo == "both" else [args.gather_algo]
-    gather_modes = ([] if world == 1 else ((["ids:" + a for a in algos] + ["none"]) if args.gather == "both"
+    # SPMX_BENCH_ONE_RANK_GATHER=1: the N > 1 control flow (process group over RCCL, both gather algorithms, reserved CUs, the
+    # watchdog) with ONE rank -- the only way to run that code on a one-GPU box; the line it prints is not a scaling figure
+    multi = world > 1 or os.environ.get("SPMX_BENCH_ONE_RANK_GATHER") == "1"
+    gather_modes = ([] if not multi else ((["ids:" + a for a in algos] + ["none"]) if args.gather == "both"
                                            else (["ids:" + a for a in algos] if args.gather == "ids" else ["none"])))
-    if world > 1 and any(m.startswith("ids") for m in gather_modes):
+    if multi and any(m.startswith("ids") for m in gather_modes):
         # an all-gather in flight needs CUs of its own: the persistent encode grids would otherwise hold every CU until
         # they end, and the gather of batch k would run after batch k + 1's encode instead of under it
         os.environ.setdefault("SPMX_RESERVE_CUS", "16")
@@ -325,9 +328,11 @@ def main():
         torch.cuda.set_device(local)
     dev = torch.device("cpu") if dry else torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29533")
         if dry:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -392,7 +397,7 @@ def main():
 
     results = {}
     late_modes = []
-    if world == 1:
+    if not multi:
         results["n/a"] = timed(encode_step)
     else:
         # The no-gather form is timed first and makes the line (its only collectives are the barrier and the MAX of the
@@ -461,7 +466,7 @@ def main():
                                       "mixed-script power-law [16, 4096] B" if c5 else "ASCII", len(text) / n,
                                       "in generator order (not length-bucketed)" if args.unsorted else "length-bucketed"),
                        "model": args.model, "sentences_per_gpu": n, "ids_per_sentence": job_ids / (world * n),
-                       "gather": gather_desc(head) if world > 1 else "n/a",
+                       "gather": gather_desc(head) if multi else "n/a",
                        "sharding": "dp%d by sentence" % world,
                        "timed_loop": "profiling off; roofline.* comes from a second loop of the same steps with HIP events on"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -505,7 +510,7 @@ def main():
             except Exception as e:
                 os.environ.pop("SPMX_NO_OVERLAP", None)
                 out["roofline"]["alone"] = {"failed": repr(e)[:200]}
-        if world > 1:
+        if multi:
             for mode, (mdt, _) in results.items():
                 key = mode.replace("ids:", "")
                 out["value_gather_%s" % key] = world * n * args.steps / mdt

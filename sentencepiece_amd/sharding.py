@@ -104,8 +104,8 @@ class IdGatherer:
 
     def reserve(self, ids_capacity, offsets_capacity=0, ids_dtype=torch.int32, offsets_dtype=torch.int64):
         """Collective.  Agrees the padded per-rank sizes (MAX over the ranks) and allocates the slots."""
-        if self.algo == "p2p_exact":
-            return                       # (exact sizes travel with every batch: nothing to agree up front)
+        if self.algo == "p2p_exact" and self.world > 1:
+            return                       # (exact sizes travel with every batch: nothing to agree up front; one rank alone takes the padded form)
         self.wait()
         t = torch.tensor([int(ids_capacity), int(offsets_capacity)], dtype=torch.int64, device=self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)

@@ -85,3 +85,22 @@ def test_bench_refuses_a_gpus_flag_that_disagrees_with_the_launch():
     p, lines = _run(2, {}, 600, torchrun=True, gpus=4)
     assert p.returncode != 0 and not lines
     assert "refusing" in (p.stderr + p.stdout)
+
+
+def test_bench_one_rank_runs_the_multi_rank_control_flow():
+    """SPMX_BENCH_ONE_RANK_GATHER=1: process group, both gather algorithms, reserved CUs and the watchdog with ONE rank --
+    how the N > 1 code is run on a one-GPU box (scripts/r05_last.sh); here over gloo with the emulated library."""
+    env = dict(os.environ, SPMX_BENCH_ONE_RANK_GATHER="1", MASTER_PORT=str(_free_port()))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_dryrun.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
+                        "--sentences", "3000", "--model", "uni32k", "--no-second-model", "--no-side-configs", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, (p.stdout[-1000:], p.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1
+    for k in ("value_gather_all_gather", "value_gather_p2p_exact", "value_gather_none"):
+        assert d[k] > 0, k
+    assert d["config"]["gather"].startswith("ids:")
