@@ -302,7 +302,6 @@ struct spmx_handle {
   // SetDecodeExtraOptions: the net effect of the options on a sentence's ids (kernels_decode.h DecodeArgs::x_*)
   int32_t dx_npre = 0, dx_nsuf = 0, dx_pre[kMaxExtra] = {0}, dx_suf[kMaxExtra] = {0};
   bool dx_reverse = false;
-  bool tag_coherent = false;     // SPMX_DYN_TAG_COHERENT=1: agent-scope loads of the call-local memo's tags in the collecting round (A/B; results identical)
   uint32_t compact_staged = 2048;  // ids a CompactKernel wave's LDS image holds (SPMX_COMPACT_STAGED=<ids>; 0: the search form for every block; results identical)
   bool no_direct = false;        // SPMX_NO_DIRECT=1: the word rounds take classify's lists even where they could do without
   int fork_cus = 0;              // SPMX_FORK_CUS: the general launch beside the word rounds takes at most this many CUs (0: every CU)
@@ -1058,7 +1057,6 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         wa.n_classes = static_cast<uint32_t>(ncls);
         uint32_t tile_base = 0;
         wa.direct = direct ? 1u : 0u;
-        wa.tag_coherent = h->tag_coherent ? 1u : 0u;
         if (direct && mode != 2) wa.lists = nullptr;             // (the first round: sentence = tile's first + lane)
         for (int c = ncls - 1; c >= 0; --c) {
           StreamClass &sc = wa.cls[c];
@@ -1568,7 +1566,6 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_FORK_WAVES")) h->fork_waves = atoi(e);
     if (const char *e = getenv("SPMX_FORK_CUS")) h->fork_cus = atoi(e);
     if (const char *e = getenv("SPMX_NO_DIRECT")) h->no_direct = e[0] == '1';
-    if (const char *e = getenv("SPMX_DYN_TAG_COHERENT")) h->tag_coherent = e[0] == '1';
     if (const char *e = getenv("SPMX_COMPACT_STAGED")) {
       const long v = atol(e);
       h->compact_staged = v <= 0 ? 0u : v < 256 ? 256u : v > static_cast<long>(kCompactLdsIdsMax) ? kCompactLdsIdsMax : static_cast<uint32_t>(v) & ~7u;

@@ -114,9 +114,6 @@ struct EncodeArgs {
   // null: sentence first + lane) or of one list (row 0 of lists); a sentence's length class -- which only says whether it
   // is a document (cls[].general) and which list it goes to when the word form hands it on -- is found from cls[].rcap
   uint32_t direct;
-  // (word per lane, collecting round) 1: the call-local memo's tags are read by agent-scope loads (SPMX_DYN_TAG_COHERENT=1,
-  // the form before round 5's last change); 0: by plain loads, 0 meaning "ask the memory side" (kernels_wordwave.h)
-  uint32_t tag_coherent;
   // ---- sentence-per-wave launch (BPE models that are not word-wise; kernels_bpe.h) ----
   const uint32_t *list;         // sentence indices of this length class
   const uint32_t *list_count;   // number of entries in list (device resident)

@@ -290,12 +290,7 @@ SPMX_DEVICE void encode_wordwave_block(const EncodeArgs &a, unsigned char *smem)
         const bool pre = MODE == kWmDyn || dyn_warm != 0u;
         if (MODE == kWmCollect && dyn_warm != 0u) --dyn_warm;
         const uint32_t dsl = (pre & valid & !hit16 & (L <= 16u)) ? (h1 & a.dyn_mask) : 0u;
-        // (a PLAIN load in the collecting round too: an agent-scope load is served by the memory side on this part -- the XCDs'
-        // L2s are not coherent with each other -- and its latency, a few microseconds under load, is more than the stage it
-        // has to land in: a model with a small load-time memo asks for a tag for EVERY word and paid 17 ms for it on C2
-        // (bpe1k_llama).  What a plain load returns is a tag some lane has written -- a slot goes from 0 to its tag once a call
-        // and never back, so a non-zero value is the truth -- or 0, possibly stale: stage B then asks the memory side)
-        const unsigned long long g = (MODE == kWmCollect && a.tag_coherent) ? wv::atomic_load64(&a.dyn_tag[dsl]) : a.dyn_tag[dsl];
+        const unsigned long long g = MODE == kWmCollect ? wv::atomic_load64(&a.dyn_tag[dsl]) : a.dyn_tag[dsl];
         S.tg_lo = static_cast<uint32_t>(g); S.tg_hi = static_cast<uint32_t>(g >> 32);
         S.warm = pre ? 1u : 0u;
         if (MODE == kWmDyn) {
@@ -383,11 +378,9 @@ SPMX_DEVICE void encode_wordwave_block(const EncodeArgs &a, unsigned char *smem)
               // find it entered)
               unsigned long long g0 = static_cast<unsigned long long>(S.tg_hi) << 32 | S.tg_lo;
               const bool have0 = S.warm != 0u;
-              const bool seen0 = have0 && g0 == tag;      // (the plain load's word: a non-zero tag is never stale)
-              const uint32_t sl0 = sl;
               for (uint32_t t = 0; t < kDynProbes && !kept; ++t) {
                 unsigned long long g = (t == 0u && have0) ? g0 : wv::atomic_load64(&a.dyn_tag[sl]);
-                if (g == 0ull) g = wv::atomic_cas(&a.dyn_tag[sl], 0ull, tag);      // (a 0 may be stale: the memory side knows)
+                if (g == 0ull) g = wv::atomic_cas(&a.dyn_tag[sl], 0ull, tag);
                 if (g == 0ull) {                         // ours: the word's bytes, and a place in the list of words to segment
                   const uint32_t at2 = wv::atomic_add(a.dyn_count, 1u);
                   a.dyn_ent[4u * sl] = U4{k0, k1, k2, k3};
@@ -398,10 +391,6 @@ SPMX_DEVICE void encode_wordwave_block(const EncodeArgs &a, unsigned char *smem)
                 if (g == tag) { kept = true; break; }    // another lane has entered it
                 sl = (sl + 1u) & a.dyn_mask;
               }
-              // The memory side holds the tag; this XCD's L2 may still hold the 0 it read before: a plain store of the SAME
-              // value puts it right for the plain loads of the word's next occurrences here (the line's other bytes are not
-              // written back: the L2 keeps byte masks).  Only the first slot is ever looked at by a plain load.
-              if (!a.tag_coherent && kept && !seen0 && sl == sl0) a.dyn_tag[sl] = tag;
             }
             if (kept) miss = true; else gone = true;
           }
