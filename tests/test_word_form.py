@@ -605,3 +605,30 @@ def test_gpu_words_that_are_not_plain_ascii(model, oracle):
     sents = _odd_word_corpus(words, 80000, seed=78)
     _check(sp.EncodePacked, o, sents, model)
     assert _word_form_sentences(sp) > 0
+
+
+# ---- (h) the switches that choose between the forms of the word rounds (api.cc): every combination gives the reference's ids ----
+
+_FORM_SWITCHES = [
+    {"SPMX_WORD_WAVE": "0"},                                   # both rounds a sentence per lane (kernels_word.h, round 3)
+    {"SPMX_WORD_WAVE": "1"},                                   # round 1 a word per lane, round 2 a sentence per lane
+    {"SPMX_WORD_WAVE": "2"},                                   # the other way round
+    {"SPMX_NO_DIRECT": "1"},                                   # classify's lists although the word rounds could do without
+    {"SPMX_NO_DIRECT": "1", "SPMX_NO_WORD_NORM": "1"},         # shape B: plain scan, general launch beside the word rounds
+    {"SPMX_NO_WORD_NORM": "1", "SPMX_FORK_CUS": "8"},          # ... on 8 CUs of its own
+    {"SPMX_NO_WORD_NORM": "1", "SPMX_NO_OVERLAP": "1"},        # ... one after the other
+    {"SPMX_WORDWAVE_WAVES": "4"},                              # 4 wavefronts per workgroup in the word-per-lane kernels
+    {"SPMX_NO_WORD_DYN": "1"},                                 # no call-local memo: one word round + the DP pass
+]
+
+
+@pytest.mark.parametrize("k", range(len(_FORM_SWITCHES)))
+@pytest.mark.parametrize("model", ["uni32k", "bpe32k", "bpe1k_llama", "uni1k_bf"])
+def test_emu_word_round_form_switches(model, k, emu, oracle):
+    blob = fixtures.model_blob(model)
+    words = wordfuzz.whole_words(blob, limit=500)
+    h, o = _emu_load(emu, blob, "default", extra=_FORM_SWITCHES[k]), oracle.load(blob)
+    rng = np.random.default_rng(900 + k)
+    plain = [b" ".join(words[int(j)] for j in rng.integers(0, len(words), size=int(rng.integers(1, 40)))) for _ in range(500)]
+    spaced = [b"  ".join(s.split(b" ")[:3]) + b" " for s in plain[:40]] + [b" " + plain[0], b"", b" ", b"a"]
+    _check(h.encode_batch, o, plain + _odd_word_corpus(words, 300, seed=k) + spaced, "%s %r" % (model, _FORM_SWITCHES[k]))
