@@ -100,7 +100,10 @@ int64_t spmx_unk_piece(const spmx_handle *h, char *out, uint64_t cap);
  * GPU; `stream` is a hipStream_t (NULL = default stream).  The call enqueues
  * its kernels on `stream`, waits for them, and returns the number of ids in
  * *total_ids.  If ids_capacity is too small, returns RESOURCE_EXHAUSTED (8)
- * with the required capacity in *total_ids (id_offsets is still valid). */
+ * with the required capacity in *total_ids (id_offsets is still valid).
+ * d_text may have any alignment; the kernels read it in ALIGNED 16-byte units, so the bytes that share a unit with the
+ * text's first or last byte may be read (never interpreted) -- a unit does not cross a page, and a device allocation
+ * covers whole pages. */
 int spmx_encode_batch_device(spmx_handle *h, const void *d_text, uint64_t text_bytes, const uint64_t *d_offsets,
                              uint64_t n, int32_t *d_ids, uint64_t ids_capacity, uint64_t *d_id_offsets, void *stream,
                              uint64_t *total_ids);

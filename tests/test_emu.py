@@ -605,7 +605,11 @@ def test_emu_id_offsets_over_whole_scan_tiles(model, shift, emu, oracle, corpora
     assert len(offs) - 1 > 2 * 2048
     want, wio = o.encode_batch(text, offs)
     n = len(offs) - 1
-    d_text = torch.from_numpy(np.frombuffer(text, dtype=np.uint8).copy() if isinstance(text, (bytes, bytearray)) else np.ascontiguousarray(text))
+    tb = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else np.ascontiguousarray(text)
+    pad = np.zeros(len(tb) + 48, dtype=np.uint8)        # (whole 16-byte units around the text, as a device allocation has: spmx.h)
+    t0 = 16 + (-pad.ctypes.data) % 16
+    pad[t0:t0 + len(tb)] = tb
+    d_text = torch.from_numpy(pad)[t0:t0 + len(tb)]
     d_offs = torch.from_numpy(np.ascontiguousarray(offs).view(np.int64))
     raw = torch.zeros(n + 1 + 3, dtype=torch.int64)
     base = (-(raw.data_ptr() // 8)) % 2          # first element that is 16-byte aligned
