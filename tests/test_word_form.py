@@ -632,3 +632,20 @@ def test_emu_word_round_form_switches(model, k, emu, oracle):
     plain = [b" ".join(words[int(j)] for j in rng.integers(0, len(words), size=int(rng.integers(1, 40)))) for _ in range(500)]
     spaced = [b"  ".join(s.split(b" ")[:3]) + b" " for s in plain[:40]] + [b" " + plain[0], b"", b" ", b"a"]
     _check(h.encode_batch, o, plain + _odd_word_corpus(words, 300, seed=k) + spaced, "%s %r" % (model, _FORM_SWITCHES[k]))
+
+
+@pytest.mark.parametrize("name", ["bpe1k_llama", "uni32k_keep_ws"])
+def test_emu_long_general_launch_beside_the_word_rounds(name, emu, oracle):
+    """Shape B with a FIFTH of the batch set aside by the scan (runs of spaces through a model that keeps them) on 128
+    emulated CUs: the general launch on CUs of its own beside the word rounds (api.cc, the fork), at the width the GPU runs."""
+    blob = _keep_ws_models()[name]
+    words = wordfuzz.whole_words(fixtures.model_blob("uni32k"), limit=400)
+    rng = np.random.default_rng(4242)
+    sents = []
+    for i in range(9000):
+        ws = [words[int(j)] for j in rng.integers(0, len(words), size=int(rng.integers(1, 12)))]
+        sents.append((b"  " if i % 5 == 0 else b" ").join(ws))            # a fifth of them with doubled spaces
+    h, o = emu.load(blob, cus=128, classes=None), oracle.load(blob)
+    _check(h.encode_batch, o, sents, name)
+    prof = {c["kernel"]: c["sentences"] for c in h.sp.LastProfile()["classes"] if c["kernel"]}
+    assert any(k.startswith("EncodeWordWave") for k in prof), prof
