@@ -175,3 +175,22 @@ def test_byte_fallback_decode(emu):
     assert _decode(sp, ids) == want
     if refshim.available():
         assert _ref_decode(blob, ids) == want
+
+
+@pytest.mark.parametrize("extra,want", [([], ["A", "B", "C"]), ([("AB", 2.0)], ["AB", "C"]), ([("AB", 2.0), ("BC", 5.0)], ["A", "BC"]),
+                                         ([("AB", 2.0), ("BC", 5.0), ("ABC", 10.0)], ["ABC"])])
+def test_lattice_viterbi_kat(extra, want, emu):
+    """LatticeTest.ViterbiTest (src/unigram_model_test.cc:195-212): nodes A, B, C at score 0, then AB 2.0, BC 5.0, ABC 10.0 added
+    one by one -- as a unigram model's pieces, through both encoders (EncodeOptimized and, by the extra entry point, kOriginal)."""
+    from tests.test_reference_kats import build_model
+    pieces = [("A", 0.0, 1), ("B", 0.0, 1), ("C", 0.0, 1)] + [(p, s, 1) for p, s in extra]
+    blob = build_model(1, pieces)
+    sp = emu.load(blob).sp
+    assert sp.EncodeAsPieces("ABC") == want
+    ids = {p: 3 + i for i, (p, _, _) in enumerate(pieces)}
+    assert sp.EncodeAsIds("ABC") == [ids[w] for w in want]
+    if refshim.available():
+        ref = refshim.RefLib().load(blob)
+        assert list(ref.encode(b"ABC")) == [ids[w] for w in want]
+        ref.set_encoder_original()
+        assert list(ref.encode(b"ABC")) == [ids[w] for w in want]
