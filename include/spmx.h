@@ -143,8 +143,8 @@ void spmx_free(void *p);
  *   d_all_ids[rank_ids[r] ...)            rank r's ids (rank order = sentence order),
  *   d_all_id_offsets[0 .. total + 1)      offsets into d_all_ids, rebased to the whole job.
  * nccl_comm: the caller's ncclComm_t (one rank per GPU), or one made by spmx_rccl_comm_init.  librccl is looked up at the
- * first call (SPMX_RCCL_LIB names another library), it is no link-time dependency of libspmx.so.  d_scratch: 5 * (1 + world)
- * uint64 of device memory.  rank_sentences / rank_ids (host, world + 1 entries each, nullable): prefix sums over the
+ * first call (SPMX_RCCL_LIB names another library), it is no link-time dependency of libspmx.so.  d_scratch:
+ * spmx_gather_scratch_words(world) uint64 of device memory (today 5 * (1 + world); ask, do not hard-code).  rank_sentences / rank_ids (host, world + 1 entries each, nullable): prefix sums over the
  * ranks.  Stream-ordered except for one read-back of the counts; collective: every rank of the communicator calls it.
  * Returns 0, or a util::StatusCode number (8: a capacity is too small -- the message names what is needed; 14: RCCL is
  * not loadable) with the text in spmx_gather_last_error().  Whether the gathered CSR fits is decided from EVERY rank's
@@ -154,6 +154,8 @@ int spmx_all_gather_ids(void *nccl_comm, int rank, int world, const int32_t *d_i
                         const uint64_t *d_id_offsets, uint64_t n_sentences, int32_t *d_all_ids, uint64_t all_ids_capacity,
                         uint64_t *d_all_id_offsets, uint64_t all_offsets_capacity, uint64_t *d_scratch,
                         uint64_t *rank_sentences, uint64_t *rank_ids, void *stream);
+/* uint64 words of device scratch spmx_all_gather_ids needs for `world` ranks (0 for a world outside 1 .. 64). */
+uint64_t spmx_gather_scratch_words(int world);
 /* A communicator without linking RCCL oneself: rank 0 makes the 128-byte id and hands it to the other ranks by whatever
  * means the job has (a file, MPI, a socket); every rank then calls spmx_rccl_comm_init with its GPU current. */
 int spmx_rccl_unique_id(void *id128);

@@ -280,8 +280,9 @@ class SentencePieceProcessor {
 
   // One process per GPU: every rank's device CSR (what EncodeBatchDevice wrote for its contiguous shard of the job's
   // sentences) on every rank, over RCCL (spmx_all_gather_ids: counts all-gather, exact-size grouped sends and receives,
-  // offsets rebased to the whole job).  comm: an ncclComm_t (the caller's, or spmx_rccl_comm_init's); d_scratch: 2 + 2 *
-  // world uint64 of device memory; rank_sentences / rank_ids (nullable): prefix sums over the ranks, world + 1 entries.
+  // offsets rebased to the whole job).  comm: an ncclComm_t (the caller's, or spmx_rccl_comm_init's); d_scratch:
+  // GatherScratchWords(world) uint64 of device memory; rank_sentences / rank_ids (nullable): prefix sums over the ranks, world + 1 entries.
+  static uint64_t GatherScratchWords(int world) { return spmx_gather_scratch_words(world); }
   static util::Status AllGatherIds(void *comm, int rank, int world, const int32_t *d_ids, uint64_t n_ids,
                                    const uint64_t *d_id_offsets, uint64_t n_sentences, int32_t *d_all_ids,
                                    uint64_t all_ids_capacity, uint64_t *d_all_id_offsets, uint64_t all_offsets_capacity,

@@ -79,6 +79,7 @@ SYMBOLS = [
     ("spmx_all_gather_ids", C.c_int,
      [C.c_void_p, C.c_int, C.c_int, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p,
       C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("spmx_gather_scratch_words", _U64, [C.c_int]),
     ("spmx_rccl_unique_id", C.c_int, [C.c_void_p]),
     ("spmx_rccl_comm_init", C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p]),
     ("spmx_rccl_comm_destroy", C.c_int, [C.c_void_p]),

@@ -471,9 +471,6 @@ int RefreshDevice(spmx_handle *h, bool types_changed) {
     HIP_OR_RETURN(h, Upload(&h->d_uall, t.uall));
     HIP_OR_RETURN(h, Upload(&h->d_udisp, t.udisp));
     HIP_OR_RETURN(h, Upload(&h->d_uhot2, t.uhot2));
-  HIP_OR_RETURN(h, Upload(&h->d_uhot2, t.uhot2));
-  HIP_OR_RETURN(h, Upload(&h->d_udisp, t.udisp));
-  HIP_OR_RETURN(h, Upload(&h->d_uhot2, t.uhot2));
     HIP_OR_RETURN(h, Upload(&h->d_uhot, t.uhot));
     HIP_OR_RETURN(h, Upload(&h->d_pscore, t.pscore));
     HIP_OR_RETURN(h, Upload(&h->d_dec_info, t.dec_info));

@@ -127,6 +127,10 @@ int spmx_rccl_comm_destroy(void *comm) {
   return 0;
 }
 
+uint64_t spmx_gather_scratch_words(int world) {
+  return world >= 1 && world <= kMaxRanks ? static_cast<uint64_t>(kGatherWords) * (1u + static_cast<uint64_t>(world)) : 0u;
+}
+
 int spmx_all_gather_ids(void *nccl_comm, int rank, int world, const int32_t *d_ids, uint64_t n_ids,
                         const uint64_t *d_id_offsets, uint64_t n_sentences, int32_t *d_all_ids, uint64_t all_ids_capacity,
                         uint64_t *d_all_id_offsets, uint64_t all_offsets_capacity, uint64_t *d_scratch,

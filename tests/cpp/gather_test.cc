@@ -51,7 +51,7 @@ int main(int argc, char **argv) {
       uint64_t total = 0;
       if (m && !sp.EncodeBatchDevice(text.data() + offs[lo], offs[hi] - offs[lo], my_offs.data(), m, ids.data(), ids.size(), io.data(), nullptr, &total).ok()) { ++bad; return; }
       std::vector<int32_t> all_ids(want_total + 8, -7);
-      std::vector<uint64_t> all_offs(n + 2, 0xCDCD), scratch(5 * (1 + world)), rs, ri;
+      std::vector<uint64_t> all_offs(n + 2, 0xCDCD), scratch(sentencepiece::SentencePieceProcessor::GatherScratchWords(world)), rs, ri;
       const sentencepiece::util::Status st = sentencepiece::SentencePieceProcessor::AllGatherIds(
           comm, rank, world, ids.data(), total, io.data(), m, all_ids.data(), all_ids.size(), all_offs.data(), all_offs.size(),
           scratch.data(), &rs, &ri, nullptr);

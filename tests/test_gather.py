@@ -25,7 +25,7 @@ def _gather_rank(lib, comm, rank, world, ids, io, cap_ids, cap_offs):
     io = np.ascontiguousarray(io, dtype=np.uint64)
     all_ids = np.full(cap_ids, -7, dtype=np.int32)
     all_offs = np.full(cap_offs, 0xCDCD, dtype=np.uint64)
-    scratch = np.zeros(5 * (1 + world), dtype=np.uint64)
+    scratch = np.zeros(int(lib.spmx_gather_scratch_words(world)), dtype=np.uint64)
     rs = np.zeros(world + 1, dtype=np.uint64)
     ri = np.zeros(world + 1, dtype=np.uint64)
     rc = lib.spmx_all_gather_ids(comm, rank, world, ids.ctypes.data, len(ids), io.ctypes.data, n, all_ids.ctypes.data, cap_ids,
@@ -152,7 +152,7 @@ def test_all_gather_ids_on_the_gpu_world_1(oracle, corpora):
     assert lib.spmx_rccl_comm_init(C.byref(comm), 1, 0, uid) == 0, lib.spmx_gather_last_error()
     all_ids = torch.full((total + 8,), -7, dtype=torch.int32, device=dev)
     all_offs = torch.zeros(n + 2, dtype=torch.int64, device=dev)
-    scratch = torch.zeros(10, dtype=torch.int64, device=dev)
+    scratch = torch.zeros(int(lib.spmx_gather_scratch_words(1)), dtype=torch.int64, device=dev)
     rs = np.zeros(2, dtype=np.uint64)
     ri = np.zeros(2, dtype=np.uint64)
     stream = torch.cuda.current_stream().cuda_stream
