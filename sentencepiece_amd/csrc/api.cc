@@ -312,6 +312,9 @@ struct spmx_handle {
   bool no_word_dyn = false;      // SPMX_NO_WORD_DYN=1: no call-local word memo (one word round, then the DP pass)
   bool memo_unsafe = false;      // TEST SEAM of the emulator build (SPMX_TEST_SEAMS + SPMX_WORDMEMO_UNSAFE=1): the call-local memo takes no margin either
   bool force_word_dp = false;    // SPMX_FORCE_WORD_DP=1: the second pass runs whatever the first one left (tests)
+  bool no_split = false;         // SPMX_NO_SPLIT=1: no class takes the split form (kernels_matchfold.h)
+  uint32_t split_min_raw = 576;  // SPMX_SPLIT_MIN: classes of MORE than this many raw bytes (up to kMfMaxRaw) take the split form
+  uint32_t split_per_byte = 4;   // SPMX_SPLIT_CANDS: candidates per normalized byte a sentence's stream holds before the overflow launch takes the sentence
   bool no_uni_wave = false;      // SPMX_NO_UNI_WAVE=1: unigram models never take the wave-cooperative form (kernels_uniwave.h)
   uint32_t uni_wave_max = 0;     // SPMX_UNI_WAVE_MAX: a staged class with fewer sentences than this takes the wave-cooperative form
   int word_wgs = 1;              // SPMX_WORD_WGS: workgroups per CU of the word kernel's first pass
@@ -554,7 +557,7 @@ struct StreamPlan {
 // (classes outside the range get no tiles); tcap_of(c) gives a class's text-column capacity.
 template <typename TcapFn>
 StreamPlan PlanStream(const spmx_handle *h, EncodeArgs *a, const uint32_t *counts, int c_lo, int c_hi, int n_classes,
-                      const uint32_t *rcaps, TcapFn tcap_of, bool all_general, int waves_cap = 0, int cus_cap = 0) {
+                      const uint32_t *rcaps, TcapFn tcap_of, bool all_general, int waves_cap = 0, int cus_cap = 0, bool allow_split = false) {
   StreamPlan sp;
   const int model = h->model.model_type;
   const uint32_t ring = HandleRing(h);
@@ -564,7 +567,17 @@ StreamPlan PlanStream(const spmx_handle *h, EncodeArgs *a, const uint32_t *count
                         h->model.pieces.size() <= kBpShortMaxVocab && !h->no_bp_short;
   a->bp_short = bp_short ? 1u : 0u;
   const uint32_t bpsz = bp_short ? 2u : 4u;
-  const uint32_t priv = StreamPrivateBytes(model, ring, bpsz);
+  uint32_t priv = StreamPrivateBytes(model, ring, bpsz);
+  // the split form (kernels_matchfold.h) for the classes of long sentences of a unigram model: its match phase keeps ONE
+  // sentence's raw and normalized image in the wavefront's LDS
+  const bool can_split = allow_split && model == kUnigram && h->tables.split_ok && !h->no_split && !(h->dev.flags & kNfHasUserDefined);
+  auto split_class = [&](int c) { return can_split && counts[c] > 0 && rcaps[c] > h->split_min_raw && rcaps[c] <= kMfMaxRaw && tcap_of(c) < 65000u; };
+  a->match_rows = static_cast<uint32_t>(h->tables.max_prefixes);
+  for (int c = c_lo; c < c_hi; ++c)
+    if (split_class(c)) {
+      const uint32_t need = ((MatchLdsBytes(rcaps[c], tcap_of(c), a->match_rows) + 15u) & ~15u) + 256u;
+      if (need > priv) priv = need;
+    }
   int waves = static_cast<int>((kLdsPerCu - kStreamSharedBytes) / priv);
   if (waves > 16) waves = 16;            // __launch_bounds__(1024)
   if (waves < 1) waves = 1;
@@ -577,8 +590,12 @@ StreamPlan PlanStream(const spmx_handle *h, EncodeArgs *a, const uint32_t *count
   if (grid < 1) grid = 1;
   // the slab of a wavefront must hold one lane of the largest class present: fewer wavefronts if the limit says so
   uint64_t need1 = 0;
+  auto slab_of = [&](int c, uint32_t sh) -> uint64_t {
+    if (!split_class(c)) return StreamSlabBytes(tcap_of(c), ring, sh, bpsz);
+    return StreamSplitBase(tcap_of(c), ring, sh, bpsz) + (MatchStreamBytes(MatchStreamCap(tcap_of(c), h->split_per_byte)) << sh);
+  };
   for (int c = c_lo; c < c_hi; ++c)
-    if (counts[c]) { const uint64_t b = StreamSlabBytes(tcap_of(c), ring, 0, bpsz); if (b > need1) need1 = b; }
+    if (counts[c]) { const uint64_t b = slab_of(c, 0); if (b > need1) need1 = b; }
   if (need1 && grid * waves * need1 > h->stream_scratch_limit) {
     uint64_t w = h->stream_scratch_limit / need1;
     if (w < 1) w = 1;
@@ -623,10 +640,15 @@ StreamPlan PlanStream(const spmx_handle *h, EncodeArgs *a, const uint32_t *count
     if (tw < 1) tw = 1;
     uint32_t sh = 0;                                   // lanes of a tile: enough for tw, as many as the budget allows
     while ((1ull << sh) < tw) ++sh;
-    while (sh > 0 && StreamSlabBytes(sc.tcap, ring, sh, bpsz) > budget) --sh;
+    while (sh > 0 && slab_of(c, sh) > budget) --sh;
     if (tw > (1ull << sh)) tw = 1ull << sh;
     sc.lane_shift = sh;
-    const uint64_t slab = StreamSlabBytes(sc.tcap, ring, sh, bpsz);
+    sc.split = split_class(c) ? 1u : 0u;
+    sc.ccap = sc.split ? MatchStreamCap(sc.tcap, h->split_per_byte) : 0u;
+    const uint64_t slab = slab_of(c, sh);
+#ifdef SPMX_TEST_SEAMS
+    if (getenv("SPMX_DEBUG_PLAN")) fprintf(stderr, "spmx plan: class %d rcap %u count %u tw %llu lanes %u split %u ccap %u slab %llu priv %u waves %d\n", c, sc.rcap, counts[c], (unsigned long long)tw, 1u << sh, sc.split, sc.ccap, (unsigned long long)slab, priv, waves);
+#endif
     if (slab > sp.slab_bytes) sp.slab_bytes = slab;
     sc.count = counts[c];
     sc.tw = static_cast<uint32_t>(tw);
@@ -644,7 +666,8 @@ StreamPlan PlanStream(const spmx_handle *h, EncodeArgs *a, const uint32_t *count
   a->slab_bytes = sp.slab_bytes;
   sp.grid = static_cast<int>(grid);
   sp.waves = waves;
-  sp.lds = StreamLdsBytes(model, ring, static_cast<uint32_t>(waves), bpsz);
+  sp.lds = kStreamSharedBytes + static_cast<uint32_t>(waves) * priv;
+  a->private_bytes = priv;
   return sp;
 }
 
@@ -801,7 +824,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         // the last class of the table takes every longer sentence too: those go straight to the overflow list
         sp = PlanStream(h, &la, counts, c_lo, c_hi, ncls, rc2,
                         [&](int c) { return esc3 ? 2u * cls[c].rcap + 64u : (h->wide_tcap ? cls[c].ncap : cls[c].rcap + cls[c].rcap / 4u + 16u); }, !fast_ok,
-                        stream_waves_cap, stream_cus_cap);
+                        stream_waves_cap, stream_cus_cap, /*allow_split=*/true);
       }
       if (la.total_main == 0) return kOk;
       la.q = &ws->d_ctrl->q[qi];
@@ -1601,6 +1624,9 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
           fprintf(stderr, "libspmx: %s is read by test-seam builds only (-DSPMX_TEST_SEAMS); this library ignores it\n", v);
     }
 #endif
+    if (const char *e = getenv("SPMX_NO_SPLIT")) h->no_split = e[0] == '1';
+    if (const char *e = getenv("SPMX_SPLIT_MIN")) h->split_min_raw = static_cast<uint32_t>(atoll(e));
+    if (const char *e = getenv("SPMX_SPLIT_CANDS")) { const int v = atoi(e); if (v >= 1 && v <= 16) h->split_per_byte = static_cast<uint32_t>(v); }
     if (const char *e = getenv("SPMX_UNI_WAVE_MAX")) h->uni_wave_max = static_cast<uint32_t>(atoll(e));
     if (const char *e = getenv("SPMX_WORD_WAVE")) { const int v = atoi(e); if (v >= 0 && v <= 3) h->word_form = v; }
     if (const char *e = getenv("SPMX_WORDWAVE_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 12) h->wordwave_waves = v; }

@@ -48,6 +48,9 @@ enum : uint32_t {
   kNfWordLocalNorm = 1u << 12,
 };
 
+constexpr uint32_t kNfiltCps = 0x20000u;
+constexpr uint32_t kNfiltWords = kNfiltCps / 32u;
+
 // One-byte stand-in for U+2581 under kNfCompressSp.  0xFF never occurs in valid UTF-8, and the normalizer's
 // output is valid UTF-8 whenever the model's own strings are (checked at load).
 constexpr uint32_t kSpByte = 0xFFu;
@@ -83,7 +86,15 @@ struct SpmxDev {
   // bit (b0 << 8 | b1): some charsmap key starts with the bytes b0 b1, or is b0 alone (then the whole row b0 is
   // set); b1 = 0 stands for "no second byte".  A clear bit proves that no rule starts at a position without a
   // single Darts probe -- most CJK ideographs and ASCII pairs (tables.cc)
-  const uint32_t *npair;   // [2048]
+  const uint32_t *npair;   // [2048] (+ the code-point filters below when nfilt != 0)
+  // code-point filters of the charsmap keys behind npair's 2048 words (tables.cc), three bitmaps of kNfiltWords words over
+  // the code points below kNfiltCps: [0] some key STARTS with the character, [1] the character ALONE is a key, [2] the
+  // character is the SECOND character of some key.  NormalizePrefix's longest-key search (normalizer.cc:218-228) finds
+  // nothing at a character c followed by d unless starts[c] and (alone[c] or second[d]) -- so most kana, Cyrillic and
+  // accented letters (keys only together with a combining mark) need no trie walk.  0: not built (a key that is not UTF-8).
+  // Behind the bitmaps, kNfiltCps words: the rule of a key that is exactly ONE character -- offset into nblob | length << 24
+  // of a replacement of 1 .. 255 bytes without a space; 0: none such (normalize_wave's common sweep applies these itself).
+  uint32_t nfilt;
   uint32_t flags;
   // normalized length <= expand_max * raw length + 3: the largest growth of any NormalizePrefix result (a charsmap
   // rule's replacement over its key, U+FFFD for one malformed byte, a space escaped to U+2581), tables.cc

@@ -47,7 +47,9 @@ struct StreamClass {
   uint32_t count;        // sentences in the class list
   uint32_t general;      // every lane of its main tiles runs norm_lane_any (models / classes the ASCII fast path cannot take)
   uint32_t min_lanes;    // an ASCII tile normalizes its non-ASCII sentences itself when at least this many lanes have one
-  uint32_t pad[3];
+  uint32_t split;        // the class's tiles take the SPLIT form (kernels_matchfold.h): match wave-cooperatively, fold per lane
+  uint32_t ccap;         // split: entries a sentence's candidate stream holds (MatchStreamCap)
+  uint32_t pad[1];
 };
 // Device-side state of the tile queue of ONE streaming launch, zeroed before it
 struct StreamQueue {
@@ -94,6 +96,8 @@ struct EncodeArgs {
   uint32_t ring;                // score ring entries (power of two > longest piece)
   uint32_t fast_ok;             // the model meets fast_norm_stream's preconditions
   uint32_t no_lane_general;     // A/B switch: ASCII tiles put every non-ASCII sentence into the backlog
+  uint32_t private_bytes;       // LDS of one wavefront of the streaming launch (StreamPrivateBytes, or more for the split form's image)
+  uint32_t match_rows;          // split form (kernels_matchfold.h): candidate-row entries = the trie's deepest chain of prefixes
   uint32_t no_char_norm;        // A/B switch: 1: no tile takes the character-stepping normalizer (kernels_normlane.h char_norm_stream); 2 (test seam): every tile does
   StreamClass cls[kMaxClasses];
   // ---- word kernel (kernels_word.h): what it cannot take, per length class, for the general launch that follows ----
@@ -231,9 +235,112 @@ SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint
   const bool has_map = (F & kNfHasCharsmap) != 0, has_uds = (F & kNfHasUserDefined) != 0;
   const uint32_t droot = has_map ? DartsOffset(d.ndarts[0]) : 0u;
   const uint32_t uroot = has_uds ? (d.utrie[0].x >> kDatBaseShiftDev) : 0u;
+  const bool try_fast = !HBM && !has_uds && (!has_map || d.nfilt != 0u);
   for (int b = 0; b < L; b += 64) {
     const int p = b + lane;
     const bool valid = p < L;
+    // (0) THE COMMON SWEEP: every position from the chain's next start on is a well-formed character (DecodeUTF8's rule,
+    // util.cc:51-84) at which no charsmap key can match (the code-point filters, dev.h nfilt) and that is no literal
+    // U+2581 -- every prefix is its own character (:231-244), so the chain of starts is the bytes that continue no
+    // character, and what remains of the loop is the whitespace state machine and a prefix sum.  One test per sweep; any
+    // other sweep takes the general steps below.  (LDS image only: the eight bytes a lane looks at may lie past the text.)
+    if (try_fast) {
+      struct __attribute__((packed, aligned(1))) U32B { uint32_t v; };
+      uint32_t w0 = 0, w1 = 0;
+      if (valid) { w0 = reinterpret_cast<const U32B *>(raw + p)->v; w1 = reinterpret_cast<const U32B *>(raw + p + 4)->v; }
+      const int rem = L - p;
+      if (rem < 8) {                                     // bytes past the text read as 0: they continue nothing
+        if (rem <= 4) { w1 = 0; if (rem < 4) w0 &= rem <= 0 ? 0u : (1u << (8 * rem)) - 1u; }
+        else w1 &= (1u << (8 * (rem - 4))) - 1u;
+      }
+      const uint32_t b0 = w0 & 0xFFu, b1 = (w0 >> 8) & 0xFFu, b2 = (w0 >> 16) & 0xFFu, b3 = w0 >> 24;
+      const bool is_cont = (b0 & 0xC0u) == 0x80u;
+      const int mb = b0 < 0x80u ? 1 : (b0 < 0xE0u ? 2 : (b0 < 0xF0u ? 3 : 4));
+      const bool c1 = (b1 & 0xC0u) == 0x80u, c2 = (b2 & 0xC0u) == 0x80u, c3 = (b3 & 0xC0u) == 0x80u;
+      bool okc;
+      uint32_t cp;
+      if (mb == 1) { okc = true; cp = b0; }
+      else if (mb == 2) { okc = b0 >= 0xC2u && c1; cp = (b0 & 0x1Fu) << 6 | (b1 & 0x3Fu); }
+      else if (mb == 3) { okc = c1 && c2 && (b0 != 0xE0u || b1 >= 0xA0u) && (b0 != 0xEDu || b1 < 0xA0u); cp = (b0 & 0x0Fu) << 12 | (b1 & 0x3Fu) << 6 | (b2 & 0x3Fu); }
+      else { okc = b0 <= 0xF4u && c1 && c2 && c3 && (b0 != 0xF0u || b1 >= 0x90u) && (b0 != 0xF4u || b1 < 0x90u);
+             cp = (b0 & 0x07u) << 18 | (b1 & 0x3Fu) << 12 | (b2 & 0x3Fu) << 6 | (b3 & 0x3Fu); }
+      const uint64_t x8 = static_cast<uint64_t>(w1) << 32 | w0;
+      const uint32_t nx = static_cast<uint32_t>(x8 >> (8 * mb));               // the four bytes behind the character
+      const uint32_t n0 = nx & 0xFFu;
+      const bool after_ok = (n0 & 0xC0u) != 0x80u;
+      const bool from = valid && p >= next_start;
+      bool cx = from && (is_cont ? p == next_start : !(okc && after_ok));
+      const bool st = from && !is_cont;
+      uint32_t rule = 0;                                                       // a one-character rule: nblob offset | length << 24
+      if (st && !cx) {
+        if (one && cp == 0x2581u) cx = true;                                   // a literal U+2581 (kind 3 below)
+        if (has_map) {
+          // (the three filter words are asked for together, whatever the first one says: one trip to the cache, not three)
+          const uint32_t n1 = (nx >> 8) & 0xFFu, n2 = (nx >> 16) & 0xFFu, n3 = nx >> 24;
+          uint32_t ncp;
+          bool nok = true;
+          if (n0 < 0x80u) ncp = n0;
+          else if (n0 < 0xE0u) { ncp = (n0 & 0x1Fu) << 6 | (n1 & 0x3Fu); nok = n0 >= 0xC2u && (n1 & 0xC0u) == 0x80u; }
+          else if (n0 < 0xF0u) { ncp = (n0 & 0x0Fu) << 12 | (n1 & 0x3Fu) << 6 | (n2 & 0x3Fu); nok = (n1 & 0xC0u) == 0x80u && (n2 & 0xC0u) == 0x80u; }
+          else { ncp = (n0 & 0x07u) << 18 | (n1 & 0x3Fu) << 12 | (n2 & 0x3Fu) << 6 | (n3 & 0x3Fu); nok = (n1 & 0xC0u) == 0x80u && (n2 & 0xC0u) == 0x80u && (n3 & 0xC0u) == 0x80u; }
+          const bool has_next = mb < rem;                                      // the character behind it, if any
+          const bool big = cp >= kNfiltCps, nbig = has_next && (!nok || ncp >= kNfiltCps);
+          const uint32_t *f = d.npair + 2048;
+          const uint32_t cq = big ? 0u : cp, nq = (has_next && !nbig) ? ncp : 0u;
+          const uint32_t w_starts = f[cq >> 5], w_alone = f[kNfiltWords + (cq >> 5)], w_second = f[2u * kNfiltWords + (nq >> 5)];
+          if (big) cx = true;
+          else if ((w_starts >> (cq & 31u)) & 1u) {
+            const bool alone = (w_alone >> (cq & 31u)) & 1u;
+            const bool second = nbig || (has_next && ((w_second >> (nq & 31u)) & 1u));
+            if (second) cx = true;
+            else if (alone) { rule = f[3u * kNfiltWords + cp]; if (rule == 0u) cx = true; }
+          }
+        }
+      }
+      if (!wv::any(cx)) {
+        const bool is_sp = st && b0 == 0x20u;
+        {
+          const uint64_t om = wv::ballot(st && !is_sp);
+          if (om && first_other < 0) first_other = b + wv::ffs64(om) - 1;
+          any_other = any_other || om != 0;
+        }
+        bool Pl = false;
+        if (rm) {                                          // (3) below with clsA = the spaces, clsN = the other characters
+          const uint64_t mA = wv::ballot(is_sp), setters = wv::ballot(st);
+          const uint64_t below = setters & ((1ull << lane) - 1ull);
+          Pl = below ? (((mA >> (63 - wv::clz64(below))) & 1ull) != 0) : P;
+          if (setters) P = ((mA >> (63 - wv::clz64(setters))) & 1ull) != 0;
+        }
+        const bool drop = is_sp && Pl;                     // :137-138
+        const uint32_t out_len = st && !drop ? (rule ? rule >> 24 : static_cast<uint32_t>(is_sp ? spw : mb)) : 0u;
+        const uint32_t incl = wv::scan_add(out_len);
+        const int total = static_cast<int>(wv::read_lane(incl, 63));
+        if (out + total > ncap) return -1;
+        if (out_len) {
+          int w = out + static_cast<int>(incl - out_len);
+          if (orig) for (uint32_t k = 0; k < out_len; ++k) orig[w + static_cast<int>(k)] = static_cast<uint16_t>(p);
+          if (rule) {                                      // :245-250 the key's replacement (no space in it)
+            const uint8_t *rs = d.nblob + (rule & 0x00FFFFFFu);
+            for (uint32_t k = 0; k < out_len; ++k) norm[w + static_cast<int>(k)] = rs[k];
+          } else if (is_sp) {
+            if (esc) { norm[w] = 0xE2; norm[w + 1] = 0x96; norm[w + 2] = 0x81; }
+            else norm[w] = static_cast<uint8_t>(sp1);
+          } else {
+            norm[w] = static_cast<uint8_t>(b0);
+            if (mb > 1) norm[w + 1] = static_cast<uint8_t>(b1);
+            if (mb > 2) norm[w + 2] = static_cast<uint8_t>(b2);
+            if (mb > 3) norm[w + 3] = static_cast<uint8_t>(b3);
+          }
+        }
+        out += total;
+        const uint64_t S = wv::ballot(st);
+        if (S) {
+          const int hi = 63 - wv::clz64(S);
+          next_start = b + hi + wv::shfl(mb, hi);
+        }
+        continue;
+      }
+    }
     // (1) NormalizePrefix at every position (:195-253)
     int uds_len = 0, rule_len = 0;
     uint32_t rule_off = 0;

@@ -148,13 +148,20 @@ SPMX_HD inline uint64_t StreamSlabBytes(uint32_t tcap, uint32_t ring, uint32_t l
   return text + (static_cast<uint64_t>(StreamBpStride(tcap)) << lane_shift) * bpsz + 32u;
 }
 
-SPMX_DEVICE StreamLds carve_stream(unsigned char *base, int model, uint32_t ring, int wave, uint32_t bpsz = 4u) {
+// split form: where the candidate streams of a tile begin in its slab, and the slab's size with them
+SPMX_HD inline uint64_t StreamSplitBase(uint32_t tcap, uint32_t ring, uint32_t lane_shift, uint32_t bpsz) {
+  return (StreamSlabBytes(tcap, ring, lane_shift, bpsz) + 255u) & ~static_cast<uint64_t>(255);
+}
+
+// priv: bytes of one wavefront's slice (EncodeArgs::private_bytes; 0: StreamPrivateBytes)
+SPMX_DEVICE StreamLds carve_stream(unsigned char *base, int model, uint32_t ring, int wave, uint32_t bpsz = 4u, uint32_t priv = 0u) {
   StreamLds t;
+  if (priv == 0u) priv = StreamPrivateBytes(model, ring, bpsz);
   t.roottab = reinterpret_cast<U4 *>(base);
   t.asym = reinterpret_cast<uint32_t *>(base);
   t.bcls = base + 256u * 16u;
-  unsigned char *mine = base + kStreamSharedBytes + static_cast<uint32_t>(wave) * StreamPrivateBytes(model, ring, bpsz);
-  t.backlog = reinterpret_cast<uint32_t *>(mine + StreamPrivateBytes(model, ring, bpsz) - 256u);
+  unsigned char *mine = base + kStreamSharedBytes + static_cast<uint32_t>(wave) * priv;
+  t.backlog = reinterpret_cast<uint32_t *>(mine + priv - 256u);
   t.rawwin = mine;
   t.ring_s = reinterpret_cast<float *>(mine);
   t.ring_b = reinterpret_cast<uint32_t *>(mine + 64u * ring * 4u);
@@ -449,6 +456,10 @@ SPMX_DEVICE int emit_stream_lane(const SpmxDev &d, const TextCol &gt, const BpCo
   return ok ? n : -1;
 }
 
+}  // namespace spmx
+#include "kernels_matchfold.h"
+namespace spmx {
+
 // ---- the tile queue of one launch ------------------------------------------------------------------------------
 // Lane 0 of a wave asks for its next main tile: one atomic; the classes are laid out longest first in the cursor's range.
 SPMX_DEVICE bool next_tile(const EncodeArgs &a, uint32_t *cls, uint32_t *first, uint32_t *cnt) {
@@ -482,7 +493,7 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
   const int lane = wv::lane();
   const SpmxDev &d = a.dev;
   const uint32_t ring = RING ? static_cast<uint32_t>(RING) : a.ring;
-  const StreamLds T = carve_stream(smem, MODEL, ring, wv::wave_in_block(), kBpSz);
+  const StreamLds T = carve_stream(smem, MODEL, ring, wv::wave_in_block(), kBpSz, a.private_bytes);
   const uint32_t rm = ring - 1;
   const uint32_t W = StreamWindow(ring);
   float *my_rs = T.ring_s + lane;
@@ -541,6 +552,11 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     const uint64_t text_bytes = ((StreamTextDwords(tcap, ring) << lane_shift) * 4u + 31u) & ~static_cast<uint64_t>(31);
     const TextCol gt{reinterpret_cast<uint32_t *>(slab) + lane, lane_shift};
     const BpCol<BT> gb{reinterpret_cast<BT *>(slab + text_bytes) + static_cast<uint32_t>(lane) * 8u, lane_shift};
+    // split form (kernels_matchfold.h): the lanes' candidate streams lie behind the tile's text and back-pointer blocks
+    const bool split = MODEL == 1 && !UDS && !backlog && sc.split != 0u;
+    const uint64_t cs_stride = MatchStreamBytes(sc.ccap);
+    const U2 *my_cs = reinterpret_cast<const U2 *>(slab + StreamSplitBase(tcap, ring, lane_shift, kBpSz) + static_cast<uint64_t>(lane) * cs_stride);
+    int my_nent = 0;
     const uint32_t *list = a.lists + static_cast<uint64_t>(c) * a.n;
     uint32_t my_sid = 0;
     uint64_t my_beg = 0;
@@ -561,7 +577,56 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
       const bool go = lane < cnt && !over;
       int nlen = 0;
       bool need_any = go && my_len > 0;
-      if (!backlog && a.fast_ok && !sc.general) {
+      if (split) {
+        // ---- match: the tile's sentences one after another, each by the whole wavefront ----
+        need_any = false;
+        nlen = -2;                               // (this lane's result is set when its sentence's turn comes)
+        const MatchLds ML = carve_match(T.rawwin, sc.rcap, tcap, a.match_rows);
+        wv::sync();                              // (the image aliases the rings the previous tile's fold used)
+        for (int j = 0; j < cnt; ++j) {
+          const uint32_t j_len = wv::shfl(my_len, j);
+          if (wv::shfl(over ? 1u : 0u, j) != 0u) continue;
+          int nl = 0, nsp = 0, nent = 0;
+          if (j_len > 0) {
+            const uint64_t j_beg = (static_cast<uint64_t>(wv::shfl(static_cast<uint32_t>(my_beg >> 32), j)) << 32) | wv::shfl(static_cast<uint32_t>(my_beg), j);
+            const uint8_t *src = a.text + j_beg;
+            const unsigned long long m0 = wv::clock();
+            // the sentence's image: the aligned 16-byte units that hold its bytes (as the word-per-lane kernel reads them:
+            // include/spmx.h on the bytes that share a unit with the text's first and last byte), four loads in flight a lane
+            const uintptr_t s_addr = reinterpret_cast<uintptr_t>(src);
+            const uint32_t s_sh = static_cast<uint32_t>(s_addr & 15u);
+            const Q4 *g = reinterpret_cast<const Q4 *>(s_addr - s_sh);
+            Q4 *img = reinterpret_cast<Q4 *>(ML.raw);
+            const uint32_t units = (s_sh + j_len + 15u) >> 4;
+            for (uint32_t u0 = static_cast<uint32_t>(lane); u0 < units; u0 += 256u) {
+              Q4 v0{0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0;
+              v0 = g[u0];
+              if (u0 + 64u < units) v1 = g[u0 + 64u];
+              if (u0 + 128u < units) v2 = g[u0 + 128u];
+              if (u0 + 192u < units) v3 = g[u0 + 192u];
+              img[u0] = v0;
+              if (u0 + 64u < units) img[u0 + 64u] = v1;
+              if (u0 + 128u < units) img[u0 + 128u] = v2;
+              if (u0 + 192u < units) img[u0 + 192u] = v3;
+            }
+            wv::sync();
+            nl = normalize_wave(d, ML.raw + s_sh, static_cast<int>(j_len), ML.norm, static_cast<int>(tcap), lane);
+            tc.cyc[0] += wv::clock() - m0;       // (of the match phase: the sentence's image and its normalization)
+            if (nl > 0) {
+              const TextCol gj{reinterpret_cast<uint32_t *>(slab) + j, lane_shift};      // (the backtrack's byte fallback reads it)
+              for (int k = lane; 4 * k < nl; k += 64) gj.dw(k) = *reinterpret_cast<const uint32_t *>(ML.norm + 4 * k);
+              U2 *out = reinterpret_cast<U2 *>(slab + StreamSplitBase(tcap, ring, lane_shift, kBpSz) + static_cast<uint64_t>(j) * cs_stride);
+              nent = match_wave(d, ML.norm, nl, T.roottab, ML, a.match_rows, out, static_cast<int>(sc.ccap), lane, &nsp);
+            }
+            wv::sync();
+          }
+          if (lane == j) {
+            if (nl < 0 || nent < 0) { over = true; }
+            else { nlen = nl; my_nsp = nsp; my_nent = nent; }
+          }
+        }
+        wv::sync_global();                       // (a lane folds what the whole wavefront wrote)
+      } else if (!backlog && a.fast_ok && !sc.general) {
         // which form: a tile where one sentence in eight begins with non-ASCII text (CJK ...) steps character by
         // character; the byte-stepping form is for ASCII with the odd accent
         bool na = false;
@@ -645,8 +710,13 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     unsigned long long c2 = c1;
     if (MODEL == 1) {
       // ---- segment, then backtrack: the slot is filled from its end (or from its start when reversing) ----
-      tc.n_trips += static_cast<unsigned long long>(
-          unigram_stream_lane<RING, UDS, BP>(d, gt, gb, my_nlen, my_rs, my_rb, rm, my_win, W - 1u, my_st, T.roottab, mine));
+      if (split) {
+        wv::sync();
+        tc.n_trips += static_cast<unsigned long long>(fold_stream_lane<RING, BP>(d, my_cs, my_nent, gb, my_nlen, my_rs, my_rb, rm, my_st, mine));
+      } else {
+        tc.n_trips += static_cast<unsigned long long>(
+            unigram_stream_lane<RING, UDS, BP>(d, gt, gb, my_nlen, my_rs, my_rb, rm, my_win, W - 1u, my_st, T.roottab, mine));
+      }
       c2 = wv::clock();
       if (!overflow) {
         n = emit_stream_lane<BP>(d, gt, gb, my_nlen, slot, tslot, cap, reinterpret_cast<int32_t *>(my_rs), mine);

@@ -172,6 +172,96 @@ Status CompileTables(const ModelData &m, HostTables *t) {
       }
     }
   }
+  // code-point filters of the keys (dev.h nfilt): every key by a depth-first walk that carries the key's first 8 bytes
+  sc.nfilt = 0;
+  if (!t->ndarts.empty()) {
+    const std::vector<uint32_t> &u = t->ndarts;
+    auto offset = [](uint32_t x) { return (x >> 10) << ((x & (1u << 9)) >> 6); };
+    // one character of s[0, n): its length (0: not valid UTF-8 by DecodeUTF8's rule, src/util.cc:51-84) and code point
+    auto decode = [](const unsigned char *s, size_t n, uint32_t *cp) -> int {
+      if (n == 0) return 0;
+      const unsigned b0 = s[0];
+      auto ct = [&](size_t k) { return k < n && (s[k] & 0xC0u) == 0x80u; };
+      if (b0 < 0x80) { *cp = b0; return 1; }
+      if (b0 >= 0xC2 && b0 < 0xE0 && ct(1)) { *cp = (b0 & 0x1Fu) << 6 | (s[1] & 0x3Fu); return 2; }
+      if (b0 >= 0xE0 && b0 < 0xF0 && ct(1) && ct(2)) {
+        *cp = (b0 & 0x0Fu) << 12 | (s[1] & 0x3Fu) << 6 | (s[2] & 0x3Fu);
+        return *cp >= 0x800 && (*cp < 0xD800 || *cp >= 0xE000) ? 3 : 0;
+      }
+      if (b0 >= 0xF0 && b0 < 0xF8 && ct(1) && ct(2) && ct(3)) {
+        *cp = (b0 & 0x07u) << 18 | (s[1] & 0x3Fu) << 12 | (s[2] & 0x3Fu) << 6 | (s[3] & 0x3Fu);
+        return *cp >= 0x10000 && *cp <= 0x10FFFF ? 4 : 0;
+      }
+      return 0;
+    };
+    std::vector<uint32_t> f(3 * kNfiltWords + kNfiltCps, 0);     // the three bitmaps, then the one-character rules (dev.h)
+    auto mark = [&](int which, uint32_t cp) {
+      if (cp >= kNfiltCps) return;                        // (the kernels take such characters the general way)
+      f[static_cast<size_t>(which) * kNfiltWords + (cp >> 5)] |= 1u << (cp & 31u);
+    };
+    struct Node { uint32_t pos, depth; unsigned char key[8]; };
+    std::vector<Node> todo;
+    Node root{offset(u[0]), 0, {0}};
+    todo.push_back(root);
+    size_t visited = 0;
+    bool ok = true;
+    while (!todo.empty() && ok && visited < 256 * u.size() + 1024) {
+      const Node nd = todo.back();
+      todo.pop_back();
+      ++visited;
+      for (uint32_t c = 1; c < 256 && ok; ++c) {
+        const uint32_t p = nd.pos ^ c;
+        if (p >= u.size() || (u[p] & 0x800000FFu) != c) continue;
+        Node ch = nd;
+        ch.pos = p ^ offset(u[p]);
+        ch.depth = nd.depth + 1;
+        if (nd.depth < 8) ch.key[nd.depth] = static_cast<unsigned char>(c);
+        if ((u[p] >> 8) & 1u) {                             // a key ends here
+          const size_t have = ch.depth < 8 ? ch.depth : 8;
+          uint32_t c1 = 0, c2 = 0;
+          const int l1 = decode(ch.key, have, &c1);
+          if (l1 == 0) {
+            if (getenv("SPMX_DEBUG_TABLES")) { fprintf(stderr, "spmx: charsmap key whose first character does not decode:"); for (size_t q = 0; q < have; ++q) fprintf(stderr, " %02X", ch.key[q]); fprintf(stderr, " (depth %u)\n", ch.depth); }
+            ok = false; break;
+          }
+          mark(0, c1);
+          if (static_cast<uint32_t>(l1) == ch.depth) {
+            mark(1, c1);
+            // the rule of a key that is ONE character: offset | length << 24 of its replacement when that is 1 .. 255 bytes
+            // without a space (a space goes through the whitespace state machine: the general steps take those)
+            if (c1 < kNfiltCps && ch.pos < u.size()) {
+              const uint32_t off = u[ch.pos] & 0x7FFFFFFFu;
+              size_t n = 0;
+              bool plain = off < (1u << 24);
+              while (off + n < t->nblob.size() && t->nblob[off + n] != 0) { if (t->nblob[off + n] == ' ') plain = false; ++n; }
+              if (plain && n >= 1 && n <= 255) f[3 * kNfiltWords + c1] = off | static_cast<uint32_t>(n) << 24;
+            }
+          }
+          else {
+            const int l2 = decode(ch.key + l1, have - static_cast<size_t>(l1), &c2);
+            if (l2 == 0) {
+              if (getenv("SPMX_DEBUG_TABLES")) { fprintf(stderr, "spmx: charsmap key whose second character does not decode:"); for (size_t q = 0; q < have; ++q) fprintf(stderr, " %02X", ch.key[q]); fprintf(stderr, " (depth %u)\n", ch.depth); }
+              ok = false; break;
+            }
+            mark(2, c2);
+          }
+        }
+        if (ch.depth < 256) todo.push_back(ch);
+      }
+    }
+    if (ok && todo.empty()) {
+      t->npair.insert(t->npair.end(), f.begin(), f.end());
+      sc.nfilt = 1;
+    }
+    if (getenv("SPMX_DEBUG_TABLES") && sc.nfilt) {
+      size_t n[3] = {0, 0, 0};
+      for (int w = 0; w < 3; ++w) for (uint32_t q = 0; q < kNfiltWords; ++q) n[w] += static_cast<size_t>(__builtin_popcount(f[static_cast<size_t>(w) * kNfiltWords + q]));
+      fprintf(stderr, "spmx: characters that start a key %zu, are a key alone %zu, are a key's second character %zu; second characters below U+0300:", n[0], n[1], n[2]);
+      for (uint32_t cp = 0; cp < 0x300; ++cp) if ((f[2 * kNfiltWords + (cp >> 5)] >> (cp & 31u)) & 1u) fprintf(stderr, " %04X", cp);
+      fprintf(stderr, "\n");
+    }
+    if (getenv("SPMX_DEBUG_TABLES")) fprintf(stderr, "spmx: code-point filters of the charsmap keys: %s (%zu nodes visited, %zu left)\n", sc.nfilt ? "built" : "NOT built", visited, todo.size());
+  }
   // Largest growth of a NormalizePrefix result over the bytes it consumes (dev.h expand_max): every key of the
   // charsmap trie by a depth-first walk of its units, the replacement's length with every ' ' counted as a
   // three-byte U+2581; at least 3 (U+FFFD for one malformed byte, an escaped space).
@@ -183,7 +273,9 @@ Status CompileTables(const ModelData &m, HostTables *t) {
     std::vector<Node> todo;
     todo.push_back({offset(u[0]), 0});                      // pos = node index after its own offset was applied
     size_t visited = 0;
-    while (!todo.empty() && visited < 4 * u.size() + 1024) {
+    // (the trie is a DAWG: a unit is reached once per key prefix that leads to it -- nmt_nfkc: 44,800 units, 262,841 prefixes;
+    // the bound only stops a malformed blob's cycles)
+    while (!todo.empty() && visited < 256 * u.size() + 1024) {
       const Node nd = todo.back();
       todo.pop_back();
       ++visited;
@@ -205,6 +297,24 @@ Status CompileTables(const ModelData &m, HostTables *t) {
         if (depth < 256) todo.push_back({child, depth});
       }
     }
+    if (getenv("SPMX_DEBUG_TABLES")) fprintf(stderr, "spmx: expand_max walk: %zu prefixes visited, %zu left, expand_max %u\n", visited, todo.size(), sc.expand_max);
+  }
+  // every replacement string valid UTF-8 by the reference's own rule (DecodeUTF8, src/util.cc:51-84)?  (kernels_matchfold.h)
+  bool blob_utf8 = true;
+  for (size_t i = 0; i < t->nblob.size() && blob_utf8;) {
+    const unsigned b0 = t->nblob[i];
+    auto cont = [&](size_t k) { return i + k < t->nblob.size() && (t->nblob[i + k] & 0xC0u) == 0x80u; };
+    if (b0 < 0x80) { i += 1; continue; }
+    if (b0 >= 0xC2 && b0 < 0xE0 && cont(1)) { i += 2; continue; }
+    if (b0 >= 0xE0 && b0 < 0xF0 && cont(1) && cont(2)) {
+      const unsigned cp = (b0 & 0x0Fu) << 12 | (t->nblob[i + 1] & 0x3Fu) << 6 | (t->nblob[i + 2] & 0x3Fu);
+      if (cp >= 0x800 && (cp < 0xD800 || cp >= 0xE000)) { i += 3; continue; }
+    }
+    if (b0 >= 0xF0 && b0 < 0xF8 && cont(1) && cont(2) && cont(3)) {
+      const unsigned cp = (b0 & 0x07u) << 18 | (t->nblob[i + 1] & 0x3Fu) << 12 | (t->nblob[i + 2] & 0x3Fu) << 6 | (t->nblob[i + 3] & 0x3Fu);
+      if (cp >= 0x10000 && cp <= 0x10FFFF) { i += 4; continue; }
+    }
+    blob_utf8 = false;
   }
   if (t->ndarts.empty()) t->ndarts.push_back(0);
   if (t->nblob.empty()) t->nblob.push_back(0);
@@ -266,6 +376,7 @@ Status CompileTables(const ModelData &m, HostTables *t) {
     if (!BuildDat(keys, &d, &err)) return Status::Error(kInternal, "piece trie: " + err);
     t->max_piece_len = d.max_key_len;
     t->max_prefixes = d.max_prefixes;
+    t->split_ok = blob_utf8 && uds_keys.empty() && m.pieces.size() < (1u << 21) && d.max_prefixes >= 1 && d.max_prefixes <= 16;
     if (d.max_key_len > kMaxPieceBytes)
       return Status::Error(kUnimplemented, "a piece is longer than 120 bytes; unsupported by the device unigram path");
     t->ptrie.resize(d.w0.size());

@@ -37,6 +37,9 @@ struct HostTables {
   SpmxDev scalars{};
   int max_piece_len = 0;
   int max_prefixes = 0;
+  // the split form (kernels_matchfold.h) may take this model: unigram, no user-defined pieces, every replacement string of
+  // the charsmap valid UTF-8 (then so is the normalized text, and its character starts are its non-continuation bytes)
+  bool split_ok = false;
 };
 
 // Builds everything that depends only on load-time structure.

@@ -638,3 +638,82 @@ def test_emu_compact_image_sizes(model, cap, emu, oracle, corpora, monkeypatch):
         oids, oio = o.encode_batch(text, offs)
         np.testing.assert_array_equal(io, oio)
         np.testing.assert_array_equal(ids, oids)
+
+
+SPLIT_MODELS = ["test_model", "test_ja_model", "uni1k", "uni1k_bf", "uni1k_ident", "uni1k_suffix", "uni32k", "uni32k_w16",
+                "c5_250k", "c5_250k_bf"]
+
+
+@pytest.mark.parametrize("model", SPLIT_MODELS)
+def test_emu_split_form(model, emu, oracle, corpora):
+    """kernels_matchfold.h: EncodeOptimized's trie walks (wave-cooperative, a start per lane) and its fold (a sentence
+    per lane, from the candidate stream) taken apart.  SPMX_SPLIT_MIN=0 sends every class of up to 4096 raw bytes there;
+    the word kernels are off so that all sentences come.  Every corpus, with and without extra options, the spans form,
+    and the longest mixed-script sentences (the classes the form exists for)."""
+    from sentencepiece_amd import synth
+    blob = fixtures.model_blob(model)
+    h = emu.load(blob, env={"SPMX_SPLIT_MIN": "0", "SPMX_NO_WORD_KERNEL": "1"})
+    o = oracle.load(blob)
+    t, of = corpora["mixed2k"]
+    n = len(of) - 1
+    pick = np.concatenate([np.arange(n - 4, n), np.arange(n - 400, n - 5, 100)])
+    batches = [fixtures.head(*corpora[name], k) for name, k in (("edge", 10 ** 6), ("botchan", 150), ("mixed2k", 40), ("ja", 20), ("synth20k", 100))]
+    batches.append(synth.gather_packed(t, of, pick))
+    for text, offs in batches:
+        for opts in ("", "bos:eos:reverse"):
+            h.sp.SetEncodeExtraOptions(opts)
+            o.set_encode_extra_options(opts)
+            ids, io = h.encode_batch(text, offs)
+            assert h.status == 0
+            oids, oio = o.encode_batch(text, offs)
+            np.testing.assert_array_equal(io, oio)
+            np.testing.assert_array_equal(ids, oids)
+        h.sp.SetEncodeExtraOptions("")
+        o.set_encode_extra_options("")
+    text, offs = fixtures.head(*corpora["mixed2k"], 60)
+    got = h.encode_spans(text, offs)
+    want = o.encode_spans(text, offs)
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(np.asarray(a).astype(np.int64), np.asarray(b).astype(np.int64))
+
+
+@pytest.mark.parametrize("model", ["uni32k", "c5_250k_bf"])
+def test_emu_split_form_stream_overflow(model, emu, oracle, corpora):
+    """A sentence whose candidate stream outgrows its share of the slab (SPMX_SPLIT_CANDS=1: one candidate per normalized
+    byte) leaves the split form for the call's overflow launch -- the lane-per-sentence kernel -- with the same ids; so
+    does one whose normalized text outgrows its column (NFKC expansions)."""
+    from sentencepiece_amd import synth
+    blob = fixtures.model_blob(model)
+    h = emu.load(blob, env={"SPMX_SPLIT_MIN": "0", "SPMX_NO_WORD_KERNEL": "1", "SPMX_SPLIT_CANDS": "1"})
+    o = oracle.load(blob)
+    docs = [b"the thing that there is " * 40, "㍿㌀㌁ ".encode() * 60, b"a", b"", "日本語のテキスト ".encode() * 30]
+    text, offs = synth.pack(docs)
+    t2, o2 = fixtures.head(*corpora["synth20k"], 80)
+    over = 0
+    for tx, ox in ((text, offs), (t2, o2)):
+        ids, io = h.encode_batch(tx, ox)
+        assert h.status == 0
+        over += h.path()["overflow"]
+        oids, oio = o.encode_batch(tx, ox)
+        np.testing.assert_array_equal(io, oio)
+        np.testing.assert_array_equal(ids, oids)
+    assert over > 0
+
+
+def test_emu_split_form_is_the_default_for_long_classes(emu, oracle, corpora):
+    """Without any switch the classes beyond 576 raw bytes of an eligible unigram model take the split form: the longest
+    sentences of the mixed-script corpus through the default plan (class table and thresholds as shipped)."""
+    from sentencepiece_amd import synth
+    blob = fixtures.model_blob("c5_250k")
+    h = emu.load(blob, classes=None, env={"SPMX_NO_WORD_KERNEL": "1"})
+    o = oracle.load(blob)
+    t, of = corpora["mixed2k"]
+    n = len(of) - 1
+    text, offs = synth.gather_packed(t, of, np.arange(n - 24, n))
+    ids, io = h.encode_batch(text, offs)
+    oids, oio = o.encode_batch(text, offs)
+    np.testing.assert_array_equal(io, oio)
+    np.testing.assert_array_equal(ids, oids)
+    trips = [c["phase_cycles"]["search_trips"] for c in h.sp.LastProfile()["classes"] if c["kernel"].startswith("EncodeStream")]
+    # the fold counts blocks of 16 candidates, the lane-per-sentence search one probe per iteration: thousands against tens of thousands
+    assert trips and max(trips) < 4096 * 2, trips
