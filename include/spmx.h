@@ -180,6 +180,20 @@ int spmx_encode(spmx_handle *h, const char *text, uint64_t len, int32_t *ids, ui
  * returns RESOURCE_EXHAUSTED (8) with the required capacity in *total_bytes (d_text_offsets is valid). */
 int spmx_decode_batch_device(spmx_handle *h, const int32_t *d_ids, const uint64_t *d_id_offsets, uint64_t n, void *d_text,
                              uint64_t text_capacity, uint64_t *d_text_offsets, void *stream, uint64_t *total_bytes);
+/* Decode from PIECES: Decode(const std::vector<std::string>& pieces, ...) (src/sentencepiece_processor.h:303-309,
+ * .cc:761-769; python/src/sentencepiece/sentencepiece.i:547 _DecodePiecesBatch).  The caller maps every piece to its id
+ * (spmx_piece_to_id); a piece that is NOT in the vocabulary -- PieceToId gives the unknown id for a string other than the
+ * unknown piece's -- goes through as it is (.cc:784-790): it travels as the id -(k + 1) with its bytes
+ * lit_bytes[lit_offsets[k], lit_offsets[k + 1]) (k < n_lit; at most 65535 bytes each).  Under a decode extra option `unk`
+ * (spmx_decode_unk_option() != 0) the reference rewrites such a piece to the unknown piece first (.cc:1050-1058): the
+ * caller then passes the unknown id instead.  Everything else as spmx_decode_batch. */
+int spmx_decode_batch_pieces(spmx_handle *h, const int32_t *ids, const uint64_t *id_offsets, uint64_t n, const char *lit_bytes,
+                             const uint64_t *lit_offsets, uint64_t n_lit, char **text, uint64_t **text_offsets);
+int spmx_decode_unk_option(const spmx_handle *h);
+/* GetScore(id) (src/sentencepiece_processor.h:650): the piece's score as the ModelProto holds it; 11 for an id out of range. */
+int spmx_piece_score(const spmx_handle *h, int id, float *score);
+/* serialized_model_proto() (src/sentencepiece_processor.h:694): the bytes the handle was created from; owned by the handle. */
+int spmx_serialized_model(const spmx_handle *h, const char **data, uint64_t *n_bytes);
 /* Host-buffer form; *text (total bytes) and *text_offsets (n + 1) are released with spmx_free(). */
 int spmx_decode_batch(spmx_handle *h, const int32_t *ids, const uint64_t *id_offsets, uint64_t n, char **text,
                       uint64_t **text_offsets);

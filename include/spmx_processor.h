@@ -4,8 +4,9 @@
 // (util::Status values, no exceptions; reference: src/sentencepiece_processor.h
 // :34-76 Status, :245 Load, :261 LoadFromSerializedProto, :264 status,
 // :267 SetEncodeExtraOptions, :279-283 SetVocabulary / ResetVocabulary,
-// :299-300 Encode(input, vector<int>*), :458-460 EncodeAsIds, :638-677
-// vocabulary accessors), plus the batch form the reference only has in its
+// :299-300 Encode(input, vector<int>*), :303-312 Decode from pieces / ids, :458-460 EncodeAsIds, :528
+// EncodeAsSerializedProto, :288 LoadVocabulary, :638-677 vocabulary accessors incl. GetScore, :694
+// serialized_model_proto; the methods the reference declares virtual (:245-677) are virtual here), plus the batch form the reference only has in its
 // Python wrapper (python/src/sentencepiece/sentencepiece.i:439-446
 // _EncodeAsIdsBatch): EncodeBatch == element-wise Encode.
 //
@@ -67,10 +68,39 @@ struct SentencePieceText {
     uint32_t id = 0;
     std::string surface;
     uint32_t begin = 0, end = 0;
+    // proto2 presence of `surface`: PopulateSentencePieceText sets it on every piece except the byte-fallback pieces before
+    // the last one of their character (src/sentencepiece_processor.cc:598-603); a bos / eos carries none (:1029-1048)
+    bool has_surface = true;
   };
   std::string text;
   std::vector<SentencePiece> pieces;
   float score = 0.f;       // set by NBestEncode only (src/sentencepiece_processor.cc:670)
+  bool has_score = false;
+  // The message's wire format (src/sentencepiece.proto:25-65), what SerializeAsString() of the reference's proto gives:
+  // text = 1, pieces = 2 {piece = 1, id = 2, surface = 3, begin = 4, end = 5}, score = 3 -- fields in number order.
+  std::string SerializeAsString() const {
+    auto varint = [](std::string *o, uint64_t v) { while (v >= 0x80) { o->push_back(static_cast<char>(v | 0x80)); v >>= 7; } o->push_back(static_cast<char>(v)); };
+    auto bytes_field = [&](std::string *o, int num, const std::string &b) { varint(o, static_cast<uint64_t>(num) << 3 | 2); varint(o, b.size()); o->append(b); };
+    auto uint_field = [&](std::string *o, int num, uint32_t v) { varint(o, static_cast<uint64_t>(num) << 3); varint(o, v); };
+    std::string out;
+    bytes_field(&out, 1, text);
+    for (const SentencePiece &p : pieces) {
+      std::string m;
+      bytes_field(&m, 1, p.piece);
+      uint_field(&m, 2, p.id);
+      if (p.has_surface) bytes_field(&m, 3, p.surface);
+      uint_field(&m, 4, p.begin);
+      uint_field(&m, 5, p.end);
+      bytes_field(&out, 2, m);
+    }
+    if (has_score) {
+      out.push_back(static_cast<char>(3 << 3 | 5));
+      char f[4];
+      memcpy(f, &score, 4);
+      out.append(f, 4);
+    }
+    return out;
+  }
 };
 // NBestSentencePieceText (src/sentencepiece.proto): the results of NBestEncode, best first
 struct NBestSentencePieceText {
@@ -110,16 +140,16 @@ class EncodedBatch {
 class SentencePieceProcessor {
  public:
   explicit SentencePieceProcessor(int device = 0) : device_(device) {}
-  ~SentencePieceProcessor() { spmx_destroy(h_); }
+  virtual ~SentencePieceProcessor() { spmx_destroy(h_); }
   SentencePieceProcessor(const SentencePieceProcessor &) = delete;
   SentencePieceProcessor &operator=(const SentencePieceProcessor &) = delete;
 
-  util::Status Load(std::string_view filename) {
+  virtual util::Status Load(std::string_view filename) {
     Reset();
     const std::string f(filename);
     return Created(spmx_create_from_file(f.c_str(), device_, &h_));
   }
-  util::Status LoadFromSerializedProto(std::string_view serialized) {
+  virtual util::Status LoadFromSerializedProto(std::string_view serialized) {
     Reset();
     return Created(spmx_create(serialized.data(), serialized.size(), device_, &h_));
   }
@@ -131,38 +161,73 @@ class SentencePieceProcessor {
   }
 
   // :270 SetDecodeExtraOptions (.cc:288-291): applied to the pieces of every later Decode before they become text (.cc:819)
-  util::Status SetDecodeExtraOptions(std::string_view extra_option) {
+  virtual util::Status SetDecodeExtraOptions(std::string_view extra_option) {
     if (!h_) return status();
     const std::string o(extra_option);
     return FromHandle(spmx_set_decode_extra_options(h_, o.c_str()));
   }
-  util::Status SetEncodeExtraOptions(std::string_view extra_option) {
+  virtual util::Status SetEncodeExtraOptions(std::string_view extra_option) {
     if (!h_) return status();
     const std::string o(extra_option);
     const int rc = spmx_set_encode_extra_options(h_, o.c_str());
     if (rc == 0) {
       unk_piece_option_ = false;
+      reverse_option_ = false;
       for (size_t p = 0; p <= o.size();) {
         const size_t q = o.find(':', p);
         const std::string f = o.substr(p, q == std::string::npos ? std::string::npos : q - p);
         if (f == "unk" || f == "unk_piece") unk_piece_option_ = true;
+        if (f == "reverse") reverse_option_ = !reverse_option_;
         if (q == std::string::npos) break;
         p = q + 1;
       }
     }
     return FromHandle(rc);
   }
-  util::Status SetVocabulary(const std::vector<std::string_view> &valid_vocab) {
+  virtual util::Status SetVocabulary(const std::vector<std::string_view> &valid_vocab) {
     if (!h_) return status();
     std::vector<const char *> p;
     std::vector<uint64_t> l;
     for (auto v : valid_vocab) { p.push_back(v.data()); l.push_back(v.size()); }
     return FromHandle(spmx_set_vocabulary(h_, p.data(), l.data(), p.size()));
   }
-  util::Status ResetVocabulary() { return h_ ? FromHandle(spmx_reset_vocabulary(h_)) : status(); }
+  virtual util::Status ResetVocabulary() { return h_ ? FromHandle(spmx_reset_vocabulary(h_)) : status(); }
+  // LoadVocabulary (sentencepiece_processor.h:288, .cc:341-362): "<token> TAB <freq>" lines; the tokens whose frequency
+  // reaches `threshold` (1 where the line has no second column) become the valid vocabulary
+  virtual util::Status LoadVocabulary(std::string_view filename, int threshold) {
+    const std::string fn(filename);
+    FILE *f = fopen(fn.c_str(), "rb");
+    if (!f) return util::Status(util::StatusCode::kNotFound, "\"" + fn + "\": No such file or directory");
+    std::string data;
+    char buf[65536];
+    for (size_t r; (r = fread(buf, 1, sizeof(buf), f)) > 0;) data.append(buf, r);
+    fclose(f);
+    std::vector<std::string> vocab;
+    for (size_t p = 0; p < data.size();) {
+      size_t q = data.find('\n', p);
+      if (q == std::string::npos) q = data.size();
+      std::string line = data.substr(p, q - p);
+      if (!line.empty() && line.back() == '\r') line.pop_back();
+      p = q + 1;
+      const size_t tab = line.find('\t');
+      const std::string tok = line.substr(0, tab);
+      if (tok.empty()) return util::Status(util::StatusCode::kInternal, "LoadVocabulary: an empty token");   // CHECK_OR_RETURN(!v[0].empty())
+      long freq = 1;
+      if (tab != std::string::npos) {
+        const size_t tab2 = line.find('\t', tab + 1);
+        const std::string num = line.substr(tab + 1, tab2 == std::string::npos ? std::string::npos : tab2 - tab - 1);
+        char *end = nullptr;
+        freq = strtol(num.c_str(), &end, 10);
+        if (num.empty() || !end || *end != 0) return util::Status(util::StatusCode::kInternal, "Could not parse the frequency");
+      }
+      if (freq >= threshold) vocab.push_back(tok);
+    }
+    std::vector<std::string_view> v(vocab.begin(), vocab.end());
+    return SetVocabulary(v);
+  }
 
   // ---- encode ----
-  util::Status Encode(std::string_view input, std::vector<int> *ids) const {
+  virtual util::Status Encode(std::string_view input, std::vector<int> *ids) const {
     if (!h_) return status();
     if (!ids) return util::Status(util::StatusCode::kInternal, "output container is null");
     ids->clear();
@@ -180,7 +245,7 @@ class SentencePieceProcessor {
     spmx_free(st);
     return code == 0 ? util::Status() : util::Status(static_cast<util::StatusCode>(code), spmx_status_message(code));
   }
-  std::vector<int> EncodeAsIds(std::string_view input) const {   // errors are swallowed, as in the reference (:427-436)
+  virtual std::vector<int> EncodeAsIds(std::string_view input) const {   // errors are swallowed, as in the reference (:427-436)
     std::vector<int> ids;
     (void)Encode(input, &ids);
     return ids;
@@ -301,7 +366,7 @@ class SentencePieceProcessor {
   // The device returns ids, input spans and normalized-text spans (spmx_encode_batch_spans) and the normalized text
   // (spmx_normalize_batch); a piece is its normalized text, the piece name for a byte-fallback piece and a bos / eos,
   // or unk_piece for an unknown token under the `unk_piece` extra option (sentencepiece_processor.cc:547-636, :1019-1064).
-  util::Status Encode(std::string_view input, SentencePieceText *spt) const {
+  virtual util::Status Encode(std::string_view input, SentencePieceText *spt) const {
     if (!h_) return status();
     if (!spt) return util::Status(util::StatusCode::kInternal, "output proto is null");   // CHECK_OR_RETURN_STATUS_PROTO
     spt->text.clear();
@@ -326,7 +391,7 @@ class SentencePieceProcessor {
     spmx_free(ids); spmx_free(io); spmx_free(b); spmx_free(e); spmx_free(nb); spmx_free(ne); spmx_free(norm); spmx_free(no);
     return FromHandle(rc);
   }
-  util::Status Encode(std::string_view input, std::vector<std::string> *pieces) const {
+  virtual util::Status Encode(std::string_view input, std::vector<std::string> *pieces) const {
     if (!h_) return status();
     if (!pieces) return util::Status(util::StatusCode::kInternal, "output container is null");
     pieces->clear();
@@ -336,14 +401,14 @@ class SentencePieceProcessor {
     for (auto &p : spt.pieces) pieces->push_back(std::move(p.piece));
     return util::Status();
   }
-  std::vector<std::string> EncodeAsPieces(std::string_view input) const {   // errors are swallowed, as in the reference
+  virtual std::vector<std::string> EncodeAsPieces(std::string_view input) const {   // errors are swallowed, as in the reference
     std::vector<std::string> pieces;
     (void)Encode(input, &pieces);
     return pieces;
   }
 
   // ---- n-best (sentencepiece_processor.h:323-324; unigram models) ----
-  util::Status NBestEncode(std::string_view input, int nbest_size, std::vector<std::vector<int>> *ids) const {
+  virtual util::Status NBestEncode(std::string_view input, int nbest_size, std::vector<std::vector<int>> *ids) const {
     if (!h_) return status();
     if (!ids) return util::Status(util::StatusCode::kInternal, "output container is null");
     ids->clear();
@@ -364,7 +429,7 @@ class SentencePieceProcessor {
   }
   // NBestEncode(input, nbest_size, NBestSentencePieceText *) (sentencepiece_processor.h:323-324, .cc:653-676): every
   // result with its score and the pieces / surfaces / byte ranges PopulateSentencePieceText gives it
-  util::Status NBestEncode(std::string_view input, int nbest_size, NBestSentencePieceText *nbest_spt) const {
+  virtual util::Status NBestEncode(std::string_view input, int nbest_size, NBestSentencePieceText *nbest_spt) const {
     if (!h_) return status();
     if (!nbest_spt) return util::Status(util::StatusCode::kInternal, "output proto is null");
     nbest_spt->nbests.clear();
@@ -381,6 +446,7 @@ class SentencePieceProcessor {
       for (uint64_t r = ro[0]; r < ro[1]; ++r) {
         nbest_spt->nbests.emplace_back();
         nbest_spt->nbests.back().score = sc[r];
+        nbest_spt->nbests.back().has_score = true;
         FillPieces(input, norm, ids, b, e, nb, ne, io[r], io[r + 1], &nbest_spt->nbests.back());
       }
     }
@@ -388,7 +454,7 @@ class SentencePieceProcessor {
     spmx_free(norm); spmx_free(no);
     return FromHandle(rc);
   }
-  util::Status NBestEncode(std::string_view input, int nbest_size, std::vector<std::vector<std::string>> *pieces) const {
+  virtual util::Status NBestEncode(std::string_view input, int nbest_size, std::vector<std::vector<std::string>> *pieces) const {
     if (!h_) return status();
     if (!pieces) return util::Status(util::StatusCode::kInternal, "output container is null");
     pieces->clear();
@@ -410,7 +476,7 @@ class SentencePieceProcessor {
   // ---- sampling (sentencepiece_processor.h:346-353, .cc:678-720): lattice sampling / n-best sampling (unigram),
   // BPE-dropout (BPE).  The draws are keyed by (seed, sentence); each call without a seed of its own takes the next
   // value of a per-process counter, so repeated calls draw afresh as the reference's thread-local generator does ----
-  util::Status SampleEncode(std::string_view input, int nbest_size, float alpha, std::vector<int> *ids) const {
+  virtual util::Status SampleEncode(std::string_view input, int nbest_size, float alpha, std::vector<int> *ids) const {
     static std::atomic<uint64_t> calls{std::random_device{}()};   // (the reference seeds from std::random_device, src/util.cc:202-204)
     return SampleEncode(input, nbest_size, alpha, ++calls, ids);
   }
@@ -432,7 +498,7 @@ class SentencePieceProcessor {
     return ids;
   }
   // SampleEncode(input, nbest_size, alpha, SentencePieceText *) (sentencepiece_processor.h:346-348, .cc:678-720)
-  util::Status SampleEncode(std::string_view input, int nbest_size, float alpha, SentencePieceText *spt) const {
+  virtual util::Status SampleEncode(std::string_view input, int nbest_size, float alpha, SentencePieceText *spt) const {
     static std::atomic<uint64_t> calls{std::random_device{}()};
     return SampleEncode(input, nbest_size, alpha, ++calls, spt);
   }
@@ -453,7 +519,7 @@ class SentencePieceProcessor {
     spmx_free(ids); spmx_free(io); spmx_free(b); spmx_free(e); spmx_free(nb); spmx_free(ne); spmx_free(norm); spmx_free(no);
     return FromHandle(rc);
   }
-  util::Status SampleEncode(std::string_view input, int nbest_size, float alpha, std::vector<std::string> *pieces) const {
+  virtual util::Status SampleEncode(std::string_view input, int nbest_size, float alpha, std::vector<std::string> *pieces) const {
     if (!h_) return status();
     if (!pieces) return util::Status(util::StatusCode::kInternal, "output container is null");
     pieces->clear();
@@ -496,7 +562,7 @@ class SentencePieceProcessor {
   }
 
   // ---- Normalize (sentencepiece_processor.h:622-631) ----
-  util::Status Normalize(std::string_view input, std::string *normalized, std::vector<size_t> *norm_to_orig) const {
+  virtual util::Status Normalize(std::string_view input, std::string *normalized, std::vector<size_t> *norm_to_orig) const {
     if (!h_) return status();
     if (!normalized || !norm_to_orig) return util::Status(util::StatusCode::kInternal, "output container is null");
     normalized->clear();
@@ -513,7 +579,7 @@ class SentencePieceProcessor {
     spmx_free(norm); spmx_free(no); spmx_free(a);
     return FromHandle(rc);
   }
-  util::Status Normalize(std::string_view input, std::string *normalized) const {
+  virtual util::Status Normalize(std::string_view input, std::string *normalized) const {
     std::vector<size_t> a;
     return Normalize(input, normalized, &a);
   }
@@ -524,7 +590,7 @@ class SentencePieceProcessor {
   }
 
   // ---- decode (sentencepiece_processor.h:311-312, :515-517) ----
-  util::Status Decode(const std::vector<int> &ids, std::string *detokenized) const {
+  virtual util::Status Decode(const std::vector<int> &ids, std::string *detokenized) const {
     if (!h_) return status();
     if (!detokenized) return util::Status(util::StatusCode::kInternal, "output container is null");
     detokenized->clear();
@@ -545,6 +611,55 @@ class SentencePieceProcessor {
     (void)Decode(ids, &out);
     return out;
   }
+  // Decode from pieces (sentencepiece_processor.h:303-309, .cc:761-769): every piece by PieceToId; a piece that is not in
+  // the vocabulary is copied through as it is (.cc:784-790) -- it travels to the decode kernels as a literal beside the ids
+  // (spmx_decode_batch_pieces) -- unless a decode extra option `unk` turns it into the unknown piece first (.cc:1050-1058)
+  virtual util::Status Decode(const std::vector<std::string_view> &pieces, std::string *detokenized) const {
+    if (!h_) return status();
+    if (!detokenized) return util::Status(util::StatusCode::kInternal, "output container is null");
+    detokenized->clear();
+    const int unk = unk_id();
+    const std::string unk_name = IdToPiece(unk);
+    const bool to_unk = spmx_decode_unk_option(h_) != 0;
+    std::vector<int32_t> ids;
+    std::string lit;
+    std::vector<uint64_t> lo{0};
+    ids.reserve(pieces.size());
+    for (std::string_view p : pieces) {
+      int32_t t = spmx_piece_to_id(h_, p.data(), p.size());
+      if (t == unk && p != unk_name && !to_unk) {
+        lit.append(p.data(), p.size());
+        lo.push_back(lit.size());
+        t = -static_cast<int32_t>(lo.size() - 1);
+      }
+      ids.push_back(t);
+    }
+    char *text = nullptr;
+    uint64_t *offs = nullptr;
+    const uint64_t io[2] = {0, ids.size()};
+    const int32_t none = 0;
+    const int rc = spmx_decode_batch_pieces(h_, ids.empty() ? &none : ids.data(), io, 1, lit.data(), lo.data(), lo.size() - 1, &text, &offs);
+    if (rc != 0) return FromHandle(rc);
+    detokenized->assign(text, text + offs[1]);
+    spmx_free(text);
+    spmx_free(offs);
+    return util::Status();
+  }
+  virtual util::Status Decode(const std::vector<std::string> &pieces, std::string *detokenized) const {
+    std::vector<std::string_view> v(pieces.begin(), pieces.end());
+    return Decode(v, detokenized);
+  }
+  std::string DecodePieces(const std::vector<std::string> &pieces) const {   // sentencepiece_processor.h:510-513; errors are swallowed
+    std::string out;
+    (void)Decode(pieces, &out);
+    return out;
+  }
+  // EncodeAsSerializedProto (sentencepiece_processor.h:528-531): the serialized SentencePieceText of Encode(input, &spt)
+  virtual std::string EncodeAsSerializedProto(std::string_view input) const {
+    SentencePieceText spt;
+    if (!Encode(input, &spt).ok()) return std::string();
+    return spt.SerializeAsString();
+  }
   // Flat form: CSR ids in, packed text + offsets out.
   util::Status DecodeBatchFlat(const int32_t *ids, const uint64_t *id_offsets, uint64_t n, std::string *text,
                                std::vector<uint64_t> *text_offsets) const {
@@ -564,9 +679,9 @@ class SentencePieceProcessor {
   }
 
   // ---- vocabulary ----
-  int GetPieceSize() const { return h_ ? spmx_piece_size(h_) : 0; }
-  int PieceToId(std::string_view piece) const { return h_ ? spmx_piece_to_id(h_, piece.data(), piece.size()) : 0; }
-  std::string IdToPiece(int id) const {
+  virtual int GetPieceSize() const { return h_ ? spmx_piece_size(h_) : 0; }
+  virtual int PieceToId(std::string_view piece) const { return h_ ? spmx_piece_to_id(h_, piece.data(), piece.size()) : 0; }
+  virtual std::string IdToPiece(int id) const {
     static const std::string kEmpty;
     if (!h_) return kEmpty;
     const int64_t n = spmx_id_to_piece(h_, id, nullptr, 0);
@@ -575,10 +690,24 @@ class SentencePieceProcessor {
     spmx_id_to_piece(h_, id, s.data(), s.size());
     return s;
   }
-  bool IsUnknown(int id) const { return h_ && spmx_piece_type(h_, id) == 2; }   // sentencepiece_processor.h:653-662
-  bool IsControl(int id) const { return h_ && spmx_piece_type(h_, id) == 3; }
-  bool IsUnused(int id) const { return h_ && spmx_piece_type(h_, id) == 5; }
-  bool IsByte(int id) const { return h_ && spmx_piece_type(h_, id) == 6; }
+  // GetScore (sentencepiece_processor.h:650): the score the ModelProto holds; 0 for an id out of range, as the reference's
+  // CHECK_STATUS_OR_RETURN_DEFAULT does for a processor without a model
+  virtual float GetScore(int id) const {
+    float s = 0.f;
+    if (!h_ || spmx_piece_score(h_, id, &s) != 0) return 0.f;
+    return s;
+  }
+  // serialized_model_proto (sentencepiece_processor.h:694): the bytes the model was loaded from
+  std::string serialized_model_proto() const {
+    const char *p = nullptr;
+    uint64_t n = 0;
+    if (!h_ || spmx_serialized_model(h_, &p, &n) != 0) return std::string();
+    return std::string(p, n);
+  }
+  virtual bool IsUnknown(int id) const { return h_ && spmx_piece_type(h_, id) == 2; }   // sentencepiece_processor.h:653-662
+  virtual bool IsControl(int id) const { return h_ && spmx_piece_type(h_, id) == 3; }
+  virtual bool IsUnused(int id) const { return h_ && spmx_piece_type(h_, id) == 5; }
+  virtual bool IsByte(int id) const { return h_ && spmx_piece_type(h_, id) == 6; }
   // trainer_spec.unk_piece: what the `unk_piece` extra option writes for unknown tokens
   std::string UnkPiece() const {
     if (!h_) return std::string();
@@ -587,10 +716,10 @@ class SentencePieceProcessor {
     if (n > 0) spmx_unk_piece(h_, s.data(), s.size());
     return s;
   }
-  int unk_id() const { return h_ ? spmx_unk_id(h_) : 0; }
-  int bos_id() const { return h_ ? spmx_bos_id(h_) : 0; }
-  int eos_id() const { return h_ ? spmx_eos_id(h_) : 0; }
-  int pad_id() const { return h_ ? spmx_pad_id(h_) : 0; }
+  virtual int unk_id() const { return h_ ? spmx_unk_id(h_) : 0; }
+  virtual int bos_id() const { return h_ ? spmx_bos_id(h_) : 0; }
+  virtual int eos_id() const { return h_ ? spmx_eos_id(h_) : 0; }
+  virtual int pad_id() const { return h_ ? spmx_pad_id(h_) : 0; }
 
   spmx_handle *handle() const { return h_; }
 
@@ -624,11 +753,20 @@ class SentencePieceProcessor {
       if (type == 2 && unk_piece_option_) p.piece = UnkPiece();
       else if (type == 6 || type == 3) p.piece = IdToPiece(ids[k]);
       else p.piece.assign(norm + nb[k], ne[k] - nb[k]);
+      // presence of `surface`: not on a bos / eos; of the byte pieces of one unknown character (consecutive, same
+      // normalized begin) only on the one that is last in TEXT order
+      if (type == 3) p.has_surface = false;
+      else if (type == 6) {
+        const bool has_next = reverse_option_ ? k > lo : k + 1 < hi;
+        const uint64_t nx = reverse_option_ ? k - 1 : k + 1;
+        if (has_next && spmx_piece_type(h_, ids[nx]) == 6 && nb[nx] == nb[k]) p.has_surface = false;
+      }
       spt->pieces.push_back(std::move(p));
     }
   }
   int device_ = 0;
   bool unk_piece_option_ = false;   // the `unk` / `unk_piece` extra option: piece strings only (:1050-1058)
+  bool reverse_option_ = false;     // an odd number of `reverse` options: the pieces come out last first
   spmx_handle *h_ = nullptr;
 };
 

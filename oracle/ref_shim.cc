@@ -390,6 +390,27 @@ int64_t spmref_encode_unicode_spans_batch(void *handle, const char *text, const 
   return static_cast<int64_t>(total);
 }
 
+// Decode(const std::vector<std::string>& pieces, std::string*) (sentencepiece_processor.h:303-305): the pieces of ONE
+// sentence packed as pieces[offsets[i], offsets[i + 1]).  Returns the text's length, -1 on a Status error,
+// -(needed) - 2 if cap is too small.
+int64_t spmref_decode_pieces(void *handle, const char *pieces, const uint64_t *offsets, uint64_t n, char *out, uint64_t cap) {
+  auto *h = static_cast<RefHandle *>(handle);
+  std::vector<std::string> v;
+  v.reserve(n);
+  for (uint64_t i = 0; i < n; ++i) v.emplace_back(pieces + offsets[i], offsets[i + 1] - offsets[i]);
+  std::string text;
+  const auto st = h->sp.Decode(v, &text);
+  if (!st.ok()) {
+    h->last_error = st.ToString();
+    return -1;
+  }
+  if (text.size() > cap) return -static_cast<int64_t>(text.size()) - 2;
+  memcpy(out, text.data(), text.size());
+  return static_cast<int64_t>(text.size());
+}
+// GetScore(id) (sentencepiece_processor.h:650)
+float spmref_get_score(void *handle, int id) { return static_cast<RefHandle *>(handle)->sp.GetScore(id); }
+
 int spmref_piece_size(void *handle) {
   return static_cast<RefHandle *>(handle)->sp.GetPieceSize();
 }

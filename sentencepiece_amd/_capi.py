@@ -80,6 +80,11 @@ SYMBOLS = [
      [C.c_void_p, C.c_int, C.c_int, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p, _U64, C.c_void_p,
       C.c_void_p, C.c_void_p, C.c_void_p]),
     ("spmx_gather_scratch_words", _U64, [C.c_int]),
+    ("spmx_decode_batch_pieces", C.c_int,
+     [_H, C.c_void_p, C.c_void_p, _U64, C.c_void_p, C.c_void_p, _U64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    ("spmx_decode_unk_option", C.c_int, [_H]),
+    ("spmx_piece_score", C.c_int, [_H, C.c_int, C.POINTER(C.c_float)]),
+    ("spmx_serialized_model", C.c_int, [_H, C.POINTER(C.c_char_p), C.POINTER(_U64)]),
     ("spmx_rccl_unique_id", C.c_int, [C.c_void_p]),
     ("spmx_rccl_comm_init", C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p]),
     ("spmx_rccl_comm_destroy", C.c_int, [C.c_void_p]),

@@ -225,6 +225,11 @@ struct Workspace {
   DevBuf<uint8_t> d_text, d_dn_text;       // d_dn_*: the decoded text before the denormalizer
   DevBuf<uint64_t> d_offs, d_id_offs, d_dn_offs;
   DevBuf<int32_t> d_ids;
+  DevBuf<uint8_t> d_lit_bytes;           // Decode(pieces): the pieces outside the vocabulary (kernels_decode.h DecodeArgs::lit_*)
+  DevBuf<uint32_t> d_lit_offs;
+  const uint8_t *lit_bytes = nullptr;    // set for the duration of one spmx_decode_batch_pieces call
+  const uint32_t *lit_offs = nullptr;
+  uint32_t n_lit = 0;
   PinBuf<uint8_t> h_text;       // pinned staging of the pipelined host form
   PinBuf<uint64_t> h_offs, h_id_offs;
   float bpe_dropout = 0.f;      // set around a call by spmx_sample_encode_batch: BPE-dropout through the long form
@@ -261,6 +266,7 @@ struct spmx_handle {
   ModelData model;
   HostTables tables;
   std::string extra_options;
+  std::string serialized;        // the ModelProto as it was loaded (serialized_model_proto, src/sentencepiece_processor.h:694)
   int device = 0;
   int n_cu = 256;
   // device copies of the tables
@@ -302,6 +308,7 @@ struct spmx_handle {
   // SetDecodeExtraOptions: the net effect of the options on a sentence's ids (kernels_decode.h DecodeArgs::x_*)
   int32_t dx_npre = 0, dx_nsuf = 0, dx_pre[kMaxExtra] = {0}, dx_suf[kMaxExtra] = {0};
   bool dx_reverse = false;
+  bool dx_unk = false;           // ... holds `unk` / `unk_piece`: Decode(pieces) turns a piece outside the vocabulary into the unknown piece (.cc:1050-1058)
   uint32_t compact_staged = 2048;  // ids a CompactKernel wave's LDS image holds (SPMX_COMPACT_STAGED=<ids>; 0: the search form for every block; results identical)
   bool no_direct = false;        // SPMX_NO_DIRECT=1: the word rounds take classify's lists even where they could do without
   int fork_cus = 0;              // SPMX_FORK_CUS: the general launch beside the word rounds takes at most this many CUs (0: every CU)
@@ -1456,6 +1463,7 @@ int DecodeRaw(spmx_handle *h, Workspace *ws, const int32_t *d_ids, const uint64_
   a.status = &ws->d_ctrl->status; a.bad_key = &ws->d_ctrl->bad_key;
   {
     std::lock_guard<std::mutex> l(h->mu);
+    a.lit_bytes = ws->lit_bytes; a.lit_offs = ws->lit_offs; a.n_lit = ws->n_lit;
     a.x_npre = h->dx_npre; a.x_nsuf = h->dx_nsuf; a.x_reverse = h->dx_reverse ? 1 : 0;
     for (int i = 0; i < kMaxExtra; ++i) { a.x_pre[i] = h->dx_pre[i]; a.x_suf[i] = h->dx_suf[i]; }
   }
@@ -1557,6 +1565,7 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (device < 0 || device >= n_dev) return Fail(nullptr, kInvalidArgument, "device ordinal out of range");
     std::unique_ptr<spmx_handle, void (*)(spmx_handle *)> h(new spmx_handle, DestroyHandle);
     h->device = device;
+    h->serialized.assign(static_cast<const char *>(model_bytes), n_bytes);
     Status st = ParseModelProto(model_bytes, n_bytes, &h->model);
     if (st.ok()) st = InitializeModel(&h->model);
     if (st.ok()) st = CompileTables(h->model, &h->tables);
@@ -1695,6 +1704,13 @@ int spmx_set_decode_extra_options(spmx_handle *h, const char *options) {
     h->dx_npre = scratch.scalars.n_prefix; h->dx_nsuf = scratch.scalars.n_suffix;
     for (int i = 0; i < kMaxExtra; ++i) { h->dx_pre[i] = scratch.scalars.prefix_ids[i]; h->dx_suf[i] = scratch.scalars.suffix_ids[i]; }
     h->dx_reverse = (scratch.scalars.flags & kNfReverse) != 0;
+    h->dx_unk = false;
+    for (std::string rest = options ? options : ""; !rest.empty();) {
+      const size_t q = rest.find(':');
+      const std::string o = rest.substr(0, q);
+      if (o == "unk" || o == "unk_piece") h->dx_unk = true;
+      rest = q == std::string::npos ? std::string() : rest.substr(q + 1);
+    }
     return kOk;
   });
 }
@@ -2676,8 +2692,34 @@ int spmx_decode_batch_device(spmx_handle *h, const int32_t *d_ids, const uint64_
   });
 }
 
+namespace {
+int DecodeBatchHost(spmx_handle *h, const int32_t *ids, const uint64_t *id_offsets, uint64_t n, const char *lit_bytes,
+                    const uint64_t *lit_offsets, uint64_t n_lit, char **text, uint64_t **text_offsets);
+}
 int spmx_decode_batch(spmx_handle *h, const int32_t *ids, const uint64_t *id_offsets, uint64_t n, char **text,
                       uint64_t **text_offsets) {
+  return DecodeBatchHost(h, ids, id_offsets, n, nullptr, nullptr, 0, text, text_offsets);
+}
+int spmx_decode_batch_pieces(spmx_handle *h, const int32_t *ids, const uint64_t *id_offsets, uint64_t n, const char *lit_bytes,
+                             const uint64_t *lit_offsets, uint64_t n_lit, char **text, uint64_t **text_offsets) {
+  if (h && n_lit && (!lit_offsets || (lit_offsets[n_lit] && !lit_bytes))) return Fail(h, kInvalidArgument, "null literal pieces");
+  return DecodeBatchHost(h, ids, id_offsets, n, lit_bytes, lit_offsets, n_lit, text, text_offsets);
+}
+int spmx_piece_score(const spmx_handle *h, int id, float *score) {
+  if (!h || !score || id < 0 || static_cast<size_t>(id) >= h->model.pieces.size()) return kOutOfRange;
+  *score = h->model.pieces[static_cast<size_t>(id)].score;
+  return kOk;
+}
+int spmx_decode_unk_option(const spmx_handle *h) { return h && h->dx_unk ? 1 : 0; }
+int spmx_serialized_model(const spmx_handle *h, const char **data, uint64_t *n_bytes) {
+  if (!h || !data || !n_bytes) return kInvalidArgument;
+  *data = h->serialized.data();
+  *n_bytes = h->serialized.size();
+  return kOk;
+}
+namespace {
+int DecodeBatchHost(spmx_handle *h, const int32_t *ids, const uint64_t *id_offsets, uint64_t n, const char *lit_bytes,
+                    const uint64_t *lit_offsets, uint64_t n_lit, char **text, uint64_t **text_offsets) {
   if (!h) return kInvalidArgument;
   if (!text || !text_offsets) return Fail(h, kInternal, "output container is null");
   *text = nullptr; *text_offsets = nullptr;
@@ -2697,6 +2739,21 @@ int spmx_decode_batch(spmx_handle *h, const int32_t *ids, const uint64_t *id_off
     if (e == hipSuccess) e = ws->d_id_offs.Reserve(n + 1);
     if (e == hipSuccess && n_ids) e = hipMemcpyAsync(ws->d_ids.p, ids + base, n_ids * sizeof(int32_t), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(ws->d_offs.p, id_offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st);
+    // the pieces outside the vocabulary (Decode(pieces)): their bytes and 32-bit offsets, for this call only
+    struct LitGuard { Workspace *w; ~LitGuard() { w->lit_bytes = nullptr; w->lit_offs = nullptr; w->n_lit = 0; } } lit_guard{ws};
+    if (e == hipSuccess && n_lit) {
+      if (n_lit >= (1ull << 31) || lit_offsets[n_lit] >= (1ull << 32)) { free(ho); return Fail(h, kInvalidArgument, "too many pieces outside the vocabulary in one batch"); }
+      std::vector<uint32_t> lo(n_lit + 1);
+      for (uint64_t k = 0; k <= n_lit; ++k) lo[k] = static_cast<uint32_t>(lit_offsets[k]);
+      for (uint64_t k = 0; k < n_lit; ++k)
+        if (lo[k + 1] < lo[k] || lo[k + 1] - lo[k] > 0xFFFFu) { free(ho); return Fail(h, kInvalidArgument, "a piece outside the vocabulary is longer than 65535 bytes"); }
+      e = ws->d_lit_offs.Reserve(n_lit + 1);
+      if (e == hipSuccess) e = ws->d_lit_bytes.Reserve(lo[n_lit] + 16);
+      if (e == hipSuccess) e = hipMemcpyAsync(ws->d_lit_offs.p, lo.data(), (n_lit + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+      if (e == hipSuccess && lo[n_lit]) e = hipMemcpyAsync(ws->d_lit_bytes.p, lit_bytes, lo[n_lit], hipMemcpyHostToDevice, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);       // (lo is a local)
+      ws->lit_bytes = ws->d_lit_bytes.p; ws->lit_offs = ws->d_lit_offs.p; ws->n_lit = static_cast<uint32_t>(n_lit);
+    }
     if (e != hipSuccess) { free(ho); return FailHip(h, e, "staging the ids"); }
     const int32_t *d_ids = ws->d_ids.p - base;     // the kernels address ids + id_offsets[i]
     uint64_t cap = n_ids * 6 + 64, total = 0;
@@ -2719,6 +2776,7 @@ int spmx_decode_batch(spmx_handle *h, const int32_t *ids, const uint64_t *id_off
     return kOk;
   });
 }
+}  // namespace
 
 int spmx_decode(spmx_handle *h, const int32_t *ids, uint64_t n_ids, char *out, uint64_t cap, uint64_t *len) {
   if (!h) return kInvalidArgument;

@@ -50,6 +50,12 @@ struct DecodeArgs {
   // reversed (tables.cc CompileExtraOptions; "unk" only rewrites piece strings of ids that decode to unk_surface anyway)
   int32_t x_npre, x_nsuf, x_reverse;
   int32_t x_pre[kMaxExtra], x_suf[kMaxExtra];
+  // Decode(pieces) (src/sentencepiece_processor.cc:761-769, :784-790): a piece that is not in the vocabulary has the id of
+  // the unknown piece and another string -- it goes through as it is.  Such a piece travels as the id -(k + 1), its bytes
+  // lit_bytes[lit_offs[k], lit_offs[k + 1]) (spmx_decode_batch_pieces; null: every negative id is an error)
+  const uint8_t *lit_bytes;
+  const uint32_t *lit_offs;
+  uint32_t n_lit;
 };
 
 template <bool WRITE>
@@ -73,14 +79,20 @@ SPMX_DEVICE void decode_block(const DecodeArgs &a) {
       const int i = base + lane;
       const bool valid = i < n_pieces;
       int32_t id = 0;
-      uint32_t info = kDkEmpty, off = 0, full = 0;
+      uint32_t info = kDkEmpty, off = 0, full = 0, lit = 0;
       if (valid) {
         if (i < a.x_npre) id = a.x_pre[i];
         else if (i < a.x_npre + n_body) {
           const int k = i - a.x_npre;
           id = a.ids[beg + static_cast<uint64_t>(a.x_reverse ? n_body - 1 - k : k)];
         } else id = a.x_suf[i - a.x_npre - n_body];
-        if (id < 0 || static_cast<uint32_t>(id) >= d.n_pieces) {
+        if (id < 0 && a.lit_offs != nullptr && static_cast<uint32_t>(-(id + 1)) < a.n_lit) {
+          const uint32_t k = static_cast<uint32_t>(-(id + 1));
+          off = a.lit_offs[k];
+          full = a.lit_offs[k + 1] - off;
+          info = kDkLiteral | (full << kDiLenShift);
+          lit = 1u;
+        } else if (id < 0 || static_cast<uint32_t>(id) >= d.n_pieces) {
           bad = true;
           wv::atomic_min(a.bad_key, (static_cast<unsigned long long>(s) << 32) | static_cast<uint32_t>(id));
         } else {
@@ -163,14 +175,14 @@ SPMX_DEVICE void decode_block(const DecodeArgs &a) {
             const uint32_t v = wv::shfl(rel, lo + st);
             if (v <= j) lo += st;
           }
-          const uint32_t r0 = wv::shfl(rel, lo), s0 = wv::shfl(src, lo), inf = wv::shfl(info, lo), ok0 = wv::shfl(okc, lo);
+          const uint32_t r0 = wv::shfl(rel, lo), s0 = wv::shfl(src, lo), inf = wv::shfl(info, lo), ok0 = wv::shfl(okc, lo), lit0 = wv::shfl(lit, lo);
           const uint32_t k = j - r0;
           // a character of byte pieces: byte k of the character is the value of piece lo + k
           const uint32_t pv = wv::shfl(bv, (lo + static_cast<int>(k & 3u)) & 63);
           if (j < static_cast<uint32_t>(total)) {
             uint32_t byte;
             if ((inf & kDkMask) == kDkByte) byte = ok0 ? pv : (k == 0 ? 0xEFu : (k == 1 ? 0xBFu : 0xBDu));   // invalid -> U+FFFD
-            else byte = d.dec_bytes[s0 + k];
+            else byte = lit0 ? a.lit_bytes[s0 + k] : d.dec_bytes[s0 + k];
             dst[out + j] = static_cast<uint8_t>(byte);
           }
         }

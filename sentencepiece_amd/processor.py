@@ -899,19 +899,45 @@ class SentencePieceProcessor:
     tokenize, detokenize = Tokenize, Detokenize
 
     def DecodePieces(self, input, out_type=str, **kwargs):
-        """``DecodePieces`` (:871-872): pieces -> text.  Every piece must be in the vocabulary (the decode kernels take
-        ids; the reference copies a piece that is not in the vocabulary through as text, which ids cannot express)."""
+        """``DecodePieces`` (:871-872, ``_DecodePiecesBatch`` sentencepiece.i:547): pieces -> text.  A piece that is not in
+        the vocabulary is copied through as text (src/sentencepiece_processor.cc:784-790): it travels to the decode
+        kernels as a literal beside the ids (``spmx_decode_batch_pieces``); under a decode extra option ``unk`` the
+        reference rewrites it to the unknown piece first (.cc:1050-1058)."""
+        self._need()
         single = not input or isinstance(input[0], (str, bytes))
         items = [input] if single else input
         unk = self.unk_id()
-        rows = []
-        for row in items:
-            ids = [self.PieceToId(p) for p in row]
-            for p, t in zip(row, ids):
-                if t == unk and (p.decode("utf-8", "replace") if isinstance(p, bytes) else p) != self.IdToPiece(unk):
-                    raise NotImplementedError("DecodePieces: %r is not a piece of the model" % (p,))
-            rows.append(ids)
-        out = self.Decode(rows, out_type=out_type, **kwargs)
+        unk_name = self.IdToPiece(unk).encode("utf-8") if unk >= 0 else None
+        to_unk = bool(self._lib.spmx_decode_unk_option(self._h))
+        ids, lits = [], []
+        offs = np.zeros(len(items) + 1, dtype=np.uint64)
+        for r, row in enumerate(items):
+            for p in row:
+                pb = p if isinstance(p, bytes) else p.encode("utf-8", "surrogateescape")
+                t = self._lib.spmx_piece_to_id(self._h, pb, len(pb))
+                if t == unk and pb != unk_name and not to_unk:
+                    lits.append(pb)
+                    t = -len(lits)
+                ids.append(t)
+            offs[r + 1] = len(ids)
+        ids = np.asarray(ids, dtype=np.int32)
+        lo = np.zeros(len(lits) + 1, dtype=np.uint64)
+        if lits:
+            np.cumsum([len(x) for x in lits], out=lo[1:])
+        blob = b"".join(lits)
+        p_text, p_off = C.c_void_p(), C.c_void_p()
+        self._check(self._lib.spmx_decode_batch_pieces(self._h, ids.ctypes.data if len(ids) else None, offs.ctypes.data, len(items),
+                                                       blob if blob else None, lo.ctypes.data, len(lits), C.byref(p_text), C.byref(p_off)))
+        try:
+            to = np.ctypeslib.as_array(C.cast(p_off, C.POINTER(C.c_uint64)), shape=(len(items) + 1,)).astype(np.int64)
+            total = int(to[-1])
+            b = bytes(np.ctypeslib.as_array(C.cast(p_text, C.POINTER(C.c_uint8)), shape=(total,))) if total else b""
+        finally:
+            self._lib.spmx_free(p_text)
+            self._lib.spmx_free(p_off)
+        out = [b[to[i]:to[i + 1]] for i in range(len(items))]
+        if out_type is str:
+            out = [x.decode("utf-8", errors="replace") for x in out]
         return out[0] if single else out
 
     decode_pieces = DecodePieces

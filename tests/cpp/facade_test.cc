@@ -49,6 +49,52 @@ int main(int argc, char **argv) {
     }
     return 0;
   }
+  if (argc > 4 && std::string(argv[4]) == "--extras") {
+    // The facade's newer methods, driven through a BASE-CLASS POINTER to a subclass that overrides nothing (they are virtual,
+    // as the reference's are).  One line each:
+    //   D <hex of Decode(pieces) of the piece list of line i, damaged by pieces outside the vocabulary>   (per input line)
+    //   P <hex of EncodeAsSerializedProto(line)>                                                          (per input line)
+    //   S <GetScore(id)> for ids 0 .. 63 as %.9g
+    //   M <size of serialized_model_proto()> <its FNV-1a>
+    //   V <ids of line 0 after LoadVocabulary(argv[5], 2)> | <ids after ResetVocabulary>
+    struct Sub : sentencepiece::SentencePieceProcessor {};
+    auto hex = [](const std::string &x) { static const char *d = "0123456789abcdef"; std::string o; for (unsigned char c : x) { o += d[c >> 4]; o += d[c & 15]; } return o.empty() ? std::string("-") : o; };
+    Sub sub;
+    sentencepiece::SentencePieceProcessor *p = &sub;
+    if (!p->Load(argv[1]).ok() || !p->SetEncodeExtraOptions(argv[3]).ok()) { fprintf(stderr, "Load through the base pointer\n"); return 1; }
+    const char *decode_opts = argc > 6 ? argv[6] : "";
+    if (!p->SetDecodeExtraOptions(decode_opts).ok()) { fprintf(stderr, "SetDecodeExtraOptions\n"); return 1; }
+    size_t li = 0;
+    for (const std::string &line : lines) {
+      std::vector<std::string> pcs = p->EncodeAsPieces(line);
+      if (li % 3 == 0) pcs.insert(pcs.begin() + static_cast<long>(pcs.size() / 2), "zzqq-not-a-piece");
+      if (li % 3 == 1) { pcs.push_back("\xE2\x96\x81outside"); pcs.insert(pcs.begin(), ""); }
+      if (li % 5 == 2) pcs.push_back(p->IdToPiece(p->unk_id()));
+      std::string text;
+      if (!p->Decode(pcs, &text).ok() || sub.DecodePieces(pcs) != text) { fprintf(stderr, "Decode(pieces) at line %zu\n", li); return 1; }
+      std::cout << "D " << hex(text) << "\n";
+      std::cout << "P " << hex(p->EncodeAsSerializedProto(line)) << "\n";
+      ++li;
+    }
+    std::cout << "S";
+    for (int id = 0; id < 64 && id < p->GetPieceSize(); ++id) { char b[32]; snprintf(b, sizeof(b), " %.9g", static_cast<double>(p->GetScore(id))); std::cout << b; }
+    std::cout << "\n";
+    const std::string blob = sub.serialized_model_proto();
+    uint64_t fnv = 1469598103934665603ull;
+    for (unsigned char c : blob) { fnv ^= c; fnv *= 1099511628211ull; }
+    std::cout << "M " << blob.size() << " " << fnv << "\n";
+    if (argc > 5 && argv[5][0]) {
+      if (!p->LoadVocabulary(argv[5], 2).ok()) { fprintf(stderr, "LoadVocabulary\n"); return 1; }
+      std::cout << "V";
+      for (int t : p->EncodeAsIds(lines[0])) std::cout << " " << t;
+      if (!p->ResetVocabulary().ok()) { fprintf(stderr, "ResetVocabulary\n"); return 1; }
+      std::cout << " |";
+      for (int t : p->EncodeAsIds(lines[0])) std::cout << " " << t;
+      std::cout << "\n";
+      if (p->LoadVocabulary("/nonexistent/vocab.tsv", 1).ok()) { fprintf(stderr, "LoadVocabulary of a missing file\n"); return 1; }
+    }
+    return 0;
+  }
   if (argc > 4 && std::string(argv[4]) == "--pieces") {
     // one line per sentence: hex(piece):id:begin:end ..., then "N " + hex(normalized) + the norm_to_orig entries
     auto hex = [](const std::string &x) { static const char *d = "0123456789abcdef"; std::string o; for (unsigned char c : x) { o += d[c >> 4]; o += d[c & 15]; } return o.empty() ? std::string("-") : o; };

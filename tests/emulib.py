@@ -71,6 +71,36 @@ class EmuLib:
         return text[:tb.value].tobytes(), offs[:nl.value + 1].copy()
 
 
+class GpuLib:
+    """The same test-facing interface over the PRODUCT library (sentencepiece_amd/libspmx.so) on a real GPU: what lets a
+    test written against EmuLib run as its own -m gpu twin (tests/test_processor_kats.py, tests/test_normalizer_kats.py)."""
+
+    def __init__(self):
+        from sentencepiece_amd import _capi
+        self.lib = _capi.lib()
+
+    def load(self, model_bytes, cus=None, classes=None, env=None):
+        e = dict(env or {})
+        old = {k: os.environ.get(k) for k in e}
+        os.environ.update(e)
+        try:
+            return EmuHandle(self.lib, model_bytes)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+
+def backend(request_param):
+    """'emu' -> EmuLib(), 'gpu' -> GpuLib(): for fixtures parametrized over both."""
+    return GpuLib() if request_param == "gpu" else EmuLib()
+
+
+BACKENDS = ["emu", "gpu"]
+
+
 class EmuHandle:
     """The test-facing wrapper: a SentencePieceProcessor bound to the emulated library + the packed calls."""
 

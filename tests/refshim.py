@@ -206,3 +206,32 @@ def _spmref_normalize_batch(self, text, offs):
 
 RefHandle.encode_pieces = _spmref_encode_pieces
 RefHandle.normalize_batch = _spmref_normalize_batch
+
+
+def _ref_decode_pieces(self, pieces):
+    """Reference Decode(pieces) of one sentence (list of str / bytes) -> bytes."""
+    pb = [p if isinstance(p, bytes) else p.encode("utf-8", "surrogateescape") for p in pieces]
+    offs = np.zeros(len(pb) + 1, dtype=np.uint64)
+    if pb:
+        np.cumsum([len(x) for x in pb], out=offs[1:])
+    blob = b"".join(pb)
+    cap = len(blob) * 4 + 64 * (len(pb) + 1)
+    out = C.create_string_buffer(cap)
+    fn = self.lib.spmref_decode_pieces
+    fn.restype = C.c_int64
+    fn.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_char_p, C.c_uint64]
+    r = fn(self.h, blob, offs.ctypes.data, len(pb), out, cap)
+    if r < 0:
+        raise RuntimeError("spmref_decode_pieces failed: %d" % r)
+    return out.raw[:r]
+
+
+def _ref_get_score(self, id):
+    fn = self.lib.spmref_get_score
+    fn.restype = C.c_float
+    fn.argtypes = [C.c_void_p, C.c_int]
+    return float(fn(self.h, id))
+
+
+RefHandle.decode_pieces = _ref_decode_pieces
+RefHandle.get_score = _ref_get_score

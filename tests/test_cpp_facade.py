@@ -146,3 +146,89 @@ def test_facade_encode_returns_the_sentence_status(tmp_path):
     b = _build()
     mp, tp, want = _status_case(tmp_path)
     _check_status(subprocess.run([b, mp, tp, "", "--status"], capture_output=True, text=True), want)
+
+
+def _extras_case(tmp_path):
+    lines = ["I saw a girl with a telescope.", "  Hello   world  ", "吾輩は猫である。", "tab\there 　x", "a", "€uro ＡＢ ㍿", "the theatre"]
+    tp = tmp_path / "in.txt"
+    tp.write_bytes("\n".join(lines).encode() + b"\n")
+    vp = tmp_path / "vocab.tsv"
+    vp.write_bytes("▁I\t5\n▁saw\t1\n▁a\t9\ns\t3\ne\n▁the\t2\n".encode())
+    return lines, str(tp), str(vp)
+
+
+def _check_extras(out, sp, ref, lines, vocab_path, decode_opts, opts=""):
+    """sp: the Python mirror over the same library (its EncodeAsSerializedProto is pinned byte for byte to the reference's
+    SerializeAsString elsewhere); ref: the compiled reference (Decode(pieces), GetScore, SetVocabulary)."""
+    assert out.returncode == 0, out.stderr
+    rows = out.stdout.decode().split("\n")
+    unk = sp.IdToPiece(sp.unk_id())
+    ref.set_decode_extra_options(decode_opts)
+    k = 0
+    for li, line in enumerate(lines):
+        pcs = sp.EncodeAsPieces(line)
+        if li % 3 == 0:
+            pcs.insert(len(pcs) // 2, "zzqq-not-a-piece")
+        if li % 3 == 1:
+            pcs.append("▁outside")
+            pcs.insert(0, "")
+        if li % 5 == 2:
+            pcs.append(unk)
+        want = ref.decode_pieces(pcs)
+        assert rows[k] == "D " + (want.hex() or "-"), (li, rows[k])
+        assert rows[k + 1] == "P " + sp.EncodeAsSerializedProto(line).hex(), li
+        k += 2
+    ref.set_decode_extra_options("")
+    scores = rows[k].split()[1:]
+    assert len(scores) == min(64, sp.GetPieceSize())
+    for i, v in enumerate(scores):
+        assert np.float32(float(v)) == np.float32(ref.get_score(i)), i
+    blob = sp.serialized_model_proto()
+    fnv = 1469598103934665603
+    for c in blob:
+        fnv = ((fnv ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert rows[k + 1] == "M %d %d" % (len(blob), fnv)
+    # LoadVocabulary(file, 2): the tokens with frequency >= 2 (no second column: 1) -- against the reference's SetVocabulary
+    keep = ["▁I", "▁a", "s", "▁the"]
+    ref.set_encode_extra_options(opts)
+    ref.set_vocabulary(keep)
+    b = np.frombuffer(lines[0].encode(), dtype=np.uint8)
+    restricted, _ = ref.encode_batch(b, np.array([0, len(b)], dtype=np.uint64))
+    ref.reset_vocabulary()
+    plain, _ = ref.encode_batch(b, np.array([0, len(b)], dtype=np.uint64))
+    v, r = rows[k + 2][1:].split("|")
+    assert [int(x) for x in v.split()] == list(restricted)
+    assert [int(x) for x in r.split()] == list(plain)
+
+
+EXTRAS = [("test_model", "", ""), ("uni1k_bf", "bos:eos", "reverse"), ("bpe1k", "reverse", "unk")]
+
+
+@pytest.mark.parametrize("model,opts,dopts", EXTRAS)
+def test_facade_extras_emulated(model, opts, dopts, tmp_path):
+    """Decode(pieces) with pieces outside the vocabulary, EncodeAsSerializedProto, GetScore, serialized_model_proto,
+    LoadVocabulary -- through a base-class pointer (the facade's methods are virtual, as the reference's are)."""
+    from tests import emulib, refshim
+    if not refshim.available():
+        pytest.skip("the compiled reference (oracle/_ref) is not built")
+    b = _build(emu=True)
+    lines, tp, vp = _extras_case(tmp_path)
+    out = subprocess.run([b, os.path.join(fixtures.GOLDEN, model + ".model"), tp, opts, "--extras", vp, dopts], capture_output=True)
+    sp = emulib.EmuLib().load(fixtures.model_blob(model)).sp
+    sp.SetEncodeExtraOptions(opts)
+    _check_extras(out, sp, refshim.RefLib().load(fixtures.model_blob(model)), lines, vp, dopts, opts)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,opts,dopts", EXTRAS)
+def test_facade_extras(model, opts, dopts, tmp_path):
+    from sentencepiece_amd.processor import SentencePieceProcessor
+    from tests import refshim
+    if not refshim.available():
+        pytest.skip("the compiled reference (oracle/_ref) is not built")
+    b = _build()
+    lines, tp, vp = _extras_case(tmp_path)
+    out = subprocess.run([b, os.path.join(fixtures.GOLDEN, model + ".model"), tp, opts, "--extras", vp, dopts], capture_output=True)
+    sp = SentencePieceProcessor(model_proto=fixtures.model_blob(model))
+    sp.SetEncodeExtraOptions(opts)
+    _check_extras(out, sp, refshim.RefLib().load(fixtures.model_blob(model)), lines, vp, dopts, opts)

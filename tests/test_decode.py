@@ -307,3 +307,69 @@ def test_gpu_decode_extra_options(model, procs, oracle, corpora):
         assert got == sp.Decode(list(reversed(ids)))
     finally:
         sp.SetDecodeExtraOptions("")
+
+
+# ---------------------------------------------------------- Decode(pieces) ----
+PIECE_MODELS = ["test_model", "uni1k_bf", "bpe1k_bf_uds", "uni1k_suffix", "bpe1k_llama", "test_ja_model"]
+
+
+def _piece_rows(ref, rng):
+    """Piece lists the reference itself produced, then damaged: pieces that are in no vocabulary (plain, with a space
+    symbol in front, empty, very long), the unknown piece by name, byte pieces, control pieces."""
+    texts = ["I saw a girl with a telescope.", "  Hello   world  ", "吾輩は猫である。", "tab\there 　x", "", "a", "€uro ＡＢ"]
+    rows = [ref.encode_pieces_one(t) for t in texts]
+    extra = ["zzzqqq", "▁notapiece", "", "<unk>", "<s>", "</s>", "<0xE3>", "<0x81>", "<0x82>", "<0xFF>", "▁", "x" * 300,
+             "▁▁double", "日本語のかたまり"]
+    out = list(rows)
+    for r in rows:
+        for _ in range(3):
+            d = list(r)
+            for _ in range(int(rng.integers(1, 4))):
+                d.insert(int(rng.integers(0, len(d) + 1)), extra[int(rng.integers(0, len(extra)))])
+            out.append(d)
+    out.append(["zzzqqq"])                      # nothing but a piece outside the vocabulary
+    out.append(["▁notapiece", "▁the"])
+    out.append(["<0xE3>", "<0x81>", "zz", "<0x82>"])     # a byte run cut by a literal
+    return out
+
+
+def _check_decode_pieces(sp, ref, rng):
+    rows = _piece_rows(ref, rng)
+    for opts in ("", "reverse", "bos:eos", "unk", "eos:reverse:unk_piece"):
+        sp.SetDecodeExtraOptions(opts)
+        ref.set_decode_extra_options(opts)
+        want = [ref.decode_pieces(r) for r in rows]
+        got = sp.DecodePieces(rows, out_type=bytes)
+        assert got == want, (opts, [(r, g, w) for r, g, w in zip(rows, got, want) if g != w][:3])
+        assert sp.DecodePieces(rows[-1], out_type=bytes) == want[-1]         # the single-sentence form
+    sp.SetDecodeExtraOptions("")
+    ref.set_decode_extra_options("")
+
+
+def _ref_with_pieces(model):
+    ref = refshim.RefLib().load(fixtures.model_blob(model))
+
+    def one(t):
+        b = np.frombuffer(t.encode("utf-8"), dtype=np.uint8)
+        _, _, _, _, blob, po = ref.encode_pieces(b, np.array([0, len(b)], dtype=np.uint64))
+        return [blob[int(po[k]):int(po[k + 1])].decode("utf-8", "surrogateescape") for k in range(len(po) - 1)]
+    ref.encode_pieces_one = one
+    return ref
+
+
+@pytest.mark.skipif(not refshim.available(), reason="the compiled reference (oracle/_ref) is not built")
+@pytest.mark.parametrize("model", PIECE_MODELS)
+def test_emu_decode_pieces(model):
+    """Decode(const std::vector<std::string>& pieces, ...) (src/sentencepiece_processor.cc:761-769): a piece that is not in
+    the vocabulary is copied through as text (:784-790), the unknown piece by name becomes unk_surface, byte pieces are
+    reassembled across it, the decode extra options apply to the piece list first -- against the compiled reference."""
+    from tests import emulib
+    e = emulib.EmuLib().load(fixtures.model_blob(model))
+    _check_decode_pieces(e.sp, _ref_with_pieces(model), np.random.default_rng(7))
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not refshim.available(), reason="the compiled reference (oracle/_ref) is not built")
+@pytest.mark.parametrize("model", PIECE_MODELS)
+def test_gpu_decode_pieces(model, procs):
+    _check_decode_pieces(procs(model), _ref_with_pieces(model), np.random.default_rng(7))

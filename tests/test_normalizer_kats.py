@@ -46,10 +46,12 @@ def _model(add_dummy_prefix=True, remove_extra_ws=True, escape=True, suffix=Fals
     return m.SerializeToString()
 
 
-@pytest.fixture(scope="module")
-def emu():
+@pytest.fixture(scope="module", params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def emu(request):
+    """The product's C ABI: on the CPU model of the wavefront (tests/emulib.py EmuLib), and -- the -m gpu twin of every test
+    of this file -- libspmx.so on the device (GpuLib)."""
     from tests import emulib
-    return emulib.EmuLib()
+    return emulib.backend(request.param)
 
 
 def _check(emu, blob, kats):

@@ -34,10 +34,12 @@ def _str_field(tag, s):
     return synth._varint(tag << 3 | 2) + synth._varint(len(b)) + b
 
 
-@pytest.fixture(scope="module")
-def emu():
+@pytest.fixture(scope="module", params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def emu(request):
+    """The product's C ABI: on the CPU model of the wavefront (tests/emulib.py EmuLib), and -- the -m gpu twin of every test
+    of this file -- libspmx.so on the device (GpuLib)."""
     from tests import emulib
-    return emulib.EmuLib()
+    return emulib.backend(request.param)
 
 
 def _nmt_nfkc_cf_spec():
