@@ -757,19 +757,18 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
     ScanArgs sa{ws->d_counts.p, n32, ws->d_tile_sums.p, d_id_offsets};
     const uint32_t tiles = (n32 + kScanTile - 1) / kScanTile;
     HIP_OR_RETURN(h, LaunchScan(sa, static_cast<int>(tiles < static_cast<uint32_t>(wide) ? tiles : wide), stream));
-    // The status comes back BEFORE the compaction is launched: after an arena overflow some kernels (the long form, the
-    // sentence-per-wave BPE) leave the range they asked for in tmp_off / counts, beyond the arena's end -- compacting
-    // that would read past the allocation (seen as a memory fault on the GPU, found again under ASAN on the emulator).
-    // The caller re-runs the batch with the arena arena_head asks for.
-    HIP_OR_RETURN(h, hipMemcpyAsync(ws->h_ctrl, ws->d_ctrl, offsetof(Ctrl, total_ids), hipMemcpyDeviceToHost, stream));
-    HIP_OR_RETURN(h, hipMemcpyAsync(&ws->h_ctrl->total_ids, d_id_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-    HIP_OR_RETURN(h, hipStreamSynchronize(stream));
-    if (ws->h_ctrl->status & kStArenaOverflow) return kOk;
-    CompactArgs pa{ws->d_arena.p, ws->d_tmp_off.p, ws->d_counts.p, d_id_offsets, d_ids, d_ids ? ids_capacity : 0, n32, h->compact_staged};
+    // After an arena overflow some kernels (the long form, the sentence-per-wave BPE) leave the range they asked for in
+    // tmp_off / counts, beyond the arena's end -- compacting that would read past the allocation (seen as a memory fault on
+    // the GPU, found again under ASAN on the emulator).  The compaction looks at the status word ITSELF (round 6: the host
+    // used to read it back first -- one more synchronisation per call); the caller re-runs the batch with the arena
+    // arena_head asks for.
+    CompactArgs pa{ws->d_arena.p, ws->d_tmp_off.p, ws->d_counts.p, d_id_offsets, d_ids, d_ids ? ids_capacity : 0, n32, &ws->d_ctrl->status, h->compact_staged};
     const uint64_t cblocks = (n + 63) / 64;
     const uint64_t cgrid = cblocks < static_cast<uint64_t>(h->n_cu) * 32 ? cblocks : static_cast<uint64_t>(h->n_cu) * 32;
     HIP_OR_RETURN(h, LaunchCompact(pa, static_cast<int>(cgrid), stream));
-    HIP_OR_RETURN(h, hipStreamSynchronize(stream));      // (as before: the call returns with its outputs complete)
+    HIP_OR_RETURN(h, hipMemcpyAsync(ws->h_ctrl, ws->d_ctrl, offsetof(Ctrl, total_ids), hipMemcpyDeviceToHost, stream));
+    HIP_OR_RETURN(h, hipMemcpyAsync(&ws->h_ctrl->total_ids, d_id_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_OR_RETURN(h, hipStreamSynchronize(stream));      // (the call returns with its outputs complete)
     return kOk;
   };
   // SPMX_ARENA_FIRST=<ids>: the first attempt's arena is no larger than this (tests force the overflow-and-retry path)
@@ -1198,6 +1197,9 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
             if (ej != hipSuccess) return fail_forked(FailHip(h, ej, "hipEventRecord(join)"));
             a.lists = left_lists[0];
           }
+          // (round 6 tried to take these counts with the control block after the compaction instead -- one synchronisation
+          // less: C2's second round does hand a few sentences on in every call, and their tail then costs a second scan +
+          // compaction: 6.11 ms a step against 5.38)
           FORKED_OR_RETURN(read_counts());
         }
       } else {
@@ -1300,7 +1302,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       // token begins to CSR order, then one align launch per staged length class over the classify lists
       const uint64_t total = ws->h_ctrl->total_ids;
       HIP_OR_RETURN(h, ws->d_tok_begin.Reserve(total));
-      CompactArgs pa{ws->d_arena_tb.p, ws->d_tmp_off.p, ws->d_counts.p, d_id_offsets, ws->d_tok_begin.p, total, n32, h->compact_staged};
+      CompactArgs pa{ws->d_arena_tb.p, ws->d_tmp_off.p, ws->d_counts.p, d_id_offsets, ws->d_tok_begin.p, total, n32, nullptr, h->compact_staged};
       const uint64_t cblocks = (n + 63) / 64;
       const uint64_t cgrid = cblocks < static_cast<uint64_t>(h->n_cu) * 32 ? cblocks : static_cast<uint64_t>(h->n_cu) * 32;
       HIP_OR_RETURN(h, LaunchCompact(pa, static_cast<int>(cgrid), stream));

@@ -1108,6 +1108,8 @@ struct CompactArgs {
   int32_t *ids;
   uint64_t ids_cap;
   uint32_t n;
+  const uint32_t *status = nullptr;   // the call's kSt* bits (null: not looked at): after an arena overflow nothing is moved -- some
+                                      // kernels leave the range they ASKED for in tmp_off / counts, beyond the arena's end
   uint32_t staged = 2048;   // ids the LDS image of a wave holds: blocks of 16-bit ids go through it (0: the search form for every block)
 };
 
@@ -1133,6 +1135,7 @@ constexpr uint32_t CompactLdsBytes(uint32_t ids) { return ids ? (ids + 8u) * 2u 
 SPMX_DEVICE void compact_block(const CompactArgs &a, uint16_t *lds) {
   const int lane = wv::lane();
   if (a.id_offs[a.n] > a.ids_cap) return;   // caller sees the needed size in id_offs[n]
+  if (a.status != nullptr && (*a.status & kStArenaOverflow)) return;   // the caller encodes the batch again with a larger arena
   const uint32_t blocks = (a.n + 63) / 64;
   const uint16_t *arena16 = reinterpret_cast<const uint16_t *>(a.arena);
   const uint32_t cap = (reinterpret_cast<uintptr_t>(a.arena) & 15u) == 0 ? a.staged : 0u;   // ids the LDS image holds
