@@ -212,6 +212,34 @@ def side_bench(sp_cls, torch, dev, name, blob, text, offs, steps, warmup, what, 
     return out
 
 
+GATHER_DEPTH = 3          # gathers in flight (sharding.IdGatherer): batch k's transfer runs under the encodes of k + 1 and k + 2
+XGMI_LINKS = 7            # peers one hop away on an 8-GPU MI355X node (point to point, no switch)
+XGMI_LINK_GBS = 76.5      # one direction of one link: 153 GB/s bidirectional
+
+
+def gather_bound(world, sentences_per_rank, ids_per_sentence, wire_bytes, count_bytes, encode_ms):
+    """What the north star's all-gather of the ids costs on the node's links, from numbers the run has: every rank sends its
+    ids (wire_bytes each) and per-sentence counts (count_bytes each) to every peer, one link per peer, so a link carries one
+    rank's payload per step in each direction; with the transfer of batch k under the encode of batch k + 1 the step is
+    the longer of the two.  A MODEL (link peak, perfect overlap) -- the measured figures are value_gather_* ."""
+    payload = sentences_per_rank * (ids_per_sentence * wire_bytes + count_bytes)
+    peers = max(world - 1, 1)
+    link_ms = payload / (XGMI_LINK_GBS * 1e9) * 1e3
+    step_ms = max(encode_ms, link_ms)
+    return {"world": world, "payload_bytes_per_rank": payload, "ids_wire_bytes": wire_bytes, "count_wire_bytes": count_bytes,
+            "ingest_bytes_per_rank_per_step": payload * peers, "encode_ms": encode_ms,
+            "ingest_gb_per_s_needed_to_hide_it": payload * peers / (encode_ms * 1e-3) / 1e9,
+            "links": XGMI_LINKS, "link_gb_per_s_one_direction": XGMI_LINK_GBS,
+            "ingest_gb_per_s_available": XGMI_LINK_GBS * min(peers, XGMI_LINKS),
+            "gather_ms_at_link_peak": link_ms, "predicted_step_ms": step_ms,
+            "predicted_scaling_vs_one_gpu": world * encode_ms / step_ms,
+            "bound": "links (the gather)" if link_ms > encode_ms else "the encode",
+            "payload_bytes_per_rank_for_6x_of_8": XGMI_LINK_GBS * 1e9 * encode_ms * 1e-3 * 8.0 / 6.0,
+            "what": "model: every rank's payload crosses one xGMI link per peer per step at the link's one-direction peak, "
+                    "fully overlapped with the next batch's encode; world = 8 is a projection from this run's own rate when "
+                    "the run has fewer ranks"}
+
+
 def corpus_for(model, sentences, seed, unsorted, corpus="synthetic"):
     from sentencepiece_amd import synth
     if corpus == "open_vocab":
@@ -348,6 +376,9 @@ def main():
     d_ids = torch.empty(int(total) + int(total) // 16 + 64, dtype=torch.int32, device=dev)
     # ids travel as int16 when the vocabulary allows it (half the bytes on the point-to-point xGMI links)
     wire = torch.int16 if sp.GetPieceSize() <= 32768 else None
+    # a sentence has at most one id per raw byte + 1 (+ the ids of the extra options): the host knows the longest sentence
+    # of its shard from the offsets, so the per-sentence counts of the exact-size gather travel in one or two bytes
+    max_count = (int(np.diff(offs.astype(np.int64)).max()) + 1 + 8) if n else 1
 
     def timed(run_step, wait=None):
         for _ in range(args.warmup):
@@ -378,12 +409,12 @@ def main():
     def run_mode(mode):
         if not mode.startswith("ids:"):
             return timed(encode_step)
-        g = sharding.IdGatherer(dist, dev, wire_dtype=wire, depth=2, algo=mode[4:])
+        g = sharding.IdGatherer(dist, dev, wire_dtype=wire, depth=GATHER_DEPTH, algo=mode[4:])
         g.reserve(d_ids.numel(), d_io.numel(), torch.int32, d_io.dtype)      # agreed once, before the loop
 
         def step_ids():
             tot = sp.EncodeDevice(d_text, d_offs, d_ids, d_io)[2]
-            g(d_ids, tot, d_io)
+            g(d_ids, tot, d_io, max_count=max_count)
             return tot
         r = timed(step_ids, g.wait)
         del g
@@ -392,8 +423,10 @@ def main():
     def gather_desc(mode):
         if not mode.startswith("ids"):
             return mode
-        return ("%s (%s on the wire, capacities agreed once, 2 gathers in flight, %s CUs left to RCCL)"
-                % (mode, "int16" if wire is not None else "int32", os.environ.get("SPMX_RESERVE_CUS", "0")))
+        return ("%s (%s on the wire, per-sentence counts in %d byte(s) where exact sizes travel, capacities agreed once, "
+                "%d gathers in flight, %s CUs left to RCCL)"
+                % (mode, "int16" if wire is not None else "int32", sharding.IdGatherer.count_width(max_count), GATHER_DEPTH,
+                   os.environ.get("SPMX_RESERVE_CUS", "0")))
 
     results = {}
     late_modes = []
@@ -467,6 +500,9 @@ def main():
                                       "in generator order (not length-bucketed)" if args.unsorted else "length-bucketed"),
                        "model": args.model, "sentences_per_gpu": n, "ids_per_sentence": job_ids / (world * n),
                        "gather": gather_desc(head) if multi else "n/a",
+                       "gather_bound": gather_bound(world if world > 1 else 8, n, job_ids / (world * n), 2 if wire is not None else 4,
+                                                    sharding.IdGatherer.count_width(max_count),
+                                                    (results["none"][0] if "none" in results else dt) / args.steps * 1e3),
                        "sharding": "dp%d by sentence" % world,
                        "timed_loop": "profiling off; roofline.* comes from a second loop of the same steps with HIP events on"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

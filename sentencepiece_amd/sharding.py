@@ -127,7 +127,16 @@ class IdGatherer:
                 sl["oout"] = torch.empty(self.world * self._ocap, dtype=offsets_dtype, device=self.device)
             self._slots.append(sl)
 
-    def _call_exact(self, ids, total, id_offsets):
+    @staticmethod
+    def count_width(max_count):
+        """Bytes a per-sentence id COUNT travels in (p2p_exact) given the caller's bound on ids per sentence -- e.g. the
+        longest raw sentence of the shard + the extra ids, which the host knows from the input offsets without reading
+        anything back from the device: 1 (uint8) up to 255, 2 (int16 pattern) up to 65535, else 4.  None: 4."""
+        if max_count is None:
+            return 4
+        return 1 if max_count <= 255 else (2 if max_count <= 65535 else 4)
+
+    def _call_exact(self, ids, total, id_offsets, max_count=None):
         """Two steps per batch, one call apart.  STAGE (now): the rank's ids and per-sentence counts are copied to the
         slot's send buffers and the two integers every receiver needs -- {total, sentences} of every rank -- start
         travelling over the side channel ASYNCHRONOUSLY.  POST (at the next call, or at wait() / result()): the sizes of
@@ -150,11 +159,14 @@ class IdGatherer:
             sl["xsend"] = torch.empty(max(total + total // 8, 1), dtype=wire, device=self.device)
         sl["xsend"][:total].copy_(ids[:total])
         csend = None
+        width = self.count_width(max_count)
         if id_offsets is not None:
-            csend = (id_offsets[1:] - id_offsets[:-1]).to(torch.int32)
+            c64 = id_offsets[1:] - id_offsets[:-1]
+            # (the width is the SENDER's promise; it travels with the sizes, so ranks may differ)
+            csend = c64.to(torch.uint8) if width == 1 else (c64.to(torch.int32).to(torch.int16) if width == 2 else c64.to(torch.int32))
         sl["xcsend"] = csend
-        meta = torch.tensor([total, n], dtype=torch.int64)
-        metas = [torch.zeros(2, dtype=torch.int64) for _ in range(self.world)]
+        meta = torch.tensor([total, n, width], dtype=torch.int64)
+        metas = [torch.zeros(3, dtype=torch.int64) for _ in range(self.world)]
         mw = dist.all_gather(metas, meta, group=self._cpu_group if self._cpu_group is not None else self.group, async_op=True)
         sl["staged"] = (mw, metas, meta, total, n, id_offsets is not None, id_offsets.dtype if id_offsets is not None else None)
         prev = self._pending
@@ -171,6 +183,7 @@ class IdGatherer:
         mw.wait()
         tots = [int(m[0]) for m in metas]
         ns = [int(m[1]) for m in metas]
+        widths = [int(m[2]) for m in metas]
         wire = sl["xsend"].dtype
         sum_t, sum_n = sum(tots), sum(ns)
         if sl["xout"] is None or sl["xout"].numel() < sum_t or sl["xout"].dtype != wire:
@@ -180,10 +193,12 @@ class IdGatherer:
         send = sl["xsend"][:total]
         sl["xout"][int(t_base[rank]):int(t_base[rank + 1])].copy_(send)
         csend = sl["xcsend"] if has_offs else None
+        cb = None                                  # byte offsets of the ranks' count arrays in the receive buffer
         if has_offs:
-            if sl["xcnt"] is None or sl["xcnt"].numel() < sum_n:
-                sl["xcnt"] = torch.empty(max(sum_n + sum_n // 8, 1), dtype=torch.int32, device=self.device)
-            sl["xcnt"][int(n_base[rank]):int(n_base[rank + 1])].copy_(csend)
+            cb = np.concatenate([[0], np.cumsum([((ns[r] * widths[r] + 15) // 16) * 16 for r in range(world)])]).astype(np.int64)
+            if sl["xcnt"] is None or sl["xcnt"].numel() < int(cb[-1]):
+                sl["xcnt"] = torch.empty(max(int(cb[-1]) + int(cb[-1]) // 8, 16), dtype=torch.uint8, device=self.device)
+            sl["xcnt"][int(cb[rank]):int(cb[rank]) + n * widths[rank]].copy_(csend.view(torch.uint8))
 
         def as_bytes(t):
             return t.view(torch.uint8) if t.dtype == torch.int16 else t
@@ -196,16 +211,18 @@ class IdGatherer:
                 ops.append(dist.P2POp(dist.irecv, as_bytes(sl["xout"][int(t_base[frm]):int(t_base[frm + 1])]), self._peer(frm), self.group))
             if csend is not None:
                 if n:
-                    ops.append(dist.P2POp(dist.isend, csend, self._peer(to), self.group))
+                    ops.append(dist.P2POp(dist.isend, csend.view(torch.uint8), self._peer(to), self.group))
                 if ns[frm]:
-                    ops.append(dist.P2POp(dist.irecv, sl["xcnt"][int(n_base[frm]):int(n_base[frm + 1])], self._peer(frm), self.group))
+                    ops.append(dist.P2POp(dist.irecv, sl["xcnt"][int(cb[frm]):int(cb[frm]) + ns[frm] * widths[frm]], self._peer(frm), self.group))
         sl["work"] = [_Works(dist.batch_isend_irecv(ops))] if ops else []
-        sl["exact"] = (tots, ns, t_base, n_base, has_offs, odtype)
+        sl["exact"] = (tots, ns, t_base, n_base, has_offs, odtype, widths, cb)
 
-    def __call__(self, ids, total, id_offsets=None):
+    def __call__(self, ids, total, id_offsets=None, max_count=None):
+        """``max_count`` (p2p_exact): the caller's bound on the ids of one sentence of this batch (count_width): the
+        counts then travel in one or two bytes instead of four.  A bound that does not hold corrupts the counts."""
         total = int(total)
         if self.algo == "p2p_exact" and self.world > 1:
-            return self._call_exact(ids, total, id_offsets)
+            return self._call_exact(ids, total, id_offsets, max_count)
         need_o = id_offsets.numel() if id_offsets is not None else 0
         if not self._slots or total > self._cap or need_o > self._ocap:
             # first use (or a caller that grew its buffers without reserve()): agree now -- collective, so every rank
@@ -251,13 +268,19 @@ class IdGatherer:
             w.wait()
         sl["work"] = []
         if "exact" in sl and sl.get("exact") is not None and self.algo == "p2p_exact" and self.world > 1:
-            tots, ns, t_base, n_base, has_offs, odt = sl["exact"]
+            tots, ns, t_base, n_base, has_offs, odt, widths, cb = sl["exact"]
             ids = [sl["xout"][int(t_base[r]):int(t_base[r + 1])].to(self._dtype) for r in range(self.world)]
             offs = None
             if has_offs:
                 offs = []
                 for r in range(self.world):
-                    c = sl["xcnt"][int(n_base[r]):int(n_base[r + 1])].to(odt)
+                    raw = sl["xcnt"][int(cb[r]):int(cb[r]) + ns[r] * widths[r]]
+                    if widths[r] == 1:
+                        c = raw.to(odt)
+                    elif widths[r] == 2:
+                        c = raw.view(torch.int16).to(torch.int32).bitwise_and(0xFFFF).to(odt)
+                    else:
+                        c = raw.view(torch.int32).to(odt)
                     offs.append(torch.cat([torch.zeros(1, dtype=odt, device=c.device), torch.cumsum(c, 0)]))
             return ids, offs
         tot = sl["tot"].cpu().tolist()

@@ -22,10 +22,10 @@ hang = os.environ.get("SPMX_DRYRUN_HANG")
 if hang:
     real_call = sharding.IdGatherer.__call__
 
-    def call(self, ids, total, id_offsets=None):
+    def call(self, ids, total, id_offsets=None, **kw):
         if self.algo == hang:
             time.sleep(3600)
-        return real_call(self, ids, total, id_offsets)
+        return real_call(self, ids, total, id_offsets, **kw)
     sharding.IdGatherer.__call__ = call
 
 import bench  # noqa: E402

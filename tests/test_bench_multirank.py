@@ -46,6 +46,12 @@ def test_bench_two_ranks_times_both_gathers_and_prints_one_line():
     for k in ("value_gather_all_gather", "value_gather_p2p_exact", "value_gather_none"):
         assert d[k] > 0, k
     assert d["value"] == max(d["value_gather_all_gather"], d["value_gather_p2p_exact"])
+    # the gather-bound model travels with the line: payload, what the links would have to carry, the predicted step and scaling
+    gb = d["config"]["gather_bound"]
+    assert gb["world"] == 2 and gb["payload_bytes_per_rank"] > 0 and gb["ids_wire_bytes"] in (2, 4) and gb["count_wire_bytes"] in (1, 2, 4)
+    assert gb["predicted_step_ms"] >= gb["encode_ms"] > 0 and 0 < gb["predicted_scaling_vs_one_gpu"] <= 2.0
+    assert abs(gb["ingest_bytes_per_rank_per_step"] - gb["payload_bytes_per_rank"]) < 1e-6          # one peer
+    assert "gathers in flight" in d["config"]["gather"] and "count" in d["config"]["gather"]
     assert d["config"]["sentences_per_gpu"] == 4500 and "dp2" in d["config"]["sharding"]
     assert d["roofline"]["kernel"]
 

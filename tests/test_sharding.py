@@ -67,7 +67,8 @@ def _worker(rank, world, port, model, corpus_name, n_sent, out_dir, engine="orac
             nsent = 0 if k == 0 else 1 + (rank + step) % 3
             cuts = np.linspace(0, k, nsent + 1).astype(np.int64)
             part = torch.arange(k, dtype=torch.int32) + 100 * rank
-            gx(part, k, torch.from_numpy(cuts))
+            # the counts travel in one, two or four bytes by the SENDER's bound on ids per sentence (ranks differ on purpose)
+            gx(part, k, torch.from_numpy(cuts), max_count=(None, 200, 40000)[(rank + step) % 3])
             got, goffs = gx.result()
             for r in range(world):
                 kk = sizes(r, step)
@@ -75,6 +76,14 @@ def _worker(rank, world, port, model, corpus_name, n_sent, out_dir, engine="orac
                 assert got[r].tolist() == [100 * r + i for i in range(kk)] and got[r].dtype == torch.int32
                 assert goffs[r].tolist() == np.linspace(0, kk, ns + 1).astype(np.int64).tolist()
         gx.wait()
+        # counts beyond a byte / beyond 32767 keep their value through the two-byte form
+        gy = sharding.IdGatherer(dist, torch.device("cpu"), wire_dtype=torch.int16, depth=3, algo="p2p_exact")
+        big = 40000 + rank
+        gy(torch.zeros(big + 3, dtype=torch.int32), big + 3, torch.tensor([0, big, big + 3], dtype=torch.int64), max_count=65535)
+        got, goffs = gy.result()
+        for r in range(world):
+            assert goffs[r].tolist() == [0, 40000 + r, 40003 + r] and got[r].numel() == 40003 + r
+        gy.wait()
     finally:
         dist.destroy_process_group()
 
