@@ -678,6 +678,43 @@ def main():
                 del h_io, h_ids
             except Exception as e:
                 out["end_to_end"] = {"failed": repr(e)[:300]}
+            # The reference's ONLY batch entry is its Python wrapper (SURVEY finding 1): sp.encode(list[str]) -> list[list[int]].
+            # The same call through this engine's Python mirror, and -- for scale -- the pip wheel of the reference on the
+            # same list with its own thread pool (python/src/sentencepiece/sentencepiece.i:210-267): both pay CPython for
+            # every list and int they hand back, which bounds either at a few M sentences/s whatever encodes.
+            try:
+                k = min(n, 2_000_000)
+                pick = np.linspace(0, n - 1, num=k).astype(np.int64)
+                raw = text.tobytes()
+                o64 = offs.astype(np.int64)
+                strs = [raw[o64[i]:o64[i + 1]].decode("utf-8", "replace") for i in pick]
+                sp.encode(strs[:1000])
+                t0 = time.perf_counter()
+                got = sp.encode(strs)
+                dt_py = time.perf_counter() - t0
+                rec = {"what": "sp.encode(list of %d str) -> list of lists of int through sentencepiece_amd.processor "
+                               "(views handed to spmx_encode_batch_views, lists built by the C extension)" % k,
+                       "value": k / dt_py, "unit": "sentences/s", "seconds": dt_py}
+                try:
+                    import sentencepiece as ref_wheel
+                    rw = ref_wheel.SentencePieceProcessor(model_proto=blob)
+                    threads = min(os.cpu_count() or 1, 64)
+                    rw.encode(strs[:1000], num_threads=threads)
+                    t0 = time.perf_counter()
+                    want = rw.encode(strs, num_threads=threads)
+                    dt_w = time.perf_counter() - t0
+                    rec["reference_wheel"] = {"version": ref_wheel.__version__, "value": k / dt_w, "seconds": dt_w, "threads": threads,
+                                              "what": "the pip wheel's sp.encode(list, num_threads) on the same list (its ids are "
+                                                      "not this engine's parity bar -- the compiled reference is -- only its rate is read)",
+                                              "lists_equal": bool(want == got)}
+                    rec["vs_reference_wheel"] = dt_w / dt_py
+                    del want
+                except Exception as e:
+                    rec["reference_wheel"] = {"failed": repr(e)[:200]}
+                out["end_to_end_python"] = rec
+                del strs, got, raw
+            except Exception as e:
+                out["end_to_end_python"] = {"failed": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             io_h = d_io.cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(text, offs, blob, np.diff(io_h), d_ids[:int(io_h[-1])].cpu().numpy(), io_h)
