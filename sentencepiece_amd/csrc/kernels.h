@@ -235,65 +235,93 @@ SPMX_DEVICE int normalize_wave(const SpmxDev &d, const uint8_t *raw, int L, uint
   const bool has_map = (F & kNfHasCharsmap) != 0, has_uds = (F & kNfHasUserDefined) != 0;
   const uint32_t droot = has_map ? DartsOffset(d.ndarts[0]) : 0u;
   const uint32_t uroot = has_uds ? (d.utrie[0].x >> kDatBaseShiftDev) : 0u;
-  const bool try_fast = !HBM && !has_uds && (!has_map || d.nfilt != 0u);
-  for (int b = 0; b < L; b += 64) {
+  const bool try_fast = !has_uds && (!has_map || d.nfilt != 0u);
+  // What the common sweep (0) knows about a position from the text alone -- the character there, the one behind it, and the
+  // three filter words -- is prepared ONE SWEEP AHEAD: the words come from global memory, and a sweep that asks for them and
+  // waits pays an L2 round trip per 64 bytes (a third of the sweep, round 6).
+  struct FastPre {
+    uint32_t w0 = 0, nx = 0, cp = 0, cq = 0, nq = 0, ws = 0, wa = 0, w2 = 0;
+    int mb = 1;
+    bool is_cont = false, okc = false, after_ok = false, has_next = false, big = false, nbig = false;
+  };
+  auto prepare = [&](int pp) __attribute__((always_inline)) -> FastPre {
+    FastPre f;
+    if (pp >= L) return f;
+    struct __attribute__((packed, aligned(1))) U32B { uint32_t v; };
+    uint32_t w0 = 0, w1 = 0;
+    const int rem = L - pp;
+    if (!HBM || rem >= 8) { w0 = reinterpret_cast<const U32B *>(raw + pp)->v; w1 = reinterpret_cast<const U32B *>(raw + pp + 4)->v; }
+    else for (int k = 0; k < rem; ++k) { if (k < 4) w0 |= static_cast<uint32_t>(raw[pp + k]) << (8 * k); else w1 |= static_cast<uint32_t>(raw[pp + k]) << (8 * (k - 4)); }
+    if (rem < 8) {                                     // bytes past the text read as 0: they continue nothing
+      if (rem <= 4) { w1 = 0; if (rem < 4) w0 &= (1u << (8 * rem)) - 1u; }
+      else w1 &= (1u << (8 * (rem - 4))) - 1u;
+    }
+    const uint32_t b0 = w0 & 0xFFu, b1 = (w0 >> 8) & 0xFFu, b2 = (w0 >> 16) & 0xFFu, b3 = w0 >> 24;
+    f.w0 = w0;
+    f.is_cont = (b0 & 0xC0u) == 0x80u;
+    const int mb = b0 < 0x80u ? 1 : (b0 < 0xE0u ? 2 : (b0 < 0xF0u ? 3 : 4));
+    f.mb = mb;
+    const bool c1 = (b1 & 0xC0u) == 0x80u, c2 = (b2 & 0xC0u) == 0x80u, c3 = (b3 & 0xC0u) == 0x80u;
+    if (mb == 1) { f.okc = true; f.cp = b0; }
+    else if (mb == 2) { f.okc = b0 >= 0xC2u && c1; f.cp = (b0 & 0x1Fu) << 6 | (b1 & 0x3Fu); }
+    else if (mb == 3) { f.okc = c1 && c2 && (b0 != 0xE0u || b1 >= 0xA0u) && (b0 != 0xEDu || b1 < 0xA0u); f.cp = (b0 & 0x0Fu) << 12 | (b1 & 0x3Fu) << 6 | (b2 & 0x3Fu); }
+    else { f.okc = b0 <= 0xF4u && c1 && c2 && c3 && (b0 != 0xF0u || b1 >= 0x90u) && (b0 != 0xF4u || b1 < 0x90u);
+           f.cp = (b0 & 0x07u) << 18 | (b1 & 0x3Fu) << 12 | (b2 & 0x3Fu) << 6 | (b3 & 0x3Fu); }
+    const uint64_t x8 = static_cast<uint64_t>(w1) << 32 | w0;
+    const uint32_t nx = static_cast<uint32_t>(x8 >> (8 * mb));               // the four bytes behind the character
+    f.nx = nx;
+    const uint32_t n0 = nx & 0xFFu;
+    f.after_ok = (n0 & 0xC0u) != 0x80u;
+    if (has_map && !f.is_cont && f.okc) {
+      // (the three filter words are asked for together, whatever the first one says: one trip to the cache, not three)
+      const uint32_t n1 = (nx >> 8) & 0xFFu, n2 = (nx >> 16) & 0xFFu, n3 = nx >> 24;
+      uint32_t ncp;
+      bool nok = true;
+      if (n0 < 0x80u) ncp = n0;
+      else if (n0 < 0xE0u) { ncp = (n0 & 0x1Fu) << 6 | (n1 & 0x3Fu); nok = n0 >= 0xC2u && (n1 & 0xC0u) == 0x80u; }
+      else if (n0 < 0xF0u) { ncp = (n0 & 0x0Fu) << 12 | (n1 & 0x3Fu) << 6 | (n2 & 0x3Fu); nok = (n1 & 0xC0u) == 0x80u && (n2 & 0xC0u) == 0x80u; }
+      else { ncp = (n0 & 0x07u) << 18 | (n1 & 0x3Fu) << 12 | (n2 & 0x3Fu) << 6 | (n3 & 0x3Fu); nok = (n1 & 0xC0u) == 0x80u && (n2 & 0xC0u) == 0x80u && (n3 & 0xC0u) == 0x80u; }
+      f.has_next = mb < rem;                                                   // the character behind it, if any
+      f.big = f.cp >= kNfiltCps;
+      f.nbig = f.has_next && (!nok || ncp >= kNfiltCps);
+      const uint32_t *ft = d.npair + 2048;
+      f.cq = f.big ? 0u : f.cp;
+      f.nq = (f.has_next && !f.nbig) ? ncp : 0u;
+      f.ws = ft[f.cq >> 5]; f.wa = ft[kNfiltWords + (f.cq >> 5)]; f.w2 = ft[2u * kNfiltWords + (f.nq >> 5)];
+    }
+    return f;
+  };
+  FastPre cur_pre, nxt_pre;
+  if (try_fast) cur_pre = prepare(lane);
+  for (int b = 0; b < L; b += 64, cur_pre = nxt_pre) {
     const int p = b + lane;
     const bool valid = p < L;
     // (0) THE COMMON SWEEP: every position from the chain's next start on is a well-formed character (DecodeUTF8's rule,
     // util.cc:51-84) at which no charsmap key can match (the code-point filters, dev.h nfilt) and that is no literal
     // U+2581 -- every prefix is its own character (:231-244), so the chain of starts is the bytes that continue no
     // character, and what remains of the loop is the whitespace state machine and a prefix sum.  One test per sweep; any
-    // other sweep takes the general steps below.  (LDS image only: the eight bytes a lane looks at may lie past the text.)
+    // other sweep takes the general steps below.  (The eight bytes a lane looks at may lie past the text: an LDS image has
+    // the slack; in HBM the last lanes of a text gather theirs byte by byte.)
     if (try_fast) {
-      struct __attribute__((packed, aligned(1))) U32B { uint32_t v; };
-      uint32_t w0 = 0, w1 = 0;
-      if (valid) { w0 = reinterpret_cast<const U32B *>(raw + p)->v; w1 = reinterpret_cast<const U32B *>(raw + p + 4)->v; }
-      const int rem = L - p;
-      if (rem < 8) {                                     // bytes past the text read as 0: they continue nothing
-        if (rem <= 4) { w1 = 0; if (rem < 4) w0 &= rem <= 0 ? 0u : (1u << (8 * rem)) - 1u; }
-        else w1 &= (1u << (8 * (rem - 4))) - 1u;
-      }
-      const uint32_t b0 = w0 & 0xFFu, b1 = (w0 >> 8) & 0xFFu, b2 = (w0 >> 16) & 0xFFu, b3 = w0 >> 24;
-      const bool is_cont = (b0 & 0xC0u) == 0x80u;
-      const int mb = b0 < 0x80u ? 1 : (b0 < 0xE0u ? 2 : (b0 < 0xF0u ? 3 : 4));
-      const bool c1 = (b1 & 0xC0u) == 0x80u, c2 = (b2 & 0xC0u) == 0x80u, c3 = (b3 & 0xC0u) == 0x80u;
-      bool okc;
-      uint32_t cp;
-      if (mb == 1) { okc = true; cp = b0; }
-      else if (mb == 2) { okc = b0 >= 0xC2u && c1; cp = (b0 & 0x1Fu) << 6 | (b1 & 0x3Fu); }
-      else if (mb == 3) { okc = c1 && c2 && (b0 != 0xE0u || b1 >= 0xA0u) && (b0 != 0xEDu || b1 < 0xA0u); cp = (b0 & 0x0Fu) << 12 | (b1 & 0x3Fu) << 6 | (b2 & 0x3Fu); }
-      else { okc = b0 <= 0xF4u && c1 && c2 && c3 && (b0 != 0xF0u || b1 >= 0x90u) && (b0 != 0xF4u || b1 < 0x90u);
-             cp = (b0 & 0x07u) << 18 | (b1 & 0x3Fu) << 12 | (b2 & 0x3Fu) << 6 | (b3 & 0x3Fu); }
-      const uint64_t x8 = static_cast<uint64_t>(w1) << 32 | w0;
-      const uint32_t nx = static_cast<uint32_t>(x8 >> (8 * mb));               // the four bytes behind the character
-      const uint32_t n0 = nx & 0xFFu;
-      const bool after_ok = (n0 & 0xC0u) != 0x80u;
+      nxt_pre = b + 64 < L ? prepare(b + 64 + lane) : FastPre();
+      const FastPre &f = cur_pre;
+      const uint32_t b0 = f.w0 & 0xFFu, b1 = (f.w0 >> 8) & 0xFFu, b2 = (f.w0 >> 16) & 0xFFu, b3 = f.w0 >> 24;
+      const int mb = f.mb;
+      const uint32_t cp = f.cp;
+      const bool is_cont = f.is_cont;
       const bool from = valid && p >= next_start;
-      bool cx = from && (is_cont ? p == next_start : !(okc && after_ok));
+      bool cx = from && (is_cont ? p == next_start : !(f.okc && f.after_ok));
       const bool st = from && !is_cont;
       uint32_t rule = 0;                                                       // a one-character rule: nblob offset | length << 24
       if (st && !cx) {
         if (one && cp == 0x2581u) cx = true;                                   // a literal U+2581 (kind 3 below)
         if (has_map) {
-          // (the three filter words are asked for together, whatever the first one says: one trip to the cache, not three)
-          const uint32_t n1 = (nx >> 8) & 0xFFu, n2 = (nx >> 16) & 0xFFu, n3 = nx >> 24;
-          uint32_t ncp;
-          bool nok = true;
-          if (n0 < 0x80u) ncp = n0;
-          else if (n0 < 0xE0u) { ncp = (n0 & 0x1Fu) << 6 | (n1 & 0x3Fu); nok = n0 >= 0xC2u && (n1 & 0xC0u) == 0x80u; }
-          else if (n0 < 0xF0u) { ncp = (n0 & 0x0Fu) << 12 | (n1 & 0x3Fu) << 6 | (n2 & 0x3Fu); nok = (n1 & 0xC0u) == 0x80u && (n2 & 0xC0u) == 0x80u; }
-          else { ncp = (n0 & 0x07u) << 18 | (n1 & 0x3Fu) << 12 | (n2 & 0x3Fu) << 6 | (n3 & 0x3Fu); nok = (n1 & 0xC0u) == 0x80u && (n2 & 0xC0u) == 0x80u && (n3 & 0xC0u) == 0x80u; }
-          const bool has_next = mb < rem;                                      // the character behind it, if any
-          const bool big = cp >= kNfiltCps, nbig = has_next && (!nok || ncp >= kNfiltCps);
-          const uint32_t *f = d.npair + 2048;
-          const uint32_t cq = big ? 0u : cp, nq = (has_next && !nbig) ? ncp : 0u;
-          const uint32_t w_starts = f[cq >> 5], w_alone = f[kNfiltWords + (cq >> 5)], w_second = f[2u * kNfiltWords + (nq >> 5)];
-          if (big) cx = true;
-          else if ((w_starts >> (cq & 31u)) & 1u) {
-            const bool alone = (w_alone >> (cq & 31u)) & 1u;
-            const bool second = nbig || (has_next && ((w_second >> (nq & 31u)) & 1u));
+          if (f.big) cx = true;
+          else if ((f.ws >> (f.cq & 31u)) & 1u) {
+            const bool alone = (f.wa >> (f.cq & 31u)) & 1u;
+            const bool second = f.nbig || (f.has_next && ((f.w2 >> (f.nq & 31u)) & 1u));
             if (second) cx = true;
-            else if (alone) { rule = f[3u * kNfiltWords + cp]; if (rule == 0u) cx = true; }
+            else if (alone) { rule = d.npair[2048u + 3u * kNfiltWords + cp]; if (rule == 0u) cx = true; }
           }
         }
       }

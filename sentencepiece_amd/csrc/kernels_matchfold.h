@@ -199,9 +199,9 @@ SPMX_DEVICE int match_wave(const SpmxDev &d, const uint8_t *norm, int nlen, cons
         for (uint32_t i = 0; i < k[w]; ++i) {
           U2 e = row[w][i];
           if (i == 0) e.x |= head;
-          o[i] = e;
+          wv::store_stream(&o[i], e);
         }
-        if (!single[w]) o[k[w]] = U2{unk_word | (static_cast<uint32_t>(mb[w]) << kCsLenShift) | (k[w] == 0 ? head : 0u), unk_bits};
+        if (!single[w]) wv::store_stream(&o[k[w]], U2{unk_word | (static_cast<uint32_t>(mb[w]) << kCsLenShift) | (k[w] == 0 ? head : 0u), unk_bits});
       }
       n_out += static_cast<int>(total);
       wv::sync();
@@ -289,8 +289,8 @@ SPMX_DEVICE int fold_stream_lane(const SpmxDev &d, const U2 *cs, int n_ent, cons
   const Q4 *blocks = reinterpret_cast<const Q4 *>(cs);     // a block of 8 entries = 4 x Q4
   Q4 A0{0, 0, 0, 0}, A1 = A0, A2 = A0, A3 = A0, B0 = A0, B1 = A0, B2 = A0, B3 = A0;
   const int n_blocks = (n_ent + 7) >> 3;
-  if (n_blocks > 0) { A0 = blocks[0]; A1 = blocks[1]; A2 = blocks[2]; A3 = blocks[3]; }
-  if (n_blocks > 1) { B0 = blocks[4]; B1 = blocks[5]; B2 = blocks[6]; B3 = blocks[7]; }
+  if (n_blocks > 0) { A0 = wv::load_stream(blocks); A1 = wv::load_stream(blocks + 1); A2 = wv::load_stream(blocks + 2); A3 = wv::load_stream(blocks + 3); }
+  if (n_blocks > 1) { B0 = wv::load_stream(blocks + 4); B1 = wv::load_stream(blocks + 5); B2 = wv::load_stream(blocks + 6); B3 = wv::load_stream(blocks + 7); }
   int trips = 0;
   for (int kb = 0; wv::any(kb < n_blocks); kb += 2) {
     ++trips;
@@ -298,13 +298,13 @@ SPMX_DEVICE int fold_stream_lane(const SpmxDev &d, const U2 *cs, int n_ent, cons
       const int k0 = kb * 8;
       step(A0.x, A0.y, k0); step(A0.z, A0.w, k0 + 1); step(A1.x, A1.y, k0 + 2); step(A1.z, A1.w, k0 + 3);
       step(A2.x, A2.y, k0 + 4); step(A2.z, A2.w, k0 + 5); step(A3.x, A3.y, k0 + 6); step(A3.z, A3.w, k0 + 7);
-      if (kb + 2 < n_blocks) { const Q4 *q = blocks + 4 * (kb + 2); A0 = q[0]; A1 = q[1]; A2 = q[2]; A3 = q[3]; }
+      if (kb + 2 < n_blocks) { const Q4 *q = blocks + 4 * (kb + 2); A0 = wv::load_stream(q); A1 = wv::load_stream(q + 1); A2 = wv::load_stream(q + 2); A3 = wv::load_stream(q + 3); }
     }
     {
       const int k0 = kb * 8 + 8;
       step(B0.x, B0.y, k0); step(B0.z, B0.w, k0 + 1); step(B1.x, B1.y, k0 + 2); step(B1.z, B1.w, k0 + 3);
       step(B2.x, B2.y, k0 + 4); step(B2.z, B2.w, k0 + 5); step(B3.x, B3.y, k0 + 6); step(B3.z, B3.w, k0 + 7);
-      if (kb + 3 < n_blocks) { const Q4 *q = blocks + 4 * (kb + 3); B0 = q[0]; B1 = q[1]; B2 = q[2]; B3 = q[3]; }
+      if (kb + 3 < n_blocks) { const Q4 *q = blocks + 4 * (kb + 3); B0 = wv::load_stream(q); B1 = wv::load_stream(q + 1); B2 = wv::load_stream(q + 2); B3 = wv::load_stream(q + 3); }
     }
   }
   if (active) {

@@ -60,6 +60,7 @@ SPMX_DEVICE bool unigram_wave(const SpmxDev &d, const uint8_t *nt, int nlen, con
                               uint16_t *blen, int lane) {
   const U4 *__restrict__ ptrie = d.ptrie;
   const uint32_t root = d.ptrie[0].x >> kDatBaseShiftDev;
+  const uint32_t root_w = d.ptrie[0].w;
   const uint32_t spb = SpByteOf(d);
   for (uint32_t k = static_cast<uint32_t>(lane); k < kUwRing; k += 64u) T.ring_b[k] = kUwUnreached;
   if (lane == 0) T.ring_s[0] = 0.f;                                   // best_path_ends_at[0].best_path_score = 0
@@ -87,17 +88,20 @@ SPMX_DEVICE bool unigram_wave(const SpmxDev &d, const uint8_t *nt, int nlen, con
     {
       bool alive = ((S >> lane) & 1ull) != 0;
       uint32_t node = root, k = 0;
+      uint32_t wsum = root_w;                                         // child-label summary of the node the walk stands on (dev.h ChildBit)
       int dep = 0;
       while (wv::any(alive)) {
         if (alive) {
           const int q = s + dep;
           if (q >= nlen) { alive = false; }
+          else if (!((wsum >> ChildBit(T.win[q - c])) & 1u)) { alive = false; }   // no child with this label: the failing probe is not issued
           else {
             const uint32_t cb = T.win[q - c];
             const U4 u = ptrie[node ^ cb];
             if ((u.x & 0x1FFu) == (0x100u | cb)) {                    // :969-971
               ++dep;
               node = u.x >> kDatBaseShiftDev;
+              wsum = u.w;
               if ((u.x & kDatTerminalDev) && !(u.y & kPtUnused) && k < J) {   // :973-974
                 T.cands[static_cast<uint32_t>(lane) * J + k] =
                     U2{(u.y & 0x00FFFFFFu) | (static_cast<uint32_t>(dep) << 24) | ((u.y & kPtUserDefined) ? 0x80000000u : 0u), u.z};

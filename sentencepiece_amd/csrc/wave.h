@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "dev.h"
+
 #define SPMX_DEVICE __device__ __forceinline__
 #define SPMX_DEVICE_CALL __device__ __attribute__((noinline))   // a real call: rare paths that sit inside unrolled code
 
@@ -108,6 +110,20 @@ SPMX_DEVICE unsigned long long atomic_cas(unsigned long long *p, unsigned long l
 SPMX_DEVICE uint32_t atomic_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 SPMX_DEVICE unsigned long long atomic_load64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+
+// Streaming accesses: data written once and read once much later (the split form's candidate streams, kernels_matchfold.h)
+// should not push the tables the probes live on out of L2 -- the non-temporal hint (slc / nt on gfx9).
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+SPMX_DEVICE void store_stream(U2 *p, const U2 &v) {                    // one 8-byte store (p is 8-byte aligned)
+  u32x2_t w;
+  w.x = v.x; w.y = v.y;
+  __builtin_nontemporal_store(w, reinterpret_cast<u32x2_t *>(p));
+}
+SPMX_DEVICE Q4 load_stream(const Q4 *p) {                              // one 16-byte load
+  const u32x4_t w = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
+  return Q4{w.x, w.y, w.z, w.w};
+}
 
 // the 64-bit value hi:lo shifted right by n & 3 bytes, its low 32 bits (v_alignbyte_b32)
 SPMX_DEVICE uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t n) { return __builtin_amdgcn_alignbyte(hi, lo, n); }

@@ -26,6 +26,8 @@
 
 #include <functional>
 
+#include "dev.h"
+
 namespace spmx {
 namespace emu {
 
@@ -113,6 +115,8 @@ inline unsigned long long atomic_cas(unsigned long long *p, unsigned long long e
 inline uint32_t atomic_load(const uint32_t *p) { return *p; }
 inline unsigned long long atomic_load64(const unsigned long long *p) { return *p; }
 
+inline void store_stream(U2 *p, const U2 &v) { *p = v; }
+inline Q4 load_stream(const Q4 *p) { return *p; }
 inline uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t n) { return static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | lo) >> (8u * (n & 3u))); }
 inline unsigned long long clock() { return 0; }
 
