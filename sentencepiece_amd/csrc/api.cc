@@ -593,6 +593,14 @@ StreamPlan PlanStream(const spmx_handle *h, EncodeArgs *a, const uint32_t *count
   uint64_t total = 0;
   for (int c = c_lo; c < c_hi; ++c) total += counts[c];
   uint64_t grid = static_cast<uint64_t>(h->n_cu - h->reserve_cus);
+  // (cus_cap is NOT applied -- it never was, although round 5's notes say otherwise -- and round 6 measured that it should
+  // not be: the general launch beside the word rounds takes a workgroup on every CU, the word-per-lane workgroups (162 KB of
+  // LDS: nothing shares a CU with them) start as those end, and that order is the fast one.  On the Llama-style model
+  // (12 % of the sentences set aside, a 13 ms general launch) real partitions cost more: 96 / 128 / 160 / 192 CUs for the
+  // general launch -> 62.9 / 49.4 / 41.0 / 35.3 ms a step against 29.9 -- the lane-per-sentence BPE kernel runs 1.7 times
+  // slower with the word rounds streaming beside it.  This is also what the "17 ms first round" of that model was: 4.7 ms
+  // of work behind the 13 ms it waited for its CUs, both inside the events that time it; profiles/r06_llama_fork_cus.txt)
+  (void)cus_cap;
   if (grid * waves > total) grid = (total + waves - 1) / waves;
   if (grid < 1) grid = 1;
   // the slab of a wavefront must hold one lane of the largest class present: fewer wavefronts if the limit says so
