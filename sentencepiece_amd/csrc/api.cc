@@ -56,7 +56,7 @@ constexpr uint32_t kDynListCapDefault = 1u << 18;     // (handle fields dyn_slot
 thread_local std::string t_error;              // text of the calling thread's last failing call
 
 // kernel slots of the per-call profile
-enum { kSlotMain = 0, kSlotDoc = 1, kSlotExact = 2, kSlotWave = 3, kSlotLong = 4, kSlotWord = 5, kSlotWord2 = 6, kNumSlots = 7 };
+enum { kSlotMain = 0, kSlotDoc = 1, kSlotExact = 2, kSlotWave = 3, kSlotLong = 4, kSlotWord = 5, kSlotWord2 = 6, kSlotSplit = 7, kNumSlots = 8 };
 
 // ctrl block layout (device + pinned host mirror), zeroed before every call
 struct Ctrl {
@@ -66,7 +66,7 @@ struct Ctrl {
   uint32_t status;
   uint32_t retry_count[2];            // long form: sentences that found the pool exhausted (ping-pong)
   uint32_t pad;
-  StreamQueue q[6];                   // tile queues of the main / document / overflow launches; [3], [4]: the word kernels; [5]: the tail launch
+  StreamQueue q[7];                   // tile queues of the main / document / overflow launches; [3], [4]: the word kernels; [5]: the tail launch; [6]: the split launch
   uint32_t left_counts[3][kMaxClasses];   // word kernels: second-round input / general input / what the second round left, per class
   uint32_t dyn_count;                     // ... words entered into the call-local memo (must follow left_counts: read together)
   uint32_t align_counts[kMaxClasses]; // spans form: escalation lists of the staged align kernels
@@ -321,6 +321,8 @@ struct spmx_handle {
   bool force_word_dp = false;    // SPMX_FORCE_WORD_DP=1: the second pass runs whatever the first one left (tests)
   bool no_split = false;         // SPMX_NO_SPLIT=1: no class takes the split form (kernels_matchfold.h)
   uint32_t split_min_raw = 576;  // SPMX_SPLIT_MIN: classes of MORE than this many raw bytes (up to kMfMaxRaw) take the split form
+  bool split_own_launch = false; // SPMX_SPLIT_LAUNCH=1: the split classes get a launch of their own (EncodeSplitKernel)
+  uint32_t split_tiles = 1;      // SPMX_SPLIT_TILES: split tiles per wavefront and class the planner aims at (their match phase is sequential: small tiles balance, large tiles fold more lanes at once)
   uint32_t split_per_byte = 4;   // SPMX_SPLIT_CANDS: candidates per normalized byte a sentence's stream holds before the overflow launch takes the sentence
   bool no_uni_wave = false;      // SPMX_NO_UNI_WAVE=1: unigram models never take the wave-cooperative form (kernels_uniwave.h)
   uint32_t uni_wave_max = 0;     // SPMX_UNI_WAVE_MAX: a staged class with fewer sentences than this takes the wave-cooperative form
@@ -558,13 +560,14 @@ struct StreamPlan {
   uint32_t lds = 0;
   uint64_t slab_bytes = 0;       // per wavefront
   uint32_t open = 0;             // non-empty classes
+  bool split_only = false;       // every tile takes the split form: LaunchEncodeSplit
 };
 
 // Fills a->cls / n_classes / total_main / ring / slab_bytes for the classes [c_lo, c_hi) whose sizes are `counts`
 // (classes outside the range get no tiles); tcap_of(c) gives a class's text-column capacity.
 template <typename TcapFn>
 StreamPlan PlanStream(const spmx_handle *h, EncodeArgs *a, const uint32_t *counts, int c_lo, int c_hi, int n_classes,
-                      const uint32_t *rcaps, TcapFn tcap_of, bool all_general, int waves_cap = 0, int cus_cap = 0, bool allow_split = false) {
+                      const uint32_t *rcaps, TcapFn tcap_of, bool all_general, int waves_cap = 0, int cus_cap = 0, int allow_split = 0) {
   StreamPlan sp;
   const int model = h->model.model_type;
   const uint32_t ring = HandleRing(h);
@@ -577,9 +580,18 @@ StreamPlan PlanStream(const spmx_handle *h, EncodeArgs *a, const uint32_t *count
   uint32_t priv = StreamPrivateBytes(model, ring, bpsz);
   // the split form (kernels_matchfold.h) for the classes of long sentences of a unigram model: its match phase keeps ONE
   // sentence's raw and normalized image in the wavefront's LDS
-  const bool can_split = allow_split && model == kUnigram && h->tables.split_ok && !h->no_split && !(h->dev.flags & kNfHasUserDefined);
+  // allow_split: 0 no class takes the split form; 1 the eligible ones do, beside lane-per-sentence tiles of other classes
+  // (a tail launch); 2 EVERY class of the launch does (the caller passes only eligible ones): the wavefront's slice then
+  // holds the match phase's image or the fold's character rings, not the lane form's byte rings -- 12 instead of 9 per CU
+  const bool can_split = allow_split != 0 && model == kUnigram && h->tables.split_ok && !h->no_split && !(h->dev.flags & kNfHasUserDefined);
   auto split_class = [&](int c) { return can_split && counts[c] > 0 && rcaps[c] > h->split_min_raw && rcaps[c] <= kMfMaxRaw && tcap_of(c) < 65000u; };
   a->match_rows = static_cast<uint32_t>(h->tables.max_prefixes);
+  a->split_ring = FoldRing(h->tables.max_piece_chars);
+  if (allow_split == 2)                        // (only if every class with sentences is eligible: else as mode 1)
+    for (int c = c_lo; c < c_hi; ++c) if (counts[c] > 0 && !split_class(c)) allow_split = 1;
+  sp.split_only = allow_split == 2;
+  if (allow_split == 2) priv = ((FoldLdsBytes(a->split_ring, bpsz) + 15u) & ~15u) + 256u;
+  if (allow_split == 2 && priv < 16u * 64u * 4u + 256u) priv = 16u * 64u * 4u + 256u;      // (emit_stream_lane's staging column of 16 ids a lane)
   for (int c = c_lo; c < c_hi; ++c)
     if (split_class(c)) {
       const uint32_t need = ((MatchLdsBytes(rcaps[c], tcap_of(c), a->match_rows) + 15u) & ~15u) + 256u;
@@ -631,6 +643,7 @@ StreamPlan PlanStream(const spmx_handle *h, EncodeArgs *a, const uint32_t *count
       if (!counts[c]) continue;
       uint64_t tw = (static_cast<uint64_t>(counts[c]) + n_waves - 1) / n_waves;
       if (tw > 64 || thin) tw = 64;
+      if (split_class(c)) { tw = (static_cast<uint64_t>(counts[c]) + h->split_tiles * n_waves - 1) / (h->split_tiles * n_waves); if (tw > 64) tw = 64; if (tw < 1) tw = 1; }   // (below)
       tiles += (static_cast<uint64_t>(counts[c]) + tw - 1) / tw;
     }
     if (tiles < n_waves) {
@@ -650,6 +663,9 @@ StreamPlan PlanStream(const spmx_handle *h, EncodeArgs *a, const uint32_t *count
     sc.tcap = tcap_of(c);
     uint64_t tw = (static_cast<uint64_t>(counts[c]) + n_waves - 1) / n_waves;   // sentences per main tile
     if (thin) tw = 64;
+    // (a split tile's match phase takes its sentences ONE AFTER ANOTHER: small tiles, two or three to a wavefront, so that
+    // the queue evens the wavefronts out -- a "thin" launch of 64-sentence tiles left 60 % of them idle, round 6)
+    if (split_class(c)) tw = (static_cast<uint64_t>(counts[c]) + h->split_tiles * n_waves - 1) / (h->split_tiles * n_waves);
     if (tw < h->tile_min_lanes) tw = h->tile_min_lanes;
     if (tw > 64) tw = 64;
     if (tw < 1) tw = 1;
@@ -822,7 +838,8 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
     // one streaming launch over the classes [c_lo, c_hi) (or, exact: over the overflow list with exact capacities)
     int stream_waves_cap = 0;            // (set while a launch has to share the CUs with the second word round)
     int stream_cus_cap = 0;
-    auto stream_launch = [&](int slot, int qi, int c_lo, int c_hi, const uint32_t *counts, bool exact, uint64_t exact_raw) -> int {
+    // smode: PlanStream's allow_split -- 1: eligible classes take the split form beside lane tiles; 2: a launch of split tiles only
+    auto stream_launch = [&](int slot, int qi, int c_lo, int c_hi, const uint32_t *counts, bool exact, uint64_t exact_raw, int smode = 1) -> int {
       EncodeArgs la = a;
       uint32_t rc2[kMaxClasses];
       for (int c = 0; c < kMaxClasses; ++c) rc2[c] = rcaps[c];
@@ -838,7 +855,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         // the last class of the table takes every longer sentence too: those go straight to the overflow list
         sp = PlanStream(h, &la, counts, c_lo, c_hi, ncls, rc2,
                         [&](int c) { return esc3 ? 2u * cls[c].rcap + 64u : (h->wide_tcap ? cls[c].ncap : cls[c].rcap + cls[c].rcap / 4u + 16u); }, !fast_ok,
-                        stream_waves_cap, stream_cus_cap, /*allow_split=*/true);
+                        stream_waves_cap, stream_cus_cap, /*allow_split=*/smode);
       }
       if (la.total_main == 0) return kOk;
       la.q = &ws->d_ctrl->q[qi];
@@ -850,10 +867,20 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
                : (la.ring == 16 ? (uds ? "EncodeStreamKernel<16, true>" : "EncodeStreamKernel<16, false>")
                                 : (uds ? "EncodeStreamKernel<0, true>" : "EncodeStreamKernel<0, false>")));
       HIP_OR_RETURN(h, record(slot, 0));
-      HIP_OR_RETURN(h, LaunchEncodeStream(h->model.model_type, uds, la, sp.grid, sp.waves, sp.lds, stream));
+      if (sp.split_only) {
+        snprintf(ws->slot_name[slot], sizeof(ws->slot_name[slot]), "%s", la.bp_short ? "EncodeSplitShortKernel" : "EncodeSplitKernel");
+        HIP_OR_RETURN(h, LaunchEncodeSplit(la, sp.grid, sp.waves, sp.lds, stream));
+      } else {
+        HIP_OR_RETURN(h, LaunchEncodeStream(h->model.model_type, uds, la, sp.grid, sp.waves, sp.lds, stream));
+      }
       HIP_OR_RETURN(h, record(slot, 1));
       ws->slot_used[slot] = true;
       return kOk;
+    };
+    // which classes a launch of split tiles takes (PlanStream decides again, from the same rules)
+    auto split_launch_class = [&](int c) -> bool {
+      return !is_bpe && h->tables.split_ok && !h->no_split && !uds && cls[c].rcap > h->split_min_raw && cls[c].rcap <= kMfMaxRaw &&
+             !((h->dev.flags & kNfEscapeWs) && !(h->dev.flags & kNfCompressSp) && 2u * cls[c].rcap + 64u >= 65000u);
     };
     // the long form over one device-side list (BPE), growing the slice pool until every sentence has had its turn
     // (uni: the wave-cooperative unigram form over the same pool, kernels_uniwave.h)
@@ -963,6 +990,24 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         if (tail) return stream_launch(kSlotDoc, tail_qi, 0, ncls, cnt, false, 0);
         int c_doc = ncls;                    // first class of the document launch
         for (int c = 0; c < ncls; ++c) if (cls[c].rcap > h->main_max_raw) { c_doc = c; break; }
+        // The long classes of a unigram model the split form takes in a launch of their OWN (EncodeSplitKernel: 12 wavefronts
+        // per CU instead of 10): measured and not the default -- 8.8 ms for the long classes + 6.0 ms for the short ones
+        // (latency-bound, half idle) against 11.2 ms for both in one launch, where the short classes' lane tiles fill
+        // the gaps of the long classes' split tiles (SPMX_SPLIT_LAUNCH=1; C5, profiles/README_r06.md)
+        if (h->split_own_launch) {
+          // (copies: the caller's counts also say which classes the spans form's align launches visit)
+          uint32_t cnt_split[kMaxClasses] = {0}, cnt_main[kMaxClasses] = {0};
+          bool any_split = false;
+          for (int c = 0; c < ncls; ++c) {
+            if (c < c_doc && cnt[c] && split_launch_class(c)) { cnt_split[c] = cnt[c]; any_split = true; }
+            else cnt_main[c] = cnt[c];
+          }
+          if (any_split) {
+            if (int rc = stream_launch(kSlotSplit, 6, 0, c_doc, cnt_split, false, 0, 2); rc != kOk) return rc;
+            if (int rc = stream_launch(kSlotMain, 0, 0, c_doc, cnt_main, false, 0); rc != kOk) return rc;
+            return stream_launch(kSlotDoc, 1, c_doc, ncls, cnt, false, 0);
+          }
+        }
         if (int rc = stream_launch(kSlotMain, 0, 0, c_doc, cnt, false, 0); rc != kOk) return rc;
         return stream_launch(kSlotDoc, 1, c_doc, ncls, cnt, false, 0);
       }
@@ -1645,6 +1690,8 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
 #endif
     if (const char *e = getenv("SPMX_NO_SPLIT")) h->no_split = e[0] == '1';
     if (const char *e = getenv("SPMX_SPLIT_MIN")) h->split_min_raw = static_cast<uint32_t>(atoll(e));
+    if (const char *e = getenv("SPMX_SPLIT_LAUNCH")) h->split_own_launch = e[0] == '1';
+    if (const char *e = getenv("SPMX_SPLIT_TILES")) { const int v = atoi(e); if (v >= 1 && v <= 16) h->split_tiles = static_cast<uint32_t>(v); }
     if (const char *e = getenv("SPMX_SPLIT_CANDS")) { const int v = atoi(e); if (v >= 1 && v <= 16) h->split_per_byte = static_cast<uint32_t>(v); }
     if (const char *e = getenv("SPMX_UNI_WAVE_MAX")) h->uni_wave_max = static_cast<uint32_t>(atoll(e));
     if (const char *e = getenv("SPMX_WORD_WAVE")) { const int v = atoi(e); if (v >= 0 && v <= 3) h->word_form = v; }

@@ -97,6 +97,7 @@ struct EncodeArgs {
   uint32_t fast_ok;             // the model meets fast_norm_stream's preconditions
   uint32_t no_lane_general;     // A/B switch: ASCII tiles put every non-ASCII sentence into the backlog
   uint32_t private_bytes;       // LDS of one wavefront of the streaming launch (StreamPrivateBytes, or more for the split form's image)
+  uint32_t split_ring;          // split form: entries of the fold's character-indexed rings (8 or 16, kernels_matchfold.h FoldRing)
   uint32_t match_rows;          // split form (kernels_matchfold.h): candidate-row entries = the trie's deepest chain of prefixes
   uint32_t no_char_norm;        // A/B switch: 1: no tile takes the character-stepping normalizer (kernels_normlane.h char_norm_stream); 2 (test seam): every tile does
   StreamClass cls[kMaxClasses];

@@ -27,6 +27,15 @@ __global__ __launch_bounds__(1024) void EncodeStreamShortKernel(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   encode_stream_block<1, RING, false, BpShort>(a, smem);
 }
+// every tile in the split form (kernels_matchfold.h): a launch of its own for the long length classes of a unigram model
+__global__ __launch_bounds__(1024) void EncodeSplitKernel(EncodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  encode_stream_block<1, 0, false, BpWord, true>(a, smem);
+}
+__global__ __launch_bounds__(1024) void EncodeSplitShortKernel(EncodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  encode_stream_block<1, 0, false, BpShort, true>(a, smem);
+}
 __global__ __launch_bounds__(1024) void EncodeBpeStreamKernel(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   encode_stream_block<2, 0, false>(a, smem);
@@ -162,6 +171,17 @@ hipError_t LaunchEncodeStream(int model_type, bool uds, const EncodeArgs &a, int
   EncodeFn fn = model_type == 2 ? EncodeBpeStreamKernel : a.bp_short ? (a.ring == 16 ? EncodeStreamShortKernel<16> : EncodeStreamShortKernel<0>)
                                 : (a.ring == 16 ? (uds ? EncodeStreamKernel<16, true> : EncodeStreamKernel<16, false>)
                                                 : (uds ? EncodeStreamKernel<0, true> : EncodeStreamKernel<0, false>));
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds_bytes));
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * waves), lds_bytes, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t LaunchEncodeSplit(const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t stream) {
+  EncodeFn fn = a.bp_short ? EncodeSplitShortKernel : EncodeSplitKernel;
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds_bytes));

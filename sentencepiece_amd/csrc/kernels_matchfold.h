@@ -27,38 +27,49 @@
 
 namespace spmx {
 
-// candidate word x: id | (character bytes - 1) << 21 | length << 24 | first-of-its-start << 31; y: score bits
-constexpr uint32_t kCsIdMask = 0x001FFFFFu;
-constexpr int kCsMbShift = 21;
-constexpr int kCsLenShift = 24;
+// candidate word x: id (19 bits) | the piece's length in CHARACTERS << 19 (4 bits) | (bytes of the start's character - 1) << 23
+// | the piece's length in bytes << 25 (6 bits) | first-of-its-start << 31; y: score bits
+constexpr uint32_t kCsIdMask = 0x0007FFFFu;
+constexpr int kCsNchShift = 19;
+constexpr int kCsMbShift = 23;
+constexpr int kCsLenShift = 25;
 constexpr uint32_t kCsFirst = 0x80000000u;
-constexpr uint32_t kMfMaxVocab = 1u << 21;
+constexpr uint32_t kMfMaxVocab = 1u << 19;
+constexpr int kMfMaxPieceBytes = 63;     // (six bits)
+constexpr int kMfMaxPieceChars = 15;     // (four bits); the fold's rings are indexed by CHARACTER: 8 or 16 entries
 constexpr uint32_t kMfMaxCands = 16;     // candidate rows: the deepest chain of pieces that are prefixes of one another
 constexpr uint32_t kMfQueue = 512;       // queued character starts (a sweep adds up to 256 to fewer than 64 * kMfWalks)
 constexpr int kMfWalks = 2;              // starts a lane walks side by side: two probes in flight per lane (four: the same cycles per start -- the gathers are bound by their throughput, scripts/ubench/gather_probe -- and fewer wavefronts for the LDS rows)
 constexpr uint32_t kMfMaxRaw = 4096;     // sentences beyond this do not fit the LDS image (normalize_wave's LDS form)
 
 // LDS of the match phase for sentences of up to rcap raw / tcap normalized bytes, rows of J candidates
+// (the queue and the candidate rows lie OVER the raw image: it is dead once the sentence is normalized)
 SPMX_HD inline uint32_t MatchLdsBytes(uint32_t rcap, uint32_t tcap, uint32_t J) {
-  return ((rcap + 48u + 15u) & ~15u) + ((tcap + 16u + 15u) & ~15u) + kMfQueue * 2u + 64u * kMfWalks * J * 8u;
+  const uint32_t raw = (rcap + 48u + 15u) & ~15u, walk = kMfQueue * 2u + 64u * kMfWalks * J * 8u;
+  return ((tcap + 16u + 15u) & ~15u) + (raw > walk ? raw : walk);
 }
+// LDS of the fold phase: the two rings of RC characters and the staging block of 8 back-pointer entries, per lane
+SPMX_HD inline uint32_t FoldLdsBytes(uint32_t rc, uint32_t bpsz) { return 64u * rc * (4u + bpsz) + 64u * 8u * bpsz; }
+// ring entries for pieces of up to max_chars characters
+SPMX_HD inline uint32_t FoldRing(int max_chars) { return max_chars < 8 ? 8u : 16u; }
 // candidates a sentence of tcap normalized bytes may put into its stream (entries), and the stream's bytes in the slab
 // (the fold reads whole blocks of 8 entries, two blocks ahead)
 SPMX_HD inline uint32_t MatchStreamCap(uint32_t tcap, uint32_t per_byte) { return (tcap * per_byte + 64u + 7u) & ~7u; }
 SPMX_HD inline uint64_t MatchStreamBytes(uint32_t ccap) { return (static_cast<uint64_t>(ccap) + 32u) * 8u; }
 
 struct MatchLds {
-  uint8_t *raw;       // [rcap + 48]: whole 16-byte units of the text; the sentence begins at raw + (its address & 15)
   uint8_t *norm;      // [tcap + 16]
-  uint16_t *queue;    // [kMfQueue] byte positions of character starts, in text order
-  U2 *cands;          // [kMfWalks][64][J]
+  uint8_t *raw;       // [rcap + 48]: whole 16-byte units of the text; the sentence begins at raw + (its address & 15)
+  uint16_t *queue;    // [kMfQueue] byte positions of character starts, in text order (over raw)
+  U2 *cands;          // [kMfWalks][64][J] (over raw, behind the queue)
 };
 SPMX_DEVICE MatchLds carve_match(unsigned char *mine, uint32_t rcap, uint32_t tcap, uint32_t) {
   MatchLds m;
-  m.raw = mine;
-  m.norm = mine + ((rcap + 48u + 15u) & ~15u);
-  m.queue = reinterpret_cast<uint16_t *>(m.norm + ((tcap + 16u + 15u) & ~15u));
-  m.cands = reinterpret_cast<U2 *>(reinterpret_cast<unsigned char *>(m.queue) + kMfQueue * 2u);
+  (void)rcap;
+  m.norm = mine;
+  m.raw = mine + ((tcap + 16u + 15u) & ~15u);
+  m.queue = reinterpret_cast<uint16_t *>(m.raw);             // (over the raw image, see MatchLdsBytes)
+  m.cands = reinterpret_cast<U2 *>(m.raw + kMfQueue * 2u);
   return m;
 }
 
@@ -106,6 +117,7 @@ SPMX_DEVICE int match_wave(const SpmxDev &d, const uint8_t *norm, int nlen, cons
     // ---- kMfWalks x 64 starts, a start per lane and walk (:965-993): every piece that begins there, by length ----
     uint32_t take[kMfWalks];
     int p0[kMfWalks], dep[kMfWalks], mb[kMfWalks];
+    uint32_t nch[kMfWalks];                          // characters of the text the walk has consumed
     uint32_t k[kMfWalks];
     bool alive[kMfWalks], single[kMfWalks], has[kMfWalks];
     U4 u[kMfWalks];
@@ -116,7 +128,7 @@ SPMX_DEVICE int match_wave(const SpmxDev &d, const uint8_t *norm, int nlen, cons
       p0[w] = has[w] ? static_cast<int>(M.queue[(qhead + static_cast<uint32_t>(lane)) & (kMfQueue - 1u)]) : 0;
       qhead += take[w];
       qn -= take[w];
-      k[w] = 0; dep[w] = 0; mb[w] = 1; single[w] = false; alive[w] = false;
+      k[w] = 0; dep[w] = 0; mb[w] = 1; nch[w] = 1; single[w] = false; alive[w] = false;
       u[w] = U4{0, 0, 0, 0};
       if (has[w]) {
         const uint32_t b0 = norm[p0[w]];
@@ -155,16 +167,20 @@ SPMX_DEVICE int match_wave(const SpmxDev &d, const uint8_t *norm, int nlen, cons
         go[w] = false; nxt[w] = 0; cb[w] = 0;
         if (alive[w]) {
           const U4 uu = u[w];
-          if ((uu.x & kDatTerminalDev) && !(uu.y & kPtUnused)) {                     // :973-974
+          const int q = p0[w] + dep[w];
+          const uint32_t cq = q < nlen ? norm[q] : 0u;                               // the byte behind what has matched (0: the text ends)
+          // a piece that ends INSIDE a character (a model whose pieces are not whole characters) only ever relaxes a position
+          // no start reaches (:1007 hops by characters) and the backtrack never visits: it is left out, and the fold may
+          // count positions in characters
+          if ((uu.x & kDatTerminalDev) && !(uu.y & kPtUnused) && (cq & 0xC0u) != 0x80u) {   // :973-974
             if (k[w] < J)
-              row[w][k[w]] = U2{(uu.y & kCsIdMask) | (static_cast<uint32_t>(dep[w]) << kCsLenShift) | ((uu.y & kPtUserDefined) ? 0x00800000u : 0u), uu.z};
+              row[w][k[w]] = U2{(uu.y & kCsIdMask) | (nch[w] << kCsNchShift) | (static_cast<uint32_t>(dep[w]) << kCsLenShift), uu.z};
             ++k[w];
             if (dep[w] == mb[w]) single[w] = true;                                   // :990
           }
-          const int q = p0[w] + dep[w];
-          if (q < nlen && dep[w] < kMaxPieceBytes) {
-            cb[w] = norm[q];
-            if ((uu.w >> ChildBit(cb[w])) & 1u) { go[w] = true; nxt[w] = (uu.x >> kDatBaseShiftDev) ^ cb[w]; }
+          if (q < nlen && dep[w] < kMfMaxPieceBytes) {
+            cb[w] = cq;
+            if ((uu.w >> ChildBit(cq)) & 1u) { go[w] = true; nxt[w] = (uu.x >> kDatBaseShiftDev) ^ cq; }
           }
           alive[w] = go[w];
         }
@@ -176,7 +192,7 @@ SPMX_DEVICE int match_wave(const SpmxDev &d, const uint8_t *norm, int nlen, cons
 #pragma unroll
       for (int w = 0; w < kMfWalks; ++w) {
         if (go[w]) {
-          if ((v[w].x & 0x1FFu) == (0x100u | cb[w])) { u[w] = v[w]; ++dep[w]; }     // :969-971
+          if ((v[w].x & 0x1FFu) == (0x100u | cb[w])) { u[w] = v[w]; ++dep[w]; if ((cb[w] & 0xC0u) != 0x80u) ++nch[w]; }     // :969-971
           else alive[w] = false;
         }
         any_alive = any_alive || alive[w];
@@ -201,7 +217,7 @@ SPMX_DEVICE int match_wave(const SpmxDev &d, const uint8_t *norm, int nlen, cons
           if (i == 0) e.x |= head;
           wv::store_stream(&o[i], e);
         }
-        if (!single[w]) wv::store_stream(&o[k[w]], U2{unk_word | (static_cast<uint32_t>(mb[w]) << kCsLenShift) | (k[w] == 0 ? head : 0u), unk_bits});
+        if (!single[w]) wv::store_stream(&o[k[w]], U2{unk_word | (1u << kCsNchShift) | (static_cast<uint32_t>(mb[w]) << kCsLenShift) | (k[w] == 0 ? head : 0u), unk_bits});
       }
       n_out += static_cast<int>(total);
       wv::sync();
@@ -211,53 +227,55 @@ SPMX_DEVICE int match_wave(const SpmxDev &d, const uint8_t *norm, int nlen, cons
   return n_out;
 }
 
-// EncodeOptimized's fold (:960-1008) for this lane's sentence from its candidate stream cs[0, n_ent): the state, the
-// rings, the staging block and the back-pointer blocks are unigram_stream_lane's (kernels_stream.h).  The stream is
-// read in blocks of 8 entries (64 bytes), two blocks ahead of their use; all lanes of the wave step through their
-// streams together.  Returns the number of blocks the wave went through.
-template <int RING, typename BP>
+// EncodeOptimized's fold (:960-1008) for this lane's sentence from its candidate stream cs[0, n_ent).  best_path_ends_at
+// lives in two LDS rings of RC entries INDEXED BY CHARACTER (a candidate carries its length in characters; positions inside
+// a character are never relaxed -- match_wave leaves such pieces out): RC = 8 or 16 instead of one entry per byte of the
+// longest piece, which is what lets a launch of split tiles keep 12 wavefronts on a CU.  The staging block and the
+// back-pointer blocks are unigram_stream_lane's (by BYTE position: the backtrack walks bytes).  The stream is read in
+// blocks of 8 entries (64 bytes), two blocks ahead of their use; all lanes of the wave step through their streams together.
+// Returns the number of blocks the wave went through.
+template <int RC, typename BP>
 SPMX_DEVICE int fold_stream_lane(const SpmxDev &d, const U2 *cs, int n_ent, const BpCol<typename BP::T> &gb, int nlen, float *ring_s,
-                                 typename BP::T *ring_b, uint32_t rm_in, typename BP::T *st, bool active_in) {
+                                 typename BP::T *ring_b, typename BP::T *st, bool active_in) {
   typedef typename BP::T BT;
   constexpr bool kShort = sizeof(BT) == 2;
-  const uint32_t rm = RING ? static_cast<uint32_t>(RING - 1) : rm_in;
-  const uint32_t R = rm + 1u;
-  auto wrap = [&](uint32_t x) __attribute__((always_inline)) -> uint32_t { return x >= R ? x - R : x; };
-  const float unk_score = d.unk_score, max_score = d.max_score;
+  constexpr uint32_t rm = static_cast<uint32_t>(RC - 1);
+  const float unk_score = d.unk_score;
   const uint32_t unk_word = static_cast<uint32_t>(d.unk_id) & kCsIdMask;
   const bool active = active_in && nlen > 0 && n_ent > 0;
   if (!active) n_ent = 0;
-  int s = 0, mb = 0;
-  uint32_t s_slot = 0;
+  int s = 0, mb = 0;                               // the start's byte position, its character's bytes
+  uint32_t sc = 0;                                 // ... its position in characters
   float sbest = 0.f;
   if (active) {
     for (uint32_t k = 0; k <= rm; ++k) ring_b[k * 64] = 0;
     ring_s[0] = 0.f;                               // best_path_ends_at[0].best_path_score = 0
   }
+  // (the staging block is written entry by entry -- 16-bit entries in the short form -- and moved as 16-byte units: by
+  // memcpy, which may alias anything -- a typed 16-byte read may legally be scheduled before the last entry's store, and
+  // g++ -O2 did exactly that in the emulator build; both compilers turn these into single 16-byte moves)
   auto put_block = [&](int blk_index) __attribute__((always_inline)) {
     BT *blk = gb.blk(blk_index);
     if (kShort) {
-      *reinterpret_cast<Q4 *>(blk) = *reinterpret_cast<const Q4 *>(st);
+      __builtin_memcpy(__builtin_assume_aligned(blk, 16), __builtin_assume_aligned(st, 16), 16);
     } else {
-      const Q4 lo = *reinterpret_cast<const Q4 *>(st), hi = *reinterpret_cast<const Q4 *>(st + 256);
-      *reinterpret_cast<Q4 *>(blk) = lo;
-      *reinterpret_cast<Q4 *>(blk + 4) = hi;
+      __builtin_memcpy(__builtin_assume_aligned(blk, 16), __builtin_assume_aligned(st, 16), 16);
+      __builtin_memcpy(__builtin_assume_aligned(blk + 4, 16), __builtin_assume_aligned(st + 256, 16), 16);
     }
   };
-  // the start moves on by its character (:1007): position s + mb is final -- its entry goes to the staging block, the
-  // block of 8 positions left behind to HBM, the ring slots of the positions passed are freed
+  // the start moves on by its character (:1007): the position behind it is final -- its entry goes to the staging block,
+  // the block of 8 byte positions left behind to HBM, its ring slot is free for the character RC further on
   auto advance = [&]() __attribute__((always_inline)) {
     const int s2 = s + mb;
-    const uint32_t slB = RING ? (static_cast<uint32_t>(s2) & rm) : wrap(s_slot + static_cast<uint32_t>(mb));
-    const BT finB = ring_b[slB << 6];
-    sbest = ring_s[slB << 6];
+    const uint32_t slB = ((sc + 1u) & rm) << 6;
+    const BT finB = ring_b[slB];
+    sbest = ring_s[slB];
     if ((s2 >> 3) != (s >> 3)) put_block(s >> 3);
     if (kShort) st[static_cast<uint32_t>(s2) & 7u] = finB;
     else st[((static_cast<uint32_t>(s2) >> 2) & 1u) * 256u + (static_cast<uint32_t>(s2) & 3u)] = finB;
-    for (int k = 0; k < mb; ++k)
-      ring_b[(RING ? (static_cast<uint32_t>(s2 - k) & rm) : (slB >= static_cast<uint32_t>(k) ? slB - static_cast<uint32_t>(k) : slB + R - static_cast<uint32_t>(k))) << 6] = 0;
+    ring_b[slB] = 0;
     s = s2;
-    s_slot = slB;
+    ++sc;
   };
   auto step = [&](uint32_t x, uint32_t y, int k) __attribute__((always_inline)) {
     if (k >= n_ent) return;
@@ -265,21 +283,16 @@ SPMX_DEVICE int fold_stream_lane(const SpmxDev &d, const U2 *cs, int n_ent, cons
       if (k > 0) advance();
       mb = static_cast<int>((x >> kCsMbShift) & 3u) + 1;
     }
-    const int len = static_cast<int>((x >> kCsLenShift) & 0x7Fu);
+    const int len = static_cast<int>((x >> kCsLenShift) & 0x3Fu);
     const uint32_t id = x & kCsIdMask;
-    const uint32_t sl = (RING ? (static_cast<uint32_t>(s + len) & rm) : wrap(s_slot + static_cast<uint32_t>(len))) << 6;
+    const uint32_t sl = ((sc + ((x >> kCsNchShift) & 15u)) & rm) << 6;
     const BT b = ring_b[sl];
     const float r = ring_s[sl];
     if (id == unk_word) {                                                            // :995-1005, float arithmetic
       const float cand = unk_score + sbest;
       if (b == 0 || cand > r) { ring_s[sl] = cand; ring_b[sl] = BP::unk(len); }
     } else {
-      double score = static_cast<double>(wv::bits_to_float(y));
-      if (x & 0x00800000u) {                                                         // (length * max_score_ - 0.1), :979-981
-        const float prod = static_cast<float>(len) * max_score;
-        score = static_cast<double>(prod) - 0.1;
-      }
-      const double cand = score + static_cast<double>(sbest);                        // :982-983
+      const double cand = static_cast<double>(wv::bits_to_float(y)) + static_cast<double>(sbest);   // :982-983
       if (b == 0 || cand > static_cast<double>(r)) {                                  // :984-989
         ring_s[sl] = static_cast<float>(cand);
         ring_b[sl] = BP::piece(id, len);

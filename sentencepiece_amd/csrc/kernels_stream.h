@@ -486,7 +486,9 @@ SPMX_DEVICE void append_lanes(uint64_t m, bool mine, uint32_t sid, uint32_t *lis
 
 // Persistent body of the streaming kernels.  MODEL: 1 unigram, 2 BPE (word-wise models only).  RING: see
 // unigram_stream_lane (0 = a.ring).  UDS: the model may have USER_DEFINED pieces.
-template <int MODEL, int RING, bool UDS, typename BP = BpWord>
+// SPLIT_ONLY: every tile of the launch takes the split form (kernels_matchfold.h; EncodeSplitKernel): the lane-per-sentence
+// normalizers and search are not even compiled in, and the wavefront's LDS slice is the split form's own (12 per CU).
+template <int MODEL, int RING, bool UDS, typename BP = BpWord, bool SPLIT_ONLY = false>
 SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
   typedef typename BP::T BT;
   constexpr uint32_t kBpSz = sizeof(BT);
@@ -553,7 +555,7 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     const TextCol gt{reinterpret_cast<uint32_t *>(slab) + lane, lane_shift};
     const BpCol<BT> gb{reinterpret_cast<BT *>(slab + text_bytes) + static_cast<uint32_t>(lane) * 8u, lane_shift};
     // split form (kernels_matchfold.h): the lanes' candidate streams lie behind the tile's text and back-pointer blocks
-    const bool split = MODEL == 1 && !UDS && !backlog && sc.split != 0u;
+    const bool split = SPLIT_ONLY || (MODEL == 1 && !UDS && !backlog && sc.split != 0u);
     const uint64_t cs_stride = MatchStreamBytes(sc.ccap);
     const U2 *my_cs = reinterpret_cast<const U2 *>(slab + StreamSplitBase(tcap, ring, lane_shift, kBpSz) + static_cast<uint64_t>(lane) * cs_stride);
     int my_nent = 0;
@@ -711,8 +713,15 @@ SPMX_DEVICE void encode_stream_block(const EncodeArgs &a, unsigned char *smem) {
     if (MODEL == 1) {
       // ---- segment, then backtrack: the slot is filled from its end (or from its start when reversing) ----
       if (split) {
+        // the fold's rings are indexed by character (a.split_ring = 8 or 16 entries): its own layout of the wave's slice
         wv::sync();
-        tc.n_trips += static_cast<unsigned long long>(fold_stream_lane<RING, BP>(d, my_cs, my_nent, gb, my_nlen, my_rs, my_rb, rm, my_st, mine));
+        const uint32_t rc = a.split_ring;
+        float *f_rs = reinterpret_cast<float *>(T.rawwin) + lane;
+        BT *f_rb = reinterpret_cast<BT *>(T.rawwin + 64u * rc * 4u) + lane;
+        BT *f_st = reinterpret_cast<BT *>(T.rawwin + 64u * rc * (4u + kBpSz)) + (kBpSz == 2 ? static_cast<uint32_t>(lane) * 8u : static_cast<uint32_t>(lane) * 4u);
+        if (rc == 8u) tc.n_trips += static_cast<unsigned long long>(fold_stream_lane<8, BP>(d, my_cs, my_nent, gb, my_nlen, f_rs, f_rb, f_st, mine));
+        else tc.n_trips += static_cast<unsigned long long>(fold_stream_lane<16, BP>(d, my_cs, my_nent, gb, my_nlen, f_rs, f_rb, f_st, mine));
+        wv::sync();
       } else {
         tc.n_trips += static_cast<unsigned long long>(
             unigram_stream_lane<RING, UDS, BP>(d, gt, gb, my_nlen, my_rs, my_rb, rm, my_win, W - 1u, my_st, T.roottab, mine));

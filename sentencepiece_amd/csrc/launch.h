@@ -35,6 +35,8 @@ inline uint32_t ScoreRing(int max_piece_len) {
 // One streaming launch (kernels_stream.h): model_type 1 unigram / 2 BPE; uds: the model has USER_DEFINED pieces
 hipError_t LaunchEncodeStream(int model_type, bool uds, const EncodeArgs &a, int grid, int waves,
                               uint32_t lds_bytes, hipStream_t stream);
+// the same launch with EVERY tile in the split form (kernels_matchfold.h): unigram, no user-defined pieces
+hipError_t LaunchEncodeSplit(const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t stream);
 // The word kernel (kernels_word.h): unigram models with kNfUniWordwise
 // mode: 0 plain first pass, 1 collecting first pass, 2 second round over the call-local memo, 3 the DP pass
 hipError_t LaunchEncodeWord(int mode, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t stream);

@@ -376,7 +376,15 @@ Status CompileTables(const ModelData &m, HostTables *t) {
     if (!BuildDat(keys, &d, &err)) return Status::Error(kInternal, "piece trie: " + err);
     t->max_piece_len = d.max_key_len;
     t->max_prefixes = d.max_prefixes;
-    t->split_ok = blob_utf8 && uds_keys.empty() && m.pieces.size() < (1u << 21) && d.max_prefixes >= 1 && d.max_prefixes <= 16;
+    t->max_piece_chars = 0;
+    for (const auto &kv : keys) {
+      int nc = 0;
+      for (unsigned char ch : kv.first) nc += (ch & 0xC0u) != 0x80u;
+      if (nc > t->max_piece_chars) t->max_piece_chars = nc;
+    }
+    // (the candidate word of the split form holds 19 bits of id, 6 of byte length, 4 of character length)
+    t->split_ok = blob_utf8 && uds_keys.empty() && m.pieces.size() < (1u << 19) && d.max_prefixes >= 1 && d.max_prefixes <= 16 &&
+                  d.max_key_len <= 63 && t->max_piece_chars <= 15;
     if (d.max_key_len > kMaxPieceBytes)
       return Status::Error(kUnimplemented, "a piece is longer than 120 bytes; unsupported by the device unigram path");
     t->ptrie.resize(d.w0.size());

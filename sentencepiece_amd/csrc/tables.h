@@ -40,6 +40,7 @@ struct HostTables {
   // the split form (kernels_matchfold.h) may take this model: unigram, no user-defined pieces, every replacement string of
   // the charsmap valid UTF-8 (then so is the normalized text, and its character starts are its non-continuation bytes)
   bool split_ok = false;
+  int max_piece_chars = 0;       // the longest piece in characters (bytes that continue no character), of the device form
 };
 
 // Builds everything that depends only on load-time structure.

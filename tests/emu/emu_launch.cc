@@ -43,6 +43,11 @@ hipError_t LaunchEncodeStream(int model_type, bool uds, const EncodeArgs &a, int
   }
   return hipSuccess;
 }
+hipError_t LaunchEncodeSplit(const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t) {
+  if (a.bp_short) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<1, 0, false, BpShort, true>(a, s); });
+  else RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_stream_block<1, 0, false, BpWord, true>(a, s); });
+  return hipSuccess;
+}
 hipError_t LaunchEncodeWord(int mode, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t) {
   if (mode == 3) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_word_block<true, kWmPlain>(a, s); });
   else if (mode == 2) RunGrid(grid, waves, lds_bytes, [&](unsigned char *s) { encode_word_block<false, kWmDyn>(a, s); });

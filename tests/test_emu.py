@@ -705,15 +705,21 @@ def test_emu_split_form_is_the_default_for_long_classes(emu, oracle, corpora):
     sentences of the mixed-script corpus through the default plan (class table and thresholds as shipped)."""
     from sentencepiece_amd import synth
     blob = fixtures.model_blob("c5_250k")
-    h = emu.load(blob, classes=None, env={"SPMX_NO_WORD_KERNEL": "1"})
     o = oracle.load(blob)
     t, of = corpora["mixed2k"]
     n = len(of) - 1
     text, offs = synth.gather_packed(t, of, np.arange(n - 24, n))
-    ids, io = h.encode_batch(text, offs)
     oids, oio = o.encode_batch(text, offs)
-    np.testing.assert_array_equal(io, oio)
-    np.testing.assert_array_equal(ids, oids)
-    trips = [c["phase_cycles"]["search_trips"] for c in h.sp.LastProfile()["classes"] if c["kernel"].startswith("EncodeStream")]
-    # the fold counts blocks of 16 candidates, the lane-per-sentence search one probe per iteration: thousands against tens of thousands
-    assert trips and max(trips) < 4096 * 2, trips
+    for own in ("0", "1"):          # split tiles beside lane tiles in one launch (the default), or in a launch of their own
+        h = emu.load(blob, classes=None, env={"SPMX_NO_WORD_KERNEL": "1", "SPMX_SPLIT_LAUNCH": own})
+        ids, io = h.encode_batch(text, offs)
+        np.testing.assert_array_equal(io, oio)
+        np.testing.assert_array_equal(ids, oids)
+        prof = h.sp.LastProfile()["classes"]
+        if own == "1":
+            split = [c for c in prof if c["kernel"].startswith("EncodeSplit")]
+            assert split and split[0]["sentences"] == 24, prof
+        else:
+            # the fold counts blocks of 16 candidates, the lane-per-sentence search one probe per iteration
+            trips = [c["phase_cycles"]["search_trips"] for c in prof if c["kernel"].startswith("EncodeStream")]
+            assert trips and max(trips) < 4096 * 2, trips
