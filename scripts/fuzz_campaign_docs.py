@@ -7,7 +7,7 @@ from tests import fixtures, oraclelib, emulib
 em = emulib.EmuLib(); orc = oraclelib.OracleLib()
 t_end = time.time() + float(sys.argv[1])
 seed = int(sys.argv[2])
-MODELS = ["bpe1k", "bpe1k_llama", "bpe32k", "test_model", "uni1k_bf", "uni1k_ident"]
+MODELS = ["bpe1k", "bpe1k_llama", "bpe32k", "test_model", "uni1k_bf", "uni1k_ident", "uni1k_uds", "test_ja_model", "uni1k_suffix", "uni32k"]
 handles = {m: (em.load(fixtures.model_blob(m)), orc.load(fixtures.model_blob(m))) for m in MODELS}
 al = b"abcdefghijklmnopqrstuvwxyz0123456789/_-.%=&?ABCXYZ"
 bad = 0

@@ -75,6 +75,7 @@ struct Ctrl {
   unsigned long long pool_head;       // long form: bytes of slices asked for
   unsigned long long stats[kStatsPerClass * kNumSlots];
   unsigned long long bad_key;         // decode: min over offending (sentence << 32 | id)
+  uint32_t big_count[2];              // CompactKernel: document blocks listed for CompactBigKernel (ids; token begins of the spans form)
   uint64_t total_ids;                 // copied from id_offs[n] by the final D2H
 };
 
@@ -212,6 +213,7 @@ struct Profile {
 struct Workspace {
   DevBuf<uint32_t> d_lists, d_counts;
   DevBuf<uint64_t> d_tmp_off, d_tile_sums, d_chunk_base;
+  DevBuf<uint32_t> d_big_list;   // CompactKernel's list of document blocks (kernels.h compact_big_block)
   DevBuf<int32_t> d_arena, d_arena_tb, d_tok_begin;
   DevBuf<uint32_t> d_span_begin, d_span_end, d_nspan_begin, d_nspan_end;
   DevBuf<uint8_t> d_norm, d_nbest_scratch, d_slab, d_pool, d_sent_status, d_flags;
@@ -244,7 +246,7 @@ struct Workspace {
   Profile prof;
 
   ~Workspace() {
-    d_lists.Free(); d_counts.Free(); d_tmp_off.Free(); d_tile_sums.Free(); d_chunk_base.Free(); d_arena.Free();
+    d_lists.Free(); d_counts.Free(); d_tmp_off.Free(); d_tile_sums.Free(); d_chunk_base.Free(); d_big_list.Free(); d_arena.Free();
     d_arena_tb.Free(); d_tok_begin.Free(); d_span_begin.Free(); d_span_end.Free(); d_nspan_begin.Free(); d_nspan_end.Free();
     d_norm.Free(); d_nbest_scratch.Free(); d_slab.Free(); d_pool.Free(); d_sent_status.Free(); d_flags.Free(); d_res_off.Free();
     d_res_score.Free(); d_dyn_tag.Free(); d_dyn_ent.Free(); d_dyn_list.Free(); d_resume.Free(); d_text.Free(); d_offs.Free(); d_id_offs.Free(); d_ids.Free(); d_dn_text.Free(); d_dn_offs.Free();
@@ -324,6 +326,8 @@ struct spmx_handle {
   bool split_own_launch = false; // SPMX_SPLIT_LAUNCH=1: the split classes get a launch of their own (EncodeSplitKernel)
   uint32_t split_tiles = 1;      // SPMX_SPLIT_TILES: split tiles per wavefront and class the planner aims at (their match phase is sequential: small tiles balance, large tiles fold more lanes at once)
   uint32_t split_per_byte = 4;   // SPMX_SPLIT_CANDS: candidates per normalized byte a sentence's stream holds before the overflow launch takes the sentence
+  uint32_t compact_big = kCompactBigIds;   // CompactKernel: blocks with more ids go to CompactBigKernel (0: none do)
+  bool uw_exact = false;
   bool no_uni_wave = false;      // SPMX_NO_UNI_WAVE=1: unigram models never take the wave-cooperative form (kernels_uniwave.h)
   uint32_t uni_wave_max = 0;     // SPMX_UNI_WAVE_MAX: a staged class with fewer sentences than this takes the wave-cooperative form
   int word_wgs = 1;              // SPMX_WORD_WGS: workgroups per CU of the word kernel's first pass
@@ -749,6 +753,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
   HIP_OR_RETURN(h, ws->d_counts.Reserve(n + 1));
   HIP_OR_RETURN(h, ws->d_tmp_off.Reserve(n + 1));
   HIP_OR_RETURN(h, ws->d_tile_sums.Reserve((n + kScanTile - 1) / kScanTile + 2));
+  HIP_OR_RETURN(h, ws->d_big_list.Reserve((n + 63) / 64 + 1));
   if (!d_status) { HIP_OR_RETURN(h, ws->d_sent_status.Reserve(n)); d_status = ws->d_sent_status.p; }
   uint32_t *const class_lists = ws->d_lists.p;
   uint32_t *const over_list = class_lists + static_cast<size_t>(kMaxClasses - 1) * n;
@@ -786,10 +791,15 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
     // the GPU, found again under ASAN on the emulator).  The compaction looks at the status word ITSELF (round 6: the host
     // used to read it back first -- one more synchronisation per call); the caller re-runs the batch with the arena
     // arena_head asks for.
-    CompactArgs pa{ws->d_arena.p, ws->d_tmp_off.p, ws->d_counts.p, d_id_offsets, d_ids, d_ids ? ids_capacity : 0, n32, &ws->d_ctrl->status, h->compact_staged};
+    // (blocks of documents go to a second launch, by the whole chip; a batch of ten million short sentences has none and
+    // does not pay for that launch)
+    const uint32_t big = (n < 65536 || text_bytes > 160ull * n) ? h->compact_big : 0u;
+    CompactArgs pa{ws->d_arena.p, ws->d_tmp_off.p, ws->d_counts.p, d_id_offsets, d_ids, d_ids ? ids_capacity : 0, n32, &ws->d_ctrl->status, h->compact_staged,
+                   big, ws->d_big_list.p, &ws->d_ctrl->big_count[0]};
     const uint64_t cblocks = (n + 63) / 64;
     const uint64_t cgrid = cblocks < static_cast<uint64_t>(h->n_cu) * 32 ? cblocks : static_cast<uint64_t>(h->n_cu) * 32;
     HIP_OR_RETURN(h, LaunchCompact(pa, static_cast<int>(cgrid), stream));
+    if (big) HIP_OR_RETURN(h, LaunchCompactBig(pa, h->n_cu * 4, stream));   // (returns at once when CompactKernel listed none)
     HIP_OR_RETURN(h, hipMemcpyAsync(ws->h_ctrl, ws->d_ctrl, offsetof(Ctrl, total_ids), hipMemcpyDeviceToHost, stream));
     HIP_OR_RETURN(h, hipMemcpyAsync(&ws->h_ctrl->total_ids, d_id_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
     HIP_OR_RETURN(h, hipStreamSynchronize(stream));      // (the call returns with its outputs complete)
@@ -887,7 +897,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
     auto long_launch = [&](const uint32_t *list, const uint32_t *d_count, uint32_t count, bool uni = false) -> int {
       if (count == 0) return kOk;
       LongArgs la{};
-      la.dev = h->dev; la.text = d_text; la.offs = d_offsets;
+      la.dev = h->dev; if (h->uw_exact) la.dev.uw_f32_limit = 0.f; la.text = d_text; la.offs = d_offsets;
       la.arena = ws->d_arena.p; la.arena_head = &ws->d_ctrl->arena_head; la.arena_cap = a.arena_cap;
       la.tmp_off = ws->d_tmp_off.p; la.counts = ws->d_counts.p; la.sent_status = d_status; la.status = &ws->d_ctrl->status;
       la.side = &ws->d_ctrl->side; la.arena_tb = spans ? ws->d_arena_tb.p : nullptr;
@@ -911,7 +921,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         if (g > static_cast<uint64_t>(h->n_cu) * 16) g = static_cast<uint64_t>(h->n_cu) * 16;
         snprintf(ws->slot_name[kSlotLong], sizeof(ws->slot_name[kSlotLong]), uni ? "UniLongKernel" : "BpeLongKernel");
         if (!ws->slot_used[kSlotLong]) HIP_OR_RETURN(h, record(kSlotLong, 0));
-        if (uni) HIP_OR_RETURN(h, LaunchUniLong(la, static_cast<uint32_t>(h->tables.max_prefixes), static_cast<int>(g), stream));
+        if (uni) HIP_OR_RETURN(h, LaunchUniLong(la, UniWaveRow(h->tables.max_piece_len), static_cast<int>(g), stream));
         else HIP_OR_RETURN(h, LaunchBpeLong(la, static_cast<int>(g), stream));
         HIP_OR_RETURN(h, record(kSlotLong, 1));
         ws->slot_used[kSlotLong] = true;
@@ -938,7 +948,7 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
     // most of the batch (a batch OF documents: one lane per document would leave the chip idle), not when they are a
     // tail of a batch of sentences (there they hide behind the main launch's other tiles).
     const bool uni_wave = !is_bpe && !spans && h->tables.max_prefixes >= 1 &&
-                          h->tables.max_prefixes <= static_cast<int>(kUwMaxCands) && !h->no_uni_wave;
+                          h->tables.max_piece_len <= static_cast<int>(kUwMaxPiece) && !h->no_uni_wave;
     bool uni_class[kMaxClasses] = {false};
     if (uni_wave) {
       uint64_t vol_staged = 0, vol_mid = 0;
@@ -1355,10 +1365,12 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
       // token begins to CSR order, then one align launch per staged length class over the classify lists
       const uint64_t total = ws->h_ctrl->total_ids;
       HIP_OR_RETURN(h, ws->d_tok_begin.Reserve(total));
-      CompactArgs pa{ws->d_arena_tb.p, ws->d_tmp_off.p, ws->d_counts.p, d_id_offsets, ws->d_tok_begin.p, total, n32, nullptr, h->compact_staged};
+      CompactArgs pa{ws->d_arena_tb.p, ws->d_tmp_off.p, ws->d_counts.p, d_id_offsets, ws->d_tok_begin.p, total, n32, nullptr, h->compact_staged,
+                     h->compact_big, ws->d_big_list.p, &ws->d_ctrl->big_count[1]};
       const uint64_t cblocks = (n + 63) / 64;
       const uint64_t cgrid = cblocks < static_cast<uint64_t>(h->n_cu) * 32 ? cblocks : static_cast<uint64_t>(h->n_cu) * 32;
       HIP_OR_RETURN(h, LaunchCompact(pa, static_cast<int>(cgrid), stream));
+      if (h->compact_big) HIP_OR_RETURN(h, LaunchCompactBig(pa, h->n_cu * 4, stream));
       HIP_OR_RETURN(h, hipMemsetAsync(&ws->d_ctrl->status, 0, sizeof(uint32_t), stream));
       HIP_OR_RETURN(h, hipMemsetAsync(ws->d_ctrl->align_counts, 0, sizeof(ws->d_ctrl->align_counts), stream));
       HIP_OR_RETURN(h, hipMemsetAsync(&ws->d_ctrl->side.long_count, 0, sizeof(uint32_t), stream));
@@ -1661,6 +1673,8 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_NBEST_BUDGET_GB")) { const long v = atol(e); if (v >= 1 && v <= 200) h->nbest_budget = static_cast<uint64_t>(v) << 30; }
 #ifdef SPMX_TEST_SEAMS   // (the emulator build, tests/emu/Makefile: the release library reads none of these)
     if (getenv("SPMX_WORDMEMO_UNSAFE")) h->memo_unsafe = true;
+    if (getenv("SPMX_UW_EXACT")) h->uw_exact = true;   // the wave-cooperative form folds in double arithmetic only (kernels_uniwave.h uw_fold_exact)
+    if (const char *e = getenv("SPMX_COMPACT_BIG")) h->compact_big = static_cast<uint32_t>(atoll(e));   // ids of a block that goes to CompactBigKernel (0: none does)
     // A/B switches of settled experiments (their measurements: DESIGN.md section 4, profiles/)
     if (const char *e = getenv("SPMX_NO_WORD_DP")) h->no_word_dp = e[0] == '1';
     if (const char *e = getenv("SPMX_NBEST_HYPS_MIN")) { const long v = atol(e); if (v >= 1024 && v <= 262144) h->nbest_hyps_min = static_cast<uint32_t>(v); }

@@ -110,6 +110,12 @@ struct SpmxDev {
   const U4 *cfirst;
   float unk_score;        // min_score - 10.0f
   float max_score;
+  // The wave-cooperative form's fold in FLOAT arithmetic (kernels_uniwave.h): while every best_path_score it adds to
+  // stays above -uw_f32_limit, the reference's (double)score + (double)best is EXACT (two floats whose exponents differ
+  // by at most 28 have a sum of at most 53 bits), so the float it stores is the float sum and its comparison is the float
+  // sum's plus, on a tie, the sign of the sum's rounding error.  0: not for this model (a score above 0, user-defined
+  // pieces -- their score is a double --, scores too far apart).  tables.cc UwFloatLimit.
+  float uw_f32_limit;
   int32_t unk_id;
   // ---- id post-processing (reference: src/sentencepiece_processor.cc:547-636) ----
   const int32_t *byte_ids;   // [256]

@@ -1140,7 +1140,14 @@ struct CompactArgs {
   const uint32_t *status = nullptr;   // the call's kSt* bits (null: not looked at): after an arena overflow nothing is moved -- some
                                       // kernels leave the range they ASKED for in tmp_off / counts, beyond the arena's end
   uint32_t staged = 2048;   // ids the LDS image of a wave holds: blocks of 16-bit ids go through it (0: the search form for every block)
+  // blocks of more than big_ids ids (documents) are not moved by their wave: it lists them, and the launch behind
+  // (compact_big_block) moves them with every wave of its grid (0 / null: no such list, every block is moved here)
+  uint32_t big_ids = 0;
+  uint32_t *big_list = nullptr;     // [(n + 63) / 64]
+  uint32_t *big_count = nullptr;
 };
+constexpr uint32_t kCompactBigIds = 32768;     // a block of 64 sentences with more ids than this is a block of documents
+constexpr uint32_t kCompactBigChunk = 8192;    // ids of one work item of compact_big_block
 
 // LDS of a CompactKernel wave: the 16-bit ids of its 64 sentences (or of a half, a quarter of them), in CSR order
 constexpr uint32_t kCompactLdsIdsMax = 16384;
@@ -1188,6 +1195,10 @@ SPMX_DEVICE void compact_block(const CompactArgs &a, uint16_t *lds) {
     const uint32_t rel = static_cast<uint32_t>(my_dst - dst0);
     const uint32_t src_lo = static_cast<uint32_t>(my_src), src_hi = static_cast<uint32_t>(my_src >> 32);
     my_dst = n_dst; my_src = n_src; end_dst = n_end;
+    if (a.big_ids != 0u && total > a.big_ids) {   // documents: for every wave of the launch behind
+      if (lane == 0) a.big_list[wv::atomic_add(a.big_count, 1u)] = b;
+      continue;
+    }
     // the block as one part, two halves or four quarters of its lanes: the fewest whose ids each fit the image
     uint32_t parts = 0u;
     if (cap) {
@@ -1275,6 +1286,55 @@ SPMX_DEVICE void compact_block(const CompactArgs &a, uint16_t *lds) {
       const uint32_t hi = wv::shfl(src_hi, lo);
       const uint64_t base = (static_cast<uint64_t>(hi & 0x7FFFFFFFu) << 32) | wv::shfl(src_lo, lo);
       if (j < total) a.ids[dst0 + j] = (hi >> 31) ? static_cast<int32_t>(arena16[base + (j - r0)]) : a.arena[base + (j - r0)];
+    }
+  }
+}
+
+// The blocks compact_block listed (documents: 64 sentences of 230 K ids each would keep ONE wave busy for 40 ms while the
+// chip idles -- 158 of the 611 ms of round 5's 256 x 1 MiB step): their sentences, cut into items of kCompactBigChunk
+// ids, dealt round-robin to every wave of the grid; an item is one coalesced stream.
+SPMX_DEVICE void compact_big_block(const CompactArgs &a) {
+  const int lane = wv::lane();
+  const uint32_t listed = *a.big_count;
+  if (listed == 0u) return;
+  if (a.id_offs[a.n] > a.ids_cap) return;
+  if (a.status != nullptr && (*a.status & kStArenaOverflow)) return;
+  const uint16_t *arena16 = reinterpret_cast<const uint16_t *>(a.arena);
+  const uint64_t nw = static_cast<uint64_t>(wv::grid_size());
+  uint64_t w = 0, mine = static_cast<uint64_t>(wv::block_id());      // items so far; this wave's next item
+  for (uint32_t i = 0; i < listed; ++i) {
+    const uint32_t b = a.big_list[i];
+    const uint32_t s = b * 64u + static_cast<uint32_t>(lane);
+    const bool have = s < a.n;
+    const uint64_t dst = have ? a.id_offs[s] : 0u;
+    const uint64_t src = have ? a.tmp_off[s] : 0u;
+    const uint32_t cnt = have ? static_cast<uint32_t>(a.id_offs[s + 1u] - dst) : 0u;
+    for (int k = 0; k < 64; ++k) {
+      const uint32_t c = wv::shfl(cnt, k);
+      const uint64_t items = (static_cast<uint64_t>(c) + kCompactBigChunk - 1u) / kCompactBigChunk;
+      if (w + items <= mine) { w += items; continue; }
+      const uint64_t d0 = (static_cast<uint64_t>(wv::shfl(static_cast<uint32_t>(dst >> 32), k)) << 32) | wv::shfl(static_cast<uint32_t>(dst), k);
+      const uint32_t s_hi = wv::shfl(static_cast<uint32_t>(src >> 32), k), s_lo = wv::shfl(static_cast<uint32_t>(src), k);
+      const uint64_t base = (static_cast<uint64_t>(s_hi & 0x7FFFFFFFu) << 32) | s_lo;
+      const bool half = (s_hi >> 31) != 0u;
+      for (; mine < w + items; mine += nw) {
+        const uint32_t j0 = static_cast<uint32_t>(mine - w) * kCompactBigChunk;
+        const uint32_t j1 = j0 + kCompactBigChunk < c ? j0 + kCompactBigChunk : c;
+        for (uint32_t j = j0 + static_cast<uint32_t>(lane); j < j1; j += 256u) {   // four loads in flight
+          int32_t v[4];
+#pragma unroll
+          for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t jj = j + 64u * u;
+            v[u] = jj < j1 ? (half ? static_cast<int32_t>(arena16[base + jj]) : a.arena[base + jj]) : 0;
+          }
+#pragma unroll
+          for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t jj = j + 64u * u;
+            if (jj < j1) a.ids[d0 + jj] = v[u];
+          }
+        }
+      }
+      w += items;
     }
   }
 }

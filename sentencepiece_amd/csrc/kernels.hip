@@ -81,9 +81,10 @@ __global__ __launch_bounds__(64) void BpeLongKernel(LongArgs a) {
   bpe_long_block(a, smem);
 }
 
-__global__ __launch_bounds__(64) void UniLongKernel(LongArgs a, uint32_t cands) {
+template <uint32_t ML>
+__global__ __launch_bounds__(64) void UniLongKernel(LongArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uni_long_block(a, smem, cands);
+  uni_long_block<ML>(a, smem);
 }
 
 __global__ __launch_bounds__(64) void NormalizeLongCountKernel(NormalizeArgs a) {
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(64) void CompactKernel(CompactArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char compact_image[];
   compact_block(a, reinterpret_cast<uint16_t *>(compact_image));
 }
+__global__ __launch_bounds__(64) void CompactBigKernel(CompactArgs a) { compact_big_block(a); }
 __global__ __launch_bounds__(64) void RebaseOffsetsKernel(RebaseArgs a) { rebase_block(a); }
 
 namespace {
@@ -223,7 +225,9 @@ hipError_t LaunchBpeLong(const LongArgs &a, int grid, hipStream_t stream) {
 }
 
 hipError_t LaunchUniLong(const LongArgs &a, uint32_t cands, int grid, hipStream_t stream) {
-  hipLaunchKernelGGL(UniLongKernel, dim3(grid), dim3(64), UniWaveLdsBytes(cands), stream, a, cands);
+  if (cands == 16u) hipLaunchKernelGGL(UniLongKernel<16>, dim3(grid), dim3(64), UniWaveLdsBytes(16), stream, a);
+  else if (cands == 32u) hipLaunchKernelGGL(UniLongKernel<32>, dim3(grid), dim3(64), UniWaveLdsBytes(32), stream, a);
+  else hipLaunchKernelGGL(UniLongKernel<64>, dim3(grid), dim3(64), UniWaveLdsBytes(64), stream, a);
   return hipGetLastError();
 }
 
@@ -302,6 +306,10 @@ hipError_t LaunchRebase(const RebaseArgs &a, int grid, hipStream_t stream) {
 
 hipError_t LaunchCompact(const CompactArgs &a, int grid, hipStream_t stream) {
   hipLaunchKernelGGL(CompactKernel, dim3(grid), dim3(64), CompactLdsBytes(a.staged), stream, a);
+  return hipGetLastError();
+}
+hipError_t LaunchCompactBig(const CompactArgs &a, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL(CompactBigKernel, dim3(grid), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
 

@@ -1,73 +1,161 @@
-// Unigram segmentation, WAVE-COOPERATIVE form: one SENTENCE PER WAVEFRONT, exact for any model and any length.
+// Unigram segmentation, WAVE-COOPERATIVE form: one SENTENCE PER WAVEFRONT, exact for any length.
 // Reference: unigram::Model::EncodeOptimized (src/unigram_model.cc:889-1020).
 //
 // The lane-per-sentence kernels (kernels_stream.h, kernels_word.h) need tens of thousands of sentences to fill the
 // chip and give one sentence a single lane: a document of a megabyte is 2.6 s of dependent iterations there.  This form
-// gives a sentence the whole wavefront, 64 consecutive character starts at a time:
+// gives a sentence the whole wavefront, 64 consecutive byte positions at a time:
 //
 //   walk   (parallel) lane l walks the piece trie from start c + l -- the reference's inner loop (:965-993) -- and
-//          writes what it finds, piece by piece in order of length, into its row of an LDS candidate list.  Which
-//          pieces match at a start does not depend on any score, so the 64 walks are independent;
-//   fold   the relaxations of best_path_ends_at in the reference's order: starts ascending one after another, a start's
-//          candidates (distinct end positions) side by side, then the UNK candidate (:995-1005); same arithmetic -- double add, double compare
-//          against the float stored, float store (:979-989).  The scores of the last 256 positions live in an LDS
-//          ring; id and length of every position's best piece go to the sentence's bid / blen arrays;
-//   then the backtrack (:1010-1018) marks the token ends and emit_wave (kernels.h) writes the ids.
+//          writes what it finds into row l of an LDS matrix indexed by LENGTH: entry [l][k - 1] is the piece of k bytes
+//          that begins at c + l (none: a NaN score).  Which pieces match at a start does not depend on any score, so the
+//          64 walks are independent.  The UNK candidate of a start without a one-character piece (:995-1005) is the
+//          entry at the character's length (no piece is there);
+//   fold   the relaxations of best_path_ends_at in the reference's order, starts ascending one after another, with the
+//          scores in REGISTERS (round 6): lane j holds best_path_ends_at[c + j] (-inf: no candidate yet) and, in a
+//          second pair of registers, [c + 64 + j]: what a piece that begins in this chunk can reach beyond it.  A step
+//          takes the start's final score with one v_readlane, and lane j relaxes ITS position with the start's piece
+//          that ends there -- entry [l][j - l - 1], one conflict-free LDS read that does not depend on the step before;
+//          the pieces of one start end at different positions, so the order among them does not matter (:973-993).
+//          The arithmetic is the reference's -- double add, double compare against the float stored, float store
+//          (:979-989), the UNK candidate in float -- in one of two forms:
+//            exact   (uw_fold_exact) as written: ~45 instructions a step, of which the seven 64-bit ones alone cost
+//                    150 cycles (scripts/ubench/fold_probe.hip: 316 cycles a step);
+//            float   (uw_fold_float) while |best_path_score| stays below the model's uw_f32_limit (dev.h) the double
+//                    sum of the two floats is EXACT, so what the reference stores is the float sum, and its comparison
+//                    is the float sum's except on a tie of the rounded values, where the sign of the rounding error
+//                    decides.  The step is one add, two compares, three selects with the start a compile-time
+//                    constant (64 steps unrolled; 88 cycles a step in the probe); a tie is only RECORDED, and a chunk
+//                    that saw one is folded again the exact way from the scores it began with;
+//   then id and length of every position's best piece go to the sentence's bid / blen arrays, the backtrack
+//   (:1010-1018) marks the token ends and emit_wave (kernels.h) writes the ids.
 //
 // The sentence's arrays (normalized text, bid, blen) live in a slice of the long form's HBM pool (kernels_long.h), so
-// nothing here depends on the sentence length; normalization is norm_lane_any (any normalizer_spec) by one lane.
-// Used for documents (length classes beyond 4 KiB) of every unigram model, and for what the word kernels leave when
-// that is too little to fill the lane-per-sentence kernel.
+// nothing here depends on the sentence length.  For models whose longest piece has at most kUwMaxPiece bytes (a piece
+// that begins in a chunk ends in it or in the next); the others take the lane-per-sentence long form (kernels_long.h).
+// Used for documents (length classes beyond 4 KiB), and for what the word kernels leave when that is too little to
+// fill the lane-per-sentence kernel.
 #ifndef SPMX_KERNELS_UNIWAVE_H_
 #define SPMX_KERNELS_UNIWAVE_H_
 
 namespace spmx {
 
-constexpr uint32_t kUwRing = 256;       // score / back-pointer rings: 64 starts + the longest piece (<= kMaxPieceBytes) + slack
+constexpr uint32_t kUwRing = 256;       // the backtrack's window of blen entries
 constexpr uint32_t kUwWindow = 256;     // bytes of text staged per chunk: 64 starts + the longest piece
-constexpr uint32_t kUwMaxCands = 32;    // candidate rows hold max_prefixes entries (<= this)
+constexpr uint32_t kUwMaxPiece = 64;    // the longest piece (bytes) this form takes: matrix rows have that many entries
 constexpr uint32_t kUwUnreached = 0xFFFFFFFFu;
-SPMX_HD inline uint32_t UniWaveLdsBytes(uint32_t J) {
-  return kUwRing * 8u + 64u * J * 8u + 64u + kUwWindow + 16u + kRawWinBytes;
+constexpr uint32_t kUwNone = 0xFFFFFFFFu;       // matrix entry, word x: no piece of this length begins here
+constexpr uint32_t kUwNan = 0x7FC00000u;        // ... and its word y: a score that wins no comparison
+// matrix rows: one entry per piece length -- 16, 32 or 64 (the kernel is compiled for each)
+SPMX_HD inline uint32_t UniWaveRow(int max_piece_bytes) { return max_piece_bytes <= 16 ? 16u : max_piece_bytes <= 32 ? 32u : 64u; }
+// the matrix with one entry in front of it and 64 behind: what the lanes a step does not concern read
+SPMX_HD inline uint32_t UniWaveMatrixEntries(uint32_t ML) { return 2u + 64u * ML + 64u; }
+SPMX_HD inline uint32_t UniWaveLdsBytes(uint32_t ML) {
+  return kUwRing * 4u + UniWaveMatrixEntries(ML) * 8u + kUwWindow + 16u + kRawWinBytes;
 }
 
 struct UniWaveLds {
-  float *ring_s;      // [kUwRing] best_path_score of position p at ring_s[p % kUwRing]
-  uint32_t *ring_b;   // [kUwRing] its best piece: id | length << 24 (kUwUnreached: no candidate yet); doubles as the
-                      //           backtrack's window of blen entries
-  U2 *cands;          // [64][J]  {id | length << 24 | user-defined << 31, score bits}
-  uint8_t *ncand;     // [64]
+  uint32_t *ring_b;   // [kUwRing] the backtrack's window of blen entries
+  U2 *cands;          // entry [l][k] at cands[l * ML + k], two entries in front of [0][0] and 64 behind [63][ML - 1]: {id | length << 24 | user-defined << 31, score bits} of
+                      // the piece of k + 1 bytes that begins at c + l; {kUwNone, kUwNan}: none.  A user-defined piece carries
+                      // (float)length * max_score_ for a score.  (16-byte aligned: the rows are cleared two entries a store)
   uint8_t *win;       // [kUwWindow + 16] text window
   uint8_t *rawwin;    // [kRawWinBytes] lane 0's raw-text window of norm_lane_any
 };
-SPMX_DEVICE UniWaveLds carve_uniwave(unsigned char *smem, uint32_t J) {
+SPMX_DEVICE UniWaveLds carve_uniwave(unsigned char *smem, uint32_t ML) {
   UniWaveLds T;
-  T.ring_s = reinterpret_cast<float *>(smem);
-  T.ring_b = reinterpret_cast<uint32_t *>(smem + kUwRing * 4u);
-  T.cands = reinterpret_cast<U2 *>(smem + kUwRing * 8u);
-  T.ncand = smem + kUwRing * 8u + 64u * J * 8u;
-  T.win = T.ncand + 64u;
+  T.ring_b = reinterpret_cast<uint32_t *>(smem);
+  T.cands = reinterpret_cast<U2 *>(smem + kUwRing * 4u) + 2;          // (entry [0][0] sits at a 16-byte boundary)
+  T.win = smem + kUwRing * 4u + UniWaveMatrixEntries(ML) * 8u;
   T.rawwin = T.win + kUwWindow + 16u;
   return T;
 }
 
+// ---- the fold of one chunk.  M = entry [0][-1]; S: the chunk's character starts; cur / nxt: best_path_ends_at of
+// positions c + lane / c + 64 + lane (score; piece: id | length << 24, kUwUnreached) ----
+
+// EXACT form: the reference's arithmetic as written.
+template <uint32_t ML>
+SPMX_DEVICE void uw_fold_exact(const SpmxDev &d, const U2 *M, uint64_t S, int lane, float &cur_s, uint32_t &cur_b, float &nxt_s,
+                               uint32_t &nxt_b) {
+  const uint32_t unk = static_cast<uint32_t>(d.unk_id) & 0x00FFFFFFu;
+  auto relax = [&](float &s, uint32_t &b, const U2 &ent, bool mine, double dbs, float fu) __attribute__((always_inline)) {
+    const bool has = mine && ent.x != kUwNone;
+    const bool isunk = (ent.x & 0x80FFFFFFu) == unk;
+    // a user-defined piece (bit 31) carries (float)length * max_score_: its score is that - 0.1 in double (:979-981)
+    const double adj = wv::bits_to_double(0xBFB999999999999Aull & static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(ent.x) >> 31)));   // -0.1 or 0.0
+    const double score = static_cast<double>(wv::bits_to_float(ent.y)) + adj;    // (+ 0.0 otherwise: the same value)
+    const double cand = score + dbs;                                  // :982-983
+    const float nv = isunk ? fu : static_cast<float>(cand);           // (:997-1001: the UNK candidate in float)
+    const bool gt = isunk ? fu > s : cand > static_cast<double>(s);   // :984-985 (s = -inf: no candidate yet)
+    const bool win = has && gt;
+    s = win ? nv : s;
+    b = win ? (ent.x & 0x7FFFFFFFu) : b;
+  };
+  for (uint64_t m = S; m != 0; m &= m - 1) {
+    const int l = wv::ffs64(m) - 1;
+    const float bs = wv::bits_to_float(wv::read_lane(wv::float_to_bits(cur_s), l));
+    const double dbs = static_cast<double>(bs);
+    const float fu = d.unk_score + bs;
+    relax(cur_s, cur_b, M[static_cast<uint32_t>(l) * (ML - 1u) + static_cast<uint32_t>(lane)], static_cast<uint32_t>(lane - l - 1) < ML, dbs, fu);
+    if (static_cast<uint32_t>(l) + ML >= 64u)                          // (wave-uniform) its row reaches beyond the chunk
+      relax(nxt_s, nxt_b, M[static_cast<uint32_t>(l) * (ML - 1u) + 64u + static_cast<uint32_t>(lane)],
+            static_cast<uint32_t>(lane + 63 - l) < ML, dbs, fu);
+  }
+}
+
+// FLOAT form (see the top): returns nonzero in some lane if a comparison met a tie of the rounded values -- the caller
+// folds the chunk again with uw_fold_exact.  D: the longest piece (bytes) any start of the chunk has.
+template <uint32_t ML>
+SPMX_DEVICE uint32_t uw_fold_float(const U2 *M, uint64_t S, uint32_t D, int lane, float &cur_s, uint32_t &cur_b, float &nxt_s,
+                                   uint32_t &nxt_b) {
+  uint32_t tie = 0;
+  const float qnan = wv::bits_to_float(kUwNan);
+#pragma unroll
+  for (int l = 0; l < 64; ++l) {
+    if (!((S >> l) & 1ull)) continue;                                 // (wave-uniform)
+    const float bs = wv::bits_to_float(wv::read_lane(wv::float_to_bits(cur_s), l));
+    {
+      const U2 e = M[static_cast<uint32_t>(l) * (ML - 1u) + static_cast<uint32_t>(lane)];      // [l][lane - l - 1]
+      const float sum = wv::bits_to_float(e.y) + (static_cast<uint32_t>(lane - l - 1) < ML ? bs : qnan);   // (the other lanes read other rows)
+      const bool gt = sum > cur_s;
+      tie |= sum == cur_s ? 1u : 0u;
+      cur_s = gt ? sum : cur_s;
+      cur_b = gt ? e.x : cur_b;
+    }
+    if (static_cast<uint32_t>(l) + ML >= 64u && static_cast<uint32_t>(l) + D >= 64u) {          // (wave-uniform; only the chunk's last starts)
+      const U2 e = M[static_cast<uint32_t>(l) * (ML - 1u) + 64u + static_cast<uint32_t>(lane)]; // [l][64 + lane - l - 1]
+      const float sum = wv::bits_to_float(e.y) + (static_cast<uint32_t>(lane + 63 - l) < ML ? bs : qnan);
+      const bool gt = sum > nxt_s;
+      tie |= sum == nxt_s ? 1u : 0u;
+      nxt_s = gt ? sum : nxt_s;
+      nxt_b = gt ? e.x : nxt_b;
+    }
+  }
+  return tie;
+}
+
 // EncodeOptimized of the normalized text nt[0, nlen) (device form, HBM) by one wavefront.  bid / blen: nlen + 2
 // entries in HBM, written here.  On return blen[e] has kTokEnd | length at every token end of the best path and bid[e]
-// the token's id (unk_id for an unknown character).  false: a broken chain (cannot happen).
-// The fold touches LDS only: scores and back-pointers of the 256 most recent positions live in rings; after the chunk
-// of starts [c, c + 64) has been folded the positions up to c + 64 are final and leave for HBM as one coalesced row.
-SPMX_DEVICE bool unigram_wave(const SpmxDev &d, const uint8_t *nt, int nlen, const UniWaveLds &T, uint32_t J, int32_t *bid,
-                              uint16_t *blen, int lane) {
+// the token's id (unk_id for an unknown character).  false: a broken chain (cannot happen).  cyc: [0] += the cycles of
+// the walks, [1] += of the folds.
+template <uint32_t ML>
+SPMX_DEVICE bool unigram_wave(const SpmxDev &d, const uint8_t *nt, int nlen, const UniWaveLds &T, int32_t *bid, uint16_t *blen,
+                              int lane, unsigned long long *cyc) {
   const U4 *__restrict__ ptrie = d.ptrie;
   const uint32_t root = d.ptrie[0].x >> kDatBaseShiftDev;
   const uint32_t root_w = d.ptrie[0].w;
   const uint32_t spb = SpByteOf(d);
-  for (uint32_t k = static_cast<uint32_t>(lane); k < kUwRing; k += 64u) T.ring_b[k] = kUwUnreached;
-  if (lane == 0) T.ring_s[0] = 0.f;                                   // best_path_ends_at[0].best_path_score = 0
+  const float ninf = -__builtin_inff();
+  const U2 *M = T.cands - 1;
+  U2 *row = T.cands + static_cast<uint32_t>(lane) * ML;
+  for (uint32_t k = static_cast<uint32_t>(lane); k < UniWaveMatrixEntries(ML); k += 64u) T.cands[static_cast<int>(k) - 2] = U2{kUwNone, kUwNan};
+  // best_path_ends_at[c + lane] and [c + 64 + lane]; [0] = {0, nothing}
+  float cur_s = lane == 0 ? 0.f : ninf, nxt_s = ninf;
+  uint32_t cur_b = kUwUnreached, nxt_b = kUwUnreached;
   int next_start = 0;                                                // the next character start (absolute), across chunks
-  for (int c = 0; c < nlen; c += 64) {
+  for (int c = 0; c <= nlen; c += 64) {                              // (c == nlen: only position nlen is left to store)
     // ---- the text of this chunk's walks: positions [c, c + kUwWindow) ----
-    wv::sync();                                                      // (the previous chunk's walks, fold and flush are done)
+    wv::sync();                                                      // (the previous chunk's walks and fold are done)
     {
       const int q = c + 4 * lane;
       uint32_t v = 0;
@@ -83,90 +171,79 @@ SPMX_DEVICE bool unigram_wave(const SpmxDev &d, const uint8_t *nt, int nlen, con
       step = b0 == spb ? 1 : OneCharLenDev(b0);                       // :962-963
       if (step > nlen - s) step = nlen - s;
     }
-    const uint64_t S = resolve_chain(c, step, valid, &next_start);   // which positions are character starts (:1007)
-    // ---- walk (:965-993): every piece that starts at s, in order of length ----
+    const uint64_t S = wv::uniform64(resolve_chain(c, step, valid, &next_start));   // which positions are character starts (:1007)
+    const unsigned long long tw0 = wv::clock();
+    // ---- walk (:965-993): every piece that starts at s, by length, into row `lane` ----
+    uint32_t deep = 0;                                                // the row's last entry that is not "none"
     {
-      bool alive = ((S >> lane) & 1ull) != 0;
-      uint32_t node = root, k = 0;
+      const bool is_start = ((S >> lane) & 1ull) != 0;
+      bool alive = is_start;
+      uint32_t node = root, dep = 0;
       uint32_t wsum = root_w;                                         // child-label summary of the node the walk stands on (dev.h ChildBit)
-      int dep = 0;
+      bool single = false;                                            // a piece of exactly one character matched (:990)
       while (wv::any(alive)) {
         if (alive) {
-          const int q = s + dep;
-          if (q >= nlen) { alive = false; }
+          const int q = s + static_cast<int>(dep);
+          if (q >= nlen || dep >= ML) { alive = false; }              // (no piece is longer than ML bytes)
           else if (!((wsum >> ChildBit(T.win[q - c])) & 1u)) { alive = false; }   // no child with this label: the failing probe is not issued
           else {
             const uint32_t cb = T.win[q - c];
             const U4 u = ptrie[node ^ cb];
             if ((u.x & 0x1FFu) == (0x100u | cb)) {                    // :969-971
-              ++dep;
               node = u.x >> kDatBaseShiftDev;
               wsum = u.w;
-              if ((u.x & kDatTerminalDev) && !(u.y & kPtUnused) && k < J) {   // :973-974
-                T.cands[static_cast<uint32_t>(lane) * J + k] =
-                    U2{(u.y & 0x00FFFFFFu) | (static_cast<uint32_t>(dep) << 24) | ((u.y & kPtUserDefined) ? 0x80000000u : 0u), u.z};
-                ++k;
+              ++dep;
+              if ((u.x & kDatTerminalDev) && !(u.y & kPtUnused)) {    // :973-974
+                const bool ud = (u.y & kPtUserDefined) != 0u;
+                row[dep - 1u] = U2{(u.y & 0x00FFFFFFu) | (dep << 24) | (ud ? 0x80000000u : 0u),
+                                   ud ? wv::float_to_bits(static_cast<float>(static_cast<int>(dep)) * d.max_score) : u.z};
+                deep = dep;
+                if (static_cast<int>(dep) == step) single = true;
               }
-              if (dep >= static_cast<int>(kUwWindow) - 64) alive = false;   // (no piece is that long)
             } else {
               alive = false;
             }
           }
         }
       }
-      T.ncand[lane] = static_cast<uint8_t>(k);
+      if (is_start && !single) {                                      // :995-1005: the UNK candidate, `step` bytes long
+        const uint32_t us = static_cast<uint32_t>(step);
+        row[us - 1u] = U2{(static_cast<uint32_t>(d.unk_id) & 0x00FFFFFFu) | (us << 24), wv::float_to_bits(d.unk_score)};
+        if (deep < us) deep = us;
+      }
     }
+    const uint32_t D = wv::uniform(wv::read_lane(wv::scan_max(deep), 63));
     wv::sync();
-    // ---- fold: the relaxations in the reference's order.  The starts one after another (a start's score must be
-    // final before its candidates are scored); the candidates of ONE start end at different positions, so lane k takes
-    // candidate k and lane 63 the UNK candidate (:995-1005, only when no piece of one character matched, so its end
-    // position is no candidate's either) ----
-    for (uint64_t m = S; m != 0; m &= m - 1) {
-      const int l = wv::ffs64(m) - 1;
-      const int ss = c + l;
-      const float bs = T.ring_s[static_cast<uint32_t>(ss) & (kUwRing - 1u)];
-      const uint32_t b0 = T.win[l];
-      int mb = b0 == spb ? 1 : OneCharLenDev(b0);
-      if (mb > nlen - ss) mb = nlen - ss;
-      const uint32_t nk = T.ncand[l];
-      const bool has = static_cast<uint32_t>(lane) < nk;
-      int len = 0;
-      if (has) {
-        const U2 cw = T.cands[static_cast<uint32_t>(l) * J + static_cast<uint32_t>(lane)];
-        len = static_cast<int>((cw.x >> 24) & 0x7Fu);
-        const uint32_t es = static_cast<uint32_t>(ss + len) & (kUwRing - 1u);
-        double score = static_cast<double>(wv::bits_to_float(cw.y));
-        if (cw.x & 0x80000000u) {                                     // (length * max_score_ - 0.1), :979-981
-          const float prod = static_cast<float>(len) * d.max_score;
-          score = static_cast<double>(prod) - 0.1;
-        }
-        const double cand = score + static_cast<double>(bs);         // :982-983
-        if (T.ring_b[es] == kUwUnreached || cand > static_cast<double>(T.ring_s[es])) {      // :984-989
-          T.ring_s[es] = static_cast<float>(cand);
-          T.ring_b[es] = cw.x & 0x7FFFFFFFu;
+    const unsigned long long tw1 = wv::clock();
+    // ---- fold: the starts one after another (a start's score must be final before its candidates are scored) ----
+    if (S != 0) {
+      // float arithmetic while every score the chunk starts from is above -uw_f32_limit (nxt has none yet)
+      const bool f32 = d.uw_f32_limit > 0.f && !wv::any(cur_s <= -d.uw_f32_limit && cur_s > ninf);
+      bool exact = !f32;
+      if (f32) {
+        const float s0 = cur_s;
+        const uint32_t b0 = cur_b;
+        if (wv::any(uw_fold_float<ML>(M, S, D, lane, cur_s, cur_b, nxt_s, nxt_b) != 0u)) {
+          cur_s = s0; cur_b = b0; nxt_s = ninf; nxt_b = kUwUnreached;
+          exact = true;
         }
       }
-      const bool single = wv::any(has && len == mb);                  // :990
-      if (!single && lane == 63) {                                    // :995-1005, float arithmetic
-        const uint32_t es = static_cast<uint32_t>(ss + mb) & (kUwRing - 1u);
-        const float cand = d.unk_score + bs;
-        if (T.ring_b[es] == kUwUnreached || cand > T.ring_s[es]) {
-          T.ring_s[es] = cand;
-          T.ring_b[es] = (static_cast<uint32_t>(d.unk_id) & 0x00FFFFFFu) | (static_cast<uint32_t>(mb) << 24);
-        }
-      }
-      wv::sync();
+      if (exact) uw_fold_exact<ML>(d, M, S, lane, cur_s, cur_b, nxt_s, nxt_b);
     }
-    wv::sync();
-    // ---- positions (c, c + 64] are final: one coalesced row to HBM, their ring slots are free for c + 256 ... ----
+    cyc[0] += tw1 - tw0; cyc[1] += wv::clock() - tw1;
+    // ---- positions [c, c + 64) are final: one coalesced row to HBM; the row of the matrix is "none" again ----
     {
-      const int p = c + 1 + lane;
+      const int p = c + lane;
       if (p <= nlen) {
-        const uint32_t sl = static_cast<uint32_t>(p) & (kUwRing - 1u);
-        const uint32_t w = T.ring_b[sl];
-        bid[p] = w == kUwUnreached ? 0 : static_cast<int32_t>(w & 0x00FFFFFFu);
-        blen[p] = w == kUwUnreached ? static_cast<uint16_t>(0) : static_cast<uint16_t>((w >> 24) & 0x7Fu);
-        T.ring_b[sl] = kUwUnreached;
+        bid[p] = cur_b == kUwUnreached ? 0 : static_cast<int32_t>(cur_b & 0x00FFFFFFu);
+        blen[p] = cur_b == kUwUnreached ? static_cast<uint16_t>(0) : static_cast<uint16_t>((cur_b >> 24) & 0x7Fu);
+      }
+      cur_s = nxt_s; cur_b = nxt_b;
+      nxt_s = ninf; nxt_b = kUwUnreached;
+      wv::sync();                                                    // (every lane has read the matrix)
+      if (deep != 0u) {
+#pragma unroll
+        for (uint32_t k = 0; k < ML; ++k) row[k] = U2{kUwNone, kUwNan};
       }
     }
   }
@@ -200,15 +277,16 @@ SPMX_DEVICE bool unigram_wave(const SpmxDev &d, const uint8_t *nt, int nlen, con
 }
 
 // One sentence per wavefront over a device-side list; slices from the long form's pool (LongArgs, kernels_long.h).
-SPMX_DEVICE void uni_long_block(const LongArgs &a, unsigned char *smem, uint32_t J) {
+template <uint32_t ML>
+SPMX_DEVICE void uni_long_block(const LongArgs &a, unsigned char *smem) {
   const int lane = wv::lane();
   const SpmxDev &d = a.dev;
-  const UniWaveLds T = carve_uniwave(smem, J);
+  const UniWaveLds T = carve_uniwave(smem, ML);
   const uint32_t wave_id = static_cast<uint32_t>(wv::block_id() * wv::waves_per_block() + wv::wave_in_block());
   const uint32_t n_waves = static_cast<uint32_t>(wv::grid_size() * wv::waves_per_block());
   const uint32_t count = *a.list_count;
   const int n_extra = d.n_prefix + d.n_suffix;
-  unsigned long long st_sent = 0, st_raw = 0, st_ids = 0, st_cyc[3] = {0, 0, 0};
+  unsigned long long st_sent = 0, st_raw = 0, st_ids = 0, st_cyc[3] = {0, 0, 0}, st_seg[2] = {0, 0};
   for (uint32_t i = wave_id; i < count; i += n_waves) {
     const unsigned long long t0 = wv::clock();
     const uint32_t sid = a.list[i];
@@ -290,7 +368,7 @@ SPMX_DEVICE void uni_long_block(const LongArgs &a, unsigned char *smem, uint32_t
     const unsigned long long t1 = wv::clock();
     if (lane == 0) { blen[0] = 0; bid[0] = 0; }
     wv::sync_global();
-    const bool ok = unigram_wave(d, norm, nlen, T, J, bid, blen, lane);
+    const bool ok = unigram_wave<ML>(d, norm, nlen, T, bid, blen, lane, st_seg);
     wv::sync_global();
     if (!ok) {                                                        // "all normalized characters are not consumed."
       if (lane == 0) {
@@ -308,6 +386,8 @@ SPMX_DEVICE void uni_long_block(const LongArgs &a, unsigned char *smem, uint32_t
     wv::atomic_add(&a.stats[0], st_sent);
     wv::atomic_add(&a.stats[1], st_raw);
     wv::atomic_add(&a.stats[2], st_ids);
+    wv::atomic_add(&a.stats[3], st_seg[0]);       // (of the segment cycles) the walks
+    wv::atomic_add(&a.stats[7], st_seg[1]);       // (of the segment cycles) the fold
     wv::atomic_add(&a.stats[4], st_cyc[0]);       // normalize
     wv::atomic_add(&a.stats[5], st_cyc[1]);       // segment
     wv::atomic_add(&a.stats[6], st_cyc[2]);       // emit

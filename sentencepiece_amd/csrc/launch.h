@@ -44,7 +44,7 @@ hipError_t LaunchEncodeWord(int mode, const EncodeArgs &a, int grid, int waves, 
 hipError_t LaunchEncodeWordWave(int mode, const EncodeArgs &a, int grid, int waves, uint32_t lds_bytes, hipStream_t stream);
 hipError_t LaunchWordResolve(const ResolveArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchBpeLong(const LongArgs &a, int grid, hipStream_t stream);
-// The wave-cooperative unigram form (kernels_uniwave.h): one sentence per 64-thread workgroup; cands = candidate-row entries
+// The wave-cooperative unigram form (kernels_uniwave.h): one sentence per 64-thread workgroup; cands = entries of a matrix row (UniWaveRow: the longest piece in bytes)
 hipError_t LaunchUniLong(const LongArgs &a, uint32_t cands, int grid, hipStream_t stream);
 hipError_t LaunchNormalizeLong(bool write, const NormalizeArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchAlignLong(const AlignLongArgs &a, int grid, hipStream_t stream);
@@ -58,6 +58,7 @@ hipError_t LaunchPlainScan(const PlainScanArgs &a, int grid, hipStream_t stream)
 hipError_t LaunchClassify(const ClassifyArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchScan(const ScanArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchCompact(const CompactArgs &a, int grid, hipStream_t stream);
+hipError_t LaunchCompactBig(const CompactArgs &a, int grid, hipStream_t stream);   // the document blocks LaunchCompact listed
 hipError_t LaunchRebase(const RebaseArgs &a, int grid, hipStream_t stream);   // kernels_gather.h
 
 }  // namespace spmx

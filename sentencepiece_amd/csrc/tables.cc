@@ -100,6 +100,31 @@ Status BuildDecodeTables(const ModelData &m, HostTables *t) {
   return Status::OK();
 }
 
+// dev.h uw_f32_limit: the bound on |best_path_score| below which the wave-cooperative fold may add in float.
+// Every score the fold adds (the pieces', the UNK candidate's) must be 0 or in [2^lo, 2^(hi+1)) with hi - lo <= 27, and
+// none above 0 (then a best_path_score is 0 or at least 2^lo in magnitude: sums of non-positive floats only grow);
+// a best_path_score below 2^(lo + 28) is then within 28 binades of every score.  One chunk of 128 positions adds at
+// most 128 * 2^(hi+1) to the largest score it starts from: that is taken off.
+static float UwFloatLimit(const ModelData &m, float unk_score) {
+  int lo = 1000, hi = -1000;
+  auto take = [&](float v) -> bool {
+    if (!(v <= 0.0f) || v < -3.0e38f) return false;      // above 0, NaN, -inf
+    if (v == 0.0f) return true;
+    int e = 0;
+    (void)std::frexp(static_cast<double>(-v), &e);       // -v = f * 2^e, f in [0.5, 1): exponent e - 1
+    lo = std::min(lo, e - 1); hi = std::max(hi, e - 1);
+    return true;
+  };
+  if (!take(unk_score)) return 0.0f;
+  for (const PieceRec &p : m.pieces) {
+    if (p.type == kUserDefined || p.load_type == kUserDefined) return 0.0f;
+    if (p.load_type == kNormal || p.load_type == kUnused || p.load_type == kByte) { if (!take(p.score)) return 0.0f; }
+  }
+  if (lo > hi || hi - lo > 27 || lo < -60 || hi > 60) return 0.0f;
+  const double limit = std::ldexp(1.0, lo + 28) - 128.0 * std::ldexp(1.0, hi + 1);
+  return limit > 0.0 ? static_cast<float>(limit * 0.999) : 0.0f;
+}
+
 Status CompileTables(const ModelData &m, HostTables *t) {
   std::string err;
   SpmxDev &sc = t->scalars;
@@ -382,6 +407,7 @@ Status CompileTables(const ModelData &m, HostTables *t) {
       for (unsigned char ch : kv.first) nc += (ch & 0xC0u) != 0x80u;
       if (nc > t->max_piece_chars) t->max_piece_chars = nc;
     }
+    sc.uw_f32_limit = UwFloatLimit(m, sc.unk_score);
     // (the candidate word of the split form holds 19 bits of id, 6 of byte length, 4 of character length)
     t->split_ok = blob_utf8 && uds_keys.empty() && m.pieces.size() < (1u << 19) && d.max_prefixes >= 1 && d.max_prefixes <= 16 &&
                   d.max_key_len <= 63 && t->max_piece_chars <= 15;

@@ -78,6 +78,10 @@ SPMX_DEVICE void keep_apart() { asm volatile("; keep_apart %0" ::"n"(N)); }
 // the value of ONE lane as a scalar (src wave-uniform)
 SPMX_DEVICE uint32_t read_lane(uint32_t v, int src) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), src)); }
 
+// a value every lane holds alike, as a scalar (v_readfirstlane): loops over it run on the scalar unit
+SPMX_DEVICE uint32_t uniform(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); }
+SPMX_DEVICE uint64_t uniform64(uint64_t v) { return static_cast<uint64_t>(uniform(static_cast<uint32_t>(v >> 32))) << 32 | uniform(static_cast<uint32_t>(v)); }
+
 // Orders this wave's LDS traffic: writes before the call are visible to every
 // lane's reads after it.  A wave executes in lock step, so only the compiler
 // and the LDS queue need to be fenced -- no s_barrier.
@@ -134,6 +138,7 @@ SPMX_DEVICE int ffs64(uint64_t x) { return __ffsll(static_cast<unsigned long lon
 SPMX_DEVICE int clz64(uint64_t x) { return __clzll(static_cast<long long>(x)); }
 SPMX_DEVICE float bits_to_float(uint32_t u) { return __uint_as_float(u); }
 SPMX_DEVICE uint32_t float_to_bits(float f) { return __float_as_uint(f); }
+SPMX_DEVICE double bits_to_double(uint64_t u) { return __longlong_as_double(static_cast<long long>(u)); }
 
 // Experiment builds (-DSPMX_EXP=<bits>, csrc/Makefile `variants`; results are WRONG, only the counters mean something):
 // which store stream writes how much -- 1 drops the id stores into the arena, 2 the back-pointer block stores, 4 the

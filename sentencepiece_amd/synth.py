@@ -357,6 +357,28 @@ def _piece_msg(piece: bytes, score: float, ptype: int) -> bytes:
     return b"\x0a" + _varint(len(body)) + body
 
 
+def requantized_model(model: bytes, quantum: float = 0.5) -> bytes:
+    """``model`` with every piece score rounded to a multiple of ``quantum``: equal-score candidates (and equal rounded
+    sums of different paths) become common -- the tie handling of the Viterbi folds is what such a model tests."""
+    out = bytearray()
+    for field, wt, payload in _top_level_fields(model):
+        if field == 1 and wt == 2:
+            piece, score, ptype = b"", 0.0, 1
+            for f2, w2, p2 in _top_level_fields(payload):
+                if f2 == 1:
+                    piece = p2
+                elif f2 == 2:
+                    score = float(np.frombuffer(p2, dtype=np.float32)[0])
+                elif f2 == 3:
+                    ptype = int(p2[0])
+            out += _piece_msg(piece, round(score / quantum) * quantum, ptype)
+        elif wt == 2:
+            out += _varint(field << 3 | 2) + _varint(len(payload)) + payload
+        else:
+            out += _varint(field << 3 | wt) + payload
+    return bytes(out)
+
+
 def c5_model(template_model: bytes, vocab_size: int = 250_000, seed: int = 20250228,
              byte_fallback: bool = False, sample_sentences: int = 30_000) -> bytes:
     """A ``vocab_size``-piece unigram ModelProto for BASELINE.json configs[4].

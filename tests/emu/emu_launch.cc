@@ -77,7 +77,9 @@ hipError_t LaunchBpeLong(const LongArgs &a, int grid, hipStream_t) {
 }
 
 hipError_t LaunchUniLong(const LongArgs &a, uint32_t cands, int grid, hipStream_t) {
-  RunGrid(grid, 1, UniWaveLdsBytes(cands), [&](unsigned char *s) { uni_long_block(a, s, cands); });
+  if (cands == 16u) RunGrid(grid, 1, UniWaveLdsBytes(16), [&](unsigned char *s) { uni_long_block<16>(a, s); });
+  else if (cands == 32u) RunGrid(grid, 1, UniWaveLdsBytes(32), [&](unsigned char *s) { uni_long_block<32>(a, s); });
+  else RunGrid(grid, 1, UniWaveLdsBytes(64), [&](unsigned char *s) { uni_long_block<64>(a, s); });
   return hipSuccess;
 }
 
@@ -136,6 +138,10 @@ hipError_t LaunchScan(const ScanArgs &a, int grid, hipStream_t) {
 }
 hipError_t LaunchCompact(const CompactArgs &a, int grid, hipStream_t) {
   RunGrid(grid, 1, CompactLdsBytes(a.staged), [&](unsigned char *s) { compact_block(a, reinterpret_cast<uint16_t *>(s)); });
+  return hipSuccess;
+}
+hipError_t LaunchCompactBig(const CompactArgs &a, int grid, hipStream_t) {
+  RunGrid(grid > 3 ? 3 : grid, 1, 0, [&](unsigned char *) { compact_big_block(a); });
   return hipSuccess;
 }
 hipError_t LaunchRebase(const RebaseArgs &a, int grid, hipStream_t) {

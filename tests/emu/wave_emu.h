@@ -93,6 +93,8 @@ inline uint32_t lane_up1(uint32_t v, uint32_t fill) { return static_cast<uint32_
 inline uint32_t lane_down1(uint32_t v, uint32_t fill) { return static_cast<uint32_t>(emu::Collective(emu::kLaneDown1, v, fill)); }
 inline uint32_t scan_add(uint32_t v) { return static_cast<uint32_t>(emu::Collective(emu::kScanAdd, v, 0)); }
 inline uint32_t scan_max(uint32_t v) { return static_cast<uint32_t>(emu::Collective(emu::kScanMax, v, 0)); }
+inline uint32_t uniform(uint32_t v) { return v; }
+inline uint64_t uniform64(uint64_t v) { return v; }
 inline uint32_t read_lane(uint32_t v, int src) { return static_cast<uint32_t>(emu::Collective(emu::kShfl, v, static_cast<uint64_t>(src & 63))); }
 template <int N> inline void keep_apart() {}
 inline void sync() { emu::Collective(emu::kSync, 0, 0); }
@@ -125,6 +127,7 @@ inline int ffs64(uint64_t x) { return __builtin_ffsll(static_cast<long long>(x))
 inline int clz64(uint64_t x) { return x ? __builtin_clzll(x) : 64; }
 inline float bits_to_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 inline uint32_t float_to_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+inline double bits_to_double(uint64_t u) { double f; memcpy(&f, &u, 8); return f; }
 #ifndef SPMX_EXP
 #define SPMX_EXP 0
 #endif

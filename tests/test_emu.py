@@ -299,6 +299,35 @@ def test_emu_no_length_limit(model, classes, emu, oracle, corpora):
         assert h.path()["overflow"] >= 1          # the NFKC expansions outgrow any class column
 
 
+@pytest.mark.parametrize("big", ["64", "5000", "0"])
+@pytest.mark.parametrize("model", ["test_model", "bpe1k"])
+def test_emu_compaction_of_document_blocks(model, big, emu, oracle, corpora):
+    """Blocks of 64 sentences with many ids (documents) are compacted by a launch of their own (kernels.h
+    compact_big_block): items of 8192 ids dealt to every wave.  A mix of documents and short sentences over several
+    blocks, ids and the spans form, with the threshold at 64 ids (nearly every block), 5000 and off."""
+    from sentencepiece_amd import synth
+    blob = fixtures.model_blob(model)
+    h, o = emu.load(blob, classes=None, env={"SPMX_COMPACT_BIG": big}), oracle.load(blob)
+    bot, boffs = corpora["botchan"]
+    rng = np.random.default_rng(7)
+    docs = []
+    for i in range(150):
+        a = int(rng.integers(0, len(boffs) - 400))
+        k = int(rng.choice([1, 1, 1, 2, 40, 300]))
+        docs.append(bot[int(boffs[a]):int(boffs[a + k])].tobytes().replace(b"\n", b" "))
+    docs[70] = b""
+    text, offs = synth.pack(docs)
+    ids, io = h.encode_batch(text, offs)
+    assert h.status == 0
+    oids, oio = o.encode_batch(text, offs)
+    np.testing.assert_array_equal(io, oio)
+    np.testing.assert_array_equal(ids, oids)
+    got = h.encode_spans(text, offs)
+    want = o.encode_spans(text, offs)
+    for a, b, nm in zip(got, want, ("ids", "begin", "end", "id_offsets")):
+        np.testing.assert_array_equal(np.asarray(a).astype(np.int64), np.asarray(b).astype(np.int64), err_msg=nm)
+
+
 def test_emu_hundred_kilobyte_documents(emu, oracle, corpora):
     """100 KB documents through a user-defined-symbol unigram model and a BPE model whose pieces span words."""
     for model in ("uni1k_uds", "bpe1k_noesc"):
@@ -487,12 +516,18 @@ def test_emu_arena_overflow_and_retry(model, emu, oracle, corpora):
 
 @pytest.mark.parametrize("model", ["test_model", "test_ja_model", "uni1k", "uni1k_bf", "uni1k_uds", "uni1k_ident", "uni1k_suffix",
                                    "uni32k", "c5_250k_bf"])
-def test_emu_wave_cooperative_unigram(model, emu, oracle, corpora):
+@pytest.mark.parametrize("fold", ["float", "exact"])
+def test_emu_wave_cooperative_unigram(model, fold, emu, oracle, corpora):
     """kernels_uniwave.h: a sentence per wavefront -- parallel trie walks from 64 character starts, the relaxations
-    folded by one lane in the reference's order.  Every unigram model, every corpus, with the word kernels off so that
-    all sentences come here (SPMX_UNI_WAVE_MAX: classes below that many sentences take this form)."""
+    folded with the scores in registers, in the reference's order.  Every unigram model, every corpus, with the word
+    kernels off so that all sentences come here (SPMX_UNI_WAVE_MAX: classes below that many sentences take this form);
+    the fold in float arithmetic where the model allows it (uw_fold_float; ties re-folded exactly) and in the
+    reference's double arithmetic throughout (uw_fold_exact)."""
     blob = fixtures.model_blob(model)
-    h = emu.load(blob, env={"SPMX_UNI_WAVE_MAX": "1000000", "SPMX_NO_WORD_KERNEL": "1"})
+    env = {"SPMX_UNI_WAVE_MAX": "1000000", "SPMX_NO_WORD_KERNEL": "1"}
+    if fold == "exact":
+        env["SPMX_UW_EXACT"] = "1"
+    h = emu.load(blob, env=env)
     o = oracle.load(blob)
     for name, k in (("edge", 10 ** 6), ("botchan", 150), ("mixed2k", 40), ("ja", 40), ("synth20k", 150)):
         text, offs = fixtures.head(*corpora[name], k)
@@ -507,6 +542,25 @@ def test_emu_wave_cooperative_unigram(model, emu, oracle, corpora):
         h.sp.SetEncodeExtraOptions("")
         o.set_encode_extra_options("")
     assert any(c["kernel"] == "UniLongKernel" for c in h.sp.LastProfile()["classes"])
+
+
+@pytest.mark.parametrize("quantum", [1.0, 0.25])
+@pytest.mark.parametrize("model", ["test_model", "uni32k"])
+def test_emu_wave_cooperative_unigram_ties(model, quantum, emu, oracle, corpora):
+    """The float fold's tie rule: with every score a multiple of 1 or 1/4, different paths reach a position with EQUAL
+    rounded sums all the time -- the reference keeps the first (strict >), and so must the chunk that is folded again
+    in double arithmetic after the float fold recorded a tie."""
+    from sentencepiece_amd import synth
+    blob = synth.requantized_model(fixtures.model_blob(model), quantum)
+    h = emu.load(blob, env={"SPMX_UNI_WAVE_MAX": "1000000", "SPMX_NO_WORD_KERNEL": "1"})
+    o = oracle.load(blob)
+    for name, k in (("botchan", 200), ("mixed2k", 30), ("synth20k", 100)):
+        text, offs = fixtures.head(*corpora[name], k)
+        ids, io = h.encode_batch(text, offs)
+        assert h.status == 0 and not h.sent_status.any()
+        oids, oio = o.encode_batch(text, offs)
+        np.testing.assert_array_equal(io, oio)
+        np.testing.assert_array_equal(ids, oids)
 
 
 @pytest.mark.parametrize("model", ["uni32k", "test_model"])
