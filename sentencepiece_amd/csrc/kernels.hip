@@ -81,8 +81,9 @@ __global__ __launch_bounds__(64) void BpeLongKernel(LongArgs a) {
   bpe_long_block(a, smem);
 }
 
+// (four wavefronts per SIMD: at most 128 vector registers -- 8192 documents are then two rounds of 4096 wavefronts)
 template <uint32_t ML>
-__global__ __launch_bounds__(64) void UniLongKernel(LongArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void UniLongKernel(LongArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uni_long_block<ML>(a, smem);
 }

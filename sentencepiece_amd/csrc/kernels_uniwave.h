@@ -48,10 +48,13 @@ constexpr uint32_t kUwNan = 0x7FC00000u;        // ... and its word y: a score t
 // matrix rows: one entry per piece length -- 16, 32 or 64 (the kernel is compiled for each)
 SPMX_HD inline uint32_t UniWaveRow(int max_piece_bytes) { return max_piece_bytes <= 16 ? 16u : max_piece_bytes <= 32 ? 32u : 64u; }
 // the matrix with one entry in front of it and 64 behind: what the lanes a step does not concern read
-SPMX_HD inline uint32_t UniWaveMatrixEntries(uint32_t ML) { return 2u + 64u * ML + 64u; }
+SPMX_HD constexpr uint32_t UniWaveMatrixEntries(uint32_t ML) { return 2u + 64u * ML + 64u; }
+// (the backtrack's window and the fallback normalizer's raw window lie over the matrix: it is dead before the first
+// chunk and behind the last)
 SPMX_HD inline uint32_t UniWaveLdsBytes(uint32_t ML) {
-  return kUwRing * 4u + UniWaveMatrixEntries(ML) * 8u + kUwWindow + 16u + kRawWinBytes;
+  return UniWaveMatrixEntries(ML) * 8u + kUwWindow + 16u;
 }
+static_assert(UniWaveMatrixEntries(16) * 8u >= kUwRing * 4u + kRawWinBytes, "the aliased windows fit the smallest matrix");
 
 struct UniWaveLds {
   uint32_t *ring_b;   // [kUwRing] the backtrack's window of blen entries
@@ -63,10 +66,10 @@ struct UniWaveLds {
 };
 SPMX_DEVICE UniWaveLds carve_uniwave(unsigned char *smem, uint32_t ML) {
   UniWaveLds T;
-  T.ring_b = reinterpret_cast<uint32_t *>(smem);
-  T.cands = reinterpret_cast<U2 *>(smem + kUwRing * 4u) + 2;          // (entry [0][0] sits at a 16-byte boundary)
-  T.win = smem + kUwRing * 4u + UniWaveMatrixEntries(ML) * 8u;
-  T.rawwin = T.win + kUwWindow + 16u;
+  T.ring_b = reinterpret_cast<uint32_t *>(smem);                      // (over the matrix)
+  T.rawwin = smem + kUwRing * 4u;                                     // (over the matrix)
+  T.cands = reinterpret_cast<U2 *>(smem) + 2;                         // (entry [0][0] sits at a 16-byte boundary)
+  T.win = smem + UniWaveMatrixEntries(ML) * 8u;
   return T;
 }
 
@@ -80,7 +83,7 @@ SPMX_DEVICE void uw_fold_exact(const SpmxDev &d, const U2 *M, uint64_t S, int la
   const uint32_t unk = static_cast<uint32_t>(d.unk_id) & 0x00FFFFFFu;
   auto relax = [&](float &s, uint32_t &b, const U2 &ent, bool mine, double dbs, float fu) __attribute__((always_inline)) {
     const bool has = mine && ent.x != kUwNone;
-    const bool isunk = (ent.x & 0x80FFFFFFu) == unk;
+    const bool isunk = (ent.x & 0x00FFFFFFu) == unk;                  // (no piece of the trie has that id; its bit 31 is not "user-defined")
     // a user-defined piece (bit 31) carries (float)length * max_score_: its score is that - 0.1 in double (:979-981)
     const double adj = wv::bits_to_double(0xBFB999999999999Aull & static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(ent.x) >> 31)));   // -0.1 or 0.0
     const double score = static_cast<double>(wv::bits_to_float(ent.y)) + adj;    // (+ 0.0 otherwise: the same value)
@@ -103,33 +106,71 @@ SPMX_DEVICE void uw_fold_exact(const SpmxDev &d, const U2 *M, uint64_t S, int la
   }
 }
 
-// FLOAT form (see the top): returns nonzero in some lane if a comparison met a tie of the rounded values -- the caller
-// folds the chunk again with uw_fold_exact.  D: the longest piece (bytes) any start of the chunk has.
-template <uint32_t ML>
+// One relaxation of the float form: the position's score / piece s / b, the candidate's score a (NaN: none) and word x,
+// the start's score bs.
+template <bool TIES>
+SPMX_DEVICE void uw_relax_float(float &s, uint32_t &b, uint32_t &tie, float a, float bs, uint32_t x) {
+  const float sum = a + bs;
+  if (!TIES) {
+    const bool gt = sum > s;
+    tie = sum == s ? 1u : tie;
+    s = gt ? sum : s;
+    b = gt ? x : b;
+  } else {
+    // (a + bs exactly) > s  <=>  sum > s, or sum == s and the rounding error (a + bs) - sum is above 0
+    const float bb = sum - a;
+    const float err = (a - (sum - bb)) + (bs - bb);
+    const float dif = sum - s;                                        // (its sign is exact; +inf over "no candidate yet", NaN for "none")
+    const float key = dif == 0.f ? (static_cast<int32_t>(x) < 0 ? -1.f : err) : dif;
+    const bool gt = key > 0.f;
+    s = gt ? sum : s;
+    b = gt ? x : b;
+  }
+}
+
+// FLOAT form (see the top).  D: the longest piece (bytes) any start of the chunk has.  ALL: every position of the chunk
+// is a character start (plain ASCII: no test per step).  The matrix entries are asked for three steps ahead (their
+// addresses depend on nothing).
+//   TIES = false  a comparison that meets a tie of the rounded values is only recorded: returns nonzero in some lane if
+//                 there was one, and the caller folds the chunk again;
+//   TIES = true   a tie is decided as the reference's double comparison decides it -- by the sign of the float sum's
+//                 rounding error (TwoSum: the error of a float addition is a float); never for the UNK candidate, whose
+//                 comparison IS the float one (:999-1000; its entry has bit 31 set).  Eight more instructions a step:
+//                 for the chunks deep inside a long document, where |best_path_score| has grown to 10^5 .. 10^6, a float
+//                 holds 1/64 .. 1/4 and different paths tie all the time.  Returns 0.
+template <uint32_t ML, bool ALL, bool TIES>
 SPMX_DEVICE uint32_t uw_fold_float(const U2 *M, uint64_t S, uint32_t D, int lane, float &cur_s, uint32_t &cur_b, float &nxt_s,
                                    uint32_t &nxt_b) {
   uint32_t tie = 0;
   const float qnan = wv::bits_to_float(kUwNan);
+  const U2 *mine = M + lane;
+  uint32_t lm1 = static_cast<uint32_t>(lane) - 1u;
+  U2 eb[4];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) eb[p] = mine[p * static_cast<int>(ML - 1u)];
 #pragma unroll
   for (int l = 0; l < 64; ++l) {
-    if (!((S >> l) & 1ull)) continue;                                 // (wave-uniform)
+    if (l + 3 < 64) eb[(l + 3) & 3] = mine[(l + 3) * static_cast<int>(ML - 1u)];            // [l + 3][lane - l - 4]
+    if (!ALL && !((S >> l) & 1ull)) continue;                         // (wave-uniform)
+    // [l][lane - l - 1]; the lanes the row does not concern (they read other rows) get a score that wins nothing -- before
+    // the start's score is asked for: the chain from one start to the next is readlane, add, compare, select
+    wv::opaque(lm1);                                                  // (the lane masks are made where they are used: 64 of them do not fit the scalar registers)
+    const U2 e = eb[l & 3];
+    const float ey = lm1 - static_cast<uint32_t>(l) < ML ? wv::bits_to_float(e.y) : qnan;
     const float bs = wv::bits_to_float(wv::read_lane(wv::float_to_bits(cur_s), l));
-    {
-      const U2 e = M[static_cast<uint32_t>(l) * (ML - 1u) + static_cast<uint32_t>(lane)];      // [l][lane - l - 1]
-      const float sum = wv::bits_to_float(e.y) + (static_cast<uint32_t>(lane - l - 1) < ML ? bs : qnan);   // (the other lanes read other rows)
-      const bool gt = sum > cur_s;
-      tie |= sum == cur_s ? 1u : 0u;
-      cur_s = gt ? sum : cur_s;
-      cur_b = gt ? e.x : cur_b;
-    }
-    if (static_cast<uint32_t>(l) + ML >= 64u && static_cast<uint32_t>(l) + D >= 64u) {          // (wave-uniform; only the chunk's last starts)
-      const U2 e = M[static_cast<uint32_t>(l) * (ML - 1u) + 64u + static_cast<uint32_t>(lane)]; // [l][64 + lane - l - 1]
-      const float sum = wv::bits_to_float(e.y) + (static_cast<uint32_t>(lane + 63 - l) < ML ? bs : qnan);
-      const bool gt = sum > nxt_s;
-      tie |= sum == nxt_s ? 1u : 0u;
-      nxt_s = gt ? sum : nxt_s;
-      nxt_b = gt ? e.x : nxt_b;
-    }
+    uw_relax_float<TIES>(cur_s, cur_b, tie, ey, bs, e.x);
+    wv::opaque(cur_b); wv::opaque(tie);                               // (here, not at the end of the 64 steps with every mask kept until then)
+  }
+  // what the chunk's last starts reach beyond it, behind the main loop: their scores are final now, so nothing here
+  // waits for a step before it but the position's own comparisons (per position the candidates still come in the order
+  // of their starts); the entries are asked for together
+#pragma unroll
+  for (int l = 64 - static_cast<int>(ML); l < 64; ++l) {
+    if (static_cast<uint32_t>(l) + D < 64u) continue;                 // (wave-uniform)
+    if (!ALL && !((S >> l) & 1ull)) continue;
+    const U2 e = mine[l * static_cast<int>(ML - 1u) + 64];           // [l][64 + lane - l - 1]
+    const float bs = wv::bits_to_float(wv::read_lane(wv::float_to_bits(cur_s), l));
+    uw_relax_float<TIES>(nxt_s, nxt_b, tie, static_cast<uint32_t>(lane + 63 - l) < ML ? wv::bits_to_float(e.y) : qnan, bs, e.x);
   }
   return tie;
 }
@@ -153,6 +194,7 @@ SPMX_DEVICE bool unigram_wave(const SpmxDev &d, const uint8_t *nt, int nlen, con
   float cur_s = lane == 0 ? 0.f : ninf, nxt_s = ninf;
   uint32_t cur_b = kUwUnreached, nxt_b = kUwUnreached;
   int next_start = 0;                                                // the next character start (absolute), across chunks
+  uint32_t tie_credit = 0;                                           // (wave-uniform) grows with every chunk that met a tie, shrinks with every one that did not
   for (int c = 0; c <= nlen; c += 64) {                              // (c == nlen: only position nlen is left to store)
     // ---- the text of this chunk's walks: positions [c, c + kUwWindow) ----
     wv::sync();                                                      // (the previous chunk's walks and fold are done)
@@ -208,7 +250,7 @@ SPMX_DEVICE bool unigram_wave(const SpmxDev &d, const uint8_t *nt, int nlen, con
       }
       if (is_start && !single) {                                      // :995-1005: the UNK candidate, `step` bytes long
         const uint32_t us = static_cast<uint32_t>(step);
-        row[us - 1u] = U2{(static_cast<uint32_t>(d.unk_id) & 0x00FFFFFFu) | (us << 24), wv::float_to_bits(d.unk_score)};
+        row[us - 1u] = U2{(static_cast<uint32_t>(d.unk_id) & 0x00FFFFFFu) | (us << 24) | 0x80000000u, wv::float_to_bits(d.unk_score)};   // (bit 31: uw_relax_float)
         if (deep < us) deep = us;
       }
     }
@@ -219,16 +261,30 @@ SPMX_DEVICE bool unigram_wave(const SpmxDev &d, const uint8_t *nt, int nlen, con
     if (S != 0) {
       // float arithmetic while every score the chunk starts from is above -uw_f32_limit (nxt has none yet)
       const bool f32 = d.uw_f32_limit > 0.f && !wv::any(cur_s <= -d.uw_f32_limit && cur_s > ninf);
-      bool exact = !f32;
       if (f32) {
-        const float s0 = cur_s;
-        const uint32_t b0 = cur_b;
-        if (wv::any(uw_fold_float<ML>(M, S, D, lane, cur_s, cur_b, nxt_s, nxt_b) != 0u)) {
-          cur_s = s0; cur_b = b0; nxt_s = ninf; nxt_b = kUwUnreached;
-          exact = true;
+        // which float flavour: the one that decides ties itself while ties are frequent (tie_credit), else the shorter
+        // one, and the chunk again with the other if it met one
+        const bool all = S == ~0ull;
+        bool ties = !all || tie_credit > 8u;
+        if (!ties) {
+          const float s0 = cur_s;
+          const uint32_t b0 = cur_b;
+          if (wv::any(uw_fold_float<ML, true, false>(M, S, D, lane, cur_s, cur_b, nxt_s, nxt_b) != 0u)) {
+            cur_s = s0; cur_b = b0; nxt_s = ninf; nxt_b = kUwUnreached;
+            tie_credit = tie_credit + 8u > 64u ? 64u : tie_credit + 8u;
+            ties = true;
+          } else if (tie_credit != 0u) {
+            --tie_credit;
+          }
+        } else if (all) {
+          --tie_credit;
+        }
+        if (ties) {
+          if (all) (void)uw_fold_float<ML, true, true>(M, S, D, lane, cur_s, cur_b, nxt_s, nxt_b);
+          else (void)uw_fold_float<ML, false, true>(M, S, D, lane, cur_s, cur_b, nxt_s, nxt_b);
         }
       }
-      if (exact) uw_fold_exact<ML>(d, M, S, lane, cur_s, cur_b, nxt_s, nxt_b);
+      else uw_fold_exact<ML>(d, M, S, lane, cur_s, cur_b, nxt_s, nxt_b);
     }
     cyc[0] += tw1 - tw0; cyc[1] += wv::clock() - tw1;
     // ---- positions [c, c + 64) are final: one coalesced row to HBM; the row of the matrix is "none" again ----

@@ -78,6 +78,8 @@ SPMX_DEVICE void keep_apart() { asm volatile("; keep_apart %0" ::"n"(N)); }
 // the value of ONE lane as a scalar (src wave-uniform)
 SPMX_DEVICE uint32_t read_lane(uint32_t v, int src) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), src)); }
 
+// the optimizer forgets what it knows about v (no instruction): what is computed from v behind this is computed here
+SPMX_DEVICE void opaque(uint32_t &v) { asm volatile("" : "+v"(v)); }
 // a value every lane holds alike, as a scalar (v_readfirstlane): loops over it run on the scalar unit
 SPMX_DEVICE uint32_t uniform(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); }
 SPMX_DEVICE uint64_t uniform64(uint64_t v) { return static_cast<uint64_t>(uniform(static_cast<uint32_t>(v >> 32))) << 32 | uniform(static_cast<uint32_t>(v)); }

@@ -360,6 +360,11 @@ def _piece_msg(piece: bytes, score: float, ptype: int) -> bytes:
 def requantized_model(model: bytes, quantum: float = 0.5) -> bytes:
     """``model`` with every piece score rounded to a multiple of ``quantum``: equal-score candidates (and equal rounded
     sums of different paths) become common -- the tie handling of the Viterbi folds is what such a model tests."""
+    return rescored_model(model, lambda v: round(v / quantum) * quantum)
+
+
+def rescored_model(model: bytes, fn) -> bytes:
+    """``model`` with every piece score v replaced by fn(v)."""
     out = bytearray()
     for field, wt, payload in _top_level_fields(model):
         if field == 1 and wt == 2:
@@ -371,7 +376,7 @@ def requantized_model(model: bytes, quantum: float = 0.5) -> bytes:
                     score = float(np.frombuffer(p2, dtype=np.float32)[0])
                 elif f2 == 3:
                     ptype = int(p2[0])
-            out += _piece_msg(piece, round(score / quantum) * quantum, ptype)
+            out += _piece_msg(piece, fn(score), ptype)
         elif wt == 2:
             out += _varint(field << 3 | 2) + _varint(len(payload)) + payload
         else:

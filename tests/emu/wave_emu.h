@@ -93,6 +93,7 @@ inline uint32_t lane_up1(uint32_t v, uint32_t fill) { return static_cast<uint32_
 inline uint32_t lane_down1(uint32_t v, uint32_t fill) { return static_cast<uint32_t>(emu::Collective(emu::kLaneDown1, v, fill)); }
 inline uint32_t scan_add(uint32_t v) { return static_cast<uint32_t>(emu::Collective(emu::kScanAdd, v, 0)); }
 inline uint32_t scan_max(uint32_t v) { return static_cast<uint32_t>(emu::Collective(emu::kScanMax, v, 0)); }
+inline void opaque(uint32_t &) {}
 inline uint32_t uniform(uint32_t v) { return v; }
 inline uint64_t uniform64(uint64_t v) { return v; }
 inline uint32_t read_lane(uint32_t v, int src) { return static_cast<uint32_t>(emu::Collective(emu::kShfl, v, static_cast<uint64_t>(src & 63))); }

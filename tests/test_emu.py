@@ -563,6 +563,26 @@ def test_emu_wave_cooperative_unigram_ties(model, quantum, emu, oracle, corpora)
         np.testing.assert_array_equal(ids, oids)
 
 
+@pytest.mark.parametrize("fold", ["float", "exact"])
+def test_emu_wave_cooperative_unigram_large_scores(fold, emu, oracle, corpora):
+    """Deep inside a megabyte document best_path_score is 10^6 and a float holds 1/8: the rounded sums of different
+    paths tie all the time and the reference's double comparison decides by what the rounding dropped.  The same
+    regime in 30 KB: a model whose scores are 64 times test_model's (the float fold's tie-deciding flavour,
+    uw_relax_float<true>, and the credit that switches to it)."""
+    from sentencepiece_amd import synth
+    blob = synth.rescored_model(fixtures.model_blob("test_model"), lambda v: v * 64.0 + 0.001)
+    env = {"SPMX_UW_EXACT": "1"} if fold == "exact" else None
+    h, o = emu.load(blob, classes=None, env=env), oracle.load(blob)
+    bot, boffs = corpora["botchan"]
+    docs = [bot[int(boffs[a]):int(boffs[a + 420])].tobytes().replace(b"\n", b" ") for a in (0, 500, 1000)] + ["猫 も 杓子 も ".encode() * 900]
+    text, offs = synth.pack(docs)
+    ids, io = h.encode_batch(text, offs)
+    assert h.status == 0 and not h.sent_status.any()
+    oids, oio = o.encode_batch(text, offs)
+    np.testing.assert_array_equal(io, oio)
+    np.testing.assert_array_equal(ids, oids)
+
+
 @pytest.mark.parametrize("model", ["uni32k", "test_model"])
 def test_emu_word_kernels_then_wave_form(model, emu, oracle, corpora):
     """The word kernels first, what they leave through the wave-cooperative form: the default order on the device."""
