@@ -581,14 +581,24 @@ SPMX_DEVICE int emit_wave(const Args &a, uint32_t sid, const uint8_t *norm, int 
   const bool reverse = (d.flags & kNfReverse) != 0;
   const uint32_t spb = SpByteOf(d);
   int total = 0;
+  // (both sweeps ask for the NEXT 64 positions' entries before they work on these: in HBM -- the long forms -- an
+  // iteration is otherwise one memory latency long)
+  auto entry = [&](int e, uint32_t *l, int32_t *id) __attribute__((always_inline)) {
+    *l = 0; *id = 0;
+    if (e <= nlen) { *l = blen[e]; *id = bid[e]; }
+  };
+  uint32_t l_nx; int32_t id_nx;
+  entry(lane + 1, &l_nx, &id_nx);
   for (int b = 0; b < nlen; b += 64) {
     const int e = b + lane + 1;
     int cnt = 0;
+    const uint32_t l = l_nx;
+    const int32_t id_e = id_nx;
+    entry(e + 64, &l_nx, &id_nx);
     if (e <= nlen) {
-      const uint32_t l = blen[e];
       if (l & kTokEnd) {
         const int len = static_cast<int>(l & (kTokEnd - 1));
-        if (bid[e] == d.unk_id) {
+        if (id_e == d.unk_id) {
           if (bf) cnt = norm[e - len] == spb ? 3 : len;   // an unknown piece is one character; U+2581 has 3 bytes
           else cnt = (e - len > 0 && bid[e - len] == d.unk_id) ? 0 : 1;
         } else {
@@ -618,15 +628,18 @@ SPMX_DEVICE int emit_wave(const Args &a, uint32_t sid, const uint8_t *norm, int 
   if (lane < d.n_prefix) dst[lane] = d.prefix_ids[lane];
   if (lane < d.n_suffix) dst[d.n_prefix + total + lane] = d.suffix_ids[lane];
   int done = 0;
+  entry(lane + 1, &l_nx, &id_nx);
   for (int b = 0; b < nlen; b += 64) {
     const int e = b + lane + 1;
     int cnt = 0, len = 0;
     int32_t id = 0;
+    const uint32_t l = l_nx;
+    const int32_t id_e = id_nx;
+    entry(e + 64, &l_nx, &id_nx);
     if (e <= nlen) {
-      const uint32_t l = blen[e];
       if (l & kTokEnd) {
         len = static_cast<int>(l & (kTokEnd - 1));
-        id = bid[e];
+        id = id_e;
         if (id == d.unk_id) {
           if (bf) cnt = norm[e - len] == spb ? 3 : len;
           else cnt = (e - len > 0 && bid[e - len] == d.unk_id) ? 0 : 1;

@@ -54,10 +54,10 @@ SPMX_HD constexpr uint32_t UniWaveMatrixEntries(uint32_t ML) { return 2u + 64u *
 SPMX_HD inline uint32_t UniWaveLdsBytes(uint32_t ML) {
   return UniWaveMatrixEntries(ML) * 8u + kUwWindow + 16u;
 }
-static_assert(UniWaveMatrixEntries(16) * 8u >= kUwRing * 4u + kRawWinBytes, "the aliased windows fit the smallest matrix");
+static_assert(UniWaveMatrixEntries(16) * 8u >= kUwRing * 16u && kUwRing * 12u >= kUwRing * 4u + kRawWinBytes, "the aliased windows fit the smallest matrix");
 
 struct UniWaveLds {
-  uint32_t *ring_b;   // [kUwRing] the backtrack's window of blen entries
+  uint32_t *ring_b;   // [4][kUwRing] the backtrack's window: lengths, two predecessor maps, marks
   U2 *cands;          // entry [l][k] at cands[l * ML + k], two entries in front of [0][0] and 64 behind [63][ML - 1]: {id | length << 24 | user-defined << 31, score bits} of
                       // the piece of k + 1 bytes that begins at c + l; {kUwNone, kUwNan}: none.  A user-defined piece carries
                       // (float)length * max_score_ for a score.  (16-byte aligned: the rows are cleared two entries a store)
@@ -194,15 +194,18 @@ SPMX_DEVICE bool unigram_wave(const SpmxDev &d, const uint8_t *nt, int nlen, con
   float cur_s = lane == 0 ? 0.f : ninf, nxt_s = ninf;
   uint32_t cur_b = kUwUnreached, nxt_b = kUwUnreached;
   int next_start = 0;                                                // the next character start (absolute), across chunks
+  uint32_t text_v = 0;                                               // this lane's dword of the NEXT chunk's window
+  if (4 * lane < nlen) text_v = *reinterpret_cast<const uint32_t *>(nt + 4 * lane);
   uint32_t tie_credit = 0;                                           // (wave-uniform) grows with every chunk that met a tie, shrinks with every one that did not
   for (int c = 0; c <= nlen; c += 64) {                              // (c == nlen: only position nlen is left to store)
-    // ---- the text of this chunk's walks: positions [c, c + kUwWindow) ----
+    // ---- the text of this chunk's walks: positions [c, c + kUwWindow), asked for one chunk ahead (the load's latency
+    // sits behind the chunk before) ----
     wv::sync();                                                      // (the previous chunk's walks and fold are done)
+    *reinterpret_cast<uint32_t *>(T.win + 4 * lane) = text_v;
     {
-      const int q = c + 4 * lane;
-      uint32_t v = 0;
-      if (q < nlen) v = *reinterpret_cast<const uint32_t *>(nt + q);   // (the slice is padded: a whole dword is readable)
-      *reinterpret_cast<uint32_t *>(T.win + 4 * lane) = v;
+      const int q = c + 64 + 4 * lane;
+      text_v = 0;
+      if (q < nlen) text_v = *reinterpret_cast<const uint32_t *>(nt + q);   // (the slice is padded: a whole dword is readable)
     }
     wv::sync();
     const int s = c + lane;
@@ -304,27 +307,68 @@ SPMX_DEVICE bool unigram_wave(const SpmxDev &d, const uint8_t *nt, int nlen, con
     }
   }
   wv::sync_global();
-  // ---- backtrack (:1010-1018) through windows of 256 blen entries staged in LDS (the idle back-pointer ring) ----
+  // ---- backtrack (:1010-1018) through windows of 256 positions staged in LDS (over the matrix, dead now).  The chain
+  // from the window's last token end is not walked token by token (a dependent LDS read each: 350 cycles a token, a sixth
+  // of a megabyte document's time in round 6's first profile) but MARKED by pointer doubling: round k marks what the
+  // marked positions' 2^k-th predecessors are and squares the predecessor map -- eight rounds for 256 positions,
+  // whatever the number of tokens.  A position whose token begins at or below the window's first position ends the
+  // window: the next one begins there. ----
   uint32_t ok = 1;
   {
-    int e = nlen;                                                     // wave-uniform: broadcast from lane 0 after every window
+    uint32_t *len_w = T.ring_b, *j_a = len_w + kUwRing, *j_b = j_a + kUwRing, *mk = j_b + kUwRing;
+    int e = nlen;                                                     // wave-uniform
     while (e > 0) {
       const int lo = e > static_cast<int>(kUwRing) - 1 ? e - (static_cast<int>(kUwRing) - 1) : 0;   // window [lo, e]
+      const int W = e - lo + 1;
       wv::sync();
-      for (int p = lo + lane; p <= e; p += 64) T.ring_b[p - lo] = blen[p];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = lane + 64 * k, p = lo + i;
+        uint32_t len = 0;
+        if (i < W) len = blen[p] & 0x7FFFu;
+        len_w[i] = len;
+        const bool inner = i < W && len != 0u && static_cast<int>(len) < p - lo;       // its token begins inside the window
+        j_a[i] = inner ? static_cast<uint32_t>(i) - len : static_cast<uint32_t>(i);
+        mk[i] = i == W - 1 ? 1u : 0u;
+      }
       wv::sync();
-      int e2 = e;
-      if (lane == 0) {
-        while (e2 > lo) {
-          const int len = static_cast<int>(T.ring_b[e2 - lo] & 0x7FFFu);
-          if (len == 0 || len > e2) { ok = 0; e2 = 0; break; }
-          blen[e2] = static_cast<uint16_t>(kTokEnd | static_cast<uint32_t>(len));
-          if (e2 - len < lo) { e2 -= len; break; }                    // (cannot happen: len < 256 - 64; kept for safety)
-          e2 -= len;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const uint32_t *src = (r & 1) ? j_b : j_a;
+        uint32_t *dst = (r & 1) ? j_a : j_b;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = lane + 64 * k;
+          if (mk[i]) mk[src[i]] = 1u;
+        }
+        wv::sync();
+        if (r < 7) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int i = lane + 64 * k;
+            dst[i] = src[src[i]];
+          }
+          wv::sync();
         }
       }
-      e2 = wv::shfl(e2, 0);
-      if (e2 >= e) { ok = 0; break; }                                 // no progress: broken
+      int e2 = e;
+      bool bad = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = lane + 64 * k, p = lo + i;
+        int next = -1;
+        if (i < W && mk[i]) {                                         // a token end of the best path
+          const int len = static_cast<int>(len_w[i]);
+          if (len == 0 || len > p) bad = true;                        // (unreached / a length beyond the text: cannot happen)
+          else {
+            blen[p] = static_cast<uint16_t>(kTokEnd | static_cast<uint32_t>(len));
+            if (p - len <= lo) next = p - len;
+          }
+        }
+        const uint64_t m = wv::ballot(next >= 0);
+        if (m) e2 = wv::shfl(next, wv::ffs64(m) - 1);
+      }
+      if (wv::any(bad) || e2 >= e) { ok = 0; break; }                 // broken chain / no progress
       e = e2;
     }
   }
