@@ -226,29 +226,24 @@ SPMX_DEVICE bool unigram_wave(const SpmxDev &d, const uint8_t *nt, int nlen, con
       uint32_t node = root, dep = 0;
       uint32_t wsum = root_w;                                         // child-label summary of the node the walk stands on (dev.h ChildBit)
       bool single = false;                                            // a piece of exactly one character matched (:990)
+      // (one level of conditions: the loop is 64 lanes' worth of straight code around one LDS read and one probe)
       while (wv::any(alive)) {
-        if (alive) {
-          const int q = s + static_cast<int>(dep);
-          if (q >= nlen || dep >= ML) { alive = false; }              // (no piece is longer than ML bytes)
-          else if (!((wsum >> ChildBit(T.win[q - c])) & 1u)) { alive = false; }   // no child with this label: the failing probe is not issued
-          else {
-            const uint32_t cb = T.win[q - c];
-            const U4 u = ptrie[node ^ cb];
-            if ((u.x & 0x1FFu) == (0x100u | cb)) {                    // :969-971
-              node = u.x >> kDatBaseShiftDev;
-              wsum = u.w;
-              ++dep;
-              if ((u.x & kDatTerminalDev) && !(u.y & kPtUnused)) {    // :973-974
-                const bool ud = (u.y & kPtUserDefined) != 0u;
-                row[dep - 1u] = U2{(u.y & 0x00FFFFFFu) | (dep << 24) | (ud ? 0x80000000u : 0u),
-                                   ud ? wv::float_to_bits(static_cast<float>(static_cast<int>(dep)) * d.max_score) : u.z};
-                deep = dep;
-                if (static_cast<int>(dep) == step) single = true;
-              }
-            } else {
-              alive = false;
-            }
-          }
+        const int q = s + static_cast<int>(dep);
+        const uint32_t cb = T.win[(q - c) & static_cast<int>(kUwWindow - 1u)];   // (a dead lane reads what it likes)
+        // the next byte has a child below the node the walk stands on (dev.h ChildBit: a failing probe is not issued)
+        const bool go = alive && q < nlen && dep < ML && ((wsum >> ChildBit(cb)) & 1u) != 0u;   // (no piece is longer than ML bytes)
+        U4 u{0u, 0u, 0u, 0u};
+        if (go) u = ptrie[node ^ cb];
+        alive = go && (u.x & 0x1FFu) == (0x100u | cb);                // :969-971
+        node = alive ? u.x >> kDatBaseShiftDev : node;
+        wsum = alive ? u.w : wsum;
+        dep += alive ? 1u : 0u;
+        if (alive && (u.x & kDatTerminalDev) && !(u.y & kPtUnused)) {   // :973-974
+          const bool ud = (u.y & kPtUserDefined) != 0u;
+          row[dep - 1u] = U2{(u.y & 0x00FFFFFFu) | (dep << 24) | (ud ? 0x80000000u : 0u),
+                             ud ? wv::float_to_bits(static_cast<float>(static_cast<int>(dep)) * d.max_score) : u.z};
+          deep = dep;
+          single = single || static_cast<int>(dep) == step;
         }
       }
       if (is_start && !single) {                                      // :995-1005: the UNK candidate, `step` bytes long
