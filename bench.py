@@ -57,7 +57,11 @@ def traffic_on_record(model, sentences, kernel):
     if not os.path.exists(tpath):
         return None, None, "no PMC pass on record for this model / size / kernel"
     with open(tpath) as f:
-        rec = json.load(f).get("%s:%d:%s" % (model, sentences, kernel))
+        recs = json.load(f)
+    rec = recs.get("%s:%d:%s" % (model, sentences, kernel))
+    if not isinstance(rec, dict):      # (a kernel compiled for several row lengths: the profile names the instance, "UniLongKernel<16u>")
+        inst = [v for k, v in recs.items() if k.startswith("%s:%d:%s<" % (model, sentences, kernel)) and isinstance(v, dict)]
+        rec = inst[0] if len(inst) == 1 else None
     if not isinstance(rec, dict):
         return None, None, "no PMC pass on record for this model / size / kernel"
     if rec.get("src_sha") != sha:

@@ -66,14 +66,18 @@ struct Ctrl {
   uint32_t status;
   uint32_t retry_count[2];            // long form: sentences that found the pool exhausted (ping-pong)
   uint32_t pad;
+  // The words the kernels update with atomics all the time -- tile cursors, list counters, the arena's head -- each on a
+  // 128-byte line of their own.  Found by accident in round 6: the control block grew by one 16-byte queue, which moved the
+  // word kernels' list counters off the line of their tile cursor, and the first word round went from 3.84 to 3.1 ms with
+  // its code unchanged (profiles/README_r06.md).
   StreamQueue q[7];                   // tile queues of the main / document / overflow launches; [3], [4]: the word kernels; [5]: the tail launch; [6]: the split launch
-  uint32_t left_counts[3][kMaxClasses];   // word kernels: second-round input / general input / what the second round left, per class
+  alignas(128) uint32_t left_counts[3][32];   // word kernels: second-round input / general input / what the second round left, per class ([kMaxClasses] of a row used; a row = a line)
   uint32_t dyn_count;                     // ... words entered into the call-local memo (must follow left_counts: read together)
-  uint32_t align_counts[kMaxClasses]; // spans form: escalation lists of the staged align kernels
-  SideLists side;
-  unsigned long long arena_head;
-  unsigned long long pool_head;       // long form: bytes of slices asked for
-  unsigned long long stats[kStatsPerClass * kNumSlots];
+  alignas(128) uint32_t align_counts[kMaxClasses]; // spans form: escalation lists of the staged align kernels
+  alignas(128) SideLists side;
+  alignas(128) unsigned long long arena_head;
+  alignas(128) unsigned long long pool_head;       // long form: bytes of slices asked for
+  alignas(128) unsigned long long stats[kStatsPerClass * kNumSlots];
   unsigned long long bad_key;         // decode: min over offending (sentence << 32 | id)
   uint32_t big_count[2];              // CompactKernel: document blocks listed for CompactBigKernel (ids; token begins of the spans form)
   uint64_t total_ids;                 // copied from id_offs[n] by the final D2H

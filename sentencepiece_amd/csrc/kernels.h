@@ -52,9 +52,11 @@ struct StreamClass {
   uint32_t pad[1];
 };
 // Device-side state of the tile queue of ONE streaming launch, zeroed before it
-struct StreamQueue {
+// (a cache line of its own: every tile a launch takes is an atomic on this word, and what else lived on its line -- the
+// word kernels' list counters did until round 6 -- waited behind them)
+struct alignas(128) StreamQueue {
   uint32_t main_cursor;               // next main tile
-  uint32_t pad[3];
+  uint32_t pad[31];
 };
 // Lists that outlive a launch (one set per call): what the streaming launches could not take
 struct SideLists {
