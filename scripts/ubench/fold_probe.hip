@@ -15,7 +15,7 @@
 //       step), the 64 steps unrolled with the start a constant (readlane of a fixed lane, the row's LDS offset an
 //       immediate), lanes at or below the start masked by a NaN score, ties only RECORDED (a chunk with one is folded
 //       again the slow way), the window beyond the chunk only in the last 8 steps
-//   V6  V5, the 64 steps unrolled (the start's lane, the row's LDS offset are immediates; a skipped start is one branch)
+//   V6  V5, the 64 steps unrolled (kept for the record: the optimizer proves its result constant and removes it -- prints 0)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
