@@ -1,11 +1,5 @@
-mkdir -p gpurun_out/uw18
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-second-model --no-side-configs > gpurun_out/uw18/bench_a.json 2> gpurun_out/uw18/bench_a.err
-SPMX_EXP_SHARE=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-second-model --no-side-configs > gpurun_out/uw18/bench_b.json 2>> gpurun_out/uw18/bench_a.err
-python - <<'PY'
-import json
-for f in "ab":
-    try:
-        j=json.loads([l for l in open("gpurun_out/uw18/bench_%s.json"%f) if l.startswith("{")][-1])
-        print(f, j["ms_per_step"], j["value"], j["roofline"]["all_kernels_ms"], j["roofline"].get("probe"), j.get("cpu_baseline"))
-    except Exception as e: print(f, e)
-PY
+mkdir -p gpurun_out/pp
+PROBE_CORPUS=docs_1m python scripts/c5_probe.py uni32k 64 "" "SPMX_UW_PIPE=0" > gpurun_out/pp/docs1m.txt 2>&1
+PROBE_CORPUS=docs_16k python scripts/c5_probe.py uni32k 8192 "" "SPMX_UW_PIPE=2" > gpurun_out/pp/docs16k.txt 2>&1
+python -m pytest tests/test_documents.py -m gpu -x -q > gpurun_out/pp/pytest.txt 2>&1; tail -2 gpurun_out/pp/pytest.txt
+cat gpurun_out/pp/docs16k.txt gpurun_out/pp/docs1m.txt

@@ -332,6 +332,7 @@ struct spmx_handle {
   uint32_t split_per_byte = 4;   // SPMX_SPLIT_CANDS: candidates per normalized byte a sentence's stream holds before the overflow launch takes the sentence
   uint32_t compact_big = kCompactBigIds;   // CompactKernel: blocks with more ids go to CompactBigKernel (0: none do)
   bool uw_exact = false;
+  int uw_pipe = 1;               // SPMX_UW_PIPE: 0 never / 1 few long documents (default) / 2 always the two-wavefront form of the wave-cooperative kernel
   bool no_uni_wave = false;      // SPMX_NO_UNI_WAVE=1: unigram models never take the wave-cooperative form (kernels_uniwave.h)
   uint32_t uni_wave_max = 0;     // SPMX_UNI_WAVE_MAX: a staged class with fewer sentences than this takes the wave-cooperative form
   int word_wgs = 1;              // SPMX_WORD_WGS: workgroups per CU of the word kernel's first pass
@@ -925,7 +926,11 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         if (g > static_cast<uint64_t>(h->n_cu) * 16) g = static_cast<uint64_t>(h->n_cu) * 16;
         snprintf(ws->slot_name[kSlotLong], sizeof(ws->slot_name[kSlotLong]), uni ? "UniLongKernel" : "BpeLongKernel");
         if (!ws->slot_used[kSlotLong]) HIP_OR_RETURN(h, record(kSlotLong, 0));
-        if (uni) HIP_OR_RETURN(h, LaunchUniLong(la, UniWaveRow(h->tables.max_piece_len), static_cast<int>(g), stream));
+        // few, long documents: a workgroup of two wavefronts each (a walker and a folder side by side); many: a wavefront each
+        const bool pipe = uni && h->uw_pipe != 0 && (h->uw_pipe == 2 || (left <= static_cast<uint32_t>(h->n_cu) * 4u && text_bytes / n >= 4096u));
+        if (pipe) snprintf(ws->slot_name[kSlotLong], sizeof(ws->slot_name[kSlotLong]), "UniLongPipeKernel");
+        if (pipe) HIP_OR_RETURN(h, LaunchUniLongPipe(la, UniWaveRow(h->tables.max_piece_len), static_cast<int>(left < static_cast<uint32_t>(h->n_cu) * 8u ? left : static_cast<uint32_t>(h->n_cu) * 8u), stream));
+        else if (uni) HIP_OR_RETURN(h, LaunchUniLong(la, UniWaveRow(h->tables.max_piece_len), static_cast<int>(g), stream));
         else HIP_OR_RETURN(h, LaunchBpeLong(la, static_cast<int>(g), stream));
         HIP_OR_RETURN(h, record(kSlotLong, 1));
         ws->slot_used[kSlotLong] = true;
@@ -1711,6 +1716,7 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_SPLIT_LAUNCH")) h->split_own_launch = e[0] == '1';
     if (const char *e = getenv("SPMX_SPLIT_TILES")) { const int v = atoi(e); if (v >= 1 && v <= 16) h->split_tiles = static_cast<uint32_t>(v); }
     if (const char *e = getenv("SPMX_SPLIT_CANDS")) { const int v = atoi(e); if (v >= 1 && v <= 16) h->split_per_byte = static_cast<uint32_t>(v); }
+    if (const char *e = getenv("SPMX_UW_PIPE")) h->uw_pipe = atoi(e);
     if (const char *e = getenv("SPMX_UNI_WAVE_MAX")) h->uni_wave_max = static_cast<uint32_t>(atoll(e));
     if (const char *e = getenv("SPMX_WORD_WAVE")) { const int v = atoi(e); if (v >= 0 && v <= 3) h->word_form = v; }
     if (const char *e = getenv("SPMX_WORDWAVE_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 12) h->wordwave_waves = v; }

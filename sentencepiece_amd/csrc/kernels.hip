@@ -88,6 +88,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   uni_long_block<ML>(a, smem);
 }
 
+template <uint32_t ML>
+__global__ __launch_bounds__(128) void UniLongPipeKernel(LongArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uni_long_pipe_block<ML>(a, smem);
+}
+
 __global__ __launch_bounds__(64) void NormalizeLongCountKernel(NormalizeArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[64 * kRawWinBytes];
   norm_long_block<false>(a, smem);
@@ -307,6 +313,12 @@ hipError_t LaunchRebase(const RebaseArgs &a, int grid, hipStream_t stream) {
 
 hipError_t LaunchCompact(const CompactArgs &a, int grid, hipStream_t stream) {
   hipLaunchKernelGGL(CompactKernel, dim3(grid), dim3(64), CompactLdsBytes(a.staged), stream, a);
+  return hipGetLastError();
+}
+hipError_t LaunchUniLongPipe(const LongArgs &a, uint32_t cands, int grid, hipStream_t stream) {
+  if (cands == 16u) hipLaunchKernelGGL(UniLongPipeKernel<16>, dim3(grid), dim3(128), UniPipeLdsBytes(16), stream, a);
+  else if (cands == 32u) hipLaunchKernelGGL(UniLongPipeKernel<32>, dim3(grid), dim3(128), UniPipeLdsBytes(32), stream, a);
+  else hipLaunchKernelGGL(UniLongPipeKernel<64>, dim3(grid), dim3(128), UniPipeLdsBytes(64), stream, a);
   return hipGetLastError();
 }
 hipError_t LaunchCompactBig(const CompactArgs &a, int grid, hipStream_t stream) {

@@ -175,142 +175,171 @@ SPMX_DEVICE uint32_t uw_fold_float(const U2 *M, uint64_t S, uint32_t D, int lane
   return tie;
 }
 
-// EncodeOptimized of the normalized text nt[0, nlen) (device form, HBM) by one wavefront.  bid / blen: nlen + 2
-// entries in HBM, written here.  On return blen[e] has kTokEnd | length at every token end of the best path and bid[e]
-// the token's id (unk_id for an unknown character).  false: a broken chain (cannot happen).  cyc: [0] += the cycles of
-// the walks, [1] += of the folds.
+// ---- the two halves of a chunk: the WALKER's (text window, character starts, trie walks into the matrix) and the FOLDER's
+// (fold, the chunk's row of results to HBM, the matrix rows "none" again).  One wavefront does both in turn
+// (unigram_wave), or two wavefronts of a workgroup one each, the walker a chunk ahead (uni_long_pipe_block). ----
+struct UwWalker {
+  uint32_t text_v;     // this lane's dword of the NEXT chunk's text window
+  int next_start;      // the next character start (absolute), across chunks
+};
+struct UwFolder {
+  float cur_s, nxt_s;              // best_path_ends_at[c + lane], [c + 64 + lane]: score (-inf: no candidate yet)
+  uint32_t cur_b, nxt_b;           // ... piece: id | length << 24 (kUwUnreached)
+  uint32_t tie_credit;             // (wave-uniform) grows with every chunk that met a tie, shrinks with every one that did not
+};
+
+SPMX_DEVICE void uw_walker_begin(UwWalker &w, const uint8_t *nt, int nlen, int lane) {
+  w.next_start = 0;
+  w.text_v = 0;
+  if (4 * lane < nlen) w.text_v = *reinterpret_cast<const uint32_t *>(nt + 4 * lane);
+}
+
+// The chunk of positions [c, c + 64): its text into `win`, its character starts (*S, wave-uniform), every piece that begins
+// at start c + lane into row `lane` of the matrix `cands` (entry [0][0]).  *deep: the row's last entry that is not "none";
+// *D (wave-uniform): the largest of them.  cyc += the cycles of the walks.
 template <uint32_t ML>
-SPMX_DEVICE bool unigram_wave(const SpmxDev &d, const uint8_t *nt, int nlen, const UniWaveLds &T, int32_t *bid, uint16_t *blen,
-                              int lane, unsigned long long *cyc) {
+SPMX_DEVICE void uw_walk_chunk(const SpmxDev &d, const uint8_t *nt, int nlen, int c, uint8_t *win, U2 *cands, int lane, UwWalker &w,
+                               uint64_t *S_out, uint32_t *D_out, uint32_t *deep_out, unsigned long long *cyc) {
   const U4 *__restrict__ ptrie = d.ptrie;
   const uint32_t root = d.ptrie[0].x >> kDatBaseShiftDev;
   const uint32_t root_w = d.ptrie[0].w;
   const uint32_t spb = SpByteOf(d);
-  const float ninf = -__builtin_inff();
-  const U2 *M = T.cands - 1;
-  U2 *row = T.cands + static_cast<uint32_t>(lane) * ML;
-  for (uint32_t k = static_cast<uint32_t>(lane); k < UniWaveMatrixEntries(ML); k += 64u) T.cands[static_cast<int>(k) - 2] = U2{kUwNone, kUwNan};
-  // best_path_ends_at[c + lane] and [c + 64 + lane]; [0] = {0, nothing}
-  float cur_s = lane == 0 ? 0.f : ninf, nxt_s = ninf;
-  uint32_t cur_b = kUwUnreached, nxt_b = kUwUnreached;
-  int next_start = 0;                                                // the next character start (absolute), across chunks
-  uint32_t text_v = 0;                                               // this lane's dword of the NEXT chunk's window
-  if (4 * lane < nlen) text_v = *reinterpret_cast<const uint32_t *>(nt + 4 * lane);
-  uint32_t tie_credit = 0;                                           // (wave-uniform) grows with every chunk that met a tie, shrinks with every one that did not
-  for (int c = 0; c <= nlen; c += 64) {                              // (c == nlen: only position nlen is left to store)
-    // ---- the text of this chunk's walks: positions [c, c + kUwWindow), asked for one chunk ahead (the load's latency
-    // sits behind the chunk before) ----
-    wv::sync();                                                      // (the previous chunk's walks and fold are done)
-    *reinterpret_cast<uint32_t *>(T.win + 4 * lane) = text_v;
-    {
-      const int q = c + 64 + 4 * lane;
-      text_v = 0;
-      if (q < nlen) text_v = *reinterpret_cast<const uint32_t *>(nt + q);   // (the slice is padded: a whole dword is readable)
-    }
-    wv::sync();
-    const int s = c + lane;
-    const bool valid = s < nlen;
-    int step = 1;
-    if (valid) {
-      const uint32_t b0 = T.win[lane];
-      step = b0 == spb ? 1 : OneCharLenDev(b0);                       // :962-963
-      if (step > nlen - s) step = nlen - s;
-    }
-    const uint64_t S = wv::uniform64(resolve_chain(c, step, valid, &next_start));   // which positions are character starts (:1007)
-    const unsigned long long tw0 = wv::clock();
-    // ---- walk (:965-993): every piece that starts at s, by length, into row `lane` ----
-    uint32_t deep = 0;                                                // the row's last entry that is not "none"
-    {
-      const bool is_start = ((S >> lane) & 1ull) != 0;
-      bool alive = is_start;
-      uint32_t node = root, dep = 0;
-      uint32_t wsum = root_w;                                         // child-label summary of the node the walk stands on (dev.h ChildBit)
-      bool single = false;                                            // a piece of exactly one character matched (:990)
-      // (one level of conditions: the loop is 64 lanes' worth of straight code around one LDS read and one probe)
-      while (wv::any(alive)) {
-        const int q = s + static_cast<int>(dep);
-        const uint32_t cb = T.win[(q - c) & static_cast<int>(kUwWindow - 1u)];   // (a dead lane reads what it likes)
-        // the next byte has a child below the node the walk stands on (dev.h ChildBit: a failing probe is not issued)
-        const bool go = alive && q < nlen && dep < ML && ((wsum >> ChildBit(cb)) & 1u) != 0u;   // (no piece is longer than ML bytes)
-        U4 u{0u, 0u, 0u, 0u};
-        if (go) u = ptrie[node ^ cb];
-        alive = go && (u.x & 0x1FFu) == (0x100u | cb);                // :969-971
-        node = alive ? u.x >> kDatBaseShiftDev : node;
-        wsum = alive ? u.w : wsum;
-        dep += alive ? 1u : 0u;
-        if (alive && (u.x & kDatTerminalDev) && !(u.y & kPtUnused)) {   // :973-974
-          const bool ud = (u.y & kPtUserDefined) != 0u;
-          row[dep - 1u] = U2{(u.y & 0x00FFFFFFu) | (dep << 24) | (ud ? 0x80000000u : 0u),
-                             ud ? wv::float_to_bits(static_cast<float>(static_cast<int>(dep)) * d.max_score) : u.z};
-          deep = dep;
-          single = single || static_cast<int>(dep) == step;
-        }
-      }
-      if (is_start && !single) {                                      // :995-1005: the UNK candidate, `step` bytes long
-        const uint32_t us = static_cast<uint32_t>(step);
-        row[us - 1u] = U2{(static_cast<uint32_t>(d.unk_id) & 0x00FFFFFFu) | (us << 24) | 0x80000000u, wv::float_to_bits(d.unk_score)};   // (bit 31: uw_relax_float)
-        if (deep < us) deep = us;
+  U2 *row = cands + static_cast<uint32_t>(lane) * ML;
+  // ---- the text of this chunk's walks: positions [c, c + kUwWindow), asked for one chunk ahead (the load's latency
+  // sits behind the chunk before) ----
+  wv::sync();                                                        // (the previous chunk's walks are done with the window)
+  *reinterpret_cast<uint32_t *>(win + 4 * lane) = w.text_v;
+  {
+    const int q = c + 64 + 4 * lane;
+    w.text_v = 0;
+    if (q < nlen) w.text_v = *reinterpret_cast<const uint32_t *>(nt + q);   // (the slice is padded: a whole dword is readable)
+  }
+  wv::sync();
+  const int s = c + lane;
+  const bool valid = s < nlen;
+  int step = 1;
+  if (valid) {
+    const uint32_t b0 = win[lane];
+    step = b0 == spb ? 1 : OneCharLenDev(b0);                         // :962-963
+    if (step > nlen - s) step = nlen - s;
+  }
+  const uint64_t S = wv::uniform64(resolve_chain(c, step, valid, &w.next_start));   // which positions are character starts (:1007)
+  const unsigned long long tw0 = wv::clock();
+  // ---- walk (:965-993): every piece that starts at s, by length, into row `lane` ----
+  uint32_t deep = 0;
+  {
+    const bool is_start = ((S >> lane) & 1ull) != 0;
+    bool alive = is_start;
+    uint32_t node = root, dep = 0;
+    uint32_t wsum = root_w;                                           // child-label summary of the node the walk stands on (dev.h ChildBit)
+    bool single = false;                                              // a piece of exactly one character matched (:990)
+    // (one level of conditions: the loop is 64 lanes' worth of straight code around one LDS read and one probe)
+    while (wv::any(alive)) {
+      const int q = s + static_cast<int>(dep);
+      const uint32_t cb = win[(q - c) & static_cast<int>(kUwWindow - 1u)];   // (a dead lane reads what it likes)
+      // the next byte has a child below the node the walk stands on (dev.h ChildBit: a failing probe is not issued)
+      const bool go = alive && q < nlen && dep < ML && ((wsum >> ChildBit(cb)) & 1u) != 0u;   // (no piece is longer than ML bytes)
+      U4 u{0u, 0u, 0u, 0u};
+      if (go) u = ptrie[node ^ cb];
+      alive = go && (u.x & 0x1FFu) == (0x100u | cb);                  // :969-971
+      node = alive ? u.x >> kDatBaseShiftDev : node;
+      wsum = alive ? u.w : wsum;
+      dep += alive ? 1u : 0u;
+      if (alive && (u.x & kDatTerminalDev) && !(u.y & kPtUnused)) {   // :973-974
+        const bool ud = (u.y & kPtUserDefined) != 0u;
+        row[dep - 1u] = U2{(u.y & 0x00FFFFFFu) | (dep << 24) | (ud ? 0x80000000u : 0u),
+                           ud ? wv::float_to_bits(static_cast<float>(static_cast<int>(dep)) * d.max_score) : u.z};
+        deep = dep;
+        single = single || static_cast<int>(dep) == step;
       }
     }
-    const uint32_t D = wv::uniform(wv::read_lane(wv::scan_max(deep), 63));
-    wv::sync();
-    const unsigned long long tw1 = wv::clock();
-    // ---- fold: the starts one after another (a start's score must be final before its candidates are scored) ----
-    if (S != 0) {
-      // float arithmetic while every score the chunk starts from is above -uw_f32_limit (nxt has none yet)
-      const bool f32 = d.uw_f32_limit > 0.f && !wv::any(cur_s <= -d.uw_f32_limit && cur_s > ninf);
-      if (f32) {
-        // which float flavour: the one that decides ties itself while ties are frequent (tie_credit), else the shorter
-        // one, and the chunk again with the other if it met one
-        const bool all = S == ~0ull;
-        bool ties = !all || tie_credit > 8u;
-        if (!ties) {
-          const float s0 = cur_s;
-          const uint32_t b0 = cur_b;
-          if (wv::any(uw_fold_float<ML, true, false>(M, S, D, lane, cur_s, cur_b, nxt_s, nxt_b) != 0u)) {
-            cur_s = s0; cur_b = b0; nxt_s = ninf; nxt_b = kUwUnreached;
-            tie_credit = tie_credit + 8u > 64u ? 64u : tie_credit + 8u;
-            ties = true;
-          } else if (tie_credit != 0u) {
-            --tie_credit;
-          }
-        } else if (all) {
-          --tie_credit;
-        }
-        if (ties) {
-          if (all) (void)uw_fold_float<ML, true, true>(M, S, D, lane, cur_s, cur_b, nxt_s, nxt_b);
-          else (void)uw_fold_float<ML, false, true>(M, S, D, lane, cur_s, cur_b, nxt_s, nxt_b);
-        }
-      }
-      else uw_fold_exact<ML>(d, M, S, lane, cur_s, cur_b, nxt_s, nxt_b);
-    }
-    cyc[0] += tw1 - tw0; cyc[1] += wv::clock() - tw1;
-    // ---- positions [c, c + 64) are final: one coalesced row to HBM; the row of the matrix is "none" again ----
-    {
-      const int p = c + lane;
-      if (p <= nlen) {
-        bid[p] = cur_b == kUwUnreached ? 0 : static_cast<int32_t>(cur_b & 0x00FFFFFFu);
-        blen[p] = cur_b == kUwUnreached ? static_cast<uint16_t>(0) : static_cast<uint16_t>((cur_b >> 24) & 0x7Fu);
-      }
-      cur_s = nxt_s; cur_b = nxt_b;
-      nxt_s = ninf; nxt_b = kUwUnreached;
-      wv::sync();                                                    // (every lane has read the matrix)
-      if (deep != 0u) {
-#pragma unroll
-        for (uint32_t k = 0; k < ML; ++k) row[k] = U2{kUwNone, kUwNan};
-      }
+    if (is_start && !single) {                                        // :995-1005: the UNK candidate, `step` bytes long
+      const uint32_t us = static_cast<uint32_t>(step);
+      row[us - 1u] = U2{(static_cast<uint32_t>(d.unk_id) & 0x00FFFFFFu) | (us << 24) | 0x80000000u, wv::float_to_bits(d.unk_score)};   // (bit 31: uw_relax_float)
+      if (deep < us) deep = us;
     }
   }
-  wv::sync_global();
-  // ---- backtrack (:1010-1018) through windows of 256 positions staged in LDS (over the matrix, dead now).  The chain
-  // from the window's last token end is not walked token by token (a dependent LDS read each: 350 cycles a token, a sixth
-  // of a megabyte document's time in round 6's first profile) but MARKED by pointer doubling: round k marks what the
-  // marked positions' 2^k-th predecessors are and squares the predecessor map -- eight rounds for 256 positions,
-  // whatever the number of tokens.  A position whose token begins at or below the window's first position ends the
-  // window: the next one begins there. ----
+  *S_out = S;
+  *D_out = wv::uniform(wv::read_lane(wv::scan_max(deep), 63));
+  *deep_out = deep;
+  *cyc += wv::clock() - tw0;
+}
+
+SPMX_DEVICE void uw_folder_begin(UwFolder &f, int lane) {
+  const float ninf = -__builtin_inff();
+  f.cur_s = lane == 0 ? 0.f : ninf;                                   // best_path_ends_at[0] = {0, nothing}
+  f.nxt_s = ninf;
+  f.cur_b = kUwUnreached; f.nxt_b = kUwUnreached;
+  f.tie_credit = 0;
+}
+
+// The fold of the chunk whose matrix is `cands` (entry [0][0]): the starts one after another (a start's score must be
+// final before its candidates are scored).  cyc += its cycles.
+template <uint32_t ML>
+SPMX_DEVICE void uw_fold_chunk(const SpmxDev &d, const U2 *cands, uint64_t S, uint32_t D, int lane, UwFolder &f, unsigned long long *cyc) {
+  const unsigned long long t0 = wv::clock();
+  const float ninf = -__builtin_inff();
+  const U2 *M = cands - 1;
+  if (S != 0) {
+    // float arithmetic while every score the chunk starts from is above -uw_f32_limit (nxt has none yet)
+    const bool f32 = d.uw_f32_limit > 0.f && !wv::any(f.cur_s <= -d.uw_f32_limit && f.cur_s > ninf);
+    if (f32) {
+      // which float flavour: the one that decides ties itself while ties are frequent (tie_credit), else the shorter
+      // one, and the chunk again with the other if it met one
+      const bool all = S == ~0ull;
+      bool ties = !all || f.tie_credit > 8u;
+      if (!ties) {
+        const float s0 = f.cur_s;
+        const uint32_t b0 = f.cur_b;
+        if (wv::any(uw_fold_float<ML, true, false>(M, S, D, lane, f.cur_s, f.cur_b, f.nxt_s, f.nxt_b) != 0u)) {
+          f.cur_s = s0; f.cur_b = b0; f.nxt_s = ninf; f.nxt_b = kUwUnreached;
+          f.tie_credit = f.tie_credit + 8u > 64u ? 64u : f.tie_credit + 8u;
+          ties = true;
+        } else if (f.tie_credit != 0u) {
+          --f.tie_credit;
+        }
+      } else if (all) {
+        --f.tie_credit;
+      }
+      if (ties) {
+        if (all) (void)uw_fold_float<ML, true, true>(M, S, D, lane, f.cur_s, f.cur_b, f.nxt_s, f.nxt_b);
+        else (void)uw_fold_float<ML, false, true>(M, S, D, lane, f.cur_s, f.cur_b, f.nxt_s, f.nxt_b);
+      }
+    }
+    else uw_fold_exact<ML>(d, M, S, lane, f.cur_s, f.cur_b, f.nxt_s, f.nxt_b);
+  }
+  *cyc += wv::clock() - t0;
+}
+
+// Positions [c, c + 64) are final: one coalesced row to HBM; what reached beyond the chunk becomes the next chunk's start;
+// row `lane` of the matrix is "none" again (deep: what the walker said of it).
+template <uint32_t ML>
+SPMX_DEVICE void uw_flush_chunk(int c, int nlen, int32_t *bid, uint16_t *blen, U2 *cands, uint32_t deep, int lane, UwFolder &f) {
+  const int p = c + lane;
+  if (p <= nlen) {
+    bid[p] = f.cur_b == kUwUnreached ? 0 : static_cast<int32_t>(f.cur_b & 0x00FFFFFFu);
+    blen[p] = f.cur_b == kUwUnreached ? static_cast<uint16_t>(0) : static_cast<uint16_t>((f.cur_b >> 24) & 0x7Fu);
+  }
+  f.cur_s = f.nxt_s; f.cur_b = f.nxt_b;
+  f.nxt_s = -__builtin_inff(); f.nxt_b = kUwUnreached;
+  wv::sync();                                                        // (every lane has read the matrix)
+  if (deep != 0u) {
+    U2 *row = cands + static_cast<uint32_t>(lane) * ML;
+#pragma unroll
+    for (uint32_t k = 0; k < ML; ++k) row[k] = U2{kUwNone, kUwNan};
+  }
+}
+
+// The backtrack (:1010-1018) through windows of 256 positions staged in LDS (`ws`: 4 * kUwRing words): on return blen[e] has
+// kTokEnd | length at every token end of the best path.  The chain from the window's last token end is not walked token by
+// token (a dependent LDS read each: 350 cycles a token, a sixth of a megabyte document's time in round 6's first profile)
+// but MARKED by pointer doubling: round k marks what the marked positions' 2^k-th predecessors are and squares the
+// predecessor map -- eight rounds for 256 positions, whatever the number of tokens.  A position whose token begins at or
+// below the window's first position ends the window: the next one begins there.  false: a broken chain (cannot happen).
+SPMX_DEVICE bool uw_backtrack(uint32_t *ws, uint16_t *blen, int nlen, int lane) {
   uint32_t ok = 1;
   {
-    uint32_t *len_w = T.ring_b, *j_a = len_w + kUwRing, *j_b = j_a + kUwRing, *mk = j_b + kUwRing;
+    uint32_t *len_w = ws, *j_a = len_w + kUwRing, *j_b = j_a + kUwRing, *mk = j_b + kUwRing;
     int e = nlen;                                                     // wave-uniform
     while (e > 0) {
       const int lo = e > static_cast<int>(kUwRing) - 1 ? e - (static_cast<int>(kUwRing) - 1) : 0;   // window [lo, e]
@@ -370,6 +399,31 @@ SPMX_DEVICE bool unigram_wave(const SpmxDev &d, const uint8_t *nt, int nlen, con
   ok = wv::shfl(ok, 0);
   return ok != 0;
 }
+
+// EncodeOptimized of the normalized text nt[0, nlen) (device form, HBM) by one wavefront.  bid / blen: nlen + 2
+// entries in HBM, written here.  On return blen[e] has kTokEnd | length at every token end of the best path and bid[e]
+// the token's id (unk_id for an unknown character).  false: a broken chain (cannot happen).  cyc: [0] += the cycles of
+// the walks, [1] += of the folds.
+template <uint32_t ML>
+SPMX_DEVICE bool unigram_wave(const SpmxDev &d, const uint8_t *nt, int nlen, const UniWaveLds &T, int32_t *bid, uint16_t *blen,
+                              int lane, unsigned long long *cyc) {
+  for (uint32_t k = static_cast<uint32_t>(lane); k < UniWaveMatrixEntries(ML); k += 64u) T.cands[static_cast<int>(k) - 2] = U2{kUwNone, kUwNan};
+  UwWalker w;
+  UwFolder f;
+  uw_walker_begin(w, nt, nlen, lane);
+  uw_folder_begin(f, lane);
+  for (int c = 0; c <= nlen; c += 64) {                              // (c == nlen: only position nlen is left to store)
+    uint64_t S;
+    uint32_t D, deep;
+    uw_walk_chunk<ML>(d, nt, nlen, c, T.win, T.cands, lane, w, &S, &D, &deep, &cyc[0]);
+    wv::sync();
+    uw_fold_chunk<ML>(d, T.cands, S, D, lane, f, &cyc[1]);
+    uw_flush_chunk<ML>(c, nlen, bid, blen, T.cands, deep, lane, f);
+  }
+  wv::sync_global();
+  return uw_backtrack(T.ring_b, blen, nlen, lane);                    // (over the matrix, dead now)
+}
+
 
 // One sentence per wavefront over a device-side list; slices from the long form's pool (LongArgs, kernels_long.h).
 template <uint32_t ML>
@@ -486,6 +540,204 @@ SPMX_DEVICE void uni_long_block(const LongArgs &a, unsigned char *smem) {
     wv::atomic_add(&a.stats[4], st_cyc[0]);       // normalize
     wv::atomic_add(&a.stats[5], st_cyc[1]);       // segment
     wv::atomic_add(&a.stats[6], st_cyc[2]);       // emit
+  }
+}
+
+// ---- a document per WORKGROUP OF TWO wavefronts (round 6): wavefront 0 normalizes and then WALKS, a chunk ahead of
+// wavefront 1, which FOLDS, stores, and at the end backtracks and emits.  The hand-over is the matrix (two of them, by the
+// chunk's parity) and three words beside it (the chunk's character starts, its longest piece, every row's depth); one
+// workgroup barrier per chunk.  For batches of FEW long documents: a document that has a CU to itself spends 130 + 40 cycles a
+// byte in the walker's half and 130 + 30 in the folder's, and this form runs them side by side.  (A batch of thousands of
+// documents fills the chip with one wavefront each -- uni_long_block -- and gains nothing from pairs.) ----
+struct UniPipeHdr {            // wavefront 0 -> wavefront 1, per document
+  unsigned long long norm, bid, blen;
+  int32_t nlen;
+  uint32_t go;                 // 1: fold it; 0: the document is done with (empty, failed, on the retry list)
+};
+struct UniPipeMeta {           // per chunk parity
+  uint32_t s_lo, s_hi, d, pad;
+  uint8_t deep[64];
+};
+SPMX_HD constexpr uint32_t UniPipeLdsBytes(uint32_t ML) {
+  return 2u * UniWaveMatrixEntries(ML) * 8u + kUwWindow + 16u + ((kRawWinBytes + 15u) & ~15u) + 64u + 2u * 96u;
+}
+
+template <uint32_t ML>
+SPMX_DEVICE void uni_long_pipe_block(const LongArgs &a, unsigned char *smem) {
+  const int lane = wv::lane();
+  const bool walker = wv::wave_in_block() == 0;
+  const SpmxDev &d = a.dev;
+  constexpr uint32_t kM = UniWaveMatrixEntries(ML) * 8u;
+  U2 *cands[2] = {reinterpret_cast<U2 *>(smem) + 2, reinterpret_cast<U2 *>(smem + kM) + 2};    // entry [0][0] of each matrix
+  uint8_t *win = smem + 2u * kM;
+  uint8_t *rawwin = win + kUwWindow + 16u;
+  UniPipeHdr *hdr = reinterpret_cast<UniPipeHdr *>(rawwin + ((kRawWinBytes + 15u) & ~15u));
+  UniPipeMeta *meta = reinterpret_cast<UniPipeMeta *>(reinterpret_cast<unsigned char *>(hdr) + 64);   // [2], 96 bytes apart
+  auto meta_of = [&](int k) -> UniPipeMeta * { return reinterpret_cast<UniPipeMeta *>(reinterpret_cast<unsigned char *>(meta) + 96 * (k & 1)); };
+  const uint32_t count = *a.list_count;
+  const int n_extra = d.n_prefix + d.n_suffix;
+  unsigned long long st_sent = 0, st_raw = 0, st_ids = 0, st_cyc[3] = {0, 0, 0}, st_seg[2] = {0, 0};
+  for (uint32_t i = static_cast<uint32_t>(wv::block_id()); i < count; i += static_cast<uint32_t>(wv::grid_size())) {
+    const unsigned long long t0 = wv::clock();
+    const uint32_t sid = a.list[i];
+    const uint64_t beg = a.offs[sid];
+    const uint64_t L64 = a.offs[sid + 1] - beg;
+    const int L = static_cast<int>(L64 > 0x7FFFFFF0ull ? 0x7FFFFFF0ull : L64);
+    if (walker) {
+      // ---- wavefront 0: the slice and the normalized text (as uni_long_block) ----
+      uint32_t go = 0;
+      uint8_t *norm = nullptr;
+      int32_t *bid = nullptr;
+      uint16_t *blen = nullptr;
+      int nlen = 0;
+      auto take_slice = [&](uint64_t cap) -> bool {
+        const uint64_t b_text = Align16(cap + kUwWindow + 16);
+        const uint64_t b_bid = Align16((cap + 2) * 4);
+        const uint64_t b_len = Align16((cap + 2) * 2);
+        const uint64_t need = b_text + b_bid + b_len;
+        unsigned long long at = 0;
+        if (lane == 0) at = wv::atomic_add(a.pool_head, static_cast<unsigned long long>(need));
+        at = (static_cast<unsigned long long>(wv::shfl(static_cast<uint32_t>(at >> 32), 0)) << 32) | wv::shfl(static_cast<uint32_t>(at), 0);
+        if (at + need > a.pool_cap) {                                 // the host grows the pool and launches again
+          if (lane == 0) { a.retry_list[wv::atomic_add(a.retry_count, 1u)] = sid; a.counts[sid] = 0u; }
+          return false;
+        }
+        norm = a.pool + at;
+        bid = reinterpret_cast<int32_t *>(norm + b_text);
+        blen = reinterpret_cast<uint16_t *>(norm + b_text + b_bid);
+        return true;
+      };
+      bool done = false;                                              // nothing for the folder: failed, on the retry list, empty
+      if (L64 > 0x7FFFFFF0ull / (d.expand_max ? d.expand_max : 1u)) {   // its normalized form could pass 2^31 bytes
+        if (lane == 0) {
+          a.counts[sid] = 0; a.tmp_off[sid] = 0; a.sent_status[sid] = static_cast<uint8_t>(kSsOutOfRange);
+          wv::atomic_add(&a.side->n_failed, 1ull);
+        }
+        done = true;
+      } else if (L > 0) {
+        const bool esc3 = (d.flags & kNfEscapeWs) && !(d.flags & kNfCompressSp);
+        uint64_t cap1 = esc3 ? 3ull * static_cast<uint64_t>(L) + 64u : static_cast<uint64_t>(L) + static_cast<uint64_t>(L) / 2u + 64u;
+        const uint64_t bound = static_cast<uint64_t>(L) * d.expand_max + 16u;
+        if (cap1 > bound) cap1 = bound;
+        if (!take_slice(cap1)) done = true;
+        else {
+          nlen = normalize_wave<true>(d, a.text + beg, L, norm, static_cast<int>(cap1), lane);
+          if (nlen < 0) {                                             // it outgrew the slice: count, a slice of that size, write
+            int n2 = 0;
+            if (lane == 0) {
+              int nsp = 0;
+              FlatSink cs{nullptr, nullptr, 0};
+              n2 = norm_lane_any(d, a.text, beg, L, cs, rawwin, &nsp);
+            }
+            n2 = wv::shfl(n2, 0);
+            if (n2 > 0) {
+              if (!take_slice(static_cast<uint64_t>(n2))) done = true;
+              else if (lane == 0) {
+                FlatSink ws{norm, nullptr, n2};
+                int nsp2 = 0;
+                norm_lane_any(d, a.text, beg, L, ws, rawwin, &nsp2);
+              }
+            }
+            nlen = n2;
+          }
+        }
+      }
+      if (!done && nlen == 0) {                                       // (empty, or nothing but whitespace)
+        if (lane == 0) {
+          const unsigned long long at = wv::atomic_add(a.arena_head, static_cast<unsigned long long>(n_extra));
+          a.tmp_off[sid] = at;
+          a.counts[sid] = static_cast<uint32_t>(n_extra);
+          if (at + static_cast<unsigned long long>(n_extra) > a.arena_cap) wv::atomic_or(a.status, kStArenaOverflow);
+          else {
+            for (int x = 0; x < d.n_prefix; ++x) a.arena[at + x] = d.prefix_ids[x];
+            for (int x = 0; x < d.n_suffix; ++x) a.arena[at + d.n_prefix + x] = d.suffix_ids[x];
+          }
+        }
+        ++st_sent; st_raw += static_cast<unsigned long long>(L); st_ids += static_cast<unsigned long long>(n_extra);
+        done = true;
+      }
+      go = done ? 0u : 1u;
+      if (lane == 0) {
+        if (go) { blen[0] = 0; bid[0] = 0; }
+        hdr->norm = reinterpret_cast<unsigned long long>(norm); hdr->bid = reinterpret_cast<unsigned long long>(bid);
+        hdr->blen = reinterpret_cast<unsigned long long>(blen); hdr->nlen = nlen; hdr->go = go;
+      }
+      wv::sync_global();                                              // (the normalized text is in HBM before the walks read it)
+      st_cyc[0] += wv::clock() - t0;
+    } else {
+      // ---- wavefront 1 meanwhile: both matrices "none" ----
+      for (uint32_t k = static_cast<uint32_t>(lane); k < 2u * UniWaveMatrixEntries(ML); k += 64u) reinterpret_cast<U2 *>(smem)[k] = U2{kUwNone, kUwNan};
+    }
+    wv::block_sync();
+    const uint32_t go = hdr->go;
+    const int nlen = hdr->nlen;
+    const uint8_t *norm = reinterpret_cast<const uint8_t *>(hdr->norm);
+    int32_t *bid = reinterpret_cast<int32_t *>(hdr->bid);
+    uint16_t *blen = reinterpret_cast<uint16_t *>(hdr->blen);
+    if (go) {
+      // ---- the chunks: iteration k walks chunk k and folds chunk k - 1 ----
+      const unsigned long long t1 = wv::clock();
+      const int n_chunks = nlen / 64 + 1;                             // (the last one may hold position nlen only)
+      UwWalker w;
+      UwFolder f;
+      if (walker) uw_walker_begin(w, norm, nlen, lane); else uw_folder_begin(f, lane);
+      for (int k = 0; k <= n_chunks; ++k) {
+        if (walker) {
+          if (k < n_chunks) {
+            uint64_t S;
+            uint32_t D, deep;
+            uw_walk_chunk<ML>(d, norm, nlen, 64 * k, win, cands[k & 1], lane, w, &S, &D, &deep, &st_seg[0]);
+            UniPipeMeta *m = meta_of(k);
+            m->deep[lane] = static_cast<uint8_t>(deep);
+            if (lane == 0) { m->s_lo = static_cast<uint32_t>(S); m->s_hi = static_cast<uint32_t>(S >> 32); m->d = D; }
+          }
+        } else if (k >= 1) {
+          const UniPipeMeta *m = meta_of(k - 1);
+          const uint64_t S = wv::uniform64(static_cast<uint64_t>(m->s_hi) << 32 | m->s_lo);
+          const uint32_t D = wv::uniform(m->d);
+          const uint32_t deep = m->deep[lane];
+          uw_fold_chunk<ML>(d, cands[(k - 1) & 1], S, D, lane, f, &st_seg[1]);
+          uw_flush_chunk<ML>(64 * (k - 1), nlen, bid, blen, cands[(k - 1) & 1], deep, lane, f);
+        }
+        wv::block_sync();
+      }
+      if (!walker) {
+        wv::sync_global();
+        const bool ok = uw_backtrack(reinterpret_cast<uint32_t *>(smem), blen, nlen, lane);      // (over the first matrix, dead now)
+        wv::sync_global();
+        const unsigned long long t2 = wv::clock();
+        if (!ok) {                                                    // "all normalized characters are not consumed."
+          if (lane == 0) {
+            a.counts[sid] = 0; a.tmp_off[sid] = 0; a.sent_status[sid] = static_cast<uint8_t>(kSsInternal);
+            wv::atomic_add(&a.side->n_failed, 1ull);
+          }
+        } else {
+          const int n_out = emit_wave(a, sid, norm, nlen, bid, blen, lane);
+          ++st_sent; st_raw += static_cast<unsigned long long>(L); st_ids += static_cast<unsigned long long>(n_out);
+          st_cyc[1] += t2 - t1; st_cyc[2] += wv::clock() - t2;
+        }
+      }
+    }
+    wv::block_sync();                                                 // (the next document's header and matrices are this one's)
+  }
+  // (one wavefront after the other: both add to the same three counters)
+  for (int turn = 0; turn < 2; ++turn) {
+    if (a.stats && lane == 0 && turn == (walker ? 0 : 1)) {
+      if (st_sent) {
+        wv::atomic_add(&a.stats[0], st_sent);
+        wv::atomic_add(&a.stats[1], st_raw);
+        wv::atomic_add(&a.stats[2], st_ids);
+      }
+      if (walker) {
+        wv::atomic_add(&a.stats[3], st_seg[0]);       // the walks
+        wv::atomic_add(&a.stats[4], st_cyc[0]);       // normalize
+      } else {
+        wv::atomic_add(&a.stats[7], st_seg[1]);       // the fold
+        wv::atomic_add(&a.stats[5], st_cyc[1]);       // segment: the chunks' pipeline and the backtrack, by the folder's clock
+        wv::atomic_add(&a.stats[6], st_cyc[2]);       // emit
+      }
+    }
+    wv::block_sync();
   }
 }
 

@@ -46,6 +46,8 @@ hipError_t LaunchWordResolve(const ResolveArgs &a, int grid, hipStream_t stream)
 hipError_t LaunchBpeLong(const LongArgs &a, int grid, hipStream_t stream);
 // The wave-cooperative unigram form (kernels_uniwave.h): one sentence per 64-thread workgroup; cands = entries of a matrix row (UniWaveRow: the longest piece in bytes)
 hipError_t LaunchUniLong(const LongArgs &a, uint32_t cands, int grid, hipStream_t stream);
+// ... a document per workgroup of two wavefronts, a walker and a folder (kernels_uniwave.h uni_long_pipe_block): few, long documents
+hipError_t LaunchUniLongPipe(const LongArgs &a, uint32_t cands, int grid, hipStream_t stream);
 hipError_t LaunchNormalizeLong(bool write, const NormalizeArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchAlignLong(const AlignLongArgs &a, int grid, hipStream_t stream);
 hipError_t LaunchEncode(int model_type, int cls, const EncodeArgs &a, int grid, uint32_t lds_bytes, hipStream_t stream);

@@ -93,6 +93,10 @@ SPMX_DEVICE void sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup barrier of a kernel whose wavefronts work TOGETHER (kernels_uniwave.h uni_long_pipe_block: a walker and a folder):
+// every wavefront of the workgroup arrives, LDS writes before it are visible behind it.
+SPMX_DEVICE void block_sync() { __syncthreads(); }
+
 // As sync(), for HBM: this wave's global stores before the call are visible to every lane's loads after it
 // (all lanes of a wave share one vector L1; the fence drains the store queue).
 SPMX_DEVICE void sync_global() {

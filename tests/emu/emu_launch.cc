@@ -4,6 +4,10 @@
 // the waves of a workgroup share one LDS block, as on the device.
 #include "wave_emu.h"
 
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../sentencepiece_amd/csrc/launch.h"
@@ -24,6 +28,70 @@ void RunGrid(int grid, int waves, uint32_t lds_bytes, F body) {
   }
   emu::g_wave.wib = 0;
   emu::g_wave.wpb = 1;
+}
+// Workgroups of TWO wavefronts that run side by side and meet at wv::block_sync() (the documents' walker / folder pair):
+// the second wavefront on a helper thread that lives as long as the process (a wavefront's 64 lane stacks belong to its
+// thread), a two-party barrier between them.
+class Together {
+ public:
+  void Arrive() {
+    std::unique_lock<std::mutex> l(mu_);
+    const uint64_t gen = gen_;
+    if (++waiting_ == 2) { waiting_ = 0; ++gen_; cv_.notify_all(); }
+    else cv_.wait(l, [&] { return gen_ != gen; });
+  }
+  void RunOnHelper(std::function<void()> f) {
+    std::unique_lock<std::mutex> l(mu_);
+    if (!started_) { started_ = true; std::thread([this] { Loop(); }).detach(); }
+    task_ = std::move(f); has_task_ = true; task_done_ = false;
+    cv_.notify_all();
+  }
+  void WaitHelper() {
+    std::unique_lock<std::mutex> l(mu_);
+    cv_.wait(l, [&] { return task_done_; });
+  }
+ private:
+  void Loop() {
+    for (;;) {
+      std::function<void()> f;
+      {
+        std::unique_lock<std::mutex> l(mu_);
+        cv_.wait(l, [&] { return has_task_; });
+        f = std::move(task_); has_task_ = false;
+      }
+      f();
+      { std::unique_lock<std::mutex> l(mu_); task_done_ = true; cv_.notify_all(); }
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  int waiting_ = 0;
+  uint64_t gen_ = 0;
+  bool started_ = false, has_task_ = false, task_done_ = true;
+  std::function<void()> task_;
+};
+Together &g_together = *new Together;              // (never destroyed: its helper thread waits on it until the process ends)
+std::mutex &g_together_user = *new std::mutex;   // (one launch of this kind at a time: the pipelined host form has several workers)
+
+template <typename F>
+void RunGridTogether(int grid, uint32_t lds_bytes, F body) {
+  std::lock_guard<std::mutex> user(g_together_user);
+  std::vector<unsigned char> raw(lds_bytes + 128);
+  unsigned char *smem = raw.data() + ((64 - (reinterpret_cast<uintptr_t>(raw.data()) & 63)) & 63);
+  for (int b = 0; b < grid; ++b) {
+    memset(smem, 0xCD, lds_bytes + 32);
+    g_together.RunOnHelper([&, b] {
+      emu::g_wave.wib = 1; emu::g_wave.wpb = 2;
+      emu::g_wave.block_barrier = [] { g_together.Arrive(); };
+      emu::RunWave(b, grid, smem, [&] { body(smem); });
+    });
+    emu::g_wave.wib = 0; emu::g_wave.wpb = 2;
+    emu::g_wave.block_barrier = [] { g_together.Arrive(); };
+    emu::RunWave(b, grid, smem, [&] { body(smem); });
+    g_together.WaitHelper();
+  }
+  emu::g_wave.wib = 0; emu::g_wave.wpb = 1;
+  emu::g_wave.block_barrier = nullptr;
 }
 }  // namespace
 
@@ -80,6 +148,13 @@ hipError_t LaunchUniLong(const LongArgs &a, uint32_t cands, int grid, hipStream_
   if (cands == 16u) RunGrid(grid, 1, UniWaveLdsBytes(16), [&](unsigned char *s) { uni_long_block<16>(a, s); });
   else if (cands == 32u) RunGrid(grid, 1, UniWaveLdsBytes(32), [&](unsigned char *s) { uni_long_block<32>(a, s); });
   else RunGrid(grid, 1, UniWaveLdsBytes(64), [&](unsigned char *s) { uni_long_block<64>(a, s); });
+  return hipSuccess;
+}
+
+hipError_t LaunchUniLongPipe(const LongArgs &a, uint32_t cands, int grid, hipStream_t) {
+  if (cands == 16u) RunGridTogether(grid, UniPipeLdsBytes(16), [&](unsigned char *s) { uni_long_pipe_block<16>(a, s); });
+  else if (cands == 32u) RunGridTogether(grid, UniPipeLdsBytes(32), [&](unsigned char *s) { uni_long_pipe_block<32>(a, s); });
+  else RunGridTogether(grid, UniPipeLdsBytes(64), [&](unsigned char *s) { uni_long_pipe_block<64>(a, s); });
   return hipSuccess;
 }
 

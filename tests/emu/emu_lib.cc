@@ -109,6 +109,10 @@ void RunWave(int block, int grid, unsigned char *smem, const std::function<void(
         }
         break;
       case kSync: break;
+      case kBlockSync:
+        if (!w.block_barrier) Fail("wv::block_sync() in a workgroup whose wavefronts run one after another");
+        w.block_barrier();
+        break;
       case kLaneUp1:
         for (int i = 63; i >= 0; --i) w.lanes[i].out = i > 0 ? w.lanes[i - 1].a : w.lanes[i].b;
         break;

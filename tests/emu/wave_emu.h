@@ -31,7 +31,7 @@
 namespace spmx {
 namespace emu {
 
-enum Op { kNone = 0, kBallot, kShfl, kShflUp, kSync, kLaneUp1, kLaneDown1, kScanAdd, kScanMax };
+enum Op { kNone = 0, kBallot, kShfl, kShflUp, kSync, kLaneUp1, kLaneDown1, kScanAdd, kScanMax, kBlockSync };
 
 struct Lane {
   void *sp = nullptr;        // saved stack pointer
@@ -48,6 +48,7 @@ struct Wave {
   int block = 0, grid = 1;
   int wib = 0, wpb = 1;      // wave index within its workgroup, waves per workgroup
   std::function<void()> body;
+  std::function<void()> block_barrier;   // (workgroups whose wavefronts run side by side, emu_launch.cc RunGridTogether) what wv::block_sync() waits at
   unsigned char *smem = nullptr;
   uint64_t n_collectives = 0;
 };
@@ -99,6 +100,7 @@ inline uint64_t uniform64(uint64_t v) { return v; }
 inline uint32_t read_lane(uint32_t v, int src) { return static_cast<uint32_t>(emu::Collective(emu::kShfl, v, static_cast<uint64_t>(src & 63))); }
 template <int N> inline void keep_apart() {}
 inline void sync() { emu::Collective(emu::kSync, 0, 0); }
+inline void block_sync() { emu::Collective(emu::kBlockSync, 0, 0); }
 inline void sync_global() { emu::Collective(emu::kSync, 0, 0); }
 
 inline uint32_t atomic_add(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }

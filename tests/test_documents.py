@@ -13,6 +13,11 @@ def eng(request):
     return request.param, emulib.backend(request.param)
 
 
+# the wave-cooperative kernel's two forms (api.cc uw_pipe): a wavefront per document, and a workgroup of two -- a walker
+# and a folder -- per document (the default for few long documents)
+FORMS = [{"SPMX_UW_PIPE": "0"}, {"SPMX_UW_PIPE": "2"}]
+
+
 def botchan_docs(corpora, lines_per_doc, n_docs, step=37):
     bot, boffs = corpora["botchan"]
     last = len(boffs) - 1 - lines_per_doc
@@ -31,8 +36,9 @@ def check(h, o, docs):
     return h
 
 
+@pytest.mark.parametrize("form", FORMS, ids=["wave", "pair"])
 @pytest.mark.parametrize("rescore", ["x1", "q1", "q025", "x64"])
-def test_document_fold_tie_regimes(rescore, eng, oracle, corpora):
+def test_document_fold_tie_regimes(rescore, form, eng, oracle, corpora):
     """The float fold's tie rule (uw_relax_float): scores quantized to 1 and 1/4 (equal sums of different paths all the
     time), and scores 64 times as large (the regime deep inside a megabyte document: the float's granularity is coarser
     than the scores' differences, the reference's double comparison decides by what the rounding dropped; never for the
@@ -46,15 +52,17 @@ def test_document_fold_tie_regimes(rescore, eng, oracle, corpora):
         blob = synth.requantized_model(blob, 0.25)
     elif rescore == "x64":
         blob = synth.rescored_model(blob, lambda v: v * 64.0 + 0.001)
-    h, o = lib.load(blob), oracle.load(blob)
+    h, o = lib.load(blob, env=form), oracle.load(blob)
     n = 24 if which == "gpu" else 3
     docs = botchan_docs(corpora, 420 if which == "gpu" else 260, n) + ["猫 も 杓子 も Zürich ".encode() * 700]
     h = check(h, o, docs)
-    assert any(c["kernel"].startswith("UniLongKernel") for c in h.sp.LastProfile()["classes"] if c["kernel"])
+    want = "UniLongPipeKernel" if form["SPMX_UW_PIPE"] == "2" else "UniLongKernel"
+    assert any(c["kernel"] == want for c in h.sp.LastProfile()["classes"] if c["kernel"])
 
 
+@pytest.mark.parametrize("form", FORMS, ids=["wave", "pair"])
 @pytest.mark.parametrize("model", ["uni32k_w16", "c5_250k_bf", "test_ja_model"])
-def test_document_rows_of_16_and_32_entries(model, eng, oracle, corpora):
+def test_document_rows_of_16_and_32_entries(model, form, eng, oracle, corpora):
     """The matrix rows (UniWaveRow): a model whose longest piece has exactly 16 bytes (a piece that fills its row and ends
     one past the chunk), and models with rows of 32; documents cut at every offset of a chunk."""
     import bench
@@ -72,7 +80,7 @@ def test_document_rows_of_16_and_32_entries(model, eng, oracle, corpora):
         docs = [ja[:int(joffs[60])].tobytes(), mixed[:int(moffs[30])].tobytes().replace(b"\n", b" ")]
         docs += [docs[0][3 * k:] for k in range(1, 12)]
     assert max(len(d) for d in docs) > 8192
-    check(lib.load(blob), oracle.load(blob), docs)
+    check(lib.load(blob, env=form), oracle.load(blob), docs)
 
 
 def test_compaction_of_document_blocks_default_threshold(eng, oracle, corpora):
@@ -90,6 +98,7 @@ def test_compaction_of_document_blocks_default_threshold(eng, oracle, corpora):
         k = 600 if 64 <= i < 128 else int(rng.choice([1, 1, 2, 30]))   # the second block is one of documents
         docs.append(bot[int(boffs[a]):int(boffs[a + k])].tobytes().replace(b"\n", b" "))
     docs[70] = b""
+    docs[100] = b"   "                                                  # (nothing but whitespace: the walker's own way out)
     check(h, o, docs)
     text, offs = synth.pack(docs)
     got = h.encode_spans(text, offs)
