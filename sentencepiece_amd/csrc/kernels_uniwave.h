@@ -265,6 +265,85 @@ SPMX_DEVICE void uw_walk_chunk(const SpmxDev &d, const uint8_t *nt, int nlen, in
   *cyc += wv::clock() - tw0;
 }
 
+// Two chunks at once -- positions [c, c + 64) and [c + 64, c + 128) -- for the walker of uni_long_pipe_block: one text
+// window, the character starts of one chunk after the other, and BOTH chunks' walks in one loop (a lane walks from c + lane
+// and from c + 64 + lane side by side: two probes in flight, the chain of dependent L2 round trips is shared).
+template <uint32_t ML>
+SPMX_DEVICE void uw_walk_pair(const SpmxDev &d, const uint8_t *nt, int nlen, int c, uint8_t *win, U2 *cands0, U2 *cands1, int lane,
+                              UwWalker &w, uint64_t *S_out, uint32_t *D_out, uint32_t *deep_out, unsigned long long *cyc) {
+  const U4 *__restrict__ ptrie = d.ptrie;
+  const uint32_t root = d.ptrie[0].x >> kDatBaseShiftDev;
+  const uint32_t root_w = d.ptrie[0].w;
+  const uint32_t spb = SpByteOf(d);
+  U2 *row[2] = {cands0 + static_cast<uint32_t>(lane) * ML, cands1 + static_cast<uint32_t>(lane) * ML};
+  wv::sync();                                                        // (the pair before is done with the window)
+  *reinterpret_cast<uint32_t *>(win + 4 * lane) = w.text_v;
+  {
+    const int q = c + 128 + 4 * lane;
+    w.text_v = 0;
+    if (q < nlen) w.text_v = *reinterpret_cast<const uint32_t *>(nt + q);   // (the slice is padded: a whole dword is readable)
+  }
+  wv::sync();
+  int s[2], step[2];
+  uint64_t S[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    s[h] = c + 64 * h + lane;
+    const bool valid = s[h] < nlen;
+    step[h] = 1;
+    if (valid) {
+      const uint32_t b0 = win[64 * h + lane];
+      step[h] = b0 == spb ? 1 : OneCharLenDev(b0);                    // :962-963
+      if (step[h] > nlen - s[h]) step[h] = nlen - s[h];
+    }
+    S[h] = c + 64 * h > nlen ? 0ull : wv::uniform64(resolve_chain(c + 64 * h, step[h], valid, &w.next_start));   // (:1007; a chunk beyond the text has none)
+  }
+  const unsigned long long tw0 = wv::clock();
+  uint32_t deep[2] = {0u, 0u}, node[2] = {root, root}, dep[2] = {0u, 0u}, wsum[2] = {root_w, root_w};
+  bool alive[2], single[2] = {false, false}, is_start[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) { is_start[h] = ((S[h] >> lane) & 1ull) != 0; alive[h] = is_start[h]; }
+  while (wv::any(alive[0] || alive[1])) {
+    uint32_t cb[2];
+    bool go[2];
+    U4 u[2] = {U4{0u, 0u, 0u, 0u}, U4{0u, 0u, 0u, 0u}};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int q = s[h] + static_cast<int>(dep[h]);
+      cb[h] = win[(q - c) & static_cast<int>(kUwWindow - 1u)];
+      go[h] = alive[h] && q < nlen && dep[h] < ML && ((wsum[h] >> ChildBit(cb[h])) & 1u) != 0u;
+    }
+    if (go[0]) u[0] = ptrie[node[0] ^ cb[0]];                          // (both probes asked for before either is looked at)
+    if (go[1]) u[1] = ptrie[node[1] ^ cb[1]];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      alive[h] = go[h] && (u[h].x & 0x1FFu) == (0x100u | cb[h]);      // :969-971
+      node[h] = alive[h] ? u[h].x >> kDatBaseShiftDev : node[h];
+      wsum[h] = alive[h] ? u[h].w : wsum[h];
+      dep[h] += alive[h] ? 1u : 0u;
+      if (alive[h] && (u[h].x & kDatTerminalDev) && !(u[h].y & kPtUnused)) {   // :973-974
+        const bool ud = (u[h].y & kPtUserDefined) != 0u;
+        row[h][dep[h] - 1u] = U2{(u[h].y & 0x00FFFFFFu) | (dep[h] << 24) | (ud ? 0x80000000u : 0u),
+                                 ud ? wv::float_to_bits(static_cast<float>(static_cast<int>(dep[h])) * d.max_score) : u[h].z};
+        deep[h] = dep[h];
+        single[h] = single[h] || static_cast<int>(dep[h]) == step[h];
+      }
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (is_start[h] && !single[h]) {                                  // :995-1005: the UNK candidate, `step` bytes long
+      const uint32_t us = static_cast<uint32_t>(step[h]);
+      row[h][us - 1u] = U2{(static_cast<uint32_t>(d.unk_id) & 0x00FFFFFFu) | (us << 24) | 0x80000000u, wv::float_to_bits(d.unk_score)};
+      if (deep[h] < us) deep[h] = us;
+    }
+    S_out[h] = S[h];
+    D_out[h] = wv::uniform(wv::read_lane(wv::scan_max(deep[h]), 63));
+    deep_out[h] = deep[h];
+  }
+  *cyc += wv::clock() - tw0;
+}
+
 SPMX_DEVICE void uw_folder_begin(UwFolder &f, int lane) {
   const float ninf = -__builtin_inff();
   f.cur_s = lane == 0 ? 0.f : ninf;                                   // best_path_ends_at[0] = {0, nothing}
@@ -543,10 +622,10 @@ SPMX_DEVICE void uni_long_block(const LongArgs &a, unsigned char *smem) {
   }
 }
 
-// ---- a document per WORKGROUP OF TWO wavefronts (round 6): wavefront 0 normalizes and then WALKS, a chunk ahead of
-// wavefront 1, which FOLDS, stores, and at the end backtracks and emits.  The hand-over is the matrix (two of them, by the
-// chunk's parity) and three words beside it (the chunk's character starts, its longest piece, every row's depth); one
-// workgroup barrier per chunk.  For batches of FEW long documents: a document that has a CU to itself spends 130 + 40 cycles a
+// ---- a document per WORKGROUP OF TWO wavefronts (round 6): wavefront 0 normalizes and then WALKS, a pair of chunks ahead of
+// wavefront 1, which FOLDS, stores, and at the end backtracks and emits.  The hand-over is the matrix (four of them: two
+// buffers of a pair of chunks) and three words beside each (the chunk's character starts, its longest piece, every row's
+// depth); one workgroup barrier per pair of chunks; the walker walks both chunks of its pair in ONE loop (uw_walk_pair).  For batches of FEW long documents: a document that has a CU to itself spends 130 + 40 cycles a
 // byte in the walker's half and 130 + 30 in the folder's, and this form runs them side by side.  (A batch of thousands of
 // documents fills the chip with one wavefront each -- uni_long_block -- and gains nothing from pairs.) ----
 struct UniPipeHdr {            // wavefront 0 -> wavefront 1, per document
@@ -554,12 +633,12 @@ struct UniPipeHdr {            // wavefront 0 -> wavefront 1, per document
   int32_t nlen;
   uint32_t go;                 // 1: fold it; 0: the document is done with (empty, failed, on the retry list)
 };
-struct UniPipeMeta {           // per chunk parity
+struct UniPipeMeta {           // per buffer and chunk of the pair
   uint32_t s_lo, s_hi, d, pad;
   uint8_t deep[64];
 };
 SPMX_HD constexpr uint32_t UniPipeLdsBytes(uint32_t ML) {
-  return 2u * UniWaveMatrixEntries(ML) * 8u + kUwWindow + 16u + ((kRawWinBytes + 15u) & ~15u) + 64u + 2u * 96u;
+  return 4u * UniWaveMatrixEntries(ML) * 8u + kUwWindow + 16u + ((kRawWinBytes + 15u) & ~15u) + 64u + 4u * 96u;
 }
 
 template <uint32_t ML>
@@ -568,12 +647,14 @@ SPMX_DEVICE void uni_long_pipe_block(const LongArgs &a, unsigned char *smem) {
   const bool walker = wv::wave_in_block() == 0;
   const SpmxDev &d = a.dev;
   constexpr uint32_t kM = UniWaveMatrixEntries(ML) * 8u;
-  U2 *cands[2] = {reinterpret_cast<U2 *>(smem) + 2, reinterpret_cast<U2 *>(smem + kM) + 2};    // entry [0][0] of each matrix
-  uint8_t *win = smem + 2u * kM;
+  // entry [0][0] of each matrix: [buffer][chunk of the pair]
+  U2 *cands[2][2] = {{reinterpret_cast<U2 *>(smem) + 2, reinterpret_cast<U2 *>(smem + kM) + 2},
+                     {reinterpret_cast<U2 *>(smem + 2u * kM) + 2, reinterpret_cast<U2 *>(smem + 3u * kM) + 2}};
+  uint8_t *win = smem + 4u * kM;
   uint8_t *rawwin = win + kUwWindow + 16u;
   UniPipeHdr *hdr = reinterpret_cast<UniPipeHdr *>(rawwin + ((kRawWinBytes + 15u) & ~15u));
-  UniPipeMeta *meta = reinterpret_cast<UniPipeMeta *>(reinterpret_cast<unsigned char *>(hdr) + 64);   // [2], 96 bytes apart
-  auto meta_of = [&](int k) -> UniPipeMeta * { return reinterpret_cast<UniPipeMeta *>(reinterpret_cast<unsigned char *>(meta) + 96 * (k & 1)); };
+  UniPipeMeta *meta = reinterpret_cast<UniPipeMeta *>(reinterpret_cast<unsigned char *>(hdr) + 64);   // [buffer][chunk of the pair], 96 bytes apart
+  auto meta_of = [&](int k, int hh) -> UniPipeMeta * { return reinterpret_cast<UniPipeMeta *>(reinterpret_cast<unsigned char *>(meta) + 96 * (2 * (k & 1) + hh)); };
   const uint32_t count = *a.list_count;
   const int n_extra = d.n_prefix + d.n_suffix;
   unsigned long long st_sent = 0, st_raw = 0, st_ids = 0, st_cyc[3] = {0, 0, 0}, st_seg[2] = {0, 0};
@@ -665,8 +746,8 @@ SPMX_DEVICE void uni_long_pipe_block(const LongArgs &a, unsigned char *smem) {
       wv::sync_global();                                              // (the normalized text is in HBM before the walks read it)
       st_cyc[0] += wv::clock() - t0;
     } else {
-      // ---- wavefront 1 meanwhile: both matrices "none" ----
-      for (uint32_t k = static_cast<uint32_t>(lane); k < 2u * UniWaveMatrixEntries(ML); k += 64u) reinterpret_cast<U2 *>(smem)[k] = U2{kUwNone, kUwNan};
+      // ---- wavefront 1 meanwhile: the four matrices "none" ----
+      for (uint32_t k = static_cast<uint32_t>(lane); k < 4u * UniWaveMatrixEntries(ML); k += 64u) reinterpret_cast<U2 *>(smem)[k] = U2{kUwNone, kUwNan};
     }
     wv::block_sync();
     const uint32_t go = hdr->go;
@@ -675,29 +756,38 @@ SPMX_DEVICE void uni_long_pipe_block(const LongArgs &a, unsigned char *smem) {
     int32_t *bid = reinterpret_cast<int32_t *>(hdr->bid);
     uint16_t *blen = reinterpret_cast<uint16_t *>(hdr->blen);
     if (go) {
-      // ---- the chunks: iteration k walks chunk k and folds chunk k - 1 ----
+      // ---- the chunks, a PAIR per iteration: iteration k walks chunks 2k, 2k + 1 and folds chunks 2k - 2, 2k - 1 ----
       const unsigned long long t1 = wv::clock();
-      const int n_chunks = nlen / 64 + 1;                             // (the last one may hold position nlen only)
+      const int n_pairs = (nlen / 64 + 2) / 2;                        // (chunks: nlen / 64 + 1; a chunk beyond the text is nothing)
       UwWalker w;
       UwFolder f;
       if (walker) uw_walker_begin(w, norm, nlen, lane); else uw_folder_begin(f, lane);
-      for (int k = 0; k <= n_chunks; ++k) {
+      for (int k = 0; k <= n_pairs; ++k) {
         if (walker) {
-          if (k < n_chunks) {
-            uint64_t S;
-            uint32_t D, deep;
-            uw_walk_chunk<ML>(d, norm, nlen, 64 * k, win, cands[k & 1], lane, w, &S, &D, &deep, &st_seg[0]);
-            UniPipeMeta *m = meta_of(k);
-            m->deep[lane] = static_cast<uint8_t>(deep);
-            if (lane == 0) { m->s_lo = static_cast<uint32_t>(S); m->s_hi = static_cast<uint32_t>(S >> 32); m->d = D; }
+          if (k < n_pairs) {
+            uint64_t S[2];
+            uint32_t D[2], deep[2];
+            uw_walk_pair<ML>(d, norm, nlen, 128 * k, win, cands[k & 1][0], cands[k & 1][1], lane, w, S, D, deep, &st_seg[0]);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              UniPipeMeta *m = meta_of(k, hh);
+              m->deep[lane] = static_cast<uint8_t>(deep[hh]);
+              if (lane == 0) { m->s_lo = static_cast<uint32_t>(S[hh]); m->s_hi = static_cast<uint32_t>(S[hh] >> 32); m->d = D[hh]; }
+            }
           }
         } else if (k >= 1) {
-          const UniPipeMeta *m = meta_of(k - 1);
-          const uint64_t S = wv::uniform64(static_cast<uint64_t>(m->s_hi) << 32 | m->s_lo);
-          const uint32_t D = wv::uniform(m->d);
-          const uint32_t deep = m->deep[lane];
-          uw_fold_chunk<ML>(d, cands[(k - 1) & 1], S, D, lane, f, &st_seg[1]);
-          uw_flush_chunk<ML>(64 * (k - 1), nlen, bid, blen, cands[(k - 1) & 1], deep, lane, f);
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const UniPipeMeta *m = meta_of(k - 1, hh);
+            const uint64_t S = wv::uniform64(static_cast<uint64_t>(m->s_hi) << 32 | m->s_lo);
+            const uint32_t D = wv::uniform(m->d);
+            const uint32_t deep = m->deep[lane];
+            const int c = 128 * (k - 1) + 64 * hh;
+            if (c <= nlen) {
+              uw_fold_chunk<ML>(d, cands[(k - 1) & 1][hh], S, D, lane, f, &st_seg[1]);
+              uw_flush_chunk<ML>(c, nlen, bid, blen, cands[(k - 1) & 1][hh], deep, lane, f);
+            }
+          }
         }
         wv::block_sync();
       }
