@@ -319,6 +319,7 @@ struct spmx_handle {
   bool no_direct = false;        // SPMX_NO_DIRECT=1: the word rounds take classify's lists even where they could do without
   int fork_cus = 0;              // SPMX_FORK_CUS: the general launch beside the word rounds takes at most this many CUs (0: every CU)
   int fork_waves = 4;            // SPMX_FORK_WAVES: wavefronts per workgroup of the general launch while it runs next to the first word round (0: by its size)
+  bool early_tail = false;       // SPMX_EARLY_TAIL=1: a direct call's first-round give-ups get a tail launch of their own beside round 2 (below: measured, not the default)
   bool no_overlap = false;       // SPMX_NO_OVERLAP=1: the general launches do not run next to the word rounds
   bool no_ids16 = false;         // SPMX_NO_IDS16=1: the word kernels write 32-bit ids into the arena whatever the vocabulary's size
   bool no_scan = false;          // SPMX_NO_SCAN=1: classify does not set the non-plain sentences aside (the word rounds find them)
@@ -1234,6 +1235,20 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         again_words = ws->h_ctrl->dyn_count < h->dyn_list_cap ? ws->h_ctrl->dyn_count : h->dyn_list_cap;
         left_at = 1;
         if (again_total > 0) {
+          // DIRECT (nothing else uses the second stream): what round 1 gave up for good is known NOW, and its tail launch
+          // COULD go to the second stream beside resolve and round 2 (SPMX_EARLY_TAIL=1; the fork recorded here, before they
+          // are enqueued -- recorded behind them, as it was until round 6, the second stream waited for round 2 anyway).
+          // Not the default: round 2's workgroups take a CU's whole LDS, so nothing runs BESIDE them whatever the streams
+          // say, and the extra launch with its read-back costs 0.03 ms (C2: 4.68 against 4.65 ms a step).  The give-ups of
+          // both rounds then share one tail launch behind round 2.
+          uint32_t gone1[kMaxClasses] = {0};
+          uint64_t gone1_total = 0;
+          for (int c = 0; c < ncls; ++c) { gone1[c] = ws->h_ctrl->left_counts[1][c]; gone1_total += gone1[c]; }
+          const bool early_tail = h->early_tail && direct && !forked && !h->no_overlap && gone1_total > 0;
+          if (early_tail) {
+            HIP_OR_RETURN(h, hipEventRecord(ws->ev_fork, stream));
+            HIP_OR_RETURN(h, hipStreamWaitEvent(ws->stream2, ws->ev_fork, 0));
+          }
           if (again_words) {      // the collected words, segmented once each (a few workgroups)
             ResolveArgs ra{};
             ra.dev = h->dev; ra.dyn_ent = ws->d_dyn_ent.p; ra.dyn_list = ws->d_dyn_list.p; ra.dyn_count = &ws->d_ctrl->dyn_count;
@@ -1244,20 +1259,12 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
           }
           // round 2 over what round 1 kept for it; what it cannot take either (a margin that does not hold, a word of
           // more than 8 pieces) is APPENDED to the lists of what round 1 gave up for good: one tail launch takes both
-          // DIRECT (nothing else uses the second stream): what round 1 gave up for good is known NOW -- its tail launch goes
-          // to the second stream and runs beside resolve and round 2 (a few hundred sentences on C2: 0.3 ms of launches and
-          // read-backs off the step's critical path); round 2 then keeps a list of its own for what it cannot take.
-          uint32_t gone1[kMaxClasses] = {0};
-          uint64_t gone1_total = 0;
-          for (int c = 0; c < ncls; ++c) { gone1[c] = ws->h_ctrl->left_counts[1][c]; gone1_total += gone1[c]; }
-          const bool early_tail = direct && !forked && !h->no_overlap && gone1_total > 0;
+          // (round 2 then keeps a list of its own for what it cannot take)
           if (early_tail) left_at = 2;
           for (int c = 0; c < ncls; ++c) known[c] = again_counts[c];
           a.lists = left_lists[0];
           FORKED_OR_RETURN(word_pass(2, kSlotWord2, 4, left_lists[left_at], ws->d_ctrl->left_counts[left_at], nullptr, nullptr));
           if (early_tail) {
-            HIP_OR_RETURN(h, hipEventRecord(ws->ev_fork, stream));          // (round 1 has ended: the read-back above waited for it)
-            HIP_OR_RETURN(h, hipStreamWaitEvent(ws->stream2, ws->ev_fork, 0));
             forked = true;
             stream = ws->stream2;
             tail_qi = 0;                                                     // (no main launch in a direct call: its queue is free)
@@ -1668,6 +1675,7 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_FORCE_WORD_DP")) h->force_word_dp = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_WORD_DYN")) h->no_word_dyn = e[0] == '1';
     if (const char *e = getenv("SPMX_NO_OVERLAP")) h->no_overlap = e[0] == '1';
+    if (const char *e = getenv("SPMX_EARLY_TAIL")) h->early_tail = e[0] == '1';
     if (const char *e = getenv("SPMX_FORK_WAVES")) h->fork_waves = atoi(e);
     if (const char *e = getenv("SPMX_FORK_CUS")) h->fork_cus = atoi(e);
     if (const char *e = getenv("SPMX_NO_DIRECT")) h->no_direct = e[0] == '1';

@@ -619,6 +619,7 @@ _FORM_SWITCHES = [
     {"SPMX_NO_WORD_NORM": "1", "SPMX_NO_OVERLAP": "1"},        # ... one after the other
     {"SPMX_WORDWAVE_WAVES": "4"},                              # 4 wavefronts per workgroup in the word-per-lane kernels
     {"SPMX_NO_WORD_DYN": "1"},                                 # no call-local memo: one word round + the DP pass
+    {"SPMX_EARLY_TAIL": "1"},                                  # a direct call's first-round give-ups in a tail launch of their own
 ]
 
 
