@@ -105,3 +105,56 @@ def test_compaction_of_document_blocks_default_threshold(eng, oracle, corpora):
     want = o.encode_spans(text, offs)
     for a, b, nm in zip(got, want, ("ids", "begin", "end", "id_offsets")):
         np.testing.assert_array_equal(np.asarray(a).astype(np.int64), np.asarray(b).astype(np.int64), err_msg=nm)
+
+
+def _custom_rule_model(model_type, tmp_path_factory):
+    """A throw-away model the pip wheel trains on the spot (test tooling only) with a normalization_rule_tsv of its own: targets
+    that begin / end with spaces, that ARE a space, that map to U+2581, that delete, on top of whitespace handling."""
+    import io
+    import sentencepiece as spm
+    d = tmp_path_factory.mktemp("rules")
+    tsv = d / "rules.tsv"
+    rules = ["41\t20 78 20",          # A -> " x "
+             "42\t2581",              # B -> U+2581
+             "43 44\t20",             # CD -> " "
+             "45\t",                  # E -> (nothing)
+             "46\t66 20",             # F -> "f "
+             "47\t20 67",             # G -> " g"
+             "E9\t65 301",            # e-acute -> e + combining acute
+             "3042\t61 20 61"]        # HIRAGANA A -> "a a"
+    tsv.write_text("\n".join(rules) + "\n")
+    bot = open(fixtures.os.path.join(fixtures.GOLDEN, "botchan.txt"), "rb").read().decode("utf-8", "replace").split("\n")[:3000]
+    buf = io.BytesIO()
+    spm.SentencePieceTrainer.train(sentence_iterator=iter(bot), model_writer=buf, vocab_size=600, model_type=model_type,
+                                   normalization_rule_tsv=str(tsv), hard_vocab_limit=False)
+    return buf.getvalue()
+
+
+@pytest.mark.parametrize("model_type", ["unigram", "bpe"])
+def test_custom_normalization_rules_through_the_default_path(model_type, eng, oracle, corpora, tmp_path_factory):
+    """A model with normalization rules of its own (replacements with leading / trailing spaces, a replacement that is the
+    space symbol itself, deletions) through the DEFAULT path -- word-local normalization in the word rounds, direct calls --
+    as sentences and as documents (ADVICE of round 5: kNfWordLocalNorm assumes a word normalizes independently of its
+    neighbours; the loader's check decides whether such a model may take that path at all)."""
+    try:
+        blob = _custom_rule_model(model_type, tmp_path_factory)
+    except Exception as e:
+        pytest.skip("the pip wheel cannot train here: %r" % (e,))
+    which, lib = eng
+    h, o = lib.load(blob), oracle.load(blob)
+    rng = np.random.default_rng(5)
+    bot, boffs = corpora["botchan"]
+    words = [b"A", b"B", b"CD", b"E", b"F", b"G", "é".encode(), "あ".encode(), b"AB", b"xAy", b"BA ", b" F", b"GG", b"ECDE",
+             b"C D", b"AF", b"FA", b"  ", b"the", b"CDCD", b"A A", b"B B"]
+    docs = []
+    for i in range(300 if which == "gpu" else 120):
+        a = int(rng.integers(0, len(boffs) - 3))
+        base = bot[int(boffs[a]):int(boffs[a + 1])].tobytes().rstrip(b"\r\n").split(b" ")
+        out = []
+        for w in base:
+            out.append(w)
+            if rng.random() < 0.35:
+                out.append(words[int(rng.integers(0, len(words)))] + (w[:2] if rng.random() < 0.5 else b""))
+        docs.append(b" ".join(out))
+    docs += [b" ".join(docs[:60]) * 3, b"A", b"B", b"E", b"CD", b" A ", b"EEEE", b""]      # a document; rules alone
+    check(h, o, docs)
