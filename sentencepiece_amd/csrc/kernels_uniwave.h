@@ -391,7 +391,7 @@ SPMX_DEVICE void uw_fold_chunk(const SpmxDev &d, const U2 *cands, uint64_t S, ui
 }
 
 // Positions [c, c + 64) are final: one coalesced row to HBM; what reached beyond the chunk becomes the next chunk's start;
-// row `lane` of the matrix is "none" again (deep: what the walker said of it).
+// the matrix is "none" again (deep: what the walker said of this lane's row; nothing to do if no row holds anything).
 template <uint32_t ML>
 SPMX_DEVICE void uw_flush_chunk(int c, int nlen, int32_t *bid, uint16_t *blen, U2 *cands, uint32_t deep, int lane, UwFolder &f) {
   const int p = c + lane;
@@ -402,10 +402,11 @@ SPMX_DEVICE void uw_flush_chunk(int c, int nlen, int32_t *bid, uint16_t *blen, U
   f.cur_s = f.nxt_s; f.cur_b = f.nxt_b;
   f.nxt_s = -__builtin_inff(); f.nxt_b = kUwUnreached;
   wv::sync();                                                        // (every lane has read the matrix)
-  if (deep != 0u) {
-    U2 *row = cands + static_cast<uint32_t>(lane) * ML;
+  // the matrix "none" again, 64 consecutive entries a store (a lane clearing its OWN row writes at a stride of ML * 8 bytes:
+  // every lane on the same LDS banks -- 57 % of the kernel's LDS cycles were bank conflicts, profiles/r06_docs_16k_pmc_sq.txt)
+  if (wv::any(deep != 0u)) {
 #pragma unroll
-    for (uint32_t k = 0; k < ML; ++k) row[k] = U2{kUwNone, kUwNan};
+    for (uint32_t k = 0; k < ML; ++k) cands[k * 64u + static_cast<uint32_t>(lane)] = U2{kUwNone, kUwNan};
   }
 }
 
