@@ -338,7 +338,7 @@ struct spmx_handle {
   uint32_t uni_wave_max = 0;     // SPMX_UNI_WAVE_MAX: a staged class with fewer sentences than this takes the wave-cooperative form
   int word_wgs = 1;              // SPMX_WORD_WGS: workgroups per CU of the word kernel's first pass
   int word_form = 3;             // SPMX_WORD_WAVE: which word rounds take the word-per-lane form (kernels_wordwave.h): bit 0 the first, bit 1 the second; 0: the sentence-per-lane loops
-  int wordwave_waves = 12;       // SPMX_WORDWAVE_WAVES: wavefronts per workgroup of the word-per-lane kernels
+  int wordwave_waves = 14;       // SPMX_WORDWAVE_WAVES: wavefronts per workgroup of the word-per-lane kernels (C2's first round: 8 -> 3.71 ms, 10 -> 3.31, 12 -> 3.08, 13 -> 3.02, 14 -> 2.96, 15 -> 2.94 with a worse step; 14 x 10 KB + the shared tables = 153 KB of LDS)
   int word_waves = 12;           // SPMX_WORD_WAVES: wavefronts per workgroup of the word kernels (C2 step: 16 -> 8.60 ms, 14 -> 8.39, 12 -> 8.37, 10 -> 8.52, 8 -> 8.90)
   int tile_waves_override = 0;   // SPMX_TILE_WAVES: cap on wavefronts per workgroup of the streaming kernels
   uint32_t lane_general_min_lanes = 0;   // SPMX_LANE_GENERAL_MIN_LANES (0: per class)
@@ -1145,7 +1145,8 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
         const bool dp = mode == 3;
         EncodeArgs wa = a;
         const bool wform = !dp && ((mode == 2 ? h->word_form & 2 : h->word_form & 1) != 0);   // word per lane
-        const int waves = dp ? 8 : wform ? h->wordwave_waves : h->word_waves;
+        int waves = dp ? 8 : wform ? h->wordwave_waves : h->word_waves;
+        while (wform && waves > 1 && WordWaveLdsBytes(static_cast<uint32_t>(waves)) > 160u * 1024u) --waves;   // (a CU's LDS: an A/B build with a larger hot table)
         uint64_t total = 0;
         for (int c = 0; c < ncls; ++c) total += known[c];
         if (total == 0) return kOk;
@@ -1727,7 +1728,7 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
     if (const char *e = getenv("SPMX_UW_PIPE")) h->uw_pipe = atoi(e);
     if (const char *e = getenv("SPMX_UNI_WAVE_MAX")) h->uni_wave_max = static_cast<uint32_t>(atoll(e));
     if (const char *e = getenv("SPMX_WORD_WAVE")) { const int v = atoi(e); if (v >= 0 && v <= 3) h->word_form = v; }
-    if (const char *e = getenv("SPMX_WORDWAVE_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 12) h->wordwave_waves = v; }
+    if (const char *e = getenv("SPMX_WORDWAVE_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 16) h->wordwave_waves = v; }
     if (const char *e = getenv("SPMX_WORD_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 16) h->word_waves = v; }
     if (const char *e = getenv("SPMX_ARENA_FIRST")) h->arena_first = static_cast<uint64_t>(atoll(e));
     if (const char *e = getenv("SPMX_NO_LANE_GENERAL")) h->no_lane_general = e[0] == '1';

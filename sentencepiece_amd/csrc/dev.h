@@ -195,6 +195,14 @@ SPMX_HD inline uint32_t HashWordKey(uint32_t k0, uint32_t k1, uint32_t k2, uint3
   const uint32_t g = h * 0x9E3779B1u;
   return g ^ (g >> 15);
 }
+#ifndef SPMX_HOT_SLOTS
+#define SPMX_HOT_SLOTS 256
+#endif
+// The LDS copy of the likeliest words (uhot / uhot2), a power of two (A/B builds: -DSPMX_HOT_SLOTS=).  2048 slots until round
+// 6; measured then on C2 (profiles/r06_hot_slots_waves.txt): the first word round takes 3.085 / 3.076 / 3.067 ms with 2048 /
+// 1024 / 512 slots at 12 wavefronts per CU -- a word the table lacks is answered by `uall` from L2, whose probe every lane
+// issues anyway -- and the 28 KB the table gives back are two more wavefronts per CU: 2.96 ms at 14.
+constexpr uint32_t kWordHotSlots = SPMX_HOT_SLOTS;
 // the perfect hash of `uall` (dev.h SpmxDev): where the key with hashes h1 = HashWordKey, h2 = UallHash2 sits under its
 // bucket's displacement d.  UallHash2 mixes the bytes another way than HashWordKey does (two keys that agree in one
 // differ in the other), at the cost of a few rotates: no second multiply.

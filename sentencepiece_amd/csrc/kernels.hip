@@ -54,17 +54,17 @@ __global__ __launch_bounds__(1024) void EncodeWordAgainKernel(EncodeArgs a) {
 }
 // word per lane (kernels_wordwave.h); H16: 16-bit ids in the arena slots (EncodeArgs::ids16)
 template <bool H16>
-__global__ __launch_bounds__(768) void EncodeWordWaveKernel(EncodeArgs a) {
+__global__ __launch_bounds__(1024) void EncodeWordWaveKernel(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   encode_wordwave_block<kWmPlain, H16>(a, smem);
 }
 template <bool H16>
-__global__ __launch_bounds__(768) void EncodeWordWaveCollectKernel(EncodeArgs a) {
+__global__ __launch_bounds__(1024) void EncodeWordWaveCollectKernel(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   encode_wordwave_block<kWmCollect, H16>(a, smem);
 }
 template <bool H16>
-__global__ __launch_bounds__(768) void EncodeWordWaveAgainKernel(EncodeArgs a) {
+__global__ __launch_bounds__(1024) void EncodeWordWaveAgainKernel(EncodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   encode_wordwave_block<kWmDyn, H16>(a, smem);
 }

@@ -64,7 +64,6 @@
 namespace spmx {
 
 constexpr uint32_t kWordMaskBytes = 18u * 16u + 32u;            // mask rows 0 .. 17 (+ padding)
-constexpr uint32_t kWordHotSlots = 2048u;                       // LDS copy of the likeliest words (dev.h uhot)
 constexpr uint32_t kWordLdsShared = kWordMaskBytes + kWordHotSlots * 16u;
 constexpr uint32_t kWordStage = 8;                              // ids per burst
 constexpr uint32_t kWordDpPos = 18;                             // positions of a word in the DP: space symbol + 16 bytes + end

@@ -701,8 +701,8 @@ void BuildWordMemo(const ModelData &m, HostTables *t) {
   sc.uall_mask = 0;
   sc.uall_perfect = 0;
   t->udisp.assign(kUallBuckets, 0);
-  t->uhot.assign(2048, U4{0, 0, 0, 0xFFFFFFFFu});       // kWordHotSlots (kernels_word.h)
-  t->uhot2.assign(2048, U4{0, 0, 0, 0xFFFFFFFFu});
+  t->uhot.assign(kWordHotSlots, U4{0, 0, 0, 0xFFFFFFFFu});
+  t->uhot2.assign(kWordHotSlots, U4{0, 0, 0, 0xFFFFFFFFu});
   sc.umemo_mask = 0;
   sc.umemo16_mask = 0;
   sc.flags &= ~(kNfUniWordwise | kNfWordLocalNorm);
@@ -908,22 +908,33 @@ void BuildWordMemo(const ModelData &m, HostTables *t) {
     if (pw > 126) pw = 126;
     return e.id0 | static_cast<uint32_t>(pw) << 16 | (len_of(e) <= 10 ? kMemo16TwoPiece : 0u) | static_cast<uint32_t>(bound2(e)) << 24;
   };
-  {
+  // The word-per-lane kernels (kernels_wordwave.h, the default) read uhot2 and uall only.  The open-addressed tiers of the
+  // sentence-per-lane kernels (kernels_word.h: umemo16, uhot, umemo) are built -- and uploaded -- only for a handle that
+  // asks for those kernels (SPMX_WORD_WAVE=0 / 1 / 2, SPMX_NO_WORD_DYN=1, SPMX_FORCE_WORD_DP=1: read here as api.cc reads them); otherwise they stay the empty
+  // sentinels set above (uni32k: 4 MB + 2 MB of HBM per handle and their inserts at load left out).
+  const bool legacy_tiers = [] {
+    auto on = [](const char *name) { const char *e = getenv(name); return e != nullptr && e[0] == '1'; };
+    const char *e = getenv("SPMX_WORD_WAVE");
+    return (e != nullptr && atoi(e) >= 0 && atoi(e) <= 2) || on("SPMX_NO_WORD_DYN") || on("SPMX_FORCE_WORD_DP");   // (the DP pass is a sentence-per-lane kernel too)
+  }();
+  for (const Ent *e : small) {   // the LDS table of the likeliest words (they come likeliest first)
+    U4 &h2s = t->uhot2[HashWordKey(e->k[0], e->k[1], e->k[2], e->k[3]) & (static_cast<uint32_t>(t->uhot2.size()) - 1u)];
+    if (h2s.w == 0xFFFFFFFFu) h2s = U4{e->k[0], e->k[1], key2_16(*e), meta16(*e)};
+  }
+  if (legacy_tiers) {
     const uint32_t wsz = NextPow2(small.size() * 6 + 16);     // sparse: a collision costs the whole wave another probe
     t->umemo16.assign(wsz, U4{0, 0, 0, 0xFFFFFFFFu});
     for (const Ent *e : small) {
       const uint32_t h = HashWordKey(e->k[0], e->k[1], e->k[2], 0u);
       U4 &hs = t->uhot[h & (static_cast<uint32_t>(t->uhot.size()) - 1u)];
       if (hs.w == 0xFFFFFFFFu) hs = U4{e->k[0], e->k[1], key2_16(*e), meta16(*e)};
-      U4 &h2s = t->uhot2[HashWordKey(e->k[0], e->k[1], e->k[2], e->k[3]) & (static_cast<uint32_t>(t->uhot2.size()) - 1u)];
-      if (h2s.w == 0xFFFFFFFFu) h2s = U4{e->k[0], e->k[1], key2_16(*e), meta16(*e)};
       uint32_t sl = h & (wsz - 1);
       while (t->umemo16[sl].w != 0xFFFFFFFFu) sl = (sl + 1) & (wsz - 1);
       t->umemo16[sl] = U4{e->k[0], e->k[1], key2_16(*e), meta16(*e)};
     }
     sc.umemo16_mask = wsz - 1;
   }
-  {
+  if (legacy_tiers) {
     const uint32_t wsz = NextPow2(big.size() * 2 + 16);
     t->umemo.assign(static_cast<size_t>(wsz) * 2, U4{0, 0, 0, 0});
     for (uint32_t i = 0; i < wsz; ++i) t->umemo[2 * i + 1].x = 0xFFFFFFFFu;
