@@ -51,7 +51,14 @@ constexpr uint32_t kWwPerWave = kWwRing + kWwRingPad + kWwMaskBytes + kWwRecs * 
 static_assert(kWwPerWave % 16u == 0u, "per-wave LDS blocks keep 16-byte alignment");
 constexpr uint32_t kWwAgain = 1u, kWwGone = 2u;     // per-sentence status bits
 constexpr uint32_t kWwKeyMaskBytes = 640u;          // 18 rows {key mask, padding under the mask's zeros} of 32 bytes (+ slack)
-constexpr uint32_t kWwShared = kWwKeyMaskBytes + kWordHotSlots * 16u + kUallBuckets * 2u;   // + the LDS table of the likeliest words, the displacements of uall's perfect hash
+// + the LDS table of the likeliest words (kWordHotSlots entries of uhot2), the displacements of uall's perfect hash.
+// The LDS table is the SECOND round's only (kWwHotIn): there a word it answers does not ask the call-local memo in HBM (64
+// bytes a word).  The first round dropped it in round 6: a word the table lacks is answered by `uall` from L2, every lane
+// issues that probe anyway, and the table's lookup was ~25 instructions per 64 words of an issue-bound loop -- 2048 / 1024 /
+// 512 slots: 3.085 / 3.076 / 3.067 ms, none: 2 % faster still; with all words asking the call-local memo the second round
+// is 12 % slower on open-vocabulary text (profiles/r06_hot_slots_waves.txt).  Same LDS layout for every mode.
+constexpr uint32_t kWwShared = kWwKeyMaskBytes + kWordHotSlots * 16u + kUallBuckets * 2u;
+SPMX_HD constexpr bool kWwHotIn(int mode) { return mode == 2; }      // (kWmDyn)
 SPMX_HD inline uint32_t WordWaveLdsBytes(uint32_t waves) { return kWwShared + waves * kWwPerWave; }
 
 struct __attribute__((packed, aligned(2))) U64H { uint32_t lo, hi; };   // 8 bytes at any 2-byte address
@@ -104,7 +111,7 @@ SPMX_DEVICE void encode_wordwave_block(const EncodeArgs &a, unsigned char *smem)
       masks[2 * lane] = Q4{m(0), m(1), m(2), m(3)};
       masks[2 * lane + 1] = Q4{kWordKeyPad & ~m(0), kWordKeyPad & ~m(1), kWordKeyPad & ~m(2), kWordKeyPad & ~m(3)};
     }
-    for (uint32_t k = static_cast<uint32_t>(lane); k < kWordHotSlots; k += 64u) hot[k] = d.uhot2[k];
+    if (kWwHotIn(MODE)) for (uint32_t k = static_cast<uint32_t>(lane); k < kWordHotSlots; k += 64u) hot[k] = d.uhot2[k];
     for (uint32_t k = static_cast<uint32_t>(lane); k < kUallBuckets; k += 64u) disp[k] = d.udisp[k];
     wv::sync();
   }
@@ -270,11 +277,11 @@ SPMX_DEVICE void encode_wordwave_block(const EncodeArgs &a, unsigned char *smem)
       const Q4 mk = masks[2u * (L < 16u ? L : 16u)], pd = masks[2u * (L < 16u ? L : 16u) + 1u];
       S.k0 = (w.x & mk.x) | pd.x; S.k1 = (w.y & mk.y) | pd.y; S.k2 = (w.z & mk.z) | pd.z; S.k3 = (w.w & mk.w) | pd.w;   // (kernels_word.h key_dword)
       const uint32_t h1 = HashWordKey(S.k0, S.k1, S.k2, S.k3), h2 = UallHash2(S.k0, S.k1, S.k2, S.k3, h1);
-      const U4 e = hot[h1 & (kWordHotSlots - 1u)];                  // (words of up to 12 bytes: k3 is all padding, as in the table's keys)
+      const U4 e = kWwHotIn(MODE) ? hot[h1 & (kWordHotSlots - 1u)] : U4{0u, 0u, 0u, 0xFFFFFFFFu};   // (words of up to 12 bytes: k3 is all padding, as in the table's keys)
       const uint32_t dsp = disp[UallBucket(h2)];
       const uint32_t zmask = L <= 10u ? 0xFFFFu : 0xFFFFFFFFu, form = L <= 10u ? kMemo16TwoPiece : 0u;
       // (bitwise: no branches, every load above is asked for at once)
-      const bool hit16 = (valid & (L <= 12u)) & ((e.x == S.k0) & (e.y == S.k1)) & ((((e.z ^ S.k2) & zmask) == 0u) &
+      const bool hit16 = kWwHotIn(MODE) & (valid & (L <= 12u)) & ((e.x == S.k0) & (e.y == S.k1)) & ((((e.z ^ S.k2) & zmask) == 0u) &
                          ((e.w & kMemo16TwoPiece) == form) & (e.w != 0xFFFFFFFFu));
       S.L = L | (hit16 ? kWwHit16 : 0u);
       S.hz = e.z; S.hw = e.w;
@@ -309,7 +316,7 @@ SPMX_DEVICE void encode_wordwave_block(const EncodeArgs &a, unsigned char *smem)
       const bool word = static_cast<uint32_t>(lane) < S.cnt;
       const uint32_t k0 = S.k0, k1 = S.k1, k2 = S.k2, k3 = S.k3, j = S.j, P = S.P;
       const bool lng = (S.L & 0xFFu) > 16u;                          // a word of more than 16 bytes
-      const bool hit16 = (S.L & kWwHit16) != 0u;
+      const bool hit16 = kWwHotIn(MODE) && (S.L & kWwHit16) != 0u;
       const bool probe = word && !hit16 && !lng;
       U4 e0{S.e0x, S.e0y, S.e0z, S.e0w}, e1{S.e1x, S.e1y, S.e1z, S.e1w};
       bool hit32 = probe & ((e0.x == k0) & (e0.y == k1)) & ((e0.z == k2) & (e0.w == k3)) & (e1.x != 0xFFFFFFFFu);
