@@ -508,6 +508,7 @@ def main():
                                                     sharding.IdGatherer.count_width(max_count),
                                                     (results["none"][0] if "none" in results else dt) / args.steps * 1e3),
                        "sharding": "dp%d by sentence" % world,
+                       "handle": sp.HandleInfo(),      # device bytes of the model's tables, spmx_create's wall-clock ms
                        "timed_loop": "profiling off; roofline.* comes from a second loop of the same steps with HIP events on"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,

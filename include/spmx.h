@@ -325,6 +325,13 @@ int spmx_last_profile(const spmx_handle *h, float *kernel_ms, uint64_t *sentence
  * iterations the waves of the lane-per-sentence forms executed. */
 int spmx_last_phase_cycles(const spmx_handle *h, uint64_t *cycles);
 
+/* What loading this handle cost: the device bytes of its tables (normalizer tries, piece trie, word memo, decode tables --
+ * not the per-call workspaces, which grow with the batches a handle sees and are kept: up to SPMX_STREAM_SCRATCH_MB, default
+ * 16 GB, for the streaming kernels' text columns) and the wall-clock milliseconds of spmx_create: parse + table build + upload.
+ * No reference counterpart (the reference's Load builds its tries on the host, sentencepiece_processor.cc:231-275); either
+ * pointer may be null. */
+int spmx_handle_info(const spmx_handle *h, uint64_t *table_bytes, double *load_ms);
+
 #ifdef __cplusplus
 }
 #endif

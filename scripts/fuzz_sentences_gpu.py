@@ -4,6 +4,7 @@
 # vocabulary, fresh random words (the call-local memo), words of more than 16 bytes, runs of spaces, punctuation glued to
 # words, CJK, accented letters, malformed bytes, empty sentences, a few sentences of several KB.
 # usage (GPU box): python scripts/fuzz_sentences_gpu.py SECONDS FIRST_SEED
+import gc
 import os
 import sys
 import time
@@ -23,10 +24,10 @@ FORMS = [{}, {"SPMX_WORD_WAVE": "0"}, {"SPMX_NO_DIRECT": "1"}, {"SPMX_NO_WORD_DY
 EMU = os.environ.get("FUZZ_EMU") == "1"                 # (a dry run of the script itself on the CPU emulator, tiny batches)
 lib = emulib.EmuLib() if EMU else emulib.GpuLib()
 ref = refshim.RefLib()
-handles = {}
-for m in MODELS:
-    blob = bench.model_blob(m)
-    handles[m] = ([lib.load(blob, env=e) for e in FORMS], ref.load(blob))
+blobs = {m: bench.model_blob(m) for m in MODELS}
+refs = {m: ref.load(blobs[m]) for m in MODELS}
+# (the product handles of ONE model at a time: a handle keeps its workspaces -- slabs of several GB after a batch with multi-KB
+# sentences -- and 70 live handles ran the device out of memory in the script's first version)
 wl = synth.WordList()
 vocab = [wl.blob[int(o):int(o) + int(l)].tobytes() for o, l in zip(wl.offs[:30000], wl.lens[:30000])]   # uni32k's / bpe32k's own words
 corp = fixtures.Corpora()
@@ -35,8 +36,7 @@ ja = corp["ja"][0].tobytes().replace(b"\n", b" ")
 al = b"abcdefghijklmnopqrstuvwxyzABCDEFXYZ0123456789"
 pun = [b",", b".", b"!", b"?", b";", b":", b"'s", b"\"", b")", b"(", b"-", b"--", b"..."]
 bad = n_sent = n_bytes = 0
-while time.time() < t_end:
-    seed += 1
+def make_batch(seed):
     rng = np.random.default_rng(seed)
     n = 300 if EMU else int(rng.choice([30000, 60000, 120000]))
     fresh = [bytes(al[int(k)] for k in rng.integers(0, 26, size=int(rng.integers(2, 13)))) for _ in range(int(rng.choice([50, 2000, 40000])))]
@@ -70,19 +70,30 @@ while time.time() < t_end:
         if rng.random() < 0.01: s = b" " + s
         if rng.random() < 0.01: s = s + b" "
         sents.append(s)
-    text, offs = synth.pack(sents)
-    n_sent += n; n_bytes += len(text)
+    return synth.pack(sents)
+
+
+BATCHES = 1 if EMU else 3
+while time.time() < t_end:
+    batch = []
+    for _ in range(BATCHES):
+        seed += 1
+        batch.append((seed,) + tuple(make_batch(seed)))
+        n_sent += len(batch[-1][2]) - 1; n_bytes += len(batch[-1][1])
     for m in MODELS:
-        hs, r = handles[m]
-        try:
-            ri, ro = r.encode_batch(text, offs)
-            for k, h in enumerate(hs):
-                ids, io = h.encode_batch(text, offs)
-                if h.status or not (np.array_equal(io, ro) and np.array_equal(ids, ri)):
-                    bad += 1
-                    d = np.nonzero(np.diff(io.astype(np.int64)) != np.diff(ro.astype(np.int64)))[0]
-                    print("MISMATCH", m, "form", FORMS[k], "seed", seed, h.status, "first sentence with another count", d[:1], flush=True)
-        except Exception as e:
-            bad += 1; print("EXC", m, seed, repr(e)[:200], flush=True)
+        hs = [lib.load(blobs[m], env=e) for e in FORMS]
+        for sd, text, offs in batch:
+            try:
+                ri, ro = refs[m].encode_batch(text, offs)
+                for k, h in enumerate(hs):
+                    ids, io = h.encode_batch(text, offs)
+                    if h.status or not (np.array_equal(io, ro) and np.array_equal(ids, ri)):
+                        bad += 1
+                        d = np.nonzero(np.diff(io.astype(np.int64)) != np.diff(ro.astype(np.int64)))[0]
+                        print("MISMATCH", m, "form", FORMS[k], "seed", sd, h.status, "first sentence with another count", d[:1], flush=True)
+            except Exception as e:
+                bad += 1; print("EXC", m, sd, repr(e)[:200], flush=True)
+        del hs
+        gc.collect()
     print("seed", seed, "sentences", n_sent, "MB", n_bytes // 1000000, "x", len(MODELS), "models x", len(FORMS), "forms, bad", bad, flush=True)
 print("DONE bad =", bad, "sentences", n_sent, "bytes", n_bytes, "models", len(MODELS), "forms", len(FORMS))

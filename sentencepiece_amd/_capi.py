@@ -98,6 +98,7 @@ SYMBOLS = [
     ("spmx_set_profiling", C.c_int, [_H, C.c_int]),
     ("spmx_last_profile_name", C.c_int, [_H, C.c_int, C.c_char_p, _U64]),
     ("spmx_last_phase_cycles", C.c_int, [_H, C.c_void_p]),
+    ("spmx_handle_info", C.c_int, [_H, C.c_void_p, C.c_void_p]),
     ("spmx_last_profile", C.c_int,
      [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
 ]

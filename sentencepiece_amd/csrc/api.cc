@@ -37,6 +37,7 @@
 #include <new>
 #include <sstream>
 #include <atomic>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -337,6 +338,8 @@ struct spmx_handle {
   bool no_uni_wave = false;      // SPMX_NO_UNI_WAVE=1: unigram models never take the wave-cooperative form (kernels_uniwave.h)
   uint32_t uni_wave_max = 0;     // SPMX_UNI_WAVE_MAX: a staged class with fewer sentences than this takes the wave-cooperative form
   int word_wgs = 1;              // SPMX_WORD_WGS: workgroups per CU of the word kernel's first pass
+  uint64_t table_bytes = 0;      // device bytes of the tables uploaded at load (spmx_handle_info)
+  double load_ms = 0.0;          // parse + table build + upload, wall clock
   int word_form = 3;             // SPMX_WORD_WAVE: which word rounds take the word-per-lane form (kernels_wordwave.h): bit 0 the first, bit 1 the second; 0: the sentence-per-lane loops
   int wordwave_waves = 14;       // SPMX_WORDWAVE_WAVES: wavefronts per workgroup of the word-per-lane kernels (C2's first round: 8 -> 3.71 ms, 10 -> 3.31, 12 -> 3.08, 13 -> 3.02, 14 -> 2.96, 15 -> 2.94 with a worse step; 14 x 10 KB + the shared tables = 153 KB of LDS)
   int word_waves = 12;           // SPMX_WORD_WAVES: wavefronts per workgroup of the word kernels (C2 step: 16 -> 8.60 ms, 14 -> 8.39, 12 -> 8.37, 10 -> 8.52, 8 -> 8.90)
@@ -402,10 +405,12 @@ struct Lease {
   }
 };
 
+thread_local uint64_t t_upload_bytes = 0;   // device bytes the tables of the handle being loaded take (spmx_handle_info)
 template <typename T>
 hipError_t Upload(DevBuf<T> *b, const std::vector<T> &v) {
   hipError_t e = b->Reserve(v.size() ? v.size() : 1);
   if (e != hipSuccess) return e;
+  t_upload_bytes += b->cap * sizeof(T);
   if (v.empty()) return hipSuccess;
   return hipMemcpy(b->p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
 }
@@ -1647,6 +1652,7 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
       return Fail(nullptr, kUnavailable, std::string("no HIP device is available (libspmx has no CPU path): ") +
                                              (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
     if (device < 0 || device >= n_dev) return Fail(nullptr, kInvalidArgument, "device ordinal out of range");
+    const auto t_load0 = std::chrono::steady_clock::now();
     std::unique_ptr<spmx_handle, void (*)(spmx_handle *)> h(new spmx_handle, DestroyHandle);
     h->device = device;
     h->serialized.assign(static_cast<const char *>(model_bytes), n_bytes);
@@ -1752,7 +1758,10 @@ int spmx_create(const void *model_bytes, uint64_t n_bytes, int device, spmx_hand
         p = *q == ',' ? q + 1 : q;
       }
     }
+    t_upload_bytes = 0;
     if (int rc = UploadTables(h.get()); rc != kOk) return rc;
+    h->table_bytes = t_upload_bytes;
+    h->load_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_load0).count();
     if (!h->model.self_test.empty())                        // "Running self-testing." (sentencepiece_processor.cc:259-278)
       if (int rc = RunSelfTest(h.get()); rc != kOk) return rc;
     *out = h.release();
@@ -3100,6 +3109,13 @@ int spmx_set_profiling(spmx_handle *h, int enabled) {
   if (!h) return kInvalidArgument;
   std::lock_guard<std::mutex> l(h->mu);
   h->profiling = enabled != 0;
+  return kOk;
+}
+
+int spmx_handle_info(const spmx_handle *h, uint64_t *table_bytes, double *load_ms) {
+  if (!h) return kInvalidArgument;
+  if (table_bytes) *table_bytes = h->table_bytes;
+  if (load_ms) *load_ms = h->load_ms;
   return kOk;
 }
 

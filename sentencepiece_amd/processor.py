@@ -1150,6 +1150,12 @@ class SentencePieceProcessor:
         self._need()
         self._lib.spmx_set_profiling(self._h, 1 if enabled else 0)
 
+    def HandleInfo(self):
+        """dict(table_bytes, load_ms): what loading this handle cost (include/spmx.h spmx_handle_info; no reference counterpart)."""
+        tb, ms = C.c_uint64(0), C.c_double(0.0)
+        self._check(self._lib.spmx_handle_info(self._h, C.byref(tb), C.byref(ms)))
+        return {"table_bytes": int(tb.value), "load_ms": float(ms.value)}
+
     def LastProfile(self):
         """Per kernel slot of the last profiled encode call (0 main streaming launch, 1 document launch, 2 overflow
         launch, 3 sentence-per-wave BPE, 4 long / wave-cooperative form, 5 word form first round, 6 second round): dict(kernel, kernel_ms, sentences, raw_bytes, ids, bytes,

@@ -56,3 +56,28 @@ def test_product_does_not_touch_oracle():
             if re.search(r"oracle|wave_emu|emu_lib|refshim|libspm_ref", s):
                 bad.append(fn)
     assert bad == []
+
+
+def _handle_info_checks(load):
+    """spmx_handle_info: table bytes and load time per handle; the sentence-per-lane kernels' memo tiers are built only
+    for a handle that asks for those kernels (tables.cc legacy_tiers)."""
+    from tests import fixtures
+    blob = fixtures.model_blob("uni32k")
+    a = load(blob, {"SPMX_FORCE_WORD_DP": "0"}).sp.HandleInfo()      # (the emulator's loader sets it to 1 by default: the DP pass reads the tiers)
+    b = load(blob, {"SPMX_FORCE_WORD_DP": "0", "SPMX_WORD_WAVE": "0"}).sp.HandleInfo()
+    assert a["load_ms"] > 0.0 and b["load_ms"] > 0.0
+    assert 1 << 20 < a["table_bytes"] < 1 << 28, a
+    assert b["table_bytes"] > a["table_bytes"] + (1 << 20), (a, b)      # umemo16 + umemo: megabytes for a 32k vocabulary
+
+
+def test_emu_handle_info():
+    from tests import emulib
+    lib = emulib.EmuLib()
+    _handle_info_checks(lambda blob, env: lib.load(blob, env=env))
+
+
+@pytest.mark.gpu
+def test_gpu_handle_info():
+    from tests import emulib
+    lib = emulib.GpuLib()
+    _handle_info_checks(lambda blob, env: lib.load(blob, env=env))
