@@ -239,6 +239,12 @@ struct Workspace {
   uint32_t n_lit = 0;
   PinBuf<uint8_t> h_text;       // pinned staging of the pipelined host form
   PinBuf<uint64_t> h_offs, h_id_offs;
+  // set around its calls by the pipelined host form: the LARGEST chunk of the batch (bytes, sentences).  A workspace sizes its
+  // arena for that, not for the chunk it happens to get: a length-bucketed batch has small chunks and large ones, a worker leases
+  // whichever workspace is free, and a workspace that grows in the second or third call of a handle costs that call a
+  // hipFree + hipMalloc of half a gigabyte in the middle of the pipeline (10 M C2 sentences: calls 2 and 3 took 115 and 60 ms
+  // against 50 from the fourth on, scripts/host_calls_probe.py)
+  uint64_t reserve_text_bytes = 0, reserve_n = 0;
   float bpe_dropout = 0.f;      // set around a call by spmx_sample_encode_batch: BPE-dropout through the long form
   uint64_t sample_seed = 0;
   hipStream_t stream = nullptr;
@@ -819,8 +825,11 @@ int EncodeDevice(spmx_handle *h, Workspace *ws, const uint8_t *d_text, uint64_t 
   // SPMX_ARENA_FIRST=<ids>: the first attempt's arena is no larger than this (tests force the overflow-and-retry path)
   uint64_t arena_cap_limit = 0;
   if (h->arena_first && arena_need > h->arena_first) { arena_need = h->arena_first; arena_cap_limit = h->arena_first; }
+  // (the pipelined host form's largest chunk: Workspace::reserve_text_bytes -- capacity only, the call's own need decides the rest)
+  const uint64_t arena_reserve = (h->arena_first || ws->reserve_text_bytes <= text_bytes) ? 0 :
+      expand * ws->reserve_text_bytes + (10 + static_cast<uint64_t>(h->dev.n_prefix + h->dev.n_suffix)) * (ws->reserve_n > n ? ws->reserve_n : n) + 4096;
   for (int attempt = 0; attempt < 4; ++attempt) {
-    HIP_OR_RETURN(h, ws->d_arena.Reserve(arena_need));
+    HIP_OR_RETURN(h, ws->d_arena.Reserve(arena_need > arena_reserve ? arena_need : arena_reserve));
     if (spans) HIP_OR_RETURN(h, ws->d_arena_tb.Reserve(ws->d_arena.cap));
     if (prof) HIP_OR_RETURN(h, hipEventRecord(ws->ev[kNumSlots][0], stream));
     HIP_OR_RETURN(h, hipMemsetAsync(ws->d_ctrl, 0, sizeof(Ctrl), stream));
@@ -2095,6 +2104,8 @@ int EncodeBatchPipelined(spmx_handle *const *hs, int n_h, const char *text, cons
     for (uint64_t k = 0; k <= n_chunks; ++k) cbeg[k] = offsets[k * chunk < n ? k * chunk : n] - offsets[0];
   }
   const uint64_t text_bytes = cbeg[n_chunks];
+  uint64_t max_bytes = 0;                                        // the largest chunk: what every worker's workspace is sized for
+  for (uint64_t k = 0; k < n_chunks; ++k) if (cbeg[k + 1] - cbeg[k] > max_bytes) max_bytes = cbeg[k + 1] - cbeg[k];
   uint64_t cap = text_bytes / 2 + 4 * n + 64;                    // ids the output array holds (more: the plain path takes over)
   int32_t *out_ids = static_cast<int32_t *>(g_pinned.Get(cap * sizeof(int32_t)));
   uint64_t *out_offs = static_cast<uint64_t *>(g_pinned.Get((n + 1) * sizeof(uint64_t)));
@@ -2119,16 +2130,21 @@ int EncodeBatchPipelined(spmx_handle *const *hs, int n_h, const char *text, cons
       if (int r = L.Ready(); r != kOk) return r;
       Workspace *ws = L.ws.get();
       hipStream_t st = ws->stream;
+      const uint64_t max_cnt = chunk < n ? chunk : n;
+      ws->reserve_text_bytes = max_bytes; ws->reserve_n = max_cnt;
+      struct ResetHint { Workspace *w; ~ResetHint() { w->reserve_text_bytes = 0; w->reserve_n = 0; } } reset_hint{ws};
+      // (staging, text, offsets and ids for the LARGEST chunk, once: see Workspace::reserve_text_bytes)
+      HIP_OR_RETURN(h, ws->h_text.Reserve(max_bytes + 32));
+      HIP_OR_RETURN(h, ws->h_offs.Reserve(max_cnt + 1));
+      HIP_OR_RETURN(h, ws->h_id_offs.Reserve(max_cnt + 1));
+      HIP_OR_RETURN(h, ws->d_text.Reserve(max_bytes + 32));
+      HIP_OR_RETURN(h, ws->d_offs.Reserve(max_cnt + 1));
+      HIP_OR_RETURN(h, ws->d_id_offs.Reserve(max_cnt + 1));
+      HIP_OR_RETURN(h, ws->d_sent_status.Reserve(max_cnt));
+      HIP_OR_RETURN(h, ws->d_ids.Reserve(max_bytes / 2 + 4 * max_cnt + 64));
       for (uint64_t k = static_cast<uint64_t>(w); k < n_chunks; k += static_cast<uint64_t>(T)) {
         const uint64_t s0 = k * chunk, s1 = (k + 1) * chunk < n ? (k + 1) * chunk : n, cnt = s1 - s0;
         const uint64_t bytes = cbeg[k + 1] - cbeg[k];
-        HIP_OR_RETURN(h, ws->h_text.Reserve(bytes + 32));
-        HIP_OR_RETURN(h, ws->h_offs.Reserve(cnt + 1));
-        HIP_OR_RETURN(h, ws->h_id_offs.Reserve(cnt + 1));
-        HIP_OR_RETURN(h, ws->d_text.Reserve(bytes + 32));
-        HIP_OR_RETURN(h, ws->d_offs.Reserve(cnt + 1));
-        HIP_OR_RETURN(h, ws->d_id_offs.Reserve(cnt + 1));
-        HIP_OR_RETURN(h, ws->d_sent_status.Reserve(cnt));
         if (views) {
           uint64_t at = 0;
           for (uint64_t i = 0; i < cnt; ++i) {
