@@ -316,7 +316,7 @@ struct spmx_handle {
   uint32_t dyn_slots = kDynSlotsDefault;        // SPMX_DYN_SLOTS_LOG2: slots of the call-local word memo (a power of two)
   uint32_t dyn_list_cap = kDynListCapDefault;   // SPMX_DYN_LIST_CAP: words it takes per call; what it cannot take stays with the general kernels
   uint64_t nbest_budget = 32ull << 30;  // SPMX_NBEST_BUDGET_GB: HBM the lattice slices of one launch may take (200 k sentences, n-best 5: 0.83 M sentences/s at 8 GB, 1.15 M at 32, 1.19 M at 96)
-  uint32_t nbest_hyps_min = 16384;   // SPMX_NBEST_HYPS_MIN: hypotheses a lane's A* may hold in the first launch (what outgrows it runs again)
+  uint32_t nbest_hyps_min = 4096;    // SPMX_NBEST_HYPS_MIN: hypotheses a lane's A* may hold in the first launch (what outgrows it runs again)
   uint32_t tile_min_lanes = 1;   // SPMX_TILE_MIN_LANES: a main tile has at least this many sentences even when that leaves wavefronts without a tile of the class
   // SetDecodeExtraOptions: the net effect of the options on a sentence's ids (kernels_decode.h DecodeArgs::x_*)
   int32_t dx_npre = 0, dx_nsuf = 0, dx_pre[kMaxExtra] = {0}, dx_suf[kMaxExtra] = {0};
@@ -2386,7 +2386,17 @@ int LatticeBatchHost(spmx_handle *h, const char *text, const uint64_t *offsets, 
     NBestArgs a{};
     a.dev = h->dev; a.norm = ws->d_norm.p; a.norm_offs = ws->d_id_offs.p; a.n = static_cast<uint32_t>(n); a.nbest = K;
     a.mode = static_cast<uint32_t>(mode); a.inv_theta = inv_theta; a.seed = seed;
-    const uint64_t hyps0 = static_cast<uint64_t>(K) * 2048;
+    const uint64_t hyps0 = static_cast<uint64_t>(K) * 512;   // (a C2 sentence's n-best 5 makes ~1,000; what outgrows the slice runs again)
+    // The first launch's capacities follow the batch: a slice sized for 1024 bytes and 16384 nodes is 0.7 MB a lane, of
+    // which a 126-byte sentence touches a twentieth, and the lanes in flight are what the budget holds (200 k sentences,
+    // n-best 5: 108 ms a call at 697 wavefronts, 94 at 2048).  A sentence that normalizes to more than the guess is set
+    // aside like one beyond the fixed capacities and runs in the wide launch.
+    uint64_t max_raw = 0;
+    for (uint64_t s = 0; s < n; ++s) max_raw = std::max<uint64_t>(max_raw, offsets[s + 1] - offsets[s]);
+    uint64_t len0 = (max_raw + max_raw / 4 + 16 + 63) & ~static_cast<uint64_t>(63);
+    if (len0 > kNbMaxLen) len0 = kNbMaxLen;
+    uint64_t nodes0 = (len0 + 2) * (static_cast<uint64_t>(h->tables.max_prefixes) + 1) + 2;
+    if (nodes0 > kNbMaxNodes) nodes0 = kNbMaxNodes;
     const uint64_t hyps_min = h->nbest_hyps_min;
     const uint32_t max_hyps0 = mode != 0 ? 512u : static_cast<uint32_t>(hyps0 < hyps_min ? hyps_min : (hyps0 > 262144 ? 262144 : hyps0));
     const uint64_t budget = h->nbest_budget;                  // HBM for the lanes' slices
@@ -2407,8 +2417,8 @@ int LatticeBatchHost(spmx_handle *h, const char *text, const uint64_t *offsets, 
         a.arena_nb = ws->d_arena_tb.p; a.arena_ne = ws->d_tok_begin.p;
       }
       HIP_OR_RETURN(h, hipMemsetAsync(ws->d_ctrl, 0, sizeof(Ctrl), st));
-      // first launch: every sentence, 16-bit lattice indices, fixed capacities
-      a.max_len = kNbMaxLen; a.max_nodes = kNbMaxNodes; a.max_hyps = max_hyps0;
+      // first launch: every sentence, 16-bit lattice indices, capacities for the batch (at most kNbMaxLen / kNbMaxNodes)
+      a.max_len = static_cast<uint32_t>(len0); a.max_nodes = static_cast<uint32_t>(nodes0); a.max_hyps = max_hyps0;
       a.lane_bytes = NbestLaneBytes(a.max_len, a.max_nodes, a.max_hyps, 2);
       a.list = nullptr; a.n_list = 0;
       a.retry_list = ws->d_lists.p; a.retry_count = &ws->d_ctrl->retry_count[0]; a.retry_max_len = &ws->d_ctrl->side.over_max_raw;
