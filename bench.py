@@ -224,7 +224,8 @@ def side_bench(sp_cls, torch, dev, name, blob, text, offs, steps, warmup, what, 
         k_traffic = [traffic_on_record(rec_name, n, c["kernel"])[0] for c in cls]
         out["pipeline"] = {"algorithmic_bytes": p_bytes, "ms": dt * 1e3, "achieved": p_ach, "unit": "GB/s",
                            "frac": p_ach / HBM_PEAK_GBS,
-                           "traffic_of_the_encode_launches": sum(k_traffic) if all(t is not None for t in k_traffic) else None,
+                           "traffic_of_the_encode_launches": sum(t for t in k_traffic if t is not None) if any(t is not None for t in k_traffic) else None,
+                           "launches_without_a_traffic_record": [c["kernel"] for c, t in zip(cls, k_traffic) if t is None],
                            "what": "every launch's algorithmic bytes over the whole step (classify, scan, compact included in the time)"}
     try:
         io_h = io.cpu().numpy()

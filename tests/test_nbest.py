@@ -167,3 +167,32 @@ def test_nbest_with_restricted_vocabulary(emu, oracle, ref, corpora):
         assert a == b and [x[0] for x in res] == a
         np.testing.assert_array_equal(sa, sb)
         np.testing.assert_array_equal(np.array([x[1] for x in res], dtype=np.float32), sa)
+
+
+# A batch large enough for the release library's threaded result assembly (api.cc LatticeBatchHost: from 2^20 ids +
+# results on; pinned ids from 8 MB on): a few hundred distinct sentences, each with its oracle answer, repeated in a
+# shuffled order.
+@pytest.mark.gpu
+def test_gpu_nbest_big_batch_threaded_assembly(oracle, corpora):
+    from sentencepiece_amd import synth
+    from sentencepiece_amd.processor import SentencePieceProcessor
+    blob = fixtures.model_blob("uni32k")
+    sp, o = SentencePieceProcessor(model_proto=blob), oracle.load(blob)
+    t0, o0 = synth.ascii_corpus(400, seed=11)
+    base = [t0[int(o0[i]):int(o0[i + 1])].tobytes() for i in range(400)] + [b"", b"hello world"]
+    k = 5
+    want = [nbest(o.lib.oracle_nbest_encode, o.h, s, k) for s in base]
+    rng = np.random.default_rng(5)
+    order = rng.integers(0, len(base), size=60000)
+    text, offs = synth.pack([base[j] for j in order])
+    for _ in range(2):                                            # (the second call takes the recycled pinned block)
+        ids, io, sc, ro = sp.NBestPacked(text, offs, k)
+        assert int(ro[-1]) >= (1 << 17) and int(io[-1]) >= (1 << 20)
+        for i, j in enumerate(order):
+            n, w_ids, w_sc = want[j]
+            r0, r1 = int(ro[i]), int(ro[i + 1])
+            assert r1 - r0 == n, (i, j)
+            for r in range(r0, r1):
+                assert ids[int(io[r]):int(io[r + 1])].tolist() == w_ids[r - r0], (i, j, r - r0)
+            np.testing.assert_array_equal(sc[r0:r1], w_sc)
+        del ids, io, sc, ro
