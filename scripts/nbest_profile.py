@@ -1,5 +1,5 @@
 """Where an NBestEncode call's time goes (host arrays in and out): wall time of the call beside the kernels' time that
-rocprofv3 --kernel-trace --stats reports for the same process.  Usage (GPU box): python scripts/nbest_profile.py [sentences] [nbest]"""
+rocprofv3 --kernel-trace --stats reports for the same process.  Usage (GPU box): python scripts/nbest_profile.py [sentences] [nbest]   (nbest 0: lattice sampling, SampleEncode with nbest_size -1)"""
 import json
 import sys
 import time
@@ -13,10 +13,11 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 text, offs = synth.ascii_corpus(n, seed=7)
 sp = SentencePieceProcessor(model_proto=fixtures.model_blob("uni32k"))
-sp.NBestPacked(text, offs, k)
+call = (lambda: sp.NBestPacked(text, offs, k)) if k > 0 else (lambda: sp.SampleEncodePacked(text, offs, -1, 0.1, seed=1))
+call()
 ts = []
 for _ in range(4):
     t = time.perf_counter()
-    sp.NBestPacked(text, offs, k)
+    call()
     ts.append(time.perf_counter() - t)
 print(json.dumps({"sentences": n, "nbest": k, "calls_s": ts, "calls": 5}))
