@@ -196,3 +196,33 @@ def test_gpu_nbest_big_batch_threaded_assembly(oracle, corpora):
                 assert ids[int(io[r]):int(io[r + 1])].tolist() == w_ids[r - r0], (i, j, r - r0)
             np.testing.assert_array_equal(sc[r0:r1], w_sc)
         del ids, io, sc, ro
+
+
+# The first launch's capacities follow the batch (api.cc LatticeBatchHost: normalized length guessed from the longest raw
+# sentence, 512 hypotheses a result): a batch of short sentences that normalize to several times their length, and a
+# sentence whose A* outgrows the first hypothesis slice, are set aside and answered by the wide launch.
+def check_capacity_guesses(make_sp, oracle):
+    from sentencepiece_amd import synth
+    blob = fixtures.model_blob("test_model")                      # nmt_nfkc: U+3300 -> four katakana, U+FDFA -> 18 code points
+    sp, o = make_sp(blob), oracle.load(blob)
+    grow = ["㌀" * 14, "ﷺ" * 6 + " a", "a", ""]          # 42 raw bytes -> 168 normalized; the guess is 64
+    wide = [(b"this is a test of the emergency broadcast system " * 6)[:280], b"hello world"]
+    for sents, k in ((grow, 3), (wide, 40), (wide + [s.encode("utf-8") for s in grow], 7)):
+        sents = [s.encode("utf-8") if isinstance(s, str) else s for s in sents]
+        text, offs = synth.pack(sents)
+        ids, io, sc, ro = sp.NBestPacked(text, offs, k)
+        for i, s in enumerate(sents):
+            n, want, wsc = nbest(o.lib.oracle_nbest_encode, o.h, s, k)
+            got = [ids[int(io[r]):int(io[r + 1])].tolist() for r in range(int(ro[i]), int(ro[i + 1]))]
+            assert got == want, (s[:30], k)
+            np.testing.assert_array_equal(sc[int(ro[i]):int(ro[i + 1])], wsc)
+
+
+def test_emu_nbest_capacity_guesses(emu, oracle):
+    check_capacity_guesses(lambda blob: emu.load(blob).sp, oracle)
+
+
+@pytest.mark.gpu
+def test_gpu_nbest_capacity_guesses(oracle):
+    from sentencepiece_amd.processor import SentencePieceProcessor
+    check_capacity_guesses(lambda blob: SentencePieceProcessor(model_proto=blob), oracle)
